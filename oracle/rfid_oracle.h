@@ -1,0 +1,162 @@
+/*
+ * rfid_oracle.h -- CPU ORACLE (test infrastructure, NOT product code)
+ *
+ * Plain-C restatement of the receive path of nkargas/Gen2-UHF-RFID-Reader:
+ *     fir_filter_ccc(5,[1]*25)  ->  gate_impl  ->  tag_decoder_impl
+ * plus the state transitions of reader_impl that steer the two blocks.
+ *
+ * WHO MAY USE THIS: only tests/, __graft_entry__.smoke() and bench.py's
+ * `cpu_baseline` leg -- as the checker / reported baseline.  The product
+ * library (librfid_mi355x.so) never links, loads or calls anything in oracle/.
+ *
+ * PARITY STATUS: **parity unpinned**.
+ *   - The reference ships no golden vectors, known-answer tests or fixtures for
+ *     this path (gr-rfid/lib/qa_rfid.cc:30-36 is an empty suite); its one known
+ *     answer (README.md:48-53) needs misc/data/file_source_test, which is absent
+ *     from the checkout (.MISSING_LARGE_BLOBS:2).
+ *   - The reference's .cc files need GNU Radio + Boost headers that this image
+ *     lacks, so by the build rules it is "unbuildable here": no oracle/_ref.
+ *   - What IS pinned: CRC-16 against the published CRC-16/GENIBUS check value,
+ *     the 20 half-period candidates against BASELINE.md section 5, the C/C++
+ *     library semantics the reference leans on (tests/test_toolchain_semantics.py)
+ *     and end-to-end decode of generator ground truth (README-shaped 71/72/70/1).
+ *
+ * TOOLCHAIN the restatement is canonical for: g++ 11 / libstdc++ 11 / glibc 2.35,
+ * x86-64, -O3 without -march / -ffast-math (the reference's Release flags,
+ * gr-rfid/CMakeLists.txt:29-33): float ops are IEEE binary32 with no FMA
+ * contraction; std::norm(z)=re*re+im*im; std::abs(z)=hypotf ==
+ * (float)sqrt((double)re*re+(double)im*im); complex/(c,0) == elementwise /c.
+ *
+ * All `file:line` citations are relative to /root/reference/gr-rfid/.
+ */
+#ifndef RFID_ORACLE_H
+#define RFID_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float re, im; } orc_cf;
+
+/* include/rfid/global_vars.h:31-34 */
+enum { ORC_RUNNING = 0, ORC_TERMINATED = 1 };
+enum { ORC_SEND_QUERY = 0, ORC_SEND_ACK, ORC_SEND_QUERY_REP, ORC_IDLE, ORC_SEND_CW, ORC_START,
+       ORC_SEND_QUERY_ADJUST, ORC_SEND_NAK_QR, ORC_SEND_NAK_Q, ORC_POWER_DOWN };
+enum { ORC_GATE_OPEN = 0, ORC_GATE_CLOSED, ORC_GATE_SEEK_RN16, ORC_GATE_SEEK_EPC };
+enum { ORC_DECODE_RN16 = 0, ORC_DECODE_EPC };
+
+/* compile-time constants of the reference that the build makes run-time
+ * (include/rfid/global_vars.h:72,76,100) */
+typedef struct {
+  int fixed_q;            /* FIXED_Q            = 0    */
+  int max_num_queries;    /* MAX_NUM_QUERIES    = 1000 */
+  int number_unique_tags; /* NUMBER_UNIQUE_TAGS = 100  */
+} orc_config;
+
+#define ORC_MAX_ROUNDS_LOG 4096
+#define ORC_MAX_MAGN 4096
+
+/* READER_STATS + READER_STATE, include/rfid/global_vars.h:36-67 */
+typedef struct {
+  int status, gen2_logic_status, gate_status, decoder_status;
+  int n_queries_sent, cur_inventory_round, cur_slot_number, max_slot_number, n_epc_correct;
+  int tag_reads[256];        /* std::map<int,int>: id is 8 bits (tag_decoder_impl.cc:348-352) */
+  int n_unique_tags;         /* tag_reads.size() */
+  int n_rounds_logged;       /* unique_tags_round.size() */
+  int unique_tags_round[ORC_MAX_ROUNDS_LOG];
+  float magn_squared[ORC_MAX_MAGN];
+  int n_magn;
+  int n_samples_to_ungate;
+  orc_config cfg;
+} orc_reader_state;
+
+/* gate_impl.h:36-44 */
+typedef struct {
+  int n_samples, n_samples_T1, n_samples_PW, n_samples_TAG_BIT;
+  int win_index, dc_index, win_length, dc_length;
+  float avg_ampl, num_pulses, sample_thresh;
+  float win_samples[512];
+  orc_cf dc_samples[512];
+  orc_cf dc_est;
+  int signal_state; /* 0 NEG_EDGE, 1 POS_EDGE */
+} orc_gate;
+
+/* tag_decoder_impl.h:37-42 */
+typedef struct {
+  float n_samples_TAG_BIT;
+  float T_global;
+  orc_cf h_est;
+  char char_bits[128];
+} orc_decoder;
+
+/* everything one decoder call computed, for score / bit parity checks */
+typedef struct {
+  int type;            /* ORC_DECODE_RN16 / ORC_DECODE_EPC */
+  int index;           /* value returned by tag_sync */
+  float corr[15];
+  orc_cf h_est;
+  float energy[20];
+  float T;
+  int n_bits;          /* 16 or 128 */
+  unsigned char bits[128];
+  int crc_ok;          /* EPC only: 1 / 0 */
+  int tag_id;          /* EPC, crc ok only */
+} orc_decode_dump;
+
+void orc_default_config(orc_config *cfg);
+void orc_initialize_reader_state(orc_reader_state *rs, const orc_config *cfg);
+
+/* a1: y[n] = sum_{k=0..24} x[5n-24+k], k ascending, zeros before stream start.
+ * Writes n_in/5 outputs; returns that count. */
+long orc_fir_boxcar25_decim5(const orc_cf *x, long n_in, orc_cf *y);
+/* same, streaming: `hist` holds the 24 raw samples before x[0] (zeros at start);
+ * `phase` = number of raw samples (0..4) already consumed towards the next
+ * output.  Updated in place. */
+long orc_fir_stream(const orc_cf *x, long n_in, orc_cf *y, orc_cf hist[24], int *phase);
+
+void orc_gate_init(orc_gate *g, int sample_rate);
+/* gate_impl::general_work.  Returns `written`; *consumed as consume_each(). */
+int orc_gate_work(orc_gate *g, orc_reader_state *rs, const orc_cf *in, int n_items, orc_cf *out,
+                  int *consumed);
+
+void orc_decoder_init(orc_decoder *d, int sample_rate);
+int orc_tag_sync(orc_decoder *d, const orc_cf *in, int size, float corr_out[15]);
+int orc_detect_rn16(const orc_decoder *d, const orc_cf *s, int n_s, float *bits);
+int orc_detect_epc(orc_decoder *d, const orc_reader_state *rs, const orc_cf *in, int index,
+                   float *bits, float energy_out[20]);
+int orc_check_crc(const char *bits, int num_bits);
+unsigned orc_crc16_bytes(const unsigned char *data, int n);
+/* tag_decoder_impl::general_work.  out0 receives RN16 bits (16 floats).
+ * Returns items produced on port 0; *consumed as consume_each().  `dump` may be NULL. */
+int orc_decoder_work(orc_decoder *d, orc_reader_state *rs, const orc_cf *in, int ninput,
+                     float *out0, int *consumed, orc_decode_dump *dump);
+
+/* reader_impl::general_work state transitions only (no TX waveform). */
+void orc_reader_work(orc_reader_state *rs, int ninput_items);
+
+/* reader_impl::print_results text into buf; returns length */
+int orc_print_results(const orc_reader_state *rs, char *buf, int cap);
+
+/* Single-threaded-scheduler harness over one raw 2 Msps trace.
+ * chunk = scheduler buffer size for the gate input (result is invariant to it).
+ * dumps/max_dumps optional.  open_idx (optional, max_dumps long) receives the
+ * decimated index of the first sample of each decoded window.  Returns number of
+ * decoder invocations that consumed a window. */
+long orc_run_trace(const orc_config *cfg, const orc_cf *raw, long n_raw, int chunk,
+                   orc_reader_state *rs_out, orc_decode_dump *dumps, long *open_idx,
+                   orc_cf *dc_at_open, long max_dumps);
+
+/* same starting from already matched-filtered 400 ksps samples */
+long orc_run_decimated(const orc_config *cfg, const orc_cf *y, long n_dec, int chunk,
+                       orc_reader_state *rs_out, orc_decode_dump *dumps, long *open_idx,
+                       orc_cf *dc_at_open, long max_dumps);
+
+/* per-stage timing leg for bench.py's cpu_baseline: runs FIR, gate, decoder
+ * separately over the trace and returns seconds spent in each (steady clock). */
+long orc_time_trace(const orc_config *cfg, const orc_cf *raw, long n_raw, int reps,
+                    double secs[3], orc_reader_state *rs_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
