@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- Gen2 receive path (matched_filter -> gate -> tag_decoder) on MI355X.
+
+One "step" = one pass of the whole hot path over a batch of synthetic traces already
+resident in HBM (BASELINE.json configs[1]: 1024 noise-replicas of the 71-round
+file_source_test stand-in, FM0 40 kHz BLF @ 2 Msps, per GPU).  Prints ONE JSON line.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--streams B]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: one process per GPU, traces sharded per rank, no data-path collective (weak
+scaling); torch.distributed is used only for the barrier and the max-over-ranks time.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "gen2-uhf-rfid-reader_amd"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
+RN16_WIN, EPC_WIN = 250, 1370
+
+
+def build_batch(torch, device, n_streams, sigma, seed, rank):
+    """Noise-free 71-round stand-in trace, replicated n_streams times on the GPU with
+    per-replica noise (replica seed = seed + global replica index)."""
+    from rfid import synth
+    base = synth.make_trace(n_rounds=71, fixed_q=0, tag_ids=(0x27,), sigma=0.0, seed=7,
+                            corrupt_rounds=(36,), noise=False)
+    L = len(base.samples)
+    stride = (L + 1) & ~1
+    host = np.zeros(stride, dtype=np.complex64)
+    host[:L] = base.samples
+    base_dev = torch.from_numpy(host.view(np.float32)).to(device)            # [2*stride] float32
+    data = torch.empty((n_streams, 2 * stride), dtype=torch.float32, device=device)
+    gen = torch.Generator(device=device)
+    rows = 32
+    for r0 in range(0, n_streams, rows):
+        r1 = min(n_streams, r0 + rows)
+        gen.manual_seed(seed + rank * n_streams + r0)
+        noise = torch.randn((r1 - r0, 2 * stride), generator=gen, device=device, dtype=torch.float32)
+        data[r0:r1] = base_dev[None, :] + sigma * noise
+        del noise
+    if stride != L:
+        data[:, 2 * L:] = 0
+    return data, L, stride, base
+
+
+def cpu_baseline(base_samples, sigma, seconds_target):
+    """The oracle (CPU port of the reference algorithm) timed on this host, 1 thread, on a
+    bounded sample: repeated passes over ONE replica of the same workload."""
+    from oracle import oracle
+    rng = np.random.default_rng(123)
+    n = rng.standard_normal((len(base_samples), 2), dtype=np.float32)
+    x = (base_samples + np.float32(sigma) * (n[:, 0] + 1j * n[:, 1])).astype(np.complex64)
+    t = oracle.time_trace(x, reps=1)
+    reps = max(1, min(2000, int(seconds_target / max(t["total_s"], 1e-4))))
+    t = oracle.time_trace(x, reps=reps)
+    msps = len(x) * reps / t["total_s"] / 1e6
+    return {"value": round(msps, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} passes over 1 replica of the workload trace ({len(x)} raw samples each), "
+                      f"oracle/rfid_oracle.c single thread: FIR {t['fir_s']:.2f}s + gate/decoder "
+                      f"{t['gate_decoder_s']:.2f}s",
+            "epc_per_s": round(t["n_epc_correct"] * reps / t["total_s"], 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=1024, help="traces per GPU")
+    ap.add_argument("--sigma", type=float, default=0.002)
+    ap.add_argument("--seed", type=int, default=1000)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import rfid
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the receive path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    n_gpus = world
+
+    B = args.streams
+    data, L, stride, base = build_batch(torch, device, B, args.sigma, args.seed, rank)
+    ctx = rfid.Context(device=local_rank)
+    ctx.batch_plan(B, L)
+    ptr = data.data_ptr()
+
+    def step():
+        ctx.batch_process_ptr(ptr, stride, L, 0, want_scores=False)
+        ctx.batch_sync()
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    k_ms = {"mf_ms": 0.0, "gate_ms": 0.0, "decode_ms": 0.0, "stats_ms": 0.0}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        t = ctx.batch_timing()      # HIP events on the ctx stream, recorded around each kernel
+        for k in k_ms:
+            k_ms[k] += t[k]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)     # control plane only: max time over ranks
+        elapsed = float(tt.item())
+    for k in k_ms:
+        k_ms[k] /= max(args.steps, 1)
+
+    # ---- result checks (size-independent properties of the workload) ----------------------
+    st = ctx.batch_stats()
+    n_epc_ok = int(st["n_epc_correct"].sum())
+    n_windows = int(st["n_windows"].sum())
+    expect_ok = 70 * B
+    parity_ok = bool((st["n_epc_correct"] == 70).all() and (st["n_queries_sent"] == 72).all()
+                     and (st["tag_reads"][:, 0x27] == 70).all() and (st["n_unique_tags"] == 1).all())
+
+    # ---- roofline: algorithmic bytes per launch / measured kernel time
+    n_dec = L // 5
+    n_rn16 = int(n_windows // 2 + n_windows % 2)
+    n_epc = int(n_windows // 2)
+    alg = {
+        "mf_boxcar25_decim5": B * (8.0 * L + 8.0 * n_dec),
+        "gate_scan": B * 8.0 * n_dec + 24.0 * n_windows,
+        "tag_decoder": n_rn16 * (8.0 * RN16_WIN + 48) + n_epc * (8.0 * EPC_WIN + 48),
+    }
+    dur_ms = {"mf_boxcar25_decim5": k_ms["mf_ms"], "gate_scan": k_ms["gate_ms"], "tag_decoder": k_ms["decode_ms"]}
+    traffic = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pt = json.load(f)
+        if pt.get("streams") == B and pt.get("raw_per_stream") == L:
+            traffic = pt.get("hbm_bytes_per_launch", {})
+    except Exception:
+        pass
+
+    def roof(name):
+        ach = alg[name] / (dur_ms[name] * 1e-3) / 1e9 if dur_ms[name] > 0 else 0.0
+        return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(name),
+                "algorithmic_bytes": int(alg[name]), "avg_ms": round(dur_ms[name], 4)}
+
+    dominant = max(dur_ms, key=lambda k: dur_ms[k])
+    total_raw = float(B) * L * args.steps * n_gpus
+    out = {
+        "metric": "I/Q Msamples/s through matched_filter->gate->tag_decoder (+ EPC decodes/s), 40 kHz FM0",
+        "value": round(total_raw / elapsed / 1e6, 2),
+        "unit": "Msamples/s",
+        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: batch of %d noise-replicas per GPU of the 71-round file_source_test "
+                               "stand-in trace, FM0 40 kHz BLF @ 2 Msps (%d raw I/Q samples each, sigma=%g), "
+                               "resident in HBM" % (B, L, args.sigma),
+                   "streams_per_gpu": B, "raw_samples_per_stream": L, "parallelism": "traces sharded per GPU, no collective"},
+        "epc_decodes_per_s": round(n_epc_ok * n_gpus * args.steps / elapsed, 1),
+        "decoder_gated_msamples_per_s": round((n_rn16 * RN16_WIN + n_epc * EPC_WIN) / (k_ms["decode_ms"] * 1e-3) / 1e6, 1)
+        if k_ms["decode_ms"] > 0 else None,
+        "windows_per_step": n_windows,
+        "parity_check": "ok: every replica 70/71 EPC, tag 0x27" if parity_ok else
+                        "FAILED: %d EPC ok, expected %d" % (n_epc_ok, expect_ok),
+        "roofline": roof(dominant),
+        "roofline_by_kernel": {k: roof(k) for k in alg},
+    }
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(base.samples, args.sigma, args.cpu_seconds)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    if not parity_ok:
+        raise SystemExit(2)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,723 @@
+// rfid_capi.hip -- C-ABI of librfid_mi355x.so (see include/rfid_mi355x.h).
+//
+// Host side of the library: context, HBM workspace, kernel launches on the context's HIP
+// stream, and the small integer bookkeeping of READER_STATE.  All sample arithmetic
+// happens in the kernels of rfid_kernels.hpp; there is no CPU implementation of the path
+// in this library -- without a gfx950 device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "rfid_host_math.h"
+#include "rfid_kernels.hpp"
+#include "rfid_mi355x.h"
+
+using namespace rfidk;
+
+namespace {
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct rfid_ctx {
+  rfid_params prm;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  char err[512];
+  float t_cand[N_TCAND];
+
+  // ---- READER_STATE (host) ----
+  rfid_reader_state rs;
+
+  // ---- streaming ----
+  GateState *d_gate1 = nullptr;   // gate state of the single streaming RX stream
+  int *d_io = nullptr;            // [2]
+  DevBuf s_in, s_out;
+  rfid_window *d_swin = nullptr;  // one window
+  int *d_scount = nullptr;
+  rfid_decode_result *d_sres = nullptr;
+  rfid_scores *d_sscores = nullptr;
+  rfid_cf32 mf_hist[NTAPS - 1];
+  int64_t mf_seen = 0;
+
+  // ---- batch plan ----
+  int B = 0;
+  int64_t max_raw = 0, y_stride = 0;
+  float2 *d_y = nullptr;
+  GateState *d_gstate = nullptr;
+  rfid_window *d_wtab = nullptr, *d_flat = nullptr;
+  int wmax = 0, flat_cap = 0;
+  int *d_wcount = nullptr, *d_flat_count = nullptr;
+  rfid_decode_result *d_res = nullptr;
+  rfid_scores *d_scores = nullptr;
+  rfid_stream_stats *d_stats = nullptr;
+  const int64_t *d_lens = nullptr;  // of the last rfid_batch_mf
+  int64_t last_n_raw = 0;
+  int decode_grid = 0;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool ev_valid[5] = {false, false, false, false, false};
+};
+
+namespace {
+
+int fail(rfid_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
+  if (c) {
+    if (e != hipSuccess)
+      snprintf(c->err, sizeof(c->err), "%s: %s", what, hipGetErrorString(e));
+    else
+      snprintf(c->err, sizeof(c->err), "%s", what);
+  }
+  return code;
+}
+
+#define HIPCHK(c, call)                                                     \
+  do {                                                                      \
+    hipError_t e__ = (call);                                                \
+    if (e__ != hipSuccess) return fail((c), RFID_ERR_HIP, #call, e__);      \
+  } while (0)
+
+int grow(rfid_ctx *c, DevBuf &b, size_t bytes) {
+  if (bytes <= b.cap) return RFID_OK;
+  if (b.p) HIPCHK(c, hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  size_t want = bytes < 4096 ? 4096 : bytes;
+  HIPCHK(c, hipMalloc(&b.p, want));
+  b.cap = want;
+  return RFID_OK;
+}
+
+// derive the sample counts exactly as the block constructors do and check that they are
+// the ones the kernels were written for (gate_impl.cc:48-53, tag_decoder_impl.cc:60)
+bool params_supported(const rfid_params &p) {
+  if (p.decim != DECIM || p.n_taps != NTAPS) return false;
+  if (p.fixed_q < 0 || p.fixed_q > 15) return false;
+  const float tag_bit_d = rfidh::tag_bit_d();
+  const int t1 = (int)(240 * (p.sample_rate / pow(10, 6)));
+  const int pw = (int)(12 * (p.sample_rate / pow(10, 6)));
+  const int nb = (int)(tag_bit_d * (p.sample_rate / pow(10, 6)));
+  const int win = (int)(250 * (p.sample_rate / pow(10, 6)));
+  const int dc = (int)(120 * (p.sample_rate / pow(10, 6)));
+  const float nbf = rfidh::n_samples_tag_bit(p.sample_rate);
+  return t1 == T1_SAMPLES && pw / 2 == PW_HALF && nb == 10 && win == WIN_LEN && dc == DC_LEN &&
+         nbf == 10.0f && (129 + 6) * nb + 2 * nb == EPC_WIN && (17 + 6) * nb + 2 * nb == RN16_WIN;
+}
+
+void compute_t_cand(float *t_cand, int sample_rate) { rfidh::t_candidates(t_cand, sample_rate); }
+
+void init_reader_state(rfid_ctx *c) {  // global_vars.cc:34-54
+  memset(&c->rs, 0, sizeof(c->rs));
+  c->rs.status = RFID_RUNNING;
+  c->rs.gen2_logic_status = RFID_START;
+  c->rs.gate_status = RFID_GATE_SEEK_RN16;
+  c->rs.decoder_status = RFID_DECODE_RN16;
+  c->rs.max_slot_number = (int)pow(2, c->prm.fixed_q);
+  c->rs.cur_inventory_round = 1;
+  c->rs.cur_slot_number = 1;
+}
+
+void free_plan(rfid_ctx *c) {
+  void *ptrs[] = {c->d_y, c->d_gstate, c->d_wtab, c->d_flat, c->d_wcount, c->d_flat_count,
+                  c->d_res, c->d_scores, c->d_stats};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  c->d_y = nullptr; c->d_gstate = nullptr; c->d_wtab = nullptr; c->d_flat = nullptr;
+  c->d_wcount = nullptr; c->d_flat_count = nullptr; c->d_res = nullptr; c->d_scores = nullptr;
+  c->d_stats = nullptr;
+  c->B = 0;
+}
+
+// slot/round roll-over of tag_decoder_impl.cc:330-343 / :369-383 (and :269-288)
+void next_slot(rfid_reader_state &rs) {
+  if (rs.cur_slot_number > rs.max_slot_number) {
+    rs.cur_slot_number = 1;
+    rs.cur_inventory_round += 1;
+    rs.gen2_logic_status = RFID_SEND_QUERY;
+  } else {
+    rs.gen2_logic_status = RFID_SEND_QUERY_REP;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rfid_version(void) { return "rfid_mi355x 0.1 (gfx950)"; }
+
+const char *rfid_strerror(int s) {
+  switch (s) {
+    case RFID_OK: return "ok";
+    case RFID_ERR_INVALID: return "invalid argument";
+    case RFID_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case RFID_ERR_HIP: return "HIP runtime error";
+    case RFID_ERR_UNSUPPORTED: return "unsupported parameters";
+    case RFID_ERR_CAPACITY: return "buffer or workspace too small";
+    case RFID_ERR_STATE: return "call not valid in this state";
+    default: return "unknown status";
+  }
+}
+
+const char *rfid_last_error(const rfid_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+int rfid_params_default(rfid_params *p) {
+  if (!p) return RFID_ERR_INVALID;
+  p->sample_rate = 400000;      // int(adc_rate/decim), apps/reader.py:76
+  p->decim = DECIM;
+  p->n_taps = NTAPS;
+  p->fixed_q = 0;               // global_vars.h:72
+  p->max_num_queries = 1000;    // global_vars.h:76
+  p->number_unique_tags = 100;  // global_vars.h:100
+  return RFID_OK;
+}
+
+int rfid_ctx_create(const rfid_params *p, int device, rfid_ctx **out) {
+  if (!p || !out) return RFID_ERR_INVALID;
+  *out = nullptr;
+  if (!params_supported(*p)) return RFID_ERR_UNSUPPORTED;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return RFID_ERR_NO_DEVICE;
+  if (device < 0 || device >= n_dev) return RFID_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return RFID_ERR_NO_DEVICE;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return RFID_ERR_NO_DEVICE;
+  rfid_ctx *c = new (std::nothrow) rfid_ctx();
+  if (!c) return RFID_ERR_CAPACITY;
+  c->prm = *p;
+  c->device = device;
+  c->err[0] = 0;
+  compute_t_cand(c->t_cand, p->sample_rate);
+  init_reader_state(c);
+  memset(c->mf_hist, 0, sizeof(c->mf_hist));
+  int rc = RFID_OK;
+  do {
+    if (hipSetDevice(device) != hipSuccess) { rc = RFID_ERR_NO_DEVICE; break; }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = RFID_ERR_HIP; break; }
+    for (int i = 0; i < 5; ++i)
+      if (hipEventCreate(&c->ev[i]) != hipSuccess) { rc = RFID_ERR_HIP; break; }
+    if (rc) break;
+    if (hipMalloc((void **)&c->d_gate1, sizeof(GateState)) != hipSuccess ||
+        hipMalloc((void **)&c->d_io, 2 * sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&c->d_swin, sizeof(rfid_window)) != hipSuccess ||
+        hipMalloc((void **)&c->d_scount, sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&c->d_sres, sizeof(rfid_decode_result)) != hipSuccess ||
+        hipMalloc((void **)&c->d_sscores, sizeof(rfid_scores)) != hipSuccess) { rc = RFID_ERR_HIP; break; }
+    if (hipMemset(c->d_gate1, 0, sizeof(GateState)) != hipSuccess) { rc = RFID_ERR_HIP; break; }
+  } while (0);
+  if (rc != RFID_OK) { rfid_ctx_destroy(c); return rc; }
+  *out = c;
+  return RFID_OK;
+}
+
+int rfid_ctx_destroy(rfid_ctx *c) {
+  if (!c) return RFID_ERR_INVALID;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  free_plan(c);
+  void *ptrs[] = {c->d_gate1, c->d_io, c->d_swin, c->d_scount, c->d_sres, c->d_sscores, c->s_in.p, c->s_out.p};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  for (int i = 0; i < 5; ++i)
+    if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return RFID_OK;
+}
+
+int rfid_ctx_reset(rfid_ctx *c) {
+  if (!c) return RFID_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  init_reader_state(c);
+  memset(c->mf_hist, 0, sizeof(c->mf_hist));
+  c->mf_seen = 0;
+  HIPCHK(c, hipMemsetAsync(c->d_gate1, 0, sizeof(GateState), c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return RFID_OK;
+}
+
+void *rfid_ctx_stream(rfid_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int rfid_get_state(const rfid_ctx *c, rfid_reader_state *out) {
+  if (!c || !out) return RFID_ERR_INVALID;
+  *out = c->rs;
+  return RFID_OK;
+}
+
+int rfid_print_results(const rfid_ctx *c, char *buf, int cap, int *len) {  // reader_impl.cc:173-192
+  if (!c || !buf || cap <= 0) return RFID_ERR_INVALID;
+  const rfid_reader_state &rs = c->rs;
+  int n = 0;
+  n += snprintf(buf + n, cap - n, "\n --------------------------\n");
+  n += snprintf(buf + n, cap - n, "| Number of queries/queryreps sent : %d\n", rs.n_queries_sent - 1);
+  n += snprintf(buf + n, cap - n, "| Current Inventory round : %d\n", rs.cur_inventory_round);
+  n += snprintf(buf + n, cap - n, " --------------------------\n");
+  n += snprintf(buf + n, cap - n, "| Correctly decoded EPC : %d\n", rs.n_epc_correct);
+  n += snprintf(buf + n, cap - n, "| Number of unique tags : %d\n", rs.n_unique_tags);
+  for (int id = 0; id < 256 && n < cap - 64; id++)
+    if (rs.tag_reads[id])
+      n += snprintf(buf + n, cap - n, "| Tag ID : %x  Num of reads : %d\n", id, rs.tag_reads[id]);
+  if (n < cap - 32) n += snprintf(buf + n, cap - n, " --------------------------\n");
+  if (len) *len = n;
+  return RFID_OK;
+}
+
+// ======================================================================================
+// self test
+// ======================================================================================
+int rfid_selftest(rfid_ctx *c, int *n_failed) {
+  if (!c) return RFID_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  float hx[64], hn[64], hd[64];
+  unsigned seed = 12345u;
+  auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (float)((seed >> 8) & 0xFFFF) / 65536.0f; };
+  for (int i = 0; i < 64; ++i) {
+    hx[i] = (rnd() - 0.5f) * 1e-3f * (float)(1 + (i % 7));
+    hn[i] = (rnd() - 0.5f) * 37.0f;
+    hd[i] = (i % 3 == 0) ? 100.0f : ((i % 3 == 1) ? 48.0f : (rnd() + 0.01f) * 9.0f);
+  }
+  const float carry = 23.456789f;
+  float *d = nullptr;
+  HIPCHK(c, hipMalloc((void **)&d, 7 * 64 * sizeof(float)));
+  HIPCHK(c, hipMemcpyAsync(d, hx, sizeof(hx), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + 64, hn, sizeof(hn), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + 128, hd, sizeof(hd), hipMemcpyHostToDevice, c->stream));
+  SelfTestArgs a;
+  a.x = d; a.num = d + 64; a.den = d + 128; a.carry = carry;
+  a.chain_out = d + 192; a.div_out = d + 256; a.hyp_out = d + 320; a.shr_out = d + 384;
+  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  float out[4 * 64];
+  HIPCHK(c, hipMemcpyAsync(out, d + 192, sizeof(out), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d);
+  int bad = 0;
+  volatile float acc = carry;
+  for (int i = 0; i < 64; ++i) {
+    acc = acc + hx[i];
+    float e_chain = acc;
+    volatile float q = hn[i] / hd[i];
+    float e_div = q;
+    float e_hyp = (float)sqrt((double)hn[i] * (double)hn[i] + (double)hd[i] * (double)hd[i]);
+    float e_shr = (i == 0) ? 0.0f : hx[i - 1];
+    if (memcmp(&e_chain, &out[i], 4)) bad++;
+    if (memcmp(&e_div, &out[64 + i], 4)) bad++;
+    if (memcmp(&e_hyp, &out[128 + i], 4)) bad++;
+    if (memcmp(&e_shr, &out[192 + i], 4)) bad++;
+  }
+  if (n_failed) *n_failed = bad;
+  if (bad) snprintf(c->err, sizeof(c->err), "selftest: %d primitive checks failed", bad);
+  return RFID_OK;
+}
+
+// ======================================================================================
+// (2) batched offline path
+// ======================================================================================
+int rfid_batch_plan(rfid_ctx *c, int n_streams, int64_t max_raw) {
+  if (!c || n_streams <= 0 || max_raw <= 0) return RFID_ERR_INVALID;
+  if (max_raw / DECIM > 0x7fffff00LL) return RFID_ERR_UNSUPPORTED;  // 32-bit sample indices per trace
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  free_plan(c);
+  const int64_t n_dec = max_raw / DECIM;
+  c->y_stride = (n_dec + 1) & ~1LL;  // even -> 16-byte aligned rows
+  if (c->y_stride < 2) c->y_stride = 2;
+  // closest two openings can be: RN16 window (250) + T1 (97 closed samples)
+  int64_t wmax = n_dec / (RN16_WIN + T1_SAMPLES + 1) + 2;
+  if (wmax * n_streams > 0x7fffffffLL) return RFID_ERR_UNSUPPORTED;
+  c->wmax = (int)wmax;
+  c->flat_cap = (int)(wmax * n_streams);
+  c->B = n_streams;
+  c->max_raw = max_raw;
+  HIPCHK(c, hipMalloc((void **)&c->d_y, sizeof(float2) * (size_t)c->y_stride * n_streams));
+  HIPCHK(c, hipMalloc((void **)&c->d_gstate, sizeof(GateState) * (size_t)n_streams));
+  HIPCHK(c, hipMalloc((void **)&c->d_wtab, sizeof(rfid_window) * (size_t)c->flat_cap));
+  HIPCHK(c, hipMalloc((void **)&c->d_flat, sizeof(rfid_window) * (size_t)c->flat_cap));
+  HIPCHK(c, hipMalloc((void **)&c->d_wcount, sizeof(int) * (size_t)n_streams));
+  HIPCHK(c, hipMalloc((void **)&c->d_flat_count, sizeof(int)));
+  HIPCHK(c, hipMalloc((void **)&c->d_res, sizeof(rfid_decode_result) * (size_t)c->flat_cap));
+  HIPCHK(c, hipMalloc((void **)&c->d_scores, sizeof(rfid_scores) * (size_t)c->flat_cap));
+  HIPCHK(c, hipMalloc((void **)&c->d_stats, sizeof(rfid_stream_stats) * (size_t)n_streams));
+  HIPCHK(c, hipMemset(c->d_wcount, 0, sizeof(int) * (size_t)n_streams));
+  HIPCHK(c, hipMemset(c->d_flat_count, 0, sizeof(int)));
+  hipDeviceProp_t prop;
+  HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+  // persistent decoder: 9 single-wave workgroups fit one CU's 160 KiB LDS (16.5 KiB each)
+  c->decode_grid = prop.multiProcessorCount * 9;
+  for (int i = 0; i < 5; ++i) c->ev_valid[i] = false;
+  return RFID_OK;
+}
+
+int rfid_batch_mf(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64_t n_raw, const void *d_lens) {
+  if (!c || !d_raw || n_raw < 0 || raw_stride < n_raw) return RFID_ERR_INVALID;
+  if (!c->B) return RFID_ERR_STATE;
+  if (n_raw > c->max_raw) return RFID_ERR_CAPACITY;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->d_lens = (const int64_t *)d_lens;
+  c->last_n_raw = n_raw;
+  MfArgs a;
+  a.x = (const float2 *)d_raw; a.x_stride = raw_stride; a.n_raw = n_raw; a.lens = c->d_lens;
+  a.n_out = n_raw / DECIM; a.in_off = -(NTAPS - 1);
+  a.vec_ok = ((raw_stride & 1) == 0 && (((uintptr_t)d_raw) & 15) == 0) ? 1 : 0;
+  a.y = c->d_y; a.y_stride = c->y_stride;
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  const int64_t tiles = (a.n_out + MF_TILE - 1) / MF_TILE;
+  if (tiles > 0) {
+    hipLaunchKernelGGL(mf_boxcar25_decim5_kernel, dim3((unsigned)tiles, (unsigned)c->B), dim3(MF_THREADS), 0,
+                       c->stream, a);
+    HIPCHK(c, hipGetLastError());
+  }
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  c->ev_valid[0] = c->ev_valid[1] = true;
+  return RFID_OK;
+}
+
+int rfid_batch_gate(rfid_ctx *c) {
+  if (!c) return RFID_ERR_INVALID;
+  if (!c->B) return RFID_ERR_STATE;
+  HIPCHK(c, hipSetDevice(c->device));
+  // fresh gate per trace (gate_impl ctor, gate_impl.cc:41-70): all-zero state; the kernel
+  // arms n_samples_to_ungate for the first RN16 itself
+  HIPCHK(c, hipMemsetAsync(c->d_gstate, 0, sizeof(GateState) * (size_t)c->B, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_flat_count, 0, sizeof(int), c->stream));
+  GateArgs a;
+  a.y = c->d_y; a.y_stride = c->y_stride; a.n_dec = c->last_n_raw / DECIM; a.lens = c->d_lens;
+  a.state = c->d_gstate; a.wtab = c->d_wtab; a.wmax = c->wmax; a.wcount = c->d_wcount;
+  a.flat = c->d_flat; a.flat_count = c->d_flat_count; a.flat_cap = c->flat_cap; a.mode = 0;
+  a.gated = nullptr; a.gated_cap = 0; a.io = nullptr;
+  if (!c->ev_valid[1]) { HIPCHK(c, hipEventRecord(c->ev[1], c->stream)); c->ev_valid[1] = true; }
+  hipLaunchKernelGGL(gate_scan_kernel, dim3((unsigned)c->B), dim3(64), 0, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  c->ev_valid[2] = true;
+  return RFID_OK;
+}
+
+int rfid_batch_decode(rfid_ctx *c, int want_scores) {
+  if (!c) return RFID_ERR_INVALID;
+  if (!c->B) return RFID_ERR_STATE;
+  HIPCHK(c, hipSetDevice(c->device));
+  DecodeArgs a;
+  a.y = c->d_y; a.y_stride = c->y_stride; a.flat = c->d_flat; a.flat_count = c->d_flat_count;
+  a.flat_cap = c->flat_cap; a.res = c->d_res; a.scores = want_scores ? c->d_scores : nullptr;
+  a.wmax = c->wmax;
+  memcpy(a.t_cand, c->t_cand, sizeof(a.t_cand));
+  if (!c->ev_valid[2]) { HIPCHK(c, hipEventRecord(c->ev[2], c->stream)); c->ev_valid[2] = true; }
+  int grid = c->decode_grid;
+  if (grid > c->flat_cap) grid = c->flat_cap;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(decode_windows_kernel, dim3((unsigned)grid), dim3(64), 0, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+  c->ev_valid[3] = true;
+  return RFID_OK;
+}
+
+int rfid_batch_stats(rfid_ctx *c) {
+  if (!c) return RFID_ERR_INVALID;
+  if (!c->B) return RFID_ERR_STATE;
+  HIPCHK(c, hipSetDevice(c->device));
+  StatsArgs a;
+  a.res = c->d_res; a.wcount = c->d_wcount; a.wmax = c->wmax; a.n_streams = c->B;
+  a.max_slot_number = (int)pow(2, c->prm.fixed_q);
+  a.max_num_queries = c->prm.max_num_queries; a.number_unique_tags = c->prm.number_unique_tags;
+  a.out = c->d_stats;
+  if (!c->ev_valid[3]) { HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->ev_valid[3] = true; }
+  hipLaunchKernelGGL(stream_stats_kernel, dim3((unsigned)((c->B + 63) / 64)), dim3(64), 0, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+  c->ev_valid[4] = true;
+  return RFID_OK;
+}
+
+int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64_t n_raw, const void *d_lens,
+                       int want_scores) {
+  int rc = rfid_batch_mf(c, d_raw, raw_stride, n_raw, d_lens);
+  if (rc) return rc;
+  if ((rc = rfid_batch_gate(c))) return rc;
+  if ((rc = rfid_batch_decode(c, want_scores))) return rc;
+  return rfid_batch_stats(c);
+}
+
+int rfid_batch_sync(rfid_ctx *c) {
+  if (!c) return RFID_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return RFID_OK;
+}
+
+int rfid_batch_timing_get(rfid_ctx *c, rfid_batch_timing *out) {
+  if (!c || !out) return RFID_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  float ms[4] = {0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i)
+    if (c->ev_valid[i] && c->ev_valid[i + 1]) HIPCHK(c, hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+  out->mf_ms = ms[0]; out->gate_ms = ms[1]; out->decode_ms = ms[2]; out->stats_ms = ms[3];
+  out->total_ms = ms[0] + ms[1] + ms[2] + ms[3];
+  return RFID_OK;
+}
+
+int rfid_batch_get_stats(rfid_ctx *c, rfid_stream_stats *out, int n_streams) {
+  if (!c || !out || n_streams <= 0) return RFID_ERR_INVALID;
+  if (!c->B) return RFID_ERR_STATE;
+  if (n_streams > c->B) n_streams = c->B;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(out, c->d_stats, sizeof(rfid_stream_stats) * (size_t)n_streams, hipMemcpyDeviceToHost,
+                           c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return RFID_OK;
+}
+
+int rfid_batch_get_windows(rfid_ctx *c, rfid_window *windows, rfid_decode_result *results, rfid_scores *scores,
+                           int64_t cap, int64_t *n) {
+  if (!c || !n) return RFID_ERR_INVALID;
+  if (!c->B) return RFID_ERR_STATE;
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<int> wc((size_t)c->B);
+  HIPCHK(c, hipMemcpyAsync(wc.data(), c->d_wcount, sizeof(int) * (size_t)c->B, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int64_t total = 0;
+  for (int s = 0; s < c->B; ++s) {
+    const int k = wc[(size_t)s];
+    const int64_t room = cap - total;
+    const int64_t take = (room <= 0) ? 0 : ((k < room) ? k : room);
+    if (take > 0) {
+      const size_t off = (size_t)s * (size_t)c->wmax;
+      if (windows)
+        HIPCHK(c, hipMemcpyAsync(windows + total, c->d_wtab + off, sizeof(rfid_window) * (size_t)take,
+                                 hipMemcpyDeviceToHost, c->stream));
+      if (results)
+        HIPCHK(c, hipMemcpyAsync(results + total, c->d_res + off, sizeof(rfid_decode_result) * (size_t)take,
+                                 hipMemcpyDeviceToHost, c->stream));
+      if (scores)
+        HIPCHK(c, hipMemcpyAsync(scores + total, c->d_scores + off, sizeof(rfid_scores) * (size_t)take,
+                                 hipMemcpyDeviceToHost, c->stream));
+    }
+    total += k;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *n = total;
+  return RFID_OK;
+}
+
+int rfid_batch_device_ptrs(rfid_ctx *c, void **d_mf_out, int64_t *mf_stride, void **d_stats, void **d_flat_count) {
+  if (!c) return RFID_ERR_INVALID;
+  if (!c->B) return RFID_ERR_STATE;
+  if (d_mf_out) *d_mf_out = c->d_y;
+  if (mf_stride) *mf_stride = c->y_stride;
+  if (d_stats) *d_stats = c->d_stats;
+  if (d_flat_count) *d_flat_count = c->d_flat_count;
+  return RFID_OK;
+}
+
+int rfid_batch_get_mf(rfid_ctx *c, int stream, rfid_cf32 *out, int64_t cap, int64_t *n) {
+  if (!c || !out || !n) return RFID_ERR_INVALID;
+  if (!c->B || stream < 0 || stream >= c->B) return RFID_ERR_STATE;
+  HIPCHK(c, hipSetDevice(c->device));
+  int64_t n_raw = c->last_n_raw;
+  if (c->d_lens) {
+    int64_t l = 0;
+    HIPCHK(c, hipMemcpyAsync(&l, c->d_lens + stream, sizeof(l), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (l < n_raw) n_raw = l;
+    if (n_raw < 0) n_raw = 0;
+  }
+  int64_t k = n_raw / DECIM;
+  *n = k;
+  if (k > cap) k = cap;
+  if (k > 0)
+    HIPCHK(c, hipMemcpyAsync(out, c->d_y + (size_t)stream * (size_t)c->y_stride, sizeof(float2) * (size_t)k,
+                             hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return RFID_OK;
+}
+
+// ======================================================================================
+// (1) streaming per-block path (host buffers)
+// ======================================================================================
+int rfid_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap, int *n_produced) {
+  if (!c || n_in < 0 || (n_in > 0 && !in) || !n_produced) return RFID_ERR_INVALID;
+  *n_produced = 0;
+  if (n_in == 0) return RFID_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int H = NTAPS - 1;
+  const int off = (int)((DECIM - (c->mf_seen % DECIM)) % DECIM);  // raw samples until the next output
+  const int n_out = (n_in > off) ? ((n_in - 1 - off) / DECIM + 1) : 0;
+  if (n_out > out_cap || (n_out > 0 && !out)) return RFID_ERR_CAPACITY;
+  if (n_out > 0) {
+    int rc = grow(c, c->s_in, sizeof(float2) * (size_t)(H + n_in + 2));
+    if (rc) return rc;
+    if ((rc = grow(c, c->s_out, sizeof(float2) * (size_t)(n_out + 2)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->s_in.p, c->mf_hist, sizeof(rfid_cf32) * H, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync((float2 *)c->s_in.p + H, in, sizeof(rfid_cf32) * (size_t)n_in, hipMemcpyHostToDevice,
+                             c->stream));
+    MfArgs a;
+    a.x = (const float2 *)c->s_in.p; a.x_stride = H + n_in; a.n_raw = H + n_in; a.lens = nullptr;
+    a.n_out = n_out; a.in_off = off; a.vec_ok = (off % 2 == 0) ? 1 : 0;
+    a.y = (float2 *)c->s_out.p; a.y_stride = n_out;
+    const int tiles = (n_out + MF_TILE - 1) / MF_TILE;
+    hipLaunchKernelGGL(mf_boxcar25_decim5_kernel, dim3((unsigned)tiles, 1), dim3(MF_THREADS), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->s_out.p, sizeof(rfid_cf32) * (size_t)n_out, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  // roll the 24-sample history
+  if (n_in >= H) {
+    memcpy(c->mf_hist, in + n_in - H, sizeof(rfid_cf32) * H);
+  } else {
+    memmove(c->mf_hist, c->mf_hist + n_in, sizeof(rfid_cf32) * (size_t)(H - n_in));
+    memcpy(c->mf_hist + H - n_in, in, sizeof(rfid_cf32) * (size_t)n_in);
+  }
+  c->mf_seen += n_in;
+  *n_produced = n_out;
+  return RFID_OK;
+}
+
+int rfid_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap, int *n_consumed,
+                   int *n_written) {
+  if (!c || n_in < 0 || (n_in > 0 && !in) || !n_consumed || !n_written) return RFID_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  rfid_reader_state &rs = c->rs;
+  *n_consumed = n_in;
+  *n_written = 0;
+  // gate_impl.cc:101-109
+  if ((rs.n_queries_sent > c->prm.max_num_queries || rs.n_unique_tags > c->prm.number_unique_tags) &&
+      rs.status != RFID_TERMINATED)
+    rs.status = RFID_TERMINATED;
+  // gate_impl.cc:112-123: SEEK_* -> CLOSED, arm n_samples_to_ungate, n_samples = 0
+  if (rs.gate_status == RFID_GATE_SEEK_EPC || rs.gate_status == RFID_GATE_SEEK_RN16) {
+    const int type = (rs.gate_status == RFID_GATE_SEEK_EPC) ? 1 : 0;
+    rs.gate_status = RFID_GATE_CLOSED;
+    rs.n_samples_to_ungate = type ? EPC_WIN : RN16_WIN;
+    const int zero = 0, ung = rs.n_samples_to_ungate;
+    HIPCHK(c, hipMemcpyAsync(&c->d_gate1->n_samples, &zero, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&c->d_gate1->n_to_ungate, &ung, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&c->d_gate1->wtype, &type, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  if (rs.status != RFID_RUNNING || n_in == 0) return RFID_OK;
+  if (!out || out_cap < n_in) return RFID_ERR_CAPACITY;  // a call can emit up to n_in samples
+  int rc = grow(c, c->s_in, sizeof(float2) * (size_t)(n_in + 2));
+  if (rc) return rc;
+  if ((rc = grow(c, c->s_out, sizeof(float2) * (size_t)(n_in + 2)))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->s_in.p, in, sizeof(rfid_cf32) * (size_t)n_in, hipMemcpyHostToDevice, c->stream));
+  GateArgs a;
+  a.y = (const float2 *)c->s_in.p; a.y_stride = n_in; a.n_dec = n_in; a.lens = nullptr;
+  a.state = c->d_gate1; a.wtab = nullptr; a.wmax = 0; a.wcount = nullptr;
+  a.flat = nullptr; a.flat_count = nullptr; a.flat_cap = 0; a.mode = 1;
+  a.gated = (float2 *)c->s_out.p; a.gated_cap = n_in; a.io = c->d_io;
+  hipLaunchKernelGGL(gate_scan_kernel, dim3(1), dim3(64), 0, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  int io[2] = {0, 0};
+  int open_now = 0;
+  HIPCHK(c, hipMemcpyAsync(io, c->d_io, sizeof(io), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&open_now, &c->d_gate1->gate_open, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (io[1] > 0)
+    HIPCHK(c, hipMemcpy(out, c->s_out.p, sizeof(rfid_cf32) * (size_t)io[1], hipMemcpyDeviceToHost));
+  rs.gate_status = open_now ? RFID_GATE_OPEN : RFID_GATE_CLOSED;
+  *n_consumed = io[0];
+  *n_written = io[1];
+  return RFID_OK;
+}
+
+int rfid_decoder_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, float *out_bits, int out_cap, int *n_consumed,
+                      int *n_produced, rfid_decode_result *res_out, rfid_scores *scores_out) {
+  if (!c || n_in < 0 || (n_in > 0 && !in) || !n_consumed || !n_produced) return RFID_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  rfid_reader_state &rs = c->rs;
+  *n_consumed = 0;
+  *n_produced = 0;
+  const int ung = rs.n_samples_to_ungate;
+  // tag_decoder_impl.cc:223 / :291 -- act only on a complete window
+  if (ung <= 0 || n_in < ung) return RFID_OK;
+  const int type = rs.decoder_status;
+  const int wlen = (type == RFID_DECODE_EPC) ? EPC_WIN : RN16_WIN;
+  if (ung != wlen) return fail(c, RFID_ERR_STATE, "n_samples_to_ungate does not match decoder_status");
+  if (type == RFID_DECODE_RN16 && (!out_bits || out_cap < 16)) return RFID_ERR_CAPACITY;
+  int rc = grow(c, c->s_in, sizeof(float2) * (size_t)(wlen + 2));
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->s_in.p, in, sizeof(rfid_cf32) * (size_t)wlen, hipMemcpyHostToDevice, c->stream));
+  rfid_window w;
+  w.stream = 0; w.seq = 0; w.start = 0; w.type = type; w.dc_re = 0.0f; w.dc_im = 0.0f;  // input is already DC-free
+  const int one = 1;
+  HIPCHK(c, hipMemcpyAsync(c->d_swin, &w, sizeof(w), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_scount, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  DecodeArgs a;
+  a.y = (const float2 *)c->s_in.p; a.y_stride = wlen; a.flat = c->d_swin; a.flat_count = c->d_scount;
+  a.flat_cap = 1; a.res = c->d_sres; a.scores = c->d_sscores; a.wmax = 1;
+  memcpy(a.t_cand, c->t_cand, sizeof(a.t_cand));
+  hipLaunchKernelGGL(decode_windows_kernel, dim3(1), dim3(64), 0, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  rfid_decode_result r;
+  rfid_scores sc;
+  HIPCHK(c, hipMemcpyAsync(&r, c->d_sres, sizeof(r), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&sc, c->d_sscores, sizeof(sc), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (res_out) *res_out = r;
+  if (scores_out) *scores_out = sc;
+  if (type == RFID_DECODE_RN16) {
+    // tag_decoder_impl.cc:256-268 (the else branch :269-288 is unreachable once n_in >= 250)
+    for (int b = 0; b < 16; ++b) out_bits[b] = (float)((r.bits[0] >> b) & 1u);
+    *n_produced = 16;
+    rs.gen2_logic_status = RFID_SEND_ACK;
+  } else {
+    rs.cur_slot_number++;  // :295
+    if (r.crc_ok) {        // :328-364
+      next_slot(rs);
+      rs.n_epc_correct += 1;
+      const int id = r.tag_id & 255;
+      if (rs.tag_reads[id] == 0) rs.n_unique_tags++;
+      rs.tag_reads[id]++;
+    } else {               // :366-387
+      next_slot(rs);
+    }
+  }
+  *n_consumed = ung;
+  return RFID_OK;
+}
+
+int rfid_reader_work(rfid_ctx *c, int n_in, int *n_consumed) {  // reader_impl.cc:200-380
+  if (!c) return RFID_ERR_INVALID;
+  rfid_reader_state &rs = c->rs;
+  if (n_consumed) *n_consumed = n_in;  // consume_each(ninput_items[0]) :378
+  switch (rs.gen2_logic_status) {
+    case RFID_START: rs.gen2_logic_status = RFID_SEND_QUERY; break;            // :218-224
+    case RFID_POWER_DOWN: rs.gen2_logic_status = RFID_START; break;            // :226-231
+    case RFID_SEND_NAK_QR: rs.gen2_logic_status = RFID_SEND_QUERY_REP; break;  // :233-240
+    case RFID_SEND_NAK_Q: rs.gen2_logic_status = RFID_SEND_QUERY; break;       // :242-249
+    case RFID_SEND_QUERY:                                                      // :251-288
+      rs.n_queries_sent += 1;
+      rs.decoder_status = RFID_DECODE_RN16;
+      rs.gate_status = RFID_GATE_SEEK_RN16;
+      rs.gen2_logic_status = RFID_IDLE;
+      break;
+    case RFID_SEND_ACK:                                                        // :290-320
+      if (n_in == 16) {
+        rs.decoder_status = RFID_DECODE_EPC;
+        rs.gate_status = RFID_GATE_SEEK_EPC;
+        rs.gen2_logic_status = RFID_SEND_CW;
+      }
+      break;
+    case RFID_SEND_CW: rs.gen2_logic_status = RFID_IDLE; break;                // :322-327
+    case RFID_SEND_QUERY_REP:                                                  // :329-344
+    case RFID_SEND_QUERY_ADJUST:                                               // :346-372
+      rs.decoder_status = RFID_DECODE_RN16;
+      rs.gate_status = RFID_GATE_SEEK_RN16;
+      rs.n_queries_sent += 1;
+      rs.gen2_logic_status = RFID_IDLE;
+      break;
+    default: break;
+  }
+  return RFID_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,703 @@
+// rfid_kernels.hpp -- hand-written CDNA4 (gfx950) kernels of the Gen2 receive path.
+//
+//   mf_boxcar25_decim5_kernel : fir_filter_ccc(5,[1]*25)            (apps/reader.py:65,75)
+//   gate_scan_kernel          : gate_impl::general_work scan loop    (lib/gate_impl.cc:127-196)
+//   decode_windows_kernel     : tag_sync + RN16 / EPC detection + CRC (lib/tag_decoder_impl.cc:78-193,401-445)
+//   stream_stats_kernel       : READER_STATS bookkeeping              (lib/tag_decoder_impl.cc:267-388,
+//                                                                      lib/reader_impl.cc:251-344,
+//                                                                      lib/gate_impl.cc:101-109)
+//
+// All paths are relative to /root/reference/gr-rfid/.  None of these is a dense
+// contraction: they are HBM-streaming / LDS-gather kernels, so no MFMA.  Arithmetic is
+// binary32 in the reference's operation order (compile with -ffp-contract=off), which
+// makes decoded bits, indices and scores bit-identical to the CPU path on finite input.
+//
+// Wave-level operations come from rfid_device_env.h (namespace wv).
+#pragma once
+#include <rfid_device_env.h>  // resolved through -I: csrc/ for hipcc (the product)
+#include "rfid_mi355x.h"
+
+namespace rfidk {
+
+// ---- constants derived from sample_rate = 400 kHz (host verifies the derivation) --------
+constexpr int DECIM = 5;           // apps/reader.py:54
+constexpr int NTAPS = 25;          // apps/reader.py:65
+constexpr int WIN_LEN = 100;       // gate_impl.cc:52  WIN_SIZE_D(250 us) * 0.4
+constexpr int DC_LEN = 48;         // gate_impl.cc:53  DC_SIZE_D(120 us) * 0.4
+constexpr int T1_SAMPLES = 96;     // gate_impl.cc:48  T1_D(240 us) * 0.4
+constexpr int PW_HALF = 2;         // gate_impl.cc:157 n_samples_PW(4) / 2
+constexpr int NUM_PULSES_CMD = 5;  // global_vars.h:99
+constexpr int RN16_WIN = 250;      // gate_impl.cc:121 (17+6)*10 + 2*10
+constexpr int EPC_WIN = 1370;      // gate_impl.cc:115 (129+6)*10 + 2*10
+constexpr int N_SYNC = 15;         // tag_decoder_impl.cc:85   i < 1.5 * 10
+constexpr int N_TCAND = 20;        // tag_decoder_impl.cc:150  number_steps
+constexpr float HALF_BIT = 5.0f;   // n_samples_TAG_BIT / 2
+constexpr float WIN_LEN_F = 100.0f;
+constexpr float DC_LEN_F = 48.0f;
+constexpr float THRESH_FRACTION = 0.75f;  // global_vars.h:139
+
+// =========================================================================================
+// 1. matched filter: y[n] = sum_{k=0..24} x[5n + in_off + k], k ascending from (0,0).
+//    Batch mode in_off = -24 (GNU Radio history: 24 zeros before the stream).
+//    One workgroup = MF_TILE outputs of one trace; the 5*MF_TILE+20 raw samples it needs are
+//    staged once through LDS with 16-byte coalesced loads; every lane then walks its own
+//    25-sample window (lane stride 40 B -> conflict-free ds_read_b64).
+// =========================================================================================
+constexpr int MF_TILE = 512;
+constexpr int MF_THREADS = 256;
+constexpr int MF_RAW = MF_TILE * DECIM + (NTAPS - DECIM);  // 2580 raw samples per tile
+
+struct MfArgs {
+  const float2 *x;      // [n_streams][x_stride]
+  int64_t x_stride;
+  int64_t n_raw;        // valid raw samples per trace (when lens == nullptr)
+  const int64_t *lens;  // optional per-trace valid raw sample counts
+  int64_t n_out;        // outputs per trace (when lens == nullptr)
+  int in_off;           // -24 in batch mode
+  int vec_ok;           // rows 16-byte aligned and in_off even -> float4 loads
+  float2 *y;            // [n_streams][y_stride]
+  int64_t y_stride;
+};
+
+RFID_KERNEL(MF_THREADS) void mf_boxcar25_decim5_kernel(MfArgs a) {
+  RFID_SHARED float4 tile4[MF_RAW / 2 + 2];
+  float2 *tile = reinterpret_cast<float2 *>(tile4);
+  const int tid = (int)threadIdx.x;
+  const int b = (int)blockIdx.y;
+  int64_t n_raw = a.n_raw, n_out = a.n_out;
+  if (a.lens) {
+    n_raw = a.lens[b];
+    if (n_raw > a.n_raw) n_raw = a.n_raw;
+    if (n_raw < 0) n_raw = 0;
+    n_out = n_raw / DECIM;
+  }
+  const int64_t n0 = (int64_t)blockIdx.x * MF_TILE;
+  if (n0 >= n_out) return;
+  const float2 *xs = a.x + (int64_t)b * a.x_stride;
+  const int64_t r0 = n0 * DECIM + a.in_off;
+  if (a.vec_ok) {
+    for (int j = tid; j < MF_RAW / 2; j += MF_THREADS) {
+      const int64_t r = r0 + 2 * j;
+      float4 v;
+      if (r >= 0 && r + 1 < n_raw) {
+        v = *reinterpret_cast<const float4 *>(xs + r);
+      } else {
+        float2 lo = (r >= 0 && r < n_raw) ? xs[r] : make_float2(0.0f, 0.0f);
+        float2 hi = (r + 1 >= 0 && r + 1 < n_raw) ? xs[r + 1] : make_float2(0.0f, 0.0f);
+        v = make_float4(lo.x, lo.y, hi.x, hi.y);
+      }
+      tile4[j] = v;
+    }
+  } else {
+    for (int j = tid; j < MF_RAW; j += MF_THREADS) {
+      const int64_t r = r0 + j;
+      tile[j] = (r >= 0 && r < n_raw) ? xs[r] : make_float2(0.0f, 0.0f);
+    }
+  }
+  wv::block_sync();
+  float2 *ys = a.y + (int64_t)b * a.y_stride;
+#pragma unroll
+  for (int rep = 0; rep < MF_TILE / MF_THREADS; ++rep) {
+    const int o = tid + rep * MF_THREADS;
+    const int64_t n = n0 + o;
+    float re = 0.0f, im = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NTAPS; ++k) {
+      const float2 v = tile[DECIM * o + k];
+      re = re + v.x;
+      im = im + v.y;
+    }
+    if (n < n_out) ys[n] = make_float2(re, im);
+  }
+}
+
+// =========================================================================================
+// 2. gate scan.  One wavefront per trace, 64 decimated samples per step (lane L <-> sample
+//    pos+L).  The reference's per-sample recurrences are kept bit-exact:
+//      * avg_ampl += (|x| - ring[w]) / 100     -> the increments are computed lane-parallel,
+//        then added IN ORDER by a 63-step DPP wave-shift chain (lane L ends up holding the
+//        value after sample L);
+//      * dc_est  += (x - dcring[d]) / 48       -> same chain, only over "closed" samples;
+//      * the edge / pulse-count / window state machine runs on the scalar unit, event
+//        driven over 64-bit vote masks (threshold crossings are rare).
+//    Output: one rfid_window {start, dc_est at opening, type} per gate opening.  Batch mode
+//    re-arms the gate itself (type alternates RN16, EPC, ... : SURVEY.md section 3.3);
+//    streaming mode stops right after a window closes, like gate_impl.cc:189-194.
+// =========================================================================================
+struct GateState {  // gate_impl members (gate_impl.h:36-44) + the READER_STATE fields the gate owns
+  float avg_ampl;
+  float dc_re, dc_im;
+  int n_samples;
+  int signal_state;  // 0 NEG_EDGE, 1 POS_EDGE
+  int num_pulses;
+  int gate_open;
+  int n_to_ungate;
+  int wtype;        // type of the window being sought / open: 0 RN16, 1 EPC
+  int win_index;
+  int dc_index;
+  int win_seq;      // windows opened so far
+  float win[WIN_LEN];
+  float dcr_re[DC_LEN];
+  float dcr_im[DC_LEN];
+};
+
+struct GateArgs {
+  const float2 *y;      // [n_streams][y_stride] matched-filter output
+  int64_t y_stride;
+  int64_t n_dec;        // valid decimated samples per trace (when lens == nullptr)
+  const int64_t *lens;  // optional per-trace RAW lengths (n_dec = lens/5)
+  GateState *state;     // [n_streams]
+  rfid_window *wtab;    // [n_streams][wmax]
+  int wmax;
+  int *wcount;          // [n_streams] complete windows recorded
+  rfid_window *flat;    // compact list over all traces (arbitrary order) for the decoder
+  int *flat_count;
+  int flat_cap;
+  int mode;             // 0 batch (self re-arming), 1 streaming (stop after close)
+  float2 *gated;        // streaming: gated, DC-removed samples
+  int gated_cap;
+  int *io;              // streaming: io[0] = consumed, io[1] = written
+};
+
+// In-order sum: returns in lane L the value  (((carry + x_0) + x_1) + ...) + x_L.
+RFID_DEVICE float chain_add(float carry, float x, int lane) {
+  const float x0 = (lane == 0) ? (carry + x) : x;
+  float p = x0;
+#pragma unroll
+  for (int s = 1; s < 64; ++s) p = wv::shr1(p) + x0;
+  return p;
+}
+
+RFID_DEVICE uint64_t lane_range(int lo, int hi) {  // bits [lo, hi), 0 <= lo <= hi <= 64
+  const uint64_t up = (hi >= 64) ? ~0ull : ((1ull << hi) - 1ull);
+  const uint64_t dn = (lo >= 64) ? ~0ull : ((1ull << lo) - 1ull);
+  return up & ~dn;
+}
+
+// wave-uniform registers of one trace's gate
+struct GateRegs {
+  float avg_c, dcr_c, dci_c;
+  int f_n, f_state, f_pulses, f_open, f_ung, f_type;
+  int win_index, dc_index, win_seq;
+  int n_complete, written, consumed;
+  bool stop;
+};
+
+// one step = 64 decimated samples [pos, pos+nvalid) of trace s; lane L holds sample pos+L
+RFID_DEVICE void gate_step(const GateArgs &a, GateRegs &g, const float2 yv_in, int pos, int n,
+                           int s, int lane, float *lds_win, float2 *lds_dc, float2 *lds_tmp) {
+  int nvalid = (n - pos < 64) ? (n - pos) : 64;
+  const bool valid = lane < nvalid;
+  const float2 yv = valid ? yv_in : make_float2(0.0f, 0.0f);
+  // --- moving average of |x| (gate_impl.cc:130-133) ---------------------------------------
+  const float amp = wv::hypot_f(yv.x, yv.y);
+  int wi = g.win_index + lane;
+  if (wi >= WIN_LEN) wi -= WIN_LEN;
+  const float amp_old = lds_win[wi];
+  const float d = valid ? wv::fdiv(amp - amp_old, WIN_LEN_F) : 0.0f;
+  const float avg = chain_add(g.avg_c, d, lane);
+  const float thresh = avg * THRESH_FRACTION;  // gate_impl.cc:136
+  const uint64_t below = wv::uniform(wv::ballot(valid && (amp < thresh)));
+  const uint64_t above = wv::uniform(wv::ballot(valid && (amp > thresh)));
+
+  // --- edge / pulse / window state machine, scalar, event driven (gate_impl.cc:145-195) ---
+  uint64_t closedmask = 0, openmask = 0;
+  int open_lane = -1;   // lane at which a window opened in this step (at most one when
+  int open_lane2 = -1;  // T1 > 64; the second slot keeps the code general)
+  int open_type = 0, open_type2 = 0;
+  int f_n = g.f_n, f_state = g.f_state, f_pulses = g.f_pulses, f_open = g.f_open;
+  int f_ung = g.f_ung, f_type = g.f_type;
+  int p = 0;
+  while (p < nvalid) {
+    if (f_open) {
+      int take = f_ung - f_n;
+      if (take > nvalid - p) take = nvalid - p;
+      if (take <= 0) take = (f_n >= f_ung) ? 0 : 1;
+      openmask |= lane_range(p, p + take);
+      f_n += take;
+      p += take;
+      if (f_n >= f_ung) {  // gate_impl.cc:189-194
+        f_open = 0;
+        if (a.mode == 0) {  // decoder + reader ran; gate re-armed at the next sample (:112-123)
+          f_n = 0;
+          f_type ^= 1;
+          f_ung = f_type ? EPC_WIN : RN16_WIN;
+        } else {
+          g.stop = true;
+          g.consumed = pos + p;
+          nvalid = p;
+        }
+      }
+    } else {
+      const uint64_t rem = lane_range(p, nvalid);
+      if (f_state == 1) {
+        const int e = wv::ffs64(below & rem);
+        int popen = 64;
+        if (f_pulses > NUM_PULSES_CMD) {
+          int need = T1_SAMPLES - f_n;
+          if (need < 0) need = 0;
+          popen = p + need;
+        }
+        if (popen < e && popen < nvalid) {  // gate_impl.cc:164-180
+          closedmask |= lane_range(p, popen + 1);
+          openmask |= 1ull << popen;
+          if (open_lane < 0) { open_lane = popen; open_type = f_type; }
+          else { open_lane2 = popen; open_type2 = f_type; }
+          f_open = 1;
+          f_n = 1;
+          f_pulses = 0;
+          p = popen + 1;
+        } else if (e < nvalid) {            // gate_impl.cc:148-152
+          closedmask |= lane_range(p, e + 1);
+          f_n = 0;
+          f_state = 0;
+          p = e + 1;
+        } else {
+          closedmask |= rem;
+          f_n += nvalid - p;
+          p = nvalid;
+        }
+      } else {
+        const int e = wv::ffs64(above & rem);
+        if (e < nvalid) {                   // gate_impl.cc:154-162
+          const int n_at = f_n + (e - p + 1);
+          f_state = 1;
+          f_pulses = (n_at > PW_HALF) ? (f_pulses + 1) : 0;
+          f_n = 0;
+          closedmask |= lane_range(p, e + 1);
+          p = e + 1;
+        } else {
+          closedmask |= rem;
+          f_n += nvalid - p;
+          p = nvalid;
+        }
+      }
+    }
+  }
+  g.f_n = f_n; g.f_state = f_state; g.f_pulses = f_pulses; g.f_open = f_open;
+  g.f_ung = f_ung; g.f_type = f_type;
+
+  // ring / carry updates only for the samples actually consumed (lanes < nvalid)
+  if (lane < nvalid) lds_win[wi] = amp;
+  g.avg_c = wv::readlane(avg, nvalid - 1);
+  g.win_index += nvalid;
+  if (g.win_index >= WIN_LEN) g.win_index -= WIN_LEN;
+
+  // --- dc offset tracking over closed samples (gate_impl.cc:141-143) -----------------------
+  const bool isclosed = ((closedmask >> lane) & 1ull) != 0;
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int rank = wv::popc64(closedmask & lt);
+  const int cnt = wv::popc64(closedmask);
+  if (isclosed) lds_tmp[rank] = yv;
+  wv::block_sync();
+  float2 old = make_float2(0.0f, 0.0f);
+  if (isclosed) {
+    if (rank < DC_LEN) {
+      int di = g.dc_index + rank;
+      if (di >= DC_LEN) di -= DC_LEN;
+      old = lds_dc[di];
+    } else {
+      old = lds_tmp[rank - DC_LEN];
+    }
+  }
+  const float tre = isclosed ? wv::fdiv(yv.x - old.x, DC_LEN_F) : 0.0f;
+  const float tim = isclosed ? wv::fdiv(yv.y - old.y, DC_LEN_F) : 0.0f;
+  wv::block_sync();
+  if (isclosed && rank >= cnt - DC_LEN) lds_dc[(g.dc_index + rank) % DC_LEN] = yv;
+  const float dcr = chain_add(g.dcr_c, tre, lane);
+  const float dci = chain_add(g.dci_c, tim, lane);
+  g.dcr_c = wv::readlane(dcr, 63);
+  g.dci_c = wv::readlane(dci, 63);
+  g.dc_index = (g.dc_index + cnt) % DC_LEN;
+
+  // --- record openings --------------------------------------------------------------------
+  for (int q = 0; q < 2; ++q) {
+    const int ol = (q == 0) ? open_lane : open_lane2;
+    if (ol < 0) continue;
+    const float odr = wv::readlane(dcr, ol), odi = wv::readlane(dci, ol);
+    const int wtype = (q == 0) ? open_type : open_type2;
+    const int wlen = wtype ? EPC_WIN : RN16_WIN;
+    const int start = pos + ol;
+    if (a.mode == 0 && start + wlen <= n) {  // only complete windows reach the decoder (:223,:291)
+      if (lane == 0 && g.win_seq < a.wmax) {
+        rfid_window w;
+        w.stream = s; w.seq = g.win_seq; w.start = start; w.type = wtype;
+        w.dc_re = odr; w.dc_im = odi;
+        a.wtab[(int64_t)s * a.wmax + g.win_seq] = w;
+        if (a.flat) {
+          const int slot = wv::atomic_add(a.flat_count, 1);
+          if (slot < a.flat_cap) a.flat[slot] = w;
+        }
+      }
+      g.n_complete++;
+    }
+    g.win_seq++;
+  }
+
+  // --- streaming mode: emit gated samples in[i] - dc_est (gate_impl.cc:176,187) ------------
+  if (a.mode == 1) {
+    const bool isopen = ((openmask >> lane) & 1ull) != 0;
+    const int orank = wv::popc64(openmask & lt);
+    if (isopen && g.written + orank < a.gated_cap)
+      a.gated[g.written + orank] = make_float2(yv.x - dcr, yv.y - dci);
+    g.written += wv::popc64(openmask);
+  }
+  wv::block_sync();
+}
+
+constexpr int GATE_PREFETCH = 4;  // steps (x64 samples) of matched-filter output held in registers
+
+RFID_KERNEL(64) void gate_scan_kernel(GateArgs a) {
+  RFID_SHARED float lds_win[WIN_LEN + 4];
+  RFID_SHARED float2 lds_dc[DC_LEN];
+  RFID_SHARED float2 lds_tmp[64];
+  const int lane = wv::lane_id();
+  const int s = (int)blockIdx.x;
+  GateState *st = a.state + s;
+  const float2 *ys = a.y + (int64_t)s * a.y_stride;
+  int64_t n64 = a.n_dec;
+  if (a.lens) {
+    int64_t r = a.lens[s];
+    if (r < 0) r = 0;
+    n64 = r / DECIM;
+    if (n64 > a.n_dec) n64 = a.n_dec;
+  }
+  const int n = (int)n64;
+
+  for (int j = lane; j < WIN_LEN; j += 64) lds_win[j] = st->win[j];
+  if (lane < DC_LEN) lds_dc[lane] = make_float2(st->dcr_re[lane], st->dcr_im[lane]);
+  GateRegs g;
+  g.avg_c = wv::uniform(st->avg_ampl);
+  g.dcr_c = wv::uniform(st->dc_re); g.dci_c = wv::uniform(st->dc_im);
+  g.f_n = wv::uniform(st->n_samples); g.f_state = wv::uniform(st->signal_state);
+  g.f_pulses = wv::uniform(st->num_pulses); g.f_open = wv::uniform(st->gate_open);
+  g.f_ung = wv::uniform(st->n_to_ungate); g.f_type = wv::uniform(st->wtype);
+  g.win_index = wv::uniform(st->win_index); g.dc_index = wv::uniform(st->dc_index);
+  g.win_seq = wv::uniform(st->win_seq);
+  if (g.f_ung == 0) g.f_ung = g.f_type ? EPC_WIN : RN16_WIN;  // fresh state: first window is an RN16
+  g.n_complete = 0; g.written = 0; g.consumed = n; g.stop = false;
+  wv::block_sync();
+
+  // register double buffer: while GATE_PREFETCH steps are processed, the loads of the next
+  // GATE_PREFETCH steps are already in flight (the scan itself is latency bound)
+  float2 cur[GATE_PREFETCH], nxt[GATE_PREFETCH];
+#pragma unroll
+  for (int u = 0; u < GATE_PREFETCH; ++u) {
+    const int i = 64 * u + lane;
+    cur[u] = (i < n) ? ys[i] : make_float2(0.0f, 0.0f);
+  }
+  for (int base = 0; base < n && !g.stop; base += 64 * GATE_PREFETCH) {
+#pragma unroll
+    for (int u = 0; u < GATE_PREFETCH; ++u) {
+      const int i = base + 64 * (GATE_PREFETCH + u) + lane;
+      nxt[u] = (i < n) ? ys[i] : make_float2(0.0f, 0.0f);
+    }
+#pragma unroll
+    for (int u = 0; u < GATE_PREFETCH; ++u) {
+      const int pos = base + 64 * u;
+      if (pos < n && !g.stop) gate_step(a, g, cur[u], pos, n, s, lane, lds_win, lds_dc, lds_tmp);
+    }
+#pragma unroll
+    for (int u = 0; u < GATE_PREFETCH; ++u) cur[u] = nxt[u];
+  }
+
+  // --- write state back -------------------------------------------------------------------
+  for (int j = lane; j < WIN_LEN; j += 64) st->win[j] = lds_win[j];
+  if (lane < DC_LEN) { st->dcr_re[lane] = lds_dc[lane].x; st->dcr_im[lane] = lds_dc[lane].y; }
+  if (lane == 0) {
+    st->avg_ampl = g.avg_c; st->dc_re = g.dcr_c; st->dc_im = g.dci_c;
+    st->n_samples = g.f_n; st->signal_state = g.f_state; st->num_pulses = g.f_pulses;
+    st->gate_open = g.f_open; st->n_to_ungate = g.f_ung; st->wtype = g.f_type;
+    st->win_index = g.win_index; st->dc_index = g.dc_index; st->win_seq = g.win_seq;
+    if (a.mode == 0) {
+      a.wcount[s] = (g.n_complete < a.wmax) ? g.n_complete : a.wmax;
+    } else {
+      a.io[0] = g.consumed;
+      a.io[1] = g.written;
+    }
+  }
+}
+
+// =========================================================================================
+// 3. tag_decoder: one wavefront per window, persistent over the compact window list.
+//    The window (250 or 1370 complex samples, 2 000 / 10 960 B) is read from HBM exactly
+//    once with coalesced loads, DC-removed on the fly and staged in LDS together with its
+//    squared magnitude; every later access (preamble correlation, 20x256 energy gathers,
+//    2x128 half-bit gathers) hits LDS.  Reductions are wave shuffles.
+// =========================================================================================
+struct DecodeArgs {
+  const float2 *y;
+  int64_t y_stride;
+  const rfid_window *flat;
+  const int *flat_count;   // device counter; the kernel clamps it to flat_cap
+  int flat_cap;
+  rfid_decode_result *res;  // [n_streams][wmax], indexed stream*wmax + seq
+  rfid_scores *scores;      // same indexing, nullable
+  int wmax;
+  float t_cand[N_TCAND];    // half-period candidates, computed on the host exactly as
+                            // tag_decoder_impl.cc:151-152,162
+};
+
+// CRC-16/CCITT (init 0xFFFF, poly 0x1021, MSB first, complemented) is GF(2)-linear:
+// register = K ^ XOR_{set message bits j} C[j].  C and K are compile-time tables.
+struct Crc16Table {
+  unsigned short c[112];
+  unsigned short k;
+  constexpr Crc16Table() : c{}, k(0) {
+    for (int j = 0; j < 112; ++j) {
+      unsigned reg = 0;
+      for (int i = 0; i < 112; ++i) {
+        const unsigned bit = (i == j) ? 1u : 0u;
+        const unsigned msb = (reg >> 15) & 1u;
+        reg = (reg << 1) & 0xFFFFu;
+        if (msb ^ bit) reg ^= 0x1021u;
+      }
+      c[j] = (unsigned short)reg;
+    }
+    unsigned reg = 0xFFFFu;
+    for (int i = 0; i < 112; ++i) {
+      const unsigned msb = (reg >> 15) & 1u;
+      reg = (reg << 1) & 0xFFFFu;
+      if (msb) reg ^= 0x1021u;
+    }
+    k = (unsigned short)reg;
+  }
+};
+__device__ const Crc16Table g_crc16 = Crc16Table();
+
+template <int LEN>
+RFID_DEVICE void stage_window(const float2 *src, float dcr, float dci, float2 *s, float *m2,
+                              int lane) {
+  constexpr int IT = (LEN + 63) / 64;
+  float2 v[IT];
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const int j = lane + 64 * k;
+    v[k] = (j < LEN) ? src[j] : make_float2(0.0f, 0.0f);
+  }
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const int j = lane + 64 * k;
+    if (j < LEN) {
+      // gate output in[i] - dc_est and its std::norm (gate_impl.cc:175-176,186-187)
+      const float re = v[k].x - dcr, im = v[k].y - dci;
+      s[j] = make_float2(re, im);
+      m2[j] = re * re + im * im;
+    }
+  }
+}
+
+// first-maximum argmax over lanes [0, nl): returns lane index; `strict_from_zero` reproduces
+// tag_sync's  `if (corr > max)` scan that starts from max = 0 (index 0 when nothing exceeds 0);
+// otherwise std::max_element semantics.
+RFID_DEVICE int wave_first_argmax(float v, int nl, int lane, bool strict_from_zero) {
+  float key = (lane < nl && v == v) ? v : -1.0f;  // scores are >= 0; NaN never wins
+  float m = key;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float o = wv::shfl_xor(m, off);
+    m = (o > m) ? o : m;
+  }
+  if (strict_from_zero && !(m > 0.0f)) return 0;
+  const uint64_t hit = wv::ballot(lane < nl && key == m);
+  return wv::ffs64(hit) & 63;
+}
+
+RFID_KERNEL(64) void decode_windows_kernel(DecodeArgs a) {
+  RFID_SHARED float2 s[EPC_WIN + 2];
+  RFID_SHARED float m2[EPC_WIN + 2];
+  const int lane = wv::lane_id();
+  int total = wv::uniform(*a.flat_count);
+  if (total > a.flat_cap) total = a.flat_cap;
+
+  for (int w = (int)blockIdx.x; w < total; w += (int)gridDim.x) {
+    const rfid_window wd = a.flat[w];
+    const int type = wv::uniform(wd.type);
+    const float dcr = wv::uniform(wd.dc_re), dci = wv::uniform(wd.dc_im);
+    const float2 *src = a.y + (int64_t)wv::uniform(wd.stream) * a.y_stride + wv::uniform(wd.start);
+    if (type == RFID_DECODE_EPC) stage_window<EPC_WIN>(src, dcr, dci, s, m2, lane);
+    else stage_window<RN16_WIN>(src, dcr, dci, s, m2, lane);
+    wv::block_sync();
+
+    // ---- tag_sync (tag_decoder_impl.cc:78-109): 15 offsets x 6 non-zero preamble taps -----
+    float cre = 0.0f, cim = 0.0f;
+    if (lane < N_SYNC) {
+      const int taps[6] = {0, 5, 15, 30, 50, 55};  // j*5 for TAG_PREAMBLE[j] == 1
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const float2 v = s[lane + taps[k]];
+        cre = cre + v.x;
+        cim = cim + v.y;
+      }
+    }
+    const float corr = cre * cre + cim * cim;
+    const int m_idx = wave_first_argmax(corr, N_SYNC, lane, true);
+    const float hre = wv::fdiv(wv::shfl(cre, m_idx), 6.0f);  // :103
+    const float him = wv::fdiv(wv::shfl(cim, m_idx), 6.0f);
+    const int index = m_idx + 65;                             // :107  m + 6*10 + 5
+    const float findex = (float)index;
+    const float nhim = -him;                                  // conj(h_est)
+
+    rfid_decode_result r;
+    r.type = type; r.index = index; r.h_re = hre; r.h_im = him; r.T = 0.0f;
+    r.bits[0] = r.bits[1] = r.bits[2] = r.bits[3] = 0u;
+    r.crc_ok = 0; r.tag_id = -1;
+    float energy = 0.0f;
+
+    if (type == RFID_DECODE_RN16) {
+      // 32 half-bit samples at index + 5q (:237-253), 16 decisions (:114-142)
+      bool cur = false;
+      if (lane < 16) {
+        const float2 p = s[index + 10 * lane], q = s[index + 10 * lane + 5];
+        const float res = (p.x - q.x) * hre - (p.y - q.y) * nhim;
+        cur = res > 0.0f;
+      }
+      const uint64_t c = wv::ballot(cur) & 0xFFFFull;
+      const uint64_t bits = (c ^ ((c << 1) | 1ull)) & 0xFFFFull;  // bit = (cur != prev), prev0 = +1
+      r.bits[0] = (uint32_t)bits;
+      r.n_bits = 16;
+    } else {
+      // ---- half-period search (:150-166): lane t sums 256 squared magnitudes in order ----
+      if (lane < N_TCAND) {
+        const float Tt = a.t_cand[lane];
+#pragma unroll 8
+        for (int i = 0; i < 256; ++i) {
+          const float pos = (float)i * Tt + findex;
+          energy = energy + m2[wv::f2i(pos)];
+        }
+      }
+      const int t_idx = wave_first_argmax(energy, N_TCAND, lane, false);
+      const float T = a.t_cand[t_idx];
+      r.T = T;
+      // ---- 128 bit decisions (:171-190), lanes take j and j+64 ---------------------------
+      const float T2 = 2.0f * T;
+      bool cur0, cur1;
+      {
+        const int j = lane;
+        const float2 p = s[wv::f2i((float)j * T2 + findex)];
+        const float2 q = s[wv::f2i(((float)(j * 2) * T + T) + findex)];
+        cur0 = ((p.x - q.x) * hre - (p.y - q.y) * nhim) > 0.0f;
+      }
+      {
+        const int j = lane + 64;
+        const float2 p = s[wv::f2i((float)j * T2 + findex)];
+        const float2 q = s[wv::f2i(((float)(j * 2) * T + T) + findex)];
+        cur1 = ((p.x - q.x) * hre - (p.y - q.y) * nhim) > 0.0f;
+      }
+      const uint64_t c0 = wv::ballot(cur0), c1 = wv::ballot(cur1);
+      const uint64_t b0 = c0 ^ ((c0 << 1) | 1ull);
+      const uint64_t b1 = c1 ^ ((c1 << 1) | (c0 >> 63));
+      r.bits[0] = (uint32_t)b0; r.bits[1] = (uint32_t)(b0 >> 32);
+      r.bits[2] = (uint32_t)b1; r.bits[3] = (uint32_t)(b1 >> 32);
+      r.n_bits = 128;
+      // ---- CRC-16 over frame bits 0..111 vs bits 112..127 (:401-445) ---------------------
+      unsigned x = 0;
+      if ((b0 >> lane) & 1ull) x ^= g_crc16.c[lane];
+      if (lane < 48 && ((b1 >> lane) & 1ull)) x ^= g_crc16.c[lane + 64];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) x ^= wv::shfl_xor(x, off);
+      const unsigned crc = (~(x ^ g_crc16.k)) & 0xFFFFu;
+      unsigned rcvd = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) rcvd |= (unsigned)((b1 >> (48 + i)) & 1ull) << (15 - i);
+      r.crc_ok = (crc == rcvd) ? 1 : 0;
+      if (r.crc_ok) {
+        int id = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) id |= (int)((b1 >> (40 + i)) & 1ull) << (7 - i);  // bits 104..111
+        r.tag_id = id;
+      }
+    }
+
+    const int64_t slot = (int64_t)wv::uniform(wd.stream) * a.wmax + wv::uniform(wd.seq);
+    if (lane == 0) a.res[slot] = r;
+    if (a.scores) {
+      rfid_scores *sc = a.scores + slot;
+      if (lane < N_SYNC) sc->corr[lane] = corr;
+      if (lane < N_TCAND) sc->energy[lane] = energy;
+    }
+    wv::block_sync();
+  }
+}
+
+// =========================================================================================
+// 4. per-trace statistics: replays the decoded windows of each trace in order through the
+//    reader/decoder bookkeeping, including the TERMINATED cut-off.  One lane per trace.
+// =========================================================================================
+struct StatsArgs {
+  const rfid_decode_result *res;  // [n_streams][wmax]
+  const int *wcount;              // [n_streams]
+  int wmax;
+  int n_streams;
+  int max_slot_number;            // 2^FIXED_Q (global_vars.cc:47)
+  int max_num_queries;
+  int number_unique_tags;
+  rfid_stream_stats *out;         // [n_streams]
+};
+
+RFID_KERNEL(64) void stream_stats_kernel(StatsArgs a) {
+  const int s = (int)(blockIdx.x * 64 + threadIdx.x);
+  if (s >= a.n_streams) return;
+  rfid_stream_stats *o = a.out + s;
+  for (int i = 0; i < 256; ++i) o->tag_reads[i] = 0;
+  int n_queries = 1;  // START -> SEND_QUERY before the first sample (reader_impl.cc:218-260)
+  int round = 1, slot = 1, n_ok = 0, n_unique = 0, status = RFID_RUNNING, used = 0;
+  const int nw = a.wcount[s];
+  const rfid_decode_result *rs = a.res + (int64_t)s * a.wmax;
+  for (int k = 0; k < nw; ++k) {
+    // gate_impl.cc:101-109, evaluated at the gate call that follows every window
+    if (n_queries > a.max_num_queries || n_unique > a.number_unique_tags) {
+      status = RFID_TERMINATED;
+      break;
+    }
+    const rfid_decode_result r = rs[k];
+    used++;
+    if (r.type == RFID_DECODE_EPC) {
+      slot++;                                          // tag_decoder_impl.cc:295
+      const bool roll = slot > a.max_slot_number;      // :330-343 / :369-383
+      if (roll) { slot = 1; round++; }
+      if (r.crc_ok) {
+        n_ok++;                                        // :346
+        const int id = r.tag_id & 255;
+        if (o->tag_reads[id] == 0) n_unique++;
+        o->tag_reads[id]++;                            // :356-364
+      }
+      n_queries++;                                     // reader_impl.cc:259 / :335
+    }
+  }
+  if (status == RFID_RUNNING &&
+      (n_queries > a.max_num_queries || n_unique > a.number_unique_tags))
+    status = RFID_TERMINATED;
+  o->n_queries_sent = n_queries;
+  o->cur_inventory_round = round;
+  o->cur_slot_number = slot;
+  o->n_epc_correct = n_ok;
+  o->n_unique_tags = n_unique;
+  o->n_windows = nw;
+  o->n_windows_used = used;
+  o->status = status;
+}
+
+// =========================================================================================
+// 5. self-test of the primitives the exactness argument rests on
+// =========================================================================================
+struct SelfTestArgs {
+  const float *x;    // [64]
+  const float *num;  // [64]
+  const float *den;  // [64]
+  float carry;
+  float *chain_out;  // [64]
+  float *div_out;    // [64]
+  float *hyp_out;    // [64] hypot(num, den)
+  float *shr_out;    // [64]
+};
+
+RFID_KERNEL(64) void selftest_kernel(SelfTestArgs a) {
+  const int lane = wv::lane_id();
+  a.chain_out[lane] = chain_add(a.carry, a.x[lane], lane);
+  a.div_out[lane] = wv::fdiv(a.num[lane], a.den[lane]);
+  a.hyp_out[lane] = wv::hypot_f(a.num[lane], a.den[lane]);
+  a.shr_out[lane] = wv::shr1(a.x[lane]);
+}
+
+}  // namespace rfidk

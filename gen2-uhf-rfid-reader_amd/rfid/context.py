@@ -1,0 +1,188 @@
+"""rfid.Context -- one RX stream / one batch workspace on one MI355X.
+
+Thin object wrapper over the C-ABI (include/rfid_mi355x.h).  All sample arithmetic runs in
+the HIP kernels behind it.  Device buffers are passed as raw pointers; torch (or any other
+allocator) is only used by callers to own HBM.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _capi as capi
+
+
+def _c64(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.complex64)
+    return a
+
+
+class Context:
+    def __init__(self, device: int = 0, **params):
+        self._lib = capi.load()
+        self.params = capi.default_params(**params)
+        h = C.c_void_p()
+        capi.check(self._lib.rfid_ctx_create(C.byref(self.params), int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self._planned: Optional[Tuple[int, int]] = None
+
+    # -- lifetime ------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.rfid_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _chk(self, status: int) -> None:
+        capi.check(status, self._h)
+
+    def reset(self) -> None:
+        self._chk(self._lib.rfid_ctx_reset(self._h))
+
+    def selftest(self) -> int:
+        n = C.c_int(0)
+        self._chk(self._lib.rfid_selftest(self._h, C.byref(n)))
+        return n.value
+
+    @property
+    def stream_handle(self) -> int:
+        return int(self._lib.rfid_ctx_stream(self._h) or 0)
+
+    # -- READER_STATE ----------------------------------------------------------------------
+    def state(self) -> capi.ReaderState:
+        st = capi.ReaderState()
+        self._chk(self._lib.rfid_get_state(self._h, C.byref(st)))
+        return st
+
+    def stats(self) -> dict:
+        s = self.state()
+        return dict(n_queries_sent=s.n_queries_sent, cur_inventory_round=s.cur_inventory_round,
+                    cur_slot_number=s.cur_slot_number, n_epc_correct=s.n_epc_correct,
+                    n_unique_tags=s.n_unique_tags, status=s.status,
+                    tag_reads={i: s.tag_reads[i] for i in range(256) if s.tag_reads[i]})
+
+    def print_results(self) -> str:
+        buf = C.create_string_buffer(1 << 15)
+        n = C.c_int(0)
+        self._chk(self._lib.rfid_print_results(self._h, buf, len(buf), C.byref(n)))
+        return buf.raw[: n.value].decode()
+
+    # -- (1) streaming, host buffers ---------------------------------------------------------
+    def mf_work(self, x) -> np.ndarray:
+        x = _c64(x)
+        out = np.empty(len(x) // 5 + 2, dtype=np.complex64)
+        n = C.c_int(0)
+        self._chk(self._lib.rfid_mf_work(self._h, x.ctypes.data, len(x), out.ctypes.data, len(out), C.byref(n)))
+        return out[: n.value].copy()
+
+    def gate_work(self, x) -> Tuple[int, np.ndarray]:
+        """-> (consumed, gated samples), as gate_impl::general_work's consume_each()/output."""
+        x = _c64(x)
+        out = np.empty(max(len(x), 1), dtype=np.complex64)
+        cons, wr = C.c_int(0), C.c_int(0)
+        self._chk(self._lib.rfid_gate_work(self._h, x.ctypes.data, len(x), out.ctypes.data, len(out),
+                                           C.byref(cons), C.byref(wr)))
+        return cons.value, out[: wr.value].copy()
+
+    def decoder_work(self, x):
+        """-> (consumed, port-0 floats, result record or None, scores record or None)."""
+        x = _c64(x)
+        bits = np.zeros(16, dtype=np.float32)
+        cons, prod = C.c_int(0), C.c_int(0)
+        res = np.zeros(1, dtype=capi.RESULT_DTYPE)
+        sc = np.zeros(1, dtype=capi.SCORES_DTYPE)
+        self._chk(self._lib.rfid_decoder_work(self._h, x.ctypes.data, len(x), bits.ctypes.data, len(bits),
+                                              C.byref(cons), C.byref(prod), res.ctypes.data, sc.ctypes.data))
+        if cons.value == 0:
+            return 0, bits[:0], None, None
+        return cons.value, bits[: prod.value].copy(), res[0], sc[0]
+
+    def reader_work(self, n_in: int) -> int:
+        cons = C.c_int(0)
+        self._chk(self._lib.rfid_reader_work(self._h, int(n_in), C.byref(cons)))
+        return cons.value
+
+    # -- (2) batched offline, device buffers ---------------------------------------------------
+    def batch_plan(self, n_streams: int, max_raw: int) -> None:
+        self._chk(self._lib.rfid_batch_plan(self._h, int(n_streams), int(max_raw)))
+        self._planned = (int(n_streams), int(max_raw))
+
+    def batch_process_ptr(self, d_raw: int, raw_stride: int, n_raw: int, d_lens: int = 0,
+                          want_scores: bool = False) -> None:
+        """Asynchronous mf->gate->decode->stats over [n_streams][raw_stride] complex64 in HBM."""
+        self._chk(self._lib.rfid_batch_process(self._h, C.c_void_p(d_raw), int(raw_stride), int(n_raw),
+                                               C.c_void_p(d_lens) if d_lens else None, int(bool(want_scores))))
+
+    def batch_stage(self, which: str, *args) -> None:
+        fn = {"mf": self._lib.rfid_batch_mf, "gate": self._lib.rfid_batch_gate,
+              "decode": self._lib.rfid_batch_decode, "stats": self._lib.rfid_batch_stats}[which]
+        if which == "mf":
+            d_raw, raw_stride, n_raw, d_lens = args
+            self._chk(fn(self._h, C.c_void_p(d_raw), int(raw_stride), int(n_raw),
+                         C.c_void_p(d_lens) if d_lens else None))
+        elif which == "decode":
+            self._chk(fn(self._h, int(bool(args[0])) if args else 0))
+        else:
+            self._chk(fn(self._h))
+
+    def batch_sync(self) -> None:
+        self._chk(self._lib.rfid_batch_sync(self._h))
+
+    def batch_timing(self) -> dict:
+        t = capi.BatchTiming()
+        self._chk(self._lib.rfid_batch_timing_get(self._h, C.byref(t)))
+        return dict(mf_ms=t.mf_ms, gate_ms=t.gate_ms, decode_ms=t.decode_ms, stats_ms=t.stats_ms,
+                    total_ms=t.total_ms)
+
+    def batch_stats(self) -> np.ndarray:
+        n = self._planned[0]
+        out = np.zeros(n, dtype=capi.STATS_DTYPE)
+        self._chk(self._lib.rfid_batch_get_stats(self._h, out.ctypes.data, n))
+        return out
+
+    def batch_windows(self, want_scores: bool = False):
+        """-> (windows, results, scores|None) ordered by (stream, seq)."""
+        n = C.c_int64(0)
+        self._chk(self._lib.rfid_batch_get_windows(self._h, None, None, None, 0, C.byref(n)))
+        k = n.value
+        w = np.zeros(k, dtype=capi.WINDOW_DTYPE)
+        r = np.zeros(k, dtype=capi.RESULT_DTYPE)
+        s = np.zeros(k, dtype=capi.SCORES_DTYPE) if want_scores else None
+        if k:
+            self._chk(self._lib.rfid_batch_get_windows(self._h, w.ctypes.data, r.ctypes.data,
+                                                       s.ctypes.data if s is not None else None, k, C.byref(n)))
+        return w, r, s
+
+    def batch_mf_output(self, stream: int) -> np.ndarray:
+        cap = self._planned[1] // 5 + 1
+        out = np.empty(cap, dtype=np.complex64)
+        n = C.c_int64(0)
+        self._chk(self._lib.rfid_batch_get_mf(self._h, int(stream), out.ctypes.data, cap, C.byref(n)))
+        return out[: n.value].copy()
+
+    def batch_device_ptrs(self) -> dict:
+        y, st, fc = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        stride = C.c_int64(0)
+        self._chk(self._lib.rfid_batch_device_ptrs(self._h, C.byref(y), C.byref(stride), C.byref(st), C.byref(fc)))
+        return dict(mf_out=y.value, mf_stride=stride.value, stats=st.value, flat_count=fc.value)
+
+
+def unpack_bits(words: np.ndarray, n_bits: int) -> np.ndarray:
+    """rfid_decode_result.bits -> array of n_bits 0/1 values (frame order)."""
+    words = np.asarray(words, dtype=np.uint32)
+    j = np.arange(n_bits)
+    return ((words[j >> 5] >> (j & 31)) & 1).astype(np.uint8)

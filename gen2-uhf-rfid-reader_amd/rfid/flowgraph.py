@@ -1,0 +1,85 @@
+"""Offline flowgraph: the DEBUG=True topology of apps/reader.py:101-112
+(file_source -> matched_filter -> gate -> tag_decoder -> reader), driven by a
+single-threaded scheduler (the README's GR_SCHEDULER=STS mode, README.md:40).
+
+Every block call goes through the C-ABI into the HIP kernels.  This is the drop-in,
+call-per-buffer form; bulk offline decoding uses rfid.batch instead.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from . import _capi as capi
+from . import blocks
+
+
+class reader_top_block:
+    def __init__(self, source_path: Optional[str] = None, samples: Optional[np.ndarray] = None,
+                 device: int = 0, chunk: int = 8192, **params):
+        # variables of apps/reader.py:52-65
+        self.dac_rate = 1e6
+        self.adc_rate = 100e6 / 50
+        self.decim = 5
+        self.num_taps = [1] * 25
+        self.chunk = int(chunk)
+        if samples is None:
+            if source_path is None:
+                raise ValueError("need source_path (interleaved float32 I,Q file) or samples")
+            samples = np.fromfile(source_path, dtype=np.complex64)   # blocks.file_source, reader.py:102
+        self.samples = np.ascontiguousarray(samples, dtype=np.complex64)
+        # construction order of apps/reader.py:75-78 (gate first: it owns the state)
+        self.gate = blocks.gate(int(self.adc_rate / self.decim), device=device, **params)
+        ctx = self.gate.ctx
+        self.matched_filter = blocks.matched_filter(self.decim, self.num_taps, ctx=ctx)
+        self.tag_decoder = blocks.tag_decoder(int(self.adc_rate / self.decim), ctx=ctx)
+        self.reader = blocks.reader(int(self.adc_rate / self.decim), int(self.dac_rate), ctx=ctx)
+        self.ctx = ctx
+        self.decoded = []        # (result, scores) per decoded window, for inspection
+
+    def _reader_until_idle(self, q: int) -> None:
+        for _ in range(8):
+            before = self.ctx.state().gen2_logic_status
+            if before == capi.IDLE:
+                break
+            self.reader.general_work(q)
+            q = 0
+            if self.ctx.state().gen2_logic_status == before:
+                break
+
+    def run(self) -> None:
+        self._reader_until_idle(0)                    # START -> SEND_QUERY -> IDLE
+        dq = np.zeros(0, dtype=np.complex64)          # decoder input buffer
+        gq = np.zeros(0, dtype=np.complex64)          # gate input buffer
+        pos = 0
+        n = len(self.samples)
+        while pos < n or len(gq):
+            if pos < n:
+                blk = self.samples[pos:pos + self.chunk * self.decim]
+                pos += len(blk)
+                y = self.matched_filter.work(blk)
+                gq = np.concatenate([gq, y]) if len(gq) else y
+            while len(gq):
+                take = gq[: self.chunk]
+                consumed, out = self.gate.general_work(take)
+                gq = gq[consumed:]
+                if len(out):
+                    dq = np.concatenate([dq, out]) if len(dq) else out
+                while True:
+                    dcons, bits, res, sc = self.tag_decoder.general_work(dq)
+                    if dcons == 0:
+                        break
+                    self.decoded.append((res, sc))
+                    dq = dq[dcons:]
+                    self._reader_until_idle(len(bits))
+                if consumed == 0:
+                    break
+            if pos >= n and not len(gq):
+                break
+
+    def start(self) -> None:          # gr.top_block.start() analogue (apps/reader.py:123)
+        self.run()
+
+    def stop(self) -> None:
+        pass

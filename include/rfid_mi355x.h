@@ -1,0 +1,205 @@
+/*
+ * rfid_mi355x.h -- C-ABI of the MI355X-native Gen2 RFID receive path
+ *                  (matched filter -> gate -> tag_decoder), librfid_mi355x.so.
+ *
+ * This is the drop-in boundary for the hot path of nkargas/Gen2-UHF-RFID-Reader.
+ * Every entry point names the reference interface it replaces (paths relative to
+ * /root/reference/gr-rfid/).  Plain C: pointers and sizes only, no C++/torch types,
+ * no exceptions; every function returns an rfid_status (0 = ok, <0 = error) and never
+ * aborts.  There is NO CPU fallback: if no gfx950 device / HIP runtime is usable,
+ * rfid_ctx_create fails with RFID_ERR_NO_DEVICE.
+ *
+ * Sample format everywhere: interleaved little-endian float32 I,Q (= gr_complex =
+ * the reference's file_source format, misc/code/plot_signal.m:5-9).
+ *
+ * Two families of entry points:
+ *   (1) per-block streaming calls on HOST buffers -- one per reference work():
+ *         rfid_mf_work       <- filter.fir_filter_ccc(5,[1]*25)      apps/reader.py:65,75
+ *         rfid_gate_work     <- gate_impl::general_work               lib/gate_impl.cc:85-200
+ *         rfid_decoder_work  <- tag_decoder_impl::general_work        lib/tag_decoder_impl.cc:196-397
+ *         rfid_reader_work   <- reader_impl::general_work (state transitions only)
+ *                                                                     lib/reader_impl.cc:200-380
+ *   (2) batched offline calls on DEVICE buffers (many independent traces per launch):
+ *         rfid_batch_mf / rfid_batch_gate / rfid_batch_decode / rfid_batch_stats and the
+ *         fused driver rfid_batch_process -- the same arithmetic, all windows of all
+ *         traces decoded in one launch.
+ *
+ * Threading: one rfid_ctx = one GPU + one HIP stream.  Calls on a ctx must be
+ * serialised by the caller; distinct contexts are independent (multi-GPU = one ctx,
+ * one process, per device; no collective).
+ */
+#ifndef RFID_MI355X_H
+#define RFID_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RFID_API __attribute__((visibility("default")))
+
+typedef enum rfid_status {
+  RFID_OK = 0,
+  RFID_ERR_INVALID = -1,      /* bad argument */
+  RFID_ERR_NO_DEVICE = -2,    /* no usable gfx950 device / HIP runtime */
+  RFID_ERR_HIP = -3,          /* a HIP call failed: see rfid_last_error() */
+  RFID_ERR_UNSUPPORTED = -4,  /* parameter combination the kernels are not built for */
+  RFID_ERR_CAPACITY = -5,     /* caller buffer or planned workspace too small */
+  RFID_ERR_STATE = -6         /* call not valid in the current state (e.g. no plan) */
+} rfid_status;
+
+/* gr_complex */
+typedef struct rfid_cf32 { float re, im; } rfid_cf32;
+
+/* enums of include/rfid/global_vars.h:31-34, same numeric values */
+enum { RFID_RUNNING = 0, RFID_TERMINATED = 1 };
+enum { RFID_SEND_QUERY = 0, RFID_SEND_ACK, RFID_SEND_QUERY_REP, RFID_IDLE, RFID_SEND_CW, RFID_START,
+       RFID_SEND_QUERY_ADJUST, RFID_SEND_NAK_QR, RFID_SEND_NAK_Q, RFID_POWER_DOWN };
+enum { RFID_GATE_OPEN = 0, RFID_GATE_CLOSED, RFID_GATE_SEEK_RN16, RFID_GATE_SEEK_EPC };
+enum { RFID_DECODE_RN16 = 0, RFID_DECODE_EPC = 1 };
+
+/* Construction parameters.  Replaces the ctor arguments gate::make(int sample_rate)
+ * (include/rfid/gate.h:51), tag_decoder::make(int sample_rate) (include/rfid/tag_decoder.h:48),
+ * the flowgraph's decim / num_taps (apps/reader.py:54,65) and the compile-time constants
+ * FIXED_Q, MAX_NUM_QUERIES, NUMBER_UNIQUE_TAGS (include/rfid/global_vars.h:72,76,100). */
+typedef struct rfid_params {
+  int32_t sample_rate;        /* rate after decimation; only 400000 is supported */
+  int32_t decim;              /* 5  */
+  int32_t n_taps;             /* 25, all-ones */
+  int32_t fixed_q;            /* 0..15 */
+  int32_t max_num_queries;    /* 1000 */
+  int32_t number_unique_tags; /* 100 */
+} rfid_params;
+
+/* READER_STATE / READER_STATS view (include/rfid/global_vars.h:36-67) */
+typedef struct rfid_reader_state {
+  int32_t status, gen2_logic_status, gate_status, decoder_status;
+  int32_t n_samples_to_ungate;
+  int32_t n_queries_sent, cur_inventory_round, cur_slot_number, max_slot_number, n_epc_correct;
+  int32_t n_unique_tags;
+  int32_t tag_reads[256];     /* std::map<int,int> tag_reads, key = EPC bits 104..111 */
+} rfid_reader_state;
+
+/* one gate opening, produced by the batched gate scan */
+typedef struct rfid_window {
+  int32_t stream;   /* trace index in the batch */
+  int32_t seq;      /* 0,1,2,... per trace; type = seq & 1 */
+  int32_t start;    /* index (400 ksps domain) of the first gated sample */
+  int32_t type;     /* RFID_DECODE_RN16 / RFID_DECODE_EPC */
+  float dc_re, dc_im; /* gate_impl::dc_est at the opening (lib/gate_impl.cc:141,176) */
+} rfid_window;
+
+/* what tag_decoder computes for one window */
+typedef struct rfid_decode_result {
+  int32_t type;       /* RFID_DECODE_RN16 / RFID_DECODE_EPC */
+  int32_t index;      /* value returned by tag_sync (lib/tag_decoder_impl.cc:107-108) */
+  float h_re, h_im;   /* h_est (:103) */
+  float T;            /* T_global (:166-169); 0 for RN16 */
+  uint32_t bits[4];   /* decoded bits, bit j of the frame at bits[j>>5] bit (j&31) */
+  int32_t n_bits;     /* 16 or 128 */
+  int32_t crc_ok;     /* EPC: 1 if check_crc()==1 (:401-445), else 0 */
+  int32_t tag_id;     /* EPC bits 104..111, MSB first (:348-352); -1 unless crc_ok */
+} rfid_decode_result;
+
+/* optional per-window scores for tolerance checks (correlation / energy values) */
+typedef struct rfid_scores {
+  float corr[15];     /* std::norm(corr2) per candidate offset (lib/tag_decoder_impl.cc:85-99) */
+  float energy[20];   /* per half-period candidate (:157-164); zeros for RN16 */
+  float pad_;
+} rfid_scores;
+
+/* per-trace statistics after the decode of a batch (READER_STATS per trace) */
+typedef struct rfid_stream_stats {
+  int32_t n_queries_sent, cur_inventory_round, cur_slot_number, n_epc_correct, n_unique_tags;
+  int32_t n_windows;       /* complete windows the gate produced */
+  int32_t n_windows_used;  /* windows consumed before TERMINATED (lib/gate_impl.cc:101-109) */
+  int32_t status;          /* RFID_RUNNING / RFID_TERMINATED */
+  int32_t tag_reads[256];
+} rfid_stream_stats;
+
+/* timing of the last rfid_batch_* pass, from HIP events on the ctx stream */
+typedef struct rfid_batch_timing {
+  float mf_ms, gate_ms, decode_ms, stats_ms, total_ms;
+} rfid_batch_timing;
+
+typedef struct rfid_ctx rfid_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------ */
+RFID_API int rfid_params_default(rfid_params *p);
+/* device = HIP device ordinal.  Fails (RFID_ERR_NO_DEVICE) when it is not a gfx950 GPU. */
+RFID_API int rfid_ctx_create(const rfid_params *p, int device, rfid_ctx **out);
+RFID_API int rfid_ctx_destroy(rfid_ctx *ctx);
+/* resets gate/decoder/reader state as the block constructors + initialize_reader_state()
+ * do (lib/gate_impl.cc:41-70, lib/global_vars.cc:34-54) */
+RFID_API int rfid_ctx_reset(rfid_ctx *ctx);
+RFID_API const char *rfid_strerror(int status);
+RFID_API const char *rfid_last_error(const rfid_ctx *ctx);
+RFID_API const char *rfid_version(void);
+/* device self-test of the wave-level primitives the kernels rely on (DPP wave shift,
+ * IEEE division, double sqrt).  0 = all good, >0 = number of failing checks. */
+RFID_API int rfid_selftest(rfid_ctx *ctx, int *n_failed);
+
+/* ---- (1) streaming, host buffers: one call per reference work() ----------------------- */
+/* fir_filter_ccc(5,[1]*25): consumes all n_in samples, keeps the 24-sample history and the
+ * decimation phase inside ctx, writes floor-ish n_in/5 outputs (exactly the outputs whose
+ * window ends inside this call).  y[n] = sum_{k=0..24} x[5n-24+k], k ascending. */
+RFID_API int rfid_mf_work(rfid_ctx *ctx, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap,
+                          int *n_produced);
+/* gate_impl::general_work: scans in[0..n_in), writes gated, DC-removed samples to out and
+ * stops right after a window closes (consume_each(i+1), lib/gate_impl.cc:189-194).
+ * *n_consumed / *n_written are the values the block passes to consume_each() / returns. */
+RFID_API int rfid_gate_work(rfid_ctx *ctx, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap,
+                            int *n_consumed, int *n_written);
+/* tag_decoder_impl::general_work: acts only when n_in >= n_samples_to_ungate.  RN16: writes 16
+ * floats (0.0/1.0) to out_bits (port 0) and sets gen2_logic_status = SEND_ACK.  EPC: decodes,
+ * checks CRC, updates the statistics.  *n_consumed as consume_each(); *n_produced = items
+ * produced on port 0.  `res`/`scores` (nullable) receive the per-window details. */
+RFID_API int rfid_decoder_work(rfid_ctx *ctx, const rfid_cf32 *in, int n_in, float *out_bits,
+                               int out_cap, int *n_consumed, int *n_produced,
+                               rfid_decode_result *res, rfid_scores *scores);
+/* reader_impl::general_work, state transitions only (gate_status / decoder_status /
+ * n_queries_sent); the TX waveform synthesis is out of scope.  n_in = float items
+ * available on the reader's input (16 after an RN16). */
+RFID_API int rfid_reader_work(rfid_ctx *ctx, int n_in, int *n_consumed);
+RFID_API int rfid_get_state(const rfid_ctx *ctx, rfid_reader_state *out);
+/* reader_impl::print_results text (lib/reader_impl.cc:173-192) */
+RFID_API int rfid_print_results(const rfid_ctx *ctx, char *buf, int cap, int *len);
+
+/* ---- (2) batched offline, device buffers ---------------------------------------------- */
+/* Plans workspace for n_streams traces of up to max_raw samples each (2 Msps domain).
+ * Allocates, in HBM: matched-filter output [n_streams][max_raw/5], window tables, results. */
+RFID_API int rfid_batch_plan(rfid_ctx *ctx, int n_streams, int64_t max_raw);
+/* d_raw: device pointer to [n_streams][raw_stride] rfid_cf32; d_lens: device int64[n_streams]
+ * valid sample counts per trace, or NULL when every trace has n_raw samples.  All launches
+ * go to the ctx stream and return without synchronising. */
+RFID_API int rfid_batch_mf(rfid_ctx *ctx, const void *d_raw, int64_t raw_stride, int64_t n_raw,
+                           const void *d_lens);
+RFID_API int rfid_batch_gate(rfid_ctx *ctx);
+RFID_API int rfid_batch_decode(rfid_ctx *ctx, int want_scores);
+RFID_API int rfid_batch_stats(rfid_ctx *ctx);
+/* mf -> gate -> decode -> stats on the ctx stream (asynchronous) */
+RFID_API int rfid_batch_process(rfid_ctx *ctx, const void *d_raw, int64_t raw_stride, int64_t n_raw,
+                                const void *d_lens, int want_scores);
+RFID_API int rfid_batch_sync(rfid_ctx *ctx);
+/* synchronises, then reports per-kernel times of the last pass */
+RFID_API int rfid_batch_timing_get(rfid_ctx *ctx, rfid_batch_timing *out);
+/* host copies of the results of the last pass (synchronising).
+ * windows/results/scores: up to cap entries, ordered by (stream, seq); *n = total count. */
+RFID_API int rfid_batch_get_stats(rfid_ctx *ctx, rfid_stream_stats *out, int n_streams);
+RFID_API int rfid_batch_get_windows(rfid_ctx *ctx, rfid_window *windows, rfid_decode_result *results,
+                                    rfid_scores *scores, int64_t cap, int64_t *n);
+/* device-side views for callers that keep everything in HBM */
+RFID_API int rfid_batch_device_ptrs(rfid_ctx *ctx, void **d_mf_out, int64_t *mf_stride,
+                                    void **d_stats, void **d_flat_count);
+/* copies the matched-filter output of trace `stream` to host (debug tap, the
+ * file_sink_matched_filter of apps/reader.py:69) */
+RFID_API int rfid_batch_get_mf(rfid_ctx *ctx, int stream, rfid_cf32 *out, int64_t cap, int64_t *n);
+/* the HIP stream the ctx launches on (hipStream_t as void*) */
+RFID_API void *rfid_ctx_stream(rfid_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFID_MI355X_H */

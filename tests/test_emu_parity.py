@@ -1,0 +1,118 @@
+"""CPU-only check of the KERNEL SOURCE (rfid_kernels.hpp) against the oracle: the kernels are
+compiled for the host against tests/wave_emu (a lock-step 64-lane emulator, test
+infrastructure only) and must reproduce the oracle bit-for-bit.  The product itself has no
+CPU path; the real parity gate is tests/test_gpu_parity.py on the MI355X."""
+import numpy as np
+import pytest
+
+import parity
+
+
+def _check(emu_mod, oracle_mod, raw2d, lens=None, cfg_kw=None):
+    cfg_kw = cfg_kw or {}
+    r = emu_mod.batch_process(raw2d, lens=lens, **cfg_kw)
+    B = raw2d.shape[0]
+    for b, (wb, rb, sb) in enumerate(parity.split_by_stream(r["windows"], r["results"], r["scores"], B)):
+        n = raw2d.shape[1] if lens is None else lens[b]
+        o = oracle_mod.run_trace(raw2d[b, :n], oracle_mod.config(**cfg_kw))
+        parity.compare_trace(wb, rb, sb, r["stats"][b], o)
+    return r
+
+
+@pytest.mark.parametrize("sigma,seed", [(0.002, 1), (0.06, 3)])
+def test_emulated_kernels_match_oracle(emu_mod, oracle_mod, synth_mod, sigma, seed):
+    traces = [synth_mod.make_trace(n_rounds=2, sigma=sigma, seed=seed * 10 + i, t1_jitter_raw=6).samples
+              for i in range(2)]
+    L = min(map(len, traces))
+    _check(emu_mod, oracle_mod, np.stack([t[:L] for t in traces]))
+
+
+def test_emulated_matched_filter_edges(emu_mod, oracle_mod, synth_mod):
+    t = synth_mod.make_trace(n_rounds=1, sigma=0.05, seed=5).samples
+    for L in (2600, 2561, 25, 7, 5, 4):
+        r = emu_mod.batch_process(t[:L][None, :], want_y=True)
+        yo = oracle_mod.fir(t[:L])
+        assert np.array_equal(r["y"][0].view(np.uint32), yo.view(np.uint32)), L
+
+
+def test_emulated_ragged_and_empty(emu_mod, oracle_mod, synth_mod):
+    a = synth_mod.make_trace(n_rounds=2, seed=21).samples
+    b = synth_mod.make_trace(n_rounds=1, seed=22).samples
+    L = len(a)
+    raw = np.zeros((4, L), dtype=np.complex64)
+    raw[0] = a
+    raw[1, : len(b)] = b
+    raw[2, : len(a) * 3 // 4] = a[: len(a) * 3 // 4]   # cut inside the second round
+    lens = [L, len(b), len(a) * 3 // 4, 0]
+    r = _check(emu_mod, oracle_mod, raw, lens=lens)
+    assert r["stats"][3]["n_windows"] == 0
+
+
+def test_emulated_fixed_q2_collisions(emu_mod, oracle_mod, synth_mod):
+    t = synth_mod.make_trace(n_rounds=1, fixed_q=2, tag_ids=(0x11, 0x22, 0x33), seed=33, sigma=0.01).samples
+    _check(emu_mod, oracle_mod, t[None, :], cfg_kw=dict(fixed_q=2))
+
+
+def test_emulated_termination(emu_mod, oracle_mod, synth_mod):
+    t = synth_mod.make_trace(n_rounds=4, seed=41).samples
+    r = emu_mod.batch_process(t[None, :], max_num_queries=2)
+    o = oracle_mod.run_trace(t, oracle_mod.config(max_num_queries=2))
+    st = r["stats"][0]
+    assert st["status"] == 1 == o.state.status
+    assert st["n_windows_used"] == o.n_windows
+    for k in ("n_queries_sent", "cur_inventory_round", "n_epc_correct"):
+        assert st[k] == getattr(o.state, k)
+
+
+def test_emulated_streaming_gate_chunks(emu_mod, oracle_mod, synth_mod):
+    """gate_scan_kernel in streaming mode with odd chunk sizes: consumed / written / samples
+    equal the oracle's gate block call by call."""
+    import ctypes as C
+    t = synth_mod.make_trace(n_rounds=2, seed=61, sigma=0.01).samples
+    y = oracle_mod.fir(t)
+    L = oracle_mod.lib()
+    g = (C.c_char * 8192)()
+    rs = oracle_mod.ReaderState()
+    cfg = oracle_mod.config()
+    L.orc_gate_init(C.byref(g), 400000)
+    L.orc_initialize_reader_state(C.byref(rs), C.byref(cfg))
+    rs.gate_status = 2   # SEEK_RN16
+    gs = emu_mod.GateStream()
+    pos, seek, typ = 0, 0, 0
+    chunk_sizes = [777, 64, 1, 63, 1500, 129]
+    k = 0
+    n_closed = 0
+    while pos < len(y):
+        n = min(chunk_sizes[k % len(chunk_sizes)], len(y) - pos)
+        k += 1
+        blk = np.ascontiguousarray(y[pos:pos + n])
+        out_o = np.zeros(n, dtype=np.complex64)
+        cons_o = C.c_int(0)
+        wr_o = L.orc_gate_work(C.byref(g), C.byref(rs), C.c_void_p(blk.ctypes.data), n,
+                               C.c_void_p(out_o.ctypes.data), C.byref(cons_o))
+        cons_e, out_e, open_e = gs.work(blk, seek_type=seek)
+        seek = -1
+        assert cons_e == cons_o.value and len(out_e) == wr_o, (pos, cons_e, cons_o.value, len(out_e), wr_o)
+        assert np.array_equal(out_e.view(np.uint32), out_o[:wr_o].view(np.uint32))
+        assert open_e == (1 if rs.gate_status == 0 else 0)
+        pos += cons_o.value
+        if wr_o and rs.gate_status == 1:      # window closed: decoder+reader re-arm the gate
+            typ ^= 1
+            rs.gate_status = 3 if typ else 2
+            seek = typ
+            n_closed += 1
+    assert n_closed == 4
+
+
+def test_emulated_primitives(emu_mod):
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal(64) * 1e-3).astype(np.float32)
+    num = (rng.standard_normal(64) * 30).astype(np.float32)
+    den = np.where(np.arange(64) % 2 == 0, 100.0, 48.0).astype(np.float32)
+    chain, div, hyp, shr = emu_mod.selftest(x, num, den, 12.5)
+    acc = np.float32(12.5)
+    for i in range(64):
+        acc = np.float32(acc + x[i])
+        assert chain[i] == acc
+    assert np.array_equal(div, num / den)
+    assert np.array_equal(shr[1:], x[:-1]) and shr[0] == 0

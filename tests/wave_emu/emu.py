@@ -1,0 +1,101 @@
+"""ctypes wrapper of tests/wave_emu/librfid_wave_emu.so -- TEST INFRASTRUCTURE ONLY.
+
+Runs the product's kernel source on the lock-step host emulator so kernel logic can be
+checked against the oracle without a GPU.  Never imported by the product package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "gen2-uhf-rfid-reader_amd"))
+sys.path.insert(0, HERE)
+from rfid import _capi as capi  # noqa: E402  (struct dtypes only)
+import build as _build  # noqa: E402
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(_build.build())
+    return _lib
+
+
+def batch_process(raw: np.ndarray, lens=None, fixed_q=0, max_num_queries=1000, number_unique_tags=100,
+                  want_y=False):
+    """raw: [B][L] complex64.  -> dict(windows, results, scores, stats, y)"""
+    raw = np.ascontiguousarray(raw, dtype=np.complex64)
+    if raw.ndim == 1:
+        raw = raw[None, :]
+    B, L = raw.shape
+    # 16-byte aligned copy with even stride so the float4 path is exercised
+    stride = (L + 1) & ~1
+    buf = np.zeros(B * stride + 2, dtype=np.complex64)
+    off = (16 - buf.ctypes.data % 16) % 16 // 8
+    view = buf[off:off + B * stride].reshape(B, stride)
+    view[:, :L] = raw
+    cap = B * (L // 5 // 347 + 2)
+    windows = np.zeros(cap, dtype=capi.WINDOW_DTYPE)
+    results = np.zeros(cap, dtype=capi.RESULT_DTYPE)
+    scores = np.zeros(cap, dtype=capi.SCORES_DTYPE)
+    stats = np.zeros(B, dtype=capi.STATS_DTYPE)
+    n = C.c_long(0)
+    y = np.zeros((B, L // 5), dtype=np.complex64) if want_y else None
+    lens_arr = None
+    if lens is not None:
+        lens_arr = np.ascontiguousarray(lens, dtype=np.int64)
+    rc = lib().emu_batch_process(
+        C.c_void_p(view.ctypes.data), B, C.c_long(stride), C.c_long(L),
+        C.c_void_p(lens_arr.ctypes.data) if lens_arr is not None else None,
+        fixed_q, max_num_queries, number_unique_tags,
+        C.c_void_p(windows.ctypes.data), C.c_void_p(results.ctypes.data), C.c_void_p(scores.ctypes.data),
+        C.c_long(cap), C.byref(n), C.c_void_p(stats.ctypes.data),
+        C.c_void_p(y.ctypes.data) if y is not None else None)
+    assert rc == 0
+    k = n.value
+    return dict(windows=windows[:k], results=results[:k], scores=scores[:k], stats=stats, y=y)
+
+
+class GateStream:
+    def __init__(self):
+        self.state = np.zeros(lib().emu_gate_state_size(), dtype=np.uint8)
+
+    def work(self, x: np.ndarray, seek_type: int = -1):
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        out = np.zeros(max(len(x), 1), dtype=np.complex64)
+        c, w, o = C.c_int(0), C.c_int(0), C.c_int(0)
+        lib().emu_gate_stream(C.c_void_p(self.state.ctypes.data), C.c_void_p(x.ctypes.data), len(x), seek_type,
+                              C.c_void_p(out.ctypes.data), C.byref(c), C.byref(w), C.byref(o))
+        return c.value, out[:w.value].copy(), o.value
+
+
+def decode_one(win: np.ndarray, type_: int):
+    win = np.ascontiguousarray(win, dtype=np.complex64)
+    res = np.zeros(1, dtype=capi.RESULT_DTYPE)
+    sc = np.zeros(1, dtype=capi.SCORES_DTYPE)
+    lib().emu_decode_one(C.c_void_p(win.ctypes.data), type_, C.c_void_p(res.ctypes.data), C.c_void_p(sc.ctypes.data))
+    return res[0], sc[0]
+
+
+def mf_stream(staging: np.ndarray, in_off: int, n_out: int) -> np.ndarray:
+    buf = np.zeros(len(staging) + 2, dtype=np.complex64)
+    off = (16 - buf.ctypes.data % 16) % 16 // 8
+    st = buf[off:off + len(staging)]
+    st[:] = staging
+    out = np.zeros(max(n_out, 1), dtype=np.complex64)
+    lib().emu_mf_stream(C.c_void_p(st.ctypes.data), len(st), in_off, n_out, C.c_void_p(out.ctypes.data))
+    return out[:n_out]
+
+
+def selftest(x, num, den, carry):
+    x, num, den = (np.ascontiguousarray(a, dtype=np.float32) for a in (x, num, den))
+    outs = [np.zeros(64, dtype=np.float32) for _ in range(4)]
+    lib().emu_selftest(C.c_void_p(x.ctypes.data), C.c_void_p(num.ctypes.data), C.c_void_p(den.ctypes.data),
+                       C.c_float(carry), *[C.c_void_p(o.ctypes.data) for o in outs])
+    return outs

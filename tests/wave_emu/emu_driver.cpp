@@ -1,0 +1,225 @@
+// tests/wave_emu/emu_driver.cpp -- TEST INFRASTRUCTURE ONLY (see rfid_device_env.h here).
+//
+// Runs the unmodified kernel source gen2-uhf-rfid-reader_amd/csrc/rfid_kernels.hpp on a
+// lock-step 64-lane host emulator so the kernel logic (indices, state machine, ring
+// handling, reductions) can be compared with the oracle in the GPU-less CI container.
+// Built by tests/wave_emu/build.py into tests/wave_emu/librfid_wave_emu.so; nothing in the
+// product imports or links it.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <functional>
+#include <vector>
+
+#include <rfid_device_env.h>
+#include "rfid_host_math.h"
+#include "rfid_kernels.hpp"
+
+namespace emu {
+
+Block *g_blk = nullptr;
+Fiber *g_cur = nullptr;
+Idx3 g_block_idx, g_grid_dim, g_block_dim;
+ucontext_t g_sched;
+static const std::function<void()> *g_body = nullptr;
+
+void yield() { swapcontext(&g_cur->ctx, &g_sched); }
+
+static void fiber_entry() {
+  (*g_body)();
+  g_cur->done = true;
+  swapcontext(&g_cur->ctx, &g_sched);
+}
+
+void launch(Idx3 grid, Idx3 block, const std::function<void()> &body) {
+  g_grid_dim = grid;
+  g_block_dim = block;
+  g_body = &body;
+  const int nthreads = (int)(block.x * block.y * block.z);
+  const int nwaves = (nthreads + 63) / 64;
+  Block B;
+  B.nthreads = nthreads;
+  B.fibers.resize((size_t)nthreads);
+  for (auto &f : B.fibers) f.stack.resize(256 * 1024);
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        g_block_idx = Idx3{bx, by, bz};
+        B.xbuf.assign((size_t)nwaves * 2 * 64, 0);
+        B.wave_arrived.assign((size_t)nwaves, 0);
+        B.wave_gen.assign((size_t)nwaves, 0);
+        B.block_arrived = 0;
+        B.block_gen = 0;
+        g_blk = &B;
+        for (int t = 0; t < nthreads; ++t) {
+          Fiber &f = B.fibers[(size_t)t];
+          f.tid = Idx3{(unsigned)t, 0, 0};
+          f.done = false;
+          f.wave_calls = 0;
+          f.block_calls = 0;
+          getcontext(&f.ctx);
+          f.ctx.uc_stack.ss_sp = f.stack.data();
+          f.ctx.uc_stack.ss_size = f.stack.size();
+          f.ctx.uc_link = &g_sched;
+          makecontext(&f.ctx, fiber_entry, 0);
+        }
+        int remaining = nthreads;
+        while (remaining > 0) {
+          remaining = 0;
+          for (int t = 0; t < nthreads; ++t) {
+            Fiber &f = B.fibers[(size_t)t];
+            if (f.done) continue;
+            g_cur = &f;
+            swapcontext(&g_sched, &f.ctx);
+            if (!f.done) remaining++;
+          }
+        }
+      }
+  g_blk = nullptr;
+  g_cur = nullptr;
+}
+
+}  // namespace emu
+
+using namespace rfidk;
+
+extern "C" {
+
+// Batched pipeline mf -> gate -> decode -> stats, mirroring rfid_batch_process().
+// raw: [B][stride] complex64.  Outputs ordered by (stream, seq).
+int emu_batch_process(const float *raw, int B, long stride, long n_raw, const int64_t *lens, int fixed_q,
+                      int max_num_queries, int number_unique_tags, rfid_window *windows,
+                      rfid_decode_result *results, rfid_scores *scores, long cap, long *n_windows,
+                      rfid_stream_stats *stats, float *y_out) {
+  const long n_dec = n_raw / DECIM;
+  long y_stride = (n_dec + 1) & ~1L;
+  if (y_stride < 2) y_stride = 2;
+  std::vector<float4> ybuf((size_t)(y_stride * B / 2 + 2));
+  float2 *y = reinterpret_cast<float2 *>(ybuf.data());
+  const int wmax = (int)(n_dec / (RN16_WIN + T1_SAMPLES + 1) + 2);
+  const int flat_cap = wmax * B;
+  std::vector<GateState> gstate((size_t)B);
+  memset(gstate.data(), 0, sizeof(GateState) * (size_t)B);
+  std::vector<rfid_window> wtab((size_t)flat_cap), flat((size_t)flat_cap);
+  std::vector<int> wcount((size_t)B, 0);
+  int flat_count = 0;
+  std::vector<rfid_decode_result> res((size_t)flat_cap);
+  std::vector<rfid_scores> sc((size_t)flat_cap);
+  memset(sc.data(), 0, sizeof(rfid_scores) * (size_t)flat_cap);
+
+  MfArgs ma;
+  ma.x = reinterpret_cast<const float2 *>(raw); ma.x_stride = stride; ma.n_raw = n_raw; ma.lens = lens;
+  ma.n_out = n_dec; ma.in_off = -(NTAPS - 1);
+  ma.vec_ok = ((stride & 1) == 0 && (((uintptr_t)raw) & 15) == 0) ? 1 : 0;
+  ma.y = y; ma.y_stride = y_stride;
+  const long tiles = (n_dec + MF_TILE - 1) / MF_TILE;
+  if (tiles > 0)
+    emu::launch(emu::Idx3{(unsigned)tiles, (unsigned)B, 1}, emu::Idx3{MF_THREADS, 1, 1},
+                [&]() { mf_boxcar25_decim5_kernel(ma); });
+  if (y_out)
+    for (int b = 0; b < B; ++b) memcpy(y_out + 2 * (size_t)b * n_dec, y + (size_t)b * y_stride, sizeof(float2) * (size_t)n_dec);
+
+  GateArgs ga;
+  ga.y = y; ga.y_stride = y_stride; ga.n_dec = n_dec; ga.lens = lens; ga.state = gstate.data();
+  ga.wtab = wtab.data(); ga.wmax = wmax; ga.wcount = wcount.data(); ga.flat = flat.data();
+  ga.flat_count = &flat_count; ga.flat_cap = flat_cap; ga.mode = 0; ga.gated = nullptr; ga.gated_cap = 0;
+  ga.io = nullptr;
+  emu::launch(emu::Idx3{(unsigned)B, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { gate_scan_kernel(ga); });
+
+  DecodeArgs da;
+  da.y = y; da.y_stride = y_stride; da.flat = flat.data(); da.flat_count = &flat_count; da.flat_cap = flat_cap;
+  da.res = res.data(); da.scores = sc.data(); da.wmax = wmax;
+  rfidh::t_candidates(da.t_cand, 400000);
+  int grid = flat_count < 7 ? (flat_count > 0 ? flat_count : 1) : 7;  // exercise the persistent loop
+  emu::launch(emu::Idx3{(unsigned)grid, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { decode_windows_kernel(da); });
+
+  StatsArgs sa;
+  sa.res = res.data(); sa.wcount = wcount.data(); sa.wmax = wmax; sa.n_streams = B;
+  sa.max_slot_number = 1 << fixed_q; sa.max_num_queries = max_num_queries;
+  sa.number_unique_tags = number_unique_tags; sa.out = stats;
+  emu::launch(emu::Idx3{(unsigned)((B + 63) / 64), 1, 1}, emu::Idx3{64, 1, 1}, [&]() { stream_stats_kernel(sa); });
+
+  long total = 0;
+  for (int s = 0; s < B; ++s) {
+    for (int k = 0; k < wcount[(size_t)s]; ++k) {
+      if (total < cap) {
+        const size_t off = (size_t)s * (size_t)wmax + (size_t)k;
+        if (windows) windows[total] = wtab[off];
+        if (results) results[total] = res[off];
+        if (scores) scores[total] = sc[off];
+      }
+      total++;
+    }
+  }
+  *n_windows = total;
+  return 0;
+}
+
+// gate_scan_kernel in streaming mode (mode 1) on one call's worth of samples.
+// seek_type: -1 none, 0 SEEK_RN16, 1 SEEK_EPC applied before the scan (gate_impl.cc:112-123).
+int emu_gate_stream(void *state_blob, const float *in, int n_in, int seek_type, float *out, int *consumed,
+                    int *written, int *gate_open) {
+  GateState *st = reinterpret_cast<GateState *>(state_blob);
+  if (seek_type >= 0) {
+    st->n_samples = 0;
+    st->wtype = seek_type;
+    st->n_to_ungate = seek_type ? EPC_WIN : RN16_WIN;
+  }
+  int io[2] = {n_in, 0};
+  if (n_in > 0) {
+    GateArgs ga;
+    ga.y = reinterpret_cast<const float2 *>(in); ga.y_stride = n_in; ga.n_dec = n_in; ga.lens = nullptr;
+    ga.state = st; ga.wtab = nullptr; ga.wmax = 0; ga.wcount = nullptr; ga.flat = nullptr;
+    ga.flat_count = nullptr; ga.flat_cap = 0; ga.mode = 1; ga.gated = reinterpret_cast<float2 *>(out);
+    ga.gated_cap = n_in; ga.io = io;
+    emu::launch(emu::Idx3{1, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { gate_scan_kernel(ga); });
+  }
+  *consumed = io[0];
+  *written = io[1];
+  *gate_open = st->gate_open;
+  return 0;
+}
+
+int emu_gate_state_size(void) { return (int)sizeof(GateState); }
+
+// matched filter in streaming form (staging = 24 history samples + new samples)
+int emu_mf_stream(const float *staging, int n_staging, int in_off, int n_out, float *out) {
+  if (n_out <= 0) return 0;
+  std::vector<float4> ybuf((size_t)(n_out / 2 + 2));
+  MfArgs ma;
+  ma.x = reinterpret_cast<const float2 *>(staging); ma.x_stride = n_staging; ma.n_raw = n_staging; ma.lens = nullptr;
+  ma.n_out = n_out; ma.in_off = in_off;
+  ma.vec_ok = (in_off % 2 == 0 && (((uintptr_t)staging) & 15) == 0) ? 1 : 0;
+  ma.y = reinterpret_cast<float2 *>(ybuf.data()); ma.y_stride = n_out;
+  const int tiles = (n_out + MF_TILE - 1) / MF_TILE;
+  emu::launch(emu::Idx3{(unsigned)tiles, 1, 1}, emu::Idx3{MF_THREADS, 1, 1}, [&]() { mf_boxcar25_decim5_kernel(ma); });
+  memcpy(out, ybuf.data(), sizeof(float2) * (size_t)n_out);
+  return 0;
+}
+
+// one window through decode_windows_kernel (input already DC-free, as the decoder block sees it)
+int emu_decode_one(const float *win, int type, rfid_decode_result *res, rfid_scores *scores) {
+  const int wlen = type ? EPC_WIN : RN16_WIN;
+  rfid_window w;
+  w.stream = 0; w.seq = 0; w.start = 0; w.type = type; w.dc_re = 0.0f; w.dc_im = 0.0f;
+  int one = 1;
+  DecodeArgs da;
+  da.y = reinterpret_cast<const float2 *>(win); da.y_stride = wlen; da.flat = &w; da.flat_count = &one;
+  da.flat_cap = 1; da.res = res; da.scores = scores; da.wmax = 1;
+  rfidh::t_candidates(da.t_cand, 400000);
+  memset(scores, 0, sizeof(*scores));
+  emu::launch(emu::Idx3{1, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { decode_windows_kernel(da); });
+  return 0;
+}
+
+// primitives self-test kernel
+int emu_selftest(const float *x, const float *num, const float *den, float carry, float *chain_out,
+                 float *div_out, float *hyp_out, float *shr_out) {
+  SelfTestArgs a;
+  a.x = x; a.num = num; a.den = den; a.carry = carry; a.chain_out = chain_out; a.div_out = div_out;
+  a.hyp_out = hyp_out; a.shr_out = shr_out;
+  emu::launch(emu::Idx3{1, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { selftest_kernel(a); });
+  return 0;
+}
+
+}  // extern "C"

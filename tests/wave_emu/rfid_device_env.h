@@ -1,0 +1,146 @@
+// tests/wave_emu/rfid_device_env.h -- HOST EMULATION of the gfx950 device environment.
+//
+// TEST INFRASTRUCTURE ONLY.  This header shadows gen2-uhf-rfid-reader_amd/csrc/
+// rfid_device_env.h when tests/wave_emu/emu_driver.cpp is compiled with g++, so that the
+// unmodified kernel source (rfid_kernels.hpp) can be executed in the GPU-less CI container:
+// every workgroup runs as a set of cooperative fibers (ucontext) that advance in lock step
+// at each wave-level operation.  It is never compiled into, linked with or loaded by
+// librfid_mi355x.so and is not a fallback of any kind: the product has no CPU path.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <ucontext.h>
+
+#include <functional>
+#include <vector>
+
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }
+static inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+
+namespace emu {
+
+struct Idx3 { unsigned x, y, z; };
+
+struct Fiber {
+  ucontext_t ctx;
+  std::vector<char> stack;
+  Idx3 tid;
+  bool done = false;
+  uint64_t wave_calls = 0;   // number of wave collectives this fiber has entered
+  uint64_t block_calls = 0;  // number of block barriers this fiber has entered
+};
+
+struct Block {
+  std::vector<Fiber> fibers;
+  int nthreads = 0;
+  // per wave: exchange buffers (double buffered), arrival counts, released generation
+  std::vector<uint64_t> xbuf;      // [nwaves][2][64]
+  std::vector<int> wave_arrived;   // [nwaves]
+  std::vector<uint64_t> wave_gen;  // [nwaves]
+  int block_arrived = 0;
+  uint64_t block_gen = 0;
+};
+
+extern Block *g_blk;
+extern Fiber *g_cur;
+extern Idx3 g_block_idx, g_grid_dim, g_block_dim;
+extern ucontext_t g_sched;
+
+void yield();
+void launch(Idx3 grid, Idx3 block, const std::function<void()> &body);
+
+static inline int lanes_in_wave(int wave) {
+  int rem = g_blk->nthreads - wave * 64;
+  return rem > 64 ? 64 : rem;
+}
+
+// all live lanes of the calling fiber's wave meet here
+static inline void wave_barrier() {
+  const int wave = (int)(g_cur->tid.x / 64);
+  const uint64_t my = g_cur->wave_calls++;
+  if (++g_blk->wave_arrived[wave] == lanes_in_wave(wave)) {
+    g_blk->wave_arrived[wave] = 0;
+    g_blk->wave_gen[wave] = my + 1;
+  } else {
+    while (g_blk->wave_gen[wave] <= my) yield();
+  }
+}
+
+// deposit a 64-bit value, meet, and get the wave's 64 deposited values
+static inline const uint64_t *exchange(uint64_t v) {
+  const int wave = (int)(g_cur->tid.x / 64), lane = (int)(g_cur->tid.x % 64);
+  uint64_t *buf = &g_blk->xbuf[((size_t)wave * 2 + (g_cur->wave_calls & 1)) * 64];
+  if (lane == 0) for (int i = lanes_in_wave(wave); i < 64; ++i) buf[i] = 0;
+  buf[lane] = v;
+  wave_barrier();
+  return buf;
+}
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+}  // namespace emu
+
+#define threadIdx (emu::g_cur->tid)
+#define blockIdx (emu::g_block_idx)
+#define gridDim (emu::g_grid_dim)
+#define blockDim (emu::g_block_dim)
+
+#define RFID_KERNEL(threads) static inline
+#define RFID_DEVICE static inline
+#define RFID_SHARED static
+#define __device__
+
+namespace wv {
+
+static inline int lane_id() { return (int)(threadIdx.x & 63u); }
+
+static inline uint64_t ballot(bool p) {
+  const uint64_t *b = emu::exchange(p ? 1 : 0);
+  uint64_t m = 0;
+  for (int i = 0; i < 64; ++i) if (b[i]) m |= 1ull << i;
+  return m;
+}
+static inline float shfl(float v, int src) { return emu::u2f((uint32_t)emu::exchange(emu::f2u(v))[src & 63]); }
+static inline int shfl(int v, int src) { return (int)(uint32_t)emu::exchange((uint32_t)v)[src & 63]; }
+static inline float shfl_xor(float v, int m) { return emu::u2f((uint32_t)emu::exchange(emu::f2u(v))[(lane_id() ^ m) & 63]); }
+static inline int shfl_xor(int v, int m) { return (int)(uint32_t)emu::exchange((uint32_t)v)[(lane_id() ^ m) & 63]; }
+static inline unsigned shfl_xor(unsigned v, int m) { return (unsigned)emu::exchange(v)[(lane_id() ^ m) & 63]; }
+static inline float shr1(float v) {
+  const uint64_t *b = emu::exchange(emu::f2u(v));
+  const int l = lane_id();
+  return (l == 0) ? 0.0f : emu::u2f((uint32_t)b[l - 1]);
+}
+static inline float readlane(float v, int k) { return emu::u2f((uint32_t)emu::exchange(emu::f2u(v))[k & 63]); }
+static inline int readlane(int v, int k) { return (int)(uint32_t)emu::exchange((uint32_t)v)[k & 63]; }
+// readfirstlane: lane 0's value (all lanes are live at every call site in the kernels)
+static inline int uniform(int v) { return (int)(uint32_t)emu::exchange((uint32_t)v)[0]; }
+static inline float uniform(float v) { return emu::u2f((uint32_t)emu::exchange(emu::f2u(v))[0]); }
+static inline uint64_t uniform(uint64_t v) { return emu::exchange(v)[0]; }
+
+static inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
+static inline int ffs64(uint64_t m) { return m ? __builtin_ctzll(m) : 64; }
+static inline float fdiv(float a, float b) { volatile float q = a / b; return q; }
+static inline float hypot_f(float x, float y) {
+  return (float)sqrt((double)x * (double)x + (double)y * (double)y);
+}
+static inline int f2i(float v) { return (int)v; }
+
+static inline void block_sync() {
+  emu::Block *B = emu::g_blk;
+  const uint64_t my = emu::g_cur->block_calls++;
+  int live = 0;
+  for (auto &f : B->fibers) if (!f.done) live++;
+  if (++B->block_arrived >= live) {
+    B->block_arrived = 0;
+    B->block_gen = my + 1;
+  } else {
+    while (B->block_gen <= my) emu::yield();
+  }
+}
+static inline int atomic_add(int *p, int v) { int o = *p; *p = o + v; return o; }
+
+}  // namespace wv
