@@ -389,12 +389,26 @@ int rfid_batch_gate(rfid_ctx *c) {
   HIPCHK(c, hipMemsetAsync(c->d_flat_count, 0, sizeof(int), c->stream));
   GateArgs a;
   a.y = c->d_y; a.y_stride = c->y_stride; a.n_dec = c->last_n_raw / DECIM; a.lens = c->d_lens;
-  a.state = c->d_gstate; a.wtab = c->d_wtab; a.wmax = c->wmax; a.wcount = c->d_wcount;
+  a.state = c->d_gstate; a.n_streams = c->B; a.wtab = c->d_wtab; a.wmax = c->wmax; a.wcount = c->d_wcount;
   a.flat = c->d_flat; a.flat_count = c->d_flat_count; a.flat_cap = c->flat_cap; a.mode = 0;
-  a.gated = nullptr; a.gated_cap = 0; a.io = nullptr;
+  a.gated = nullptr; a.gated_cap = 0; a.io = nullptr; a.prof = nullptr;
   if (!c->ev_valid[1]) { HIPCHK(c, hipEventRecord(c->ev[1], c->stream)); c->ev_valid[1] = true; }
-  hipLaunchKernelGGL(gate_scan_kernel, dim3((unsigned)c->B), dim3(64), 0, c->stream, a);
-  HIPCHK(c, hipGetLastError());
+  if (getenv("RFID_GATE_PROF")) {  // developer aid: phase counters of the consumer wave
+    long long *d_prof = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_prof, sizeof(long long) * 12 * (size_t)c->B));
+    a.prof = d_prof;
+    hipLaunchKernelGGL(gate_scan_kernel_prof, dim3((unsigned)((c->B + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG)), dim3(GATE_THREADS), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    std::vector<long long> h((size_t)c->B * 12);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(h.data(), d_prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+    (void)hipFree(d_prof);
+    const char *names[12] = {"read+chains", "finish-back", "thresh+fsm(rest)", "dc-prep", "pins", "wait-producer", "total", "ticks() cost", "chain-complete", "thresh+ballot", "fsm", "-"};
+    for (int i = 0; i < 11; ++i) fprintf(stderr, "[gate prof] %-12s %lld ticks (stream 0)\n", names[i], h[(size_t)i]);
+  } else {
+    hipLaunchKernelGGL(gate_scan_kernel, dim3((unsigned)((c->B + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG)), dim3(GATE_THREADS), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+  }
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   c->ev_valid[2] = true;
   return RFID_OK;
@@ -611,10 +625,10 @@ int rfid_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, i
   HIPCHK(c, hipMemcpyAsync(c->s_in.p, in, sizeof(rfid_cf32) * (size_t)n_in, hipMemcpyHostToDevice, c->stream));
   GateArgs a;
   a.y = (const float2 *)c->s_in.p; a.y_stride = n_in; a.n_dec = n_in; a.lens = nullptr;
-  a.state = c->d_gate1; a.wtab = nullptr; a.wmax = 0; a.wcount = nullptr;
+  a.state = c->d_gate1; a.n_streams = 1; a.wtab = nullptr; a.wmax = 0; a.wcount = nullptr;
   a.flat = nullptr; a.flat_count = nullptr; a.flat_cap = 0; a.mode = 1;
-  a.gated = (float2 *)c->s_out.p; a.gated_cap = n_in; a.io = c->d_io;
-  hipLaunchKernelGGL(gate_scan_kernel, dim3(1), dim3(64), 0, c->stream, a);
+  a.gated = (float2 *)c->s_out.p; a.gated_cap = n_in; a.io = c->d_io; a.prof = nullptr;
+  hipLaunchKernelGGL(gate_scan_kernel, dim3(1), dim3(GATE_THREADS), 0, c->stream, a);
   HIPCHK(c, hipGetLastError());
   int io[2] = {0, 0};
   int open_now = 0;

@@ -65,6 +65,39 @@ RFID_DEVICE float hypot_f(float x, float y) {
 RFID_DEVICE int f2i(float v) { return (int)v; }
 
 RFID_DEVICE void block_sync() { __syncthreads(); }
+// LDS hand-off inside ONE wavefront (single-wave workgroups): the LDS queue of a wave is
+// in order, so a later ds_read sees an earlier ds_write of any lane; only the compiler must
+// not reorder them.  Unlike __syncthreads() this does not drain outstanding global loads
+// (s_waitcnt vmcnt(0)), which would serialise the register prefetch of the gate scan.
+RFID_DEVICE void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// workgroup barrier that waits for this wave's LDS traffic only (lgkmcnt), not for its
+// outstanding global loads: __syncthreads() adds s_waitcnt vmcnt(0), which would drain the
+// producer wave's register prefetch every step
+RFID_DEVICE void block_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 RFID_DEVICE int atomic_add(int *p, int v) { return atomicAdd(p, v); }
+// LDS mailbox words shared by two waves of one workgroup: volatile accesses, in-order LDS
+// queue per wave; the store is issued by one lane after the wave's earlier LDS writes.
+#define RFID_LDS_AS __attribute__((address_space(3)))
+RFID_DEVICE int lds_load(const int *p) {
+  // explicit LDS address space: through a generic pointer a volatile access becomes a
+  // system-coherent flat load (flat_load_dword sc0 sc1, ~1 us) instead of a ds_read_b32
+  const volatile RFID_LDS_AS int *q = (const volatile RFID_LDS_AS int *)p;
+  return __builtin_amdgcn_readfirstlane(*q);
+}
+RFID_DEVICE void lds_store(int *p, int v, int lane) {
+  volatile RFID_LDS_AS int *q = (volatile RFID_LDS_AS int *)p;
+  asm volatile("" ::: "memory");
+  if (lane == 0) *q = v;
+  asm volatile("" ::: "memory");
+}
+RFID_DEVICE void set_priority_high() { __builtin_amdgcn_s_setprio(3); }
+RFID_DEVICE void backoff() { __builtin_amdgcn_s_sleep(1); }
+RFID_DEVICE void keep(float v) { asm volatile("" ::"s"(v)); }
+RFID_DEVICE void keep(int v) { asm volatile("" ::"s"(v)); }
+RFID_DEVICE long long ticks() { return (long long)__builtin_amdgcn_s_memtime(); }
 
 }  // namespace wv

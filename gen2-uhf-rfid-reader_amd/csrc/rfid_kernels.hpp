@@ -147,6 +147,7 @@ struct GateArgs {
   int64_t n_dec;        // valid decimated samples per trace (when lens == nullptr)
   const int64_t *lens;  // optional per-trace RAW lengths (n_dec = lens/5)
   GateState *state;     // [n_streams]
+  int n_streams;
   rfid_window *wtab;    // [n_streams][wmax]
   int wmax;
   int *wcount;          // [n_streams] complete windows recorded
@@ -157,6 +158,7 @@ struct GateArgs {
   float2 *gated;        // streaming: gated, DC-removed samples
   int gated_cap;
   int *io;              // streaming: io[0] = consumed, io[1] = written
+  long long *prof;      // optional phase counters (gate_scan_kernel_prof only)
 };
 
 // In-order sum: returns in lane L the value  (((carry + x_0) + x_1) + ...) + x_L.
@@ -174,45 +176,199 @@ RFID_DEVICE uint64_t lane_range(int lo, int hi) {  // bits [lo, hi), 0 <= lo <= 
   return up & ~dn;
 }
 
-// wave-uniform registers of one trace's gate
+// Three independent in-order sums advanced together: a dependent DPP add has ~12 cycles of
+// latency but a single wave can issue one every ~4, so three chains cost the same as one.
+RFID_DEVICE void chain_add3(float ca, float xa, float cb, float xb, float cc, float xc, int lane,
+                            float &pa, float &pb, float &pc) {
+  const float a0 = (lane == 0) ? (ca + xa) : xa;
+  const float b0 = (lane == 0) ? (cb + xb) : xb;
+  const float c0 = (lane == 0) ? (cc + xc) : xc;
+  pa = a0; pb = b0; pc = c0;
+#pragma unroll
+  for (int s = 1; s < 64; ++s) {
+    pa = wv::shr1(pa) + a0;
+    pb = wv::shr1(pb) + b0;
+    pc = wv::shr1(pc) + c0;
+  }
+}
+
+// wave-uniform registers of one trace's gate (consumer wave)
 struct GateRegs {
   float avg_c, dcr_c, dci_c;
   int f_n, f_state, f_pulses, f_open, f_ung, f_type;
-  int win_index, dc_index, win_seq;
+  int dc_index, win_seq;
+  int run_closed;   // closed samples seen back-to-back up to the current position (this call)
+  int ring_stale;   // lds_dc not maintained during fast-path steps; rebuilt on demand
   int n_complete, written, consumed;
   bool stop;
 };
 
-// one step = 64 decimated samples [pos, pos+nvalid) of trace s; lane L holds sample pos+L
-RFID_DEVICE void gate_step(const GateArgs &a, GateRegs &g, const float2 yv_in, int pos, int n,
-                           int s, int lane, float *lds_win, float2 *lds_dc, float2 *lds_tmp) {
-  int nvalid = (n - pos < 64) ? (n - pos) : 64;
+// One step (64 decimated samples) handed from the producer wave to the consumer wave.
+struct GateSlot {
+  float amp[64];   // |x|                                   (gate_impl.cc:130)
+  float d[64];     // (|x| - win_samples[win_index]) / 100   (gate_impl.cc:131)
+  float2 yv[64];   // the samples themselves
+  float tre[64];   // speculative (x - x[i-48]) / 48: exact whenever the previous 48 samples
+  float tim[64];   //   were all "closed" samples, the common case (gate_impl.cc:141)
+};
+
+// "back" half of a step, finished one iteration later: dc increments of the closed samples
+struct GateBack {
+  float2 yv;
+  float tre, tim;
+  uint64_t openmask;
+  int open_lane, open_type, open_lane2, open_type2;
+  int pos;
+  bool has;
+};
+
+// ---- producer wave: everything that is lane-parallel ---------------------------------------
+RFID_DEVICE void gate_produce(GateSlot &slot, float2 yv_in, float2 &prev_yv, int pos, int n, int lane,
+                              float *lds_win, int &win_index) {
+  const int nvalid = (n - pos < 64) ? (n - pos) : 64;
   const bool valid = lane < nvalid;
   const float2 yv = valid ? yv_in : make_float2(0.0f, 0.0f);
-  // --- moving average of |x| (gate_impl.cc:130-133) ---------------------------------------
+#if defined(RFID_ABLATE) && (RFID_ABLATE & 1)
+  const float amp = yv.x;
+#else
   const float amp = wv::hypot_f(yv.x, yv.y);
-  int wi = g.win_index + lane;
+#endif
+  int wi = win_index + lane;
   if (wi >= WIN_LEN) wi -= WIN_LEN;
   const float amp_old = lds_win[wi];
   const float d = valid ? wv::fdiv(amp - amp_old, WIN_LEN_F) : 0.0f;
-  const float avg = chain_add(g.avg_c, d, lane);
-  const float thresh = avg * THRESH_FRACTION;  // gate_impl.cc:136
-  const uint64_t below = wv::uniform(wv::ballot(valid && (amp < thresh)));
-  const uint64_t above = wv::uniform(wv::ballot(valid && (amp > thresh)));
+  wv::wave_sync();
+  if (valid) lds_win[wi] = amp;
+  wv::wave_sync();
+  win_index += nvalid;
+  if (win_index >= WIN_LEN) win_index -= WIN_LEN;
+  // x[i-48]: lanes 0..47 take it from the previous step (its lanes 16..63), lanes 48..63 from
+  // this step (lanes 0..15)
+  const int src = (lane < DC_LEN) ? (lane + 64 - DC_LEN) : (lane - DC_LEN);
+  const float pre = wv::shfl(prev_yv.x, src), pim = wv::shfl(prev_yv.y, src);
+  const float cre = wv::shfl(yv.x, src), cim = wv::shfl(yv.y, src);
+  const float ore = (lane < DC_LEN) ? pre : cre, oim = (lane < DC_LEN) ? pim : cim;
+  slot.amp[lane] = amp;
+  slot.d[lane] = d;
+  slot.yv[lane] = yv;
+#if defined(RFID_ABLATE) && (RFID_ABLATE & 1)
+  slot.tre[lane] = (yv.x - ore) * 0.02f;
+  slot.tim[lane] = (yv.y - oim) * 0.02f;
+#else
+  slot.tre[lane] = wv::fdiv(yv.x - ore, DC_LEN_F);
+  slot.tim[lane] = wv::fdiv(yv.y - oim, DC_LEN_F);
+#endif
+  prev_yv = yv;
+}
 
-  // --- edge / pulse / window state machine, scalar, event driven (gate_impl.cc:145-195) ---
+// a gate opening at lane `ol` of the step that starts at `pos`: dc_est is the in-order sum at
+// that lane (the opening sample itself is still a "closed" sample, gate_impl.cc:141-176)
+RFID_DEVICE void gate_record_window(const GateArgs &a, GateRegs &g, int ol, int wtype, int pos, int n, int s,
+                                    int lane, float dcr, float dci) {
+  const float odr = wv::readlane(dcr, ol), odi = wv::readlane(dci, ol);
+  const int wlen = wtype ? EPC_WIN : RN16_WIN;
+  const int start = pos + ol;
+  if (a.mode == 0 && start + wlen <= n) {  // only complete windows reach the decoder (:223,:291)
+    if (lane == 0 && g.win_seq < a.wmax) {
+      rfid_window w;
+      w.stream = s; w.seq = g.win_seq; w.start = start; w.type = wtype;
+      w.dc_re = odr; w.dc_im = odi;
+      a.wtab[(int64_t)s * a.wmax + g.win_seq] = w;
+      if (a.flat) {
+        const int slotw = wv::atomic_add(a.flat_count, 1);
+        if (slotw < a.flat_cap) a.flat[slotw] = w;
+      }
+    }
+    g.n_complete++;
+  }
+  g.win_seq++;
+}
+
+// ---- consumer wave: the in-order sums and the scalar state machine ---------------------------
+// One pipeline iteration: the in-order sum of avg_ampl for step k runs interleaved with the
+// two in-order sums of dc_est for step k-1; then step k-1 is finished (window records, gated
+// output) and step k goes through the threshold test and the state machine.
+// Optional readfirstlane pinning of loop-carried wave-uniform values (LLVM's
+// uniformity analysis can demote refined uniform values to VGPRs).  Empty by default: with
+// the front/back flags passed as compile-time constants no refinement happens any more.
+#ifndef RFID_GATE_PINS
+#define RFID_GATE_PINS
+#endif
+
+template <bool PROF>
+RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const GateSlot *slot, bool has_front,
+                              int pos, int n, int s, int lane, float2 *lds_dc, float2 *lds_tmp, long long *tk) {
+  long long t0 = 0, t1 = 0;
+  if (PROF) t0 = wv::ticks();
+  float f_amp = 0.0f, f_d = 0.0f, f_tre = 0.0f, f_tim = 0.0f;
+  float2 f_yv = make_float2(0.0f, 0.0f);
+  if (has_front) {
+    f_amp = slot->amp[lane]; f_d = slot->d[lane]; f_yv = slot->yv[lane];
+    f_tre = slot->tre[lane]; f_tim = slot->tim[lane];
+  }
+  float avg, dcr, dci;
+  chain_add3(g.avg_c, f_d, g.dcr_c, B.has ? B.tre : 0.0f, g.dci_c, B.has ? B.tim : 0.0f, lane, avg, dcr, dci);
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  if (PROF) { t1 = wv::ticks(); tk[0] += t1 - t0; t0 = t1; wv::keep(wv::readlane(avg, 63)); t1 = wv::ticks(); tk[8] += t1 - t0; t0 = t1; }
+
+  // ---- finish the back step ----------------------------------------------------------------
+  if (B.has) {
+    g.dcr_c = wv::readlane(dcr, 63);
+    g.dci_c = wv::readlane(dci, 63);
+    if (B.open_lane >= 0) {   // rare: a window opened in the back step
+      gate_record_window(a, g, B.open_lane, B.open_type, B.pos, n, s, lane, dcr, dci);
+      if (B.open_lane2 >= 0) gate_record_window(a, g, B.open_lane2, B.open_type2, B.pos, n, s, lane, dcr, dci);
+    }
+    if (a.mode == 1 && B.openmask != 0) {  // streaming: emit gated samples in[i] - dc_est (gate_impl.cc:176,187)
+      const bool isopen = ((B.openmask >> lane) & 1ull) != 0;
+      const int orank = wv::popc64(B.openmask & lt);
+      if (isopen && g.written + orank < a.gated_cap)
+        a.gated[g.written + orank] = make_float2(B.yv.x - dcr, B.yv.y - dci);
+      g.written += wv::popc64(B.openmask);
+    }
+  }
+  const float2 prev_yv = B.yv;   // samples of step k-1 (for the dc ring rebuild)
+  B.has = false;
+  if (PROF) { t1 = wv::ticks(); tk[1] += t1 - t0; t0 = t1; }
+
+  // ---- carry the front step through threshold test and state machine --------------------------
+  if (has_front) {
+  int nvalid = (n - pos < 64) ? (n - pos) : 64;
+  const int nvalid_in = nvalid;
+  const bool valid = lane < nvalid;
+  const float thresh = avg * THRESH_FRACTION;  // gate_impl.cc:136
+  const uint64_t below = wv::ballot(valid && (f_amp < thresh));
+  const uint64_t above = wv::ballot(valid && (f_amp > thresh));
+  if (PROF) { wv::keep((int)(below ^ above)); t1 = wv::ticks(); tk[9] += t1 - t0; t0 = t1; }
+
+  // edge / pulse / window state machine on the scalar unit, event driven (gate_impl.cc:145-195)
   uint64_t closedmask = 0, openmask = 0;
-  int open_lane = -1;   // lane at which a window opened in this step (at most one when
-  int open_lane2 = -1;  // T1 > 64; the second slot keeps the code general)
-  int open_type = 0, open_type2 = 0;
+  int open_lane = -1, open_lane2 = -1, open_type = 0, open_type2 = 0;
   int f_n = g.f_n, f_state = g.f_state, f_pulses = g.f_pulses, f_open = g.f_open;
   int f_ung = g.f_ung, f_type = g.f_type;
   int p = 0;
-  while (p < nvalid) {
+  const uint64_t vmask = lane_range(0, nvalid);
+#if defined(RFID_ABLATE) && (RFID_ABLATE & 2)
+  closedmask = vmask; p = nvalid;
+#endif
+  // O(1) cases first: a step entirely inside a window, or a closed step without any event
+  if (p == nvalid) {
+  } else if (f_open) {
+    if (f_ung - f_n > nvalid) { openmask = vmask; f_n += nvalid; p = nvalid; }
+  } else if (f_state == 1) {
+    const bool may_open = (f_pulses > NUM_PULSES_CMD) && (T1_SAMPLES - f_n < nvalid);
+    if ((below & vmask) == 0 && !may_open) { closedmask = vmask; f_n += nvalid; p = nvalid; }
+  } else {
+    if ((above & vmask) == 0) { closedmask = vmask; f_n += nvalid; p = nvalid; }
+  }
+#if defined(RFID_ABLATE) && (RFID_ABLATE & 8)
+  if (p < nvalid) { closedmask = vmask; f_n += nvalid; p = nvalid; }
+#endif
+  while (p < nvalid) {   // general event-driven scan (a few percent of the steps)
     if (f_open) {
       int take = f_ung - f_n;
       if (take > nvalid - p) take = nvalid - p;
-      if (take <= 0) take = (f_n >= f_ung) ? 0 : 1;
+      if (take < 0) take = 0;
       openmask |= lane_range(p, p + take);
       f_n += take;
       p += take;
@@ -276,83 +432,123 @@ RFID_DEVICE void gate_step(const GateArgs &a, GateRegs &g, const float2 yv_in, i
   }
   g.f_n = f_n; g.f_state = f_state; g.f_pulses = f_pulses; g.f_open = f_open;
   g.f_ung = f_ung; g.f_type = f_type;
+  if (PROF) { wv::keep(f_n + p); t1 = wv::ticks(); tk[10] += t1 - t0; t0 = t1; }
+  g.avg_c = wv::readlane(avg, nvalid - 1);   // carry only over the samples actually consumed
+  if (PROF) { t1 = wv::ticks(); tk[2] += t1 - t0; t0 = t1; }
 
-  // ring / carry updates only for the samples actually consumed (lanes < nvalid)
-  if (lane < nvalid) lds_win[wi] = amp;
-  g.avg_c = wv::readlane(avg, nvalid - 1);
-  g.win_index += nvalid;
-  if (g.win_index >= WIN_LEN) g.win_index -= WIN_LEN;
-
-  // --- dc offset tracking over closed samples (gate_impl.cc:141-143) -----------------------
-  const bool isclosed = ((closedmask >> lane) & 1ull) != 0;
-  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const int rank = wv::popc64(closedmask & lt);
+  // ---- dc increments of the closed samples (gate_impl.cc:141-143) -> next back step ------------
+#if defined(RFID_ABLATE) && (RFID_ABLATE & 4)
+  const int cnt = 0;
+#else
   const int cnt = wv::popc64(closedmask);
-  if (isclosed) lds_tmp[rank] = yv;
-  wv::block_sync();
-  float2 old = make_float2(0.0f, 0.0f);
-  if (isclosed) {
-    if (rank < DC_LEN) {
+#endif
+  if (cnt == 0) {
+    // whole step inside a window: dc_est, ring and index untouched
+    B.tre = 0.0f; B.tim = 0.0f;
+    g.run_closed = 0;
+#if defined(RFID_ABLATE) && (RFID_ABLATE & 16)
+  } else if (true) {
+#else
+  } else if (cnt == 64 && openmask == 0 && nvalid_in == 64 && g.run_closed >= DC_LEN) {
+#endif
+    // fast path: the 48 samples before every lane were closed too, so dc_samples[dc_index]
+    // is x[i-48] and the producer's increments are the reference's
+    B.tre = f_tre; B.tim = f_tim;
+    g.dc_index += 64 - DC_LEN;            // (dc_index + 64) mod 48
+    if (g.dc_index >= DC_LEN) g.dc_index -= DC_LEN;
+    g.ring_stale = 1;
+    if (g.run_closed < (1 << 28)) g.run_closed += 64;
+  } else {
+    if (g.ring_stale) {
+      // the ring was not maintained on the fast path: its content is x[pos-48 .. pos-1]
+      // (= lanes 16..63 of the previous step), oldest at dc_index
+      if (lane >= 64 - DC_LEN) {
+        int di = g.dc_index + (lane - (64 - DC_LEN));
+        if (di >= DC_LEN) di -= DC_LEN;
+        lds_dc[di] = prev_yv;
+      }
+      g.ring_stale = 0;
+      wv::wave_sync();
+    }
+    const bool isclosed = ((closedmask >> lane) & 1ull) != 0;
+    const int rank = wv::popc64(closedmask & lt);
+    if (isclosed) lds_tmp[rank] = f_yv;
+    wv::wave_sync();
+    float2 old = make_float2(0.0f, 0.0f);
+    if (isclosed) {
+      if (rank < DC_LEN) {
+        int di = g.dc_index + rank;
+        if (di >= DC_LEN) di -= DC_LEN;
+        old = lds_dc[di];
+      } else {
+        old = lds_tmp[rank - DC_LEN];
+      }
+    }
+    B.tre = isclosed ? wv::fdiv(f_yv.x - old.x, DC_LEN_F) : 0.0f;
+    B.tim = isclosed ? wv::fdiv(f_yv.y - old.y, DC_LEN_F) : 0.0f;
+    wv::wave_sync();
+    if (isclosed && rank >= cnt - DC_LEN) {
       int di = g.dc_index + rank;
       if (di >= DC_LEN) di -= DC_LEN;
-      old = lds_dc[di];
+      if (di >= DC_LEN) di -= DC_LEN;
+      lds_dc[di] = f_yv;
+    }
+    wv::wave_sync();
+    g.dc_index += cnt;
+    if (g.dc_index >= DC_LEN) g.dc_index -= DC_LEN;
+    if (g.dc_index >= DC_LEN) g.dc_index -= DC_LEN;
+    // closed samples back-to-back up to the end of this step
+    const uint64_t notclosed = lane_range(0, nvalid) & ~closedmask;
+    if (notclosed == 0) {
+      if (g.run_closed < (1 << 28)) g.run_closed += nvalid;
     } else {
-      old = lds_tmp[rank - DC_LEN];
+      g.run_closed = nvalid - 1 - (63 - __builtin_clzll(notclosed));
     }
   }
-  const float tre = isclosed ? wv::fdiv(yv.x - old.x, DC_LEN_F) : 0.0f;
-  const float tim = isclosed ? wv::fdiv(yv.y - old.y, DC_LEN_F) : 0.0f;
-  wv::block_sync();
-  if (isclosed && rank >= cnt - DC_LEN) lds_dc[(g.dc_index + rank) % DC_LEN] = yv;
-  const float dcr = chain_add(g.dcr_c, tre, lane);
-  const float dci = chain_add(g.dci_c, tim, lane);
-  g.dcr_c = wv::readlane(dcr, 63);
-  g.dci_c = wv::readlane(dci, 63);
-  g.dc_index = (g.dc_index + cnt) % DC_LEN;
+  B.yv = f_yv; B.openmask = openmask;
+  B.open_lane = open_lane; B.open_type = open_type; B.open_lane2 = open_lane2; B.open_type2 = open_type2;
+  B.pos = pos;
+  B.has = true;
+  if (PROF) { t1 = wv::ticks(); tk[3] += t1 - t0; t0 = t1; }
+  }  // if (has_front)
 
-  // --- record openings --------------------------------------------------------------------
-  for (int q = 0; q < 2; ++q) {
-    const int ol = (q == 0) ? open_lane : open_lane2;
-    if (ol < 0) continue;
-    const float odr = wv::readlane(dcr, ol), odi = wv::readlane(dci, ol);
-    const int wtype = (q == 0) ? open_type : open_type2;
-    const int wlen = wtype ? EPC_WIN : RN16_WIN;
-    const int start = pos + ol;
-    if (a.mode == 0 && start + wlen <= n) {  // only complete windows reach the decoder (:223,:291)
-      if (lane == 0 && g.win_seq < a.wmax) {
-        rfid_window w;
-        w.stream = s; w.seq = g.win_seq; w.start = start; w.type = wtype;
-        w.dc_re = odr; w.dc_im = odi;
-        a.wtab[(int64_t)s * a.wmax + g.win_seq] = w;
-        if (a.flat) {
-          const int slot = wv::atomic_add(a.flat_count, 1);
-          if (slot < a.flat_cap) a.flat[slot] = w;
-        }
-      }
-      g.n_complete++;
-    }
-    g.win_seq++;
-  }
-
-  // --- streaming mode: emit gated samples in[i] - dc_est (gate_impl.cc:176,187) ------------
-  if (a.mode == 1) {
-    const bool isopen = ((openmask >> lane) & 1ull) != 0;
-    const int orank = wv::popc64(openmask & lt);
-    if (isopen && g.written + orank < a.gated_cap)
-      a.gated[g.written + orank] = make_float2(yv.x - dcr, yv.y - dci);
-    g.written += wv::popc64(openmask);
-  }
-  wv::block_sync();
+  RFID_GATE_PINS
+  if (PROF) { t1 = wv::ticks(); tk[4] += t1 - t0; t0 = wv::ticks(); tk[7] += t0 - t1; }
 }
 
-constexpr int GATE_PREFETCH = 4;  // steps (x64 samples) of matched-filter output held in registers
+// Workgroup = 8 waves = 4 traces: waves 0..3 are the consumers of traces 4b..4b+3, waves 4..7
+// their producers.  A workgroup's waves are placed round-robin over the CU's 4 SIMDs, so every
+// SIMD hosts exactly one consumer (DPP chains do not co-issue across waves) and one producer.
+// Producer and consumer of a trace talk through a 4-slot LDS ring with sequence counters --
+// no s_barrier, hence no coupling between the traces of a workgroup.
+constexpr int GATE_STREAMS_PER_WG = 4;
+constexpr int GATE_THREADS = 128 * GATE_STREAMS_PER_WG;
+constexpr int GATE_SLOTS = 4;
+constexpr int GATE_PREFETCH = 4;    // steps (x64 samples) of matched-filter output held in registers
 
-RFID_KERNEL(64) void gate_scan_kernel(GateArgs a) {
-  RFID_SHARED float lds_win[WIN_LEN + 4];
-  RFID_SHARED float2 lds_dc[DC_LEN];
-  RFID_SHARED float2 lds_tmp[64];
+struct GateShared {          // per trace
+  GateSlot slots[GATE_SLOTS];
+  float win[WIN_LEN + 4];    // producer's working copy of gate_impl::win_samples
+  float2 dc[DC_LEN];         // gate_impl::dc_samples
+  float2 tmp[64];
+  int prod_seq;              // steps produced so far
+  int cons_seq;              // steps consumed so far
+  int stop;                  // consumer -> producer: stop (streaming mode window close)
+  int pad_;
+};
+
+template <bool PROF>
+RFID_DEVICE void gate_scan_body(const GateArgs &a) {
+  RFID_SHARED GateShared sh_all[GATE_STREAMS_PER_WG];
   const int lane = wv::lane_id();
-  const int s = (int)blockIdx.x;
+  const int wave = wv::uniform((int)(threadIdx.x >> 6));
+  const int role = wave / GATE_STREAMS_PER_WG;           // 0 consumer, 1 producer
+  const int sl = wave % GATE_STREAMS_PER_WG;
+  const int s = (int)blockIdx.x * GATE_STREAMS_PER_WG + sl;
+  GateShared &sh = sh_all[sl];
+  if (lane == 0 && role == 0) { sh.prod_seq = 0; sh.cons_seq = 0; sh.stop = 0; }
+  wv::block_sync();   // once, before any hand-off
+  if (s >= a.n_streams) return;
   GateState *st = a.state + s;
   const float2 *ys = a.y + (int64_t)s * a.y_stride;
   int64_t n64 = a.n_dec;
@@ -362,61 +558,129 @@ RFID_KERNEL(64) void gate_scan_kernel(GateArgs a) {
     n64 = r / DECIM;
     if (n64 > a.n_dec) n64 = a.n_dec;
   }
-  const int n = (int)n64;
+  const int n = wv::uniform((int)n64);
+  const int nsteps = (n + 63) >> 6;
+  const int win_index0 = wv::uniform(st->win_index);
 
-  for (int j = lane; j < WIN_LEN; j += 64) lds_win[j] = st->win[j];
-  if (lane < DC_LEN) lds_dc[lane] = make_float2(st->dcr_re[lane], st->dcr_im[lane]);
-  GateRegs g;
-  g.avg_c = wv::uniform(st->avg_ampl);
-  g.dcr_c = wv::uniform(st->dc_re); g.dci_c = wv::uniform(st->dc_im);
-  g.f_n = wv::uniform(st->n_samples); g.f_state = wv::uniform(st->signal_state);
-  g.f_pulses = wv::uniform(st->num_pulses); g.f_open = wv::uniform(st->gate_open);
-  g.f_ung = wv::uniform(st->n_to_ungate); g.f_type = wv::uniform(st->wtype);
-  g.win_index = wv::uniform(st->win_index); g.dc_index = wv::uniform(st->dc_index);
-  g.win_seq = wv::uniform(st->win_seq);
-  if (g.f_ung == 0) g.f_ung = g.f_type ? EPC_WIN : RN16_WIN;  // fresh state: first window is an RN16
-  g.n_complete = 0; g.written = 0; g.consumed = n; g.stop = false;
-  wv::block_sync();
-
-  // register double buffer: while GATE_PREFETCH steps are processed, the loads of the next
-  // GATE_PREFETCH steps are already in flight (the scan itself is latency bound)
-  float2 cur[GATE_PREFETCH], nxt[GATE_PREFETCH];
-#pragma unroll
-  for (int u = 0; u < GATE_PREFETCH; ++u) {
-    const int i = 64 * u + lane;
-    cur[u] = (i < n) ? ys[i] : make_float2(0.0f, 0.0f);
-  }
-  for (int base = 0; base < n && !g.stop; base += 64 * GATE_PREFETCH) {
+  if (role == 1) {
+    // ================= producer ===============================================================
+    for (int j = lane; j < WIN_LEN; j += 64) sh.win[j] = st->win[j];
+    int win_index = win_index0;
+    wv::wave_sync();
+    float2 cur[GATE_PREFETCH], nxt[GATE_PREFETCH];
 #pragma unroll
     for (int u = 0; u < GATE_PREFETCH; ++u) {
-      const int i = base + 64 * (GATE_PREFETCH + u) + lane;
-      nxt[u] = (i < n) ? ys[i] : make_float2(0.0f, 0.0f);
+      const int i = 64 * u + lane;
+      cur[u] = (i < n) ? ys[i] : make_float2(0.0f, 0.0f);
     }
+    float2 prev_yv = make_float2(0.0f, 0.0f);
+    bool stopped = false;
+    for (int base = 0; base < nsteps && !stopped; base += GATE_PREFETCH) {
 #pragma unroll
-    for (int u = 0; u < GATE_PREFETCH; ++u) {
-      const int pos = base + 64 * u;
-      if (pos < n && !g.stop) gate_step(a, g, cur[u], pos, n, s, lane, lds_win, lds_dc, lds_tmp);
+      for (int u = 0; u < GATE_PREFETCH; ++u) {
+        const int i = 64 * (base + GATE_PREFETCH + u) + lane;
+        nxt[u] = (i < n) ? ys[i] : make_float2(0.0f, 0.0f);
+      }
+#pragma unroll
+      for (int u = 0; u < GATE_PREFETCH; ++u) {
+        const int k = base + u;
+        if (k < nsteps && !stopped) {
+          // wait for a free slot (the consumer is at most GATE_SLOTS steps behind)
+          while (!stopped && k - wv::lds_load(&sh.cons_seq) >= GATE_SLOTS) {
+            stopped = wv::lds_load(&sh.stop) != 0;
+            wv::backoff();
+          }
+          if (!stopped) {
+            gate_produce(sh.slots[k % GATE_SLOTS], cur[u], prev_yv, 64 * k, n, lane, sh.win, win_index);
+            wv::lds_store(&sh.prod_seq, k + 1, lane);   // after the slot's data (in-order LDS queue)
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < GATE_PREFETCH; ++u) cur[u] = nxt[u];
     }
-#pragma unroll
-    for (int u = 0; u < GATE_PREFETCH; ++u) cur[u] = nxt[u];
-  }
+  } else {
+    // ================= consumer ===============================================================
+    // the consumer owns the critical path (dependent DPP adds): it must win VALU arbitration
+    // against the producer wave that shares its SIMD
+    wv::set_priority_high();
+    float2 *lds_dc = sh.dc, *lds_tmp = sh.tmp;
+    if (lane < DC_LEN) lds_dc[lane] = make_float2(st->dcr_re[lane], st->dcr_im[lane]);
+    GateRegs g;
+    g.avg_c = wv::uniform(st->avg_ampl);
+    g.dcr_c = wv::uniform(st->dc_re); g.dci_c = wv::uniform(st->dc_im);
+    g.f_n = wv::uniform(st->n_samples); g.f_state = wv::uniform(st->signal_state);
+    g.f_pulses = wv::uniform(st->num_pulses); g.f_open = wv::uniform(st->gate_open);
+    g.f_ung = wv::uniform(st->n_to_ungate); g.f_type = wv::uniform(st->wtype);
+    g.dc_index = wv::uniform(st->dc_index);
+    g.win_seq = wv::uniform(st->win_seq);
+    if (g.f_ung == 0) g.f_ung = g.f_type ? EPC_WIN : RN16_WIN;  // fresh state: first window is an RN16
+    g.run_closed = 0; g.ring_stale = 0;
+    g.n_complete = 0; g.written = 0; g.consumed = n; g.stop = false;
+    long long tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const long long t_start = PROF ? wv::ticks() : 0;
+    GateBack B;
+    B.has = false; B.tre = 0.0f; B.tim = 0.0f; B.openmask = 0; B.yv = make_float2(0.0f, 0.0f);
+    B.open_lane = B.open_lane2 = -1; B.open_type = B.open_type2 = 0; B.pos = 0;
+    wv::wave_sync();
+    for (int k = 0; k < nsteps && !g.stop; ++k) {
+      long long tb = 0;
+      if (PROF) tb = wv::ticks();
+      while (wv::lds_load(&sh.prod_seq) <= k) wv::backoff();   // step k produced?
+      if (PROF) tk[5] += wv::ticks() - tb;
+      gate_consume<PROF>(a, g, B, &sh.slots[k % GATE_SLOTS], true, 64 * k, n, s, lane, lds_dc, lds_tmp, tk);
+      wv::lds_store(&sh.cons_seq, k + 1, lane);   // slot k free again (its data are in registers)
+    }
+    if (g.stop) wv::lds_store(&sh.stop, 1, lane);
+    // drain: finish the pending back half (window records / gated output of the last step)
+    if (B.has) gate_consume<PROF>(a, g, B, &sh.slots[0], false, 0, n, s, lane, lds_dc, lds_tmp, tk);
+    if (PROF && a.prof && lane == 0) {
+      tk[6] = wv::ticks() - t_start;
+      for (int i = 0; i < 12; ++i) a.prof[(int64_t)s * 12 + i] = tk[i];
+    }
 
-  // --- write state back -------------------------------------------------------------------
-  for (int j = lane; j < WIN_LEN; j += 64) st->win[j] = lds_win[j];
-  if (lane < DC_LEN) { st->dcr_re[lane] = lds_dc[lane].x; st->dcr_im[lane] = lds_dc[lane].y; }
-  if (lane == 0) {
-    st->avg_ampl = g.avg_c; st->dc_re = g.dcr_c; st->dc_im = g.dci_c;
-    st->n_samples = g.f_n; st->signal_state = g.f_state; st->num_pulses = g.f_pulses;
-    st->gate_open = g.f_open; st->n_to_ungate = g.f_ung; st->wtype = g.f_type;
-    st->win_index = g.win_index; st->dc_index = g.dc_index; st->win_seq = g.win_seq;
-    if (a.mode == 0) {
-      a.wcount[s] = (g.n_complete < a.wmax) ? g.n_complete : a.wmax;
-    } else {
-      a.io[0] = g.consumed;
-      a.io[1] = g.written;
+    // ---- write state back ----------------------------------------------------------------
+    if (g.ring_stale) {
+      // materialise the dc ring: the last 48 consumed samples, oldest at dc_index
+      if (lane < DC_LEN) {
+        int di = g.dc_index + lane;
+        if (di >= DC_LEN) di -= DC_LEN;
+        lds_dc[di] = ys[g.consumed - DC_LEN + lane];
+      }
+      wv::wave_sync();
+    }
+    if (lane < DC_LEN) { st->dcr_re[lane] = lds_dc[lane].x; st->dcr_im[lane] = lds_dc[lane].y; }
+    // amplitude ring: the last min(100, consumed) samples of this call overwrite their slots
+    // (the producer read st->win before it produced step 0, i.e. long before this point --
+    // except for an empty call, which writes nothing here)
+    {
+      const int c = g.consumed;
+      const int first = (c > WIN_LEN) ? (c - WIN_LEN) : 0;
+      for (int i = first + lane; i < c; i += 64) {
+        const float2 v = ys[i];
+        st->win[(win_index0 + i) % WIN_LEN] = wv::hypot_f(v.x, v.y);
+      }
+    }
+    if (lane == 0) {
+      st->avg_ampl = g.avg_c; st->dc_re = g.dcr_c; st->dc_im = g.dci_c;
+      st->n_samples = g.f_n; st->signal_state = g.f_state; st->num_pulses = g.f_pulses;
+      st->gate_open = g.f_open; st->n_to_ungate = g.f_ung; st->wtype = g.f_type;
+      st->win_index = (win_index0 + g.consumed) % WIN_LEN; st->dc_index = g.dc_index; st->win_seq = g.win_seq;
+      if (a.mode == 0) {
+        a.wcount[s] = (g.n_complete < a.wmax) ? g.n_complete : a.wmax;
+      } else {
+        a.io[0] = g.consumed;
+        a.io[1] = g.written;
+      }
     }
   }
 }
+
+RFID_KERNEL(GATE_THREADS) void gate_scan_kernel(GateArgs a) { gate_scan_body<false>(a); }
+// same kernel with s_memtime phase counters of the consumer wave (a.prof: [n_streams][8]):
+// 0 slot read + in-order sums, 1 finish back step, 2 threshold + state machine,
+// 3 dc increments, 4 SGPR pinning, 5 waiting for the producer, 6 total
+RFID_KERNEL(GATE_THREADS) void gate_scan_kernel_prof(GateArgs a) { gate_scan_body<true>(a); }
 
 // =========================================================================================
 // 3. tag_decoder: one wavefront per window, persistent over the compact window list.
@@ -517,7 +781,7 @@ RFID_KERNEL(64) void decode_windows_kernel(DecodeArgs a) {
     const float2 *src = a.y + (int64_t)wv::uniform(wd.stream) * a.y_stride + wv::uniform(wd.start);
     if (type == RFID_DECODE_EPC) stage_window<EPC_WIN>(src, dcr, dci, s, m2, lane);
     else stage_window<RN16_WIN>(src, dcr, dci, s, m2, lane);
-    wv::block_sync();
+    wv::wave_sync();
 
     // ---- tag_sync (tag_decoder_impl.cc:78-109): 15 offsets x 6 non-zero preamble taps -----
     float cre = 0.0f, cim = 0.0f;
@@ -616,7 +880,7 @@ RFID_KERNEL(64) void decode_windows_kernel(DecodeArgs a) {
       if (lane < N_SYNC) sc->corr[lane] = corr;
       if (lane < N_TCAND) sc->energy[lane] = energy;
     }
-    wv::block_sync();
+    wv::wave_sync();
   }
 }
 

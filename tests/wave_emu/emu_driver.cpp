@@ -120,11 +120,11 @@ int emu_batch_process(const float *raw, int B, long stride, long n_raw, const in
     for (int b = 0; b < B; ++b) memcpy(y_out + 2 * (size_t)b * n_dec, y + (size_t)b * y_stride, sizeof(float2) * (size_t)n_dec);
 
   GateArgs ga;
-  ga.y = y; ga.y_stride = y_stride; ga.n_dec = n_dec; ga.lens = lens; ga.state = gstate.data();
+  ga.y = y; ga.y_stride = y_stride; ga.n_dec = n_dec; ga.lens = lens; ga.state = gstate.data(); ga.n_streams = B;
   ga.wtab = wtab.data(); ga.wmax = wmax; ga.wcount = wcount.data(); ga.flat = flat.data();
   ga.flat_count = &flat_count; ga.flat_cap = flat_cap; ga.mode = 0; ga.gated = nullptr; ga.gated_cap = 0;
-  ga.io = nullptr;
-  emu::launch(emu::Idx3{(unsigned)B, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { gate_scan_kernel(ga); });
+  ga.io = nullptr; ga.prof = nullptr;
+  emu::launch(emu::Idx3{(unsigned)((B + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG), 1, 1}, emu::Idx3{GATE_THREADS, 1, 1}, [&]() { gate_scan_kernel(ga); });
 
   DecodeArgs da;
   da.y = y; da.y_stride = y_stride; da.flat = flat.data(); da.flat_count = &flat_count; da.flat_cap = flat_cap;
@@ -169,10 +169,10 @@ int emu_gate_stream(void *state_blob, const float *in, int n_in, int seek_type, 
   if (n_in > 0) {
     GateArgs ga;
     ga.y = reinterpret_cast<const float2 *>(in); ga.y_stride = n_in; ga.n_dec = n_in; ga.lens = nullptr;
-    ga.state = st; ga.wtab = nullptr; ga.wmax = 0; ga.wcount = nullptr; ga.flat = nullptr;
+    ga.state = st; ga.n_streams = 1; ga.wtab = nullptr; ga.wmax = 0; ga.wcount = nullptr; ga.flat = nullptr;
     ga.flat_count = nullptr; ga.flat_cap = 0; ga.mode = 1; ga.gated = reinterpret_cast<float2 *>(out);
-    ga.gated_cap = n_in; ga.io = io;
-    emu::launch(emu::Idx3{1, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { gate_scan_kernel(ga); });
+    ga.gated_cap = n_in; ga.io = io; ga.prof = nullptr;
+    emu::launch(emu::Idx3{1, 1, 1}, emu::Idx3{GATE_THREADS, 1, 1}, [&]() { gate_scan_kernel(ga); });
   }
   *consumed = io[0];
   *written = io[1];

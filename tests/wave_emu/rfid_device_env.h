@@ -141,6 +141,15 @@ static inline void block_sync() {
     while (B->block_gen <= my) emu::yield();
   }
 }
+static inline void wave_sync() { emu::wave_barrier(); }
+static inline void block_sync_lds() { block_sync(); }
+static inline int lds_load(const int *p) { return *(const volatile int *)p; }
+static inline void lds_store(int *p, int v, int lane) { emu::wave_barrier(); if (lane == 0) *(volatile int *)p = v; }
+static inline void set_priority_high() {}
+static inline void backoff() { emu::yield(); }
+static inline void keep(float) {}
+static inline void keep(int) {}
+static inline long long ticks() { return 0; }
 static inline int atomic_add(int *p, int v) { int o = *p; *p = o + v; return o; }
 
 }  // namespace wv
