@@ -1,0 +1,107 @@
+"""Pins for the CPU oracle (oracle/rfid_oracle.c).  The reference ships no golden vectors for
+this path and cannot be built in this image ("parity unpinned", see oracle/rfid_oracle.h), so
+the oracle is anchored on: published constants, the generator's ground truth, the README's
+known-answer shape, self-consistency across scheduler chunk sizes, and committed fixtures."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def test_crc16_published_check_value(oracle_mod):
+    # CRC-16/GENIBUS (poly 0x1021, init 0xFFFF, xorout 0xFFFF, no reflection) check("123456789") = 0xD64E;
+    # this is the EPC Gen2 CRC-16 that check_crc implements (tag_decoder_impl.cc:401-445)
+    assert oracle_mod.lib().orc_crc16_bytes(b"123456789", 9) == 0xD64E
+
+
+def test_check_crc_accepts_valid_and_rejects_flipped_frames(oracle_mod, synth_mod):
+    frame = synth_mod.epc_frame(synth_mod.epc_for_id(0x27))
+    s = "".join("1" if b else "0" for b in frame).encode()
+    assert oracle_mod.lib().orc_check_crc(s, 128) == 1
+    for pos in (0, 17, 111, 112, 127):
+        f = list(frame)
+        f[pos] ^= 1
+        assert oracle_mod.lib().orc_check_crc("".join("1" if b else "0" for b in f).encode(), 128) == -1
+
+
+def test_half_period_candidates_match_baseline_md(oracle_mod, synth_mod):
+    # BASELINE.md section 5 lists the 20 float32 candidates of tag_decoder_impl.cc:151-166
+    expected = [4.94999981, 4.95526314, 4.96052599, 4.96578932, 4.97105265, 4.97631550, 4.98157883, 4.98684216,
+                4.99210501, 4.99736834, 5.00263166, 5.00789499, 5.01315784, 5.01842117, 5.02368450, 5.02894735,
+                5.03421068, 5.03947401, 5.04473686, 5.05000019]
+    mn, mx = np.float32(10.0 / 2.0 - 10.0 / 2.0 / 100), np.float32(10.0 / 2.0 + 10.0 / 2.0 / 100)
+    cand = [np.float32(mn + np.float32(np.float32(t) * np.float32(mx - mn)) / np.float32(19)) for t in range(20)]
+    assert np.allclose(cand, expected, rtol=0, atol=5e-8)
+    # every T the oracle reports is one of them
+    o = oracle_mod.run_trace(synth_mod.make_trace(n_rounds=3, seed=3).samples)
+    for d in o.dumps[o.dumps["type"] == 1]:
+        assert any(d["T"] == c for c in cand)
+
+
+@pytest.mark.parametrize("sigma", [0.002, 0.03, 0.06])
+def test_oracle_decodes_generator_truth(oracle_mod, synth_mod, sigma):
+    t = synth_mod.make_trace(n_rounds=6, sigma=sigma, seed=int(sigma * 1000) + 5, t1_jitter_raw=8)
+    o = oracle_mod.run_trace(t.samples)
+    assert o.n_windows == 2 * len(t.slots)
+    for k, s in enumerate(t.slots):
+        assert list(o.dumps[2 * k]["bits"][:16]) == s.rn16
+        assert list(o.dumps[2 * k + 1]["bits"]) == s.epc and o.dumps[2 * k + 1]["crc_ok"] == 1
+        assert o.dumps[2 * k + 1]["tag_id"] == 0x27
+    assert o.state.n_epc_correct == 6 and o.state.n_queries_sent == 7
+
+
+def test_readme_known_answer_shape(oracle_mod, synth_mod):
+    # README.md:48-53 on the stand-in for the missing misc/data/file_source_test
+    o = oracle_mod.run_trace(synth_mod.fst_like_trace().samples)
+    assert o.print_results() == ("\n --------------------------\n"
+                                 "| Number of queries/queryreps sent : 71\n"
+                                 "| Current Inventory round : 72\n"
+                                 " --------------------------\n"
+                                 "| Correctly decoded EPC : 70\n"
+                                 "| Number of unique tags : 1\n"
+                                 "| Tag ID : 27  Num of reads : 70\n"
+                                 " --------------------------\n")
+
+
+def test_scheduler_chunk_invariance(oracle_mod, synth_mod):
+    t = synth_mod.make_trace(n_rounds=4, sigma=0.02, seed=9).samples
+    ref = oracle_mod.run_trace(t, chunk=4096)
+    for chunk in (1, 63, 512, 777, 1500, 8191):
+        o = oracle_mod.run_trace(t, chunk=chunk)
+        assert o.stats() == ref.stats()
+        assert np.array_equal(o.dumps, ref.dumps) and np.array_equal(o.open_idx, ref.open_idx)
+        assert np.array_equal(o.dc.view(np.uint32), ref.dc.view(np.uint32))
+
+
+def test_streaming_fir_equals_batch_fir(oracle_mod, synth_mod):
+    x = synth_mod.make_trace(n_rounds=1, seed=2).samples[:5003]
+    L = oracle_mod.lib()
+    L.orc_fir_stream.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+    L.orc_fir_stream.restype = C.c_long
+    hist = np.zeros(24, dtype=np.complex64)
+    phase = C.c_int(0)
+    out = []
+    pos = 0
+    for n in (1, 4, 5, 23, 24, 25, 1000, 3921):
+        blk = np.ascontiguousarray(x[pos:pos + n])
+        y = np.zeros(n // 5 + 2, dtype=np.complex64)
+        k = L.orc_fir_stream(blk.ctypes.data, len(blk), y.ctypes.data, hist.ctypes.data, C.byref(phase))
+        out.append(y[:k])
+        pos += n
+    got = np.concatenate(out)
+    ref = oracle_mod.fir(x[:pos])
+    assert np.array_equal(got[: len(ref)].view(np.uint32), ref.view(np.uint32))
+
+
+def test_fixed_q_rounds_and_termination(oracle_mod, synth_mod):
+    t = synth_mod.make_trace(n_rounds=3, fixed_q=2, tag_ids=(1, 2, 3), seed=4).samples
+    o = oracle_mod.run_trace(t, oracle_mod.config(fixed_q=2))
+    assert o.n_windows == 2 * 12 and o.state.cur_inventory_round == 4 and o.state.n_queries_sent == 13
+    o2 = oracle_mod.run_trace(t, oracle_mod.config(fixed_q=2, max_num_queries=5))
+    assert o2.state.status == 1 and o2.state.n_queries_sent == 6   # TERMINATED after the 6th query
+
+
+def test_empty_and_tiny_inputs(oracle_mod):
+    for n in (0, 1, 4, 5, 24):
+        o = oracle_mod.run_trace(np.zeros(n, dtype=np.complex64))
+        assert o.n_windows == 0 and o.state.n_queries_sent == 1
