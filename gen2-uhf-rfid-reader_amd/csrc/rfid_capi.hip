@@ -339,18 +339,18 @@ int rfid_batch_plan(rfid_ctx *c, int n_streams, int64_t max_raw) {
   HIPCHK(c, hipMalloc((void **)&c->d_y, sizeof(float2) * (size_t)c->y_stride * n_streams));
   HIPCHK(c, hipMalloc((void **)&c->d_gstate, sizeof(GateState) * (size_t)n_streams));
   HIPCHK(c, hipMalloc((void **)&c->d_wtab, sizeof(rfid_window) * (size_t)c->flat_cap));
-  HIPCHK(c, hipMalloc((void **)&c->d_flat, sizeof(rfid_window) * (size_t)c->flat_cap));
+  HIPCHK(c, hipMalloc((void **)&c->d_flat, sizeof(rfid_window) * 2 * (size_t)c->flat_cap));
   HIPCHK(c, hipMalloc((void **)&c->d_wcount, sizeof(int) * (size_t)n_streams));
-  HIPCHK(c, hipMalloc((void **)&c->d_flat_count, sizeof(int)));
+  HIPCHK(c, hipMalloc((void **)&c->d_flat_count, 2 * sizeof(int)));
   HIPCHK(c, hipMalloc((void **)&c->d_res, sizeof(rfid_decode_result) * (size_t)c->flat_cap));
   HIPCHK(c, hipMalloc((void **)&c->d_scores, sizeof(rfid_scores) * (size_t)c->flat_cap));
   HIPCHK(c, hipMalloc((void **)&c->d_stats, sizeof(rfid_stream_stats) * (size_t)n_streams));
   HIPCHK(c, hipMemset(c->d_wcount, 0, sizeof(int) * (size_t)n_streams));
-  HIPCHK(c, hipMemset(c->d_flat_count, 0, sizeof(int)));
+  HIPCHK(c, hipMemset(c->d_flat_count, 0, 2 * sizeof(int)));
   hipDeviceProp_t prop;
   HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
-  // persistent decoder: 9 single-wave workgroups fit one CU's 160 KiB LDS (16.5 KiB each)
-  c->decode_grid = prop.multiProcessorCount * 9;
+  // persistent decoders: the EPC kernel holds 18.6 KiB of LDS per single-wave workgroup -> 8 per CU
+  c->decode_grid = prop.multiProcessorCount * 8;
   for (int i = 0; i < 5; ++i) c->ev_valid[i] = false;
   return RFID_OK;
 }
@@ -386,7 +386,7 @@ int rfid_batch_gate(rfid_ctx *c) {
   // fresh gate per trace (gate_impl ctor, gate_impl.cc:41-70): all-zero state; the kernel
   // arms n_samples_to_ungate for the first RN16 itself
   HIPCHK(c, hipMemsetAsync(c->d_gstate, 0, sizeof(GateState) * (size_t)c->B, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->d_flat_count, 0, sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_flat_count, 0, 2 * sizeof(int), c->stream));
   GateArgs a;
   a.y = c->d_y; a.y_stride = c->y_stride; a.n_dec = c->last_n_raw / DECIM; a.lens = c->d_lens;
   a.state = c->d_gstate; a.n_streams = c->B; a.wtab = c->d_wtab; a.wmax = c->wmax; a.wcount = c->d_wcount;
@@ -418,16 +418,20 @@ int rfid_batch_decode(rfid_ctx *c, int want_scores) {
   if (!c) return RFID_ERR_INVALID;
   if (!c->B) return RFID_ERR_STATE;
   HIPCHK(c, hipSetDevice(c->device));
-  DecodeArgs a;
-  a.y = c->d_y; a.y_stride = c->y_stride; a.flat = c->d_flat; a.flat_count = c->d_flat_count;
-  a.flat_cap = c->flat_cap; a.res = c->d_res; a.scores = want_scores ? c->d_scores : nullptr;
-  a.wmax = c->wmax;
+  DecodeListArgs a;
+  a.y = c->d_y; a.y_stride = c->y_stride; a.cap = c->flat_cap; a.res = c->d_res;
+  a.scores = want_scores ? c->d_scores : nullptr; a.wmax = c->wmax;
   memcpy(a.t_cand, c->t_cand, sizeof(a.t_cand));
   if (!c->ev_valid[2]) { HIPCHK(c, hipEventRecord(c->ev[2], c->stream)); c->ev_valid[2] = true; }
   int grid = c->decode_grid;
-  if (grid > c->flat_cap) grid = c->flat_cap;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(decode_windows_kernel, dim3((unsigned)grid), dim3(64), 0, c->stream, a);
+  // EPC windows: 3 per wavefront
+  a.list = c->d_flat + c->flat_cap; a.count = c->d_flat_count + 1;
+  hipLaunchKernelGGL(decode_epc3_kernel, dim3((unsigned)grid), dim3(64), 0, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  // RN16 windows: 4 per wavefront
+  a.list = c->d_flat; a.count = c->d_flat_count;
+  hipLaunchKernelGGL(decode_rn16x4_kernel, dim3((unsigned)(grid * 2)), dim3(64), 0, c->stream, a);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   c->ev_valid[3] = true;

@@ -151,9 +151,9 @@ struct GateArgs {
   rfid_window *wtab;    // [n_streams][wmax]
   int wmax;
   int *wcount;          // [n_streams] complete windows recorded
-  rfid_window *flat;    // compact list over all traces (arbitrary order) for the decoder
-  int *flat_count;
-  int flat_cap;
+  rfid_window *flat;    // compact lists over all traces (arbitrary order) for the decoder:
+  int *flat_count;      //   flat[0 .. flat_cap) RN16 windows, flat[flat_cap .. 2*flat_cap) EPC windows,
+  int flat_cap;         //   flat_count[0] / flat_count[1] their device counters
   int mode;             // 0 batch (self re-arming), 1 streaming (stop after close)
   float2 *gated;        // streaming: gated, DC-removed samples
   int gated_cap;
@@ -275,8 +275,8 @@ RFID_DEVICE void gate_record_window(const GateArgs &a, GateRegs &g, int ol, int 
       w.dc_re = odr; w.dc_im = odi;
       a.wtab[(int64_t)s * a.wmax + g.win_seq] = w;
       if (a.flat) {
-        const int slotw = wv::atomic_add(a.flat_count, 1);
-        if (slotw < a.flat_cap) a.flat[slotw] = w;
+        const int slotw = wv::atomic_add(a.flat_count + wtype, 1);
+        if (slotw < a.flat_cap) a.flat[(int64_t)wtype * a.flat_cap + slotw] = w;
       }
     }
     g.n_complete++;
@@ -881,6 +881,324 @@ RFID_KERNEL(64) void decode_windows_kernel(DecodeArgs a) {
       if (lane < N_TCAND) sc->energy[lane] = energy;
     }
     wv::wave_sync();
+  }
+}
+
+// -----------------------------------------------------------------------------------------
+// 3b. Batched decoders, one launch per window type (the gate writes two compact lists).
+//
+// decode_epc3_kernel: THREE EPC windows per wavefront.  The cost of an EPC window is the
+// half-period search: 20 candidates x 256 strictly sequential gathers.  One window keeps only
+// 20 of 64 lanes busy, three keep 60.  Only what is gathered often is staged in LDS -- the
+// squared magnitudes (5.5 KB / window) and the first 72 samples for the preamble correlation;
+// the 256 half-bit samples of the final decision are re-gathered from global memory (they
+// were streamed through this CU's L2 microseconds earlier).  18.6 KB LDS per wave -> 8 waves
+// per CU, each with up to two windows of loads in flight.
+// -----------------------------------------------------------------------------------------
+struct DecodeListArgs {
+  const float2 *y;
+  int64_t y_stride;
+  const rfid_window *list;  // compact list of one window type
+  const int *count;         // device counter; clamped to cap
+  int cap;
+  rfid_decode_result *res;  // [n_streams][wmax]
+  rfid_scores *scores;      // nullable
+  int wmax;
+  float t_cand[N_TCAND];
+};
+
+constexpr int EPC_PACK = 3;
+constexpr int EPC_GRP = N_TCAND;            // 20 lanes per window
+constexpr int EPC_M2_STRIDE = EPC_WIN + 6;  // 1376
+constexpr int SYNC_KEEP = 72;               // samples 0..69 are touched by tag_sync
+
+template <int K0>
+RFID_DEVICE void epc_load_regs(const float2 *src, float2 (&v)[(EPC_WIN + 63) / 64], int lane, bool on) {
+#pragma unroll
+  for (int k = 0; k < (EPC_WIN + 63) / 64; ++k) {
+    const int j = lane + 64 * k;
+    v[k] = (on && j < EPC_WIN) ? src[j] : make_float2(0.0f, 0.0f);
+  }
+}
+
+RFID_DEVICE void epc_stage_regs(const float2 (&v)[(EPC_WIN + 63) / 64], float dcr, float dci, float *m2,
+                                float2 *sy, int lane) {
+#pragma unroll
+  for (int k = 0; k < (EPC_WIN + 63) / 64; ++k) {
+    const int j = lane + 64 * k;
+    if (j < EPC_WIN) {
+      const float re = v[k].x - dcr, im = v[k].y - dci;   // gate output in[i] - dc_est
+      m2[j] = re * re + im * im;                          // std::norm   (gate_impl.cc:175,186)
+      if (k == 0 || (k == 1 && j < SYNC_KEEP)) sy[j] = make_float2(re, im);
+    }
+  }
+}
+
+struct EpcPackDesc {   // wave-uniform description of one pack of (up to) three EPC windows
+  const float2 *src[EPC_PACK];
+  float dcr[EPC_PACK], dci[EPC_PACK];
+  int64_t slot[EPC_PACK];
+  bool on[EPC_PACK];
+};
+
+// descriptor fetch is split in two so that the (vector-memory) loads can be issued two packs
+// ahead and turned into wave-uniform values only when they have long arrived
+RFID_DEVICE void epc_fetch_raw(const DecodeListArgs &a, int pk, int total, rfid_window (&raw)[EPC_PACK]) {
+  const int w0 = pk * EPC_PACK;
+#pragma unroll
+  for (int q = 0; q < EPC_PACK; ++q) {
+    const int w = w0 + q;
+    raw[q] = a.list[(w < total) ? w : ((w0 < total) ? w0 : 0)];
+  }
+}
+
+RFID_DEVICE void epc_uniformize(const DecodeListArgs &a, int pk, int total, const rfid_window (&raw)[EPC_PACK],
+                                EpcPackDesc &d) {
+  const int w0 = pk * EPC_PACK;
+#pragma unroll
+  for (int q = 0; q < EPC_PACK; ++q) {
+    d.on[q] = (w0 + q) < total;
+    const int stream = wv::uniform(raw[q].stream);
+    d.src[q] = a.y + (int64_t)stream * a.y_stride + wv::uniform(raw[q].start);
+    d.dcr[q] = wv::uniform(raw[q].dc_re);
+    d.dci[q] = wv::uniform(raw[q].dc_im);
+    d.slot[q] = (int64_t)stream * a.wmax + wv::uniform(raw[q].seq);
+  }
+}
+
+RFID_KERNEL(64) void decode_epc3_kernel(DecodeListArgs a) {
+  RFID_SHARED float m2[EPC_PACK * EPC_M2_STRIDE];   // |x|^2 of the 3 windows; later reused as complex samples
+  RFID_SHARED float2 sy[EPC_PACK * SYNC_KEEP];
+  RFID_SHARED float sc0[64];
+  RFID_SHARED float sc1[64];
+  RFID_SHARED float sc2[64];
+  const int lane = wv::lane_id();
+  int total = wv::uniform(*a.count);
+  if (total > a.cap) total = a.cap;
+  const int g = lane / EPC_GRP;          // window of this lane within the pack (3 = idle lanes 60..63)
+  const int t = lane - g * EPC_GRP;      // candidate / offset index
+  const bool lane_on = g < EPC_PACK;
+  const int n_packs = (total + EPC_PACK - 1) / EPC_PACK;
+  const int stride = (int)gridDim.x;
+  constexpr int NV = (EPC_WIN + 63) / 64;
+  // per-lane constants fetched once (no vector-memory load inside the search/decision phases)
+  const float my_Tt = a.t_cand[(t < N_TCAND) ? t : 0];
+  const unsigned crc_lo = g_crc16.c[lane];
+  const unsigned crc_hi = (lane < 48) ? g_crc16.c[lane + 64] : 0u;
+  const unsigned crc_k = g_crc16.k;
+
+  int pk = (int)blockIdx.x;
+  if (pk >= n_packs) return;
+  EpcPackDesc cur;
+  rfid_window rawN[EPC_PACK];
+  epc_fetch_raw(a, pk, total, rawN);
+
+  while (pk < n_packs) {
+    const int pk_next = pk + stride;
+    epc_uniformize(a, pk, total, rawN, cur);
+    // ---- the pack's windows are read from HBM exactly once, into registers --------------------
+    float2 v0[NV], v1[NV], v2[NV];
+    epc_load_regs<0>(cur.src[0], v0, lane, cur.on[0]);
+    epc_load_regs<1>(cur.src[1], v1, lane, cur.on[1]);
+    epc_load_regs<2>(cur.src[2], v2, lane, cur.on[2]);
+    if (pk_next < n_packs) epc_fetch_raw(a, pk_next, total, rawN);   // descriptors one pack ahead
+    // ---- stage |x|^2 and the sync samples -----------------------------------------------------
+    epc_stage_regs(v0, cur.dcr[0], cur.dci[0], m2, sy, lane);
+    epc_stage_regs(v1, cur.dcr[1], cur.dci[1], m2 + EPC_M2_STRIDE, sy + SYNC_KEEP, lane);
+    epc_stage_regs(v2, cur.dcr[2], cur.dci[2], m2 + 2 * EPC_M2_STRIDE, sy + 2 * SYNC_KEEP, lane);
+    wv::wave_sync();
+
+    // ---- tag_sync per window: lane (g,t<15) sums the 6 non-zero preamble taps (:78-99) --------
+    float cre = 0.0f, cim = 0.0f;
+    if (lane_on && t < N_SYNC) {
+      const float2 *sg = sy + g * SYNC_KEEP;
+      const int taps[6] = {0, 5, 15, 30, 50, 55};
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const float2 v = sg[t + taps[k]];
+        cre = cre + v.x;
+        cim = cim + v.y;
+      }
+    }
+    const float corr = cre * cre + cim * cim;
+    sc0[lane] = corr; sc1[lane] = cre; sc2[lane] = cim;
+    wv::wave_sync();
+    int m_idx = 0;
+    float hre = 0.0f, him = 0.0f;
+    if (lane_on) {
+      float best = 0.0f;                       // the reference's scan: if (corr > max) ... from max = 0
+      const int gb = g * EPC_GRP;
+#pragma unroll
+      for (int j = 0; j < N_SYNC; ++j) {
+        const float v = sc0[gb + j];
+        if (v > best) { best = v; m_idx = j; }
+      }
+      hre = wv::fdiv(sc1[gb + m_idx], 6.0f);   // :103
+      him = wv::fdiv(sc2[gb + m_idx], 6.0f);
+    }
+    const int index = m_idx + 65;              // :107
+    const float findex = (float)index;
+    wv::wave_sync();
+
+    // ---- half-period search (:150-166): lane (g,t) sums 256 squared magnitudes in order -------
+    float energy = 0.0f;
+    if (lane_on) {
+      const float Tt = my_Tt;
+      const float *mg = m2 + g * EPC_M2_STRIDE;
+#pragma unroll 16
+      for (int i = 0; i < 256; ++i) {
+        const float pos = (float)i * Tt + findex;
+        energy = energy + mg[wv::f2i(pos)];
+      }
+    }
+    sc0[lane] = energy;
+    wv::wave_sync();
+    int t_idx = 0;
+    if (lane_on) {
+      const int gb = g * EPC_GRP;
+      float best = sc0[gb];                    // std::max_element: first largest (:165)
+#pragma unroll
+      for (int j = 1; j < N_TCAND; ++j) {
+        const float v = sc0[gb + j];
+        if (best < v) { best = v; t_idx = j; }
+      }
+    }
+    const float T_lane = wv::shfl(my_Tt, (lane_on ? g * EPC_GRP : 0) + t_idx);   // t_cand[t_idx]
+    wv::wave_sync();   // all three searches done: the |x|^2 area is free
+
+    // ---- per window: rewrite it as complex samples into LDS, gather the 2 x 128 half-bit
+    //      samples from there (:171-190), CRC-16 (:401-445), result ---------------------------
+    float2 *cs = reinterpret_cast<float2 *>(m2);
+#pragma unroll
+    for (int q = 0; q < EPC_PACK; ++q) {
+      if (!cur.on[q]) continue;
+      const float dcr = cur.dcr[q], dci = cur.dci[q];
+      const float2 (&vq)[NV] = (q == 0) ? v0 : ((q == 1) ? v1 : v2);
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int j = lane + 64 * k;
+        if (j < EPC_WIN) cs[j] = make_float2(vq[k].x - dcr, vq[k].y - dci);   // in[i] - dc_est
+      }
+      wv::wave_sync();
+      const int lead = q * EPC_GRP;            // any lane of the group holds the window's values
+      const float T = wv::readlane(T_lane, lead);
+      const float fidx = wv::readlane(findex, lead);
+      const float h_re = wv::readlane(hre, lead), h_im = wv::readlane(him, lead);
+      const float nhim = -h_im, T2 = 2.0f * T;
+      const int j0 = lane, j1 = lane + 64;
+      const float2 pa = cs[wv::f2i((float)j0 * T2 + fidx)];
+      const float2 qa = cs[wv::f2i(((float)(j0 * 2) * T + T) + fidx)];
+      const float2 pb = cs[wv::f2i((float)j1 * T2 + fidx)];
+      const float2 qb = cs[wv::f2i(((float)(j1 * 2) * T + T) + fidx)];
+      const bool cur0 = ((pa.x - qa.x) * h_re - (pa.y - qa.y) * nhim) > 0.0f;
+      const bool cur1 = ((pb.x - qb.x) * h_re - (pb.y - qb.y) * nhim) > 0.0f;
+      const uint64_t c0 = wv::ballot(cur0), c1 = wv::ballot(cur1);
+      const uint64_t b0 = c0 ^ ((c0 << 1) | 1ull);
+      const uint64_t b1 = c1 ^ ((c1 << 1) | (c0 >> 63));
+      unsigned x = 0;
+      if ((b0 >> lane) & 1ull) x ^= crc_lo;
+      if (lane < 48 && ((b1 >> lane) & 1ull)) x ^= crc_hi;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) x ^= wv::shfl_xor(x, off);
+      const unsigned crc = (~(x ^ crc_k)) & 0xFFFFu;
+      unsigned rcvd = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) rcvd |= (unsigned)((b1 >> (48 + i)) & 1ull) << (15 - i);
+      rfid_decode_result r;
+      r.type = RFID_DECODE_EPC; r.index = wv::f2i(fidx); r.h_re = h_re; r.h_im = h_im; r.T = T;
+      r.bits[0] = (uint32_t)b0; r.bits[1] = (uint32_t)(b0 >> 32);
+      r.bits[2] = (uint32_t)b1; r.bits[3] = (uint32_t)(b1 >> 32);
+      r.n_bits = 128;
+      r.crc_ok = (crc == rcvd) ? 1 : 0;
+      r.tag_id = -1;
+      if (r.crc_ok) {
+        int id = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) id |= (int)((b1 >> (40 + i)) & 1ull) << (7 - i);
+        r.tag_id = id;
+      }
+      if (lane == 0) a.res[cur.slot[q]] = r;
+      if (a.scores) {
+        rfid_scores *sc = a.scores + cur.slot[q];
+        if (g == q && t < N_SYNC) sc->corr[t] = corr;
+        if (g == q) sc->energy[t] = energy;
+      }
+      wv::wave_sync();   // the next window overwrites the complex-sample area
+    }
+    pk = pk_next;
+  }
+}
+
+// decode_rn16x4_kernel: FOUR RN16 windows per wavefront, one 16-lane row each, no LDS.  An RN16
+// decode touches 6x15 preamble taps and 32 half-bit samples; the lanes gather them straight
+// from global memory (8-byte loads, neighbouring lanes -> neighbouring addresses).
+constexpr int RN16_PACK = 4;
+
+RFID_DEVICE float row_max16(float v) {   // maximum over the 16-lane row of the calling lane
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) {
+    const float o = wv::shfl_xor(v, off);
+    v = (o > v) ? o : v;
+  }
+  return v;
+}
+
+RFID_KERNEL(64) void decode_rn16x4_kernel(DecodeListArgs a) {
+  const int lane = wv::lane_id();
+  int total = wv::uniform(*a.count);
+  if (total > a.cap) total = a.cap;
+  const int row = lane >> 4, t = lane & 15;
+  const int n_packs = (total + RN16_PACK - 1) / RN16_PACK;
+  for (int pk = (int)blockIdx.x; pk < n_packs; pk += (int)gridDim.x) {
+    const int w = pk * RN16_PACK + row;
+    const bool on = w < total;
+    const rfid_window wd = a.list[on ? w : (total - 1)];
+    const float2 *src = a.y + (int64_t)wd.stream * a.y_stride + wd.start;
+    const float dcr = wd.dc_re, dci = wd.dc_im;
+    // ---- tag_sync: offset t (0..14), 6 taps, in order ---------------------------------------
+    float cre = 0.0f, cim = 0.0f;
+    if (t < N_SYNC) {
+      const int taps[6] = {0, 5, 15, 30, 50, 55};
+      float2 v[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) v[k] = src[t + taps[k]];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        cre = cre + (v[k].x - dcr);
+        cim = cim + (v[k].y - dci);
+      }
+    }
+    const float corr = cre * cre + cim * cim;
+    const float key = (t < N_SYNC && corr == corr) ? corr : -1.0f;
+    const float mx = row_max16(key);
+    const uint64_t hit = wv::ballot(t < N_SYNC && key == mx);
+    const unsigned rowhit = (unsigned)((hit >> (row * 16)) & 0xFFFFull);
+    const int m_idx = (mx > 0.0f && rowhit) ? (wv::ffs64((uint64_t)rowhit) & 15) : 0;   // first maximum > 0, else 0
+    const float hre = wv::fdiv(wv::shfl(cre, row * 16 + m_idx), 6.0f);
+    const float him = wv::fdiv(wv::shfl(cim, row * 16 + m_idx), 6.0f);
+    const int index = m_idx + 65;
+    // ---- 32 half-bit samples at index + 5q (:237-253), 16 decisions (:114-142) ----------------
+    const float2 p = src[index + 10 * t], q = src[index + 10 * t + 5];
+    const float res = ((p.x - dcr) - (q.x - dcr)) * hre - ((p.y - dci) - (q.y - dci)) * (-him);
+    const uint64_t call = wv::ballot(res > 0.0f);
+    const uint64_t c = (call >> (row * 16)) & 0xFFFFull;
+    const uint64_t bits = (c ^ ((c << 1) | 1ull)) & 0xFFFFull;
+    if (on) {
+      const int64_t slot = (int64_t)wd.stream * a.wmax + wd.seq;
+      if (t == 0) {
+        rfid_decode_result r;
+        r.type = RFID_DECODE_RN16; r.index = index; r.h_re = hre; r.h_im = him; r.T = 0.0f;
+        r.bits[0] = (uint32_t)bits; r.bits[1] = r.bits[2] = r.bits[3] = 0u;
+        r.n_bits = 16; r.crc_ok = 0; r.tag_id = -1;
+        a.res[slot] = r;
+      }
+      if (a.scores) {
+        rfid_scores *sc = a.scores + slot;
+        if (t < N_SYNC) sc->corr[t] = corr;
+        sc->energy[t] = 0.0f;
+        if (t < 4) sc->energy[16 + t] = 0.0f;
+      }
+    }
   }
 }
 

@@ -100,9 +100,9 @@ int emu_batch_process(const float *raw, int B, long stride, long n_raw, const in
   const int flat_cap = wmax * B;
   std::vector<GateState> gstate((size_t)B);
   memset(gstate.data(), 0, sizeof(GateState) * (size_t)B);
-  std::vector<rfid_window> wtab((size_t)flat_cap), flat((size_t)flat_cap);
+  std::vector<rfid_window> wtab((size_t)flat_cap), flat((size_t)flat_cap * 2);
   std::vector<int> wcount((size_t)B, 0);
-  int flat_count = 0;
+  int flat_count[2] = {0, 0};
   std::vector<rfid_decode_result> res((size_t)flat_cap);
   std::vector<rfid_scores> sc((size_t)flat_cap);
   memset(sc.data(), 0, sizeof(rfid_scores) * (size_t)flat_cap);
@@ -122,16 +122,17 @@ int emu_batch_process(const float *raw, int B, long stride, long n_raw, const in
   GateArgs ga;
   ga.y = y; ga.y_stride = y_stride; ga.n_dec = n_dec; ga.lens = lens; ga.state = gstate.data(); ga.n_streams = B;
   ga.wtab = wtab.data(); ga.wmax = wmax; ga.wcount = wcount.data(); ga.flat = flat.data();
-  ga.flat_count = &flat_count; ga.flat_cap = flat_cap; ga.mode = 0; ga.gated = nullptr; ga.gated_cap = 0;
+  ga.flat_count = flat_count; ga.flat_cap = flat_cap; ga.mode = 0; ga.gated = nullptr; ga.gated_cap = 0;
   ga.io = nullptr; ga.prof = nullptr;
   emu::launch(emu::Idx3{(unsigned)((B + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG), 1, 1}, emu::Idx3{GATE_THREADS, 1, 1}, [&]() { gate_scan_kernel(ga); });
 
-  DecodeArgs da;
-  da.y = y; da.y_stride = y_stride; da.flat = flat.data(); da.flat_count = &flat_count; da.flat_cap = flat_cap;
-  da.res = res.data(); da.scores = sc.data(); da.wmax = wmax;
+  DecodeListArgs da;
+  da.y = y; da.y_stride = y_stride; da.cap = flat_cap; da.res = res.data(); da.scores = sc.data(); da.wmax = wmax;
   rfidh::t_candidates(da.t_cand, 400000);
-  int grid = flat_count < 7 ? (flat_count > 0 ? flat_count : 1) : 7;  // exercise the persistent loop
-  emu::launch(emu::Idx3{(unsigned)grid, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { decode_windows_kernel(da); });
+  da.list = flat.data() + flat_cap; da.count = &flat_count[1];
+  emu::launch(emu::Idx3{2, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { decode_epc3_kernel(da); });   // 2 persistent waves
+  da.list = flat.data(); da.count = &flat_count[0];
+  emu::launch(emu::Idx3{2, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { decode_rn16x4_kernel(da); });
 
   StatsArgs sa;
   sa.res = res.data(); sa.wcount = wcount.data(); sa.wmax = wmax; sa.n_streams = B;
