@@ -65,6 +65,12 @@ struct rfid_ctx {
   int decode_grid = 0;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool ev_valid[5] = {false, false, false, false, false};
+  // overlapped front end: matched filter on `stream`, gate scan on `stream2`, time-chunked
+  static const int MAX_CHUNKS = 16;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_mf[MAX_CHUNKS + 1], ev_gate[2 * MAX_CHUNKS], ev_pass = nullptr, ev_front_end = nullptr;
+  int n_chunks_last = 0;   // > 0 when the last pass used the overlapped path
+  float front_ms = 0.0f;
 };
 
 namespace {
@@ -204,6 +210,16 @@ int rfid_ctx_create(const rfid_params *p, int device, rfid_ctx **out) {
     for (int i = 0; i < 5; ++i)
       if (hipEventCreate(&c->ev[i]) != hipSuccess) { rc = RFID_ERR_HIP; break; }
     if (rc) break;
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { rc = RFID_ERR_HIP; break; }
+    for (int i = 0; i <= rfid_ctx::MAX_CHUNKS; ++i) c->ev_mf[i] = nullptr;
+    for (int i = 0; i < 2 * rfid_ctx::MAX_CHUNKS; ++i) c->ev_gate[i] = nullptr;
+    for (int i = 0; i <= rfid_ctx::MAX_CHUNKS && !rc; ++i)
+      if (hipEventCreate(&c->ev_mf[i]) != hipSuccess) rc = RFID_ERR_HIP;
+    for (int i = 0; i < 2 * rfid_ctx::MAX_CHUNKS && !rc; ++i)
+      if (hipEventCreate(&c->ev_gate[i]) != hipSuccess) rc = RFID_ERR_HIP;
+    if (!rc && (hipEventCreate(&c->ev_pass) != hipSuccess || hipEventCreate(&c->ev_front_end) != hipSuccess))
+      rc = RFID_ERR_HIP;
+    if (rc) break;
     if (hipMalloc((void **)&c->d_gate1, sizeof(GateState)) != hipSuccess ||
         hipMalloc((void **)&c->d_io, 2 * sizeof(int)) != hipSuccess ||
         hipMalloc((void **)&c->d_swin, sizeof(rfid_window)) != hipSuccess ||
@@ -227,6 +243,16 @@ int rfid_ctx_destroy(rfid_ctx *c) {
     if (p) (void)hipFree(p);
   for (int i = 0; i < 5; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->stream2) {
+    (void)hipStreamSynchronize(c->stream2);
+    for (int i = 0; i <= rfid_ctx::MAX_CHUNKS; ++i)
+      if (c->ev_mf[i]) (void)hipEventDestroy(c->ev_mf[i]);
+    for (int i = 0; i < 2 * rfid_ctx::MAX_CHUNKS; ++i)
+      if (c->ev_gate[i]) (void)hipEventDestroy(c->ev_gate[i]);
+    if (c->ev_pass) (void)hipEventDestroy(c->ev_pass);
+    if (c->ev_front_end) (void)hipEventDestroy(c->ev_front_end);
+    (void)hipStreamDestroy(c->stream2);
+  }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return RFID_OK;
@@ -366,7 +392,8 @@ int rfid_batch_mf(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64_t n_
   a.x = (const float2 *)d_raw; a.x_stride = raw_stride; a.n_raw = n_raw; a.lens = c->d_lens;
   a.n_out = n_raw / DECIM; a.in_off = -(NTAPS - 1);
   a.vec_ok = ((raw_stride & 1) == 0 && (((uintptr_t)d_raw) & 15) == 0) ? 1 : 0;
-  a.y = c->d_y; a.y_stride = c->y_stride;
+  a.y = c->d_y; a.y_stride = c->y_stride; a.tile0 = 0;
+  c->n_chunks_last = 0;
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   const int64_t tiles = (a.n_out + MF_TILE - 1) / MF_TILE;
   if (tiles > 0) {
@@ -389,6 +416,7 @@ int rfid_batch_gate(rfid_ctx *c) {
   HIPCHK(c, hipMemsetAsync(c->d_flat_count, 0, 2 * sizeof(int), c->stream));
   GateArgs a;
   a.y = c->d_y; a.y_stride = c->y_stride; a.n_dec = c->last_n_raw / DECIM; a.lens = c->d_lens;
+  a.pos0 = 0; a.chunk_len = a.n_dec;
   a.state = c->d_gstate; a.n_streams = c->B; a.wtab = c->d_wtab; a.wmax = c->wmax; a.wcount = c->d_wcount;
   a.flat = c->d_flat; a.flat_count = c->d_flat_count; a.flat_cap = c->flat_cap; a.mode = 0;
   a.gated = nullptr; a.gated_cap = 0; a.io = nullptr; a.prof = nullptr;
@@ -448,25 +476,88 @@ int rfid_batch_stats(rfid_ctx *c) {
   a.max_num_queries = c->prm.max_num_queries; a.number_unique_tags = c->prm.number_unique_tags;
   a.out = c->d_stats;
   if (!c->ev_valid[3]) { HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->ev_valid[3] = true; }
-  hipLaunchKernelGGL(stream_stats_kernel, dim3((unsigned)((c->B + 63) / 64)), dim3(64), 0, c->stream, a);
+  hipLaunchKernelGGL(stream_stats_kernel, dim3((unsigned)c->B), dim3(64), 0, c->stream, a);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
   c->ev_valid[4] = true;
   return RFID_OK;
 }
 
+// mf -> gate -> decode -> stats.  The matched filter (HBM-bound) and the gate scan (bound by the
+// latency of its in-order sums, one wave per SIMD) are overlapped: the traces are cut along
+// time into chunks; chunk k of the gate scan runs on a second stream as soon as chunk k of the
+// matched filter is done, carrying the gate state from chunk to chunk (exactly the state a
+// streaming call sequence would carry).
 int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64_t n_raw, const void *d_lens,
                        int want_scores) {
-  int rc = rfid_batch_mf(c, d_raw, raw_stride, n_raw, d_lens);
+  if (!c || !d_raw || n_raw < 0 || raw_stride < n_raw) return RFID_ERR_INVALID;
+  if (!c->B) return RFID_ERR_STATE;
+  if (n_raw > c->max_raw) return RFID_ERR_CAPACITY;
+  const int64_t n_out = n_raw / DECIM;
+  const int64_t tiles = (n_out + MF_TILE - 1) / MF_TILE;
+  int nch = 8;
+  if (const char *e = getenv("RFID_FRONT_CHUNKS")) nch = atoi(e);
+  if (nch > rfid_ctx::MAX_CHUNKS) nch = rfid_ctx::MAX_CHUNKS;
+  if (tiles < 4 * (int64_t)nch || nch < 2) {   // short traces: plain sequence
+    int rc = rfid_batch_mf(c, d_raw, raw_stride, n_raw, d_lens);
+    if (rc) return rc;
+    if ((rc = rfid_batch_gate(c))) return rc;
+    if ((rc = rfid_batch_decode(c, want_scores))) return rc;
+    return rfid_batch_stats(c);
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  c->d_lens = (const int64_t *)d_lens;
+  c->last_n_raw = n_raw;
+  const int64_t tiles_per_chunk = (tiles + nch - 1) / nch;
+  // the previous pass (decode/stats on `stream`) must be over before the gate state is reset
+  HIPCHK(c, hipEventRecord(c->ev_pass, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_pass, 0));
+  HIPCHK(c, hipMemsetAsync(c->d_gstate, 0, sizeof(GateState) * (size_t)c->B, c->stream2));
+  HIPCHK(c, hipMemsetAsync(c->d_flat_count, 0, 2 * sizeof(int), c->stream2));
+  MfArgs m;
+  m.x = (const float2 *)d_raw; m.x_stride = raw_stride; m.n_raw = n_raw; m.lens = c->d_lens;
+  m.n_out = n_out; m.in_off = -(NTAPS - 1);
+  m.vec_ok = ((raw_stride & 1) == 0 && (((uintptr_t)d_raw) & 15) == 0) ? 1 : 0;
+  m.y = c->d_y; m.y_stride = c->y_stride;
+  GateArgs g;
+  g.y = c->d_y; g.y_stride = c->y_stride; g.n_dec = n_out; g.lens = c->d_lens;
+  g.state = c->d_gstate; g.n_streams = c->B; g.wtab = c->d_wtab; g.wmax = c->wmax; g.wcount = c->d_wcount;
+  g.flat = c->d_flat; g.flat_count = c->d_flat_count; g.flat_cap = c->flat_cap; g.mode = 0;
+  g.gated = nullptr; g.gated_cap = 0; g.io = nullptr; g.prof = nullptr;
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  HIPCHK(c, hipEventRecord(c->ev_mf[0], c->stream));
+  int used = 0;
+  for (int k = 0; k < nch; ++k) {
+    const int64_t t0 = (int64_t)k * tiles_per_chunk;
+    if (t0 >= tiles) break;
+    const int64_t tn = (t0 + tiles_per_chunk <= tiles) ? tiles_per_chunk : (tiles - t0);
+    m.tile0 = t0;
+    hipLaunchKernelGGL(mf_boxcar25_decim5_kernel, dim3((unsigned)tn, (unsigned)c->B), dim3(MF_THREADS), 0, c->stream, m);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev_mf[k + 1], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_mf[k + 1], 0));
+    g.pos0 = t0 * MF_TILE; g.chunk_len = tn * MF_TILE;
+    HIPCHK(c, hipEventRecord(c->ev_gate[2 * k], c->stream2));
+    hipLaunchKernelGGL(gate_scan_kernel, dim3((unsigned)((c->B + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG)),
+                       dim3(GATE_THREADS), 0, c->stream2, g);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev_gate[2 * k + 1], c->stream2));
+    used = k + 1;
+  }
+  c->n_chunks_last = used;
+  HIPCHK(c, hipEventRecord(c->ev_front_end, c->stream2));
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_front_end, 0));
+  HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  c->ev_valid[0] = true; c->ev_valid[1] = false; c->ev_valid[2] = true;
+  int rc = rfid_batch_decode(c, want_scores);
   if (rc) return rc;
-  if ((rc = rfid_batch_gate(c))) return rc;
-  if ((rc = rfid_batch_decode(c, want_scores))) return rc;
   return rfid_batch_stats(c);
 }
 
 int rfid_batch_sync(rfid_ctx *c) {
   if (!c) return RFID_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream2));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return RFID_OK;
 }
@@ -474,12 +565,29 @@ int rfid_batch_sync(rfid_ctx *c) {
 int rfid_batch_timing_get(rfid_ctx *c, rfid_batch_timing *out) {
   if (!c || !out) return RFID_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream2));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   float ms[4] = {0, 0, 0, 0};
-  for (int i = 0; i < 4; ++i)
-    if (c->ev_valid[i] && c->ev_valid[i + 1]) HIPCHK(c, hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+  float front = 0.0f;
+  if (c->n_chunks_last > 0) {
+    // overlapped front end: kernel times are the sums over the chunks on their own streams
+    for (int k = 0; k < c->n_chunks_last; ++k) {
+      float t = 0.0f;
+      HIPCHK(c, hipEventElapsedTime(&t, c->ev_mf[k], c->ev_mf[k + 1]));
+      ms[0] += t;
+      HIPCHK(c, hipEventElapsedTime(&t, c->ev_gate[2 * k], c->ev_gate[2 * k + 1]));
+      ms[1] += t;
+    }
+    HIPCHK(c, hipEventElapsedTime(&front, c->ev_mf[0], c->ev_front_end));
+    for (int i = 2; i < 4; ++i)
+      if (c->ev_valid[i] && c->ev_valid[i + 1]) HIPCHK(c, hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+    out->total_ms = front + ms[2] + ms[3];
+  } else {
+    for (int i = 0; i < 4; ++i)
+      if (c->ev_valid[i] && c->ev_valid[i + 1]) HIPCHK(c, hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+    out->total_ms = ms[0] + ms[1] + ms[2] + ms[3];
+  }
   out->mf_ms = ms[0]; out->gate_ms = ms[1]; out->decode_ms = ms[2]; out->stats_ms = ms[3];
-  out->total_ms = ms[0] + ms[1] + ms[2] + ms[3];
   return RFID_OK;
 }
 
@@ -580,7 +688,7 @@ int rfid_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int
     MfArgs a;
     a.x = (const float2 *)c->s_in.p; a.x_stride = H + n_in; a.n_raw = H + n_in; a.lens = nullptr;
     a.n_out = n_out; a.in_off = off; a.vec_ok = (off % 2 == 0) ? 1 : 0;
-    a.y = (float2 *)c->s_out.p; a.y_stride = n_out;
+    a.y = (float2 *)c->s_out.p; a.y_stride = n_out; a.tile0 = 0;
     const int tiles = (n_out + MF_TILE - 1) / MF_TILE;
     hipLaunchKernelGGL(mf_boxcar25_decim5_kernel, dim3((unsigned)tiles, 1), dim3(MF_THREADS), 0, c->stream, a);
     HIPCHK(c, hipGetLastError());
@@ -629,6 +737,7 @@ int rfid_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, i
   HIPCHK(c, hipMemcpyAsync(c->s_in.p, in, sizeof(rfid_cf32) * (size_t)n_in, hipMemcpyHostToDevice, c->stream));
   GateArgs a;
   a.y = (const float2 *)c->s_in.p; a.y_stride = n_in; a.n_dec = n_in; a.lens = nullptr;
+  a.pos0 = 0; a.chunk_len = n_in;
   a.state = c->d_gate1; a.n_streams = 1; a.wtab = nullptr; a.wmax = 0; a.wcount = nullptr;
   a.flat = nullptr; a.flat_count = nullptr; a.flat_cap = 0; a.mode = 1;
   a.gated = (float2 *)c->s_out.p; a.gated_cap = n_in; a.io = c->d_io; a.prof = nullptr;

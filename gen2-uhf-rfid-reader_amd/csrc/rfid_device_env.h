@@ -94,6 +94,18 @@ RFID_DEVICE void lds_store(int *p, int v, int lane) {
   if (lane == 0) *q = v;
   asm volatile("" ::: "memory");
 }
+RFID_DEVICE uint64_t lds_load64(const uint64_t *p) {
+  const volatile RFID_LDS_AS uint32_t *q = (const volatile RFID_LDS_AS uint32_t *)p;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)q[0]);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)q[1]);
+  return ((uint64_t)hi << 32) | lo;
+}
+RFID_DEVICE void lds_store64(uint64_t *p, uint64_t v, int lane) {
+  volatile RFID_LDS_AS uint32_t *q = (volatile RFID_LDS_AS uint32_t *)p;
+  asm volatile("" ::: "memory");
+  if (lane == 0) { q[0] = (uint32_t)v; q[1] = (uint32_t)(v >> 32); }
+  asm volatile("" ::: "memory");
+}
 RFID_DEVICE void set_priority_high() { __builtin_amdgcn_s_setprio(3); }
 RFID_DEVICE void backoff() { __builtin_amdgcn_s_sleep(1); }
 RFID_DEVICE void keep(float v) { asm volatile("" ::"s"(v)); }

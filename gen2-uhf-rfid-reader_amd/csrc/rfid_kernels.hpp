@@ -57,6 +57,7 @@ struct MfArgs {
   int vec_ok;           // rows 16-byte aligned and in_off even -> float4 loads
   float2 *y;            // [n_streams][y_stride]
   int64_t y_stride;
+  int64_t tile0;        // first output tile of this launch (time-chunked launches)
 };
 
 RFID_KERNEL(MF_THREADS) void mf_boxcar25_decim5_kernel(MfArgs a) {
@@ -71,7 +72,7 @@ RFID_KERNEL(MF_THREADS) void mf_boxcar25_decim5_kernel(MfArgs a) {
     if (n_raw < 0) n_raw = 0;
     n_out = n_raw / DECIM;
   }
-  const int64_t n0 = (int64_t)blockIdx.x * MF_TILE;
+  const int64_t n0 = ((int64_t)blockIdx.x + a.tile0) * MF_TILE;
   if (n0 >= n_out) return;
   const float2 *xs = a.x + (int64_t)b * a.x_stride;
   const int64_t r0 = n0 * DECIM + a.in_off;
@@ -145,6 +146,8 @@ struct GateArgs {
   const float2 *y;      // [n_streams][y_stride] matched-filter output
   int64_t y_stride;
   int64_t n_dec;        // valid decimated samples per trace (when lens == nullptr)
+  int64_t pos0;         // time-chunked launches: this launch scans samples [pos0, pos0 + chunk_len)
+  int64_t chunk_len;    //   of every trace, carrying the gate state from the previous chunk
   const int64_t *lens;  // optional per-trace RAW lengths (n_dec = lens/5)
   GateState *state;     // [n_streams]
   int n_streams;
@@ -267,7 +270,7 @@ RFID_DEVICE void gate_record_window(const GateArgs &a, GateRegs &g, int ol, int 
                                     int lane, float dcr, float dci) {
   const float odr = wv::readlane(dcr, ol), odi = wv::readlane(dci, ol);
   const int wlen = wtype ? EPC_WIN : RN16_WIN;
-  const int start = pos + ol;
+  const int start = (int)a.pos0 + pos + ol;
   if (a.mode == 0 && start + wlen <= n) {  // only complete windows reach the decoder (:223,:291)
     if (lane == 0 && g.win_seq < a.wmax) {
       rfid_window w;
@@ -297,7 +300,8 @@ RFID_DEVICE void gate_record_window(const GateArgs &a, GateRegs &g, int ol, int 
 
 template <bool PROF>
 RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const GateSlot *slot, bool has_front,
-                              int pos, int n, int s, int lane, float2 *lds_dc, float2 *lds_tmp, long long *tk) {
+                              int pos, int n, int n_total, int s, int lane, float2 *lds_dc, float2 *lds_tmp,
+                              long long *tk) {
   long long t0 = 0, t1 = 0;
   if (PROF) t0 = wv::ticks();
   float f_amp = 0.0f, f_d = 0.0f, f_tre = 0.0f, f_tim = 0.0f;
@@ -316,8 +320,8 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
     g.dcr_c = wv::readlane(dcr, 63);
     g.dci_c = wv::readlane(dci, 63);
     if (B.open_lane >= 0) {   // rare: a window opened in the back step
-      gate_record_window(a, g, B.open_lane, B.open_type, B.pos, n, s, lane, dcr, dci);
-      if (B.open_lane2 >= 0) gate_record_window(a, g, B.open_lane2, B.open_type2, B.pos, n, s, lane, dcr, dci);
+      gate_record_window(a, g, B.open_lane, B.open_type, B.pos, n_total, s, lane, dcr, dci);
+      if (B.open_lane2 >= 0) gate_record_window(a, g, B.open_lane2, B.open_type2, B.pos, n_total, s, lane, dcr, dci);
     }
     if (a.mode == 1 && B.openmask != 0) {  // streaming: emit gated samples in[i] - dc_est (gate_impl.cc:176,187)
       const bool isopen = ((B.openmask >> lane) & 1ull) != 0;
@@ -550,7 +554,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
   wv::block_sync();   // once, before any hand-off
   if (s >= a.n_streams) return;
   GateState *st = a.state + s;
-  const float2 *ys = a.y + (int64_t)s * a.y_stride;
+  const float2 *ys = a.y + (int64_t)s * a.y_stride + a.pos0;
   int64_t n64 = a.n_dec;
   if (a.lens) {
     int64_t r = a.lens[s];
@@ -558,7 +562,11 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
     n64 = r / DECIM;
     if (n64 > a.n_dec) n64 = a.n_dec;
   }
-  const int n = wv::uniform((int)n64);
+  const int n_total = wv::uniform((int)n64);          // valid samples of the whole trace
+  int64_t nl = n64 - a.pos0;                          // ... of this launch's chunk
+  if (nl > a.chunk_len) nl = a.chunk_len;
+  if (nl < 0) nl = 0;
+  const int n = wv::uniform((int)nl);
   const int nsteps = (n + 63) >> 6;
   const int win_index0 = wv::uniform(st->win_index);
 
@@ -628,12 +636,12 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
       if (PROF) tb = wv::ticks();
       while (wv::lds_load(&sh.prod_seq) <= k) wv::backoff();   // step k produced?
       if (PROF) tk[5] += wv::ticks() - tb;
-      gate_consume<PROF>(a, g, B, &sh.slots[k % GATE_SLOTS], true, 64 * k, n, s, lane, lds_dc, lds_tmp, tk);
+      gate_consume<PROF>(a, g, B, &sh.slots[k % GATE_SLOTS], true, 64 * k, n, n_total, s, lane, lds_dc, lds_tmp, tk);
       wv::lds_store(&sh.cons_seq, k + 1, lane);   // slot k free again (its data are in registers)
     }
     if (g.stop) wv::lds_store(&sh.stop, 1, lane);
     // drain: finish the pending back half (window records / gated output of the last step)
-    if (B.has) gate_consume<PROF>(a, g, B, &sh.slots[0], false, 0, n, s, lane, lds_dc, lds_tmp, tk);
+    if (B.has) gate_consume<PROF>(a, g, B, &sh.slots[0], false, 0, n, n_total, s, lane, lds_dc, lds_tmp, tk);
     if (PROF && a.prof && lane == 0) {
       tk[6] = wv::ticks() - t_start;
       for (int i = 0; i < 12; ++i) a.prof[(int64_t)s * 12 + i] = tk[i];
@@ -667,7 +675,9 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
       st->gate_open = g.f_open; st->n_to_ungate = g.f_ung; st->wtype = g.f_type;
       st->win_index = (win_index0 + g.consumed) % WIN_LEN; st->dc_index = g.dc_index; st->win_seq = g.win_seq;
       if (a.mode == 0) {
-        a.wcount[s] = (g.n_complete < a.wmax) ? g.n_complete : a.wmax;
+        const int before = (a.pos0 > 0) ? a.wcount[s] : 0;   // windows recorded by earlier chunks
+        const int tot = before + g.n_complete;
+        a.wcount[s] = (tot < a.wmax) ? tot : a.wmax;
       } else {
         a.io[0] = g.consumed;
         a.io[1] = g.written;
@@ -1204,7 +1214,7 @@ RFID_KERNEL(64) void decode_rn16x4_kernel(DecodeListArgs a) {
 
 // =========================================================================================
 // 4. per-trace statistics: replays the decoded windows of each trace in order through the
-//    reader/decoder bookkeeping, including the TERMINATED cut-off.  One lane per trace.
+//    reader/decoder bookkeeping, including the TERMINATED cut-off.  One wavefront per trace.
 // =========================================================================================
 struct StatsArgs {
   const rfid_decode_result *res;  // [n_streams][wmax]
@@ -1217,47 +1227,71 @@ struct StatsArgs {
   rfid_stream_stats *out;         // [n_streams]
 };
 
+// One wavefront per trace: the lanes fetch the decoded windows in parallel and compact what the
+// replay needs (type, crc flag, tag id) into LDS; lane 0 then replays them in order.
+constexpr int STATS_CHUNK = 1024;
+
 RFID_KERNEL(64) void stream_stats_kernel(StatsArgs a) {
-  const int s = (int)(blockIdx.x * 64 + threadIdx.x);
+  RFID_SHARED int packed[STATS_CHUNK];
+  RFID_SHARED int hist[256];
+  const int lane = wv::lane_id();
+  const int s = (int)blockIdx.x;
   if (s >= a.n_streams) return;
   rfid_stream_stats *o = a.out + s;
-  for (int i = 0; i < 256; ++i) o->tag_reads[i] = 0;
+  for (int i = lane; i < 256; i += 64) hist[i] = 0;
   int n_queries = 1;  // START -> SEND_QUERY before the first sample (reader_impl.cc:218-260)
   int round = 1, slot = 1, n_ok = 0, n_unique = 0, status = RFID_RUNNING, used = 0;
-  const int nw = a.wcount[s];
+  const int nw = wv::uniform(a.wcount[s]);
   const rfid_decode_result *rs = a.res + (int64_t)s * a.wmax;
-  for (int k = 0; k < nw; ++k) {
-    // gate_impl.cc:101-109, evaluated at the gate call that follows every window
-    if (n_queries > a.max_num_queries || n_unique > a.number_unique_tags) {
-      status = RFID_TERMINATED;
-      break;
+  bool done = false;
+  for (int base = 0; base < nw && !done; base += STATS_CHUNK) {
+    const int m = (nw - base < STATS_CHUNK) ? (nw - base) : STATS_CHUNK;
+    wv::wave_sync();
+    for (int k = lane; k < m; k += 64) {
+      const rfid_decode_result &r = rs[base + k];
+      packed[k] = (r.type & 1) | ((r.crc_ok & 1) << 1) | ((r.tag_id & 255) << 2);
     }
-    const rfid_decode_result r = rs[k];
-    used++;
-    if (r.type == RFID_DECODE_EPC) {
-      slot++;                                          // tag_decoder_impl.cc:295
-      const bool roll = slot > a.max_slot_number;      // :330-343 / :369-383
-      if (roll) { slot = 1; round++; }
-      if (r.crc_ok) {
-        n_ok++;                                        // :346
-        const int id = r.tag_id & 255;
-        if (o->tag_reads[id] == 0) n_unique++;
-        o->tag_reads[id]++;                            // :356-364
+    wv::wave_sync();
+    if (lane == 0) {
+      for (int k = 0; k < m; ++k) {
+        // gate_impl.cc:101-109, evaluated at the gate call that follows every window
+        if (n_queries > a.max_num_queries || n_unique > a.number_unique_tags) {
+          status = RFID_TERMINATED;
+          done = true;
+          break;
+        }
+        const int v = packed[k];
+        used++;
+        if (v & 1) {                                       // EPC window
+          slot++;                                          // tag_decoder_impl.cc:295
+          if (slot > a.max_slot_number) { slot = 1; round++; }  // :330-343 / :369-383
+          if (v & 2) {
+            n_ok++;                                        // :346
+            const int id = (v >> 2) & 255;
+            if (hist[id] == 0) n_unique++;
+            hist[id]++;                                    // :356-364
+          }
+          n_queries++;                                     // reader_impl.cc:259 / :335
+        }
       }
-      n_queries++;                                     // reader_impl.cc:259 / :335
     }
+    done = wv::uniform((int)done) != 0;
   }
-  if (status == RFID_RUNNING &&
-      (n_queries > a.max_num_queries || n_unique > a.number_unique_tags))
-    status = RFID_TERMINATED;
-  o->n_queries_sent = n_queries;
-  o->cur_inventory_round = round;
-  o->cur_slot_number = slot;
-  o->n_epc_correct = n_ok;
-  o->n_unique_tags = n_unique;
-  o->n_windows = nw;
-  o->n_windows_used = used;
-  o->status = status;
+  wv::wave_sync();
+  for (int i = lane; i < 256; i += 64) o->tag_reads[i] = hist[i];
+  if (lane == 0) {
+    if (status == RFID_RUNNING &&
+        (n_queries > a.max_num_queries || n_unique > a.number_unique_tags))
+      status = RFID_TERMINATED;
+    o->n_queries_sent = n_queries;
+    o->cur_inventory_round = round;
+    o->cur_slot_number = slot;
+    o->n_epc_correct = n_ok;
+    o->n_unique_tags = n_unique;
+    o->n_windows = nw;
+    o->n_windows_used = used;
+    o->status = status;
+  }
 }
 
 // =========================================================================================

@@ -116,3 +116,14 @@ def test_emulated_primitives(emu_mod):
         assert chain[i] == acc
     assert np.array_equal(div, num / den)
     assert np.array_equal(shr[1:], x[:-1]) and shr[0] == 0
+
+
+@pytest.mark.parametrize("chunk", [512, 1536, 777])
+def test_emulated_time_chunked_gate(emu_mod, oracle_mod, synth_mod, chunk):
+    """rfid_batch_process() cuts the traces along time and carries the gate state from chunk
+    to chunk (so the gate scan can overlap the matched filter): same result as one launch."""
+    t = synth_mod.make_trace(n_rounds=2, seed=71, sigma=0.02, t1_jitter_raw=5).samples
+    raw = np.stack([t, np.roll(t, 3)])
+    r = emu_mod.batch_process(raw, gate_chunk=chunk)
+    for b, (wb, rb, sb) in enumerate(parity.split_by_stream(r["windows"], r["results"], r["scores"], 2)):
+        parity.compare_trace(wb, rb, sb, r["stats"][b], oracle_mod.run_trace(raw[b]))

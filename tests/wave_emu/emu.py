@@ -28,7 +28,7 @@ def lib():
 
 
 def batch_process(raw: np.ndarray, lens=None, fixed_q=0, max_num_queries=1000, number_unique_tags=100,
-                  want_y=False):
+                  want_y=False, gate_chunk=0):
     """raw: [B][L] complex64.  -> dict(windows, results, scores, stats, y)"""
     raw = np.ascontiguousarray(raw, dtype=np.complex64)
     if raw.ndim == 1:
@@ -56,7 +56,7 @@ def batch_process(raw: np.ndarray, lens=None, fixed_q=0, max_num_queries=1000, n
         fixed_q, max_num_queries, number_unique_tags,
         C.c_void_p(windows.ctypes.data), C.c_void_p(results.ctypes.data), C.c_void_p(scores.ctypes.data),
         C.c_long(cap), C.byref(n), C.c_void_p(stats.ctypes.data),
-        C.c_void_p(y.ctypes.data) if y is not None else None)
+        C.c_void_p(y.ctypes.data) if y is not None else None, C.c_long(gate_chunk))
     assert rc == 0
     k = n.value
     return dict(windows=windows[:k], results=results[:k], scores=scores[:k], stats=stats, y=y)

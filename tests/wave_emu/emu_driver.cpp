@@ -90,7 +90,7 @@ extern "C" {
 int emu_batch_process(const float *raw, int B, long stride, long n_raw, const int64_t *lens, int fixed_q,
                       int max_num_queries, int number_unique_tags, rfid_window *windows,
                       rfid_decode_result *results, rfid_scores *scores, long cap, long *n_windows,
-                      rfid_stream_stats *stats, float *y_out) {
+                      rfid_stream_stats *stats, float *y_out, long gate_chunk) {
   const long n_dec = n_raw / DECIM;
   long y_stride = (n_dec + 1) & ~1L;
   if (y_stride < 2) y_stride = 2;
@@ -111,7 +111,7 @@ int emu_batch_process(const float *raw, int B, long stride, long n_raw, const in
   ma.x = reinterpret_cast<const float2 *>(raw); ma.x_stride = stride; ma.n_raw = n_raw; ma.lens = lens;
   ma.n_out = n_dec; ma.in_off = -(NTAPS - 1);
   ma.vec_ok = ((stride & 1) == 0 && (((uintptr_t)raw) & 15) == 0) ? 1 : 0;
-  ma.y = y; ma.y_stride = y_stride;
+  ma.y = y; ma.y_stride = y_stride; ma.tile0 = 0;
   const long tiles = (n_dec + MF_TILE - 1) / MF_TILE;
   if (tiles > 0)
     emu::launch(emu::Idx3{(unsigned)tiles, (unsigned)B, 1}, emu::Idx3{MF_THREADS, 1, 1},
@@ -124,7 +124,15 @@ int emu_batch_process(const float *raw, int B, long stride, long n_raw, const in
   ga.wtab = wtab.data(); ga.wmax = wmax; ga.wcount = wcount.data(); ga.flat = flat.data();
   ga.flat_count = flat_count; ga.flat_cap = flat_cap; ga.mode = 0; ga.gated = nullptr; ga.gated_cap = 0;
   ga.io = nullptr; ga.prof = nullptr;
-  emu::launch(emu::Idx3{(unsigned)((B + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG), 1, 1}, emu::Idx3{GATE_THREADS, 1, 1}, [&]() { gate_scan_kernel(ga); });
+  {
+    // time-chunked launches with carried state, as rfid_batch_process() issues them
+    const long chunk = (gate_chunk > 0) ? gate_chunk : (n_dec > 0 ? n_dec : 1);
+    for (long p0 = 0; p0 == 0 || p0 < n_dec; p0 += chunk) {
+      ga.pos0 = p0; ga.chunk_len = chunk;
+      emu::launch(emu::Idx3{(unsigned)((B + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG), 1, 1},
+                  emu::Idx3{GATE_THREADS, 1, 1}, [&]() { gate_scan_kernel(ga); });
+    }
+  }
 
   DecodeListArgs da;
   da.y = y; da.y_stride = y_stride; da.cap = flat_cap; da.res = res.data(); da.scores = sc.data(); da.wmax = wmax;
@@ -138,7 +146,7 @@ int emu_batch_process(const float *raw, int B, long stride, long n_raw, const in
   sa.res = res.data(); sa.wcount = wcount.data(); sa.wmax = wmax; sa.n_streams = B;
   sa.max_slot_number = 1 << fixed_q; sa.max_num_queries = max_num_queries;
   sa.number_unique_tags = number_unique_tags; sa.out = stats;
-  emu::launch(emu::Idx3{(unsigned)((B + 63) / 64), 1, 1}, emu::Idx3{64, 1, 1}, [&]() { stream_stats_kernel(sa); });
+  emu::launch(emu::Idx3{(unsigned)B, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { stream_stats_kernel(sa); });
 
   long total = 0;
   for (int s = 0; s < B; ++s) {
@@ -170,7 +178,7 @@ int emu_gate_stream(void *state_blob, const float *in, int n_in, int seek_type, 
   if (n_in > 0) {
     GateArgs ga;
     ga.y = reinterpret_cast<const float2 *>(in); ga.y_stride = n_in; ga.n_dec = n_in; ga.lens = nullptr;
-    ga.state = st; ga.n_streams = 1; ga.wtab = nullptr; ga.wmax = 0; ga.wcount = nullptr; ga.flat = nullptr;
+    ga.pos0 = 0; ga.chunk_len = n_in; ga.state = st; ga.n_streams = 1; ga.wtab = nullptr; ga.wmax = 0; ga.wcount = nullptr; ga.flat = nullptr;
     ga.flat_count = nullptr; ga.flat_cap = 0; ga.mode = 1; ga.gated = reinterpret_cast<float2 *>(out);
     ga.gated_cap = n_in; ga.io = io; ga.prof = nullptr;
     emu::launch(emu::Idx3{1, 1, 1}, emu::Idx3{GATE_THREADS, 1, 1}, [&]() { gate_scan_kernel(ga); });
@@ -191,7 +199,7 @@ int emu_mf_stream(const float *staging, int n_staging, int in_off, int n_out, fl
   ma.x = reinterpret_cast<const float2 *>(staging); ma.x_stride = n_staging; ma.n_raw = n_staging; ma.lens = nullptr;
   ma.n_out = n_out; ma.in_off = in_off;
   ma.vec_ok = (in_off % 2 == 0 && (((uintptr_t)staging) & 15) == 0) ? 1 : 0;
-  ma.y = reinterpret_cast<float2 *>(ybuf.data()); ma.y_stride = n_out;
+  ma.y = reinterpret_cast<float2 *>(ybuf.data()); ma.y_stride = n_out; ma.tile0 = 0;
   const int tiles = (n_out + MF_TILE - 1) / MF_TILE;
   emu::launch(emu::Idx3{(unsigned)tiles, 1, 1}, emu::Idx3{MF_THREADS, 1, 1}, [&]() { mf_boxcar25_decim5_kernel(ma); });
   memcpy(out, ybuf.data(), sizeof(float2) * (size_t)n_out);

@@ -145,6 +145,8 @@ static inline void wave_sync() { emu::wave_barrier(); }
 static inline void block_sync_lds() { block_sync(); }
 static inline int lds_load(const int *p) { return *(const volatile int *)p; }
 static inline void lds_store(int *p, int v, int lane) { emu::wave_barrier(); if (lane == 0) *(volatile int *)p = v; }
+static inline uint64_t lds_load64(const uint64_t *p) { return *(const volatile uint64_t *)p; }
+static inline void lds_store64(uint64_t *p, uint64_t v, int lane) { emu::wave_barrier(); if (lane == 0) *(volatile uint64_t *)p = v; }
 static inline void set_priority_high() {}
 static inline void backoff() { emu::yield(); }
 static inline void keep(float) {}
