@@ -120,7 +120,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    k_ms = {"mf_ms": 0.0, "gate_ms": 0.0, "decode_ms": 0.0, "stats_ms": 0.0}
+    k_ms = {"mf_ms": 0.0, "gate_ms": 0.0, "decode_ms": 0.0, "stats_ms": 0.0, "front_ms": 0.0}
+    launches = {"front_chunks": 1, "decode_launches": 2}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -128,6 +129,7 @@ def main():
         t = ctx.batch_timing()      # HIP events on the ctx stream, recorded around each kernel
         for k in k_ms:
             k_ms[k] += t[k]
+        launches = {"front_chunks": int(t["front_chunks"]), "decode_launches": int(t["decode_launches"])}
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -155,20 +157,27 @@ def main():
         "tag_decoder": n_rn16 * (8.0 * RN16_WIN + 48) + n_epc * (8.0 * EPC_WIN + 48),
     }
     dur_ms = {"mf_boxcar25_decim5": k_ms["mf_ms"], "gate_scan": k_ms["gate_ms"], "tag_decoder": k_ms["decode_ms"]}
+    n_launch = {"mf_boxcar25_decim5": launches["front_chunks"], "gate_scan": launches["front_chunks"],
+                "tag_decoder": launches["decode_launches"]}
     traffic = {}
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pt = json.load(f)
         if pt.get("streams") == B and pt.get("raw_per_stream") == L:
-            traffic = pt.get("hbm_bytes_per_launch", {})
+            traffic = pt.get("hbm_bytes_per_step", {})
     except Exception:
         pass
 
     def roof(name):
+        # a pass issues n_launch launches of this kernel (time chunks / window types), each moving
+        # 1/n_launch of the bytes: the per-launch ratio equals the per-pass ratio
+        nl = max(1, n_launch[name])
         ach = alg[name] / (dur_ms[name] * 1e-3) / 1e9 if dur_ms[name] > 0 else 0.0
+        tr = traffic.get(name)
         return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(name),
-                "algorithmic_bytes": int(alg[name]), "avg_ms": round(dur_ms[name], 4)}
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": (int(tr / nl) if tr else None),
+                "algorithmic_bytes": int(alg[name] / nl), "launches_per_step": nl,
+                "avg_launch_ms": round(dur_ms[name] / nl, 4), "ms_per_step": round(dur_ms[name], 4)}
 
     dominant = max(dur_ms, key=lambda k: dur_ms[k])
     total_raw = float(B) * L * args.steps * n_gpus
@@ -192,6 +201,7 @@ def main():
                         "FAILED: %d EPC ok, expected %d" % (n_epc_ok, expect_ok),
         "roofline": roof(dominant),
         "roofline_by_kernel": {k: roof(k) for k in alg},
+        "front_end_ms": round(k_ms["front_ms"], 4),
     }
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(base.samples, args.sigma, args.cpu_seconds)

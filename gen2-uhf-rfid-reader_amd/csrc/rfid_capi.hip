@@ -588,6 +588,9 @@ int rfid_batch_timing_get(rfid_ctx *c, rfid_batch_timing *out) {
     out->total_ms = ms[0] + ms[1] + ms[2] + ms[3];
   }
   out->mf_ms = ms[0]; out->gate_ms = ms[1]; out->decode_ms = ms[2]; out->stats_ms = ms[3];
+  out->front_ms = (c->n_chunks_last > 0) ? front : (ms[0] + ms[1]);
+  out->front_chunks = (c->n_chunks_last > 0) ? c->n_chunks_last : 1;
+  out->decode_launches = 2;
   return RFID_OK;
 }
 

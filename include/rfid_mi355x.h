@@ -121,7 +121,11 @@ typedef struct rfid_stream_stats {
 
 /* timing of the last rfid_batch_* pass, from HIP events on the ctx stream */
 typedef struct rfid_batch_timing {
-  float mf_ms, gate_ms, decode_ms, stats_ms, total_ms;
+  float mf_ms, gate_ms, decode_ms, stats_ms; /* kernel time per pass (summed over the launches of a pass) */
+  float total_ms;       /* wall time of the pass on the device (front end overlapped) */
+  float front_ms;       /* wall time of matched filter + gate scan (they overlap on two streams) */
+  int32_t front_chunks; /* launches of each of the two front-end kernels in the pass (1 = not chunked) */
+  int32_t decode_launches; /* 2: one EPC launch, one RN16 launch */
 } rfid_batch_timing;
 
 typedef struct rfid_ctx rfid_ctx;
