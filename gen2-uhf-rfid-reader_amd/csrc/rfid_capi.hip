@@ -431,7 +431,7 @@ int rfid_batch_gate(rfid_ctx *c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(h.data(), d_prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
     (void)hipFree(d_prof);
-    const char *names[12] = {"read+chains", "finish-back", "thresh+fsm(rest)", "dc-prep", "pins", "wait-producer", "total", "ticks() cost", "chain-complete", "thresh+ballot", "fsm", "-"};
+    const char *names[12] = {"steps open-fast", "steps closed-fast", "steps general", "general loop iterations", "dc none", "wait-producer ticks", "total ticks", "dc fast", "dc slow", "-", "-", "-"};
     for (int i = 0; i < 11; ++i) fprintf(stderr, "[gate prof] %-12s %lld ticks (stream 0)\n", names[i], h[(size_t)i]);
   } else {
     hipLaunchKernelGGL(gate_scan_kernel, dim3((unsigned)((c->B + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG)), dim3(GATE_THREADS), 0, c->stream, a);
@@ -495,7 +495,10 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
   if (n_raw > c->max_raw) return RFID_ERR_CAPACITY;
   const int64_t n_out = n_raw / DECIM;
   const int64_t tiles = (n_out + MF_TILE - 1) / MF_TILE;
-  int nch = 8;
+  // measured on MI355X (1024 traces): the overlap paid off while the gate scan took 4 ms (-5 %), but the
+  // scan is slowed down by anything that shares its SIMDs; since it runs in 2.9 ms the plain sequence is
+  // faster, so chunking is opt-in (RFID_FRONT_CHUNKS=8)
+  int nch = 1;
   if (const char *e = getenv("RFID_FRONT_CHUNKS")) nch = atoi(e);
   if (nch > rfid_ctx::MAX_CHUNKS) nch = rfid_ctx::MAX_CHUNKS;
   if (tiles < 4 * (int64_t)nch || nch < 2) {   // short traces: plain sequence

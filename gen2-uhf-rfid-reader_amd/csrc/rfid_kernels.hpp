@@ -302,8 +302,6 @@ template <bool PROF>
 RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const GateSlot *slot, bool has_front,
                               int pos, int n, int n_total, int s, int lane, float2 *lds_dc, float2 *lds_tmp,
                               long long *tk) {
-  long long t0 = 0, t1 = 0;
-  if (PROF) t0 = wv::ticks();
   float f_amp = 0.0f, f_d = 0.0f, f_tre = 0.0f, f_tim = 0.0f;
   float2 f_yv = make_float2(0.0f, 0.0f);
   if (has_front) {
@@ -313,7 +311,6 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
   float avg, dcr, dci;
   chain_add3(g.avg_c, f_d, g.dcr_c, B.has ? B.tre : 0.0f, g.dci_c, B.has ? B.tim : 0.0f, lane, avg, dcr, dci);
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  if (PROF) { t1 = wv::ticks(); tk[0] += t1 - t0; t0 = t1; wv::keep(wv::readlane(avg, 63)); t1 = wv::ticks(); tk[8] += t1 - t0; t0 = t1; }
 
   // ---- finish the back step ----------------------------------------------------------------
   if (B.has) {
@@ -333,7 +330,6 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
   }
   const float2 prev_yv = B.yv;   // samples of step k-1 (for the dc ring rebuild)
   B.has = false;
-  if (PROF) { t1 = wv::ticks(); tk[1] += t1 - t0; t0 = t1; }
 
   // ---- carry the front step through threshold test and state machine --------------------------
   if (has_front) {
@@ -343,7 +339,6 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
   const float thresh = avg * THRESH_FRACTION;  // gate_impl.cc:136
   const uint64_t below = wv::ballot(valid && (f_amp < thresh));
   const uint64_t above = wv::ballot(valid && (f_amp > thresh));
-  if (PROF) { wv::keep((int)(below ^ above)); t1 = wv::ticks(); tk[9] += t1 - t0; t0 = t1; }
 
   // edge / pulse / window state machine on the scalar unit, event driven (gate_impl.cc:145-195)
   uint64_t closedmask = 0, openmask = 0;
@@ -351,94 +346,90 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
   int f_n = g.f_n, f_state = g.f_state, f_pulses = g.f_pulses, f_open = g.f_open;
   int f_ung = g.f_ung, f_type = g.f_type;
   int p = 0;
-  const uint64_t vmask = lane_range(0, nvalid);
-#if defined(RFID_ABLATE) && (RFID_ABLATE & 2)
-  closedmask = vmask; p = nvalid;
-#endif
-  // O(1) cases first: a step entirely inside a window, or a closed step without any event
-  if (p == nvalid) {
-  } else if (f_open) {
-    if (f_ung - f_n > nvalid) { openmask = vmask; f_n += nvalid; p = nvalid; }
-  } else if (f_state == 1) {
-    const bool may_open = (f_pulses > NUM_PULSES_CMD) && (T1_SAMPLES - f_n < nvalid);
-    if ((below & vmask) == 0 && !may_open) { closedmask = vmask; f_n += nvalid; p = nvalid; }
-  } else {
-    if ((above & vmask) == 0) { closedmask = vmask; f_n += nvalid; p = nvalid; }
-  }
-#if defined(RFID_ABLATE) && (RFID_ABLATE & 8)
-  if (p < nvalid) { closedmask = vmask; f_n += nvalid; p = nvalid; }
-#endif
-  while (p < nvalid) {   // general event-driven scan (a few percent of the steps)
-    if (f_open) {
-      int take = f_ung - f_n;
-      if (take > nvalid - p) take = nvalid - p;
-      if (take < 0) take = 0;
-      openmask |= lane_range(p, p + take);
-      f_n += take;
-      p += take;
-      if (f_n >= f_ung) {  // gate_impl.cc:189-194
-        f_open = 0;
-        if (a.mode == 0) {  // decoder + reader ran; gate re-armed at the next sample (:112-123)
-          f_n = 0;
-          f_type ^= 1;
-          f_ung = f_type ? EPC_WIN : RN16_WIN;
-        } else {
-          g.stop = true;
-          g.consumed = pos + p;
-          nvalid = p;
-        }
-      }
-    } else {
-      const uint64_t rem = lane_range(p, nvalid);
-      if (f_state == 1) {
-        const int e = wv::ffs64(below & rem);
-        int popen = 64;
-        if (f_pulses > NUM_PULSES_CMD) {
-          int need = T1_SAMPLES - f_n;
-          if (need < 0) need = 0;
-          popen = p + need;
-        }
-        if (popen < e && popen < nvalid) {  // gate_impl.cc:164-180
-          closedmask |= lane_range(p, popen + 1);
-          openmask |= 1ull << popen;
-          if (open_lane < 0) { open_lane = popen; open_type = f_type; }
-          else { open_lane2 = popen; open_type2 = f_type; }
-          f_open = 1;
-          f_n = 1;
-          f_pulses = 0;
-          p = popen + 1;
-        } else if (e < nvalid) {            // gate_impl.cc:148-152
-          closedmask |= lane_range(p, e + 1);
-          f_n = 0;
-          f_state = 0;
-          p = e + 1;
-        } else {
-          closedmask |= rem;
-          f_n += nvalid - p;
-          p = nvalid;
-        }
+  // (1) a window is open at the start of the step (gate_impl.cc:182-195)
+  if (f_open) {
+    int take = f_ung - f_n;
+    if (take > nvalid) take = nvalid;
+    if (take < 0) take = 0;
+    openmask = lane_range(0, take);
+    f_n += take;
+    p = take;
+    if (f_n >= f_ung) {  // gate_impl.cc:189-194
+      f_open = 0;
+      if (a.mode == 0) {  // decoder + reader ran; gate re-armed at the next sample (:112-123)
+        f_n = 0;
+        f_type ^= 1;
+        f_ung = f_type ? EPC_WIN : RN16_WIN;
       } else {
-        const int e = wv::ffs64(above & rem);
-        if (e < nvalid) {                   // gate_impl.cc:154-162
-          const int n_at = f_n + (e - p + 1);
-          f_state = 1;
-          f_pulses = (n_at > PW_HALF) ? (f_pulses + 1) : 0;
-          f_n = 0;
-          closedmask |= lane_range(p, e + 1);
-          p = e + 1;
-        } else {
-          closedmask |= rem;
-          f_n += nvalid - p;
-          p = nvalid;
-        }
+        g.stop = true;
+        g.consumed = pos + p;
+        nvalid = p;
       }
+    }
+    if (PROF) tk[0]++;
+  }
+  // (2) closed samples [p, nvalid)
+  if (p < nvalid) {
+    const uint64_t rem = lane_range(p, nvalid);
+    // (2a) end of a reader command: the gate opens at the first sample with n_samples > T1 while
+    //      POS_EDGE and num_pulses > 5 (gate_impl.cc:164-180) -- possible only before the first
+    //      falling edge of the step (any edge restarts the 97-sample count)
+    if (f_state == 1 && f_pulses > NUM_PULSES_CMD) {
+      const int e = wv::ffs64(below & rem);
+      int need = T1_SAMPLES - f_n;
+      if (need < 0) need = 0;
+      const int popen = p + need;
+      if (popen < e && popen < nvalid) {
+        closedmask = lane_range(p, popen + 1);
+        openmask |= lane_range(popen, nvalid);     // the opening sample and everything after it
+        open_lane = popen; open_type = f_type;
+        f_open = 1;
+        f_pulses = 0;
+        f_n = nvalid - popen;                       // 1 for the opening sample + the rest of the step
+        p = nvalid;
+      }
+    }
+    // (2b) edge / pulse bookkeeping of a closed segment without opening, loop-free
+    //      (gate_impl.cc:145-162).  The POS/NEG state after each sample is the type of the last
+    //      threshold crossing: a carry chain with generate = above, kill = below.
+    if (p < nvalid) {
+      const int len = nvalid - p;
+      const uint64_t m = lane_range(0, len);
+      const uint64_t av = (above >> p) & m, bv = (below >> p) & m;
+      const uint64_t pr = ~(av | bv) & m;                       // propagate: no crossing
+      const uint64_t X = av | pr, Y = av;
+      const uint64_t sum = X + Y + (uint64_t)(f_state & 1);
+      const uint64_t s_before = (X ^ Y ^ sum) & m;              // carry INTO bit i = state before sample i
+      const uint64_t F = bv & s_before;                         // falling edges (POS -> NEG)
+      const uint64_t R = av & ~s_before;                        // rising edges  (NEG -> POS)
+      const uint64_t marks = av | bv;
+      if (marks) f_state = (int)((av >> (63 - __builtin_clzll(marks))) & 1ull);
+      const uint64_t E = F | R;
+      if (E == 0) {
+        f_n += len;
+      } else {
+        if (R) {
+          // a rising edge counts as a pulse if the low phase before it lasted more than PW/2 = 2
+          // samples (n_samples > n_samples_PW/2), else the pulse count restarts
+          uint64_t shortm = R & ((F << 1) | (F << 2));
+          const int r1 = __builtin_ctzll(R);
+          if ((F & lane_range(0, r1)) == 0 && !(f_n + r1 + 1 > PW_HALF)) shortm |= 1ull << r1;  // low phase began earlier
+          if (shortm == 0) {
+            f_pulses += wv::popc64(R);
+          } else {
+            const int hb = 63 - __builtin_clzll(shortm);
+            f_pulses = wv::popc64(R & ~lane_range(0, hb + 1));
+          }
+        }
+        f_n = len - 1 - (63 - __builtin_clzll(E));              // samples since the last edge
+      }
+      closedmask |= rem;
+      if (PROF) tk[1]++;
     }
   }
   g.f_n = f_n; g.f_state = f_state; g.f_pulses = f_pulses; g.f_open = f_open;
   g.f_ung = f_ung; g.f_type = f_type;
-  if (PROF) { wv::keep(f_n + p); t1 = wv::ticks(); tk[10] += t1 - t0; t0 = t1; }
   g.avg_c = wv::readlane(avg, nvalid - 1);   // carry only over the samples actually consumed
-  if (PROF) { t1 = wv::ticks(); tk[2] += t1 - t0; t0 = t1; }
 
   // ---- dc increments of the closed samples (gate_impl.cc:141-143) -> next back step ------------
 #if defined(RFID_ABLATE) && (RFID_ABLATE & 4)
@@ -461,8 +452,10 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
     g.dc_index += 64 - DC_LEN;            // (dc_index + 64) mod 48
     if (g.dc_index >= DC_LEN) g.dc_index -= DC_LEN;
     g.ring_stale = 1;
+    if (PROF) tk[7]++;
     if (g.run_closed < (1 << 28)) g.run_closed += 64;
   } else {
+    if (PROF) tk[8]++;
     if (g.ring_stale) {
       // the ring was not maintained on the fast path: its content is x[pos-48 .. pos-1]
       // (= lanes 16..63 of the previous step), oldest at dc_index
@@ -513,11 +506,9 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
   B.open_lane = open_lane; B.open_type = open_type; B.open_lane2 = open_lane2; B.open_type2 = open_type2;
   B.pos = pos;
   B.has = true;
-  if (PROF) { t1 = wv::ticks(); tk[3] += t1 - t0; t0 = t1; }
   }  // if (has_front)
 
   RFID_GATE_PINS
-  if (PROF) { t1 = wv::ticks(); tk[4] += t1 - t0; t0 = wv::ticks(); tk[7] += t0 - t1; }
 }
 
 // Workgroup = 8 waves = 4 traces: waves 0..3 are the consumers of traces 4b..4b+3, waves 4..7
