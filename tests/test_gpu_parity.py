@@ -140,3 +140,39 @@ def test_fst_like_known_answer(gpu_ctx, synth_mod):
     for res, slot in zip(epc, t.slots):
         assert list(rfid.unpack_bits(res["bits"], 128)) == slot.epc
         assert bool(res["crc_ok"]) == slot.epc_valid
+
+
+def test_multi_tag_q4_long_trace_matches_oracle(oracle_mod, synth_mod):
+    """BASELINE.json configs[2] shape at a size the oracle finishes in a second: FIXED_Q=4
+    (16 slots per round), 8 tags, empty and collided slots, 12 rounds (192 slots, ~2.7 M raw
+    samples), cut into ragged copies.  Everything bit-exact, incl. the slot/round counters."""
+    import rfid
+    t = synth_mod.make_trace(n_rounds=12, fixed_q=4, tag_ids=(3, 17, 39, 77, 120, 200, 201, 255), seed=77,
+                             sigma=0.01, t1_jitter_raw=4).samples
+    L = len(t)
+    raw = np.zeros((5, L), dtype=np.complex64)     # 5 traces: the gate workgroup holds 4 -> partial group
+    lens = [L, L - 12345, L // 2, L // 3, 17]
+    for i, n in enumerate(lens):
+        raw[i, :n] = t[:n]
+    ctx = rfid.Context(device=0, fixed_q=4)
+    try:
+        w, r, s, st = _run_batch(ctx, raw, lens=lens)
+        cfg = oracle_mod.config(fixed_q=4)
+        for i, (wb, rb, sb) in enumerate(parity.split_by_stream(w, r, s, 5)):
+            parity.compare_trace(wb, rb, sb, st[i], oracle_mod.run_trace(raw[i, : lens[i]], cfg))
+        assert st[0]["cur_inventory_round"] == 13 and st[0]["n_queries_sent"] == 193
+    finally:
+        ctx.close()
+
+
+def test_front_end_time_chunking_matches_single_launch(gpu_ctx, oracle_mod, synth_mod, monkeypatch):
+    """rfid_batch_process with RFID_FRONT_CHUNKS: matched filter and gate scan overlapped on two
+    streams, gate state carried from chunk to chunk -- identical results."""
+    t = synth_mod.make_trace(n_rounds=9, seed=88, sigma=0.02).samples
+    raw = np.stack([t, np.roll(t, 7)])
+    monkeypatch.setenv("RFID_FRONT_CHUNKS", "4")
+    w, r, s, st = _run_batch(gpu_ctx, raw)
+    monkeypatch.delenv("RFID_FRONT_CHUNKS")
+    assert gpu_ctx.batch_timing()["front_chunks"] == 4
+    for b, (wb, rb, sb) in enumerate(parity.split_by_stream(w, r, s, 2)):
+        parity.compare_trace(wb, rb, sb, st[b], oracle_mod.run_trace(raw[b]))
