@@ -9,6 +9,7 @@ from . import _capi as capi
 from .blocks import gate, matched_filter, reader, tag_decoder
 from .context import Context, unpack_bits
 from .flowgraph import reader_top_block
+from . import batch, shard
 
 __all__ = ["capi", "Context", "unpack_bits", "gate", "tag_decoder", "reader", "matched_filter",
-           "reader_top_block"]
+           "reader_top_block", "batch", "shard"]

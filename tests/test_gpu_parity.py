@@ -176,3 +176,27 @@ def test_front_end_time_chunking_matches_single_launch(gpu_ctx, oracle_mod, synt
     assert gpu_ctx.batch_timing()["front_chunks"] == 4
     for b, (wb, rb, sb) in enumerate(parity.split_by_stream(w, r, s, 2)):
         parity.compare_trace(wb, rb, sb, st[b], oracle_mod.run_trace(raw[b]))
+
+
+def test_file_ingest_batch_decoder(tmp_path, oracle_mod, synth_mod):
+    """Trace files in the reference's format (interleaved float32 I,Q, apps/reader.py:102) ->
+    pinned staging -> HBM -> one batched pass; ragged lengths."""
+    import rfid
+    traces = [synth_mod.make_trace(n_rounds=r, seed=300 + r, sigma=0.01).samples for r in (1, 3, 2)]
+    paths = []
+    for i, t in enumerate(traces):
+        p = tmp_path / f"trace{i}.cf32"
+        rfid.batch.write_trace_file(str(p), t)
+        paths.append(str(p))
+    assert np.array_equal(rfid.batch.read_trace_file(paths[1]), traces[1])
+    dec = rfid.batch.BatchDecoder(device=0)
+    try:
+        timing = {}
+        stats, w, r, s = dec.decode_files(paths, want_scores=True, timing=timing)
+        for b, (wb, rb, sb) in enumerate(parity.split_by_stream(w, r, s, 3)):
+            parity.compare_trace(wb, rb, sb, stats[b], oracle_mod.run_trace(traces[b]))
+        summ = rfid.batch.summarize(stats)
+        assert [x["n_epc_correct"] for x in summ] == [1, 3, 2] and summ[1]["tag_reads"] == {0x27: 3}
+        assert timing["raw_samples"] == sum(map(len, traces))
+    finally:
+        dec.close()
