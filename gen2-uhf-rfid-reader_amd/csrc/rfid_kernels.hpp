@@ -223,6 +223,7 @@ struct GateBack {
   int open_lane, open_type, open_lane2, open_type2;
   int pos;
   bool has;
+  bool any_closed;   // some sample of the step updates dc_est
 };
 
 // ---- producer wave: everything that is lane-parallel ---------------------------------------
@@ -309,7 +310,14 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
     f_tre = slot->tre[lane]; f_tim = slot->tim[lane];
   }
   float avg, dcr, dci;
-  chain_add3(g.avg_c, f_d, g.dcr_c, B.has ? B.tre : 0.0f, g.dci_c, B.has ? B.tim : 0.0f, lane, avg, dcr, dci);
+  if (B.has && B.any_closed) {
+    chain_add3(g.avg_c, f_d, g.dcr_c, B.tre, g.dci_c, B.tim, lane, avg, dcr, dci);
+  } else {
+    // the back step lies entirely inside a window (or there is none): all its dc increments are
+    // zero, dc_est does not move -- only the avg_ampl sum runs (a third of the DPP work)
+    avg = chain_add(g.avg_c, f_d, lane);
+    dcr = g.dcr_c; dci = g.dci_c;
+  }
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
   // ---- finish the back step ----------------------------------------------------------------
@@ -506,6 +514,7 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
   B.open_lane = open_lane; B.open_type = open_type; B.open_lane2 = open_lane2; B.open_type2 = open_type2;
   B.pos = pos;
   B.has = true;
+  B.any_closed = cnt != 0;
   }  // if (has_front)
 
   RFID_GATE_PINS
@@ -620,7 +629,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
     const long long t_start = PROF ? wv::ticks() : 0;
     GateBack B;
     B.has = false; B.tre = 0.0f; B.tim = 0.0f; B.openmask = 0; B.yv = make_float2(0.0f, 0.0f);
-    B.open_lane = B.open_lane2 = -1; B.open_type = B.open_type2 = 0; B.pos = 0;
+    B.open_lane = B.open_lane2 = -1; B.open_type = B.open_type2 = 0; B.pos = 0; B.any_closed = false;
     wv::wave_sync();
     for (int k = 0; k < nsteps && !g.stop; ++k) {
       long long tb = 0;
