@@ -307,7 +307,7 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
   float2 f_yv = make_float2(0.0f, 0.0f);
   if (has_front) {
     f_amp = slot->amp[lane]; f_d = slot->d[lane]; f_yv = slot->yv[lane];
-    f_tre = slot->tre[lane]; f_tim = slot->tim[lane];
+    // (the speculative dc increments slot->tre / tim are fetched only by the steps that use them)
   }
   float avg, dcr, dci;
   if (B.has && B.any_closed) {
@@ -324,11 +324,11 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
   if (B.has) {
     g.dcr_c = wv::readlane(dcr, 63);
     g.dci_c = wv::readlane(dci, 63);
-    if (B.open_lane >= 0) {   // rare: a window opened in the back step
+    if (__builtin_expect(B.open_lane >= 0, 0)) {   // rare: a window opened in the back step
       gate_record_window(a, g, B.open_lane, B.open_type, B.pos, n_total, s, lane, dcr, dci);
       if (B.open_lane2 >= 0) gate_record_window(a, g, B.open_lane2, B.open_type2, B.pos, n_total, s, lane, dcr, dci);
     }
-    if (a.mode == 1 && B.openmask != 0) {  // streaming: emit gated samples in[i] - dc_est (gate_impl.cc:176,187)
+    if (__builtin_expect(a.mode == 1 && B.openmask != 0, 0)) {  // streaming: emit gated samples in[i] - dc_est (gate_impl.cc:176,187)
       const bool isopen = ((B.openmask >> lane) & 1ull) != 0;
       const int orank = wv::popc64(B.openmask & lt);
       if (isopen && g.written + orank < a.gated_cap)
@@ -343,11 +343,42 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
   if (has_front) {
   int nvalid = (n - pos < 64) ? (n - pos) : 64;
   const int nvalid_in = nvalid;
-  const bool valid = lane < nvalid;
   const float thresh = avg * THRESH_FRACTION;  // gate_impl.cc:136
-  const uint64_t below = wv::ballot(valid && (f_amp < thresh));
-  const uint64_t above = wv::ballot(valid && (f_amp > thresh));
+  uint64_t below = wv::ballot(f_amp < thresh);
+  uint64_t above = wv::ballot(f_amp > thresh);
+  if (__builtin_expect(nvalid < 64, 0)) {   // last step of the call: ignore the lanes past the end
+    const uint64_t vm = lane_range(0, nvalid);
+    below &= vm; above &= vm;
+  }
 
+  // The two by far most frequent kinds of step are decided with a handful of scalar
+  // instructions (the consumer wave is issue bound: every instruction costs ~4.5 cycles):
+  //   (A) the whole step lies inside an open window that does not end in it;
+  //   (B) gate closed, POS_EDGE, no sample below the threshold, no opening due, and the dc ring
+  //       fast path applies (the previous 48 samples were closed too).
+  const bool plain_open = (nvalid == 64) && g.f_open && (g.f_ung - g.f_n > 64);
+  const bool plain_closed = (nvalid == 64) && !g.f_open && (g.f_state == 1) && (below == 0) &&
+                            !((g.f_pulses > NUM_PULSES_CMD) && (T1_SAMPLES - g.f_n < 64)) &&
+                            (g.run_closed >= DC_LEN);
+  if (__builtin_expect(plain_open || plain_closed, 1)) {
+    // both plain cases in one straight-line block (selects, no branch between them)
+    const float s_tre = slot->tre[lane], s_tim = slot->tim[lane];
+    g.f_n += 64;
+    g.avg_c = wv::readlane(avg, 63);
+    int di = g.dc_index + (64 - DC_LEN);   // (dc_index + 64) mod 48
+    if (di >= DC_LEN) di -= DC_LEN;
+    g.dc_index = plain_closed ? di : g.dc_index;
+    g.ring_stale = plain_closed ? 1 : g.ring_stale;
+    int rc = g.run_closed + 64;
+    if (rc > (1 << 28)) rc = 1 << 28;
+    g.run_closed = plain_closed ? rc : 0;
+    B.yv = f_yv;
+    B.tre = plain_closed ? s_tre : 0.0f;
+    B.tim = plain_closed ? s_tim : 0.0f;
+    B.openmask = plain_closed ? 0ull : ~0ull;
+    B.open_lane = -1; B.open_lane2 = -1; B.pos = pos; B.has = true; B.any_closed = plain_closed;
+  } else {
+  f_tre = slot->tre[lane]; f_tim = slot->tim[lane];
   // edge / pulse / window state machine on the scalar unit, event driven (gate_impl.cc:145-195)
   uint64_t closedmask = 0, openmask = 0;
   int open_lane = -1, open_lane2 = -1, open_type = 0, open_type2 = 0;
@@ -515,6 +546,7 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
   B.pos = pos;
   B.has = true;
   B.any_closed = cnt != 0;
+  }  // general step
   }  // if (has_front)
 
   RFID_GATE_PINS
