@@ -122,6 +122,7 @@ def main():
 
     k_ms = {"mf_ms": 0.0, "gate_ms": 0.0, "decode_ms": 0.0, "stats_ms": 0.0, "front_ms": 0.0}
     launches = {"front_chunks": 1, "decode_launches": 2}
+    fused = False
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -130,6 +131,7 @@ def main():
         for k in k_ms:
             k_ms[k] += t[k]
         launches = {"front_chunks": int(t["front_chunks"]), "decode_launches": int(t["decode_launches"])}
+        fused = bool(t["fused_front"])
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -151,14 +153,19 @@ def main():
     n_dec = L // 5
     n_rn16 = int(n_windows // 2 + n_windows % 2)
     n_epc = int(n_windows // 2)
-    alg = {
-        "mf_boxcar25_decim5": B * (8.0 * L + 8.0 * n_dec),
-        "gate_scan": B * 8.0 * n_dec + 24.0 * n_windows,
-        "tag_decoder": n_rn16 * (8.0 * RN16_WIN + 48) + n_epc * (8.0 * EPC_WIN + 48),
-    }
-    dur_ms = {"mf_boxcar25_decim5": k_ms["mf_ms"], "gate_scan": k_ms["gate_ms"], "tag_decoder": k_ms["decode_ms"]}
-    n_launch = {"mf_boxcar25_decim5": launches["front_chunks"], "gate_scan": launches["front_chunks"],
-                "tag_decoder": launches["decode_launches"]}
+    dec_bytes = n_rn16 * (8.0 * RN16_WIN + 48) + n_epc * (8.0 * EPC_WIN + 48)
+    if fused:
+        # rfid_batch_process() default: one front-end launch (matched filter inside the gate's producer
+        # waves): reads every raw sample once, writes y once for the decoder, writes the window records
+        alg = {"front_end_fused": B * (8.0 * L + 8.0 * n_dec) + 24.0 * n_windows, "tag_decoder": dec_bytes}
+        dur_ms = {"front_end_fused": k_ms["gate_ms"], "tag_decoder": k_ms["decode_ms"]}
+        n_launch = {"front_end_fused": 1, "tag_decoder": launches["decode_launches"]}
+    else:
+        alg = {"mf_boxcar25_decim5": B * (8.0 * L + 8.0 * n_dec),
+               "gate_scan": B * 8.0 * n_dec + 24.0 * n_windows, "tag_decoder": dec_bytes}
+        dur_ms = {"mf_boxcar25_decim5": k_ms["mf_ms"], "gate_scan": k_ms["gate_ms"], "tag_decoder": k_ms["decode_ms"]}
+        n_launch = {"mf_boxcar25_decim5": launches["front_chunks"], "gate_scan": launches["front_chunks"],
+                    "tag_decoder": launches["decode_launches"]}
     traffic = {}
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:

@@ -70,6 +70,7 @@ struct rfid_ctx {
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_mf[MAX_CHUNKS + 1], ev_gate[2 * MAX_CHUNKS], ev_pass = nullptr, ev_front_end = nullptr;
   int n_chunks_last = 0;   // > 0 when the last pass used the overlapped path
+  int fused_last = 0;      // 1 when the last rfid_batch_process pass used front_end_fused_kernel
   float front_ms = 0.0f;
 };
 
@@ -394,6 +395,7 @@ int rfid_batch_mf(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64_t n_
   a.vec_ok = ((raw_stride & 1) == 0 && (((uintptr_t)d_raw) & 15) == 0) ? 1 : 0;
   a.y = c->d_y; a.y_stride = c->y_stride; a.tile0 = 0;
   c->n_chunks_last = 0;
+  c->fused_last = 0;
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   const int64_t tiles = (a.n_out + MF_TILE - 1) / MF_TILE;
   if (tiles > 0) {
@@ -414,7 +416,7 @@ int rfid_batch_gate(rfid_ctx *c) {
   // arms n_samples_to_ungate for the first RN16 itself
   HIPCHK(c, hipMemsetAsync(c->d_gstate, 0, sizeof(GateState) * (size_t)c->B, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_flat_count, 0, 2 * sizeof(int), c->stream));
-  GateArgs a;
+  GateArgs a = {};
   a.y = c->d_y; a.y_stride = c->y_stride; a.n_dec = c->last_n_raw / DECIM; a.lens = c->d_lens;
   a.pos0 = 0; a.chunk_len = a.n_dec;
   a.state = c->d_gstate; a.n_streams = c->B; a.wtab = c->d_wtab; a.wmax = c->wmax; a.wcount = c->d_wcount;
@@ -501,7 +503,36 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
   int nch = 1;
   if (const char *e = getenv("RFID_FRONT_CHUNKS")) nch = atoi(e);
   if (nch > rfid_ctx::MAX_CHUNKS) nch = rfid_ctx::MAX_CHUNKS;
-  if (tiles < 4 * (int64_t)nch || nch < 2) {   // short traces: plain sequence
+  if (nch < 2 && raw_stride >= 2 && !getenv("RFID_FRONT_UNFUSED")) {
+    // default: fused front end -- the gate's producer waves run the matched filter themselves
+    // (one read of the raw samples, one write of y for the decoder, no second pass over y)
+    HIPCHK(c, hipSetDevice(c->device));
+    c->d_lens = (const int64_t *)d_lens;
+    c->last_n_raw = n_raw;
+    c->n_chunks_last = 0;
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));   // mf_ms = 0: the filter runs inside the gate launch
+    HIPCHK(c, hipMemsetAsync(c->d_gstate, 0, sizeof(GateState) * (size_t)c->B, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_flat_count, 0, 2 * sizeof(int), c->stream));
+    GateArgs g = {};
+    g.y = c->d_y; g.y_w = c->d_y; g.y_stride = c->y_stride; g.n_dec = n_out; g.lens = c->d_lens;
+    g.pos0 = 0; g.chunk_len = n_out;
+    g.state = c->d_gstate; g.n_streams = c->B; g.wtab = c->d_wtab; g.wmax = c->wmax; g.wcount = c->d_wcount;
+    g.flat = c->d_flat; g.flat_count = c->d_flat_count; g.flat_cap = c->flat_cap; g.mode = 0;
+    g.raw = (const float2 *)d_raw; g.raw_stride = raw_stride; g.n_raw = n_raw;
+    g.raw_vec_ok = ((raw_stride & 1) == 0 && (((uintptr_t)d_raw) & 15) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(front_end_fused_kernel, dim3((unsigned)((c->B + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG)),
+                       dim3(GATE_THREADS), 0, c->stream, g);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    c->ev_valid[0] = c->ev_valid[1] = c->ev_valid[2] = true;
+    c->fused_last = 1;
+    int rc = rfid_batch_decode(c, want_scores);
+    if (rc) return rc;
+    return rfid_batch_stats(c);
+  }
+  c->fused_last = 0;
+  if (tiles < 4 * (int64_t)nch || nch < 2) {   // plain sequence of the stage kernels
     int rc = rfid_batch_mf(c, d_raw, raw_stride, n_raw, d_lens);
     if (rc) return rc;
     if ((rc = rfid_batch_gate(c))) return rc;
@@ -522,7 +553,7 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
   m.n_out = n_out; m.in_off = -(NTAPS - 1);
   m.vec_ok = ((raw_stride & 1) == 0 && (((uintptr_t)d_raw) & 15) == 0) ? 1 : 0;
   m.y = c->d_y; m.y_stride = c->y_stride;
-  GateArgs g;
+  GateArgs g = {};
   g.y = c->d_y; g.y_stride = c->y_stride; g.n_dec = n_out; g.lens = c->d_lens;
   g.state = c->d_gstate; g.n_streams = c->B; g.wtab = c->d_wtab; g.wmax = c->wmax; g.wcount = c->d_wcount;
   g.flat = c->d_flat; g.flat_count = c->d_flat_count; g.flat_cap = c->flat_cap; g.mode = 0;
@@ -594,6 +625,8 @@ int rfid_batch_timing_get(rfid_ctx *c, rfid_batch_timing *out) {
   out->front_ms = (c->n_chunks_last > 0) ? front : (ms[0] + ms[1]);
   out->front_chunks = (c->n_chunks_last > 0) ? c->n_chunks_last : 1;
   out->decode_launches = 2;
+  out->fused_front = c->fused_last;
+  out->reserved_ = 0;
   return RFID_OK;
 }
 
@@ -741,7 +774,7 @@ int rfid_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, i
   if (rc) return rc;
   if ((rc = grow(c, c->s_out, sizeof(float2) * (size_t)(n_in + 2)))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->s_in.p, in, sizeof(rfid_cf32) * (size_t)n_in, hipMemcpyHostToDevice, c->stream));
-  GateArgs a;
+  GateArgs a = {};
   a.y = (const float2 *)c->s_in.p; a.y_stride = n_in; a.n_dec = n_in; a.lens = nullptr;
   a.pos0 = 0; a.chunk_len = n_in;
   a.state = c->d_gate1; a.n_streams = 1; a.wtab = nullptr; a.wmax = 0; a.wcount = nullptr;

@@ -79,6 +79,15 @@ RFID_DEVICE void wave_sync() {
 // producer wave's register prefetch every step
 RFID_DEVICE void block_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 RFID_DEVICE int atomic_add(int *p, int v) { return atomicAdd(p, v); }
+// this wave's global stores are visible device-wide when this returns
+RFID_DEVICE void global_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+// global load that bypasses the per-CU vector cache (device-coherent): for data another wave of
+// the workgroup stored earlier in this launch
+RFID_DEVICE float2 load_coherent(const float2 *p) {
+  const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+  return make_float2(__uint_as_float((unsigned)(u & 0xffffffffu)), __uint_as_float((unsigned)(u >> 32)));
+}
 // LDS mailbox words shared by two waves of one workgroup: volatile accesses, in-order LDS
 // queue per wave; the store is issued by one lane after the wave's earlier LDS writes.
 #define RFID_LDS_AS __attribute__((address_space(3)))

@@ -162,6 +162,13 @@ struct GateArgs {
   int gated_cap;
   int *io;              // streaming: io[0] = consumed, io[1] = written
   long long *prof;      // optional phase counters (gate_scan_kernel_prof only)
+  // fused front end (front_end_fused_kernel): the producer wave computes the matched filter
+  // itself from the raw 2 Msps samples and writes y (for the decoder) instead of reading it
+  const float2 *raw;    // [n_streams][raw_stride]
+  int64_t raw_stride;
+  int64_t n_raw;        // valid raw samples per trace (when lens == nullptr)
+  int raw_vec_ok;       // rows 16-byte aligned -> float4 loads
+  float2 *y_w;          // [n_streams][y_stride], written
 };
 
 // In-order sum: returns in lane L the value  (((carry + x_0) + x_1) + ...) + x_L.
@@ -557,6 +564,9 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
 // SIMD hosts exactly one consumer (DPP chains do not co-issue across waves) and one producer.
 // Producer and consumer of a trace talk through a 4-slot LDS ring with sequence counters --
 // no s_barrier, hence no coupling between the traces of a workgroup.
+constexpr int GATE_RAW = 64 * DECIM + (NTAPS - DECIM);   // 344 raw samples feed 64 matched-filter outputs
+constexpr int GATE_RAW4 = GATE_RAW / 2;                  // as float4 (2 samples each): 172
+constexpr int GATE_RAW_LD = (GATE_RAW4 + 63) / 64;       // float4 loads per lane and step: 3
 constexpr int GATE_STREAMS_PER_WG = 4;
 constexpr int GATE_THREADS = 128 * GATE_STREAMS_PER_WG;
 constexpr int GATE_SLOTS = 4;
@@ -567,13 +577,64 @@ struct GateShared {          // per trace
   float win[WIN_LEN + 4];    // producer's working copy of gate_impl::win_samples
   float2 dc[DC_LEN];         // gate_impl::dc_samples
   float2 tmp[64];
+  float4 rawtile[GATE_RAW4 + 2];   // fused front end: the 344 raw samples one step's matched filter needs
   int prod_seq;              // steps produced so far
   int cons_seq;              // steps consumed so far
   int stop;                  // consumer -> producer: stop (streaming mode window close)
-  int pad_;
+  int prod_done;             // fused front end: the producer's y stores are visible device-wide
 };
 
-template <bool PROF>
+// raw samples of one step (fused front end): float4 #(lane + 64 j) of the 172 the step needs
+struct GateRawRegs {
+  float4 v[GATE_RAW_LD];
+};
+
+// Loads are unconditional (a select or a lane-divergent branch on a loaded value would force an
+// s_waitcnt right behind the load and drain the prefetch): the index is clamped into the row
+// instead.  Samples below index 0 are zeroed when the step is consumed (gate_fir_step, first
+// step only); samples at or above the trace length only feed outputs that do not exist.
+RFID_DEVICE void gate_load_raw(GateRawRegs &r, const float2 *xs, int hi_idx, int r0, int lane, bool vec) {
+  // r0 = raw index of the first sample of the step's window (even; -24 for the first step)
+#pragma unroll
+  for (int j = 0; j < GATE_RAW_LD; ++j) {
+    int q = lane + 64 * j;
+    q = (q < GATE_RAW4) ? q : (GATE_RAW4 - 1);
+    int ri = r0 + 2 * q;
+    ri = (ri < 0) ? 0 : ri;
+    ri = (ri > hi_idx) ? hi_idx : ri;
+    if (vec) {
+      r.v[j] = *reinterpret_cast<const float4 *>(xs + ri);
+    } else {
+      const float2 lo = xs[ri], hi = xs[ri + 1];
+      r.v[j] = make_float4(lo.x, lo.y, hi.x, hi.y);
+    }
+  }
+}
+
+// matched filter of one step inside the producer wave: y[n] = sum_{k=0..24} x[5n-24+k], k ascending
+// (the arithmetic of mf_boxcar25_decim5_kernel), for n = first output of the step + lane
+RFID_DEVICE float2 gate_fir_step(const GateRawRegs &r, float4 *tile4, int lane, bool first) {
+  wv::wave_sync();   // the previous step's reads of the tile are done
+#pragma unroll
+  for (int j = 0; j < GATE_RAW_LD; ++j) {
+    const int q = lane + 64 * j;
+    float4 v = r.v[j];
+    if (j == 0 && first && q < (NTAPS - 1) / 2) v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // x[-24..-1] = 0
+    if (q < GATE_RAW4) tile4[q] = v;
+  }
+  wv::wave_sync();
+  const float2 *tile = reinterpret_cast<const float2 *>(tile4);
+  float re = 0.0f, im = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NTAPS; ++k) {
+    const float2 v = tile[DECIM * lane + k];
+    re = re + v.x;
+    im = im + v.y;
+  }
+  return make_float2(re, im);
+}
+
+template <bool PROF, bool FUSED>
 RFID_DEVICE void gate_scan_body(const GateArgs &a) {
   RFID_SHARED GateShared sh_all[GATE_STREAMS_PER_WG];
   const int lane = wv::lane_id();
@@ -582,7 +643,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
   const int sl = wave % GATE_STREAMS_PER_WG;
   const int s = (int)blockIdx.x * GATE_STREAMS_PER_WG + sl;
   GateShared &sh = sh_all[sl];
-  if (lane == 0 && role == 0) { sh.prod_seq = 0; sh.cons_seq = 0; sh.stop = 0; }
+  if (lane == 0 && role == 0) { sh.prod_seq = 0; sh.cons_seq = 0; sh.stop = 0; sh.prod_done = 0; }
   wv::block_sync();   // once, before any hand-off
   if (s >= a.n_streams) return;
   GateState *st = a.state + s;
@@ -607,37 +668,76 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
     for (int j = lane; j < WIN_LEN; j += 64) sh.win[j] = st->win[j];
     int win_index = win_index0;
     wv::wave_sync();
-    float2 cur[GATE_PREFETCH], nxt[GATE_PREFETCH];
-#pragma unroll
-    for (int u = 0; u < GATE_PREFETCH; ++u) {
-      const int i = 64 * u + lane;
-      cur[u] = (i < n) ? ys[i] : make_float2(0.0f, 0.0f);
-    }
     float2 prev_yv = make_float2(0.0f, 0.0f);
     bool stopped = false;
-    for (int base = 0; base < nsteps && !stopped; base += GATE_PREFETCH) {
+    if (FUSED) {
+      // ---- fused front end: raw samples in, matched filter here, y written for the decoder ----
+      const float2 *xs = a.raw + (int64_t)s * a.raw_stride;
+      const bool vec = a.raw_vec_ok != 0;
+      // last index a (two-sample) load may start at: inside the row's stride (rows are contiguous)
+      const int hi_idx = vec ? (int)((a.raw_stride - 2) & ~(int64_t)1) : (int)(a.raw_stride - 2);
+      float2 *yw = a.y_w + (int64_t)s * a.y_stride + a.pos0;
+      const int rbase = (int)a.pos0 * DECIM - (NTAPS - 1);   // raw index of the window of output pos0
+      GateRawRegs cur[GATE_PREFETCH], nxt[GATE_PREFETCH];
 #pragma unroll
-      for (int u = 0; u < GATE_PREFETCH; ++u) {
-        const int i = 64 * (base + GATE_PREFETCH + u) + lane;
-        nxt[u] = (i < n) ? ys[i] : make_float2(0.0f, 0.0f);
-      }
+      for (int u = 0; u < GATE_PREFETCH; ++u) gate_load_raw(cur[u], xs, hi_idx, rbase + u * 64 * DECIM, lane, vec);
+      for (int base = 0; base < nsteps && !stopped; base += GATE_PREFETCH) {
 #pragma unroll
-      for (int u = 0; u < GATE_PREFETCH; ++u) {
-        const int k = base + u;
-        if (k < nsteps && !stopped) {
-          // wait for a free slot (the consumer is at most GATE_SLOTS steps behind)
-          while (!stopped && k - wv::lds_load(&sh.cons_seq) >= GATE_SLOTS) {
-            stopped = wv::lds_load(&sh.stop) != 0;
-            wv::backoff();
-          }
-          if (!stopped) {
-            gate_produce(sh.slots[k % GATE_SLOTS], cur[u], prev_yv, 64 * k, n, lane, sh.win, win_index);
-            wv::lds_store(&sh.prod_seq, k + 1, lane);   // after the slot's data (in-order LDS queue)
+        for (int u = 0; u < GATE_PREFETCH; ++u)
+          gate_load_raw(nxt[u], xs, hi_idx, rbase + (base + GATE_PREFETCH + u) * 64 * DECIM, lane, vec);
+#pragma unroll
+        for (int u = 0; u < GATE_PREFETCH; ++u) {
+          const int k = base + u;
+          if (k < nsteps && !stopped) {
+            while (!stopped && k - wv::lds_load(&sh.cons_seq) >= GATE_SLOTS) {
+              stopped = wv::lds_load(&sh.stop) != 0;
+              wv::backoff();
+            }
+            if (!stopped) {
+              float2 yv = gate_fir_step(cur[u], sh.rawtile, lane, k == 0 && a.pos0 == 0);
+              if (64 * k + lane < n) yw[64 * k + lane] = yv;
+              else yv = make_float2(0.0f, 0.0f);
+              gate_produce(sh.slots[k % GATE_SLOTS], yv, prev_yv, 64 * k, n, lane, sh.win, win_index);
+              wv::lds_store(&sh.prod_seq, k + 1, lane);   // after the slot's data (in-order LDS queue)
+            }
           }
         }
-      }
 #pragma unroll
-      for (int u = 0; u < GATE_PREFETCH; ++u) cur[u] = nxt[u];
+        for (int u = 0; u < GATE_PREFETCH; ++u) cur[u] = nxt[u];
+      }
+      wv::global_release();                       // the consumer's write-back re-reads y
+      wv::lds_store(&sh.prod_done, 1, lane);
+    } else {
+      float2 cur[GATE_PREFETCH], nxt[GATE_PREFETCH];
+#pragma unroll
+      for (int u = 0; u < GATE_PREFETCH; ++u) {
+        const int i = 64 * u + lane;
+        cur[u] = (i < n) ? ys[i] : make_float2(0.0f, 0.0f);
+      }
+      for (int base = 0; base < nsteps && !stopped; base += GATE_PREFETCH) {
+#pragma unroll
+        for (int u = 0; u < GATE_PREFETCH; ++u) {
+          const int i = 64 * (base + GATE_PREFETCH + u) + lane;
+          nxt[u] = (i < n) ? ys[i] : make_float2(0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int u = 0; u < GATE_PREFETCH; ++u) {
+          const int k = base + u;
+          if (k < nsteps && !stopped) {
+            // wait for a free slot (the consumer is at most GATE_SLOTS steps behind)
+            while (!stopped && k - wv::lds_load(&sh.cons_seq) >= GATE_SLOTS) {
+              stopped = wv::lds_load(&sh.stop) != 0;
+              wv::backoff();
+            }
+            if (!stopped) {
+              gate_produce(sh.slots[k % GATE_SLOTS], cur[u], prev_yv, 64 * k, n, lane, sh.win, win_index);
+              wv::lds_store(&sh.prod_seq, k + 1, lane);   // after the slot's data (in-order LDS queue)
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < GATE_PREFETCH; ++u) cur[u] = nxt[u];
+      }
     }
   } else {
     // ================= consumer ===============================================================
@@ -680,12 +780,16 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
     }
 
     // ---- write state back ----------------------------------------------------------------
+    if (FUSED) {
+      // y was written by the producer wave during this launch: wait until its stores are visible
+      while (wv::lds_load(&sh.prod_done) == 0) wv::backoff();
+    }
     if (g.ring_stale) {
       // materialise the dc ring: the last 48 consumed samples, oldest at dc_index
       if (lane < DC_LEN) {
         int di = g.dc_index + lane;
         if (di >= DC_LEN) di -= DC_LEN;
-        lds_dc[di] = ys[g.consumed - DC_LEN + lane];
+        lds_dc[di] = FUSED ? wv::load_coherent(&ys[g.consumed - DC_LEN + lane]) : ys[g.consumed - DC_LEN + lane];
       }
       wv::wave_sync();
     }
@@ -697,7 +801,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
       const int c = g.consumed;
       const int first = (c > WIN_LEN) ? (c - WIN_LEN) : 0;
       for (int i = first + lane; i < c; i += 64) {
-        const float2 v = ys[i];
+        const float2 v = FUSED ? wv::load_coherent(&ys[i]) : ys[i];
         st->win[(win_index0 + i) % WIN_LEN] = wv::hypot_f(v.x, v.y);
       }
     }
@@ -718,11 +822,14 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
   }
 }
 
-RFID_KERNEL(GATE_THREADS) void gate_scan_kernel(GateArgs a) { gate_scan_body<false>(a); }
+RFID_KERNEL(GATE_THREADS) void gate_scan_kernel(GateArgs a) { gate_scan_body<false, false>(a); }
+// fused front end: matched filter (in the producer waves) + gate scan in one launch; reads the raw
+// 2 Msps samples once, writes y for the decoder
+RFID_KERNEL(GATE_THREADS) void front_end_fused_kernel(GateArgs a) { gate_scan_body<false, true>(a); }
 // same kernel with s_memtime phase counters of the consumer wave (a.prof: [n_streams][8]):
 // 0 slot read + in-order sums, 1 finish back step, 2 threshold + state machine,
 // 3 dc increments, 4 SGPR pinning, 5 waiting for the producer, 6 total
-RFID_KERNEL(GATE_THREADS) void gate_scan_kernel_prof(GateArgs a) { gate_scan_body<true>(a); }
+RFID_KERNEL(GATE_THREADS) void gate_scan_kernel_prof(GateArgs a) { gate_scan_body<true, false>(a); }
 
 // =========================================================================================
 // 3. tag_decoder: one wavefront per window, persistent over the compact window list.

@@ -50,7 +50,8 @@ class ReaderState(C.Structure):
 class BatchTiming(C.Structure):
     _fields_ = [("mf_ms", C.c_float), ("gate_ms", C.c_float), ("decode_ms", C.c_float),
                 ("stats_ms", C.c_float), ("total_ms", C.c_float), ("front_ms", C.c_float),
-                ("front_chunks", C.c_int32), ("decode_launches", C.c_int32)]
+                ("front_chunks", C.c_int32), ("decode_launches", C.c_int32),
+                ("fused_front", C.c_int32), ("reserved_", C.c_int32)]
 
 
 WINDOW_DTYPE = np.dtype([("stream", "<i4"), ("seq", "<i4"), ("start", "<i4"), ("type", "<i4"),

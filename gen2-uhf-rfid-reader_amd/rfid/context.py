@@ -147,7 +147,7 @@ class Context:
         self._chk(self._lib.rfid_batch_timing_get(self._h, C.byref(t)))
         return dict(mf_ms=t.mf_ms, gate_ms=t.gate_ms, decode_ms=t.decode_ms, stats_ms=t.stats_ms,
                     total_ms=t.total_ms, front_ms=t.front_ms, front_chunks=t.front_chunks,
-                    decode_launches=t.decode_launches)
+                    decode_launches=t.decode_launches, fused_front=t.fused_front)
 
     def batch_stats(self) -> np.ndarray:
         n = self._planned[0]

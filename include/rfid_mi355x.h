@@ -126,6 +126,9 @@ typedef struct rfid_batch_timing {
   float front_ms;       /* wall time of matched filter + gate scan (they overlap on two streams) */
   int32_t front_chunks; /* launches of each of the two front-end kernels in the pass (1 = not chunked) */
   int32_t decode_launches; /* 2: one EPC launch, one RN16 launch */
+  int32_t fused_front;  /* 1: rfid_batch_process ran the fused front end (matched filter inside the gate launch:
+                           mf_ms = 0, gate_ms = the fused kernel) */
+  int32_t reserved_;
 } rfid_batch_timing;
 
 typedef struct rfid_ctx rfid_ctx;

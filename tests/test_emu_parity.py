@@ -127,3 +127,21 @@ def test_emulated_time_chunked_gate(emu_mod, oracle_mod, synth_mod, chunk):
     r = emu_mod.batch_process(raw, gate_chunk=chunk)
     for b, (wb, rb, sb) in enumerate(parity.split_by_stream(r["windows"], r["results"], r["scores"], 2)):
         parity.compare_trace(wb, rb, sb, r["stats"][b], oracle_mod.run_trace(raw[b]))
+
+
+@pytest.mark.parametrize("unaligned", [False, True])
+def test_emulated_fused_front_end(emu_mod, oracle_mod, synth_mod, unaligned):
+    """front_end_fused_kernel (what rfid_batch_process() launches by default): the gate's
+    producer waves run the matched filter from the raw samples.  Same windows, decisions, scores
+    and matched-filter output as the oracle, for 16-byte aligned rows (float4 loads) and 8-byte
+    aligned rows, ragged lengths included."""
+    t = synth_mod.make_trace(n_rounds=3, seed=91, sigma=0.02, t1_jitter_raw=7).samples
+    L = len(t)
+    raw = np.stack([t, np.roll(t, 5), t * np.float32(0.5)])
+    lens = np.array([L, L - 1237, L - 20001], dtype=np.int64)
+    r = emu_mod.batch_process(raw, lens=lens, gate_chunk=-1, want_y=True, unaligned=unaligned)
+    for b, (wb, rb, sb) in enumerate(parity.split_by_stream(r["windows"], r["results"], r["scores"], 3)):
+        o = oracle_mod.run_trace(raw[b][: lens[b]])
+        parity.compare_trace(wb, rb, sb, r["stats"][b], o)
+        n = int(lens[b]) // 5
+        assert np.array_equal(r["y"][b][:n].view(np.uint32), oracle_mod.fir(raw[b][: lens[b]])[:n].view(np.uint32))

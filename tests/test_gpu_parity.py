@@ -178,6 +178,43 @@ def test_front_end_time_chunking_matches_single_launch(gpu_ctx, oracle_mod, synt
         parity.compare_trace(wb, rb, sb, st[b], oracle_mod.run_trace(raw[b]))
 
 
+def test_fused_front_end_equals_stage_kernels(gpu_ctx, oracle_mod, synth_mod):
+    """rfid_batch_process() runs the fused front end (matched filter inside the gate launch);
+    rfid_batch_mf + rfid_batch_gate + rfid_batch_decode + rfid_batch_stats run the stage
+    kernels one by one.  Same windows, results, scores, stats and matched-filter output, for
+    16-byte aligned rows and for rows that are only 8-byte aligned (odd stride)."""
+    import torch
+    t = synth_mod.make_trace(n_rounds=5, seed=314, sigma=0.03, t1_jitter_raw=9).samples
+    raw = np.stack([t, np.roll(t, 11), t * np.float32(0.25)])
+    B, L = raw.shape
+    for stride in ((L + 1) & ~1, L | 1):
+        host = np.zeros((B, stride), dtype=np.complex64)
+        host[:, :L] = raw
+        dev = torch.from_numpy(host.view(np.float32)).to("cuda:0")
+        gpu_ctx.batch_plan(B, L)
+        gpu_ctx.batch_process_ptr(dev.data_ptr(), stride, L, 0, want_scores=True)
+        gpu_ctx.batch_sync()
+        assert gpu_ctx.batch_timing()["fused_front"] == 1
+        w1, r1, s1 = gpu_ctx.batch_windows(want_scores=True)
+        st1 = gpu_ctx.batch_stats().copy()
+        y1 = [gpu_ctx.batch_mf_output(b) for b in range(B)]
+        gpu_ctx.batch_stage("mf", dev.data_ptr(), stride, L, 0)
+        gpu_ctx.batch_stage("gate")
+        gpu_ctx.batch_stage("decode", True)
+        gpu_ctx.batch_stage("stats")
+        gpu_ctx.batch_sync()
+        assert gpu_ctx.batch_timing()["fused_front"] == 0
+        w2, r2, s2 = gpu_ctx.batch_windows(want_scores=True)
+        st2 = gpu_ctx.batch_stats()
+        assert w1.tobytes() == w2.tobytes() and r1.tobytes() == r2.tobytes() and s1.tobytes() == s2.tobytes()
+        assert st1.tobytes() == st2.tobytes()
+        for b in range(B):
+            assert np.array_equal(y1[b].view(np.uint32), gpu_ctx.batch_mf_output(b).view(np.uint32))
+            assert np.array_equal(y1[b].view(np.uint32), oracle_mod.fir(raw[b]).view(np.uint32))
+        for b, (wb, rb, sb) in enumerate(parity.split_by_stream(w1, r1, s1, B)):
+            parity.compare_trace(wb, rb, sb, st1[b], oracle_mod.run_trace(raw[b]))
+
+
 def test_file_ingest_batch_decoder(tmp_path, oracle_mod, synth_mod):
     """Trace files in the reference's format (interleaved float32 I,Q, apps/reader.py:102) ->
     pinned staging -> HBM -> one batched pass; ragged lengths."""

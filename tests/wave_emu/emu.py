@@ -28,7 +28,7 @@ def lib():
 
 
 def batch_process(raw: np.ndarray, lens=None, fixed_q=0, max_num_queries=1000, number_unique_tags=100,
-                  want_y=False, gate_chunk=0):
+                  want_y=False, gate_chunk=0, unaligned=False):
     """raw: [B][L] complex64.  -> dict(windows, results, scores, stats, y)"""
     raw = np.ascontiguousarray(raw, dtype=np.complex64)
     if raw.ndim == 1:
@@ -38,6 +38,8 @@ def batch_process(raw: np.ndarray, lens=None, fixed_q=0, max_num_queries=1000, n
     stride = (L + 1) & ~1
     buf = np.zeros(B * stride + 2, dtype=np.complex64)
     off = (16 - buf.ctypes.data % 16) % 16 // 8
+    if unaligned:          # rows 8-byte aligned only: the kernels' float2 load path
+        off ^= 1
     view = buf[off:off + B * stride].reshape(B, stride)
     view[:, :L] = raw
     cap = B * (L // 5 // 347 + 2)
@@ -86,6 +88,8 @@ def decode_one(win: np.ndarray, type_: int):
 def mf_stream(staging: np.ndarray, in_off: int, n_out: int) -> np.ndarray:
     buf = np.zeros(len(staging) + 2, dtype=np.complex64)
     off = (16 - buf.ctypes.data % 16) % 16 // 8
+    if unaligned:          # rows 8-byte aligned only: the kernels' float2 load path
+        off ^= 1
     st = buf[off:off + len(staging)]
     st[:] = staging
     out = np.zeros(max(n_out, 1), dtype=np.complex64)

@@ -113,18 +113,22 @@ int emu_batch_process(const float *raw, int B, long stride, long n_raw, const in
   ma.vec_ok = ((stride & 1) == 0 && (((uintptr_t)raw) & 15) == 0) ? 1 : 0;
   ma.y = y; ma.y_stride = y_stride; ma.tile0 = 0;
   const long tiles = (n_dec + MF_TILE - 1) / MF_TILE;
-  if (tiles > 0)
+  const bool fused = gate_chunk < 0;   // gate_chunk -1: the fused front end, as rfid_batch_process() runs by default
+  if (tiles > 0 && !fused)
     emu::launch(emu::Idx3{(unsigned)tiles, (unsigned)B, 1}, emu::Idx3{MF_THREADS, 1, 1},
                 [&]() { mf_boxcar25_decim5_kernel(ma); });
-  if (y_out)
-    for (int b = 0; b < B; ++b) memcpy(y_out + 2 * (size_t)b * n_dec, y + (size_t)b * y_stride, sizeof(float2) * (size_t)n_dec);
 
-  GateArgs ga;
+  GateArgs ga = {};
   ga.y = y; ga.y_stride = y_stride; ga.n_dec = n_dec; ga.lens = lens; ga.state = gstate.data(); ga.n_streams = B;
   ga.wtab = wtab.data(); ga.wmax = wmax; ga.wcount = wcount.data(); ga.flat = flat.data();
   ga.flat_count = flat_count; ga.flat_cap = flat_cap; ga.mode = 0; ga.gated = nullptr; ga.gated_cap = 0;
   ga.io = nullptr; ga.prof = nullptr;
-  {
+  if (fused) {
+    ga.pos0 = 0; ga.chunk_len = n_dec; ga.y_w = y;
+    ga.raw = reinterpret_cast<const float2 *>(raw); ga.raw_stride = stride; ga.n_raw = n_raw; ga.raw_vec_ok = ma.vec_ok;
+    emu::launch(emu::Idx3{(unsigned)((B + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG), 1, 1},
+                emu::Idx3{GATE_THREADS, 1, 1}, [&]() { front_end_fused_kernel(ga); });
+  } else {
     // time-chunked launches with carried state, as rfid_batch_process() issues them
     const long chunk = (gate_chunk > 0) ? gate_chunk : (n_dec > 0 ? n_dec : 1);
     for (long p0 = 0; p0 == 0 || p0 < n_dec; p0 += chunk) {
@@ -133,6 +137,8 @@ int emu_batch_process(const float *raw, int B, long stride, long n_raw, const in
                   emu::Idx3{GATE_THREADS, 1, 1}, [&]() { gate_scan_kernel(ga); });
     }
   }
+  if (y_out)
+    for (int b = 0; b < B; ++b) memcpy(y_out + 2 * (size_t)b * n_dec, y + (size_t)b * y_stride, sizeof(float2) * (size_t)n_dec);
 
   DecodeListArgs da;
   da.y = y; da.y_stride = y_stride; da.cap = flat_cap; da.res = res.data(); da.scores = sc.data(); da.wmax = wmax;
@@ -176,7 +182,7 @@ int emu_gate_stream(void *state_blob, const float *in, int n_in, int seek_type, 
   }
   int io[2] = {n_in, 0};
   if (n_in > 0) {
-    GateArgs ga;
+    GateArgs ga = {};
     ga.y = reinterpret_cast<const float2 *>(in); ga.y_stride = n_in; ga.n_dec = n_in; ga.lens = nullptr;
     ga.pos0 = 0; ga.chunk_len = n_in; ga.state = st; ga.n_streams = 1; ga.wtab = nullptr; ga.wmax = 0; ga.wcount = nullptr; ga.flat = nullptr;
     ga.flat_count = nullptr; ga.flat_cap = 0; ga.mode = 1; ga.gated = reinterpret_cast<float2 *>(out);
