@@ -305,40 +305,48 @@ int rfid_selftest(rfid_ctx *c, int *n_failed) {
   float hx[64], hn[64], hd[64];
   unsigned seed = 12345u;
   auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (float)((seed >> 8) & 0xFFFF) / 65536.0f; };
-  for (int i = 0; i < 64; ++i) {
-    hx[i] = (rnd() - 0.5f) * 1e-3f * (float)(1 + (i % 7));
-    hn[i] = (rnd() - 0.5f) * 37.0f;
-    hd[i] = (i % 3 == 0) ? 100.0f : ((i % 3 == 1) ? 48.0f : (rnd() + 0.01f) * 9.0f);
-  }
-  const float carry = 23.456789f;
   float *d = nullptr;
   HIPCHK(c, hipMalloc((void **)&d, 7 * 64 * sizeof(float)));
-  HIPCHK(c, hipMemcpyAsync(d, hx, sizeof(hx), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d + 64, hn, sizeof(hn), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d + 128, hd, sizeof(hd), hipMemcpyHostToDevice, c->stream));
-  SelfTestArgs a;
-  a.x = d; a.num = d + 64; a.den = d + 128; a.carry = carry;
-  a.chain_out = d + 192; a.div_out = d + 256; a.hyp_out = d + 320; a.shr_out = d + 384;
-  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, c->stream, a);
-  HIPCHK(c, hipGetLastError());
-  float out[4 * 64];
-  HIPCHK(c, hipMemcpyAsync(out, d + 192, sizeof(out), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  (void)hipFree(d);
   int bad = 0;
-  volatile float acc = carry;
-  for (int i = 0; i < 64; ++i) {
-    acc = acc + hx[i];
-    float e_chain = acc;
-    volatile float q = hn[i] / hd[i];
-    float e_div = q;
-    float e_hyp = (float)sqrt((double)hn[i] * (double)hn[i] + (double)hd[i] * (double)hd[i]);
-    float e_shr = (i == 0) ? 0.0f : hx[i - 1];
-    if (memcmp(&e_chain, &out[i], 4)) bad++;
-    if (memcmp(&e_div, &out[64 + i], 4)) bad++;
-    if (memcmp(&e_hyp, &out[128 + i], 4)) bad++;
-    if (memcmp(&e_shr, &out[192 + i], 4)) bad++;
+  // round 0: the magnitudes of the receive path; later rounds sweep the numerators over the binary
+  // exponent range (2^-150 .. 2^124, zeros and denormals included) so that both paths of the
+  // constant divisions (div_const) are compared with the host's correctly rounded quotient
+  for (int round = 0; round < 48; ++round) {
+    const float scale = (round == 0) ? 1.0f : ldexpf(1.0f, -150 + 6 * (round - 1));
+    for (int i = 0; i < 64; ++i) {
+      hx[i] = (rnd() - 0.5f) * 1e-3f * (float)(1 + (i % 7));
+      hn[i] = (rnd() - 0.5f) * 37.0f * scale;
+      if (round > 0 && i == 5) hn[i] = 0.0f;
+      if (round > 0 && i == 6) hn[i] = -0.0f;
+      hd[i] = (i % 3 == 0) ? 100.0f : ((i % 3 == 1) ? 48.0f : (rnd() + 0.01f) * 9.0f);
+    }
+    const float carry = 23.456789f;
+    HIPCHK(c, hipMemcpyAsync(d, hx, sizeof(hx), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d + 64, hn, sizeof(hn), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d + 128, hd, sizeof(hd), hipMemcpyHostToDevice, c->stream));
+    SelfTestArgs a;
+    a.x = d; a.num = d + 64; a.den = d + 128; a.carry = carry;
+    a.chain_out = d + 192; a.div_out = d + 256; a.hyp_out = d + 320; a.shr_out = d + 384;
+    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    float out[4 * 64];
+    HIPCHK(c, hipMemcpyAsync(out, d + 192, sizeof(out), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    volatile float acc = carry;
+    for (int i = 0; i < 64; ++i) {
+      acc = acc + hx[i];
+      float e_chain = acc;
+      volatile float q = hn[i] / hd[i];
+      float e_div = q;
+      float e_hyp = (float)sqrt((double)hn[i] * (double)hn[i] + (double)hd[i] * (double)hd[i]);
+      float e_shr = (i == 0) ? 0.0f : hx[i - 1];
+      if (memcmp(&e_chain, &out[i], 4)) bad++;
+      if (memcmp(&e_div, &out[64 + i], 4)) bad++;
+      if (memcmp(&e_hyp, &out[128 + i], 4)) bad++;
+      if (memcmp(&e_shr, &out[192 + i], 4)) bad++;
+    }
   }
+  (void)hipFree(d);
   if (n_failed) *n_failed = bad;
   if (bad) snprintf(c->err, sizeof(c->err), "selftest: %d primitive checks failed", bad);
   return RFID_OK;
@@ -408,6 +416,27 @@ int rfid_batch_mf(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64_t n_
   return RFID_OK;
 }
 
+// developer aid (RFID_GATE_PROF=1): s_memtime counters of trace 0's consumer / producer / averaging wave
+static int launch_gate_prof(rfid_ctx *c, GateArgs a, bool fused) {
+  long long *d_prof = nullptr;
+  HIPCHK(c, hipMalloc((void **)&d_prof, sizeof(long long) * 16 * (size_t)c->B));
+  HIPCHK(c, hipMemsetAsync(d_prof, 0, sizeof(long long) * 16 * (size_t)c->B, c->stream));
+  a.prof = d_prof;
+  const dim3 grid((unsigned)((c->B + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG));
+  if (fused) hipLaunchKernelGGL(front_end_fused_kernel_prof, grid, dim3(GATE_THREADS), 0, c->stream, a);
+  else hipLaunchKernelGGL(gate_scan_kernel_prof, grid, dim3(GATE_THREADS), 0, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  std::vector<long long> h((size_t)c->B * 16);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(h.data(), d_prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+  (void)hipFree(d_prof);
+  const char *names[14] = {"steps open-fast", "steps closed-fast", "steps general", "general loop iterations", "dc none",
+                           "consumer wait ticks", "consumer total ticks", "dc fast", "dc slow", "producer wait ticks",
+                           "producer total ticks", "averaging wait ticks", "producer fir ticks", "producer rest ticks"};
+  for (int i = 0; i < 14; ++i) fprintf(stderr, "[gate prof] %-24s %lld (stream 0)\n", names[i], h[(size_t)i]);
+  return RFID_OK;
+}
+
 int rfid_batch_gate(rfid_ctx *c) {
   if (!c) return RFID_ERR_INVALID;
   if (!c->B) return RFID_ERR_STATE;
@@ -423,18 +452,9 @@ int rfid_batch_gate(rfid_ctx *c) {
   a.flat = c->d_flat; a.flat_count = c->d_flat_count; a.flat_cap = c->flat_cap; a.mode = 0;
   a.gated = nullptr; a.gated_cap = 0; a.io = nullptr; a.prof = nullptr;
   if (!c->ev_valid[1]) { HIPCHK(c, hipEventRecord(c->ev[1], c->stream)); c->ev_valid[1] = true; }
-  if (getenv("RFID_GATE_PROF")) {  // developer aid: phase counters of the consumer wave
-    long long *d_prof = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d_prof, sizeof(long long) * 12 * (size_t)c->B));
-    a.prof = d_prof;
-    hipLaunchKernelGGL(gate_scan_kernel_prof, dim3((unsigned)((c->B + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG)), dim3(GATE_THREADS), 0, c->stream, a);
-    HIPCHK(c, hipGetLastError());
-    std::vector<long long> h((size_t)c->B * 12);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(h.data(), d_prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
-    (void)hipFree(d_prof);
-    const char *names[12] = {"steps open-fast", "steps closed-fast", "steps general", "general loop iterations", "dc none", "wait-producer ticks", "total ticks", "dc fast", "dc slow", "-", "-", "-"};
-    for (int i = 0; i < 11; ++i) fprintf(stderr, "[gate prof] %-12s %lld ticks (stream 0)\n", names[i], h[(size_t)i]);
+  if (getenv("RFID_GATE_PROF")) {  // developer aid: wait / phase counters of the gate's waves
+    int rc = launch_gate_prof(c, a, false);
+    if (rc) return rc;
   } else {
     hipLaunchKernelGGL(gate_scan_kernel, dim3((unsigned)((c->B + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG)), dim3(GATE_THREADS), 0, c->stream, a);
     HIPCHK(c, hipGetLastError());
@@ -521,9 +541,14 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
     g.flat = c->d_flat; g.flat_count = c->d_flat_count; g.flat_cap = c->flat_cap; g.mode = 0;
     g.raw = (const float2 *)d_raw; g.raw_stride = raw_stride; g.n_raw = n_raw;
     g.raw_vec_ok = ((raw_stride & 1) == 0 && (((uintptr_t)d_raw) & 15) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(front_end_fused_kernel, dim3((unsigned)((c->B + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG)),
-                       dim3(GATE_THREADS), 0, c->stream, g);
-    HIPCHK(c, hipGetLastError());
+    if (getenv("RFID_GATE_PROF")) {
+      int rc = launch_gate_prof(c, g, true);
+      if (rc) return rc;
+    } else {
+      hipLaunchKernelGGL(front_end_fused_kernel, dim3((unsigned)((c->B + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG)),
+                         dim3(GATE_THREADS), 0, c->stream, g);
+      HIPCHK(c, hipGetLastError());
+    }
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     c->ev_valid[0] = c->ev_valid[1] = c->ev_valid[2] = true;
     c->fused_last = 1;

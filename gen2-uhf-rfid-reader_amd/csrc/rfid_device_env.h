@@ -56,6 +56,12 @@ RFID_DEVICE int ffs64(uint64_t m) { return m ? (__ffsll((long long)m) - 1) : 64;
 
 // IEEE-754 correctly rounded binary32 quotient
 RFID_DEVICE float fdiv(float a, float b) { return __fdiv_rn(a, b); }
+RFID_DEVICE float fma_f(float a, float b, float c) { return __builtin_fmaf(a, b, c); }   // one v_fma_f32, single rounding
+RFID_DEVICE uint32_t f2u(float x) { return __float_as_uint(x); }
+// all LDS reads issued so far have returned (and none issued later starts before): keeps a batch of
+// independent ds_reads in flight together instead of the compiler's just-in-time interleaving
+RFID_DEVICE void compiler_fence() { asm volatile("" ::: "memory"); }
+RFID_DEVICE void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // glibc-2.35 hypotf: (float)sqrt((double)x*x + (double)y*y), double sqrt correctly rounded
 RFID_DEVICE float hypot_f(float x, float y) {
   double s = (double)x * (double)x + (double)y * (double)y;
@@ -97,6 +103,25 @@ RFID_DEVICE int lds_load(const int *p) {
   const volatile RFID_LDS_AS int *q = (const volatile RFID_LDS_AS int *)p;
   return __builtin_amdgcn_readfirstlane(*q);
 }
+// the same read without waiting for it: the value stays in a VGPR until wv::uniform() looks at it
+RFID_DEVICE int lds_peek(const int *p) {
+  const volatile RFID_LDS_AS int *q = (const volatile RFID_LDS_AS int *)p;
+  return *q;
+}
+// two adjacent 64-bit mask words (16-byte aligned) in one ds_read_b128; uniform64() afterwards
+typedef uint32_t rfid_u32x4 __attribute__((ext_vector_type(4)));
+RFID_DEVICE void lds_peek_masks(const uint64_t *p, uint64_t &a, uint64_t &b) {
+  const volatile RFID_LDS_AS rfid_u32x4 *q = (const volatile RFID_LDS_AS rfid_u32x4 *)p;
+  const rfid_u32x4 v = *q;
+  a = ((uint64_t)v.y << 32) | v.x;
+  b = ((uint64_t)v.w << 32) | v.z;
+}
+RFID_DEVICE uint64_t uniform64(uint64_t v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+RFID_DEVICE float lds_load_f(const float *p) { return __int_as_float(lds_load(reinterpret_cast<const int *>(p))); }
 RFID_DEVICE void lds_store(int *p, int v, int lane) {
   volatile RFID_LDS_AS int *q = (volatile RFID_LDS_AS int *)p;
   asm volatile("" ::: "memory");

@@ -171,6 +171,29 @@ struct GateArgs {
   float2 *y_w;          // [n_streams][y_stride], written
 };
 
+// x / C for the gate's two constant divisors (100: gate_impl.cc:131, 48: :141) in three instructions
+// instead of the ~11 of a generic correctly rounded division:
+//     q1 = x * RN(1/C);   q = fma(fma(-q1, C, x), RN(1/C), q1)
+// equals RN(x / C) bit for bit for every finite |x| >= 2^-120 -- checked exhaustively over all
+// 2^31 magnitudes on the host (tests/tools/divcheck.c) and sampled on the device by rfid_selftest().
+// div_const_ok() admits |x| in [2^-100, inf) and +0; anything else (tiny, -0, inf, NaN) sends the
+// whole wave through wv::fdiv.
+RFID_DEVICE bool div_const_ok(float x) {
+  const uint32_t u = wv::f2u(x);
+  return ((u & 0x7fffffffu) - 0x0d800000u) < (0x7f800000u - 0x0d800000u) || u == 0u;
+}
+template <int C>
+RFID_DEVICE float div_const_fast(float x) {
+  constexpr float c = (float)C, rc = 1.0f / (float)C;
+  const float q1 = x * rc;
+  return wv::fma_f(wv::fma_f(-q1, c, x), rc, q1);
+}
+template <int C>
+RFID_DEVICE float div_const(float x) {   // wave-uniform choice of the path
+  if (__builtin_expect(wv::ballot(!div_const_ok(x)) == 0, 1)) return div_const_fast<C>(x);
+  return wv::fdiv(x, (float)C);
+}
+
 // In-order sum: returns in lane L the value  (((carry + x_0) + x_1) + ...) + x_L.
 RFID_DEVICE float chain_add(float carry, float x, int lane) {
   const float x0 = (lane == 0) ? (carry + x) : x;
@@ -202,6 +225,18 @@ RFID_DEVICE void chain_add3(float ca, float xa, float cb, float xb, float cc, fl
   }
 }
 
+// two chains (dc_est real / imaginary)
+RFID_DEVICE void chain_add2(float cb, float xb, float cc, float xc, int lane, float &pb, float &pc) {
+  const float b0 = (lane == 0) ? (cb + xb) : xb;
+  const float c0 = (lane == 0) ? (cc + xc) : xc;
+  pb = b0; pc = c0;
+#pragma unroll
+  for (int s = 1; s < 64; ++s) {
+    pb = wv::shr1(pb) + b0;
+    pc = wv::shr1(pc) + c0;
+  }
+}
+
 // wave-uniform registers of one trace's gate (consumer wave)
 struct GateRegs {
   float avg_c, dcr_c, dci_c;
@@ -215,8 +250,14 @@ struct GateRegs {
 
 // One step (64 decimated samples) handed from the producer wave to the consumer wave.
 struct GateSlot {
-  float amp[64];   // |x|                                   (gate_impl.cc:130)
-  float d[64];     // (|x| - win_samples[win_index]) / 100   (gate_impl.cc:131)
+  float amp[64];   // |x|                                   (gate_impl.cc:130)    producer -> averaging wave
+  float d[64];     // (|x| - win_samples[win_index]) / 100   (gate_impl.cc:131)    producer -> averaging wave
+  float avg[64];   // avg_ampl after each sample: in-order sum of (|x| - win_samples[win_index]) / 100
+                   //   (gate_impl.cc:130-134), run by the averaging wave -- it does not depend on the state machine
+  uint64_t below;  // lanes with |x| < 0.75 avg_ampl  (gate_impl.cc:136,147)
+  uint64_t above;  // lanes with |x| > 0.75 avg_ampl  (gate_impl.cc:155)
+  float avg_in;    // avg_ampl before the first sample of the step
+  int pad_[3];
   float2 yv[64];   // the samples themselves
   float tre[64];   // speculative (x - x[i-48]) / 48: exact whenever the previous 48 samples
   float tim[64];   //   were all "closed" samples, the common case (gate_impl.cc:141)
@@ -239,15 +280,11 @@ RFID_DEVICE void gate_produce(GateSlot &slot, float2 yv_in, float2 &prev_yv, int
   const int nvalid = (n - pos < 64) ? (n - pos) : 64;
   const bool valid = lane < nvalid;
   const float2 yv = valid ? yv_in : make_float2(0.0f, 0.0f);
-#if defined(RFID_ABLATE) && (RFID_ABLATE & 1)
-  const float amp = yv.x;
-#else
   const float amp = wv::hypot_f(yv.x, yv.y);
-#endif
   int wi = win_index + lane;
   if (wi >= WIN_LEN) wi -= WIN_LEN;
   const float amp_old = lds_win[wi];
-  const float d = valid ? wv::fdiv(amp - amp_old, WIN_LEN_F) : 0.0f;
+  const float nd = valid ? (amp - amp_old) : 0.0f;
   wv::wave_sync();
   if (valid) lds_win[wi] = amp;
   wv::wave_sync();
@@ -259,17 +296,39 @@ RFID_DEVICE void gate_produce(GateSlot &slot, float2 yv_in, float2 &prev_yv, int
   const float pre = wv::shfl(prev_yv.x, src), pim = wv::shfl(prev_yv.y, src);
   const float cre = wv::shfl(yv.x, src), cim = wv::shfl(yv.y, src);
   const float ore = (lane < DC_LEN) ? pre : cre, oim = (lane < DC_LEN) ? pim : cim;
+  const float nr = yv.x - ore, ni = yv.y - oim;
+  // the three divisions by constants (gate_impl.cc:131,141), one wave-uniform choice of the path
+  float d, tre, tim;
+  if (__builtin_expect(wv::ballot(!(div_const_ok(nd) && div_const_ok(nr) && div_const_ok(ni))) == 0, 1)) {
+    d = div_const_fast<WIN_LEN>(nd);
+    tre = div_const_fast<DC_LEN>(nr);
+    tim = div_const_fast<DC_LEN>(ni);
+  } else {
+    d = wv::fdiv(nd, WIN_LEN_F);
+    tre = wv::fdiv(nr, DC_LEN_F);
+    tim = wv::fdiv(ni, DC_LEN_F);
+  }
   slot.amp[lane] = amp;
   slot.d[lane] = d;
-  slot.yv[lane] = yv;
-#if defined(RFID_ABLATE) && (RFID_ABLATE & 1)
-  slot.tre[lane] = (yv.x - ore) * 0.02f;
-  slot.tim[lane] = (yv.y - oim) * 0.02f;
-#else
-  slot.tre[lane] = wv::fdiv(yv.x - ore, DC_LEN_F);
-  slot.tim[lane] = wv::fdiv(yv.y - oim, DC_LEN_F);
-#endif
+  // (slot.yv was written by the filter wave; lanes past the end of the call hold zeros there)
+  slot.tre[lane] = tre;
+  slot.tim[lane] = tim;
   prev_yv = yv;
+}
+
+// ---- averaging wave: avg_ampl and the threshold test -------------------------------------------
+// avg_ampl is an in-order sum over all samples that does not depend on the state machine
+// (gate_impl.cc:130-134), so it runs one or more steps ahead of the consumer in a wave of its own.
+RFID_DEVICE void gate_average(GateSlot &slot, int nvalid, int lane, float &avg_c) {
+  const float amp = slot.amp[lane], d = slot.d[lane];
+  const float avg = chain_add(avg_c, d, lane);
+  const float thresh = avg * THRESH_FRACTION;   // gate_impl.cc:136
+  const bool valid = lane < nvalid;             // the last step of a call may be partial
+  const uint64_t below = wv::ballot(valid && amp < thresh);
+  const uint64_t above = wv::ballot(valid && amp > thresh);
+  slot.avg[lane] = avg;
+  if (lane == 0) { slot.below = below; slot.above = above; slot.avg_in = avg_c; }
+  avg_c = wv::readlane(avg, 63);   // the lanes past the end of the call add +0
 }
 
 // a gate opening at lane `ol` of the step that starts at `pos`: dc_est is the in-order sum at
@@ -308,21 +367,41 @@ RFID_DEVICE void gate_record_window(const GateArgs &a, GateRegs &g, int ol, int 
 
 template <bool PROF>
 RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const GateSlot *slot, bool has_front,
-                              int pos, int n, int n_total, int s, int lane, float2 *lds_dc, float2 *lds_tmp,
-                              long long *tk) {
-  float f_amp = 0.0f, f_d = 0.0f, f_tre = 0.0f, f_tim = 0.0f;
+                              const int *seq, int k, int pos, int n, int n_total, int s, int lane, float2 *lds_dc,
+                              float2 *lds_tmp, long long *tk) {
+  float f_tre = 0.0f, f_tim = 0.0f;
   float2 f_yv = make_float2(0.0f, 0.0f);
+  uint64_t below = 0, above = 0;
   if (has_front) {
-    f_amp = slot->amp[lane]; f_d = slot->d[lane]; f_yv = slot->yv[lane];
-    // (the speculative dc increments slot->tre / tim are fetched only by the steps that use them)
+    // Wait for step k and fetch it in ONE LDS round trip: the sequence word and the slot are read
+    // back to back (a wave's LDS reads execute in order, and the averaging wave wrote the slot
+    // before it advanced the sequence word), and only then is the sequence word looked at.
+    long long tb = 0;
+    if (PROF) tb = wv::ticks();
+    for (;;) {
+      const int sq = wv::lds_peek(seq);
+      wv::lds_peek_masks(&slot->below, below, above);
+      f_yv = slot->yv[lane];
+      f_tre = slot->tre[lane]; f_tim = slot->tim[lane];
+      if (wv::uniform(sq) > k) break;
+      wv::backoff();
+    }
+    below = wv::uniform64(below); above = wv::uniform64(above);
+    if (PROF) tk[5] += wv::ticks() - tb;
   }
-  float avg, dcr, dci;
+  // the two plain kinds of step (see below) are recognised before the dc_est chains start, so that
+  // their scalar bookkeeping can be scheduled into the chains' latency
+  const int nvalid0 = (n - pos < 64) ? (n - pos) : 64;
+  const bool plain_open = has_front && (nvalid0 == 64) && g.f_open && (g.f_ung - g.f_n > 64);
+  const bool plain_closed = has_front && (nvalid0 == 64) && !g.f_open && (g.f_state == 1) && (below == 0) &&
+                            !((g.f_pulses > NUM_PULSES_CMD) && (T1_SAMPLES - g.f_n < 64)) &&
+                            (g.run_closed >= DC_LEN);
+  float dcr, dci;
   if (B.has && B.any_closed) {
-    chain_add3(g.avg_c, f_d, g.dcr_c, B.tre, g.dci_c, B.tim, lane, avg, dcr, dci);
+    chain_add2(g.dcr_c, B.tre, g.dci_c, B.tim, lane, dcr, dci);
   } else {
     // the back step lies entirely inside a window (or there is none): all its dc increments are
-    // zero, dc_est does not move -- only the avg_ampl sum runs (a third of the DPP work)
-    avg = chain_add(g.avg_c, f_d, lane);
+    // zero, dc_est does not move
     dcr = g.dcr_c; dci = g.dci_c;
   }
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -350,28 +429,17 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
   if (has_front) {
   int nvalid = (n - pos < 64) ? (n - pos) : 64;
   const int nvalid_in = nvalid;
-  const float thresh = avg * THRESH_FRACTION;  // gate_impl.cc:136
-  uint64_t below = wv::ballot(f_amp < thresh);
-  uint64_t above = wv::ballot(f_amp > thresh);
-  if (__builtin_expect(nvalid < 64, 0)) {   // last step of the call: ignore the lanes past the end
-    const uint64_t vm = lane_range(0, nvalid);
-    below &= vm; above &= vm;
-  }
+  // (the producer's threshold masks already exclude the lanes past the end of the call)
 
   // The two by far most frequent kinds of step are decided with a handful of scalar
   // instructions (the consumer wave is issue bound: every instruction costs ~4.5 cycles):
   //   (A) the whole step lies inside an open window that does not end in it;
   //   (B) gate closed, POS_EDGE, no sample below the threshold, no opening due, and the dc ring
   //       fast path applies (the previous 48 samples were closed too).
-  const bool plain_open = (nvalid == 64) && g.f_open && (g.f_ung - g.f_n > 64);
-  const bool plain_closed = (nvalid == 64) && !g.f_open && (g.f_state == 1) && (below == 0) &&
-                            !((g.f_pulses > NUM_PULSES_CMD) && (T1_SAMPLES - g.f_n < 64)) &&
-                            (g.run_closed >= DC_LEN);
   if (__builtin_expect(plain_open || plain_closed, 1)) {
     // both plain cases in one straight-line block (selects, no branch between them)
-    const float s_tre = slot->tre[lane], s_tim = slot->tim[lane];
+    const float s_tre = f_tre, s_tim = f_tim;
     g.f_n += 64;
-    g.avg_c = wv::readlane(avg, 63);
     int di = g.dc_index + (64 - DC_LEN);   // (dc_index + 64) mod 48
     if (di >= DC_LEN) di -= DC_LEN;
     g.dc_index = plain_closed ? di : g.dc_index;
@@ -385,7 +453,6 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
     B.openmask = plain_closed ? 0ull : ~0ull;
     B.open_lane = -1; B.open_lane2 = -1; B.pos = pos; B.has = true; B.any_closed = plain_closed;
   } else {
-  f_tre = slot->tre[lane]; f_tim = slot->tim[lane];
   // edge / pulse / window state machine on the scalar unit, event driven (gate_impl.cc:145-195)
   uint64_t closedmask = 0, openmask = 0;
   int open_lane = -1, open_lane2 = -1, open_type = 0, open_type2 = 0;
@@ -475,23 +542,16 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
   }
   g.f_n = f_n; g.f_state = f_state; g.f_pulses = f_pulses; g.f_open = f_open;
   g.f_ung = f_ung; g.f_type = f_type;
-  g.avg_c = wv::readlane(avg, nvalid - 1);   // carry only over the samples actually consumed
+  // streaming mode stopped inside the step: avg_ampl carries only over the samples actually consumed
+  if (g.stop) g.avg_c = (nvalid > 0) ? wv::lds_load_f(&slot->avg[nvalid - 1]) : wv::lds_load_f(&slot->avg_in);
 
   // ---- dc increments of the closed samples (gate_impl.cc:141-143) -> next back step ------------
-#if defined(RFID_ABLATE) && (RFID_ABLATE & 4)
-  const int cnt = 0;
-#else
   const int cnt = wv::popc64(closedmask);
-#endif
   if (cnt == 0) {
     // whole step inside a window: dc_est, ring and index untouched
     B.tre = 0.0f; B.tim = 0.0f;
     g.run_closed = 0;
-#if defined(RFID_ABLATE) && (RFID_ABLATE & 16)
-  } else if (true) {
-#else
   } else if (cnt == 64 && openmask == 0 && nvalid_in == 64 && g.run_closed >= DC_LEN) {
-#endif
     // fast path: the 48 samples before every lane were closed too, so dc_samples[dc_index]
     // is x[i-48] and the producer's increments are the reference's
     B.tre = f_tre; B.tim = f_tim;
@@ -567,8 +627,9 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
 constexpr int GATE_RAW = 64 * DECIM + (NTAPS - DECIM);   // 344 raw samples feed 64 matched-filter outputs
 constexpr int GATE_RAW4 = GATE_RAW / 2;                  // as float4 (2 samples each): 172
 constexpr int GATE_RAW_LD = (GATE_RAW4 + 63) / 64;       // float4 loads per lane and step: 3
+constexpr int GATE_RAW_DEPTH = 6;                        // steps of raw samples in flight per producer wave
 constexpr int GATE_STREAMS_PER_WG = 4;
-constexpr int GATE_THREADS = 128 * GATE_STREAMS_PER_WG;
+constexpr int GATE_THREADS = 256 * GATE_STREAMS_PER_WG;   // consumer + filter + averaging + producer wave per trace
 constexpr int GATE_SLOTS = 4;
 constexpr int GATE_PREFETCH = 4;    // steps (x64 samples) of matched-filter output held in registers
 
@@ -577,11 +638,15 @@ struct GateShared {          // per trace
   float win[WIN_LEN + 4];    // producer's working copy of gate_impl::win_samples
   float2 dc[DC_LEN];         // gate_impl::dc_samples
   float2 tmp[64];
-  float4 rawtile[GATE_RAW4 + 2];   // fused front end: the 344 raw samples one step's matched filter needs
+  float4 rawtile[64 * GATE_RAW_LD];   // fused front end: the 344 raw samples one step's matched filter needs (+ padding)
   int prod_seq;              // steps produced so far
   int cons_seq;              // steps consumed so far
   int stop;                  // consumer -> producer: stop (streaming mode window close)
-  int prod_done;             // fused front end: the producer's y stores are visible device-wide
+  int prod_done;             // the producer is through (fused front end: its y stores are visible device-wide)
+  float avg_final;           // avg_ampl after the last sample of the call (from the averaging wave)
+  int avg_seq;               // steps averaged so far
+  int avg_done;
+  int fir_seq;               // steps whose samples are in the slot (filter wave)
 };
 
 // raw samples of one step (fused front end): float4 #(lane + 64 j) of the 172 the step needs
@@ -620,30 +685,58 @@ RFID_DEVICE float2 gate_fir_step(const GateRawRegs &r, float4 *tile4, int lane, 
     const int q = lane + 64 * j;
     float4 v = r.v[j];
     if (j == 0 && first && q < (NTAPS - 1) / 2) v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // x[-24..-1] = 0
-    if (q < GATE_RAW4) tile4[q] = v;
+    tile4[q] = v;   // (entries >= GATE_RAW4 are padding: no lane-dependent branch around a pending load)
   }
   wv::wave_sync();
   const float2 *tile = reinterpret_cast<const float2 *>(tile4);
+  float2 v[NTAPS];
+#pragma unroll
+  for (int k = 0; k < NTAPS; ++k) v[k] = tile[DECIM * lane + k];
+  wv::lds_wait();   // all 25 reads in flight together: one LDS round trip instead of ten
   float re = 0.0f, im = 0.0f;
 #pragma unroll
   for (int k = 0; k < NTAPS; ++k) {
-    const float2 v = tile[DECIM * lane + k];
-    re = re + v.x;
-    im = im + v.y;
+    re = re + v[k].x;
+    im = im + v[k].y;
   }
   return make_float2(re, im);
 }
+
+#ifndef RFID_PRIO_VARIANT
+#define RFID_PRIO_VARIANT 0
+#endif
+#if RFID_PRIO_VARIANT == 0
+#define RFID_PRIO_AVG wv::set_priority_high()
+#define RFID_PRIO_CONS wv::set_priority_high()
+#define RFID_PRIO_PROD
+#elif RFID_PRIO_VARIANT == 1
+#define RFID_PRIO_AVG
+#define RFID_PRIO_CONS
+#define RFID_PRIO_PROD
+#elif RFID_PRIO_VARIANT == 2
+#define RFID_PRIO_AVG
+#define RFID_PRIO_CONS wv::set_priority_high()
+#define RFID_PRIO_PROD
+#elif RFID_PRIO_VARIANT == 3
+#define RFID_PRIO_AVG
+#define RFID_PRIO_CONS
+#define RFID_PRIO_PROD wv::set_priority_high()
+#elif RFID_PRIO_VARIANT == 4
+#define RFID_PRIO_AVG wv::set_priority_high()
+#define RFID_PRIO_CONS
+#define RFID_PRIO_PROD wv::set_priority_high()
+#endif
 
 template <bool PROF, bool FUSED>
 RFID_DEVICE void gate_scan_body(const GateArgs &a) {
   RFID_SHARED GateShared sh_all[GATE_STREAMS_PER_WG];
   const int lane = wv::lane_id();
   const int wave = wv::uniform((int)(threadIdx.x >> 6));
-  const int role = wave / GATE_STREAMS_PER_WG;           // 0 consumer, 1 producer
+  const int role = wave / GATE_STREAMS_PER_WG;           // 0 consumer, 1 filter, 2 averaging, 3 producer
   const int sl = wave % GATE_STREAMS_PER_WG;
   const int s = (int)blockIdx.x * GATE_STREAMS_PER_WG + sl;
   GateShared &sh = sh_all[sl];
-  if (lane == 0 && role == 0) { sh.prod_seq = 0; sh.cons_seq = 0; sh.stop = 0; sh.prod_done = 0; }
+  if (lane == 0 && role == 0) { sh.fir_seq = 0; sh.prod_seq = 0; sh.cons_seq = 0; sh.stop = 0; sh.prod_done = 0; sh.avg_seq = 0; sh.avg_done = 0; }
   wv::block_sync();   // once, before any hand-off
   if (s >= a.n_streams) return;
   GateState *st = a.state + s;
@@ -664,49 +757,64 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
   const int win_index0 = wv::uniform(st->win_index);
 
   if (role == 1) {
-    // ================= producer ===============================================================
-    for (int j = lane; j < WIN_LEN; j += 64) sh.win[j] = st->win[j];
-    int win_index = win_index0;
-    wv::wave_sync();
-    float2 prev_yv = make_float2(0.0f, 0.0f);
+    // ================= filter wave: samples -> slot.yv =========================================
+    // fused front end: raw samples in, matched filter here, y written for the decoder;
+    // stage kernels / streaming: y in
     bool stopped = false;
+    long long p_wait = 0, p_fir = 0;
+    const long long p_start = PROF ? wv::ticks() : 0;
     if (FUSED) {
-      // ---- fused front end: raw samples in, matched filter here, y written for the decoder ----
       const float2 *xs = a.raw + (int64_t)s * a.raw_stride;
       const bool vec = a.raw_vec_ok != 0;
       // last index a (two-sample) load may start at: inside the row's stride (rows are contiguous)
       const int hi_idx = vec ? (int)((a.raw_stride - 2) & ~(int64_t)1) : (int)(a.raw_stride - 2);
       float2 *yw = a.y_w + (int64_t)s * a.y_stride + a.pos0;
       const int rbase = (int)a.pos0 * DECIM - (NTAPS - 1);   // raw index of the window of output pos0
-      GateRawRegs cur[GATE_PREFETCH], nxt[GATE_PREFETCH];
+      // Rolling prefetch: the raw samples of the next GATE_RAW_DEPTH steps are in flight at all times
+      // (a register set is reloaded right after its step went to LDS) -- with 1024 filter waves
+      // on the device HBM needs that many bytes outstanding to stream.  The main loop runs over
+      // whole groups of GATE_RAW_DEPTH full steps with no conditional step inside: s_waitcnt vmcnt
+      // counts in order, and any control-flow path on which a step is skipped makes the compiler
+      // wait for the youngest load instead of the oldest.  (Batch mode only: nothing stops the scan.)
+      const int nfull = n >> 6;                       // steps with all 64 samples
+      const int ngroups = nfull / GATE_RAW_DEPTH;
+      const bool at_start = a.pos0 == 0;
+      if (ngroups > 0) {
+        GateRawRegs buf[GATE_RAW_DEPTH];
 #pragma unroll
-      for (int u = 0; u < GATE_PREFETCH; ++u) gate_load_raw(cur[u], xs, hi_idx, rbase + u * 64 * DECIM, lane, vec);
-      for (int base = 0; base < nsteps && !stopped; base += GATE_PREFETCH) {
+        for (int u = 0; u < GATE_RAW_DEPTH; ++u) {
+          gate_load_raw(buf[u], xs, hi_idx, rbase + u * 64 * DECIM, lane, vec);
+          wv::compiler_fence();                       // keep the issue order: step 0 first
+        }
+        for (int grp = 0; grp < ngroups; ++grp) {
 #pragma unroll
-        for (int u = 0; u < GATE_PREFETCH; ++u)
-          gate_load_raw(nxt[u], xs, hi_idx, rbase + (base + GATE_PREFETCH + u) * 64 * DECIM, lane, vec);
-#pragma unroll
-        for (int u = 0; u < GATE_PREFETCH; ++u) {
-          const int k = base + u;
-          if (k < nsteps && !stopped) {
-            while (!stopped && k - wv::lds_load(&sh.cons_seq) >= GATE_SLOTS) {
-              stopped = wv::lds_load(&sh.stop) != 0;
-              wv::backoff();
-            }
-            if (!stopped) {
-              float2 yv = gate_fir_step(cur[u], sh.rawtile, lane, k == 0 && a.pos0 == 0);
-              if (64 * k + lane < n) yw[64 * k + lane] = yv;
-              else yv = make_float2(0.0f, 0.0f);
-              gate_produce(sh.slots[k % GATE_SLOTS], yv, prev_yv, 64 * k, n, lane, sh.win, win_index);
-              wv::lds_store(&sh.prod_seq, k + 1, lane);   // after the slot's data (in-order LDS queue)
-            }
+          for (int u = 0; u < GATE_RAW_DEPTH; ++u) {
+            const int k = grp * GATE_RAW_DEPTH + u;
+            long long tw = 0, t1 = 0;
+            if (PROF) tw = wv::ticks();
+            while (k - wv::lds_load(&sh.cons_seq) >= GATE_SLOTS) wv::backoff();
+            if (PROF) { t1 = wv::ticks(); p_wait += t1 - tw; }
+            const float2 yv = gate_fir_step(buf[u], sh.rawtile, lane, u == 0 && grp == 0 && at_start);
+            gate_load_raw(buf[u], xs, hi_idx, rbase + (k + GATE_RAW_DEPTH) * 64 * DECIM, lane, vec);
+            yw[64 * k + lane] = yv;
+            sh.slots[k % GATE_SLOTS].yv[lane] = yv;
+            wv::lds_store(&sh.fir_seq, k + 1, lane);   // after the slot's data (in-order LDS queue)
+            if (PROF) p_fir += wv::ticks() - t1;
           }
         }
-#pragma unroll
-        for (int u = 0; u < GATE_PREFETCH; ++u) cur[u] = nxt[u];
+      }
+      // the last few steps (fewer than a group, the partial step included): load, then filter
+      for (int k = ngroups * GATE_RAW_DEPTH; k < nsteps; ++k) {
+        while (k - wv::lds_load(&sh.cons_seq) >= GATE_SLOTS) wv::backoff();
+        GateRawRegs r;
+        gate_load_raw(r, xs, hi_idx, rbase + k * 64 * DECIM, lane, vec);
+        float2 yv = gate_fir_step(r, sh.rawtile, lane, k == 0 && at_start);
+        if (64 * k + lane < n) yw[64 * k + lane] = yv;
+        else yv = make_float2(0.0f, 0.0f);
+        sh.slots[k % GATE_SLOTS].yv[lane] = yv;
+        wv::lds_store(&sh.fir_seq, k + 1, lane);
       }
       wv::global_release();                       // the consumer's write-back re-reads y
-      wv::lds_store(&sh.prod_done, 1, lane);
     } else {
       float2 cur[GATE_PREFETCH], nxt[GATE_PREFETCH];
 #pragma unroll
@@ -730,8 +838,8 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
               wv::backoff();
             }
             if (!stopped) {
-              gate_produce(sh.slots[k % GATE_SLOTS], cur[u], prev_yv, 64 * k, n, lane, sh.win, win_index);
-              wv::lds_store(&sh.prod_seq, k + 1, lane);   // after the slot's data (in-order LDS queue)
+              sh.slots[k % GATE_SLOTS].yv[lane] = cur[u];
+              wv::lds_store(&sh.fir_seq, k + 1, lane);
             }
           }
         }
@@ -739,11 +847,64 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
         for (int u = 0; u < GATE_PREFETCH; ++u) cur[u] = nxt[u];
       }
     }
+    if (PROF && a.prof && lane == 0) { a.prof[(int64_t)s * 16 + 9] = p_wait; a.prof[(int64_t)s * 16 + 10] = wv::ticks() - p_start;
+      a.prof[(int64_t)s * 16 + 12] = p_fir; }
+    wv::lds_store(&sh.prod_done, 1, lane);
+  } else if (role == 3) {
+    // ================= producer: everything that is lane-parallel ================================
+    RFID_PRIO_PROD;
+    for (int j = lane; j < WIN_LEN; j += 64) sh.win[j] = st->win[j];
+    int win_index = win_index0;
+    wv::wave_sync();
+    float2 prev_yv = make_float2(0.0f, 0.0f);
+    bool stopped = false;
+    long long g_wait = 0;
+    for (int k = 0; k < nsteps && !stopped; ++k) {
+      long long tw = 0;
+      if (PROF) tw = wv::ticks();
+      while (!stopped && wv::lds_load(&sh.fir_seq) <= k) {
+        stopped = wv::lds_load(&sh.stop) != 0;
+        wv::backoff();
+      }
+      if (PROF) g_wait += wv::ticks() - tw;
+      if (!stopped) {
+        GateSlot &slot = sh.slots[k % GATE_SLOTS];
+#if !(defined(RFID_EXPERIMENT) && (RFID_EXPERIMENT & 4))
+        gate_produce(slot, slot.yv[lane], prev_yv, 64 * k, n, lane, sh.win, win_index);
+#endif
+        wv::lds_store(&sh.prod_seq, k + 1, lane);   // after the slot's data (in-order LDS queue)
+      }
+    }
+    if (PROF && a.prof && lane == 0) a.prof[(int64_t)s * 16 + 13] = g_wait;
+  } else if (role == 2) {
+    // ================= averaging wave =========================================================
+    RFID_PRIO_AVG;
+    float avg_c = wv::uniform(st->avg_ampl);
+    bool stopped = false;
+    long long a_wait = 0;
+    for (int k = 0; k < nsteps && !stopped; ++k) {
+      long long tw = 0;
+      if (PROF) tw = wv::ticks();
+      while (!stopped && wv::lds_load(&sh.prod_seq) <= k) {
+        stopped = wv::lds_load(&sh.stop) != 0;
+        wv::backoff();
+      }
+      if (PROF) a_wait += wv::ticks() - tw;
+      if (!stopped) {
+#if !(defined(RFID_EXPERIMENT) && (RFID_EXPERIMENT & 2))
+        gate_average(sh.slots[k % GATE_SLOTS], n - 64 * k, lane, avg_c);
+#endif
+        wv::lds_store(&sh.avg_seq, k + 1, lane);
+      }
+    }
+    if (lane == 0) sh.avg_final = avg_c;
+    if (PROF && a.prof && lane == 0) a.prof[(int64_t)s * 16 + 11] = a_wait;
+    wv::lds_store(&sh.avg_done, 1, lane);
   } else {
     // ================= consumer ===============================================================
     // the consumer owns the critical path (dependent DPP adds): it must win VALU arbitration
     // against the producer wave that shares its SIMD
-    wv::set_priority_high();
+    RFID_PRIO_CONS;
     float2 *lds_dc = sh.dc, *lds_tmp = sh.tmp;
     if (lane < DC_LEN) lds_dc[lane] = make_float2(st->dcr_re[lane], st->dcr_im[lane]);
     GateRegs g;
@@ -764,26 +925,24 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
     B.open_lane = B.open_lane2 = -1; B.open_type = B.open_type2 = 0; B.pos = 0; B.any_closed = false;
     wv::wave_sync();
     for (int k = 0; k < nsteps && !g.stop; ++k) {
-      long long tb = 0;
-      if (PROF) tb = wv::ticks();
-      while (wv::lds_load(&sh.prod_seq) <= k) wv::backoff();   // step k produced?
-      if (PROF) tk[5] += wv::ticks() - tb;
-      gate_consume<PROF>(a, g, B, &sh.slots[k % GATE_SLOTS], true, 64 * k, n, n_total, s, lane, lds_dc, lds_tmp, tk);
+      // (waits until step k is produced and averaged)
+      gate_consume<PROF>(a, g, B, &sh.slots[k % GATE_SLOTS], true, &sh.avg_seq, k, 64 * k, n, n_total, s, lane, lds_dc,
+                         lds_tmp, tk);
       wv::lds_store(&sh.cons_seq, k + 1, lane);   // slot k free again (its data are in registers)
     }
     if (g.stop) wv::lds_store(&sh.stop, 1, lane);
     // drain: finish the pending back half (window records / gated output of the last step)
-    if (B.has) gate_consume<PROF>(a, g, B, &sh.slots[0], false, 0, n, n_total, s, lane, lds_dc, lds_tmp, tk);
+    if (B.has) gate_consume<PROF>(a, g, B, &sh.slots[0], false, &sh.avg_seq, 0, 0, n, n_total, s, lane, lds_dc, lds_tmp, tk);
     if (PROF && a.prof && lane == 0) {
       tk[6] = wv::ticks() - t_start;
-      for (int i = 0; i < 12; ++i) a.prof[(int64_t)s * 12 + i] = tk[i];
+      for (int i = 0; i < 9; ++i) a.prof[(int64_t)s * 16 + i] = tk[i];
     }
 
     // ---- write state back ----------------------------------------------------------------
-    if (FUSED) {
-      // y was written by the producer wave during this launch: wait until its stores are visible
-      while (wv::lds_load(&sh.prod_done) == 0) wv::backoff();
-    }
+    // wait for the producer: its final avg_ampl, and (fused front end) its y stores being visible
+    while (wv::lds_load(&sh.prod_done) == 0) wv::backoff();
+    while (wv::lds_load(&sh.avg_done) == 0) wv::backoff();
+    if (!g.stop) g.avg_c = wv::lds_load_f(&sh.avg_final);
     if (g.ring_stale) {
       // materialise the dc ring: the last 48 consumed samples, oldest at dc_index
       if (lane < DC_LEN) {
@@ -830,6 +989,7 @@ RFID_KERNEL(GATE_THREADS) void front_end_fused_kernel(GateArgs a) { gate_scan_bo
 // 0 slot read + in-order sums, 1 finish back step, 2 threshold + state machine,
 // 3 dc increments, 4 SGPR pinning, 5 waiting for the producer, 6 total
 RFID_KERNEL(GATE_THREADS) void gate_scan_kernel_prof(GateArgs a) { gate_scan_body<true, false>(a); }
+RFID_KERNEL(GATE_THREADS) void front_end_fused_kernel_prof(GateArgs a) { gate_scan_body<true, true>(a); }
 
 // =========================================================================================
 // 3. tag_decoder: one wavefront per window, persistent over the compact window list.
@@ -1450,7 +1610,10 @@ struct SelfTestArgs {
 RFID_KERNEL(64) void selftest_kernel(SelfTestArgs a) {
   const int lane = wv::lane_id();
   a.chain_out[lane] = chain_add(a.carry, a.x[lane], lane);
-  a.div_out[lane] = wv::fdiv(a.num[lane], a.den[lane]);
+  {
+    const float num = a.num[lane], den = a.den[lane];
+    a.div_out[lane] = (den == WIN_LEN_F) ? div_const<WIN_LEN>(num) : ((den == DC_LEN_F) ? div_const<DC_LEN>(num) : wv::fdiv(num, den));
+  }
   a.hyp_out[lane] = wv::hypot_f(a.num[lane], a.den[lane]);
   a.shr_out[lane] = wv::shr1(a.x[lane]);
 }

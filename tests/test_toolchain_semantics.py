@@ -49,3 +49,20 @@ def test_libstdcxx_glibc_semantics(tmp_path):
     subprocess.check_call(["g++", "-O3", "-DNDEBUG", "-o", str(exe), str(src)])
     out = subprocess.check_output([str(exe)]).decode().strip()
     assert out == "0"
+
+
+def test_constant_division_sequence_is_correctly_rounded(tmp_path):
+    """div_const_fast (rfid_kernels.hpp): q1 = x*RN(1/C), q = fma(fma(-q1, C, x), RN(1/C), q1) equals the
+    correctly rounded x / C for C = 100 and 48 whenever |x| >= 2^-100 (the range div_const_ok admits).
+    Sampled here (every 64th magnitude + every magnitude around the admission boundary and near
+    FLT_MAX); tests/tools/divcheck.c without an argument runs all 2^31 magnitudes (about a minute:
+    mismatches exist only below 2^-122)."""
+    exe = tmp_path / "divcheck"
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "divcheck.c")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), src, "-lm"])
+    out = subprocess.check_output([str(exe), "64"]).decode().strip().splitlines()
+    assert len(out) == 2
+    for line in out:
+        kv = dict(f.split("=") for f in line.split()[0:] if "=" in f)
+        assert int(kv["largest_bad_bits"], 16) < 0x0d800000, line      # nothing admitted by div_const_ok fails
+        assert int(kv["smallest_large_bad_bits"], 16) == 0x7f800000, line

@@ -124,6 +124,10 @@ static inline uint64_t uniform(uint64_t v) { return emu::exchange(v)[0]; }
 static inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
 static inline int ffs64(uint64_t m) { return m ? __builtin_ctzll(m) : 64; }
 static inline float fdiv(float a, float b) { volatile float q = a / b; return q; }
+static inline float fma_f(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+static inline uint32_t f2u(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
+static inline void compiler_fence() {}
+static inline void lds_wait() {}
 static inline float hypot_f(float x, float y) {
   return (float)sqrt((double)x * (double)x + (double)y * (double)y);
 }
@@ -144,6 +148,10 @@ static inline void block_sync() {
 static inline void wave_sync() { emu::wave_barrier(); }
 static inline void block_sync_lds() { block_sync(); }
 static inline int lds_load(const int *p) { return *(const volatile int *)p; }
+static inline int lds_peek(const int *p) { return *(const volatile int *)p; }
+static inline void lds_peek_masks(const uint64_t *p, uint64_t &a, uint64_t &b) { a = ((const volatile uint64_t *)p)[0]; b = ((const volatile uint64_t *)p)[1]; }
+static inline uint64_t uniform64(uint64_t v) { return v; }
+static inline float lds_load_f(const float *p) { return *(const volatile float *)p; }
 static inline void lds_store(int *p, int v, int lane) { emu::wave_barrier(); if (lane == 0) *(volatile int *)p = v; }
 static inline uint64_t lds_load64(const uint64_t *p) { return *(const volatile uint64_t *)p; }
 static inline void lds_store64(uint64_t *p, uint64_t v, int lane) { emu::wave_barrier(); if (lane == 0) *(volatile uint64_t *)p = v; }
