@@ -358,12 +358,6 @@ RFID_DEVICE void gate_record_window(const GateArgs &a, GateRegs &g, int ol, int 
 // One pipeline iteration: the in-order sum of avg_ampl for step k runs interleaved with the
 // two in-order sums of dc_est for step k-1; then step k-1 is finished (window records, gated
 // output) and step k goes through the threshold test and the state machine.
-// Optional readfirstlane pinning of loop-carried wave-uniform values (LLVM's
-// uniformity analysis can demote refined uniform values to VGPRs).  Empty by default: with
-// the front/back flags passed as compile-time constants no refinement happens any more.
-#ifndef RFID_GATE_PINS
-#define RFID_GATE_PINS
-#endif
 
 template <bool PROF>
 RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const GateSlot *slot, bool has_front,
@@ -587,8 +581,17 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
         old = lds_tmp[rank - DC_LEN];
       }
     }
-    B.tre = isclosed ? wv::fdiv(f_yv.x - old.x, DC_LEN_F) : 0.0f;
-    B.tim = isclosed ? wv::fdiv(f_yv.y - old.y, DC_LEN_F) : 0.0f;
+    {
+      const float nr = f_yv.x - old.x, ni = f_yv.y - old.y;
+      float qr, qi;
+      if (__builtin_expect(wv::ballot(!(div_const_ok(nr) && div_const_ok(ni))) == 0, 1)) {
+        qr = div_const_fast<DC_LEN>(nr); qi = div_const_fast<DC_LEN>(ni);
+      } else {
+        qr = wv::fdiv(nr, DC_LEN_F); qi = wv::fdiv(ni, DC_LEN_F);
+      }
+      B.tre = isclosed ? qr : 0.0f;
+      B.tim = isclosed ? qi : 0.0f;
+    }
     wv::wave_sync();
     if (isclosed && rank >= cnt - DC_LEN) {
       int di = g.dc_index + rank;
@@ -616,7 +619,6 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
   }  // general step
   }  // if (has_front)
 
-  RFID_GATE_PINS
 }
 
 // Workgroup = 8 waves = 4 traces: waves 0..3 are the consumers of traces 4b..4b+3, waves 4..7
@@ -701,31 +703,6 @@ RFID_DEVICE float2 gate_fir_step(const GateRawRegs &r, float4 *tile4, int lane, 
   }
   return make_float2(re, im);
 }
-
-#ifndef RFID_PRIO_VARIANT
-#define RFID_PRIO_VARIANT 0
-#endif
-#if RFID_PRIO_VARIANT == 0
-#define RFID_PRIO_AVG wv::set_priority_high()
-#define RFID_PRIO_CONS wv::set_priority_high()
-#define RFID_PRIO_PROD
-#elif RFID_PRIO_VARIANT == 1
-#define RFID_PRIO_AVG
-#define RFID_PRIO_CONS
-#define RFID_PRIO_PROD
-#elif RFID_PRIO_VARIANT == 2
-#define RFID_PRIO_AVG
-#define RFID_PRIO_CONS wv::set_priority_high()
-#define RFID_PRIO_PROD
-#elif RFID_PRIO_VARIANT == 3
-#define RFID_PRIO_AVG
-#define RFID_PRIO_CONS
-#define RFID_PRIO_PROD wv::set_priority_high()
-#elif RFID_PRIO_VARIANT == 4
-#define RFID_PRIO_AVG wv::set_priority_high()
-#define RFID_PRIO_CONS
-#define RFID_PRIO_PROD wv::set_priority_high()
-#endif
 
 template <bool PROF, bool FUSED>
 RFID_DEVICE void gate_scan_body(const GateArgs &a) {
@@ -852,7 +829,6 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
     wv::lds_store(&sh.prod_done, 1, lane);
   } else if (role == 3) {
     // ================= producer: everything that is lane-parallel ================================
-    RFID_PRIO_PROD;
     for (int j = lane; j < WIN_LEN; j += 64) sh.win[j] = st->win[j];
     int win_index = win_index0;
     wv::wave_sync();
@@ -869,16 +845,14 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
       if (PROF) g_wait += wv::ticks() - tw;
       if (!stopped) {
         GateSlot &slot = sh.slots[k % GATE_SLOTS];
-#if !(defined(RFID_EXPERIMENT) && (RFID_EXPERIMENT & 4))
         gate_produce(slot, slot.yv[lane], prev_yv, 64 * k, n, lane, sh.win, win_index);
-#endif
         wv::lds_store(&sh.prod_seq, k + 1, lane);   // after the slot's data (in-order LDS queue)
       }
     }
     if (PROF && a.prof && lane == 0) a.prof[(int64_t)s * 16 + 13] = g_wait;
   } else if (role == 2) {
     // ================= averaging wave =========================================================
-    RFID_PRIO_AVG;
+    wv::set_priority_high();
     float avg_c = wv::uniform(st->avg_ampl);
     bool stopped = false;
     long long a_wait = 0;
@@ -891,9 +865,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
       }
       if (PROF) a_wait += wv::ticks() - tw;
       if (!stopped) {
-#if !(defined(RFID_EXPERIMENT) && (RFID_EXPERIMENT & 2))
         gate_average(sh.slots[k % GATE_SLOTS], n - 64 * k, lane, avg_c);
-#endif
         wv::lds_store(&sh.avg_seq, k + 1, lane);
       }
     }
@@ -904,7 +876,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
     // ================= consumer ===============================================================
     // the consumer owns the critical path (dependent DPP adds): it must win VALU arbitration
     // against the producer wave that shares its SIMD
-    RFID_PRIO_CONS;
+    wv::set_priority_high();
     float2 *lds_dc = sh.dc, *lds_tmp = sh.tmp;
     if (lane < DC_LEN) lds_dc[lane] = make_float2(st->dcr_re[lane], st->dcr_im[lane]);
     GateRegs g;
