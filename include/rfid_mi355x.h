@@ -186,7 +186,9 @@ RFID_API int rfid_batch_mf(rfid_ctx *ctx, const void *d_raw, int64_t raw_stride,
 RFID_API int rfid_batch_gate(rfid_ctx *ctx);
 RFID_API int rfid_batch_decode(rfid_ctx *ctx, int want_scores);
 RFID_API int rfid_batch_stats(rfid_ctx *ctx);
-/* mf -> gate -> decode -> stats on the ctx stream (asynchronous) */
+/* mf -> gate -> decode -> stats on the ctx stream (asynchronous).  Matched filter and gate run as ONE launch
+ * (fused front end: the raw samples are read from HBM once); results are identical to calling the four stage
+ * functions above one after the other.  The matched-filter output stays available (rfid_batch_get_mf). */
 RFID_API int rfid_batch_process(rfid_ctx *ctx, const void *d_raw, int64_t raw_stride, int64_t n_raw,
                                 const void *d_lens, int want_scores);
 RFID_API int rfid_batch_sync(rfid_ctx *ctx);

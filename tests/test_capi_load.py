@@ -69,3 +69,22 @@ def test_product_never_imports_oracle_or_emulator():
                 assert "librfid_oracle" not in text and "import oracle" not in text, f
                 assert "from oracle" not in text and "orc_" not in text, f
                 assert "emu_driver" not in text and "librfid_wave_emu" not in text, f
+
+
+def test_cxx_block_adaptors_build_and_refuse_without_gpu(tmp_path):
+    """cxx/rfid_blocks.hpp (gate / tag_decoder / reader / matched_filter adaptors with the reference's
+    factory names and general_work signatures) compiles against the C-ABI header, and the offline
+    flowgraph binary fails loudly -- exit code 3 -- when there is no gfx950 device."""
+    import subprocess
+    import torch
+    import rfid
+    cxx = os.path.join(rfid.capi.PKG_ROOT, "cxx")
+    subprocess.check_call(["make", "-C", cxx], stdout=subprocess.DEVNULL)
+    exe = os.path.join(rfid.capi.PKG_ROOT, "bin", "rfid_reader_offline")
+    assert subprocess.run([exe], capture_output=True).returncode == 2            # usage
+    assert subprocess.run([exe, str(tmp_path / "missing.bin")], capture_output=True).returncode == 2
+    if not torch.cuda.is_available():
+        trace = tmp_path / "t.bin"
+        trace.write_bytes(b"\0" * 8 * 1000)
+        r = subprocess.run([exe, str(trace)], capture_output=True, text=True)
+        assert r.returncode == 3 and "no usable gfx950 device" in r.stderr

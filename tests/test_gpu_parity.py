@@ -128,6 +128,26 @@ def test_streaming_blocks_match_oracle(oracle_mod, synth_mod):
         tb.ctx.close()
 
 
+def test_cxx_offline_flowgraph_binary(tmp_path, oracle_mod, synth_mod):
+    """bin/rfid_reader_offline = apps/reader.py's DEBUG topology in C++ (block adaptors of
+    cxx/rfid_blocks.hpp, one C-ABI call per general_work): its print_results text equals the
+    oracle's for the same trace file, FIXED_Q = 0 and 2, odd chunk size included."""
+    import os
+    import subprocess
+    import rfid
+    exe = os.path.join(rfid.capi.PKG_ROOT, "bin", "rfid_reader_offline")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    for q, chunk in ((0, 8192), (2, 1531)):
+        t = synth_mod.make_trace(n_rounds=3, fixed_q=q, tag_ids=(0x27, 0x42) if q else (0x27,), seed=77 + q, sigma=0.01)
+        path = tmp_path / f"trace_q{q}.bin"
+        rfid.batch.write_trace_file(str(path), t.samples)
+        out = subprocess.run([exe, str(path), "--fixed-q", str(q), "--chunk", str(chunk)], capture_output=True,
+                             text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        o = oracle_mod.run_trace(t.samples, oracle_mod.config(fixed_q=q))
+        assert out.stdout == o.print_results()
+
+
 def test_fst_like_known_answer(gpu_ctx, synth_mod):
     """README.md:48-53 shape on the stand-in trace: 71 queries / round 72 / 70 EPC / 1 tag 0x27 x70."""
     t = synth_mod.fst_like_trace()
