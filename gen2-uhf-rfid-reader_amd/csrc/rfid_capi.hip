@@ -430,10 +430,12 @@ static int launch_gate_prof(rfid_ctx *c, GateArgs a, bool fused) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(h.data(), d_prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
   (void)hipFree(d_prof);
-  const char *names[14] = {"steps open-fast", "steps closed-fast", "steps general", "general loop iterations", "dc none",
-                           "consumer wait ticks", "consumer total ticks", "dc fast", "dc slow", "producer wait ticks",
-                           "producer total ticks", "averaging wait ticks", "producer fir ticks", "producer rest ticks"};
-  for (int i = 0; i < 14; ++i) fprintf(stderr, "[gate prof] %-24s %lld (stream 0)\n", names[i], h[(size_t)i]);
+  const char *names[16] = {"windows-open segments (general path)", "closed segments (general path)", "plain steps",
+                           "plain-step ticks", "general-step ticks", "consumer wait+fetch ticks", "consumer total ticks",
+                           "dc fast steps (general)", "dc slow steps (general)", "filter wait ticks", "filter total ticks",
+                           "averaging wait ticks", "filter busy ticks", "producer wait ticks", "consumer chain+finish ticks",
+                           "steps with dc chains"};
+  for (int i = 0; i < 16; ++i) fprintf(stderr, "[gate prof] %-38s %lld (stream 0)\n", names[i], h[(size_t)i]);
   return RFID_OK;
 }
 

@@ -383,6 +383,8 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
     below = wv::uniform64(below); above = wv::uniform64(above);
     if (PROF) tk[5] += wv::ticks() - tb;
   }
+  long long tp0 = 0, tp1 = 0;
+  if (PROF) tp0 = wv::ticks();
   // the two plain kinds of step (see below) are recognised before the dc_est chains start, so that
   // their scalar bookkeeping can be scheduled into the chains' latency
   const int nvalid0 = (n - pos < 64) ? (n - pos) : 64;
@@ -417,6 +419,7 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
     }
   }
   const float2 prev_yv = B.yv;   // samples of step k-1 (for the dc ring rebuild)
+  if (PROF) { wv::keep(g.dcr_c); tp1 = wv::ticks(); tk[9] += tp1 - tp0; if (B.has && B.any_closed) tk[10]++; }
   B.has = false;
 
   // ---- carry the front step through threshold test and state machine --------------------------
@@ -446,6 +449,7 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
     B.tim = plain_closed ? s_tim : 0.0f;
     B.openmask = plain_closed ? 0ull : ~0ull;
     B.open_lane = -1; B.open_lane2 = -1; B.pos = pos; B.has = true; B.any_closed = plain_closed;
+    if (PROF) { tk[2]++; tk[3] += wv::ticks() - tp1; }
   } else {
   // edge / pulse / window state machine on the scalar unit, event driven (gate_impl.cc:145-195)
   uint64_t closedmask = 0, openmask = 0;
@@ -616,6 +620,7 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
   B.pos = pos;
   B.has = true;
   B.any_closed = cnt != 0;
+  if (PROF) tk[4] += wv::ticks() - tp1;
   }  // general step
   }  // if (has_front)
 
@@ -908,6 +913,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
     if (PROF && a.prof && lane == 0) {
       tk[6] = wv::ticks() - t_start;
       for (int i = 0; i < 9; ++i) a.prof[(int64_t)s * 16 + i] = tk[i];
+      a.prof[(int64_t)s * 16 + 14] = tk[9]; a.prof[(int64_t)s * 16 + 15] = tk[10];
     }
 
     // ---- write state back ----------------------------------------------------------------
