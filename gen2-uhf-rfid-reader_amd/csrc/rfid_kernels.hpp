@@ -113,14 +113,18 @@ RFID_KERNEL(MF_THREADS) void mf_boxcar25_decim5_kernel(MfArgs a) {
 }
 
 // =========================================================================================
-// 2. gate scan.  One wavefront per trace, 64 decimated samples per step (lane L <-> sample
-//    pos+L).  The reference's per-sample recurrences are kept bit-exact:
-//      * avg_ampl += (|x| - ring[w]) / 100     -> the increments are computed lane-parallel,
-//        then added IN ORDER by a 63-step DPP wave-shift chain (lane L ends up holding the
-//        value after sample L);
-//      * dc_est  += (x - dcring[d]) / 48       -> same chain, only over "closed" samples;
-//      * the edge / pulse-count / window state machine runs on the scalar unit, event
-//        driven over 64-bit vote masks (threshold crossings are rare).
+// 2. gate scan (+ fused matched filter).  64 decimated samples per step (lane L <-> sample
+//    pos+L), four pipelined wavefronts per trace.  The reference's per-sample recurrences are
+//    kept bit-exact:
+//      * avg_ampl += (|x| - ring[w]) / 100     -> the increments are computed lane-parallel
+//        (producer wave), then added IN ORDER by a 63-step DPP wave-shift chain (lane L ends up
+//        holding the value after sample L) in the averaging wave;
+//      * dc_est  += (x - dcring[d]) / 48       -> same kind of chain in the consumer wave, only
+//        over "closed" samples;
+//      * the edge / pulse-count / window state machine runs on the scalar unit of the consumer
+//        wave over 64-bit vote masks, loop-free.
+//    The filter wave feeds the samples: matched-filter output y (stage kernel) or the raw 2 Msps
+//    samples, filtered on the fly (fused front end; y is then written for the decoder).
 //    Output: one rfid_window {start, dc_est at opening, type} per gate opening.  Batch mode
 //    re-arms the gate itself (type alternates RN16, EPC, ... : SURVEY.md section 3.3);
 //    streaming mode stops right after a window closes, like gate_impl.cc:189-194.
@@ -626,15 +630,15 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
 
 }
 
-// Workgroup = 8 waves = 4 traces: waves 0..3 are the consumers of traces 4b..4b+3, waves 4..7
-// their producers.  A workgroup's waves are placed round-robin over the CU's 4 SIMDs, so every
-// SIMD hosts exactly one consumer (DPP chains do not co-issue across waves) and one producer.
-// Producer and consumer of a trace talk through a 4-slot LDS ring with sequence counters --
-// no s_barrier, hence no coupling between the traces of a workgroup.
+// Workgroup = 16 waves = 4 traces.  Wave w serves trace w % 4 in role w / 4: 0 consumer, 1 filter,
+// 2 averaging, 3 producer.  A workgroup's waves are placed round-robin over the CU's 4 SIMDs, so the
+// four waves of a trace share one SIMD (1024 traces = the 1024 SIMDs of the device).  The waves of
+// a trace talk through a 4-slot LDS ring with sequence counters (filter -> producer -> averaging ->
+// consumer -> filter) -- no s_barrier, hence no coupling between the traces of a workgroup.
 constexpr int GATE_RAW = 64 * DECIM + (NTAPS - DECIM);   // 344 raw samples feed 64 matched-filter outputs
 constexpr int GATE_RAW4 = GATE_RAW / 2;                  // as float4 (2 samples each): 172
 constexpr int GATE_RAW_LD = (GATE_RAW4 + 63) / 64;       // float4 loads per lane and step: 3
-constexpr int GATE_RAW_DEPTH = 6;                        // steps of raw samples in flight per producer wave
+constexpr int GATE_RAW_DEPTH = 6;                        // steps of raw samples in flight per filter wave
 constexpr int GATE_STREAMS_PER_WG = 4;
 constexpr int GATE_THREADS = 256 * GATE_STREAMS_PER_WG;   // consumer + filter + averaging + producer wave per trace
 constexpr int GATE_SLOTS = 4;
@@ -960,12 +964,11 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
 }
 
 RFID_KERNEL(GATE_THREADS) void gate_scan_kernel(GateArgs a) { gate_scan_body<false, false>(a); }
-// fused front end: matched filter (in the producer waves) + gate scan in one launch; reads the raw
+// fused front end: matched filter (in the filter waves) + gate scan in one launch; reads the raw
 // 2 Msps samples once, writes y for the decoder
 RFID_KERNEL(GATE_THREADS) void front_end_fused_kernel(GateArgs a) { gate_scan_body<false, true>(a); }
-// same kernel with s_memtime phase counters of the consumer wave (a.prof: [n_streams][8]):
-// 0 slot read + in-order sums, 1 finish back step, 2 threshold + state machine,
-// 3 dc increments, 4 SGPR pinning, 5 waiting for the producer, 6 total
+// the same kernels with s_memtime wait / phase counters of the four waves (a.prof: [n_streams][16],
+// printed by the RFID_GATE_PROF=1 developer aid in rfid_capi.hip)
 RFID_KERNEL(GATE_THREADS) void gate_scan_kernel_prof(GateArgs a) { gate_scan_body<true, false>(a); }
 RFID_KERNEL(GATE_THREADS) void front_end_fused_kernel_prof(GateArgs a) { gate_scan_body<true, true>(a); }
 
