@@ -641,7 +641,7 @@ constexpr int GATE_RAW_LD = (GATE_RAW4 + 63) / 64;       // float4 loads per lan
 constexpr int GATE_RAW_DEPTH = 6;                        // steps of raw samples in flight per filter wave
 constexpr int GATE_STREAMS_PER_WG = 4;
 constexpr int GATE_THREADS = 256 * GATE_STREAMS_PER_WG;   // consumer + filter + averaging + producer wave per trace
-constexpr int GATE_SLOTS = 4;
+constexpr int GATE_SLOTS = 16;   // deep enough to ride out a reader command (a burst of ~20 slow consumer steps)
 constexpr int GATE_PREFETCH = 4;    // steps (x64 samples) of matched-filter output held in registers
 
 struct GateShared {          // per trace
