@@ -363,9 +363,18 @@ RFID_DEVICE void gate_record_window(const GateArgs &a, GateRegs &g, int ol, int 
 // two in-order sums of dc_est for step k-1; then step k-1 is finished (window records, gated
 // output) and step k goes through the threshold test and the state machine.
 
+// the next step's slot, fetched one step early by the consumer
+struct GateNext {
+  int step;           // the step these values belong to (-1: none)
+  int sq;             // the sequence word as read just before them: valid iff > step
+  uint64_t below, above;
+  float2 yv;
+  float tre, tim;
+};
+
 template <bool PROF>
-RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const GateSlot *slot, bool has_front,
-                              const int *seq, int k, int pos, int n, int n_total, int s, int lane, float2 *lds_dc,
+RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const GateSlot *slot, const GateSlot *slot_next,
+                              GateNext &nx, bool has_front, const int *seq, int k, int pos, int n, int n_total, int s, int lane, float2 *lds_dc,
                               float2 *lds_tmp, long long *tk) {
   float f_tre = 0.0f, f_tim = 0.0f;
   float2 f_yv = make_float2(0.0f, 0.0f);
@@ -374,17 +383,29 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
     // Wait for step k and fetch it in ONE LDS round trip: the sequence word and the slot are read
     // back to back (a wave's LDS reads execute in order, and the averaging wave wrote the slot
     // before it advanced the sequence word), and only then is the sequence word looked at.
+    // Usually not even that: the previous step already fetched this slot (see below).
     long long tb = 0;
     if (PROF) tb = wv::ticks();
-    for (;;) {
-      const int sq = wv::lds_peek(seq);
-      wv::lds_peek_masks(&slot->below, below, above);
-      f_yv = slot->yv[lane];
-      f_tre = slot->tre[lane]; f_tim = slot->tim[lane];
-      if (wv::uniform(sq) > k) break;
-      wv::backoff();
+    if (nx.step == k && wv::uniform(nx.sq) > k) {
+      below = nx.below; above = nx.above; f_yv = nx.yv; f_tre = nx.tre; f_tim = nx.tim;
+    } else {
+      for (;;) {
+        const int sq = wv::lds_peek(seq);
+        wv::lds_peek_masks(&slot->below, below, above);
+        f_yv = slot->yv[lane];
+        f_tre = slot->tre[lane]; f_tim = slot->tim[lane];
+        if (wv::uniform(sq) > k) break;
+        wv::backoff();
+      }
     }
     below = wv::uniform64(below); above = wv::uniform64(above);
+    // fetch step k+1 now: the averaging wave is normally more than one step ahead, and the reads
+    // complete while this step is worked on (the sequence word tells the next call whether they count)
+    nx.sq = wv::lds_peek(seq);
+    wv::lds_peek_masks(&slot_next->below, nx.below, nx.above);
+    nx.yv = slot_next->yv[lane];
+    nx.tre = slot_next->tre[lane]; nx.tim = slot_next->tim[lane];
+    nx.step = k + 1;
     if (PROF) tk[5] += wv::ticks() - tb;
   }
   long long tp0 = 0, tp1 = 0;
@@ -902,18 +923,20 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
     long long tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const long long t_start = PROF ? wv::ticks() : 0;
     GateBack B;
+    GateNext nx;
+    nx.step = -1; nx.sq = 0; nx.below = nx.above = 0; nx.yv = make_float2(0.0f, 0.0f); nx.tre = nx.tim = 0.0f;
     B.has = false; B.tre = 0.0f; B.tim = 0.0f; B.openmask = 0; B.yv = make_float2(0.0f, 0.0f);
     B.open_lane = B.open_lane2 = -1; B.open_type = B.open_type2 = 0; B.pos = 0; B.any_closed = false;
     wv::wave_sync();
     for (int k = 0; k < nsteps && !g.stop; ++k) {
       // (waits until step k is produced and averaged)
-      gate_consume<PROF>(a, g, B, &sh.slots[k % GATE_SLOTS], true, &sh.avg_seq, k, 64 * k, n, n_total, s, lane, lds_dc,
+      gate_consume<PROF>(a, g, B, &sh.slots[k % GATE_SLOTS], &sh.slots[(k + 1) % GATE_SLOTS], nx, true, &sh.avg_seq, k, 64 * k, n, n_total, s, lane, lds_dc,
                          lds_tmp, tk);
       wv::lds_store(&sh.cons_seq, k + 1, lane);   // slot k free again (its data are in registers)
     }
     if (g.stop) wv::lds_store(&sh.stop, 1, lane);
     // drain: finish the pending back half (window records / gated output of the last step)
-    if (B.has) gate_consume<PROF>(a, g, B, &sh.slots[0], false, &sh.avg_seq, 0, 0, n, n_total, s, lane, lds_dc, lds_tmp, tk);
+    if (B.has) gate_consume<PROF>(a, g, B, &sh.slots[0], &sh.slots[0], nx, false, &sh.avg_seq, 0, 0, n, n_total, s, lane, lds_dc, lds_tmp, tk);
     if (PROF && a.prof && lane == 0) {
       tk[6] = wv::ticks() - t_start;
       for (int i = 0; i < 9; ++i) a.prof[(int64_t)s * 16 + i] = tk[i];
