@@ -314,7 +314,8 @@ int rfid_selftest(rfid_ctx *c, int *n_failed) {
   for (int round = 0; round < 48; ++round) {
     const float scale = (round == 0) ? 1.0f : ldexpf(1.0f, -150 + 6 * (round - 1));
     for (int i = 0; i < 64; ++i) {
-      hx[i] = (rnd() - 0.5f) * 1e-3f * (float)(1 + (i % 7));
+      hx[i] = (rnd() - 0.5f) * 1e-3f * (float)(1 + (i % 7)) * ((round & 1) ? scale : 1.0f);   // (|x|: odd rounds sweep both operands)
+      if (round > 0 && i == 9) hx[i] = 0.0f;
       hn[i] = (rnd() - 0.5f) * 37.0f * scale;
       if (round > 0 && i == 5) hn[i] = 0.0f;
       if (round > 0 && i == 6) hn[i] = -0.0f;
@@ -338,7 +339,7 @@ int rfid_selftest(rfid_ctx *c, int *n_failed) {
       float e_chain = acc;
       volatile float q = hn[i] / hd[i];
       float e_div = q;
-      float e_hyp = (float)sqrt((double)hn[i] * (double)hn[i] + (double)hd[i] * (double)hd[i]);
+      float e_hyp = (float)sqrt((double)hn[i] * (double)hn[i] + (double)hx[i] * (double)hx[i]);
       float e_shr = (i == 0) ? 0.0f : hx[i - 1];
       if (memcmp(&e_chain, &out[i], 4)) bad++;
       if (memcmp(&e_div, &out[64 + i], 4)) bad++;

@@ -1607,7 +1607,7 @@ struct SelfTestArgs {
   float carry;
   float *chain_out;  // [64]
   float *div_out;    // [64]
-  float *hyp_out;    // [64] hypot(num, den)
+  float *hyp_out;    // [64] hypot(num, x)
   float *shr_out;    // [64]
 };
 
@@ -1618,7 +1618,7 @@ RFID_KERNEL(64) void selftest_kernel(SelfTestArgs a) {
     const float num = a.num[lane], den = a.den[lane];
     a.div_out[lane] = (den == WIN_LEN_F) ? div_const<WIN_LEN>(num) : ((den == DC_LEN_F) ? div_const<DC_LEN>(num) : wv::fdiv(num, den));
   }
-  a.hyp_out[lane] = wv::hypot_f(a.num[lane], a.den[lane]);
+  a.hyp_out[lane] = wv::hypot_f(a.num[lane], a.x[lane]);
   a.shr_out[lane] = wv::shr1(a.x[lane]);
 }
 
