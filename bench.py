@@ -62,7 +62,7 @@ def cpu_baseline(base_samples, sigma, seconds_target):
     n = rng.standard_normal((len(base_samples), 2), dtype=np.float32)
     x = (base_samples + np.float32(sigma) * (n[:, 0] + 1j * n[:, 1])).astype(np.complex64)
     t = oracle.time_trace(x, reps=1)
-    reps = max(1, min(2000, int(seconds_target / max(t["total_s"], 1e-4))))
+    reps = max(1, min(20000, int(seconds_target / max(t["total_s"], 1e-4))))
     t = oracle.time_trace(x, reps=reps)
     msps = len(x) * reps / t["total_s"] / 1e6
     return {"value": round(msps, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
