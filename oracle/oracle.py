@@ -89,6 +89,9 @@ def lib() -> C.CDLL:
         L.orc_time_trace.argtypes = [C.POINTER(Config), vp, C.c_long, C.c_int, C.POINTER(C.c_double * 3),
                                      C.POINTER(ReaderState)]
         L.orc_time_trace.restype = C.c_long
+        L.orc_time_trace_mt.argtypes = [C.POINTER(Config), vp, C.c_long, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                        C.POINTER(C.c_int)]
+        L.orc_time_trace_mt.restype = C.c_long
         L.orc_print_results.argtypes = [C.POINTER(ReaderState), C.c_char_p, C.c_int]
         L.orc_print_results.restype = C.c_int
         L.orc_check_crc.argtypes = [C.c_char_p, C.c_int]
@@ -165,3 +168,13 @@ def time_trace(raw: np.ndarray, reps: int = 1, cfg: Optional[Config] = None):
     nw = lib().orc_time_trace(C.byref(cfg), raw.ctypes.data, len(raw), reps, C.byref(secs), C.byref(st))
     return dict(fir_s=secs[0], gate_decoder_s=secs[1], total_s=secs[2], windows=nw,
                 n_epc_correct=st.n_epc_correct)
+
+
+def time_trace_mt(raw: np.ndarray, reps: int, nthreads: int, cfg: Optional[Config] = None):
+    """`nthreads` independent single-thread runs of time_trace() at once -> wall time."""
+    raw = np.ascontiguousarray(raw, dtype=np.complex64)
+    wall = C.c_double(0.0)
+    nepc = C.c_int(0)
+    cfg = cfg or config()
+    nw = lib().orc_time_trace_mt(C.byref(cfg), raw.ctypes.data, len(raw), reps, nthreads, C.byref(wall), C.byref(nepc))
+    return dict(wall_s=wall.value, windows=nw, n_epc_correct=nepc.value, threads=nthreads, reps=reps)

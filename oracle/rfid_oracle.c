@@ -565,3 +565,34 @@ long orc_time_trace(const orc_config *cfg, const orc_cf *raw, long n_raw, int re
   free(y);
   return nw;
 }
+
+/* cpu_baseline leg, all host cores: `nthreads` independent copies of the single-thread run above
+ * (the reference is single-threaded per stream; independent streams are the only parallelism it has).
+ * Returns the wall time of the slowest thread in *wall_s; every thread decodes the same trace `reps`
+ * times.  n_epc_out (nullable) = EPC decodes of one pass. */
+#include <pthread.h>
+typedef struct {
+  const orc_config *cfg; const orc_cf *raw; long n_raw; int reps; double secs[3]; orc_reader_state rs; long nw;
+} orc_mt_job;
+static void *orc_mt_main(void *p) {
+  orc_mt_job *j = (orc_mt_job *)p;
+  j->nw = orc_time_trace(j->cfg, j->raw, j->n_raw, j->reps, j->secs, &j->rs);
+  return NULL;
+}
+long orc_time_trace_mt(const orc_config *cfg, const orc_cf *raw, long n_raw, int reps, int nthreads,
+                       double *wall_s, int *n_epc_out) {
+  if (nthreads < 1) nthreads = 1;
+  orc_mt_job *jobs = (orc_mt_job *)calloc((size_t)nthreads, sizeof(orc_mt_job));
+  pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+  double t0 = now_s();
+  for (int i = 0; i < nthreads; i++) {
+    jobs[i].cfg = cfg; jobs[i].raw = raw; jobs[i].n_raw = n_raw; jobs[i].reps = reps;
+    pthread_create(&th[i], NULL, orc_mt_main, &jobs[i]);
+  }
+  for (int i = 0; i < nthreads; i++) pthread_join(th[i], NULL);
+  *wall_s = now_s() - t0;
+  long nw = jobs[0].nw;
+  if (n_epc_out) *n_epc_out = jobs[0].rs.n_epc_correct;
+  free(jobs); free(th);
+  return nw;
+}

@@ -155,6 +155,9 @@ long orc_run_decimated(const orc_config *cfg, const orc_cf *y, long n_dec, int c
  * separately over the trace and returns seconds spent in each (steady clock). */
 long orc_time_trace(const orc_config *cfg, const orc_cf *raw, long n_raw, int reps,
                     double secs[3], orc_reader_state *rs_out);
+/* the same on `nthreads` host threads at once (independent copies); *wall_s = wall time */
+long orc_time_trace_mt(const orc_config *cfg, const orc_cf *raw, long n_raw, int reps, int nthreads,
+                       double *wall_s, int *n_epc_out);
 
 #ifdef __cplusplus
 }

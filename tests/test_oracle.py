@@ -105,3 +105,13 @@ def test_empty_and_tiny_inputs(oracle_mod):
     for n in (0, 1, 4, 5, 24):
         o = oracle_mod.run_trace(np.zeros(n, dtype=np.complex64))
         assert o.n_windows == 0 and o.state.n_queries_sent == 1
+
+
+def test_multi_thread_timing_leg_decodes_the_same(oracle_mod, synth_mod):
+    """bench.py's cpu_baseline leg on all host cores: every thread runs the single-thread chain on its own
+    copy; the decode counts equal the single-thread run's."""
+    t = synth_mod.make_trace(n_rounds=3, seed=4, sigma=0.01).samples
+    one = oracle_mod.time_trace(t, reps=2)
+    many = oracle_mod.time_trace_mt(t, reps=2, nthreads=3)
+    assert many["windows"] == one["windows"] and many["n_epc_correct"] == one["n_epc_correct"]
+    assert many["wall_s"] > 0.0
