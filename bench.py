@@ -54,6 +54,30 @@ def build_batch(torch, device, n_streams, sigma, seed, rank):
     return data, L, stride, base
 
 
+def _usable_cores():
+    """Host threads worth starting: the affinity mask, capped by a cgroup CPU quota if there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(float(parts[0]) / float(parts[1]) + 0.999)))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                        n = min(n, max(1, int(q / int(f2.read().split()[0]) + 0.999)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(base_samples, sigma, seconds_target):
     """The oracle (CPU port of the reference algorithm) timed on this host on a bounded sample: repeated passes
     over ONE replica of the same workload -- first on one thread (the reference is single-threaded per stream;
@@ -67,11 +91,10 @@ def cpu_baseline(base_samples, sigma, seconds_target):
     reps1 = max(1, min(20000, int(0.5 * seconds_target / t_pass)))
     t = oracle.time_trace(x, reps=reps1)
     msps1 = len(x) * reps1 / t["total_s"] / 1e6
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    reps_mt = max(1, min(20000, int(0.5 * seconds_target / t_pass)))
+    cores = _usable_cores()
+    # calibrate the all-cores leg with one pass per thread, then size it to ~half the time budget of wall time
+    cal = oracle.time_trace_mt(x, reps=1, nthreads=cores)
+    reps_mt = max(1, min(20000, int(0.5 * seconds_target / max(cal["wall_s"], 1e-4))))
     m = oracle.time_trace_mt(x, reps=reps_mt, nthreads=cores)
     msps = len(x) * reps_mt * cores / m["wall_s"] / 1e6
     return {"value": round(msps, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
