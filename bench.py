@@ -29,28 +29,22 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s;
 RN16_WIN, EPC_WIN = 250, 1370
 
 
-def build_batch(torch, device, n_streams, sigma, seed, rank):
-    """Noise-free 71-round stand-in trace, replicated n_streams times on the GPU with
-    per-replica noise (replica seed = seed + global replica index)."""
+def build_batch(torch, ctx, device, n_streams, sigma, seed, rank):
+    """Noise-free 71-round stand-in trace, replicated n_streams times in HBM with per-replica noise by the library's
+    device-side generator (rfid_synth_replicas; replica index = rank * n_streams + row, so every GPU of a multi-GPU
+    run holds different replicas).  torch only owns the buffers."""
     from rfid import synth
     base = synth.make_trace(n_rounds=71, fixed_q=0, tag_ids=(0x27,), sigma=0.0, seed=7,
                             corrupt_rounds=(36,), noise=False)
     L = len(base.samples)
     stride = (L + 1) & ~1
-    host = np.zeros(stride, dtype=np.complex64)
-    host[:L] = base.samples
-    base_dev = torch.from_numpy(host.view(np.float32)).to(device)            # [2*stride] float32
-    data = torch.empty((n_streams, 2 * stride), dtype=torch.float32, device=device)
-    gen = torch.Generator(device=device)
-    rows = 32
-    for r0 in range(0, n_streams, rows):
-        r1 = min(n_streams, r0 + rows)
-        gen.manual_seed(seed + rank * n_streams + r0)
-        noise = torch.randn((r1 - r0, 2 * stride), generator=gen, device=device, dtype=torch.float32)
-        data[r0:r1] = base_dev[None, :] + sigma * noise
-        del noise
-    if stride != L:
-        data[:, 2 * L:] = 0
+    base_dev = torch.from_numpy(base.samples.view(np.float32).copy()).to(device)     # [2*L] float32
+    data = torch.zeros((n_streams, 2 * stride), dtype=torch.float32, device=device)
+    torch.cuda.synchronize()     # the library runs on its own (non-blocking) stream: torch's fill must be over
+    ctx.synth_replicas_ptr(base_dev.data_ptr(), L, data.data_ptr(), stride, n_streams, sigma, seed,
+                           first_replica=rank * n_streams)
+    ctx.batch_sync()
+    del base_dev
     return data, L, stride, base
 
 
@@ -136,8 +130,8 @@ def main():
     n_gpus = world
 
     B = args.streams
-    data, L, stride, base = build_batch(torch, device, B, args.sigma, args.seed, rank)
     ctx = rfid.Context(device=local_rank)
+    data, L, stride, base = build_batch(torch, ctx, device, B, args.sigma, args.seed, rank)
     ctx.batch_plan(B, L)
     ptr = data.data_ptr()
 

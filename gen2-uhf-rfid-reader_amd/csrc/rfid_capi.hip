@@ -734,6 +734,30 @@ int rfid_batch_get_mf(rfid_ctx *c, int stream, rfid_cf32 *out, int64_t cap, int6
 }
 
 // ======================================================================================
+// (3) synthetic workloads
+// ======================================================================================
+int rfid_synth_replicas(rfid_ctx *c, const void *d_base, int64_t n_raw, void *d_out, int64_t out_stride, int n_streams,
+                        float sigma, uint64_t seed, int64_t first_replica) {
+  if (!c || !d_base || !d_out || n_raw < 0 || out_stride < n_raw || n_streams < 0 || first_replica < 0) return RFID_ERR_INVALID;
+  if (n_raw == 0 || n_streams == 0) return RFID_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  SynthArgs a;
+  a.base = (const float2 *)d_base; a.out = (float2 *)d_out; a.n_raw = n_raw; a.out_stride = out_stride;
+  a.first_replica = first_replica; a.sigma = sigma; a.key0 = (uint32_t)seed; a.key1 = (uint32_t)(seed >> 32);
+  const int64_t per_block = (int64_t)SYNTH_THREADS * SYNTH_PAIRS_PER_THREAD * 2;
+  const int64_t blocks = (n_raw + per_block - 1) / per_block;
+  for (int s0 = 0; s0 < n_streams; s0 += 65535) {   // grid.y limit
+    const int ns = (n_streams - s0 < 65535) ? (n_streams - s0) : 65535;
+    SynthArgs b = a;
+    b.out = a.out + (int64_t)s0 * out_stride;
+    b.first_replica = first_replica + s0;
+    hipLaunchKernelGGL(synth_replicas_kernel, dim3((unsigned)blocks, (unsigned)ns), dim3(SYNTH_THREADS), 0, c->stream, b);
+    HIPCHK(c, hipGetLastError());
+  }
+  return RFID_OK;
+}
+
+// ======================================================================================
 // (1) streaming per-block path (host buffers)
 // ======================================================================================
 int rfid_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap, int *n_produced) {

@@ -67,6 +67,11 @@ RFID_DEVICE float hypot_f(float x, float y) {
   double s = (double)x * (double)x + (double)y * (double)y;
   return (float)__dsqrt_rn(s);
 }
+// fast transcendental functions for the synthetic-replica generator only (never on the receive path)
+RFID_DEVICE float log_fast(float x) { return __logf(x); }
+RFID_DEVICE float sin_fast(float x) { return __sinf(x); }
+RFID_DEVICE float cos_fast(float x) { return __cosf(x); }
+RFID_DEVICE float sqrt_fast(float x) { return __fsqrt_rn(x); }
 // truncation toward zero of a binary32 value, as (int) in C
 RFID_DEVICE int f2i(float v) { return (int)v; }
 

@@ -1622,4 +1622,68 @@ RFID_KERNEL(64) void selftest_kernel(SelfTestArgs a) {
   a.shr_out[lane] = wv::shr1(a.x[lane]);
 }
 
+// =========================================================================================
+// 6. synthetic replicas (SURVEY.md section 8 d, configs 1/3/5: noise replicas of a base trace made
+//    on the device).  out[s][i] = base[i] + sigma * (N(0,1) + j N(0,1)); the noise of replica r is a
+//    pure function of (seed, r, i): Philox4x32-10 keyed by the seed, counter = (r, i / 2), two
+//    Box-Muller pairs per call -> two complex samples.  Nothing here is on the receive path and
+//    nothing needs to be bit-exact against the reference: this is the workload generator.
+// =========================================================================================
+struct SynthArgs {
+  const float2 *base;   // [n_raw]
+  float2 *out;          // [n_streams][out_stride]
+  int64_t n_raw, out_stride;
+  int64_t first_replica;   // replica index of out row 0 (so that a batch can be generated in pieces)
+  float sigma;
+  uint32_t key0, key1;  // seed
+};
+constexpr int SYNTH_THREADS = 256;
+constexpr int SYNTH_PAIRS_PER_THREAD = 4;   // 4 x 2 complex samples per thread
+
+RFID_DEVICE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                               uint32_t (&o)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+RFID_DEVICE void box_muller(uint32_t a, uint32_t b, float &n0, float &n1) {
+  const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
+  const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);            // [0, 1)
+  const float r = wv::sqrt_fast(-2.0f * wv::log_fast(u1));
+  const float th = 6.28318530717958647692f * u2;
+  n0 = r * wv::cos_fast(th);
+  n1 = r * wv::sin_fast(th);
+}
+
+RFID_KERNEL(SYNTH_THREADS) void synth_replicas_kernel(SynthArgs a) {
+  const int64_t s = (int64_t)blockIdx.y;
+  const int64_t pair0 = ((int64_t)blockIdx.x * SYNTH_THREADS + threadIdx.x) * SYNTH_PAIRS_PER_THREAD;
+  const uint64_t rep = (uint64_t)(a.first_replica + s);
+  float2 *row = a.out + s * a.out_stride;
+#pragma unroll
+  for (int q = 0; q < SYNTH_PAIRS_PER_THREAD; ++q) {
+    const int64_t pair = pair0 + q;
+    const int64_t i = 2 * pair;
+    if (i >= a.n_raw) break;
+    uint32_t rnd[4];
+    philox4x32_10((uint32_t)pair, (uint32_t)((uint64_t)pair >> 32), (uint32_t)rep, (uint32_t)(rep >> 32), a.key0, a.key1, rnd);
+    float g0, g1, g2, g3;
+    box_muller(rnd[0], rnd[1], g0, g1);
+    box_muller(rnd[2], rnd[3], g2, g3);
+    const float2 b0 = a.base[i];
+    row[i] = make_float2(b0.x + a.sigma * g0, b0.y + a.sigma * g1);
+    if (i + 1 < a.n_raw) {
+      const float2 b1 = a.base[i + 1];
+      row[i + 1] = make_float2(b1.x + a.sigma * g2, b1.y + a.sigma * g3);
+    }
+  }
+}
+
 }  // namespace rfidk

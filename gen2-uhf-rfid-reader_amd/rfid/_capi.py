@@ -95,6 +95,7 @@ SIGNATURES = {
     "rfid_batch_device_ptrs": (_i, [_vp, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_vp), C.POINTER(_vp)]),
     "rfid_batch_get_mf": (_i, [_vp, _i, _vp, _i64, C.POINTER(_i64)]),
     "rfid_ctx_stream": (_vp, [_vp]),
+    "rfid_synth_replicas": (_i, [_vp, _vp, _i64, _vp, _i64, _i, C.c_float, C.c_uint64, _i64]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -175,6 +175,12 @@ class Context:
         self._chk(self._lib.rfid_batch_get_mf(self._h, int(stream), out.ctypes.data, cap, C.byref(n)))
         return out[: n.value].copy()
 
+    def synth_replicas_ptr(self, d_base: int, n_raw: int, d_out: int, out_stride: int, n_streams: int, sigma: float,
+                           seed: int, first_replica: int = 0) -> None:
+        """Asynchronous: d_out[s] = d_base + sigma * complex Gaussian noise (replica first_replica + s)."""
+        self._chk(self._lib.rfid_synth_replicas(self._h, C.c_void_p(d_base), int(n_raw), C.c_void_p(d_out), int(out_stride),
+                                                int(n_streams), C.c_float(sigma), C.c_uint64(seed), int(first_replica)))
+
     def batch_device_ptrs(self) -> dict:
         y, st, fc = C.c_void_p(), C.c_void_p(), C.c_void_p()
         stride = C.c_int64(0)

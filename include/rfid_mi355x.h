@@ -180,7 +180,9 @@ RFID_API int rfid_print_results(const rfid_ctx *ctx, char *buf, int cap, int *le
 RFID_API int rfid_batch_plan(rfid_ctx *ctx, int n_streams, int64_t max_raw);
 /* d_raw: device pointer to [n_streams][raw_stride] rfid_cf32; d_lens: device int64[n_streams]
  * valid sample counts per trace, or NULL when every trace has n_raw samples.  All launches
- * go to the ctx stream and return without synchronising. */
+ * go to the ctx stream (a non-blocking stream of its own, see rfid_ctx_stream) and return without
+ * synchronising: work the caller queued on OTHER streams that produces d_raw / d_lens must be
+ * complete (or ordered before the ctx stream with an event) when these functions are called. */
 RFID_API int rfid_batch_mf(rfid_ctx *ctx, const void *d_raw, int64_t raw_stride, int64_t n_raw,
                            const void *d_lens);
 RFID_API int rfid_batch_gate(rfid_ctx *ctx);
@@ -207,6 +209,15 @@ RFID_API int rfid_batch_device_ptrs(rfid_ctx *ctx, void **d_mf_out, int64_t *mf_
 RFID_API int rfid_batch_get_mf(rfid_ctx *ctx, int stream, rfid_cf32 *out, int64_t cap, int64_t *n);
 /* the HIP stream the ctx launches on (hipStream_t as void*) */
 RFID_API void *rfid_ctx_stream(rfid_ctx *ctx);
+
+/* ---- (3) synthetic workloads (SURVEY.md section 8 d: noise replicas made on the device) ---------- */
+/* d_out[s][i] = d_base[i] + sigma * (N(0,1) + j N(0,1)) for s in [0, n_streams), i in [0, n_raw): replica
+ * first_replica + s of the base trace.  The noise is a pure function of (seed, replica index, i)
+ * (Philox4x32-10 + Box-Muller), so a batch may be generated in pieces and on any number of GPUs.
+ * Asynchronous on the ctx stream.  Not part of the receive path: the workload generator of bench.py
+ * and of the HBM-capacity configurations. */
+RFID_API int rfid_synth_replicas(rfid_ctx *ctx, const void *d_base, int64_t n_raw, void *d_out, int64_t out_stride,
+                                 int n_streams, float sigma, uint64_t seed, int64_t first_replica);
 
 #ifdef __cplusplus
 }

@@ -145,3 +145,26 @@ def test_emulated_fused_front_end(emu_mod, oracle_mod, synth_mod, unaligned):
         parity.compare_trace(wb, rb, sb, r["stats"][b], o)
         n = int(lens[b]) // 5
         assert np.array_equal(r["y"][b][:n].view(np.uint32), oracle_mod.fir(raw[b][: lens[b]])[:n].view(np.uint32))
+
+
+def test_emulated_replica_generator(emu_mod):
+    """synth_replicas_kernel (workload generator): Philox4x32-10 reproduces the Random123 known-answer
+    vectors; the noise is a pure function of (seed, replica, sample) -- generating in pieces gives the
+    same bytes -- with unit-variance independent components."""
+    kat = [([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, want in kat:
+        assert [int(v) for v in emu_mod.philox4x32_10(ctr, key)] == want
+    base = (np.arange(4099) * (0.25 + 0.5j)).astype(np.complex64)          # odd length: the tail sample
+    a = emu_mod.synth_replicas(base, 4, 0.5, seed=99)
+    b = np.concatenate([emu_mod.synth_replicas(base, 1, 0.5, seed=99, first_replica=0),
+                        emu_mod.synth_replicas(base, 3, 0.5, seed=99, first_replica=1)])
+    assert a.tobytes() == b.tobytes()
+    assert emu_mod.synth_replicas(base, 1, 0.5, seed=100).tobytes() != a[:1].tobytes()
+    nz = (a - base[None, :]) / np.float32(0.5)
+    assert abs(nz.real.mean()) < 0.03 and abs(nz.imag.mean()) < 0.03
+    assert abs(nz.real.std() - 1) < 0.03 and abs(nz.imag.std() - 1) < 0.03
+    assert abs(np.corrcoef(nz[0].real, nz[1].real)[0, 1]) < 0.06 and abs(np.corrcoef(nz[0].real, nz[0].imag)[0, 1]) < 0.06
+    assert np.array_equal(emu_mod.synth_replicas(base, 2, 0.0, seed=1), np.stack([base, base]))

@@ -264,6 +264,34 @@ def test_full_size_properties_idempotence_and_scaling(gpu_ctx, synth_mod):
     assert np.array_equal(s4["corr"], s1["corr"] * np.float32(16)) and np.array_equal(s4["energy"], s1["energy"] * np.float32(16))
 
 
+def test_device_replica_generator(gpu_ctx, synth_mod):
+    """rfid_synth_replicas: deterministic, piecewise-consistent, N(0, sigma^2) per component, and the generated
+    batch decodes like the base trace (70 of 71 EPCs in every replica of the stand-in)."""
+    import torch
+    base = synth_mod.fst_like_trace().samples
+    L, B = len(base), 6
+    stride = (L + 1) & ~1
+    d_base = torch.from_numpy(base.view(np.float32).copy()).to("cuda:0")
+    out = torch.zeros((B, 2 * stride), dtype=torch.float32, device="cuda:0")
+    out2 = torch.zeros_like(out)
+    torch.cuda.synchronize()     # the library runs on its own stream: torch's fills must be over
+    gpu_ctx.synth_replicas_ptr(d_base.data_ptr(), L, out.data_ptr(), stride, B, 0.004, seed=1234)
+    gpu_ctx.batch_plan(B, L)
+    gpu_ctx.batch_sync()
+    a = out.cpu().numpy().view(np.complex64)[:, :L].copy()
+    gpu_ctx.synth_replicas_ptr(d_base.data_ptr(), L, out2.data_ptr(), stride, 2, 0.004, seed=1234, first_replica=0)
+    gpu_ctx.synth_replicas_ptr(d_base.data_ptr(), L, out2.data_ptr() + 2 * 8 * stride, stride, 4, 0.004, seed=1234, first_replica=2)
+    gpu_ctx.batch_sync()
+    assert torch.equal(out, out2)
+    nz = (a - base[None, :]) / np.float32(0.004)
+    assert abs(nz.real.mean()) < 0.01 and abs(nz.real.std() - 1) < 0.01 and abs(nz.imag.std() - 1) < 0.01
+    assert abs(np.corrcoef(nz[0].real, nz[1].real)[0, 1]) < 0.01
+    gpu_ctx.batch_process_ptr(out.data_ptr(), stride, L, 0, want_scores=False)
+    gpu_ctx.batch_sync()
+    st = gpu_ctx.batch_stats()
+    assert (st["n_epc_correct"] == 70).all() and (st["tag_reads"][:, 0x27] == 70).all()
+
+
 def test_file_ingest_batch_decoder(tmp_path, oracle_mod, synth_mod):
     """Trace files in the reference's format (interleaved float32 I,Q, apps/reader.py:102) ->
     pinned staging -> HBM -> one batched pass; ragged lengths."""

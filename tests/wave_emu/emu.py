@@ -103,3 +103,17 @@ def selftest(x, num, den, carry):
     lib().emu_selftest(C.c_void_p(x.ctypes.data), C.c_void_p(num.ctypes.data), C.c_void_p(den.ctypes.data),
                        C.c_float(carry), *[C.c_void_p(o.ctypes.data) for o in outs])
     return outs
+
+
+def synth_replicas(base: np.ndarray, n_streams: int, sigma: float, seed: int, first_replica: int = 0) -> np.ndarray:
+    base = np.ascontiguousarray(base, dtype=np.complex64)
+    out = np.zeros((n_streams, len(base)), dtype=np.complex64)
+    lib().emu_synth_replicas(C.c_void_p(base.ctypes.data), C.c_long(len(base)), C.c_void_p(out.ctypes.data),
+                             C.c_long(len(base)), n_streams, C.c_float(sigma), C.c_ulonglong(seed), C.c_long(first_replica))
+    return out
+
+
+def philox4x32_10(ctr, key) -> np.ndarray:
+    c = np.asarray(ctr, dtype=np.uint32); k = np.asarray(key, dtype=np.uint32); o = np.zeros(4, dtype=np.uint32)
+    lib().emu_philox4x32_10(C.c_void_p(c.ctypes.data), C.c_void_p(k.ctypes.data), C.c_void_p(o.ctypes.data))
+    return o

@@ -237,4 +237,25 @@ int emu_selftest(const float *x, const float *num, const float *den, float carry
   return 0;
 }
 
+// synthetic-replica generator (workload generator, not on the receive path)
+int emu_synth_replicas(const float *base, long n_raw, float *out, long out_stride, int n_streams, float sigma,
+                       unsigned long long seed, long first_replica) {
+  if (n_raw <= 0 || n_streams <= 0) return 0;
+  SynthArgs a;
+  a.base = reinterpret_cast<const float2 *>(base); a.out = reinterpret_cast<float2 *>(out); a.n_raw = n_raw;
+  a.out_stride = out_stride; a.first_replica = first_replica; a.sigma = sigma;
+  a.key0 = (uint32_t)seed; a.key1 = (uint32_t)(seed >> 32);
+  const long per_block = (long)SYNTH_THREADS * SYNTH_PAIRS_PER_THREAD * 2;
+  const long blocks = (n_raw + per_block - 1) / per_block;
+  emu::launch(emu::Idx3{(unsigned)blocks, (unsigned)n_streams, 1}, emu::Idx3{SYNTH_THREADS, 1, 1},
+              [&]() { synth_replicas_kernel(a); });
+  return 0;
+}
+
+void emu_philox4x32_10(const uint32_t *ctr, const uint32_t *key, uint32_t *out) {
+  uint32_t o[4];
+  philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], o);
+  for (int i = 0; i < 4; ++i) out[i] = o[i];
+}
+
 }  // extern "C"

@@ -124,6 +124,10 @@ static inline uint64_t uniform(uint64_t v) { return emu::exchange(v)[0]; }
 static inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
 static inline int ffs64(uint64_t m) { return m ? __builtin_ctzll(m) : 64; }
 static inline float fdiv(float a, float b) { volatile float q = a / b; return q; }
+static inline float log_fast(float x) { return logf(x); }
+static inline float sin_fast(float x) { return sinf(x); }
+static inline float cos_fast(float x) { return cosf(x); }
+static inline float sqrt_fast(float x) { return sqrtf(x); }
 static inline float fma_f(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 static inline uint32_t f2u(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
 static inline void compiler_fence() {}
