@@ -264,6 +264,17 @@ def test_full_size_properties_idempotence_and_scaling(gpu_ctx, synth_mod):
     assert np.array_equal(s4["corr"], s1["corr"] * np.float32(16)) and np.array_equal(s4["energy"], s1["energy"] * np.float32(16))
 
 
+def test_extreme_amplitudes_match_oracle(gpu_ctx, oracle_mod, synth_mod):
+    """The same trace scaled into the binary32 corners: products and increments in the denormal range
+    (3e-39 .. 1e-30: the constant-division fast path hands over to the generic division), energies
+    overflowing to +inf (1e18), and an all-zero trace.  Everything stays bit-identical to the oracle."""
+    t = synth_mod.make_trace(n_rounds=3, seed=5, sigma=0.01).samples
+    for scale in (1e-20, 1e-30, 1e-36, 3e-39, 1e15, 1e18, 0.0):
+        x = (t * np.float32(scale)).astype(np.complex64)
+        w, r, s, st = _run_batch(gpu_ctx, x[None, :])
+        parity.compare_trace(w, r, s, st[0], oracle_mod.run_trace(x))
+
+
 def test_device_replica_generator(gpu_ctx, synth_mod):
     """rfid_synth_replicas: deterministic, piecewise-consistent, N(0, sigma^2) per component, and the generated
     batch decodes like the base trace (70 of 71 EPCs in every replica of the stand-in)."""
