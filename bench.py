@@ -119,6 +119,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the receive path has no CPU fallback")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with "
+                         f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                         f"bench.py --gpus {args.gpus} ...")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
