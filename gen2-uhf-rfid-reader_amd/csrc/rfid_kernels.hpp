@@ -166,7 +166,7 @@ struct GateArgs {
   int gated_cap;
   int *io;              // streaming: io[0] = consumed, io[1] = written
   long long *prof;      // optional phase counters (gate_scan_kernel_prof only)
-  // fused front end (front_end_fused_kernel): the producer wave computes the matched filter
+  // fused front end (front_end_fused_kernel): the filter wave computes the matched filter
   // itself from the raw 2 Msps samples and writes y (for the decoder) instead of reading it
   const float2 *raw;    // [n_streams][raw_stride]
   int64_t raw_stride;
@@ -252,7 +252,8 @@ struct GateRegs {
   bool stop;
 };
 
-// One step (64 decimated samples) handed from the producer wave to the consumer wave.
+// One step (64 decimated samples) on its way through the waves of a trace (filter -> producer ->
+// averaging -> consumer).
 struct GateSlot {
   float amp[64];   // |x|                                   (gate_impl.cc:130)    producer -> averaging wave
   float d[64];     // (|x| - win_samples[win_index]) / 100   (gate_impl.cc:131)    producer -> averaging wave
@@ -451,7 +452,7 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
   if (has_front) {
   int nvalid = (n - pos < 64) ? (n - pos) : 64;
   const int nvalid_in = nvalid;
-  // (the producer's threshold masks already exclude the lanes past the end of the call)
+  // (the averaging wave's threshold masks already exclude the lanes past the end of the call)
 
   // The two by far most frequent kinds of step are decided with a handful of scalar
   // instructions (the consumer wave is issue bound: every instruction costs ~4.5 cycles):
@@ -654,7 +655,7 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
 // Workgroup = 16 waves = 4 traces.  Wave w serves trace w % 4 in role w / 4: 0 consumer, 1 filter,
 // 2 averaging, 3 producer.  A workgroup's waves are placed round-robin over the CU's 4 SIMDs, so the
 // four waves of a trace share one SIMD (1024 traces = the 1024 SIMDs of the device).  The waves of
-// a trace talk through a 4-slot LDS ring with sequence counters (filter -> producer -> averaging ->
+// a trace talk through a 16-slot LDS ring with sequence counters (filter -> producer -> averaging ->
 // consumer -> filter) -- no s_barrier, hence no coupling between the traces of a workgroup.
 constexpr int GATE_RAW = 64 * DECIM + (NTAPS - DECIM);   // 344 raw samples feed 64 matched-filter outputs
 constexpr int GATE_RAW4 = GATE_RAW / 2;                  // as float4 (2 samples each): 172
@@ -673,8 +674,8 @@ struct GateShared {          // per trace
   float4 rawtile[64 * GATE_RAW_LD];   // fused front end: the 344 raw samples one step's matched filter needs (+ padding)
   int prod_seq;              // steps produced so far
   int cons_seq;              // steps consumed so far
-  int stop;                  // consumer -> producer: stop (streaming mode window close)
-  int prod_done;             // the producer is through (fused front end: its y stores are visible device-wide)
+  int stop;                  // consumer -> the other waves: stop (streaming mode window close)
+  int prod_done;             // the filter wave is through (fused front end: its y stores are visible device-wide)
   float avg_final;           // avg_ampl after the last sample of the call (from the averaging wave)
   int avg_seq;               // steps averaged so far
   int avg_done;
@@ -708,7 +709,7 @@ RFID_DEVICE void gate_load_raw(GateRawRegs &r, const float2 *xs, int hi_idx, int
   }
 }
 
-// matched filter of one step inside the producer wave: y[n] = sum_{k=0..24} x[5n-24+k], k ascending
+// matched filter of one step inside the filter wave: y[n] = sum_{k=0..24} x[5n-24+k], k ascending
 // (the arithmetic of mf_boxcar25_decim5_kernel), for n = first output of the step + lane
 RFID_DEVICE float2 gate_fir_step(const GateRawRegs &r, float4 *tile4, int lane, bool first) {
   wv::wave_sync();   // the previous step's reads of the tile are done
@@ -904,8 +905,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
     wv::lds_store(&sh.avg_done, 1, lane);
   } else {
     // ================= consumer ===============================================================
-    // the consumer owns the critical path (dependent DPP adds): it must win VALU arbitration
-    // against the producer wave that shares its SIMD
+    // the consumer owns the critical path (the state machine and the dependent DPP adds of dc_est)
     wv::set_priority_high();
     float2 *lds_dc = sh.dc, *lds_tmp = sh.tmp;
     if (lane < DC_LEN) lds_dc[lane] = make_float2(st->dcr_re[lane], st->dcr_im[lane]);
@@ -944,7 +944,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
     }
 
     // ---- write state back ----------------------------------------------------------------
-    // wait for the producer: its final avg_ampl, and (fused front end) its y stores being visible
+    // wait for the other waves: the final avg_ampl, and (fused front end) the y stores being visible
     while (wv::lds_load(&sh.prod_done) == 0) wv::backoff();
     while (wv::lds_load(&sh.avg_done) == 0) wv::backoff();
     if (!g.stop) g.avg_c = wv::lds_load_f(&sh.avg_final);
