@@ -98,3 +98,44 @@ def summarize(stats: np.ndarray) -> List[dict]:
                         n_epc_correct=int(s["n_epc_correct"]), n_unique_tags=int(s["n_unique_tags"]),
                         tag_reads={i: int(c) for i, c in enumerate(s["tag_reads"]) if c}))
     return out
+
+
+def format_results(stats_row) -> str:
+    """The text reader_impl::print_results writes (lib/reader_impl.cc:173-192) for one trace of a batch."""
+    s = stats_row
+    lines = ["", " --------------------------", "| Number of queries/queryreps sent : %d" % (int(s["n_queries_sent"]) - 1),
+             "| Current Inventory round : %d" % int(s["cur_inventory_round"]), " --------------------------",
+             "| Correctly decoded EPC : %d" % int(s["n_epc_correct"]),
+             "| Number of unique tags : %d" % int(s["n_unique_tags"])]
+    for i, c in enumerate(s["tag_reads"]):
+        if c:
+            lines.append("| Tag ID : %x  Num of reads : %d" % (i, int(c)))
+    lines.append(" --------------------------")
+    return "\n".join(lines) + "\n"
+
+
+def main(argv=None) -> int:
+    """python -m rfid.batch [--device N] [--fixed-q Q] TRACE_FILE...  -- decode recorded traces in one batched pass."""
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m rfid.batch", description=main.__doc__)
+    ap.add_argument("files", nargs="+")
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--fixed-q", type=int, default=0)
+    ap.add_argument("--max-queries", type=int, default=1000)
+    args = ap.parse_args(argv)
+    dec = BatchDecoder(device=args.device, fixed_q=args.fixed_q, max_num_queries=args.max_queries)
+    try:
+        timing = {}
+        stats, _, _, _ = dec.decode_files(args.files, timing=timing)
+        for path, row in zip(args.files, stats):
+            print(path)
+            print(format_results(row), end="")
+        print("%d traces, %.1f M raw samples: %.3f s (host->HBM %.3f s, GPU pass %.4f s)" %
+              (len(args.files), timing["raw_samples"] / 1e6, timing["total_s"], timing["h2d_s"], timing["gpu_s"]))
+    finally:
+        dec.close()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -323,5 +323,12 @@ def test_file_ingest_batch_decoder(tmp_path, oracle_mod, synth_mod):
         summ = rfid.batch.summarize(stats)
         assert [x["n_epc_correct"] for x in summ] == [1, 3, 2] and summ[1]["tag_reads"] == {0x27: 3}
         assert timing["raw_samples"] == sum(map(len, traces))
+        for b in range(3):   # the per-trace report text equals reader_impl::print_results as the oracle writes it
+            assert rfid.batch.format_results(stats[b]) == oracle_mod.run_trace(traces[b]).print_results()
     finally:
         dec.close()
+    import io, contextlib
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        assert rfid.batch.main(paths) == 0          # python -m rfid.batch FILE...
+    assert buf.getvalue().count("Correctly decoded EPC") == 3
