@@ -939,3 +939,136 @@ int rfid_reader_work(rfid_ctx *c, int n_in, int *n_consumed) {  // reader_impl.c
 }
 
 }  // extern "C"
+
+// ---- reader TX waveform (reader_impl.cc:43-129 tables, :131-162 command bits, :383-443 CRC-5) ------------
+namespace {
+struct ReaderTx {
+  int dac_rate = 0, fixed_q = -1;
+  std::vector<float> data_0, data_1, cw, cw_ack, cw_query, delim, frame_sync, preamble, rtcal, trcal, query_bits,
+      query_rep, nak, query_adjust_bits, p_down;
+};
+void append(std::vector<float> &dst, const std::vector<float> &src) { dst.insert(dst.end(), src.begin(), src.end()); }
+void build_reader_tx(ReaderTx &t, int dac_rate, int fixed_q) {
+  t = ReaderTx();
+  t.dac_rate = dac_rate; t.fixed_q = fixed_q;
+  const float sample_d = (float)(1.0 / dac_rate * pow(10, 6));
+  const float n_data0_s = 2 * 12 / sample_d, n_data1_s = 4 * 12 / sample_d, n_pw_s = 12 / sample_d;   // PW_D = 12 us
+  const float n_cw_s = 250 / sample_d, n_delim_s = 12 / sample_d, n_trcal_s = 200 / sample_d;
+  const int n_cwquery_s = (int)((240 + 480 + 575) / sample_d);      // T1 + T2 + RN16
+  const int n_cwack_s = (int)((3 * 240 + 480 + 3375) / sample_d);   // 3 T1 + T2 + EPC
+  t.p_down.assign((size_t)(2000 / sample_d), 0.0f);
+  t.cw_query.assign((size_t)n_cwquery_s, 1.0f);
+  t.cw_ack.assign((size_t)n_cwack_s, 1.0f);
+  t.data_0.assign((size_t)n_data0_s, 0.0f);
+  t.data_1.assign((size_t)n_data1_s, 0.0f);
+  t.cw.assign((size_t)n_cw_s, 1.0f);
+  t.delim.assign((size_t)n_delim_s, 0.0f);
+  t.rtcal.assign((size_t)(n_data0_s + n_data1_s), 0.0f);
+  t.trcal.assign((size_t)n_trcal_s, 0.0f);
+  std::fill_n(t.data_0.begin(), t.data_0.size() / 2, 1.0f);
+  std::fill_n(t.data_1.begin(), 3 * t.data_1.size() / 4, 1.0f);
+  std::fill_n(t.rtcal.begin(), (size_t)((float)t.rtcal.size() - n_pw_s), 1.0f);
+  std::fill_n(t.trcal.begin(), (size_t)((float)t.trcal.size() - n_pw_s), 1.0f);
+  append(t.preamble, t.delim); append(t.preamble, t.data_0); append(t.preamble, t.rtcal); append(t.preamble, t.trcal);
+  append(t.frame_sync, t.delim); append(t.frame_sync, t.data_0); append(t.frame_sync, t.rtcal);
+  append(t.query_rep, t.frame_sync);
+  for (int i = 0; i < 4; ++i) append(t.query_rep, t.data_0);
+  append(t.nak, t.frame_sync);
+  append(t.nak, t.data_1); append(t.nak, t.data_1);
+  for (int i = 0; i < 6; ++i) append(t.nak, t.data_0);
+  // Query: 1000 DR M(2) TRext Sel(2) Session(2) Target Q(4) + CRC-5
+  const int head[13] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int b : head) t.query_bits.push_back((float)b);
+  for (int i = 3; i >= 0; --i) t.query_bits.push_back((float)((fixed_q >> i) & 1));
+  unsigned reg = 0x09;   // 01001
+  for (int i = 0; i < 17; ++i) {
+    const unsigned fb = ((reg >> 4) & 1u) ^ (t.query_bits[(size_t)i] == 1.0f ? 1u : 0u);
+    reg = (reg << 1) & 0x1Fu;
+    if (fb) reg ^= 0x09;
+  }
+  for (int i = 4; i >= 0; --i) t.query_bits.push_back((float)((reg >> i) & 1u));
+  const int qadj[9] = {1, 0, 0, 1, 0, 0, 0, 0, 0};   // QADJ_CODE, SESSION, Q_UPDN[1] (unchanged)
+  for (int b : qadj) t.query_adjust_bits.push_back((float)b);
+}
+size_t pie_len(const ReaderTx &t, const std::vector<float> &bits) {
+  size_t n = 0;
+  for (float b : bits) n += (b == 1.0f) ? t.data_1.size() : t.data_0.size();
+  return n;
+}
+void emit(float *out, int &w, const std::vector<float> &v) {
+  if (!v.empty()) memcpy(out + w, v.data(), sizeof(float) * v.size());
+  w += (int)v.size();
+}
+void emit_bits(const ReaderTx &t, float *out, int &w, const float *bits, int n) {
+  for (int i = 0; i < n; ++i) emit(out, w, bits[i] == 1.0f ? t.data_1 : t.data_0);
+}
+}  // namespace
+
+extern "C" {
+
+int rfid_reader_tx_max(int dac_rate) {
+  if (dac_rate <= 0) return 0;
+  ReaderTx t;
+  build_reader_tx(t, dac_rate, 15);
+  // the longest outputs: Query (all-ones upper bound on its bits) and START / SEND_CW (cw_ack)
+  const size_t q = t.preamble.size() + 22 * t.data_1.size() + t.cw_query.size();
+  const size_t m = q > t.cw_ack.size() ? q : t.cw_ack.size();
+  return (int)m;
+}
+
+int rfid_reader_work_tx(rfid_ctx *c, int dac_rate, const float *in_bits, int n_in, float *out, int out_cap, int *n_consumed,
+                        int *n_written) {
+  if (!c || dac_rate <= 0 || n_in < 0 || (!out && out_cap > 0) || out_cap < 0) return RFID_ERR_INVALID;
+  static thread_local ReaderTx t;
+  if (t.dac_rate != dac_rate || t.fixed_q != c->prm.fixed_q) build_reader_tx(t, dac_rate, c->prm.fixed_q);
+  const rfid_reader_state &rs = c->rs;
+  // how much the state at hand writes (reader_impl.cc:216-373)
+  size_t need = 0;
+  std::vector<float> ack_bits;
+  switch (rs.gen2_logic_status) {
+    case RFID_START: case RFID_SEND_CW: need = t.cw_ack.size(); break;
+    case RFID_POWER_DOWN: need = t.p_down.size(); break;
+    case RFID_SEND_NAK_QR: case RFID_SEND_NAK_Q: need = t.nak.size() + t.cw.size(); break;
+    case RFID_SEND_QUERY: need = t.preamble.size() + pie_len(t, t.query_bits) + t.cw_query.size(); break;
+    case RFID_SEND_ACK:
+      if (n_in == 16) {
+        if (!in_bits) return RFID_ERR_INVALID;
+        ack_bits.push_back(0.0f); ack_bits.push_back(1.0f);   // ACK_CODE
+        ack_bits.insert(ack_bits.end(), in_bits, in_bits + 16);
+        need = t.frame_sync.size() + pie_len(t, ack_bits);
+      }
+      break;
+    case RFID_SEND_QUERY_REP: need = t.query_rep.size() + t.cw_query.size(); break;
+    case RFID_SEND_QUERY_ADJUST: need = t.frame_sync.size() + pie_len(t, t.query_adjust_bits) + t.cw_query.size(); break;
+    default: break;
+  }
+  if (need > (size_t)out_cap) {
+    snprintf(c->err, sizeof(c->err), "rfid_reader_work_tx: %zu floats needed, out_cap %d", need, out_cap);
+    return RFID_ERR_CAPACITY;
+  }
+  int w = 0;
+  switch (rs.gen2_logic_status) {
+    case RFID_START: case RFID_SEND_CW: emit(out, w, t.cw_ack); break;
+    case RFID_POWER_DOWN: emit(out, w, t.p_down); break;
+    case RFID_SEND_NAK_QR: case RFID_SEND_NAK_Q: emit(out, w, t.nak); emit(out, w, t.cw); break;
+    case RFID_SEND_QUERY:
+      emit(out, w, t.preamble);
+      emit_bits(t, out, w, t.query_bits.data(), (int)t.query_bits.size());
+      emit(out, w, t.cw_query);
+      break;
+    case RFID_SEND_ACK:
+      if (n_in == 16) { emit(out, w, t.frame_sync); emit_bits(t, out, w, ack_bits.data(), (int)ack_bits.size()); }
+      break;
+    case RFID_SEND_QUERY_REP: emit(out, w, t.query_rep); emit(out, w, t.cw_query); break;
+    case RFID_SEND_QUERY_ADJUST:
+      emit(out, w, t.frame_sync);
+      emit_bits(t, out, w, t.query_adjust_bits.data(), (int)t.query_adjust_bits.size());
+      emit(out, w, t.cw_query);
+      break;
+    default: break;
+  }
+  if (n_written) *n_written = w;
+  return rfid_reader_work(c, n_in, n_consumed);   // the state transitions
+}
+
+}  // extern "C"

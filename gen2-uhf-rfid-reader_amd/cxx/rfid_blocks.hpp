@@ -190,19 +190,28 @@ class tag_decoder : public rfid_rt::block {
   bool d_last_valid = false;
 };
 
-// gr::rfid::reader (include/rfid/reader.h:42,51; lib/reader_impl.cc:200-380): float in -> float out.
-// Only the state transitions are on the receive path; the TX waveform is not synthesised (0 items out).
+// gr::rfid::reader (include/rfid/reader.h:42,51; lib/reader_impl.cc:43-380): float in -> float out: the Gen2 state
+// transitions and the transmit waveform of the state at hand (Query / ACK / QueryRep / NAK / carrier).
 class reader : public rfid_rt::block {
  public:
   typedef std::shared_ptr<reader> sptr;
   static sptr make(int sample_rate, int dac_rate, context_sptr ctx) { (void)sample_rate; return sptr(new reader(ctx, dac_rate)); }
   void forecast(int, gr_vector_int &req) override { req.assign(1, 0); }   // reader_impl.cc:194-198
-  int general_work(int, gr_vector_int &ninput_items, gr_vector_const_void_star &, gr_vector_void_star &) override {
+  // the largest number of items one call writes (the scheduler's output buffer must hold it)
+  int max_output() const { return rfid_reader_tx_max(d_dac_rate); }
+  int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
+                   gr_vector_void_star &output_items) override {
     begin_work(1);
-    int consumed = 0;
-    d_ctx->check(rfid_reader_work(d_ctx->get(), ninput_items[0], &consumed), "rfid_reader_work");
+    int consumed = 0, written = 0;
+    float *out = output_items.empty() ? nullptr : (float *)output_items[0];
+    const float *in = input_items.empty() ? nullptr : (const float *)input_items[0];
+    if (out)
+      d_ctx->check(rfid_reader_work_tx(d_ctx->get(), d_dac_rate, in, ninput_items[0], out, noutput_items, &consumed, &written),
+                   "rfid_reader_work_tx");
+    else   // no output buffer connected: transitions only
+      d_ctx->check(rfid_reader_work(d_ctx->get(), ninput_items[0], &consumed), "rfid_reader_work");
     consume_each(consumed);   // reader_impl.cc:378
-    return 0;
+    return written;           // :379
   }
   void print_results() {      // reader_impl.cc:173-192
     std::vector<char> buf(1 << 15);
@@ -233,11 +242,16 @@ class sts_scheduler {
       : d_mf(mf), d_gate(g), d_dec(d), d_reader(r), d_ctx(g->context()), d_chunk(chunk) {}
 
   long windows_decoded() const { return d_windows; }
+  // everything the reader block wrote (apps/reader.py:110-112 connects it to a file_sink in DEBUG mode)
+  const std::vector<float> &tx_samples() const { return d_tx; }
+  void keep_tx(bool on) { d_keep_tx = on; }
 
   void run(const gr_complex *samples, size_t n) {
     reader_until_idle(0);   // START -> SEND_QUERY -> IDLE
     std::vector<gr_complex> gq, dq, mf_out((size_t)d_chunk + 8), gate_out((size_t)d_chunk);
     std::vector<float> bits(16);
+    d_bits = &bits;
+    d_txbuf.assign((size_t)d_reader->max_output(), 0.0f);
     size_t pos = 0;
     while (pos < n || !gq.empty()) {
       if (pos < n) {
@@ -280,10 +294,12 @@ class sts_scheduler {
     for (int it = 0; it < 8; ++it) {
       const int before = d_ctx->state().gen2_logic_status;
       if (before == RFID_IDLE) break;
+      if (d_txbuf.empty()) d_txbuf.assign((size_t)d_reader->max_output(), 0.0f);
       gr_vector_int nin(1, q);
-      gr_vector_const_void_star in(1, nullptr);
-      gr_vector_void_star out(1, nullptr);
-      d_reader->general_work(0, nin, in, out);
+      gr_vector_const_void_star in(1, d_bits ? (const void *)d_bits->data() : nullptr);
+      gr_vector_void_star out(1, d_txbuf.data());
+      const int written = d_reader->general_work((int)d_txbuf.size(), nin, in, out);
+      if (d_keep_tx) d_tx.insert(d_tx.end(), d_txbuf.begin(), d_txbuf.begin() + written);
       q = 0;
       if (d_ctx->state().gen2_logic_status == before) break;
     }
@@ -295,6 +311,9 @@ class sts_scheduler {
   context_sptr d_ctx;
   int d_chunk;
   long d_windows = 0;
+  std::vector<float> d_tx, d_txbuf;
+  const std::vector<float> *d_bits = nullptr;
+  bool d_keep_tx = false;
 };
 
 }  // namespace rfid_rt

@@ -4,6 +4,7 @@
 // general_work), then reader.print_results() (apps/reader.py:130; lib/reader_impl.cc:173-192).
 //
 //   rfid_reader_offline TRACE_FILE [--device N] [--chunk N] [--fixed-q Q] [--max-queries N] [--unique-tags N]
+//                       [--tx-out FILE]   (the reader block's output, float32: apps/reader.py's file_sink_reader)
 //
 // TRACE_FILE: headerless little-endian interleaved float32 I,Q at 2 Msps (apps/reader.py:102).
 // Exit codes: 0 ok, 2 usage / file error, 3 no gfx950 device (there is no CPU fallback), 4 other library error.
@@ -15,7 +16,7 @@
 #include "rfid_blocks.hpp"
 
 int main(int argc, char **argv) {
-  const char *path = nullptr;
+  const char *path = nullptr, *tx_path = nullptr;
   int device = 0, chunk = 8192;
   rfid_params p;
   rfid_params_default(&p);
@@ -29,11 +30,12 @@ int main(int argc, char **argv) {
     else if (!std::strcmp(argv[i], "--fixed-q")) p.fixed_q = need("--fixed-q");
     else if (!std::strcmp(argv[i], "--max-queries")) p.max_num_queries = need("--max-queries");
     else if (!std::strcmp(argv[i], "--unique-tags")) p.number_unique_tags = need("--unique-tags");
+    else if (!std::strcmp(argv[i], "--tx-out")) { if (i + 1 >= argc) return 2; tx_path = argv[++i]; }
     else if (argv[i][0] == '-') { std::cerr << "unknown option " << argv[i] << "\n"; return 2; }
     else path = argv[i];
   }
   if (!path || chunk < 64) {
-    std::cerr << "usage: rfid_reader_offline TRACE_FILE [--device N] [--chunk N] [--fixed-q Q] [--max-queries N] [--unique-tags N]\n";
+    std::cerr << "usage: rfid_reader_offline TRACE_FILE [--device N] [--chunk N] [--fixed-q Q] [--max-queries N] [--unique-tags N] [--tx-out FILE]\n";
     return 2;
   }
   std::ifstream f(path, std::ios::binary | std::ios::ate);
@@ -58,8 +60,15 @@ int main(int argc, char **argv) {
     blocks::tag_decoder::sptr dec = blocks::tag_decoder::make(rate, gate->context());
     blocks::reader::sptr reader = blocks::reader::make(rate, (int)dac_rate, gate->context());
     rfid_rt::sts_scheduler tb(mf, gate, dec, reader, chunk);
+    tb.keep_tx(tx_path != nullptr);
     tb.run(samples.data(), samples.size());
     reader->print_results();
+    if (tx_path) {
+      std::ofstream o(tx_path, std::ios::binary);
+      const std::vector<float> &tx = tb.tx_samples();
+      o.write(reinterpret_cast<const char *>(tx.data()), (std::streamsize)(tx.size() * sizeof(float)));
+      if (!o) { std::cerr << "cannot write " << tx_path << "\n"; return 2; }
+    }
   } catch (const rfid_rt::error &e) {
     std::cerr << "rfid_reader_offline: " << e.what() << "\n";
     return e.status == RFID_ERR_NO_DEVICE ? 3 : 4;

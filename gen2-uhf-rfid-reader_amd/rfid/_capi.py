@@ -80,6 +80,8 @@ SIGNATURES = {
     "rfid_gate_work": (_i, [_vp, _vp, _i, _vp, _i, _ip, _ip]),
     "rfid_decoder_work": (_i, [_vp, _vp, _i, _vp, _i, _ip, _ip, _vp, _vp]),
     "rfid_reader_work": (_i, [_vp, _i, _ip]),
+    "rfid_reader_work_tx": (_i, [_vp, _i, _vp, _i, _vp, _i, _ip, _ip]),
+    "rfid_reader_tx_max": (_i, [_i]),
     "rfid_get_state": (_i, [_vp, C.POINTER(ReaderState)]),
     "rfid_print_results": (_i, [_vp, C.c_char_p, _i, _ip]),
     "rfid_batch_plan": (_i, [_vp, _i, _i64]),

@@ -116,6 +116,15 @@ class Context:
         self._chk(self._lib.rfid_reader_work(self._h, int(n_in), C.byref(cons)))
         return cons.value
 
+    def reader_work_tx(self, in_bits=None, dac_rate: int = 1000000):
+        """reader_impl::general_work incl. the TX waveform -> (consumed, float32 samples written)."""
+        bits = np.ascontiguousarray(in_bits if in_bits is not None else [], dtype=np.float32)
+        out = np.zeros(self._lib.rfid_reader_tx_max(int(dac_rate)), dtype=np.float32)
+        cons, wr = C.c_int(0), C.c_int(0)
+        self._chk(self._lib.rfid_reader_work_tx(self._h, int(dac_rate), bits.ctypes.data if len(bits) else None, len(bits),
+                                                out.ctypes.data, len(out), C.byref(cons), C.byref(wr)))
+        return cons.value, out[: wr.value].copy()
+
     # -- (2) batched offline, device buffers ---------------------------------------------------
     def batch_plan(self, n_streams: int, max_raw: int) -> None:
         self._chk(self._lib.rfid_batch_plan(self._h, int(n_streams), int(max_raw)))

@@ -17,7 +17,8 @@
  *         rfid_mf_work       <- filter.fir_filter_ccc(5,[1]*25)      apps/reader.py:65,75
  *         rfid_gate_work     <- gate_impl::general_work               lib/gate_impl.cc:85-200
  *         rfid_decoder_work  <- tag_decoder_impl::general_work        lib/tag_decoder_impl.cc:196-397
- *         rfid_reader_work   <- reader_impl::general_work (state transitions only)
+ *         rfid_reader_work_tx <- reader_impl::general_work (state transitions + transmit waveform)
+ *         rfid_reader_work    <- its state transitions alone
  *                                                                     lib/reader_impl.cc:200-380
  *   (2) batched offline calls on DEVICE buffers (many independent traces per launch):
  *         rfid_batch_mf / rfid_batch_gate / rfid_batch_decode / rfid_batch_stats and the
@@ -167,9 +168,18 @@ RFID_API int rfid_decoder_work(rfid_ctx *ctx, const rfid_cf32 *in, int n_in, flo
                                int out_cap, int *n_consumed, int *n_produced,
                                rfid_decode_result *res, rfid_scores *scores);
 /* reader_impl::general_work, state transitions only (gate_status / decoder_status /
- * n_queries_sent); the TX waveform synthesis is out of scope.  n_in = float items
+ * n_queries_sent) without the transmit waveform (see rfid_reader_work_tx).  n_in = float items
  * available on the reader's input (16 after an RN16). */
 RFID_API int rfid_reader_work(rfid_ctx *ctx, int n_in, int *n_consumed);
+/* reader_impl::general_work complete: the same state transitions AND the transmit waveform the block writes
+ * to its output for the state it was in (lib/reader_impl.cc:43-129 tables, :200-380; float samples 0/1 at
+ * dac_rate, e.g. preamble + 22 PIE-coded Query bits + 1295 us of carrier).  in_bits: the reader's float input
+ * (the 16 RN16 bits when the state is SEND_ACK), n_in its item count.  *n_written = floats written to out
+ * (what general_work returns); RFID_ERR_CAPACITY (state untouched) when out_cap is too small --
+ * rfid_reader_tx_max(dac_rate) floats always suffice. */
+RFID_API int rfid_reader_work_tx(rfid_ctx *ctx, int dac_rate, const float *in_bits, int n_in, float *out, int out_cap,
+                                 int *n_consumed, int *n_written);
+RFID_API int rfid_reader_tx_max(int dac_rate);
 RFID_API int rfid_get_state(const rfid_ctx *ctx, rfid_reader_state *out);
 /* reader_impl::print_results text (lib/reader_impl.cc:173-192) */
 RFID_API int rfid_print_results(const rfid_ctx *ctx, char *buf, int cap, int *len);

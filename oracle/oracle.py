@@ -38,6 +38,11 @@ class ReaderState(C.Structure):
     ]
 
 
+class ReaderTx(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("n_data0", "n_data1", "n_pw", "n_cw", "n_delim", "n_trcal", "n_cwquery",
+                                       "n_cwack", "n_pdown", "fixed_q")] + [("query_bits", C.c_float * 22)]
+
+
 class Cf(C.Structure):
     _fields_ = [("re", C.c_float), ("im", C.c_float)]
 
@@ -92,6 +97,10 @@ def lib() -> C.CDLL:
         L.orc_time_trace_mt.argtypes = [C.POINTER(Config), vp, C.c_long, C.c_int, C.c_int, C.POINTER(C.c_double),
                                         C.POINTER(C.c_int)]
         L.orc_time_trace_mt.restype = C.c_long
+        L.orc_reader_tx_init.argtypes = [C.POINTER(ReaderTx), C.c_int, C.c_int]
+        L.orc_reader_work_tx.argtypes = [C.POINTER(ReaderTx), C.POINTER(ReaderState), vp, C.c_int, vp]
+        L.orc_reader_work_tx.restype = C.c_int
+        L.orc_initialize_reader_state.argtypes = [C.POINTER(ReaderState), C.POINTER(Config)]
         L.orc_print_results.argtypes = [C.POINTER(ReaderState), C.c_char_p, C.c_int]
         L.orc_print_results.restype = C.c_int
         L.orc_check_crc.argtypes = [C.c_char_p, C.c_int]
@@ -178,3 +187,21 @@ def time_trace_mt(raw: np.ndarray, reps: int, nthreads: int, cfg: Optional[Confi
     cfg = cfg or config()
     nw = lib().orc_time_trace_mt(C.byref(cfg), raw.ctypes.data, len(raw), reps, nthreads, C.byref(wall), C.byref(nepc))
     return dict(wall_s=wall.value, windows=nw, n_epc_correct=nepc.value, threads=nthreads, reps=reps)
+
+
+class ReaderTxSim:
+    """reader_impl::general_work incl. the TX waveform (orc_reader_work_tx), stepping a READER_STATE."""
+
+    def __init__(self, dac_rate: int = 1000000, cfg: Optional[Config] = None):
+        self.cfg = cfg or config()
+        self.tx = ReaderTx()
+        lib().orc_reader_tx_init(C.byref(self.tx), int(dac_rate), int(self.cfg.fixed_q))
+        self.state = ReaderState()
+        lib().orc_initialize_reader_state(C.byref(self.state), C.byref(self.cfg))
+
+    def work(self, in_bits=None) -> np.ndarray:
+        bits = np.ascontiguousarray(in_bits if in_bits is not None else [], dtype=np.float32)
+        out = np.zeros(16384, dtype=np.float32)
+        n = lib().orc_reader_work_tx(C.byref(self.tx), C.byref(self.state), bits.ctypes.data if len(bits) else None,
+                                     len(bits), out.ctypes.data)
+        return out[:n].copy()

@@ -440,6 +440,106 @@ void orc_reader_work(orc_reader_state *rs, int ninput_items) {
   }
 }
 
+/* ---- reader TX waveform -------------------------------------------------------------------------
+ * Durations in us (include/rfid/global_vars.h:87-96): CW_D 250, P_DOWN_D 2000, T1_D 240, T2_D 480, PW_D 12,
+ * DELIM_D 12, TRCAL_D 200; RN16_D = (17+6)*25 = 575, EPC_D = (129+6)*25 = 3375 (:107-109). */
+void orc_reader_tx_init(orc_reader_tx *t, int dac_rate, int fixed_q) {
+  const float sample_d = (float)(1.0 / dac_rate * pow(10, 6));            /* reader_impl.cc:51 */
+  t->n_data0 = (int)(2 * 12 / sample_d);                                   /* :55-60, float -> size on resize() */
+  t->n_data1 = (int)(4 * 12 / sample_d);
+  t->n_pw = (int)(12 / sample_d);
+  t->n_cw = (int)(250 / sample_d);
+  t->n_delim = (int)(12 / sample_d);
+  t->n_trcal = (int)(200 / sample_d);
+  t->n_cwquery = (int)((240 + 480 + 575) / sample_d);                      /* :69 */
+  t->n_cwack = (int)((3 * 240 + 480 + 3375) / sample_d);                   /* :70 */
+  t->n_pdown = (int)(2000 / sample_d);                                     /* :71 */
+  t->fixed_q = fixed_q;
+  /* gen_query_bits :131-146: 1000 | DR 0 | M 00 | TRext 0 | Sel 00 | Session 00 | Target 0 | Q(4) | CRC-5 */
+  float *q = t->query_bits;
+  int n = 0;
+  q[n++] = 1; q[n++] = 0; q[n++] = 0; q[n++] = 0;
+  for (int i = 0; i < 9; i++) q[n++] = 0;
+  for (int i = 3; i >= 0; i--) q[n++] = (float)((fixed_q >> i) & 1);       /* Q_VALUE[FIXED_Q], global_vars.h:79-85 */
+  /* crc_append :383-443: 5-bit register preset 01001 (crc[4]..crc[0]), feedback = crc[4] xor bit into
+   * positions 0 and 3, appended crc[4] first */
+  int crc[5] = {1, 0, 0, 1, 0};
+  for (int i = 0; i < 17; i++) {
+    const int f = crc[4] ^ (q[i] == 1.0f);
+    const int t4 = crc[3], t3 = crc[2] ^ f, t2 = crc[1], t1 = crc[0], t0 = f;
+    crc[0] = t0; crc[1] = t1; crc[2] = t2; crc[3] = t3; crc[4] = t4;
+  }
+  for (int i = 4; i >= 0; i--) q[n++] = (float)crc[i];
+}
+
+static int tx_fill(float *out, int w, float v, int n) { for (int i = 0; i < n; i++) out[w + i] = v; return w + n; }
+static int tx_data0(const orc_reader_tx *t, float *out, int w) {            /* half high, half low :89 */
+  w = tx_fill(out, w, 1.0f, t->n_data0 / 2); return tx_fill(out, w, 0.0f, t->n_data0 - t->n_data0 / 2);
+}
+static int tx_data1(const orc_reader_tx *t, float *out, int w) {            /* 3/4 high :90 */
+  w = tx_fill(out, w, 1.0f, 3 * t->n_data1 / 4); return tx_fill(out, w, 0.0f, t->n_data1 - 3 * t->n_data1 / 4);
+}
+static int tx_frame_sync(const orc_reader_tx *t, float *out, int w) {       /* delim, data_0, rtcal :101-104 */
+  w = tx_fill(out, w, 0.0f, t->n_delim);
+  w = tx_data0(t, out, w);
+  const int n_rtcal = t->n_data0 + t->n_data1;                              /* :84,92 */
+  w = tx_fill(out, w, 1.0f, n_rtcal - t->n_pw);
+  return tx_fill(out, w, 0.0f, t->n_pw);
+}
+static int tx_bits(const orc_reader_tx *t, float *out, int w, const float *bits, int n) {
+  for (int i = 0; i < n; i++) w = (bits[i] == 1.0f) ? tx_data1(t, out, w) : tx_data0(t, out, w);
+  return w;
+}
+
+int orc_reader_work_tx(const orc_reader_tx *t, orc_reader_state *rs, const float *in, int ninput_items, float *out) {
+  int w = 0;
+  switch (rs->gen2_logic_status) {
+    case ORC_START: w = tx_fill(out, w, 1.0f, t->n_cwack); break;                       /* :218-224 */
+    case ORC_POWER_DOWN: w = tx_fill(out, w, 0.0f, t->n_pdown); break;                  /* :226-231 */
+    case ORC_SEND_NAK_QR:
+    case ORC_SEND_NAK_Q: {                                                              /* :233-249; nak :114-123 */
+      const float nak_bits[8] = {1, 1, 0, 0, 0, 0, 0, 0};
+      w = tx_frame_sync(t, out, w);
+      w = tx_bits(t, out, w, nak_bits, 8);
+      w = tx_fill(out, w, 1.0f, t->n_cw);
+      break;
+    }
+    case ORC_SEND_QUERY:                                                                /* :251-288 */
+      w = tx_frame_sync(t, out, w);                                                     /* preamble = frame_sync + trcal :95-99 */
+      w = tx_fill(out, w, 1.0f, t->n_trcal - t->n_pw);
+      w = tx_fill(out, w, 0.0f, t->n_pw);
+      w = tx_bits(t, out, w, t->query_bits, 22);
+      w = tx_fill(out, w, 1.0f, t->n_cwquery);
+      break;
+    case ORC_SEND_ACK:                                                                  /* :290-320 */
+      if (ninput_items == RN16_BITS - 1) {
+        const float ack_code[2] = {0, 1};
+        w = tx_frame_sync(t, out, w);
+        w = tx_bits(t, out, w, ack_code, 2);
+        w = tx_bits(t, out, w, in, 16);
+      }
+      break;
+    case ORC_SEND_CW: w = tx_fill(out, w, 1.0f, t->n_cwack); break;                     /* :322-327 */
+    case ORC_SEND_QUERY_REP: {                                                          /* :329-344; query_rep :106-111 */
+      const float z4[4] = {0, 0, 0, 0};
+      w = tx_frame_sync(t, out, w);
+      w = tx_bits(t, out, w, z4, 4);
+      w = tx_fill(out, w, 1.0f, t->n_cwquery);
+      break;
+    }
+    case ORC_SEND_QUERY_ADJUST: {                                                       /* :346-372; bits :155-161 */
+      const float qa[9] = {1, 0, 0, 1, 0, 0, 0, 0, 0};                                  /* QADJ_CODE, SESSION, Q_UPDN[1] */
+      w = tx_frame_sync(t, out, w);
+      w = tx_bits(t, out, w, qa, 9);
+      w = tx_fill(out, w, 1.0f, t->n_cwquery);
+      break;
+    }
+    default: break;
+  }
+  orc_reader_work(rs, ninput_items);
+  return w;
+}
+
 /* ---- reader_impl::print_results, lib/reader_impl.cc:173-192 ------------------------ */
 int orc_print_results(const orc_reader_state *rs, char *buf, int cap) {
   int n = 0;

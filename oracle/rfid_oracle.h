@@ -155,6 +155,19 @@ long orc_run_decimated(const orc_config *cfg, const orc_cf *y, long n_dec, int c
  * separately over the trace and returns seconds spent in each (steady clock). */
 long orc_time_trace(const orc_config *cfg, const orc_cf *raw, long n_raw, int reps,
                     double secs[3], orc_reader_state *rs_out);
+/* ---- reader TX waveform: reader_impl ctor tables + general_work output ----------
+ * lib/reader_impl.cc:43-129 (tables), :131-162 (command bits), :200-380 (what each state emits), :383-443 (CRC-5) */
+#define ORC_TX_MAX 16384
+typedef struct {
+  int n_data0, n_data1, n_pw, n_cw, n_delim, n_trcal, n_cwquery, n_cwack, n_pdown;
+  int fixed_q;
+  float query_bits[22];
+} orc_reader_tx;
+void orc_reader_tx_init(orc_reader_tx *t, int dac_rate, int fixed_q);
+/* orc_reader_work + the samples reader_impl::general_work writes for the state it was in; returns the
+ * number of floats written to out (capacity ORC_TX_MAX) */
+int orc_reader_work_tx(const orc_reader_tx *t, orc_reader_state *rs, const float *in, int ninput_items, float *out);
+
 /* the same on `nthreads` host threads at once (independent copies); *wall_s = wall time */
 long orc_time_trace_mt(const orc_config *cfg, const orc_cf *raw, long n_raw, int reps, int nthreads,
                        double *wall_s, int *n_epc_out);

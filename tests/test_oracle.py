@@ -115,3 +115,40 @@ def test_multi_thread_timing_leg_decodes_the_same(oracle_mod, synth_mod):
     many = oracle_mod.time_trace_mt(t, reps=2, nthreads=3)
     assert many["windows"] == one["windows"] and many["n_epc_correct"] == one["n_epc_correct"]
     assert many["wall_s"] > 0.0
+
+
+def test_reader_tx_waveforms_match_the_trace_generator(oracle_mod, synth_mod):
+    """orc_reader_work_tx (restating reader_impl.cc:43-129,200-380,383-443) against rfid/synth.py, which was
+    written separately to build the test traces: START carrier, Query (preamble + 22 PIE bits incl. CRC-5 for
+    every Q) + 1295 us CW, ACK (frame sync + 01 + RN16), the 4575 us CW after it, QueryRep."""
+    for q in range(16):
+        sim = oracle_mod.ReaderTxSim(cfg=oracle_mod.config(fixed_q=q))
+        assert sim.state.gen2_logic_status == 5                                   # START
+        w = sim.work()
+        assert len(w) == synth_mod.CW_ACK and (w == 1).all()                      # :218-224
+        w = sim.work()                                                            # SEND_QUERY
+        want = np.concatenate([synth_mod.query_cmd(q), np.ones(synth_mod.CW_QUERY, np.float32)])
+        assert np.array_equal(w, want), q
+        assert sim.state.gen2_logic_status == 3 and sim.state.n_queries_sent == 1  # IDLE
+    sim = oracle_mod.ReaderTxSim()
+    sim.work(); sim.work()
+    assert len(sim.work()) == 0                                                   # IDLE writes nothing
+    rn16 = [1, 0, 1, 1, 0, 0, 1, 0, 1, 1, 1, 0, 0, 1, 0, 1]
+    sim.state.gen2_logic_status = 1                                               # SEND_ACK (set by the decoder)
+    assert len(sim.work(rn16[:5])) == 0 and sim.state.gen2_logic_status == 1      # needs exactly 16 items (:293)
+    w = sim.work(rn16)
+    assert np.array_equal(w, synth_mod.ack_cmd(rn16)) and sim.state.gen2_logic_status == 4   # SEND_CW
+    w = sim.work()
+    assert len(w) == synth_mod.CW_ACK and (w == 1).all() and sim.state.gen2_logic_status == 3
+    sim.state.gen2_logic_status = 2                                               # SEND_QUERY_REP
+    w = sim.work()
+    assert np.array_equal(w, np.concatenate([synth_mod.query_rep_cmd(), np.ones(synth_mod.CW_QUERY, np.float32)]))
+    assert sim.state.n_queries_sent == 2
+    sim.state.gen2_logic_status = 7                                               # SEND_NAK_QR -> QueryRep next
+    w = sim.work()
+    nak = np.concatenate([synth_mod._FRAME_SYNC, synth_mod.pie([1, 1, 0, 0, 0, 0, 0, 0]), np.ones(250, np.float32)])
+    assert np.array_equal(w, nak) and sim.state.gen2_logic_status == 2
+    # a 2 MHz DAC doubles every duration
+    sim2 = oracle_mod.ReaderTxSim(dac_rate=2000000)
+    assert len(sim2.work()) == 2 * synth_mod.CW_ACK
+    assert np.array_equal(sim2.work(), np.repeat(np.concatenate([synth_mod.query_cmd(0), np.ones(synth_mod.CW_QUERY, np.float32)]), 2))
