@@ -84,8 +84,13 @@ class reader(_Block):
         return 0                      # reader_impl.cc:194-198
 
     def general_work(self, n_in: int) -> int:
-        """State transitions of reader_impl::general_work; TX waveform synthesis is out of scope."""
+        """The state transitions of reader_impl::general_work alone -> consumed."""
         return self.ctx.reader_work(n_in)
+
+    def general_work_tx(self, in_bits=None):
+        """reader_impl::general_work complete: transitions + the transmit waveform written to the block's
+        output (float32 samples at dac_rate) -> (consumed, samples)."""
+        return self.ctx.reader_work_tx(in_bits, dac_rate=self.dac_rate)
 
     def print_results(self) -> None:
         print(self.ctx.print_results(), end="")
