@@ -297,6 +297,21 @@ def test_reader_tx_waveform_matches_oracle(oracle_mod, synth_mod):
         tb.ctx.close()
 
 
+def test_reader_tx_capacity_error_leaves_state_untouched(gpu_ctx):
+    import ctypes as C
+    import rfid
+    lib = rfid.capi.load()
+    assert lib.rfid_reader_tx_max(1000000) >= 4575 and lib.rfid_reader_tx_max(2000000) >= 9150
+    gpu_ctx.reset()
+    before = gpu_ctx.state().gen2_logic_status
+    out = np.zeros(100, dtype=np.float32)
+    cons, wr = C.c_int(0), C.c_int(0)
+    st = lib.rfid_reader_work_tx(gpu_ctx._h, 1000000, None, 0, out.ctypes.data, len(out), C.byref(cons), C.byref(wr))
+    assert st == rfid.capi.ERR_CAPACITY and gpu_ctx.state().gen2_logic_status == before
+    cons2, w = gpu_ctx.reader_work_tx()
+    assert len(w) == 4575 and gpu_ctx.state().gen2_logic_status == rfid.capi.SEND_QUERY
+
+
 def test_cxx_offline_binary_writes_the_reader_tx_stream(tmp_path, oracle_mod, synth_mod):
     """rfid_reader_offline --tx-out: the reader block's float output over a whole run (what apps/reader.py's
     DEBUG file sink records) = START carrier, then per slot Query|QueryRep + 1295 us CW, ACK + 4575 us CW,
