@@ -264,6 +264,39 @@ def test_full_size_properties_idempotence_and_scaling(gpu_ctx, synth_mod):
     assert np.array_equal(s4["corr"], s1["corr"] * np.float32(16)) and np.array_equal(s4["energy"], s1["energy"] * np.float32(16))
 
 
+def test_randomized_batches_match_oracle(oracle_mod, synth_mod):
+    """Randomised sweep: 3 x 64 traces with random tag sets (FIXED_Q 0, 1, 3: empty and collided slots), round
+    counts, noise levels up to the decode limit, T1 jitter and truncation points, decoded as ragged batches.
+    Every window, decision, score and counter bit-identical to the oracle."""
+    import torch
+    import rfid
+    rng = np.random.default_rng(2026)
+    total = 0
+    for q in (0, 1, 3):
+        ctx = rfid.Context(device=0, fixed_q=q)
+        try:
+            traces = []
+            for _ in range(64):
+                ntags = 1 if q == 0 else int(rng.integers(1, 5))
+                ids = tuple(int(x) for x in rng.choice(256, size=ntags, replace=False))
+                t = synth_mod.make_trace(n_rounds=int(rng.integers(1, 4)), fixed_q=q, tag_ids=ids,
+                                         seed=int(rng.integers(1 << 30)), sigma=float(rng.uniform(0, 0.08)),
+                                         t1_jitter_raw=int(rng.integers(0, 12))).samples
+                cut = int(rng.integers(0, 4000)) if rng.random() < 0.3 else 0
+                traces.append(t[: len(t) - cut])
+            L = max(map(len, traces))
+            raw = np.zeros((len(traces), L), dtype=np.complex64)
+            for i, t in enumerate(traces):
+                raw[i, : len(t)] = t
+            w, r, s, st = _run_batch(ctx, raw, lens=[len(t) for t in traces])
+            for b, (wb, rb, sb) in enumerate(parity.split_by_stream(w, r, s, len(traces))):
+                parity.compare_trace(wb, rb, sb, st[b], oracle_mod.run_trace(traces[b], oracle_mod.config(fixed_q=q)))
+                total += len(wb)
+        finally:
+            ctx.close()
+    assert total > 2000
+
+
 def test_reader_tx_waveform_matches_oracle(oracle_mod, synth_mod):
     """rfid_reader_work_tx (the complete reader block: transitions + transmit waveform, reader_impl.cc:43-380)
     against the oracle's restatement, state by state, for several Q values and both DAC rates."""
