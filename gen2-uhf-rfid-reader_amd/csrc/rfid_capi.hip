@@ -46,11 +46,15 @@ struct rfid_ctx {
   int *d_scount = nullptr;
   rfid_decode_result *d_sres = nullptr;
   rfid_scores *d_sscores = nullptr;
-  rfid_cf32 mf_hist[NTAPS - 1];
+  // last MF_HIST raw samples seen: the 24-sample filter history plus the up to 4 samples that wait for
+  // their decimation group of 5 to complete
+  static const int MF_HIST = NTAPS - 1 + DECIM - 1;
+  rfid_cf32 mf_hist[MF_HIST];
   int64_t mf_seen = 0;
 
   // ---- batch plan ----
-  int B = 0;
+  int B = 0;        // traces the next pass processes (rfid_batch_set_streams), <= B_plan
+  int B_plan = 0;   // traces the workspace was planned for; 0 = no plan
   int64_t max_raw = 0, y_stride = 0;
   float2 *d_y = nullptr;
   GateState *d_gstate = nullptr;
@@ -141,6 +145,7 @@ void free_plan(rfid_ctx *c) {
   c->d_wcount = nullptr; c->d_flat_count = nullptr; c->d_res = nullptr; c->d_scores = nullptr;
   c->d_stats = nullptr;
   c->B = 0;
+  c->B_plan = 0;
 }
 
 // slot/round roll-over of tag_decoder_impl.cc:330-343 / :369-383 (and :269-288)
@@ -370,24 +375,42 @@ int rfid_batch_plan(rfid_ctx *c, int n_streams, int64_t max_raw) {
   if (wmax * n_streams > 0x7fffffffLL) return RFID_ERR_UNSUPPORTED;
   c->wmax = (int)wmax;
   c->flat_cap = (int)(wmax * n_streams);
-  c->B = n_streams;
   c->max_raw = max_raw;
-  HIPCHK(c, hipMalloc((void **)&c->d_y, sizeof(float2) * (size_t)c->y_stride * n_streams));
-  HIPCHK(c, hipMalloc((void **)&c->d_gstate, sizeof(GateState) * (size_t)n_streams));
-  HIPCHK(c, hipMalloc((void **)&c->d_wtab, sizeof(rfid_window) * (size_t)c->flat_cap));
-  HIPCHK(c, hipMalloc((void **)&c->d_flat, sizeof(rfid_window) * 2 * (size_t)c->flat_cap));
-  HIPCHK(c, hipMalloc((void **)&c->d_wcount, sizeof(int) * (size_t)n_streams));
-  HIPCHK(c, hipMalloc((void **)&c->d_flat_count, 2 * sizeof(int)));
-  HIPCHK(c, hipMalloc((void **)&c->d_res, sizeof(rfid_decode_result) * (size_t)c->flat_cap));
-  HIPCHK(c, hipMalloc((void **)&c->d_scores, sizeof(rfid_scores) * (size_t)c->flat_cap));
-  HIPCHK(c, hipMalloc((void **)&c->d_stats, sizeof(rfid_stream_stats) * (size_t)n_streams));
-  HIPCHK(c, hipMemset(c->d_wcount, 0, sizeof(int) * (size_t)n_streams));
-  HIPCHK(c, hipMemset(c->d_flat_count, 0, 2 * sizeof(int)));
+  // B (= "a plan exists") is set only after every allocation succeeded: a failed plan leaves the
+  // context unplanned (free_plan), so later rfid_batch_* calls return RFID_ERR_STATE instead of
+  // launching on null workspace pointers
+  hipError_t e = hipSuccess;
+  auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 1); };
+  alloc((void **)&c->d_y, sizeof(float2) * (size_t)c->y_stride * n_streams);
+  alloc((void **)&c->d_gstate, sizeof(GateState) * (size_t)n_streams);
+  alloc((void **)&c->d_wtab, sizeof(rfid_window) * (size_t)c->flat_cap);
+  alloc((void **)&c->d_flat, sizeof(rfid_window) * 2 * (size_t)c->flat_cap);
+  alloc((void **)&c->d_wcount, sizeof(int) * (size_t)n_streams);
+  alloc((void **)&c->d_flat_count, 2 * sizeof(int));
+  alloc((void **)&c->d_res, sizeof(rfid_decode_result) * (size_t)c->flat_cap);
+  alloc((void **)&c->d_scores, sizeof(rfid_scores) * (size_t)c->flat_cap);
+  alloc((void **)&c->d_stats, sizeof(rfid_stream_stats) * (size_t)n_streams);
+  if (e == hipSuccess) e = hipMemset(c->d_wcount, 0, sizeof(int) * (size_t)n_streams);
+  if (e == hipSuccess) e = hipMemset(c->d_flat_count, 0, 2 * sizeof(int));
+  if (e != hipSuccess) {
+    (void)hipGetLastError();   // clear the sticky allocation error
+    free_plan(c);
+    return fail(c, RFID_ERR_HIP, "rfid_batch_plan: workspace allocation", e);
+  }
+  c->B = c->B_plan = n_streams;
   hipDeviceProp_t prop;
   HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
   // persistent decoders: the EPC kernel holds 18.6 KiB of LDS per single-wave workgroup -> 8 per CU
   c->decode_grid = prop.multiProcessorCount * 8;
   for (int i = 0; i < 5; ++i) c->ev_valid[i] = false;
+  return RFID_OK;
+}
+
+int rfid_batch_set_streams(rfid_ctx *c, int n_streams) {
+  if (!c || n_streams <= 0) return RFID_ERR_INVALID;
+  if (!c->B_plan) return RFID_ERR_STATE;
+  if (n_streams > c->B_plan) return RFID_ERR_CAPACITY;
+  c->B = n_streams;
   return RFID_OK;
 }
 
@@ -402,15 +425,19 @@ int rfid_batch_mf(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64_t n_
   a.x = (const float2 *)d_raw; a.x_stride = raw_stride; a.n_raw = n_raw; a.lens = c->d_lens;
   a.n_out = n_raw / DECIM; a.in_off = -(NTAPS - 1);
   a.vec_ok = ((raw_stride & 1) == 0 && (((uintptr_t)d_raw) & 15) == 0) ? 1 : 0;
-  a.y = c->d_y; a.y_stride = c->y_stride; a.tile0 = 0;
+  a.y = c->d_y; a.y_stride = c->y_stride; a.tile0 = 0; a.stream0 = 0;
   c->n_chunks_last = 0;
   c->fused_last = 0;
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   const int64_t tiles = (a.n_out + MF_TILE - 1) / MF_TILE;
   if (tiles > 0) {
-    hipLaunchKernelGGL(mf_boxcar25_decim5_kernel, dim3((unsigned)tiles, (unsigned)c->B), dim3(MF_THREADS), 0,
-                       c->stream, a);
-    HIPCHK(c, hipGetLastError());
+    for (int s0 = 0; s0 < c->B; s0 += 65535) {   // gridDim.y limit
+      a.stream0 = s0;
+      const int ns = (c->B - s0 < 65535) ? (c->B - s0) : 65535;
+      hipLaunchKernelGGL(mf_boxcar25_decim5_kernel, dim3((unsigned)tiles, (unsigned)ns), dim3(MF_THREADS), 0,
+                         c->stream, a);
+      HIPCHK(c, hipGetLastError());
+    }
   }
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   c->ev_valid[0] = c->ev_valid[1] = true;
@@ -581,7 +608,7 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
   m.x = (const float2 *)d_raw; m.x_stride = raw_stride; m.n_raw = n_raw; m.lens = c->d_lens;
   m.n_out = n_out; m.in_off = -(NTAPS - 1);
   m.vec_ok = ((raw_stride & 1) == 0 && (((uintptr_t)d_raw) & 15) == 0) ? 1 : 0;
-  m.y = c->d_y; m.y_stride = c->y_stride;
+  m.y = c->d_y; m.y_stride = c->y_stride; m.stream0 = 0;
   GateArgs g = {};
   g.y = c->d_y; g.y_stride = c->y_stride; g.n_dec = n_out; g.lens = c->d_lens;
   g.state = c->d_gstate; g.n_streams = c->B; g.wtab = c->d_wtab; g.wmax = c->wmax; g.wcount = c->d_wcount;
@@ -595,8 +622,12 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
     if (t0 >= tiles) break;
     const int64_t tn = (t0 + tiles_per_chunk <= tiles) ? tiles_per_chunk : (tiles - t0);
     m.tile0 = t0;
-    hipLaunchKernelGGL(mf_boxcar25_decim5_kernel, dim3((unsigned)tn, (unsigned)c->B), dim3(MF_THREADS), 0, c->stream, m);
-    HIPCHK(c, hipGetLastError());
+    for (int s0 = 0; s0 < c->B; s0 += 65535) {   // gridDim.y limit
+      m.stream0 = s0;
+      const int ns = (c->B - s0 < 65535) ? (c->B - s0) : 65535;
+      hipLaunchKernelGGL(mf_boxcar25_decim5_kernel, dim3((unsigned)tn, (unsigned)ns), dim3(MF_THREADS), 0, c->stream, m);
+      HIPCHK(c, hipGetLastError());
+    }
     HIPCHK(c, hipEventRecord(c->ev_mf[k + 1], c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_mf[k + 1], 0));
     g.pos0 = t0 * MF_TILE; g.chunk_len = tn * MF_TILE;
@@ -766,9 +797,14 @@ int rfid_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int
   *n_produced = 0;
   if (n_in == 0) return RFID_OK;
   HIPCHK(c, hipSetDevice(c->device));
-  const int H = NTAPS - 1;
-  const int off = (int)((DECIM - (c->mf_seen % DECIM)) % DECIM);  // raw samples until the next output
-  const int n_out = (n_in > off) ? ((n_in - 1 - off) / DECIM + 1) : 0;
+  // A decimating GNU Radio block produces output n once the whole group x[5n .. 5n+4] has arrived
+  // (sync_decimator: noutput = ninput / decim), although y[n] only needs x[5n-24 .. 5n]: a stream of
+  // N samples yields floor(N/5) outputs, the same as rfid_batch_mf / the fused front end.
+  const int H = rfid_ctx::MF_HIST;
+  const int64_t n_first = c->mf_seen / DECIM;                       // first output not yet produced
+  const int n_out = (int)((c->mf_seen + n_in) / DECIM - n_first);
+  // staging[0] is raw sample mf_seen - H; y[n_first] starts at raw 5 n_first - 24
+  const int off = (int)(DECIM * n_first - (NTAPS - 1) - (c->mf_seen - H));   // 0..4
   if (n_out > out_cap || (n_out > 0 && !out)) return RFID_ERR_CAPACITY;
   if (n_out > 0) {
     int rc = grow(c, c->s_in, sizeof(float2) * (size_t)(H + n_in + 2));
@@ -780,14 +816,14 @@ int rfid_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int
     MfArgs a;
     a.x = (const float2 *)c->s_in.p; a.x_stride = H + n_in; a.n_raw = H + n_in; a.lens = nullptr;
     a.n_out = n_out; a.in_off = off; a.vec_ok = (off % 2 == 0) ? 1 : 0;
-    a.y = (float2 *)c->s_out.p; a.y_stride = n_out; a.tile0 = 0;
+    a.y = (float2 *)c->s_out.p; a.y_stride = n_out; a.tile0 = 0; a.stream0 = 0;
     const int tiles = (n_out + MF_TILE - 1) / MF_TILE;
     hipLaunchKernelGGL(mf_boxcar25_decim5_kernel, dim3((unsigned)tiles, 1), dim3(MF_THREADS), 0, c->stream, a);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out, c->s_out.p, sizeof(rfid_cf32) * (size_t)n_out, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
-  // roll the 24-sample history
+  // roll the history
   if (n_in >= H) {
     memcpy(c->mf_hist, in + n_in - H, sizeof(rfid_cf32) * H);
   } else {

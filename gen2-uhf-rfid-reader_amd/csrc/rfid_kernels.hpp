@@ -58,13 +58,14 @@ struct MfArgs {
   float2 *y;            // [n_streams][y_stride]
   int64_t y_stride;
   int64_t tile0;        // first output tile of this launch (time-chunked launches)
+  int stream0;          // first trace of this launch (gridDim.y <= 65535 traces per launch)
 };
 
 RFID_KERNEL(MF_THREADS) void mf_boxcar25_decim5_kernel(MfArgs a) {
   RFID_SHARED float4 tile4[MF_RAW / 2 + 2];
   float2 *tile = reinterpret_cast<float2 *>(tile4);
   const int tid = (int)threadIdx.x;
-  const int b = (int)blockIdx.y;
+  const int b = (int)blockIdx.y + a.stream0;
   int64_t n_raw = a.n_raw, n_out = a.n_out;
   if (a.lens) {
     n_raw = a.lens[b];

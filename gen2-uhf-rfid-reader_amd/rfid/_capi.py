@@ -85,6 +85,7 @@ SIGNATURES = {
     "rfid_get_state": (_i, [_vp, C.POINTER(ReaderState)]),
     "rfid_print_results": (_i, [_vp, C.c_char_p, _i, _ip]),
     "rfid_batch_plan": (_i, [_vp, _i, _i64]),
+    "rfid_batch_set_streams": (_i, [_vp, _i]),
     "rfid_batch_mf": (_i, [_vp, _vp, _i64, _i64, _vp]),
     "rfid_batch_gate": (_i, [_vp]),
     "rfid_batch_decode": (_i, [_vp, _i]),

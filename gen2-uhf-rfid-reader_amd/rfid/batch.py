@@ -47,8 +47,10 @@ class BatchDecoder:
         torch = self._torch
         stride = (max_len + 1) & ~1
         if self._planned[0] < n_traces or self._planned[1] < max_len:
-            self.ctx.batch_plan(n_traces, max_len)
-            self._planned = (n_traces, max_len)
+            self.ctx.batch_plan(max(n_traces, self._planned[0]), max(max_len, self._planned[1]))
+            self._planned = (max(n_traces, self._planned[0]), max(max_len, self._planned[1]))
+        # the plan may be larger than this batch (decoder reuse): process exactly n_traces rows
+        self.ctx.batch_set_streams(n_traces)
         need = n_traces * stride * 2
         if self._dev is None or self._dev.numel() < need:
             self._dev = torch.empty(need, dtype=torch.float32, device=f"cuda:{self.device}")

@@ -129,6 +129,12 @@ class Context:
     def batch_plan(self, n_streams: int, max_raw: int) -> None:
         self._chk(self._lib.rfid_batch_plan(self._h, int(n_streams), int(max_raw)))
         self._planned = (int(n_streams), int(max_raw))
+        self._active = int(n_streams)
+
+    def batch_set_streams(self, n_streams: int) -> None:
+        """Process only the first n_streams (<= planned) rows in the following passes."""
+        self._chk(self._lib.rfid_batch_set_streams(self._h, int(n_streams)))
+        self._active = int(n_streams)
 
     def batch_process_ptr(self, d_raw: int, raw_stride: int, n_raw: int, d_lens: int = 0,
                           want_scores: bool = False) -> None:
@@ -159,7 +165,7 @@ class Context:
                     decode_launches=t.decode_launches, fused_front=t.fused_front)
 
     def batch_stats(self) -> np.ndarray:
-        n = self._planned[0]
+        n = self._active
         out = np.zeros(n, dtype=capi.STATS_DTYPE)
         self._chk(self._lib.rfid_batch_get_stats(self._h, out.ctypes.data, n))
         return out

@@ -150,9 +150,11 @@ RFID_API const char *rfid_version(void);
 RFID_API int rfid_selftest(rfid_ctx *ctx, int *n_failed);
 
 /* ---- (1) streaming, host buffers: one call per reference work() ----------------------- */
-/* fir_filter_ccc(5,[1]*25): consumes all n_in samples, keeps the 24-sample history and the
- * decimation phase inside ctx, writes floor-ish n_in/5 outputs (exactly the outputs whose
- * window ends inside this call).  y[n] = sum_{k=0..24} x[5n-24+k], k ascending. */
+/* fir_filter_ccc(5,[1]*25): consumes all n_in samples, keeps the filter history and the decimation
+ * phase inside ctx.  y[n] = sum_{k=0..24} x[5n-24+k], k ascending; output n is written by the call
+ * that completes its decimation group x[5n .. 5n+4] (GNU Radio's sync_decimator: noutput =
+ * ninput / decim), so a stream of N samples yields floor(N/5) outputs whatever the call sizes --
+ * the same outputs as rfid_batch_mf / rfid_batch_process on the same samples. */
 RFID_API int rfid_mf_work(rfid_ctx *ctx, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap,
                           int *n_produced);
 /* gate_impl::general_work: scans in[0..n_in), writes gated, DC-removed samples to out and
@@ -186,8 +188,14 @@ RFID_API int rfid_print_results(const rfid_ctx *ctx, char *buf, int cap, int *le
 
 /* ---- (2) batched offline, device buffers ---------------------------------------------- */
 /* Plans workspace for n_streams traces of up to max_raw samples each (2 Msps domain).
- * Allocates, in HBM: matched-filter output [n_streams][max_raw/5], window tables, results. */
+ * Allocates, in HBM: matched-filter output [n_streams][max_raw/5], window tables, results.
+ * On failure (e.g. RFID_ERR_HIP: out of memory) the context is left WITHOUT a plan: every later
+ * rfid_batch_* call returns RFID_ERR_STATE until a plan succeeds. */
 RFID_API int rfid_batch_plan(rfid_ctx *ctx, int n_streams, int64_t max_raw);
+/* Number of traces (rows of d_raw, entries of d_lens) the following rfid_batch_* calls process:
+ * 1 <= n_streams <= the planned count (rfid_batch_plan sets it to the planned count).  Lets one plan
+ * serve batches of different sizes; results and statistics cover exactly these rows. */
+RFID_API int rfid_batch_set_streams(rfid_ctx *ctx, int n_streams);
 /* d_raw: device pointer to [n_streams][raw_stride] rfid_cf32; d_lens: device int64[n_streams]
  * valid sample counts per trace, or NULL when every trace has n_raw samples.  All launches
  * go to the ctx stream (a non-blocking stream of its own, see rfid_ctx_stream) and return without

@@ -40,7 +40,8 @@ class ReaderState(C.Structure):
 
 class ReaderTx(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("n_data0", "n_data1", "n_pw", "n_cw", "n_delim", "n_trcal", "n_cwquery",
-                                       "n_cwack", "n_pdown", "fixed_q")] + [("query_bits", C.c_float * 22)]
+                                       "n_cwack", "n_pdown", "fixed_q", "n_rtcal", "n_rtcal_hi", "n_trcal_hi")] + \
+               [("query_bits", C.c_float * 22)]
 
 
 class Cf(C.Structure):

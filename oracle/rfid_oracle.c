@@ -445,15 +445,21 @@ void orc_reader_work(orc_reader_state *rs, int ninput_items) {
  * DELIM_D 12, TRCAL_D 200; RN16_D = (17+6)*25 = 575, EPC_D = (129+6)*25 = 3375 (:107-109). */
 void orc_reader_tx_init(orc_reader_tx *t, int dac_rate, int fixed_q) {
   const float sample_d = (float)(1.0 / dac_rate * pow(10, 6));            /* reader_impl.cc:51 */
-  t->n_data0 = (int)(2 * 12 / sample_d);                                   /* :55-60, float -> size on resize() */
-  t->n_data1 = (int)(4 * 12 / sample_d);
-  t->n_pw = (int)(12 / sample_d);
-  t->n_cw = (int)(250 / sample_d);
-  t->n_delim = (int)(12 / sample_d);
-  t->n_trcal = (int)(200 / sample_d);
-  t->n_cwquery = (int)((240 + 480 + 575) / sample_d);                      /* :69 */
-  t->n_cwack = (int)((3 * 240 + 480 + 3375) / sample_d);                   /* :70 */
-  t->n_pdown = (int)(2000 / sample_d);                                     /* :71 */
+  /* float members (reader_impl.h:35); each use truncates where the reference does */
+  const float n_data0_s = 2 * 12 / sample_d, n_data1_s = 4 * 12 / sample_d, n_pw_s = 12 / sample_d;   /* :55-57 */
+  const float n_cw_s = 250 / sample_d, n_delim_s = 12 / sample_d, n_trcal_s = 200 / sample_d;          /* :58-60 */
+  t->n_data0 = (int)(size_t)n_data0_s;                                     /* data_0.resize(n_data0_s) :84 */
+  t->n_data1 = (int)(size_t)n_data1_s;
+  t->n_pw = (int)n_pw_s;
+  t->n_cw = (int)(size_t)n_cw_s;
+  t->n_delim = (int)(size_t)n_delim_s;
+  t->n_trcal = (int)(size_t)n_trcal_s;
+  t->n_rtcal = (int)(size_t)(n_data0_s + n_data1_s);                       /* rtcal.resize(n_data0_s + n_data1_s) :88 */
+  t->n_rtcal_hi = (int)(size_t)((float)(size_t)t->n_rtcal - n_pw_s);       /* fill_n(rtcal.size() - n_pw_s) :95 */
+  t->n_trcal_hi = (int)(size_t)((float)(size_t)t->n_trcal - n_pw_s);       /* :96 */
+  t->n_cwquery = (int)((240 + 480 + 575) / sample_d);                      /* int members :69-71 */
+  t->n_cwack = (int)((3 * 240 + 480 + 3375) / sample_d);
+  t->n_pdown = (int)(2000 / sample_d);
   t->fixed_q = fixed_q;
   /* gen_query_bits :131-146: 1000 | DR 0 | M 00 | TRext 0 | Sel 00 | Session 00 | Target 0 | Q(4) | CRC-5 */
   float *q = t->query_bits;
@@ -482,9 +488,8 @@ static int tx_data1(const orc_reader_tx *t, float *out, int w) {            /* 3
 static int tx_frame_sync(const orc_reader_tx *t, float *out, int w) {       /* delim, data_0, rtcal :101-104 */
   w = tx_fill(out, w, 0.0f, t->n_delim);
   w = tx_data0(t, out, w);
-  const int n_rtcal = t->n_data0 + t->n_data1;                              /* :84,92 */
-  w = tx_fill(out, w, 1.0f, n_rtcal - t->n_pw);
-  return tx_fill(out, w, 0.0f, t->n_pw);
+  w = tx_fill(out, w, 1.0f, t->n_rtcal_hi);                                 /* :88,95 */
+  return tx_fill(out, w, 0.0f, t->n_rtcal - t->n_rtcal_hi);
 }
 static int tx_bits(const orc_reader_tx *t, float *out, int w, const float *bits, int n) {
   for (int i = 0; i < n; i++) w = (bits[i] == 1.0f) ? tx_data1(t, out, w) : tx_data0(t, out, w);
@@ -506,8 +511,8 @@ int orc_reader_work_tx(const orc_reader_tx *t, orc_reader_state *rs, const float
     }
     case ORC_SEND_QUERY:                                                                /* :251-288 */
       w = tx_frame_sync(t, out, w);                                                     /* preamble = frame_sync + trcal :95-99 */
-      w = tx_fill(out, w, 1.0f, t->n_trcal - t->n_pw);
-      w = tx_fill(out, w, 0.0f, t->n_pw);
+      w = tx_fill(out, w, 1.0f, t->n_trcal_hi);
+      w = tx_fill(out, w, 0.0f, t->n_trcal - t->n_trcal_hi);
       w = tx_bits(t, out, w, t->query_bits, 22);
       w = tx_fill(out, w, 1.0f, t->n_cwquery);
       break;

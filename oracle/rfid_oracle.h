@@ -159,8 +159,11 @@ long orc_time_trace(const orc_config *cfg, const orc_cf *raw, long n_raw, int re
  * lib/reader_impl.cc:43-129 (tables), :131-162 (command bits), :200-380 (what each state emits), :383-443 (CRC-5) */
 #define ORC_TX_MAX 16384
 typedef struct {
+  /* vector sizes / fill counts as the reference's float members truncate them (reader_impl.h:34-35:
+   * n_data0_s ... n_trcal_s are float, n_cwquery_s / n_cwack_s / n_p_down_s int) */
   int n_data0, n_data1, n_pw, n_cw, n_delim, n_trcal, n_cwquery, n_cwack, n_pdown;
   int fixed_q;
+  int n_rtcal, n_rtcal_hi, n_trcal_hi;   /* rtcal.resize(n_data0_s + n_data1_s), fill_n(size() - n_pw_s) :84,92-93 */
   float query_bits[22];
 } orc_reader_tx;
 void orc_reader_tx_init(orc_reader_tx *t, int dac_rate, int fixed_q);

@@ -302,7 +302,7 @@ def test_reader_tx_waveform_matches_oracle(oracle_mod, synth_mod):
     against the oracle's restatement, state by state, for several Q values and both DAC rates."""
     import rfid
     rn16 = np.array([1, 0, 1, 1, 0, 0, 1, 0, 1, 1, 1, 0, 0, 1, 0, 1], dtype=np.float32)
-    for q, dac in ((0, 1000000), (4, 1000000), (15, 2000000)):
+    for q, dac in ((0, 1000000), (4, 1000000), (15, 2000000), (3, 800000)):   # 800 kHz: non-integer sample_d
         ctx = rfid.Context(device=0, fixed_q=q)
         sim = oracle_mod.ReaderTxSim(dac_rate=dac, cfg=oracle_mod.config(fixed_q=q))
         try:
@@ -317,7 +317,8 @@ def test_reader_tx_waveform_matches_oracle(oracle_mod, synth_mod):
                 return w
             assert len(both()) == 4575 * dac // 1000000          # START: carrier
             w = both()                                            # Query
-            assert np.array_equal(w[:: dac // 1000000][: len(synth_mod.query_cmd(q))], synth_mod.query_cmd(q))
+            if dac % 1000000 == 0:
+                assert np.array_equal(w[:: dac // 1000000][: len(synth_mod.query_cmd(q))], synth_mod.query_cmd(q))
             assert len(both()) == 0                               # IDLE
         finally:
             ctx.close()

@@ -152,3 +152,26 @@ def test_reader_tx_waveforms_match_the_trace_generator(oracle_mod, synth_mod):
     sim2 = oracle_mod.ReaderTxSim(dac_rate=2000000)
     assert len(sim2.work()) == 2 * synth_mod.CW_ACK
     assert np.array_equal(sim2.work(), np.repeat(np.concatenate([synth_mod.query_cmd(0), np.ones(synth_mod.CW_QUERY, np.float32)]), 2))
+
+
+def test_reader_tx_non_integer_sample_duration(oracle_mod):
+    """dac_rate = 800 kHz (sample_d = 1.25 us): the reference keeps n_data0_s ... n_trcal_s as float members
+    (reader_impl.h:35) and truncates at each use -- rtcal.resize(19.2f + 38.4f) = 57 samples,
+    fill_n(57 - 9.6f) = 47 ones, not (19 + 38) - 9 = 48 (reader_impl.cc:84-96)."""
+    sim = oracle_mod.ReaderTxSim(dac_rate=800000)
+    tx = sim.tx
+    assert (tx.n_data0, tx.n_data1, tx.n_pw, tx.n_delim, tx.n_trcal) == (19, 38, 9, 9, 160)
+    assert (tx.n_rtcal, tx.n_rtcal_hi, tx.n_trcal_hi) == (57, 47, 150)
+    assert len(sim.work()) == 3660                                  # START: (int)(4575 / 1.25)
+    w = sim.work()                                                  # Query
+    # delim(9 low) data_0(9 high, 10 low) rtcal(47 high, 10 low) trcal(150 high, 10 low)
+    want = np.concatenate([np.zeros(9), np.ones(9), np.zeros(10), np.ones(47), np.zeros(10), np.ones(150), np.zeros(10)])
+    assert np.array_equal(w[: len(want)], want.astype(np.float32))
+
+
+def test_real_blob_hook_documents_the_missing_known_answer():
+    """The reference's only known answer needs misc/data/file_source_test, which this checkout lacks; the GPU
+    suite carries a skipped-if-absent replay (tests/test_gpu_round2.py) that pins parity where the blob exists."""
+    import os
+    src = open(os.path.join(os.path.dirname(__file__), "test_gpu_round2.py")).read()
+    assert "RFID_FILE_SOURCE_TEST" in src and "Tag ID : 27  Num of reads : 70" in src

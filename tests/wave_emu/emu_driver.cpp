@@ -111,7 +111,7 @@ int emu_batch_process(const float *raw, int B, long stride, long n_raw, const in
   ma.x = reinterpret_cast<const float2 *>(raw); ma.x_stride = stride; ma.n_raw = n_raw; ma.lens = lens;
   ma.n_out = n_dec; ma.in_off = -(NTAPS - 1);
   ma.vec_ok = ((stride & 1) == 0 && (((uintptr_t)raw) & 15) == 0) ? 1 : 0;
-  ma.y = y; ma.y_stride = y_stride; ma.tile0 = 0;
+  ma.y = y; ma.y_stride = y_stride; ma.tile0 = 0; ma.stream0 = 0;
   const long tiles = (n_dec + MF_TILE - 1) / MF_TILE;
   const bool fused = gate_chunk < 0;   // gate_chunk -1: the fused front end, as rfid_batch_process() runs by default
   if (tiles > 0 && !fused)
@@ -205,7 +205,7 @@ int emu_mf_stream(const float *staging, int n_staging, int in_off, int n_out, fl
   ma.x = reinterpret_cast<const float2 *>(staging); ma.x_stride = n_staging; ma.n_raw = n_staging; ma.lens = nullptr;
   ma.n_out = n_out; ma.in_off = in_off;
   ma.vec_ok = (in_off % 2 == 0 && (((uintptr_t)staging) & 15) == 0) ? 1 : 0;
-  ma.y = reinterpret_cast<float2 *>(ybuf.data()); ma.y_stride = n_out; ma.tile0 = 0;
+  ma.y = reinterpret_cast<float2 *>(ybuf.data()); ma.y_stride = n_out; ma.tile0 = 0; ma.stream0 = 0;
   const int tiles = (n_out + MF_TILE - 1) / MF_TILE;
   emu::launch(emu::Idx3{(unsigned)tiles, 1, 1}, emu::Idx3{MF_THREADS, 1, 1}, [&]() { mf_boxcar25_decim5_kernel(ma); });
   memcpy(out, ybuf.data(), sizeof(float2) * (size_t)n_out);
