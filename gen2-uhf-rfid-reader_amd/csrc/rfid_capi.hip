@@ -16,6 +16,7 @@
 #include "rfid_host_math.h"
 #include "rfid_kernels.hpp"
 #include "rfid_mi355x.h"
+#include "rfid_gen2_host.h"
 
 using namespace rfidk;
 
@@ -42,6 +43,7 @@ struct rfid_ctx {
   GateState *d_gate1 = nullptr;   // gate state of the single streaming RX stream
   int *d_io = nullptr;            // [2]
   DevBuf s_in, s_out;
+  DevBuf synth_tab;               // slot table of rfid_synth_gen2
   rfid_window *d_swin = nullptr;  // one window
   int *d_scount = nullptr;
   rfid_decode_result *d_sres = nullptr;
@@ -244,7 +246,8 @@ int rfid_ctx_destroy(rfid_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   free_plan(c);
-  void *ptrs[] = {c->d_gate1, c->d_io, c->d_swin, c->d_scount, c->d_sres, c->d_sscores, c->s_in.p, c->s_out.p};
+  void *ptrs[] = {c->d_gate1, c->d_io, c->d_swin, c->d_scount, c->d_sres, c->d_sscores, c->s_in.p, c->s_out.p,
+                  c->synth_tab.p};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < 5; ++i)
@@ -788,6 +791,52 @@ int rfid_synth_replicas(rfid_ctx *c, const void *d_base, int64_t n_raw, void *d_
   }
   return RFID_OK;
 }
+
+
+}  // extern "C"
+
+extern "C" {
+
+int rfid_synth_gen2_size(const rfid_synth_gen2_params *p, const rfid_synth_slot *slots, int64_t n_slots, int64_t *n_raw) {
+  if (!p || n_slots < 0 || (n_slots > 0 && !slots) || !n_raw) return RFID_ERR_INVALID;
+  const int64_t n = rfidh::gen2_layout(*p, slots, n_slots, nullptr);
+  if (n < 0) return RFID_ERR_INVALID;
+  *n_raw = n;
+  return RFID_OK;
+}
+
+int rfid_synth_gen2(rfid_ctx *c, const rfid_synth_gen2_params *p, const rfid_synth_slot *slots, int64_t n_slots,
+                    void *d_out, int64_t out_cap, float sigma, uint64_t seed, int64_t replica, int64_t *n_raw) {
+  if (!c || !p || n_slots < 0 || (n_slots > 0 && !slots) || !d_out || replica < 0) return RFID_ERR_INVALID;
+  if (((uintptr_t)d_out) & 15) return fail(c, RFID_ERR_INVALID, "rfid_synth_gen2: d_out must be 16-byte aligned");
+  std::vector<Gen2SlotDev> dev;
+  dev.reserve((size_t)n_slots + 2);
+  const int64_t total = rfidh::gen2_layout(*p, slots, n_slots, &dev);
+  if (total < 0) return fail(c, RFID_ERR_INVALID, "rfid_synth_gen2: bad slot table");
+  if (total > out_cap) return RFID_ERR_CAPACITY;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = grow(c, c->synth_tab, sizeof(Gen2SlotDev) * dev.size());
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->synth_tab.p, dev.data(), sizeof(Gen2SlotDev) * dev.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // `dev` is pageable host memory that dies with this call
+  Gen2Args a;
+  memset(&a, 0, sizeof(a));
+  a.slots = (const Gen2SlotDev *)c->synth_tab.p; a.n_slots = (int64_t)dev.size();
+  a.out = (float2 *)d_out; a.n_raw = total;
+  a.leak_re = p->leak_re; a.leak_im = p->leak_im;
+  for (int k = 0; k < G2_MAX_TAGS; ++k) { a.h_re[k] = p->h_re[k]; a.h_im[k] = p->h_im[k]; }
+  a.sigma = sigma; a.key0 = (uint32_t)seed; a.key1 = (uint32_t)(seed >> 32); a.replica = (uint64_t)replica;
+  const int64_t n = (int64_t)dev.size();
+  const unsigned gx = (unsigned)(n < 32768 ? n : 32768), gy = (unsigned)((n + gx - 1) / gx);
+  hipLaunchKernelGGL(synth_gen2_kernel, dim3(gx, gy), dim3(G2_THREADS), 0, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  if (n_raw) *n_raw = total;
+  return RFID_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
 
 // ======================================================================================
 // (1) streaming per-block path (host buffers)

@@ -1687,4 +1687,191 @@ RFID_KERNEL(SYNTH_THREADS) void synth_replicas_kernel(SynthArgs a) {
   }
 }
 
+
+// =========================================================================================
+// 7. Gen2 trace synthesiser: the receive trace of a whole inventory run written
+//    straight into HBM from a small slot table -- the reader's PIE envelope as reader_impl transmits it
+//    (tables lib/reader_impl.cc:84-125 at the 1 us DAC resolution, command bits :131-162 with the CRC-5
+//    of :383-443 appended by the host), the tags' FM0 backscatter (preamble global_vars.h:136) and
+//    Philox noise:   x = L*tx + sum_k h_k * level_k * tx + sigma * (N(0,1) + j N(0,1))
+//    at 2 Msps (two samples per microsecond).  One workgroup per slot
+//        [Query | QueryRep] [1295 us CW: RN16 replies] [ACK] [4575 us CW: EPC reply]
+//    (a carrier-only pseudo slot opens and closes the trace).  The noise-free part is bit-identical to
+//    the numpy generator rfid/synth.py (same operation order: leak first, then the responders in table
+//    order); the noise is that of synth_replicas_kernel -- a pure function of (seed, replica, sample).
+//    Workload generator: nothing here is on the receive path.
+// =========================================================================================
+constexpr int G2_MAX_RESP = 8;          // responders per slot (collisions)
+constexpr int G2_MAX_TAGS = 16;         // distinct backscatter coefficients
+constexpr int G2_THREADS = 256;
+constexpr int G2_PW = 12, G2_DELIM = 12, G2_DATA0 = 24, G2_DATA1 = 48, G2_RTCAL = 72, G2_TRCAL = 200;   // us
+constexpr int G2_CW_QUERY = 240 + 480 + (17 + 6) * 25;      // 1295 us  (reader_impl.cc:69)
+constexpr int G2_CW_ACK = 3 * 240 + 480 + (129 + 6) * 25;   // 4575 us  (reader_impl.cc:70)
+constexpr int G2_HALF_BIT_RAW = 25;     // 12.5 us at 2 Msps
+constexpr int G2_RN16_LV = 12 + 2 * 17; // half-bit levels of an RN16 reply (preamble + 16 bits + dummy 1)
+constexpr int G2_EPC_LV = 12 + 2 * 129;
+constexpr int G2_ENV_MAX = 1408;        // us: Query = 308 + 22 * 48 at most
+
+struct Gen2SlotDev {     // one slot as the kernel reads it (the public rfid_synth_slot + what the host derived)
+  int64_t raw_start;     // raw index of the slot's first sample
+  int32_t kind;          // 0 Query, 1 QueryRep, 2 carrier only (cw_us long)
+  int32_t cw_us;         // kind 2: length
+  uint32_t cmd_bits;     // command bits after the frame sync / preamble, first bit = bit (n_cmd_bits - 1)
+  int32_t n_cmd_bits;    // 22 (Query incl. CRC-5) / 4 (QueryRep)
+  uint32_t ack_bits;     // 18 bits: 01 + RN16
+  int32_t n_tags;        // responders
+  int32_t has_epc;
+  int32_t rn16_off_raw;  // reply start, raw samples after the end of the command
+  int32_t epc_off_raw;   // EPC reply start, raw samples after the end of the ACK
+  uint8_t tag[G2_MAX_RESP];
+  uint16_t rn16[G2_MAX_RESP];   // bit 15 = first bit sent
+  uint32_t epc[4];       // frame bit j at epc[j >> 5] bit (j & 31)
+};
+
+struct Gen2Args {
+  const Gen2SlotDev *slots;
+  int64_t n_slots;
+  float2 *out;
+  int64_t n_raw;         // samples of the whole trace (= capacity check done on the host)
+  float leak_re, leak_im;
+  float h_re[G2_MAX_TAGS], h_im[G2_MAX_TAGS];
+  float sigma;
+  uint32_t key0, key1;
+  uint64_t replica;
+};
+
+RFID_DEVICE int g2_popc(uint32_t v) { return wv::popc64((uint64_t)v); }
+
+// PIE envelope of: [delim data_0 RTcal (TRcal)] + n bits, one entry per microsecond; returns its length
+RFID_DEVICE int g2_build_env(unsigned char *env, int *sym, bool with_trcal, uint32_t bits, int n_bits, int tid) {
+  // sym[2k] = start, sym[2k+1] = high time of symbol k
+  int n_sym = 0;
+  if (tid == 0) {
+    int t = 0, k = 0;
+    sym[2 * k] = t; sym[2 * k + 1] = 0; t += G2_DELIM; k++;                                   // delimiter: low
+    sym[2 * k] = t; sym[2 * k + 1] = G2_DATA0 / 2; t += G2_DATA0; k++;                        // data_0
+    sym[2 * k] = t; sym[2 * k + 1] = G2_RTCAL - G2_PW; t += G2_RTCAL; k++;                    // RTcal
+    if (with_trcal) { sym[2 * k] = t; sym[2 * k + 1] = G2_TRCAL - G2_PW; t += G2_TRCAL; k++; } // TRcal
+    for (int b = n_bits - 1; b >= 0; --b) {
+      const bool one = ((bits >> b) & 1u) != 0;
+      sym[2 * k] = t; sym[2 * k + 1] = one ? (3 * G2_DATA1 / 4) : (G2_DATA0 / 2);
+      t += one ? G2_DATA1 : G2_DATA0; k++;
+    }
+    sym[2 * k] = t;   // end
+    sym[63] = k;
+  }
+  wv::block_sync();
+  n_sym = sym[63];
+  for (int k = 0; k < n_sym; ++k) {
+    const int st = sym[2 * k], len = sym[2 * k + 2] - st, hi = sym[2 * k + 1];
+    if (tid < len) env[st + tid] = (tid < hi) ? 1 : 0;
+  }
+  const int total = sym[2 * n_sym];
+  wv::block_sync();
+  return total;
+}
+
+// FM0 half-bit levels of preamble + n bits + dummy 1 (rfid/synth.py fm0_levels): the first half of bit m
+// is the parity of the ones before it, the second half differs iff the bit is 0
+RFID_DEVICE void g2_build_levels(unsigned char *lv, const uint32_t *words, int n_bits, bool msb16, int tid) {
+  const unsigned char pre[12] = {1, 1, 0, 1, 0, 0, 1, 0, 0, 0, 1, 1};   // global_vars.h:136
+  if (tid < 12) lv[tid] = pre[tid];
+  if (tid <= n_bits) {
+    const int m = tid;
+    int ones = 0, bit = 1;   // the dummy bit is a 1
+    if (msb16) {
+      const uint32_t w = words[0] & 0xFFFFu;
+      ones = g2_popc(m ? (w >> (16 - m)) : 0u);
+      if (m < n_bits) bit = (int)((w >> (15 - m)) & 1u);
+    } else {
+      for (int q = 0; q < (m >> 5); ++q) ones += g2_popc(words[q]);
+      if (m & 31) ones += g2_popc(words[m >> 5] & ((1u << (m & 31)) - 1u));
+      if (m < n_bits) bit = (int)((words[m >> 5] >> (m & 31)) & 1u);
+    }
+    const int first = ones & 1;
+    lv[12 + 2 * m] = (unsigned char)first;
+    lv[12 + 2 * m + 1] = (unsigned char)(first ^ (bit ? 0 : 1));
+  }
+}
+
+RFID_KERNEL(G2_THREADS) void synth_gen2_kernel(Gen2Args a) {
+  RFID_SHARED unsigned char env_cmd[G2_ENV_MAX];
+  RFID_SHARED unsigned char env_ack[G2_ENV_MAX];
+  RFID_SHARED unsigned char lv_rn[G2_MAX_RESP][G2_RN16_LV + 2];
+  RFID_SHARED unsigned char lv_epc[G2_EPC_LV + 2];
+  RFID_SHARED int sym[64];
+  RFID_SHARED Gen2SlotDev sl;
+  const int tid = (int)threadIdx.x;
+  const int64_t si = (int64_t)blockIdx.x + (int64_t)blockIdx.y * (int64_t)gridDim.x;
+  if (si >= a.n_slots) return;
+  if (tid == 0) sl = a.slots[si];
+  wv::block_sync();
+  int cmd_us = 0, ack_us = 0, total_us;
+  if (sl.kind == 2) {
+    total_us = sl.cw_us;
+  } else {
+    cmd_us = g2_build_env(env_cmd, sym, sl.kind == 0, sl.cmd_bits, sl.n_cmd_bits, tid);
+    ack_us = g2_build_env(env_ack, sym, false, sl.ack_bits, 18, tid);
+    for (int r = 0; r < sl.n_tags; ++r) {
+      const uint32_t w = sl.rn16[r];
+      g2_build_levels(lv_rn[r], &w, 16, true, tid);
+    }
+    if (sl.has_epc) g2_build_levels(lv_epc, sl.epc, 128, false, tid);
+    wv::block_sync();
+    total_us = cmd_us + G2_CW_QUERY + ack_us + G2_CW_ACK;
+  }
+  const int ack_at = cmd_us + G2_CW_QUERY;            // us
+  const int rn_at = 2 * cmd_us + sl.rn16_off_raw;     // raw
+  const int epc_at = 2 * (ack_at + ack_us) + sl.epc_off_raw;
+  float2 *out = a.out + sl.raw_start;
+  for (int us = tid; us < total_us; us += G2_THREADS) {
+    // carrier envelope of this microsecond (both raw samples)
+    float tx = 1.0f;
+    if (sl.kind != 2) {
+      if (us < cmd_us) tx = (float)env_cmd[us];
+      else if (us >= ack_at && us < ack_at + ack_us) tx = (float)env_ack[us - ack_at];
+    }
+    float4 o;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = 2 * us + h;
+      // numpy's complex64 * float32: (ar*br - ai*0, ar*0 + ai*br)
+      float re = a.leak_re * tx - a.leak_im * 0.0f;
+      float im = a.leak_re * 0.0f + a.leak_im * tx;
+      if (sl.kind != 2) {
+        const int d = r - rn_at;
+        if (d >= 0 && d < G2_RN16_LV * G2_HALF_BIT_RAW) {
+          const int j = d / G2_HALF_BIT_RAW;
+          for (int q = 0; q < sl.n_tags; ++q) {
+            const float lvl = (float)lv_rn[q][j];
+            const int t = sl.tag[q];
+            re = re + (a.h_re[t] * lvl) * tx;
+            im = im + (a.h_im[t] * lvl) * tx;
+          }
+        }
+        const int e = r - epc_at;
+        if (sl.has_epc && e >= 0 && e < G2_EPC_LV * G2_HALF_BIT_RAW) {
+          const float lvl = (float)lv_epc[e / G2_HALF_BIT_RAW];
+          const int t = sl.tag[0];
+          re = re + (a.h_re[t] * lvl) * tx;
+          im = im + (a.h_im[t] * lvl) * tx;
+        }
+      }
+      if (h == 0) { o.x = re; o.y = im; } else { o.z = re; o.w = im; }
+    }
+    if (a.sigma != 0.0f) {
+      const int64_t pair = (sl.raw_start >> 1) + us;     // raw_start is even
+      uint32_t rnd[4];
+      philox4x32_10((uint32_t)pair, (uint32_t)((uint64_t)pair >> 32), (uint32_t)a.replica, (uint32_t)(a.replica >> 32),
+                    a.key0, a.key1, rnd);
+      float g0, g1, g2, g3;
+      box_muller(rnd[0], rnd[1], g0, g1);
+      box_muller(rnd[2], rnd[3], g2, g3);
+      o.x = o.x + a.sigma * g0; o.y = o.y + a.sigma * g1;
+      o.z = o.z + a.sigma * g2; o.w = o.w + a.sigma * g3;
+    }
+    *reinterpret_cast<float4 *>(out + 2 * us) = o;
+  }
+}
+
 }  // namespace rfidk

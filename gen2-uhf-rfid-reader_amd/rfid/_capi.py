@@ -47,6 +47,11 @@ class ReaderState(C.Structure):
                 ("n_unique_tags", C.c_int32), ("tag_reads", C.c_int32 * 256)]
 
 
+class SynthGen2Params(C.Structure):
+    _fields_ = [("leak_re", C.c_float), ("leak_im", C.c_float), ("h_re", C.c_float * 16), ("h_im", C.c_float * 16),
+                ("n_tags", C.c_int32), ("tail_us", C.c_int32)]
+
+
 class BatchTiming(C.Structure):
     _fields_ = [("mf_ms", C.c_float), ("gate_ms", C.c_float), ("decode_ms", C.c_float),
                 ("stats_ms", C.c_float), ("total_ms", C.c_float), ("front_ms", C.c_float),
@@ -84,6 +89,8 @@ SIGNATURES = {
     "rfid_reader_tx_max": (_i, [_i]),
     "rfid_get_state": (_i, [_vp, C.POINTER(ReaderState)]),
     "rfid_print_results": (_i, [_vp, C.c_char_p, _i, _ip]),
+    "rfid_synth_gen2_size": (_i, [_vp, _vp, _i64, C.POINTER(C.c_int64)]),
+    "rfid_synth_gen2": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, C.c_float, C.c_uint64, _i64, C.POINTER(C.c_int64)]),
     "rfid_batch_plan": (_i, [_vp, _i, _i64]),
     "rfid_batch_set_streams": (_i, [_vp, _i]),
     "rfid_batch_mf": (_i, [_vp, _vp, _i64, _i64, _vp]),

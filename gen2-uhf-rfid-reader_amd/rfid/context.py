@@ -196,6 +196,34 @@ class Context:
         self._chk(self._lib.rfid_synth_replicas(self._h, C.c_void_p(d_base), int(n_raw), C.c_void_p(d_out), int(out_stride),
                                                 int(n_streams), C.c_float(sigma), C.c_uint64(seed), int(first_replica)))
 
+    def _gen2_params(self, plan) -> "capi.SynthGen2Params":
+        p = capi.SynthGen2Params()
+        lk = np.complex64(plan.leak)
+        p.leak_re, p.leak_im = float(lk.real), float(lk.imag)
+        for k, h in enumerate(plan.hs):
+            hk = np.complex64(h)
+            p.h_re[k], p.h_im[k] = float(hk.real), float(hk.imag)
+        p.n_tags = len(plan.hs)
+        p.tail_us = int(plan.tail_us)
+        return p
+
+    def synth_gen2_size(self, plan) -> int:
+        """Samples of the trace rfid_synth_gen2 builds from `plan` (rfid.synth.TracePlan)."""
+        slots = np.ascontiguousarray(plan.slots)
+        n = C.c_int64(0)
+        p = self._gen2_params(plan)
+        self._chk(self._lib.rfid_synth_gen2_size(C.byref(p), slots.ctypes.data, len(slots), C.byref(n)))
+        return n.value
+
+    def synth_gen2_ptr(self, plan, d_out: int, out_cap: int, sigma: float = 0.0, seed: int = 0, replica: int = 0) -> int:
+        """Asynchronous: the Gen2 receive trace of `plan` generated in HBM at d_out; returns its sample count."""
+        slots = np.ascontiguousarray(plan.slots)
+        n = C.c_int64(0)
+        p = self._gen2_params(plan)
+        self._chk(self._lib.rfid_synth_gen2(self._h, C.byref(p), slots.ctypes.data, len(slots), C.c_void_p(d_out),
+                                            int(out_cap), C.c_float(sigma), C.c_uint64(seed), int(replica), C.byref(n)))
+        return n.value
+
     def batch_device_ptrs(self) -> dict:
         y, st, fc = C.c_void_p(), C.c_void_p(), C.c_void_p()
         stride = C.c_int64(0)

@@ -126,18 +126,53 @@ class SlotTruth:
     epc_raw_start: int = -1
 
 
+# rfid_synth_slot of include/rfid_mi355x.h (56 bytes): the slot table the device-side synthesiser
+# (rfid_synth_gen2) expands into samples
+SLOT_DTYPE = np.dtype([("cmd", "u1"), ("q", "u1"), ("n_tags", "u1"), ("has_epc", "u1"), ("tag", "u1", (8,)),
+                       ("rn16", "<u2", (8,)), ("ack", "<u2"), ("reserved_", "<i2"), ("rn16_off_raw", "<i4"),
+                       ("epc_off_raw", "<i4"), ("epc", "<u4", (4,))])
+assert SLOT_DTYPE.itemsize == 56
+MAX_RESP, MAX_TAGS = 8, 16
+
+
+def _pack16(bits: Sequence[int]) -> int:
+    v = 0
+    for b in bits:
+        v = (v << 1) | int(b)
+    return v
+
+
+def _pack_frame(bits: Sequence[int]) -> List[int]:
+    w = [0, 0, 0, 0]
+    for j, b in enumerate(bits):
+        if b:
+            w[j >> 5] |= 1 << (j & 31)
+    return w
+
+
+@dataclass
+class TracePlan:
+    """What rfid_synth_gen2 needs to build the same (noise-free) trace on the device."""
+    slots: np.ndarray              # SLOT_DTYPE records
+    leak: complex
+    hs: List[complex]              # backscatter coefficient per tag index
+    tail_us: int
+    n_raw: int                     # samples of the trace
+
+
 @dataclass
 class Trace:
-    samples: np.ndarray            # complex64 @ 2 Msps
+    samples: Optional[np.ndarray]  # complex64 @ 2 Msps (None when only the plan was asked for)
     slots: List[SlotTruth] = field(default_factory=list)
     fixed_q: int = 0
+    plan: Optional[TracePlan] = None
 
 
 def make_trace(n_rounds: int = 5, fixed_q: int = 0, tag_ids: Sequence[int] = (0x27,),
                sigma: float = 0.002, seed: int = 1, leak: complex = 1.0 * np.exp(0.7j),
                h: complex = 0.10 * np.exp(2.1j), corrupt_rounds: Sequence[int] = (),
                t1_us: float = T1_US, tail_us: int = 200, noise: bool = True,
-               t1_jitter_raw: int = 0) -> Trace:
+               t1_jitter_raw: int = 0, render: bool = True) -> Trace:
     """Build one RX trace of `n_rounds` inventory rounds with 2**fixed_q slots each.
 
     Each tag picks a slot uniformly per round; slots with exactly one tag carry an
@@ -145,6 +180,10 @@ def make_trace(n_rounds: int = 5, fixed_q: int = 0, tag_ids: Sequence[int] = (0x
     empty slots carry noise.  The reader ACKs every slot (the reference has no
     empty-slot detection: SURVEY.md section 3.3).  `corrupt_rounds` flips one EPC frame
     bit in the first occupied slot of those rounds (1-based) so the CRC fails.
+
+    `render=False` skips the numpy rendering (samples = None) and only returns the ground truth and the
+    slot table (`.plan`) from which rfid_synth_gen2 builds the identical noise-free trace in HBM -- the
+    way the large configurations (10 000 rounds x 16 slots = 17.5 GB) are generated.
     """
     rng = np.random.default_rng(seed)
     n_slots = 1 << fixed_q
@@ -155,8 +194,12 @@ def make_trace(n_rounds: int = 5, fixed_q: int = 0, tag_ids: Sequence[int] = (0x
 
     def emit(seg: np.ndarray):
         nonlocal t
-        tx_parts.append(seg)
+        if render:
+            tx_parts.append(seg)
         t += len(seg)
+
+    table = np.zeros(n_rounds * n_slots, dtype=SLOT_DTYPE)
+    n_tab = 0
 
     emit(np.ones(CW_ACK, np.float32))             # START: cw_ack (reader_impl.cc:218-224)
     hs = [h * np.exp(1j * 0.9 * k) * (1.0 - 0.1 * (k % 3)) for k in range(len(tag_ids))]
@@ -170,16 +213,28 @@ def make_trace(n_rounds: int = 5, fixed_q: int = 0, tag_ids: Sequence[int] = (0x
             jit = int(rng.integers(-t1_jitter_raw, t1_jitter_raw + 1)) if t1_jitter_raw else 0
             reply_at = t + t1_us + jit / 2.0
             truth = SlotTruth(r, s + 1, len(who), None, None, None, False)
+            rec = table[n_tab]
+            n_tab += 1
+            rec["cmd"] = 0 if s == 0 else 1
+            rec["q"] = fixed_q
+            if len(who) > MAX_RESP or len(tag_ids) > MAX_TAGS:
+                raise ValueError("slot table: at most %d responders per slot and %d tags" % (MAX_RESP, MAX_TAGS))
+            rec["n_tags"] = len(who)
+            rec["rn16_off_raw"] = int(round(reply_at * 2)) - 2 * t
             rn = None
-            for k in who:
+            for i_who, k in enumerate(who):
                 bits = rng.integers(0, 2, 16).tolist()
-                events.append((reply_at, fm0_levels(bits), hs[k]))
+                if render:
+                    events.append((reply_at, fm0_levels(bits), hs[k]))
+                rec["tag"][i_who] = k
+                rec["rn16"][i_who] = _pack16(bits)
                 rn = bits
             if len(who) == 1:
                 truth.rn16 = rn
                 truth.rn16_raw_start = int(round(reply_at * 2))
             emit(np.ones(CW_QUERY, np.float32))
             ack_bits = rn if rn is not None else rng.integers(0, 2, 16).tolist()
+            rec["ack"] = _pack16(ack_bits)
             emit(ack_cmd(ack_bits))
             if len(who) == 1:
                 k = who[0]
@@ -192,7 +247,11 @@ def make_trace(n_rounds: int = 5, fixed_q: int = 0, tag_ids: Sequence[int] = (0x
                     corrupted = True
                 jit = int(rng.integers(-t1_jitter_raw, t1_jitter_raw + 1)) if t1_jitter_raw else 0
                 reply_at = t + t1_us + jit / 2.0
-                events.append((reply_at, fm0_levels(frame), hs[k]))
+                if render:
+                    events.append((reply_at, fm0_levels(frame), hs[k]))
+                rec["has_epc"] = 1
+                rec["epc_off_raw"] = int(round(reply_at * 2)) - 2 * t
+                rec["epc"] = _pack_frame(frame)
                 truth.epc = list(frame)
                 truth.tag_id = tag_ids[k]
                 truth.epc_valid = valid
@@ -200,6 +259,10 @@ def make_trace(n_rounds: int = 5, fixed_q: int = 0, tag_ids: Sequence[int] = (0x
             emit(np.ones(CW_ACK, np.float32))
             slots.append(truth)
     emit(np.ones(tail_us, np.float32))
+    plan = TracePlan(slots=table[:n_tab], leak=complex(np.complex64(leak)), hs=[complex(np.complex64(v)) for v in hs],
+                     tail_us=int(tail_us), n_raw=2 * t)
+    if not render:
+        return Trace(samples=None, slots=slots, fixed_q=fixed_q, plan=plan)
 
     tx = np.repeat(np.concatenate(tx_parts), 2)     # 1 Msps -> 2 Msps
     x = (np.complex64(leak) * tx).astype(np.complex64)
@@ -211,7 +274,7 @@ def make_trace(n_rounds: int = 5, fixed_q: int = 0, tag_ids: Sequence[int] = (0x
     if noise and sigma > 0:
         n = rng.standard_normal((len(x), 2), dtype=np.float32)
         x += (np.float32(sigma) * (n[:, 0] + 1j * n[:, 1])).astype(np.complex64)
-    return Trace(samples=np.ascontiguousarray(x, dtype=np.complex64), slots=slots, fixed_q=fixed_q)
+    return Trace(samples=np.ascontiguousarray(x, dtype=np.complex64), slots=slots, fixed_q=fixed_q, plan=plan)
 
 
 def fst_like_trace(sigma: float = 0.002, seed: int = 7) -> Trace:

@@ -237,6 +237,46 @@ RFID_API void *rfid_ctx_stream(rfid_ctx *ctx);
 RFID_API int rfid_synth_replicas(rfid_ctx *ctx, const void *d_base, int64_t n_raw, void *d_out, int64_t out_stride,
                                  int n_streams, float sigma, uint64_t seed, int64_t first_replica);
 
+
+/* ---- (3b) Gen2 trace synthesiser ------------------------------------------ */
+/* One inventory slot of a synthetic receive trace: what the reader sends (reader_impl.cc:84-162: Query with
+ * CRC-5 for the first slot of a round, QueryRep otherwise, then the ACK) and what the tags answer. */
+#define RFID_SYNTH_MAX_RESP 8
+#define RFID_SYNTH_MAX_TAGS 16
+typedef struct rfid_synth_slot {
+  uint8_t cmd;            /* 0 Query, 1 QueryRep */
+  uint8_t q;              /* Q field of the Query (FIXED_Q) */
+  uint8_t n_tags;         /* tags answering in this slot: 0 empty, 1 single, >1 collision (<= 8) */
+  uint8_t has_epc;        /* the (single) responder backscatters its EPC frame after the ACK */
+  uint8_t tag[RFID_SYNTH_MAX_RESP];   /* index of each responder's backscatter coefficient */
+  uint16_t rn16[RFID_SYNTH_MAX_RESP]; /* the RN16 each responder backscatters, bit 15 sent first */
+  uint16_t ack;           /* RN16 the reader's ACK carries, bit 15 first (the reference ACKs every slot) */
+  int16_t reserved_;
+  int32_t rn16_off_raw;   /* start of the RN16 replies, raw samples (2 Msps) after the end of the command: 500 = 250 us */
+  int32_t epc_off_raw;    /* start of the EPC reply after the end of the ACK */
+  uint32_t epc[4];        /* 128 EPC frame bits (PC + EPC + CRC-16), frame bit j at epc[j >> 5] bit (j & 31) */
+} rfid_synth_slot;        /* 56 bytes */
+
+typedef struct rfid_synth_gen2_params {
+  float leak_re, leak_im;                 /* carrier leakage L */
+  float h_re[RFID_SYNTH_MAX_TAGS];        /* backscatter coefficient of tag k */
+  float h_im[RFID_SYNTH_MAX_TAGS];
+  int32_t n_tags;
+  int32_t tail_us;                        /* carrier after the last slot */
+} rfid_synth_gen2_params;
+
+/* Samples (2 Msps) of the trace these slots make: 4575 us carrier, then per slot command + 1295 us carrier +
+ * ACK + 4575 us carrier (reader_impl.cc:69-70,218-224), then tail_us of carrier. */
+RFID_API int rfid_synth_gen2_size(const rfid_synth_gen2_params *p, const rfid_synth_slot *slots, int64_t n_slots,
+                                  int64_t *n_raw);
+/* Writes the trace  x = L tx + sum_k h_k level_k tx + sigma (N(0,1) + j N(0,1))  into d_out (device, 16-byte
+ * aligned, room for out_cap samples), generated on the device from the slot table (host pointer; copied).
+ * The noise is that of rfid_synth_replicas for replica index `replica` (so sigma = 0 here followed by
+ * rfid_synth_replicas gives the same bytes).  Asynchronous on the ctx stream; *n_raw = samples written. */
+RFID_API int rfid_synth_gen2(rfid_ctx *ctx, const rfid_synth_gen2_params *p, const rfid_synth_slot *slots,
+                             int64_t n_slots, void *d_out, int64_t out_cap, float sigma, uint64_t seed,
+                             int64_t replica, int64_t *n_raw);
+
 #ifdef __cplusplus
 }
 #endif

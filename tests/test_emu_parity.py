@@ -168,3 +168,22 @@ def test_emulated_replica_generator(emu_mod):
     assert abs(nz.real.std() - 1) < 0.03 and abs(nz.imag.std() - 1) < 0.03
     assert abs(np.corrcoef(nz[0].real, nz[1].real)[0, 1]) < 0.06 and abs(np.corrcoef(nz[0].real, nz[0].imag)[0, 1]) < 0.06
     assert np.array_equal(emu_mod.synth_replicas(base, 2, 0.0, seed=1), np.stack([base, base]))
+
+
+@pytest.mark.parametrize("kw", [dict(n_rounds=2, fixed_q=0, tag_ids=(0x27,), seed=3),
+                                dict(n_rounds=2, fixed_q=2, tag_ids=(1, 2, 3, 4, 5, 6), seed=8, t1_jitter_raw=7,
+                                     corrupt_rounds=(1,)),
+                                dict(n_rounds=1, fixed_q=4, tag_ids=tuple(range(9)), seed=2, leak=-0.8 + 0.3j)])
+def test_emulated_gen2_synthesiser_equals_numpy_generator(emu_mod, synth_mod, kw):
+    """synth_gen2_kernel (reader PIE envelope incl. Query CRC-5, ACKs, FM0 backscatter with
+    collisions and empty slots, built on the device from a slot table) equals rfid/synth.py sample for sample on the
+    noise-free part; with noise it is the noise-free trace plus the replica generator's noise."""
+    t = synth_mod.make_trace(sigma=0.0, noise=False, **kw)
+    x = emu_mod.synth_gen2(t.plan)
+    assert len(x) == len(t.samples)
+    assert np.array_equal(x, t.samples)
+    if "leak" not in kw:
+        assert np.array_equal(x.view(np.uint32), t.samples.view(np.uint32))
+    xn = emu_mod.synth_gen2(t.plan, sigma=0.01, seed=77, replica=5)
+    want = emu_mod.synth_replicas(t.samples, 1, 0.01, seed=77, first_replica=5)[0]
+    assert np.array_equal(xn.view(np.uint32), want.view(np.uint32))

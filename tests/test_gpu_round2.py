@@ -109,3 +109,73 @@ def test_real_file_source_test_replay_matches_readme():
         assert README_BLOCK in rfid.batch.format_results(stats[0])
     finally:
         dec.close()
+
+
+def _gen2_on_device(ctx, plan, sigma=0.0, seed=0, replica=0):
+    import torch
+    n = ctx.synth_gen2_size(plan)
+    assert n == plan.n_raw
+    out = torch.zeros(2 * n, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    assert ctx.synth_gen2_ptr(plan, out.data_ptr(), n, sigma=sigma, seed=seed, replica=replica) == n
+    ctx.batch_sync()
+    return out
+
+
+@pytest.mark.parametrize("kw", [dict(n_rounds=3, fixed_q=0, tag_ids=(0x27,), seed=3, corrupt_rounds=(2,)),
+                                dict(n_rounds=2, fixed_q=3, tag_ids=(1, 2, 3, 4, 5, 6), seed=8, t1_jitter_raw=7),
+                                dict(n_rounds=1, fixed_q=4, tag_ids=tuple(range(9)), seed=2)])
+def test_device_gen2_synthesiser_equals_numpy_generator(gpu_ctx, oracle_mod, synth_mod, kw):
+    """rfid_synth_gen2 (f4: device-side PIE / CRC-5 / FM0 generator) == rfid/synth.py sample for sample at
+    sigma = 0; with noise == base + rfid_synth_replicas noise; and the generated trace decodes to the slot
+    table's truth through the batched path, bit-identical to the oracle on the same samples."""
+    import rfid
+    import torch
+    t = synth_mod.make_trace(sigma=0.0, noise=False, **kw)
+    out = _gen2_on_device(gpu_ctx, t.plan)
+    x = out.cpu().numpy().view(np.complex64)
+    assert np.array_equal(x.view(np.uint32), t.samples.view(np.uint32))
+    # noisy: same bytes as the noise-free trace + the replica generator
+    outn = _gen2_on_device(gpu_ctx, t.plan, sigma=0.01, seed=5, replica=3)
+    L = len(x)
+    ref = torch.zeros(2 * L, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    gpu_ctx.synth_replicas_ptr(out.data_ptr(), L, ref.data_ptr(), L, 1, 0.01, 5, first_replica=3)
+    gpu_ctx.batch_sync()
+    assert torch.equal(outn, ref)
+    # decode it
+    q = kw["fixed_q"]
+    ctx = rfid.Context(device=0, fixed_q=q)
+    try:
+        ctx.batch_plan(1, L)
+        ctx.batch_process_ptr(outn.data_ptr(), L, L, 0, want_scores=True)
+        ctx.batch_sync()
+        w, r, s = ctx.batch_windows(want_scores=True)
+        st = ctx.batch_stats()
+        xn = outn.cpu().numpy().view(np.complex64)
+        parity.compare_trace(w, r, s, st[0], oracle_mod.run_trace(xn, oracle_mod.config(fixed_q=q)))
+        n_valid = sum(1 for sl in t.slots if sl.epc_valid)
+        assert st[0]["n_epc_correct"] == n_valid
+        # every single-responder slot's RN16 comes back exactly
+        rn = [rfid.unpack_bits(rr["bits"], 16).tolist() for rr in r[r["type"] == 0]]
+        for i, sl in enumerate(t.slots):
+            if sl.n_tags == 1:
+                assert rn[i] == sl.rn16, i
+    finally:
+        ctx.close()
+
+
+def test_gen2_slot_table_validation(gpu_ctx, synth_mod):
+    import rfid
+    import torch
+    lib = rfid.capi.load()
+    t = synth_mod.make_trace(n_rounds=1, render=False)
+    buf = torch.zeros(2 * t.plan.n_raw, dtype=torch.float32, device="cuda:0")
+    with pytest.raises(rfid.capi.RfidError):            # capacity
+        gpu_ctx.synth_gen2_ptr(t.plan, buf.data_ptr(), t.plan.n_raw - 2)
+    bad = synth_mod.make_trace(n_rounds=1, render=False).plan
+    bad.slots["rn16_off_raw"] = 2 * 1295               # reply would run into the ACK
+    with pytest.raises(rfid.capi.RfidError):
+        gpu_ctx.synth_gen2_ptr(bad, buf.data_ptr(), t.plan.n_raw)
+    with pytest.raises(rfid.capi.RfidError):            # unaligned output
+        gpu_ctx.synth_gen2_ptr(t.plan, buf.data_ptr() + 8, t.plan.n_raw)

@@ -113,6 +113,27 @@ def synth_replicas(base: np.ndarray, n_streams: int, sigma: float, seed: int, fi
     return out
 
 
+def synth_gen2(plan, sigma: float = 0.0, seed: int = 0, replica: int = 0) -> np.ndarray:
+    """synth_gen2_kernel on the emulator: the trace of an rfid.synth.TracePlan."""
+    p = capi.SynthGen2Params()
+    lk = np.complex64(plan.leak)
+    p.leak_re, p.leak_im = float(lk.real), float(lk.imag)
+    for k, h in enumerate(plan.hs):
+        hk = np.complex64(h)
+        p.h_re[k], p.h_im[k] = float(hk.real), float(hk.imag)
+    p.n_tags, p.tail_us = len(plan.hs), int(plan.tail_us)
+    slots = np.ascontiguousarray(plan.slots)
+    buf = np.zeros(plan.n_raw + 2, dtype=np.complex64)
+    off = (16 - buf.ctypes.data % 16) % 16 // 8
+    out = buf[off:off + plan.n_raw]
+    fn = lib().emu_synth_gen2
+    fn.restype = C.c_long
+    n = fn(C.byref(p), C.c_void_p(slots.ctypes.data), C.c_long(len(slots)), C.c_void_p(out.ctypes.data),
+           C.c_long(plan.n_raw), C.c_float(sigma), C.c_ulonglong(seed), C.c_long(replica))
+    assert n == plan.n_raw, (n, plan.n_raw)
+    return out.copy()
+
+
 def philox4x32_10(ctr, key) -> np.ndarray:
     c = np.asarray(ctr, dtype=np.uint32); k = np.asarray(key, dtype=np.uint32); o = np.zeros(4, dtype=np.uint32)
     lib().emu_philox4x32_10(C.c_void_p(c.ctypes.data), C.c_void_p(k.ctypes.data), C.c_void_p(o.ctypes.data))

@@ -14,6 +14,7 @@
 #include <rfid_device_env.h>
 #include "rfid_host_math.h"
 #include "rfid_kernels.hpp"
+#include "rfid_gen2_host.h"
 
 namespace emu {
 
@@ -250,6 +251,22 @@ int emu_synth_replicas(const float *base, long n_raw, float *out, long out_strid
   emu::launch(emu::Idx3{(unsigned)blocks, (unsigned)n_streams, 1}, emu::Idx3{SYNTH_THREADS, 1, 1},
               [&]() { synth_replicas_kernel(a); });
   return 0;
+}
+
+// Gen2 trace synthesiser (workload generator): the same host layout as rfid_synth_gen2, the kernel emulated
+long emu_synth_gen2(const rfid_synth_gen2_params *p, const rfid_synth_slot *slots, long n_slots, float *out, long out_cap,
+                    float sigma, unsigned long long seed, long replica) {
+  std::vector<Gen2SlotDev> dev;
+  const int64_t total = rfidh::gen2_layout(*p, slots, n_slots, &dev);
+  if (total < 0 || total > out_cap) return -1;
+  Gen2Args a;
+  memset(&a, 0, sizeof(a));
+  a.slots = dev.data(); a.n_slots = (int64_t)dev.size(); a.out = reinterpret_cast<float2 *>(out); a.n_raw = total;
+  a.leak_re = p->leak_re; a.leak_im = p->leak_im;
+  for (int k = 0; k < G2_MAX_TAGS; ++k) { a.h_re[k] = p->h_re[k]; a.h_im[k] = p->h_im[k]; }
+  a.sigma = sigma; a.key0 = (uint32_t)seed; a.key1 = (uint32_t)(seed >> 32); a.replica = (uint64_t)replica;
+  emu::launch(emu::Idx3{(unsigned)dev.size(), 1, 1}, emu::Idx3{G2_THREADS, 1, 1}, [&]() { synth_gen2_kernel(a); });
+  return (long)total;
 }
 
 void emu_philox4x32_10(const uint32_t *ctr, const uint32_t *key, uint32_t *out) {
