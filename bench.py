@@ -2,11 +2,18 @@
 """bench.py -- Gen2 receive path (matched_filter -> gate -> tag_decoder) on MI355X.
 
 One "step" = one pass of the whole hot path over a batch of synthetic traces already
-resident in HBM (BASELINE.json configs[1]: 1024 noise-replicas of the 71-round
-file_source_test stand-in, FM0 40 kHz BLF @ 2 Msps, per GPU).  Prints ONE JSON line.
+resident in HBM.  Prints ONE JSON line.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--streams B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|2|3stream|4shard]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Workloads (BASELINE.json `configs`; the default -- the driver's line -- is configs[1]):
+  --config 1        configs[1]: 1024 noise replicas per GPU of the 71-round file_source_test stand-in
+  --config 2        configs[2]: ONE multi-tag inventory trace, FIXED_Q=4 (16 slots/round), 10 000 rounds
+                    (~2.2 G raw samples, 17.5 GB), generated in HBM by the device-side Gen2 synthesiser
+  --config 3stream  configs[3], the per-GPU workload: one long RX stream per GPU (different tags/seed per rank)
+  --config 4shard   configs[4], the per-GPU shard: as many replicas of the 71-round trace as HBM holds
+                    (~250 GB incl. the matched-filter output), full chain over all of them
 
 Multi-GPU: one process per GPU, traces sharded per rank, no data-path collective (weak
 scaling); torch.distributed is used only for the barrier and the max-over-ranks time.
@@ -16,6 +23,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -27,25 +35,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
 RN16_WIN, EPC_WIN = 250, 1370
-
-
-def build_batch(torch, ctx, device, n_streams, sigma, seed, rank):
-    """Noise-free 71-round stand-in trace, replicated n_streams times in HBM with per-replica noise by the library's
-    device-side generator (rfid_synth_replicas; replica index = rank * n_streams + row, so every GPU of a multi-GPU
-    run holds different replicas).  torch only owns the buffers."""
-    from rfid import synth
-    base = synth.make_trace(n_rounds=71, fixed_q=0, tag_ids=(0x27,), sigma=0.0, seed=7,
-                            corrupt_rounds=(36,), noise=False)
-    L = len(base.samples)
-    stride = (L + 1) & ~1
-    base_dev = torch.from_numpy(base.samples.view(np.float32).copy()).to(device)     # [2*L] float32
-    data = torch.zeros((n_streams, 2 * stride), dtype=torch.float32, device=device)
-    torch.cuda.synchronize()     # the library runs on its own (non-blocking) stream: torch's fill must be over
-    ctx.synth_replicas_ptr(base_dev.data_ptr(), L, data.data_ptr(), stride, n_streams, sigma, seed,
-                           first_replica=rank * n_streams)
-    ctx.batch_sync()
-    del base_dev
-    return data, L, stride, base
+PER_WINDOW_WS = 24 * 3 + 48 + 144      # window table + two compact lists + result + scores (bytes)
 
 
 def _usable_cores():
@@ -72,47 +62,145 @@ def _usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(base_samples, sigma, seconds_target):
-    """The oracle (CPU port of the reference algorithm) timed on this host on a bounded sample: repeated passes
-    over ONE replica of the same workload -- first on one thread (the reference is single-threaded per stream;
-    per-stage split), then one independent copy per host core at once (`value`, `cores`)."""
+def cpu_baseline(x, seconds_target, fixed_q=0, what="1 replica of the workload trace"):
+    """The oracle (CPU port of the reference algorithm) timed on this host on a bounded sample `x` of the
+    workload -- first on one thread (the reference is single-threaded per stream; per-stage split), then
+    one independent copy per host core at once (`value`, `cores`)."""
     from oracle import oracle
-    rng = np.random.default_rng(123)
-    n = rng.standard_normal((len(base_samples), 2), dtype=np.float32)
-    x = (base_samples + np.float32(sigma) * (n[:, 0] + 1j * n[:, 1])).astype(np.complex64)
-    t = oracle.time_trace(x, reps=1)
+    cfg = oracle.config(fixed_q=fixed_q, max_num_queries=1 << 30)
+    t = oracle.time_trace(x, reps=1, cfg=cfg)
     t_pass = max(t["total_s"], 1e-4)
     reps1 = max(1, min(20000, int(0.5 * seconds_target / t_pass)))
-    t = oracle.time_trace(x, reps=reps1)
+    t = oracle.time_trace(x, reps=reps1, cfg=cfg)
     msps1 = len(x) * reps1 / t["total_s"] / 1e6
     cores = _usable_cores()
     # calibrate the all-cores leg with one pass per thread, then size it to ~half the time budget of wall time
-    cal = oracle.time_trace_mt(x, reps=1, nthreads=cores)
+    cal = oracle.time_trace_mt(x, reps=1, nthreads=cores, cfg=cfg)
     reps_mt = max(1, min(20000, int(0.5 * seconds_target / max(cal["wall_s"], 1e-4))))
-    m = oracle.time_trace_mt(x, reps=reps_mt, nthreads=cores)
+    m = oracle.time_trace_mt(x, reps=reps_mt, nthreads=cores, cfg=cfg)
     msps = len(x) * reps_mt * cores / m["wall_s"] / 1e6
     return {"value": round(msps, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"{cores} host threads x {reps_mt} passes over 1 replica of the workload trace ({len(x)} raw samples "
+            "sample": f"{cores} host threads x {reps_mt} passes over {what} ({len(x)} raw samples "
                       f"each) in {m['wall_s']:.2f} s wall, oracle/rfid_oracle.c; one thread alone: {reps1} passes, "
                       f"FIR {t['fir_s']:.2f}s + gate/decoder {t['gate_decoder_s']:.2f}s",
             "single_thread_msamples_per_s": round(msps1, 3),
             "epc_per_s": round(m["n_epc_correct"] * reps_mt * cores / m["wall_s"], 1)}
 
 
+# ---------------------------------------------------------------------------------------------------
+# workloads: each returns a dict(data, ptr, stride, L, B, fixed_q, describe, check(stats)->(ok, text), sample())
+# ---------------------------------------------------------------------------------------------------
+def _fst_plan(synth):
+    """Slot table of the noise-free 71-round stand-in for misc/data/file_source_test (one EPC corrupted)."""
+    return synth.make_trace(n_rounds=71, fixed_q=0, tag_ids=(0x27,), sigma=0.0, seed=7, corrupt_rounds=(36,),
+                            noise=False, render=False)
+
+
+def _replicas(torch, ctx, device, plan, B, sigma, seed, first_replica):
+    """The plan's trace built in HBM by the device-side Gen2 synthesiser, then B noise replicas of it by the
+    replica generator (replica index = first_replica + row).  torch only owns the buffers."""
+    L = ctx.synth_gen2_size(plan)
+    stride = (L + 1) & ~1
+    base = torch.zeros(2 * stride, dtype=torch.float32, device=device)
+    data = torch.empty((B, 2 * stride), dtype=torch.float32, device=device)
+    torch.cuda.synchronize()     # the library runs on its own (non-blocking) stream: torch's fills must be over
+    ctx.synth_gen2_ptr(plan, base.data_ptr(), stride, sigma=0.0)
+    ctx.synth_replicas_ptr(base.data_ptr(), L, data.data_ptr(), stride, B, sigma, seed, first_replica=first_replica)
+    if stride != L:
+        data[:, 2 * L:] = 0
+    ctx.batch_sync()
+    return data, base, L, stride
+
+
+def workload_replicas(torch, rfid, synth, args, device, rank, B, tag):
+    t = _fst_plan(synth)
+    ctx = rfid.Context(device=device.index)
+    data, base, L, stride = _replicas(torch, ctx, device, t.plan, B, args.sigma, args.seed, rank * B)
+
+    def check(st):
+        ok = bool((st["n_epc_correct"] == 70).all() and (st["n_queries_sent"] == 72).all()
+                  and (st["tag_reads"][:, 0x27] == 70).all() and (st["n_unique_tags"] == 1).all())
+        return ok, ("ok: every replica 70/71 EPC, tag 0x27" if ok else
+                    "FAILED: %d EPC ok, expected %d" % (int(st["n_epc_correct"].sum()), 70 * B))
+
+    def sample():
+        rng = np.random.default_rng(123)
+        b = base.cpu().numpy().view(np.complex64)[:L]
+        n = rng.standard_normal((L, 2), dtype=np.float32)
+        return (b + np.float32(args.sigma) * (n[:, 0] + 1j * n[:, 1])).astype(np.complex64), "1 replica of the workload trace"
+
+    return dict(ctx=ctx, data=data, stride=stride, L=L, B=B, fixed_q=0, check=check, sample=sample,
+                describe="%s: batch of %d noise-replicas per GPU of the 71-round file_source_test stand-in trace, "
+                         "FM0 40 kHz BLF @ 2 Msps (%d raw I/Q samples each, sigma=%g), generated and resident in HBM"
+                         % (tag, B, L, args.sigma))
+
+
+def workload_single_trace(torch, rfid, synth, args, device, rank, fixed_q, n_rounds, n_tags, tag):
+    """One long trace built in HBM from its slot table (different tags / seed per rank)."""
+    tag_ids = tuple(((0x11 + 0x10 * k + rank) & 0xFF) for k in range(n_tags))
+    t0 = time.perf_counter()
+    t = synth.make_trace(n_rounds=n_rounds, fixed_q=fixed_q, tag_ids=tag_ids, sigma=0.0, seed=args.seed + rank,
+                         noise=False, render=False)
+    plan_s = time.perf_counter() - t0
+    ctx = rfid.Context(device=device.index, fixed_q=fixed_q, max_num_queries=(1 << 31) - 2)
+    L = ctx.synth_gen2_size(t.plan)
+    stride = (L + 1) & ~1
+    data = torch.zeros((1, 2 * stride), dtype=torch.float32, device=device)
+    torch.cuda.synchronize()
+    ctx.synth_gen2_ptr(t.plan, data.data_ptr(), stride, sigma=args.sigma, seed=args.seed, replica=rank)
+    ctx.batch_sync()
+    n_slots = len(t.slots)
+    n_valid = sum(1 for s in t.slots if s.epc_valid)
+    hist = np.zeros(256, dtype=np.int64)
+    for s in t.slots:
+        if s.epc_valid:
+            hist[s.tag_id] += 1
+
+    def check(st):
+        ok = bool(st[0]["n_windows"] == 2 * n_slots and st[0]["n_epc_correct"] == n_valid
+                  and np.array_equal(st[0]["tag_reads"].astype(np.int64), hist)
+                  and st[0]["n_queries_sent"] == n_slots + 1
+                  and st[0]["cur_inventory_round"] == n_slots // (1 << fixed_q) + 1)
+        return ok, ("ok: %d slots -> %d RN16 + %d EPC windows, %d of %d single-responder EPCs CRC-verified, per-tag "
+                    "read counts equal the slot table's" % (n_slots, n_slots, n_slots, int(st[0]["n_epc_correct"]), n_valid)
+                    if ok else "FAILED: windows %d (want %d), EPC ok %d (want %d)"
+                    % (int(st[0]["n_windows"]), 2 * n_slots, int(st[0]["n_epc_correct"]), n_valid))
+
+    def sample():
+        n = min(L, 24_000_000)     # the first ~1 750 slots of the trace
+        x = data[0, : 2 * n].cpu().numpy().view(np.complex64)
+        return x, "the first %d raw samples of the workload trace" % n
+
+    return dict(ctx=ctx, data=data, stride=stride, L=L, B=1, fixed_q=fixed_q, check=check, sample=sample,
+                describe="%s: one RX trace per GPU, FIXED_Q=%d (%d slots/round), %d rounds, %d tags (collisions and "
+                         "empty slots included), FM0 40 kHz BLF @ 2 Msps: %d raw I/Q samples (%.1f GB), sigma=%g, built in "
+                         "HBM by rfid_synth_gen2 from a %d-slot table (host planning %.1f s)"
+                         % (tag, fixed_q, 1 << fixed_q, n_rounds, n_tags, L, 8e-9 * L, args.sigma, n_slots, plan_s))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=1024, help="traces per GPU")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="1", choices=["1", "2", "3stream", "4shard"])
+    ap.add_argument("--streams", type=int, default=None, help="traces per GPU (configs 1 / 4shard)")
+    ap.add_argument("--rounds", type=int, default=None, help="inventory rounds of the single trace (configs 2 / 3stream)")
+    ap.add_argument("--tags", type=int, default=8, help="tags in the field (config 2)")
+    ap.add_argument("--hbm-frac", type=float, default=0.90, help="4shard: fraction of the free HBM to fill")
     ap.add_argument("--sigma", type=float, default=0.002)
     ap.add_argument("--seed", type=int, default=1000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 10 if args.config in ("1", "3stream") else 3
+    if args.warmup is None:
+        args.warmup = 2 if args.config in ("1", "3stream") else 1
 
     import torch
     import rfid
+    from rfid import synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -133,9 +221,22 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
     n_gpus = world
 
-    B = args.streams
-    ctx = rfid.Context(device=local_rank)
-    data, L, stride, base = build_batch(torch, ctx, device, B, args.sigma, args.seed, rank)
+    if args.config == "1":
+        wl = workload_replicas(torch, rfid, synth, args, device, rank, args.streams or 1024, "configs[1]")
+    elif args.config == "4shard":
+        B = args.streams
+        if B is None:
+            free, _ = torch.cuda.mem_get_info(device)
+            L0 = 1076066
+            per_trace = 8 * (L0 + 2) + 8 * (L0 // 5 + 2) + (L0 // 5 // 347 + 2) * PER_WINDOW_WS + 1056 + 1016
+            B = max(1, int(free * args.hbm_frac / per_trace))
+        wl = workload_replicas(torch, rfid, synth, args, device, rank, B, "configs[4], the per-GPU shard")
+    elif args.config == "2":
+        wl = workload_single_trace(torch, rfid, synth, args, device, rank, 4, args.rounds or 10000, args.tags, "configs[2]")
+    else:
+        wl = workload_single_trace(torch, rfid, synth, args, device, rank, 0, args.rounds or 2000, 1,
+                                   "configs[3], the per-GPU workload")
+    ctx, data, stride, L, B = wl["ctx"], wl["data"], wl["stride"], wl["L"], wl["B"]
     ctx.batch_plan(B, L)
     ptr = data.data_ptr()
 
@@ -151,34 +252,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    k_ms = {"mf_ms": 0.0, "gate_ms": 0.0, "decode_ms": 0.0, "stats_ms": 0.0, "front_ms": 0.0}
-    launches = {"front_chunks": 1, "decode_launches": 2}
-    fused = False
+    # ---- the timed region: exactly `steps` passes, nothing else ----------------------------------
+    step_s = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         step()
-        t = ctx.batch_timing()      # HIP events on the ctx stream, recorded around each kernel
-        for k in k_ms:
-            k_ms[k] += t[k]
-        launches = {"front_chunks": int(t["front_chunks"]), "decode_launches": int(t["decode_launches"])}
-        fused = bool(t["fused_front"])
+        step_s.append(time.perf_counter() - ts)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)     # control plane only: max time over ranks
         elapsed = float(tt.item())
-    for k in k_ms:
-        k_ms[k] /= max(args.steps, 1)
+
+    # ---- kernel durations: HIP events on the ctx stream around each launch, read in a separate (untimed)
+    #      series of the same passes so that the event reads stay out of the timed region -----------------
+    k_series = {"mf_ms": [], "gate_ms": [], "decode_ms": [], "stats_ms": [], "front_ms": []}
+    launches = {"front_chunks": 1, "decode_launches": 2}
+    fused = False
+    for _ in range(max(3, min(args.steps, 20))):
+        step()
+        t = ctx.batch_timing()
+        for k in k_series:
+            k_series[k].append(t[k])
+        launches = {"front_chunks": int(t["front_chunks"]), "decode_launches": int(t["decode_launches"])}
+        fused = bool(t["fused_front"])
+    k_ms = {k: statistics.fmean(v) for k, v in k_series.items()}
+    k_min = {k: min(v) for k, v in k_series.items()}
+    k_med = {k: statistics.median(v) for k, v in k_series.items()}
 
     # ---- result checks (size-independent properties of the workload) ----------------------
     st = ctx.batch_stats()
     n_epc_ok = int(st["n_epc_correct"].sum())
     n_windows = int(st["n_windows"].sum())
-    expect_ok = 70 * B
-    parity_ok = bool((st["n_epc_correct"] == 70).all() and (st["n_queries_sent"] == 72).all()
-                     and (st["tag_reads"][:, 0x27] == 70).all() and (st["n_unique_tags"] == 1).all())
+    parity_ok, parity_text = wl["check"](st)
 
     # ---- roofline: algorithmic bytes per launch / measured kernel time
     n_dec = L // 5
@@ -186,23 +295,25 @@ def main():
     n_epc = int(n_windows // 2)
     dec_bytes = n_rn16 * (8.0 * RN16_WIN + 48) + n_epc * (8.0 * EPC_WIN + 48)
     if fused:
-        # rfid_batch_process() default: one front-end launch (matched filter inside the gate's producer
+        # rfid_batch_process() default: one front-end launch (matched filter inside the gate's filter
         # waves): reads every raw sample once, writes y once for the decoder, writes the window records
         alg = {"front_end_fused": B * (8.0 * L + 8.0 * n_dec) + 24.0 * n_windows, "tag_decoder": dec_bytes}
-        dur_ms = {"front_end_fused": k_ms["gate_ms"], "tag_decoder": k_ms["decode_ms"]}
+        key = {"front_end_fused": "gate_ms", "tag_decoder": "decode_ms"}
         n_launch = {"front_end_fused": 1, "tag_decoder": launches["decode_launches"]}
     else:
         alg = {"mf_boxcar25_decim5": B * (8.0 * L + 8.0 * n_dec),
                "gate_scan": B * 8.0 * n_dec + 24.0 * n_windows, "tag_decoder": dec_bytes}
-        dur_ms = {"mf_boxcar25_decim5": k_ms["mf_ms"], "gate_scan": k_ms["gate_ms"], "tag_decoder": k_ms["decode_ms"]}
+        key = {"mf_boxcar25_decim5": "mf_ms", "gate_scan": "gate_ms", "tag_decoder": "decode_ms"}
         n_launch = {"mf_boxcar25_decim5": launches["front_chunks"], "gate_scan": launches["front_chunks"],
                     "tag_decoder": launches["decode_launches"]}
-    traffic = {}
+    traffic, traffic_source = {}, None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pt = json.load(f)
         if pt.get("streams") == B and pt.get("raw_per_stream") == L:
             traffic = pt.get("hbm_bytes_per_step", {})
+            traffic_source = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of "
+                              "this workload (%s); a committed cross-reference, NOT measured in this run" % pt.get("source", "?"))
     except Exception:
         pass
 
@@ -210,14 +321,19 @@ def main():
         # a pass issues n_launch launches of this kernel (time chunks / window types), each moving
         # 1/n_launch of the bytes: the per-launch ratio equals the per-pass ratio
         nl = max(1, n_launch[name])
-        ach = alg[name] / (dur_ms[name] * 1e-3) / 1e9 if dur_ms[name] > 0 else 0.0
+        dur = k_ms[key[name]]
+        ach = alg[name] / (dur * 1e-3) / 1e9 if dur > 0 else 0.0
         tr = traffic.get(name)
         return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": (int(tr / nl) if tr else None),
+                "traffic_source": traffic_source if tr else None,
                 "algorithmic_bytes": int(alg[name] / nl), "launches_per_step": nl,
-                "avg_launch_ms": round(dur_ms[name] / nl, 4), "ms_per_step": round(dur_ms[name], 4)}
+                "avg_launch_ms": round(dur / nl, 4), "ms_per_step": round(dur, 4),
+                "min_ms_per_step": round(k_min[key[name]], 4), "median_ms_per_step": round(k_med[key[name]], 4),
+                "timing": "HIP events on the library's stream around each launch, %d untimed passes after the timed region"
+                          % len(k_series["gate_ms"])}
 
-    dominant = max(dur_ms, key=lambda k: dur_ms[k])
+    dominant = max(alg, key=lambda k: k_ms[key[k]])
     total_raw = float(B) * L * args.steps * n_gpus
     out = {
         "metric": "I/Q Msamples/s through matched_filter->gate->tag_decoder (+ EPC decodes/s), 40 kHz FM0",
@@ -225,30 +341,35 @@ def main():
         "unit": "Msamples/s",
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "min_ms_per_step": round(min(step_s) * 1e3, 4), "median_ms_per_step": round(statistics.median(step_s) * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: batch of %d noise-replicas per GPU of the 71-round file_source_test "
-                               "stand-in trace, FM0 40 kHz BLF @ 2 Msps (%d raw I/Q samples each, sigma=%g), "
-                               "resident in HBM" % (B, L, args.sigma),
-                   "streams_per_gpu": B, "raw_samples_per_stream": L, "parallelism": "traces sharded per GPU, no collective"},
+        "config": {"workload": wl["describe"], "streams_per_gpu": B, "raw_samples_per_stream": L,
+                   "hbm_bytes_traces": int(8 * stride * B),
+                   "parallelism": "traces sharded per GPU, no collective"},
         "epc_decodes_per_s": round(n_epc_ok * n_gpus * args.steps / elapsed, 1),
         "decoder_gated_msamples_per_s": round((n_rn16 * RN16_WIN + n_epc * EPC_WIN) / (k_ms["decode_ms"] * 1e-3) / 1e6, 1)
         if k_ms["decode_ms"] > 0 else None,
         "windows_per_step": n_windows,
-        "parity_check": "ok: every replica 70/71 EPC, tag 0x27" if parity_ok else
-                        "FAILED: %d EPC ok, expected %d" % (n_epc_ok, expect_ok),
+        "parity_check": parity_text,
         "roofline": roof(dominant),
         "roofline_by_kernel": {k: roof(k) for k in alg},
         "front_end_ms": round(k_ms["front_ms"], 4),
     }
-    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(base.samples, args.sigma, args.cpu_seconds)
+    if B == 1:
+        out["single_stream"] = {"raw_msamples_per_s": round(L / (elapsed / args.steps) / 1e6, 2),
+                                "x_realtime_at_2Msps": round(L / (elapsed / args.steps) / 2e6, 1)}
+    if rank == 0 and not args.no_cpu_baseline:
+        # rank 0 only (N = 1 and N > 1 alike): the same host serves all ranks
+        x, what = wl["sample"]()
+        out["cpu_baseline"] = cpu_baseline(x, args.cpu_seconds, fixed_q=wl["fixed_q"], what=what)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
     ctx.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
     if not parity_ok:
         raise SystemExit(2)

@@ -556,8 +556,7 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
   int nch = 1;
   if (const char *e = getenv("RFID_FRONT_CHUNKS")) nch = atoi(e);
   if (nch > rfid_ctx::MAX_CHUNKS) nch = rfid_ctx::MAX_CHUNKS;
-  // (the fused kernel indexes the raw samples of a trace with 32 bits; longer traces take the stage kernels)
-  if (nch < 2 && raw_stride >= 2 && raw_stride <= 0x7fffff00LL && !getenv("RFID_FRONT_UNFUSED")) {
+  if (nch < 2 && raw_stride >= 2 && !getenv("RFID_FRONT_UNFUSED")) {
     // default: fused front end -- the gate's producer waves run the matched filter themselves
     // (one read of the raw samples, one write of y for the decoder, no second pass over y)
     HIPCHK(c, hipSetDevice(c->device));

@@ -692,20 +692,28 @@ struct GateRawRegs {
 // s_waitcnt right behind the load and drain the prefetch): the index is clamped into the row
 // instead.  Samples below index 0 are zeroed when the step is consumed (gate_fir_step, first
 // step only); samples at or above the trace length only feed outputs that do not exist.
-RFID_DEVICE void gate_load_raw(GateRawRegs &r, const float2 *xs, int hi_idx, int r0, int lane, bool vec) {
-  // r0 = raw index of the first sample of the step's window (even; -24 for the first step)
+RFID_DEVICE void gate_load_raw(GateRawRegs &r, const float2 *xs, int64_t hi_idx, int64_t r0, int lane, bool vec) {
+  // r0 = raw index of the first sample of the step's window (even; -24 for the first step), wave-uniform and
+  // 64 bits wide (a trace may hold more than 2^31 raw samples): the step's base pointer is scalar, the lane
+  // offsets and their clamps are 32-bit
+  const float2 *p = xs + r0;
+  const int lo = (r0 < 0) ? (int)(-r0) : 0;
+  int64_t hrel = hi_idx - r0;
+  hrel = (hrel > (1 << 30)) ? (1 << 30) : hrel;
+  hrel = (hrel < -(1 << 30)) ? -(1 << 30) : hrel;
+  const int hi = (int)hrel;
 #pragma unroll
   for (int j = 0; j < GATE_RAW_LD; ++j) {
     int q = lane + 64 * j;
     q = (q < GATE_RAW4) ? q : (GATE_RAW4 - 1);
-    int ri = r0 + 2 * q;
-    ri = (ri < 0) ? 0 : ri;
-    ri = (ri > hi_idx) ? hi_idx : ri;
+    int ri = 2 * q;
+    ri = (ri < lo) ? lo : ri;
+    ri = (ri > hi) ? hi : ri;
     if (vec) {
-      r.v[j] = *reinterpret_cast<const float4 *>(xs + ri);
+      r.v[j] = *reinterpret_cast<const float4 *>(p + ri);
     } else {
-      const float2 lo = xs[ri], hi = xs[ri + 1];
-      r.v[j] = make_float4(lo.x, lo.y, hi.x, hi.y);
+      const float2 lo2 = p[ri], hi2 = p[ri + 1];
+      r.v[j] = make_float4(lo2.x, lo2.y, hi2.x, hi2.y);
     }
   }
 }
@@ -776,9 +784,9 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
       const float2 *xs = a.raw + (int64_t)s * a.raw_stride;
       const bool vec = a.raw_vec_ok != 0;
       // last index a (two-sample) load may start at: inside the row's stride (rows are contiguous)
-      const int hi_idx = vec ? (int)((a.raw_stride - 2) & ~(int64_t)1) : (int)(a.raw_stride - 2);
+      const int64_t hi_idx = vec ? ((a.raw_stride - 2) & ~(int64_t)1) : (a.raw_stride - 2);
       float2 *yw = a.y_w + (int64_t)s * a.y_stride + a.pos0;
-      const int rbase = (int)a.pos0 * DECIM - (NTAPS - 1);   // raw index of the window of output pos0
+      const int64_t rbase = a.pos0 * DECIM - (NTAPS - 1);   // raw index of the window of output pos0
       // Rolling prefetch: the raw samples of the next GATE_RAW_DEPTH steps are in flight at all times
       // (a register set is reloaded right after its step went to LDS) -- with 1024 filter waves
       // on the device HBM needs that many bytes outstanding to stream.  The main loop runs over
@@ -792,7 +800,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
         GateRawRegs buf[GATE_RAW_DEPTH];
 #pragma unroll
         for (int u = 0; u < GATE_RAW_DEPTH; ++u) {
-          gate_load_raw(buf[u], xs, hi_idx, rbase + u * 64 * DECIM, lane, vec);
+          gate_load_raw(buf[u], xs, hi_idx, rbase + (int64_t)u * 64 * DECIM, lane, vec);
           wv::compiler_fence();                       // keep the issue order: step 0 first
         }
         for (int grp = 0; grp < ngroups; ++grp) {
@@ -804,7 +812,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
             while (k - wv::lds_load(&sh.cons_seq) >= GATE_SLOTS) wv::backoff();
             if (PROF) { t1 = wv::ticks(); p_wait += t1 - tw; }
             const float2 yv = gate_fir_step(buf[u], sh.rawtile, lane, u == 0 && grp == 0 && at_start);
-            gate_load_raw(buf[u], xs, hi_idx, rbase + (k + GATE_RAW_DEPTH) * 64 * DECIM, lane, vec);
+            gate_load_raw(buf[u], xs, hi_idx, rbase + (int64_t)(k + GATE_RAW_DEPTH) * 64 * DECIM, lane, vec);
             yw[64 * k + lane] = yv;
             sh.slots[k % GATE_SLOTS].yv[lane] = yv;
             wv::lds_store(&sh.fir_seq, k + 1, lane);   // after the slot's data (in-order LDS queue)
@@ -816,7 +824,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
       for (int k = ngroups * GATE_RAW_DEPTH; k < nsteps; ++k) {
         while (k - wv::lds_load(&sh.cons_seq) >= GATE_SLOTS) wv::backoff();
         GateRawRegs r;
-        gate_load_raw(r, xs, hi_idx, rbase + k * 64 * DECIM, lane, vec);
+        gate_load_raw(r, xs, hi_idx, rbase + (int64_t)k * 64 * DECIM, lane, vec);
         float2 yv = gate_fir_step(r, sh.rawtile, lane, k == 0 && at_start);
         if (64 * k + lane < n) yw[64 * k + lane] = yv;
         else yv = make_float2(0.0f, 0.0f);
