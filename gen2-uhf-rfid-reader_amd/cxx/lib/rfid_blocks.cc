@@ -1,0 +1,305 @@
+// rfid_blocks.cc -- gr::rfid::{gate, tag_decoder, reader}::make and the shared reader_state of the reference's
+// block API (cxx/include/rfid/*.h), implemented on the MI355X C-ABI (include/rfid_mi355x.h): every general_work()
+// is ONE C-ABI call that hands the scheduler's buffer to the HIP kernels and translates the returned counts into
+// consume_each() / produce() / the return value exactly as the reference's blocks do
+// (lib/gate_impl.cc:79-83,198-199; lib/tag_decoder_impl.cc:72-76,266,395-396; lib/reader_impl.cc:194-198,378-379).
+// No sample arithmetic happens here and there is no CPU fallback: gate::make() throws without a gfx950 device.
+#include <rfid/mi355x.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace gr {
+namespace rfid {
+
+READER_STATE *reader_state = nullptr;   // include/rfid/global_vars.h:146 (allocated by the gate, lib/gate_impl.cc:67-69)
+
+namespace {
+
+// one RX stream: the C-ABI context + the READER_STATE mirror the reference's API exposes
+struct stream {
+  rfid_ctx *ctx = nullptr;
+  rfid_params params;
+  READER_STATE mirror;
+  bool has_filter = false;   // a matched_filter block is bound to this stream
+  ~stream() { if (ctx) rfid_ctx_destroy(ctx); if (reader_state == &mirror) reader_state = nullptr; }
+  void check(int st, const char *what) const {
+    if (st != RFID_OK)
+      throw mi355x::error(st, std::string(what) + ": " + rfid_strerror(st) + " (" + rfid_last_error(ctx) + ")");
+  }
+  void refresh() {   // READER_STATE <- rfid_reader_state
+    rfid_reader_state s;
+    check(rfid_get_state(ctx, &s), "rfid_get_state");
+    mirror.status = (STATUS)s.status;
+    mirror.gen2_logic_status = (GEN2_LOGIC_STATUS)s.gen2_logic_status;
+    mirror.gate_status = (GATE_STATUS)s.gate_status;
+    mirror.decoder_status = (DECODER_STATUS)s.decoder_status;
+    mirror.n_samples_to_ungate = s.n_samples_to_ungate;
+    READER_STATS &r = mirror.reader_stats;
+    r.n_queries_sent = s.n_queries_sent; r.cur_inventory_round = s.cur_inventory_round;
+    r.cur_slot_number = s.cur_slot_number; r.max_slot_number = s.max_slot_number;
+    r.max_inventory_round = MAX_INVENTORY_ROUND; r.n_epc_correct = s.n_epc_correct;
+    r.tag_reads.clear();
+    for (int id = 0; id < 256; ++id)
+      if (s.tag_reads[id]) r.tag_reads[id] = s.tag_reads[id];
+  }
+};
+typedef std::shared_ptr<stream> stream_sptr;
+
+struct next_config { int device = 0; rfid_params p; bool set = false; } g_next;
+// Binding rule = the reference's construction order (apps/reader.py:75-78), per thread: tag_decoder / reader bind at
+// construction to the stream of the most recent gate; a matched_filter binds to it too unless that stream already
+// has one -- then, or when no gate exists yet (apps/reader.py:75 builds the filter first), it waits for the next gate.
+thread_local stream_sptr g_current;
+thread_local std::vector<stream_sptr *> g_pending_filters;
+
+int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+
+stream_sptr current_or_throw(const char *who) {
+  if (!g_current)
+    throw mi355x::error(RFID_ERR_STATE, std::string(who) + ": construct gr::rfid::gate first -- it owns the shared reader "
+                                        "state (lib/gate_impl.cc:67-69, apps/reader.py:76-78)");
+  return g_current;
+}
+
+// ---- gate ------------------------------------------------------------------------------------------
+class gate_impl : public gate {
+ public:
+  explicit gate_impl(int sample_rate)
+      : gr::block("gate", gr::io_signature::make(1, 1, sizeof(gr_complex)), gr::io_signature::make(1, 1, sizeof(gr_complex))) {
+    stream_sptr s(new stream());
+    rfid_params_default(&s->params);
+    int device = env_int("RFID_DEVICE", 0);
+    s->params.fixed_q = env_int("RFID_FIXED_Q", FIXED_Q);
+    s->params.max_num_queries = env_int("RFID_MAX_NUM_QUERIES", MAX_NUM_QUERIES);
+    s->params.number_unique_tags = env_int("RFID_NUMBER_UNIQUE_TAGS", NUMBER_UNIQUE_TAGS);
+    if (g_next.set) { device = g_next.device; s->params = g_next.p; }
+    s->params.sample_rate = sample_rate;
+    const int st = rfid_ctx_create(&s->params, device, &s->ctx);
+    if (st != RFID_OK)
+      throw mi355x::error(st, std::string("gr::rfid::gate: rfid_ctx_create: ") + rfid_strerror(st) +
+                                  " (the MI355X receive path has no CPU fallback)");
+    d_stream = s;
+    g_current = s;
+    if (!g_pending_filters.empty()) {
+      *g_pending_filters.front() = s;
+      g_pending_filters.erase(g_pending_filters.begin());
+      s->has_filter = true;
+    }
+    gettimeofday(&s->mirror.reader_stats.start, nullptr);
+    initialize_reader_state();   // lib/gate_impl.cc:69
+  }
+  void forecast(int noutput_items, gr_vector_int &ninput_items_required) override {
+    ninput_items_required[0] = noutput_items;   // lib/gate_impl.cc:79-83
+  }
+  int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
+                   gr_vector_void_star &output_items) override {
+    const int n_items = std::min(ninput_items[0], noutput_items);   // lib/gate_impl.cc:91
+    const GATE_STATUS before = d_stream->mirror.gate_status;
+    int consumed = 0, written = 0;
+    d_stream->check(rfid_gate_work(d_stream->ctx, (const rfid_cf32 *)input_items[0], n_items, (rfid_cf32 *)output_items[0],
+                                   noutput_items, &consumed, &written), "rfid_gate_work");
+    d_stream->refresh();
+    if (written > 0) {   // magn_squared_samples side channel (lib/gate_impl.cc:171,175,186)
+      std::vector<float> &m2 = d_stream->mirror.magn_squared_samples;
+      if (before != GATE_OPEN) m2.clear();
+      const gr_complex *o = (const gr_complex *)output_items[0];
+      for (int i = 0; i < written; ++i) m2.push_back(std::norm(o[i]));
+    }
+    consume_each(consumed);   // lib/gate_impl.cc:198
+    return written;           // :199
+  }
+  stream_sptr d_stream;
+};
+
+// ---- tag_decoder ------------------------------------------------------------------------------------
+class tag_decoder_impl : public tag_decoder {
+ public:
+  explicit tag_decoder_impl(int sample_rate)
+      : gr::block("tag_decoder", gr::io_signature::make(1, 1, sizeof(gr_complex)),
+                  gr::io_signature::makev(2, 2, std::vector<int>{(int)sizeof(float), (int)sizeof(gr_complex)})),   // lib/tag_decoder_impl.cc:39-41
+        d_stream(current_or_throw("gr::rfid::tag_decoder")) {
+    if (sample_rate != d_stream->params.sample_rate)
+      throw mi355x::error(RFID_ERR_INVALID, "gr::rfid::tag_decoder: sample_rate differs from the gate's");
+  }
+  void forecast(int noutput_items, gr_vector_int &ninput_items_required) override {
+    ninput_items_required[0] = noutput_items;   // lib/tag_decoder_impl.cc:72-76
+  }
+  int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
+                   gr_vector_void_star &output_items) override {
+    int consumed = 0, produced0 = 0;
+    d_stream->check(rfid_decoder_work(d_stream->ctx, (const rfid_cf32 *)input_items[0], ninput_items[0], (float *)output_items[0],
+                                      noutput_items, &consumed, &produced0, nullptr, nullptr), "rfid_decoder_work");
+    d_stream->refresh();
+    if (produced0 > 0) produce(0, produced0);   // lib/tag_decoder_impl.cc:266 (port 1, the complex debug port, never produces)
+    consume_each(consumed);                     // :395
+    return WORK_CALLED_PRODUCE;                 // :396
+  }
+  stream_sptr d_stream;
+};
+
+// ---- reader -----------------------------------------------------------------------------------------
+class reader_impl : public reader {
+ public:
+  reader_impl(int sample_rate, int dac_rate)
+      : gr::block("reader", gr::io_signature::make(1, 1, sizeof(float)), gr::io_signature::make(1, 1, sizeof(float))),
+        d_stream(current_or_throw("gr::rfid::reader")), d_dac_rate(dac_rate) {
+    (void)sample_rate;
+  }
+  void forecast(int, gr_vector_int &ninput_items_required) override { ninput_items_required[0] = 0; }   // lib/reader_impl.cc:194-198
+  int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
+                   gr_vector_void_star &output_items) override {
+    int consumed = 0, written = 0;
+    d_stream->check(rfid_reader_work_tx(d_stream->ctx, d_dac_rate, (const float *)input_items[0], ninput_items[0],
+                                        (float *)output_items[0], noutput_items, &consumed, &written), "rfid_reader_work_tx");
+    d_stream->refresh();
+    consume_each(consumed);   // lib/reader_impl.cc:378
+    return written;           // :379
+  }
+  void print_results() override {   // lib/reader_impl.cc:173-192
+    std::vector<char> buf(1 << 15);
+    int len = 0;
+    d_stream->check(rfid_print_results(d_stream->ctx, buf.data(), (int)buf.size(), &len), "rfid_print_results");
+    fwrite(buf.data(), 1, (size_t)len, stdout);
+    fflush(stdout);
+  }
+  stream_sptr d_stream;
+  int d_dac_rate;
+};
+
+// ---- matched filter (replaces the third-party filter.fir_filter_ccc(5,[1]*25), apps/reader.py:65,75) -------
+class matched_filter_impl : public matched_filter {
+ public:
+  matched_filter_impl(int decim, const std::vector<gr_complex> &taps)
+      : gr::block("matched_filter", gr::io_signature::make(1, 1, sizeof(gr_complex)), gr::io_signature::make(1, 1, sizeof(gr_complex))),
+        d_slot(new stream_sptr()) {
+    if (decim != 5 || taps.size() != 25) throw mi355x::error(RFID_ERR_UNSUPPORTED, "only fir_filter_ccc(5, [1]*25) is built");
+    for (const gr_complex &t : taps)
+      if (t != gr_complex(1.0f, 0.0f)) throw mi355x::error(RFID_ERR_UNSUPPORTED, "only all-ones taps are built");
+    if (g_current && !g_current->has_filter) { *d_slot = g_current; g_current->has_filter = true; }
+    else g_pending_filters.push_back(d_slot.get());
+  }
+  ~matched_filter_impl() {
+    for (size_t i = 0; i < g_pending_filters.size(); ++i)
+      if (g_pending_filters[i] == d_slot.get()) { g_pending_filters.erase(g_pending_filters.begin() + (long)i); break; }
+  }
+  void forecast(int noutput_items, gr_vector_int &ninput_items_required) override { ninput_items_required[0] = noutput_items * 5; }
+  int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
+                   gr_vector_void_star &output_items) override {
+    if (!*d_slot) throw mi355x::error(RFID_ERR_STATE, "gr::rfid::matched_filter: no gate constructed yet");
+    stream &st = **d_slot;
+    int n_out = 0;
+    st.check(rfid_mf_work(st.ctx, (const rfid_cf32 *)input_items[0], ninput_items[0], (rfid_cf32 *)output_items[0],
+                          noutput_items, &n_out), "rfid_mf_work");
+    consume_each(ninput_items[0]);
+    return n_out;
+  }
+  std::unique_ptr<stream_sptr> d_slot;   // bound now or by the next gate
+};
+
+}  // namespace
+
+// ---- the reference's public symbols --------------------------------------------------------------------
+void initialize_reader_state() {   // lib/global_vars.cc:34-54: state of the current stream back to its initial values
+  stream_sptr s = current_or_throw("initialize_reader_state");
+  s->check(rfid_ctx_reset(s->ctx), "rfid_ctx_reset");
+  s->mirror.magn_squared_samples.clear();
+  s->mirror.reader_stats.unique_tags_round.clear();
+  s->refresh();
+  reader_state = &s->mirror;
+}
+
+gate::sptr gate::make(int sample_rate) { return gnuradio::get_initial_sptr(new gate_impl(sample_rate)); }
+tag_decoder::sptr tag_decoder::make(int sample_rate) { return gnuradio::get_initial_sptr(new tag_decoder_impl(sample_rate)); }
+reader::sptr reader::make(int sample_rate, int dac_rate) { return gnuradio::get_initial_sptr(new reader_impl(sample_rate, dac_rate)); }
+matched_filter::sptr matched_filter::make(int decim, const std::vector<gr_complex> &taps) {
+  return gnuradio::get_initial_sptr(new matched_filter_impl(decim, taps));
+}
+
+namespace mi355x {
+
+void configure(int device, int fixed_q, int max_num_queries, int number_unique_tags) {
+  rfid_params_default(&g_next.p);
+  g_next.device = device;
+  g_next.p.fixed_q = fixed_q;
+  g_next.p.max_num_queries = max_num_queries;
+  g_next.p.number_unique_tags = number_unique_tags;
+  g_next.set = true;
+}
+
+rfid_ctx *current_context() { return g_current ? g_current->ctx : nullptr; }
+
+#ifdef GR_RFID_MINIRT
+sts_flowgraph::sts_flowgraph(matched_filter::sptr mf, gate::sptr g, tag_decoder::sptr d, reader::sptr r, int chunk)
+    : d_mf(mf), d_gate(g), d_dec(d), d_reader(r), d_chunk(chunk), d_bits(16, 0.0f) {
+  d_txbuf.assign((size_t)rfid_reader_tx_max(1000000) * 4, 0.0f);
+}
+
+void sts_flowgraph::reader_until_idle(int n_items) {
+  for (int it = 0; it < 8; ++it) {
+    const int before = reader_state->gen2_logic_status;
+    if (before == IDLE) break;
+    gr_vector_int nin(1, n_items);
+    gr_vector_const_void_star in(1, d_bits.data());
+    gr_vector_void_star out(1, d_txbuf.data());
+    d_reader->minirt_begin_work();
+    const int written = d_reader->general_work((int)d_txbuf.size(), nin, in, out);
+    if (d_keep_tx) d_tx.insert(d_tx.end(), d_txbuf.begin(), d_txbuf.begin() + written);
+    n_items = 0;
+    if (reader_state->gen2_logic_status == before) break;
+  }
+}
+
+void sts_flowgraph::run(const gr_complex *samples, size_t n) {
+  reader_until_idle(0);   // START -> SEND_QUERY -> IDLE
+  std::vector<gr_complex> gq, dq, mf_out((size_t)d_chunk + 8), gate_out((size_t)d_chunk);
+  size_t pos = 0;
+  while (pos < n || !gq.empty()) {
+    if (pos < n) {
+      const size_t take = (n - pos < (size_t)d_chunk * 5) ? (n - pos) : (size_t)d_chunk * 5;
+      gr_vector_int nin(1, (int)take);
+      gr_vector_const_void_star in(1, samples + pos);
+      gr_vector_void_star out(1, mf_out.data());
+      d_mf->minirt_begin_work();
+      const int produced = d_mf->general_work((int)mf_out.size(), nin, in, out);
+      gq.insert(gq.end(), mf_out.begin(), mf_out.begin() + produced);
+      if (d_keep_taps) d_tap_mf.insert(d_tap_mf.end(), mf_out.begin(), mf_out.begin() + produced);
+      pos += take;
+    }
+    while (!gq.empty()) {
+      const int avail = (int)(gq.size() < (size_t)d_chunk ? gq.size() : (size_t)d_chunk);
+      gr_vector_int nin(1, avail);
+      gr_vector_const_void_star in(1, gq.data());
+      gr_vector_void_star out(1, gate_out.data());
+      d_gate->minirt_begin_work();
+      const int written = d_gate->general_work(avail, nin, in, out);
+      const int consumed = d_gate->minirt_consumed();
+      gq.erase(gq.begin(), gq.begin() + consumed);
+      dq.insert(dq.end(), gate_out.begin(), gate_out.begin() + written);
+      if (d_keep_taps) d_tap_gate.insert(d_tap_gate.end(), gate_out.begin(), gate_out.begin() + written);
+      for (;;) {
+        gr_vector_int dn(1, (int)dq.size());
+        gr_vector_const_void_star din(1, dq.data());
+        gr_vector_void_star dout(2, nullptr);
+        dout[0] = d_bits.data();
+        d_dec->minirt_begin_work();
+        d_dec->general_work((int)d_bits.size(), dn, din, dout);
+        const int dcons = d_dec->minirt_consumed();
+        if (dcons == 0) break;
+        d_windows++;
+        dq.erase(dq.begin(), dq.begin() + dcons);
+        reader_until_idle(d_dec->minirt_produced(0));
+      }
+      if (consumed == 0) break;
+    }
+  }
+}
+#endif
+
+}  // namespace mi355x
+}  // namespace rfid
+}  // namespace gr

@@ -1,41 +1,57 @@
-// rfid_reader_offline -- the offline (DEBUG = True) flowgraph of gr-rfid/apps/reader.py:101-112 in C++:
-//   file_source(misc/data/file_source_test) -> matched_filter -> gate -> tag_decoder -> reader
-// driven buffer by buffer through the block adaptors of rfid_blocks.hpp (one C-ABI call per
-// general_work), then reader.print_results() (apps/reader.py:130; lib/reader_impl.cc:173-192).
+// rfid_reader_offline -- the offline (DEBUG = True) flowgraph of gr-rfid/apps/reader.py:101-112 in C++, written
+// against the reference's own block API (cxx/include/rfid/{gate,tag_decoder,reader,global_vars}.h = the classes,
+// factories and the `reader_state` global of gr-rfid/include/rfid/*.h):
+//   file_source(misc/data/file_source_test) -> matched_filter -> gate -> tag_decoder -> reader ; reader.print_results()
+// Blocks are made in the order and with the arguments of apps/reader.py:75-78 -- gate::make(int),
+// tag_decoder::make(int), reader::make(int,int), nothing else -- and driven buffer by buffer (one C-ABI call per
+// general_work) by the single-threaded scheduler of rfid/mi355x.h.
 //
 //   rfid_reader_offline TRACE_FILE [--device N] [--chunk N] [--fixed-q Q] [--max-queries N] [--unique-tags N]
-//                       [--tx-out FILE]   (the reader block's output, float32: apps/reader.py's file_sink_reader)
+//                       [--tx-out FILE]    the reader block's output, float32 (apps/reader.py's file_sink_reader)
+//                       [--mf-out FILE]    matched-filter output, complex64     (file_sink_matched_filter, :69)
+//                       [--gate-out FILE]  gated samples, complex64            (file_sink_gate, :70)
 //
 // TRACE_FILE: headerless little-endian interleaved float32 I,Q at 2 Msps (apps/reader.py:102).
 // Exit codes: 0 ok, 2 usage / file error, 3 no gfx950 device (there is no CPU fallback), 4 other library error.
+#include <rfid/mi355x.h>
+
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
 
-#include "rfid_blocks.hpp"
+namespace {
+template <class T>
+bool dump(const char *path, const std::vector<T> &v) {
+  std::ofstream o(path, std::ios::binary);
+  o.write(reinterpret_cast<const char *>(v.data()), (std::streamsize)(v.size() * sizeof(T)));
+  return (bool)o;
+}
+}  // namespace
 
 int main(int argc, char **argv) {
-  const char *path = nullptr, *tx_path = nullptr;
+  const char *path = nullptr, *tx_path = nullptr, *mf_path = nullptr, *gate_path = nullptr;
   int device = 0, chunk = 8192;
-  rfid_params p;
-  rfid_params_default(&p);
+  int fixed_q = gr::rfid::FIXED_Q, max_q = gr::rfid::MAX_NUM_QUERIES, uniq = gr::rfid::NUMBER_UNIQUE_TAGS;
   for (int i = 1; i < argc; ++i) {
-    auto need = [&](const char *flag) -> int {
+    auto need = [&](const char *flag) -> const char * {
       if (i + 1 >= argc) { std::cerr << flag << " needs a value\n"; std::exit(2); }
-      return std::atoi(argv[++i]);
+      return argv[++i];
     };
-    if (!std::strcmp(argv[i], "--device")) device = need("--device");
-    else if (!std::strcmp(argv[i], "--chunk")) chunk = need("--chunk");
-    else if (!std::strcmp(argv[i], "--fixed-q")) p.fixed_q = need("--fixed-q");
-    else if (!std::strcmp(argv[i], "--max-queries")) p.max_num_queries = need("--max-queries");
-    else if (!std::strcmp(argv[i], "--unique-tags")) p.number_unique_tags = need("--unique-tags");
-    else if (!std::strcmp(argv[i], "--tx-out")) { if (i + 1 >= argc) return 2; tx_path = argv[++i]; }
+    if (!std::strcmp(argv[i], "--device")) device = std::atoi(need("--device"));
+    else if (!std::strcmp(argv[i], "--chunk")) chunk = std::atoi(need("--chunk"));
+    else if (!std::strcmp(argv[i], "--fixed-q")) fixed_q = std::atoi(need("--fixed-q"));
+    else if (!std::strcmp(argv[i], "--max-queries")) max_q = std::atoi(need("--max-queries"));
+    else if (!std::strcmp(argv[i], "--unique-tags")) uniq = std::atoi(need("--unique-tags"));
+    else if (!std::strcmp(argv[i], "--tx-out")) tx_path = need("--tx-out");
+    else if (!std::strcmp(argv[i], "--mf-out")) mf_path = need("--mf-out");
+    else if (!std::strcmp(argv[i], "--gate-out")) gate_path = need("--gate-out");
     else if (argv[i][0] == '-') { std::cerr << "unknown option " << argv[i] << "\n"; return 2; }
     else path = argv[i];
   }
   if (!path || chunk < 64) {
-    std::cerr << "usage: rfid_reader_offline TRACE_FILE [--device N] [--chunk N] [--fixed-q Q] [--max-queries N] [--unique-tags N] [--tx-out FILE]\n";
+    std::cerr << "usage: rfid_reader_offline TRACE_FILE [--device N] [--chunk N] [--fixed-q Q] [--max-queries N] "
+                 "[--unique-tags N] [--tx-out FILE] [--mf-out FILE] [--gate-out FILE]\n";
     return 2;
   }
   std::ifstream f(path, std::ios::binary | std::ios::ate);
@@ -49,27 +65,31 @@ int main(int argc, char **argv) {
   }
 
   try {
+    using namespace gr::rfid;
+    mi355x::configure(device, fixed_q, max_q, uniq);   // what the reference fixes at compile time (global_vars.h:72,76,100)
     // variables of apps/reader.py:52-65
     const double dac_rate = 1e6, adc_rate = 100e6 / 50;
     const int decim = 5;
     const std::vector<gr_complex> num_taps(25, gr_complex(1.0f, 0.0f));
-    const int rate = (int)(adc_rate / decim);
-    // construction order of apps/reader.py:75-78: the gate owns the shared reader state
-    blocks::gate::sptr gate = blocks::gate::make(rate, device, &p);
-    blocks::matched_filter::sptr mf = blocks::matched_filter::make(decim, num_taps, gate->context());
-    blocks::tag_decoder::sptr dec = blocks::tag_decoder::make(rate, gate->context());
-    blocks::reader::sptr reader = blocks::reader::make(rate, (int)dac_rate, gate->context());
-    rfid_rt::sts_scheduler tb(mf, gate, dec, reader, chunk);
+    // blocks of apps/reader.py:75-78, same order, same arguments (the gate owns the shared reader state)
+    matched_filter::sptr mf = matched_filter::make(decim, num_taps);   // (built before the gate, as at :75)
+    gate::sptr gate_blk = gate::make(int(adc_rate / decim));
+    tag_decoder::sptr dec = tag_decoder::make(int(adc_rate / decim));
+    reader::sptr reader_blk = reader::make(int(adc_rate / decim), int(dac_rate));
+    mi355x::sts_flowgraph tb(mf, gate_blk, dec, reader_blk, chunk);
     tb.keep_tx(tx_path != nullptr);
+    tb.keep_taps(mf_path != nullptr || gate_path != nullptr);
     tb.run(samples.data(), samples.size());
-    reader->print_results();
-    if (tx_path) {
-      std::ofstream o(tx_path, std::ios::binary);
-      const std::vector<float> &tx = tb.tx_samples();
-      o.write(reinterpret_cast<const char *>(tx.data()), (std::streamsize)(tx.size() * sizeof(float)));
-      if (!o) { std::cerr << "cannot write " << tx_path << "\n"; return 2; }
-    }
-  } catch (const rfid_rt::error &e) {
+    reader_blk->print_results();   // apps/reader.py:130
+    if (getenv("RFID_PRINT_READER_STATE"))   // the reference's global, for tests of the mirror
+      std::cout << "reader_state: n_queries_sent=" << reader_state->reader_stats.n_queries_sent
+                << " n_epc_correct=" << reader_state->reader_stats.n_epc_correct
+                << " unique=" << reader_state->reader_stats.tag_reads.size()
+                << " gate_status=" << reader_state->gate_status << " windows=" << tb.windows_decoded() << "\n";
+    if (tx_path && !dump(tx_path, tb.tx_samples())) { std::cerr << "cannot write " << tx_path << "\n"; return 2; }
+    if (mf_path && !dump(mf_path, tb.tap_matched_filter())) { std::cerr << "cannot write " << mf_path << "\n"; return 2; }
+    if (gate_path && !dump(gate_path, tb.tap_gate())) { std::cerr << "cannot write " << gate_path << "\n"; return 2; }
+  } catch (const gr::rfid::mi355x::error &e) {
     std::cerr << "rfid_reader_offline: " << e.what() << "\n";
     return e.status == RFID_ERR_NO_DEVICE ? 3 : 4;
   }

@@ -5,25 +5,39 @@
     rfid.reader(sample_rate, dac)   <- gr::rfid::reader::make        (include/rfid/reader.h:51)
     rfid.matched_filter(decim,taps) <- filter.fir_filter_ccc         (apps/reader.py:75)
 
-As in the reference, the gate block is constructed first and owns the shared reader state
-(lib/gate_impl.cc:67-69): here that state lives in an rfid.Context (one per RX stream); the
-other blocks attach to the context of the most recently constructed gate unless one is
-passed explicitly.  Each block's general_work() hands its buffer through the C-ABI to the
-HIP kernels and returns what the C++ block would pass to consume_each()/produce().
+As in the reference, the gate block owns the shared reader state (lib/gate_impl.cc:67-69): here that state
+lives in an rfid.Context (one per RX stream).  The reference's factories take no stream argument
+(`rfid.tag_decoder(int)`, `rfid.reader(int, int)`), so the binding rule is the reference's construction order
+(apps/reader.py:75-78), made explicit and per thread instead of a process-wide "current context":
+  * tag_decoder / reader bind, at construction, to the stream of the most recently constructed gate of this thread;
+  * a matched_filter binds to that stream too if it has no matched filter yet, otherwise (or when no gate exists
+    yet -- apps/reader.py:75 builds the filter BEFORE the gate) it waits for the next gate of this thread.
+Several flowgraphs in one process therefore never share or steal state; passing `ctx=` binds explicitly.
+Each block's general_work() hands its buffer through the C-ABI to the HIP kernels and returns what the C++
+block would pass to consume_each()/produce().
 """
 from __future__ import annotations
 
+import threading
 from typing import Optional, Tuple
 
 import numpy as np
 
 from .context import Context
 
-_current: Optional[Context] = None
+
+class _Binding(threading.local):
+    def __init__(self):
+        self.current: Optional[Context] = None      # stream of the most recent gate of this thread
+        self.has_filter = False                     # ... already has its matched filter
+        self.pending_filters = []                   # matched filters built before their gate
+
+
+_bind = _Binding()
 
 
 def _ctx(ctx: Optional[Context]) -> Context:
-    c = ctx or _current
+    c = ctx or _bind.current
     if c is None:
         raise RuntimeError("construct rfid.gate(...) first: it owns the shared reader state "
                            "(reference: gate_impl.cc:67-69, apps/reader.py:76-78)")
@@ -31,7 +45,7 @@ def _ctx(ctx: Optional[Context]) -> Context:
 
 
 class _Block:
-    def __init__(self, ctx: Context):
+    def __init__(self, ctx: Optional[Context]):
         self.ctx = ctx
 
     def forecast(self, noutput_items: int) -> int:
@@ -39,25 +53,32 @@ class _Block:
 
 
 class matched_filter(_Block):
-    def __init__(self, decim: int = 5, taps=(1,) * 25, ctx: Optional[Context] = None, device: int = 0):
-        global _current
-        if ctx is None and _current is None:
-            _current = Context(device=device)
-        super().__init__(_ctx(ctx))
+    def __init__(self, decim: int = 5, taps=(1,) * 25, ctx: Optional[Context] = None):
         if decim != 5 or len(taps) != 25 or any(complex(t) != 1 for t in taps):
             raise ValueError("only fir_filter_ccc(5, [1]*25) is built (apps/reader.py:65,75)")
+        if ctx is None and _bind.current is not None and not _bind.has_filter:
+            ctx = _bind.current
+            _bind.has_filter = True
+        super().__init__(ctx)
+        if ctx is None:
+            _bind.pending_filters.append(self)      # bound by the next gate (apps/reader.py:75-76 order)
 
     def work(self, x) -> np.ndarray:
+        if self.ctx is None:
+            raise RuntimeError("matched_filter is not bound to a stream yet: construct rfid.gate(...)")
         return self.ctx.mf_work(x)
 
 
 class gate(_Block):
     def __init__(self, sample_rate: int, ctx: Optional[Context] = None, device: int = 0, **params):
-        global _current
         if ctx is None:
             ctx = Context(device=device, sample_rate=int(sample_rate), **params)
-            _current = ctx
         super().__init__(ctx)
+        _bind.current = ctx
+        _bind.has_filter = False
+        if _bind.pending_filters:
+            _bind.pending_filters.pop(0).ctx = ctx
+            _bind.has_filter = True
 
     def general_work(self, x) -> Tuple[int, np.ndarray]:
         return self.ctx.gate_work(x)

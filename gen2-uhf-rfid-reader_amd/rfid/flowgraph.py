@@ -29,13 +29,14 @@ class reader_top_block:
                 raise ValueError("need source_path (interleaved float32 I,Q file) or samples")
             samples = np.fromfile(source_path, dtype=np.complex64)   # blocks.file_source, reader.py:102
         self.samples = np.ascontiguousarray(samples, dtype=np.complex64)
-        # construction order of apps/reader.py:75-78 (gate first: it owns the state)
+        # the blocks of apps/reader.py:75-78, in that order and with those arguments (device / params are what
+        # the reference fixes at compile time); the gate owns the stream, the others bind to it (rfid/blocks.py)
+        self.matched_filter = blocks.matched_filter(self.decim, self.num_taps)
         self.gate = blocks.gate(int(self.adc_rate / self.decim), device=device, **params)
-        ctx = self.gate.ctx
-        self.matched_filter = blocks.matched_filter(self.decim, self.num_taps, ctx=ctx)
-        self.tag_decoder = blocks.tag_decoder(int(self.adc_rate / self.decim), ctx=ctx)
-        self.reader = blocks.reader(int(self.adc_rate / self.decim), int(self.dac_rate), ctx=ctx)
-        self.ctx = ctx
+        self.tag_decoder = blocks.tag_decoder(int(self.adc_rate / self.decim))
+        self.reader = blocks.reader(int(self.adc_rate / self.decim), int(self.dac_rate))
+        self.ctx = self.gate.ctx
+        assert self.matched_filter.ctx is self.ctx and self.tag_decoder.ctx is self.ctx and self.reader.ctx is self.ctx
         self.decoded = []        # (result, scores) per decoded window, for inspection
 
     def _reader_until_idle(self, q: int) -> None:

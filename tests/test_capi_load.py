@@ -72,9 +72,9 @@ def test_product_never_imports_oracle_or_emulator():
 
 
 def test_cxx_block_adaptors_build_and_refuse_without_gpu(tmp_path):
-    """cxx/rfid_blocks.hpp (gate / tag_decoder / reader / matched_filter adaptors with the reference's
-    factory names and general_work signatures) compiles against the C-ABI header, and the offline
-    flowgraph binary fails loudly -- exit code 3 -- when there is no gfx950 device."""
+    """cxx/include/rfid/*.h + cxx/lib/rfid_blocks.cc (gr::rfid::gate / tag_decoder / reader with the reference's exact
+    factories, the reader_state global, general_work signatures) compile against the C-ABI header into
+    libgnuradio-rfid.so, and the offline flowgraph binary fails loudly -- exit code 3 -- when there is no gfx950 device."""
     import subprocess
     import torch
     import rfid
@@ -88,3 +88,57 @@ def test_cxx_block_adaptors_build_and_refuse_without_gpu(tmp_path):
         trace.write_bytes(b"\0" * 8 * 1000)
         r = subprocess.run([exe, str(trace)], capture_output=True, text=True)
         assert r.returncode == 3 and "no usable gfx950 device" in r.stderr
+
+
+def test_cxx_block_api_is_the_references(tmp_path):
+    """A translation unit written only against the reference's public block API -- gr::rfid::gate::make(int),
+    tag_decoder::make(int), reader::make(int,int) + print_results(), `extern READER_STATE* reader_state`,
+    `initialize_reader_state()`, sptr typedefs, `virtual public gr::block`, forecast/general_work signatures
+    (gr-rfid/include/rfid/gate.h:51, tag_decoder.h:48, reader.h:42,51, global_vars.h:146-147) -- compiles and links
+    against the shipped headers and libgnuradio-rfid.so.  (Construction needs a GPU: tests/test_gpu_round2.py.)"""
+    import subprocess
+    import rfid
+    cxx = os.path.join(rfid.capi.PKG_ROOT, "cxx")
+    subprocess.check_call(["make", "-C", cxx], stdout=subprocess.DEVNULL)
+    src = tmp_path / "api_tu.cc"
+    src.write_text(r"""
+#include <rfid/gate.h>
+#include <rfid/tag_decoder.h>
+#include <rfid/reader.h>
+#include <rfid/global_vars.h>
+#include <type_traits>
+using namespace gr::rfid;
+static_assert(std::is_base_of<gr::block, gate>::value && std::is_base_of<gr::block, tag_decoder>::value &&
+              std::is_base_of<gr::block, reader>::value, "blocks derive from gr::block");
+static_assert(std::is_abstract<reader>::value, "reader::print_results is pure virtual");
+gate::sptr (*f_gate)(int) = &gate::make;
+tag_decoder::sptr (*f_dec)(int) = &tag_decoder::make;
+reader::sptr (*f_reader)(int, int) = &reader::make;
+void (reader::*f_print)() = &reader::print_results;
+void (*f_init)() = &initialize_reader_state;
+int (gr::block::*f_work)(int, gr_vector_int &, gr_vector_const_void_star &, gr_vector_void_star &) = &gr::block::general_work;
+void (gr::block::*f_forecast)(int, gr_vector_int &) = &gr::block::forecast;
+static_assert(FIXED_Q == 0 && MAX_NUM_QUERIES == 1000 && NUMBER_UNIQUE_TAGS == 100 && RN16_BITS == 17 && EPC_BITS == 129, "");
+static_assert(SEND_ACK == 1 && IDLE == 3 && START == 5 && GATE_SEEK_EPC == 3 && DECODER_DECODE_EPC == 1 && TERMINATED == 1, "");
+int main(int argc, char **) {
+  READER_STATE **p = &reader_state;        // the global of include/rfid/global_vars.h:146
+  if (argc > 100) {                        // never executed here: needs a GPU
+    gate::sptr g = gate::make(400000);
+    tag_decoder::sptr d = tag_decoder::make(400000);
+    reader::sptr r = reader::make(400000, 1000000);
+    r->print_results();
+    return (*p)->reader_stats.n_epc_correct + (int)(*p)->reader_stats.tag_reads.size() + (*p)->n_samples_to_ungate;
+  }
+  return *p == nullptr ? 0 : 1;
+}
+""")
+    exe = tmp_path / "api_tu"
+    libdir = os.path.join(rfid.capi.PKG_ROOT, "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(cxx, "minigr"), "-I", os.path.join(cxx, "include"),
+                           "-I", os.path.join(rfid.capi.REPO_ROOT, "include"), str(src), "-o", str(exe), "-L", libdir,
+                           "-lgnuradio-rfid", "-lrfid_mi355x", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    assert subprocess.run([str(exe)]).returncode == 0
+    syms = subprocess.run(["nm", "-DC", os.path.join(libdir, "libgnuradio-rfid.so")], capture_output=True, text=True).stdout
+    for want in ("gr::rfid::gate::make(int)", "gr::rfid::tag_decoder::make(int)", "gr::rfid::reader::make(int, int)",
+                 "gr::rfid::reader_state", "gr::rfid::initialize_reader_state()"):
+        assert want in syms, want

@@ -129,8 +129,8 @@ def test_streaming_blocks_match_oracle(oracle_mod, synth_mod):
 
 
 def test_cxx_offline_flowgraph_binary(tmp_path, oracle_mod, synth_mod):
-    """bin/rfid_reader_offline = apps/reader.py's DEBUG topology in C++ (block adaptors of
-    cxx/rfid_blocks.hpp, one C-ABI call per general_work): its print_results text equals the
+    """bin/rfid_reader_offline = apps/reader.py's DEBUG topology in C++ on the reference's own block API
+    (gr::rfid::gate::make(int) etc., cxx/include/rfid/*.h; one C-ABI call per general_work): its print_results text equals the
     oracle's for the same trace file, FIXED_Q = 0 and 2, odd chunk size included."""
     import os
     import subprocess
