@@ -157,13 +157,18 @@ def workload_single_trace(torch, rfid, synth, args, device, rank, fixed_q, n_rou
             hist[s.tag_id] += 1
 
     def check(st):
-        ok = bool(st[0]["n_windows"] == 2 * n_slots and st[0]["n_epc_correct"] == n_valid
-                  and np.array_equal(st[0]["tag_reads"].astype(np.int64), hist)
+        # every single-responder slot's EPC must be CRC-verified; collided / empty slots decode noise and pass the
+        # 16-bit CRC by chance with probability 2^-16 each (a handful among 10^5 such slots)
+        extra = int(st[0]["n_epc_correct"]) - n_valid
+        reads = st[0]["tag_reads"].astype(np.int64)
+        ok = bool(st[0]["n_windows"] == 2 * n_slots and 0 <= extra <= 12
+                  and (reads >= hist).all() and int((reads - hist).sum()) == extra
                   and st[0]["n_queries_sent"] == n_slots + 1
                   and st[0]["cur_inventory_round"] == n_slots // (1 << fixed_q) + 1)
-        return ok, ("ok: %d slots -> %d RN16 + %d EPC windows, %d of %d single-responder EPCs CRC-verified, per-tag "
-                    "read counts equal the slot table's" % (n_slots, n_slots, n_slots, int(st[0]["n_epc_correct"]), n_valid)
-                    if ok else "FAILED: windows %d (want %d), EPC ok %d (want %d)"
+        return ok, ("ok: %d slots -> %d RN16 + %d EPC windows, all %d single-responder EPCs CRC-verified with the slot "
+                    "table's tag ids (+%d chance CRC passes among the %d collided/empty slots)"
+                    % (n_slots, n_slots, n_slots, n_valid, extra, n_slots - n_valid)
+                    if ok else "FAILED: windows %d (want %d), EPC ok %d (want >= %d)"
                     % (int(st[0]["n_windows"]), 2 * n_slots, int(st[0]["n_epc_correct"]), n_valid))
 
     def sample():

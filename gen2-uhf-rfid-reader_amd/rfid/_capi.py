@@ -120,6 +120,14 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise RfidError(ERR_NO_DEVICE, f"{LIB_PATH} is missing: the HIP library has not been built; "
                                        "there is no CPU fallback")
+    # Callers own HBM through PyTorch, whose wheel bundles its own HIP runtime (same soname as /opt/rocm's):
+    # whichever copy is loaded first serves the whole process, and torch finds no device when it comes second
+    # (measured on the MI355X box).  So let torch load and initialise its runtime first when it is installed.
+    try:
+        import torch
+        torch.cuda.is_available()
+    except ImportError:
+        pass
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # e.g. libamdhip64 not found

@@ -92,6 +92,15 @@ def lib() -> C.CDLL:
         L.orc_run_trace.restype = C.c_long
         L.orc_run_decimated.argtypes = L.orc_run_trace.argtypes
         L.orc_run_decimated.restype = C.c_long
+        L.orc_stream_new.argtypes = [C.POINTER(Config), C.c_int]
+        L.orc_stream_new.restype = vp
+        L.orc_stream_free.argtypes = [vp]
+        L.orc_stream_state.argtypes = [vp, C.POINTER(ReaderState)]
+        L.orc_stream_windows.argtypes = [vp]
+        L.orc_stream_windows.restype = C.c_long
+        for fn in (L.orc_stream_feed, L.orc_stream_feed_raw):
+            fn.argtypes = [vp, vp, C.c_long, vp, vp, vp, C.c_long]
+            fn.restype = C.c_long
         L.orc_time_trace.argtypes = [C.POINTER(Config), vp, C.c_long, C.c_int, C.POINTER(C.c_double * 3),
                                      C.POINTER(ReaderState)]
         L.orc_time_trace.restype = C.c_long
@@ -168,6 +177,52 @@ def run_trace(raw: np.ndarray, cfg: Optional[Config] = None, chunk: int = 4096,
 def run_decimated(y: np.ndarray, cfg: Optional[Config] = None, chunk: int = 4096,
                   max_dumps: Optional[int] = None) -> Result:
     return _run(lib().orc_run_decimated, cfg or config(), y, chunk, max_dumps)
+
+
+class Stream:
+    """The harness as a resumable object: feed a trace in pieces (raw 2 Msps or decimated samples); windows,
+    dumps and the reader state accumulate exactly as in one run_trace() call over the concatenation."""
+
+    def __init__(self, cfg: Optional[Config] = None, chunk: int = 4096):
+        self.cfg = cfg or config()
+        self._h = lib().orc_stream_new(C.byref(self.cfg), chunk)
+        self._dumps, self._open, self._dc = [], [], []
+
+    def _feed(self, fn, x: np.ndarray, keep: bool):
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        cap = max(16, len(x) // 40)
+        dumps = np.zeros(cap, dtype=DUMP_DTYPE)
+        open_idx = np.zeros(cap, dtype=np.int64)
+        dc = np.zeros(cap, dtype=np.complex64)
+        n = fn(self._h, x.ctypes.data, len(x), dumps.ctypes.data, open_idx.ctypes.data, dc.ctypes.data, cap)
+        assert n <= cap
+        if keep:
+            self._dumps.append(dumps[:n]); self._open.append(open_idx[:n]); self._dc.append(dc[:n])
+        return n
+
+    def feed_raw(self, x: np.ndarray, keep: bool = True) -> int:
+        return self._feed(lib().orc_stream_feed_raw, x, keep)
+
+    def feed_decimated(self, y: np.ndarray, keep: bool = True) -> int:
+        return self._feed(lib().orc_stream_feed, y, keep)
+
+    def result(self) -> Result:
+        st = ReaderState()
+        lib().orc_stream_state(self._h, C.byref(st))
+        cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dtype=dt)
+        return Result(st, cat(self._dumps, DUMP_DTYPE), cat(self._open, np.int64), cat(self._dc, np.complex64),
+                      int(lib().orc_stream_windows(self._h)))
+
+    def close(self) -> None:
+        if self._h:
+            lib().orc_stream_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def time_trace(raw: np.ndarray, reps: int = 1, cfg: Optional[Config] = None):

@@ -576,38 +576,72 @@ static void reader_until_idle(orc_reader_state *rs, int *reader_q) {
   }
 }
 
-long orc_run_decimated(const orc_config *cfg, const orc_cf *y, long n_dec, int chunk,
-                       orc_reader_state *rs, orc_decode_dump *dumps, long *open_idx,
-                       orc_cf *dc_at_open, long max_dumps) {
+/* The harness as a resumable object: decimated samples may be fed in pieces of any size (the gate, decoder
+ * and reader state, the decoder's input queue and the open-window bookkeeping carry over), so a trace far
+ * larger than host memory can be checked chunk by chunk.  open_idx values are global decimated indices. */
+struct orc_stream {
+  orc_config cfg;
   orc_gate g;
   orc_decoder d;
-  orc_gate_init(&g, 400000);          /* gate first: it owns reader_state (gate_impl.cc:69) */
-  orc_initialize_reader_state(rs, cfg);
-  orc_decoder_init(&d, 400000);
-  int reader_q = 0;
-  reader_until_idle(rs, &reader_q);   /* START -> SEND_QUERY -> IDLE */
+  orc_reader_state rs;
+  int reader_q;
+  int chunk;
+  orc_cf *gout, *dq;
+  int dq_n;
+  long n_windows, pos0;       /* windows so far; global index of the next decimated sample */
+  long cur_open;
+  orc_cf cur_dc;
+  /* raw side (orc_stream_feed_raw): the last 28 raw samples and how many were seen */
+  orc_cf hist[28];
+  long raw_seen;
+};
 
-  if (chunk < 1) chunk = 4096;
-  orc_cf *gout = (orc_cf *)malloc(sizeof(orc_cf) * (size_t)chunk);
-  orc_cf *dq = (orc_cf *)malloc(sizeof(orc_cf) * 8192);
-  int dq_n = 0;
-  long n_windows = 0, pos = 0;
-  long cur_open = -1;
-  orc_cf cur_dc = cf(0, 0);
+orc_stream *orc_stream_new(const orc_config *cfg, int chunk) {
+  orc_stream *s = (orc_stream *)calloc(1, sizeof(orc_stream));
+  s->cfg = *cfg;
+  orc_gate_init(&s->g, 400000);          /* gate first: it owns reader_state (gate_impl.cc:69) */
+  orc_initialize_reader_state(&s->rs, cfg);
+  orc_decoder_init(&s->d, 400000);
+  s->reader_q = 0;
+  reader_until_idle(&s->rs, &s->reader_q);   /* START -> SEND_QUERY -> IDLE */
+  s->chunk = (chunk < 1) ? 4096 : chunk;
+  s->gout = (orc_cf *)malloc(sizeof(orc_cf) * (size_t)s->chunk);
+  s->dq = (orc_cf *)malloc(sizeof(orc_cf) * 8192);
+  s->cur_open = -1;
+  s->cur_dc = cf(0, 0);
+  return s;
+}
+
+void orc_stream_free(orc_stream *s) {
+  if (!s) return;
+  free(s->gout);
+  free(s->dq);
+  free(s);
+}
+
+void orc_stream_state(const orc_stream *s, orc_reader_state *rs) { *rs = s->rs; }
+long orc_stream_windows(const orc_stream *s) { return s->n_windows; }
+
+/* feeds n_dec decimated samples; dumps / open_idx / dc_at_open (nullable) receive the windows completed in THIS
+ * call (at most max_dumps of them are stored); returns how many were completed */
+long orc_stream_feed(orc_stream *s, const orc_cf *y, long n_dec, orc_decode_dump *dumps, long *open_idx,
+                     orc_cf *dc_at_open, long max_dumps) {
+  orc_reader_state *rs = &s->rs;
+  long pos = 0, n_new = 0;
   while (pos < n_dec) {
-    int n_items = (int)((n_dec - pos < chunk) ? (n_dec - pos) : chunk);
+    int n_items = (int)((n_dec - pos < s->chunk) ? (n_dec - pos) : s->chunk);
     int consumed = 0;
-    int written = orc_gate_work(&g, rs, y + pos, n_items, gout, &consumed);
+    int written = orc_gate_work(&s->g, rs, y + pos, n_items, s->gout, &consumed);
     /* track open index: the gate emits contiguous samples; the first emitted sample of
      * a window sits (written-1) samples before the last emitted one.  When the window
      * closes in this call the last emitted sample is y[pos+consumed-1]. */
     if (written > 0) {
-      if (dq_n == 0) {
+      if (s->dq_n == 0) {
         long last = (rs->gate_status == ORC_GATE_OPEN) ? (pos + n_items - 1) : (pos + consumed - 1);
-        cur_open = last - (written - 1);
-        cur_dc = g.dc_est;
+        s->cur_open = s->pos0 + last - (written - 1);
+        s->cur_dc = s->g.dc_est;
       }
-      if (dq_n + written <= 8192) { memcpy(dq + dq_n, gout, sizeof(orc_cf) * (size_t)written); dq_n += written; }
+      if (s->dq_n + written <= 8192) { memcpy(s->dq + s->dq_n, s->gout, sizeof(orc_cf) * (size_t)written); s->dq_n += written; }
     }
     pos += consumed;
     /* decoder + reader to quiescence */
@@ -615,23 +649,64 @@ long orc_run_decimated(const orc_config *cfg, const orc_cf *y, long n_dec, int c
       float out0[32];
       int dcons = 0;
       orc_decode_dump tmp;
-      int produced = orc_decoder_work(&d, rs, dq, dq_n, out0, &dcons, &tmp);
+      int produced = orc_decoder_work(&s->d, rs, s->dq, s->dq_n, out0, &dcons, &tmp);
       if (dcons == 0) break;
-      if (n_windows < max_dumps) {
-        if (dumps) dumps[n_windows] = tmp;
-        if (open_idx) open_idx[n_windows] = cur_open;
-        if (dc_at_open) dc_at_open[n_windows] = cur_dc;
+      if (n_new < max_dumps) {
+        if (dumps) dumps[n_new] = tmp;
+        if (open_idx) open_idx[n_new] = s->cur_open;
+        if (dc_at_open) dc_at_open[n_new] = s->cur_dc;
       }
-      n_windows++;
-      memmove(dq, dq + dcons, sizeof(orc_cf) * (size_t)(dq_n - dcons));
-      dq_n -= dcons;
-      reader_q += produced;
-      reader_until_idle(rs, &reader_q);
+      n_new++;
+      s->n_windows++;
+      memmove(s->dq, s->dq + dcons, sizeof(orc_cf) * (size_t)(s->dq_n - dcons));
+      s->dq_n -= dcons;
+      s->reader_q += produced;
+      reader_until_idle(rs, &s->reader_q);
     }
   }
-  free(gout);
-  free(dq);
-  return n_windows;
+  s->pos0 += n_dec;
+  return n_new;
+}
+
+/* the same from raw 2 Msps samples: matched filter first (a1), emitting y[n] once its decimation group
+ * x[5n..5n+4] is complete, so that any split of a trace yields the floor(N/5) outputs of the one-shot filter */
+long orc_stream_feed_raw(orc_stream *s, const orc_cf *x, long n_raw, orc_decode_dump *dumps, long *open_idx,
+                         orc_cf *dc_at_open, long max_dumps) {
+  const long n_first = s->raw_seen / 5, n_last = (s->raw_seen + n_raw) / 5;
+  const long n_out = n_last - n_first;
+  orc_cf *y = (orc_cf *)malloc(sizeof(orc_cf) * (size_t)(n_out > 0 ? n_out : 1));
+  for (long n = n_first; n < n_last; n++) {
+    orc_cf acc = cf(0.0f, 0.0f);
+    for (int k = 0; k < 25; k++) {
+      const long g = 5 * n - 24 + k;              /* global raw index */
+      const long rel = g - s->raw_seen;           /* relative to this call's x[0] */
+      orc_cf v;
+      if (g < 0) v = cf(0.0f, 0.0f);
+      else if (rel >= 0) v = x[rel];
+      else v = s->hist[28 + rel];
+      acc = cadd(acc, v);
+    }
+    y[n - n_first] = acc;
+  }
+  if (n_raw >= 28) memcpy(s->hist, x + n_raw - 28, 28 * sizeof(orc_cf));
+  else if (n_raw > 0) {
+    memmove(s->hist, s->hist + n_raw, (size_t)(28 - n_raw) * sizeof(orc_cf));
+    memcpy(s->hist + 28 - n_raw, x, (size_t)n_raw * sizeof(orc_cf));
+  }
+  s->raw_seen += n_raw;
+  const long r = orc_stream_feed(s, y, n_out, dumps, open_idx, dc_at_open, max_dumps);
+  free(y);
+  return r;
+}
+
+long orc_run_decimated(const orc_config *cfg, const orc_cf *y, long n_dec, int chunk,
+                       orc_reader_state *rs, orc_decode_dump *dumps, long *open_idx,
+                       orc_cf *dc_at_open, long max_dumps) {
+  orc_stream *s = orc_stream_new(cfg, chunk);
+  const long n = orc_stream_feed(s, y, n_dec, dumps, open_idx, dc_at_open, max_dumps);
+  *rs = s->rs;
+  orc_stream_free(s);
+  return n;
 }
 
 long orc_run_trace(const orc_config *cfg, const orc_cf *raw, long n_raw, int chunk,

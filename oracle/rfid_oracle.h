@@ -151,6 +151,17 @@ long orc_run_decimated(const orc_config *cfg, const orc_cf *y, long n_dec, int c
                        orc_reader_state *rs_out, orc_decode_dump *dumps, long *open_idx,
                        orc_cf *dc_at_open, long max_dumps);
 
+/* the same harness as a resumable object (decimated or raw samples fed in pieces of any size) */
+typedef struct orc_stream orc_stream;
+orc_stream *orc_stream_new(const orc_config *cfg, int chunk);
+void orc_stream_free(orc_stream *s);
+void orc_stream_state(const orc_stream *s, orc_reader_state *rs);
+long orc_stream_windows(const orc_stream *s);
+long orc_stream_feed(orc_stream *s, const orc_cf *y, long n_dec, orc_decode_dump *dumps, long *open_idx,
+                     orc_cf *dc_at_open, long max_dumps);
+long orc_stream_feed_raw(orc_stream *s, const orc_cf *x, long n_raw, orc_decode_dump *dumps, long *open_idx,
+                         orc_cf *dc_at_open, long max_dumps);
+
 /* per-stage timing leg for bench.py's cpu_baseline: runs FIR, gate, decoder
  * separately over the trace and returns seconds spent in each (steady clock). */
 long orc_time_trace(const orc_config *cfg, const orc_cf *raw, long n_raw, int reps,

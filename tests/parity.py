@@ -57,3 +57,32 @@ def split_by_stream(windows, results, scores, n_streams):
         m = windows["stream"] == b
         out.append((windows[m], results[m], scores[m] if scores is not None else None))
     return out
+
+
+def compare_trace_fast(windows, results, stats, o):
+    """compare_trace() without scores, vectorised over the windows (hundreds of thousands in the full-size
+    configurations): every start, type, dc_est, sync index, h_est, T, decoded bit, CRC flag and tag id."""
+    n = o.n_windows
+    assert len(windows) == n and len(o.dumps) == n, (len(windows), n, len(o.dumps))
+    d = o.dumps
+    assert np.array_equal(windows["start"], o.open_idx) and np.array_equal(windows["type"], d["type"])
+    assert _bits_equal(windows["dc_re"], o.dc.real) and _bits_equal(windows["dc_im"], o.dc.imag), "dc_est"
+    assert np.array_equal(results["type"], d["type"]) and np.array_equal(results["index"], d["index"])
+    assert np.array_equal(results["n_bits"], d["n_bits"])
+    assert _bits_equal(results["h_re"], d["h_est"][:, 0]) and _bits_equal(results["h_im"], d["h_est"][:, 1]), "h_est"
+    epc = d["type"] == 1
+    assert _bits_equal(results["T"][epc], d["T"][epc]), "T"
+    assert np.array_equal(results["crc_ok"][epc], d["crc_ok"][epc])
+    ok = epc & (d["crc_ok"] == 1)
+    assert np.array_equal(results["tag_id"][ok], d["tag_id"][ok])
+    # bits: oracle keeps one byte per bit (frame order); the result packs bit j at word j>>5, bit j&31
+    j = np.arange(128)
+    got = ((results["bits"][:, j >> 5] >> (j & 31).astype(np.uint32)) & 1).astype(np.uint8)
+    mask = j[None, :] < d["n_bits"][:, None]
+    assert np.array_equal(got[mask], d["bits"][mask]), "decoded bits"
+    if stats is not None:
+        s = o.state
+        assert stats["n_windows"] == n
+        for k in ("n_queries_sent", "cur_inventory_round", "cur_slot_number", "n_epc_correct", "n_unique_tags"):
+            assert stats[k] == getattr(s, k), (k, stats[k], getattr(s, k))
+        assert np.array_equal(stats["tag_reads"], np.array(s.tag_reads[:], dtype=np.int32))

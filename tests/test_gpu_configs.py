@@ -1,0 +1,150 @@
+"""The BASELINE.json configurations at FULL size on one MI355X (the per-GPU workloads of the 8-GPU ones), each
+generated in HBM by the device-side synthesiser and checked against the oracle / the slot table's truth.
+RFID_TEST_SCALE=small shrinks them (developer runs)."""
+import os
+
+import numpy as np
+import pytest
+
+import parity
+
+pytestmark = pytest.mark.gpu
+SMALL = os.environ.get("RFID_TEST_SCALE", "") == "small"
+
+
+def _gen_trace(ctx, plan, sigma, seed, replica=0):
+    import torch
+    L = ctx.synth_gen2_size(plan)
+    stride = (L + 1) & ~1
+    data = torch.zeros(2 * stride, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    ctx.synth_gen2_ptr(plan, data.data_ptr(), stride, sigma=sigma, seed=seed, replica=replica)
+    ctx.batch_sync()
+    return data, L, stride
+
+
+def _oracle_over_device_trace(oracle_mod, data, L, cfg, piece=48_000_000):
+    """The oracle over a trace that lives in HBM (and may not fit a host array comfortably): fed piece by piece."""
+    st = oracle_mod.Stream(cfg)
+    for pos in range(0, L, piece):
+        n = min(piece, L - pos)
+        st.feed_raw(data[2 * pos: 2 * (pos + n)].cpu().numpy().view(np.complex64))
+    r = st.result()
+    st.close()
+    return r
+
+
+def test_config2_full_size_multi_tag_inventory(oracle_mod, synth_mod):
+    """configs[2]: FIXED_Q=4 (16 slots/round), 10 000 rounds, 8 tags -- ONE trace of 2.2 G raw samples (17.6 GB,
+    beyond 32-bit raw indexing) built in HBM from its 160 000-slot table.  Size-independent properties on every
+    slot (window count, every single-responder RN16 and EPC equal to the table's truth, per-tag read counts) AND
+    every one of the 320 000 windows bit-identical to the oracle run over the same samples (starts, types, dc_est,
+    sync index, h_est, T, bits, CRC, tag id, statistics); the stage kernels (mf + gate_scan) give the same bytes as
+    the fused front end."""
+    import rfid
+    n_rounds = 300 if SMALL else 10000
+    t = synth_mod.make_trace(n_rounds=n_rounds, fixed_q=4, tag_ids=tuple(0x11 + 0x10 * k for k in range(8)), sigma=0.0,
+                             seed=2024, noise=False, render=False)
+    ctx = rfid.Context(device=0, fixed_q=4, max_num_queries=(1 << 31) - 2)
+    try:
+        data, L, stride = _gen_trace(ctx, t.plan, sigma=0.002, seed=99)
+        if not SMALL:
+            assert L > (1 << 31)
+        ctx.batch_plan(1, L)
+        ctx.batch_process_ptr(data.data_ptr(), stride, L, 0, want_scores=False)
+        ctx.batch_sync()
+        assert ctx.batch_timing()["fused_front"] == 1
+        w, r, _ = ctx.batch_windows()
+        st = ctx.batch_stats()
+        n_slots = len(t.slots)
+        # ---- properties on every slot ---------------------------------------------------------------
+        assert st[0]["n_windows"] == 2 * n_slots and np.array_equal(w["type"], np.arange(2 * n_slots) & 1)
+        rn, epc = r[0::2], r[1::2]
+        single = np.array([s.n_tags == 1 for s in t.slots])
+        valid = np.array([s.epc_valid for s in t.slots])
+        want_rn = np.array([int("".join(map(str, s.rn16[::-1])), 2) if s.n_tags == 1 else 0 for s in t.slots], dtype=np.uint32)
+        assert np.array_equal(rn["bits"][single, 0], want_rn[single]), "RN16 of single-responder slots"
+        assert (epc["crc_ok"][valid] == 1).all()
+        assert np.array_equal(epc["tag_id"][valid], np.array([s.tag_id for s in t.slots if s.epc_valid]))
+        # collided / empty slots decode noise: each passes the 16-bit CRC by chance with probability 2^-16
+        # (~1.7 expected among the ~110 000 such slots of the full-size trace); the oracle agrees on every one
+        chance = epc[~valid & (epc["crc_ok"] == 1)]
+        assert len(chance) <= 12
+        assert st[0]["n_epc_correct"] == valid.sum() + len(chance) and st[0]["cur_inventory_round"] == n_rounds + 1
+        hist = np.bincount([s.tag_id for s in t.slots if s.epc_valid], minlength=256) + \
+            np.bincount(chance["tag_id"], minlength=256)
+        assert np.array_equal(st[0]["tag_reads"], hist)
+        # ---- every window against the oracle -----------------------------------------------------------
+        o = _oracle_over_device_trace(oracle_mod, data, L, oracle_mod.config(fixed_q=4, max_num_queries=(1 << 31) - 2))
+        parity.compare_trace_fast(w, r, st[0], o)
+        # ---- stage kernels == fused front end ----------------------------------------------------------
+        os.environ["RFID_FRONT_UNFUSED"] = "1"
+        try:
+            ctx.batch_process_ptr(data.data_ptr(), stride, L, 0, want_scores=False)
+            ctx.batch_sync()
+            assert ctx.batch_timing()["fused_front"] == 0
+        finally:
+            del os.environ["RFID_FRONT_UNFUSED"]
+        w2, r2, _ = ctx.batch_windows()
+        assert w2.tobytes() == w.tobytes() and r2.tobytes() == r.tobytes()
+    finally:
+        ctx.close()
+
+
+def test_config3_one_long_stream_per_gpu(oracle_mod, synth_mod):
+    """configs[3], the per-GPU workload: one RX stream (2 000 inventory rounds, 30 M raw samples = 15 s on air at
+    2 Msps) -- bit-identical to the oracle, window by window."""
+    import rfid
+    t = synth_mod.make_trace(n_rounds=200 if SMALL else 2000, fixed_q=0, tag_ids=(0x5A,), sigma=0.0, seed=303,
+                             noise=False, render=False, t1_jitter_raw=6)
+    ctx = rfid.Context(device=0, max_num_queries=(1 << 31) - 2)
+    try:
+        data, L, stride = _gen_trace(ctx, t.plan, sigma=0.004, seed=5, replica=3)
+        ctx.batch_plan(1, L)
+        ctx.batch_process_ptr(data.data_ptr(), stride, L, 0, want_scores=False)
+        ctx.batch_sync()
+        w, r, _ = ctx.batch_windows()
+        st = ctx.batch_stats()
+        o = _oracle_over_device_trace(oracle_mod, data, L, oracle_mod.config(max_num_queries=(1 << 31) - 2))
+        parity.compare_trace_fast(w, r, st[0], o)
+        assert st[0]["n_epc_correct"] == len(t.slots) and st[0]["tag_reads"][0x5A] == len(t.slots)
+    finally:
+        ctx.close()
+
+
+def test_config4_hbm_capacity_shard(gpu_ctx, oracle_mod, synth_mod):
+    """configs[4], the per-GPU shard: as many noise replicas of the 71-round trace as fit ~85 % of the free HBM
+    (~25 000 replicas, ~215 GB of traces + 43 GB of matched-filter output), full chain over all of them in one pass:
+    plan succeeds, every replica decodes 70 of 71 EPCs with tag 0x27, and a replica picked from the far end of the
+    buffer is bit-identical to the oracle."""
+    import torch
+    plan = synth_mod.make_trace(n_rounds=71, fixed_q=0, tag_ids=(0x27,), sigma=0.0, seed=7, corrupt_rounds=(36,),
+                                noise=False, render=False).plan
+    L = gpu_ctx.synth_gen2_size(plan)
+    stride = (L + 1) & ~1
+    free, _ = torch.cuda.mem_get_info(0)
+    per_trace = 8 * stride + 8 * (L // 5 + 2) + (L // 5 // 347 + 2) * (24 * 3 + 48 + 144) + 2100
+    B = 300 if SMALL else int(free * 0.85 / per_trace)
+    base = torch.zeros(2 * stride, dtype=torch.float32, device="cuda:0")
+    data = torch.empty((B, 2 * stride), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    gpu_ctx.synth_gen2_ptr(plan, base.data_ptr(), stride)
+    gpu_ctx.synth_replicas_ptr(base.data_ptr(), L, data.data_ptr(), stride, B, 0.002, 777, first_replica=0)
+    try:
+        gpu_ctx.batch_plan(B, L)
+        gpu_ctx.batch_process_ptr(data.data_ptr(), stride, L, 0, want_scores=False)
+        gpu_ctx.batch_sync()
+        st = gpu_ctx.batch_stats()
+        assert len(st) == B
+        assert (st["n_epc_correct"] == 70).all() and (st["n_queries_sent"] == 72).all()
+        assert (st["tag_reads"][:, 0x27] == 70).all() and (st["n_unique_tags"] == 1).all()
+        assert (st["n_windows"] == 142).all()
+        w, r, _ = gpu_ctx.batch_windows()
+        b = B - 1
+        x = data[b, : 2 * L].cpu().numpy().view(np.complex64)
+        m = w["stream"] == b
+        parity.compare_trace_fast(w[m], r[m], st[b], oracle_mod.run_trace(x))
+    finally:
+        gpu_ctx.batch_plan(1, 4096)
+        del data
+        torch.cuda.empty_cache()

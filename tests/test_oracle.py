@@ -175,3 +175,24 @@ def test_real_blob_hook_documents_the_missing_known_answer():
     import os
     src = open(os.path.join(os.path.dirname(__file__), "test_gpu_round2.py")).read()
     assert "RFID_FILE_SOURCE_TEST" in src and "Tag ID : 27  Num of reads : 70" in src
+
+
+def test_oracle_stream_equals_one_shot(oracle_mod, synth_mod):
+    """oracle.Stream (the harness fed in pieces -- how traces larger than host memory are checked) gives the
+    same windows, dumps and reader state as run_trace() over the whole trace, whatever the piece sizes."""
+    t = synth_mod.make_trace(n_rounds=4, fixed_q=1, tag_ids=(0x11, 0x22), seed=17, sigma=0.02, t1_jitter_raw=5).samples
+    cfg = oracle_mod.config(fixed_q=1)
+    o = oracle_mod.run_trace(t, cfg)
+    for sizes in ([len(t)], [1, 7, 1000, 33333], [50001]):
+        st = oracle_mod.Stream(cfg)
+        pos, k = 0, 0
+        while pos < len(t):
+            n = sizes[k % len(sizes)] if k < len(sizes) - 1 or len(sizes) == 1 else sizes[-1]
+            st.feed_raw(t[pos:pos + n])
+            pos += n
+            k += 1
+        r = st.result()
+        st.close()
+        assert r.n_windows == o.n_windows and np.array_equal(r.open_idx, o.open_idx)
+        assert r.dumps.tobytes() == o.dumps.tobytes() and r.dc.tobytes() == o.dc.tobytes()
+        assert r.stats() == o.stats()
