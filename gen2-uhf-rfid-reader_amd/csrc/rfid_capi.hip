@@ -314,7 +314,7 @@ int rfid_selftest(rfid_ctx *c, int *n_failed) {
   unsigned seed = 12345u;
   auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (float)((seed >> 8) & 0xFFFF) / 65536.0f; };
   float *d = nullptr;
-  HIPCHK(c, hipMalloc((void **)&d, 7 * 64 * sizeof(float)));
+  HIPCHK(c, hipMalloc((void **)&d, 9 * 64 * sizeof(float)));
   int bad = 0;
   // round 0: the magnitudes of the receive path; later rounds sweep the numerators over the binary
   // exponent range (2^-150 .. 2^124, zeros and denormals included) so that both paths of the
@@ -329,16 +329,22 @@ int rfid_selftest(rfid_ctx *c, int *n_failed) {
       if (round > 0 && i == 6) hn[i] = -0.0f;
       hd[i] = (i % 3 == 0) ? 100.0f : ((i % 3 == 1) ? 48.0f : (rnd() + 0.01f) * 9.0f);
     }
-    const float carry = 23.456789f;
+    // carries for the in-order sums: plain, negative, next to a binade edge on either side (partial sums cross
+    // it), zero, tiny, large; some rounds add exact half-ulp multiples (ties) -- the integer-scan form of the
+    // sum must hand those steps to the chain and agree with the host's sequential sum everywhere
+    const float carries[8] = {23.456789f, -19.12345f, 31.99999f, 16.000002f, 0.0f, 1e-30f, -15.99999f, 3.0e5f};
+    const float carry = carries[round % 8];
+    if (round % 8 == 5 || round % 16 == 8)
+      for (int i = 0; i < 64; i += 3) hx[i] = ldexpf((float)((i % 7) - 3), -20) + ldexpf(1.0f, -20);
     HIPCHK(c, hipMemcpyAsync(d, hx, sizeof(hx), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d + 64, hn, sizeof(hn), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d + 128, hd, sizeof(hd), hipMemcpyHostToDevice, c->stream));
     SelfTestArgs a;
     a.x = d; a.num = d + 64; a.den = d + 128; a.carry = carry;
-    a.chain_out = d + 192; a.div_out = d + 256; a.hyp_out = d + 320; a.shr_out = d + 384;
+    a.chain_out = d + 192; a.div_out = d + 256; a.hyp_out = d + 320; a.shr_out = d + 384; a.scan_out = d + 448;
     hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, c->stream, a);
     HIPCHK(c, hipGetLastError());
-    float out[4 * 64];
+    float out[5 * 64 + 1];
     HIPCHK(c, hipMemcpyAsync(out, d + 192, sizeof(out), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     volatile float acc = carry;
@@ -353,6 +359,7 @@ int rfid_selftest(rfid_ctx *c, int *n_failed) {
       if (memcmp(&e_div, &out[64 + i], 4)) bad++;
       if (memcmp(&e_hyp, &out[128 + i], 4)) bad++;
       if (memcmp(&e_shr, &out[192 + i], 4)) bad++;
+      if (memcmp(&e_chain, &out[256 + i], 4)) bad++;   // the integer-scan form of the in-order sum (or its fallback)
     }
   }
   (void)hipFree(d);
@@ -574,6 +581,7 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
     g.flat = c->d_flat; g.flat_count = c->d_flat_count; g.flat_cap = c->flat_cap; g.mode = 0;
     g.raw = (const float2 *)d_raw; g.raw_stride = raw_stride; g.n_raw = n_raw;
     g.raw_vec_ok = ((raw_stride & 1) == 0 && (((uintptr_t)d_raw) & 15) == 0) ? 1 : 0;
+    if (const char *e = getenv("RFID_GATE_KNOCK")) g.knock = atoi(e);   // developer aid: times parts of the kernel, WRONG RESULTS
     if (getenv("RFID_GATE_PROF")) {
       int rc = launch_gate_prof(c, g, true);
       if (rc) return rc;

@@ -35,6 +35,20 @@ RFID_DEVICE float shr1(float v) {
       float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
 
+// inclusive prefix sum of a 32-bit integer over the 64 lanes (lane L gets v_0 + ... + v_L): four row_shr steps
+// scan each 16-lane row, row_bcast:15 / row_bcast:31 carry the row totals across (6 DPP adds, no LDS)
+RFID_DEVICE int scan_add(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2 and 3
+  return v;
+}
+RFID_DEVICE float rint_f(float v) { return __builtin_rintf(v); }     // v_rndne_f32: to nearest, ties to even
+RFID_DEVICE float u2f(uint32_t u) { return __uint_as_float(u); }
+
 // value of lane `k` (k wave-uniform) broadcast to the wave
 RFID_DEVICE float readlane(float v, int k) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));

@@ -174,6 +174,7 @@ struct GateArgs {
   int64_t n_raw;        // valid raw samples per trace (when lens == nullptr)
   int raw_vec_ok;       // rows 16-byte aligned -> float4 loads
   float2 *y_w;          // [n_streams][y_stride], written
+  int knock;            // developer aid (RFID_GATE_KNOCK): knock out parts of the work to time the rest -- WRONG RESULTS
 };
 
 // x / C for the gate's two constant divisors (100: gate_impl.cc:131, 48: :141) in three instructions
@@ -206,6 +207,72 @@ RFID_DEVICE float chain_add(float carry, float x, int lane) {
 #pragma unroll
   for (int s = 1; s < 64; ++s) p = wv::shr1(p) + x0;
   return p;
+}
+
+// The same in-order sum without the 63-deep chain.  While every partial sum stays in the binade of the carry
+// s_0 = S_0 * u (u = its ulp, S_0 in [2^23, 2^24)), binary32 addition is integer arithmetic on the mantissa:
+//     RN(S*u + d) = (S + RNE(d/u)) * u,
+// and the rounding of d/u does not depend on S -- unless d/u lies exactly half-way between two integers
+// I and I+1: ties-to-even then picks the one that makes the SUM even, i.e. adds I + ((S + I) & 1).  Such ties
+// are frequent here: the addends are differences of binary32 samples (multiples of the sample's ulp) divided
+// by 100 or 48, so d/u = K/100 hits x.5 once in a hundred samples.  They need only the PARITY of S, and the
+// parity sequence is cheap: a tie leaves an even sum (parity 0), anything else toggles the parity by RNE(d/u)&1
+// -- a prefix XOR with resets, done on the scalar unit over 64-bit vote masks (the "state before each sample"
+// is a carry chain, generate = tie & Q, kill = tie & ~Q, as in the gate's edge state machine).  Then
+//     s_{L+1} = as_float(as_int(s_0) + sum_{j<=L} R_j)
+// is the reference's value bit for bit (one integer prefix sum, 6 DPP adds), PROVIDED that
+//   (1) all |d_j/u| < 2^22 (exact conversion),
+//   (2) every partial sum keeps the exponent of s_0 and a non-zero mantissa: then each exact sum lies strictly
+//       inside the binade, where the spacing of binary32 numbers is u (a result that rounds onto a binade
+//       edge, or crosses it, is rounded on a different grid -- not this arithmetic).
+// Both are checked on all 64 lanes (one vote); a step that fails -- reader commands moving avg_ampl / dc_est
+// across a power of two, the first samples of a trace -- takes the exact chain above.
+// (carry < 0: the same on magnitudes with d negated -- rounding to nearest-even is symmetric.)
+RFID_DEVICE uint64_t prefix_xor64(uint64_t x) {   // bit k = x_0 ^ ... ^ x_k
+  x ^= x << 1; x ^= x << 2; x ^= x << 4; x ^= x << 8; x ^= x << 16; x ^= x << 32;
+  return x;
+}
+RFID_DEVICE bool chain_add_scan(float carry, float x, int lane, float &out) {
+  const uint32_t cb = wv::f2u(carry);
+  const uint32_t e_b = (cb >> 23) & 0xffu;                        // biased exponent of the carry (wave-uniform)
+  const uint32_t sign = cb & 0x80000000u;
+  // 2^(23 - e) as a float: biased exponent 277 - e_b, representable for e_b in [23, 254]
+  const float scale = wv::u2f(((277u - e_b) & 0xffu) << 23);
+  const float t = sign ? -(x * scale) : (x * scale);              // d / u (exact: a power-of-two scaling)
+  const float r = wv::rint_f(t);                                  // to nearest, ties to even
+  const float frac = t - r;                                       // exact
+  const bool bad_t = !(__builtin_fabsf(t) < 4194304.0f);
+  const bool tie = !bad_t && __builtin_fabsf(frac) == 0.5f;
+  int R = wv::f2i(bad_t ? 0.0f : r);
+  const uint64_t tiemask = wv::ballot(tie);
+  if (tiemask != 0ull) {
+    // ties: d/u = I + 1/2 with I = floor(d/u) = r - (frac < 0); the sum takes I + ((S + I) & 1)
+    const int I = R - ((frac < 0.0f) ? 1 : 0);
+    const uint64_t rodd = wv::ballot(!tie && (R & 1));            // parity toggles of the other samples
+    const uint64_t iodd = wv::ballot(tie && (I & 1));
+    const uint64_t Q = prefix_xor64(rodd);                        // toggles accumulated up to and including sample k
+    // parity of S before sample k = (toggles up to k-1) ^ (toggles up to the last tie before k, or the carry's
+    // parity if there is none): the second term is a fill-forward of Q from the tie positions = the carry
+    // into bit k of a binary addition with generate = tie & Q, kill = tie & ~Q, carry-in = parity of S_0
+    const uint64_t gen = tiemask & Q, X = gen | ~tiemask;
+    const uint64_t sum = X + gen + (uint64_t)(cb & 1u);
+    const uint64_t W = X ^ gen ^ sum;
+    const uint64_t par = (Q << 1) ^ W;                            // bit k = parity of S_k
+    const uint64_t up = (par ^ iodd) & tiemask;                   // ties that take I + 1
+    R = tie ? (I + (int)((up >> lane) & 1ull)) : R;
+  }
+  const uint32_t mag = (cb & 0x7fffffffu) + (uint32_t)wv::scan_add(R);
+  const bool bad_s = ((mag ^ cb) & 0x7f800000u) != 0u || (mag & 0x007fffffu) == 0u;
+  const bool bad_c = e_b < 23u || e_b > 254u;
+  out = wv::u2f(mag | sign);
+  return wv::ballot(bad_t || bad_s || bad_c) == 0ull;
+}
+
+// in-order sum, scan when it is provably exact, else the chain
+RFID_DEVICE float chain_add_auto(float carry, float x, int lane) {
+  float v;
+  if (__builtin_expect(chain_add_scan(carry, x, lane, v), 1)) return v;
+  return chain_add(carry, x, lane);
 }
 
 RFID_DEVICE uint64_t lane_range(int lo, int hi) {  // bits [lo, hi), 0 <= lo <= hi <= 64
@@ -282,11 +349,11 @@ struct GateBack {
 
 // ---- producer wave: everything that is lane-parallel ---------------------------------------
 RFID_DEVICE void gate_produce(GateSlot &slot, float2 yv_in, float2 &prev_yv, int pos, int n, int lane,
-                              float *lds_win, int &win_index) {
+                              float *lds_win, int &win_index, int knock) {
   const int nvalid = (n - pos < 64) ? (n - pos) : 64;
   const bool valid = lane < nvalid;
   const float2 yv = valid ? yv_in : make_float2(0.0f, 0.0f);
-  const float amp = wv::hypot_f(yv.x, yv.y);
+  const float amp = (knock & 8) ? (__builtin_fabsf(yv.x) + __builtin_fabsf(yv.y)) : wv::hypot_f(yv.x, yv.y);
   int wi = win_index + lane;
   if (wi >= WIN_LEN) wi -= WIN_LEN;
   const float amp_old = lds_win[wi];
@@ -325,9 +392,11 @@ RFID_DEVICE void gate_produce(GateSlot &slot, float2 yv_in, float2 &prev_yv, int
 // ---- averaging wave: avg_ampl and the threshold test -------------------------------------------
 // avg_ampl is an in-order sum over all samples that does not depend on the state machine
 // (gate_impl.cc:130-134), so it runs one or more steps ahead of the consumer in a wave of its own.
-RFID_DEVICE void gate_average(GateSlot &slot, int nvalid, int lane, float &avg_c) {
+RFID_DEVICE void gate_average(GateSlot &slot, int nvalid, int lane, float &avg_c, int knock) {
   const float amp = slot.amp[lane], d = slot.d[lane];
-  const float avg = chain_add(avg_c, d, lane);
+  // (chain_add_auto -- the integer-scan form -- was measured here: no gain, the pipeline is bound by the filter wave's
+  //  staging and the hand-offs, not by the chain's latency; knock & 16 times it)
+  const float avg = (knock & 2) ? (avg_c + d) : ((knock & 16) ? chain_add_auto(avg_c, d, lane) : chain_add(avg_c, d, lane));
   const float thresh = avg * THRESH_FRACTION;   // gate_impl.cc:136
   const bool valid = lane < nvalid;             // the last step of a call may be partial
   const uint64_t below = wv::ballot(valid && amp < thresh);
@@ -420,7 +489,15 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
                             !((g.f_pulses > NUM_PULSES_CMD) && (T1_SAMPLES - g.f_n < 64)) &&
                             (g.run_closed >= DC_LEN);
   float dcr, dci;
-  if (B.has && B.any_closed) {
+  if (a.knock & 1) {
+    dcr = g.dcr_c + B.tre; dci = g.dci_c + B.tim;
+  } else if ((a.knock & 16) && B.has && B.any_closed) {   // developer aid: the integer-scan form of the sums (same results)
+    float sr, si;
+    const bool okr = chain_add_scan(g.dcr_c, B.tre, lane, sr);
+    const bool oki = chain_add_scan(g.dci_c, B.tim, lane, si);
+    if (__builtin_expect(okr && oki, 1)) { dcr = sr; dci = si; }
+    else chain_add2(g.dcr_c, B.tre, g.dci_c, B.tim, lane, dcr, dci);
+  } else if (B.has && B.any_closed) {
     chain_add2(g.dcr_c, B.tre, g.dci_c, B.tim, lane, dcr, dci);
   } else {
     // the back step lies entirely inside a window (or there is none): all its dc increments are
@@ -460,7 +537,7 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
   //   (A) the whole step lies inside an open window that does not end in it;
   //   (B) gate closed, POS_EDGE, no sample below the threshold, no opening due, and the dc ring
   //       fast path applies (the previous 48 samples were closed too).
-  if (__builtin_expect(plain_open || plain_closed, 1)) {
+  if (__builtin_expect(plain_open || plain_closed || (a.knock & 4), 1)) {
     // both plain cases in one straight-line block (selects, no branch between them)
     const float s_tre = f_tre, s_tim = f_tim;
     g.f_n += 64;
@@ -812,8 +889,8 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
             while (k - wv::lds_load(&sh.cons_seq) >= GATE_SLOTS) wv::backoff();
             if (PROF) { t1 = wv::ticks(); p_wait += t1 - tw; }
             const float2 yv = gate_fir_step(buf[u], sh.rawtile, lane, u == 0 && grp == 0 && at_start);
-            gate_load_raw(buf[u], xs, hi_idx, rbase + (int64_t)(k + GATE_RAW_DEPTH) * 64 * DECIM, lane, vec);
-            yw[64 * k + lane] = yv;
+            gate_load_raw(buf[u], xs, hi_idx, rbase + (int64_t)(((a.knock & 64) ? (k & 7) : k) + GATE_RAW_DEPTH) * 64 * DECIM, lane, vec);
+            yw[64 * ((a.knock & 64) ? (k & 7) : k) + lane] = yv;
             sh.slots[k % GATE_SLOTS].yv[lane] = yv;
             wv::lds_store(&sh.fir_seq, k + 1, lane);   // after the slot's data (in-order LDS queue)
             if (PROF) p_fir += wv::ticks() - t1;
@@ -885,7 +962,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
       if (PROF) g_wait += wv::ticks() - tw;
       if (!stopped) {
         GateSlot &slot = sh.slots[k % GATE_SLOTS];
-        gate_produce(slot, slot.yv[lane], prev_yv, 64 * k, n, lane, sh.win, win_index);
+        gate_produce(slot, slot.yv[lane], prev_yv, 64 * k, n, lane, sh.win, win_index, a.knock);
         wv::lds_store(&sh.prod_seq, k + 1, lane);   // after the slot's data (in-order LDS queue)
       }
     }
@@ -905,7 +982,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
       }
       if (PROF) a_wait += wv::ticks() - tw;
       if (!stopped) {
-        gate_average(sh.slots[k % GATE_SLOTS], n - 64 * k, lane, avg_c);
+        gate_average(sh.slots[k % GATE_SLOTS], n - 64 * k, lane, avg_c, a.knock);
         wv::lds_store(&sh.avg_seq, k + 1, lane);
       }
     }
@@ -937,6 +1014,12 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
     B.has = false; B.tre = 0.0f; B.tim = 0.0f; B.openmask = 0; B.yv = make_float2(0.0f, 0.0f);
     B.open_lane = B.open_lane2 = -1; B.open_type = B.open_type2 = 0; B.pos = 0; B.any_closed = false;
     wv::wave_sync();
+    if (a.knock & 32) {
+      for (int k = 0; k < nsteps; ++k) {
+        while (wv::lds_load(&sh.avg_seq) <= k) wv::backoff();
+        wv::lds_store(&sh.cons_seq, k + 1, lane);
+      }
+    } else
     for (int k = 0; k < nsteps && !g.stop; ++k) {
       // (waits until step k is produced and averaged)
       gate_consume<PROF>(a, g, B, &sh.slots[k % GATE_SLOTS], &sh.slots[(k + 1) % GATE_SLOTS], nx, true, &sh.avg_seq, k, 64 * k, n, n_total, s, lane, lds_dc,
@@ -1618,11 +1701,18 @@ struct SelfTestArgs {
   float *div_out;    // [64]
   float *hyp_out;    // [64] hypot(num, x)
   float *shr_out;    // [64]
+  float *scan_out;   // [65] chain_add_scan (or its fallback); [64] = 1 when the scan was provably exact
 };
 
 RFID_KERNEL(64) void selftest_kernel(SelfTestArgs a) {
   const int lane = wv::lane_id();
   a.chain_out[lane] = chain_add(a.carry, a.x[lane], lane);
+  if (a.scan_out) {
+    float v = 0.0f;
+    const bool ok = chain_add_scan(a.carry, a.x[lane], lane, v);
+    a.scan_out[lane] = ok ? v : chain_add(a.carry, a.x[lane], lane);
+    if (lane == 0) a.scan_out[64] = ok ? 1.0f : 0.0f;
+  }
   {
     const float num = a.num[lane], den = a.den[lane];
     a.div_out[lane] = (den == WIN_LEN_F) ? div_const<WIN_LEN>(num) : ((den == DC_LEN_F) ? div_const<DC_LEN>(num) : wv::fdiv(num, den));

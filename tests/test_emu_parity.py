@@ -187,3 +187,36 @@ def test_emulated_gen2_synthesiser_equals_numpy_generator(emu_mod, synth_mod, kw
     xn = emu_mod.synth_gen2(t.plan, sigma=0.01, seed=77, replica=5)
     want = emu_mod.synth_replicas(t.samples, 1, 0.01, seed=77, first_replica=5)[0]
     assert np.array_equal(xn.view(np.uint32), want.view(np.uint32))
+
+
+def test_emulated_chain_scan_is_exact(emu_mod):
+    """chain_add_scan (the in-order binary32 sum as ONE integer prefix sum on the mantissa, taken only when every
+    partial sum provably stays inside the carry's binade and no addend is a rounding tie) equals the 63-deep
+    sequential chain bit for bit -- on random data of the receive path's magnitudes, negative carries, exact ties,
+    partial sums that cross a power of two, zero / tiny / huge carries -- and does apply in the common case."""
+    rng = np.random.default_rng(11)
+    n_clean = 0
+    cases = []
+    for _ in range(300):
+        carry = float(rng.choice([23.456789, -19.12345, 31.99999, 16.000002, 0.0, 1e-30, -15.99999, 3.0e5, 25.0, 8.5, -0.75]))
+        scale = float(rng.choice([1e-4, 1e-3, 1e-2, 0.3, 1e-8, 1e3]))
+        x = (rng.standard_normal(64) * scale).astype(np.float32)
+        kind = rng.integers(0, 4)
+        if kind == 1:
+            x[::3] = np.ldexp(rng.integers(-7, 8, len(x[::3])).astype(np.float32) + 0.5, -19)   # half-ulp at 16..32
+        if kind == 2:
+            x[rng.integers(0, 64)] = 0.0
+            x[5] = -0.0
+        cases.append((x, carry))
+    cases.append((np.zeros(64, np.float32), 25.0))
+    cases.append((np.full(64, 2.0 ** -19, np.float32), 31.9999))      # walks up to and across 32
+    cases.append((np.full(64, -2.0 ** -20, np.float32), 16.00001))    # walks down across 16: ties and a binade edge
+    for x, carry in cases:
+        chain, scan, clean = emu_mod.chain_scan(x, carry)
+        acc = np.float32(carry)
+        for i in range(64):
+            acc = np.float32(acc + x[i])
+            assert chain[i].view(np.uint32) == acc.view(np.uint32)
+        assert np.array_equal(scan.view(np.uint32), chain.view(np.uint32)), (carry, clean)
+        n_clean += clean
+    assert n_clean > 60       # the scan path is exercised, not just the fallback

@@ -105,6 +105,15 @@ def selftest(x, num, den, carry):
     return outs
 
 
+def chain_scan(x, carry):
+    """-> (chain, scan, clean): the exact 63-deep chain, chain_add_scan (or its fallback), and whether the scan applied."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    chain = np.zeros(64, dtype=np.float32)
+    scan = np.zeros(65, dtype=np.float32)
+    lib().emu_chain_scan(C.c_void_p(x.ctypes.data), C.c_float(carry), C.c_void_p(chain.ctypes.data), C.c_void_p(scan.ctypes.data))
+    return chain, scan[:64], bool(scan[64])
+
+
 def synth_replicas(base: np.ndarray, n_streams: int, sigma: float, seed: int, first_replica: int = 0) -> np.ndarray:
     base = np.ascontiguousarray(base, dtype=np.complex64)
     out = np.zeros((n_streams, len(base)), dtype=np.complex64)

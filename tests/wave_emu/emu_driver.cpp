@@ -65,7 +65,24 @@ void launch(Idx3 grid, Idx3 block, const std::function<void()> &body) {
           makecontext(&f.ctx, fiber_entry, 0);
         }
         int remaining = nthreads;
+        long sweeps = 0;
         while (remaining > 0) {
+          // watchdog (a kernel that never finishes under lock-step emulation): report where the waves stand
+          if (++sweeps == 3000000L && getenv("RFID_EMU_WATCHDOG")) {
+            for (int w = 0; w < nwaves; ++w) {
+              const Fiber &f0 = B.fibers[(size_t)w * 64];
+              fprintf(stderr, "[emu watchdog] wave %d: lane0 done=%d wave_calls=%llu arrived=%d gen=%llu", w, (int)f0.done,
+                      (unsigned long long)f0.wave_calls, B.wave_arrived[(size_t)w], (unsigned long long)B.wave_gen[(size_t)w]);
+              for (int l = 1; l < 64 && w * 64 + l < nthreads; ++l)
+                if (B.fibers[(size_t)w * 64 + l].wave_calls != f0.wave_calls || B.fibers[(size_t)w * 64 + l].done != f0.done) {
+                  fprintf(stderr, " | lane %d: done=%d wave_calls=%llu", l, (int)B.fibers[(size_t)w * 64 + l].done,
+                          (unsigned long long)B.fibers[(size_t)w * 64 + l].wave_calls);
+                  break;
+                }
+              fprintf(stderr, "\n");
+            }
+            abort();
+          }
           remaining = 0;
           for (int t = 0; t < nthreads; ++t) {
             Fiber &f = B.fibers[(size_t)t];
@@ -233,7 +250,17 @@ int emu_selftest(const float *x, const float *num, const float *den, float carry
                  float *div_out, float *hyp_out, float *shr_out) {
   SelfTestArgs a;
   a.x = x; a.num = num; a.den = den; a.carry = carry; a.chain_out = chain_out; a.div_out = div_out;
-  a.hyp_out = hyp_out; a.shr_out = shr_out;
+  a.hyp_out = hyp_out; a.shr_out = shr_out; a.scan_out = nullptr;
+  emu::launch(emu::Idx3{1, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { selftest_kernel(a); });
+  return 0;
+}
+
+// in-order sum: the integer-scan form against the chain; scan_out[64] = 1 when the scan was provably exact
+int emu_chain_scan(const float *x, float carry, float *chain_out, float *scan_out) {
+  std::vector<float> z(64, 1.0f), o(64 * 3);
+  SelfTestArgs a;
+  a.x = x; a.num = z.data(); a.den = z.data(); a.carry = carry; a.chain_out = chain_out; a.div_out = o.data();
+  a.hyp_out = o.data() + 64; a.shr_out = o.data() + 128; a.scan_out = scan_out;
   emu::launch(emu::Idx3{1, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { selftest_kernel(a); });
   return 0;
 }

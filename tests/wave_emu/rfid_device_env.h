@@ -114,6 +114,14 @@ static inline float shr1(float v) {
   const int l = lane_id();
   return (l == 0) ? 0.0f : emu::u2f((uint32_t)b[l - 1]);
 }
+static inline int scan_add(int v) {
+  const uint64_t *b = emu::exchange((uint32_t)v);
+  int acc = 0;
+  for (int i = 0; i <= lane_id(); ++i) acc += (int)(uint32_t)b[i];
+  return acc;
+}
+static inline float rint_f(float v) { return nearbyintf(v); }   // default rounding mode: to nearest, ties to even
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline float readlane(float v, int k) { return emu::u2f((uint32_t)emu::exchange(emu::f2u(v))[k & 63]); }
 static inline int readlane(int v, int k) { return (int)(uint32_t)emu::exchange((uint32_t)v)[k & 63]; }
 // readfirstlane: lane 0's value (all lanes are live at every call site in the kernels)
@@ -151,13 +159,15 @@ static inline void block_sync() {
 }
 static inline void wave_sync() { emu::wave_barrier(); }
 static inline void block_sync_lds() { block_sync(); }
-static inline int lds_load(const int *p) { return *(const volatile int *)p; }
+// the device versions end in v_readfirstlane: every lane gets LANE 0's read (lanes are fibers here and would
+// otherwise sample a mailbox word at different times and diverge)
+static inline int lds_load(const int *p) { return (int)(uint32_t)emu::exchange((uint32_t)*(const volatile int *)p)[0]; }
 static inline int lds_peek(const int *p) { return *(const volatile int *)p; }
 static inline void lds_peek_masks(const uint64_t *p, uint64_t &a, uint64_t &b) { a = ((const volatile uint64_t *)p)[0]; b = ((const volatile uint64_t *)p)[1]; }
 static inline uint64_t uniform64(uint64_t v) { return v; }
-static inline float lds_load_f(const float *p) { return *(const volatile float *)p; }
+static inline float lds_load_f(const float *p) { return emu::u2f((uint32_t)emu::exchange(emu::f2u(*(const volatile float *)p))[0]); }
 static inline void lds_store(int *p, int v, int lane) { emu::wave_barrier(); if (lane == 0) *(volatile int *)p = v; }
-static inline uint64_t lds_load64(const uint64_t *p) { return *(const volatile uint64_t *)p; }
+static inline uint64_t lds_load64(const uint64_t *p) { return emu::exchange(*(const volatile uint64_t *)p)[0]; }
 static inline void lds_store64(uint64_t *p, uint64_t v, int lane) { emu::wave_barrier(); if (lane == 0) *(volatile uint64_t *)p = v; }
 static inline void set_priority_high() {}
 static inline void backoff() { emu::yield(); }
