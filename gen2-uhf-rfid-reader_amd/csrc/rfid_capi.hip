@@ -7,9 +7,11 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <ctime>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
 #include <vector>
 
@@ -44,6 +46,10 @@ struct rfid_ctx {
   int *d_io = nullptr;            // [2]
   DevBuf s_in, s_out;
   DevBuf synth_tab;               // slot table of rfid_synth_gen2
+  // long-stream front end (few long traces cut into concurrently scanned units)
+  DevBuf ls_cut, ls_units, ls_runs, ls_tmpl, ls_state, ls_uw, ls_uwc, ls_heads, ls_seq0, ls_gath;
+  int ls_mode = 1;                // 0 never, 1 automatic, 2 whenever a trace can be cut
+  rfid_ls_report ls_rep;
   rfid_window *d_swin = nullptr;  // one window
   int *d_scount = nullptr;
   rfid_decode_result *d_sres = nullptr;
@@ -163,6 +169,383 @@ void next_slot(rfid_reader_state &rs) {
 
 }  // namespace
 
+
+// ======================================================================================
+// long-stream front end
+// ======================================================================================
+// The gate scan is a sequential recurrence per trace; with few traces most of the chip idles (one trace = one
+// SIMD).  Here a trace is cut along time into units at idle points of the gate's state machine and the units are
+// scanned CONCURRENTLY by the same gate_scan_kernel, each from a predicted gate state.  What a unit needs from its
+// past are three binary32 values -- avg_ampl and the two components of dc_est, in-order sums over the whole trace,
+// rounding drift included -- plus the idle state machine and the two rings (the preceding samples themselves).
+// Binary32 addition commutes with a shift of the start value by a multiple of its ulp except where a partial sum
+// sits next to a power of two, and except for the parity of the shift at rounding ties; so every round runs each
+// unit from its predicted start s (variant A) and from s + 1 ulp (variant B), and the host chains the units:
+//   true start t = s + d ulps  ->  predicted end = end_A + d (d even) or end_B + (d - 1) (d odd).
+// A round whose predictions were all exact (d = 0 for all three values of every unit, every cut idle) is, by
+// induction over the units, THE sequential scan: its variant-A windows are accepted.  Otherwise the predictions
+// become the next round's starts (first round: ring means; typically exact from the third round on).  Nothing is
+// assumed about the arithmetic: a wrong prediction only costs another round, and after LS_MAX_ROUNDS the caller
+// falls back to the plain sequential scan.
+namespace {
+const int LS_MAX_ROUNDS = 10;
+const int LS_TARGET_UNITS = 4096;
+const int LS_MIN_CHUNK = 6144;
+
+struct LsStart {  // what a unit needs from its past besides the rings: the three recurrences + the state machine's scalars
+  float v[3];     // avg_ampl, dc_re, dc_im
+  int f[6];       // n_samples, signal_state, num_pulses, gate_open, n_to_ungate, wtype
+};
+struct LsHead {   // first 12 words of GateState
+  float avg, dcr, dci;
+  int n_samples, signal_state, num_pulses, gate_open, n_to_ungate, wtype, win_index, dc_index, win_seq;
+};
+static_assert(sizeof(LsHead) == 48, "GateState head");
+
+inline int64_t f_ord(float f) {   // monotone integer image of a binary32 value (distance = ulps)
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return (u & 0x80000000u) ? -(int64_t)(u & 0x7fffffffu) : (int64_t)u;
+}
+inline float f_from_ord(int64_t k) {
+  uint32_t u = (k < 0) ? (0x80000000u | (uint32_t)(-k)) : (uint32_t)k;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// returns RFID_OK and *done = 1 when the window tables were produced; *done = 0: not applicable / gave up (caller
+// runs the sequential scan); < 0 on errors
+double ls_now_ms() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
+}
+int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done) {
+  *done = 0;
+  const bool dbg = getenv("RFID_LS_DEBUG") != nullptr;
+  const double t_begin = ls_now_ms();
+  auto lap = [&](const char *what) { if (dbg) fprintf(stderr, "[ls] t=%8.2f ms  %s\n", ls_now_ms() - t_begin, what); };
+  rfid_ls_report &rep = c->ls_rep;
+  memset(&rep, 0, sizeof(rep));
+  const int B = c->B;
+  if (c->ls_mode == 0 || n_dec < 2 * LS_MIN_CHUNK) return RFID_OK;
+  if (c->ls_mode == 1 && B > 512) return RFID_OK;
+  // ---- per-trace lengths ----
+  std::vector<int64_t> nd((size_t)B, n_dec);
+  if (c->d_lens) {
+    std::vector<int64_t> hl((size_t)B);
+    HIPCHK(c, hipMemcpyAsync(hl.data(), c->d_lens, sizeof(int64_t) * (size_t)B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int s = 0; s < B; ++s) {
+      int64_t r = hl[(size_t)s] < 0 ? 0 : hl[(size_t)s] / DECIM;
+      nd[(size_t)s] = r < n_dec ? r : n_dec;
+    }
+  }
+  int64_t total = 0;
+  for (int64_t v : nd) total += v;
+  int64_t chunk = (total + LS_TARGET_UNITS - 1) / LS_TARGET_UNITS;
+  if (chunk < LS_MIN_CHUNK) chunk = LS_MIN_CHUNK;
+  chunk = (chunk + 63) & ~63LL;
+  if (chunk > 0x3fffffff) return RFID_OK;
+  int max_b = 1;
+  int64_t nominal = 0;
+  for (int64_t v : nd) {
+    const int nb = (int)(v / chunk);
+    if (nb + 1 > max_b) max_b = nb + 1;
+    nominal += (nb > 0 ? nb : 1);
+  }
+  if (max_b < 2 || (c->ls_mode == 1 && nominal < 2 * (int64_t)B)) return RFID_OK;   // nothing to gain
+  // ---- idle cut points near the nominal boundaries ----
+  int rc = grow(c, c->ls_cut, sizeof(int) * (size_t)B * (size_t)max_b);
+  if (rc) return rc;
+  LsCutArgs ca;
+  ca.y = c->d_y; ca.y_stride = c->y_stride; ca.lens = c->d_lens; ca.n_dec = n_dec; ca.chunk = (int)chunk;
+  ca.limit = (int)(chunk / 2); ca.max_b = max_b; ca.cut = (int *)c->ls_cut.p;
+  hipLaunchKernelGGL(ls_cut_kernel, dim3((unsigned)(max_b - 1), (unsigned)B), dim3(64), 0, c->stream, ca);
+  HIPCHK(c, hipGetLastError());
+  std::vector<int> cut((size_t)B * (size_t)max_b);
+  HIPCHK(c, hipMemcpyAsync(cut.data(), c->ls_cut.p, sizeof(int) * cut.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<char> banned(cut.size(), 0);
+  lap("cut points found");
+  std::map<int64_t, LsStart> known;   // predictions carried over when a cut is withdrawn and the units are rebuilt
+
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    // ---- units ----
+    std::vector<GateUnit> units;
+    std::vector<size_t> cut_of_unit;            // index into cut[] of the boundary that STARTS the unit (0 for a trace's first)
+    for (int s = 0; s < B; ++s) {
+      int pos = 0;
+      const int n = (int)nd[(size_t)s];
+      size_t started_by = (size_t)-1;
+      for (int j = 1; j < max_b; ++j) {
+        const size_t ci = (size_t)s * (size_t)max_b + (size_t)j;
+        const int p = cut[ci];
+        if (p <= pos || p >= n || banned[ci]) continue;
+        GateUnit u; u.stream = s; u.pos0 = pos; u.len = p - pos; u.row = 0;
+        units.push_back(u); cut_of_unit.push_back(started_by);
+        pos = p; started_by = ci;
+      }
+      GateUnit u; u.stream = s; u.pos0 = pos; u.len = n - pos; u.row = 0;
+      units.push_back(u); cut_of_unit.push_back(started_by);
+    }
+    const int U = (int)units.size();
+    if (U <= B) return RFID_OK;   // no cut found: sequential scan
+    int max_len = 0;
+    for (const GateUnit &u : units) if (u.len > max_len) max_len = u.len;
+    const int uwmax = max_len / (RN16_WIN + T1_SAMPLES + 1) + 2;
+    if ((rc = grow(c, c->ls_units, sizeof(GateUnit) * (size_t)U))) return rc;
+    if ((rc = grow(c, c->ls_runs, sizeof(GateUnit) * 2 * (size_t)U))) return rc;
+    if ((rc = grow(c, c->ls_tmpl, sizeof(GateState) * (size_t)U))) return rc;
+    if ((rc = grow(c, c->ls_state, sizeof(GateState) * 2 * (size_t)U))) return rc;
+    if ((rc = grow(c, c->ls_uw, sizeof(rfid_window) * 2 * (size_t)U * (size_t)uwmax))) return rc;
+    if ((rc = grow(c, c->ls_uwc, sizeof(int) * 2 * (size_t)U))) return rc;
+    if ((rc = grow(c, c->ls_heads, sizeof(int) * LS_HEAD_WORDS * 2 * (size_t)U + sizeof(float) * 4 * (size_t)U))) return rc;
+    if ((rc = grow(c, c->ls_seq0, sizeof(int) * (size_t)U))) return rc;
+    if ((rc = grow(c, c->ls_gath, sizeof(int) * (12 * 2 + 1) * (size_t)U))) return rc;
+    for (int u = 0; u < U; ++u) units[(size_t)u].row = u;
+    HIPCHK(c, hipMemcpyAsync(c->ls_units.p, units.data(), sizeof(GateUnit) * (size_t)U, hipMemcpyHostToDevice, c->stream));
+    LsInitArgs ia;
+    ia.y = c->d_y; ia.y_stride = c->y_stride; ia.units = (const GateUnit *)c->ls_units.p; ia.n_units = U;
+    ia.tmpl = (GateState *)c->ls_tmpl.p;
+    hipLaunchKernelGGL(ls_init_kernel, dim3((unsigned)U), dim3(64), 0, c->stream, ia);
+    HIPCHK(c, hipGetLastError());
+    std::vector<LsHead> th((size_t)U), eh(2 * (size_t)U);
+    HIPCHK(c, hipMemcpy2DAsync(th.data(), sizeof(LsHead), c->ls_tmpl.p, sizeof(GateState), sizeof(LsHead), (size_t)U,
+                               hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // predicted start of every unit: first guess = the template (ring means, idle state machine), or what an earlier
+    // attempt (before a cut was withdrawn) had already worked out for a unit that starts at the same sample
+    std::vector<LsStart> start((size_t)U);
+    std::vector<char> avg_known((size_t)U, 0);
+    for (int u = 0; u < U; ++u) {
+      LsStart &st = start[(size_t)u];
+      st.v[0] = th[u].avg; st.v[1] = th[u].dcr; st.v[2] = th[u].dci;
+      st.f[0] = th[u].n_samples; st.f[1] = th[u].signal_state; st.f[2] = th[u].num_pulses; st.f[3] = th[u].gate_open;
+      st.f[4] = th[u].n_to_ungate; st.f[5] = th[u].wtype;
+      auto it = known.find(((int64_t)units[(size_t)u].stream << 32) | (uint32_t)units[(size_t)u].pos0);
+      if (it != known.end()) { st = it->second; avg_known[(size_t)u] = 1; }
+    }
+    lap("units built, templates initialised");
+    auto first_of_trace = [&](int u) { return units[(size_t)u].pos0 == 0; };
+    auto last_of_trace = [&](int u) { return (u + 1 == U) || units[(size_t)u + 1].stream != units[(size_t)u].stream; };
+    // runs are launched selectively: per trace, the units before `frozen` already ran from their exact start state in an
+    // earlier round (their end state / windows in rows [0, U) are final); the rest is re-run
+    std::vector<GateUnit> runs;
+    runs.reserve(2 * (size_t)U);
+
+    // ---- phase 1: avg_ampl alone (cheap kernel): exact value at every cut ---------------------------------------------
+    {
+      std::vector<float> av(2 * (size_t)U), ae(2 * (size_t)U);
+      std::vector<char> exact((size_t)U, 0);
+      bool all = false;
+      for (int round = 1; round <= 3 * LS_MAX_ROUNDS && !all; ++round) {
+        runs.clear();
+        for (int v = 0; v < 2; ++v)
+          for (int u = 0; u < U; ++u) {
+            if (exact[(size_t)u]) continue;
+            if (v == 1 && first_of_trace(u)) continue;
+            GateUnit r = units[(size_t)u];
+            r.row = v * U + u;
+            runs.push_back(r);
+            av[(size_t)r.row] = v ? f_from_ord(f_ord(start[(size_t)u].v[0]) + 1) : start[(size_t)u].v[0];
+          }
+        if ((rc = grow(c, c->ls_heads, sizeof(int) * LS_HEAD_WORDS * 2 * (size_t)U + sizeof(float) * 4 * (size_t)U))) return rc;
+        float *d_av = (float *)((int *)c->ls_heads.p + LS_HEAD_WORDS * 2 * (size_t)U), *d_ae = d_av + 2 * (size_t)U;
+        if ((rc = grow(c, c->ls_runs, sizeof(GateUnit) * 2 * (size_t)U))) return rc;
+        HIPCHK(c, hipMemcpyAsync(d_av, av.data(), sizeof(float) * 2 * (size_t)U, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->ls_runs.p, runs.data(), sizeof(GateUnit) * runs.size(), hipMemcpyHostToDevice, c->stream));
+        LsAvgArgs aa;
+        aa.y = c->d_y; aa.y_stride = c->y_stride; aa.units = (const GateUnit *)c->ls_runs.p; aa.n_runs = (int)runs.size();
+        aa.start = d_av; aa.end = d_ae;
+        hipLaunchKernelGGL(ls_avg_kernel, dim3((unsigned)runs.size()), dim3(64), 0, c->stream, aa);
+        HIPCHK(c, hipGetLastError());
+        std::vector<float> got(2 * (size_t)U);
+        HIPCHK(c, hipMemcpyAsync(got.data(), d_ae, sizeof(float) * 2 * (size_t)U, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (const GateUnit &r : runs) ae[(size_t)r.row] = got[(size_t)r.row];
+        rep.avg_passes++;
+        all = true;
+        float t = 0.0f;
+        bool chain_exact = true;   // every unit of this trace so far started from its true value
+        for (int u = 0; u < U; ++u) {
+          if (first_of_trace(u)) { t = 0.0f; chain_exact = true; }
+          const float sA = start[(size_t)u].v[0];
+          const int64_t d = f_ord(t) - f_ord(sA);
+          float pred;
+          if (d == 0) pred = ae[(size_t)u];
+          else if ((d & 1) == 0 || first_of_trace(u)) pred = f_from_ord(f_ord(ae[(size_t)u]) + d);
+          else pred = f_from_ord(f_ord(ae[(size_t)U + (size_t)u]) + (d - 1));
+          if (d != 0) chain_exact = false;
+          if (chain_exact) exact[(size_t)u] = 1; else all = false;
+          start[(size_t)u].v[0] = t;
+          t = pred;
+        }
+      }
+      if (!all) break;   // (gives up: sequential scan)
+    }
+    lap("avg_ampl settled");
+
+    // ---- phase 2: the full gate scan; avg_ampl starts exact, dc_est and the state machine's scalars are predicted ------
+    std::vector<int> heads((size_t)LS_HEAD_WORDS * 2 * (size_t)U);
+    std::vector<char> frozen((size_t)U, 0);
+    std::vector<LsHead> got;
+    bool restart = false, accepted = false;
+    for (int round = 1; round <= LS_MAX_ROUNDS && !restart && !accepted; ++round) {
+      // both variants (dc_est starts s and s + 1 ulp) while predictions still move; a round that is expected to
+      // confirm runs variant A alone first
+      for (int pass = 0; pass < 2 && !accepted && !restart; ++pass) {
+        const bool with_b = (round == 2) || pass == 1;
+        if (round <= 2 && pass == 1) break;
+        runs.clear();
+        for (int v = 0; v < (with_b ? 2 : 1); ++v)
+          for (int u = 0; u < U; ++u) {
+            if (frozen[(size_t)u]) continue;
+            GateUnit r = units[(size_t)u];
+            r.row = v * U + u;
+            runs.push_back(r);
+            const LsStart &st = start[(size_t)u];
+            int *h = &heads[(size_t)LS_HEAD_WORDS * (size_t)r.row];
+            memcpy(&h[0], &st.v[0], 4);   // avg_ampl: exact in both variants (it steers the state machine)
+            for (int k = 1; k < 3; ++k) {
+              const float vb = (v == 0 || first_of_trace(u)) ? st.v[k] : f_from_ord(f_ord(st.v[k]) + 1);
+              memcpy(&h[k], &vb, 4);
+            }
+            for (int k = 0; k < 6; ++k) h[3 + k] = st.f[k];
+          }
+        const int n_run = (int)runs.size();
+        HIPCHK(c, hipMemcpyAsync(c->ls_heads.p, heads.data(), sizeof(int) * heads.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->ls_runs.p, runs.data(), sizeof(GateUnit) * runs.size(), hipMemcpyHostToDevice, c->stream));
+        LsHeadsArgs ha;
+        ha.tmpl = (const GateState *)c->ls_tmpl.p; ha.state = (GateState *)c->ls_state.p; ha.heads = (const int *)c->ls_heads.p;
+        ha.runs = (const GateUnit *)c->ls_runs.p; ha.n_runs = n_run; ha.n_units = U;
+        hipLaunchKernelGGL(ls_set_state_kernel, dim3((unsigned)n_run), dim3(64), 0, c->stream, ha);
+        HIPCHK(c, hipGetLastError());
+        GateArgs g = {};
+        g.y = c->d_y; g.y_stride = c->y_stride; g.n_dec = n_dec; g.lens = c->d_lens; g.pos0 = 0; g.chunk_len = n_dec;
+        g.state = (GateState *)c->ls_state.p; g.n_streams = n_run; g.wtab = (rfid_window *)c->ls_uw.p; g.wmax = uwmax;
+        g.wcount = (int *)c->ls_uwc.p; g.flat = nullptr; g.flat_count = nullptr; g.flat_cap = 0; g.mode = 0;
+        g.units = (const GateUnit *)c->ls_runs.p;
+        hipLaunchKernelGGL(gate_scan_kernel, dim3((unsigned)((n_run + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG)),
+                           dim3(GATE_THREADS), 0, c->stream, g);
+        HIPCHK(c, hipGetLastError());
+        rep.gate_passes += with_b ? 2 : 1;
+        rep.unit_runs += n_run;
+        {
+          LsGatherArgs ga;
+          ga.state = (const GateState *)c->ls_state.p; ga.heads = (int *)c->ls_gath.p; ga.n_rows = 2 * U;
+          ga.uwtab = (const rfid_window *)c->ls_uw.p; ga.uwcount = (const int *)c->ls_uwc.p; ga.n_units = U; ga.uwmax = uwmax;
+          ga.last_end = (int *)c->ls_gath.p + 12 * 2 * (size_t)U;
+          hipLaunchKernelGGL(ls_gather_kernel, dim3((unsigned)((2 * U * 12 + 255) / 256)), dim3(256), 0, c->stream, ga);
+          HIPCHK(c, hipGetLastError());
+        }
+        got.resize(2 * (size_t)U);
+        HIPCHK(c, hipMemcpyAsync(got.data(), c->ls_gath.p, sizeof(LsHead) * 2 * (size_t)U, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (const GateUnit &r : runs) eh[(size_t)r.row] = got[(size_t)r.row];
+        // ---- chain the units of every trace: true start of unit u+1 = (predicted) end of unit u ----
+        bool all_exact = true, chain_exact = true;
+        int n_moved = 0;
+        std::vector<LsStart> next(start);
+        for (int u = 0; u < U; ++u) {
+          if (first_of_trace(u)) chain_exact = true;
+          if (frozen[(size_t)u]) {   // final: its end state is the exact one
+            if (!last_of_trace(u)) {
+              LsStart &nx = next[(size_t)u + 1];
+              nx.v[0] = eh[u].avg; nx.v[1] = eh[u].dcr; nx.v[2] = eh[u].dci;
+              nx.f[0] = eh[u].n_samples; nx.f[1] = eh[u].signal_state; nx.f[2] = eh[u].num_pulses; nx.f[3] = eh[u].gate_open;
+              nx.f[4] = eh[u].n_to_ungate; nx.f[5] = eh[u].wtype;
+            }
+            continue;
+          }
+          const LsStart t = first_of_trace(u) ? start[(size_t)u] : next[(size_t)u];   // (a first unit's start is the exact fresh gate)
+          const LsStart &sA = start[(size_t)u];
+          const float eA[3] = {eh[u].avg, eh[u].dcr, eh[u].dci};
+          LsStart pred;
+          bool exact = true;
+          for (int k = 0; k < 3; ++k) {
+            const int64_t d = f_ord(t.v[k]) - f_ord(sA.v[k]);
+            if (d != 0) exact = false;
+            if (d == 0) pred.v[k] = eA[k];
+            else if (k == 0 || (d & 1) == 0 || !with_b || first_of_trace(u)) pred.v[k] = f_from_ord(f_ord(eA[k]) + d);
+            else pred.v[k] = f_from_ord(f_ord(k == 1 ? eh[U + u].dcr : eh[U + u].dci) + (d - 1));
+          }
+          for (int k = 0; k < 6; ++k) if (t.f[k] != sA.f[k]) exact = false;
+          pred.f[0] = eh[u].n_samples; pred.f[1] = eh[u].signal_state; pred.f[2] = eh[u].num_pulses; pred.f[3] = eh[u].gate_open;
+          pred.f[4] = eh[u].n_to_ungate; pred.f[5] = eh[u].wtype;
+          if (!exact) { chain_exact = false; n_moved++; }
+          if (chain_exact) frozen[(size_t)u] = 1; else all_exact = false;
+          next[(size_t)u] = t;
+          if (!last_of_trace(u)) next[(size_t)u + 1] = pred;
+        }
+        rep.rounds = round;
+        rep.units = U;
+        rep.last_round_moved = n_moved;
+        if (getenv("RFID_LS_DEBUG")) {
+          int first_bad = -1;
+          for (int u = 0; u < U && first_bad < 0; ++u) if (!frozen[(size_t)u]) first_bad = u;
+          int64_t dmax = 0;
+          for (int u = 0; u < U; ++u) for (int k = 0; k < 3; ++k) {
+            int64_t d = f_ord(next[(size_t)u].v[k]) - f_ord(start[(size_t)u].v[k]); if (d < 0) d = -d; if (d > dmax) dmax = d; }
+          fprintf(stderr, "[ls] attempt %d round %d pass %d with_b=%d runs=%d moved=%d first_open=%d max|d|=%lld ulps avg_passes=%d\n", attempt,
+                  round, pass, (int)with_b, n_run, n_moved, first_bad, (long long)dmax, rep.avg_passes);
+        }
+        start = next;
+        if (all_exact) {
+          // ---- what the rings need at every cut: the 48 samples before it all "closed" (then dc_samples holds exactly
+          //      those samples, as the template does; win_samples always holds the last 100 amplitudes) ----
+          std::vector<int> uwc((size_t)U), lend((size_t)U);
+          HIPCHK(c, hipMemcpyAsync(uwc.data(), c->ls_uwc.p, sizeof(int) * (size_t)U, hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(c, hipMemcpyAsync(lend.data(), (int *)c->ls_gath.p + 12 * 2 * (size_t)U, sizeof(int) * (size_t)U, hipMemcpyDeviceToHost,
+                                   c->stream));
+          HIPCHK(c, hipStreamSynchronize(c->stream));
+          std::vector<int> seq0((size_t)U, 0), wc((size_t)B, 0);
+          int last_end = -(1 << 30);
+          for (int u = 0; u < U && !restart; ++u) {
+            const GateUnit &un = units[(size_t)u];
+            if (un.pos0 == 0) last_end = -(1 << 30);
+            else if (last_end > un.pos0 - DC_LEN || start[(size_t)u].f[3] != 0) {
+              banned[cut_of_unit[(size_t)u]] = 1; restart = true; rep.cuts_dropped++;
+              break;
+            }
+            int k = uwc[(size_t)u];
+            if (k > uwmax) k = uwmax;
+            seq0[(size_t)u] = wc[(size_t)un.stream];
+            wc[(size_t)un.stream] += k;
+            if (k > 0) last_end = lend[(size_t)u];
+          }
+          if (restart) {
+            for (int u = 0; u < U; ++u) known[((int64_t)units[(size_t)u].stream << 32) | (uint32_t)units[(size_t)u].pos0] = start[(size_t)u];
+            break;
+          }
+          // ---- accept: the frozen runs ARE the sequential scan; assemble their windows ----
+          for (int s = 0; s < B; ++s) if (wc[(size_t)s] > c->wmax) wc[(size_t)s] = c->wmax;
+          HIPCHK(c, hipMemcpyAsync(c->ls_seq0.p, seq0.data(), sizeof(int) * (size_t)U, hipMemcpyHostToDevice, c->stream));
+          HIPCHK(c, hipMemcpyAsync(c->d_wcount, wc.data(), sizeof(int) * (size_t)B, hipMemcpyHostToDevice, c->stream));
+          HIPCHK(c, hipMemsetAsync(c->d_flat_count, 0, 2 * sizeof(int), c->stream));
+          LsAssembleArgs aa;
+          aa.units = (const GateUnit *)c->ls_units.p; aa.uwtab = (const rfid_window *)c->ls_uw.p; aa.uwcount = (const int *)c->ls_uwc.p;
+          aa.seq0 = (const int *)c->ls_seq0.p; aa.n_units = U; aa.uwmax = uwmax; aa.wtab = c->d_wtab; aa.wmax = c->wmax;
+          aa.flat = c->d_flat; aa.flat_count = c->d_flat_count; aa.flat_cap = c->flat_cap;
+          hipLaunchKernelGGL(ls_assemble_kernel, dim3((unsigned)U), dim3(64), 0, c->stream, aa);
+          HIPCHK(c, hipGetLastError());
+          HIPCHK(c, hipStreamSynchronize(c->stream));   // seq0 / wc are host vectors
+          accepted = true;
+          rep.verified = 1;
+          lap("accepted and assembled");
+          break;
+        }
+      }
+    }
+    if (accepted) { *done = 1; rep.chunk = (int)chunk; return RFID_OK; }
+    if (!restart) break;   // rounds exhausted
+  }
+  rep.gave_up = 1;
+  return RFID_OK;
+}
+}  // namespace
+
 extern "C" {
 
 const char *rfid_version(void) { return "rfid_mi355x 0.1 (gfx950)"; }
@@ -209,6 +592,8 @@ int rfid_ctx_create(const rfid_params *p, int device, rfid_ctx **out) {
   c->device = device;
   c->err[0] = 0;
   compute_t_cand(c->t_cand, p->sample_rate);
+  if (const char *e = getenv("RFID_LONG_STREAM")) c->ls_mode = atoi(e);
+  memset(&c->ls_rep, 0, sizeof(c->ls_rep));
   init_reader_state(c);
   memset(c->mf_hist, 0, sizeof(c->mf_hist));
   int rc = RFID_OK;
@@ -247,7 +632,8 @@ int rfid_ctx_destroy(rfid_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   free_plan(c);
   void *ptrs[] = {c->d_gate1, c->d_io, c->d_swin, c->d_scount, c->d_sres, c->d_sscores, c->s_in.p, c->s_out.p,
-                  c->synth_tab.p};
+                  c->synth_tab.p, c->ls_cut.p, c->ls_units.p, c->ls_runs.p, c->ls_tmpl.p, c->ls_state.p, c->ls_uw.p, c->ls_uwc.p,
+                  c->ls_heads.p, c->ls_seq0.p, c->ls_gath.p};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < 5; ++i)
@@ -563,6 +949,23 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
   int nch = 1;
   if (const char *e = getenv("RFID_FRONT_CHUNKS")) nch = atoi(e);
   if (nch > rfid_ctx::MAX_CHUNKS) nch = rfid_ctx::MAX_CHUNKS;
+  memset(&c->ls_rep, 0, sizeof(c->ls_rep));
+  if (nch < 2 && c->ls_mode != 0 && n_out >= 2 * LS_MIN_CHUNK && (c->ls_mode == 2 || c->B <= 512)) {
+    // few long traces: matched filter, then the gate scan over concurrently scanned units of each trace
+    int rc = rfid_batch_mf(c, d_raw, raw_stride, n_raw, d_lens);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->d_gstate, 0, sizeof(GateState) * (size_t)c->B, c->stream));
+    int done = 0;
+    if ((rc = ls_front_end(c, n_out, &done))) return rc;
+    if (done) {
+      HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+      c->ev_valid[2] = true;
+    } else if ((rc = rfid_batch_gate(c))) {
+      return rc;
+    }
+    if ((rc = rfid_batch_decode(c, want_scores))) return rc;
+    return rfid_batch_stats(c);
+  }
   if (nch < 2 && raw_stride >= 2 && !getenv("RFID_FRONT_UNFUSED")) {
     // default: fused front end -- the gate's producer waves run the matched filter themselves
     // (one read of the raw samples, one write of y for the decoder, no second pass over y)
@@ -656,6 +1059,18 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
   int rc = rfid_batch_decode(c, want_scores);
   if (rc) return rc;
   return rfid_batch_stats(c);
+}
+
+int rfid_batch_set_long_stream(rfid_ctx *c, int mode) {
+  if (!c || mode < 0 || mode > 2) return RFID_ERR_INVALID;
+  c->ls_mode = mode;
+  return RFID_OK;
+}
+
+int rfid_batch_ls_report(const rfid_ctx *c, rfid_ls_report *out) {
+  if (!c || !out) return RFID_ERR_INVALID;
+  *out = c->ls_rep;
+  return RFID_OK;
 }
 
 int rfid_batch_sync(rfid_ctx *c) {

@@ -104,6 +104,7 @@ RFID_DEVICE void wave_sync() {
 // producer wave's register prefetch every step
 RFID_DEVICE void block_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 RFID_DEVICE int atomic_add(int *p, int v) { return atomicAdd(p, v); }
+RFID_DEVICE int atomic_min(int *p, int v) { return atomicMin(p, v); }
 // this wave's global stores are visible device-wide when this returns
 RFID_DEVICE void global_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
 // global load that bypasses the per-CU vector cache (device-coherent): for data another wave of

@@ -147,6 +147,15 @@ struct GateState {  // gate_impl members (gate_impl.h:36-44) + the READER_STATE 
   float dcr_im[DC_LEN];
 };
 
+// long-stream mode: one trace cut along time into units that are scanned concurrently, each from its own
+// (predicted) gate state -- see rfid_capi.hip, long-stream front end
+struct GateUnit {
+  int stream;           // trace the unit belongs to
+  int pos0;             // first decimated sample of the unit
+  int len;              // samples in the unit
+  int row;              // row of state / wtab / wcount this run uses (units are re-run selectively)
+};
+
 struct GateArgs {
   const float2 *y;      // [n_streams][y_stride] matched-filter output
   int64_t y_stride;
@@ -174,6 +183,7 @@ struct GateArgs {
   int64_t n_raw;        // valid raw samples per trace (when lens == nullptr)
   int raw_vec_ok;       // rows 16-byte aligned -> float4 loads
   float2 *y_w;          // [n_streams][y_stride], written
+  const GateUnit *units; // optional: n_streams counts UNITS; state / wtab / wcount are per unit
   int knock;            // developer aid (RFID_GATE_KNOCK): knock out parts of the work to time the rest -- WRONG RESULTS
 };
 
@@ -317,6 +327,7 @@ struct GateRegs {
   int run_closed;   // closed samples seen back-to-back up to the current position (this call)
   int ring_stale;   // lds_dc not maintained during fast-path steps; rebuilt on demand
   int n_complete, written, consumed;
+  int pos0, strm;   // first sample of this launch's chunk (or unit) within the trace; the trace index
   bool stop;
 };
 
@@ -412,11 +423,11 @@ RFID_DEVICE void gate_record_window(const GateArgs &a, GateRegs &g, int ol, int 
                                     int lane, float dcr, float dci) {
   const float odr = wv::readlane(dcr, ol), odi = wv::readlane(dci, ol);
   const int wlen = wtype ? EPC_WIN : RN16_WIN;
-  const int start = (int)a.pos0 + pos + ol;
+  const int start = g.pos0 + pos + ol;
   if (a.mode == 0 && start + wlen <= n) {  // only complete windows reach the decoder (:223,:291)
     if (lane == 0 && g.win_seq < a.wmax) {
       rfid_window w;
-      w.stream = s; w.seq = g.win_seq; w.start = start; w.type = wtype;
+      w.stream = g.strm; w.seq = g.win_seq; w.start = start; w.type = wtype;
       w.dc_re = odr; w.dc_im = odi;
       a.wtab[(int64_t)s * a.wmax + g.win_seq] = w;
       if (a.flat) {
@@ -833,18 +844,24 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
   if (lane == 0 && role == 0) { sh.fir_seq = 0; sh.prod_seq = 0; sh.cons_seq = 0; sh.stop = 0; sh.prod_done = 0; sh.avg_seq = 0; sh.avg_done = 0; }
   wv::block_sync();   // once, before any hand-off
   if (s >= a.n_streams) return;
-  GateState *st = a.state + s;
-  const float2 *ys = a.y + (int64_t)s * a.y_stride + a.pos0;
+  int strm = s, row = s;
+  int64_t pos0 = a.pos0, chunk_len = a.chunk_len;
+  if (a.units) {   // long-stream mode: s is a unit run
+    strm = wv::uniform(a.units[s].stream); pos0 = wv::uniform(a.units[s].pos0); chunk_len = wv::uniform(a.units[s].len);
+    row = wv::uniform(a.units[s].row);
+  }
+  GateState *st = a.state + row;
+  const float2 *ys = a.y + (int64_t)strm * a.y_stride + pos0;
   int64_t n64 = a.n_dec;
   if (a.lens) {
-    int64_t r = a.lens[s];
+    int64_t r = a.lens[strm];
     if (r < 0) r = 0;
     n64 = r / DECIM;
     if (n64 > a.n_dec) n64 = a.n_dec;
   }
   const int n_total = wv::uniform((int)n64);          // valid samples of the whole trace
-  int64_t nl = n64 - a.pos0;                          // ... of this launch's chunk
-  if (nl > a.chunk_len) nl = a.chunk_len;
+  int64_t nl = n64 - pos0;                            // ... of this launch's chunk
+  if (nl > chunk_len) nl = chunk_len;
   if (nl < 0) nl = 0;
   const int n = wv::uniform((int)nl);
   const int nsteps = (n + 63) >> 6;
@@ -858,12 +875,12 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
     long long p_wait = 0, p_fir = 0;
     const long long p_start = PROF ? wv::ticks() : 0;
     if (FUSED) {
-      const float2 *xs = a.raw + (int64_t)s * a.raw_stride;
+      const float2 *xs = a.raw + (int64_t)strm * a.raw_stride;
       const bool vec = a.raw_vec_ok != 0;
       // last index a (two-sample) load may start at: inside the row's stride (rows are contiguous)
       const int64_t hi_idx = vec ? ((a.raw_stride - 2) & ~(int64_t)1) : (a.raw_stride - 2);
-      float2 *yw = a.y_w + (int64_t)s * a.y_stride + a.pos0;
-      const int64_t rbase = a.pos0 * DECIM - (NTAPS - 1);   // raw index of the window of output pos0
+      float2 *yw = a.y_w + (int64_t)strm * a.y_stride + pos0;
+      const int64_t rbase = pos0 * DECIM - (NTAPS - 1);   // raw index of the window of output pos0
       // Rolling prefetch: the raw samples of the next GATE_RAW_DEPTH steps are in flight at all times
       // (a register set is reloaded right after its step went to LDS) -- with 1024 filter waves
       // on the device HBM needs that many bytes outstanding to stream.  The main loop runs over
@@ -872,7 +889,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
       // wait for the youngest load instead of the oldest.  (Batch mode only: nothing stops the scan.)
       const int nfull = n >> 6;                       // steps with all 64 samples
       const int ngroups = nfull / GATE_RAW_DEPTH;
-      const bool at_start = a.pos0 == 0;
+      const bool at_start = pos0 == 0;
       if (ngroups > 0) {
         GateRawRegs buf[GATE_RAW_DEPTH];
 #pragma unroll
@@ -1006,6 +1023,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
     if (g.f_ung == 0) g.f_ung = g.f_type ? EPC_WIN : RN16_WIN;  // fresh state: first window is an RN16
     g.run_closed = 0; g.ring_stale = 0;
     g.n_complete = 0; g.written = 0; g.consumed = n; g.stop = false;
+    g.pos0 = (int)pos0; g.strm = strm;
     long long tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const long long t_start = PROF ? wv::ticks() : 0;
     GateBack B;
@@ -1022,13 +1040,13 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
     } else
     for (int k = 0; k < nsteps && !g.stop; ++k) {
       // (waits until step k is produced and averaged)
-      gate_consume<PROF>(a, g, B, &sh.slots[k % GATE_SLOTS], &sh.slots[(k + 1) % GATE_SLOTS], nx, true, &sh.avg_seq, k, 64 * k, n, n_total, s, lane, lds_dc,
+      gate_consume<PROF>(a, g, B, &sh.slots[k % GATE_SLOTS], &sh.slots[(k + 1) % GATE_SLOTS], nx, true, &sh.avg_seq, k, 64 * k, n, n_total, row, lane, lds_dc,
                          lds_tmp, tk);
       wv::lds_store(&sh.cons_seq, k + 1, lane);   // slot k free again (its data are in registers)
     }
     if (g.stop) wv::lds_store(&sh.stop, 1, lane);
     // drain: finish the pending back half (window records / gated output of the last step)
-    if (B.has) gate_consume<PROF>(a, g, B, &sh.slots[0], &sh.slots[0], nx, false, &sh.avg_seq, 0, 0, n, n_total, s, lane, lds_dc, lds_tmp, tk);
+    if (B.has) gate_consume<PROF>(a, g, B, &sh.slots[0], &sh.slots[0], nx, false, &sh.avg_seq, 0, 0, n, n_total, row, lane, lds_dc, lds_tmp, tk);
     if (PROF && a.prof && lane == 0) {
       tk[6] = wv::ticks() - t_start;
       for (int i = 0; i < 9; ++i) a.prof[(int64_t)s * 16 + i] = tk[i];
@@ -1067,9 +1085,9 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
       st->gate_open = g.f_open; st->n_to_ungate = g.f_ung; st->wtype = g.f_type;
       st->win_index = (win_index0 + g.consumed) % WIN_LEN; st->dc_index = g.dc_index; st->win_seq = g.win_seq;
       if (a.mode == 0) {
-        const int before = (a.pos0 > 0) ? a.wcount[s] : 0;   // windows recorded by earlier chunks
+        const int before = (pos0 > 0 && !a.units) ? a.wcount[row] : 0;   // windows recorded by earlier chunks
         const int tot = before + g.n_complete;
-        a.wcount[s] = (tot < a.wmax) ? tot : a.wmax;
+        a.wcount[row] = (tot < a.wmax) ? tot : a.wmax;
       } else {
         a.io[0] = g.consumed;
         a.io[1] = g.written;
@@ -1086,6 +1104,250 @@ RFID_KERNEL(GATE_THREADS) void front_end_fused_kernel(GateArgs a) { gate_scan_bo
 // printed by the RFID_GATE_PROF=1 developer aid in rfid_capi.hip)
 RFID_KERNEL(GATE_THREADS) void gate_scan_kernel_prof(GateArgs a) { gate_scan_body<true, false>(a); }
 RFID_KERNEL(GATE_THREADS) void front_end_fused_kernel_prof(GateArgs a) { gate_scan_body<true, true>(a); }
+
+
+// =========================================================================================
+// 2b. Long-stream front end: helpers around gate_scan_kernel for ONE long trace (or a few) cut along time into
+//     units that are scanned concurrently.  The gate's recurrences (avg_ampl, dc_est: in-order binary32 sums over
+//     the whole trace) make a unit's result depend on the exact values it starts from; the host (rfid_capi.hip)
+//     predicts them, runs the units, and accepts the result only when every unit's start state is bit-identical to
+//     its predecessor's end state -- so the concatenation IS the sequential scan of gate_impl.cc:127-196.
+//     Units are cut where the gate's state machine is in its idle state: closed, POS_EDGE, no pulses counted, the
+//     last 48 samples closed (then the two rings hold exactly the preceding samples) -- found here from the data.
+// =========================================================================================
+constexpr int LS_QUIET = EPC_WIN + T1_SAMPLES + 1 + 100 + DC_LEN;   // 1615: a window opened by the last command has closed, + ring fill
+
+struct LsCutArgs {
+  const float2 *y;
+  int64_t y_stride;
+  const int64_t *lens;     // optional per-trace RAW lengths
+  int64_t n_dec;
+  int chunk;               // nominal unit length (decimated samples)
+  int limit;               // search at most this far past the nominal boundary
+  int max_b;               // boundaries per trace (row length of cut)
+  int *cut;                // [n_streams][max_b]: cut position for nominal boundary j (j >= 1), or -1
+};
+
+// one wave per (trace, nominal boundary j): the first position p >= j*chunk whose LS_QUIET preceding samples all have
+// |y|^2 >= 1/4 of the largest |y|^2 seen in the look-back region (carrier, no reader command), or -1
+RFID_KERNEL(64) void ls_cut_kernel(LsCutArgs a) {
+  const int lane = wv::lane_id();
+  const int s = (int)blockIdx.y, j = (int)blockIdx.x + 1;
+  int64_t n64 = a.n_dec;
+  if (a.lens) { int64_t r = a.lens[s]; if (r < 0) r = 0; n64 = r / DECIM; if (n64 > a.n_dec) n64 = a.n_dec; }
+  const int n = (int)n64;
+  const int P = j * a.chunk;
+  int *out = a.cut + (int64_t)s * a.max_b + j;
+  if (P >= n) { if (lane == 0) *out = -1; return; }
+  const float2 *ys = a.y + (int64_t)s * a.y_stride;
+  int lo = P - LS_QUIET - 64;
+  if (lo < 0) lo = 0;
+  float ref = 0.0f;
+  for (int base = lo; base < P; base += 64) {
+    const int i = base + lane;
+    float m2 = 0.0f;
+    if (i < P) { const float2 v = ys[i]; m2 = v.x * v.x + v.y * v.y; }
+    ref = (m2 > ref) ? m2 : ref;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { const float o = wv::shfl_xor(ref, off); ref = (o > ref) ? o : ref; }
+  const float theta = 0.25f * ref;
+  int run = 0, found = -1;
+  int end = P + a.limit;
+  if (end > n) end = n;
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int base = lo; base < end && found < 0; base += 64) {
+    const int i = base + lane;
+    bool low = false;
+    if (i < n) { const float2 v = ys[i]; low = (v.x * v.x + v.y * v.y) < theta; } else low = true;
+    const uint64_t lowmask = wv::ballot(low);
+    const uint64_t below = lowmask & lt;
+    const int q = below ? (lane - 1 - (63 - __builtin_clzll(below))) : (run + lane);   // quiet samples right before i
+    const uint64_t hit = wv::ballot(i >= P && i < end && q >= LS_QUIET);
+    if (hit) found = base + wv::ffs64(hit);
+    run = lowmask ? __builtin_clzll(lowmask) : (run + 64);   // quiet samples at the end of the step
+  }
+  if (lane == 0) *out = found;
+}
+
+struct LsInitArgs {
+  const float2 *y;
+  int64_t y_stride;
+  const GateUnit *units;
+  int n_units;
+  GateState *tmpl;         // [n_units]: rings + idle state machine; avg_ampl / dc_est = first guesses
+};
+
+// template gate state of a unit: the rings as the sequential scan leaves them at an idle cut (the last 100
+// amplitudes, the last 48 samples), the state machine idle, avg_ampl / dc_est guessed as the ring means
+RFID_KERNEL(64) void ls_init_kernel(LsInitArgs a) {
+  RFID_SHARED float amp[WIN_LEN];
+  const int lane = wv::lane_id();
+  const int u = (int)blockIdx.x;
+  if (u >= a.n_units) return;
+  GateState *st = a.tmpl + u;
+  const int pos0 = a.units[u].pos0;
+  {  // zero everything first (a unit that starts the trace is the fresh gate of gate_impl.cc:41-70)
+    int *w = reinterpret_cast<int *>(st);
+    for (int i = lane; i < (int)(sizeof(GateState) / 4); i += 64) w[i] = 0;
+  }
+  wv::wave_sync();
+  if (pos0 < WIN_LEN) return;   // (only unit 0 starts before sample 100: cuts lie >= LS_QUIET into the trace)
+  const float2 *ys = a.y + (int64_t)a.units[u].stream * a.y_stride;
+  for (int i = lane; i < WIN_LEN; i += 64) {
+    const float2 v = ys[pos0 - WIN_LEN + i];
+    const float h = wv::hypot_f(v.x, v.y);
+    st->win[i] = h;
+    amp[i] = h;
+  }
+  if (lane < DC_LEN) {
+    const float2 v = ys[pos0 - DC_LEN + lane];
+    st->dcr_re[lane] = v.x;
+    st->dcr_im[lane] = v.y;
+  }
+  wv::wave_sync();
+  if (lane == 0) {
+    double sa = 0.0, sr = 0.0, si = 0.0;
+    for (int i = 0; i < WIN_LEN; ++i) sa += (double)amp[i];
+    for (int i = 0; i < DC_LEN; ++i) { const float2 v = ys[pos0 - DC_LEN + i]; sr += (double)v.x; si += (double)v.y; }
+    st->avg_ampl = (float)(sa / WIN_LEN);
+    st->dc_re = (float)(sr / DC_LEN);
+    st->dc_im = (float)(si / DC_LEN);
+    st->n_samples = LS_QUIET;          // any value: irrelevant while POS_EDGE with no pulses counted
+    st->signal_state = 1;              // POS_EDGE
+    st->num_pulses = 0;
+    st->gate_open = 0;
+    st->n_to_ungate = RN16_WIN;        // the next window is an RN16
+    st->wtype = 0;
+    st->win_index = 0; st->dc_index = 0; st->win_seq = 0;
+  }
+}
+
+// avg_ampl alone over the units (gate_impl.cc:130-133: the amplitude ring and the in-order sum; no state machine, no
+// dc_est): one wave per run, many per SIMD.  The long-stream front end settles the exact avg_ampl at every cut with
+// this cheap pass first -- the threshold tests, hence the state machine, hence which samples dc_est sums over, all
+// hang on it -- before the full gate scan runs.  Same arithmetic as the producer / averaging waves, value for value.
+struct LsAvgArgs {
+  const float2 *y;
+  int64_t y_stride;
+  const GateUnit *units;   // [n_runs]: row = index into start / end
+  int n_runs;
+  const float *start;      // avg_ampl at the unit's first sample
+  float *end;              // avg_ampl after its last sample
+};
+RFID_KERNEL(64) void ls_avg_kernel(LsAvgArgs a) {
+  const int lane = wv::lane_id();
+  const int r = (int)blockIdx.x;
+  if (r >= a.n_runs) return;
+  const GateUnit un = a.units[r];
+  const int pos0 = wv::uniform(un.pos0), n = wv::uniform(un.len), row = wv::uniform(un.row);
+  const float2 *ys = a.y + (int64_t)wv::uniform(un.stream) * a.y_stride + pos0;
+  // amplitudes of the 128 samples before the unit (the ring of gate_impl.cc:131 holds the last 100); a unit that
+  // starts the trace has an all-zero ring
+  float a2 = 0.0f, a1 = 0.0f;
+  if (pos0 >= 128) {
+    const float2 p2 = ys[lane - 128], p1 = ys[lane - 64];
+    a2 = wv::hypot_f(p2.x, p2.y);
+    a1 = wv::hypot_f(p1.x, p1.y);
+  }
+  float avg = wv::uniform(a.start[row]);
+  const int nsteps = (n + 63) >> 6;
+  float2 v = (lane < n) ? ys[lane] : make_float2(0.0f, 0.0f);
+  for (int k = 0; k < nsteps; ++k) {
+    const int i_next = 64 * (k + 1) + lane;
+    const float2 vn = (i_next < n) ? ys[i_next] : make_float2(0.0f, 0.0f);   // next step in flight
+    const bool valid = 64 * k + lane < n;
+    const float amp = wv::hypot_f(v.x, v.y);
+    // sample i - 100: lanes 0..35 take it from two steps back (lane + 28), lanes 36..63 from the previous step (lane - 36)
+    const float o2 = wv::shfl(a2, (lane + 28) & 63), o1 = wv::shfl(a1, (lane - 36) & 63);
+    const float old = (lane < 36) ? o2 : o1;
+    const float nd = valid ? (amp - old) : 0.0f;
+    const float d = div_const<WIN_LEN>(nd);
+    const float sacc = chain_add_auto(avg, d, lane);
+    avg = wv::readlane(sacc, 63);
+    a2 = a1; a1 = amp; v = vn;
+  }
+  if (lane == 0) a.end[row] = avg;
+}
+
+// start values for this round: state[u] = tmpl[u] (the rings) with the three recurrences and the scalar state of
+// the edge / pulse / window state machine replaced by the predicted ones
+constexpr int LS_HEAD_WORDS = 9;   // avg_ampl, dc_re, dc_im, n_samples, signal_state, num_pulses, gate_open, n_to_ungate, wtype
+struct LsHeadsArgs {
+  const GateState *tmpl;   // [n_units]
+  GateState *state;        // [2 n_units] rows
+  const int *heads;        // [2 n_units][LS_HEAD_WORDS] by row (floats as bit patterns)
+  const GateUnit *runs;    // [n_runs]: row = state row; template = row mod n_units
+  int n_runs, n_units;
+};
+RFID_KERNEL(64) void ls_set_state_kernel(LsHeadsArgs a) {
+  const int lane = wv::lane_id();
+  const int r = (int)blockIdx.x;
+  if (r >= a.n_runs) return;
+  const int row = a.runs[r].row;
+  const int *src = reinterpret_cast<const int *>(a.tmpl + (row % a.n_units));
+  int *dst = reinterpret_cast<int *>(a.state + row);
+  for (int i = lane; i < (int)(sizeof(GateState) / 4); i += 64) dst[i] = src[i];
+  wv::wave_sync();
+  // the nine values are the first nine words of GateState, in this order
+  if (lane < LS_HEAD_WORDS) dst[lane] = a.heads[LS_HEAD_WORDS * row + lane];
+}
+
+// compact copies for the host: the first 12 words of every state row; the end of the last window of every unit
+struct LsGatherArgs {
+  const GateState *state;   // [n_rows]
+  int *heads;               // [n_rows][12]
+  int n_rows;
+  const rfid_window *uwtab; // [n_units][uwmax] (rows [0, n_units) = variant A)
+  const int *uwcount;
+  int n_units, uwmax;
+  int *last_end;            // [n_units]: start + length of the unit's last window, or INT_MIN
+};
+RFID_KERNEL(256) void ls_gather_kernel(LsGatherArgs a) {
+  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (i < a.n_rows * 12) a.heads[i] = reinterpret_cast<const int *>(a.state + i / 12)[i % 12];
+  if (a.last_end && i < a.n_units) {
+    int k = a.uwcount[i];
+    if (k > a.uwmax) k = a.uwmax;
+    int e = -2147483647 - 1;
+    if (k > 0) {
+      const rfid_window &w = a.uwtab[(int64_t)i * a.uwmax + (k - 1)];
+      e = w.start + (w.type ? EPC_WIN : RN16_WIN);
+    }
+    a.last_end[i] = e;
+  }
+}
+
+// the verified units' window tables -> the per-trace window table (seq renumbered) + the decoder's compact lists
+struct LsAssembleArgs {
+  const GateUnit *units;
+  const rfid_window *uwtab;  // [n_units][uwmax]
+  const int *uwcount;        // [n_units]
+  const int *seq0;           // [n_units]: windows of the trace before this unit
+  int n_units, uwmax;
+  rfid_window *wtab;         // [n_streams][wmax]
+  int wmax;
+  rfid_window *flat;
+  int *flat_count;
+  int flat_cap;
+};
+RFID_KERNEL(64) void ls_assemble_kernel(LsAssembleArgs a) {
+  const int lane = wv::lane_id();
+  const int u = (int)blockIdx.x;
+  if (u >= a.n_units) return;
+  int k = a.uwcount[u];
+  if (k > a.uwmax) k = a.uwmax;
+  const int s = a.units[u].stream, seq0 = a.seq0[u];
+  for (int i = lane; i < k; i += 64) {
+    rfid_window w = a.uwtab[(int64_t)u * a.uwmax + i];
+    w.seq = seq0 + i;
+    if (w.seq < a.wmax) {
+      a.wtab[(int64_t)s * a.wmax + w.seq] = w;
+      const int slotw = wv::atomic_add(a.flat_count + w.type, 1);
+      if (slotw < a.flat_cap) a.flat[(int64_t)w.type * a.flat_cap + slotw] = w;
+    }
+  }
+}
 
 // =========================================================================================
 // 3. tag_decoder: one wavefront per window, persistent over the compact window list.
@@ -1622,69 +1884,103 @@ struct StatsArgs {
   rfid_stream_stats *out;         // [n_streams]
 };
 
-// One wavefront per trace: the lanes fetch the decoded windows in parallel and compact what the
-// replay needs (type, crc flag, tag id) into LDS; lane 0 then replays them in order.
-constexpr int STATS_CHUNK = 1024;
-
+// One wavefront per trace, 64 windows per step.  The replay is sequential only through the TERMINATED cut-off
+// (gate_impl.cc:101-109: checked before every window against n_queries_sent and the number of distinct tag ids
+// read so far); both are monotone counts, so the cut-off index is found first -- n_queries_sent passes its limit
+// right after the max_num_queries-th EPC window, the distinct-id count after the first read of the
+// (number_unique_tags + 1)-th new id -- and everything before it is plain counting (a trace may hold hundreds of
+// thousands of windows: a one-lane replay cost 40 ms for the 320 000 windows of a 10 000-round inventory).
 RFID_KERNEL(64) void stream_stats_kernel(StatsArgs a) {
-  RFID_SHARED int packed[STATS_CHUNK];
   RFID_SHARED int hist[256];
+  RFID_SHARED int first[256];      // index of the first CRC-verified read of each tag id
   const int lane = wv::lane_id();
   const int s = (int)blockIdx.x;
   if (s >= a.n_streams) return;
   rfid_stream_stats *o = a.out + s;
-  for (int i = lane; i < 256; i += 64) hist[i] = 0;
-  int n_queries = 1;  // START -> SEND_QUERY before the first sample (reader_impl.cc:218-260)
-  int round = 1, slot = 1, n_ok = 0, n_unique = 0, status = RFID_RUNNING, used = 0;
+  for (int i = lane; i < 256; i += 64) { hist[i] = 0; first[i] = 0x7fffffff; }
+  wv::wave_sync();
   const int nw = wv::uniform(a.wcount[s]);
   const rfid_decode_result *rs = a.res + (int64_t)s * a.wmax;
-  bool done = false;
-  for (int base = 0; base < nw && !done; base += STATS_CHUNK) {
-    const int m = (nw - base < STATS_CHUNK) ? (nw - base) : STATS_CHUNK;
-    wv::wave_sync();
-    for (int k = lane; k < m; k += 64) {
-      const rfid_decode_result &r = rs[base + k];
-      packed[k] = (r.type & 1) | ((r.crc_ok & 1) << 1) | ((r.tag_id & 255) << 2);
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  // ---- pass 1: where the two limits are passed ----
+  int k_q = 0x7fffffff;            // first window index BEFORE which n_queries_sent > max_num_queries
+  int epc_seen = 0;
+  for (int base = 0; base < nw; base += 64) {
+    const int k = base + lane;
+    int v = 0;
+    if (k < nw) {
+      const rfid_decode_result &r = rs[k];
+      v = (r.type & 1) | ((r.crc_ok & 1) << 1) | ((r.tag_id & 255) << 2);
+      if ((v & 3) == 3) wv::atomic_min(&first[(v >> 2) & 255], k);
     }
-    wv::wave_sync();
-    if (lane == 0) {
-      for (int k = 0; k < m; ++k) {
-        // gate_impl.cc:101-109, evaluated at the gate call that follows every window
-        if (n_queries > a.max_num_queries || n_unique > a.number_unique_tags) {
-          status = RFID_TERMINATED;
-          done = true;
-          break;
-        }
-        const int v = packed[k];
-        used++;
-        if (v & 1) {                                       // EPC window
-          slot++;                                          // tag_decoder_impl.cc:295
-          if (slot > a.max_slot_number) { slot = 1; round++; }  // :330-343 / :369-383
-          if (v & 2) {
-            n_ok++;                                        // :346
-            const int id = (v >> 2) & 255;
-            if (hist[id] == 0) n_unique++;
-            hist[id]++;                                    // :356-364
-          }
-          n_queries++;                                     // reader_impl.cc:259 / :335
-        }
+    const uint64_t epc = wv::ballot((v & 1) != 0);
+    if (k_q == 0x7fffffff) {
+      // n_queries_sent = 1 + EPC windows so far (reader_impl.cc:259,335); it exceeds the limit once
+      // max_num_queries EPC windows have been processed
+      const int need = a.max_num_queries - epc_seen;           // that many more EPC windows
+      const int c = wv::popc64(epc);
+      if (need <= 0) k_q = base;
+      else if (c >= need) {
+        const uint64_t hit = wv::ballot(((epc >> lane) & 1ull) && wv::popc64(epc & lt) == need - 1);
+        k_q = base + wv::ffs64(hit) + 1;
       }
     }
-    done = wv::uniform((int)done) != 0;
+    epc_seen += wv::popc64(epc);
   }
   wv::wave_sync();
-  for (int i = lane; i < 256; i += 64) o->tag_reads[i] = hist[i];
+  // the (number_unique_tags + 1)-th smallest first-read index: the distinct-id count exceeds the limit right after it
+  int k_u = 0x7fffffff;
+  {
+    int cand = 0x7fffffff;
+    for (int q = 0; q < 4; ++q) {
+      const int id = lane + 64 * q;
+      const int f = first[id];
+      if (f == 0x7fffffff) continue;
+      int rank = 0;                                            // ids first read earlier than this one
+      for (int j = 0; j < 256; ++j) rank += (first[j] < f) ? 1 : 0;
+      if (rank == a.number_unique_tags && f < cand) cand = f;  // (first-read indices are distinct: one id per window)
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const int ot = wv::shfl_xor(cand, off); cand = (ot < cand) ? ot : cand; }
+    if (cand != 0x7fffffff) k_u = cand + 1;
+  }
+  int k_term = (k_q < k_u) ? k_q : k_u;
+  const bool cut = k_term < nw;
+  if (!cut) k_term = nw;
+  // ---- pass 2: counts over the windows before the cut-off ----
+  int n_epc = 0, n_ok = 0;
+  for (int base = 0; base < k_term; base += 64) {
+    const int k = base + lane;
+    int v = 0;
+    if (k < k_term) {
+      const rfid_decode_result &r = rs[k];
+      v = (r.type & 1) | ((r.crc_ok & 1) << 1) | ((r.tag_id & 255) << 2);
+      if ((v & 3) == 3) wv::atomic_add(&hist[(v >> 2) & 255], 1);   // tag_decoder_impl.cc:356-364
+    }
+    n_epc += wv::popc64(wv::ballot((v & 1) != 0));
+    n_ok += wv::popc64(wv::ballot((v & 3) == 3));                     // :346
+  }
+  wv::wave_sync();
+  int uniq = 0;
+  for (int i = lane; i < 256; i += 64) {
+    o->tag_reads[i] = hist[i];
+    uniq += hist[i] ? 1 : 0;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) uniq += wv::shfl_xor(uniq, off);
   if (lane == 0) {
-    if (status == RFID_RUNNING &&
-        (n_queries > a.max_num_queries || n_unique > a.number_unique_tags))
-      status = RFID_TERMINATED;
+    const int n_queries = 1 + n_epc;  // START -> SEND_QUERY before the first sample (reader_impl.cc:218-260), +1 per EPC window (:259/:335)
+    // slot / round roll-over per EPC window (tag_decoder_impl.cc:295,330-343,369-383): slot++ ; past max_slot_number -> 1, round++
+    const int round = 1 + n_epc / a.max_slot_number, slot = 1 + n_epc % a.max_slot_number;
+    int status = cut ? RFID_TERMINATED : RFID_RUNNING;
+    if (status == RFID_RUNNING && (n_queries > a.max_num_queries || uniq > a.number_unique_tags)) status = RFID_TERMINATED;
     o->n_queries_sent = n_queries;
     o->cur_inventory_round = round;
     o->cur_slot_number = slot;
     o->n_epc_correct = n_ok;
-    o->n_unique_tags = n_unique;
+    o->n_unique_tags = uniq;
     o->n_windows = nw;
-    o->n_windows_used = used;
+    o->n_windows_used = k_term;
     o->status = status;
   }
 }

@@ -52,6 +52,12 @@ class SynthGen2Params(C.Structure):
                 ("n_tags", C.c_int32), ("tail_us", C.c_int32)]
 
 
+class LsReport(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("units", "chunk", "rounds", "gate_passes", "unit_runs", "avg_passes", "verified", "gave_up",
+                                         "cuts_dropped",
+                                         "last_round_moved")]
+
+
 class BatchTiming(C.Structure):
     _fields_ = [("mf_ms", C.c_float), ("gate_ms", C.c_float), ("decode_ms", C.c_float),
                 ("stats_ms", C.c_float), ("total_ms", C.c_float), ("front_ms", C.c_float),
@@ -93,6 +99,8 @@ SIGNATURES = {
     "rfid_synth_gen2": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, C.c_float, C.c_uint64, _i64, C.POINTER(C.c_int64)]),
     "rfid_batch_plan": (_i, [_vp, _i, _i64]),
     "rfid_batch_set_streams": (_i, [_vp, _i]),
+    "rfid_batch_set_long_stream": (_i, [_vp, _i]),
+    "rfid_batch_ls_report": (_i, [_vp, _vp]),
     "rfid_batch_mf": (_i, [_vp, _vp, _i64, _i64, _vp]),
     "rfid_batch_gate": (_i, [_vp]),
     "rfid_batch_decode": (_i, [_vp, _i]),

@@ -154,6 +154,15 @@ class Context:
         else:
             self._chk(fn(self._h))
 
+    def batch_set_long_stream(self, mode: int) -> None:
+        """0: never cut traces along time, 1: automatic (few long traces), 2: whenever possible."""
+        self._chk(self._lib.rfid_batch_set_long_stream(self._h, int(mode)))
+
+    def batch_ls_report(self) -> dict:
+        r = capi.LsReport()
+        self._chk(self._lib.rfid_batch_ls_report(self._h, C.byref(r)))
+        return {n: int(getattr(r, n)) for n, _ in capi.LsReport._fields_}
+
     def batch_sync(self) -> None:
         self._chk(self._lib.rfid_batch_sync(self._h))
 

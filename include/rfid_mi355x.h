@@ -132,6 +132,20 @@ typedef struct rfid_batch_timing {
   int32_t reserved_;
 } rfid_batch_timing;
 
+/* what the long-stream front end did in the last rfid_batch_process pass (all zero when it was not used) */
+typedef struct rfid_ls_report {
+  int32_t units;            /* units the traces were cut into */
+  int32_t chunk;            /* nominal unit length, decimated samples */
+  int32_t rounds;           /* prediction rounds until every unit started from its predecessor's exact end state */
+  int32_t gate_passes;      /* gate-scan launches those rounds cost (two variants per round while predictions move) */
+  int32_t unit_runs;        /* unit runs in those launches (units that already ran from their exact start are not re-run) */
+  int32_t avg_passes;       /* launches of the cheap avg_ampl-only pass that settles avg_ampl at every cut first */
+  int32_t verified;         /* 1: accepted -- bit-identical to the sequential scan by construction */
+  int32_t gave_up;          /* 1: not verified within the round limit; the sequential scan was run instead */
+  int32_t cuts_dropped;     /* cut points withdrawn because the state machine was not idle there */
+  int32_t last_round_moved; /* units whose start still moved in the last round (0 when verified) */
+} rfid_ls_report;
+
 typedef struct rfid_ctx rfid_ctx;
 
 /* ---- lifetime ------------------------------------------------------------------------ */
@@ -211,6 +225,14 @@ RFID_API int rfid_batch_stats(rfid_ctx *ctx);
  * functions above one after the other.  The matched-filter output stays available (rfid_batch_get_mf). */
 RFID_API int rfid_batch_process(rfid_ctx *ctx, const void *d_raw, int64_t raw_stride, int64_t n_raw,
                                 const void *d_lens, int want_scores);
+/* Long-stream front end of rfid_batch_process: with few, long traces the gate scan (a sequential recurrence per
+ * trace) leaves the chip idle, so each trace is cut along time at idle points of the gate's state machine and the
+ * units are scanned concurrently from predicted gate states; a pass is accepted only when every unit started from
+ * a state bit-identical to its predecessor's end state, i.e. the result IS the sequential scan (otherwise the
+ * sequential scan runs).  mode 0: never, 1 (default): when the batch has at most 512 traces that can each be cut
+ * at least once, 2: whenever a trace can be cut.  The environment variable RFID_LONG_STREAM overrides the default. */
+RFID_API int rfid_batch_set_long_stream(rfid_ctx *ctx, int mode);
+RFID_API int rfid_batch_ls_report(const rfid_ctx *ctx, rfid_ls_report *out);
 RFID_API int rfid_batch_sync(rfid_ctx *ctx);
 /* synchronises, then reports per-kernel times of the last pass */
 RFID_API int rfid_batch_timing_get(rfid_ctx *ctx, rfid_batch_timing *out);

@@ -220,3 +220,20 @@ def test_emulated_chain_scan_is_exact(emu_mod):
         assert np.array_equal(scan.view(np.uint32), chain.view(np.uint32)), (carry, clean)
         n_clean += clean
     assert n_clean > 60       # the scan path is exercised, not just the fallback
+
+
+@pytest.mark.parametrize("kw", [dict(max_num_queries=3), dict(number_unique_tags=1), dict(number_unique_tags=0),
+                                dict(max_num_queries=1, number_unique_tags=2), dict(max_num_queries=0)])
+def test_emulated_termination_limits(emu_mod, oracle_mod, synth_mod, kw):
+    """stream_stats_kernel finds the TERMINATED cut-off (gate_impl.cc:101-109) without replaying the windows one by
+    one: queries limit, distinct-tag limit, both, and limits that stop the run before its first window."""
+    t = synth_mod.make_trace(n_rounds=2, fixed_q=3, tag_ids=(0x21, 0x43, 0x65), seed=78, sigma=0.01).samples
+    assert oracle_mod.run_trace(t, oracle_mod.config(fixed_q=3)).state.n_unique_tags == 3     # the limits below do cut the run
+    r = emu_mod.batch_process(t[None, :], fixed_q=3, **kw)
+    o = oracle_mod.run_trace(t, oracle_mod.config(fixed_q=3, **kw))
+    st = r["stats"][0]
+    assert st["status"] == o.state.status == 1
+    assert st["n_windows_used"] == o.n_windows
+    for k in ("n_queries_sent", "cur_inventory_round", "cur_slot_number", "n_epc_correct", "n_unique_tags"):
+        assert st[k] == getattr(o.state, k), k
+    assert np.array_equal(st["tag_reads"], np.array(o.state.tag_reads[:], dtype=np.int32))

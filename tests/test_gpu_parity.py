@@ -212,6 +212,7 @@ def test_fused_front_end_equals_stage_kernels(gpu_ctx, oracle_mod, synth_mod):
         host[:, :L] = raw
         dev = torch.from_numpy(host.view(np.float32)).to("cuda:0")
         gpu_ctx.batch_plan(B, L)
+        gpu_ctx.batch_set_long_stream(0)       # (3 short traces would otherwise be cut along time: see below)
         gpu_ctx.batch_process_ptr(dev.data_ptr(), stride, L, 0, want_scores=True)
         gpu_ctx.batch_sync()
         assert gpu_ctx.batch_timing()["fused_front"] == 1
@@ -228,6 +229,17 @@ def test_fused_front_end_equals_stage_kernels(gpu_ctx, oracle_mod, synth_mod):
         st2 = gpu_ctx.batch_stats()
         assert w1.tobytes() == w2.tobytes() and r1.tobytes() == r2.tobytes() and s1.tobytes() == s2.tobytes()
         assert st1.tobytes() == st2.tobytes()
+        # third front end: the long-stream one (traces cut along time, units scanned concurrently, accepted only when
+        # every unit started from its predecessor's exact end state)
+        gpu_ctx.batch_set_long_stream(2)
+        gpu_ctx.batch_process_ptr(dev.data_ptr(), stride, L, 0, want_scores=True)
+        gpu_ctx.batch_sync()
+        gpu_ctx.batch_set_long_stream(1)
+        rep = gpu_ctx.batch_ls_report()
+        assert rep["verified"] == 1 and rep["units"] > B, rep
+        w3, r3, s3 = gpu_ctx.batch_windows(want_scores=True)
+        assert w1.tobytes() == w3.tobytes() and r1.tobytes() == r3.tobytes() and s1.tobytes() == s3.tobytes()
+        assert st1.tobytes() == gpu_ctx.batch_stats().tobytes()
         for b in range(B):
             assert np.array_equal(y1[b].view(np.uint32), gpu_ctx.batch_mf_output(b).view(np.uint32))
             assert np.array_equal(y1[b].view(np.uint32), oracle_mod.fir(raw[b]).view(np.uint32))

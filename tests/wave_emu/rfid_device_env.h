@@ -175,6 +175,7 @@ static inline void keep(float) {}
 static inline void keep(int) {}
 static inline long long ticks() { return 0; }
 static inline int atomic_add(int *p, int v) { int o = *p; *p = o + v; return o; }
+static inline int atomic_min(int *p, int v) { int o = *p; if (v < o) *p = v; return o; }
 static inline void global_release() {}
 static inline float2 load_coherent(const float2 *p) { return *p; }
 
