@@ -183,6 +183,49 @@ def workload_single_trace(torch, rfid, synth, args, device, rank, fixed_q, n_rou
                          % (tag, fixed_q, 1 << fixed_q, n_rounds, n_tags, L, 8e-9 * L, args.sigma, n_slots, plan_s))
 
 
+def streaming_leg(torch, rfid, wl, args, device):
+    """The drop-in path from HOST memory, end to end: one RX stream (the first --stream-replicas replicas of the
+    workload back to back = 71 x K inventory rounds) lies in page-locked host memory and goes through rfid_stream_work
+    chunk by chunk -- DMA to HBM, matched filter, gate, tag_decoder, decoded windows back -- with the upload of chunk
+    k+1 overlapping the processing of chunk k.  PCIe-inclusive, never the headline `value`."""
+    K = min(args.stream_replicas, wl["B"])
+    L, stride = wl["L"], wl["stride"]
+    if stride != L:
+        return None
+    n_total = K * L
+    host = torch.empty(2 * n_total, dtype=torch.float32, pin_memory=True)
+    host.copy_(wl["data"][:K].reshape(-1)[: 2 * n_total])
+    torch.cuda.synchronize()
+    x = host.numpy().view(np.complex64)
+    ctx = rfid.Context(device=device.index, max_num_queries=(1 << 31) - 2)
+    try:
+        chunk = min(args.stream_chunk, n_total)
+        ctx.stream_begin(chunk)
+        best = None
+        for rep in range(3):
+            if rep:
+                ctx.stream_end()
+                ctx.stream_begin(chunk)
+            n_win, n_ok = 0, 0
+            t0 = time.perf_counter()
+            for pos in range(0, n_total, chunk):
+                w, r = ctx.stream_work(x[pos:pos + chunk])
+                n_win += len(w); n_ok += int(r["crc_ok"].sum())
+            w, r = ctx.stream_work(flush=True)
+            n_win += len(w); n_ok += int(r["crc_ok"].sum())
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        ok = (n_win == 142 * K and n_ok == 70 * K)
+        return {"msamples_per_s": round(n_total / best / 1e6, 1), "host_gb_per_s": round(8e-9 * n_total / best, 2),
+                "stream_raw_samples": n_total, "chunk_raw_samples": chunk, "calls": (n_total + chunk - 1) // chunk + 1,
+                "source": "page-locked host memory (a pinned torch tensor), uploaded by DMA from where it lies",
+                "check": ("ok: %d windows, %d of %d EPCs CRC-verified" % (n_win, n_ok, 71 * K)) if ok else
+                         ("FAILED: %d windows, %d EPC ok" % (n_win, n_ok)),
+                "note": "rfid_stream_work: raw chunk in -> decoded windows out, block state carried on the device; best of 3"}
+    finally:
+        ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,6 +240,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stream-leg", action="store_true")
+    ap.add_argument("--stream-replicas", type=int, default=160, help="replicas concatenated into the host-resident stream")
+    ap.add_argument("--stream-chunk", type=int, default=32_000_000, help="raw samples per rfid_stream_work call")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 10 if args.config in ("1", "3stream") else 3
@@ -369,6 +415,8 @@ def main():
     if B == 1:
         out["single_stream"] = {"raw_msamples_per_s": round(L / (elapsed / args.steps) / 1e6, 2),
                                 "x_realtime_at_2Msps": round(L / (elapsed / args.steps) / 2e6, 1)}
+    if rank == 0 and args.config == "1" and not args.no_stream_leg:
+        out["streaming"] = streaming_leg(torch, rfid, wl, args, device)
     if rank == 0 and not args.no_cpu_baseline:
         # rank 0 only (N = 1 and N > 1 alike): the same host serves all ranks
         x, what = wl["sample"]()

@@ -49,6 +49,24 @@ struct rfid_ctx {
   // long-stream front end (few long traces cut into concurrently scanned units)
   DevBuf ls_cut, ls_units, ls_runs, ls_tmpl, ls_state, ls_uw, ls_uwc, ls_heads, ls_seq0, ls_gath;
   int ls_mode = 1;                // 0 never, 1 automatic, 2 whenever a trace can be cut
+  // whole-chain streaming (rfid_stream_*)
+  struct StreamIO {
+    bool open = false;
+    int64_t max_chunk = 0, tail_max = 0;
+    float2 *d_buf[2] = {nullptr, nullptr};
+    rfid_cf32 *h_pin[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_up[2] = {nullptr, nullptr};
+    hipEvent_t ev_free[2] = {nullptr, nullptr};   // processing of the chunk in d_buf[i] is over (buffer reusable)
+    int cur = 0;                  // buffer that receives the next upload
+    bool pending = false;         // a chunk is uploaded (or uploading) into d_buf[pend_idx] and not processed yet
+    int pend_idx = 0;
+    int64_t pend_new = 0;         // its new samples (at offset tail_max)
+    int64_t tail_len = 0;         // raw samples held back by the last processed chunk, placed right before tail_max in d_buf[pend_idx / cur]
+    int64_t raw_base = 0;         // global raw index of the first held-back sample (multiple of 5)
+    std::vector<rfid_stream_window> out_w;   // windows completed but not yet delivered (caller arrays too small)
+    std::vector<rfid_decode_result> out_r;
+  } sio;
   rfid_ls_report ls_rep;
   rfid_window *d_swin = nullptr;  // one window
   int *d_scount = nullptr;
@@ -87,6 +105,8 @@ struct rfid_ctx {
 };
 
 namespace {
+
+void sio_free(rfid_ctx *c);   // (whole-chain streaming, below)
 
 int fail(rfid_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
   if (c) {
@@ -221,16 +241,28 @@ double ls_now_ms() {
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
 }
-int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done) {
+struct LsOpts {
+  bool carry = false;       // a trace's first unit starts from c->d_gstate[trace] (streaming) instead of the fresh gate,
+                            // and the state after the last processed unit is written back there
+  bool hold_last = false;   // leave each trace's last unit unprocessed (streaming: whatever follows the last idle cut
+                            // waits for more samples); *consumed = its first sample
+  bool force = false;       // run even when it cannot pay off (streaming needs the idle cut, not the speed)
+};
+int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOpts(), int64_t *consumed = nullptr) {
   *done = 0;
+  if (consumed) *consumed = 0;
   const bool dbg = getenv("RFID_LS_DEBUG") != nullptr;
   const double t_begin = ls_now_ms();
   auto lap = [&](const char *what) { if (dbg) fprintf(stderr, "[ls] t=%8.2f ms  %s\n", ls_now_ms() - t_begin, what); };
   rfid_ls_report &rep = c->ls_rep;
   memset(&rep, 0, sizeof(rep));
   const int B = c->B;
-  if (c->ls_mode == 0 || n_dec < 2 * LS_MIN_CHUNK) return RFID_OK;
-  if (c->ls_mode == 1 && B > 512) return RFID_OK;
+  if (!opt.force) {
+    if (c->ls_mode == 0 || n_dec < 2 * LS_MIN_CHUNK) return RFID_OK;
+    if (c->ls_mode == 1 && B > 512) return RFID_OK;
+  } else if (n_dec < LS_QUIET + 256) {
+    return RFID_OK;
+  }
   // ---- per-trace lengths ----
   std::vector<int64_t> nd((size_t)B, n_dec);
   if (c->d_lens) {
@@ -255,7 +287,7 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done) {
     if (nb + 1 > max_b) max_b = nb + 1;
     nominal += (nb > 0 ? nb : 1);
   }
-  if (max_b < 2 || (c->ls_mode == 1 && nominal < 2 * (int64_t)B)) return RFID_OK;   // nothing to gain
+  if (max_b < 2 || (!opt.force && c->ls_mode == 1 && nominal < 2 * (int64_t)B)) return RFID_OK;   // nothing to gain
   // ---- idle cut points near the nominal boundaries ----
   int rc = grow(c, c->ls_cut, sizeof(int) * (size_t)B * (size_t)max_b);
   if (rc) return rc;
@@ -290,8 +322,13 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done) {
       GateUnit u; u.stream = s; u.pos0 = pos; u.len = n - pos; u.row = 0;
       units.push_back(u); cut_of_unit.push_back(started_by);
     }
+    if (opt.hold_last) {   // (streaming: one trace) what follows the last idle cut stays unprocessed
+      if (units.size() < 2) return RFID_OK;
+      if (consumed) *consumed = units.back().pos0;
+      units.pop_back(); cut_of_unit.pop_back();
+    }
     const int U = (int)units.size();
-    if (U <= B) return RFID_OK;   // no cut found: sequential scan
+    if (U <= B && !opt.force) return RFID_OK;   // no cut found: sequential scan
     int max_len = 0;
     for (const GateUnit &u : units) if (u.len > max_len) max_len = u.len;
     const int uwmax = max_len / (RN16_WIN + T1_SAMPLES + 1) + 2;
@@ -308,7 +345,7 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done) {
     HIPCHK(c, hipMemcpyAsync(c->ls_units.p, units.data(), sizeof(GateUnit) * (size_t)U, hipMemcpyHostToDevice, c->stream));
     LsInitArgs ia;
     ia.y = c->d_y; ia.y_stride = c->y_stride; ia.units = (const GateUnit *)c->ls_units.p; ia.n_units = U;
-    ia.tmpl = (GateState *)c->ls_tmpl.p;
+    ia.tmpl = (GateState *)c->ls_tmpl.p; ia.carry = opt.carry ? c->d_gstate : nullptr;
     hipLaunchKernelGGL(ls_init_kernel, dim3((unsigned)U), dim3(64), 0, c->stream, ia);
     HIPCHK(c, hipGetLastError());
     std::vector<LsHead> th((size_t)U), eh(2 * (size_t)U);
@@ -358,7 +395,7 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done) {
         HIPCHK(c, hipMemcpyAsync(c->ls_runs.p, runs.data(), sizeof(GateUnit) * runs.size(), hipMemcpyHostToDevice, c->stream));
         LsAvgArgs aa;
         aa.y = c->d_y; aa.y_stride = c->y_stride; aa.units = (const GateUnit *)c->ls_runs.p; aa.n_runs = (int)runs.size();
-        aa.start = d_av; aa.end = d_ae;
+        aa.start = d_av; aa.end = d_ae; aa.carry = opt.carry ? c->d_gstate : nullptr;
         hipLaunchKernelGGL(ls_avg_kernel, dim3((unsigned)runs.size()), dim3(64), 0, c->stream, aa);
         HIPCHK(c, hipGetLastError());
         std::vector<float> got(2 * (size_t)U);
@@ -370,7 +407,7 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done) {
         float t = 0.0f;
         bool chain_exact = true;   // every unit of this trace so far started from its true value
         for (int u = 0; u < U; ++u) {
-          if (first_of_trace(u)) { t = 0.0f; chain_exact = true; }
+          if (first_of_trace(u)) { t = start[(size_t)u].v[0]; chain_exact = true; }   // the fresh gate's 0, or the carried value
           const float sA = start[(size_t)u].v[0];
           const int64_t d = f_ord(t) - f_ord(sA);
           float pred;
@@ -531,6 +568,9 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done) {
           hipLaunchKernelGGL(ls_assemble_kernel, dim3((unsigned)U), dim3(64), 0, c->stream, aa);
           HIPCHK(c, hipGetLastError());
           HIPCHK(c, hipStreamSynchronize(c->stream));   // seq0 / wc are host vectors
+          if (opt.carry)   // (one trace) the state after its last processed unit
+            HIPCHK(c, hipMemcpyAsync(c->d_gstate, (GateState *)c->ls_state.p + (U - 1), sizeof(GateState), hipMemcpyDeviceToDevice,
+                                     c->stream));
           accepted = true;
           rep.verified = 1;
           lap("accepted and assembled");
@@ -630,6 +670,7 @@ int rfid_ctx_destroy(rfid_ctx *c) {
   if (!c) return RFID_ERR_INVALID;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  sio_free(c);
   free_plan(c);
   void *ptrs[] = {c->d_gate1, c->d_io, c->d_swin, c->d_scount, c->d_sres, c->d_sscores, c->s_in.p, c->s_out.p,
                   c->synth_tab.p, c->ls_cut.p, c->ls_units.p, c->ls_runs.p, c->ls_tmpl.p, c->ls_state.p, c->ls_uw.p, c->ls_uwc.p,
@@ -1322,11 +1363,8 @@ int rfid_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, i
     const int type = (rs.gate_status == RFID_GATE_SEEK_EPC) ? 1 : 0;
     rs.gate_status = RFID_GATE_CLOSED;
     rs.n_samples_to_ungate = type ? EPC_WIN : RN16_WIN;
-    const int zero = 0, ung = rs.n_samples_to_ungate;
-    HIPCHK(c, hipMemcpyAsync(&c->d_gate1->n_samples, &zero, sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&c->d_gate1->n_to_ungate, &ung, sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&c->d_gate1->wtype, &type, sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipLaunchKernelGGL(gate_arm_kernel, dim3(1), dim3(64), 0, c->stream, c->d_gate1, rs.n_samples_to_ungate, type);
+    HIPCHK(c, hipGetLastError());   // (stream-ordered before the scan below: no host round trip)
   }
   if (rs.status != RFID_RUNNING || n_in == 0) return RFID_OK;
   if (!out || out_cap < n_in) return RFID_ERR_CAPACITY;  // a call can emit up to n_in samples
@@ -1443,6 +1481,258 @@ int rfid_reader_work(rfid_ctx *c, int n_in, int *n_consumed) {  // reader_impl.c
       break;
     default: break;
   }
+  return RFID_OK;
+}
+
+}  // extern "C"
+
+
+// ======================================================================================
+// (1b) whole-chain streaming
+// ======================================================================================
+namespace {
+const int SIO_HIST = 28;   // raw samples kept before the held-back tail: 24 of filter history + the decimation group
+
+void sio_free(rfid_ctx *c) {
+  rfid_ctx::StreamIO &io = c->sio;
+  for (int i = 0; i < 2; ++i) {
+    if (io.d_buf[i]) (void)hipFree(io.d_buf[i]);
+    if (io.h_pin[i]) (void)hipHostFree(io.h_pin[i]);
+    if (io.ev_up[i]) (void)hipEventDestroy(io.ev_up[i]);
+    if (io.ev_free[i]) (void)hipEventDestroy(io.ev_free[i]);
+    io.d_buf[i] = nullptr; io.h_pin[i] = nullptr; io.ev_up[i] = nullptr; io.ev_free[i] = nullptr;
+  }
+  if (io.copy_stream) (void)hipStreamDestroy(io.copy_stream);
+  io.copy_stream = nullptr;
+  io.open = false;
+}
+
+// READER_STATE bookkeeping for one decoded window, as the blocks do it call by call (tag_decoder_impl.cc:267-388,
+// reader_impl.cc:251-344) incl. the TERMINATED cut-off that gate_impl.cc:101-109 applies before the next window
+bool sio_account(rfid_ctx *c, const rfid_decode_result &r) {
+  rfid_reader_state &rs = c->rs;
+  if (rs.n_queries_sent > c->prm.max_num_queries || rs.n_unique_tags > c->prm.number_unique_tags) rs.status = RFID_TERMINATED;
+  if (rs.status != RFID_RUNNING) return false;
+  if (r.type == RFID_DECODE_EPC) {
+    rs.cur_slot_number++;
+    if (rs.cur_slot_number > rs.max_slot_number) { rs.cur_slot_number = 1; rs.cur_inventory_round += 1; }
+    if (r.crc_ok) {
+      rs.n_epc_correct += 1;
+      const int id = r.tag_id & 255;
+      if (rs.tag_reads[id] == 0) rs.n_unique_tags++;
+      rs.tag_reads[id]++;
+    }
+    rs.n_queries_sent += 1;
+    rs.decoder_status = RFID_DECODE_RN16; rs.gate_status = RFID_GATE_SEEK_RN16;
+  } else {
+    rs.decoder_status = RFID_DECODE_EPC; rs.gate_status = RFID_GATE_SEEK_EPC;
+  }
+  rs.gen2_logic_status = RFID_IDLE;
+  return true;
+}
+
+// processes the chunk that sits in d_buf[b]: [SIO_HIST history | tail_len held back | n_new new] ending at tail_max + n_new
+int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
+  rfid_ctx::StreamIO &io = c->sio;
+  const int64_t n_have = io.tail_len + n_new;          // raw samples available beyond the history
+  const int64_t n_out = n_have / DECIM;
+  float2 *data = io.d_buf[b] + (io.tail_max - io.tail_len);   // first held-back (or new) sample
+  int64_t consumed = 0;                                 // decimated samples processed
+  int n_windows = 0;
+  memset(&c->ls_rep, 0, sizeof(c->ls_rep));
+  if (n_out > 0) {
+    // ---- matched filter over everything available: y[n] = sum x[5n - 24 .. 5n], history in front of `data` ----
+    MfArgs a;
+    a.x = data - SIO_HIST; a.x_stride = SIO_HIST + n_have; a.n_raw = SIO_HIST + n_have; a.lens = nullptr;
+    a.n_out = n_out; a.in_off = SIO_HIST - (NTAPS - 1);
+    a.vec_ok = ((((uintptr_t)a.x) & 15) == 0) ? 1 : 0;
+    a.y = c->d_y; a.y_stride = c->y_stride; a.tile0 = 0; a.stream0 = 0;
+    const int64_t tiles = (n_out + MF_TILE - 1) / MF_TILE;
+    hipLaunchKernelGGL(mf_boxcar25_decim5_kernel, dim3((unsigned)tiles, 1), dim3(MF_THREADS), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    c->d_lens = nullptr;
+    c->last_n_raw = n_have;
+    // ---- gate: units up to the last idle cut, from the carried state ----
+    LsOpts opt;
+    opt.carry = true; opt.hold_last = !flush; opt.force = true;
+    int done = 0;
+    int rc = ls_front_end(c, n_out, &done, opt, &consumed);
+    if (rc) return rc;
+    if (done) {
+      if (flush) consumed = n_out;
+    } else if (flush) {
+      // end of the stream and too little left to cut: the plain sequential scan from the carried state; only complete
+      // windows are recorded, as the decoder would only ever see those (tag_decoder_impl.cc:223,291)
+      HIPCHK(c, hipMemsetAsync(c->d_flat_count, 0, 2 * sizeof(int), c->stream));
+      HIPCHK(c, hipMemsetAsync(&c->d_gstate->win_seq, 0, sizeof(int), c->stream));   // windows are numbered per call
+      GateArgs g = {};
+      g.y = c->d_y; g.y_stride = c->y_stride; g.n_dec = n_out; g.lens = nullptr; g.pos0 = 0; g.chunk_len = n_out;
+      g.state = c->d_gstate; g.n_streams = 1; g.wtab = c->d_wtab; g.wmax = c->wmax; g.wcount = c->d_wcount;
+      g.flat = c->d_flat; g.flat_count = c->d_flat_count; g.flat_cap = c->flat_cap; g.mode = 0;
+      hipLaunchKernelGGL(gate_scan_kernel, dim3(1), dim3(GATE_THREADS), 0, c->stream, g);
+      HIPCHK(c, hipGetLastError());
+      consumed = n_out;
+      done = 1;
+    } else {
+      consumed = 0;   // no verified idle cut in what is available: wait for more samples
+    }
+    if (done) {
+      // ---- decode what the gate found, fetch it ----
+      c->ev_valid[2] = false;
+      if ((rc = rfid_batch_decode(c, 0))) return rc;
+      int wc = 0;
+      HIPCHK(c, hipMemcpyAsync(&wc, c->d_wcount, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      n_windows = wc;
+      if (wc > 0) {
+        std::vector<rfid_window> w((size_t)wc);
+        std::vector<rfid_decode_result> r((size_t)wc);
+        HIPCHK(c, hipMemcpyAsync(w.data(), c->d_wtab, sizeof(rfid_window) * (size_t)wc, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(r.data(), c->d_res, sizeof(rfid_decode_result) * (size_t)wc, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const int64_t n0 = io.raw_base / DECIM;
+        for (int i = 0; i < wc; ++i) {
+          if (!sio_account(c, r[(size_t)i])) break;   // TERMINATED: the gate swallows the rest (gate_impl.cc:125,198)
+          rfid_stream_window sw;
+          sw.start = n0 + w[(size_t)i].start; sw.type = w[(size_t)i].type; sw.reserved_ = 0;
+          sw.dc_re = w[(size_t)i].dc_re; sw.dc_im = w[(size_t)i].dc_im;
+          io.out_w.push_back(sw);
+          io.out_r.push_back(r[(size_t)i]);
+        }
+      }
+    }
+  }
+  // ---- what was not processed moves in front of the other buffer's upload area, history included ----
+  const int64_t left = n_have - DECIM * consumed;
+  if (left + SIO_HIST > io.tail_max)
+    return fail(c, RFID_ERR_CAPACITY, "rfid_stream_work: no idle point of the gate within the hold-back capacity (is this a Gen2 trace?)");
+  const int o = b ^ 1;
+  HIPCHK(c, hipMemcpyAsync(io.d_buf[o] + (io.tail_max - left - SIO_HIST), data + DECIM * consumed - SIO_HIST,
+                           sizeof(float2) * (size_t)(left + SIO_HIST), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(io.ev_free[b], c->stream));
+  io.tail_len = left;
+  io.raw_base += DECIM * consumed;
+  (void)n_windows;
+  return RFID_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int rfid_stream_begin(rfid_ctx *c, int64_t max_chunk_raw) {
+  if (!c || max_chunk_raw < 5 * 4 * LS_MIN_CHUNK) return RFID_ERR_INVALID;   // a chunk must hold a few units
+  HIPCHK(c, hipSetDevice(c->device));
+  rfid_ctx::StreamIO &io = c->sio;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  sio_free(c);
+  // held back per call: at most one (stretched) unit of the chunk's unit grid + the cut search range
+  int64_t chunk_units = (max_chunk_raw / DECIM + LS_TARGET_UNITS - 1) / LS_TARGET_UNITS;
+  if (chunk_units < LS_MIN_CHUNK) chunk_units = LS_MIN_CHUNK;
+  io.tail_max = ((DECIM * 4 * chunk_units + SIO_HIST + 63) & ~63LL);
+  io.max_chunk = max_chunk_raw;
+  int rc = rfid_batch_plan(c, 1, io.tail_max + max_chunk_raw);
+  if (rc) return rc;
+  for (int i = 0; i < 2; ++i) {
+    if (hipMalloc((void **)&io.d_buf[i], sizeof(float2) * (size_t)(io.tail_max + max_chunk_raw)) != hipSuccess ||
+        hipHostMalloc((void **)&io.h_pin[i], sizeof(rfid_cf32) * (size_t)max_chunk_raw, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&io.ev_up[i], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&io.ev_free[i], hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      sio_free(c);
+      return fail(c, RFID_ERR_HIP, "rfid_stream_begin: staging allocation");
+    }
+    if (hipMemsetAsync(io.d_buf[i], 0, sizeof(float2) * (size_t)io.tail_max, c->stream) != hipSuccess) { sio_free(c); return RFID_ERR_HIP; }
+  }
+  if (hipStreamCreateWithFlags(&io.copy_stream, hipStreamNonBlocking) != hipSuccess) { sio_free(c); return RFID_ERR_HIP; }
+  // fresh blocks: gate_impl ctor state (zeros), READER_STATE after START -> SEND_QUERY (reader_impl.cc:218-288)
+  init_reader_state(c);
+  c->rs.n_queries_sent = 1;
+  c->rs.gen2_logic_status = RFID_IDLE;
+  HIPCHK(c, hipMemsetAsync(c->d_gstate, 0, sizeof(GateState), c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  io.cur = 0; io.pending = false; io.pend_new = 0; io.tail_len = 0; io.raw_base = 0;
+  io.out_w.clear(); io.out_r.clear();
+  io.open = true;
+  return RFID_OK;
+}
+
+int rfid_stream_staging(rfid_ctx *c, int idx, rfid_cf32 **host, int64_t *cap) {
+  if (!c || idx < 0 || idx > 1 || !host) return RFID_ERR_INVALID;
+  if (!c->sio.open) return RFID_ERR_STATE;
+  *host = c->sio.h_pin[idx];
+  if (cap) *cap = c->sio.max_chunk;
+  return RFID_OK;
+}
+
+int rfid_stream_work(rfid_ctx *c, const rfid_cf32 *raw, int64_t n_raw, int flush, rfid_stream_window *windows,
+                     rfid_decode_result *results, int64_t cap, int64_t *n_out) {
+  if (!c || n_raw < 0 || (n_raw > 0 && !raw) || !n_out || cap < 0) return RFID_ERR_INVALID;
+  rfid_ctx::StreamIO &io = c->sio;
+  if (!io.open) return RFID_ERR_STATE;
+  if (n_raw > io.max_chunk) return RFID_ERR_CAPACITY;
+  HIPCHK(c, hipSetDevice(c->device));
+  *n_out = 0;
+  // ---- 1. start the upload of the new samples ----
+  int up_idx = -1;
+  if (n_raw > 0) {
+    up_idx = io.cur;
+    const rfid_cf32 *src = raw;
+    bool pinned = (raw == io.h_pin[0] || raw == io.h_pin[1]);
+    if (!pinned) {   // page-locked memory of the caller's own (hipHostMalloc / hipHostRegister, a torch pinned tensor)?
+      hipPointerAttribute_t attr;
+      if (hipPointerGetAttributes(&attr, raw) == hipSuccess) pinned = (attr.type == hipMemoryTypeHost);
+      else (void)hipGetLastError();
+    }
+    if (!pinned) {   // ordinary host memory: through the pinned buffer of this slot (its previous upload is long over:
+                     // the chunk it carried was processed one call ago -- waited for all the same)
+      HIPCHK(c, hipEventSynchronize(io.ev_up[up_idx]));
+      memcpy(io.h_pin[up_idx], raw, sizeof(rfid_cf32) * (size_t)n_raw);
+      src = io.h_pin[up_idx];
+    }
+    HIPCHK(c, hipStreamWaitEvent(io.copy_stream, io.ev_free[up_idx], 0));   // the chunk last processed from this buffer is done
+    HIPCHK(c, hipMemcpyAsync(io.d_buf[up_idx] + io.tail_max, src, sizeof(rfid_cf32) * (size_t)n_raw, hipMemcpyHostToDevice,
+                             io.copy_stream));
+    HIPCHK(c, hipEventRecord(io.ev_up[up_idx], io.copy_stream));
+    io.cur ^= 1;
+  }
+  // ---- 2. process the chunk of the previous call while that upload runs ----
+  if (io.pending) {
+    HIPCHK(c, hipStreamWaitEvent(c->stream, io.ev_up[io.pend_idx], 0));
+    int rc = sio_process(c, io.pend_idx, io.pend_new, false);
+    if (rc) return rc;
+    io.pending = false;
+  }
+  if (n_raw > 0) { io.pending = true; io.pend_idx = up_idx; io.pend_new = n_raw; }
+  // ---- 3. end of stream: the new chunk too, and whatever is still held back ----
+  if (flush) {
+    if (io.pending) {
+      HIPCHK(c, hipStreamWaitEvent(c->stream, io.ev_up[io.pend_idx], 0));
+      int rc = sio_process(c, io.pend_idx, io.pend_new, true);
+      if (rc) return rc;
+      io.pending = false;
+    } else if (io.tail_len > 0) {
+      int rc = sio_process(c, io.cur, 0, true);   // the held-back samples sit in front of the next upload area
+      if (rc) return rc;
+    }
+  }
+  // ---- 4. deliver ----
+  const int64_t have = (int64_t)io.out_w.size();
+  if (have > cap || (have > 0 && (!windows || !results))) { *n_out = have; return RFID_ERR_CAPACITY; }
+  if (have > 0) {
+    memcpy(windows, io.out_w.data(), sizeof(rfid_stream_window) * (size_t)have);
+    memcpy(results, io.out_r.data(), sizeof(rfid_decode_result) * (size_t)have);
+  }
+  io.out_w.clear(); io.out_r.clear();
+  *n_out = have;
+  return RFID_OK;
+}
+
+int rfid_stream_end(rfid_ctx *c) {
+  if (!c) return RFID_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->sio.copy_stream) (void)hipStreamSynchronize(c->sio.copy_stream);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  sio_free(c);
   return RFID_OK;
 }
 

@@ -1176,6 +1176,8 @@ struct LsInitArgs {
   const GateUnit *units;
   int n_units;
   GateState *tmpl;         // [n_units]: rings + idle state machine; avg_ampl / dc_est = first guesses
+  const GateState *carry;  // optional [n_streams]: the state a trace's FIRST unit starts from (streaming: the gate
+                           // state the previous call ended in); nullptr = the fresh gate
 };
 
 // template gate state of a unit: the rings as the sequential scan leaves them at an idle cut (the last 100
@@ -1192,7 +1194,16 @@ RFID_KERNEL(64) void ls_init_kernel(LsInitArgs a) {
     for (int i = lane; i < (int)(sizeof(GateState) / 4); i += 64) w[i] = 0;
   }
   wv::wave_sync();
-  if (pos0 < WIN_LEN) return;   // (only unit 0 starts before sample 100: cuts lie >= LS_QUIET into the trace)
+  if (pos0 == 0) {   // (only a trace's first unit starts before sample 100: cuts lie >= LS_QUIET into the trace)
+    if (a.carry) {
+      const int *src = reinterpret_cast<const int *>(a.carry + a.units[u].stream);
+      int *w = reinterpret_cast<int *>(st);
+      for (int i = lane; i < (int)(sizeof(GateState) / 4); i += 64) w[i] = src[i];
+      wv::wave_sync();
+      if (lane == 0) st->win_seq = 0;   // windows are numbered per unit (the carried count belongs to earlier calls)
+    }
+    return;
+  }
   const float2 *ys = a.y + (int64_t)a.units[u].stream * a.y_stride;
   for (int i = lane; i < WIN_LEN; i += 64) {
     const float2 v = ys[pos0 - WIN_LEN + i];
@@ -1234,6 +1245,7 @@ struct LsAvgArgs {
   int n_runs;
   const float *start;      // avg_ampl at the unit's first sample
   float *end;              // avg_ampl after its last sample
+  const GateState *carry;  // optional [n_streams]: amplitude ring a trace's first unit starts with (else all zero)
 };
 RFID_KERNEL(64) void ls_avg_kernel(LsAvgArgs a) {
   const int lane = wv::lane_id();
@@ -1249,6 +1261,13 @@ RFID_KERNEL(64) void ls_avg_kernel(LsAvgArgs a) {
     const float2 p2 = ys[lane - 128], p1 = ys[lane - 64];
     a2 = wv::hypot_f(p2.x, p2.y);
     a1 = wv::hypot_f(p1.x, p1.y);
+  } else if (a.carry) {
+    // sample -j (j = 1..100) of the carried ring: win[(win_index - j) mod 100] (win_index = the oldest = next written)
+    const GateState *cs = a.carry + wv::uniform(un.stream);
+    const int wi = wv::uniform(cs->win_index);
+    const int j1 = 64 - lane, j2 = 128 - lane;
+    a1 = cs->win[(wi - j1 + 2 * WIN_LEN) % WIN_LEN];
+    a2 = (j2 <= WIN_LEN) ? cs->win[(wi - j2 + 2 * WIN_LEN) % WIN_LEN] : 0.0f;
   }
   float avg = wv::uniform(a.start[row]);
   const int nsteps = (n + 63) >> 6;
@@ -1291,6 +1310,11 @@ RFID_KERNEL(64) void ls_set_state_kernel(LsHeadsArgs a) {
   wv::wave_sync();
   // the nine values are the first nine words of GateState, in this order
   if (lane < LS_HEAD_WORDS) dst[lane] = a.heads[LS_HEAD_WORDS * row + lane];
+}
+
+// gate_impl.cc:112-123 for the streaming gate: SEEK_* -> CLOSED arms the next window (one launch, no host round trip)
+RFID_KERNEL(64) void gate_arm_kernel(GateState *st, int n_to_ungate, int wtype) {
+  if (threadIdx.x == 0) { st->n_samples = 0; st->n_to_ungate = n_to_ungate; st->wtype = wtype; }
 }
 
 // compact copies for the host: the first 12 words of every state row; the end of the last window of every unit

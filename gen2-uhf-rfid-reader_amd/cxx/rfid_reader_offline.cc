@@ -10,11 +10,15 @@
 //                       [--tx-out FILE]    the reader block's output, float32 (apps/reader.py's file_sink_reader)
 //                       [--mf-out FILE]    matched-filter output, complex64     (file_sink_matched_filter, :69)
 //                       [--gate-out FILE]  gated samples, complex64            (file_sink_gate, :70)
+//                       [--whole-chain N]  instead of block-by-block calls: rfid_stream_work, N raw samples per call
+//                                          (matched filter -> gate -> tag_decoder in one submission, state on the device)
+//                       [--time]           print the run's wall time and rate to stderr
 //
 // TRACE_FILE: headerless little-endian interleaved float32 I,Q at 2 Msps (apps/reader.py:102).
 // Exit codes: 0 ok, 2 usage / file error, 3 no gfx950 device (there is no CPU fallback), 4 other library error.
 #include <rfid/mi355x.h>
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -32,6 +36,8 @@ bool dump(const char *path, const std::vector<T> &v) {
 int main(int argc, char **argv) {
   const char *path = nullptr, *tx_path = nullptr, *mf_path = nullptr, *gate_path = nullptr;
   int device = 0, chunk = 8192;
+  long whole_chain = 0;
+  bool show_time = false;
   int fixed_q = gr::rfid::FIXED_Q, max_q = gr::rfid::MAX_NUM_QUERIES, uniq = gr::rfid::NUMBER_UNIQUE_TAGS;
   for (int i = 1; i < argc; ++i) {
     auto need = [&](const char *flag) -> const char * {
@@ -46,6 +52,8 @@ int main(int argc, char **argv) {
     else if (!std::strcmp(argv[i], "--tx-out")) tx_path = need("--tx-out");
     else if (!std::strcmp(argv[i], "--mf-out")) mf_path = need("--mf-out");
     else if (!std::strcmp(argv[i], "--gate-out")) gate_path = need("--gate-out");
+    else if (!std::strcmp(argv[i], "--whole-chain")) whole_chain = std::atol(need("--whole-chain"));
+    else if (!std::strcmp(argv[i], "--time")) show_time = true;
     else if (argv[i][0] == '-') { std::cerr << "unknown option " << argv[i] << "\n"; return 2; }
     else path = argv[i];
   }
@@ -79,13 +87,48 @@ int main(int argc, char **argv) {
     mi355x::sts_flowgraph tb(mf, gate_blk, dec, reader_blk, chunk);
     tb.keep_tx(tx_path != nullptr);
     tb.keep_taps(mf_path != nullptr || gate_path != nullptr);
-    tb.run(samples.data(), samples.size());
+    const auto t0 = std::chrono::steady_clock::now();
+    long n_windows = 0;
+    if (whole_chain > 0) {
+      // the same blocks' stream, fed chunk by chunk through the whole-chain call of the C-ABI
+      rfid_ctx *ctx = mi355x::current_context();
+      if (whole_chain < 200000) whole_chain = 200000;
+      int st = rfid_stream_begin(ctx, whole_chain);
+      if (st != RFID_OK) throw mi355x::error(st, std::string("rfid_stream_begin: ") + rfid_last_error(ctx));
+      std::vector<rfid_stream_window> w(1 << 16);
+      std::vector<rfid_decode_result> r(1 << 16);
+      size_t pos = 0;
+      bool flushed = false;
+      while (!flushed) {
+        const size_t n = (samples.size() - pos < (size_t)whole_chain) ? samples.size() - pos : (size_t)whole_chain;
+        flushed = (pos + n >= samples.size());
+        int64_t got = 0;
+        st = rfid_stream_work(ctx, (const rfid_cf32 *)samples.data() + pos, (int64_t)n, flushed ? 1 : 0, w.data(), r.data(),
+                              (int64_t)w.size(), &got);
+        if (st == RFID_ERR_CAPACITY && got > (int64_t)w.size()) {
+          w.resize((size_t)got * 2); r.resize((size_t)got * 2);
+          st = rfid_stream_work(ctx, nullptr, 0, flushed ? 1 : 0, w.data(), r.data(), (int64_t)w.size(), &got);
+        }
+        if (st != RFID_OK) throw mi355x::error(st, std::string("rfid_stream_work: ") + rfid_last_error(ctx));
+        n_windows += (long)got;
+        pos += n;
+      }
+      rfid_stream_end(ctx);
+    } else {
+      tb.run(samples.data(), samples.size());
+      n_windows = tb.windows_decoded();
+    }
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     reader_blk->print_results();   // apps/reader.py:130
+    if (show_time)
+      std::cerr << "rfid_reader_offline: " << samples.size() << " raw samples, " << n_windows << " windows in " << secs * 1e3
+                << " ms = " << (double)samples.size() / secs / 1e6 << " Msamples/s ("
+                << (whole_chain > 0 ? "whole-chain calls" : "block-by-block calls") << ")\n";
     if (getenv("RFID_PRINT_READER_STATE"))   // the reference's global, for tests of the mirror
       std::cout << "reader_state: n_queries_sent=" << reader_state->reader_stats.n_queries_sent
                 << " n_epc_correct=" << reader_state->reader_stats.n_epc_correct
                 << " unique=" << reader_state->reader_stats.tag_reads.size()
-                << " gate_status=" << reader_state->gate_status << " windows=" << tb.windows_decoded() << "\n";
+                << " gate_status=" << reader_state->gate_status << " windows=" << n_windows << "\n";
     if (tx_path && !dump(tx_path, tb.tx_samples())) { std::cerr << "cannot write " << tx_path << "\n"; return 2; }
     if (mf_path && !dump(mf_path, tb.tap_matched_filter())) { std::cerr << "cannot write " << mf_path << "\n"; return 2; }
     if (gate_path && !dump(gate_path, tb.tap_gate())) { std::cerr << "cannot write " << gate_path << "\n"; return 2; }

@@ -73,6 +73,8 @@ SCORES_DTYPE = np.dtype([("corr", "<f4", (15,)), ("energy", "<f4", (20,)), ("pad
 STATS_DTYPE = np.dtype([("n_queries_sent", "<i4"), ("cur_inventory_round", "<i4"), ("cur_slot_number", "<i4"),
                         ("n_epc_correct", "<i4"), ("n_unique_tags", "<i4"), ("n_windows", "<i4"),
                         ("n_windows_used", "<i4"), ("status", "<i4"), ("tag_reads", "<i4", (256,))])
+STREAM_WINDOW_DTYPE = np.dtype([("start", "<i8"), ("type", "<i4"), ("reserved_", "<i4"), ("dc_re", "<f4"), ("dc_im", "<f4")])
+assert STREAM_WINDOW_DTYPE.itemsize == 24
 assert WINDOW_DTYPE.itemsize == 24 and RESULT_DTYPE.itemsize == 48
 assert SCORES_DTYPE.itemsize == 144 and STATS_DTYPE.itemsize == 1056
 
@@ -97,6 +99,10 @@ SIGNATURES = {
     "rfid_print_results": (_i, [_vp, C.c_char_p, _i, _ip]),
     "rfid_synth_gen2_size": (_i, [_vp, _vp, _i64, C.POINTER(C.c_int64)]),
     "rfid_synth_gen2": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, C.c_float, C.c_uint64, _i64, C.POINTER(C.c_int64)]),
+    "rfid_stream_begin": (_i, [_vp, _i64]),
+    "rfid_stream_staging": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(C.c_int64)]),
+    "rfid_stream_work": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _i64, C.POINTER(C.c_int64)]),
+    "rfid_stream_end": (_i, [_vp]),
     "rfid_batch_plan": (_i, [_vp, _i, _i64]),
     "rfid_batch_set_streams": (_i, [_vp, _i]),
     "rfid_batch_set_long_stream": (_i, [_vp, _i]),

@@ -125,6 +125,42 @@ class Context:
                                                 out.ctypes.data, len(out), C.byref(cons), C.byref(wr)))
         return cons.value, out[: wr.value].copy()
 
+    # -- (1b) whole-chain streaming ------------------------------------------------------------------
+    def stream_begin(self, max_chunk_raw: int) -> None:
+        self._chk(self._lib.rfid_stream_begin(self._h, int(max_chunk_raw)))
+        self._stream_cap = 4096
+
+    def stream_staging(self, idx: int) -> np.ndarray:
+        """One of the two pinned staging buffers as a complex64 array (fill it, then pass a slice that starts at
+        element 0 to stream_work: the upload is then a true asynchronous DMA)."""
+        p, cap = C.c_void_p(), C.c_int64(0)
+        self._chk(self._lib.rfid_stream_staging(self._h, int(idx), C.byref(p), C.byref(cap)))
+        buf = (C.c_float * (2 * cap.value)).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.complex64)
+
+    def stream_work(self, raw=None, flush: bool = False):
+        """-> (windows, results) completed by this call (rfid_stream_work)."""
+        if raw is None:
+            raw = np.zeros(0, dtype=np.complex64)
+        raw = np.ascontiguousarray(raw, dtype=np.complex64)
+        n = C.c_int64(0)
+        ptr = raw.ctypes.data if len(raw) else None
+        n_in = len(raw)
+        while True:
+            w = np.zeros(self._stream_cap, dtype=capi.STREAM_WINDOW_DTYPE)
+            r = np.zeros(self._stream_cap, dtype=capi.RESULT_DTYPE)
+            st = self._lib.rfid_stream_work(self._h, ptr, n_in, int(bool(flush)), w.ctypes.data, r.ctypes.data,
+                                            self._stream_cap, C.byref(n))
+            if st == capi.ERR_CAPACITY and n.value > self._stream_cap:   # arrays too small: nothing lost, ask again
+                self._stream_cap = int(n.value) * 2
+                ptr, n_in = None, 0
+                continue
+            self._chk(st)
+            return w[: n.value].copy(), r[: n.value].copy()
+
+    def stream_end(self) -> None:
+        self._chk(self._lib.rfid_stream_end(self._h))
+
     # -- (2) batched offline, device buffers ---------------------------------------------------
     def batch_plan(self, n_streams: int, max_raw: int) -> None:
         self._chk(self._lib.rfid_batch_plan(self._h, int(n_streams), int(max_raw)))

@@ -200,6 +200,42 @@ RFID_API int rfid_get_state(const rfid_ctx *ctx, rfid_reader_state *out);
 /* reader_impl::print_results text (lib/reader_impl.cc:173-192) */
 RFID_API int rfid_print_results(const rfid_ctx *ctx, char *buf, int cap, int *len);
 
+
+/* ---- (1b) streaming, whole chain per call: raw chunk in -> decoded windows out ------------------------------------ */
+/* The drop-in calls above cross the host / device boundary three times per buffer.  This family runs
+ * matched filter -> gate -> tag_decoder for one RX stream in ONE submission per chunk, with all block state carried
+ * on the device (filter history, gate state incl. both rings, window alternation, READER_STATE), and overlaps the
+ * host -> HBM copy of chunk k+1 with the processing of chunk k (two pinned staging buffers, a copy stream).
+ * The gate scan of a chunk uses the long-stream front end (units scanned concurrently, accepted only when bit-identical
+ * to the sequential scan), so a single stream is not limited to one SIMD.  Results equal rfid_batch_process over the
+ * concatenated stream, window for window. */
+typedef struct rfid_stream_window {
+  int64_t start;          /* index (400 ksps domain, from the start of the stream) of the first gated sample */
+  int32_t type;           /* RFID_DECODE_RN16 / RFID_DECODE_EPC */
+  int32_t reserved_;
+  float dc_re, dc_im;     /* gate_impl::dc_est at the opening */
+} rfid_stream_window;
+
+/* Allocates the staging (2 pinned host buffers + 2 device buffers of max_chunk_raw samples, plus room for the samples a
+ * call leaves unprocessed) and resets the stream (fresh blocks).  Replaces any batch plan of the context. */
+RFID_API int rfid_stream_begin(rfid_ctx *ctx, int64_t max_chunk_raw);
+/* the two pinned staging buffers (idx 0 / 1): filling them directly makes the upload a true asynchronous DMA; any other
+ * host pointer passed to rfid_stream_work is first copied into one of them */
+RFID_API int rfid_stream_staging(rfid_ctx *ctx, int idx, rfid_cf32 **host, int64_t *cap);
+/* Hands over n_raw NEW samples (their upload starts at once) and processes the chunk handed over by the PREVIOUS call
+ * while that upload runs; flush != 0 also processes the new samples and everything held back (end of stream).
+ * A call holds back what follows the last idle point of the gate's state machine (the reference's blocks do the same
+ * through consume_each(): lib/gate_impl.cc:189-199, lib/tag_decoder_impl.cc:223,291); held-back samples are processed
+ * with a later call.  windows / results (cap entries each, in stream order) receive the windows completed by this call,
+ * *n_out their number (RFID_ERR_CAPACITY if cap is too small: nothing is lost, call again with larger arrays and
+ * n_raw = 0).  READER_STATE (rfid_get_state, rfid_print_results) advances as in the per-block calls.
+ * raw may be page-locked host memory -- one of the staging buffers or the caller's own (hipHostMalloc, hipHostRegister,
+ * a pinned torch tensor): it is then uploaded by DMA straight from there and must stay untouched until the NEXT call
+ * has returned -- or ordinary host memory, which is first copied into the staging buffer of the call (free on return). */
+RFID_API int rfid_stream_work(rfid_ctx *ctx, const rfid_cf32 *raw, int64_t n_raw, int flush, rfid_stream_window *windows,
+                              rfid_decode_result *results, int64_t cap, int64_t *n_out);
+RFID_API int rfid_stream_end(rfid_ctx *ctx);
+
 /* ---- (2) batched offline, device buffers ---------------------------------------------- */
 /* Plans workspace for n_streams traces of up to max_raw samples each (2 Msps domain).
  * Allocates, in HBM: matched-filter output [n_streams][max_raw/5], window tables, results.

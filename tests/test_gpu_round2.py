@@ -319,3 +319,61 @@ def test_two_ranks_shard_a_batch_through_the_hip_path(tmp_path, gpu_ctx, oracle_
     o = oracle_mod.run_trace(first)
     assert o.state.n_epc_correct == 70 and gpu_ctx.batch_stats()[5]["n_epc_correct"] == 70
     gpu_ctx.batch_plan(1, 4096)
+
+
+@pytest.mark.parametrize("sizes", [[400_000], [150_000, 333_333, 123_457], [1_000_000]])
+def test_whole_chain_streaming_equals_batch_and_oracle(oracle_mod, synth_mod, sizes):
+    """rfid_stream_work: raw chunks in, decoded windows out, all block state carried on the device, upload of chunk
+    k+1 overlapping the processing of chunk k.  Whatever the chunk sizes (also from the pinned staging buffers), the
+    windows (global positions, dc_est), every decoded field and the final READER_STATE / print_results text equal
+    the oracle's run over the whole stream."""
+    import rfid
+    t = synth_mod.make_trace(n_rounds=80, fixed_q=1, tag_ids=(0x27, 0x3C), seed=812, sigma=0.01, t1_jitter_raw=5).samples
+    o = oracle_mod.run_trace(t, oracle_mod.config(fixed_q=1))
+    ctx = rfid.Context(device=0, fixed_q=1)
+    try:
+        ctx.stream_begin(max(sizes) + 1000)
+        ws, rs = [], []
+        pos, k = 0, 0
+        while pos < len(t):
+            n = min(sizes[k % len(sizes)], len(t) - pos)
+            if k % 2 == 1:                                   # every other chunk goes through a pinned staging buffer
+                stg = ctx.stream_staging(k % 2)              # (the slot the library itself would stage chunk k in)
+                stg[:n] = t[pos:pos + n]
+                w, r = ctx.stream_work(stg[:n])
+            else:
+                w, r = ctx.stream_work(t[pos:pos + n])
+            ws.append(w); rs.append(r)
+            pos += n
+            k += 1
+        w, r = ctx.stream_work(flush=True)
+        ws.append(w); rs.append(r)
+        w, r = np.concatenate(ws), np.concatenate(rs)
+        assert len(w) == o.n_windows, ([len(x) for x in ws], o.n_windows)
+        assert np.array_equal(w["start"], o.open_idx) and np.array_equal(w["type"], o.dumps["type"])
+        assert np.array_equal(w["dc_re"].view(np.uint32), o.dc.real.view(np.uint32))
+        assert np.array_equal(w["dc_im"].view(np.uint32), o.dc.imag.view(np.uint32))
+        fake = np.zeros(len(w), dtype=rfid.capi.WINDOW_DTYPE)
+        fake["start"], fake["type"], fake["dc_re"], fake["dc_im"] = w["start"], w["type"], w["dc_re"], w["dc_im"]
+        parity.compare_trace_fast(fake, r, None, o)
+        assert ctx.stats() == o.stats()
+        assert ctx.print_results() == o.print_results()
+        ctx.stream_end()
+    finally:
+        ctx.close()
+
+
+def test_cxx_offline_binary_whole_chain_mode(tmp_path, oracle_mod, synth_mod):
+    """rfid_reader_offline --whole-chain N: the same blocks, fed through rfid_stream_work -- same report as block by
+    block and as the oracle.  (print_results reads the context both modes share.)"""
+    import rfid
+    exe = os.path.join(rfid.capi.PKG_ROOT, "bin", "rfid_reader_offline")
+    t = synth_mod.make_trace(n_rounds=40, seed=23, sigma=0.01, t1_jitter_raw=3, corrupt_rounds=(7,))
+    path = tmp_path / "t.bin"
+    rfid.batch.write_trace_file(str(path), t.samples)
+    want = oracle_mod.run_trace(t.samples).print_results()
+    for extra in ([], ["--whole-chain", "250000"], ["--whole-chain", "100000000"]):
+        out = subprocess.run([exe, str(path), "--time"] + extra, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout == want, extra
+        print(out.stderr.strip())
