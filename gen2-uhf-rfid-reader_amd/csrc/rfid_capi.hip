@@ -1025,7 +1025,6 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
     g.flat = c->d_flat; g.flat_count = c->d_flat_count; g.flat_cap = c->flat_cap; g.mode = 0;
     g.raw = (const float2 *)d_raw; g.raw_stride = raw_stride; g.n_raw = n_raw;
     g.raw_vec_ok = ((raw_stride & 1) == 0 && (((uintptr_t)d_raw) & 15) == 0) ? 1 : 0;
-    if (const char *e = getenv("RFID_GATE_KNOCK")) g.knock = atoi(e);   // developer aid: times parts of the kernel, WRONG RESULTS
     if (getenv("RFID_GATE_PROF")) {
       int rc = launch_gate_prof(c, g, true);
       if (rc) return rc;
@@ -1228,6 +1227,33 @@ int rfid_batch_get_mf(rfid_ctx *c, int stream, rfid_cf32 *out, int64_t cap, int6
     HIPCHK(c, hipMemcpyAsync(out, c->d_y + (size_t)stream * (size_t)c->y_stride, sizeof(float2) * (size_t)k,
                              hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return RFID_OK;
+}
+
+int rfid_batch_get_gated(rfid_ctx *c, int stream, int seq, rfid_cf32 *out, int64_t cap, int64_t *n) {
+  if (!c || !out || !n || seq < 0) return RFID_ERR_INVALID;
+  if (!c->B || stream < 0 || stream >= c->B || seq >= c->wmax) return RFID_ERR_STATE;
+  HIPCHK(c, hipSetDevice(c->device));
+  int wc = 0;
+  rfid_window w;
+  HIPCHK(c, hipMemcpyAsync(&wc, c->d_wcount + stream, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&w, c->d_wtab + (size_t)stream * (size_t)c->wmax + (size_t)seq, sizeof(w), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (seq >= wc) return fail(c, RFID_ERR_INVALID, "rfid_batch_get_gated: no such window");
+  const int64_t len = w.type ? EPC_WIN : RN16_WIN;
+  *n = len;
+  const int64_t k = len < cap ? len : cap;
+  if (k > 0) {
+    HIPCHK(c, hipMemcpyAsync(out, c->d_y + (size_t)stream * (size_t)c->y_stride + (size_t)w.start, sizeof(float2) * (size_t)k,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // in[i] - dc_est: one binary32 subtraction per component, the same operation on any IEEE host (no sample arithmetic
+    // beyond this debug tap's formatting happens on the host)
+    for (int64_t i = 0; i < k; ++i) {
+      volatile float re = out[i].re - w.dc_re, im = out[i].im - w.dc_im;
+      out[i].re = re; out[i].im = im;
+    }
+  }
   return RFID_OK;
 }
 

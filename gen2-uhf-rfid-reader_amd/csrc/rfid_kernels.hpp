@@ -184,7 +184,6 @@ struct GateArgs {
   int raw_vec_ok;       // rows 16-byte aligned -> float4 loads
   float2 *y_w;          // [n_streams][y_stride], written
   const GateUnit *units; // optional: n_streams counts UNITS; state / wtab / wcount are per unit
-  int knock;            // developer aid (RFID_GATE_KNOCK): knock out parts of the work to time the rest -- WRONG RESULTS
 };
 
 // x / C for the gate's two constant divisors (100: gate_impl.cc:131, 48: :141) in three instructions
@@ -360,11 +359,11 @@ struct GateBack {
 
 // ---- producer wave: everything that is lane-parallel ---------------------------------------
 RFID_DEVICE void gate_produce(GateSlot &slot, float2 yv_in, float2 &prev_yv, int pos, int n, int lane,
-                              float *lds_win, int &win_index, int knock) {
+                              float *lds_win, int &win_index) {
   const int nvalid = (n - pos < 64) ? (n - pos) : 64;
   const bool valid = lane < nvalid;
   const float2 yv = valid ? yv_in : make_float2(0.0f, 0.0f);
-  const float amp = (knock & 8) ? (__builtin_fabsf(yv.x) + __builtin_fabsf(yv.y)) : wv::hypot_f(yv.x, yv.y);
+  const float amp = wv::hypot_f(yv.x, yv.y);
   int wi = win_index + lane;
   if (wi >= WIN_LEN) wi -= WIN_LEN;
   const float amp_old = lds_win[wi];
@@ -403,11 +402,11 @@ RFID_DEVICE void gate_produce(GateSlot &slot, float2 yv_in, float2 &prev_yv, int
 // ---- averaging wave: avg_ampl and the threshold test -------------------------------------------
 // avg_ampl is an in-order sum over all samples that does not depend on the state machine
 // (gate_impl.cc:130-134), so it runs one or more steps ahead of the consumer in a wave of its own.
-RFID_DEVICE void gate_average(GateSlot &slot, int nvalid, int lane, float &avg_c, int knock) {
+RFID_DEVICE void gate_average(GateSlot &slot, int nvalid, int lane, float &avg_c) {
   const float amp = slot.amp[lane], d = slot.d[lane];
-  // (chain_add_auto -- the integer-scan form -- was measured here: no gain, the pipeline is bound by the filter wave's
-  //  staging and the hand-offs, not by the chain's latency; knock & 16 times it)
-  const float avg = (knock & 2) ? (avg_c + d) : ((knock & 16) ? chain_add_auto(avg_c, d, lane) : chain_add(avg_c, d, lane));
+  // (the integer-scan form chain_add_auto was measured here: no gain -- this pipeline is bound by the filter wave's
+  //  staging and the hand-offs, not by the chain's latency; profiles/r02/knockout_front_end.txt)
+  const float avg = chain_add(avg_c, d, lane);
   const float thresh = avg * THRESH_FRACTION;   // gate_impl.cc:136
   const bool valid = lane < nvalid;             // the last step of a call may be partial
   const uint64_t below = wv::ballot(valid && amp < thresh);
@@ -500,15 +499,7 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
                             !((g.f_pulses > NUM_PULSES_CMD) && (T1_SAMPLES - g.f_n < 64)) &&
                             (g.run_closed >= DC_LEN);
   float dcr, dci;
-  if (a.knock & 1) {
-    dcr = g.dcr_c + B.tre; dci = g.dci_c + B.tim;
-  } else if ((a.knock & 16) && B.has && B.any_closed) {   // developer aid: the integer-scan form of the sums (same results)
-    float sr, si;
-    const bool okr = chain_add_scan(g.dcr_c, B.tre, lane, sr);
-    const bool oki = chain_add_scan(g.dci_c, B.tim, lane, si);
-    if (__builtin_expect(okr && oki, 1)) { dcr = sr; dci = si; }
-    else chain_add2(g.dcr_c, B.tre, g.dci_c, B.tim, lane, dcr, dci);
-  } else if (B.has && B.any_closed) {
+  if (B.has && B.any_closed) {
     chain_add2(g.dcr_c, B.tre, g.dci_c, B.tim, lane, dcr, dci);
   } else {
     // the back step lies entirely inside a window (or there is none): all its dc increments are
@@ -548,7 +539,7 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const
   //   (A) the whole step lies inside an open window that does not end in it;
   //   (B) gate closed, POS_EDGE, no sample below the threshold, no opening due, and the dc ring
   //       fast path applies (the previous 48 samples were closed too).
-  if (__builtin_expect(plain_open || plain_closed || (a.knock & 4), 1)) {
+  if (__builtin_expect(plain_open || plain_closed, 1)) {
     // both plain cases in one straight-line block (selects, no branch between them)
     const float s_tre = f_tre, s_tim = f_tim;
     g.f_n += 64;
@@ -906,8 +897,8 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
             while (k - wv::lds_load(&sh.cons_seq) >= GATE_SLOTS) wv::backoff();
             if (PROF) { t1 = wv::ticks(); p_wait += t1 - tw; }
             const float2 yv = gate_fir_step(buf[u], sh.rawtile, lane, u == 0 && grp == 0 && at_start);
-            gate_load_raw(buf[u], xs, hi_idx, rbase + (int64_t)(((a.knock & 64) ? (k & 7) : k) + GATE_RAW_DEPTH) * 64 * DECIM, lane, vec);
-            yw[64 * ((a.knock & 64) ? (k & 7) : k) + lane] = yv;
+            gate_load_raw(buf[u], xs, hi_idx, rbase + (int64_t)(k + GATE_RAW_DEPTH) * 64 * DECIM, lane, vec);
+            yw[64 * k + lane] = yv;
             sh.slots[k % GATE_SLOTS].yv[lane] = yv;
             wv::lds_store(&sh.fir_seq, k + 1, lane);   // after the slot's data (in-order LDS queue)
             if (PROF) p_fir += wv::ticks() - t1;
@@ -979,7 +970,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
       if (PROF) g_wait += wv::ticks() - tw;
       if (!stopped) {
         GateSlot &slot = sh.slots[k % GATE_SLOTS];
-        gate_produce(slot, slot.yv[lane], prev_yv, 64 * k, n, lane, sh.win, win_index, a.knock);
+        gate_produce(slot, slot.yv[lane], prev_yv, 64 * k, n, lane, sh.win, win_index);
         wv::lds_store(&sh.prod_seq, k + 1, lane);   // after the slot's data (in-order LDS queue)
       }
     }
@@ -999,7 +990,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
       }
       if (PROF) a_wait += wv::ticks() - tw;
       if (!stopped) {
-        gate_average(sh.slots[k % GATE_SLOTS], n - 64 * k, lane, avg_c, a.knock);
+        gate_average(sh.slots[k % GATE_SLOTS], n - 64 * k, lane, avg_c);
         wv::lds_store(&sh.avg_seq, k + 1, lane);
       }
     }
@@ -1032,12 +1023,6 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
     B.has = false; B.tre = 0.0f; B.tim = 0.0f; B.openmask = 0; B.yv = make_float2(0.0f, 0.0f);
     B.open_lane = B.open_lane2 = -1; B.open_type = B.open_type2 = 0; B.pos = 0; B.any_closed = false;
     wv::wave_sync();
-    if (a.knock & 32) {
-      for (int k = 0; k < nsteps; ++k) {
-        while (wv::lds_load(&sh.avg_seq) <= k) wv::backoff();
-        wv::lds_store(&sh.cons_seq, k + 1, lane);
-      }
-    } else
     for (int k = 0; k < nsteps && !g.stop; ++k) {
       // (waits until step k is produced and averaged)
       gate_consume<PROF>(a, g, B, &sh.slots[k % GATE_SLOTS], &sh.slots[(k + 1) % GATE_SLOTS], nx, true, &sh.avg_seq, k, 64 * k, n, n_total, row, lane, lds_dc,
@@ -1600,7 +1585,7 @@ struct DecodeListArgs {
 
 constexpr int EPC_PACK = 3;
 constexpr int EPC_GRP = N_TCAND;            // 20 lanes per window
-constexpr int EPC_M2_STRIDE = EPC_WIN + 6;  // 1376
+constexpr int EPC_M2_STRIDE = EPC_WIN + 17; // 1387 = 11 mod 32: the three windows of a pack gather from disjoint LDS banks (1376 = 0 mod 32 made every gather a 2-way conflict)
 constexpr int SYNC_KEEP = 72;               // samples 0..69 are touched by tag_sync
 
 template <int K0>

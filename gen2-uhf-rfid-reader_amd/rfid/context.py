@@ -235,6 +235,13 @@ class Context:
         self._chk(self._lib.rfid_batch_get_mf(self._h, int(stream), out.ctypes.data, cap, C.byref(n)))
         return out[: n.value].copy()
 
+    def batch_gated_output(self, stream: int, seq: int) -> np.ndarray:
+        """Gated, DC-removed samples of window `seq` of trace `stream` (the gate block's output; debug tap)."""
+        out = np.empty(1370, dtype=np.complex64)
+        n = C.c_int64(0)
+        self._chk(self._lib.rfid_batch_get_gated(self._h, int(stream), int(seq), out.ctypes.data, len(out), C.byref(n)))
+        return out[: n.value].copy()
+
     def synth_replicas_ptr(self, d_base: int, n_raw: int, d_out: int, out_stride: int, n_streams: int, sigma: float,
                            seed: int, first_replica: int = 0) -> None:
         """Asynchronous: d_out[s] = d_base + sigma * complex Gaussian noise (replica first_replica + s)."""

@@ -283,6 +283,10 @@ RFID_API int rfid_batch_device_ptrs(rfid_ctx *ctx, void **d_mf_out, int64_t *mf_
 /* copies the matched-filter output of trace `stream` to host (debug tap, the
  * file_sink_matched_filter of apps/reader.py:69) */
 RFID_API int rfid_batch_get_mf(rfid_ctx *ctx, int stream, rfid_cf32 *out, int64_t cap, int64_t *n);
+/* copies the gated, DC-removed samples of window `seq` of trace `stream` to host -- in[i] - dc_est over the window,
+ * exactly what the gate block writes to its output (lib/gate_impl.cc:176,187; debug tap = the file_sink_gate of
+ * apps/reader.py:70).  *n = window length (250 / 1370). */
+RFID_API int rfid_batch_get_gated(rfid_ctx *ctx, int stream, int seq, rfid_cf32 *out, int64_t cap, int64_t *n);
 /* the HIP stream the ctx launches on (hipStream_t as void*) */
 RFID_API void *rfid_ctx_stream(rfid_ctx *ctx);
 

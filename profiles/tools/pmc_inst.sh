@@ -3,7 +3,7 @@ R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 OUT=$R/gpurun_out/pmc_inst; rm -rf $OUT; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVE_CYCLES" "SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "FETCH_SIZE WRITE_SIZE"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)
-  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/$tag -o f -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline $BENCH_ARGS > $OUT/$tag.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/$tag -o f -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-stream-leg $BENCH_ARGS > $OUT/$tag.log 2>&1
 done
 python - <<PY
 import csv, collections, glob

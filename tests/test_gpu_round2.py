@@ -377,3 +377,25 @@ def test_cxx_offline_binary_whole_chain_mode(tmp_path, oracle_mod, synth_mod):
         assert out.returncode == 0, out.stderr
         assert out.stdout == want, extra
         print(out.stderr.strip())
+
+
+def test_batch_debug_taps(gpu_ctx, oracle_mod, synth_mod):
+    """Per-stage debug sinks of apps/reader.py:67-72 in batch mode: the matched-filter output of a trace and the gated,
+    DC-removed samples of any of its windows (what the gate block emits: in[i] - dc_est)."""
+    import torch
+    t = synth_mod.make_trace(n_rounds=3, seed=44, sigma=0.02).samples
+    L = len(t)
+    dev = torch.from_numpy(np.concatenate([t, np.zeros(L & 1, np.complex64)]).view(np.float32)).to("cuda:0")
+    gpu_ctx.batch_plan(1, L)
+    gpu_ctx.batch_process_ptr(dev.data_ptr(), (L + 1) & ~1, L, 0, want_scores=False)
+    gpu_ctx.batch_sync()
+    o = oracle_mod.run_trace(t)
+    y = oracle_mod.fir(t)
+    assert np.array_equal(gpu_ctx.batch_mf_output(0).view(np.uint32), y.view(np.uint32))
+    for seq in range(o.n_windows):
+        g = gpu_ctx.batch_gated_output(0, seq)
+        n = 1370 if seq & 1 else 250
+        want = (y[o.open_idx[seq]: o.open_idx[seq] + n] - np.complex64(o.dc[seq])).astype(np.complex64)
+        assert len(g) == n and np.array_equal(g.view(np.uint32), want.view(np.uint32)), seq
+    with pytest.raises(Exception):
+        gpu_ctx.batch_gated_output(0, o.n_windows)
