@@ -399,3 +399,76 @@ def test_batch_debug_taps(gpu_ctx, oracle_mod, synth_mod):
         assert len(g) == n and np.array_equal(g.view(np.uint32), want.view(np.uint32)), seq
     with pytest.raises(Exception):
         gpu_ctx.batch_gated_output(0, o.n_windows)
+
+
+def test_long_stream_front_end_ragged_batch_and_limits(oracle_mod, synth_mod):
+    """The long-stream front end on a small ragged batch (per-trace lengths, one trace too short to cut, one empty), with
+    FIXED_Q = 2 collisions and a max_num_queries limit that terminates two of the traces: windows, results, scores and
+    statistics equal the oracle's; the report says verified."""
+    import rfid
+    import torch
+    kw = dict(fixed_q=2, tag_ids=(0x11, 0x22, 0x33), sigma=0.01, t1_jitter_raw=5)
+    traces = [synth_mod.make_trace(n_rounds=r, seed=900 + r, **kw).samples for r in (9, 6, 1)]
+    L = max(map(len, traces))
+    raw = np.zeros((4, L), dtype=np.complex64)
+    lens = []
+    for i, t in enumerate(traces):
+        raw[i, : len(t)] = t
+        lens.append(len(t))
+    lens.append(0)
+    lens[1] -= 12345                                   # cut inside a slot: the last window is incomplete
+    ctx = rfid.Context(device=0, fixed_q=2, max_num_queries=20)
+    try:
+        ctx.batch_set_long_stream(2)
+        stride = (L + 1) & ~1
+        host = np.zeros((4, stride), dtype=np.complex64)
+        host[:, :L] = raw
+        dev = torch.from_numpy(host.view(np.float32)).to("cuda:0")
+        d_lens = torch.tensor(np.asarray(lens, dtype=np.int64)).to("cuda:0")
+        ctx.batch_plan(4, L)
+        ctx.batch_process_ptr(dev.data_ptr(), stride, L, d_lens.data_ptr(), want_scores=True)
+        ctx.batch_sync()
+        rep = ctx.batch_ls_report()
+        assert rep["verified"] == 1 and rep["units"] > 4, rep
+        w, r, s = ctx.batch_windows(want_scores=True)
+        st = ctx.batch_stats()
+        cfg = oracle_mod.config(fixed_q=2, max_num_queries=20)
+        full = oracle_mod.config(fixed_q=2, max_num_queries=1 << 30)
+        n_term = 0
+        for b, (wb, rb, sb) in enumerate(parity.split_by_stream(w, r, s, 4)):
+            o_all = oracle_mod.run_trace(raw[b, : lens[b]], full)        # every window the gate produces ...
+            parity.compare_trace(wb, rb, sb, None, o_all)
+            o = oracle_mod.run_trace(raw[b, : lens[b]], cfg)             # ... and the statistics up to the TERMINATED cut-off
+            for k in ("n_queries_sent", "cur_inventory_round", "cur_slot_number", "n_epc_correct", "n_unique_tags"):
+                assert st[b][k] == getattr(o.state, k), (b, k)
+            assert st[b]["status"] == o.state.status and st[b]["n_windows_used"] == o.n_windows
+            n_term += int(o.state.status)
+        assert n_term == 2 and st[3]["n_windows"] == 0
+    finally:
+        ctx.close()
+
+
+def test_streaming_terminates_like_the_blocks(oracle_mod, synth_mod):
+    """rfid_stream_work with the reference's default MAX_NUM_QUERIES-style limit: after TERMINATED the gate swallows the
+    rest of the stream (gate_impl.cc:101-109,125): no further windows are delivered, READER_STATE equals the oracle's."""
+    import rfid
+    t = synth_mod.make_trace(n_rounds=60, seed=5150, sigma=0.01).samples
+    cfg = oracle_mod.config(max_num_queries=20)
+    o = oracle_mod.run_trace(t, cfg)
+    assert o.state.status == 1
+    ctx = rfid.Context(device=0, max_num_queries=20)
+    try:
+        ctx.stream_begin(300_000)
+        n_win = 0
+        for pos in range(0, len(t), 300_000):
+            w, r = ctx.stream_work(t[pos:pos + 300_000])
+            n_win += len(w)
+        w, r = ctx.stream_work(flush=True)
+        n_win += len(w)
+        assert n_win == o.n_windows
+        assert ctx.stats() == o.stats() and ctx.print_results() == o.print_results()
+        ctx.stream_end()
+        with pytest.raises(rfid.capi.RfidError):
+            ctx.stream_work(t[:1000])                 # the stream is closed
+    finally:
+        ctx.close()
