@@ -881,29 +881,6 @@ int rfid_batch_mf(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64_t n_
   return RFID_OK;
 }
 
-// developer aid (RFID_GATE_PROF=1): s_memtime counters of trace 0's consumer / producer / averaging wave
-static int launch_gate_prof(rfid_ctx *c, GateArgs a, bool fused) {
-  long long *d_prof = nullptr;
-  HIPCHK(c, hipMalloc((void **)&d_prof, sizeof(long long) * 16 * (size_t)c->B));
-  HIPCHK(c, hipMemsetAsync(d_prof, 0, sizeof(long long) * 16 * (size_t)c->B, c->stream));
-  a.prof = d_prof;
-  const dim3 grid((unsigned)((c->B + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG));
-  if (fused) hipLaunchKernelGGL(front_end_fused_kernel_prof, grid, dim3(GATE_THREADS), 0, c->stream, a);
-  else hipLaunchKernelGGL(gate_scan_kernel_prof, grid, dim3(GATE_THREADS), 0, c->stream, a);
-  HIPCHK(c, hipGetLastError());
-  std::vector<long long> h((size_t)c->B * 16);
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(h.data(), d_prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
-  (void)hipFree(d_prof);
-  const char *names[16] = {"windows-open segments (general path)", "closed segments (general path)", "plain steps",
-                           "plain-step ticks", "general-step ticks", "consumer wait+fetch ticks", "consumer total ticks",
-                           "dc fast steps (general)", "dc slow steps (general)", "filter wait ticks", "filter total ticks",
-                           "averaging wait ticks", "filter busy ticks", "producer wait ticks", "consumer chain+finish ticks",
-                           "steps with dc chains"};
-  for (int i = 0; i < 16; ++i) fprintf(stderr, "[gate prof] %-38s %lld (stream 0)\n", names[i], h[(size_t)i]);
-  return RFID_OK;
-}
-
 int rfid_batch_gate(rfid_ctx *c) {
   if (!c) return RFID_ERR_INVALID;
   if (!c->B) return RFID_ERR_STATE;
@@ -917,15 +894,10 @@ int rfid_batch_gate(rfid_ctx *c) {
   a.pos0 = 0; a.chunk_len = a.n_dec;
   a.state = c->d_gstate; a.n_streams = c->B; a.wtab = c->d_wtab; a.wmax = c->wmax; a.wcount = c->d_wcount;
   a.flat = c->d_flat; a.flat_count = c->d_flat_count; a.flat_cap = c->flat_cap; a.mode = 0;
-  a.gated = nullptr; a.gated_cap = 0; a.io = nullptr; a.prof = nullptr;
+  a.gated = nullptr; a.gated_cap = 0; a.io = nullptr;
   if (!c->ev_valid[1]) { HIPCHK(c, hipEventRecord(c->ev[1], c->stream)); c->ev_valid[1] = true; }
-  if (getenv("RFID_GATE_PROF")) {  // developer aid: wait / phase counters of the gate's waves
-    int rc = launch_gate_prof(c, a, false);
-    if (rc) return rc;
-  } else {
-    hipLaunchKernelGGL(gate_scan_kernel, dim3((unsigned)((c->B + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG)), dim3(GATE_THREADS), 0, c->stream, a);
-    HIPCHK(c, hipGetLastError());
-  }
+  hipLaunchKernelGGL(gate_scan_kernel, dim3((unsigned)((c->B + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG)), dim3(GATE_THREADS), 0, c->stream, a);
+  HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   c->ev_valid[2] = true;
   return RFID_OK;
@@ -1025,14 +997,9 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
     g.flat = c->d_flat; g.flat_count = c->d_flat_count; g.flat_cap = c->flat_cap; g.mode = 0;
     g.raw = (const float2 *)d_raw; g.raw_stride = raw_stride; g.n_raw = n_raw;
     g.raw_vec_ok = ((raw_stride & 1) == 0 && (((uintptr_t)d_raw) & 15) == 0) ? 1 : 0;
-    if (getenv("RFID_GATE_PROF")) {
-      int rc = launch_gate_prof(c, g, true);
-      if (rc) return rc;
-    } else {
-      hipLaunchKernelGGL(front_end_fused_kernel, dim3((unsigned)((c->B + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG)),
-                         dim3(GATE_THREADS), 0, c->stream, g);
-      HIPCHK(c, hipGetLastError());
-    }
+    hipLaunchKernelGGL(front_end_fused_kernel, dim3((unsigned)((c->B + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG)),
+                       dim3(GATE_THREADS), 0, c->stream, g);
+    HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     c->ev_valid[0] = c->ev_valid[1] = c->ev_valid[2] = true;
     c->fused_last = 1;
@@ -1066,7 +1033,7 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
   g.y = c->d_y; g.y_stride = c->y_stride; g.n_dec = n_out; g.lens = c->d_lens;
   g.state = c->d_gstate; g.n_streams = c->B; g.wtab = c->d_wtab; g.wmax = c->wmax; g.wcount = c->d_wcount;
   g.flat = c->d_flat; g.flat_count = c->d_flat_count; g.flat_cap = c->flat_cap; g.mode = 0;
-  g.gated = nullptr; g.gated_cap = 0; g.io = nullptr; g.prof = nullptr;
+  g.gated = nullptr; g.gated_cap = 0; g.io = nullptr;
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   HIPCHK(c, hipEventRecord(c->ev_mf[0], c->stream));
   int used = 0;
@@ -1403,7 +1370,7 @@ int rfid_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, i
   a.pos0 = 0; a.chunk_len = n_in;
   a.state = c->d_gate1; a.n_streams = 1; a.wtab = nullptr; a.wmax = 0; a.wcount = nullptr;
   a.flat = nullptr; a.flat_count = nullptr; a.flat_cap = 0; a.mode = 1;
-  a.gated = (float2 *)c->s_out.p; a.gated_cap = n_in; a.io = c->d_io; a.prof = nullptr;
+  a.gated = (float2 *)c->s_out.p; a.gated_cap = n_in; a.io = c->d_io;
   hipLaunchKernelGGL(gate_scan_kernel, dim3(1), dim3(GATE_THREADS), 0, c->stream, a);
   HIPCHK(c, hipGetLastError());
   int io[2] = {0, 0};

@@ -12,6 +12,8 @@
 #include <stdint.h>
 
 #define RFID_KERNEL(threads) __global__ __launch_bounds__(threads)
+// ... with at least `waves` waves per SIMD resident (caps the VGPR budget: 512 / waves)
+#define RFID_KERNEL_OCC(threads, waves) __global__ __launch_bounds__(threads, waves)
 #define RFID_DEVICE __device__ __forceinline__
 #define RFID_SHARED __shared__
 
@@ -76,10 +78,23 @@ RFID_DEVICE uint32_t f2u(float x) { return __float_as_uint(x); }
 // independent ds_reads in flight together instead of the compiler's just-in-time interleaving
 RFID_DEVICE void compiler_fence() { asm volatile("" ::: "memory"); }
 RFID_DEVICE void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-// glibc-2.35 hypotf: (float)sqrt((double)x*x + (double)y*y), double sqrt correctly rounded
+// glibc-2.35 hypotf: (float)sqrt((double)x*x + (double)y*y), double sqrt correctly rounded.  Both products are
+// exact in binary64, so the fma rounds once exactly like the sum.  The square root is the device library's
+// correctly rounded sequence (v_rsq_f64 + two coupled Newton steps + two residual corrections) without its range
+// scaling: the sum of two squared binary32 numbers is 0, inf, nan or lies in [2^-298, 2^129), where none is needed.
 RFID_DEVICE float hypot_f(float x, float y) {
-  double s = (double)x * (double)x + (double)y * (double)y;
-  return (float)__dsqrt_rn(s);
+  const double xd = (double)x, yd = (double)y;
+  const double s = __builtin_fma(xd, xd, yd * yd);
+  const double y0 = __builtin_amdgcn_rsq(s);
+  double g = s * y0, h = y0 * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, s);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, s);
+  g = __builtin_fma(d, h, g);
+  return (float)(__builtin_amdgcn_class(s, 0x260) ? s : g);   // +-0 and +inf are their own square roots
 }
 // fast transcendental functions for the synthetic-replica generator only (never on the receive path)
 RFID_DEVICE float log_fast(float x) { return __logf(x); }
@@ -135,6 +150,29 @@ RFID_DEVICE void lds_peek_masks(const uint64_t *p, uint64_t &a, uint64_t &b) {
   const rfid_u32x4 v = *q;
   a = ((uint64_t)v.y << 32) | v.x;
   b = ((uint64_t)v.w << 32) | v.z;
+}
+// step descriptor between two waves: 32 bytes at a 16-byte aligned LDS address, written by lane 0 with two 16-byte
+// stores (after the wave's earlier LDS writes), read back with two 16-byte loads
+RFID_DEVICE void lds_store_desc(int *p, int flags, int nvalid, uint64_t m0, uint64_t m1, int info, int lane) {
+  volatile RFID_LDS_AS rfid_u32x4 *q = (volatile RFID_LDS_AS rfid_u32x4 *)p;
+  asm volatile("" ::: "memory");
+  if (lane == 0) {
+    rfid_u32x4 a, b;
+    a.x = (uint32_t)flags; a.y = (uint32_t)nvalid; a.z = (uint32_t)m0; a.w = (uint32_t)(m0 >> 32);
+    b.x = (uint32_t)m1; b.y = (uint32_t)(m1 >> 32); b.z = (uint32_t)info; b.w = 0u;
+    q[0] = a;
+    q[1] = b;
+  }
+  asm volatile("" ::: "memory");
+}
+RFID_DEVICE void lds_load_desc(const int *p, int &flags, int &nvalid, uint64_t &m0, uint64_t &m1, int &info) {
+  const volatile RFID_LDS_AS rfid_u32x4 *q = (const volatile RFID_LDS_AS rfid_u32x4 *)p;
+  const rfid_u32x4 a = q[0], b = q[1];
+  flags = __builtin_amdgcn_readfirstlane((int)a.x);
+  nvalid = __builtin_amdgcn_readfirstlane((int)a.y);
+  m0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)a.w) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)a.z);
+  m1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)b.y) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)b.x);
+  info = __builtin_amdgcn_readfirstlane((int)b.z);
 }
 RFID_DEVICE uint64_t uniform64(uint64_t v) {
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);

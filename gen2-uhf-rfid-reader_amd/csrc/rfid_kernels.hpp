@@ -118,10 +118,11 @@ RFID_KERNEL(MF_THREADS) void mf_boxcar25_decim5_kernel(MfArgs a) {
 //    pos+L), four pipelined wavefronts per trace.  The reference's per-sample recurrences are
 //    kept bit-exact:
 //      * avg_ampl += (|x| - ring[w]) / 100     -> the increments are computed lane-parallel
-//        (producer wave), then added IN ORDER by a 63-step DPP wave-shift chain (lane L ends up
-//        holding the value after sample L) in the averaging wave;
-//      * dc_est  += (x - dcring[d]) / 48       -> same kind of chain in the consumer wave, only
-//        over "closed" samples;
+//        (producer wave), then added IN ORDER in the consumer wave (lane L ends up holding the
+//        value after sample L): as one integer prefix sum where that is provably the same
+//        binary32 arithmetic, else by a 63-step DPP wave-shift chain (chain_add_auto);
+//      * dc_est  += (x - dcring[d]) / 48       -> two such chains in the back wave, only over
+//        "closed" samples;
 //      * the edge / pulse-count / window state machine runs on the scalar unit of the consumer
 //        wave over 64-bit vote masks, loop-free.
 //    The filter wave feeds the samples: matched-filter output y (stage kernel) or the raw 2 Msps
@@ -175,7 +176,6 @@ struct GateArgs {
   float2 *gated;        // streaming: gated, DC-removed samples
   int gated_cap;
   int *io;              // streaming: io[0] = consumed, io[1] = written
-  long long *prof;      // optional phase counters (gate_scan_kernel_prof only)
   // fused front end (front_end_fused_kernel): the filter wave computes the matched filter
   // itself from the raw 2 Msps samples and writes y (for the decoder) instead of reading it
   const float2 *raw;    // [n_streams][raw_stride]
@@ -318,43 +318,41 @@ RFID_DEVICE void chain_add2(float cb, float xb, float cc, float xc, int lane, fl
   }
 }
 
-// wave-uniform registers of one trace's gate (consumer wave)
+// wave-uniform registers of one trace's state machine (consumer wave)
 struct GateRegs {
-  float avg_c, dcr_c, dci_c;
+  float avg_c;
   int f_n, f_state, f_pulses, f_open, f_ung, f_type;
-  int dc_index, win_seq;
-  int run_closed;   // closed samples seen back-to-back up to the current position (this call)
-  int ring_stale;   // lds_dc not maintained during fast-path steps; rebuilt on demand
-  int n_complete, written, consumed;
-  int pos0, strm;   // first sample of this launch's chunk (or unit) within the trace; the trace index
+  int consumed;
   bool stop;
 };
 
-// One step (64 decimated samples) on its way through the waves of a trace (filter -> producer ->
-// averaging -> consumer).
-struct GateSlot {
-  float amp[64];   // |x|                                   (gate_impl.cc:130)    producer -> averaging wave
-  float d[64];     // (|x| - win_samples[win_index]) / 100   (gate_impl.cc:131)    producer -> averaging wave
-  float avg[64];   // avg_ampl after each sample: in-order sum of (|x| - win_samples[win_index]) / 100
-                   //   (gate_impl.cc:130-134), run by the averaging wave -- it does not depend on the state machine
-  uint64_t below;  // lanes with |x| < 0.75 avg_ampl  (gate_impl.cc:136,147)
-  uint64_t above;  // lanes with |x| > 0.75 avg_ampl  (gate_impl.cc:155)
-  float avg_in;    // avg_ampl before the first sample of the step
-  int pad_[3];
-  float2 yv[64];   // the samples themselves
-  float tre[64];   // speculative (x - x[i-48]) / 48: exact whenever the previous 48 samples
-  float tim[64];   //   were all "closed" samples, the common case (gate_impl.cc:141)
+// wave-uniform registers of the back wave: dc_est and the window records
+struct GateBackRegs {
+  float dcr_c, dci_c;
+  int dc_index;
+  int run_closed;   // closed samples seen back-to-back up to the current position (this call)
+  int ring_stale;   // the dc ring in LDS is not maintained while whole steps are closed; rebuilt on demand from prev_yv
+  float2 prev_yv;   // the samples of the last step with closed samples
+  int win_seq, n_complete, written;
+  int pos0, strm;   // first sample of this launch's chunk (or unit) within the trace; the trace index
 };
 
-// "back" half of a step, finished one iteration later: dc increments of the closed samples
-struct GateBack {
-  float2 yv;
-  float tre, tim;
-  uint64_t openmask;
-  int open_lane, open_type, open_lane2, open_type2;
-  int pos;
-  bool has;
-  bool any_closed;   // some sample of the step updates dc_est
+// One step (64 decimated samples) on its way through the waves of a trace:
+//   filter (yv) -> producer (amp, d, tre, tim) -> consumer (avg_ampl, threshold votes, state machine; b_*) ->
+//   back (dc ring, dc_est, window records; frees the slot)
+struct GateSlot {
+  float amp[64];   // |x|                                   (gate_impl.cc:130)    producer -> consumer
+  float d[64];     // (|x| - win_samples[win_index]) / 100   (gate_impl.cc:131)    producer -> consumer
+  // consumer -> back (two 16-byte records, written by lane 0)
+  alignas(16) int b_flags;                  //   bit 0 some sample of the step is "closed" (updates dc_est), bit 1 the scan stops after this step
+  int b_nvalid;                             //   samples of the step that were consumed
+  uint64_t b_closedmask;                    //   the closed samples (gate_impl.cc:139-143)
+  uint64_t b_openmask;                      //   lanes inside an open window (streaming: their gated samples are emitted)
+  int b_open;                               //   gate openings of the step: lane | type << 8 | (lane2 | type2 << 8) << 16, 0xff = none
+  int b_pad_;
+  float2 yv[64];   // the samples themselves
+  float tre[64];   // dc_est increments of the step's samples: the producer's speculative (x - x[i-48]) / 48 -- exact
+  float tim[64];   //   whenever the previous 48 samples were all "closed" (gate_impl.cc:141) -- else the back wave recomputes them
 };
 
 // ---- producer wave: everything that is lane-parallel ---------------------------------------
@@ -399,26 +397,9 @@ RFID_DEVICE void gate_produce(GateSlot &slot, float2 yv_in, float2 &prev_yv, int
   prev_yv = yv;
 }
 
-// ---- averaging wave: avg_ampl and the threshold test -------------------------------------------
-// avg_ampl is an in-order sum over all samples that does not depend on the state machine
-// (gate_impl.cc:130-134), so it runs one or more steps ahead of the consumer in a wave of its own.
-RFID_DEVICE void gate_average(GateSlot &slot, int nvalid, int lane, float &avg_c) {
-  const float amp = slot.amp[lane], d = slot.d[lane];
-  // (the integer-scan form chain_add_auto was measured here: no gain -- this pipeline is bound by the filter wave's
-  //  staging and the hand-offs, not by the chain's latency; profiles/r02/knockout_front_end.txt)
-  const float avg = chain_add(avg_c, d, lane);
-  const float thresh = avg * THRESH_FRACTION;   // gate_impl.cc:136
-  const bool valid = lane < nvalid;             // the last step of a call may be partial
-  const uint64_t below = wv::ballot(valid && amp < thresh);
-  const uint64_t above = wv::ballot(valid && amp > thresh);
-  slot.avg[lane] = avg;
-  if (lane == 0) { slot.below = below; slot.above = above; slot.avg_in = avg_c; }
-  avg_c = wv::readlane(avg, 63);   // the lanes past the end of the call add +0
-}
-
 // a gate opening at lane `ol` of the step that starts at `pos`: dc_est is the in-order sum at
 // that lane (the opening sample itself is still a "closed" sample, gate_impl.cc:141-176)
-RFID_DEVICE void gate_record_window(const GateArgs &a, GateRegs &g, int ol, int wtype, int pos, int n, int s,
+RFID_DEVICE void gate_record_window(const GateArgs &a, GateBackRegs &g, int ol, int wtype, int pos, int n, int s,
                                     int lane, float dcr, float dci) {
   const float odr = wv::readlane(dcr, ol), odi = wv::readlane(dci, ol);
   const int wlen = wtype ? EPC_WIN : RN16_WIN;
@@ -439,327 +420,298 @@ RFID_DEVICE void gate_record_window(const GateArgs &a, GateRegs &g, int ol, int 
   g.win_seq++;
 }
 
-// ---- consumer wave: the in-order sums and the scalar state machine ---------------------------
-// One pipeline iteration: the in-order sum of avg_ampl for step k runs interleaved with the
-// two in-order sums of dc_est for step k-1; then step k-1 is finished (window records, gated
-// output) and step k goes through the threshold test and the state machine.
+// ---- consumer wave: avg_ampl, the threshold votes, the scalar state machine -----------------------
+// Step k goes through the edge / pulse / window state machine (on the scalar unit, over the vote masks); what the
+// back wave needs -- which samples are "closed" (update dc_est), which lie inside a window, the gate openings --
+// is left in the slot.
 
 // the next step's slot, fetched one step early by the consumer
 struct GateNext {
   int step;           // the step these values belong to (-1: none)
   int sq;             // the sequence word as read just before them: valid iff > step
-  uint64_t below, above;
-  float2 yv;
-  float tre, tim;
+  float amp, d;
 };
 
-template <bool PROF>
-RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateBack &B, const GateSlot *slot, const GateSlot *slot_next,
-                              GateNext &nx, bool has_front, const int *seq, int k, int pos, int n, int n_total, int s, int lane, float2 *lds_dc,
-                              float2 *lds_tmp, long long *tk) {
-  float f_tre = 0.0f, f_tim = 0.0f;
-  float2 f_yv = make_float2(0.0f, 0.0f);
-  uint64_t below = 0, above = 0;
-  if (has_front) {
+RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateSlot *slot, const GateSlot *slot_next, GateNext &nx,
+                              const int *seq, int k, int pos, int n, int lane) {
+  float f_amp = 0.0f, f_d = 0.0f;
+  {
     // Wait for step k and fetch it in ONE LDS round trip: the sequence word and the slot are read
-    // back to back (a wave's LDS reads execute in order, and the averaging wave wrote the slot
+    // back to back (a wave's LDS reads execute in order, and the producer wrote the slot
     // before it advanced the sequence word), and only then is the sequence word looked at.
     // Usually not even that: the previous step already fetched this slot (see below).
-    long long tb = 0;
-    if (PROF) tb = wv::ticks();
     if (nx.step == k && wv::uniform(nx.sq) > k) {
-      below = nx.below; above = nx.above; f_yv = nx.yv; f_tre = nx.tre; f_tim = nx.tim;
+      f_amp = nx.amp; f_d = nx.d;
     } else {
       for (;;) {
         const int sq = wv::lds_peek(seq);
-        wv::lds_peek_masks(&slot->below, below, above);
-        f_yv = slot->yv[lane];
-        f_tre = slot->tre[lane]; f_tim = slot->tim[lane];
+        f_amp = slot->amp[lane]; f_d = slot->d[lane];
         if (wv::uniform(sq) > k) break;
         wv::backoff();
       }
     }
-    below = wv::uniform64(below); above = wv::uniform64(above);
-    // fetch step k+1 now: the averaging wave is normally more than one step ahead, and the reads
+    // fetch step k+1 now: the producer is normally more than one step ahead, and the reads
     // complete while this step is worked on (the sequence word tells the next call whether they count)
     nx.sq = wv::lds_peek(seq);
-    wv::lds_peek_masks(&slot_next->below, nx.below, nx.above);
-    nx.yv = slot_next->yv[lane];
-    nx.tre = slot_next->tre[lane]; nx.tim = slot_next->tim[lane];
+    nx.amp = slot_next->amp[lane]; nx.d = slot_next->d[lane];
     nx.step = k + 1;
-    if (PROF) tk[5] += wv::ticks() - tb;
   }
-  long long tp0 = 0, tp1 = 0;
-  if (PROF) tp0 = wv::ticks();
-  // the two plain kinds of step (see below) are recognised before the dc_est chains start, so that
-  // their scalar bookkeeping can be scheduled into the chains' latency
-  const int nvalid0 = (n - pos < 64) ? (n - pos) : 64;
-  const bool plain_open = has_front && (nvalid0 == 64) && g.f_open && (g.f_ung - g.f_n > 64);
-  const bool plain_closed = has_front && (nvalid0 == 64) && !g.f_open && (g.f_state == 1) && (below == 0) &&
-                            !((g.f_pulses > NUM_PULSES_CMD) && (T1_SAMPLES - g.f_n < 64)) &&
-                            (g.run_closed >= DC_LEN);
-  float dcr, dci;
-  if (B.has && B.any_closed) {
-    chain_add2(g.dcr_c, B.tre, g.dci_c, B.tim, lane, dcr, dci);
-  } else {
-    // the back step lies entirely inside a window (or there is none): all its dc increments are
-    // zero, dc_est does not move
-    dcr = g.dcr_c; dci = g.dci_c;
-  }
-  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-
-  // ---- finish the back step ----------------------------------------------------------------
-  if (B.has) {
-    g.dcr_c = wv::readlane(dcr, 63);
-    g.dci_c = wv::readlane(dci, 63);
-    if (__builtin_expect(B.open_lane >= 0, 0)) {   // rare: a window opened in the back step
-      gate_record_window(a, g, B.open_lane, B.open_type, B.pos, n_total, s, lane, dcr, dci);
-      if (B.open_lane2 >= 0) gate_record_window(a, g, B.open_lane2, B.open_type2, B.pos, n_total, s, lane, dcr, dci);
-    }
-    if (__builtin_expect(a.mode == 1 && B.openmask != 0, 0)) {  // streaming: emit gated samples in[i] - dc_est (gate_impl.cc:176,187)
-      const bool isopen = ((B.openmask >> lane) & 1ull) != 0;
-      const int orank = wv::popc64(B.openmask & lt);
-      if (isopen && g.written + orank < a.gated_cap)
-        a.gated[g.written + orank] = make_float2(B.yv.x - dcr, B.yv.y - dci);
-      g.written += wv::popc64(B.openmask);
-    }
-  }
-  const float2 prev_yv = B.yv;   // samples of step k-1 (for the dc ring rebuild)
-  if (PROF) { wv::keep(g.dcr_c); tp1 = wv::ticks(); tk[9] += tp1 - tp0; if (B.has && B.any_closed) tk[10]++; }
-  B.has = false;
-
-  // ---- carry the front step through threshold test and state machine --------------------------
-  if (has_front) {
+  // avg_ampl after every sample (gate_impl.cc:130-134): the in-order sum in its integer-scan form where that is
+  // provably exact, the 63-step chain otherwise; then the 0.75 avg threshold test (:136,147,155) as two votes
   int nvalid = (n - pos < 64) ? (n - pos) : 64;
-  const int nvalid_in = nvalid;
-  // (the averaging wave's threshold masks already exclude the lanes past the end of the call)
+  const float avg_in = g.avg_c;
+  const float avg = chain_add_auto(g.avg_c, f_d, lane);
+  g.avg_c = wv::readlane(avg, 63);   // the lanes past the end of the call add +0
+  const float thresh = avg * THRESH_FRACTION;
+  const uint64_t below = wv::ballot(lane < nvalid && f_amp < thresh);
+  const uint64_t above = wv::ballot(lane < nvalid && f_amp > thresh);
+  const bool plain_open = (nvalid == 64) && g.f_open && (g.f_ung - g.f_n > 64);
+  const bool plain_closed = (nvalid == 64) && !g.f_open && (g.f_state == 1) && (below == 0) &&
+                            !((g.f_pulses > NUM_PULSES_CMD) && (T1_SAMPLES - g.f_n < 64));
+  // what the back wave gets for this step
+  uint64_t closedmask = 0, openmask = 0;
+  int open_lane = 0xff, open_type = 0;   // (at most one opening per step: a window is longer than a step)
 
   // The two by far most frequent kinds of step are decided with a handful of scalar
   // instructions (the consumer wave is issue bound: every instruction costs ~4.5 cycles):
   //   (A) the whole step lies inside an open window that does not end in it;
-  //   (B) gate closed, POS_EDGE, no sample below the threshold, no opening due, and the dc ring
-  //       fast path applies (the previous 48 samples were closed too).
+  //   (B) gate closed, POS_EDGE, no sample below the threshold, no opening due.
   if (__builtin_expect(plain_open || plain_closed, 1)) {
-    // both plain cases in one straight-line block (selects, no branch between them)
-    const float s_tre = f_tre, s_tim = f_tim;
     g.f_n += 64;
-    int di = g.dc_index + (64 - DC_LEN);   // (dc_index + 64) mod 48
-    if (di >= DC_LEN) di -= DC_LEN;
-    g.dc_index = plain_closed ? di : g.dc_index;
-    g.ring_stale = plain_closed ? 1 : g.ring_stale;
-    int rc = g.run_closed + 64;
-    if (rc > (1 << 28)) rc = 1 << 28;
-    g.run_closed = plain_closed ? rc : 0;
-    B.yv = f_yv;
-    B.tre = plain_closed ? s_tre : 0.0f;
-    B.tim = plain_closed ? s_tim : 0.0f;
-    B.openmask = plain_closed ? 0ull : ~0ull;
-    B.open_lane = -1; B.open_lane2 = -1; B.pos = pos; B.has = true; B.any_closed = plain_closed;
-    if (PROF) { tk[2]++; tk[3] += wv::ticks() - tp1; }
+    closedmask = plain_closed ? ~0ull : 0ull;
+    openmask = plain_closed ? 0ull : ~0ull;
   } else {
-  // edge / pulse / window state machine on the scalar unit, event driven (gate_impl.cc:145-195)
-  uint64_t closedmask = 0, openmask = 0;
-  int open_lane = -1, open_lane2 = -1, open_type = 0, open_type2 = 0;
-  int f_n = g.f_n, f_state = g.f_state, f_pulses = g.f_pulses, f_open = g.f_open;
-  int f_ung = g.f_ung, f_type = g.f_type;
-  int p = 0;
-  // (1) a window is open at the start of the step (gate_impl.cc:182-195)
-  if (f_open) {
-    int take = f_ung - f_n;
-    if (take > nvalid) take = nvalid;
-    if (take < 0) take = 0;
-    openmask = lane_range(0, take);
-    f_n += take;
-    p = take;
-    if (f_n >= f_ung) {  // gate_impl.cc:189-194
-      f_open = 0;
-      if (a.mode == 0) {  // decoder + reader ran; gate re-armed at the next sample (:112-123)
-        f_n = 0;
-        f_type ^= 1;
-        f_ung = f_type ? EPC_WIN : RN16_WIN;
-      } else {
-        g.stop = true;
-        g.consumed = pos + p;
-        nvalid = p;
-      }
-    }
-    if (PROF) tk[0]++;
-  }
-  // (2) closed samples [p, nvalid)
-  if (p < nvalid) {
-    const uint64_t rem = lane_range(p, nvalid);
-    // (2a) end of a reader command: the gate opens at the first sample with n_samples > T1 while
-    //      POS_EDGE and num_pulses > 5 (gate_impl.cc:164-180) -- possible only before the first
-    //      falling edge of the step (any edge restarts the 97-sample count)
-    if (f_state == 1 && f_pulses > NUM_PULSES_CMD) {
-      const int e = wv::ffs64(below & rem);
-      int need = T1_SAMPLES - f_n;
-      if (need < 0) need = 0;
-      const int popen = p + need;
-      if (popen < e && popen < nvalid) {
-        closedmask = lane_range(p, popen + 1);
-        openmask |= lane_range(popen, nvalid);     // the opening sample and everything after it
-        open_lane = popen; open_type = f_type;
-        f_open = 1;
-        f_pulses = 0;
-        f_n = nvalid - popen;                       // 1 for the opening sample + the rest of the step
-        p = nvalid;
-      }
-    }
-    // (2b) edge / pulse bookkeeping of a closed segment without opening, loop-free
-    //      (gate_impl.cc:145-162).  The POS/NEG state after each sample is the type of the last
-    //      threshold crossing: a carry chain with generate = above, kill = below.
-    if (p < nvalid) {
-      const int len = nvalid - p;
-      const uint64_t m = lane_range(0, len);
-      const uint64_t av = (above >> p) & m, bv = (below >> p) & m;
-      const uint64_t pr = ~(av | bv) & m;                       // propagate: no crossing
-      const uint64_t X = av | pr, Y = av;
-      const uint64_t sum = X + Y + (uint64_t)(f_state & 1);
-      const uint64_t s_before = (X ^ Y ^ sum) & m;              // carry INTO bit i = state before sample i
-      const uint64_t F = bv & s_before;                         // falling edges (POS -> NEG)
-      const uint64_t R = av & ~s_before;                        // rising edges  (NEG -> POS)
-      const uint64_t marks = av | bv;
-      if (marks) f_state = (int)((av >> (63 - __builtin_clzll(marks))) & 1ull);
-      const uint64_t E = F | R;
-      if (E == 0) {
-        f_n += len;
-      } else {
-        if (R) {
-          // a rising edge counts as a pulse if the low phase before it lasted more than PW/2 = 2
-          // samples (n_samples > n_samples_PW/2), else the pulse count restarts
-          uint64_t shortm = R & ((F << 1) | (F << 2));
-          const int r1 = __builtin_ctzll(R);
-          if ((F & lane_range(0, r1)) == 0 && !(f_n + r1 + 1 > PW_HALF)) shortm |= 1ull << r1;  // low phase began earlier
-          if (shortm == 0) {
-            f_pulses += wv::popc64(R);
-          } else {
-            const int hb = 63 - __builtin_clzll(shortm);
-            f_pulses = wv::popc64(R & ~lane_range(0, hb + 1));
-          }
+    // edge / pulse / window state machine on the scalar unit, event driven (gate_impl.cc:145-195)
+    int f_n = g.f_n, f_state = g.f_state, f_pulses = g.f_pulses, f_open = g.f_open;
+    int f_ung = g.f_ung, f_type = g.f_type;
+    int p = 0;
+    // (1) a window is open at the start of the step (gate_impl.cc:182-195)
+    if (f_open) {
+      int take = f_ung - f_n;
+      if (take > nvalid) take = nvalid;
+      if (take < 0) take = 0;
+      openmask = lane_range(0, take);
+      f_n += take;
+      p = take;
+      if (f_n >= f_ung) {  // gate_impl.cc:189-194
+        f_open = 0;
+        if (a.mode == 0) {  // decoder + reader ran; gate re-armed at the next sample (:112-123)
+          f_n = 0;
+          f_type ^= 1;
+          f_ung = f_type ? EPC_WIN : RN16_WIN;
+        } else {
+          g.stop = true;
+          g.consumed = pos + p;
+          nvalid = p;
         }
-        f_n = len - 1 - (63 - __builtin_clzll(E));              // samples since the last edge
       }
-      closedmask |= rem;
-      if (PROF) tk[1]++;
     }
+    // (2) closed samples [p, nvalid)
+    if (p < nvalid) {
+      const uint64_t rem = lane_range(p, nvalid);
+      // (2a) end of a reader command: the gate opens at the first sample with n_samples > T1 while
+      //      POS_EDGE and num_pulses > 5 (gate_impl.cc:164-180) -- possible only before the first
+      //      falling edge of the step (any edge restarts the 97-sample count)
+      if (f_state == 1 && f_pulses > NUM_PULSES_CMD) {
+        const int e = wv::ffs64(below & rem);
+        int need = T1_SAMPLES - f_n;
+        if (need < 0) need = 0;
+        const int popen = p + need;
+        if (popen < e && popen < nvalid) {
+          closedmask = lane_range(p, popen + 1);
+          openmask |= lane_range(popen, nvalid);     // the opening sample and everything after it
+          open_lane = popen; open_type = f_type;
+          f_open = 1;
+          f_pulses = 0;
+          f_n = nvalid - popen;                       // 1 for the opening sample + the rest of the step
+          p = nvalid;
+        }
+      }
+      // (2b) edge / pulse bookkeeping of a closed segment without opening, loop-free
+      //      (gate_impl.cc:145-162).  The POS/NEG state after each sample is the type of the last
+      //      threshold crossing: a carry chain with generate = above, kill = below.
+      if (p < nvalid) {
+        const int len = nvalid - p;
+        const uint64_t m = lane_range(0, len);
+        const uint64_t av = (above >> p) & m, bv = (below >> p) & m;
+        const uint64_t pr = ~(av | bv) & m;                       // propagate: no crossing
+        const uint64_t X = av | pr, Y = av;
+        const uint64_t sum = X + Y + (uint64_t)(f_state & 1);
+        const uint64_t s_before = (X ^ Y ^ sum) & m;              // carry INTO bit i = state before sample i
+        const uint64_t F = bv & s_before;                         // falling edges (POS -> NEG)
+        const uint64_t R = av & ~s_before;                        // rising edges  (NEG -> POS)
+        const uint64_t marks = av | bv;
+        if (marks) f_state = (int)((av >> (63 - __builtin_clzll(marks))) & 1ull);
+        const uint64_t E = F | R;
+        if (E == 0) {
+          f_n += len;
+        } else {
+          if (R) {
+            // a rising edge counts as a pulse if the low phase before it lasted more than PW/2 = 2
+            // samples (n_samples > n_samples_PW/2), else the pulse count restarts
+            uint64_t shortm = R & ((F << 1) | (F << 2));
+            const int r1 = __builtin_ctzll(R);
+            if ((F & lane_range(0, r1)) == 0 && !(f_n + r1 + 1 > PW_HALF)) shortm |= 1ull << r1;  // low phase began earlier
+            if (shortm == 0) {
+              f_pulses += wv::popc64(R);
+            } else {
+              const int hb = 63 - __builtin_clzll(shortm);
+              f_pulses = wv::popc64(R & ~lane_range(0, hb + 1));
+            }
+          }
+          f_n = len - 1 - (63 - __builtin_clzll(E));              // samples since the last edge
+        }
+        closedmask |= rem;
+      }
+    }
+    g.f_n = f_n; g.f_state = f_state; g.f_pulses = f_pulses; g.f_open = f_open;
+    g.f_ung = f_ung; g.f_type = f_type;
+    // streaming mode stopped inside the step: avg_ampl carries only over the samples actually consumed
+    if (g.stop) g.avg_c = (nvalid > 0) ? wv::readlane(avg, nvalid - 1) : avg_in;
   }
-  g.f_n = f_n; g.f_state = f_state; g.f_pulses = f_pulses; g.f_open = f_open;
-  g.f_ung = f_ung; g.f_type = f_type;
-  // streaming mode stopped inside the step: avg_ampl carries only over the samples actually consumed
-  if (g.stop) g.avg_c = (nvalid > 0) ? wv::lds_load_f(&slot->avg[nvalid - 1]) : wv::lds_load_f(&slot->avg_in);
+  // hand the step to the back wave (lane 0 writes after this wave's earlier LDS writes: in-order queue)
+  wv::lds_store_desc(&slot->b_flags, ((closedmask != 0) ? 1 : 0) | (g.stop ? 2 : 0), nvalid, closedmask, openmask,
+                     open_lane | (open_type << 8), lane);
+}
 
-  // ---- dc increments of the closed samples (gate_impl.cc:141-143) -> next back step ------------
-  const int cnt = wv::popc64(closedmask);
-  if (cnt == 0) {
-    // whole step inside a window: dc_est, ring and index untouched
-    B.tre = 0.0f; B.tim = 0.0f;
-    g.run_closed = 0;
-  } else if (cnt == 64 && openmask == 0 && nvalid_in == 64 && g.run_closed >= DC_LEN) {
-    // fast path: the 48 samples before every lane were closed too, so dc_samples[dc_index]
-    // is x[i-48] and the producer's increments are the reference's
-    B.tre = f_tre; B.tim = f_tim;
-    g.dc_index += 64 - DC_LEN;            // (dc_index + 64) mod 48
-    if (g.dc_index >= DC_LEN) g.dc_index -= DC_LEN;
-    g.ring_stale = 1;
-    if (PROF) tk[7]++;
-    if (g.run_closed < (1 << 28)) g.run_closed += 64;
-  } else {
-    if (PROF) tk[8]++;
-    if (g.ring_stale) {
-      // the ring was not maintained on the fast path: its content is x[pos-48 .. pos-1]
-      // (= lanes 16..63 of the previous step), oldest at dc_index
-      if (lane >= 64 - DC_LEN) {
-        int di = g.dc_index + (lane - (64 - DC_LEN));
-        if (di >= DC_LEN) di -= DC_LEN;
-        lds_dc[di] = prev_yv;
+// ---- back wave: the dc ring, dc_est and what hangs on it ------------------------------------------
+// dc_est += (x - dc_samples[dc_index]) / 48 over the step's closed samples, in order (gate_impl.cc:139-143).  While
+// whole steps are closed -- a reader command, the carrier between commands -- dc_samples[dc_index] is x[i-48] and
+// the increments are the producer wave's; around the windows they are formed here from the ring.  Then two
+// interleaved in-order sums, the window records (dc_est at the opening sample, gate_impl.cc:176) and, when
+// streaming, the gated samples in[i] - dc_est (:176,187).
+RFID_DEVICE void gate_back(const GateArgs &a, GateBackRegs &g, const GateSlot *slot, int pos, int n_total, int row, int lane,
+                           float2 *lds_dc, float2 *lds_tmp, bool &stop) {
+  int flags, nvalid, open;
+  uint64_t closedmask, openmask;
+  wv::lds_load_desc(&slot->b_flags, flags, nvalid, closedmask, openmask, open);
+  float dcr, dci;
+  if (flags & 1) {
+    const float2 yv = slot->yv[lane];
+    const int cnt = wv::popc64(closedmask);
+    float tre, tim;
+    if (__builtin_expect(cnt == 64 && openmask == 0 && g.run_closed >= DC_LEN, 1)) {
+      // the 48 samples before every lane were closed too: dc_samples[dc_index] is x[i-48] and the producer wave's
+      // increments are the reference's; the ring itself is left alone
+      tre = slot->tre[lane]; tim = slot->tim[lane];
+      g.dc_index += 64 - DC_LEN;            // (dc_index + 64) mod 48
+      if (g.dc_index >= DC_LEN) g.dc_index -= DC_LEN;
+      g.ring_stale = 1;
+      if (g.run_closed < (1 << 28)) g.run_closed += 64;
+    } else {
+      if (g.ring_stale) {
+        // the ring was not maintained: its content is the 48 samples before this step
+        // (= lanes 16..63 of the previous closed step), oldest at dc_index
+        if (lane >= 64 - DC_LEN) {
+          int di = g.dc_index + (lane - (64 - DC_LEN));
+          if (di >= DC_LEN) di -= DC_LEN;
+          lds_dc[di] = g.prev_yv;
+        }
+        g.ring_stale = 0;
+        wv::wave_sync();
       }
-      g.ring_stale = 0;
+      const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      const bool isclosed = ((closedmask >> lane) & 1ull) != 0;
+      const int rank = wv::popc64(closedmask & lt);
+      if (isclosed) lds_tmp[rank] = yv;
       wv::wave_sync();
-    }
-    const bool isclosed = ((closedmask >> lane) & 1ull) != 0;
-    const int rank = wv::popc64(closedmask & lt);
-    if (isclosed) lds_tmp[rank] = f_yv;
-    wv::wave_sync();
-    float2 old = make_float2(0.0f, 0.0f);
-    if (isclosed) {
-      if (rank < DC_LEN) {
-        int di = g.dc_index + rank;
-        if (di >= DC_LEN) di -= DC_LEN;
-        old = lds_dc[di];
-      } else {
-        old = lds_tmp[rank - DC_LEN];
+      float2 old = make_float2(0.0f, 0.0f);
+      if (isclosed) {
+        if (rank < DC_LEN) {
+          int di = g.dc_index + rank;
+          if (di >= DC_LEN) di -= DC_LEN;
+          old = lds_dc[di];
+        } else {
+          old = lds_tmp[rank - DC_LEN];
+        }
       }
-    }
-    {
-      const float nr = f_yv.x - old.x, ni = f_yv.y - old.y;
+      const float nr = yv.x - old.x, ni = yv.y - old.y;
       float qr, qi;
       if (__builtin_expect(wv::ballot(!(div_const_ok(nr) && div_const_ok(ni))) == 0, 1)) {
         qr = div_const_fast<DC_LEN>(nr); qi = div_const_fast<DC_LEN>(ni);
       } else {
         qr = wv::fdiv(nr, DC_LEN_F); qi = wv::fdiv(ni, DC_LEN_F);
       }
-      B.tre = isclosed ? qr : 0.0f;
-      B.tim = isclosed ? qi : 0.0f;
+      tre = isclosed ? qr : 0.0f;
+      tim = isclosed ? qi : 0.0f;
+      wv::wave_sync();
+      if (isclosed && rank >= cnt - DC_LEN) {
+        int di = g.dc_index + rank;
+        if (di >= DC_LEN) di -= DC_LEN;
+        if (di >= DC_LEN) di -= DC_LEN;
+        lds_dc[di] = yv;
+      }
+      wv::wave_sync();
+      g.dc_index += cnt;
+      if (g.dc_index >= DC_LEN) g.dc_index -= DC_LEN;
+      if (g.dc_index >= DC_LEN) g.dc_index -= DC_LEN;
+      // closed samples back-to-back up to the end of this step
+      const uint64_t notclosed = lane_range(0, nvalid) & ~closedmask;
+      if (notclosed == 0) {
+        if (g.run_closed < (1 << 28)) g.run_closed += nvalid;
+      } else {
+        g.run_closed = nvalid - 1 - (63 - __builtin_clzll(notclosed));
+      }
     }
-    wv::wave_sync();
-    if (isclosed && rank >= cnt - DC_LEN) {
-      int di = g.dc_index + rank;
-      if (di >= DC_LEN) di -= DC_LEN;
-      if (di >= DC_LEN) di -= DC_LEN;
-      lds_dc[di] = f_yv;
-    }
-    wv::wave_sync();
-    g.dc_index += cnt;
-    if (g.dc_index >= DC_LEN) g.dc_index -= DC_LEN;
-    if (g.dc_index >= DC_LEN) g.dc_index -= DC_LEN;
-    // closed samples back-to-back up to the end of this step
-    const uint64_t notclosed = lane_range(0, nvalid) & ~closedmask;
-    if (notclosed == 0) {
-      if (g.run_closed < (1 << 28)) g.run_closed += nvalid;
-    } else {
-      g.run_closed = nvalid - 1 - (63 - __builtin_clzll(notclosed));
+    g.prev_yv = yv;
+    chain_add2(g.dcr_c, tre, g.dci_c, tim, lane, dcr, dci);
+    g.dcr_c = wv::readlane(dcr, 63);
+    g.dci_c = wv::readlane(dci, 63);
+  } else {
+    // the step lies entirely inside a window: dc_est, the ring and its index do not move
+    g.run_closed = 0;
+    dcr = g.dcr_c; dci = g.dci_c;
+  }
+  const int open_lane = open & 0xff;
+  if (__builtin_expect(open_lane != 0xff, 0))   // rare: a window opened in this step
+    gate_record_window(a, g, open_lane, (open >> 8) & 1, pos, n_total, row, lane, dcr, dci);
+  if (__builtin_expect(a.mode == 1, 0)) {  // streaming: emit gated samples in[i] - dc_est (gate_impl.cc:176,187)
+    if (openmask != 0) {
+      const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      const float2 yv = slot->yv[lane];
+      const bool isopen = ((openmask >> lane) & 1ull) != 0;
+      const int orank = wv::popc64(openmask & lt);
+      if (isopen && g.written + orank < a.gated_cap)
+        a.gated[g.written + orank] = make_float2(yv.x - dcr, yv.y - dci);
+      g.written += wv::popc64(openmask);
     }
   }
-  B.yv = f_yv; B.openmask = openmask;
-  B.open_lane = open_lane; B.open_type = open_type; B.open_lane2 = open_lane2; B.open_type2 = open_type2;
-  B.pos = pos;
-  B.has = true;
-  B.any_closed = cnt != 0;
-  if (PROF) tk[4] += wv::ticks() - tp1;
-  }  // general step
-  }  // if (has_front)
-
+  stop = (flags & 2) != 0;
 }
 
-// Workgroup = 16 waves = 4 traces.  Wave w serves trace w % 4 in role w / 4: 0 consumer, 1 filter,
-// 2 averaging, 3 producer.  A workgroup's waves are placed round-robin over the CU's 4 SIMDs, so the
-// four waves of a trace share one SIMD (1024 traces = the 1024 SIMDs of the device).  The waves of
-// a trace talk through a 16-slot LDS ring with sequence counters (filter -> producer -> averaging ->
-// consumer -> filter) -- no s_barrier, hence no coupling between the traces of a workgroup.
+// Workgroup = 16 waves = 4 traces.  Wave w serves trace w % 4 in role w / 4: 0 consumer (avg_ampl, state machine),
+// 1 filter, 2 back (dc_est, window records), 3 producer (amplitude, ring difference, speculative dc increments).  A
+// workgroup's waves are placed round-robin over the CU's 4 SIMDs, so the four waves of a trace share one SIMD (1024
+// traces = the 1024 SIMDs of the device), and at that load the SIMD's vector ALU is what the trace is bound by: the
+// four roles together issue ~300 vector instructions per step.  (Measured alternative: five roles per trace, the
+// averaging in a wave of its own, two traces per workgroup -- 1.4x faster per trace while a CU holds two traces, 1.45x
+// slower with the four it has to hold at 1024 traces.)  The waves of a trace talk through a 16-slot LDS ring with
+// sequence counters (filter -> producer -> consumer -> back -> filter) -- no s_barrier, hence no coupling between
+// the traces of a workgroup.
 constexpr int GATE_RAW = 64 * DECIM + (NTAPS - DECIM);   // 344 raw samples feed 64 matched-filter outputs
 constexpr int GATE_RAW4 = GATE_RAW / 2;                  // as float4 (2 samples each): 172
 constexpr int GATE_RAW_LD = (GATE_RAW4 + 63) / 64;       // float4 loads per lane and step: 3
 constexpr int GATE_RAW_DEPTH = 6;                        // steps of raw samples in flight per filter wave
 constexpr int GATE_STREAMS_PER_WG = 4;
-constexpr int GATE_THREADS = 256 * GATE_STREAMS_PER_WG;   // consumer + filter + averaging + producer wave per trace
+constexpr int GATE_ROLES = 4;            // consumer, filter, back, producer wave per trace
+constexpr int GATE_THREADS = 64 * GATE_ROLES * GATE_STREAMS_PER_WG;
+constexpr int GATE_WAVES_PER_SIMD = 4;   // one workgroup per CU: 16 waves, at most 128 VGPRs each
 constexpr int GATE_SLOTS = 16;   // deep enough to ride out a reader command (a burst of ~20 slow consumer steps)
 constexpr int GATE_PREFETCH = 4;    // steps (x64 samples) of matched-filter output held in registers
 
 struct GateShared {          // per trace
   GateSlot slots[GATE_SLOTS];
-  float win[WIN_LEN + 4];    // producer's working copy of gate_impl::win_samples
-  float2 dc[DC_LEN];         // gate_impl::dc_samples
+  float win[WIN_LEN + 4];    // the producer wave's working copy of gate_impl::win_samples
+  float2 dc[DC_LEN];         // gate_impl::dc_samples (back wave)
   float2 tmp[64];
   float4 rawtile[64 * GATE_RAW_LD];   // fused front end: the 344 raw samples one step's matched filter needs (+ padding)
-  int prod_seq;              // steps produced so far
-  int cons_seq;              // steps consumed so far
-  int stop;                  // consumer -> the other waves: stop (streaming mode window close)
-  int prod_done;             // the filter wave is through (fused front end: its y stores are visible device-wide)
-  float avg_final;           // avg_ampl after the last sample of the call (from the averaging wave)
-  int avg_seq;               // steps averaged so far
-  int avg_done;
   int fir_seq;               // steps whose samples are in the slot (filter wave)
+  int prod_seq;              // steps the producer wave is through with
+  int fsm_seq;               // steps the state machine is through with (consumer)
+  int back_seq;              // steps finished by the back wave: their slots are free again
+  int stop;                  // consumer -> the other waves: stop (streaming mode window close)
+  int fsm_done;              // the consumer will not hand over any more steps (fsm_seq is final)
+  int prod_done;             // the filter wave is through (fused front end: its y stores are visible device-wide)
 };
 
 // raw samples of one step (fused front end): float4 #(lane + 64 j) of the 172 the step needs
@@ -771,11 +723,26 @@ struct GateRawRegs {
 // s_waitcnt right behind the load and drain the prefetch): the index is clamped into the row
 // instead.  Samples below index 0 are zeroed when the step is consumed (gate_fir_step, first
 // step only); samples at or above the trace length only feed outputs that do not exist.
+struct GateTrue { static constexpr bool value = true; };
+struct GateFalse { static constexpr bool value = false; };
+template <bool INTERIOR = false>
 RFID_DEVICE void gate_load_raw(GateRawRegs &r, const float2 *xs, int64_t hi_idx, int64_t r0, int lane, bool vec) {
   // r0 = raw index of the first sample of the step's window (even; -24 for the first step), wave-uniform and
   // 64 bits wide (a trace may hold more than 2^31 raw samples): the step's base pointer is scalar, the lane
   // offsets and their clamps are 32-bit
   const float2 *p = xs + r0;
+  if (INTERIOR) {
+    // the caller knows that the whole window lies inside the row and that rows are 16-byte aligned: scalar base +
+    // a per-lane byte offset that does not change from step to step, no clamps
+    const char *pb = reinterpret_cast<const char *>(p);
+#pragma unroll
+    for (int j = 0; j < GATE_RAW_LD; ++j) {
+      int q = lane + 64 * j;
+      q = (q < GATE_RAW4) ? q : (GATE_RAW4 - 1);
+      r.v[j] = *reinterpret_cast<const float4 *>(pb + (uint32_t)(16 * q));
+    }
+    return;
+  }
   const int lo = (r0 < 0) ? (int)(-r0) : 0;
   int64_t hrel = hi_idx - r0;
   hrel = (hrel > (1 << 30)) ? (1 << 30) : hrel;
@@ -823,16 +790,18 @@ RFID_DEVICE float2 gate_fir_step(const GateRawRegs &r, float4 *tile4, int lane, 
   return make_float2(re, im);
 }
 
-template <bool PROF, bool FUSED>
+template <bool FUSED>
 RFID_DEVICE void gate_scan_body(const GateArgs &a) {
   RFID_SHARED GateShared sh_all[GATE_STREAMS_PER_WG];
   const int lane = wv::lane_id();
   const int wave = wv::uniform((int)(threadIdx.x >> 6));
-  const int role = wave / GATE_STREAMS_PER_WG;           // 0 consumer, 1 filter, 2 averaging, 3 producer
+  const int role = wave / GATE_STREAMS_PER_WG;           // 0 consumer, 1 filter, 2 back, 3 producer
   const int sl = wave % GATE_STREAMS_PER_WG;
   const int s = (int)blockIdx.x * GATE_STREAMS_PER_WG + sl;
   GateShared &sh = sh_all[sl];
-  if (lane == 0 && role == 0) { sh.fir_seq = 0; sh.prod_seq = 0; sh.cons_seq = 0; sh.stop = 0; sh.prod_done = 0; sh.avg_seq = 0; sh.avg_done = 0; }
+  if (lane == 0 && role == 0) {
+    sh.fir_seq = 0; sh.prod_seq = 0; sh.fsm_seq = 0; sh.back_seq = 0; sh.stop = 0; sh.fsm_done = 0; sh.prod_done = 0;
+  }
   wv::block_sync();   // once, before any hand-off
   if (s >= a.n_streams) return;
   int strm = s, row = s;
@@ -863,8 +832,6 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
     // fused front end: raw samples in, matched filter here, y written for the decoder;
     // stage kernels / streaming: y in
     bool stopped = false;
-    long long p_wait = 0, p_fir = 0;
-    const long long p_start = PROF ? wv::ticks() : 0;
     if (FUSED) {
       const float2 *xs = a.raw + (int64_t)strm * a.raw_stride;
       const bool vec = a.raw_vec_ok != 0;
@@ -881,6 +848,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
       const int nfull = n >> 6;                       // steps with all 64 samples
       const int ngroups = nfull / GATE_RAW_DEPTH;
       const bool at_start = pos0 == 0;
+      int back_seen = 0;   // sh.back_seq as last read: it only grows, so the slot ring is polled only when it looks full
       if (ngroups > 0) {
         GateRawRegs buf[GATE_RAW_DEPTH];
 #pragma unroll
@@ -888,26 +856,34 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
           gate_load_raw(buf[u], xs, hi_idx, rbase + (int64_t)u * 64 * DECIM, lane, vec);
           wv::compiler_fence();                       // keep the issue order: step 0 first
         }
-        for (int grp = 0; grp < ngroups; ++grp) {
+        // groups whose reloads (the steps one group further on) lie wholly inside the row take the clamp-free loader
+        // -- two copies of the loop, not a branch inside it (see above)
+        int g_fast = 0;
+        if (vec) {
+          const int64_t j_max = (hi_idx - 2 * (GATE_RAW4 - 1) - rbase) / (64 * DECIM);   // last step with an interior window
+          int64_t gf = (j_max + 1) / GATE_RAW_DEPTH - 1;
+          gf = (gf < 0) ? 0 : gf;
+          g_fast = (gf > ngroups) ? ngroups : (int)gf;
+        }
+        auto group = [&](int grp, auto interior) {
 #pragma unroll
           for (int u = 0; u < GATE_RAW_DEPTH; ++u) {
             const int k = grp * GATE_RAW_DEPTH + u;
-            long long tw = 0, t1 = 0;
-            if (PROF) tw = wv::ticks();
-            while (k - wv::lds_load(&sh.cons_seq) >= GATE_SLOTS) wv::backoff();
-            if (PROF) { t1 = wv::ticks(); p_wait += t1 - tw; }
+            while (k - back_seen >= GATE_SLOTS) { back_seen = wv::lds_load(&sh.back_seq); if (k - back_seen >= GATE_SLOTS) wv::backoff(); }
             const float2 yv = gate_fir_step(buf[u], sh.rawtile, lane, u == 0 && grp == 0 && at_start);
-            gate_load_raw(buf[u], xs, hi_idx, rbase + (int64_t)(k + GATE_RAW_DEPTH) * 64 * DECIM, lane, vec);
+            gate_load_raw<decltype(interior)::value>(buf[u], xs, hi_idx, rbase + (int64_t)(k + GATE_RAW_DEPTH) * 64 * DECIM, lane, vec);
             yw[64 * k + lane] = yv;
             sh.slots[k % GATE_SLOTS].yv[lane] = yv;
             wv::lds_store(&sh.fir_seq, k + 1, lane);   // after the slot's data (in-order LDS queue)
-            if (PROF) p_fir += wv::ticks() - t1;
           }
-        }
+        };
+        int grp = 0;
+        for (; grp < g_fast; ++grp) group(grp, GateTrue());
+        for (; grp < ngroups; ++grp) group(grp, GateFalse());
       }
       // the last few steps (fewer than a group, the partial step included): load, then filter
       for (int k = ngroups * GATE_RAW_DEPTH; k < nsteps; ++k) {
-        while (k - wv::lds_load(&sh.cons_seq) >= GATE_SLOTS) wv::backoff();
+        while (k - back_seen >= GATE_SLOTS) { back_seen = wv::lds_load(&sh.back_seq); if (k - back_seen >= GATE_SLOTS) wv::backoff(); }
         GateRawRegs r;
         gate_load_raw(r, xs, hi_idx, rbase + (int64_t)k * 64 * DECIM, lane, vec);
         float2 yv = gate_fir_step(r, sh.rawtile, lane, k == 0 && at_start);
@@ -934,8 +910,8 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
         for (int u = 0; u < GATE_PREFETCH; ++u) {
           const int k = base + u;
           if (k < nsteps && !stopped) {
-            // wait for a free slot (the consumer is at most GATE_SLOTS steps behind)
-            while (!stopped && k - wv::lds_load(&sh.cons_seq) >= GATE_SLOTS) {
+            // wait for a free slot (the back wave is at most GATE_SLOTS steps behind)
+            while (!stopped && k - wv::lds_load(&sh.back_seq) >= GATE_SLOTS) {
               stopped = wv::lds_load(&sh.stop) != 0;
               wv::backoff();
             }
@@ -949,112 +925,105 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
         for (int u = 0; u < GATE_PREFETCH; ++u) cur[u] = nxt[u];
       }
     }
-    if (PROF && a.prof && lane == 0) { a.prof[(int64_t)s * 16 + 9] = p_wait; a.prof[(int64_t)s * 16 + 10] = wv::ticks() - p_start;
-      a.prof[(int64_t)s * 16 + 12] = p_fir; }
     wv::lds_store(&sh.prod_done, 1, lane);
   } else if (role == 3) {
-    // ================= producer: everything that is lane-parallel ================================
+    // ================= producer wave: amplitude ring, (|x| - old)/100, speculative dc increments =================
     for (int j = lane; j < WIN_LEN; j += 64) sh.win[j] = st->win[j];
     int win_index = win_index0;
     wv::wave_sync();
     float2 prev_yv = make_float2(0.0f, 0.0f);
     bool stopped = false;
-    long long g_wait = 0;
+    int fir_seen = 0;    // sh.fir_seq as last read (it only grows)
     for (int k = 0; k < nsteps && !stopped; ++k) {
-      long long tw = 0;
-      if (PROF) tw = wv::ticks();
-      while (!stopped && wv::lds_load(&sh.fir_seq) <= k) {
-        stopped = wv::lds_load(&sh.stop) != 0;
-        wv::backoff();
+      while (!stopped && fir_seen <= k) {
+        fir_seen = wv::lds_load(&sh.fir_seq);
+        if (fir_seen <= k) {
+          stopped = wv::lds_load(&sh.stop) != 0;
+          wv::backoff();
+        }
       }
-      if (PROF) g_wait += wv::ticks() - tw;
       if (!stopped) {
         GateSlot &slot = sh.slots[k % GATE_SLOTS];
         gate_produce(slot, slot.yv[lane], prev_yv, 64 * k, n, lane, sh.win, win_index);
         wv::lds_store(&sh.prod_seq, k + 1, lane);   // after the slot's data (in-order LDS queue)
       }
     }
-    if (PROF && a.prof && lane == 0) a.prof[(int64_t)s * 16 + 13] = g_wait;
   } else if (role == 2) {
-    // ================= averaging wave =========================================================
-    wv::set_priority_high();
-    float avg_c = wv::uniform(st->avg_ampl);
-    bool stopped = false;
-    long long a_wait = 0;
-    for (int k = 0; k < nsteps && !stopped; ++k) {
-      long long tw = 0;
-      if (PROF) tw = wv::ticks();
-      while (!stopped && wv::lds_load(&sh.prod_seq) <= k) {
-        stopped = wv::lds_load(&sh.stop) != 0;
-        wv::backoff();
-      }
-      if (PROF) a_wait += wv::ticks() - tw;
-      if (!stopped) {
-        gate_average(sh.slots[k % GATE_SLOTS], n - 64 * k, lane, avg_c);
-        wv::lds_store(&sh.avg_seq, k + 1, lane);
-      }
-    }
-    if (lane == 0) sh.avg_final = avg_c;
-    if (PROF && a.prof && lane == 0) a.prof[(int64_t)s * 16 + 11] = a_wait;
-    wv::lds_store(&sh.avg_done, 1, lane);
-  } else {
-    // ================= consumer ===============================================================
-    // the consumer owns the critical path (the state machine and the dependent DPP adds of dc_est)
-    wv::set_priority_high();
+    // ================= back wave: dc_est, window records, gated output; frees the slots ===========================
     float2 *lds_dc = sh.dc, *lds_tmp = sh.tmp;
     if (lane < DC_LEN) lds_dc[lane] = make_float2(st->dcr_re[lane], st->dcr_im[lane]);
-    GateRegs g;
-    g.avg_c = wv::uniform(st->avg_ampl);
+    GateBackRegs g;
     g.dcr_c = wv::uniform(st->dc_re); g.dci_c = wv::uniform(st->dc_im);
-    g.f_n = wv::uniform(st->n_samples); g.f_state = wv::uniform(st->signal_state);
-    g.f_pulses = wv::uniform(st->num_pulses); g.f_open = wv::uniform(st->gate_open);
-    g.f_ung = wv::uniform(st->n_to_ungate); g.f_type = wv::uniform(st->wtype);
     g.dc_index = wv::uniform(st->dc_index);
-    g.win_seq = wv::uniform(st->win_seq);
-    if (g.f_ung == 0) g.f_ung = g.f_type ? EPC_WIN : RN16_WIN;  // fresh state: first window is an RN16
     g.run_closed = 0; g.ring_stale = 0;
-    g.n_complete = 0; g.written = 0; g.consumed = n; g.stop = false;
+    g.prev_yv = make_float2(0.0f, 0.0f);
+    g.win_seq = wv::uniform(st->win_seq);
+    g.n_complete = 0; g.written = 0;
     g.pos0 = (int)pos0; g.strm = strm;
-    long long tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const long long t_start = PROF ? wv::ticks() : 0;
-    GateBack B;
-    GateNext nx;
-    nx.step = -1; nx.sq = 0; nx.below = nx.above = 0; nx.yv = make_float2(0.0f, 0.0f); nx.tre = nx.tim = 0.0f;
-    B.has = false; B.tre = 0.0f; B.tim = 0.0f; B.openmask = 0; B.yv = make_float2(0.0f, 0.0f);
-    B.open_lane = B.open_lane2 = -1; B.open_type = B.open_type2 = 0; B.pos = 0; B.any_closed = false;
     wv::wave_sync();
-    for (int k = 0; k < nsteps && !g.stop; ++k) {
-      // (waits until step k is produced and averaged)
-      gate_consume<PROF>(a, g, B, &sh.slots[k % GATE_SLOTS], &sh.slots[(k + 1) % GATE_SLOTS], nx, true, &sh.avg_seq, k, 64 * k, n, n_total, row, lane, lds_dc,
-                         lds_tmp, tk);
-      wv::lds_store(&sh.cons_seq, k + 1, lane);   // slot k free again (its data are in registers)
+    bool stop = false;
+    int fsm_seen = 0;    // sh.fsm_seq as last read (it only grows)
+    for (int k = 0; k < nsteps && !stop; ++k) {
+      bool have = true;
+      while (fsm_seen <= k) {
+        fsm_seen = wv::lds_load(&sh.fsm_seq);
+        if (fsm_seen > k) break;
+        if (wv::lds_load(&sh.fsm_done) != 0) {
+          fsm_seen = wv::lds_load(&sh.fsm_seq);
+          if (fsm_seen <= k) { have = false; break; }
+        } else {
+          wv::backoff();
+        }
+      }
+      if (!have) break;
+      gate_back(a, g, &sh.slots[k % GATE_SLOTS], 64 * k, n_total, row, lane, lds_dc, lds_tmp, stop);
+      wv::lds_store(&sh.back_seq, k + 1, lane);   // slot k free again
     }
-    if (g.stop) wv::lds_store(&sh.stop, 1, lane);
-    // drain: finish the pending back half (window records / gated output of the last step)
-    if (B.has) gate_consume<PROF>(a, g, B, &sh.slots[0], &sh.slots[0], nx, false, &sh.avg_seq, 0, 0, n, n_total, row, lane, lds_dc, lds_tmp, tk);
-    if (PROF && a.prof && lane == 0) {
-      tk[6] = wv::ticks() - t_start;
-      for (int i = 0; i < 9; ++i) a.prof[(int64_t)s * 16 + i] = tk[i];
-      a.prof[(int64_t)s * 16 + 14] = tk[9]; a.prof[(int64_t)s * 16 + 15] = tk[10];
-    }
-
-    // ---- write state back ----------------------------------------------------------------
-    // wait for the other waves: the final avg_ampl, and (fused front end) the y stores being visible
-    while (wv::lds_load(&sh.prod_done) == 0) wv::backoff();
-    while (wv::lds_load(&sh.avg_done) == 0) wv::backoff();
-    if (!g.stop) g.avg_c = wv::lds_load_f(&sh.avg_final);
     if (g.ring_stale) {
-      // materialise the dc ring: the last 48 consumed samples, oldest at dc_index
-      if (lane < DC_LEN) {
-        int di = g.dc_index + lane;
+      // materialise the dc ring: the last 48 closed samples (lanes 16..63 of the last closed step), oldest at dc_index
+      if (lane >= 64 - DC_LEN) {
+        int di = g.dc_index + (lane - (64 - DC_LEN));
         if (di >= DC_LEN) di -= DC_LEN;
-        lds_dc[di] = FUSED ? wv::load_coherent(&ys[g.consumed - DC_LEN + lane]) : ys[g.consumed - DC_LEN + lane];
+        lds_dc[di] = g.prev_yv;
       }
       wv::wave_sync();
     }
     if (lane < DC_LEN) { st->dcr_re[lane] = lds_dc[lane].x; st->dcr_im[lane] = lds_dc[lane].y; }
+    if (lane == 0) {
+      st->dc_re = g.dcr_c; st->dc_im = g.dci_c; st->win_seq = g.win_seq; st->dc_index = g.dc_index;
+      if (a.mode == 0) {
+        const int before = (pos0 > 0 && !a.units) ? a.wcount[row] : 0;   // windows recorded by earlier chunks
+        const int tot = before + g.n_complete;
+        a.wcount[row] = (tot < a.wmax) ? tot : a.wmax;
+      } else {
+        a.io[1] = g.written;
+      }
+    }
+  } else {
+    // ================= consumer: the edge / pulse / window state machine ============================================
+    wv::set_priority_high();
+    GateRegs g;
+    g.avg_c = wv::uniform(st->avg_ampl);
+    g.f_n = wv::uniform(st->n_samples); g.f_state = wv::uniform(st->signal_state);
+    g.f_pulses = wv::uniform(st->num_pulses); g.f_open = wv::uniform(st->gate_open);
+    g.f_ung = wv::uniform(st->n_to_ungate); g.f_type = wv::uniform(st->wtype);
+    if (g.f_ung == 0) g.f_ung = g.f_type ? EPC_WIN : RN16_WIN;  // fresh state: first window is an RN16
+    g.consumed = n; g.stop = false;
+    GateNext nx;
+    nx.step = -1; nx.sq = 0; nx.amp = nx.d = 0.0f;
+    for (int k = 0; k < nsteps && !g.stop; ++k) {
+      // (waits until step k went through the producer wave)
+      gate_consume(a, g, &sh.slots[k % GATE_SLOTS], &sh.slots[(k + 1) % GATE_SLOTS], nx, &sh.prod_seq, k, 64 * k, n, lane);
+      wv::lds_store(&sh.fsm_seq, k + 1, lane);   // step k handed to the back wave
+    }
+    wv::lds_store(&sh.fsm_done, 1, lane);
+    if (g.stop) wv::lds_store(&sh.stop, 1, lane);
+
+    // ---- write state back ----------------------------------------------------------------
+    // wait for the filter wave (fused front end: its y stores being visible)
+    while (wv::lds_load(&sh.prod_done) == 0) wv::backoff();
     // amplitude ring: the last min(100, consumed) samples of this call overwrite their slots
-    // (the producer read st->win before it produced step 0, i.e. long before this point --
+    // (the producer wave read st->win before it produced step 0, i.e. long before this point --
     // except for an empty call, which writes nothing here)
     {
       const int c = g.consumed;
@@ -1065,31 +1034,19 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
       }
     }
     if (lane == 0) {
-      st->avg_ampl = g.avg_c; st->dc_re = g.dcr_c; st->dc_im = g.dci_c;
+      st->avg_ampl = g.avg_c;
       st->n_samples = g.f_n; st->signal_state = g.f_state; st->num_pulses = g.f_pulses;
       st->gate_open = g.f_open; st->n_to_ungate = g.f_ung; st->wtype = g.f_type;
-      st->win_index = (win_index0 + g.consumed) % WIN_LEN; st->dc_index = g.dc_index; st->win_seq = g.win_seq;
-      if (a.mode == 0) {
-        const int before = (pos0 > 0 && !a.units) ? a.wcount[row] : 0;   // windows recorded by earlier chunks
-        const int tot = before + g.n_complete;
-        a.wcount[row] = (tot < a.wmax) ? tot : a.wmax;
-      } else {
-        a.io[0] = g.consumed;
-        a.io[1] = g.written;
-      }
+      st->win_index = (win_index0 + g.consumed) % WIN_LEN;
+      if (a.mode != 0) a.io[0] = g.consumed;
     }
   }
 }
 
-RFID_KERNEL(GATE_THREADS) void gate_scan_kernel(GateArgs a) { gate_scan_body<false, false>(a); }
+RFID_KERNEL_OCC(GATE_THREADS, GATE_WAVES_PER_SIMD) void gate_scan_kernel(GateArgs a) { gate_scan_body<false>(a); }
 // fused front end: matched filter (in the filter waves) + gate scan in one launch; reads the raw
 // 2 Msps samples once, writes y for the decoder
-RFID_KERNEL(GATE_THREADS) void front_end_fused_kernel(GateArgs a) { gate_scan_body<false, true>(a); }
-// the same kernels with s_memtime wait / phase counters of the four waves (a.prof: [n_streams][16],
-// printed by the RFID_GATE_PROF=1 developer aid in rfid_capi.hip)
-RFID_KERNEL(GATE_THREADS) void gate_scan_kernel_prof(GateArgs a) { gate_scan_body<true, false>(a); }
-RFID_KERNEL(GATE_THREADS) void front_end_fused_kernel_prof(GateArgs a) { gate_scan_body<true, true>(a); }
-
+RFID_KERNEL_OCC(GATE_THREADS, GATE_WAVES_PER_SIMD) void front_end_fused_kernel(GateArgs a) { gate_scan_body<true>(a); }
 
 // =========================================================================================
 // 2b. Long-stream front end: helpers around gate_scan_kernel for ONE long trace (or a few) cut along time into
@@ -1222,7 +1179,7 @@ RFID_KERNEL(64) void ls_init_kernel(LsInitArgs a) {
 // avg_ampl alone over the units (gate_impl.cc:130-133: the amplitude ring and the in-order sum; no state machine, no
 // dc_est): one wave per run, many per SIMD.  The long-stream front end settles the exact avg_ampl at every cut with
 // this cheap pass first -- the threshold tests, hence the state machine, hence which samples dc_est sums over, all
-// hang on it -- before the full gate scan runs.  Same arithmetic as the producer / averaging waves, value for value.
+// hang on it -- before the full gate scan runs.  Same arithmetic as the producer / consumer waves, value for value.
 struct LsAvgArgs {
   const float2 *y;
   int64_t y_stride;

@@ -140,7 +140,7 @@ int emu_batch_process(const float *raw, int B, long stride, long n_raw, const in
   ga.y = y; ga.y_stride = y_stride; ga.n_dec = n_dec; ga.lens = lens; ga.state = gstate.data(); ga.n_streams = B;
   ga.wtab = wtab.data(); ga.wmax = wmax; ga.wcount = wcount.data(); ga.flat = flat.data();
   ga.flat_count = flat_count; ga.flat_cap = flat_cap; ga.mode = 0; ga.gated = nullptr; ga.gated_cap = 0;
-  ga.io = nullptr; ga.prof = nullptr;
+  ga.io = nullptr;
   if (fused) {
     ga.pos0 = 0; ga.chunk_len = n_dec; ga.y_w = y;
     ga.raw = reinterpret_cast<const float2 *>(raw); ga.raw_stride = stride; ga.n_raw = n_raw; ga.raw_vec_ok = ma.vec_ok;
@@ -204,7 +204,7 @@ int emu_gate_stream(void *state_blob, const float *in, int n_in, int seek_type, 
     ga.y = reinterpret_cast<const float2 *>(in); ga.y_stride = n_in; ga.n_dec = n_in; ga.lens = nullptr;
     ga.pos0 = 0; ga.chunk_len = n_in; ga.state = st; ga.n_streams = 1; ga.wtab = nullptr; ga.wmax = 0; ga.wcount = nullptr; ga.flat = nullptr;
     ga.flat_count = nullptr; ga.flat_cap = 0; ga.mode = 1; ga.gated = reinterpret_cast<float2 *>(out);
-    ga.gated_cap = n_in; ga.io = io; ga.prof = nullptr;
+    ga.gated_cap = n_in; ga.io = io;
     emu::launch(emu::Idx3{1, 1, 1}, emu::Idx3{GATE_THREADS, 1, 1}, [&]() { gate_scan_kernel(ga); });
   }
   *consumed = io[0];

@@ -90,6 +90,7 @@ static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 #define blockDim (emu::g_block_dim)
 
 #define RFID_KERNEL(threads) static inline
+#define RFID_KERNEL_OCC(threads, waves) static inline
 #define RFID_DEVICE static inline
 #define RFID_SHARED static
 #define __device__
@@ -169,6 +170,19 @@ static inline float lds_load_f(const float *p) { return emu::u2f((uint32_t)emu::
 static inline void lds_store(int *p, int v, int lane) { emu::wave_barrier(); if (lane == 0) *(volatile int *)p = v; }
 static inline uint64_t lds_load64(const uint64_t *p) { return emu::exchange(*(const volatile uint64_t *)p)[0]; }
 static inline void lds_store64(uint64_t *p, uint64_t v, int lane) { emu::wave_barrier(); if (lane == 0) *(volatile uint64_t *)p = v; }
+static inline void lds_store_desc(int *p, int flags, int nvalid, uint64_t m0, uint64_t m1, int info, int lane) {
+  emu::wave_barrier();
+  if (lane == 0) {
+    volatile uint32_t *q = (volatile uint32_t *)p;
+    q[0] = (uint32_t)flags; q[1] = (uint32_t)nvalid; q[2] = (uint32_t)m0; q[3] = (uint32_t)(m0 >> 32);
+    q[4] = (uint32_t)m1; q[5] = (uint32_t)(m1 >> 32); q[6] = (uint32_t)info; q[7] = 0u;
+  }
+}
+static inline void lds_load_desc(const int *p, int &flags, int &nvalid, uint64_t &m0, uint64_t &m1, int &info) {
+  flags = lds_load(p); nvalid = lds_load(p + 1);
+  m0 = lds_load64((const uint64_t *)(p + 2)); m1 = lds_load64((const uint64_t *)(p + 4));
+  info = lds_load(p + 6);
+}
 static inline void set_priority_high() {}
 static inline void backoff() { emu::yield(); }
 static inline void keep(float) {}
