@@ -114,10 +114,6 @@ RFID_DEVICE void wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-// workgroup barrier that waits for this wave's LDS traffic only (lgkmcnt), not for its
-// outstanding global loads: __syncthreads() adds s_waitcnt vmcnt(0), which would drain the
-// producer wave's register prefetch every step
-RFID_DEVICE void block_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 RFID_DEVICE int atomic_add(int *p, int v) { return atomicAdd(p, v); }
 RFID_DEVICE int atomic_min(int *p, int v) { return atomicMin(p, v); }
 // this wave's global stores are visible device-wide when this returns
@@ -143,14 +139,7 @@ RFID_DEVICE int lds_peek(const int *p) {
   const volatile RFID_LDS_AS int *q = (const volatile RFID_LDS_AS int *)p;
   return *q;
 }
-// two adjacent 64-bit mask words (16-byte aligned) in one ds_read_b128; uniform64() afterwards
 typedef uint32_t rfid_u32x4 __attribute__((ext_vector_type(4)));
-RFID_DEVICE void lds_peek_masks(const uint64_t *p, uint64_t &a, uint64_t &b) {
-  const volatile RFID_LDS_AS rfid_u32x4 *q = (const volatile RFID_LDS_AS rfid_u32x4 *)p;
-  const rfid_u32x4 v = *q;
-  a = ((uint64_t)v.y << 32) | v.x;
-  b = ((uint64_t)v.w << 32) | v.z;
-}
 // step descriptor between two waves: 32 bytes at a 16-byte aligned LDS address, written by lane 0 with two 16-byte
 // stores (after the wave's earlier LDS writes), read back with two 16-byte loads
 RFID_DEVICE void lds_store_desc(int *p, int flags, int nvalid, uint64_t m0, uint64_t m1, int info, int lane) {
@@ -174,34 +163,13 @@ RFID_DEVICE void lds_load_desc(const int *p, int &flags, int &nvalid, uint64_t &
   m1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)b.y) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)b.x);
   info = __builtin_amdgcn_readfirstlane((int)b.z);
 }
-RFID_DEVICE uint64_t uniform64(uint64_t v) {
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-  return ((uint64_t)hi << 32) | lo;
-}
-RFID_DEVICE float lds_load_f(const float *p) { return __int_as_float(lds_load(reinterpret_cast<const int *>(p))); }
 RFID_DEVICE void lds_store(int *p, int v, int lane) {
   volatile RFID_LDS_AS int *q = (volatile RFID_LDS_AS int *)p;
   asm volatile("" ::: "memory");
   if (lane == 0) *q = v;
   asm volatile("" ::: "memory");
 }
-RFID_DEVICE uint64_t lds_load64(const uint64_t *p) {
-  const volatile RFID_LDS_AS uint32_t *q = (const volatile RFID_LDS_AS uint32_t *)p;
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)q[0]);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)q[1]);
-  return ((uint64_t)hi << 32) | lo;
-}
-RFID_DEVICE void lds_store64(uint64_t *p, uint64_t v, int lane) {
-  volatile RFID_LDS_AS uint32_t *q = (volatile RFID_LDS_AS uint32_t *)p;
-  asm volatile("" ::: "memory");
-  if (lane == 0) { q[0] = (uint32_t)v; q[1] = (uint32_t)(v >> 32); }
-  asm volatile("" ::: "memory");
-}
 RFID_DEVICE void set_priority_high() { __builtin_amdgcn_s_setprio(3); }
 RFID_DEVICE void backoff() { __builtin_amdgcn_s_sleep(1); }
-RFID_DEVICE void keep(float v) { asm volatile("" ::"s"(v)); }
-RFID_DEVICE void keep(int v) { asm volatile("" ::"s"(v)); }
-RFID_DEVICE long long ticks() { return (long long)__builtin_amdgcn_s_memtime(); }
 
 }  // namespace wv

@@ -290,23 +290,8 @@ RFID_DEVICE uint64_t lane_range(int lo, int hi) {  // bits [lo, hi), 0 <= lo <= 
   return up & ~dn;
 }
 
-// Three independent in-order sums advanced together: a dependent DPP add has ~12 cycles of
-// latency but a single wave can issue one every ~4, so three chains cost the same as one.
-RFID_DEVICE void chain_add3(float ca, float xa, float cb, float xb, float cc, float xc, int lane,
-                            float &pa, float &pb, float &pc) {
-  const float a0 = (lane == 0) ? (ca + xa) : xa;
-  const float b0 = (lane == 0) ? (cb + xb) : xb;
-  const float c0 = (lane == 0) ? (cc + xc) : xc;
-  pa = a0; pb = b0; pc = c0;
-#pragma unroll
-  for (int s = 1; s < 64; ++s) {
-    pa = wv::shr1(pa) + a0;
-    pb = wv::shr1(pb) + b0;
-    pc = wv::shr1(pc) + c0;
-  }
-}
-
-// two chains (dc_est real / imaginary)
+// two chains (dc_est real / imaginary) advanced together: a dependent DPP add has ~12 cycles of latency but a
+// single wave can issue one every ~4, so two chains cost little more than one
 RFID_DEVICE void chain_add2(float cb, float xb, float cc, float xc, int lane, float &pb, float &pc) {
   const float b0 = (lane == 0) ? (cb + xb) : xb;
   const float c0 = (lane == 0) ? (cc + xc) : xc;

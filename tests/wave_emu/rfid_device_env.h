@@ -159,17 +159,12 @@ static inline void block_sync() {
   }
 }
 static inline void wave_sync() { emu::wave_barrier(); }
-static inline void block_sync_lds() { block_sync(); }
 // the device versions end in v_readfirstlane: every lane gets LANE 0's read (lanes are fibers here and would
 // otherwise sample a mailbox word at different times and diverge)
 static inline int lds_load(const int *p) { return (int)(uint32_t)emu::exchange((uint32_t)*(const volatile int *)p)[0]; }
 static inline int lds_peek(const int *p) { return *(const volatile int *)p; }
-static inline void lds_peek_masks(const uint64_t *p, uint64_t &a, uint64_t &b) { a = ((const volatile uint64_t *)p)[0]; b = ((const volatile uint64_t *)p)[1]; }
-static inline uint64_t uniform64(uint64_t v) { return v; }
-static inline float lds_load_f(const float *p) { return emu::u2f((uint32_t)emu::exchange(emu::f2u(*(const volatile float *)p))[0]); }
 static inline void lds_store(int *p, int v, int lane) { emu::wave_barrier(); if (lane == 0) *(volatile int *)p = v; }
 static inline uint64_t lds_load64(const uint64_t *p) { return emu::exchange(*(const volatile uint64_t *)p)[0]; }
-static inline void lds_store64(uint64_t *p, uint64_t v, int lane) { emu::wave_barrier(); if (lane == 0) *(volatile uint64_t *)p = v; }
 static inline void lds_store_desc(int *p, int flags, int nvalid, uint64_t m0, uint64_t m1, int info, int lane) {
   emu::wave_barrier();
   if (lane == 0) {
@@ -185,9 +180,6 @@ static inline void lds_load_desc(const int *p, int &flags, int &nvalid, uint64_t
 }
 static inline void set_priority_high() {}
 static inline void backoff() { emu::yield(); }
-static inline void keep(float) {}
-static inline void keep(int) {}
-static inline long long ticks() { return 0; }
 static inline int atomic_add(int *p, int v) { int o = *p; *p = o + v; return o; }
 static inline int atomic_min(int *p, int v) { int o = *p; if (v < o) *p = v; return o; }
 static inline void global_release() {}
