@@ -47,7 +47,7 @@ struct rfid_ctx {
   DevBuf s_in, s_out;
   DevBuf synth_tab;               // slot table of rfid_synth_gen2
   // long-stream front end (few long traces cut into concurrently scanned units)
-  DevBuf ls_cut, ls_units, ls_runs, ls_tmpl, ls_state, ls_uw, ls_uwc, ls_heads, ls_seq0, ls_gath;
+  DevBuf ls_cut, ls_units, ls_runs, ls_tmpl, ls_state, ls_uw, ls_uwc, ls_heads, ls_seq0, ls_gath, ls_rec, ls_dcache;
   int ls_mode = 1;                // 0 never, 1 automatic, 2 whenever a trace can be cut
   // whole-chain streaming (rfid_stream_*)
   struct StreamIO {
@@ -341,6 +341,9 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
     if ((rc = grow(c, c->ls_heads, sizeof(int) * LS_HEAD_WORDS * 2 * (size_t)U + sizeof(float) * 4 * (size_t)U))) return rc;
     if ((rc = grow(c, c->ls_seq0, sizeof(int) * (size_t)U))) return rc;
     if ((rc = grow(c, c->ls_gath, sizeof(int) * (12 * 2 + 1) * (size_t)U))) return rc;
+    const int rec_stride = (max_len + 63) / 64;   // steps of the longest unit
+    if ((rc = grow(c, c->ls_rec, sizeof(uint64_t) * (size_t)U * (size_t)rec_stride))) return rc;
+    if ((rc = grow(c, c->ls_dcache, sizeof(float) * (size_t)B * (size_t)c->y_stride))) return rc;
     for (int u = 0; u < U; ++u) units[(size_t)u].row = u;
     HIPCHK(c, hipMemcpyAsync(c->ls_units.p, units.data(), sizeof(GateUnit) * (size_t)U, hipMemcpyHostToDevice, c->stream));
     LsInitArgs ia;
@@ -396,6 +399,8 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
         LsAvgArgs aa;
         aa.y = c->d_y; aa.y_stride = c->y_stride; aa.units = (const GateUnit *)c->ls_runs.p; aa.n_runs = (int)runs.size();
         aa.start = d_av; aa.end = d_ae; aa.carry = opt.carry ? c->d_gstate : nullptr;
+        // the addends are data only: written by the first pass of an attempt (all units run), read by the later ones
+        aa.dcache = (float *)c->ls_dcache.p; aa.cache_mode = (round == 1) ? 1 : 2; aa.n_units = U;
         hipLaunchKernelGGL(ls_avg_kernel, dim3((unsigned)runs.size()), dim3(64), 0, c->stream, aa);
         HIPCHK(c, hipGetLastError());
         std::vector<float> got(2 * (size_t)U);
@@ -427,6 +432,10 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
     // ---- phase 2: the full gate scan; avg_ampl starts exact, dc_est and the state machine's scalars are predicted ------
     std::vector<int> heads((size_t)LS_HEAD_WORDS * 2 * (size_t)U);
     std::vector<char> frozen((size_t)U, 0);
+    // units whose start was right in everything but dc_est when they last went through the full scan: their closed
+    // samples and window positions are final, later rounds re-run only the dc_est arithmetic (ls_dc_kernel)
+    std::vector<char> fsm_final((size_t)U, 0);
+    std::vector<GateUnit> runs_dc;
     std::vector<LsHead> got;
     bool restart = false, accepted = false;
     for (int round = 1; round <= LS_MAX_ROUNDS && !restart && !accepted; ++round) {
@@ -436,12 +445,15 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
         const bool with_b = (round == 2) || pass == 1;
         if (round <= 2 && pass == 1) break;
         runs.clear();
+        runs_dc.clear();
         for (int v = 0; v < (with_b ? 2 : 1); ++v)
           for (int u = 0; u < U; ++u) {
             if (frozen[(size_t)u]) continue;
             GateUnit r = units[(size_t)u];
             r.row = v * U + u;
-            runs.push_back(r);
+            // (variant B differs from A in the dc_est start only: it never needs more than the dc_est arithmetic over
+            // what variant A's scan -- of this pass or an earlier one -- found closed)
+            ((fsm_final[(size_t)u] || v == 1) ? runs_dc : runs).push_back(r);
             const LsStart &st = start[(size_t)u];
             int *h = &heads[(size_t)LS_HEAD_WORDS * (size_t)r.row];
             memcpy(&h[0], &st.v[0], 4);   // avg_ampl: exact in both variants (it steers the state machine)
@@ -451,9 +463,14 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
             }
             for (int k = 0; k < 6; ++k) h[3 + k] = st.f[k];
           }
-        const int n_run = (int)runs.size();
+        const int n_run = (int)runs.size(), n_dc = (int)runs_dc.size();
         HIPCHK(c, hipMemcpyAsync(c->ls_heads.p, heads.data(), sizeof(int) * heads.size(), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->ls_runs.p, runs.data(), sizeof(GateUnit) * runs.size(), hipMemcpyHostToDevice, c->stream));
+        if (n_run)
+          HIPCHK(c, hipMemcpyAsync(c->ls_runs.p, runs.data(), sizeof(GateUnit) * runs.size(), hipMemcpyHostToDevice, c->stream));
+        if (n_dc)   // (ls_runs holds 2 U entries: the full runs first, the dc_est-only runs behind them)
+          HIPCHK(c, hipMemcpyAsync((GateUnit *)c->ls_runs.p + n_run, runs_dc.data(), sizeof(GateUnit) * runs_dc.size(),
+                                   hipMemcpyHostToDevice, c->stream));
+        if (n_run) {
         LsHeadsArgs ha;
         ha.tmpl = (const GateState *)c->ls_tmpl.p; ha.state = (GateState *)c->ls_state.p; ha.heads = (const int *)c->ls_heads.p;
         ha.runs = (const GateUnit *)c->ls_runs.p; ha.n_runs = n_run; ha.n_units = U;
@@ -464,10 +481,22 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
         g.state = (GateState *)c->ls_state.p; g.n_streams = n_run; g.wtab = (rfid_window *)c->ls_uw.p; g.wmax = uwmax;
         g.wcount = (int *)c->ls_uwc.p; g.flat = nullptr; g.flat_count = nullptr; g.flat_cap = 0; g.mode = 0;
         g.units = (const GateUnit *)c->ls_runs.p;
+        g.rec = (uint64_t *)c->ls_rec.p; g.rec_stride = rec_stride; g.rec_mod = U;
         hipLaunchKernelGGL(gate_scan_kernel, dim3((unsigned)((n_run + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG)),
                            dim3(GATE_THREADS), 0, c->stream, g);
         HIPCHK(c, hipGetLastError());
-        rep.gate_passes += with_b ? 2 : 1;
+        }
+        if (n_dc) {
+          LsDcArgs da;
+          da.y = c->d_y; da.y_stride = c->y_stride; da.runs = (const GateUnit *)c->ls_runs.p + n_run; da.n_runs = n_dc; da.n_units = U;
+          da.tmpl = (const GateState *)c->ls_tmpl.p; da.heads = (const int *)c->ls_heads.p; da.state = (GateState *)c->ls_state.p;
+          da.rec = (const uint64_t *)c->ls_rec.p; da.rec_stride = rec_stride;
+          da.uwtab = (rfid_window *)c->ls_uw.p; da.uwcount = (int *)c->ls_uwc.p; da.uwmax = uwmax;
+          hipLaunchKernelGGL(ls_dc_kernel, dim3((unsigned)n_dc), dim3(64), 0, c->stream, da);
+          HIPCHK(c, hipGetLastError());
+          rep.dc_runs += n_dc;
+        }
+        if (n_run) rep.gate_passes += 1;
         rep.unit_runs += n_run;
         {
           LsGatherArgs ga;
@@ -481,12 +510,13 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
         HIPCHK(c, hipMemcpyAsync(got.data(), c->ls_gath.p, sizeof(LsHead) * 2 * (size_t)U, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         for (const GateUnit &r : runs) eh[(size_t)r.row] = got[(size_t)r.row];
+        for (const GateUnit &r : runs_dc) eh[(size_t)r.row] = got[(size_t)r.row];
         // ---- chain the units of every trace: true start of unit u+1 = (predicted) end of unit u ----
-        bool all_exact = true, chain_exact = true;
+        bool all_exact = true, chain_exact = true, fsm_chain = true;
         int n_moved = 0;
         std::vector<LsStart> next(start);
         for (int u = 0; u < U; ++u) {
-          if (first_of_trace(u)) chain_exact = true;
+          if (first_of_trace(u)) { chain_exact = true; fsm_chain = true; }
           if (frozen[(size_t)u]) {   // final: its end state is the exact one
             if (!last_of_trace(u)) {
               LsStart &nx = next[(size_t)u + 1];
@@ -508,7 +538,10 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
             else if (k == 0 || (d & 1) == 0 || !with_b || first_of_trace(u)) pred.v[k] = f_from_ord(f_ord(eA[k]) + d);
             else pred.v[k] = f_from_ord(f_ord(k == 1 ? eh[U + u].dcr : eh[U + u].dci) + (d - 1));
           }
-          for (int k = 0; k < 6; ++k) if (t.f[k] != sA.f[k]) exact = false;
+          bool fsm_match = f_ord(t.v[0]) == f_ord(sA.v[0]);
+          for (int k = 0; k < 6; ++k) if (t.f[k] != sA.f[k]) { exact = false; fsm_match = false; }
+          if (!fsm_match) fsm_chain = false;
+          if (fsm_chain) fsm_final[(size_t)u] = 1;
           pred.f[0] = eh[u].n_samples; pred.f[1] = eh[u].signal_state; pred.f[2] = eh[u].num_pulses; pred.f[3] = eh[u].gate_open;
           pred.f[4] = eh[u].n_to_ungate; pred.f[5] = eh[u].wtype;
           if (!exact) { chain_exact = false; n_moved++; }
@@ -525,8 +558,8 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
           int64_t dmax = 0;
           for (int u = 0; u < U; ++u) for (int k = 0; k < 3; ++k) {
             int64_t d = f_ord(next[(size_t)u].v[k]) - f_ord(start[(size_t)u].v[k]); if (d < 0) d = -d; if (d > dmax) dmax = d; }
-          fprintf(stderr, "[ls] attempt %d round %d pass %d with_b=%d runs=%d moved=%d first_open=%d max|d|=%lld ulps avg_passes=%d\n", attempt,
-                  round, pass, (int)with_b, n_run, n_moved, first_bad, (long long)dmax, rep.avg_passes);
+          fprintf(stderr, "[ls] t=%8.2f ms  attempt %d round %d pass %d with_b=%d runs=%d dc_runs=%d moved=%d first_open=%d max|d|=%lld ulps\n",
+                  ls_now_ms() - t_begin, attempt, round, pass, (int)with_b, n_run, n_dc, n_moved, first_bad, (long long)dmax);
         }
         start = next;
         if (all_exact) {
@@ -674,7 +707,7 @@ int rfid_ctx_destroy(rfid_ctx *c) {
   free_plan(c);
   void *ptrs[] = {c->d_gate1, c->d_io, c->d_swin, c->d_scount, c->d_sres, c->d_sscores, c->s_in.p, c->s_out.p,
                   c->synth_tab.p, c->ls_cut.p, c->ls_units.p, c->ls_runs.p, c->ls_tmpl.p, c->ls_state.p, c->ls_uw.p, c->ls_uwc.p,
-                  c->ls_heads.p, c->ls_seq0.p, c->ls_gath.p};
+                  c->ls_heads.p, c->ls_seq0.p, c->ls_gath.p, c->ls_rec.p, c->ls_dcache.p};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < 5; ++i)

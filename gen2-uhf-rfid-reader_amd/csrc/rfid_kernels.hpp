@@ -184,6 +184,11 @@ struct GateArgs {
   int raw_vec_ok;       // rows 16-byte aligned -> float4 loads
   float2 *y_w;          // [n_streams][y_stride], written
   const GateUnit *units; // optional: n_streams counts UNITS; state / wtab / wcount are per unit
+  // long-stream mode: the closed samples of every step (gate_impl.cc:139-143) go to rec[(row % rec_mod) * rec_stride
+  // + step] -- they depend on avg_ampl and the state machine only, so a unit whose start was right in those can be
+  // re-run for another dc_est start value by ls_dc_kernel alone
+  uint64_t *rec;
+  int rec_stride, rec_mod;
 };
 
 // x / C for the gate's two constant divisors (100: gate_impl.cc:131, 48: :141) in three instructions
@@ -565,83 +570,102 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateSlot *slot, co
 // the increments are the producer wave's; around the windows they are formed here from the ring.  Then two
 // interleaved in-order sums, the window records (dc_est at the opening sample, gate_impl.cc:176) and, when
 // streaming, the gated samples in[i] - dc_est (:176,187).
+#ifndef RFID_BACK_SCAN
+#define RFID_BACK_SCAN 0
+#endif
+constexpr bool GATE_BACK_SCAN = RFID_BACK_SCAN != 0;
+// the dc_est part of one step with closed samples: increments (from `spec` while whole steps are closed, else from
+// the ring), ring upkeep, the two in-order sums; dcr / dci = dc_est after every sample of the step
+template <bool SCAN, class Spec>
+RFID_DEVICE void gate_dc_step(GateBackRegs &g, uint64_t closedmask, uint64_t openmask, int nvalid, float2 yv, int lane,
+                              float2 *lds_dc, float2 *lds_tmp, Spec spec, float &dcr, float &dci) {
+  const int cnt = wv::popc64(closedmask);
+  float tre, tim;
+  if (__builtin_expect(cnt == 64 && openmask == 0 && g.run_closed >= DC_LEN, 1)) {
+    // the 48 samples before every lane were closed too: dc_samples[dc_index] is x[i-48] and the speculative
+    // increments are the reference's; the ring itself is left alone
+    spec(tre, tim);
+    g.dc_index += 64 - DC_LEN;            // (dc_index + 64) mod 48
+    if (g.dc_index >= DC_LEN) g.dc_index -= DC_LEN;
+    g.ring_stale = 1;
+    if (g.run_closed < (1 << 28)) g.run_closed += 64;
+  } else {
+    if (g.ring_stale) {
+      // the ring was not maintained: its content is the 48 samples before this step
+      // (= lanes 16..63 of the previous closed step), oldest at dc_index
+      if (lane >= 64 - DC_LEN) {
+        int di = g.dc_index + (lane - (64 - DC_LEN));
+        if (di >= DC_LEN) di -= DC_LEN;
+        lds_dc[di] = g.prev_yv;
+      }
+      g.ring_stale = 0;
+      wv::wave_sync();
+    }
+    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const bool isclosed = ((closedmask >> lane) & 1ull) != 0;
+    const int rank = wv::popc64(closedmask & lt);
+    if (isclosed) lds_tmp[rank] = yv;
+    wv::wave_sync();
+    float2 old = make_float2(0.0f, 0.0f);
+    if (isclosed) {
+      if (rank < DC_LEN) {
+        int di = g.dc_index + rank;
+        if (di >= DC_LEN) di -= DC_LEN;
+        old = lds_dc[di];
+      } else {
+        old = lds_tmp[rank - DC_LEN];
+      }
+    }
+    const float nr = yv.x - old.x, ni = yv.y - old.y;
+    float qr, qi;
+    if (__builtin_expect(wv::ballot(!(div_const_ok(nr) && div_const_ok(ni))) == 0, 1)) {
+      qr = div_const_fast<DC_LEN>(nr); qi = div_const_fast<DC_LEN>(ni);
+    } else {
+      qr = wv::fdiv(nr, DC_LEN_F); qi = wv::fdiv(ni, DC_LEN_F);
+    }
+    tre = isclosed ? qr : 0.0f;
+    tim = isclosed ? qi : 0.0f;
+    wv::wave_sync();
+    if (isclosed && rank >= cnt - DC_LEN) {
+      int di = g.dc_index + rank;
+      if (di >= DC_LEN) di -= DC_LEN;
+      if (di >= DC_LEN) di -= DC_LEN;
+      lds_dc[di] = yv;
+    }
+    wv::wave_sync();
+    g.dc_index += cnt;
+    if (g.dc_index >= DC_LEN) g.dc_index -= DC_LEN;
+    if (g.dc_index >= DC_LEN) g.dc_index -= DC_LEN;
+    // closed samples back-to-back up to the end of this step
+    const uint64_t notclosed = lane_range(0, nvalid) & ~closedmask;
+    if (notclosed == 0) {
+      if (g.run_closed < (1 << 28)) g.run_closed += nvalid;
+    } else {
+      g.run_closed = nvalid - 1 - (63 - __builtin_clzll(notclosed));
+    }
+  }
+  g.prev_yv = yv;
+  if (SCAN) {
+    // (ls_dc_kernel: one wave per unit, bound by the latency of its own sums)
+    dcr = chain_add_auto(g.dcr_c, tre, lane);
+    dci = chain_add_auto(g.dci_c, tim, lane);
+  } else {
+    chain_add2(g.dcr_c, tre, g.dci_c, tim, lane, dcr, dci);
+  }
+  g.dcr_c = wv::readlane(dcr, 63);
+  g.dci_c = wv::readlane(dci, 63);
+}
+
 RFID_DEVICE void gate_back(const GateArgs &a, GateBackRegs &g, const GateSlot *slot, int pos, int n_total, int row, int lane,
-                           float2 *lds_dc, float2 *lds_tmp, bool &stop) {
+                           float2 *lds_dc, float2 *lds_tmp, uint64_t *rec, bool &stop) {
   int flags, nvalid, open;
   uint64_t closedmask, openmask;
   wv::lds_load_desc(&slot->b_flags, flags, nvalid, closedmask, openmask, open);
+  if (rec && lane == 0) *rec = closedmask;
   float dcr, dci;
   if (flags & 1) {
-    const float2 yv = slot->yv[lane];
-    const int cnt = wv::popc64(closedmask);
-    float tre, tim;
-    if (__builtin_expect(cnt == 64 && openmask == 0 && g.run_closed >= DC_LEN, 1)) {
-      // the 48 samples before every lane were closed too: dc_samples[dc_index] is x[i-48] and the producer wave's
-      // increments are the reference's; the ring itself is left alone
-      tre = slot->tre[lane]; tim = slot->tim[lane];
-      g.dc_index += 64 - DC_LEN;            // (dc_index + 64) mod 48
-      if (g.dc_index >= DC_LEN) g.dc_index -= DC_LEN;
-      g.ring_stale = 1;
-      if (g.run_closed < (1 << 28)) g.run_closed += 64;
-    } else {
-      if (g.ring_stale) {
-        // the ring was not maintained: its content is the 48 samples before this step
-        // (= lanes 16..63 of the previous closed step), oldest at dc_index
-        if (lane >= 64 - DC_LEN) {
-          int di = g.dc_index + (lane - (64 - DC_LEN));
-          if (di >= DC_LEN) di -= DC_LEN;
-          lds_dc[di] = g.prev_yv;
-        }
-        g.ring_stale = 0;
-        wv::wave_sync();
-      }
-      const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-      const bool isclosed = ((closedmask >> lane) & 1ull) != 0;
-      const int rank = wv::popc64(closedmask & lt);
-      if (isclosed) lds_tmp[rank] = yv;
-      wv::wave_sync();
-      float2 old = make_float2(0.0f, 0.0f);
-      if (isclosed) {
-        if (rank < DC_LEN) {
-          int di = g.dc_index + rank;
-          if (di >= DC_LEN) di -= DC_LEN;
-          old = lds_dc[di];
-        } else {
-          old = lds_tmp[rank - DC_LEN];
-        }
-      }
-      const float nr = yv.x - old.x, ni = yv.y - old.y;
-      float qr, qi;
-      if (__builtin_expect(wv::ballot(!(div_const_ok(nr) && div_const_ok(ni))) == 0, 1)) {
-        qr = div_const_fast<DC_LEN>(nr); qi = div_const_fast<DC_LEN>(ni);
-      } else {
-        qr = wv::fdiv(nr, DC_LEN_F); qi = wv::fdiv(ni, DC_LEN_F);
-      }
-      tre = isclosed ? qr : 0.0f;
-      tim = isclosed ? qi : 0.0f;
-      wv::wave_sync();
-      if (isclosed && rank >= cnt - DC_LEN) {
-        int di = g.dc_index + rank;
-        if (di >= DC_LEN) di -= DC_LEN;
-        if (di >= DC_LEN) di -= DC_LEN;
-        lds_dc[di] = yv;
-      }
-      wv::wave_sync();
-      g.dc_index += cnt;
-      if (g.dc_index >= DC_LEN) g.dc_index -= DC_LEN;
-      if (g.dc_index >= DC_LEN) g.dc_index -= DC_LEN;
-      // closed samples back-to-back up to the end of this step
-      const uint64_t notclosed = lane_range(0, nvalid) & ~closedmask;
-      if (notclosed == 0) {
-        if (g.run_closed < (1 << 28)) g.run_closed += nvalid;
-      } else {
-        g.run_closed = nvalid - 1 - (63 - __builtin_clzll(notclosed));
-      }
-    }
-    g.prev_yv = yv;
-    chain_add2(g.dcr_c, tre, g.dci_c, tim, lane, dcr, dci);
-    g.dcr_c = wv::readlane(dcr, 63);
-    g.dci_c = wv::readlane(dci, 63);
+    gate_dc_step<GATE_BACK_SCAN>(g, closedmask, openmask, nvalid, slot->yv[lane], lane, lds_dc, lds_tmp,
+                 [&](float &tre, float &tim) { tre = slot->tre[lane]; tim = slot->tim[lane]; }, dcr, dci);
   } else {
     // the step lies entirely inside a window: dc_est, the ring and its index do not move
     g.run_closed = 0;
@@ -946,6 +970,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
     g.n_complete = 0; g.written = 0;
     g.pos0 = (int)pos0; g.strm = strm;
     wv::wave_sync();
+    uint64_t *rec = a.rec ? a.rec + (int64_t)(row % a.rec_mod) * a.rec_stride : nullptr;
     bool stop = false;
     int fsm_seen = 0;    // sh.fsm_seq as last read (it only grows)
     for (int k = 0; k < nsteps && !stop; ++k) {
@@ -961,7 +986,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
         }
       }
       if (!have) break;
-      gate_back(a, g, &sh.slots[k % GATE_SLOTS], 64 * k, n_total, row, lane, lds_dc, lds_tmp, stop);
+      gate_back(a, g, &sh.slots[k % GATE_SLOTS], 64 * k, n_total, row, lane, lds_dc, lds_tmp, rec ? rec + k : nullptr, stop);
       wv::lds_store(&sh.back_seq, k + 1, lane);   // slot k free again
     }
     if (g.ring_stale) {
@@ -1173,6 +1198,11 @@ struct LsAvgArgs {
   const float *start;      // avg_ampl at the unit's first sample
   float *end;              // avg_ampl after its last sample
   const GateState *carry;  // optional [n_streams]: amplitude ring a trace's first unit starts with (else all zero)
+  // the addends (|x| - win_samples[win_index]) / 100 depend on the samples only, not on where avg_ampl starts: the
+  // first pass (every unit runs) leaves them in dcache[stream * y_stride + sample], later passes add them up again
+  float *dcache;
+  int cache_mode;          // 0 not used, 1 write (rows < n_units), 2 read
+  int n_units;
 };
 RFID_KERNEL(64) void ls_avg_kernel(LsAvgArgs a) {
   const int lane = wv::lane_id();
@@ -1198,6 +1228,27 @@ RFID_KERNEL(64) void ls_avg_kernel(LsAvgArgs a) {
   }
   float avg = wv::uniform(a.start[row]);
   const int nsteps = (n + 63) >> 6;
+  if (a.cache_mode == 2) {
+    const float *dc = a.dcache + (int64_t)wv::uniform(un.stream) * a.y_stride + pos0;
+    constexpr int AHEAD = 4;
+    float buf[AHEAD];
+#pragma unroll
+    for (int j = 0; j < AHEAD; ++j) { const int i = 64 * j + lane; buf[j] = (i < n) ? dc[i] : 0.0f; }
+    for (int kb = 0; kb < nsteps; kb += AHEAD) {
+#pragma unroll
+      for (int j = 0; j < AHEAD; ++j) {
+        if (kb + j < nsteps) {
+          const float d = buf[j];
+          const int i = 64 * (kb + j + AHEAD) + lane;
+          buf[j] = (i < n) ? dc[i] : 0.0f;
+          avg = wv::readlane(chain_add_auto(avg, d, lane), 63);
+        }
+      }
+    }
+    if (lane == 0) a.end[row] = avg;
+    return;
+  }
+  float *dcw = (a.cache_mode == 1 && row < a.n_units) ? a.dcache + (int64_t)wv::uniform(un.stream) * a.y_stride + pos0 : nullptr;
   float2 v = (lane < n) ? ys[lane] : make_float2(0.0f, 0.0f);
   for (int k = 0; k < nsteps; ++k) {
     const int i_next = 64 * (k + 1) + lane;
@@ -1209,6 +1260,7 @@ RFID_KERNEL(64) void ls_avg_kernel(LsAvgArgs a) {
     const float old = (lane < 36) ? o2 : o1;
     const float nd = valid ? (amp - old) : 0.0f;
     const float d = div_const<WIN_LEN>(nd);
+    if (dcw && valid) dcw[64 * k + lane] = d;
     const float sacc = chain_add_auto(avg, d, lane);
     avg = wv::readlane(sacc, 63);
     a2 = a1; a1 = amp; v = vn;
@@ -1237,6 +1289,127 @@ RFID_KERNEL(64) void ls_set_state_kernel(LsHeadsArgs a) {
   wv::wave_sync();
   // the nine values are the first nine words of GateState, in this order
   if (lane < LS_HEAD_WORDS) dst[lane] = a.heads[LS_HEAD_WORDS * row + lane];
+}
+
+// dc_est alone over the units (gate_impl.cc:139-143,176): which samples are "closed" was recorded by the unit's full
+// gate scan (GateArgs::rec) and depends on avg_ampl and the state machine only, so another start value of dc_est
+// needs neither of them again -- one wave per run, many per SIMD, the back wave's arithmetic value for value.
+// Writes dc_est and the dc ring at the unit's end into the run's state row and the dc_est fields of its window records.
+struct LsDcArgs {
+  const float2 *y;
+  int64_t y_stride;
+  const GateUnit *runs;    // [n_runs]: row = state / window-table row; unit = row mod n_units
+  int n_runs, n_units;
+  const GateState *tmpl;   // [n_units]: the dc ring at the unit's first sample
+  const int *heads;        // [2 n_units][LS_HEAD_WORDS] by row: words 1, 2 = dc_est (re, im) at the unit's first sample
+  GateState *state;        // [2 n_units] rows
+  const uint64_t *rec;     // [n_units][rec_stride]: the closed samples of every step
+  int rec_stride;
+  rfid_window *uwtab;      // [2 n_units][uwmax]: starts / types from row (row mod n_units) -- the unit's full scan
+  int *uwcount;
+  int uwmax;
+};
+RFID_KERNEL(64) void ls_dc_kernel(LsDcArgs a) {
+  RFID_SHARED float2 lds_dc[DC_LEN];
+  RFID_SHARED float2 lds_tmp[64];
+  const int lane = wv::lane_id();
+  const int r = (int)blockIdx.x;
+  if (r >= a.n_runs) return;
+  const GateUnit un = a.runs[r];
+  const int pos0 = wv::uniform(un.pos0), n = wv::uniform(un.len), row = wv::uniform(un.row);
+  const int u = row % a.n_units;
+  const float2 *ys = a.y + (int64_t)wv::uniform(un.stream) * a.y_stride + pos0;
+  const GateState *ts = a.tmpl + u;
+  GateState *st = a.state + row;
+  if (lane < DC_LEN) lds_dc[lane] = make_float2(ts->dcr_re[lane], ts->dcr_im[lane]);
+  GateBackRegs g;
+  g.dcr_c = __builtin_bit_cast(float, wv::uniform(a.heads[LS_HEAD_WORDS * row + 1]));
+  g.dci_c = __builtin_bit_cast(float, wv::uniform(a.heads[LS_HEAD_WORDS * row + 2]));
+  g.dc_index = wv::uniform(ts->dc_index);
+  g.run_closed = 0; g.ring_stale = 0;
+  g.prev_yv = make_float2(0.0f, 0.0f);
+  g.win_seq = 0; g.n_complete = 0; g.written = 0; g.pos0 = pos0; g.strm = wv::uniform(un.stream);
+  wv::wave_sync();
+  const rfid_window *wsrc = a.uwtab + (int64_t)u * a.uwmax;
+  rfid_window *wdst = a.uwtab + (int64_t)row * a.uwmax;
+  int nw = wv::uniform(a.uwcount[u]);
+  if (nw > a.uwmax) nw = a.uwmax;
+  int wi = 0;
+  int next_rel = (nw > 0) ? (wv::uniform(wsrc[0].start) - pos0) : 0x7fffffff;   // opening sample of the next window
+  const uint64_t *rec = a.rec + (int64_t)u * a.rec_stride;
+  const int nsteps = (n + 63) >> 6;
+  constexpr int AHEAD = 4;   // steps of samples in flight
+  float2 buf[AHEAD];
+#pragma unroll
+  for (int j = 0; j < AHEAD; ++j) {
+    const int i = 64 * j + lane;
+    buf[j] = (i < n) ? ys[i] : make_float2(0.0f, 0.0f);
+  }
+  float2 before = make_float2(0.0f, 0.0f);   // the samples of the previous step
+  uint64_t masks = 0;                         // lane j: the closed samples of step 64 * block + j
+  for (int kb = 0; kb < nsteps; kb += AHEAD) {
+#pragma unroll
+    for (int j = 0; j < AHEAD; ++j) {
+      const int k = kb + j;
+      if (k < nsteps) {
+        if ((k & 63) == 0) masks = (k + lane < nsteps) ? rec[k + lane] : 0ull;
+        const float2 yv = buf[j];
+        {
+          const int i = 64 * (k + AHEAD) + lane;
+          buf[j] = (i < n) ? ys[i] : make_float2(0.0f, 0.0f);
+        }
+        const uint64_t closedmask = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(masks >> 32), k & 63) << 32) |
+                                    (uint32_t)wv::readlane((int)(uint32_t)masks, k & 63);
+        const int nvalid = (n - 64 * k < 64) ? (n - 64 * k) : 64;
+        float dcr, dci;
+        if (closedmask != 0) {
+          gate_dc_step<true>(g, closedmask, 0ull, nvalid, yv, lane, lds_dc, lds_tmp,
+                       [&](float &tre, float &tim) {
+                         // (x - x[i-48]) / 48 as the producer wave forms it: x[i-48] from the previous step's lanes 16..63
+                         // or this step's lanes 0..15
+                         const int src = (lane < DC_LEN) ? (lane + 64 - DC_LEN) : (lane - DC_LEN);
+                         const float pre = wv::shfl(before.x, src), pim = wv::shfl(before.y, src);
+                         const float cre = wv::shfl(yv.x, src), cim = wv::shfl(yv.y, src);
+                         const float nr = yv.x - ((lane < DC_LEN) ? pre : cre), ni = yv.y - ((lane < DC_LEN) ? pim : cim);
+                         if (__builtin_expect(wv::ballot(!(div_const_ok(nr) && div_const_ok(ni))) == 0, 1)) {
+                           tre = div_const_fast<DC_LEN>(nr); tim = div_const_fast<DC_LEN>(ni);
+                         } else {
+                           tre = wv::fdiv(nr, DC_LEN_F); tim = wv::fdiv(ni, DC_LEN_F);
+                         }
+                       },
+                       dcr, dci);
+        } else {
+          g.run_closed = 0;
+          dcr = g.dcr_c; dci = g.dci_c;
+        }
+        before = yv;
+        while (next_rel < 64 * (k + 1)) {   // windows that opened in this step (gate_impl.cc:176)
+          const int ol = next_rel - 64 * k;
+          const float odr = wv::readlane(dcr, ol), odi = wv::readlane(dci, ol);
+          if (lane == 0) {
+            rfid_window w = wsrc[wi];
+            w.dc_re = odr; w.dc_im = odi;
+            wdst[wi] = w;
+          }
+          ++wi;
+          next_rel = (wi < nw) ? (wv::uniform(wsrc[wi].start) - pos0) : 0x7fffffff;
+        }
+      }
+    }
+  }
+  if (g.ring_stale) {
+    if (lane >= 64 - DC_LEN) {
+      int di = g.dc_index + (lane - (64 - DC_LEN));
+      if (di >= DC_LEN) di -= DC_LEN;
+      lds_dc[di] = g.prev_yv;
+    }
+    wv::wave_sync();
+  }
+  if (lane < DC_LEN) { st->dcr_re[lane] = lds_dc[lane].x; st->dcr_im[lane] = lds_dc[lane].y; }
+  if (lane == 0) {
+    st->dc_re = g.dcr_c; st->dc_im = g.dci_c; st->dc_index = g.dc_index;
+    a.uwcount[row] = a.uwcount[u];
+  }
 }
 
 // gate_impl.cc:112-123 for the streaming gate: SEEK_* -> CLOSED arms the next window (one launch, no host round trip)

@@ -54,8 +54,7 @@ class SynthGen2Params(C.Structure):
 
 class LsReport(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("units", "chunk", "rounds", "gate_passes", "unit_runs", "avg_passes", "verified", "gave_up",
-                                         "cuts_dropped",
-                                         "last_round_moved")]
+                                         "cuts_dropped", "last_round_moved", "dc_runs", "reserved_")]
 
 
 class BatchTiming(C.Structure):

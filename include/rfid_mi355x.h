@@ -144,6 +144,9 @@ typedef struct rfid_ls_report {
   int32_t gave_up;          /* 1: not verified within the round limit; the sequential scan was run instead */
   int32_t cuts_dropped;     /* cut points withdrawn because the state machine was not idle there */
   int32_t last_round_moved; /* units whose start still moved in the last round (0 when verified) */
+  int32_t dc_runs;          /* unit re-runs of the dc_est arithmetic alone (units whose avg_ampl / state-machine start was already
+                             * the exact one: what is closed and where windows open cannot change any more) */
+  int32_t reserved_;
 } rfid_ls_report;
 
 typedef struct rfid_ctx rfid_ctx;
