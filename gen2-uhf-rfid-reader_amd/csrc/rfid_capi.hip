@@ -408,6 +408,7 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
         HIPCHK(c, hipStreamSynchronize(c->stream));
         for (const GateUnit &r : runs) ae[(size_t)r.row] = got[(size_t)r.row];
         rep.avg_passes++;
+        if (dbg) fprintf(stderr, "[ls] t=%8.2f ms  avg pass %d runs=%d\n", ls_now_ms() - t_begin, rep.avg_passes, (int)runs.size());
         all = true;
         float t = 0.0f;
         bool chain_exact = true;   // every unit of this trace so far started from its true value

@@ -1462,12 +1462,27 @@ RFID_KERNEL(64) void ls_assemble_kernel(LsAssembleArgs a) {
   int k = a.uwcount[u];
   if (k > a.uwmax) k = a.uwmax;
   const int s = a.units[u].stream, seq0 = a.seq0[u];
-  for (int i = lane; i < k; i += 64) {
-    rfid_window w = a.uwtab[(int64_t)u * a.uwmax + i];
-    w.seq = seq0 + i;
-    if (w.seq < a.wmax) {
-      a.wtab[(int64_t)s * a.wmax + w.seq] = w;
-      const int slotw = wv::atomic_add(a.flat_count + w.type, 1);
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int base = 0; base < k; base += 64) {
+    const int i = base + lane;
+    rfid_window w = {};
+    bool on = false;
+    if (i < k) {
+      w = a.uwtab[(int64_t)u * a.uwmax + i];
+      w.seq = seq0 + i;
+      on = w.seq < a.wmax;
+    }
+    if (on) a.wtab[(int64_t)s * a.wmax + w.seq] = w;
+    // places in the decoder's two lists: one atomic per list and 64 windows, not one per window
+    const uint64_t m1 = wv::ballot(on && w.type != 0), m0 = wv::ballot(on && w.type == 0);
+    int b0 = 0, b1 = 0;
+    if (lane == 0) {
+      if (m0) b0 = wv::atomic_add(a.flat_count + 0, wv::popc64(m0));
+      if (m1) b1 = wv::atomic_add(a.flat_count + 1, wv::popc64(m1));
+    }
+    b0 = wv::uniform(b0); b1 = wv::uniform(b1);
+    if (on) {
+      const int slotw = w.type ? (b1 + wv::popc64(m1 & lt)) : (b0 + wv::popc64(m0 & lt));
       if (slotw < a.flat_cap) a.flat[(int64_t)w.type * a.flat_cap + slotw] = w;
     }
   }
