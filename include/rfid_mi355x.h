@@ -137,8 +137,9 @@ typedef struct rfid_ls_report {
   int32_t units;            /* units the traces were cut into */
   int32_t chunk;            /* nominal unit length, decimated samples */
   int32_t rounds;           /* prediction rounds until every unit started from its predecessor's exact end state */
-  int32_t gate_passes;      /* gate-scan launches those rounds cost (two variants per round while predictions move) */
-  int32_t unit_runs;        /* unit runs in those launches (units that already ran from their exact start are not re-run) */
+  int32_t gate_passes;      /* full gate-scan launches those rounds cost */
+  int32_t unit_runs;        /* unit runs in those launches (units that already ran from their exact start are not re-run;
+                             * see dc_runs) */
   int32_t avg_passes;       /* launches of the cheap avg_ampl-only pass that settles avg_ampl at every cut first */
   int32_t verified;         /* 1: accepted -- bit-identical to the sequential scan by construction */
   int32_t gave_up;          /* 1: not verified within the round limit; the sequential scan was run instead */
