@@ -209,7 +209,10 @@ void next_slot(rfid_reader_state &rs) {
 // falls back to the plain sequential scan.
 namespace {
 const int LS_MAX_ROUNDS = 10;
-const int LS_TARGET_UNITS = 4096;
+// units per pass: enough to fill the device several times over; the avg_ampl / dc_est passes run one wave per unit and
+// take as long as ONE unit takes (64 samples per ~0.5 us), so shorter units shorten every pass -- measured on the
+// 2.2 G-sample trace: 2048 units 36.5 ms, 4096 37.0, 8192 34.1, 16384 34.6, 32768 45.8 (more cuts, more rounds)
+const int LS_TARGET_UNITS = 8192;
 const int LS_MIN_CHUNK = 6144;
 
 struct LsStart {  // what a unit needs from its past besides the rings: the three recurrences + the state machine's scalars
@@ -241,6 +244,16 @@ double ls_now_ms() {
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
 }
+// Automatic choice between the two front ends (mode 1), from their measured rates on MI355X: the fused front end
+// runs up to 1024 traces side by side at ~10.2 ns per decimated sample of the LONGEST trace; the long-stream front end
+// costs ~1 ms of passes whose length does not depend on the data plus ~0.065 ns per decimated sample of ALL traces
+// (two full scans + the avg_ampl / dc_est passes).  64 traces of 215 k samples: 1.8 vs 2.2 ms; 128: 2.7 vs 2.25 ms;
+// one trace of 6 M samples: 1.3 vs 61 ms.
+bool ls_pays_off(int B, int64_t n_dec) {
+  const double t_seq = 1.02e-5 * (double)n_dec * (double)((B + 1023) / 1024);
+  const double t_ls = 1.0 + 6.5e-8 * (double)B * (double)n_dec;
+  return t_ls < 0.9 * t_seq;
+}
 struct LsOpts {
   bool carry = false;       // a trace's first unit starts from c->d_gstate[trace] (streaming) instead of the fresh gate,
                             // and the state after the last processed unit is written back there
@@ -259,7 +272,7 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
   const int B = c->B;
   if (!opt.force) {
     if (c->ls_mode == 0 || n_dec < 2 * LS_MIN_CHUNK) return RFID_OK;
-    if (c->ls_mode == 1 && B > 512) return RFID_OK;
+    if (c->ls_mode == 1 && !ls_pays_off(B, n_dec)) return RFID_OK;
   } else if (n_dec < LS_QUIET + 256) {
     return RFID_OK;
   }
@@ -997,7 +1010,7 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
   if (const char *e = getenv("RFID_FRONT_CHUNKS")) nch = atoi(e);
   if (nch > rfid_ctx::MAX_CHUNKS) nch = rfid_ctx::MAX_CHUNKS;
   memset(&c->ls_rep, 0, sizeof(c->ls_rep));
-  if (nch < 2 && c->ls_mode != 0 && n_out >= 2 * LS_MIN_CHUNK && (c->ls_mode == 2 || c->B <= 512)) {
+  if (nch < 2 && c->ls_mode != 0 && n_out >= 2 * LS_MIN_CHUNK && (c->ls_mode == 2 || ls_pays_off(c->B, n_out))) {
     // few long traces: matched filter, then the gate scan over concurrently scanned units of each trace
     int rc = rfid_batch_mf(c, d_raw, raw_stride, n_raw, d_lens);
     if (rc) return rc;

@@ -269,8 +269,9 @@ RFID_API int rfid_batch_process(rfid_ctx *ctx, const void *d_raw, int64_t raw_st
  * trace) leaves the chip idle, so each trace is cut along time at idle points of the gate's state machine and the
  * units are scanned concurrently from predicted gate states; a pass is accepted only when every unit started from
  * a state bit-identical to its predecessor's end state, i.e. the result IS the sequential scan (otherwise the
- * sequential scan runs).  mode 0: never, 1 (default): when the batch has at most 512 traces that can each be cut
- * at least once, 2: whenever a trace can be cut.  The environment variable RFID_LONG_STREAM overrides the default. */
+ * sequential scan runs).  mode 0: never, 1 (default): when it is expected to be faster than the fused front end --
+ * few traces, long enough (an estimate from the batch size and the trace length: e.g. up to ~100 traces of 1 M raw
+ * samples, one trace of more than ~0.6 M), 2: whenever a trace can be cut.  The environment variable RFID_LONG_STREAM overrides the default. */
 RFID_API int rfid_batch_set_long_stream(rfid_ctx *ctx, int mode);
 RFID_API int rfid_batch_ls_report(const rfid_ctx *ctx, rfid_ls_report *out);
 RFID_API int rfid_batch_sync(rfid_ctx *ctx);
