@@ -207,6 +207,12 @@ void next_slot(rfid_reader_state &rs) {
 // become the next round's starts (first round: ring means; typically exact from the third round on).  Nothing is
 // assumed about the arithmetic: a wrong prediction only costs another round, and after LS_MAX_ROUNDS the caller
 // falls back to the plain sequential scan.
+// Only a unit's first scans are full ones: which samples are "closed" (update dc_est) and where windows open depend on
+// avg_ampl and the state machine, never on dc_est.  gate_scan_kernel records the closed-sample mask of every step; a unit
+// whose start was right in everything but dc_est (and every variant-B run: B differs from A in the dc_est start only) is
+// re-run by ls_dc_kernel, which redoes the back wave's arithmetic over the recorded masks and patches the dc_est fields
+// of the window records.  avg_ampl is settled beforehand by its own passes (ls_avg_kernel; the addends are data only and
+// are cached by the first pass).
 namespace {
 const int LS_MAX_ROUNDS = 10;
 // units per pass: enough to fill the device several times over; the avg_ampl / dc_est passes run one wave per unit and
