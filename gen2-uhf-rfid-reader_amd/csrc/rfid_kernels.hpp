@@ -570,10 +570,6 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateSlot *slot, co
 // the increments are the producer wave's; around the windows they are formed here from the ring.  Then two
 // interleaved in-order sums, the window records (dc_est at the opening sample, gate_impl.cc:176) and, when
 // streaming, the gated samples in[i] - dc_est (:176,187).
-#ifndef RFID_BACK_SCAN
-#define RFID_BACK_SCAN 0
-#endif
-constexpr bool GATE_BACK_SCAN = RFID_BACK_SCAN != 0;
 // the dc_est part of one step with closed samples: increments (from `spec` while whole steps are closed, else from
 // the ring), ring upkeep, the two in-order sums; dcr / dci = dc_est after every sample of the step
 template <bool SCAN, class Spec>
@@ -646,7 +642,8 @@ RFID_DEVICE void gate_dc_step(GateBackRegs &g, uint64_t closedmask, uint64_t ope
   }
   g.prev_yv = yv;
   if (SCAN) {
-    // (ls_dc_kernel: one wave per unit, bound by the latency of its own sums)
+    // (ls_dc_kernel: one wave per unit, bound by the latency of its own sums.  In the back wave of the 4-wave
+    // pipeline the two interleaved chains are faster: 2.45 vs 2.69 ms for the fused front end)
     dcr = chain_add_auto(g.dcr_c, tre, lane);
     dci = chain_add_auto(g.dci_c, tim, lane);
   } else {
@@ -664,7 +661,7 @@ RFID_DEVICE void gate_back(const GateArgs &a, GateBackRegs &g, const GateSlot *s
   if (rec && lane == 0) *rec = closedmask;
   float dcr, dci;
   if (flags & 1) {
-    gate_dc_step<GATE_BACK_SCAN>(g, closedmask, openmask, nvalid, slot->yv[lane], lane, lds_dc, lds_tmp,
+    gate_dc_step<false>(g, closedmask, openmask, nvalid, slot->yv[lane], lane, lds_dc, lds_tmp,
                  [&](float &tre, float &tim) { tre = slot->tre[lane]; tim = slot->tim[lane]; }, dcr, dci);
   } else {
     // the step lies entirely inside a window: dc_est, the ring and its index do not move
