@@ -237,3 +237,15 @@ def test_emulated_termination_limits(emu_mod, oracle_mod, synth_mod, kw):
     for k in ("n_queries_sent", "cur_inventory_round", "cur_slot_number", "n_epc_correct", "n_unique_tags"):
         assert st[k] == getattr(o.state, k), k
     assert np.array_equal(st["tag_reads"], np.array(o.state.tag_reads[:], dtype=np.int32))
+
+
+@pytest.mark.parametrize("dc0", [(0.0, 0.0), (19.125, 16.0625), (19.125001907348633, -3.5), (1e-3, 7.75)])
+def test_emulated_dc_only_rerun_equals_full_gate_scan(emu_mod, oracle_mod, synth_mod, dc0):
+    """ls_dc_kernel (long-stream front end: later rounds redo a unit's dc_est arithmetic alone, over the closed-sample
+    masks its full gate scan recorded) against gate_scan_kernel started from the same dc_est: dc_est and the dc ring at
+    the end of the unit and the dc_est of every window record must agree bit for bit -- and the start value of dc_est
+    must not move any window (the state machine does not depend on it).  The trace ends inside a partial step."""
+    t = synth_mod.make_trace(n_rounds=3, seed=17, sigma=0.02, t1_jitter_raw=3).samples
+    y = oracle_mod.fir(t)[: len(t) // 5 - 37]
+    bad, nw = emu_mod.ls_dc_check(y, dc0[0], dc0[1])
+    assert nw == 6 and bad == 0

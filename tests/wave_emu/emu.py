@@ -85,6 +85,14 @@ def decode_one(win: np.ndarray, type_: int):
     return res[0], sc[0]
 
 
+def ls_dc_check(y: np.ndarray, dc_re0: float, dc_im0: float):
+    """-> (mismatching words, windows): ls_dc_kernel replaying a unit against the full gate scan from the same dc_est start"""
+    y = np.ascontiguousarray(y, dtype=np.complex64)
+    nw = C.c_int(0)
+    bad = lib().emu_ls_dc_check(C.c_void_p(y.ctypes.data), len(y), C.c_float(dc_re0), C.c_float(dc_im0), C.byref(nw))
+    return bad, nw.value
+
+
 def mf_stream(staging: np.ndarray, in_off: int, n_out: int) -> np.ndarray:
     buf = np.zeros(len(staging) + 2, dtype=np.complex64)
     off = (16 - buf.ctypes.data % 16) % 16 // 8

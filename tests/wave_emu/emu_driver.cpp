@@ -188,6 +188,54 @@ int emu_batch_process(const float *raw, int B, long stride, long n_raw, const in
   return 0;
 }
 
+// Long-stream building blocks on ONE unit (the whole of y): a full gate scan from dc_est = (0, 0) that records the closed
+// samples of every step; a full scan from dc_est = (dc_re0, dc_im0); and ls_dc_kernel replaying the recorded masks from
+// that same start.  The two last must agree bit for bit: dc_est and the dc ring at the end, every window record.
+// Returns the number of mismatching words (0 = equal); *n_windows = windows of the unit.
+int emu_ls_dc_check(const float *y_in, int n, float dc_re0, float dc_im0, int *n_windows) {
+  const float2 *y = reinterpret_cast<const float2 *>(y_in);
+  const int uwmax = n / (RN16_WIN + T1_SAMPLES + 1) + 2, steps = (n + 63) / 64;
+  std::vector<GateState> tmpl(1), state(3);
+  memset(tmpl.data(), 0, sizeof(GateState));
+  memset(state.data(), 0, sizeof(GateState) * 3);
+  std::vector<rfid_window> uw((size_t)3 * uwmax);
+  memset(uw.data(), 0, sizeof(rfid_window) * uw.size());
+  std::vector<int> uwc(3, 0);
+  std::vector<uint64_t> rec((size_t)steps, ~0ull);
+  std::vector<int> heads((size_t)3 * LS_HEAD_WORDS, 0);
+  GateUnit un[3];
+  for (int r = 0; r < 3; ++r) { un[r].stream = 0; un[r].pos0 = 0; un[r].len = n; un[r].row = r; }
+  for (int r = 1; r < 3; ++r) { memcpy(&heads[(size_t)r * LS_HEAD_WORDS + 1], &dc_re0, 4); memcpy(&heads[(size_t)r * LS_HEAD_WORDS + 2], &dc_im0, 4); }
+  state[1].dc_re = dc_re0; state[1].dc_im = dc_im0;
+  GateArgs ga = {};
+  ga.y = y; ga.y_stride = n; ga.n_dec = n; ga.lens = nullptr; ga.pos0 = 0; ga.chunk_len = n; ga.state = state.data();
+  ga.n_streams = 1; ga.wtab = uw.data(); ga.wmax = uwmax; ga.wcount = uwc.data(); ga.mode = 0;
+  ga.rec = rec.data(); ga.rec_stride = steps; ga.rec_mod = 1;
+  for (int r = 0; r < 2; ++r) {   // row 0: the recording scan; row 1: the full scan from the other start
+    ga.units = &un[r];
+    emu::launch(emu::Idx3{1, 1, 1}, emu::Idx3{GATE_THREADS, 1, 1}, [&]() { gate_scan_kernel(ga); });
+  }
+  LsDcArgs da;
+  da.y = y; da.y_stride = n; da.runs = &un[2]; da.n_runs = 1; da.n_units = 1; da.tmpl = tmpl.data(); da.heads = heads.data();
+  da.state = state.data(); da.rec = rec.data(); da.rec_stride = steps; da.uwtab = uw.data(); da.uwcount = uwc.data(); da.uwmax = uwmax;
+  emu::launch(emu::Idx3{1, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { ls_dc_kernel(da); });
+  int bad = 0;
+  bad += memcmp(&state[1].dc_re, &state[2].dc_re, 4) != 0;
+  bad += memcmp(&state[1].dc_im, &state[2].dc_im, 4) != 0;
+  bad += state[1].dc_index != state[2].dc_index;
+  bad += memcmp(state[1].dcr_re, state[2].dcr_re, sizeof(state[1].dcr_re)) != 0;
+  bad += memcmp(state[1].dcr_im, state[2].dcr_im, sizeof(state[1].dcr_im)) != 0;
+  bad += uwc[1] != uwc[2] || uwc[0] != uwc[1];
+  const int k = uwc[1] < uwmax ? uwc[1] : uwmax;
+  for (int i = 0; i < k; ++i) {
+    const rfid_window &a = uw[(size_t)uwmax + i], &b = uw[(size_t)2 * uwmax + i], &c0 = uw[(size_t)i];
+    bad += a.start != b.start || a.type != b.type || a.seq != b.seq || memcmp(&a.dc_re, &b.dc_re, 4) != 0 || memcmp(&a.dc_im, &b.dc_im, 4) != 0;
+    bad += a.start != c0.start || a.type != c0.type;   // (the start of dc_est never moves a window)
+  }
+  *n_windows = k;
+  return bad;
+}
+
 // gate_scan_kernel in streaming mode (mode 1) on one call's worth of samples.
 // seek_type: -1 none, 0 SEEK_RN16, 1 SEEK_EPC applied before the scan (gate_impl.cc:112-123).
 int emu_gate_stream(void *state_blob, const float *in, int n_in, int seek_type, float *out, int *consumed,
