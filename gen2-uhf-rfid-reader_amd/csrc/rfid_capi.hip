@@ -427,14 +427,16 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
         HIPCHK(c, hipStreamSynchronize(c->stream));
         for (const GateUnit &r : runs) ae[(size_t)r.row] = got[(size_t)r.row];
         rep.avg_passes++;
-        if (dbg) fprintf(stderr, "[ls] t=%8.2f ms  avg pass %d runs=%d\n", ls_now_ms() - t_begin, rep.avg_passes, (int)runs.size());
+
         all = true;
         float t = 0.0f;
         bool chain_exact = true;   // every unit of this trace so far started from its true value
+        int dbg_first = -1, dbg_n0 = 0, dbg_n1 = 0, dbg_nbig = 0; long long dbg_dfirst = 0;
         for (int u = 0; u < U; ++u) {
           if (first_of_trace(u)) { t = start[(size_t)u].v[0]; chain_exact = true; }   // the fresh gate's 0, or the carried value
           const float sA = start[(size_t)u].v[0];
           const int64_t d = f_ord(t) - f_ord(sA);
+          if (dbg && !exact[(size_t)u]) { if (d == 0) dbg_n0++; else if (d == 1 || d == -1) dbg_n1++; else dbg_nbig++; if (d != 0 && dbg_first < 0) { dbg_first = u; dbg_dfirst = (long long)d; } }
           float pred;
           if (d == 0) pred = ae[(size_t)u];
           else if ((d & 1) == 0 || first_of_trace(u)) pred = f_from_ord(f_ord(ae[(size_t)u]) + d);
@@ -444,6 +446,8 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
           start[(size_t)u].v[0] = t;
           t = pred;
         }
+        if (dbg) fprintf(stderr, "[ls] t=%8.2f ms  avg pass %d runs=%d: d=0 %d, |d|=1 %d, |d|>1 %d; first d!=0 at unit %d (d=%lld)\n",
+                         ls_now_ms() - t_begin, rep.avg_passes, (int)runs.size(), dbg_n0, dbg_n1, dbg_nbig, dbg_first, dbg_dfirst);
       }
       if (!all) break;   // (gives up: sequential scan)
     }
