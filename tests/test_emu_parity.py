@@ -249,3 +249,20 @@ def test_emulated_dc_only_rerun_equals_full_gate_scan(emu_mod, oracle_mod, synth
     y = oracle_mod.fir(t)[: len(t) // 5 - 37]
     bad, nw = emu_mod.ls_dc_check(y, dc0[0], dc0[1])
     assert nw == 6 and bad == 0
+
+
+def test_emulated_avg_pass_from_cached_addends(emu_mod, oracle_mod, synth_mod):
+    """ls_avg_kernel: the addends (|x| - win_samples[win_index]) / 100 depend on the samples only; the first pass of the
+    long-stream front end caches them, later passes re-add them from another start value.  Both ways must give the same
+    avg_ampl bit for bit -- and the value the oracle's gate ends with when started fresh (start 0)."""
+    t = synth_mod.make_trace(n_rounds=2, seed=23, sigma=0.02).samples
+    y = oracle_mod.fir(t)[: len(t) // 5 - 11]
+    out = emu_mod.ls_avg_check(y, 0.0).view(np.uint32)
+    assert out[0] == out[1] and out[2] == out[3]
+    amp = np.hypot(y.real.astype(np.float32), y.imag.astype(np.float32)).astype(np.float32)   # (hypotf, as the gate)
+    avg = np.float32(0.0)
+    ring = np.zeros(100, dtype=np.float32)
+    for i, a in enumerate(amp):                                                              # gate_impl.cc:130-134
+        avg = np.float32(avg + np.float32(np.float32(a - ring[i % 100]) / np.float32(100.0)))
+        ring[i % 100] = a
+    assert out[0] == avg.view(np.uint32)

@@ -93,6 +93,14 @@ def ls_dc_check(y: np.ndarray, dc_re0: float, dc_im0: float):
     return bad, nw.value
 
 
+def ls_avg_check(y: np.ndarray, start: float) -> np.ndarray:
+    """-> [end computed, end from the addend cache, end from the cache for start + 1 ulp, end computed for start + 1 ulp]"""
+    y = np.ascontiguousarray(y, dtype=np.complex64)
+    out = np.zeros(4, dtype=np.float32)
+    lib().emu_ls_avg_check(C.c_void_p(y.ctypes.data), len(y), C.c_float(start), C.c_void_p(out.ctypes.data))
+    return out
+
+
 def mf_stream(staging: np.ndarray, in_off: int, n_out: int) -> np.ndarray:
     buf = np.zeros(len(staging) + 2, dtype=np.complex64)
     off = (16 - buf.ctypes.data % 16) % 16 // 8

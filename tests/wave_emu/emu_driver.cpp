@@ -236,6 +236,34 @@ int emu_ls_dc_check(const float *y_in, int n, float dc_re0, float dc_im0, int *n
   return bad;
 }
 
+// ls_avg_kernel on ONE unit (the whole of y, fresh amplitude ring): the first pass computes the addends from the samples
+// and caches them, a later pass re-adds the cached addends.  out[0] / out[1] = avg_ampl at the end of the unit from `start`
+// computed / from the cache; out[2] = from the cache with start + 1 ulp (variant B), out[3] = computed with start + 1 ulp.
+int emu_ls_avg_check(const float *y_in, int n, float start, float *out) {
+  const float2 *y = reinterpret_cast<const float2 *>(y_in);
+  uint32_t sb;
+  memcpy(&sb, &start, 4);
+  sb += 1;
+  float start_b;
+  memcpy(&start_b, &sb, 4);
+  const float st[2] = {start, start_b};
+  float end[2] = {0.0f, 0.0f};
+  std::vector<float> cache((size_t)n, -1.0f);
+  GateUnit un[2];
+  for (int r = 0; r < 2; ++r) { un[r].stream = 0; un[r].pos0 = 0; un[r].len = n; un[r].row = r; }
+  LsAvgArgs a;
+  a.y = y; a.y_stride = n; a.units = un; a.n_runs = 2; a.start = st; a.end = end; a.carry = nullptr;
+  a.dcache = cache.data(); a.n_units = 1;
+  a.cache_mode = 1;
+  emu::launch(emu::Idx3{2, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { ls_avg_kernel(a); });
+  out[0] = end[0]; out[3] = end[1];
+  end[0] = end[1] = 0.0f;
+  a.cache_mode = 2;
+  emu::launch(emu::Idx3{2, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { ls_avg_kernel(a); });
+  out[1] = end[0]; out[2] = end[1];
+  return 0;
+}
+
 // gate_scan_kernel in streaming mode (mode 1) on one call's worth of samples.
 // seek_type: -1 none, 0 SEEK_RN16, 1 SEEK_EPC applied before the scan (gate_impl.cc:112-123).
 int emu_gate_stream(void *state_blob, const float *in, int n_in, int seek_type, float *out, int *consumed,
