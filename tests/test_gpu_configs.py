@@ -163,3 +163,36 @@ def test_config4_hbm_capacity_shard(gpu_ctx, oracle_mod, synth_mod):
         gpu_ctx.batch_plan(1, 4096)
         del data
         torch.cuda.empty_cache()
+
+
+def test_front_end_is_chosen_by_cost_estimate(synth_mod):
+    """Mode 1 of rfid_batch_set_long_stream (the default): the long-stream front end runs when it is expected to beat the
+    fused one -- one trace of 80 inventory rounds (1.2 M raw samples) is cut into units; 128 replicas of it are not
+    (the fused front end serves up to 1024 traces side by side).  Same windows and results either way."""
+    import rfid
+    import torch
+    t = synth_mod.make_trace(n_rounds=80, fixed_q=0, tag_ids=(0x3C,), sigma=0.0, seed=31, noise=False, render=False)
+    ctx = rfid.Context(device=0, max_num_queries=(1 << 31) - 2)
+    try:
+        data, L, stride = _gen_trace(ctx, t.plan, sigma=0.003, seed=8)
+        ctx.batch_plan(1, L)
+        ctx.batch_process_ptr(data.data_ptr(), stride, L, 0, want_scores=False)
+        ctx.batch_sync()
+        rep = ctx.batch_ls_report()
+        assert rep["verified"] == 1 and rep["units"] > 1 and ctx.batch_timing()["fused_front"] == 0, rep
+        w1, r1, _ = ctx.batch_windows()
+        assert ctx.batch_stats()[0]["n_epc_correct"] == len(t.slots)
+        B = 128
+        many = data[: 2 * stride].repeat(B)
+        torch.cuda.synchronize()
+        ctx.batch_plan(B, L)
+        ctx.batch_process_ptr(many.data_ptr(), stride, L, 0, want_scores=False)
+        ctx.batch_sync()
+        assert ctx.batch_ls_report()["units"] == 0 and ctx.batch_timing()["fused_front"] == 1
+        w, r, _ = ctx.batch_windows()
+        for b, (wb, rb, _sb) in enumerate(parity.split_by_stream(w, r, None, B)):
+            wb = wb.copy()
+            wb["stream"] = 0
+            assert wb.tobytes() == w1.tobytes() and rb.tobytes() == r1.tobytes(), b
+    finally:
+        ctx.close()
