@@ -537,7 +537,7 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
         for (const GateUnit &r : runs_dc) eh[(size_t)r.row] = got[(size_t)r.row];
         // ---- chain the units of every trace: true start of unit u+1 = (predicted) end of unit u ----
         bool all_exact = true, chain_exact = true, fsm_chain = true;
-        int n_moved = 0;
+        int n_moved = 0, dbg_mism = 0;
         std::vector<LsStart> next(start);
         for (int u = 0; u < U; ++u) {
           if (first_of_trace(u)) { chain_exact = true; fsm_chain = true; }
@@ -564,6 +564,9 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
           }
           bool fsm_match = f_ord(t.v[0]) == f_ord(sA.v[0]);
           for (int k = 0; k < 6; ++k) if (t.f[k] != sA.f[k]) { exact = false; fsm_match = false; }
+          if (dbg && !fsm_match && round == 1 && dbg_mism++ < 4)
+            fprintf(stderr, "[ls]   unit %d start mismatch: avg %d | n %d/%d state %d/%d pulses %d/%d open %d/%d ung %d/%d type %d/%d\n", u,
+                    (int)(f_ord(t.v[0]) != f_ord(sA.v[0])), t.f[0], sA.f[0], t.f[1], sA.f[1], t.f[2], sA.f[2], t.f[3], sA.f[3], t.f[4], sA.f[4], t.f[5], sA.f[5]);
           if (!fsm_match) fsm_chain = false;
           if (fsm_chain) fsm_final[(size_t)u] = 1;
           pred.f[0] = eh[u].n_samples; pred.f[1] = eh[u].signal_state; pred.f[2] = eh[u].num_pulses; pred.f[3] = eh[u].gate_open;

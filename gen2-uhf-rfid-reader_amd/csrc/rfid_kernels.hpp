@@ -26,6 +26,11 @@ constexpr int WIN_LEN = 100;       // gate_impl.cc:52  WIN_SIZE_D(250 us) * 0.4
 constexpr int DC_LEN = 48;         // gate_impl.cc:53  DC_SIZE_D(120 us) * 0.4
 constexpr int T1_SAMPLES = 96;     // gate_impl.cc:48  T1_D(240 us) * 0.4
 constexpr int PW_HALF = 2;         // gate_impl.cc:157 n_samples_PW(4) / 2
+// While the gate is closed, n_samples (gate_impl.cc:145-180) is only ever compared with PW/2 = 2 and T1 = 96, so the
+// scan lets it saturate: every value >= N_SAT behaves like N_SAT.  That makes the state machine's state at an idle
+// point a known constant (long-stream front end: the cuts lie where the count has saturated).
+constexpr int GATE_N_SAT = 128;
+static_assert(GATE_N_SAT > T1_SAMPLES && GATE_N_SAT > PW_HALF, "the saturated count must pass every comparison");
 constexpr int NUM_PULSES_CMD = 5;  // global_vars.h:99
 constexpr int RN16_WIN = 250;      // gate_impl.cc:121 (17+6)*10 + 2*10
 constexpr int EPC_WIN = 1370;      // gate_impl.cc:115 (129+6)*10 + 2*10
@@ -559,6 +564,7 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateSlot *slot, co
     // streaming mode stopped inside the step: avg_ampl carries only over the samples actually consumed
     if (g.stop) g.avg_c = (nvalid > 0) ? wv::readlane(avg, nvalid - 1) : avg_in;
   }
+  if (!g.f_open && g.f_n > GATE_N_SAT) g.f_n = GATE_N_SAT;
   // hand the step to the back wave (lane 0 writes after this wave's earlier LDS writes: in-order queue)
   wv::lds_store_desc(&slot->b_flags, ((closedmask != 0) ? 1 : 0) | (g.stop ? 2 : 0), nvalid, closedmask, openmask,
                      open_lane | (open_type << 8), lane);
@@ -1064,7 +1070,9 @@ RFID_KERNEL_OCC(GATE_THREADS, GATE_WAVES_PER_SIMD) void front_end_fused_kernel(G
 //     Units are cut where the gate's state machine is in its idle state: closed, POS_EDGE, no pulses counted, the
 //     last 48 samples closed (then the two rings hold exactly the preceding samples) -- found here from the data.
 // =========================================================================================
-constexpr int LS_QUIET = EPC_WIN + T1_SAMPLES + 1 + 100 + DC_LEN;   // 1615: a window opened by the last command has closed, + ring fill
+constexpr int LS_QUIET = EPC_WIN + T1_SAMPLES + 1 + WIN_LEN + DC_LEN;   // 1615: a window opened by the last command has closed,
+                                                                        // both rings have refilled and n_samples has saturated since
+static_assert(GATE_N_SAT < WIN_LEN + DC_LEN - 1, "n_samples must have saturated at every cut (147 samples after a window at least)");
 
 struct LsCutArgs {
   const float2 *y;
@@ -1173,7 +1181,7 @@ RFID_KERNEL(64) void ls_init_kernel(LsInitArgs a) {
     st->avg_ampl = (float)(sa / WIN_LEN);
     st->dc_re = (float)(sr / DC_LEN);
     st->dc_im = (float)(si / DC_LEN);
-    st->n_samples = LS_QUIET;          // any value: irrelevant while POS_EDGE with no pulses counted
+    st->n_samples = GATE_N_SAT;        // saturated: no edge and no window end in the last GATE_N_SAT samples
     st->signal_state = 1;              // POS_EDGE
     st->num_pulses = 0;
     st->gate_open = 0;
