@@ -1086,7 +1086,7 @@ struct LsCutArgs {
 };
 
 // one wave per (trace, nominal boundary j): the first position p >= j*chunk whose LS_QUIET preceding samples all have
-// |y|^2 >= 1/4 of the largest |y|^2 seen in the look-back region (carrier, no reader command), or -1
+// |y|^2 >= 0.72 of the largest |y|^2 seen in the look-back region (carrier, no reader command), or -1
 RFID_KERNEL(64) void ls_cut_kernel(LsCutArgs a) {
   const int lane = wv::lane_id();
   const int s = (int)blockIdx.y, j = (int)blockIdx.x + 1;
@@ -1108,7 +1108,9 @@ RFID_KERNEL(64) void ls_cut_kernel(LsCutArgs a) {
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) { const float o = wv::shfl_xor(ref, off); ref = (o > ref) ? o : ref; }
-  const float theta = 0.25f * ref;
+  // (0.85 of the largest amplitude: above the gate's own 0.75 avg_ampl test, so that the first, still high samples of
+  // a reader command's falling ramp do not pass for carrier -- the state machine would already be at NEG_EDGE there)
+  const float theta = 0.7225f * ref;
   int run = 0, found = -1;
   int end = P + a.limit;
   if (end > n) end = n;
