@@ -47,7 +47,7 @@ struct rfid_ctx {
   DevBuf s_in, s_out;
   DevBuf synth_tab;               // slot table of rfid_synth_gen2
   // long-stream front end (few long traces cut into concurrently scanned units)
-  DevBuf ls_cut, ls_units, ls_runs, ls_tmpl, ls_state, ls_uw, ls_uwc, ls_heads, ls_seq0, ls_gath, ls_rec, ls_dcache;
+  DevBuf ls_cut, ls_units, ls_runs, ls_tmpl, ls_state, ls_uw, ls_uwc, ls_heads, ls_seq0, ls_gath, ls_rec, ls_dcache, ls_avgbuf, ls_cutf;
   int ls_mode = 1;                // 0 never, 1 automatic, 2 whenever a trace can be cut
   // whole-chain streaming (rfid_stream_*)
   struct StreamIO {
@@ -220,6 +220,8 @@ const int LS_MAX_ROUNDS = 10;
 // 2.2 G-sample trace: 2048 units 36.5 ms, 4096 37.0, 8192 34.1, 16384 34.6, 32768 45.8 (more cuts, more rounds)
 const int LS_TARGET_UNITS = 8192;
 const int LS_MIN_CHUNK = 6144;
+const int LS_AVG_SPLIT = 4;          // avg_ampl passes: a gate unit in about this many pieces ...
+const int LS_AVG_MIN_PIECE = 4096;   // ... of at least this many samples (the idle points are >= 1615 samples long)
 
 struct LsStart {  // what a unit needs from its past besides the rings: the three recurrences + the state machine's scalars
   float v[3];     // avg_ampl, dc_re, dc_im
@@ -319,6 +321,22 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
   HIPCHK(c, hipMemcpyAsync(cut.data(), c->ls_cut.p, sizeof(int) * cut.size(), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::vector<char> banned(cut.size(), 0);
+  // a finer grid of idle points for the avg_ampl passes alone (phase 1 below)
+  int64_t chunk_f = ((chunk / LS_AVG_SPLIT) + 63) & ~63LL;
+  if (chunk_f < LS_AVG_MIN_PIECE) chunk_f = LS_AVG_MIN_PIECE;
+  std::vector<int> cutf;
+  int max_bf = 0;
+  if (chunk_f * 2 <= chunk) {
+    for (int64_t v : nd) { const int nb = (int)(v / chunk_f) + 1; if (nb > max_bf) max_bf = nb; }
+    if ((rc = grow(c, c->ls_cutf, sizeof(int) * (size_t)B * (size_t)max_bf))) return rc;
+    LsCutArgs cf = ca;
+    cf.chunk = (int)chunk_f; cf.limit = (int)(chunk_f / 2); cf.max_b = max_bf; cf.cut = (int *)c->ls_cutf.p;
+    hipLaunchKernelGGL(ls_cut_kernel, dim3((unsigned)(max_bf - 1), (unsigned)B), dim3(64), 0, c->stream, cf);
+    HIPCHK(c, hipGetLastError());
+    cutf.resize((size_t)B * (size_t)max_bf);
+    HIPCHK(c, hipMemcpyAsync(cutf.data(), c->ls_cutf.p, sizeof(int) * cutf.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   lap("cut points found");
   std::map<int64_t, LsStart> known;   // predictions carried over when a cut is withdrawn and the units are rebuilt
 
@@ -395,61 +413,102 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
     runs.reserve(2 * (size_t)U);
 
     // ---- phase 1: avg_ampl alone (cheap kernel): exact value at every cut ---------------------------------------------
+    // A pass takes as long as ONE unit takes (a chain of dependent steps) and avg_ampl needs nothing of the state machine,
+    // so its passes run on a finer grid: every gate unit in pieces that end at idle points too (away from them avg_ampl
+    // is on the move across binades and the chained predictions fail every few pieces).  A gate unit's value is its first
+    // piece's; a piece's first guess is the mean of the 100 amplitudes before it (formed by the kernel).
     {
-      std::vector<float> av(2 * (size_t)U), ae(2 * (size_t)U);
-      std::vector<char> exact((size_t)U, 0);
+      std::vector<GateUnit> au;          // the pieces, in trace order
+      std::vector<int> piece0((size_t)U);
+      for (int u = 0; u < U; ++u) {
+        const GateUnit &un = units[(size_t)u];
+        piece0[(size_t)u] = (int)au.size();
+        int pos = un.pos0;
+        if (max_bf > 0) {
+          const int *cf = &cutf[(size_t)un.stream * (size_t)max_bf];
+          for (int j = (int)(un.pos0 / chunk_f); j < max_bf; ++j) {
+            const int p = (j >= 1) ? cf[j] : -1;
+            if (p >= un.pos0 + un.len) break;
+            if (p <= pos) continue;
+            GateUnit q; q.stream = un.stream; q.pos0 = pos; q.len = p - pos; q.row = 0;
+            au.push_back(q);
+            pos = p;
+          }
+        }
+        GateUnit q; q.stream = un.stream; q.pos0 = pos; q.len = un.pos0 + un.len - pos; q.row = 0;
+        au.push_back(q);
+      }
+      const int AU = (int)au.size();
+      auto a_first = [&](int i) { return au[(size_t)i].pos0 == 0; };
+      std::vector<float> astart((size_t)AU, std::numeric_limits<float>::quiet_NaN());
+      for (int u = 0; u < U; ++u) astart[(size_t)piece0[(size_t)u]] = start[(size_t)u].v[0];   // (ring mean from the template, 0, carried or known)
+      std::vector<float> av(2 * (size_t)AU), ae(2 * (size_t)AU), got(4 * (size_t)AU);
+      std::vector<char> exact((size_t)AU, 0);
+      if ((rc = grow(c, c->ls_avgbuf, sizeof(float) * 4 * (size_t)AU + sizeof(GateUnit) * 2 * (size_t)AU))) return rc;
+      float *d_av = (float *)c->ls_avgbuf.p, *d_ae = d_av + 2 * (size_t)AU;
+      GateUnit *d_aruns = (GateUnit *)(d_ae + 2 * (size_t)AU);
       bool all = false;
+      // variant B (start + 1 ulp) serves corrections by an odd number of ulps (the parity of the shift decides rounding
+      // ties).  After the first pass the corrections are usually even (a rounding that went the other way one binade up
+      // = 2 ulps here): B then runs only in the pass after one that met an odd correction; without it the prediction
+      // for an odd correction is just less likely to hold, and every value is verified by a run from it anyway.
+      bool with_b = true;
       for (int round = 1; round <= 3 * LS_MAX_ROUNDS && !all; ++round) {
         runs.clear();
-        for (int v = 0; v < 2; ++v)
-          for (int u = 0; u < U; ++u) {
-            if (exact[(size_t)u]) continue;
-            if (v == 1 && first_of_trace(u)) continue;
-            GateUnit r = units[(size_t)u];
-            r.row = v * U + u;
+        for (int v = 0; v < (with_b ? 2 : 1); ++v)
+          for (int i = 0; i < AU; ++i) {
+            if (exact[(size_t)i]) continue;
+            if (v == 1 && a_first(i)) continue;
+            GateUnit r = au[(size_t)i];
+            r.row = v * AU + i;
             runs.push_back(r);
-            av[(size_t)r.row] = v ? f_from_ord(f_ord(start[(size_t)u].v[0]) + 1) : start[(size_t)u].v[0];
+            const float s0 = astart[(size_t)i];
+            av[(size_t)r.row] = (v && s0 == s0) ? f_from_ord(f_ord(s0) + 1) : s0;
           }
-        if ((rc = grow(c, c->ls_heads, sizeof(int) * LS_HEAD_WORDS * 2 * (size_t)U + sizeof(float) * 4 * (size_t)U))) return rc;
-        float *d_av = (float *)((int *)c->ls_heads.p + LS_HEAD_WORDS * 2 * (size_t)U), *d_ae = d_av + 2 * (size_t)U;
-        if ((rc = grow(c, c->ls_runs, sizeof(GateUnit) * 2 * (size_t)U))) return rc;
-        HIPCHK(c, hipMemcpyAsync(d_av, av.data(), sizeof(float) * 2 * (size_t)U, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->ls_runs.p, runs.data(), sizeof(GateUnit) * runs.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_av, av.data(), sizeof(float) * 2 * (size_t)AU, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_aruns, runs.data(), sizeof(GateUnit) * runs.size(), hipMemcpyHostToDevice, c->stream));
         LsAvgArgs aa;
-        aa.y = c->d_y; aa.y_stride = c->y_stride; aa.units = (const GateUnit *)c->ls_runs.p; aa.n_runs = (int)runs.size();
+        aa.y = c->d_y; aa.y_stride = c->y_stride; aa.units = d_aruns; aa.n_runs = (int)runs.size();
         aa.start = d_av; aa.end = d_ae; aa.carry = opt.carry ? c->d_gstate : nullptr;
-        // the addends are data only: written by the first pass of an attempt (all units run), read by the later ones
-        aa.dcache = (float *)c->ls_dcache.p; aa.cache_mode = (round == 1) ? 1 : 2; aa.n_units = U;
+        // the addends are data only: written by the first pass of an attempt (all pieces run), read by the later ones
+        aa.dcache = (float *)c->ls_dcache.p; aa.cache_mode = (round == 1) ? 1 : 2; aa.n_units = AU;
         hipLaunchKernelGGL(ls_avg_kernel, dim3((unsigned)runs.size()), dim3(64), 0, c->stream, aa);
         HIPCHK(c, hipGetLastError());
-        std::vector<float> got(2 * (size_t)U);
-        HIPCHK(c, hipMemcpyAsync(got.data(), d_ae, sizeof(float) * 2 * (size_t)U, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(got.data(), d_av, sizeof(float) * 4 * (size_t)AU, hipMemcpyDeviceToHost, c->stream));   // starts (first guesses filled in) + ends
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (const GateUnit &r : runs) ae[(size_t)r.row] = got[(size_t)r.row];
+        for (const GateUnit &r : runs) {
+          ae[(size_t)r.row] = got[2 * (size_t)AU + (size_t)r.row];
+          if (r.row < AU) astart[(size_t)r.row] = got[(size_t)r.row];
+        }
         rep.avg_passes++;
 
         all = true;
         float t = 0.0f;
-        bool chain_exact = true;   // every unit of this trace so far started from its true value
-        int dbg_first = -1, dbg_n0 = 0, dbg_n1 = 0, dbg_nbig = 0; long long dbg_dfirst = 0;
-        for (int u = 0; u < U; ++u) {
-          if (first_of_trace(u)) { t = start[(size_t)u].v[0]; chain_exact = true; }   // the fresh gate's 0, or the carried value
-          const float sA = start[(size_t)u].v[0];
+        bool chain_exact = true;   // every piece of this trace so far started from its true value
+        bool odd_seen = false;
+        int dbg_first = -1, dbg_n0 = 0, dbg_nbig = 0; long long dbg_dfirst = 0;
+        for (int i = 0; i < AU; ++i) {
+          if (a_first(i)) { t = astart[(size_t)i]; chain_exact = true; }   // the fresh gate's 0, or the carried value
+          const float sA = astart[(size_t)i];
           const int64_t d = f_ord(t) - f_ord(sA);
-          if (dbg && !exact[(size_t)u]) { if (d == 0) dbg_n0++; else if (d == 1 || d == -1) dbg_n1++; else dbg_nbig++; if (d != 0 && dbg_first < 0) { dbg_first = u; dbg_dfirst = (long long)d; } }
+          if (dbg && !exact[(size_t)i]) { if (d == 0) dbg_n0++; else dbg_nbig++; if (d != 0 && dbg_first < 0) { dbg_first = i; dbg_dfirst = (long long)d; } }
           float pred;
-          if (d == 0) pred = ae[(size_t)u];
-          else if ((d & 1) == 0 || first_of_trace(u)) pred = f_from_ord(f_ord(ae[(size_t)u]) + d);
-          else pred = f_from_ord(f_ord(ae[(size_t)U + (size_t)u]) + (d - 1));
+          if (d == 0) pred = ae[(size_t)i];
+          else if ((d & 1) == 0 || a_first(i) || !with_b) pred = f_from_ord(f_ord(ae[(size_t)i]) + d);
+          else pred = f_from_ord(f_ord(ae[(size_t)AU + (size_t)i]) + (d - 1));
+          if ((d & 1) != 0 && !exact[(size_t)i]) odd_seen = true;
           if (d != 0) chain_exact = false;
-          if (chain_exact) exact[(size_t)u] = 1; else all = false;
-          start[(size_t)u].v[0] = t;
+          if (chain_exact) exact[(size_t)i] = 1; else all = false;
+          astart[(size_t)i] = t;
           t = pred;
         }
-        if (dbg) fprintf(stderr, "[ls] t=%8.2f ms  avg pass %d runs=%d: d=0 %d, |d|=1 %d, |d|>1 %d; first d!=0 at unit %d (d=%lld)\n",
-                         ls_now_ms() - t_begin, rep.avg_passes, (int)runs.size(), dbg_n0, dbg_n1, dbg_nbig, dbg_first, dbg_dfirst);
+        if (dbg) fprintf(stderr, "[ls] t=%8.2f ms  avg pass %d runs=%d (%s) of %d pieces: d=0 %d, d!=0 %d%s; first d!=0 at piece %d (d=%lld)\n",
+                         ls_now_ms() - t_begin, rep.avg_passes, (int)runs.size(), with_b ? "A+B" : "A", AU, dbg_n0, dbg_nbig,
+                         odd_seen ? ", odd ones among them" : "", dbg_first, dbg_dfirst);
+        with_b = odd_seen;
       }
       if (!all) break;   // (gives up: sequential scan)
+      for (int u = 0; u < U; ++u) start[(size_t)u].v[0] = astart[(size_t)piece0[(size_t)u]];
     }
     lap("avg_ampl settled");
 
@@ -734,7 +793,7 @@ int rfid_ctx_destroy(rfid_ctx *c) {
   free_plan(c);
   void *ptrs[] = {c->d_gate1, c->d_io, c->d_swin, c->d_scount, c->d_sres, c->d_sscores, c->s_in.p, c->s_out.p,
                   c->synth_tab.p, c->ls_cut.p, c->ls_units.p, c->ls_runs.p, c->ls_tmpl.p, c->ls_state.p, c->ls_uw.p, c->ls_uwc.p,
-                  c->ls_heads.p, c->ls_seq0.p, c->ls_gath.p, c->ls_rec.p, c->ls_dcache.p};
+                  c->ls_heads.p, c->ls_seq0.p, c->ls_gath.p, c->ls_rec.p, c->ls_dcache.p, c->ls_avgbuf.p, c->ls_cutf.p};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < 5; ++i)

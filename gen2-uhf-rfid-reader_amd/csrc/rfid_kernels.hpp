@@ -1202,7 +1202,8 @@ struct LsAvgArgs {
   int64_t y_stride;
   const GateUnit *units;   // [n_runs]: row = index into start / end
   int n_runs;
-  const float *start;      // avg_ampl at the unit's first sample
+  float *start;            // avg_ampl at the unit's first sample; NaN = not known yet: the run starts from the mean of the
+                           // 100 amplitudes before the unit (+ 1 ulp for rows >= n_units, variant B) and writes that back
   float *end;              // avg_ampl after its last sample
   const GateState *carry;  // optional [n_streams]: amplitude ring a trace's first unit starts with (else all zero)
   // the addends (|x| - win_samples[win_index]) / 100 depend on the samples only, not on where avg_ampl starts: the
@@ -1234,6 +1235,15 @@ RFID_KERNEL(64) void ls_avg_kernel(LsAvgArgs a) {
     a2 = (j2 <= WIN_LEN) ? cs->win[(wi - j2 + 2 * WIN_LEN) % WIN_LEN] : 0.0f;
   }
   float avg = wv::uniform(a.start[row]);
+  if (avg != avg) {
+    // first guess: the ring mean (what avg_ampl is up to its rounding drift), lanes 28..63 of a2 and all of a1
+    float part = a1 + ((lane >= 28) ? a2 : 0.0f);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) part += wv::shfl_xor(part, off);
+    avg = wv::uniform(part) / WIN_LEN_F;
+    if (row >= a.n_units) avg = wv::u2f(wv::f2u(avg) + 1u);   // (amplitudes are >= 0: the next binary32 value up)
+    if (lane == 0) a.start[row] = avg;
+  }
   const int nsteps = (n + 63) >> 6;
   if (a.cache_mode == 2) {
     const float *dc = a.dcache + (int64_t)wv::uniform(un.stream) * a.y_stride + pos0;

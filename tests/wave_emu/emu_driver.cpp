@@ -246,7 +246,7 @@ int emu_ls_avg_check(const float *y_in, int n, float start, float *out) {
   sb += 1;
   float start_b;
   memcpy(&start_b, &sb, 4);
-  const float st[2] = {start, start_b};
+  float st[2] = {start, start_b};
   float end[2] = {0.0f, 0.0f};
   std::vector<float> cache((size_t)n, -1.0f);
   GateUnit un[2];
