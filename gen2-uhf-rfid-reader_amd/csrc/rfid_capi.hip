@@ -254,12 +254,12 @@ double ls_now_ms() {
 }
 // Automatic choice between the two front ends (mode 1), from their measured rates on MI355X: the fused front end
 // runs up to 1024 traces side by side at ~10.2 ns per decimated sample of the LONGEST trace; the long-stream front end
-// costs ~1 ms of passes whose length does not depend on the data plus ~0.065 ns per decimated sample of ALL traces
-// (two full scans + the avg_ampl / dc_est passes).  64 traces of 215 k samples: 1.8 vs 2.2 ms; 128: 2.7 vs 2.25 ms;
-// one trace of 6 M samples: 1.3 vs 61 ms.
+// costs ~0.8 ms of passes whose length does not depend on the data plus ~0.058 ns per decimated sample of ALL traces
+// (one full scan + the avg_ampl / dc_est passes).  64 traces of 215 k samples: 1.55 vs 2.2 ms; 128: 2.5 vs 2.25 ms;
+// one trace of 6 M samples: 1.2 vs 61 ms.
 bool ls_pays_off(int B, int64_t n_dec) {
   const double t_seq = 1.02e-5 * (double)n_dec * (double)((B + 1023) / 1024);
-  const double t_ls = 1.0 + 6.5e-8 * (double)B * (double)n_dec;
+  const double t_ls = 0.8 + 5.8e-8 * (double)B * (double)n_dec;
   return t_ls < 0.9 * t_seq;
 }
 struct LsOpts {
