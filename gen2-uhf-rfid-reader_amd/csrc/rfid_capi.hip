@@ -521,11 +521,12 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
     std::vector<GateUnit> runs_dc;
     std::vector<LsHead> got;
     bool restart = false, accepted = false;
+    bool dc_odd = true;   // the last pass met a correction of dc_est by an odd number of ulps (then variant B is worth its runs)
     for (int round = 1; round <= LS_MAX_ROUNDS && !restart && !accepted; ++round) {
       // both variants (dc_est starts s and s + 1 ulp) while predictions still move; a round that is expected to
       // confirm runs variant A alone first
       for (int pass = 0; pass < 2 && !accepted && !restart; ++pass) {
-        const bool with_b = (round == 2) || pass == 1;
+        const bool with_b = (round == 2) || (pass == 1 && dc_odd);
         if (round <= 2 && pass == 1) break;
         runs.clear();
         runs_dc.clear();
@@ -595,7 +596,7 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
         for (const GateUnit &r : runs) eh[(size_t)r.row] = got[(size_t)r.row];
         for (const GateUnit &r : runs_dc) eh[(size_t)r.row] = got[(size_t)r.row];
         // ---- chain the units of every trace: true start of unit u+1 = (predicted) end of unit u ----
-        bool all_exact = true, chain_exact = true, fsm_chain = true;
+        bool all_exact = true, chain_exact = true, fsm_chain = true, odd_now = false;
         int n_moved = 0, dbg_mism = 0;
         std::vector<LsStart> next(start);
         for (int u = 0; u < U; ++u) {
@@ -617,6 +618,7 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
           for (int k = 0; k < 3; ++k) {
             const int64_t d = f_ord(t.v[k]) - f_ord(sA.v[k]);
             if (d != 0) exact = false;
+            if (k > 0 && (d & 1) != 0) odd_now = true;
             if (d == 0) pred.v[k] = eA[k];
             else if (k == 0 || (d & 1) == 0 || !with_b || first_of_trace(u)) pred.v[k] = f_from_ord(f_ord(eA[k]) + d);
             else pred.v[k] = f_from_ord(f_ord(k == 1 ? eh[U + u].dcr : eh[U + u].dci) + (d - 1));
@@ -648,6 +650,7 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
                   ls_now_ms() - t_begin, attempt, round, pass, (int)with_b, n_run, n_dc, n_moved, first_bad, (long long)dmax);
         }
         start = next;
+        dc_odd = odd_now;
         if (all_exact) {
           // ---- what the rings need at every cut: the 48 samples before it all "closed" (then dc_samples holds exactly
           //      those samples, as the template does; win_samples always holds the last 100 amplitudes) ----
