@@ -1059,7 +1059,8 @@ int rfid_batch_stats(rfid_ctx *c) {
   a.max_num_queries = c->prm.max_num_queries; a.number_unique_tags = c->prm.number_unique_tags;
   a.out = c->d_stats;
   if (!c->ev_valid[3]) { HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->ev_valid[3] = true; }
-  hipLaunchKernelGGL(stream_stats_kernel, dim3((unsigned)c->B), dim3(64), 0, c->stream, a);
+  // one wave per trace; sixteen when a trace can hold thousands of windows (few long traces)
+  hipLaunchKernelGGL(stream_stats_kernel, dim3((unsigned)c->B), dim3(c->wmax > 2048 ? 64 * STATS_MAX_WAVES : 64), 0, c->stream, a);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
   c->ev_valid[4] = true;
@@ -1087,11 +1088,14 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
   memset(&c->ls_rep, 0, sizeof(c->ls_rep));
   if (nch < 2 && c->ls_mode != 0 && n_out >= 2 * LS_MIN_CHUNK && (c->ls_mode == 2 || ls_pays_off(c->B, n_out))) {
     // few long traces: matched filter, then the gate scan over concurrently scanned units of each trace
+    const double t_dbg = getenv("RFID_LS_DEBUG") ? ls_now_ms() : 0.0;
     int rc = rfid_batch_mf(c, d_raw, raw_stride, n_raw, d_lens);
     if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_gstate, 0, sizeof(GateState) * (size_t)c->B, c->stream));
     int done = 0;
+    if (t_dbg != 0.0) fprintf(stderr, "[ls] pass: %.2f ms of host time before the long-stream front end\n", ls_now_ms() - t_dbg);
     if ((rc = ls_front_end(c, n_out, &done))) return rc;
+    if (t_dbg != 0.0) fprintf(stderr, "[ls] pass: %.2f ms when it returned\n", ls_now_ms() - t_dbg);
     if (done) {
       HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
       c->ev_valid[2] = true;

@@ -2040,51 +2040,75 @@ struct StatsArgs {
   rfid_stream_stats *out;         // [n_streams]
 };
 
-// One wavefront per trace, 64 windows per step.  The replay is sequential only through the TERMINATED cut-off
-// (gate_impl.cc:101-109: checked before every window against n_queries_sent and the number of distinct tag ids
-// read so far); both are monotone counts, so the cut-off index is found first -- n_queries_sent passes its limit
-// right after the max_num_queries-th EPC window, the distinct-id count after the first read of the
-// (number_unique_tags + 1)-th new id -- and everything before it is plain counting (a trace may hold hundreds of
-// thousands of windows: a one-lane replay cost 40 ms for the 320 000 windows of a 10 000-round inventory).
-RFID_KERNEL(64) void stream_stats_kernel(StatsArgs a) {
+// One workgroup per trace (one wavefront, or sixteen when traces hold many windows: the host picks), 64 windows per
+// wave and step.  The replay is sequential only through the TERMINATED cut-off (gate_impl.cc:101-109: checked before
+// every window against n_queries_sent and the number of distinct tag ids read so far); both are monotone counts, so the
+// cut-off index is found first -- n_queries_sent passes its limit right after the max_num_queries-th EPC window, the
+// distinct-id count after the first read of the (number_unique_tags + 1)-th new id -- and everything before it is plain
+// counting, each wave over its own contiguous share of the windows (a trace may hold hundreds of thousands: a one-lane
+// replay cost 40 ms for the 320 000 windows of a 10 000-round inventory, one wave 4 ms).
+constexpr int STATS_MAX_WAVES = 16;
+RFID_KERNEL(64 * STATS_MAX_WAVES) void stream_stats_kernel(StatsArgs a) {
   RFID_SHARED int hist[256];
   RFID_SHARED int first[256];      // index of the first CRC-verified read of each tag id
+  RFID_SHARED int epc_cnt[STATS_MAX_WAVES];
+  RFID_SHARED int sh_kq, sh_nepc, sh_nok;
   const int lane = wv::lane_id();
+  const int wave = wv::uniform((int)(threadIdx.x >> 6)), nwv = (int)(blockDim.x >> 6);
   const int s = (int)blockIdx.x;
   if (s >= a.n_streams) return;
   rfid_stream_stats *o = a.out + s;
-  for (int i = lane; i < 256; i += 64) { hist[i] = 0; first[i] = 0x7fffffff; }
-  wv::wave_sync();
+  for (int i = (int)threadIdx.x; i < 256; i += (int)blockDim.x) { hist[i] = 0; first[i] = 0x7fffffff; }
+  if (threadIdx.x == 0) { sh_kq = 0x7fffffff; sh_nepc = 0; sh_nok = 0; }
+  wv::block_sync();
   const int nw = wv::uniform(a.wcount[s]);
   const rfid_decode_result *rs = a.res + (int64_t)s * a.wmax;
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  // ---- pass 1: where the two limits are passed ----
-  int k_q = 0x7fffffff;            // first window index BEFORE which n_queries_sent > max_num_queries
-  int epc_seen = 0;
-  for (int base = 0; base < nw; base += 64) {
+  const int seg = (((nw + nwv - 1) / nwv) + 63) & ~63;            // windows per wave
+  const int k0 = wave * seg, k1 = (k0 + seg < nw) ? (k0 + seg) : nw;
+  // ---- pass 1: first reads of every id; EPC windows per wave ----
+  int epc_mine = 0;
+  for (int base = k0; base < k1; base += 64) {
     const int k = base + lane;
     int v = 0;
-    if (k < nw) {
+    if (k < k1) {
       const rfid_decode_result &r = rs[k];
       v = (r.type & 1) | ((r.crc_ok & 1) << 1) | ((r.tag_id & 255) << 2);
       if ((v & 3) == 3) wv::atomic_min(&first[(v >> 2) & 255], k);
     }
-    const uint64_t epc = wv::ballot((v & 1) != 0);
-    if (k_q == 0x7fffffff) {
-      // n_queries_sent = 1 + EPC windows so far (reader_impl.cc:259,335); it exceeds the limit once
-      // max_num_queries EPC windows have been processed
-      const int need = a.max_num_queries - epc_seen;           // that many more EPC windows
-      const int c = wv::popc64(epc);
-      if (need <= 0) k_q = base;
-      else if (c >= need) {
-        const uint64_t hit = wv::ballot(((epc >> lane) & 1ull) && wv::popc64(epc & lt) == need - 1);
-        k_q = base + wv::ffs64(hit) + 1;
+    epc_mine += wv::popc64(wv::ballot((v & 1) != 0));
+  }
+  if (lane == 0) epc_cnt[wave] = epc_mine;
+  wv::block_sync();
+  // n_queries_sent = 1 + EPC windows so far (reader_impl.cc:259,335); it exceeds the limit once max_num_queries EPC
+  // windows have been processed: k_q = the index right after the max_num_queries-th EPC window -- found by the wave
+  // whose share holds it
+  {
+    int before = 0;
+    for (int j = 0; j < wave; ++j) before += epc_cnt[j];
+    const int need = a.max_num_queries - before;                   // that many more EPC windows, counted from k0
+    if (a.max_num_queries <= 0) {
+      if (threadIdx.x == 0) sh_kq = 0;
+    } else if (need > 0 && need <= epc_mine) {
+      int seen = 0;
+      for (int base = k0; base < k1; base += 64) {
+        const int k = base + lane;
+        const bool is_epc = (k < k1) && (rs[k].type & 1);
+        const uint64_t epc = wv::ballot(is_epc);
+        const int c = wv::popc64(epc);
+        if (seen + c >= need) {
+          const uint64_t hit = wv::ballot(((epc >> lane) & 1ull) && wv::popc64(epc & lt) == need - seen - 1);
+          if (lane == 0) sh_kq = base + wv::ffs64(hit) + 1;
+          break;
+        }
+        seen += c;
       }
     }
-    epc_seen += wv::popc64(epc);
   }
-  wv::wave_sync();
+  wv::block_sync();
+  const int k_q = sh_kq;
   // the (number_unique_tags + 1)-th smallest first-read index: the distinct-id count exceeds the limit right after it
+  // (every wave works it out for itself: 256 ids)
   int k_u = 0x7fffffff;
   {
     int cand = 0x7fffffff;
@@ -2098,6 +2122,7 @@ RFID_KERNEL(64) void stream_stats_kernel(StatsArgs a) {
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { const int ot = wv::shfl_xor(cand, off); cand = (ot < cand) ? ot : cand; }
+    cand = wv::uniform(cand);
     if (cand != 0x7fffffff) k_u = cand + 1;
   }
   int k_term = (k_q < k_u) ? k_q : k_u;
@@ -2105,10 +2130,11 @@ RFID_KERNEL(64) void stream_stats_kernel(StatsArgs a) {
   if (!cut) k_term = nw;
   // ---- pass 2: counts over the windows before the cut-off ----
   int n_epc = 0, n_ok = 0;
-  for (int base = 0; base < k_term; base += 64) {
+  const int k1t = (k1 < k_term) ? k1 : k_term;
+  for (int base = k0; base < k1t; base += 64) {
     const int k = base + lane;
     int v = 0;
-    if (k < k_term) {
+    if (k < k1t) {
       const rfid_decode_result &r = rs[k];
       v = (r.type & 1) | ((r.crc_ok & 1) << 1) | ((r.tag_id & 255) << 2);
       if ((v & 3) == 3) wv::atomic_add(&hist[(v >> 2) & 255], 1);   // tag_decoder_impl.cc:356-364
@@ -2116,7 +2142,10 @@ RFID_KERNEL(64) void stream_stats_kernel(StatsArgs a) {
     n_epc += wv::popc64(wv::ballot((v & 1) != 0));
     n_ok += wv::popc64(wv::ballot((v & 3) == 3));                     // :346
   }
-  wv::wave_sync();
+  if (lane == 0) { wv::atomic_add(&sh_nepc, n_epc); wv::atomic_add(&sh_nok, n_ok); }
+  wv::block_sync();
+  if (wave != 0) return;
+  n_epc = sh_nepc; n_ok = sh_nok;
   int uniq = 0;
   for (int i = lane; i < 256; i += 64) {
     o->tag_reads[i] = hist[i];

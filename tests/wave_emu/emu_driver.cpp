@@ -170,7 +170,7 @@ int emu_batch_process(const float *raw, int B, long stride, long n_raw, const in
   sa.res = res.data(); sa.wcount = wcount.data(); sa.wmax = wmax; sa.n_streams = B;
   sa.max_slot_number = 1 << fixed_q; sa.max_num_queries = max_num_queries;
   sa.number_unique_tags = number_unique_tags; sa.out = stats;
-  emu::launch(emu::Idx3{(unsigned)B, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { stream_stats_kernel(sa); });
+  emu::launch(emu::Idx3{(unsigned)B, 1, 1}, emu::Idx3{256, 1, 1}, [&]() { stream_stats_kernel(sa); });   // four waves share a trace's windows
 
   long total = 0;
   for (int s = 0; s < B; ++s) {
