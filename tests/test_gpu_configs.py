@@ -196,3 +196,29 @@ def test_front_end_is_chosen_by_cost_estimate(synth_mod):
             assert wb.tobytes() == w1.tobytes() and rb.tobytes() == r1.tobytes(), b
     finally:
         ctx.close()
+
+
+def test_long_stream_falls_back_when_no_idle_cut_exists(synth_mod):
+    """A trace whose carrier never looks idle to the cut search (noise 1.5x the carrier per raw sample, 30 % after the matched filter: no 1 615 consecutive samples
+    within 15 % of the largest amplitude) cannot be cut.  Forced long-stream mode must then hand the trace to the
+    sequential scan and give exactly the bytes of mode 0."""
+    import rfid
+    t = synth_mod.make_trace(n_rounds=40, fixed_q=0, tag_ids=(0x3C,), sigma=0.0, seed=33, noise=False, render=False)
+    ctx = rfid.Context(device=0, max_num_queries=(1 << 31) - 2)
+    try:
+        data, L, stride = _gen_trace(ctx, t.plan, sigma=1.5, seed=9)
+        ctx.batch_plan(1, L)
+        ctx.batch_set_long_stream(0)
+        ctx.batch_process_ptr(data.data_ptr(), stride, L, 0, want_scores=False)
+        ctx.batch_sync()
+        w0, r0, _ = ctx.batch_windows()
+        st0 = ctx.batch_stats().tobytes()
+        ctx.batch_set_long_stream(2)
+        ctx.batch_process_ptr(data.data_ptr(), stride, L, 0, want_scores=False)
+        ctx.batch_sync()
+        rep = ctx.batch_ls_report()
+        assert rep["verified"] == 0, rep
+        w1, r1, _ = ctx.batch_windows()
+        assert w1.tobytes() == w0.tobytes() and r1.tobytes() == r0.tobytes() and ctx.batch_stats().tobytes() == st0
+    finally:
+        ctx.close()
