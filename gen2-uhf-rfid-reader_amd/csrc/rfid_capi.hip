@@ -48,6 +48,7 @@ struct rfid_ctx {
   DevBuf synth_tab;               // slot table of rfid_synth_gen2
   // long-stream front end (few long traces cut into concurrently scanned units)
   DevBuf ls_cut, ls_units, ls_runs, ls_tmpl, ls_state, ls_uw, ls_uwc, ls_heads, ls_seq0, ls_gath, ls_rec, ls_dcache, ls_avgbuf, ls_cutf;
+  DevBuf ls_pin;   // page-locked HOST memory: what the long-stream passes copy to and from the device every pass
   int ls_mode = 1;                // 0 never, 1 automatic, 2 whenever a trace can be cut
   // whole-chain streaming (rfid_stream_*)
   struct StreamIO {
@@ -131,6 +132,17 @@ int grow(rfid_ctx *c, DevBuf &b, size_t bytes) {
   b.cap = 0;
   size_t want = bytes < 4096 ? 4096 : bytes;
   HIPCHK(c, hipMalloc(&b.p, want));
+  b.cap = want;
+  return RFID_OK;
+}
+
+int grow_pinned(rfid_ctx *c, DevBuf &b, size_t bytes) {
+  if (bytes <= b.cap) return RFID_OK;
+  if (b.p) HIPCHK(c, hipHostFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  const size_t want = bytes < 65536 ? 65536 : bytes;
+  HIPCHK(c, hipHostMalloc(&b.p, want, hipHostMallocDefault));
   b.cap = want;
   return RFID_OK;
 }
@@ -442,7 +454,10 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
       auto a_first = [&](int i) { return au[(size_t)i].pos0 == 0; };
       std::vector<float> astart((size_t)AU, std::numeric_limits<float>::quiet_NaN());
       for (int u = 0; u < U; ++u) astart[(size_t)piece0[(size_t)u]] = start[(size_t)u].v[0];   // (ring mean from the template, 0, carried or known)
-      std::vector<float> av(2 * (size_t)AU), ae(2 * (size_t)AU), got(4 * (size_t)AU);
+      std::vector<float> ae(2 * (size_t)AU);
+      if ((rc = grow_pinned(c, c->ls_pin, sizeof(float) * 6 * (size_t)AU + sizeof(GateUnit) * 2 * (size_t)AU))) return rc;
+      float *av = (float *)c->ls_pin.p, *got = av + 2 * (size_t)AU;   // (page-locked: copied every pass)
+      GateUnit *pruns = (GateUnit *)(got + 4 * (size_t)AU);
       std::vector<char> exact((size_t)AU, 0);
       if ((rc = grow(c, c->ls_avgbuf, sizeof(float) * 4 * (size_t)AU + sizeof(GateUnit) * 2 * (size_t)AU))) return rc;
       float *d_av = (float *)c->ls_avgbuf.p, *d_ae = d_av + 2 * (size_t)AU;
@@ -465,8 +480,9 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
             const float s0 = astart[(size_t)i];
             av[(size_t)r.row] = (v && s0 == s0) ? f_from_ord(f_ord(s0) + 1) : s0;
           }
-        HIPCHK(c, hipMemcpyAsync(d_av, av.data(), sizeof(float) * 2 * (size_t)AU, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(d_aruns, runs.data(), sizeof(GateUnit) * runs.size(), hipMemcpyHostToDevice, c->stream));
+        memcpy(pruns, runs.data(), sizeof(GateUnit) * runs.size());
+        HIPCHK(c, hipMemcpyAsync(d_av, av, sizeof(float) * 2 * (size_t)AU, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_aruns, pruns, sizeof(GateUnit) * runs.size(), hipMemcpyHostToDevice, c->stream));
         LsAvgArgs aa;
         aa.y = c->d_y; aa.y_stride = c->y_stride; aa.units = d_aruns; aa.n_runs = (int)runs.size();
         aa.start = d_av; aa.end = d_ae; aa.carry = opt.carry ? c->d_gstate : nullptr;
@@ -474,7 +490,7 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
         aa.dcache = (float *)c->ls_dcache.p; aa.cache_mode = (round == 1) ? 1 : 2; aa.n_units = AU;
         hipLaunchKernelGGL(ls_avg_kernel, dim3((unsigned)runs.size()), dim3(64), 0, c->stream, aa);
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(got.data(), d_av, sizeof(float) * 4 * (size_t)AU, hipMemcpyDeviceToHost, c->stream));   // starts (first guesses filled in) + ends
+        HIPCHK(c, hipMemcpyAsync(got, d_av, sizeof(float) * 4 * (size_t)AU, hipMemcpyDeviceToHost, c->stream));   // starts (first guesses filled in) + ends
         HIPCHK(c, hipStreamSynchronize(c->stream));
         for (const GateUnit &r : runs) {
           ae[(size_t)r.row] = got[2 * (size_t)AU + (size_t)r.row];
@@ -513,13 +529,18 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
     lap("avg_ampl settled");
 
     // ---- phase 2: the full gate scan; avg_ampl starts exact, dc_est and the state machine's scalars are predicted ------
-    std::vector<int> heads((size_t)LS_HEAD_WORDS * 2 * (size_t)U);
+    // page-locked staging of what every pass copies: start values, run lists, end states
+    const size_t n_heads = (size_t)LS_HEAD_WORDS * 2 * (size_t)U;
+    if ((rc = grow_pinned(c, c->ls_pin, sizeof(int) * n_heads + sizeof(GateUnit) * 2 * (size_t)U + sizeof(LsHead) * 2 * (size_t)U))) return rc;
+    int *heads = (int *)c->ls_pin.p;
+    GateUnit *pruns2 = (GateUnit *)(heads + n_heads);
+    LsHead *got = (LsHead *)(pruns2 + 2 * (size_t)U);
+    memset(heads, 0, sizeof(int) * n_heads);
     std::vector<char> frozen((size_t)U, 0);
     // units whose start was right in everything but dc_est when they last went through the full scan: their closed
     // samples and window positions are final, later rounds re-run only the dc_est arithmetic (ls_dc_kernel)
     std::vector<char> fsm_final((size_t)U, 0);
     std::vector<GateUnit> runs_dc;
-    std::vector<LsHead> got;
     bool restart = false, accepted = false;
     bool dc_odd = true;   // the last pass met a correction of dc_est by an odd number of ulps (then variant B is worth its runs)
     for (int round = 1; round <= LS_MAX_ROUNDS && !restart && !accepted; ++round) {
@@ -548,11 +569,13 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
             for (int k = 0; k < 6; ++k) h[3 + k] = st.f[k];
           }
         const int n_run = (int)runs.size(), n_dc = (int)runs_dc.size();
-        HIPCHK(c, hipMemcpyAsync(c->ls_heads.p, heads.data(), sizeof(int) * heads.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->ls_heads.p, heads, sizeof(int) * n_heads, hipMemcpyHostToDevice, c->stream));
+        memcpy(pruns2, runs.data(), sizeof(GateUnit) * runs.size());
+        memcpy(pruns2 + n_run, runs_dc.data(), sizeof(GateUnit) * runs_dc.size());
         if (n_run)
-          HIPCHK(c, hipMemcpyAsync(c->ls_runs.p, runs.data(), sizeof(GateUnit) * runs.size(), hipMemcpyHostToDevice, c->stream));
+          HIPCHK(c, hipMemcpyAsync(c->ls_runs.p, pruns2, sizeof(GateUnit) * runs.size(), hipMemcpyHostToDevice, c->stream));
         if (n_dc)   // (ls_runs holds 2 U entries: the full runs first, the dc_est-only runs behind them)
-          HIPCHK(c, hipMemcpyAsync((GateUnit *)c->ls_runs.p + n_run, runs_dc.data(), sizeof(GateUnit) * runs_dc.size(),
+          HIPCHK(c, hipMemcpyAsync((GateUnit *)c->ls_runs.p + n_run, pruns2 + n_run, sizeof(GateUnit) * runs_dc.size(),
                                    hipMemcpyHostToDevice, c->stream));
         if (n_run) {
         LsHeadsArgs ha;
@@ -590,8 +613,7 @@ int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOp
           hipLaunchKernelGGL(ls_gather_kernel, dim3((unsigned)((2 * U * 12 + 255) / 256)), dim3(256), 0, c->stream, ga);
           HIPCHK(c, hipGetLastError());
         }
-        got.resize(2 * (size_t)U);
-        HIPCHK(c, hipMemcpyAsync(got.data(), c->ls_gath.p, sizeof(LsHead) * 2 * (size_t)U, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(got, c->ls_gath.p, sizeof(LsHead) * 2 * (size_t)U, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         for (const GateUnit &r : runs) eh[(size_t)r.row] = got[(size_t)r.row];
         for (const GateUnit &r : runs_dc) eh[(size_t)r.row] = got[(size_t)r.row];
@@ -799,6 +821,7 @@ int rfid_ctx_destroy(rfid_ctx *c) {
                   c->ls_heads.p, c->ls_seq0.p, c->ls_gath.p, c->ls_rec.p, c->ls_dcache.p, c->ls_avgbuf.p, c->ls_cutf.p};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
+  if (c->ls_pin.p) (void)hipHostFree(c->ls_pin.p);
   for (int i = 0; i < 5; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->stream2) {
