@@ -408,10 +408,11 @@ def main():
         "front_end_ms": round(k_ms["front_ms"], 4),
     }
     rep = ctx.batch_ls_report()
-    if rep["units"]:
-        out["long_stream"] = dict(rep, note="traces cut along time into units scanned concurrently from predicted gate "
-                                  "states; accepted only when every unit started from a state bit-identical to its predecessor's "
-                                  "end state (verified = 1), i.e. the windows ARE those of the sequential scan")
+    if rep["pieces"]:
+        out["long_stream"] = dict(rep, note="traces cut along time into pieces processed at once (avg_ampl, state machine, dc_est) "
+                                  "from guessed start values; accepted only when every piece's run is exact or provably covers its "
+                                  "true start (verified = 1), i.e. the windows ARE those of the sequential scan; no host "
+                                  "synchronisation inside a pass")
     if B == 1:
         out["single_stream"] = {"raw_msamples_per_s": round(L / (elapsed / args.steps) / 1e6, 2),
                                 "x_realtime_at_2Msps": round(L / (elapsed / args.steps) / 2e6, 1)}

@@ -19,6 +19,11 @@
 #include "rfid_kernels.hpp"
 #include "rfid_mi355x.h"
 #include "rfid_gen2_host.h"
+// the launch list of the long-stream front end, on the stream named by the enclosing scope's `ls2_stream`
+#define LS2_LAUNCH(kernel, gx, gy, block, args) \
+  hipLaunchKernelGGL(rfidk::kernel, dim3((unsigned)(gx), (unsigned)(gy)), dim3((unsigned)(block)), 0, ls2_stream, args)
+static thread_local hipStream_t ls2_stream = nullptr;
+#include "rfid_ls2_enqueue.hpp"
 
 using namespace rfidk;
 
@@ -46,13 +51,17 @@ struct rfid_ctx {
   int *d_io = nullptr;            // [2]
   DevBuf s_in, s_out;
   DevBuf synth_tab;               // slot table of rfid_synth_gen2
-  // long-stream front end (few long traces cut into concurrently scanned units)
-  DevBuf ls_cut, ls_units, ls_runs, ls_tmpl, ls_state, ls_uw, ls_uwc, ls_heads, ls_seq0, ls_gath, ls_rec, ls_dcache, ls_avgbuf, ls_cutf;
-  DevBuf ls_pin;   // page-locked HOST memory: what the long-stream passes copy to and from the device every pass
+  // long-stream front end (few long traces cut along time into concurrently processed pieces, rfid_ls2.hpp)
+  DevBuf ls2_ws;                  // its work space (one allocation, carved up by ls2_layout)
+  Ls2Ctl *ls2_host = nullptr;     // page-locked copy of the control block of the last pass (report) + consumed[0]
+  Ls2Ctl *d_ls2_ctl = nullptr;    // the control block of the last pass that ran the front end (device), else nullptr
+  int ls2_P = 0;                  // its nominal piece length
   int ls_mode = 1;                // 0 never, 1 automatic, 2 whenever a trace can be cut
+  double ls_fixed_ms = 0.35, ls_ns_per_sample = 0.025, seq_ns_per_sample = 10.2;   // cost model of the automatic choice
   // whole-chain streaming (rfid_stream_*)
   struct StreamIO {
     bool open = false;
+    bool failed = false;          // a call failed half-way: the stream has to be begun again
     int64_t max_chunk = 0, tail_max = 0;
     float2 *d_buf[2] = {nullptr, nullptr};
     rfid_cf32 *h_pin[2] = {nullptr, nullptr};
@@ -68,7 +77,6 @@ struct rfid_ctx {
     std::vector<rfid_stream_window> out_w;   // windows completed but not yet delivered (caller arrays too small)
     std::vector<rfid_decode_result> out_r;
   } sio;
-  rfid_ls_report ls_rep;
   rfid_window *d_swin = nullptr;  // one window
   int *d_scount = nullptr;
   rfid_decode_result *d_sres = nullptr;
@@ -203,529 +211,81 @@ void next_slot(rfid_reader_state &rs) {
 
 
 // ======================================================================================
-// long-stream front end
+// long-stream front end (kernels: rfid_ls2.hpp; launch list: rfid_ls2_enqueue.hpp)
 // ======================================================================================
-// The gate scan is a sequential recurrence per trace; with few traces most of the chip idles (one trace = one
-// SIMD).  Here a trace is cut along time into units at idle points of the gate's state machine and the units are
-// scanned CONCURRENTLY by the same gate_scan_kernel, each from a predicted gate state.  What a unit needs from its
-// past are three binary32 values -- avg_ampl and the two components of dc_est, in-order sums over the whole trace,
-// rounding drift included -- plus the idle state machine and the two rings (the preceding samples themselves).
-// Binary32 addition commutes with a shift of the start value by a multiple of its ulp except where a partial sum
-// sits next to a power of two, and except for the parity of the shift at rounding ties; so every round runs each
-// unit from its predicted start s (variant A) and from s + 1 ulp (variant B), and the host chains the units:
-//   true start t = s + d ulps  ->  predicted end = end_A + d (d even) or end_B + (d - 1) (d odd).
-// A round whose predictions were all exact (d = 0 for all three values of every unit, every cut idle) is, by
-// induction over the units, THE sequential scan: its variant-A windows are accepted.  Otherwise the predictions
-// become the next round's starts (first round: ring means; typically exact from the third round on).  Nothing is
-// assumed about the arithmetic: a wrong prediction only costs another round, and after LS_MAX_ROUNDS the caller
-// falls back to the plain sequential scan.
-// Only a unit's first scans are full ones: which samples are "closed" (update dc_est) and where windows open depend on
-// avg_ampl and the state machine, never on dc_est.  gate_scan_kernel records the closed-sample mask of every step; a unit
-// whose start was right in everything but dc_est (and every variant-B run: B differs from A in the dc_est start only) is
-// re-run by ls_dc_kernel, which redoes the back wave's arithmetic over the recorded masks and patches the dc_est fields
-// of the window records.  avg_ampl is settled beforehand by its own passes (ls_avg_kernel; the addends are data only and
-// are cached by the first pass).
 namespace {
-const int LS_MAX_ROUNDS = 10;
-// units per pass: enough to fill the device several times over; the avg_ampl / dc_est passes run one wave per unit and
-// take as long as ONE unit takes (64 samples per ~0.5 us), so shorter units shorten every pass -- measured on the
-// 2.2 G-sample trace: 2048 units 36.5 ms, 4096 37.0, 8192 34.1, 16384 34.6, 32768 45.8 (more cuts, more rounds)
-const int LS_TARGET_UNITS = 8192;
-const int LS_MIN_CHUNK = 6144;
-const int LS_AVG_SPLIT = 4;          // avg_ampl passes: a gate unit in about this many pieces ...
-const int LS_AVG_MIN_PIECE = 4096;   // ... of at least this many samples (the idle points are >= 1615 samples long)
-
-struct LsStart {  // what a unit needs from its past besides the rings: the three recurrences + the state machine's scalars
-  float v[3];     // avg_ampl, dc_re, dc_im
-  int f[6];       // n_samples, signal_state, num_pulses, gate_open, n_to_ungate, wtype
-};
-struct LsHead {   // first 12 words of GateState
-  float avg, dcr, dci;
-  int n_samples, signal_state, num_pulses, gate_open, n_to_ungate, wtype, win_index, dc_index, win_seq;
-};
-static_assert(sizeof(LsHead) == 48, "GateState head");
-
-inline int64_t f_ord(float f) {   // monotone integer image of a binary32 value (distance = ulps)
-  uint32_t u;
-  memcpy(&u, &f, 4);
-  return (u & 0x80000000u) ? -(int64_t)(u & 0x7fffffffu) : (int64_t)u;
-}
-inline float f_from_ord(int64_t k) {
-  uint32_t u = (k < 0) ? (0x80000000u | (uint32_t)(-k)) : (uint32_t)k;
-  float f;
-  memcpy(&f, &u, 4);
-  return f;
-}
-
-// returns RFID_OK and *done = 1 when the window tables were produced; *done = 0: not applicable / gave up (caller
-// runs the sequential scan); < 0 on errors
 double ls_now_ms() {
   struct timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
 }
-// Automatic choice between the two front ends (mode 1), from their measured rates on MI355X: the fused front end
-// runs up to 1024 traces side by side at ~10.2 ns per decimated sample of the LONGEST trace; the long-stream front end
-// costs ~0.8 ms of passes whose length does not depend on the data plus ~0.058 ns per decimated sample of ALL traces
-// (one full scan + the avg_ampl / dc_est passes).  64 traces of 215 k samples: 1.55 vs 2.2 ms; 128: 2.5 vs 2.25 ms;
-// one trace of 6 M samples: 1.2 vs 61 ms.
-bool ls_pays_off(int B, int64_t n_dec) {
-  const double t_seq = 1.02e-5 * (double)n_dec * (double)((B + 1023) / 1024);
-  const double t_ls = 0.8 + 5.8e-8 * (double)B * (double)n_dec;
+// Automatic choice between the two front ends (mode 1): the fused front end runs up to 1024 traces side by side at
+// seq_ns_per_sample per decimated sample of the LONGEST trace; the long-stream front end costs a fixed string of short
+// launches plus ls_ns_per_sample per decimated sample of ALL traces.  The three numbers are measured on the device at
+// hand when the context is created (rfid_ctx_create: ls_calibrate).
+bool ls_pays_off(const rfid_ctx *c, int B, int64_t n_dec) {
+  const double t_seq = 1e-6 * c->seq_ns_per_sample * (double)n_dec * (double)((B + 1023) / 1024);
+  const double t_ls = c->ls_fixed_ms + 1e-6 * c->ls_ns_per_sample * (double)B * (double)n_dec;
   return t_ls < 0.9 * t_seq;
 }
+bool ls_applicable(const rfid_ctx *c, int B, int64_t n_dec) {
+  if (c->ls_mode == 0 || B > 4096) return false;
+  if (ls2_geometry(B, n_dec).P == 0) return false;
+  return c->ls_mode == 2 || ls_pays_off(c, B, n_dec);
+}
+size_t ls_workspace_bytes(int B, int64_t n_dec, int64_t y_stride) {
+  const Ls2Geometry g = ls2_geometry(B, n_dec);
+  return g.P ? ls2_layout(g, B, y_stride).total : 0;
+}
+
 struct LsOpts {
-  bool carry = false;       // a trace's first unit starts from c->d_gstate[trace] (streaming) instead of the fresh gate,
-                            // and the state after the last processed unit is written back there
-  bool hold_last = false;   // leave each trace's last unit unprocessed (streaming: whatever follows the last idle cut
-                            // waits for more samples); *consumed = its first sample
-  bool force = false;       // run even when it cannot pay off (streaming needs the idle cut, not the speed)
+  bool carry = false;       // the trace starts from c->d_gstate[trace] (streaming) instead of the fresh gate, and the state
+                            // after the last processed piece is written back there
+  bool hold_last = false;   // leave each trace's last piece unprocessed (streaming: whatever follows the last idle cut
+                            // waits for more samples)
+  bool force = false;       // run even when no trace could be cut more than once
 };
-int ls_front_end(rfid_ctx *c, int64_t n_dec, int *done, const LsOpts &opt = LsOpts(), int64_t *consumed = nullptr) {
-  *done = 0;
-  if (consumed) *consumed = 0;
-  const bool dbg = getenv("RFID_LS_DEBUG") != nullptr;
-  const double t_begin = ls_now_ms();
-  auto lap = [&](const char *what) { if (dbg) fprintf(stderr, "[ls] t=%8.2f ms  %s\n", ls_now_ms() - t_begin, what); };
-  rfid_ls_report &rep = c->ls_rep;
-  memset(&rep, 0, sizeof(rep));
-  const int B = c->B;
-  if (!opt.force) {
-    if (c->ls_mode == 0 || n_dec < 2 * LS_MIN_CHUNK) return RFID_OK;
-    if (c->ls_mode == 1 && !ls_pays_off(B, n_dec)) return RFID_OK;
-  } else if (n_dec < LS_QUIET + 256) {
-    return RFID_OK;
+// Enqueues one pass of the front end over c->d_y (n_dec decimated samples per trace, c->d_lens).  *enqueued = 0: not
+// applicable here (traces too short, no work space) -- nothing was launched.  Whether the pass produced the window
+// tables is known on the device only (Ls2Ctl::ok); the caller enqueues the sequential scan behind it with
+// GateArgs::skip_if = &ctl->ok, or synchronises and looks at c->ls2_host.
+int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
+  *enqueued = 0;
+  c->d_ls2_ctl = nullptr;
+  const Ls2Geometry geo = ls2_geometry(c->B, n_dec);
+  if (geo.P == 0 || c->B > 65535) return RFID_OK;
+  const Ls2Layout L = ls2_layout(geo, c->B, c->y_stride);
+  if (L.total > c->ls2_ws.cap) {
+    // (normally reserved by rfid_batch_plan; a pass that needs it all the same must not fail on a full device)
+    if (c->ls2_ws.p) { (void)hipFree(c->ls2_ws.p); c->ls2_ws.p = nullptr; c->ls2_ws.cap = 0; }
+    if (hipMalloc(&c->ls2_ws.p, L.total) != hipSuccess) { (void)hipGetLastError(); c->ls2_ws.p = nullptr; return RFID_OK; }
+    c->ls2_ws.cap = L.total;
   }
-  // ---- per-trace lengths ----
-  std::vector<int64_t> nd((size_t)B, n_dec);
-  if (c->d_lens) {
-    std::vector<int64_t> hl((size_t)B);
-    HIPCHK(c, hipMemcpyAsync(hl.data(), c->d_lens, sizeof(int64_t) * (size_t)B, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int s = 0; s < B; ++s) {
-      int64_t r = hl[(size_t)s] < 0 ? 0 : hl[(size_t)s] / DECIM;
-      nd[(size_t)s] = r < n_dec ? r : n_dec;
+  if (!c->ls2_host) {
+    if (hipHostMalloc((void **)&c->ls2_host, sizeof(Ls2Ctl) + 64, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError(); c->ls2_host = nullptr; return RFID_OK;
     }
+    memset(c->ls2_host, 0, sizeof(Ls2Ctl) + 64);
   }
-  int64_t total = 0;
-  for (int64_t v : nd) total += v;
-  int64_t chunk = (total + LS_TARGET_UNITS - 1) / LS_TARGET_UNITS;
-  if (chunk < LS_MIN_CHUNK) chunk = LS_MIN_CHUNK;
-  chunk = (chunk + 63) & ~63LL;
-  if (chunk > 0x3fffffff) return RFID_OK;
-  int max_b = 1;
-  int64_t nominal = 0;
-  for (int64_t v : nd) {
-    const int nb = (int)(v / chunk);
-    if (nb + 1 > max_b) max_b = nb + 1;
-    nominal += (nb > 0 ? nb : 1);
-  }
-  if (max_b < 2 || (!opt.force && c->ls_mode == 1 && nominal < 2 * (int64_t)B)) return RFID_OK;   // nothing to gain
-  // ---- idle cut points near the nominal boundaries ----
-  int rc = grow(c, c->ls_cut, sizeof(int) * (size_t)B * (size_t)max_b);
-  if (rc) return rc;
-  LsCutArgs ca;
-  ca.y = c->d_y; ca.y_stride = c->y_stride; ca.lens = c->d_lens; ca.n_dec = n_dec; ca.chunk = (int)chunk;
-  ca.limit = (int)(chunk / 2); ca.max_b = max_b; ca.cut = (int *)c->ls_cut.p;
-  hipLaunchKernelGGL(ls_cut_kernel, dim3((unsigned)(max_b - 1), (unsigned)B), dim3(64), 0, c->stream, ca);
+  Ls2Args a;
+  memset(&a, 0, sizeof(a));
+  a.y = c->d_y; a.y_stride = c->y_stride; a.lens = c->d_lens; a.n_dec = n_dec; a.n_streams = c->B;
+  ls2_bind(a, (char *)c->ls2_ws.p, L, geo);
+  a.wtab = c->d_wtab; a.wmax = c->wmax; a.wcount = c->d_wcount; a.flat = c->d_flat; a.flat_count = c->d_flat_count; a.flat_cap = c->flat_cap;
+  a.carry = opt.carry ? c->d_gstate : nullptr; a.carry_out = opt.carry ? c->d_gstate : nullptr;
+  a.hold_last = opt.hold_last ? 1 : 0; a.force = opt.force ? 1 : 0;
+  HIPCHK(c, hipMemsetAsync(a.ctl, 0, sizeof(Ls2Ctl), c->stream));
+  HIPCHK(c, hipMemsetAsync(a.consumed, 0, sizeof(int) * (size_t)c->B, c->stream));
+  HIPCHK(c, hipMemsetAsync(a.wb, 0, sizeof(Ls2Win) * (size_t)c->B * (size_t)geo.wb_stride, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_flat_count, 0, 2 * sizeof(int), c->stream));
+  ls2_stream = c->stream;
+  ls2_enqueue(a);
   HIPCHK(c, hipGetLastError());
-  std::vector<int> cut((size_t)B * (size_t)max_b);
-  HIPCHK(c, hipMemcpyAsync(cut.data(), c->ls_cut.p, sizeof(int) * cut.size(), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  std::vector<char> banned(cut.size(), 0);
-  // a finer grid of idle points for the avg_ampl passes alone (phase 1 below)
-  int64_t chunk_f = ((chunk / LS_AVG_SPLIT) + 63) & ~63LL;
-  if (chunk_f < LS_AVG_MIN_PIECE) chunk_f = LS_AVG_MIN_PIECE;
-  std::vector<int> cutf;
-  int max_bf = 0;
-  if (chunk_f * 2 <= chunk) {
-    for (int64_t v : nd) { const int nb = (int)(v / chunk_f) + 1; if (nb > max_bf) max_bf = nb; }
-    if ((rc = grow(c, c->ls_cutf, sizeof(int) * (size_t)B * (size_t)max_bf))) return rc;
-    LsCutArgs cf = ca;
-    cf.chunk = (int)chunk_f; cf.limit = (int)(chunk_f / 2); cf.max_b = max_bf; cf.cut = (int *)c->ls_cutf.p;
-    hipLaunchKernelGGL(ls_cut_kernel, dim3((unsigned)(max_bf - 1), (unsigned)B), dim3(64), 0, c->stream, cf);
-    HIPCHK(c, hipGetLastError());
-    cutf.resize((size_t)B * (size_t)max_bf);
-    HIPCHK(c, hipMemcpyAsync(cutf.data(), c->ls_cutf.p, sizeof(int) * cutf.size(), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-  }
-  lap("cut points found");
-  std::map<int64_t, LsStart> known;   // predictions carried over when a cut is withdrawn and the units are rebuilt
-
-  for (int attempt = 0; attempt < 4; ++attempt) {
-    // ---- units ----
-    std::vector<GateUnit> units;
-    std::vector<size_t> cut_of_unit;            // index into cut[] of the boundary that STARTS the unit (0 for a trace's first)
-    for (int s = 0; s < B; ++s) {
-      int pos = 0;
-      const int n = (int)nd[(size_t)s];
-      size_t started_by = (size_t)-1;
-      for (int j = 1; j < max_b; ++j) {
-        const size_t ci = (size_t)s * (size_t)max_b + (size_t)j;
-        const int p = cut[ci];
-        if (p <= pos || p >= n || banned[ci]) continue;
-        GateUnit u; u.stream = s; u.pos0 = pos; u.len = p - pos; u.row = 0;
-        units.push_back(u); cut_of_unit.push_back(started_by);
-        pos = p; started_by = ci;
-      }
-      GateUnit u; u.stream = s; u.pos0 = pos; u.len = n - pos; u.row = 0;
-      units.push_back(u); cut_of_unit.push_back(started_by);
-    }
-    if (opt.hold_last) {   // (streaming: one trace) what follows the last idle cut stays unprocessed
-      if (units.size() < 2) return RFID_OK;
-      if (consumed) *consumed = units.back().pos0;
-      units.pop_back(); cut_of_unit.pop_back();
-    }
-    const int U = (int)units.size();
-    if (U <= B && !opt.force) return RFID_OK;   // no cut found: sequential scan
-    int max_len = 0;
-    for (const GateUnit &u : units) if (u.len > max_len) max_len = u.len;
-    const int uwmax = max_len / (RN16_WIN + T1_SAMPLES + 1) + 2;
-    if ((rc = grow(c, c->ls_units, sizeof(GateUnit) * (size_t)U))) return rc;
-    if ((rc = grow(c, c->ls_runs, sizeof(GateUnit) * 2 * (size_t)U))) return rc;
-    if ((rc = grow(c, c->ls_tmpl, sizeof(GateState) * (size_t)U))) return rc;
-    if ((rc = grow(c, c->ls_state, sizeof(GateState) * 2 * (size_t)U))) return rc;
-    if ((rc = grow(c, c->ls_uw, sizeof(rfid_window) * 2 * (size_t)U * (size_t)uwmax))) return rc;
-    if ((rc = grow(c, c->ls_uwc, sizeof(int) * 2 * (size_t)U))) return rc;
-    if ((rc = grow(c, c->ls_heads, sizeof(int) * LS_HEAD_WORDS * 2 * (size_t)U + sizeof(float) * 4 * (size_t)U))) return rc;
-    if ((rc = grow(c, c->ls_seq0, sizeof(int) * (size_t)U))) return rc;
-    if ((rc = grow(c, c->ls_gath, sizeof(int) * (12 * 2 + 1) * (size_t)U))) return rc;
-    const int rec_stride = (max_len + 63) / 64;   // steps of the longest unit
-    if ((rc = grow(c, c->ls_rec, sizeof(uint64_t) * (size_t)U * (size_t)rec_stride))) return rc;
-    if ((rc = grow(c, c->ls_dcache, sizeof(float) * (size_t)B * (size_t)c->y_stride))) return rc;
-    for (int u = 0; u < U; ++u) units[(size_t)u].row = u;
-    HIPCHK(c, hipMemcpyAsync(c->ls_units.p, units.data(), sizeof(GateUnit) * (size_t)U, hipMemcpyHostToDevice, c->stream));
-    LsInitArgs ia;
-    ia.y = c->d_y; ia.y_stride = c->y_stride; ia.units = (const GateUnit *)c->ls_units.p; ia.n_units = U;
-    ia.tmpl = (GateState *)c->ls_tmpl.p; ia.carry = opt.carry ? c->d_gstate : nullptr;
-    hipLaunchKernelGGL(ls_init_kernel, dim3((unsigned)U), dim3(64), 0, c->stream, ia);
-    HIPCHK(c, hipGetLastError());
-    std::vector<LsHead> th((size_t)U), eh(2 * (size_t)U);
-    HIPCHK(c, hipMemcpy2DAsync(th.data(), sizeof(LsHead), c->ls_tmpl.p, sizeof(GateState), sizeof(LsHead), (size_t)U,
-                               hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    // predicted start of every unit: first guess = the template (ring means, idle state machine), or what an earlier
-    // attempt (before a cut was withdrawn) had already worked out for a unit that starts at the same sample
-    std::vector<LsStart> start((size_t)U);
-    std::vector<char> avg_known((size_t)U, 0);
-    for (int u = 0; u < U; ++u) {
-      LsStart &st = start[(size_t)u];
-      st.v[0] = th[u].avg; st.v[1] = th[u].dcr; st.v[2] = th[u].dci;
-      st.f[0] = th[u].n_samples; st.f[1] = th[u].signal_state; st.f[2] = th[u].num_pulses; st.f[3] = th[u].gate_open;
-      st.f[4] = th[u].n_to_ungate; st.f[5] = th[u].wtype;
-      auto it = known.find(((int64_t)units[(size_t)u].stream << 32) | (uint32_t)units[(size_t)u].pos0);
-      if (it != known.end()) { st = it->second; avg_known[(size_t)u] = 1; }
-    }
-    lap("units built, templates initialised");
-    auto first_of_trace = [&](int u) { return units[(size_t)u].pos0 == 0; };
-    auto last_of_trace = [&](int u) { return (u + 1 == U) || units[(size_t)u + 1].stream != units[(size_t)u].stream; };
-    // runs are launched selectively: per trace, the units before `frozen` already ran from their exact start state in an
-    // earlier round (their end state / windows in rows [0, U) are final); the rest is re-run
-    std::vector<GateUnit> runs;
-    runs.reserve(2 * (size_t)U);
-
-    // ---- phase 1: avg_ampl alone (cheap kernel): exact value at every cut ---------------------------------------------
-    // A pass takes as long as ONE unit takes (a chain of dependent steps) and avg_ampl needs nothing of the state machine,
-    // so its passes run on a finer grid: every gate unit in pieces that end at idle points too (away from them avg_ampl
-    // is on the move across binades and the chained predictions fail every few pieces).  A gate unit's value is its first
-    // piece's; a piece's first guess is the mean of the 100 amplitudes before it (formed by the kernel).
-    {
-      std::vector<GateUnit> au;          // the pieces, in trace order
-      std::vector<int> piece0((size_t)U);
-      for (int u = 0; u < U; ++u) {
-        const GateUnit &un = units[(size_t)u];
-        piece0[(size_t)u] = (int)au.size();
-        int pos = un.pos0;
-        if (max_bf > 0) {
-          const int *cf = &cutf[(size_t)un.stream * (size_t)max_bf];
-          for (int j = (int)(un.pos0 / chunk_f); j < max_bf; ++j) {
-            const int p = (j >= 1) ? cf[j] : -1;
-            if (p >= un.pos0 + un.len) break;
-            if (p <= pos) continue;
-            GateUnit q; q.stream = un.stream; q.pos0 = pos; q.len = p - pos; q.row = 0;
-            au.push_back(q);
-            pos = p;
-          }
-        }
-        GateUnit q; q.stream = un.stream; q.pos0 = pos; q.len = un.pos0 + un.len - pos; q.row = 0;
-        au.push_back(q);
-      }
-      const int AU = (int)au.size();
-      auto a_first = [&](int i) { return au[(size_t)i].pos0 == 0; };
-      std::vector<float> astart((size_t)AU, std::numeric_limits<float>::quiet_NaN());
-      for (int u = 0; u < U; ++u) astart[(size_t)piece0[(size_t)u]] = start[(size_t)u].v[0];   // (ring mean from the template, 0, carried or known)
-      std::vector<float> ae(2 * (size_t)AU);
-      if ((rc = grow_pinned(c, c->ls_pin, sizeof(float) * 6 * (size_t)AU + sizeof(GateUnit) * 2 * (size_t)AU))) return rc;
-      float *av = (float *)c->ls_pin.p, *got = av + 2 * (size_t)AU;   // (page-locked: copied every pass)
-      GateUnit *pruns = (GateUnit *)(got + 4 * (size_t)AU);
-      std::vector<char> exact((size_t)AU, 0);
-      if ((rc = grow(c, c->ls_avgbuf, sizeof(float) * 4 * (size_t)AU + sizeof(GateUnit) * 2 * (size_t)AU))) return rc;
-      float *d_av = (float *)c->ls_avgbuf.p, *d_ae = d_av + 2 * (size_t)AU;
-      GateUnit *d_aruns = (GateUnit *)(d_ae + 2 * (size_t)AU);
-      bool all = false;
-      // variant B (start + 1 ulp) serves corrections by an odd number of ulps (the parity of the shift decides rounding
-      // ties).  After the first pass the corrections are usually even (a rounding that went the other way one binade up
-      // = 2 ulps here): B then runs only in the pass after one that met an odd correction; without it the prediction
-      // for an odd correction is just less likely to hold, and every value is verified by a run from it anyway.
-      bool with_b = true;
-      for (int round = 1; round <= 3 * LS_MAX_ROUNDS && !all; ++round) {
-        runs.clear();
-        for (int v = 0; v < (with_b ? 2 : 1); ++v)
-          for (int i = 0; i < AU; ++i) {
-            if (exact[(size_t)i]) continue;
-            if (v == 1 && a_first(i)) continue;
-            GateUnit r = au[(size_t)i];
-            r.row = v * AU + i;
-            runs.push_back(r);
-            const float s0 = astart[(size_t)i];
-            av[(size_t)r.row] = (v && s0 == s0) ? f_from_ord(f_ord(s0) + 1) : s0;
-          }
-        memcpy(pruns, runs.data(), sizeof(GateUnit) * runs.size());
-        HIPCHK(c, hipMemcpyAsync(d_av, av, sizeof(float) * 2 * (size_t)AU, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(d_aruns, pruns, sizeof(GateUnit) * runs.size(), hipMemcpyHostToDevice, c->stream));
-        LsAvgArgs aa;
-        aa.y = c->d_y; aa.y_stride = c->y_stride; aa.units = d_aruns; aa.n_runs = (int)runs.size();
-        aa.start = d_av; aa.end = d_ae; aa.carry = opt.carry ? c->d_gstate : nullptr;
-        // the addends are data only: written by the first pass of an attempt (all pieces run), read by the later ones
-        aa.dcache = (float *)c->ls_dcache.p; aa.cache_mode = (round == 1) ? 1 : 2; aa.n_units = AU;
-        hipLaunchKernelGGL(ls_avg_kernel, dim3((unsigned)runs.size()), dim3(64), 0, c->stream, aa);
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(got, d_av, sizeof(float) * 4 * (size_t)AU, hipMemcpyDeviceToHost, c->stream));   // starts (first guesses filled in) + ends
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (const GateUnit &r : runs) {
-          ae[(size_t)r.row] = got[2 * (size_t)AU + (size_t)r.row];
-          if (r.row < AU) astart[(size_t)r.row] = got[(size_t)r.row];
-        }
-        rep.avg_passes++;
-
-        all = true;
-        float t = 0.0f;
-        bool chain_exact = true;   // every piece of this trace so far started from its true value
-        bool odd_seen = false;
-        int dbg_first = -1, dbg_n0 = 0, dbg_nbig = 0; long long dbg_dfirst = 0;
-        for (int i = 0; i < AU; ++i) {
-          if (a_first(i)) { t = astart[(size_t)i]; chain_exact = true; }   // the fresh gate's 0, or the carried value
-          const float sA = astart[(size_t)i];
-          const int64_t d = f_ord(t) - f_ord(sA);
-          if (dbg && !exact[(size_t)i]) { if (d == 0) dbg_n0++; else dbg_nbig++; if (d != 0 && dbg_first < 0) { dbg_first = i; dbg_dfirst = (long long)d; } }
-          float pred;
-          if (d == 0) pred = ae[(size_t)i];
-          else if ((d & 1) == 0 || a_first(i) || !with_b) pred = f_from_ord(f_ord(ae[(size_t)i]) + d);
-          else pred = f_from_ord(f_ord(ae[(size_t)AU + (size_t)i]) + (d - 1));
-          if ((d & 1) != 0 && !exact[(size_t)i]) odd_seen = true;
-          if (d != 0) chain_exact = false;
-          if (chain_exact) exact[(size_t)i] = 1; else all = false;
-          astart[(size_t)i] = t;
-          t = pred;
-        }
-        if (dbg) fprintf(stderr, "[ls] t=%8.2f ms  avg pass %d runs=%d (%s) of %d pieces: d=0 %d, d!=0 %d%s; first d!=0 at piece %d (d=%lld)\n",
-                         ls_now_ms() - t_begin, rep.avg_passes, (int)runs.size(), with_b ? "A+B" : "A", AU, dbg_n0, dbg_nbig,
-                         odd_seen ? ", odd ones among them" : "", dbg_first, dbg_dfirst);
-        with_b = odd_seen;
-      }
-      if (!all) break;   // (gives up: sequential scan)
-      for (int u = 0; u < U; ++u) start[(size_t)u].v[0] = astart[(size_t)piece0[(size_t)u]];
-    }
-    lap("avg_ampl settled");
-
-    // ---- phase 2: the full gate scan; avg_ampl starts exact, dc_est and the state machine's scalars are predicted ------
-    // page-locked staging of what every pass copies: start values, run lists, end states
-    const size_t n_heads = (size_t)LS_HEAD_WORDS * 2 * (size_t)U;
-    if ((rc = grow_pinned(c, c->ls_pin, sizeof(int) * n_heads + sizeof(GateUnit) * 2 * (size_t)U + sizeof(LsHead) * 2 * (size_t)U))) return rc;
-    int *heads = (int *)c->ls_pin.p;
-    GateUnit *pruns2 = (GateUnit *)(heads + n_heads);
-    LsHead *got = (LsHead *)(pruns2 + 2 * (size_t)U);
-    memset(heads, 0, sizeof(int) * n_heads);
-    std::vector<char> frozen((size_t)U, 0);
-    // units whose start was right in everything but dc_est when they last went through the full scan: their closed
-    // samples and window positions are final, later rounds re-run only the dc_est arithmetic (ls_dc_kernel)
-    std::vector<char> fsm_final((size_t)U, 0);
-    std::vector<GateUnit> runs_dc;
-    bool restart = false, accepted = false;
-    bool dc_odd = true;   // the last pass met a correction of dc_est by an odd number of ulps (then variant B is worth its runs)
-    for (int round = 1; round <= LS_MAX_ROUNDS && !restart && !accepted; ++round) {
-      // both variants (dc_est starts s and s + 1 ulp) while predictions still move; a round that is expected to
-      // confirm runs variant A alone first
-      for (int pass = 0; pass < 2 && !accepted && !restart; ++pass) {
-        const bool with_b = (round == 2) || (pass == 1 && dc_odd);
-        if (round <= 2 && pass == 1) break;
-        runs.clear();
-        runs_dc.clear();
-        for (int v = 0; v < (with_b ? 2 : 1); ++v)
-          for (int u = 0; u < U; ++u) {
-            if (frozen[(size_t)u]) continue;
-            GateUnit r = units[(size_t)u];
-            r.row = v * U + u;
-            // (variant B differs from A in the dc_est start only: it never needs more than the dc_est arithmetic over
-            // what variant A's scan -- of this pass or an earlier one -- found closed)
-            ((fsm_final[(size_t)u] || v == 1) ? runs_dc : runs).push_back(r);
-            const LsStart &st = start[(size_t)u];
-            int *h = &heads[(size_t)LS_HEAD_WORDS * (size_t)r.row];
-            memcpy(&h[0], &st.v[0], 4);   // avg_ampl: exact in both variants (it steers the state machine)
-            for (int k = 1; k < 3; ++k) {
-              const float vb = (v == 0 || first_of_trace(u)) ? st.v[k] : f_from_ord(f_ord(st.v[k]) + 1);
-              memcpy(&h[k], &vb, 4);
-            }
-            for (int k = 0; k < 6; ++k) h[3 + k] = st.f[k];
-          }
-        const int n_run = (int)runs.size(), n_dc = (int)runs_dc.size();
-        HIPCHK(c, hipMemcpyAsync(c->ls_heads.p, heads, sizeof(int) * n_heads, hipMemcpyHostToDevice, c->stream));
-        memcpy(pruns2, runs.data(), sizeof(GateUnit) * runs.size());
-        memcpy(pruns2 + n_run, runs_dc.data(), sizeof(GateUnit) * runs_dc.size());
-        if (n_run)
-          HIPCHK(c, hipMemcpyAsync(c->ls_runs.p, pruns2, sizeof(GateUnit) * runs.size(), hipMemcpyHostToDevice, c->stream));
-        if (n_dc)   // (ls_runs holds 2 U entries: the full runs first, the dc_est-only runs behind them)
-          HIPCHK(c, hipMemcpyAsync((GateUnit *)c->ls_runs.p + n_run, pruns2 + n_run, sizeof(GateUnit) * runs_dc.size(),
-                                   hipMemcpyHostToDevice, c->stream));
-        if (n_run) {
-        LsHeadsArgs ha;
-        ha.tmpl = (const GateState *)c->ls_tmpl.p; ha.state = (GateState *)c->ls_state.p; ha.heads = (const int *)c->ls_heads.p;
-        ha.runs = (const GateUnit *)c->ls_runs.p; ha.n_runs = n_run; ha.n_units = U;
-        hipLaunchKernelGGL(ls_set_state_kernel, dim3((unsigned)n_run), dim3(64), 0, c->stream, ha);
-        HIPCHK(c, hipGetLastError());
-        GateArgs g = {};
-        g.y = c->d_y; g.y_stride = c->y_stride; g.n_dec = n_dec; g.lens = c->d_lens; g.pos0 = 0; g.chunk_len = n_dec;
-        g.state = (GateState *)c->ls_state.p; g.n_streams = n_run; g.wtab = (rfid_window *)c->ls_uw.p; g.wmax = uwmax;
-        g.wcount = (int *)c->ls_uwc.p; g.flat = nullptr; g.flat_count = nullptr; g.flat_cap = 0; g.mode = 0;
-        g.units = (const GateUnit *)c->ls_runs.p;
-        g.rec = (uint64_t *)c->ls_rec.p; g.rec_stride = rec_stride; g.rec_mod = U;
-        hipLaunchKernelGGL(gate_scan_kernel, dim3((unsigned)((n_run + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG)),
-                           dim3(GATE_THREADS), 0, c->stream, g);
-        HIPCHK(c, hipGetLastError());
-        }
-        if (n_dc) {
-          LsDcArgs da;
-          da.y = c->d_y; da.y_stride = c->y_stride; da.runs = (const GateUnit *)c->ls_runs.p + n_run; da.n_runs = n_dc; da.n_units = U;
-          da.tmpl = (const GateState *)c->ls_tmpl.p; da.heads = (const int *)c->ls_heads.p; da.state = (GateState *)c->ls_state.p;
-          da.rec = (const uint64_t *)c->ls_rec.p; da.rec_stride = rec_stride;
-          da.uwtab = (rfid_window *)c->ls_uw.p; da.uwcount = (int *)c->ls_uwc.p; da.uwmax = uwmax;
-          hipLaunchKernelGGL(ls_dc_kernel, dim3((unsigned)n_dc), dim3(64), 0, c->stream, da);
-          HIPCHK(c, hipGetLastError());
-          rep.dc_runs += n_dc;
-        }
-        if (n_run) rep.gate_passes += 1;
-        rep.unit_runs += n_run;
-        {
-          LsGatherArgs ga;
-          ga.state = (const GateState *)c->ls_state.p; ga.heads = (int *)c->ls_gath.p; ga.n_rows = 2 * U;
-          ga.uwtab = (const rfid_window *)c->ls_uw.p; ga.uwcount = (const int *)c->ls_uwc.p; ga.n_units = U; ga.uwmax = uwmax;
-          ga.last_end = (int *)c->ls_gath.p + 12 * 2 * (size_t)U;
-          hipLaunchKernelGGL(ls_gather_kernel, dim3((unsigned)((2 * U * 12 + 255) / 256)), dim3(256), 0, c->stream, ga);
-          HIPCHK(c, hipGetLastError());
-        }
-        HIPCHK(c, hipMemcpyAsync(got, c->ls_gath.p, sizeof(LsHead) * 2 * (size_t)U, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (const GateUnit &r : runs) eh[(size_t)r.row] = got[(size_t)r.row];
-        for (const GateUnit &r : runs_dc) eh[(size_t)r.row] = got[(size_t)r.row];
-        // ---- chain the units of every trace: true start of unit u+1 = (predicted) end of unit u ----
-        bool all_exact = true, chain_exact = true, fsm_chain = true, odd_now = false;
-        int n_moved = 0, dbg_mism = 0;
-        std::vector<LsStart> next(start);
-        for (int u = 0; u < U; ++u) {
-          if (first_of_trace(u)) { chain_exact = true; fsm_chain = true; }
-          if (frozen[(size_t)u]) {   // final: its end state is the exact one
-            if (!last_of_trace(u)) {
-              LsStart &nx = next[(size_t)u + 1];
-              nx.v[0] = eh[u].avg; nx.v[1] = eh[u].dcr; nx.v[2] = eh[u].dci;
-              nx.f[0] = eh[u].n_samples; nx.f[1] = eh[u].signal_state; nx.f[2] = eh[u].num_pulses; nx.f[3] = eh[u].gate_open;
-              nx.f[4] = eh[u].n_to_ungate; nx.f[5] = eh[u].wtype;
-            }
-            continue;
-          }
-          const LsStart t = first_of_trace(u) ? start[(size_t)u] : next[(size_t)u];   // (a first unit's start is the exact fresh gate)
-          const LsStart &sA = start[(size_t)u];
-          const float eA[3] = {eh[u].avg, eh[u].dcr, eh[u].dci};
-          LsStart pred;
-          bool exact = true;
-          for (int k = 0; k < 3; ++k) {
-            const int64_t d = f_ord(t.v[k]) - f_ord(sA.v[k]);
-            if (d != 0) exact = false;
-            if (k > 0 && (d & 1) != 0) odd_now = true;
-            if (d == 0) pred.v[k] = eA[k];
-            else if (k == 0 || (d & 1) == 0 || !with_b || first_of_trace(u)) pred.v[k] = f_from_ord(f_ord(eA[k]) + d);
-            else pred.v[k] = f_from_ord(f_ord(k == 1 ? eh[U + u].dcr : eh[U + u].dci) + (d - 1));
-          }
-          bool fsm_match = f_ord(t.v[0]) == f_ord(sA.v[0]);
-          for (int k = 0; k < 6; ++k) if (t.f[k] != sA.f[k]) { exact = false; fsm_match = false; }
-          if (dbg && !fsm_match && round == 1 && dbg_mism++ < 4)
-            fprintf(stderr, "[ls]   unit %d start mismatch: avg %d | n %d/%d state %d/%d pulses %d/%d open %d/%d ung %d/%d type %d/%d\n", u,
-                    (int)(f_ord(t.v[0]) != f_ord(sA.v[0])), t.f[0], sA.f[0], t.f[1], sA.f[1], t.f[2], sA.f[2], t.f[3], sA.f[3], t.f[4], sA.f[4], t.f[5], sA.f[5]);
-          if (!fsm_match) fsm_chain = false;
-          if (fsm_chain) fsm_final[(size_t)u] = 1;
-          pred.f[0] = eh[u].n_samples; pred.f[1] = eh[u].signal_state; pred.f[2] = eh[u].num_pulses; pred.f[3] = eh[u].gate_open;
-          pred.f[4] = eh[u].n_to_ungate; pred.f[5] = eh[u].wtype;
-          if (!exact) { chain_exact = false; n_moved++; }
-          if (chain_exact) frozen[(size_t)u] = 1; else all_exact = false;
-          next[(size_t)u] = t;
-          if (!last_of_trace(u)) next[(size_t)u + 1] = pred;
-        }
-        rep.rounds = round;
-        rep.units = U;
-        rep.last_round_moved = n_moved;
-        if (getenv("RFID_LS_DEBUG")) {
-          int first_bad = -1;
-          for (int u = 0; u < U && first_bad < 0; ++u) if (!frozen[(size_t)u]) first_bad = u;
-          int64_t dmax = 0;
-          for (int u = 0; u < U; ++u) for (int k = 0; k < 3; ++k) {
-            int64_t d = f_ord(next[(size_t)u].v[k]) - f_ord(start[(size_t)u].v[k]); if (d < 0) d = -d; if (d > dmax) dmax = d; }
-          fprintf(stderr, "[ls] t=%8.2f ms  attempt %d round %d pass %d with_b=%d runs=%d dc_runs=%d moved=%d first_open=%d max|d|=%lld ulps\n",
-                  ls_now_ms() - t_begin, attempt, round, pass, (int)with_b, n_run, n_dc, n_moved, first_bad, (long long)dmax);
-        }
-        start = next;
-        dc_odd = odd_now;
-        if (all_exact) {
-          // ---- what the rings need at every cut: the 48 samples before it all "closed" (then dc_samples holds exactly
-          //      those samples, as the template does; win_samples always holds the last 100 amplitudes) ----
-          std::vector<int> uwc((size_t)U), lend((size_t)U);
-          HIPCHK(c, hipMemcpyAsync(uwc.data(), c->ls_uwc.p, sizeof(int) * (size_t)U, hipMemcpyDeviceToHost, c->stream));
-          HIPCHK(c, hipMemcpyAsync(lend.data(), (int *)c->ls_gath.p + 12 * 2 * (size_t)U, sizeof(int) * (size_t)U, hipMemcpyDeviceToHost,
-                                   c->stream));
-          HIPCHK(c, hipStreamSynchronize(c->stream));
-          std::vector<int> seq0((size_t)U, 0), wc((size_t)B, 0);
-          int last_end = -(1 << 30);
-          for (int u = 0; u < U && !restart; ++u) {
-            const GateUnit &un = units[(size_t)u];
-            if (un.pos0 == 0) last_end = -(1 << 30);
-            else if (last_end > un.pos0 - DC_LEN || start[(size_t)u].f[3] != 0) {
-              banned[cut_of_unit[(size_t)u]] = 1; restart = true; rep.cuts_dropped++;
-              break;
-            }
-            int k = uwc[(size_t)u];
-            if (k > uwmax) k = uwmax;
-            seq0[(size_t)u] = wc[(size_t)un.stream];
-            wc[(size_t)un.stream] += k;
-            if (k > 0) last_end = lend[(size_t)u];
-          }
-          if (restart) {
-            for (int u = 0; u < U; ++u) known[((int64_t)units[(size_t)u].stream << 32) | (uint32_t)units[(size_t)u].pos0] = start[(size_t)u];
-            break;
-          }
-          // ---- accept: the frozen runs ARE the sequential scan; assemble their windows ----
-          for (int s = 0; s < B; ++s) if (wc[(size_t)s] > c->wmax) wc[(size_t)s] = c->wmax;
-          HIPCHK(c, hipMemcpyAsync(c->ls_seq0.p, seq0.data(), sizeof(int) * (size_t)U, hipMemcpyHostToDevice, c->stream));
-          HIPCHK(c, hipMemcpyAsync(c->d_wcount, wc.data(), sizeof(int) * (size_t)B, hipMemcpyHostToDevice, c->stream));
-          HIPCHK(c, hipMemsetAsync(c->d_flat_count, 0, 2 * sizeof(int), c->stream));
-          LsAssembleArgs aa;
-          aa.units = (const GateUnit *)c->ls_units.p; aa.uwtab = (const rfid_window *)c->ls_uw.p; aa.uwcount = (const int *)c->ls_uwc.p;
-          aa.seq0 = (const int *)c->ls_seq0.p; aa.n_units = U; aa.uwmax = uwmax; aa.wtab = c->d_wtab; aa.wmax = c->wmax;
-          aa.flat = c->d_flat; aa.flat_count = c->d_flat_count; aa.flat_cap = c->flat_cap;
-          hipLaunchKernelGGL(ls_assemble_kernel, dim3((unsigned)U), dim3(64), 0, c->stream, aa);
-          HIPCHK(c, hipGetLastError());
-          HIPCHK(c, hipStreamSynchronize(c->stream));   // seq0 / wc are host vectors
-          if (opt.carry)   // (one trace) the state after its last processed unit
-            HIPCHK(c, hipMemcpyAsync(c->d_gstate, (GateState *)c->ls_state.p + (U - 1), sizeof(GateState), hipMemcpyDeviceToDevice,
-                                     c->stream));
-          accepted = true;
-          rep.verified = 1;
-          lap("accepted and assembled");
-          break;
-        }
-      }
-    }
-    if (accepted) { *done = 1; rep.chunk = (int)chunk; return RFID_OK; }
-    if (!restart) break;   // rounds exhausted
-  }
-  rep.gave_up = 1;
+  HIPCHK(c, hipMemcpyAsync(c->ls2_host, a.ctl, sizeof(Ls2Ctl), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync((char *)c->ls2_host + sizeof(Ls2Ctl), a.consumed, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  c->d_ls2_ctl = a.ctl;
+  c->ls2_P = geo.P;
+  *enqueued = 1;
   return RFID_OK;
 }
 }  // namespace
@@ -776,8 +336,10 @@ int rfid_ctx_create(const rfid_params *p, int device, rfid_ctx **out) {
   c->device = device;
   c->err[0] = 0;
   compute_t_cand(c->t_cand, p->sample_rate);
-  if (const char *e = getenv("RFID_LONG_STREAM")) c->ls_mode = atoi(e);
-  memset(&c->ls_rep, 0, sizeof(c->ls_rep));
+  if (const char *e = getenv("RFID_LONG_STREAM")) {
+    const int m = atoi(e);
+    c->ls_mode = m < 0 ? 0 : (m > 2 ? 2 : m);
+  }
   init_reader_state(c);
   memset(c->mf_hist, 0, sizeof(c->mf_hist));
   int rc = RFID_OK;
@@ -817,11 +379,10 @@ int rfid_ctx_destroy(rfid_ctx *c) {
   sio_free(c);
   free_plan(c);
   void *ptrs[] = {c->d_gate1, c->d_io, c->d_swin, c->d_scount, c->d_sres, c->d_sscores, c->s_in.p, c->s_out.p,
-                  c->synth_tab.p, c->ls_cut.p, c->ls_units.p, c->ls_runs.p, c->ls_tmpl.p, c->ls_state.p, c->ls_uw.p, c->ls_uwc.p,
-                  c->ls_heads.p, c->ls_seq0.p, c->ls_gath.p, c->ls_rec.p, c->ls_dcache.p, c->ls_avgbuf.p, c->ls_cutf.p};
+                  c->synth_tab.p, c->ls2_ws.p};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
-  if (c->ls_pin.p) (void)hipHostFree(c->ls_pin.p);
+  if (c->ls2_host) (void)hipHostFree(c->ls2_host);
   for (int i = 0; i < 5; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->stream2) {
@@ -948,6 +509,7 @@ int rfid_batch_plan(rfid_ctx *c, int n_streams, int64_t max_raw) {
   if (max_raw / DECIM > 0x7fffff00LL) return RFID_ERR_UNSUPPORTED;  // 32-bit sample indices per trace
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->sio.open) sio_free(c);   // a new plan replaces the work space an open stream runs on: the stream is closed
   free_plan(c);
   const int64_t n_dec = max_raw / DECIM;
   c->y_stride = (n_dec + 1) & ~1LL;  // even -> 16-byte aligned rows
@@ -980,6 +542,17 @@ int rfid_batch_plan(rfid_ctx *c, int n_streams, int64_t max_raw) {
     return fail(c, RFID_ERR_HIP, "rfid_batch_plan: workspace allocation", e);
   }
   c->B = c->B_plan = n_streams;
+  // the long-stream front end's work space, when this shape can take that path: reserved here so that a planned batch
+  // does not meet an allocation in its passes (a pass that finds none falls back to the sequential scan)
+  if (ls_applicable(c, n_streams, n_dec)) {
+    const size_t need = ls_workspace_bytes(n_streams, n_dec, c->y_stride);
+    if (need > c->ls2_ws.cap) {
+      if (c->ls2_ws.p) (void)hipFree(c->ls2_ws.p);
+      c->ls2_ws.p = nullptr; c->ls2_ws.cap = 0;
+      if (hipMalloc(&c->ls2_ws.p, need) == hipSuccess) c->ls2_ws.cap = need;
+      else { (void)hipGetLastError(); c->ls2_ws.p = nullptr; }
+    }
+  }
   hipDeviceProp_t prop;
   HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
   // persistent decoders: the EPC kernel holds 18.6 KiB of LDS per single-wave workgroup -> 8 per CU
@@ -1026,15 +599,16 @@ int rfid_batch_mf(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64_t n_
   return RFID_OK;
 }
 
-int rfid_batch_gate(rfid_ctx *c) {
+static int rfid_batch_gate_impl(rfid_ctx *c, const int *skip_if) {
   if (!c) return RFID_ERR_INVALID;
   if (!c->B) return RFID_ERR_STATE;
   HIPCHK(c, hipSetDevice(c->device));
   // fresh gate per trace (gate_impl ctor, gate_impl.cc:41-70): all-zero state; the kernel
   // arms n_samples_to_ungate for the first RN16 itself
   HIPCHK(c, hipMemsetAsync(c->d_gstate, 0, sizeof(GateState) * (size_t)c->B, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->d_flat_count, 0, 2 * sizeof(int), c->stream));
+  if (!skip_if) HIPCHK(c, hipMemsetAsync(c->d_flat_count, 0, 2 * sizeof(int), c->stream));   // (else: zeroed before the front end)
   GateArgs a = {};
+  a.skip_if = skip_if;
   a.y = c->d_y; a.y_stride = c->y_stride; a.n_dec = c->last_n_raw / DECIM; a.lens = c->d_lens;
   a.pos0 = 0; a.chunk_len = a.n_dec;
   a.state = c->d_gstate; a.n_streams = c->B; a.wtab = c->d_wtab; a.wmax = c->wmax; a.wcount = c->d_wcount;
@@ -1046,6 +620,10 @@ int rfid_batch_gate(rfid_ctx *c) {
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   c->ev_valid[2] = true;
   return RFID_OK;
+}
+int rfid_batch_gate(rfid_ctx *c) {
+  if (c) c->d_ls2_ctl = nullptr;
+  return rfid_batch_gate_impl(c, nullptr);
 }
 
 int rfid_batch_decode(rfid_ctx *c, int want_scores) {
@@ -1108,23 +686,15 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
   int nch = 1;
   if (const char *e = getenv("RFID_FRONT_CHUNKS")) nch = atoi(e);
   if (nch > rfid_ctx::MAX_CHUNKS) nch = rfid_ctx::MAX_CHUNKS;
-  memset(&c->ls_rep, 0, sizeof(c->ls_rep));
-  if (nch < 2 && c->ls_mode != 0 && n_out >= 2 * LS_MIN_CHUNK && (c->ls_mode == 2 || ls_pays_off(c->B, n_out))) {
-    // few long traces: matched filter, then the gate scan over concurrently scanned units of each trace
-    const double t_dbg = getenv("RFID_LS_DEBUG") ? ls_now_ms() : 0.0;
+  c->d_ls2_ctl = nullptr;
+  if (nch < 2 && ls_applicable(c, c->B, n_out)) {
+    // few long traces: matched filter, then the gate scan as the long-stream front end -- every launch of it enqueued
+    // here, the sequential scan behind them as the fallback that skips itself when the front end succeeded
     int rc = rfid_batch_mf(c, d_raw, raw_stride, n_raw, d_lens);
     if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(c->d_gstate, 0, sizeof(GateState) * (size_t)c->B, c->stream));
-    int done = 0;
-    if (t_dbg != 0.0) fprintf(stderr, "[ls] pass: %.2f ms of host time before the long-stream front end\n", ls_now_ms() - t_dbg);
-    if ((rc = ls_front_end(c, n_out, &done))) return rc;
-    if (t_dbg != 0.0) fprintf(stderr, "[ls] pass: %.2f ms when it returned\n", ls_now_ms() - t_dbg);
-    if (done) {
-      HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-      c->ev_valid[2] = true;
-    } else if ((rc = rfid_batch_gate(c))) {
-      return rc;
-    }
+    int enq = 0;
+    if ((rc = ls_enqueue(c, n_out, LsOpts(), &enq))) return rc;
+    if ((rc = rfid_batch_gate_impl(c, enq ? &c->d_ls2_ctl->ok : nullptr))) return rc;
     if ((rc = rfid_batch_decode(c, want_scores))) return rc;
     return rfid_batch_stats(c);
   }
@@ -1225,7 +795,23 @@ int rfid_batch_set_long_stream(rfid_ctx *c, int mode) {
 
 int rfid_batch_ls_report(const rfid_ctx *c, rfid_ls_report *out) {
   if (!c || !out) return RFID_ERR_INVALID;
-  *out = c->ls_rep;
+  memset(out, 0, sizeof(*out));
+  if (!c->d_ls2_ctl || !c->ls2_host) return RFID_OK;   // the last pass did not run the long-stream front end
+  (void)hipSetDevice(c->device);
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return RFID_ERR_HIP;   // (the copy of the control block rides on the pass)
+  const Ls2Ctl &k = *c->ls2_host;
+  const bool settled = k.fail == 0 && k.avg_count[LS2_AVG_ROUNDS] == 0 && k.fsm_count[LS2_FSM_ROUNDS] == 0 &&
+                       k.dc_count[LS2_DC_ROUNDS] == 0 && k.wb_clash == 0;
+  out->pieces = k.n_pieces;
+  out->units = k.n_units;
+  out->chunk = c->ls2_P;
+  out->avg_rounds = k.avg_rounds; out->avg_reruns = k.avg_reruns;
+  out->fsm_rounds = k.fsm_rounds;
+  out->dc_rounds = k.dc_rounds; out->dc_reruns = k.dc_reruns;
+  for (int r = 0; r <= LS2_FSM_ROUNDS; ++r) out->cuts_dropped += k.fsm_count[r];
+  out->windows = k.n_windows;
+  out->verified = (k.ok != 0 && settled) ? 1 : 0;
+  out->gave_up = out->verified ? 0 : (k.fail ? k.fail : (k.avg_count[LS2_AVG_ROUNDS] ? 2 : (k.fsm_count[LS2_FSM_ROUNDS] ? 3 : (k.dc_count[LS2_DC_ROUNDS] ? 4 : 5))));
   return RFID_OK;
 }
 
@@ -1647,6 +1233,7 @@ void sio_free(rfid_ctx *c) {
   if (io.copy_stream) (void)hipStreamDestroy(io.copy_stream);
   io.copy_stream = nullptr;
   io.open = false;
+  io.failed = false;
 }
 
 // READER_STATE bookkeeping for one decoded window, as the blocks do it call by call (tag_decoder_impl.cc:267-388,
@@ -1681,7 +1268,7 @@ int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
   float2 *data = io.d_buf[b] + (io.tail_max - io.tail_len);   // first held-back (or new) sample
   int64_t consumed = 0;                                 // decimated samples processed
   int n_windows = 0;
-  memset(&c->ls_rep, 0, sizeof(c->ls_rep));
+  c->d_ls2_ctl = nullptr;
   if (n_out > 0) {
     // ---- matched filter over everything available: y[n] = sum x[5n - 24 .. 5n], history in front of `data` ----
     MfArgs a;
@@ -1694,30 +1281,46 @@ int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
     HIPCHK(c, hipGetLastError());
     c->d_lens = nullptr;
     c->last_n_raw = n_have;
-    // ---- gate: units up to the last idle cut, from the carried state ----
+    // ---- gate: the pieces up to the last idle cut, from the carried state (the long-stream front end) ----
     LsOpts opt;
     opt.carry = true; opt.hold_last = !flush; opt.force = true;
-    int done = 0;
-    int rc = ls_front_end(c, n_out, &done, opt, &consumed);
+    int enq = 0;
+    int rc = ls_enqueue(c, n_out, opt, &enq);
     if (rc) return rc;
-    if (done) {
-      if (flush) consumed = n_out;
-    } else if (flush) {
-      // end of the stream and too little left to cut: the plain sequential scan from the carried state; only complete
-      // windows are recorded, as the decoder would only ever see those (tag_decoder_impl.cc:223,291)
+    bool ok = false;
+    if (enq) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      ok = c->ls2_host->ok != 0;
+      if (ok) consumed = flush ? n_out : *(const int *)((const char *)c->ls2_host + sizeof(Ls2Ctl));
+      if (ok && consumed <= 0) ok = false;
+    } else {
       HIPCHK(c, hipMemsetAsync(c->d_flat_count, 0, 2 * sizeof(int), c->stream));
-      HIPCHK(c, hipMemsetAsync(&c->d_gstate->win_seq, 0, sizeof(int), c->stream));   // windows are numbered per call
+    }
+    // What the front end could not take -- no idle cut in what is available (a silent or noise-only stretch, not a Gen2
+    // trace), rounds exhausted, or so much behind the last cut that it would not fit the hold-back area -- goes through
+    // the plain sequential scan from the carried state, up to EPC_WIN samples before the end of what is available: a
+    // window that opens there is complete within these samples, so its record is written (only complete windows are
+    // recorded, as the decoder would only ever see those: tag_decoder_impl.cc:223,291) and the next call resumes
+    // inside it, the gate open.  At the end of the stream: everything.
+    if (!ok) consumed = 0;
+    const int64_t seq_end = flush ? n_out : (n_out - EPC_WIN);
+    const bool tail_too_long = DECIM * (n_out - consumed) + (n_have - DECIM * n_out) + SIO_HIST > io.tail_max;
+    if ((!ok || tail_too_long) && seq_end > consumed) {
+      if (!ok) {
+        HIPCHK(c, hipMemsetAsync(c->d_flat_count, 0, 2 * sizeof(int), c->stream));
+        HIPCHK(c, hipMemsetAsync(&c->d_gstate->win_seq, 0, sizeof(int), c->stream));   // windows are numbered per call
+        HIPCHK(c, hipMemsetAsync(c->d_wcount, 0, sizeof(int), c->stream));
+      }
       GateArgs g = {};
-      g.y = c->d_y; g.y_stride = c->y_stride; g.n_dec = n_out; g.lens = nullptr; g.pos0 = 0; g.chunk_len = n_out;
+      g.y = c->d_y; g.y_stride = c->y_stride; g.n_dec = n_out; g.lens = nullptr; g.pos0 = consumed; g.chunk_len = seq_end - consumed;
       g.state = c->d_gstate; g.n_streams = 1; g.wtab = c->d_wtab; g.wmax = c->wmax; g.wcount = c->d_wcount;
       g.flat = c->d_flat; g.flat_count = c->d_flat_count; g.flat_cap = c->flat_cap; g.mode = 0;
       hipLaunchKernelGGL(gate_scan_kernel, dim3(1), dim3(GATE_THREADS), 0, c->stream, g);
       HIPCHK(c, hipGetLastError());
-      consumed = n_out;
-      done = 1;
-    } else {
-      consumed = 0;   // no verified idle cut in what is available: wait for more samples
+      consumed = seq_end;
+      ok = true;
     }
+    const bool done = ok;
     if (done) {
       // ---- decode what the gate found, fetch it ----
       c->ev_valid[2] = false;
@@ -1746,8 +1349,8 @@ int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
   }
   // ---- what was not processed moves in front of the other buffer's upload area, history included ----
   const int64_t left = n_have - DECIM * consumed;
-  if (left + SIO_HIST > io.tail_max)
-    return fail(c, RFID_ERR_CAPACITY, "rfid_stream_work: no idle point of the gate within the hold-back capacity (is this a Gen2 trace?)");
+  if (left + SIO_HIST > io.tail_max)   // (cannot happen: the sequential scan above leaves EPC_WIN samples at most)
+    return fail(c, RFID_ERR_CAPACITY, "rfid_stream_work: hold-back capacity exceeded");
   const int o = b ^ 1;
   HIPCHK(c, hipMemcpyAsync(io.d_buf[o] + (io.tail_max - left - SIO_HIST), data + DECIM * consumed - SIO_HIST,
                            sizeof(float2) * (size_t)(left + SIO_HIST), hipMemcpyDeviceToDevice, c->stream));
@@ -1762,15 +1365,15 @@ int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
 extern "C" {
 
 int rfid_stream_begin(rfid_ctx *c, int64_t max_chunk_raw) {
-  if (!c || max_chunk_raw < 5 * 4 * LS_MIN_CHUNK) return RFID_ERR_INVALID;   // a chunk must hold a few units
+  if (!c || max_chunk_raw < 5 * 4 * LS2_MIN_PIECE) return RFID_ERR_INVALID;   // a chunk must hold a few pieces
   HIPCHK(c, hipSetDevice(c->device));
   rfid_ctx::StreamIO &io = c->sio;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   sio_free(c);
-  // held back per call: at most one (stretched) unit of the chunk's unit grid + the cut search range
-  int64_t chunk_units = (max_chunk_raw / DECIM + LS_TARGET_UNITS - 1) / LS_TARGET_UNITS;
-  if (chunk_units < LS_MIN_CHUNK) chunk_units = LS_MIN_CHUNK;
-  io.tail_max = ((DECIM * 4 * chunk_units + SIO_HIST + 63) & ~63LL);
+  // held back per call: at most a few (stretched) pieces of the largest call's grid -- more goes through the sequential scan
+  int64_t piece = (max_chunk_raw / DECIM + LS2_TARGET_PIECES - 1) / LS2_TARGET_PIECES;
+  if (piece < LS2_MIN_PIECE) piece = LS2_MIN_PIECE;
+  io.tail_max = ((DECIM * 6 * piece + DECIM * (int64_t)EPC_WIN + SIO_HIST + 63) & ~63LL);
   io.max_chunk = max_chunk_raw;
   int rc = rfid_batch_plan(c, 1, io.tail_max + max_chunk_raw);
   if (rc) return rc;
@@ -1810,7 +1413,7 @@ int rfid_stream_work(rfid_ctx *c, const rfid_cf32 *raw, int64_t n_raw, int flush
                      rfid_decode_result *results, int64_t cap, int64_t *n_out) {
   if (!c || n_raw < 0 || (n_raw > 0 && !raw) || !n_out || cap < 0) return RFID_ERR_INVALID;
   rfid_ctx::StreamIO &io = c->sio;
-  if (!io.open) return RFID_ERR_STATE;
+  if (!io.open || io.failed) return RFID_ERR_STATE;
   if (n_raw > io.max_chunk) return RFID_ERR_CAPACITY;
   HIPCHK(c, hipSetDevice(c->device));
   *n_out = 0;
@@ -1841,7 +1444,7 @@ int rfid_stream_work(rfid_ctx *c, const rfid_cf32 *raw, int64_t n_raw, int flush
   if (io.pending) {
     HIPCHK(c, hipStreamWaitEvent(c->stream, io.ev_up[io.pend_idx], 0));
     int rc = sio_process(c, io.pend_idx, io.pend_new, false);
-    if (rc) return rc;
+    if (rc) { io.failed = true; return rc; }
     io.pending = false;
   }
   if (n_raw > 0) { io.pending = true; io.pend_idx = up_idx; io.pend_new = n_raw; }
@@ -1850,11 +1453,11 @@ int rfid_stream_work(rfid_ctx *c, const rfid_cf32 *raw, int64_t n_raw, int flush
     if (io.pending) {
       HIPCHK(c, hipStreamWaitEvent(c->stream, io.ev_up[io.pend_idx], 0));
       int rc = sio_process(c, io.pend_idx, io.pend_new, true);
-      if (rc) return rc;
+      if (rc) { io.failed = true; return rc; }
       io.pending = false;
     } else if (io.tail_len > 0) {
       int rc = sio_process(c, io.cur, 0, true);   // the held-back samples sit in front of the next upload area
-      if (rc) return rc;
+      if (rc) { io.failed = true; return rc; }
     }
   }
   // ---- 4. deliver ----

@@ -153,15 +153,6 @@ struct GateState {  // gate_impl members (gate_impl.h:36-44) + the READER_STATE 
   float dcr_im[DC_LEN];
 };
 
-// long-stream mode: one trace cut along time into units that are scanned concurrently, each from its own
-// (predicted) gate state -- see rfid_capi.hip, long-stream front end
-struct GateUnit {
-  int stream;           // trace the unit belongs to
-  int pos0;             // first decimated sample of the unit
-  int len;              // samples in the unit
-  int row;              // row of state / wtab / wcount this run uses (units are re-run selectively)
-};
-
 struct GateArgs {
   const float2 *y;      // [n_streams][y_stride] matched-filter output
   int64_t y_stride;
@@ -188,12 +179,9 @@ struct GateArgs {
   int64_t n_raw;        // valid raw samples per trace (when lens == nullptr)
   int raw_vec_ok;       // rows 16-byte aligned -> float4 loads
   float2 *y_w;          // [n_streams][y_stride], written
-  const GateUnit *units; // optional: n_streams counts UNITS; state / wtab / wcount are per unit
-  // long-stream mode: the closed samples of every step (gate_impl.cc:139-143) go to rec[(row % rec_mod) * rec_stride
-  // + step] -- they depend on avg_ampl and the state machine only, so a unit whose start was right in those can be
-  // re-run for another dc_est start value by ls_dc_kernel alone
-  uint64_t *rec;
-  int rec_stride, rec_mod;
+  // optional: the launch does nothing when *skip_if != 0 (the sequential scan enqueued behind the long-stream front end
+  // as its fallback: it only runs when that front end gave up)
+  const int *skip_if;
 };
 
 // x / C for the gate's two constant divisors (100: gate_impl.cc:131, 48: :141) in three instructions
@@ -415,57 +403,18 @@ RFID_DEVICE void gate_record_window(const GateArgs &a, GateBackRegs &g, int ol, 
   g.win_seq++;
 }
 
-// ---- consumer wave: avg_ampl, the threshold votes, the scalar state machine -----------------------
-// Step k goes through the edge / pulse / window state machine (on the scalar unit, over the vote masks); what the
-// back wave needs -- which samples are "closed" (update dc_est), which lie inside a window, the gate openings --
-// is left in the slot.
-
-// the next step's slot, fetched one step early by the consumer
-struct GateNext {
-  int step;           // the step these values belong to (-1: none)
-  int sq;             // the sequence word as read just before them: valid iff > step
-  float amp, d;
-};
-
-RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateSlot *slot, const GateSlot *slot_next, GateNext &nx,
-                              const int *seq, int k, int pos, int n, int lane) {
-  float f_amp = 0.0f, f_d = 0.0f;
-  {
-    // Wait for step k and fetch it in ONE LDS round trip: the sequence word and the slot are read
-    // back to back (a wave's LDS reads execute in order, and the producer wrote the slot
-    // before it advanced the sequence word), and only then is the sequence word looked at.
-    // Usually not even that: the previous step already fetched this slot (see below).
-    if (nx.step == k && wv::uniform(nx.sq) > k) {
-      f_amp = nx.amp; f_d = nx.d;
-    } else {
-      for (;;) {
-        const int sq = wv::lds_peek(seq);
-        f_amp = slot->amp[lane]; f_d = slot->d[lane];
-        if (wv::uniform(sq) > k) break;
-        wv::backoff();
-      }
-    }
-    // fetch step k+1 now: the producer is normally more than one step ahead, and the reads
-    // complete while this step is worked on (the sequence word tells the next call whether they count)
-    nx.sq = wv::lds_peek(seq);
-    nx.amp = slot_next->amp[lane]; nx.d = slot_next->d[lane];
-    nx.step = k + 1;
-  }
-  // avg_ampl after every sample (gate_impl.cc:130-134): the in-order sum in its integer-scan form where that is
-  // provably exact, the 63-step chain otherwise; then the 0.75 avg threshold test (:136,147,155) as two votes
-  int nvalid = (n - pos < 64) ? (n - pos) : 64;
-  const float avg_in = g.avg_c;
-  const float avg = chain_add_auto(g.avg_c, f_d, lane);
-  g.avg_c = wv::readlane(avg, 63);   // the lanes past the end of the call add +0
-  const float thresh = avg * THRESH_FRACTION;
-  const uint64_t below = wv::ballot(lane < nvalid && f_amp < thresh);
-  const uint64_t above = wv::ballot(lane < nvalid && f_amp > thresh);
+// One step (64 samples, the first `nvalid` of them valid) through the edge / pulse / window state machine of
+// gate_impl.cc:145-195, on the scalar unit over the two threshold-vote masks.  Out: which samples are "closed" (update
+// dc_est), which lie inside an open window, and the gate opening of the step if there is one.  Shared by the consumer
+// wave of the gate scan and by the long-stream front end's state-machine pass (rfid_ls2.hpp).
+RFID_DEVICE void gate_fsm_step(const int mode, GateRegs &g, const uint64_t below, const uint64_t above, const int pos, int &nvalid,
+                               uint64_t &closedmask, uint64_t &openmask, int &open_lane, int &open_type) {
   const bool plain_open = (nvalid == 64) && g.f_open && (g.f_ung - g.f_n > 64);
   const bool plain_closed = (nvalid == 64) && !g.f_open && (g.f_state == 1) && (below == 0) &&
                             !((g.f_pulses > NUM_PULSES_CMD) && (T1_SAMPLES - g.f_n < 64));
   // what the back wave gets for this step
-  uint64_t closedmask = 0, openmask = 0;
-  int open_lane = 0xff, open_type = 0;   // (at most one opening per step: a window is longer than a step)
+  closedmask = 0; openmask = 0;
+  open_lane = 0xff; open_type = 0;   // (at most one opening per step: a window is longer than a step)
 
   // The two by far most frequent kinds of step are decided with a handful of scalar
   // instructions (the consumer wave is issue bound: every instruction costs ~4.5 cycles):
@@ -490,7 +439,7 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateSlot *slot, co
       p = take;
       if (f_n >= f_ung) {  // gate_impl.cc:189-194
         f_open = 0;
-        if (a.mode == 0) {  // decoder + reader ran; gate re-armed at the next sample (:112-123)
+        if (mode == 0) {  // decoder + reader ran; gate re-armed at the next sample (:112-123)
           f_n = 0;
           f_type ^= 1;
           f_ung = f_type ? EPC_WIN : RN16_WIN;
@@ -561,10 +510,60 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateSlot *slot, co
     }
     g.f_n = f_n; g.f_state = f_state; g.f_pulses = f_pulses; g.f_open = f_open;
     g.f_ung = f_ung; g.f_type = f_type;
-    // streaming mode stopped inside the step: avg_ampl carries only over the samples actually consumed
-    if (g.stop) g.avg_c = (nvalid > 0) ? wv::readlane(avg, nvalid - 1) : avg_in;
   }
   if (!g.f_open && g.f_n > GATE_N_SAT) g.f_n = GATE_N_SAT;
+}
+
+// ---- consumer wave: avg_ampl, the threshold votes, the scalar state machine -----------------------
+// Step k goes through the edge / pulse / window state machine (on the scalar unit, over the vote masks); what the
+// back wave needs -- which samples are "closed" (update dc_est), which lie inside a window, the gate openings --
+// is left in the slot.
+
+// the next step's slot, fetched one step early by the consumer
+struct GateNext {
+  int step;           // the step these values belong to (-1: none)
+  int sq;             // the sequence word as read just before them: valid iff > step
+  float amp, d;
+};
+
+RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateSlot *slot, const GateSlot *slot_next, GateNext &nx,
+                              const int *seq, int k, int pos, int n, int lane) {
+  float f_amp = 0.0f, f_d = 0.0f;
+  {
+    // Wait for step k and fetch it in ONE LDS round trip: the sequence word and the slot are read
+    // back to back (a wave's LDS reads execute in order, and the producer wrote the slot
+    // before it advanced the sequence word), and only then is the sequence word looked at.
+    // Usually not even that: the previous step already fetched this slot (see below).
+    if (nx.step == k && wv::uniform(nx.sq) > k) {
+      f_amp = nx.amp; f_d = nx.d;
+    } else {
+      for (;;) {
+        const int sq = wv::lds_peek(seq);
+        f_amp = slot->amp[lane]; f_d = slot->d[lane];
+        if (wv::uniform(sq) > k) break;
+        wv::backoff();
+      }
+    }
+    // fetch step k+1 now: the producer is normally more than one step ahead, and the reads
+    // complete while this step is worked on (the sequence word tells the next call whether they count)
+    nx.sq = wv::lds_peek(seq);
+    nx.amp = slot_next->amp[lane]; nx.d = slot_next->d[lane];
+    nx.step = k + 1;
+  }
+  // avg_ampl after every sample (gate_impl.cc:130-134): the in-order sum in its integer-scan form where that is
+  // provably exact, the 63-step chain otherwise; then the 0.75 avg threshold test (:136,147,155) as two votes
+  int nvalid = (n - pos < 64) ? (n - pos) : 64;
+  const float avg_in = g.avg_c;
+  const float avg = chain_add_auto(g.avg_c, f_d, lane);
+  g.avg_c = wv::readlane(avg, 63);   // the lanes past the end of the call add +0
+  const float thresh = avg * THRESH_FRACTION;
+  const uint64_t below = wv::ballot(lane < nvalid && f_amp < thresh);
+  const uint64_t above = wv::ballot(lane < nvalid && f_amp > thresh);
+  uint64_t closedmask, openmask;
+  int open_lane, open_type;
+  gate_fsm_step(a.mode, g, below, above, pos, nvalid, closedmask, openmask, open_lane, open_type);
+  // streaming mode stopped inside the step: avg_ampl carries only over the samples actually consumed
+  if (g.stop) g.avg_c = (nvalid > 0) ? wv::readlane(avg, nvalid - 1) : avg_in;
   // hand the step to the back wave (lane 0 writes after this wave's earlier LDS writes: in-order queue)
   wv::lds_store_desc(&slot->b_flags, ((closedmask != 0) ? 1 : 0) | (g.stop ? 2 : 0), nvalid, closedmask, openmask,
                      open_lane | (open_type << 8), lane);
@@ -578,11 +577,12 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateSlot *slot, co
 // streaming, the gated samples in[i] - dc_est (:176,187).
 // the dc_est part of one step with closed samples: increments (from `spec` while whole steps are closed, else from
 // the ring), ring upkeep, the two in-order sums; dcr / dci = dc_est after every sample of the step
-template <bool SCAN, class Spec>
-RFID_DEVICE void gate_dc_step(GateBackRegs &g, uint64_t closedmask, uint64_t openmask, int nvalid, float2 yv, int lane,
-                              float2 *lds_dc, float2 *lds_tmp, Spec spec, float &dcr, float &dci) {
+// (first half: the increments of the step's closed samples and the ring upkeep; shared with the long-stream front end's
+// dc_est pass, which sums them from two start values at once)
+template <class Spec>
+RFID_DEVICE void gate_dc_incr(GateBackRegs &g, uint64_t closedmask, uint64_t openmask, int nvalid, float2 yv, int lane,
+                              float2 *lds_dc, float2 *lds_tmp, Spec spec, float &tre, float &tim) {
   const int cnt = wv::popc64(closedmask);
-  float tre, tim;
   if (__builtin_expect(cnt == 64 && openmask == 0 && g.run_closed >= DC_LEN, 1)) {
     // the 48 samples before every lane were closed too: dc_samples[dc_index] is x[i-48] and the speculative
     // increments are the reference's; the ring itself is left alone
@@ -647,6 +647,12 @@ RFID_DEVICE void gate_dc_step(GateBackRegs &g, uint64_t closedmask, uint64_t ope
     }
   }
   g.prev_yv = yv;
+}
+template <bool SCAN, class Spec>
+RFID_DEVICE void gate_dc_step(GateBackRegs &g, uint64_t closedmask, uint64_t openmask, int nvalid, float2 yv, int lane,
+                              float2 *lds_dc, float2 *lds_tmp, Spec spec, float &dcr, float &dci) {
+  float tre, tim;
+  gate_dc_incr(g, closedmask, openmask, nvalid, yv, lane, lds_dc, lds_tmp, spec, tre, tim);
   if (SCAN) {
     // (ls_dc_kernel: one wave per unit, bound by the latency of its own sums.  In the back wave of the 4-wave
     // pipeline the two interleaved chains are faster: 2.45 vs 2.69 ms for the fused front end)
@@ -660,11 +666,10 @@ RFID_DEVICE void gate_dc_step(GateBackRegs &g, uint64_t closedmask, uint64_t ope
 }
 
 RFID_DEVICE void gate_back(const GateArgs &a, GateBackRegs &g, const GateSlot *slot, int pos, int n_total, int row, int lane,
-                           float2 *lds_dc, float2 *lds_tmp, uint64_t *rec, bool &stop) {
+                           float2 *lds_dc, float2 *lds_tmp, bool &stop) {
   int flags, nvalid, open;
   uint64_t closedmask, openmask;
   wv::lds_load_desc(&slot->b_flags, flags, nvalid, closedmask, openmask, open);
-  if (rec && lane == 0) *rec = closedmask;
   float dcr, dci;
   if (flags & 1) {
     gate_dc_step<false>(g, closedmask, openmask, nvalid, slot->yv[lane], lane, lds_dc, lds_tmp,
@@ -816,12 +821,9 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
   }
   wv::block_sync();   // once, before any hand-off
   if (s >= a.n_streams) return;
-  int strm = s, row = s;
-  int64_t pos0 = a.pos0, chunk_len = a.chunk_len;
-  if (a.units) {   // long-stream mode: s is a unit run
-    strm = wv::uniform(a.units[s].stream); pos0 = wv::uniform(a.units[s].pos0); chunk_len = wv::uniform(a.units[s].len);
-    row = wv::uniform(a.units[s].row);
-  }
+  if (a.skip_if && wv::uniform(*a.skip_if) != 0) return;
+  const int strm = s, row = s;
+  const int64_t pos0 = a.pos0, chunk_len = a.chunk_len;
   GateState *st = a.state + row;
   const float2 *ys = a.y + (int64_t)strm * a.y_stride + pos0;
   int64_t n64 = a.n_dec;
@@ -973,7 +975,6 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
     g.n_complete = 0; g.written = 0;
     g.pos0 = (int)pos0; g.strm = strm;
     wv::wave_sync();
-    uint64_t *rec = a.rec ? a.rec + (int64_t)(row % a.rec_mod) * a.rec_stride : nullptr;
     bool stop = false;
     int fsm_seen = 0;    // sh.fsm_seq as last read (it only grows)
     for (int k = 0; k < nsteps && !stop; ++k) {
@@ -989,7 +990,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
         }
       }
       if (!have) break;
-      gate_back(a, g, &sh.slots[k % GATE_SLOTS], 64 * k, n_total, row, lane, lds_dc, lds_tmp, rec ? rec + k : nullptr, stop);
+      gate_back(a, g, &sh.slots[k % GATE_SLOTS], 64 * k, n_total, row, lane, lds_dc, lds_tmp, stop);
       wv::lds_store(&sh.back_seq, k + 1, lane);   // slot k free again
     }
     if (g.ring_stale) {
@@ -1005,7 +1006,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
     if (lane == 0) {
       st->dc_re = g.dcr_c; st->dc_im = g.dci_c; st->win_seq = g.win_seq; st->dc_index = g.dc_index;
       if (a.mode == 0) {
-        const int before = (pos0 > 0 && !a.units) ? a.wcount[row] : 0;   // windows recorded by earlier chunks
+        const int before = (pos0 > 0) ? a.wcount[row] : 0;   // windows recorded by earlier chunks
         const int tot = before + g.n_complete;
         a.wcount[row] = (tot < a.wmax) ? tot : a.wmax;
       } else {
@@ -1062,13 +1063,9 @@ RFID_KERNEL_OCC(GATE_THREADS, GATE_WAVES_PER_SIMD) void gate_scan_kernel(GateArg
 RFID_KERNEL_OCC(GATE_THREADS, GATE_WAVES_PER_SIMD) void front_end_fused_kernel(GateArgs a) { gate_scan_body<true>(a); }
 
 // =========================================================================================
-// 2b. Long-stream front end: helpers around gate_scan_kernel for ONE long trace (or a few) cut along time into
-//     units that are scanned concurrently.  The gate's recurrences (avg_ampl, dc_est: in-order binary32 sums over
-//     the whole trace) make a unit's result depend on the exact values it starts from; the host (rfid_capi.hip)
-//     predicts them, runs the units, and accepts the result only when every unit's start state is bit-identical to
-//     its predecessor's end state -- so the concatenation IS the sequential scan of gate_impl.cc:127-196.
-//     Units are cut where the gate's state machine is in its idle state: closed, POS_EDGE, no pulses counted, the
-//     last 48 samples closed (then the two rings hold exactly the preceding samples) -- found here from the data.
+// 2b. Long-stream front end (rfid_ls2.hpp): where ONE long trace (or a few) can be cut along time.  Pieces are cut
+//     where the gate's state machine is in its idle state: closed, POS_EDGE, no pulses counted, the last 48 samples
+//     closed (then the two rings hold exactly the preceding samples) -- found here from the data.
 // =========================================================================================
 constexpr int LS_QUIET = EPC_WIN + T1_SAMPLES + 1 + WIN_LEN + DC_LEN;   // 1615: a window opened by the last command has closed,
                                                                         // both rings have refilled and n_samples has saturated since
@@ -1129,380 +1126,9 @@ RFID_KERNEL(64) void ls_cut_kernel(LsCutArgs a) {
   if (lane == 0) *out = found;
 }
 
-struct LsInitArgs {
-  const float2 *y;
-  int64_t y_stride;
-  const GateUnit *units;
-  int n_units;
-  GateState *tmpl;         // [n_units]: rings + idle state machine; avg_ampl / dc_est = first guesses
-  const GateState *carry;  // optional [n_streams]: the state a trace's FIRST unit starts from (streaming: the gate
-                           // state the previous call ended in); nullptr = the fresh gate
-};
-
-// template gate state of a unit: the rings as the sequential scan leaves them at an idle cut (the last 100
-// amplitudes, the last 48 samples), the state machine idle, avg_ampl / dc_est guessed as the ring means
-RFID_KERNEL(64) void ls_init_kernel(LsInitArgs a) {
-  RFID_SHARED float amp[WIN_LEN];
-  const int lane = wv::lane_id();
-  const int u = (int)blockIdx.x;
-  if (u >= a.n_units) return;
-  GateState *st = a.tmpl + u;
-  const int pos0 = a.units[u].pos0;
-  {  // zero everything first (a unit that starts the trace is the fresh gate of gate_impl.cc:41-70)
-    int *w = reinterpret_cast<int *>(st);
-    for (int i = lane; i < (int)(sizeof(GateState) / 4); i += 64) w[i] = 0;
-  }
-  wv::wave_sync();
-  if (pos0 == 0) {   // (only a trace's first unit starts before sample 100: cuts lie >= LS_QUIET into the trace)
-    if (a.carry) {
-      const int *src = reinterpret_cast<const int *>(a.carry + a.units[u].stream);
-      int *w = reinterpret_cast<int *>(st);
-      for (int i = lane; i < (int)(sizeof(GateState) / 4); i += 64) w[i] = src[i];
-      wv::wave_sync();
-      if (lane == 0) st->win_seq = 0;   // windows are numbered per unit (the carried count belongs to earlier calls)
-    }
-    return;
-  }
-  const float2 *ys = a.y + (int64_t)a.units[u].stream * a.y_stride;
-  for (int i = lane; i < WIN_LEN; i += 64) {
-    const float2 v = ys[pos0 - WIN_LEN + i];
-    const float h = wv::hypot_f(v.x, v.y);
-    st->win[i] = h;
-    amp[i] = h;
-  }
-  if (lane < DC_LEN) {
-    const float2 v = ys[pos0 - DC_LEN + lane];
-    st->dcr_re[lane] = v.x;
-    st->dcr_im[lane] = v.y;
-  }
-  wv::wave_sync();
-  if (lane == 0) {
-    double sa = 0.0, sr = 0.0, si = 0.0;
-    for (int i = 0; i < WIN_LEN; ++i) sa += (double)amp[i];
-    for (int i = 0; i < DC_LEN; ++i) { const float2 v = ys[pos0 - DC_LEN + i]; sr += (double)v.x; si += (double)v.y; }
-    st->avg_ampl = (float)(sa / WIN_LEN);
-    st->dc_re = (float)(sr / DC_LEN);
-    st->dc_im = (float)(si / DC_LEN);
-    st->n_samples = GATE_N_SAT;        // saturated: no edge and no window end in the last GATE_N_SAT samples
-    st->signal_state = 1;              // POS_EDGE
-    st->num_pulses = 0;
-    st->gate_open = 0;
-    st->n_to_ungate = RN16_WIN;        // the next window is an RN16
-    st->wtype = 0;
-    st->win_index = 0; st->dc_index = 0; st->win_seq = 0;
-  }
-}
-
-// avg_ampl alone over the units (gate_impl.cc:130-133: the amplitude ring and the in-order sum; no state machine, no
-// dc_est): one wave per run, many per SIMD.  The long-stream front end settles the exact avg_ampl at every cut with
-// this cheap pass first -- the threshold tests, hence the state machine, hence which samples dc_est sums over, all
-// hang on it -- before the full gate scan runs.  Same arithmetic as the producer / consumer waves, value for value.
-struct LsAvgArgs {
-  const float2 *y;
-  int64_t y_stride;
-  const GateUnit *units;   // [n_runs]: row = index into start / end
-  int n_runs;
-  float *start;            // avg_ampl at the unit's first sample; NaN = not known yet: the run starts from the mean of the
-                           // 100 amplitudes before the unit (+ 1 ulp for rows >= n_units, variant B) and writes that back
-  float *end;              // avg_ampl after its last sample
-  const GateState *carry;  // optional [n_streams]: amplitude ring a trace's first unit starts with (else all zero)
-  // the addends (|x| - win_samples[win_index]) / 100 depend on the samples only, not on where avg_ampl starts: the
-  // first pass (every unit runs) leaves them in dcache[stream * y_stride + sample], later passes add them up again
-  float *dcache;
-  int cache_mode;          // 0 not used, 1 write (rows < n_units), 2 read
-  int n_units;
-};
-RFID_KERNEL(64) void ls_avg_kernel(LsAvgArgs a) {
-  const int lane = wv::lane_id();
-  const int r = (int)blockIdx.x;
-  if (r >= a.n_runs) return;
-  const GateUnit un = a.units[r];
-  const int pos0 = wv::uniform(un.pos0), n = wv::uniform(un.len), row = wv::uniform(un.row);
-  const float2 *ys = a.y + (int64_t)wv::uniform(un.stream) * a.y_stride + pos0;
-  // amplitudes of the 128 samples before the unit (the ring of gate_impl.cc:131 holds the last 100); a unit that
-  // starts the trace has an all-zero ring
-  float a2 = 0.0f, a1 = 0.0f;
-  if (pos0 >= 128) {
-    const float2 p2 = ys[lane - 128], p1 = ys[lane - 64];
-    a2 = wv::hypot_f(p2.x, p2.y);
-    a1 = wv::hypot_f(p1.x, p1.y);
-  } else if (a.carry) {
-    // sample -j (j = 1..100) of the carried ring: win[(win_index - j) mod 100] (win_index = the oldest = next written)
-    const GateState *cs = a.carry + wv::uniform(un.stream);
-    const int wi = wv::uniform(cs->win_index);
-    const int j1 = 64 - lane, j2 = 128 - lane;
-    a1 = cs->win[(wi - j1 + 2 * WIN_LEN) % WIN_LEN];
-    a2 = (j2 <= WIN_LEN) ? cs->win[(wi - j2 + 2 * WIN_LEN) % WIN_LEN] : 0.0f;
-  }
-  float avg = wv::uniform(a.start[row]);
-  if (avg != avg) {
-    // first guess: the ring mean (what avg_ampl is up to its rounding drift), lanes 28..63 of a2 and all of a1
-    float part = a1 + ((lane >= 28) ? a2 : 0.0f);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) part += wv::shfl_xor(part, off);
-    avg = wv::uniform(part) / WIN_LEN_F;
-    if (row >= a.n_units) avg = wv::u2f(wv::f2u(avg) + 1u);   // (amplitudes are >= 0: the next binary32 value up)
-    if (lane == 0) a.start[row] = avg;
-  }
-  const int nsteps = (n + 63) >> 6;
-  if (a.cache_mode == 2) {
-    const float *dc = a.dcache + (int64_t)wv::uniform(un.stream) * a.y_stride + pos0;
-    constexpr int AHEAD = 4;
-    float buf[AHEAD];
-#pragma unroll
-    for (int j = 0; j < AHEAD; ++j) { const int i = 64 * j + lane; buf[j] = (i < n) ? dc[i] : 0.0f; }
-    for (int kb = 0; kb < nsteps; kb += AHEAD) {
-#pragma unroll
-      for (int j = 0; j < AHEAD; ++j) {
-        if (kb + j < nsteps) {
-          const float d = buf[j];
-          const int i = 64 * (kb + j + AHEAD) + lane;
-          buf[j] = (i < n) ? dc[i] : 0.0f;
-          avg = wv::readlane(chain_add_auto(avg, d, lane), 63);
-        }
-      }
-    }
-    if (lane == 0) a.end[row] = avg;
-    return;
-  }
-  float *dcw = (a.cache_mode == 1 && row < a.n_units) ? a.dcache + (int64_t)wv::uniform(un.stream) * a.y_stride + pos0 : nullptr;
-  float2 v = (lane < n) ? ys[lane] : make_float2(0.0f, 0.0f);
-  for (int k = 0; k < nsteps; ++k) {
-    const int i_next = 64 * (k + 1) + lane;
-    const float2 vn = (i_next < n) ? ys[i_next] : make_float2(0.0f, 0.0f);   // next step in flight
-    const bool valid = 64 * k + lane < n;
-    const float amp = wv::hypot_f(v.x, v.y);
-    // sample i - 100: lanes 0..35 take it from two steps back (lane + 28), lanes 36..63 from the previous step (lane - 36)
-    const float o2 = wv::shfl(a2, (lane + 28) & 63), o1 = wv::shfl(a1, (lane - 36) & 63);
-    const float old = (lane < 36) ? o2 : o1;
-    const float nd = valid ? (amp - old) : 0.0f;
-    const float d = div_const<WIN_LEN>(nd);
-    if (dcw && valid) dcw[64 * k + lane] = d;
-    const float sacc = chain_add_auto(avg, d, lane);
-    avg = wv::readlane(sacc, 63);
-    a2 = a1; a1 = amp; v = vn;
-  }
-  if (lane == 0) a.end[row] = avg;
-}
-
-// start values for this round: state[u] = tmpl[u] (the rings) with the three recurrences and the scalar state of
-// the edge / pulse / window state machine replaced by the predicted ones
-constexpr int LS_HEAD_WORDS = 9;   // avg_ampl, dc_re, dc_im, n_samples, signal_state, num_pulses, gate_open, n_to_ungate, wtype
-struct LsHeadsArgs {
-  const GateState *tmpl;   // [n_units]
-  GateState *state;        // [2 n_units] rows
-  const int *heads;        // [2 n_units][LS_HEAD_WORDS] by row (floats as bit patterns)
-  const GateUnit *runs;    // [n_runs]: row = state row; template = row mod n_units
-  int n_runs, n_units;
-};
-RFID_KERNEL(64) void ls_set_state_kernel(LsHeadsArgs a) {
-  const int lane = wv::lane_id();
-  const int r = (int)blockIdx.x;
-  if (r >= a.n_runs) return;
-  const int row = a.runs[r].row;
-  const int *src = reinterpret_cast<const int *>(a.tmpl + (row % a.n_units));
-  int *dst = reinterpret_cast<int *>(a.state + row);
-  for (int i = lane; i < (int)(sizeof(GateState) / 4); i += 64) dst[i] = src[i];
-  wv::wave_sync();
-  // the nine values are the first nine words of GateState, in this order
-  if (lane < LS_HEAD_WORDS) dst[lane] = a.heads[LS_HEAD_WORDS * row + lane];
-}
-
-// dc_est alone over the units (gate_impl.cc:139-143,176): which samples are "closed" was recorded by the unit's full
-// gate scan (GateArgs::rec) and depends on avg_ampl and the state machine only, so another start value of dc_est
-// needs neither of them again -- one wave per run, many per SIMD, the back wave's arithmetic value for value.
-// Writes dc_est and the dc ring at the unit's end into the run's state row and the dc_est fields of its window records.
-struct LsDcArgs {
-  const float2 *y;
-  int64_t y_stride;
-  const GateUnit *runs;    // [n_runs]: row = state / window-table row; unit = row mod n_units
-  int n_runs, n_units;
-  const GateState *tmpl;   // [n_units]: the dc ring at the unit's first sample
-  const int *heads;        // [2 n_units][LS_HEAD_WORDS] by row: words 1, 2 = dc_est (re, im) at the unit's first sample
-  GateState *state;        // [2 n_units] rows
-  const uint64_t *rec;     // [n_units][rec_stride]: the closed samples of every step
-  int rec_stride;
-  rfid_window *uwtab;      // [2 n_units][uwmax]: starts / types from row (row mod n_units) -- the unit's full scan
-  int *uwcount;
-  int uwmax;
-};
-RFID_KERNEL(64) void ls_dc_kernel(LsDcArgs a) {
-  RFID_SHARED float2 lds_dc[DC_LEN];
-  RFID_SHARED float2 lds_tmp[64];
-  const int lane = wv::lane_id();
-  const int r = (int)blockIdx.x;
-  if (r >= a.n_runs) return;
-  const GateUnit un = a.runs[r];
-  const int pos0 = wv::uniform(un.pos0), n = wv::uniform(un.len), row = wv::uniform(un.row);
-  const int u = row % a.n_units;
-  const float2 *ys = a.y + (int64_t)wv::uniform(un.stream) * a.y_stride + pos0;
-  const GateState *ts = a.tmpl + u;
-  GateState *st = a.state + row;
-  if (lane < DC_LEN) lds_dc[lane] = make_float2(ts->dcr_re[lane], ts->dcr_im[lane]);
-  GateBackRegs g;
-  g.dcr_c = __builtin_bit_cast(float, wv::uniform(a.heads[LS_HEAD_WORDS * row + 1]));
-  g.dci_c = __builtin_bit_cast(float, wv::uniform(a.heads[LS_HEAD_WORDS * row + 2]));
-  g.dc_index = wv::uniform(ts->dc_index);
-  g.run_closed = 0; g.ring_stale = 0;
-  g.prev_yv = make_float2(0.0f, 0.0f);
-  g.win_seq = 0; g.n_complete = 0; g.written = 0; g.pos0 = pos0; g.strm = wv::uniform(un.stream);
-  wv::wave_sync();
-  const rfid_window *wsrc = a.uwtab + (int64_t)u * a.uwmax;
-  rfid_window *wdst = a.uwtab + (int64_t)row * a.uwmax;
-  int nw = wv::uniform(a.uwcount[u]);
-  if (nw > a.uwmax) nw = a.uwmax;
-  int wi = 0;
-  int next_rel = (nw > 0) ? (wv::uniform(wsrc[0].start) - pos0) : 0x7fffffff;   // opening sample of the next window
-  const uint64_t *rec = a.rec + (int64_t)u * a.rec_stride;
-  const int nsteps = (n + 63) >> 6;
-  constexpr int AHEAD = 4;   // steps of samples in flight
-  float2 buf[AHEAD];
-#pragma unroll
-  for (int j = 0; j < AHEAD; ++j) {
-    const int i = 64 * j + lane;
-    buf[j] = (i < n) ? ys[i] : make_float2(0.0f, 0.0f);
-  }
-  float2 before = make_float2(0.0f, 0.0f);   // the samples of the previous step
-  uint64_t masks = 0;                         // lane j: the closed samples of step 64 * block + j
-  for (int kb = 0; kb < nsteps; kb += AHEAD) {
-#pragma unroll
-    for (int j = 0; j < AHEAD; ++j) {
-      const int k = kb + j;
-      if (k < nsteps) {
-        if ((k & 63) == 0) masks = (k + lane < nsteps) ? rec[k + lane] : 0ull;
-        const float2 yv = buf[j];
-        {
-          const int i = 64 * (k + AHEAD) + lane;
-          buf[j] = (i < n) ? ys[i] : make_float2(0.0f, 0.0f);
-        }
-        const uint64_t closedmask = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(masks >> 32), k & 63) << 32) |
-                                    (uint32_t)wv::readlane((int)(uint32_t)masks, k & 63);
-        const int nvalid = (n - 64 * k < 64) ? (n - 64 * k) : 64;
-        float dcr, dci;
-        if (closedmask != 0) {
-          gate_dc_step<true>(g, closedmask, 0ull, nvalid, yv, lane, lds_dc, lds_tmp,
-                       [&](float &tre, float &tim) {
-                         // (x - x[i-48]) / 48 as the producer wave forms it: x[i-48] from the previous step's lanes 16..63
-                         // or this step's lanes 0..15
-                         const int src = (lane < DC_LEN) ? (lane + 64 - DC_LEN) : (lane - DC_LEN);
-                         const float pre = wv::shfl(before.x, src), pim = wv::shfl(before.y, src);
-                         const float cre = wv::shfl(yv.x, src), cim = wv::shfl(yv.y, src);
-                         const float nr = yv.x - ((lane < DC_LEN) ? pre : cre), ni = yv.y - ((lane < DC_LEN) ? pim : cim);
-                         if (__builtin_expect(wv::ballot(!(div_const_ok(nr) && div_const_ok(ni))) == 0, 1)) {
-                           tre = div_const_fast<DC_LEN>(nr); tim = div_const_fast<DC_LEN>(ni);
-                         } else {
-                           tre = wv::fdiv(nr, DC_LEN_F); tim = wv::fdiv(ni, DC_LEN_F);
-                         }
-                       },
-                       dcr, dci);
-        } else {
-          g.run_closed = 0;
-          dcr = g.dcr_c; dci = g.dci_c;
-        }
-        before = yv;
-        while (next_rel < 64 * (k + 1)) {   // windows that opened in this step (gate_impl.cc:176)
-          const int ol = next_rel - 64 * k;
-          const float odr = wv::readlane(dcr, ol), odi = wv::readlane(dci, ol);
-          if (lane == 0) {
-            rfid_window w = wsrc[wi];
-            w.dc_re = odr; w.dc_im = odi;
-            wdst[wi] = w;
-          }
-          ++wi;
-          next_rel = (wi < nw) ? (wv::uniform(wsrc[wi].start) - pos0) : 0x7fffffff;
-        }
-      }
-    }
-  }
-  if (g.ring_stale) {
-    if (lane >= 64 - DC_LEN) {
-      int di = g.dc_index + (lane - (64 - DC_LEN));
-      if (di >= DC_LEN) di -= DC_LEN;
-      lds_dc[di] = g.prev_yv;
-    }
-    wv::wave_sync();
-  }
-  if (lane < DC_LEN) { st->dcr_re[lane] = lds_dc[lane].x; st->dcr_im[lane] = lds_dc[lane].y; }
-  if (lane == 0) {
-    st->dc_re = g.dcr_c; st->dc_im = g.dci_c; st->dc_index = g.dc_index;
-    a.uwcount[row] = a.uwcount[u];
-  }
-}
-
 // gate_impl.cc:112-123 for the streaming gate: SEEK_* -> CLOSED arms the next window (one launch, no host round trip)
 RFID_KERNEL(64) void gate_arm_kernel(GateState *st, int n_to_ungate, int wtype) {
   if (threadIdx.x == 0) { st->n_samples = 0; st->n_to_ungate = n_to_ungate; st->wtype = wtype; }
-}
-
-// compact copies for the host: the first 12 words of every state row; the end of the last window of every unit
-struct LsGatherArgs {
-  const GateState *state;   // [n_rows]
-  int *heads;               // [n_rows][12]
-  int n_rows;
-  const rfid_window *uwtab; // [n_units][uwmax] (rows [0, n_units) = variant A)
-  const int *uwcount;
-  int n_units, uwmax;
-  int *last_end;            // [n_units]: start + length of the unit's last window, or INT_MIN
-};
-RFID_KERNEL(256) void ls_gather_kernel(LsGatherArgs a) {
-  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
-  if (i < a.n_rows * 12) a.heads[i] = reinterpret_cast<const int *>(a.state + i / 12)[i % 12];
-  if (a.last_end && i < a.n_units) {
-    int k = a.uwcount[i];
-    if (k > a.uwmax) k = a.uwmax;
-    int e = -2147483647 - 1;
-    if (k > 0) {
-      const rfid_window &w = a.uwtab[(int64_t)i * a.uwmax + (k - 1)];
-      e = w.start + (w.type ? EPC_WIN : RN16_WIN);
-    }
-    a.last_end[i] = e;
-  }
-}
-
-// the verified units' window tables -> the per-trace window table (seq renumbered) + the decoder's compact lists
-struct LsAssembleArgs {
-  const GateUnit *units;
-  const rfid_window *uwtab;  // [n_units][uwmax]
-  const int *uwcount;        // [n_units]
-  const int *seq0;           // [n_units]: windows of the trace before this unit
-  int n_units, uwmax;
-  rfid_window *wtab;         // [n_streams][wmax]
-  int wmax;
-  rfid_window *flat;
-  int *flat_count;
-  int flat_cap;
-};
-RFID_KERNEL(64) void ls_assemble_kernel(LsAssembleArgs a) {
-  const int lane = wv::lane_id();
-  const int u = (int)blockIdx.x;
-  if (u >= a.n_units) return;
-  int k = a.uwcount[u];
-  if (k > a.uwmax) k = a.uwmax;
-  const int s = a.units[u].stream, seq0 = a.seq0[u];
-  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  for (int base = 0; base < k; base += 64) {
-    const int i = base + lane;
-    rfid_window w = {};
-    bool on = false;
-    if (i < k) {
-      w = a.uwtab[(int64_t)u * a.uwmax + i];
-      w.seq = seq0 + i;
-      on = w.seq < a.wmax;
-    }
-    if (on) a.wtab[(int64_t)s * a.wmax + w.seq] = w;
-    // places in the decoder's two lists: one atomic per list and 64 windows, not one per window
-    const uint64_t m1 = wv::ballot(on && w.type != 0), m0 = wv::ballot(on && w.type == 0);
-    int b0 = 0, b1 = 0;
-    if (lane == 0) {
-      if (m0) b0 = wv::atomic_add(a.flat_count + 0, wv::popc64(m0));
-      if (m1) b1 = wv::atomic_add(a.flat_count + 1, wv::popc64(m1));
-    }
-    b0 = wv::uniform(b0); b1 = wv::uniform(b1);
-    if (on) {
-      const int slotw = w.type ? (b1 + wv::popc64(m1 & lt)) : (b0 + wv::popc64(m0 & lt));
-      if (slotw < a.flat_cap) a.flat[(int64_t)w.type * a.flat_cap + slotw] = w;
-    }
-  }
 }
 
 // =========================================================================================
@@ -2454,3 +2080,5 @@ RFID_KERNEL(G2_THREADS) void synth_gen2_kernel(Gen2Args a) {
 }
 
 }  // namespace rfidk
+
+#include "rfid_ls2.hpp"   // long-stream front end (few long traces cut along time), built on the pieces above

@@ -1,0 +1,954 @@
+// rfid_ls2.hpp -- long-stream front end: the gate scan of gate_impl.cc:127-196 over FEW LONG traces, cut along time
+// into pieces that are processed concurrently -- and still the sequential scan, bit for bit.
+//
+// The scan carries two binary32 recurrences (avg_ampl, dc_est: in-order sums over the whole past) and a small state
+// machine.  They are separated here, because they depend on each other in one direction only:
+//
+//   avg_ampl  (amplitudes only)  ->  threshold votes  ->  state machine  ->  which samples are "closed", where
+//   windows open  ->  dc_est (sums over closed samples)  ->  dc_est at every window opening.
+//
+//   1. pieces        ls_cut_kernel / ls2_pieces_kernel: cut points near a regular grid, where the state machine idles
+//   2. avg_ampl      ls2_avg_kernel: every piece at once from a GUESSED start value s (the mean of the amplitude ring)
+//                    and from s + 1 ulp, leaving |x| and the addends (|x| - ring)/100 in HBM, the threshold votes of
+//                    every step, the two end values and a MARGIN (below);  ls2_avg_chain_kernel: one prefix scan per
+//                    trace over the pieces' (end - start) pairs gives every piece's true start; pieces whose run does
+//                    not provably cover it are run again from it (rare), until none is left
+//   3. state machine ls2_fsm_kernel over the votes (scalar unit only), from the idle state at every cut;
+//                    ls2_fsm_chain_kernel checks that each piece's start state IS its predecessor's end state (and
+//                    that the dc ring is what a cut assumes) -- a piece that fails is appended to its predecessor
+//   4. dc_est        ls2_dc_kernel / ls2_dc_chain_kernel: as 2., over the closed samples, two components
+//   5. windows       ls2_seq_kernel / ls2_assemble_kernel: per-trace window tables + the decoder's lists
+//
+// No host decision lies between the launches: every kernel looks at the control block (Ls2Ctl) in HBM and returns at
+// once when there is nothing to do, so one pass is ENQUEUE-ONLY (rfid_ls2_enqueue.hpp), the sequential gate scan
+// behind it included -- it runs only when this front end gave up (GateArgs::skip_if).
+//
+// Why a run from the wrong start value can still be exact.  Let a run start from s and the true start be s + D, D an
+// EVEN multiple of u0 = ulp(s).  If every partial sum S_j of the run lies in a binade not above that of s, then D is an
+// even multiple of ulp(S_j) as well; if moreover S_j and S_j + D always lie in the SAME binade, each rounding
+// RN(S_j + D + d_j) = RN(S_j + d_j) + D: same grid, same distance to it, same parity at ties-to-even.  By induction
+// the whole trajectory is shifted by exactly D -- end value, dc_est at every opening -- and, for avg_ampl, no
+// threshold vote changes as long as no |x| lies between the two thresholds.  The run records the smallest distance
+// of any partial sum from a power of two and of any |x| from its threshold, in units of u0: the MARGIN.  |D| + 4 <=
+// margin proves the shift (a few ulps of slack: variant B's trajectory may run 2 ulps off variant A's).  Odd D: the same from the run that started at s + 1 ulp (variant B).  A piece whose margin
+// does not cover its D (it passes close to a power of two: a few per cent of the pieces) is simply run again from
+// its predicted start; the prediction is then verified, not assumed: the procedure ends when every piece's latest
+// run is exact (D = 0) or proven.  Nothing else is assumed about the data -- pathological input (partial sums
+// hovering at a binade edge, no idle points) costs rounds and finally the sequential scan, never correctness.
+#pragma once
+
+namespace rfidk {
+
+constexpr int LS2_WBUCKET = 320;      // two gate openings are at least RN16_WIN + T1_SAMPLES = 346 samples apart:
+                                      // window records live in a per-trace table indexed by start / LS2_WBUCKET
+static_assert(LS2_WBUCKET <= RN16_WIN + T1_SAMPLES, "one window per bucket");
+constexpr int LS2_AVG_ROUNDS = 4;     // re-run rounds after the first pass, per recurrence
+constexpr int LS2_FSM_ROUNDS = 3;
+constexpr int LS2_DC_ROUNDS = 4;
+constexpr int LS2_MAXR = 8;
+constexpr int LS2_CHAIN_THREADS = 1024;
+
+struct Ls2Piece { int pos0, len; };   // len 0: slot not in use
+
+struct Ls2Ctl {   // control block in HBM, zeroed before every pass
+  int fail;                   // != 0: the front end gave up (1 no cut, 2 avg_ampl, 3 state machine, 4 dc_est rounds exhausted)
+  int ok;                     // 1: the window tables were produced (set last; the fallback scan skips itself on it)
+  int n_pieces;               // pieces the traces were cut into
+  int avg_count[LS2_MAXR];    // pieces on the re-run list after chain round r
+  int fsm_count[LS2_MAXR];    // pieces appended to their predecessor in chain round r
+  int dc_count[LS2_MAXR];     // units on the re-run list after chain round r
+  int avg_reruns, fsm_reruns, dc_reruns;   // totals (report)
+  int avg_rounds, fsm_rounds, dc_rounds;   // launches that had work (report)
+  int n_units;                // units (runs of pieces scanned in one go) at the end
+  int n_windows;              // complete windows
+  int wb_clash;               // two openings in one bucket (cannot happen; checked all the same -> fail)
+  int reserved_[3];
+};
+
+struct Ls2AvgRun { float s, eA, eB; int margin; };        // start used, end from it, end from s + 1 ulp, margin (ulps of s)
+struct Ls2DcRun { float s[2], eA[2], eB[2]; int margin[2]; };
+struct Ls2Fsm {   // per slot
+  int head;       // the piece starts a unit (scanned from the idle state, or from the trace's start state)
+  int unit;       // slot of the head of the unit the piece belongs to
+  int gen;        // generation of the state-machine launch that last covered the piece
+  int rerun;      // (head) scan again in the next round
+  int nwin;       // complete windows opened in the piece
+  int last_end;   // end of the last window opened in the unit up to and including this piece (INT_MIN: none)
+  int st[6];      // (head) start state used: n_samples, signal_state, num_pulses, gate_open, n_to_ungate, wtype
+  int en[6];      // state after the piece
+};
+struct Ls2Win {   // one gate opening
+  int start;
+  int tag;        // type | complete << 1 | gen << 8;  0: empty
+  float a_re, a_im, b_re, b_im;   // dc_est at the opening from the unit's run: variant A, variant B
+};
+
+struct Ls2Args {
+  const float2 *y; int64_t y_stride;
+  const int64_t *lens; int64_t n_dec; int n_streams;
+  int P, max_b;                 // nominal piece length; slots per trace
+  int *cut;                     // [NS] from ls_cut_kernel (slot 0 unused)
+  Ls2Piece *piece;              // [NS]
+  int *nextv, *prevv;           // [NS] next / previous slot in use of the same trace, -1 none
+  float *amp, *dadd;            // [n_streams][y_stride]
+  uint64_t *votes;              // [n_streams][vstride][2]: below, above
+  uint64_t *closed;             // [n_streams][vstride]
+  int *openinfo;                // [n_streams][vstride]: lane | type << 8 of the step's opening, 0xff none
+  int64_t vstride;
+  Ls2AvgRun *arun; int *aT;     // [NS]; aT = true start of the piece (monotone integer image)
+  int *alist;                   // [LS2_MAXR][NS]
+  Ls2Fsm *fsm;                  // [NS]
+  Ls2Win *wb; int64_t wb_stride;   // [n_streams][wb_stride]
+  Ls2DcRun *drun; int *dT;      // [NS], [NS][2]
+  int *dlist;                   // [LS2_MAXR][NS]
+  int *seq0;                    // [NS] complete windows of the trace before the piece
+  rfid_window *wtab; int wmax; int *wcount;
+  rfid_window *flat; int *flat_count; int flat_cap;
+  Ls2Ctl *ctl;
+  const GateState *carry;       // optional [n_streams]: the state a trace starts from (streaming); nullptr: the fresh gate
+  GateState *carry_out;         // optional [n_streams]: the state after the last processed piece
+  int hold_last;                // streaming: a trace's last piece stays unprocessed; consumed[s] = its first sample
+  int force;                    // run even when no trace could be cut
+  int *consumed;                // [n_streams]
+  int round;
+};
+
+// ---- small helpers -----------------------------------------------------------------------------------------------
+RFID_DEVICE int ls2_ord(float f) {   // monotone integer image of a binary32 value: distance = ulps
+  const uint32_t u = wv::f2u(f);
+  return (u & 0x80000000u) ? -(int)(u & 0x7fffffffu) : (int)u;
+}
+RFID_DEVICE float ls2_from_ord(int k) { return wv::u2f((k < 0) ? (0x80000000u | (uint32_t)(-k)) : (uint32_t)k); }
+RFID_DEVICE int ls2_trace_len(const Ls2Args &a, int s) {
+  int64_t n = a.n_dec;
+  if (a.lens) { int64_t r = a.lens[s]; if (r < 0) r = 0; r /= DECIM; if (r < n) n = r; }
+  return (int)n;
+}
+// distance of v from the nearest power of two in ulps of the value whose bit pattern is `sb` (rounded down); 0 when v
+// lies in a higher binade, has the other sign, or either is zero / denormal / tiny / not finite
+RFID_DEVICE int ls2_margin(float v, uint32_t sb) {
+  const uint32_t b = wv::f2u(v);
+  const int e0 = (int)((sb >> 23) & 0xffu), e = (int)((b >> 23) & 0xffu);
+  const int m = (int)(b & 0x7fffffu);
+  const int up = 0x800000 - m;
+  const int dist = (m < up) ? m : up;
+  const int sh = e0 - e;
+  const bool bad = (((b ^ sb) >> 31) != 0u) || sh < 0 || sh > 23 || e == 0 || e0 == 255 || e0 < 25;
+  return bad ? 0 : (dist >> sh);
+}
+RFID_DEVICE int ls2_wave_min(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { const int o = wv::shfl_xor(v, off); v = (o < v) ? o : v; }
+  return v;
+}
+
+// The in-order sums of one step's addends from TWO carries in one go (variants A and B of a run): everything that
+// depends on the addends and the binade only is shared (see chain_add_scan), the parities at ties and the prefix sums
+// are per carry.  false: not both in one binade, or a partial sum left it -- the caller takes chain_add_auto twice.
+RFID_DEVICE bool chain_add_scan2(float ca, float cb2, float x, int lane, float &oa, float &ob) {
+  const uint32_t ba = wv::f2u(ca), bb = wv::f2u(cb2);
+  if (((ba ^ bb) & 0xff800000u) != 0u) return false;
+  const uint32_t e_b = (ba >> 23) & 0xffu;
+  const uint32_t sign = ba & 0x80000000u;
+  const float scale = wv::u2f(((277u - e_b) & 0xffu) << 23);
+  const float t = sign ? -(x * scale) : (x * scale);
+  const float r = wv::rint_f(t);
+  const float frac = t - r;
+  const bool bad_t = !(__builtin_fabsf(t) < 4194304.0f);
+  const bool tie = !bad_t && __builtin_fabsf(frac) == 0.5f;
+  const int R = wv::f2i(bad_t ? 0.0f : r);
+  int Ra = R, Rb = R;
+  const uint64_t tiemask = wv::ballot(tie);
+  if (tiemask != 0ull) {
+    const int I = R - ((frac < 0.0f) ? 1 : 0);
+    const uint64_t rodd = wv::ballot(!tie && (R & 1));
+    const uint64_t iodd = wv::ballot(tie && (I & 1));
+    const uint64_t Q = prefix_xor64(rodd);
+    const uint64_t gen = tiemask & Q, X = gen | ~tiemask;
+    const uint64_t suma = X + gen + (uint64_t)(ba & 1u), sumb = X + gen + (uint64_t)(bb & 1u);
+    const uint64_t upa = (((Q << 1) ^ X ^ gen ^ suma) ^ iodd) & tiemask;
+    const uint64_t upb = (((Q << 1) ^ X ^ gen ^ sumb) ^ iodd) & tiemask;
+    Ra = tie ? (I + (int)((upa >> lane) & 1ull)) : R;
+    Rb = tie ? (I + (int)((upb >> lane) & 1ull)) : R;
+  }
+  const uint32_t maga = (ba & 0x7fffffffu) + (uint32_t)wv::scan_add(Ra);
+  const uint32_t magb = (bb & 0x7fffffffu) + (uint32_t)wv::scan_add(Rb);
+  const bool bad_s = ((maga ^ ba) & 0x7f800000u) != 0u || (maga & 0x007fffffu) == 0u ||
+                     ((magb ^ bb) & 0x7f800000u) != 0u || (magb & 0x007fffffu) == 0u;
+  const bool bad_c = e_b < 23u || e_b > 254u;
+  oa = wv::u2f(maga | sign);
+  ob = wv::u2f(magb | sign);
+  return wv::ballot(bad_t || bad_s || bad_c) == 0ull;
+}
+RFID_DEVICE void chain_add_auto2(float ca, float cb2, float x, int lane, float &oa, float &ob) {
+  if (__builtin_expect(chain_add_scan2(ca, cb2, x, lane, oa, ob), 1)) return;
+  oa = chain_add_auto(ca, x, lane);
+  ob = chain_add_auto(cb2, x, lane);
+}
+
+// ---- 1. pieces -----------------------------------------------------------------------------------------------------
+// one thread per slot (trace s, grid point j): the piece that starts at the slot's cut and ends at the next cut in use
+RFID_KERNEL(256) void ls2_pieces_kernel(Ls2Args a) {
+  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  const int NS = a.n_streams * a.max_b;
+  const int lane = wv::lane_id();
+  bool used = false;
+  if (i < NS) {
+    const int s = i / a.max_b, j = i - s * a.max_b;
+    const int n = ls2_trace_len(a, s);
+    const int *cut = a.cut + (int64_t)s * a.max_b;
+    auto at = [&](int jj) -> int {
+      if (jj == 0) return (n > 0) ? 0 : -1;
+      const int p = cut[jj];
+      return (p > 0 && p < n) ? p : -1;
+    };
+    const int p = at(j);
+    Ls2Piece pc; pc.pos0 = 0; pc.len = 0;
+    int nx = -1, pv = -1;
+    if (p >= 0) {
+      int end = n;
+      for (int j2 = j + 1; j2 < a.max_b; ++j2) { const int q = at(j2); if (q >= 0) { end = q; nx = s * a.max_b + j2; break; } }
+      for (int j2 = j - 1; j2 >= 0; --j2) if (at(j2) >= 0) { pv = s * a.max_b + j2; break; }
+      pc.pos0 = p; pc.len = end - p;
+      if (a.hold_last && nx < 0) {   // the trace's last piece waits for more samples
+        pc.len = 0;
+        if (a.consumed) a.consumed[s] = p;
+      }
+    } else if (j == 0 && a.consumed) {
+      a.consumed[s] = 0;
+    }
+    used = pc.len > 0;
+    a.piece[i] = pc;
+    a.nextv[i] = nx;
+    a.prevv[i] = pv;
+    Ls2Fsm f;
+    f.head = used ? 1 : 0; f.unit = i; f.gen = -1; f.rerun = 0; f.nwin = 0; f.last_end = -2147483647 - 1;
+    for (int k = 0; k < 6; ++k) { f.st[k] = 0; f.en[k] = 0; }
+    a.fsm[i] = f;
+    a.seq0[i] = 0;
+  }
+  const uint64_t m = wv::ballot(used);
+  if (lane == 0 && m) wv::atomic_add(&a.ctl->n_pieces, wv::popc64(m));
+}
+
+// nothing to gain (no trace could be cut) -> the sequential scan; one thread
+RFID_KERNEL(64) void ls2_check_kernel(Ls2Args a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Ls2Ctl *c = a.ctl;
+  if (c->n_pieces <= 0 || (!a.force && c->n_pieces <= a.n_streams)) c->fail = 1;
+}
+
+// ---- 2. avg_ampl ---------------------------------------------------------------------------------------------------
+// One wave per piece.  FIRST: |x| and the addends from the samples (and into HBM), start value guessed; later rounds: the
+// pieces of the re-run list from their predicted start, |x| and the addends from HBM.  Same arithmetic as the producer /
+// consumer waves of the gate scan, value for value (gate_impl.cc:130-136).
+template <bool FIRST>
+RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
+  const int s = i / a.max_b, j = i - s * a.max_b;
+  const Ls2Piece pc = a.piece[i];
+  const int pos0 = wv::uniform(pc.pos0), n = wv::uniform(pc.len);
+  if (n <= 0) return;
+  const int64_t row = (int64_t)s * a.y_stride + pos0;
+  const float2 *ys = a.y + row;
+  float *ampc = a.amp + row, *dc = a.dadd + row;
+  uint64_t *votes = a.votes + 2 * ((int64_t)s * a.vstride + (pos0 >> 6) + j);
+  float sA;
+  float a2 = 0.0f, a1 = 0.0f;   // amplitudes of the 128 samples before the step (the ring of gate_impl.cc:131 holds the last 100)
+  if (FIRST) {
+    if (pos0 >= 128) {
+      const float2 p2 = ys[lane - 128], p1 = ys[lane - 64];
+      a2 = wv::hypot_f(p2.x, p2.y);
+      a1 = wv::hypot_f(p1.x, p1.y);
+    } else if (a.carry) {
+      // sample -k (k = 1..100) of the carried ring: win[(win_index - k) mod 100] (win_index = the oldest = next written)
+      const GateState *cs = a.carry + s;
+      const int wi = wv::uniform(cs->win_index);
+      const int k1 = 64 - lane, k2 = 128 - lane;
+      a1 = cs->win[(wi - k1 + 2 * WIN_LEN) % WIN_LEN];
+      a2 = (k2 <= WIN_LEN) ? cs->win[(wi - k2 + 2 * WIN_LEN) % WIN_LEN] : 0.0f;
+    }
+    if (j == 0) {
+      sA = a.carry ? wv::uniform(a.carry[s].avg_ampl) : 0.0f;   // the exact start of the trace
+    } else {
+      // first guess: the ring mean (what avg_ampl is up to its rounding drift): lanes 28..63 of a2 and all of a1
+      float part = a1 + ((lane >= 28) ? a2 : 0.0f);
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) part += wv::shfl_xor(part, off);
+      sA = wv::uniform(part) / WIN_LEN_F;
+    }
+  } else {
+    sA = wv::uniform(a.arun[i].s);
+  }
+  const uint32_t sbA = wv::f2u(sA);
+  const float sB = ls2_from_ord(ls2_ord(sA) + 1);
+  const uint32_t sbB = wv::f2u(sB);
+  float avA = sA, avB = sB;
+  int marg = ls2_margin(sA, sbA);
+  const int nsteps = (n + 63) >> 6;
+  constexpr int AHEAD = 4;
+  float2 ybuf[AHEAD];
+  float abuf[AHEAD], dbuf[AHEAD];
+#pragma unroll
+  for (int u = 0; u < AHEAD; ++u) {
+    const int idx = 64 * u + lane;
+    if (FIRST) ybuf[u] = (idx < n) ? ys[idx] : make_float2(0.0f, 0.0f);
+    else { abuf[u] = (idx < n) ? ampc[idx] : 0.0f; dbuf[u] = (idx < n) ? dc[idx] : 0.0f; }
+  }
+  uint64_t my_lt = 0, my_gt = 0;   // lane (k & 63) keeps the votes of step k until 64 steps are stored together
+  for (int kb = 0; kb < nsteps; kb += AHEAD) {
+#pragma unroll
+    for (int u = 0; u < AHEAD; ++u) {
+      const int k = kb + u;
+      if (k < nsteps) {
+        const bool valid = 64 * k + lane < n;
+        float amp, d;
+        if (FIRST) {
+          const float2 v = ybuf[u];
+          { const int idx = 64 * (k + AHEAD) + lane; ybuf[u] = (idx < n) ? ys[idx] : make_float2(0.0f, 0.0f); }
+          amp = wv::hypot_f(v.x, v.y);
+          // sample i - 100: lanes 0..35 take it from two steps back (lane + 28), lanes 36..63 from the previous step (lane - 36)
+          const float o2 = wv::shfl(a2, (lane + 28) & 63), o1 = wv::shfl(a1, (lane - 36) & 63);
+          const float old = (lane < 36) ? o2 : o1;
+          const float nd = valid ? (amp - old) : 0.0f;
+          d = div_const<WIN_LEN>(nd);
+          if (valid) { ampc[64 * k + lane] = amp; dc[64 * k + lane] = d; }
+          a2 = a1; a1 = amp;
+        } else {
+          amp = abuf[u]; d = dbuf[u];
+          const int idx = 64 * (k + AHEAD) + lane;
+          abuf[u] = (idx < n) ? ampc[idx] : 0.0f;
+          dbuf[u] = (idx < n) ? dc[idx] : 0.0f;
+        }
+        float vA, vB;
+        chain_add_auto2(avA, avB, d, lane, vA, vB);
+        avA = wv::readlane(vA, 63);
+        avB = wv::readlane(vB, 63);
+        const float thresh = vA * THRESH_FRACTION;
+        const uint64_t below = wv::ballot(valid && amp < thresh);
+        const uint64_t above = wv::ballot(valid && amp > thresh);
+        if (lane == (k & 63)) { my_lt = below; my_gt = above; }
+        // margin: the partial sums of both variants against the powers of two, |x| against the threshold
+        {
+          const int mA = ls2_margin(vA, sbA), mB = ls2_margin(vB, sbB);
+          const uint32_t tb = wv::f2u(thresh), ab = wv::f2u(amp);
+          int dv = (int)ab - (int)tb;
+          dv = (dv < 0) ? -dv : dv;
+          const int sh = (int)((sbA >> 23) & 0xffu) - (int)((wv::f2u(vA) >> 23) & 0xffu);
+          int mV = ((tb >> 31) != 0u || sh < 0 || sh > 23) ? 0 : (((dv - 3) >> 1) >> sh);
+          mV = valid ? mV : 0x7fffffff;
+          int mm = (mA < mB) ? mA : mB;
+          mm = (mV < mm) ? mV : mm;
+          marg = (mm < marg) ? mm : marg;
+        }
+        if ((k & 63) == 63 || k == nsteps - 1) {
+          const int k0 = k & ~63;
+          if (k0 + lane <= k) { votes[2 * (k0 + lane)] = my_lt; votes[2 * (k0 + lane) + 1] = my_gt; }
+        }
+      }
+    }
+  }
+  marg = ls2_wave_min(marg);
+  if (lane == 0) {
+    Ls2AvgRun r;
+    r.s = sA; r.eA = avA; r.eB = avB; r.margin = marg;
+    a.arun[i] = r;
+  }
+}
+
+RFID_KERNEL(64) void ls2_avg_first_kernel(Ls2Args a) {
+  if (wv::uniform(a.ctl->fail) != 0) return;
+  const int NS = a.n_streams * a.max_b;
+  const int lane = wv::lane_id();
+  for (int i = (int)blockIdx.x; i < NS; i += (int)gridDim.x) ls2_avg_piece<true>(a, i, lane);
+}
+RFID_KERNEL(64) void ls2_avg_rerun_kernel(Ls2Args a) {
+  if (wv::uniform(a.ctl->fail) != 0) return;
+  const int NS = a.n_streams * a.max_b;
+  const int cnt = wv::uniform(a.ctl->avg_count[a.round - 1]);
+  const int lane = wv::lane_id();
+  const int *list = a.alist + (int64_t)(a.round - 1) * NS;
+  for (int r = (int)blockIdx.x; r < cnt; r += (int)gridDim.x) ls2_avg_piece<false>(a, wv::uniform(list[r]), lane);
+}
+
+// A piece's latest run as a function "true start -> true end", on the monotone integer image of binary32: T -> T + c[q],
+// q = parity of T (the run from s serves the starts s + even, the run from s + 1 ulp the starts s + odd).  Functions
+// of this form compose to the same form, so a trace's chain of pieces is ONE prefix scan.
+struct Ls2Aff { int64_t c0, c1; };
+RFID_DEVICE Ls2Aff ls2_compose(const Ls2Aff f, const Ls2Aff g) {   // f first, then g
+  Ls2Aff r;
+  r.c0 = f.c0 + ((f.c0 & 1) ? g.c1 : g.c0);
+  r.c1 = f.c1 + (((1 + f.c1) & 1) ? g.c1 : g.c0);
+  return r;
+}
+RFID_DEVICE Ls2Aff ls2_aff(float s, float eA, float eB) {
+  const int64_t os = ls2_ord(s), a0 = (int64_t)ls2_ord(eA) - os, a1 = (int64_t)ls2_ord(eB) - 1 - os;
+  Ls2Aff r;
+  // T even-distant from s -> a0, odd-distant -> a1
+  if (os & 1) { r.c0 = a1; r.c1 = a0; } else { r.c0 = a0; r.c1 = a1; }
+  return r;
+}
+// exclusive prefix "scan" of per-thread aggregates over one workgroup (thread t gets the composition of threads < t)
+RFID_DEVICE Ls2Aff ls2_block_exscan(Ls2Aff mine, Ls2Aff *sh /* [2][LS2_CHAIN_THREADS] */, int tid) {
+  int cur = 0;
+  sh[tid] = mine;
+  wv::block_sync();
+  for (int off = 1; off < LS2_CHAIN_THREADS; off <<= 1) {
+    Ls2Aff v = sh[cur * LS2_CHAIN_THREADS + tid];
+    if (tid >= off) v = ls2_compose(sh[cur * LS2_CHAIN_THREADS + tid - off], v);
+    sh[(cur ^ 1) * LS2_CHAIN_THREADS + tid] = v;
+    cur ^= 1;
+    wv::block_sync();
+  }
+  Ls2Aff ex; ex.c0 = 0; ex.c1 = 0;
+  if (tid > 0) ex = sh[cur * LS2_CHAIN_THREADS + tid - 1];
+  wv::block_sync();
+  return ex;
+}
+
+// one workgroup per trace: every piece's true start from the chain of the latest runs; what is not proven goes on the
+// re-run list of this round
+RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_avg_chain_kernel(Ls2Args a) {
+  RFID_SHARED Ls2Aff sh[2 * LS2_CHAIN_THREADS];
+  Ls2Ctl *ctl = a.ctl;
+  const int r = a.round;
+  const int tid = (int)threadIdx.x, s = (int)blockIdx.x;
+  if (ctl->fail != 0) return;
+  if (r > 0 && ctl->avg_count[r - 1] == 0) return;   // settled in an earlier round (avg_count[r] stays 0)
+  const int NS = a.n_streams * a.max_b;
+  const int per = (a.max_b + LS2_CHAIN_THREADS - 1) / LS2_CHAIN_THREADS;
+  const int j0 = tid * per, j1 = (j0 + per < a.max_b) ? (j0 + per) : a.max_b;
+  const int base = s * a.max_b;
+  Ls2Aff agg; agg.c0 = 0; agg.c1 = 0;
+  for (int j = j0; j < j1; ++j) {
+    if (a.piece[base + j].len <= 0) continue;
+    const Ls2AvgRun ru = a.arun[base + j];
+    agg = ls2_compose(agg, ls2_aff(ru.s, ru.eA, ru.eB));
+  }
+  const Ls2Aff ex = ls2_block_exscan(agg, sh, tid);
+  if (a.piece[base].len <= 0) return;                 // empty trace
+  const int64_t T0 = ls2_ord(a.arun[base].s);         // the trace's first piece starts from the exact value
+  int64_t T = T0 + ((T0 & 1) ? ex.c1 : ex.c0);
+  int n_rerun = 0;
+  for (int j = j0; j < j1; ++j) {
+    const int i = base + j;
+    if (a.piece[i].len <= 0) continue;
+    const Ls2AvgRun ru = a.arun[i];
+    const int64_t D = T - (int64_t)ls2_ord(ru.s);
+    const int64_t aD = (D < 0) ? -D : D;
+    a.aT[i] = (int)T;
+    if (D != 0 && !(aD + 4 <= (int64_t)ru.margin)) {
+      a.arun[i].s = ls2_from_ord((int)T);
+      const int k = wv::atomic_add(&ctl->avg_count[r], 1);
+      a.alist[(int64_t)r * NS + k] = i;
+      n_rerun++;
+    }
+    const Ls2Aff f = ls2_aff(ru.s, ru.eA, ru.eB);
+    T += (T & 1) ? f.c1 : f.c0;
+  }
+  if (n_rerun) wv::atomic_add(&ctl->avg_reruns, n_rerun);
+  if (tid == 0 && s == 0) ctl->avg_rounds = r + 1;
+}
+
+// ---- 3. state machine ----------------------------------------------------------------------------------------------
+constexpr int LS2_IDLE_N = GATE_N_SAT;   // the state at an idle cut: saturated count, POS_EDGE, no pulses, closed, next window an RN16
+
+// one wave per unit (head slot): the unit's pieces one after the other over the recorded votes; scalar work only
+RFID_KERNEL(64) void ls2_fsm_kernel(Ls2Args a) {
+  Ls2Ctl *ctl = a.ctl;
+  if (wv::uniform(ctl->fail) != 0) return;
+  const int r = a.round;
+  if (r == 0) { if (wv::uniform(ctl->avg_count[LS2_AVG_ROUNDS]) != 0) return; }
+  else if (wv::uniform(ctl->fsm_count[r - 1]) == 0) return;
+  const int NS = a.n_streams * a.max_b;
+  const int lane = wv::lane_id();
+  for (int i = (int)blockIdx.x; i < NS; i += (int)gridDim.x) {
+    if (wv::uniform(a.piece[i].len) <= 0) continue;
+    Ls2Fsm *fh = a.fsm + i;
+    if (wv::uniform(fh->head) == 0) continue;
+    if (r > 0 && wv::uniform(fh->rerun) == 0) continue;
+    const int s = i / a.max_b;
+    const int n_total = ls2_trace_len(a, s);
+    GateRegs g;
+    g.avg_c = 0.0f; g.consumed = 0; g.stop = false;
+    if (i == s * a.max_b) {   // the trace's first piece: the fresh gate, or the carried state
+      if (a.carry) {
+        const GateState *cs = a.carry + s;
+        g.f_n = wv::uniform(cs->n_samples); g.f_state = wv::uniform(cs->signal_state); g.f_pulses = wv::uniform(cs->num_pulses);
+        g.f_open = wv::uniform(cs->gate_open); g.f_ung = wv::uniform(cs->n_to_ungate); g.f_type = wv::uniform(cs->wtype);
+      } else {
+        g.f_n = 0; g.f_state = 0; g.f_pulses = 0; g.f_open = 0; g.f_ung = 0; g.f_type = 0;
+      }
+      if (g.f_ung == 0) g.f_ung = g.f_type ? EPC_WIN : RN16_WIN;   // fresh state: first window is an RN16
+    } else {
+      g.f_n = LS2_IDLE_N; g.f_state = 1; g.f_pulses = 0; g.f_open = 0; g.f_ung = RN16_WIN; g.f_type = 0;
+    }
+    if (lane == 0) {
+      fh->st[0] = g.f_n; fh->st[1] = g.f_state; fh->st[2] = g.f_pulses; fh->st[3] = g.f_open; fh->st[4] = g.f_ung; fh->st[5] = g.f_type;
+      fh->rerun = 0;
+    }
+    int last_end = -2147483647 - 1;
+    int n_run = 0;
+    for (int cur = i;;) {
+      const Ls2Piece pc = a.piece[cur];
+      const int pos0 = wv::uniform(pc.pos0), n = wv::uniform(pc.len);
+      const int jc = cur - s * a.max_b;
+      const int64_t wbase = (int64_t)s * a.vstride + (pos0 >> 6) + jc;
+      const uint64_t *votes = a.votes + 2 * wbase;
+      uint64_t *closed = a.closed + wbase;
+      int *oinfo = a.openinfo + wbase;
+      Ls2Win *wb = a.wb + (int64_t)s * a.wb_stride;
+      const int nsteps = (n + 63) >> 6;
+      int nwin = 0;
+      uint64_t v_lt = 0, v_gt = 0, my_closed = 0;
+      int my_open = 0xff;
+      for (int k = 0; k < nsteps; ++k) {
+        if ((k & 63) == 0) {
+          const bool in = k + lane < nsteps;
+          v_lt = in ? votes[2 * (k + lane)] : 0ull;
+          v_gt = in ? votes[2 * (k + lane) + 1] : 0ull;
+        }
+        const int kk = k & 63;
+        const uint64_t below = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(v_lt >> 32), kk) << 32) | (uint32_t)wv::readlane((int)(uint32_t)v_lt, kk);
+        const uint64_t above = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(v_gt >> 32), kk) << 32) | (uint32_t)wv::readlane((int)(uint32_t)v_gt, kk);
+        int nvalid = (n - 64 * k < 64) ? (n - 64 * k) : 64;
+        uint64_t closedmask, openmask;
+        int open_lane, open_type;
+        gate_fsm_step(0, g, below, above, 64 * k, nvalid, closedmask, openmask, open_lane, open_type);
+        if (open_lane != 0xff) {   // gate_impl.cc:164-180
+          const int start = pos0 + 64 * k + open_lane;
+          const int wlen = open_type ? EPC_WIN : RN16_WIN;
+          const int complete = (start + wlen <= n_total) ? 1 : 0;   // only complete windows reach the decoder (:223,:291)
+          if (lane == 0) {
+            Ls2Win *w = wb + start / LS2_WBUCKET;
+            if (w->tag != 0 && ((w->tag >> 8) == r + 1) && w->start != start) ctl->wb_clash = 1;   // (the table is cleared before every pass)
+            w->start = start;
+            w->tag = open_type | (complete << 1) | ((r + 1) << 8);
+          }
+          nwin += complete;
+          last_end = start + wlen;
+        }
+        if (lane == kk) { my_closed = closedmask; my_open = open_lane | (open_type << 8); }
+        if (kk == 63 || k == nsteps - 1) {
+          const int k0 = k & ~63;
+          if (k0 + lane <= k) { closed[k0 + lane] = my_closed; oinfo[k0 + lane] = my_open; }
+        }
+      }
+      if (lane == 0) {
+        Ls2Fsm *f = a.fsm + cur;
+        f->unit = i; f->gen = r + 1; f->nwin = nwin; f->last_end = last_end;
+        f->en[0] = g.f_n; f->en[1] = g.f_state; f->en[2] = g.f_pulses; f->en[3] = g.f_open; f->en[4] = g.f_ung; f->en[5] = g.f_type;
+      }
+      n_run++;
+      const int nx = wv::uniform(a.nextv[cur]);
+      if (nx < 0) break;
+      if (wv::uniform(a.piece[nx].len) <= 0 || wv::uniform(a.fsm[nx].head) != 0) break;
+      cur = nx;
+    }
+    if (lane == 0 && r > 0) wv::atomic_add(&ctl->fsm_reruns, n_run);
+  }
+}
+
+// one workgroup per trace: does every unit start from the state its predecessor ended in, with the dc ring a cut assumes
+// (the 48 samples before it closed)?  A unit that does not is appended to its predecessor, which is scanned again.
+RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_fsm_chain_kernel(Ls2Args a) {
+  Ls2Ctl *ctl = a.ctl;
+  const int r = a.round;
+  if (ctl->fail != 0) return;
+  if (r == 0) { if (ctl->avg_count[LS2_AVG_ROUNDS] != 0) return; }
+  else if (ctl->fsm_count[r - 1] == 0) return;
+  const int s = (int)blockIdx.x;
+  int n_bad = 0;
+  for (int j = (int)threadIdx.x + 1; j < a.max_b; j += LS2_CHAIN_THREADS) {
+    const int i = s * a.max_b + j;
+    if (a.piece[i].len <= 0 || a.fsm[i].head == 0) continue;
+    const int p = a.prevv[i];
+    if (p < 0) continue;
+    const Ls2Fsm &fp = a.fsm[p];
+    const Ls2Fsm &fi = a.fsm[i];
+    bool same = fp.last_end <= a.piece[i].pos0 - DC_LEN;
+    for (int k = 0; k < 6; ++k) same = same && (fp.en[k] == fi.st[k]);
+    if (!same) {
+      a.fsm[i].head = 0;
+      a.fsm[fp.unit].rerun = 1;   // (if that unit is appended to ITS predecessor in this round, the flag is stale: the
+      n_bad++;                    //  predecessor's unit is flagged by that very mismatch and scans through both)
+    }
+  }
+  if (n_bad) wv::atomic_add(&ctl->fsm_count[r], n_bad);
+  if (threadIdx.x == 0 && s == 0) ctl->fsm_rounds = r + 1;
+}
+
+// ---- 4. dc_est -----------------------------------------------------------------------------------------------------
+// One wave per unit: dc_est += (x - dc_samples[dc_index]) / 48 over the closed samples (gate_impl.cc:139-143), from the
+// unit's start value and from 1 ulp above it (per component), the back wave's arithmetic value for value; dc_est at
+// every opening (:176) goes to the window's record.
+RFID_DEVICE void ls2_dc_unit(const Ls2Args &a, const int i, const bool first, const int lane, float2 *lds_dc, float2 *lds_tmp) {
+  const int s = i / a.max_b;
+  const Ls2Piece p0 = a.piece[i];
+  const int upos0 = wv::uniform(p0.pos0);
+  const float2 *yrow = a.y + (int64_t)s * a.y_stride;
+  GateBackRegs g;
+  g.run_closed = 0; g.ring_stale = 0; g.prev_yv = make_float2(0.0f, 0.0f);
+  g.win_seq = 0; g.n_complete = 0; g.written = 0; g.pos0 = upos0; g.strm = s;
+  g.dc_index = 0;
+  float sre, sim;
+  wv::wave_sync();   // (the previous unit's LDS reads are over)
+  if (i == s * a.max_b) {   // the trace's first piece: the fresh gate (all zero) or the carried state, exactly
+    if (a.carry) {
+      const GateState *cs = a.carry + s;
+      if (lane < DC_LEN) lds_dc[lane] = make_float2(cs->dcr_re[lane], cs->dcr_im[lane]);
+      g.dc_index = wv::uniform(cs->dc_index);
+      sre = wv::uniform(cs->dc_re); sim = wv::uniform(cs->dc_im);
+    } else {
+      if (lane < DC_LEN) lds_dc[lane] = make_float2(0.0f, 0.0f);
+      sre = 0.0f; sim = 0.0f;
+    }
+  } else {
+    // an idle cut: the ring holds the 48 samples before it; first guess of dc_est = their mean
+    float2 v = make_float2(0.0f, 0.0f);
+    if (lane < DC_LEN) { v = yrow[upos0 - DC_LEN + lane]; lds_dc[lane] = v; }
+    if (first) {
+      float pr = v.x, pi = v.y;   // (lanes >= 48 hold zeros)
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) { pr += wv::shfl_xor(pr, off); pi += wv::shfl_xor(pi, off); }
+      sre = wv::uniform(pr) / DC_LEN_F; sim = wv::uniform(pi) / DC_LEN_F;
+    } else {
+      sre = 0.0f; sim = 0.0f;
+    }
+  }
+  if (!first) { sre = wv::uniform(a.drun[i].s[0]); sim = wv::uniform(a.drun[i].s[1]); }
+  wv::wave_sync();
+  const uint32_t sbr = wv::f2u(sre), sbi = wv::f2u(sim);
+  const float sreB = ls2_from_ord(ls2_ord(sre) + 1), simB = ls2_from_ord(ls2_ord(sim) + 1);
+  const uint32_t sbrB = wv::f2u(sreB), sbiB = wv::f2u(simB);
+  g.dcr_c = sre; g.dci_c = sim;
+  float bre = sreB, bim = simB;   // variant B's carries
+  int mre = ls2_margin(sre, sbr), mim = ls2_margin(sim, sbi);
+  Ls2Win *wb = a.wb + (int64_t)s * a.wb_stride;
+  for (int cur = i;;) {
+    const Ls2Piece pc = a.piece[cur];
+    const int pos0 = wv::uniform(pc.pos0), n = wv::uniform(pc.len);
+    const int jc = cur - s * a.max_b;
+    const int64_t wbase = (int64_t)s * a.vstride + (pos0 >> 6) + jc;
+    const uint64_t *closed = a.closed + wbase;
+    const int *oinfo = a.openinfo + wbase;
+    const float2 *ys = yrow + pos0;
+    const int nsteps = (n + 63) >> 6;
+    constexpr int AHEAD = 4;
+    float2 buf[AHEAD];
+#pragma unroll
+    for (int u = 0; u < AHEAD; ++u) { const int idx = 64 * u + lane; buf[u] = (idx < n) ? ys[idx] : make_float2(0.0f, 0.0f); }
+    // the samples of the step before the piece (x[i-48] of the first step's lanes 0..47 when everything around is closed)
+    float2 before = (pos0 + lane - 64 >= 0) ? ys[lane - 64] : make_float2(0.0f, 0.0f);
+    uint64_t masks = 0;
+    int oi_l = 0xff;
+    for (int kb = 0; kb < nsteps; kb += AHEAD) {
+#pragma unroll
+      for (int u = 0; u < AHEAD; ++u) {
+        const int k = kb + u;
+        if (k < nsteps) {
+          if ((k & 63) == 0) {
+            const bool in = k + lane < nsteps;
+            masks = in ? closed[k + lane] : 0ull;
+            oi_l = in ? oinfo[k + lane] : 0xff;
+          }
+          const float2 yv = buf[u];
+          { const int idx = 64 * (k + AHEAD) + lane; buf[u] = (idx < n) ? ys[idx] : make_float2(0.0f, 0.0f); }
+          const int kk = k & 63;
+          const uint64_t closedmask = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(masks >> 32), kk) << 32) |
+                                      (uint32_t)wv::readlane((int)(uint32_t)masks, kk);
+          const int oi = wv::readlane(oi_l, kk);
+          const int nvalid = (n - 64 * k < 64) ? (n - 64 * k) : 64;
+          float ar, ai, br, bi;   // dc_est after every sample of the step, variants A and B
+          if (closedmask != 0) {
+            float tre, tim;
+            gate_dc_incr(g, closedmask, 0ull, nvalid, yv, lane, lds_dc, lds_tmp,
+                         [&](float &qre, float &qim) {
+                           // (x - x[i-48]) / 48 as the producer wave forms it: x[i-48] from the previous step's lanes 16..63
+                           // or this step's lanes 0..15
+                           const int src = (lane < DC_LEN) ? (lane + 64 - DC_LEN) : (lane - DC_LEN);
+                           const float pre = wv::shfl(before.x, src), pim = wv::shfl(before.y, src);
+                           const float cre = wv::shfl(yv.x, src), cim = wv::shfl(yv.y, src);
+                           const float nr = yv.x - ((lane < DC_LEN) ? pre : cre), ni = yv.y - ((lane < DC_LEN) ? pim : cim);
+                           if (__builtin_expect(wv::ballot(!(div_const_ok(nr) && div_const_ok(ni))) == 0, 1)) {
+                             qre = div_const_fast<DC_LEN>(nr); qim = div_const_fast<DC_LEN>(ni);
+                           } else {
+                             qre = wv::fdiv(nr, DC_LEN_F); qim = wv::fdiv(ni, DC_LEN_F);
+                           }
+                         },
+                         tre, tim);
+            chain_add_auto2(g.dcr_c, bre, tre, lane, ar, br);
+            chain_add_auto2(g.dci_c, bim, tim, lane, ai, bi);
+            g.dcr_c = wv::readlane(ar, 63); bre = wv::readlane(br, 63);
+            g.dci_c = wv::readlane(ai, 63); bim = wv::readlane(bi, 63);
+            const int m1 = ls2_margin(ar, sbr), m2 = ls2_margin(br, sbrB), m3 = ls2_margin(ai, sbi), m4 = ls2_margin(bi, sbiB);
+            const int mr = (m1 < m2) ? m1 : m2, mi = (m3 < m4) ? m3 : m4;
+            mre = (mr < mre) ? mr : mre;
+            mim = (mi < mim) ? mi : mim;
+          } else {
+            g.run_closed = 0;   // the step lies entirely inside a window: dc_est, the ring and its index do not move
+            ar = g.dcr_c; ai = g.dci_c; br = bre; bi = bim;
+          }
+          before = yv;
+          if ((oi & 0xff) != 0xff) {   // a window opened in this step: dc_est at that sample (the opening sample is still closed)
+            const int ol = oi & 0xff;
+            const float war = wv::readlane(ar, ol), wai = wv::readlane(ai, ol), wbr = wv::readlane(br, ol), wbi = wv::readlane(bi, ol);
+            if (lane == 0) {
+              Ls2Win *w = wb + (pos0 + 64 * k + ol) / LS2_WBUCKET;
+              w->a_re = war; w->a_im = wai; w->b_re = wbr; w->b_im = wbi;
+            }
+          }
+        }
+      }
+    }
+    const int nx = wv::uniform(a.nextv[cur]);
+    if (nx < 0) break;
+    if (wv::uniform(a.piece[nx].len) <= 0 || wv::uniform(a.fsm[nx].head) != 0) break;
+    cur = nx;
+  }
+  mre = ls2_wave_min(mre);
+  mim = ls2_wave_min(mim);
+  if (lane == 0) {
+    Ls2DcRun ru;
+    ru.s[0] = sre; ru.s[1] = sim; ru.eA[0] = g.dcr_c; ru.eA[1] = g.dci_c; ru.eB[0] = bre; ru.eB[1] = bim;
+    ru.margin[0] = mre; ru.margin[1] = mim;
+    a.drun[i] = ru;
+  }
+  // streaming: the dc ring after the trace's last processed piece is rebuilt from the samples (ls2_carry_kernel): a
+  // processed piece always ends at an idle cut
+}
+
+RFID_DEVICE bool ls2_fsm_settled(const Ls2Ctl *ctl) {
+  return wv::uniform(ctl->fail) == 0 && wv::uniform(ctl->avg_count[LS2_AVG_ROUNDS]) == 0 && wv::uniform(ctl->fsm_count[LS2_FSM_ROUNDS]) == 0;
+}
+RFID_KERNEL(64) void ls2_dc_first_kernel(Ls2Args a) {
+  RFID_SHARED float2 lds_dc[DC_LEN];
+  RFID_SHARED float2 lds_tmp[64];
+  if (!ls2_fsm_settled(a.ctl)) return;
+  const int NS = a.n_streams * a.max_b;
+  const int lane = wv::lane_id();
+  for (int i = (int)blockIdx.x; i < NS; i += (int)gridDim.x) {
+    if (wv::uniform(a.piece[i].len) <= 0 || wv::uniform(a.fsm[i].head) == 0) continue;
+    ls2_dc_unit(a, i, true, lane, lds_dc, lds_tmp);
+  }
+}
+RFID_KERNEL(64) void ls2_dc_rerun_kernel(Ls2Args a) {
+  RFID_SHARED float2 lds_dc[DC_LEN];
+  RFID_SHARED float2 lds_tmp[64];
+  if (!ls2_fsm_settled(a.ctl)) return;
+  const int NS = a.n_streams * a.max_b;
+  const int cnt = wv::uniform(a.ctl->dc_count[a.round - 1]);
+  const int lane = wv::lane_id();
+  const int *list = a.dlist + (int64_t)(a.round - 1) * NS;
+  for (int r = (int)blockIdx.x; r < cnt; r += (int)gridDim.x) ls2_dc_unit(a, wv::uniform(list[r]), false, lane, lds_dc, lds_tmp);
+}
+
+// one workgroup per trace: as ls2_avg_chain_kernel, over the units and the two components of dc_est
+RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_dc_chain_kernel(Ls2Args a) {
+  RFID_SHARED Ls2Aff sh[2 * LS2_CHAIN_THREADS];
+  Ls2Ctl *ctl = a.ctl;
+  const int r = a.round;
+  const int tid = (int)threadIdx.x, s = (int)blockIdx.x;
+  if (ctl->fail != 0 || ctl->avg_count[LS2_AVG_ROUNDS] != 0 || ctl->fsm_count[LS2_FSM_ROUNDS] != 0) return;
+  if (r > 0 && ctl->dc_count[r - 1] == 0) return;
+  const int NS = a.n_streams * a.max_b;
+  const int per = (a.max_b + LS2_CHAIN_THREADS - 1) / LS2_CHAIN_THREADS;
+  const int j0 = tid * per, j1 = (j0 + per < a.max_b) ? (j0 + per) : a.max_b;
+  const int base = s * a.max_b;
+  int64_t T[2];
+  for (int c = 0; c < 2; ++c) {
+    Ls2Aff agg; agg.c0 = 0; agg.c1 = 0;
+    for (int j = j0; j < j1; ++j) {
+      if (a.piece[base + j].len <= 0 || a.fsm[base + j].head == 0) continue;
+      const Ls2DcRun &ru = a.drun[base + j];
+      agg = ls2_compose(agg, ls2_aff(ru.s[c], ru.eA[c], ru.eB[c]));
+    }
+    const Ls2Aff ex = ls2_block_exscan(agg, sh, tid);
+    const int64_t T0 = (a.piece[base].len > 0) ? ls2_ord(a.drun[base].s[c]) : 0;
+    T[c] = T0 + ((T0 & 1) ? ex.c1 : ex.c0);
+  }
+  if (a.piece[base].len <= 0) return;
+  int n_rerun = 0, n_units = 0;
+  for (int j = j0; j < j1; ++j) {
+    const int i = base + j;
+    if (a.piece[i].len <= 0 || a.fsm[i].head == 0) continue;
+    n_units++;
+    const Ls2DcRun ru = a.drun[i];
+    bool again = false;
+    for (int c = 0; c < 2; ++c) {
+      const int64_t D = T[c] - (int64_t)ls2_ord(ru.s[c]);
+      const int64_t aD = (D < 0) ? -D : D;
+      a.dT[2 * i + c] = (int)T[c];
+      if (D != 0 && !(aD + 4 <= (int64_t)ru.margin[c])) again = true;
+    }
+    if (again) {
+      a.drun[i].s[0] = ls2_from_ord((int)T[0]);
+      a.drun[i].s[1] = ls2_from_ord((int)T[1]);
+      const int k = wv::atomic_add(&ctl->dc_count[r], 1);
+      a.dlist[(int64_t)r * NS + k] = i;
+      n_rerun++;
+    }
+    for (int c = 0; c < 2; ++c) {
+      const Ls2Aff f = ls2_aff(ru.s[c], ru.eA[c], ru.eB[c]);
+      T[c] += (T[c] & 1) ? f.c1 : f.c0;
+    }
+  }
+  if (n_rerun) wv::atomic_add(&ctl->dc_reruns, n_rerun);
+  if (r == 0 && n_units) wv::atomic_add(&ctl->n_units, n_units);
+  if (tid == 0 && s == 0) ctl->dc_rounds = r + 1;
+}
+
+// ---- 5. windows ----------------------------------------------------------------------------------------------------
+RFID_DEVICE bool ls2_all_settled(const Ls2Ctl *ctl) {
+  return ctl->fail == 0 && ctl->avg_count[LS2_AVG_ROUNDS] == 0 && ctl->fsm_count[LS2_FSM_ROUNDS] == 0 &&
+         ctl->dc_count[LS2_DC_ROUNDS] == 0 && ctl->wb_clash == 0;
+}
+// one workgroup per trace: the number of complete windows before every piece (exclusive prefix sum), the trace's count
+RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_seq_kernel(Ls2Args a) {
+  RFID_SHARED int shs[2 * LS2_CHAIN_THREADS];
+  const Ls2Ctl *ctl = a.ctl;
+  if (!ls2_all_settled(ctl)) return;
+  const int tid = (int)threadIdx.x, s = (int)blockIdx.x;
+  const int per = (a.max_b + LS2_CHAIN_THREADS - 1) / LS2_CHAIN_THREADS;
+  const int j0 = tid * per, j1 = (j0 + per < a.max_b) ? (j0 + per) : a.max_b;
+  const int base = s * a.max_b;
+  int agg = 0;
+  for (int j = j0; j < j1; ++j) if (a.piece[base + j].len > 0) agg += a.fsm[base + j].nwin;
+  int cur = 0;
+  shs[tid] = agg;
+  wv::block_sync();
+  for (int off = 1; off < LS2_CHAIN_THREADS; off <<= 1) {
+    int v = shs[cur * LS2_CHAIN_THREADS + tid];
+    if (tid >= off) v += shs[cur * LS2_CHAIN_THREADS + tid - off];
+    shs[(cur ^ 1) * LS2_CHAIN_THREADS + tid] = v;
+    cur ^= 1;
+    wv::block_sync();
+  }
+  int run = (tid > 0) ? shs[cur * LS2_CHAIN_THREADS + tid - 1] : 0;
+  const int total = shs[cur * LS2_CHAIN_THREADS + LS2_CHAIN_THREADS - 1];
+  for (int j = j0; j < j1; ++j) {
+    if (a.piece[base + j].len <= 0) continue;
+    a.seq0[base + j] = run;
+    run += a.fsm[base + j].nwin;
+  }
+  if (tid == 0) {
+    a.wcount[s] = (total < a.wmax) ? total : a.wmax;
+    wv::atomic_add(&a.ctl->n_windows, total);
+  }
+}
+
+// one wave per piece: its windows (in order) -> the trace's window table, dc_est shifted to the unit's true start, and
+// the decoder's two lists
+RFID_KERNEL(64) void ls2_assemble_kernel(Ls2Args a) {
+  Ls2Ctl *ctl = a.ctl;
+  if (!(wv::uniform(ctl->fail) == 0 && wv::uniform(ctl->avg_count[LS2_AVG_ROUNDS]) == 0 && wv::uniform(ctl->fsm_count[LS2_FSM_ROUNDS]) == 0 &&
+        wv::uniform(ctl->dc_count[LS2_DC_ROUNDS]) == 0 && wv::uniform(ctl->wb_clash) == 0)) return;
+  const int NS = a.n_streams * a.max_b;
+  const int lane = wv::lane_id();
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  if (blockIdx.x == 0 && lane == 0) ctl->ok = 1;
+  for (int i = (int)blockIdx.x; i < NS; i += (int)gridDim.x) {
+    const Ls2Piece pc = a.piece[i];
+    const int pos0 = wv::uniform(pc.pos0), n = wv::uniform(pc.len);
+    if (n <= 0) continue;
+    const Ls2Fsm *f = a.fsm + i;
+    if (wv::uniform(f->nwin) == 0) continue;
+    const int s = i / a.max_b;
+    const int h = wv::uniform(f->unit), gen = wv::uniform(f->gen);
+    // the unit's true start against the start its run used: D ulps (even: variant A + D, odd: variant B + D - 1)
+    const Ls2DcRun ru = a.drun[h];
+    float shift[2];
+    bool useb[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int D = wv::uniform(a.dT[2 * h + c]) - ls2_ord(ru.s[c]);
+      useb[c] = (D & 1) != 0;
+      const int De = useb[c] ? (D - 1) : D;
+      const uint32_t e0 = (wv::f2u(ru.s[c]) >> 23) & 0xffu;
+      const float u0 = (e0 >= 25u) ? wv::u2f((e0 - 23u) << 23) : 0.0f;   // (D != 0 was only accepted with a margin, i.e. e0 >= 25)
+      shift[c] = (float)De * u0;
+    }
+    const Ls2Win *wb = a.wb + (int64_t)s * a.wb_stride;
+    const int b0 = pos0 / LS2_WBUCKET, b1 = (pos0 + n - 1) / LS2_WBUCKET;
+    int seq = wv::uniform(a.seq0[i]);
+    for (int bb = b0; bb <= b1; bb += 64) {
+      const int b = bb + lane;
+      Ls2Win w; w.start = 0; w.tag = 0; w.a_re = w.a_im = w.b_re = w.b_im = 0.0f;
+      if (b <= b1) w = wb[b];
+      const bool on = b <= b1 && (w.tag >> 8) == gen && (w.tag & 2) != 0 && w.start >= pos0 && w.start < pos0 + n;
+      const uint64_t m = wv::ballot(on);
+      if (m == 0ull) continue;
+      const int type = w.tag & 1;
+      rfid_window o;
+      o.stream = s; o.seq = seq + wv::popc64(m & lt); o.start = w.start; o.type = type;
+      o.dc_re = (useb[0] ? w.b_re : w.a_re) + shift[0];
+      o.dc_im = (useb[1] ? w.b_im : w.a_im) + shift[1];
+      const bool put = on && o.seq < a.wmax;
+      if (put) a.wtab[(int64_t)s * a.wmax + o.seq] = o;
+      // places in the decoder's two lists: one atomic per list and 64 windows
+      const uint64_t m1 = wv::ballot(put && type != 0), m0 = wv::ballot(put && type == 0);
+      int c0 = 0, c1 = 0;
+      if (lane == 0) {
+        if (m0) c0 = wv::atomic_add(a.flat_count + 0, wv::popc64(m0));
+        if (m1) c1 = wv::atomic_add(a.flat_count + 1, wv::popc64(m1));
+      }
+      c0 = wv::uniform(c0); c1 = wv::uniform(c1);
+      if (put) {
+        const int slotw = type ? (c1 + wv::popc64(m1 & lt)) : (c0 + wv::popc64(m0 & lt));
+        if (slotw < a.flat_cap) a.flat[(int64_t)type * a.flat_cap + slotw] = o;
+      }
+      seq += wv::popc64(m);
+    }
+  }
+}
+
+// streaming: the gate state after each trace's last processed piece -- it ends at an idle cut, so both rings are the
+// preceding samples; avg_ampl / dc_est / the state machine from the chains.  One wave per trace.
+RFID_KERNEL(64) void ls2_carry_kernel(Ls2Args a) {
+  const Ls2Ctl *ctl = a.ctl;
+  if (!a.carry_out) return;
+  if (!(wv::uniform(ctl->fail) == 0 && wv::uniform(ctl->avg_count[LS2_AVG_ROUNDS]) == 0 && wv::uniform(ctl->fsm_count[LS2_FSM_ROUNDS]) == 0 &&
+        wv::uniform(ctl->dc_count[LS2_DC_ROUNDS]) == 0 && wv::uniform(ctl->wb_clash) == 0)) return;
+  const int lane = wv::lane_id();
+  const int s = (int)blockIdx.x;
+  const int base = s * a.max_b;
+  // the last piece in use
+  int last;
+  last = -1;
+  for (int j = a.max_b - 1; j >= 0; --j) if (wv::uniform(a.piece[base + j].len) > 0) { last = base + j; break; }
+  if (last < 0) return;
+  const Ls2Piece pc = a.piece[last];
+  const int end = wv::uniform(pc.pos0) + wv::uniform(pc.len);
+  GateState *st = a.carry_out + s;
+  const float2 *yrow = a.y + (int64_t)s * a.y_stride;
+  const float *amp = a.amp + (int64_t)s * a.y_stride;
+  // avg_ampl after the piece: its true start through its latest run
+  const Ls2AvgRun ar = a.arun[last];
+  const int Da = wv::uniform(a.aT[last]) - ls2_ord(ar.s);
+  const float avg_end = ls2_from_ord(ls2_ord((Da & 1) ? ar.eB : ar.eA) + ((Da & 1) ? (Da - 1) : Da));
+  const int h = wv::uniform(a.fsm[last].unit);
+  const Ls2DcRun dr = a.drun[h];
+  float dc_end[2];
+  for (int c = 0; c < 2; ++c) {
+    const int D = wv::uniform(a.dT[2 * h + c]) - ls2_ord(dr.s[c]);
+    dc_end[c] = ls2_from_ord(ls2_ord((D & 1) ? dr.eB[c] : dr.eA[c]) + ((D & 1) ? (D - 1) : D));
+  }
+  for (int k = lane; k < WIN_LEN; k += 64) {
+    const int idx = end - WIN_LEN + k;
+    st->win[k] = (idx >= 0) ? amp[idx] : 0.0f;
+  }
+  if (lane < DC_LEN) {
+    const int idx = end - DC_LEN + lane;
+    const float2 v = (idx >= 0) ? yrow[idx] : make_float2(0.0f, 0.0f);
+    st->dcr_re[lane] = v.x; st->dcr_im[lane] = v.y;
+  }
+  if (lane == 0) {
+    const Ls2Fsm &f = a.fsm[last];
+    st->avg_ampl = avg_end; st->dc_re = dc_end[0]; st->dc_im = dc_end[1];
+    st->n_samples = f.en[0]; st->signal_state = f.en[1]; st->num_pulses = f.en[2]; st->gate_open = f.en[3];
+    st->n_to_ungate = f.en[4]; st->wtype = f.en[5];
+    st->win_index = 0; st->dc_index = 0;
+    st->win_seq = a.wcount[s];   // (a sequential scan that continues from here in the same call appends its windows)
+  }
+}
+
+}  // namespace rfidk

@@ -1,0 +1,124 @@
+// rfid_ls2_enqueue.hpp -- the launch sequence of the long-stream front end (rfid_ls2.hpp): sizes, work space layout and the
+// fixed list of launches of one pass.  There is no decision between the launches (the kernels look at Ls2Ctl themselves),
+// so the same sequence serves the library (hipLaunchKernelGGL on the context's stream) and the host emulator of the
+// test suite; the includer defines
+//     LS2_LAUNCH(kernel, grid_x, grid_y, block, args)
+// before including this file.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace rfidk {
+
+constexpr int LS2_TARGET_PIECES = 32768;   // pieces per pass to aim for (all traces together)
+constexpr int LS2_MIN_PIECE = 2048;        // ... of at least this many decimated samples (a cut needs LS_QUIET = 1615 idle ones before it)
+
+struct Ls2Geometry {
+  int P = 0, max_b = 0, NS = 0;
+  int64_t vstride = 0, wb_stride = 0;
+};
+// P: nominal piece length for `n_streams` traces of (at most) n_dec decimated samples; 0 = the traces are too short to cut
+inline Ls2Geometry ls2_geometry(int n_streams, int64_t n_dec, int min_piece = LS2_MIN_PIECE, int target = LS2_TARGET_PIECES) {
+  Ls2Geometry g;
+  if (n_streams <= 0 || n_dec < 2 * (int64_t)min_piece) return g;
+  int64_t P = ((int64_t)n_streams * n_dec + target - 1) / target;
+  if (P < min_piece) P = min_piece;
+  P = (P + 63) & ~63LL;
+  if (P > 0x3fffffff) return g;
+  g.P = (int)P;
+  g.max_b = (int)(n_dec / P) + 1;
+  g.NS = n_streams * g.max_b;
+  g.vstride = (n_dec >> 6) + g.max_b + 2;
+  g.wb_stride = n_dec / LS2_WBUCKET + 2;
+  return g;
+}
+
+// work space: one allocation, carved up here (offsets in bytes, 256-byte aligned)
+struct Ls2Layout {
+  size_t cut, piece, nextv, prevv, amp, dadd, votes, closed, openinfo, arun, aT, alist, fsm, wb, drun, dT, dlist, seq0, ctl, consumed, total;
+};
+inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_stride) {
+  Ls2Layout L;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t NS = (size_t)g.NS, B = (size_t)n_streams;
+  L.cut = take(sizeof(int) * NS);
+  L.piece = take(sizeof(Ls2Piece) * NS);
+  L.nextv = take(sizeof(int) * NS);
+  L.prevv = take(sizeof(int) * NS);
+  L.amp = take(sizeof(float) * B * (size_t)y_stride);
+  L.dadd = take(sizeof(float) * B * (size_t)y_stride);
+  L.votes = take(sizeof(uint64_t) * 2 * B * (size_t)g.vstride);
+  L.closed = take(sizeof(uint64_t) * B * (size_t)g.vstride);
+  L.openinfo = take(sizeof(int) * B * (size_t)g.vstride);
+  L.arun = take(sizeof(Ls2AvgRun) * NS);
+  L.aT = take(sizeof(int) * NS);
+  L.alist = take(sizeof(int) * LS2_MAXR * NS);
+  L.fsm = take(sizeof(Ls2Fsm) * NS);
+  L.wb = take(sizeof(Ls2Win) * B * (size_t)g.wb_stride);
+  L.drun = take(sizeof(Ls2DcRun) * NS);
+  L.dT = take(sizeof(int) * 2 * NS);
+  L.dlist = take(sizeof(int) * LS2_MAXR * NS);
+  L.seq0 = take(sizeof(int) * NS);
+  L.ctl = take(sizeof(Ls2Ctl));
+  L.consumed = take(sizeof(int) * B);
+  L.total = off;
+  return L;
+}
+inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geometry &g) {
+  a.P = g.P; a.max_b = g.max_b; a.vstride = g.vstride; a.wb_stride = g.wb_stride;
+  a.cut = (int *)(base + L.cut); a.piece = (Ls2Piece *)(base + L.piece);
+  a.nextv = (int *)(base + L.nextv); a.prevv = (int *)(base + L.prevv);
+  a.amp = (float *)(base + L.amp); a.dadd = (float *)(base + L.dadd);
+  a.votes = (uint64_t *)(base + L.votes); a.closed = (uint64_t *)(base + L.closed); a.openinfo = (int *)(base + L.openinfo);
+  a.arun = (Ls2AvgRun *)(base + L.arun); a.aT = (int *)(base + L.aT); a.alist = (int *)(base + L.alist);
+  a.fsm = (Ls2Fsm *)(base + L.fsm); a.wb = (Ls2Win *)(base + L.wb);
+  a.drun = (Ls2DcRun *)(base + L.drun); a.dT = (int *)(base + L.dT); a.dlist = (int *)(base + L.dlist);
+  a.seq0 = (int *)(base + L.seq0); a.ctl = (Ls2Ctl *)(base + L.ctl); a.consumed = (int *)(base + L.consumed);
+}
+
+#ifdef LS2_LAUNCH
+// One pass.  Before it (stream-ordered): Ls2Ctl, the window buckets (a.wb) and flat_count zeroed.  `a` complete but for
+// `round`.  After it: wtab / wcount / flat lists + Ls2Ctl::ok = 1, or ok = 0 (the caller's fallback scan, enqueued
+// behind with GateArgs::skip_if = &ctl->ok, then runs).
+inline void ls2_enqueue(Ls2Args a, bool search_cuts = true) {   // (search_cuts = false: a.cut is given -- tests)
+  const int NS = a.n_streams * a.max_b;
+  const int B = a.n_streams;
+  if (a.max_b > 1 && search_cuts) {
+    LsCutArgs ca;
+    ca.y = a.y; ca.y_stride = a.y_stride; ca.lens = a.lens; ca.n_dec = a.n_dec; ca.chunk = a.P; ca.limit = a.P / 2;
+    ca.max_b = a.max_b; ca.cut = a.cut;
+    LS2_LAUNCH(ls_cut_kernel, a.max_b - 1, B, 64, ca);
+  }
+  a.round = 0;
+  LS2_LAUNCH(ls2_pieces_kernel, (NS + 255) / 256, 1, 256, a);
+  LS2_LAUNCH(ls2_check_kernel, 1, 1, 64, a);
+  const int rerun_grid = NS < 2048 ? NS : 2048;
+  LS2_LAUNCH(ls2_avg_first_kernel, NS, 1, 64, a);
+  LS2_LAUNCH(ls2_avg_chain_kernel, B, 1, LS2_CHAIN_THREADS, a);
+  for (int r = 1; r <= LS2_AVG_ROUNDS; ++r) {
+    a.round = r;
+    LS2_LAUNCH(ls2_avg_rerun_kernel, rerun_grid, 1, 64, a);
+    LS2_LAUNCH(ls2_avg_chain_kernel, B, 1, LS2_CHAIN_THREADS, a);
+  }
+  for (int r = 0; r <= LS2_FSM_ROUNDS; ++r) {
+    a.round = r;
+    LS2_LAUNCH(ls2_fsm_kernel, (r == 0) ? NS : rerun_grid, 1, 64, a);
+    LS2_LAUNCH(ls2_fsm_chain_kernel, B, 1, LS2_CHAIN_THREADS, a);
+  }
+  a.round = 0;
+  LS2_LAUNCH(ls2_dc_first_kernel, NS, 1, 64, a);
+  LS2_LAUNCH(ls2_dc_chain_kernel, B, 1, LS2_CHAIN_THREADS, a);
+  for (int r = 1; r <= LS2_DC_ROUNDS; ++r) {
+    a.round = r;
+    LS2_LAUNCH(ls2_dc_rerun_kernel, rerun_grid, 1, 64, a);
+    LS2_LAUNCH(ls2_dc_chain_kernel, B, 1, LS2_CHAIN_THREADS, a);
+  }
+  a.round = 0;
+  LS2_LAUNCH(ls2_seq_kernel, B, 1, LS2_CHAIN_THREADS, a);
+  LS2_LAUNCH(ls2_assemble_kernel, NS < 8192 ? NS : 8192, 1, 64, a);
+  if (a.carry_out) LS2_LAUNCH(ls2_carry_kernel, B, 1, 64, a);
+}
+#endif
+
+}  // namespace rfidk

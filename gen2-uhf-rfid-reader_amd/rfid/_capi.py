@@ -53,8 +53,8 @@ class SynthGen2Params(C.Structure):
 
 
 class LsReport(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("units", "chunk", "rounds", "gate_passes", "unit_runs", "avg_passes", "verified", "gave_up",
-                                         "cuts_dropped", "last_round_moved", "dc_runs", "reserved_")]
+    _fields_ = [(n, C.c_int32) for n in ("pieces", "units", "chunk", "avg_rounds", "avg_reruns", "fsm_rounds", "dc_rounds",
+                                         "dc_reruns", "verified", "gave_up", "cuts_dropped", "windows")]
 
 
 class BatchTiming(C.Structure):

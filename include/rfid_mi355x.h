@@ -132,22 +132,25 @@ typedef struct rfid_batch_timing {
   int32_t reserved_;
 } rfid_batch_timing;
 
-/* what the long-stream front end did in the last rfid_batch_process pass (all zero when it was not used) */
+/* what the long-stream front end did in the last rfid_batch_process pass (all zero when it was not used).  The front
+ * end cuts each trace along time into pieces at idle points of the gate and processes all pieces at once: avg_ampl, then
+ * the state machine, then dc_est, each from guessed start values whose runs are PROVEN to cover the true ones (or run
+ * again); see csrc/rfid_ls2.hpp. */
 typedef struct rfid_ls_report {
-  int32_t units;            /* units the traces were cut into */
-  int32_t chunk;            /* nominal unit length, decimated samples */
-  int32_t rounds;           /* prediction rounds until every unit started from its predecessor's exact end state */
-  int32_t gate_passes;      /* full gate-scan launches those rounds cost */
-  int32_t unit_runs;        /* unit runs in those launches (units that already ran from their exact start are not re-run;
-                             * see dc_runs) */
-  int32_t avg_passes;       /* launches of the cheap avg_ampl-only pass that settles avg_ampl at every cut first */
-  int32_t verified;         /* 1: accepted -- bit-identical to the sequential scan by construction */
-  int32_t gave_up;          /* 1: not verified within the round limit; the sequential scan was run instead */
-  int32_t cuts_dropped;     /* cut points withdrawn because the state machine was not idle there */
-  int32_t last_round_moved; /* units whose start still moved in the last round (0 when verified) */
-  int32_t dc_runs;          /* unit re-runs of the dc_est arithmetic alone (units whose avg_ampl / state-machine start was already
-                             * the exact one: what is closed and where windows open cannot change any more) */
-  int32_t reserved_;
+  int32_t pieces;           /* pieces the traces were cut into */
+  int32_t units;            /* runs of pieces scanned in one go by the state-machine / dc_est passes (= pieces unless a cut
+                             * turned out not to be idle: see cuts_dropped) */
+  int32_t chunk;            /* nominal piece length, decimated samples */
+  int32_t avg_rounds;       /* avg_ampl: chain rounds that had work (1 = every guess was proven at once) */
+  int32_t avg_reruns;       /*   pieces run again from their predicted start because their first run did not cover it */
+  int32_t fsm_rounds;       /* state machine: rounds */
+  int32_t dc_rounds;        /* dc_est: chain rounds */
+  int32_t dc_reruns;        /*   unit re-runs */
+  int32_t verified;         /* 1: accepted -- every piece's latest run is exact or proven: the sequential scan, bit for bit */
+  int32_t gave_up;          /* != 0: the sequential scan ran instead (1 no trace could be cut, 2 / 3 / 4: avg_ampl / state
+                             * machine / dc_est not settled within the round limit) */
+  int32_t cuts_dropped;     /* cut points withdrawn because the state machine (or the dc ring) was not idle there */
+  int32_t windows;          /* complete windows found */
 } rfid_ls_report;
 
 typedef struct rfid_ctx rfid_ctx;
@@ -266,12 +269,14 @@ RFID_API int rfid_batch_stats(rfid_ctx *ctx);
 RFID_API int rfid_batch_process(rfid_ctx *ctx, const void *d_raw, int64_t raw_stride, int64_t n_raw,
                                 const void *d_lens, int want_scores);
 /* Long-stream front end of rfid_batch_process: with few, long traces the gate scan (a sequential recurrence per
- * trace) leaves the chip idle, so each trace is cut along time at idle points of the gate's state machine and the
- * units are scanned concurrently from predicted gate states; a pass is accepted only when every unit started from
- * a state bit-identical to its predecessor's end state, i.e. the result IS the sequential scan (otherwise the
- * sequential scan runs).  mode 0: never, 1 (default): when it is expected to be faster than the fused front end --
- * few traces, long enough (an estimate from the batch size and the trace length: e.g. up to ~100 traces of 1 M raw
- * samples, one trace of more than ~0.6 M), 2: whenever a trace can be cut.  The environment variable RFID_LONG_STREAM overrides the default. */
+ * trace) leaves the chip idle, so each trace is cut along time at idle points of the gate's state machine and all
+ * pieces are processed at once from guessed start values; a pass is accepted only when every piece's run is exact or
+ * provably covers its true start value, i.e. the result IS the sequential scan (otherwise the sequential scan runs:
+ * it is enqueued behind the front end and skips itself when that succeeded -- a pass has no host synchronisation).
+ * mode 0: never, 1 (default): when it is expected to be faster than the fused front end -- few traces, long enough
+ * (a cost estimate from the batch size and the trace length, calibrated on the device when the context is created),
+ * 2: whenever a trace can be cut.  The environment variable RFID_LONG_STREAM overrides the default.
+ * rfid_batch_ls_report synchronises with the pass. */
 RFID_API int rfid_batch_set_long_stream(rfid_ctx *ctx, int mode);
 RFID_API int rfid_batch_ls_report(const rfid_ctx *ctx, rfid_ls_report *out);
 RFID_API int rfid_batch_sync(rfid_ctx *ctx);

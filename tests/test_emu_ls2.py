@@ -1,0 +1,167 @@
+"""CPU-only checks of the long-stream front end (csrc/rfid_ls2.hpp + the launch list of csrc/rfid_ls2_enqueue.hpp): the
+UNMODIFIED kernel source and launch sequence run on the lock-step wave emulator (tests/wave_emu, test infrastructure)
+and must reproduce the oracle's sequential gate scan bit for bit -- window starts, types, dc_est at every opening,
+everything the decoder derives from them -- and an independent restatement of the avg_ampl recurrence at every cut.
+The front end never assumes: a piece whose run does not PROVABLY cover its true start value is run again, cuts that
+turn out not to be idle are withdrawn, and when rounds run out the sequential scan takes over; every one of those paths
+is driven here.  (The real parity gate is on the MI355X: tests/test_gpu_*.py.)"""
+import numpy as np
+import pytest
+
+import parity
+
+
+def avg_reference(y):
+    """gate_impl.cc:130-133 restated in numpy binary32 scalars: avg_ampl BEFORE every sample (and after the last)"""
+    amp = np.sqrt(y.real.astype(np.float64) ** 2 + y.imag.astype(np.float64) ** 2).astype(np.float32)
+    ring = np.zeros(100, np.float32)
+    avg = np.float32(0.0)
+    out = np.empty(len(y) + 1, np.float32)
+    hundred = np.float32(100.0)
+    for i in range(len(y)):
+        out[i] = avg
+        wi = i % 100
+        avg = np.float32(avg + np.float32(np.float32(amp[i] - ring[wi]) / hundred))
+        ring[wi] = amp[i]
+    out[len(y)] = avg
+    return out
+
+
+def _check(emu_mod, oracle_mod, raw2d, lens=None, cfg_kw=None, check_avg=True, expect_ok=None, **kw):
+    cfg_kw = cfg_kw or {}
+    r = emu_mod.ls2_process(raw2d, lens=lens, **cfg_kw, **kw)
+    B = raw2d.shape[0]
+    for b, (wb, rb, sb) in enumerate(parity.split_by_stream(r["windows"], r["results"], r["scores"], B)):
+        n = raw2d.shape[1] if lens is None else lens[b]
+        o = oracle_mod.run_trace(raw2d[b, :n], oracle_mod.config(**cfg_kw))
+        parity.compare_trace(wb, rb, sb, r["stats"][b], o)
+        if check_avg and r["ok"]:
+            ref = avg_reference(oracle_mod.fir(raw2d[b, :n]))
+            for pc in r["pieces"]:
+                if pc[0] == b:
+                    assert pc[3:4].view(np.uint32)[0] == ref[pc[1]].view(np.uint32), ("avg_ampl at a cut", b, pc)
+    if expect_ok is not None:
+        assert r["ok"] == expect_ok, r["ctl"]
+    return r
+
+
+def test_ls2_matches_oracle_and_avg_recurrence(emu_mod, oracle_mod, synth_mod):
+    """Two traces of different carrier level / phase / noise, cut into ~10 pieces each: accepted, and identical to the
+    sequential scan; avg_ampl at every cut equals the in-order recurrence."""
+    rng = np.random.default_rng(3)
+    ts = []
+    for k, (sigma, leak) in enumerate([(0.01, 14.9 * np.exp(0.91j)), (0.03, 3.8 * np.exp(3.4j))]):
+        ts.append(synth_mod.make_trace(n_rounds=16, sigma=sigma, seed=200 + k, leak=leak, t1_jitter_raw=4).samples)
+    L = min(map(len, ts))
+    r = _check(emu_mod, oracle_mod, np.stack([t[:L] for t in ts]), expect_ok=1)
+    c = r["ctl"]
+    assert c["n_pieces"] >= 12 and c["n_units"] == c["n_pieces"] and c["n_windows"] == len(r["windows"])
+    del rng
+
+
+def test_ls2_rerun_rounds_are_exercised(emu_mod, oracle_mod, synth_mod):
+    """Noise of 8 % of the carrier makes dc_est pass close to powers of two inside pieces: some runs do not cover their
+    true start and are repeated from it (dc_reruns > 0) -- the result is still the sequential scan."""
+    t = synth_mod.make_trace(n_rounds=20, sigma=0.08, seed=9).samples
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1)
+    assert r["ctl"]["dc_reruns"] > 0 and r["ctl"]["dc_rounds"] >= 2, r["ctl"]
+    # few, long pieces: avg_ampl too
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, target=6)
+    assert r["ctl"]["n_pieces"] <= 8
+
+
+def test_ls2_gives_up_on_a_carrier_at_a_power_of_two(emu_mod, oracle_mod, synth_mod):
+    """A carrier whose filtered amplitude is exactly 16.0: avg_ampl hovers at a binade edge, no run is provable and the
+    rounds run out.  The front end must say so (ok = 0) and the sequential scan behind it must give the result."""
+    t = synth_mod.make_trace(n_rounds=30, sigma=0.01, seed=5).samples
+    t = (t * np.complex64(0.64)).astype(np.complex64)
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=0)
+    assert r["ctl"]["avg_count4"] > 0 and r["ctl"]["n_pieces"] > 3, r["ctl"]
+
+
+def test_ls2_ragged_batch_collisions_and_limits(emu_mod, oracle_mod, synth_mod):
+    """Per-trace lengths (one trace cut inside a slot, one too short to be cut, one empty), FIXED_Q = 2 collisions."""
+    kw = dict(fixed_q=2, tag_ids=(0x11, 0x22, 0x33), sigma=0.01, t1_jitter_raw=5)
+    traces = [synth_mod.make_trace(n_rounds=r, seed=900 + r, **kw).samples for r in (4, 3, 1)]
+    L = max(map(len, traces))
+    raw = np.zeros((4, L), dtype=np.complex64)
+    lens = []
+    for i, t in enumerate(traces):
+        raw[i, : len(t)] = t
+        lens.append(len(t))
+    lens.append(0)
+    lens[1] -= 12345
+    r = _check(emu_mod, oracle_mod, raw, lens=lens, cfg_kw=dict(fixed_q=2), expect_ok=1)
+    assert r["stats"][3]["n_windows"] == 0
+
+
+def test_ls2_cuts_that_are_not_idle_are_withdrawn(emu_mod, oracle_mod, synth_mod):
+    """Cut points forced to arbitrary places -- inside reader commands, inside open windows, right behind a window: the
+    state machine's end state does not meet the idle state assumed at the next cut (or the dc ring is not the last 48
+    samples), the pieces are appended to their predecessors (n_units < n_pieces) and scanned through; avg_ampl needs no
+    idle point at all.  Still the sequential scan, bit for bit."""
+    t = synth_mod.make_trace(n_rounds=6, sigma=0.02, seed=77, t1_jitter_raw=3).samples
+    o = oracle_mod.run_trace(t)
+    n = len(t) // 5
+    opens = [int(p) for p in o.open_idx]
+    cuts = sorted({2048 + 13, opens[2] + 100, opens[3] + 251 + 20, opens[5] - 30, opens[6] + 1370 + 2, opens[8] - 400, n - 3000})
+    cuts = [c for c in cuts if 64 < c < n - 64]
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, cuts=cuts, min_piece=64, target=1 << 20)
+    c = r["ctl"]
+    assert c["n_pieces"] == len(cuts) + 1 and c["n_units"] < c["n_pieces"] and c["fsm_rounds"] >= 2, c
+
+
+def test_ls2_streaming_form_carries_the_gate_state(emu_mod, oracle_mod, synth_mod):
+    """The form rfid_stream_work uses: a call processes up to its last idle cut (hold_last), leaves the gate state there
+    (rings rebuilt from the samples, recurrences from the chains) and the next call starts from it.  Two calls over one
+    trace give the windows of the sequential scan over the whole trace."""
+    t = synth_mod.make_trace(n_rounds=14, sigma=0.01, seed=123).samples
+    o = oracle_mod.run_trace(t)
+    state = np.zeros(emu_mod.lib().emu_gate_state_size(), dtype=np.uint8)
+    half = (len(t) // 2) // 5 * 5
+    r1 = emu_mod.ls2_process(t[None, :half], state=state, hold_last=True)
+    assert r1["ok"] == 1 and 0 < r1["consumed"] < half // 5
+    c1 = r1["consumed"]
+    # the second call: 25 raw samples early, so that the matched filter has its history (the 5 leading outputs are skipped)
+    r2 = emu_mod.ls2_process(t[None, 5 * c1 - 25:], state=state, hold_last=False, y_skip=5)
+    assert r2["ok"] == 1
+    k = len(r1["windows"])
+    assert k > 4 and len(r2["windows"]) > 4
+    assert np.array_equal(np.concatenate([r1["windows"]["start"], r2["windows"]["start"] + c1]), o.open_idx)
+    assert np.array_equal(np.concatenate([r1["windows"]["type"], r2["windows"]["type"]]), o.dumps["type"])
+    # dc_est is a sum over the whole past: the second call's values prove the carried rings and recurrences
+    for f, ref in (("dc_re", o.dc.real), ("dc_im", o.dc.imag)):
+        got = np.concatenate([r1["windows"][f], r2["windows"][f]])
+        assert np.array_equal(got.view(np.uint32), ref.astype(np.float32).view(np.uint32)), f
+    # ... and so does avg_ampl at the second call's cuts
+    ref = avg_reference(oracle_mod.fir(t))
+    for pc in r2["pieces"]:
+        assert pc[3:4].view(np.uint32)[0] == ref[c1 + pc[1]].view(np.uint32), pc
+
+
+def test_chain_add_auto2_equals_two_sequential_sums(emu_mod):
+    """The in-order sums from two carries one ulp apart in ONE pass (shared conversion of the addends, per-carry tie
+    parities): each must equal the plain sequential binary32 sum from its carry -- ties, binade edges, zeros, both signs."""
+    rng = np.random.default_rng(11)
+    n_scanned = 0
+    for trial in range(200):
+        carry = np.float32(rng.choice([23.456789, -19.12345, 31.99999, 16.000002, 0.0, 1e-30, -15.99999, 3.0e5, 25.0, 8.5, -0.75, 15.999999]))
+        scale = float(rng.choice([1e-4, 1e-3, 1e-2, 0.3, 1e-8, 1e3]))
+        x = (rng.standard_normal(64) * scale).astype(np.float32)
+        kind = rng.integers(0, 4)
+        if kind == 1:
+            x[::3] = np.ldexp(rng.integers(-7, 8, len(x[::3])).astype(np.float32) + 0.5, -19)   # half-ulp at 16..32: ties
+        if kind == 2:
+            x[rng.integers(0, 64)] = 0.0
+            x[5] = -0.0
+        cb = np.nextafter(carry, np.float32(np.inf)) if carry >= 0 else np.nextafter(carry, np.float32(0))
+        if carry == 0:
+            cb = np.float32(np.nextafter(np.float32(0), np.float32(1)))
+        oa, ob, sc = emu_mod.chain_scan2(x, float(carry), float(cb))
+        n_scanned += sc
+        for c0, got in ((carry, oa), (np.float32(cb), ob)):
+            acc = np.float32(c0)
+            for i in range(64):
+                acc = np.float32(acc + x[i])
+                assert got[i].view(np.uint32) == acc.view(np.uint32), (trial, float(c0), i)
+    assert n_scanned > 40

@@ -237,32 +237,3 @@ def test_emulated_termination_limits(emu_mod, oracle_mod, synth_mod, kw):
     for k in ("n_queries_sent", "cur_inventory_round", "cur_slot_number", "n_epc_correct", "n_unique_tags"):
         assert st[k] == getattr(o.state, k), k
     assert np.array_equal(st["tag_reads"], np.array(o.state.tag_reads[:], dtype=np.int32))
-
-
-@pytest.mark.parametrize("dc0", [(0.0, 0.0), (19.125, 16.0625), (19.125001907348633, -3.5), (1e-3, 7.75)])
-def test_emulated_dc_only_rerun_equals_full_gate_scan(emu_mod, oracle_mod, synth_mod, dc0):
-    """ls_dc_kernel (long-stream front end: later rounds redo a unit's dc_est arithmetic alone, over the closed-sample
-    masks its full gate scan recorded) against gate_scan_kernel started from the same dc_est: dc_est and the dc ring at
-    the end of the unit and the dc_est of every window record must agree bit for bit -- and the start value of dc_est
-    must not move any window (the state machine does not depend on it).  The trace ends inside a partial step."""
-    t = synth_mod.make_trace(n_rounds=3, seed=17, sigma=0.02, t1_jitter_raw=3).samples
-    y = oracle_mod.fir(t)[: len(t) // 5 - 37]
-    bad, nw = emu_mod.ls_dc_check(y, dc0[0], dc0[1])
-    assert nw == 6 and bad == 0
-
-
-def test_emulated_avg_pass_from_cached_addends(emu_mod, oracle_mod, synth_mod):
-    """ls_avg_kernel: the addends (|x| - win_samples[win_index]) / 100 depend on the samples only; the first pass of the
-    long-stream front end caches them, later passes re-add them from another start value.  Both ways must give the same
-    avg_ampl bit for bit -- and the value the oracle's gate ends with when started fresh (start 0)."""
-    t = synth_mod.make_trace(n_rounds=2, seed=23, sigma=0.02).samples
-    y = oracle_mod.fir(t)[: len(t) // 5 - 11]
-    out = emu_mod.ls_avg_check(y, 0.0).view(np.uint32)
-    assert out[0] == out[1] and out[2] == out[3]
-    amp = np.hypot(y.real.astype(np.float32), y.imag.astype(np.float32)).astype(np.float32)   # (hypotf, as the gate)
-    avg = np.float32(0.0)
-    ring = np.zeros(100, dtype=np.float32)
-    for i, a in enumerate(amp):                                                              # gate_impl.cc:130-134
-        avg = np.float32(avg + np.float32(np.float32(a - ring[i % 100]) / np.float32(100.0)))
-        ring[i % 100] = a
-    assert out[0] == avg.view(np.uint32)

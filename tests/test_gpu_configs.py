@@ -55,8 +55,8 @@ def test_config2_full_size_multi_tag_inventory(oracle_mod, synth_mod):
         ctx.batch_sync()
         rep = ctx.batch_ls_report()
         print("long-stream report:", rep)
-        assert rep["verified"] == 1 and rep["units"] > (1000 if not SMALL else 100) and not rep["gave_up"]
-        assert rep["dc_runs"] > 0, rep
+        assert rep["verified"] == 1 and rep["pieces"] > (1000 if not SMALL else 100) and not rep["gave_up"]
+        assert rep["windows"] == 2 * len(t.slots) and rep["avg_rounds"] <= 5 and rep["dc_rounds"] <= 5, rep
         w, r, _ = ctx.batch_windows()
         st = ctx.batch_stats()
         n_slots = len(t.slots)
@@ -84,7 +84,7 @@ def test_config2_full_size_multi_tag_inventory(oracle_mod, synth_mod):
         ctx.batch_set_long_stream(0)
         ctx.batch_process_ptr(data.data_ptr(), stride, L, 0, want_scores=False)
         ctx.batch_sync()
-        assert ctx.batch_timing()["fused_front"] == 1 and ctx.batch_ls_report()["units"] == 0
+        assert ctx.batch_timing()["fused_front"] == 1 and ctx.batch_ls_report()["pieces"] == 0
         w2, r2, _ = ctx.batch_windows()
         assert w2.tobytes() == w.tobytes() and r2.tobytes() == r.tobytes()
         os.environ["RFID_FRONT_UNFUSED"] = "1"
@@ -114,10 +114,9 @@ def test_config3_one_long_stream_per_gpu(oracle_mod, synth_mod):
         ctx.batch_sync()
         rep = ctx.batch_ls_report()
         print("long-stream report:", rep)
-        assert rep["verified"] == 1 and rep["units"] > 50
-        # rounds after a unit's first full scan redo the dc_est arithmetic alone (ls_dc_kernel) -- the comparison with
-        # the oracle below covers the window records that kernel patches
-        assert rep["dc_runs"] > 0 and rep["gate_passes"] <= 3, rep
+        assert rep["verified"] == 1 and rep["pieces"] > 50 and rep["units"] > 50
+        # (the comparison with the oracle below covers dc_est at every window: the runs' values shifted to the true starts)
+        assert rep["avg_rounds"] >= 1 and rep["dc_rounds"] >= 1 and rep["fsm_rounds"] >= 1, rep
         w, r, _ = ctx.batch_windows()
         st = ctx.batch_stats()
         o = _oracle_over_device_trace(oracle_mod, data, L, oracle_mod.config(max_num_queries=(1 << 31) - 2))
@@ -188,7 +187,7 @@ def test_front_end_is_chosen_by_cost_estimate(synth_mod):
         ctx.batch_plan(B, L)
         ctx.batch_process_ptr(many.data_ptr(), stride, L, 0, want_scores=False)
         ctx.batch_sync()
-        assert ctx.batch_ls_report()["units"] == 0 and ctx.batch_timing()["fused_front"] == 1
+        assert ctx.batch_ls_report()["pieces"] == 0 and ctx.batch_timing()["fused_front"] == 1
         w, r, _ = ctx.batch_windows()
         for b, (wb, rb, _sb) in enumerate(parity.split_by_stream(w, r, None, B)):
             wb = wb.copy()
@@ -217,7 +216,7 @@ def test_long_stream_falls_back_when_no_idle_cut_exists(synth_mod):
         ctx.batch_process_ptr(data.data_ptr(), stride, L, 0, want_scores=False)
         ctx.batch_sync()
         rep = ctx.batch_ls_report()
-        assert rep["verified"] == 0, rep
+        assert rep["verified"] == 0 and rep["gave_up"] == 1, rep    # (1: no trace could be cut)
         w1, r1, _ = ctx.batch_windows()
         assert w1.tobytes() == w0.tobytes() and r1.tobytes() == r0.tobytes() and ctx.batch_stats().tobytes() == st0
     finally:

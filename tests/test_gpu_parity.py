@@ -229,14 +229,14 @@ def test_fused_front_end_equals_stage_kernels(gpu_ctx, oracle_mod, synth_mod):
         st2 = gpu_ctx.batch_stats()
         assert w1.tobytes() == w2.tobytes() and r1.tobytes() == r2.tobytes() and s1.tobytes() == s2.tobytes()
         assert st1.tobytes() == st2.tobytes()
-        # third front end: the long-stream one (traces cut along time, units scanned concurrently, accepted only when
-        # every unit started from its predecessor's exact end state)
+        # third front end: the long-stream one (traces cut along time, all pieces processed at once, accepted only when
+        # every piece's run is exact or provably covers its true start value)
         gpu_ctx.batch_set_long_stream(2)
         gpu_ctx.batch_process_ptr(dev.data_ptr(), stride, L, 0, want_scores=True)
         gpu_ctx.batch_sync()
         gpu_ctx.batch_set_long_stream(1)
         rep = gpu_ctx.batch_ls_report()
-        assert rep["verified"] == 1 and rep["units"] > B, rep
+        assert rep["verified"] == 1 and rep["pieces"] > B, rep
         w3, r3, s3 = gpu_ctx.batch_windows(want_scores=True)
         assert w1.tobytes() == w3.tobytes() and r1.tobytes() == r3.tobytes() and s1.tobytes() == s3.tobytes()
         assert st1.tobytes() == gpu_ctx.batch_stats().tobytes()

@@ -429,7 +429,7 @@ def test_long_stream_front_end_ragged_batch_and_limits(oracle_mod, synth_mod):
         ctx.batch_process_ptr(dev.data_ptr(), stride, L, d_lens.data_ptr(), want_scores=True)
         ctx.batch_sync()
         rep = ctx.batch_ls_report()
-        assert rep["verified"] == 1 and rep["units"] > 4, rep
+        assert rep["verified"] == 1 and rep["pieces"] > 4, rep
         w, r, s = ctx.batch_windows(want_scores=True)
         st = ctx.batch_stats()
         cfg = oracle_mod.config(fixed_q=2, max_num_queries=20)

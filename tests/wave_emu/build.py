@@ -11,7 +11,8 @@ OUT = os.path.join(HERE, "librfid_wave_emu.so")
 
 def build(force: bool = False) -> str:
     srcs = [os.path.join(HERE, "emu_driver.cpp"), os.path.join(HERE, "rfid_device_env.h"),
-            os.path.join(CSRC, "rfid_kernels.hpp"), os.path.join(CSRC, "rfid_host_math.h"),
+            os.path.join(CSRC, "rfid_kernels.hpp"), os.path.join(CSRC, "rfid_ls2.hpp"), os.path.join(CSRC, "rfid_ls2_enqueue.hpp"),
+            os.path.join(CSRC, "rfid_host_math.h"),
             os.path.join(CSRC, "rfid_gen2_host.h"),
             os.path.join(ROOT, "include", "rfid_mi355x.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(s) <= os.path.getmtime(OUT) for s in srcs):

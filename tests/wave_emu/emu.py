@@ -64,6 +64,55 @@ def batch_process(raw: np.ndarray, lens=None, fixed_q=0, max_num_queries=1000, n
     return dict(windows=windows[:k], results=results[:k], scores=scores[:k], stats=stats, y=y)
 
 
+LS2_CTL_FIELDS = (["fail", "ok", "n_pieces"] + [f"avg_count{r}" for r in range(8)] + [f"fsm_count{r}" for r in range(8)] +
+                  [f"dc_count{r}" for r in range(8)] +
+                  ["avg_reruns", "fsm_reruns", "dc_reruns", "avg_rounds", "fsm_rounds", "dc_rounds", "n_units", "n_windows",
+                   "wb_clash"])
+
+
+def ls2_process(raw: np.ndarray, lens=None, fixed_q=0, max_num_queries=1000, number_unique_tags=100, min_piece=2048,
+                target=32768, state=None, hold_last=False, cuts=None, y_skip=0):
+    """batch_process() with the long-stream front end (rfid_ls2.hpp) in place of the sequential gate scan.
+    -> dict(windows, results, scores, stats, ctl, ok[, consumed])"""
+    raw = np.ascontiguousarray(raw, dtype=np.complex64)
+    if raw.ndim == 1:
+        raw = raw[None, :]
+    B, L = raw.shape
+    stride = (L + 1) & ~1
+    buf = np.zeros(B * stride + 2, dtype=np.complex64)
+    off = (16 - buf.ctypes.data % 16) % 16 // 8
+    view = buf[off:off + B * stride].reshape(B, stride)
+    view[:, :L] = raw
+    cap = B * (L // 5 // 347 + 4)
+    windows = np.zeros(cap, dtype=capi.WINDOW_DTYPE)
+    results = np.zeros(cap, dtype=capi.RESULT_DTYPE)
+    scores = np.zeros(cap, dtype=capi.SCORES_DTYPE)
+    stats = np.zeros(B, dtype=capi.STATS_DTYPE)
+    n = C.c_long(0)
+    lens_arr = None
+    if lens is not None:
+        lens_arr = np.ascontiguousarray(lens, dtype=np.int64)
+    nw = lib().emu_ls2_ctl_words()
+    ctl = np.zeros(nw, dtype=np.int32)
+    consumed = np.zeros(1, dtype=np.int32)
+    pcs = np.full((4096, 8), -1, dtype=np.int32)
+    cuts_arr = None if cuts is None else np.ascontiguousarray(cuts, dtype=np.int32)
+    ok = lib().emu_ls2_process(
+        C.c_void_p(view.ctypes.data), B, C.c_long(stride), C.c_long(L),
+        C.c_void_p(lens_arr.ctypes.data) if lens_arr is not None else None,
+        fixed_q, max_num_queries, number_unique_tags,
+        C.c_void_p(windows.ctypes.data), C.c_void_p(results.ctypes.data), C.c_void_p(scores.ctypes.data),
+        C.c_long(cap), C.byref(n), C.c_void_p(stats.ctypes.data), int(min_piece), int(target),
+        C.c_void_p(ctl.ctypes.data), nw,
+        C.c_void_p(state.ctypes.data) if state is not None else None, 1 if hold_last else 0, C.c_void_p(consumed.ctypes.data),
+        C.c_void_p(pcs.ctypes.data), len(pcs) - 1,
+        C.c_void_p(cuts_arr.ctypes.data) if cuts_arr is not None else None, 0 if cuts_arr is None else len(cuts_arr), int(y_skip))
+    k = n.value
+    npc = int(np.argmax(pcs[:, 0] < 0)) if (pcs[:, 0] < 0).any() else len(pcs)
+    return dict(windows=windows[:k], results=results[:k], scores=scores[:k], stats=stats, ok=int(ok),
+                ctl=dict(zip(LS2_CTL_FIELDS, ctl.tolist())), consumed=int(consumed[0]), pieces=pcs[:npc].copy())
+
+
 class GateStream:
     def __init__(self):
         self.state = np.zeros(lib().emu_gate_state_size(), dtype=np.uint8)
@@ -85,20 +134,14 @@ def decode_one(win: np.ndarray, type_: int):
     return res[0], sc[0]
 
 
-def ls_dc_check(y: np.ndarray, dc_re0: float, dc_im0: float):
-    """-> (mismatching words, windows): ls_dc_kernel replaying a unit against the full gate scan from the same dc_est start"""
-    y = np.ascontiguousarray(y, dtype=np.complex64)
-    nw = C.c_int(0)
-    bad = lib().emu_ls_dc_check(C.c_void_p(y.ctypes.data), len(y), C.c_float(dc_re0), C.c_float(dc_im0), C.byref(nw))
-    return bad, nw.value
-
-
-def ls_avg_check(y: np.ndarray, start: float) -> np.ndarray:
-    """-> [end computed, end from the addend cache, end from the cache for start + 1 ulp, end computed for start + 1 ulp]"""
-    y = np.ascontiguousarray(y, dtype=np.complex64)
-    out = np.zeros(4, dtype=np.float32)
-    lib().emu_ls_avg_check(C.c_void_p(y.ctypes.data), len(y), C.c_float(start), C.c_void_p(out.ctypes.data))
-    return out
+def chain_scan2(x, ca, cb):
+    """-> (sums from carry ca, sums from carry cb, scanned): chain_add_auto2 on one 64-sample step"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    oa = np.zeros(64, dtype=np.float32); ob = np.zeros(64, dtype=np.float32)
+    sc = C.c_int(0)
+    lib().emu_chain_scan2(C.c_void_p(x.ctypes.data), C.c_float(ca), C.c_float(cb), C.c_void_p(oa.ctypes.data),
+                          C.c_void_p(ob.ctypes.data), C.byref(sc))
+    return oa, ob, bool(sc.value)
 
 
 def mf_stream(staging: np.ndarray, in_off: int, n_out: int) -> np.ndarray:

@@ -15,6 +15,9 @@
 #include "rfid_host_math.h"
 #include "rfid_kernels.hpp"
 #include "rfid_gen2_host.h"
+#define LS2_LAUNCH(kernel, gx, gy, block, args) \
+  emu::launch(emu::Idx3{(unsigned)(gx), (unsigned)(gy), 1}, emu::Idx3{(unsigned)(block), 1, 1}, [&]() { rfidk::kernel(args); })
+#include "rfid_ls2_enqueue.hpp"
 
 namespace emu {
 
@@ -188,81 +191,125 @@ int emu_batch_process(const float *raw, int B, long stride, long n_raw, const in
   return 0;
 }
 
-// Long-stream building blocks on ONE unit (the whole of y): a full gate scan from dc_est = (0, 0) that records the closed
-// samples of every step; a full scan from dc_est = (dc_re0, dc_im0); and ls_dc_kernel replaying the recorded masks from
-// that same start.  The two last must agree bit for bit: dc_est and the dc ring at the end, every window record.
-// Returns the number of mismatching words (0 = equal); *n_windows = windows of the unit.
-int emu_ls_dc_check(const float *y_in, int n, float dc_re0, float dc_im0, int *n_windows) {
-  const float2 *y = reinterpret_cast<const float2 *>(y_in);
-  const int uwmax = n / (RN16_WIN + T1_SAMPLES + 1) + 2, steps = (n + 63) / 64;
-  std::vector<GateState> tmpl(1), state(3);
-  memset(tmpl.data(), 0, sizeof(GateState));
-  memset(state.data(), 0, sizeof(GateState) * 3);
-  std::vector<rfid_window> uw((size_t)3 * uwmax);
-  memset(uw.data(), 0, sizeof(rfid_window) * uw.size());
-  std::vector<int> uwc(3, 0);
-  std::vector<uint64_t> rec((size_t)steps, ~0ull);
-  std::vector<int> heads((size_t)3 * LS_HEAD_WORDS, 0);
-  GateUnit un[3];
-  for (int r = 0; r < 3; ++r) { un[r].stream = 0; un[r].pos0 = 0; un[r].len = n; un[r].row = r; }
-  for (int r = 1; r < 3; ++r) { memcpy(&heads[(size_t)r * LS_HEAD_WORDS + 1], &dc_re0, 4); memcpy(&heads[(size_t)r * LS_HEAD_WORDS + 2], &dc_im0, 4); }
-  state[1].dc_re = dc_re0; state[1].dc_im = dc_im0;
-  GateArgs ga = {};
-  ga.y = y; ga.y_stride = n; ga.n_dec = n; ga.lens = nullptr; ga.pos0 = 0; ga.chunk_len = n; ga.state = state.data();
-  ga.n_streams = 1; ga.wtab = uw.data(); ga.wmax = uwmax; ga.wcount = uwc.data(); ga.mode = 0;
-  ga.rec = rec.data(); ga.rec_stride = steps; ga.rec_mod = 1;
-  for (int r = 0; r < 2; ++r) {   // row 0: the recording scan; row 1: the full scan from the other start
-    ga.units = &un[r];
-    emu::launch(emu::Idx3{1, 1, 1}, emu::Idx3{GATE_THREADS, 1, 1}, [&]() { gate_scan_kernel(ga); });
-  }
-  LsDcArgs da;
-  da.y = y; da.y_stride = n; da.runs = &un[2]; da.n_runs = 1; da.n_units = 1; da.tmpl = tmpl.data(); da.heads = heads.data();
-  da.state = state.data(); da.rec = rec.data(); da.rec_stride = steps; da.uwtab = uw.data(); da.uwcount = uwc.data(); da.uwmax = uwmax;
-  emu::launch(emu::Idx3{1, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { ls_dc_kernel(da); });
-  int bad = 0;
-  bad += memcmp(&state[1].dc_re, &state[2].dc_re, 4) != 0;
-  bad += memcmp(&state[1].dc_im, &state[2].dc_im, 4) != 0;
-  bad += state[1].dc_index != state[2].dc_index;
-  bad += memcmp(state[1].dcr_re, state[2].dcr_re, sizeof(state[1].dcr_re)) != 0;
-  bad += memcmp(state[1].dcr_im, state[2].dcr_im, sizeof(state[1].dcr_im)) != 0;
-  bad += uwc[1] != uwc[2] || uwc[0] != uwc[1];
-  const int k = uwc[1] < uwmax ? uwc[1] : uwmax;
-  for (int i = 0; i < k; ++i) {
-    const rfid_window &a = uw[(size_t)uwmax + i], &b = uw[(size_t)2 * uwmax + i], &c0 = uw[(size_t)i];
-    bad += a.start != b.start || a.type != b.type || a.seq != b.seq || memcmp(&a.dc_re, &b.dc_re, 4) != 0 || memcmp(&a.dc_im, &b.dc_im, 4) != 0;
-    bad += a.start != c0.start || a.type != c0.type;   // (the start of dc_est never moves a window)
-  }
-  *n_windows = k;
-  return bad;
-}
+// The long-stream front end (rfid_ls2.hpp) in place of the sequential gate scan: mf -> pieces / avg_ampl / state machine /
+// dc_est / windows (the launch list of rfid_ls2_enqueue.hpp, as the library enqueues it) -> the sequential scan as the
+// skipped-or-not fallback -> decode -> stats.  min_piece / target shrink the pieces so that small traces are cut many
+// times.  ctl_out: the Ls2Ctl block as ints.  carry / hold_last = the streaming form (state_blob: GateState of trace 0 in
+// and out, consumed[0] = first unprocessed sample).
+int emu_ls2_process(const float *raw, int B, long stride, long n_raw, const int64_t *lens, int fixed_q,
+                    int max_num_queries, int number_unique_tags, rfid_window *windows,
+                    rfid_decode_result *results, rfid_scores *scores, long cap, long *n_windows,
+                    rfid_stream_stats *stats, int min_piece, int target, int *ctl_out, int ctl_cap,
+                    void *state_blob, int hold_last, int *consumed_out, int *pieces_out, int pieces_cap,
+                    const int *cuts, int n_cuts, int y_skip) {
+  const long n_dec_all = n_raw / DECIM;
+  const long n_dec = n_dec_all - y_skip;   // (y_skip: leading outputs that only exist to give the filter its history)
+  long y_stride = (n_dec_all + 1) & ~1L;
+  if (y_stride < 2) y_stride = 2;
+  std::vector<float4> ybuf((size_t)(y_stride * B / 2 + 2));
+  float2 *y0 = reinterpret_cast<float2 *>(ybuf.data());
+  float2 *y = y0 + y_skip;
+  const int wmax = (int)(n_dec / (RN16_WIN + T1_SAMPLES + 1) + 2);
+  const int flat_cap = wmax * B;
+  std::vector<GateState> gstate((size_t)B);
+  memset(gstate.data(), 0, sizeof(GateState) * (size_t)B);
+  if (state_blob) memcpy(gstate.data(), state_blob, sizeof(GateState));
+  std::vector<rfid_window> wtab((size_t)flat_cap), flat((size_t)flat_cap * 2);
+  std::vector<int> wcount((size_t)B, 0);
+  int flat_count[2] = {0, 0};
+  std::vector<rfid_decode_result> res((size_t)flat_cap);
+  std::vector<rfid_scores> sc((size_t)flat_cap);
+  memset(sc.data(), 0, sizeof(rfid_scores) * (size_t)flat_cap);
 
-// ls_avg_kernel on ONE unit (the whole of y, fresh amplitude ring): the first pass computes the addends from the samples
-// and caches them, a later pass re-adds the cached addends.  out[0] / out[1] = avg_ampl at the end of the unit from `start`
-// computed / from the cache; out[2] = from the cache with start + 1 ulp (variant B), out[3] = computed with start + 1 ulp.
-int emu_ls_avg_check(const float *y_in, int n, float start, float *out) {
-  const float2 *y = reinterpret_cast<const float2 *>(y_in);
-  uint32_t sb;
-  memcpy(&sb, &start, 4);
-  sb += 1;
-  float start_b;
-  memcpy(&start_b, &sb, 4);
-  float st[2] = {start, start_b};
-  float end[2] = {0.0f, 0.0f};
-  std::vector<float> cache((size_t)n, -1.0f);
-  GateUnit un[2];
-  for (int r = 0; r < 2; ++r) { un[r].stream = 0; un[r].pos0 = 0; un[r].len = n; un[r].row = r; }
-  LsAvgArgs a;
-  a.y = y; a.y_stride = n; a.units = un; a.n_runs = 2; a.start = st; a.end = end; a.carry = nullptr;
-  a.dcache = cache.data(); a.n_units = 1;
-  a.cache_mode = 1;
-  emu::launch(emu::Idx3{2, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { ls_avg_kernel(a); });
-  out[0] = end[0]; out[3] = end[1];
-  end[0] = end[1] = 0.0f;
-  a.cache_mode = 2;
-  emu::launch(emu::Idx3{2, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { ls_avg_kernel(a); });
-  out[1] = end[0]; out[2] = end[1];
-  return 0;
+  MfArgs ma;
+  ma.x = reinterpret_cast<const float2 *>(raw); ma.x_stride = stride; ma.n_raw = n_raw; ma.lens = lens;
+  ma.n_out = n_dec_all; ma.in_off = -(NTAPS - 1);
+  ma.vec_ok = ((stride & 1) == 0 && (((uintptr_t)raw) & 15) == 0) ? 1 : 0;
+  ma.y = y0; ma.y_stride = y_stride; ma.tile0 = 0; ma.stream0 = 0;
+  const long tiles = (n_dec_all + MF_TILE - 1) / MF_TILE;
+  if (tiles > 0)
+    emu::launch(emu::Idx3{(unsigned)tiles, (unsigned)B, 1}, emu::Idx3{MF_THREADS, 1, 1}, [&]() { mf_boxcar25_decim5_kernel(ma); });
+
+  const Ls2Geometry geo = ls2_geometry(B, n_dec, min_piece, target);
+  std::vector<char> ws;
+  Ls2Ctl ctl_host;
+  memset(&ctl_host, 0, sizeof(ctl_host));
+  int ok = 0;
+  if (geo.P > 0) {
+    const Ls2Layout L = ls2_layout(geo, B, y_stride);
+    ws.assign(L.total + 256, 0);
+    char *base = ws.data() + (256 - ((uintptr_t)ws.data() & 255));
+    Ls2Args a;
+    memset(&a, 0, sizeof(a));
+    a.y = y; a.y_stride = y_stride; a.lens = lens; a.n_dec = n_dec; a.n_streams = B;
+    ls2_bind(a, base, L, geo);
+    a.wtab = wtab.data(); a.wmax = wmax; a.wcount = wcount.data(); a.flat = flat.data(); a.flat_count = flat_count; a.flat_cap = flat_cap;
+    a.carry = state_blob ? gstate.data() : nullptr; a.carry_out = state_blob ? gstate.data() : nullptr;
+    a.hold_last = hold_last; a.force = state_blob ? 1 : 0;
+    if (cuts) {   // test hook: cut trace 0 at the given positions (ascending) instead of searching idle points
+      for (int i = 0; i < geo.NS; ++i) a.cut[i] = -1;
+      for (int k = 0; k < n_cuts && k + 1 < geo.max_b; ++k) a.cut[k + 1] = cuts[k];
+    }
+    ls2_enqueue(a, cuts == nullptr);
+    ctl_host = *a.ctl;
+    ok = a.ctl->ok;
+    if (consumed_out) consumed_out[0] = a.consumed[0];
+    if (pieces_out) {   // per piece in use: trace, pos0, len, true start of avg_ampl / dc_est (bit patterns), unit head
+      int k = 0;
+      for (int i = 0; i < geo.NS && k < pieces_cap; ++i) {
+        if (a.piece[i].len <= 0) continue;
+        int *o = pieces_out + 8 * k++;
+        const int h = a.fsm[i].unit;
+        o[0] = i / geo.max_b; o[1] = a.piece[i].pos0; o[2] = a.piece[i].len;
+        float f = ls2_from_ord(a.aT[i]); memcpy(&o[3], &f, 4);
+        f = ls2_from_ord(a.dT[2 * h]); memcpy(&o[4], &f, 4);
+        f = ls2_from_ord(a.dT[2 * h + 1]); memcpy(&o[5], &f, 4);
+        o[6] = h; o[7] = i;
+      }
+      if (k < pieces_cap) pieces_out[8 * k] = -1;
+    }
+  }
+  if (ctl_out) memcpy(ctl_out, &ctl_host, sizeof(int) * (size_t)((int)(sizeof(Ls2Ctl) / 4) < ctl_cap ? (int)(sizeof(Ls2Ctl) / 4) : ctl_cap));
+  if (!ok && !hold_last) {   // the fallback the library enqueues behind the front end (GateArgs::skip_if)
+    GateArgs ga = {};
+    ga.y = y; ga.y_stride = y_stride; ga.n_dec = n_dec; ga.lens = lens; ga.state = gstate.data(); ga.n_streams = B;
+    ga.wtab = wtab.data(); ga.wmax = wmax; ga.wcount = wcount.data(); ga.flat = flat.data();
+    ga.flat_count = flat_count; ga.flat_cap = flat_cap; ga.mode = 0; ga.pos0 = 0; ga.chunk_len = n_dec;
+    emu::launch(emu::Idx3{(unsigned)((B + GATE_STREAMS_PER_WG - 1) / GATE_STREAMS_PER_WG), 1, 1},
+                emu::Idx3{GATE_THREADS, 1, 1}, [&]() { gate_scan_kernel(ga); });
+  }
+  if (state_blob) memcpy(state_blob, gstate.data(), sizeof(GateState));
+
+  DecodeListArgs da;
+  da.y = y; da.y_stride = y_stride; da.cap = flat_cap; da.res = res.data(); da.scores = sc.data(); da.wmax = wmax;
+  rfidh::t_candidates(da.t_cand, 400000);
+  da.list = flat.data() + flat_cap; da.count = &flat_count[1];
+  emu::launch(emu::Idx3{2, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { decode_epc3_kernel(da); });
+  da.list = flat.data(); da.count = &flat_count[0];
+  emu::launch(emu::Idx3{2, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { decode_rn16x4_kernel(da); });
+
+  StatsArgs sa;
+  sa.res = res.data(); sa.wcount = wcount.data(); sa.wmax = wmax; sa.n_streams = B;
+  sa.max_slot_number = 1 << fixed_q; sa.max_num_queries = max_num_queries;
+  sa.number_unique_tags = number_unique_tags; sa.out = stats;
+  emu::launch(emu::Idx3{(unsigned)B, 1, 1}, emu::Idx3{256, 1, 1}, [&]() { stream_stats_kernel(sa); });
+
+  long total = 0;
+  for (int s = 0; s < B; ++s) {
+    for (int k = 0; k < wcount[(size_t)s]; ++k) {
+      if (total < cap) {
+        const size_t off = (size_t)s * (size_t)wmax + (size_t)k;
+        if (windows) windows[total] = wtab[off];
+        if (results) results[total] = res[off];
+        if (scores) scores[total] = sc[off];
+      }
+      total++;
+    }
+  }
+  *n_windows = total;
+  return ok;
 }
+int emu_ls2_ctl_words(void) { return (int)(sizeof(Ls2Ctl) / 4); }
 
 // gate_scan_kernel in streaming mode (mode 1) on one call's worth of samples.
 // seek_type: -1 none, 0 SEEK_RN16, 1 SEEK_EPC applied before the scan (gate_impl.cc:112-123).
@@ -338,6 +385,21 @@ int emu_chain_scan(const float *x, float carry, float *chain_out, float *scan_ou
   a.x = x; a.num = z.data(); a.den = z.data(); a.carry = carry; a.chain_out = chain_out; a.div_out = o.data();
   a.hyp_out = o.data() + 64; a.shr_out = o.data() + 128; a.scan_out = scan_out;
   emu::launch(emu::Idx3{1, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { selftest_kernel(a); });
+  return 0;
+}
+
+// chain_add_auto2 (long-stream front end: the in-order sums from two carries at once) on one step; scanned[0] = 1 when the
+// shared integer-scan form applied
+int emu_chain_scan2(const float *x, float ca, float cb, float *out_a, float *out_b, int *scanned) {
+  struct Args { const float *x; float ca, cb; float *oa, *ob; int *sc; } a = {x, ca, cb, out_a, out_b, scanned};
+  emu::launch(emu::Idx3{1, 1, 1}, emu::Idx3{64, 1, 1}, [&]() {
+    const int lane = wv::lane_id();
+    float va, vb;
+    const bool ok = chain_add_scan2(a.ca, a.cb, a.x[lane], lane, va, vb);
+    if (lane == 0) a.sc[0] = ok ? 1 : 0;
+    chain_add_auto2(a.ca, a.cb, a.x[lane], lane, va, vb);
+    a.oa[lane] = va; a.ob[lane] = vb;
+  });
   return 0;
 }
 
