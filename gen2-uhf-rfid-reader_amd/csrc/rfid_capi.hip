@@ -286,6 +286,40 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
   c->d_ls2_ctl = a.ctl;
   c->ls2_P = geo.P;
   *enqueued = 1;
+  if (getenv("RFID_LS_DEBUG")) {   // what the rounds did: per-round counts, margins against the shifts they had to cover
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const Ls2Ctl &k = *c->ls2_host;
+    fprintf(stderr, "[ls2] pieces %d P %d fail %d ok %d | avg:", k.n_pieces, geo.P, k.fail, k.ok);
+    for (int r = 0; r <= LS2_AVG_ROUNDS; ++r) fprintf(stderr, " %d", k.avg_count[r]);
+    fprintf(stderr, " | fsm:");
+    for (int r = 0; r <= LS2_FSM_ROUNDS; ++r) fprintf(stderr, " %d", k.fsm_count[r]);
+    fprintf(stderr, " | dc:");
+    for (int r = 0; r <= LS2_DC_ROUNDS; ++r) fprintf(stderr, " %d", k.dc_count[r]);
+    fprintf(stderr, " | units %d windows %d\n", k.n_units, k.n_windows);
+    std::vector<Ls2AvgRun> ar((size_t)geo.NS);
+    std::vector<int> aT((size_t)geo.NS);
+    std::vector<Ls2Piece> pc((size_t)geo.NS);
+    HIPCHK(c, hipMemcpy(ar.data(), a.arun, sizeof(Ls2AvgRun) * ar.size(), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(aT.data(), a.aT, sizeof(int) * aT.size(), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(pc.data(), a.piece, sizeof(Ls2Piece) * pc.size(), hipMemcpyDeviceToHost));
+    long hist_m[8] = {0}, hist_d[8] = {0};
+    int shown = 0;
+    for (int i = 0; i < geo.NS; ++i) {
+      if (pc[(size_t)i].len <= 0) continue;
+      uint32_t u; memcpy(&u, &ar[(size_t)i].s, 4);
+      const long D = labs((long)aT[(size_t)i] - (long)(int)u);
+      const int m = ar[(size_t)i].margin;
+      int bm = 0; for (long v = m; v > 0 && bm < 7; v >>= 3) bm++;
+      int bd = 0; for (long v = D; v > 0 && bd < 7; v >>= 3) bd++;
+      hist_m[bm]++; hist_d[bd]++;
+      if (shown < 12 && (i % 2500) == 1) { fprintf(stderr, "[ls2]   piece %d pos %d len %d s %.9g margin %d |D| %ld\n", i, pc[(size_t)i].pos0, pc[(size_t)i].len, ar[(size_t)i].s, m, D); shown++; }
+    }
+    fprintf(stderr, "[ls2] margin histogram (0, <8, <64, <512, <4096, <32768, <262144, more):");
+    for (int b = 0; b < 8; ++b) fprintf(stderr, " %ld", hist_m[b]);
+    fprintf(stderr, "\n[ls2] |D| histogram (same bins):");
+    for (int b = 0; b < 8; ++b) fprintf(stderr, " %ld", hist_d[b]);
+    fprintf(stderr, "\n");
+  }
   return RFID_OK;
 }
 }  // namespace

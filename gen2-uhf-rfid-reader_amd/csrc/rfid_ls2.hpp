@@ -42,10 +42,12 @@ namespace rfidk {
 constexpr int LS2_WBUCKET = 320;      // two gate openings are at least RN16_WIN + T1_SAMPLES = 346 samples apart:
                                       // window records live in a per-trace table indexed by start / LS2_WBUCKET
 static_assert(LS2_WBUCKET <= RN16_WIN + T1_SAMPLES, "one window per bucket");
-constexpr int LS2_AVG_ROUNDS = 4;     // re-run rounds after the first pass, per recurrence
+constexpr int LS2_AVG_ROUNDS = 9;     // re-run rounds after the first pass, per recurrence (a round without work costs two empty launches)
 constexpr int LS2_FSM_ROUNDS = 3;
-constexpr int LS2_DC_ROUNDS = 4;
-constexpr int LS2_MAXR = 8;
+constexpr int LS2_DC_ROUNDS = 7;
+constexpr int LS2_MAXR = 12;
+constexpr int LS2_WIDE_BELOW = 64;    // a piece whose margin is below this is re-run from six neighbouring start values at once
+constexpr int LS2_WIDE_LO = -2, LS2_WIDE_HI = 3;
 constexpr int LS2_CHAIN_THREADS = 1024;
 
 struct Ls2Piece { int pos0, len; };   // len 0: slot not in use
@@ -65,7 +67,13 @@ struct Ls2Ctl {   // control block in HBM, zeroed before every pass
   int reserved_[3];
 };
 
-struct Ls2AvgRun { float s, eA, eB; int margin; };        // start used, end from it, end from s + 1 ulp, margin (ulps of s)
+struct Ls2AvgRun {   // a piece's latest run
+  float s, eA, eB;   // start used, end from it, end from s + 1 ulp
+  int margin;        // (ulps of s)
+  int wide;          // in: run wide next time;  out (bit 1): ew[] holds the ends from s - 2, s - 1, s + 2, s + 3 ulps
+  float ew[4];
+  int pad_[3];
+};
 struct Ls2DcRun { float s[2], eA[2], eB[2]; int margin[2]; };
 struct Ls2Fsm {   // per slot
   int head;       // the piece starts a unit (scanned from the idle state, or from the trace's start state)
@@ -83,6 +91,8 @@ struct Ls2Win {   // one gate opening
   float a_re, a_im, b_re, b_im;   // dc_est at the opening from the unit's run: variant A, variant B
 };
 
+struct Ls2Aff { int64_t c0, c1; };
+
 struct Ls2Args {
   const float2 *y; int64_t y_stride;
   const int64_t *lens; int64_t n_dec; int n_streams;
@@ -96,11 +106,12 @@ struct Ls2Args {
   int *openinfo;                // [n_streams][vstride]: lane | type << 8 of the step's opening, 0xff none
   int64_t vstride;
   Ls2AvgRun *arun; int *aT;     // [NS]; aT = true start of the piece (monotone integer image)
-  int *alist;                   // [LS2_MAXR][NS]
+  int *alist;                   // [2][NS]: the re-run list of chain round r at (r & 1)
+  Ls2Aff *aover;                // [NS] chain scratch: a piece's function with an exact candidate end put in
   Ls2Fsm *fsm;                  // [NS]
   Ls2Win *wb; int64_t wb_stride;   // [n_streams][wb_stride]
   Ls2DcRun *drun; int *dT;      // [NS], [NS][2]
-  int *dlist;                   // [LS2_MAXR][NS]
+  int *dlist;                   // [2][NS]
   int *seq0;                    // [NS] complete windows of the trace before the piece
   rfid_window *wtab; int wmax; int *wcount;
   rfid_window *flat; int *flat_count; int flat_cap;
@@ -279,6 +290,14 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
   } else {
     sA = wv::uniform(a.arun[i].s);
   }
+  // a piece that passes so close to a power of two that hardly any shift is provable is run from six neighbouring start
+  // values at once (s - 2 .. s + 3 ulps): their ends are exact, not predicted, whatever the chain turns up among them
+  const bool wide = !FIRST && (wv::uniform(a.arun[i].wide) & 1) != 0;
+  float wv0 = 0.0f, wv1 = 0.0f, wv2 = 0.0f, wv3 = 0.0f;   // carries of s - 2, s - 1, s + 2, s + 3
+  if (wide) {
+    const int os = ls2_ord(sA);
+    wv0 = ls2_from_ord(os - 2); wv1 = ls2_from_ord(os - 1); wv2 = ls2_from_ord(os + 2); wv3 = ls2_from_ord(os + 3);
+  }
   const uint32_t sbA = wv::f2u(sA);
   const float sB = ls2_from_ord(ls2_ord(sA) + 1);
   const uint32_t sbB = wv::f2u(sB);
@@ -323,6 +342,12 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
         chain_add_auto2(avA, avB, d, lane, vA, vB);
         avA = wv::readlane(vA, 63);
         avB = wv::readlane(vB, 63);
+        if (wide) {
+          float t0, t1, t2, t3;
+          chain_add_auto2(wv0, wv1, d, lane, t0, t1);
+          chain_add_auto2(wv2, wv3, d, lane, t2, t3);
+          wv0 = wv::readlane(t0, 63); wv1 = wv::readlane(t1, 63); wv2 = wv::readlane(t2, 63); wv3 = wv::readlane(t3, 63);
+        }
         const float thresh = vA * THRESH_FRACTION;
         const uint64_t below = wv::ballot(valid && amp < thresh);
         const uint64_t above = wv::ballot(valid && amp > thresh);
@@ -351,6 +376,9 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
   if (lane == 0) {
     Ls2AvgRun r;
     r.s = sA; r.eA = avA; r.eB = avB; r.margin = marg;
+    r.wide = wide ? 2 : 0;
+    r.ew[0] = wv0; r.ew[1] = wv1; r.ew[2] = wv2; r.ew[3] = wv3;
+    r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
     a.arun[i] = r;
   }
 }
@@ -366,14 +394,13 @@ RFID_KERNEL(64) void ls2_avg_rerun_kernel(Ls2Args a) {
   const int NS = a.n_streams * a.max_b;
   const int cnt = wv::uniform(a.ctl->avg_count[a.round - 1]);
   const int lane = wv::lane_id();
-  const int *list = a.alist + (int64_t)(a.round - 1) * NS;
+  const int *list = a.alist + (int64_t)((a.round - 1) & 1) * NS;
   for (int r = (int)blockIdx.x; r < cnt; r += (int)gridDim.x) ls2_avg_piece<false>(a, wv::uniform(list[r]), lane);
 }
 
 // A piece's latest run as a function "true start -> true end", on the monotone integer image of binary32: T -> T + c[q],
 // q = parity of T (the run from s serves the starts s + even, the run from s + 1 ulp the starts s + odd).  Functions
 // of this form compose to the same form, so a trace's chain of pieces is ONE prefix scan.
-struct Ls2Aff { int64_t c0, c1; };
 RFID_DEVICE Ls2Aff ls2_compose(const Ls2Aff f, const Ls2Aff g) {   // f first, then g
   Ls2Aff r;
   r.c0 = f.c0 + ((f.c0 & 1) ? g.c1 : g.c0);
@@ -406,9 +433,18 @@ RFID_DEVICE Ls2Aff ls2_block_exscan(Ls2Aff mine, Ls2Aff *sh /* [2][LS2_CHAIN_THR
 }
 
 // one workgroup per trace: every piece's true start from the chain of the latest runs; what is not proven goes on the
-// re-run list of this round
+// re-run list of this round.  A run that was made from six neighbouring starts knows its end for each of them exactly;
+// when the chain lands on one of those, that end replaces the prediction and the scan is repeated (a few times at most:
+// such pieces are rare), so that no error is handed downstream.
+RFID_DEVICE bool ls2_wide_end(const Ls2AvgRun &ru, int64_t D, int64_t &end_ord) {   // exact end for true start s + D, if known
+  if (!(ru.wide & 2) || D < LS2_WIDE_LO || D > LS2_WIDE_HI) return false;
+  const float e = (D == 0) ? ru.eA : (D == 1) ? ru.eB : (D == -2) ? ru.ew[0] : (D == -1) ? ru.ew[1] : (D == 2) ? ru.ew[2] : ru.ew[3];
+  end_ord = ls2_ord(e);
+  return true;
+}
 RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_avg_chain_kernel(Ls2Args a) {
   RFID_SHARED Ls2Aff sh[2 * LS2_CHAIN_THREADS];
+  RFID_SHARED int sh_changed[2];
   Ls2Ctl *ctl = a.ctl;
   const int r = a.round;
   const int tid = (int)threadIdx.x, s = (int)blockIdx.x;
@@ -418,31 +454,61 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_avg_chain_kernel(Ls2Args a) {
   const int per = (a.max_b + LS2_CHAIN_THREADS - 1) / LS2_CHAIN_THREADS;
   const int j0 = tid * per, j1 = (j0 + per < a.max_b) ? (j0 + per) : a.max_b;
   const int base = s * a.max_b;
-  Ls2Aff agg; agg.c0 = 0; agg.c1 = 0;
-  for (int j = j0; j < j1; ++j) {
-    if (a.piece[base + j].len <= 0) continue;
-    const Ls2AvgRun ru = a.arun[base + j];
-    agg = ls2_compose(agg, ls2_aff(ru.s, ru.eA, ru.eB));
+  const bool any = a.piece[base].len > 0;                                  // (else: an empty trace)
+  const int64_t T0 = any ? (int64_t)ls2_ord(a.arun[base].s) : 0;           // the trace's first piece starts from the exact value
+  for (int j = j0; j < j1; ++j)
+    if (a.piece[base + j].len > 0) { const Ls2AvgRun ru = a.arun[base + j]; a.aover[base + j] = ls2_aff(ru.s, ru.eA, ru.eB); }
+  int64_t Tfirst = 0;
+  for (int it = 0; it < 4; ++it) {
+    Ls2Aff agg; agg.c0 = 0; agg.c1 = 0;
+    for (int j = j0; j < j1; ++j)
+      if (a.piece[base + j].len > 0) agg = ls2_compose(agg, a.aover[base + j]);
+    if (tid < 2) sh_changed[tid] = 0;
+    const Ls2Aff ex = ls2_block_exscan(agg, sh, tid);   // (its barriers also publish sh_changed)
+    Tfirst = T0 + ((T0 & 1) ? ex.c1 : ex.c0);
+    int64_t T = Tfirst;
+    bool changed = false;
+    for (int j = j0; j < j1; ++j) {
+      const int i = base + j;
+      if (a.piece[i].len <= 0) continue;
+      const Ls2AvgRun ru = a.arun[i];
+      Ls2Aff f = a.aover[i];
+      int64_t e_exact;
+      if (ls2_wide_end(ru, T - (int64_t)ls2_ord(ru.s), e_exact)) {
+        const int64_t want = e_exact - T;
+        int64_t &cq = (T & 1) ? f.c1 : f.c0;
+        if (cq != want) { cq = want; a.aover[i] = f; changed = true; }
+      }
+      T += (T & 1) ? f.c1 : f.c0;
+    }
+    if (changed) sh_changed[it & 1] = 1;
+    wv::block_sync();
+    const bool again = sh_changed[it & 1] != 0;
+    wv::block_sync();
+    if (!again) break;
   }
-  const Ls2Aff ex = ls2_block_exscan(agg, sh, tid);
-  if (a.piece[base].len <= 0) return;                 // empty trace
-  const int64_t T0 = ls2_ord(a.arun[base].s);         // the trace's first piece starts from the exact value
-  int64_t T = T0 + ((T0 & 1) ? ex.c1 : ex.c0);
+  if (!any) return;
+  int64_t T = Tfirst;
   int n_rerun = 0;
   for (int j = j0; j < j1; ++j) {
     const int i = base + j;
     if (a.piece[i].len <= 0) continue;
     const Ls2AvgRun ru = a.arun[i];
+    const Ls2Aff f = a.aover[i];
     const int64_t D = T - (int64_t)ls2_ord(ru.s);
     const int64_t aD = (D < 0) ? -D : D;
     a.aT[i] = (int)T;
+    // settled: the run started from the true value, or provably covers it (its votes included).  Anything else is run
+    // again from the true (or predicted) start -- also a piece whose END is known exactly from a neighbouring start: its
+    // votes are not.
     if (D != 0 && !(aD + 4 <= (int64_t)ru.margin)) {
-      a.arun[i].s = ls2_from_ord((int)T);
+      Ls2AvgRun *w = a.arun + i;
+      w->s = ls2_from_ord((int)T);
+      w->wide = (ru.margin < LS2_WIDE_BELOW || r >= 3) ? 1 : 0;
       const int k = wv::atomic_add(&ctl->avg_count[r], 1);
-      a.alist[(int64_t)r * NS + k] = i;
+      a.alist[(int64_t)(r & 1) * NS + k] = i;
       n_rerun++;
     }
-    const Ls2Aff f = ls2_aff(ru.s, ru.eA, ru.eB);
     T += (T & 1) ? f.c1 : f.c0;
   }
   if (n_rerun) wv::atomic_add(&ctl->avg_reruns, n_rerun);
@@ -738,7 +804,7 @@ RFID_KERNEL(64) void ls2_dc_rerun_kernel(Ls2Args a) {
   const int NS = a.n_streams * a.max_b;
   const int cnt = wv::uniform(a.ctl->dc_count[a.round - 1]);
   const int lane = wv::lane_id();
-  const int *list = a.dlist + (int64_t)(a.round - 1) * NS;
+  const int *list = a.dlist + (int64_t)((a.round - 1) & 1) * NS;
   for (int r = (int)blockIdx.x; r < cnt; r += (int)gridDim.x) ls2_dc_unit(a, wv::uniform(list[r]), false, lane, lds_dc, lds_tmp);
 }
 
@@ -784,7 +850,7 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_dc_chain_kernel(Ls2Args a) {
       a.drun[i].s[0] = ls2_from_ord((int)T[0]);
       a.drun[i].s[1] = ls2_from_ord((int)T[1]);
       const int k = wv::atomic_add(&ctl->dc_count[r], 1);
-      a.dlist[(int64_t)r * NS + k] = i;
+      a.dlist[(int64_t)(r & 1) * NS + k] = i;
       n_rerun++;
     }
     for (int c = 0; c < 2; ++c) {

@@ -35,7 +35,7 @@ inline Ls2Geometry ls2_geometry(int n_streams, int64_t n_dec, int min_piece = LS
 
 // work space: one allocation, carved up here (offsets in bytes, 256-byte aligned)
 struct Ls2Layout {
-  size_t cut, piece, nextv, prevv, amp, dadd, votes, closed, openinfo, arun, aT, alist, fsm, wb, drun, dT, dlist, seq0, ctl, consumed, total;
+  size_t cut, piece, nextv, prevv, amp, dadd, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, drun, dT, dlist, seq0, ctl, consumed, total;
 };
 inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_stride) {
   Ls2Layout L;
@@ -53,12 +53,13 @@ inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_strid
   L.openinfo = take(sizeof(int) * B * (size_t)g.vstride);
   L.arun = take(sizeof(Ls2AvgRun) * NS);
   L.aT = take(sizeof(int) * NS);
-  L.alist = take(sizeof(int) * LS2_MAXR * NS);
+  L.alist = take(sizeof(int) * 2 * NS);
+  L.aover = take(sizeof(Ls2Aff) * NS);
   L.fsm = take(sizeof(Ls2Fsm) * NS);
   L.wb = take(sizeof(Ls2Win) * B * (size_t)g.wb_stride);
   L.drun = take(sizeof(Ls2DcRun) * NS);
   L.dT = take(sizeof(int) * 2 * NS);
-  L.dlist = take(sizeof(int) * LS2_MAXR * NS);
+  L.dlist = take(sizeof(int) * 2 * NS);
   L.seq0 = take(sizeof(int) * NS);
   L.ctl = take(sizeof(Ls2Ctl));
   L.consumed = take(sizeof(int) * B);
@@ -71,7 +72,7 @@ inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geomet
   a.nextv = (int *)(base + L.nextv); a.prevv = (int *)(base + L.prevv);
   a.amp = (float *)(base + L.amp); a.dadd = (float *)(base + L.dadd);
   a.votes = (uint64_t *)(base + L.votes); a.closed = (uint64_t *)(base + L.closed); a.openinfo = (int *)(base + L.openinfo);
-  a.arun = (Ls2AvgRun *)(base + L.arun); a.aT = (int *)(base + L.aT); a.alist = (int *)(base + L.alist);
+  a.arun = (Ls2AvgRun *)(base + L.arun); a.aT = (int *)(base + L.aT); a.alist = (int *)(base + L.alist); a.aover = (Ls2Aff *)(base + L.aover);
   a.fsm = (Ls2Fsm *)(base + L.fsm); a.wb = (Ls2Win *)(base + L.wb);
   a.drun = (Ls2DcRun *)(base + L.drun); a.dT = (int *)(base + L.dT); a.dlist = (int *)(base + L.dlist);
   a.seq0 = (int *)(base + L.seq0); a.ctl = (Ls2Ctl *)(base + L.ctl); a.consumed = (int *)(base + L.consumed);

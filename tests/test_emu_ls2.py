@@ -76,7 +76,7 @@ def test_ls2_gives_up_on_a_carrier_at_a_power_of_two(emu_mod, oracle_mod, synth_
     t = synth_mod.make_trace(n_rounds=30, sigma=0.01, seed=5).samples
     t = (t * np.complex64(0.64)).astype(np.complex64)
     r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=0)
-    assert r["ctl"]["avg_count4"] > 0 and r["ctl"]["n_pieces"] > 3, r["ctl"]
+    assert r["ctl"]["avg_count9"] > 0 and r["ctl"]["n_pieces"] > 3, r["ctl"]
 
 
 def test_ls2_ragged_batch_collisions_and_limits(emu_mod, oracle_mod, synth_mod):

@@ -64,8 +64,8 @@ def batch_process(raw: np.ndarray, lens=None, fixed_q=0, max_num_queries=1000, n
     return dict(windows=windows[:k], results=results[:k], scores=scores[:k], stats=stats, y=y)
 
 
-LS2_CTL_FIELDS = (["fail", "ok", "n_pieces"] + [f"avg_count{r}" for r in range(8)] + [f"fsm_count{r}" for r in range(8)] +
-                  [f"dc_count{r}" for r in range(8)] +
+LS2_CTL_FIELDS = (["fail", "ok", "n_pieces"] + [f"avg_count{r}" for r in range(12)] + [f"fsm_count{r}" for r in range(12)] +
+                  [f"dc_count{r}" for r in range(12)] +
                   ["avg_reruns", "fsm_reruns", "dc_reruns", "avg_rounds", "fsm_rounds", "dc_rounds", "n_units", "n_windows",
                    "wb_clash"])
 
