@@ -30,7 +30,9 @@
 // the whole trajectory is shifted by exactly D -- end value, dc_est at every opening -- and, for avg_ampl, no
 // threshold vote changes as long as no |x| lies between the two thresholds.  The run records the smallest distance
 // of any partial sum from a power of two and of any |x| from its threshold, in units of u0: the MARGIN.  |D| + 4 <=
-// margin proves the shift (a few ulps of slack: variant B's trajectory may run 2 ulps off variant A's).  Odd D: the same from the run that started at s + 1 ulp (variant B).  A piece whose margin
+// margin proves the shift (a few ulps of slack: variant B's trajectory may run 2 ulps off variant A's) -- for the values
+// inside the piece; the chain of pieces is integer arithmetic on binary32 bit patterns, so a piece that ends in another
+// binade than it starts in only counts when run from its exact start.  Odd D: the same from the run that started at s + 1 ulp (variant B).  A piece whose margin
 // does not cover its D (it passes close to a power of two: a few per cent of the pieces) is simply run again from
 // its predicted start; the prediction is then verified, not assumed: the procedure ends when every piece's latest
 // run is exact (D = 0) or proven.  Nothing else is assumed about the data -- pathological input (partial sums
@@ -81,6 +83,7 @@ struct Ls2Fsm {   // per slot
   int gen;        // generation of the state-machine launch that last covered the piece
   int rerun;      // (head) scan again in the next round
   int nwin;       // complete windows opened in the piece
+  int nepc;       //   ... of them EPC windows
   int last_end;   // end of the last window opened in the unit up to and including this piece (INT_MIN: none)
   int st[6];      // (head) start state used: n_samples, signal_state, num_pulses, gate_open, n_to_ungate, wtype
   int en[6];      // state after the piece
@@ -112,7 +115,8 @@ struct Ls2Args {
   Ls2Win *wb; int64_t wb_stride;   // [n_streams][wb_stride]
   Ls2DcRun *drun; int *dT;      // [NS], [NS][2]
   int *dlist;                   // [2][NS]
-  int *seq0;                    // [NS] complete windows of the trace before the piece
+  int *seq0;                    // [NS][2] complete windows of the trace before the piece: all, EPC
+  int *flat_base;               // [n_streams][2] the trace's first place in the decoder's RN16 / EPC list
   rfid_window *wtab; int wmax; int *wcount;
   rfid_window *flat; int *flat_count; int flat_cap;
   Ls2Ctl *ctl;
@@ -233,10 +237,10 @@ RFID_KERNEL(256) void ls2_pieces_kernel(Ls2Args a) {
     a.nextv[i] = nx;
     a.prevv[i] = pv;
     Ls2Fsm f;
-    f.head = used ? 1 : 0; f.unit = i; f.gen = -1; f.rerun = 0; f.nwin = 0; f.last_end = -2147483647 - 1;
+    f.head = used ? 1 : 0; f.unit = i; f.gen = -1; f.rerun = 0; f.nwin = 0; f.nepc = 0; f.last_end = -2147483647 - 1;
     for (int k = 0; k < 6; ++k) { f.st[k] = 0; f.en[k] = 0; }
     a.fsm[i] = f;
-    a.seq0[i] = 0;
+    a.seq0[2 * i] = 0; a.seq0[2 * i + 1] = 0;
   }
   const uint64_t m = wv::ballot(used);
   if (lane == 0 && m) wv::atomic_add(&a.ctl->n_pieces, wv::popc64(m));
@@ -373,6 +377,9 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
     }
   }
   marg = ls2_wave_min(marg);
+  // the chain works on the integer image of binary32, where a shift by D ulps of the start is a shift by D at the end only
+  // if both lie in one binade: else nothing but the exact start counts
+  if ((((wv::f2u(avA) ^ sbA) | (wv::f2u(avB) ^ sbB)) & 0xff800000u) != 0u) marg = 0;
   if (lane == 0) {
     Ls2AvgRun r;
     r.s = sA; r.eA = avA; r.eB = avB; r.margin = marg;
@@ -395,7 +402,7 @@ RFID_KERNEL(64) void ls2_avg_rerun_kernel(Ls2Args a) {
   const int cnt = wv::uniform(a.ctl->avg_count[a.round - 1]);
   const int lane = wv::lane_id();
   const int *list = a.alist + (int64_t)((a.round - 1) & 1) * NS;
-  for (int r = (int)blockIdx.x; r < cnt; r += (int)gridDim.x) ls2_avg_piece<false>(a, wv::uniform(list[r]), lane);
+  for (int r = (int)blockIdx.x; r < cnt; r += (int)gridDim.x) ls2_avg_piece<false>(a, wv::uniform(list[r]), lane);   // (grid = NS: one each)
 }
 
 // A piece's latest run as a function "true start -> true end", on the monotone integer image of binary32: T -> T + c[q],
@@ -563,45 +570,74 @@ RFID_KERNEL(64) void ls2_fsm_kernel(Ls2Args a) {
       uint64_t *closed = a.closed + wbase;
       int *oinfo = a.openinfo + wbase;
       Ls2Win *wb = a.wb + (int64_t)s * a.wb_stride;
-      const int nsteps = (n + 63) >> 6;
-      int nwin = 0;
-      uint64_t v_lt = 0, v_gt = 0, my_closed = 0;
-      int my_open = 0xff;
-      for (int k = 0; k < nsteps; ++k) {
-        if ((k & 63) == 0) {
-          const bool in = k + lane < nsteps;
-          v_lt = in ? votes[2 * (k + lane)] : 0ull;
-          v_gt = in ? votes[2 * (k + lane) + 1] : 0ull;
-        }
-        const int kk = k & 63;
-        const uint64_t below = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(v_lt >> 32), kk) << 32) | (uint32_t)wv::readlane((int)(uint32_t)v_lt, kk);
-        const uint64_t above = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(v_gt >> 32), kk) << 32) | (uint32_t)wv::readlane((int)(uint32_t)v_gt, kk);
-        int nvalid = (n - 64 * k < 64) ? (n - 64 * k) : 64;
-        uint64_t closedmask, openmask;
-        int open_lane, open_type;
-        gate_fsm_step(0, g, below, above, 64 * k, nvalid, closedmask, openmask, open_lane, open_type);
-        if (open_lane != 0xff) {   // gate_impl.cc:164-180
-          const int start = pos0 + 64 * k + open_lane;
-          const int wlen = open_type ? EPC_WIN : RN16_WIN;
-          const int complete = (start + wlen <= n_total) ? 1 : 0;   // only complete windows reach the decoder (:223,:291)
-          if (lane == 0) {
-            Ls2Win *w = wb + start / LS2_WBUCKET;
-            if (w->tag != 0 && ((w->tag >> 8) == r + 1) && w->start != start) ctl->wb_clash = 1;   // (the table is cleared before every pass)
-            w->start = start;
-            w->tag = open_type | (complete << 1) | ((r + 1) << 8);
+      const int nsteps = (n + 63) >> 6, nfull = n >> 6;
+      int nwin = 0, nepc = 0;
+      for (int k0 = 0; k0 < nsteps; k0 += 64) {
+        // 64 steps at a time: lane L holds the votes of step k0 + L and collects what that step leaves behind
+        const int nb = (nsteps - k0 < 64) ? (nsteps - k0) : 64;
+        const bool in = lane < nb;
+        const uint64_t v_lt = in ? votes[2 * (k0 + lane)] : 0ull;
+        const uint64_t v_gt = in ? votes[2 * (k0 + lane) + 1] : 0ull;
+        uint64_t my_closed = 0;
+        int my_open = 0xff;
+        // steps that cannot be skipped while the gate idles (closed, POS_EDGE, no command counted): any vote below the
+        // threshold, the partial step at the end, the lanes past the block
+        const uint64_t busy = wv::ballot(!(in && k0 + lane < nfull && v_lt == 0ull));
+        for (int kk = 0; kk < nb;) {
+          const int k = k0 + kk;
+          if (!g.f_open && g.f_state == 1 && g.f_pulses <= NUM_PULSES_CMD) {
+            // gate closed, nothing pending: every step without a sample below the threshold only counts samples
+            const uint64_t m = busy >> kk;
+            const int run = m ? wv::ffs64(m) : (64 - kk);
+            if (run > 0) {
+              if (lane >= kk && lane < kk + run) { my_closed = ~0ull; my_open = 0xff; }
+              const int64_t fn = (int64_t)g.f_n + 64ll * run;
+              g.f_n = (fn > GATE_N_SAT) ? GATE_N_SAT : (int)fn;
+              kk += run;
+              continue;
+            }
+          } else if (g.f_open) {
+            // inside a window: the steps that lie wholly inside it
+            const int rem = g.f_ung - g.f_n;
+            int run = (rem > 64) ? ((rem - 65) / 64 + 1) : 0;
+            const int room = nfull - k;
+            run = (run < room) ? run : room;
+            run = (run < nb - kk) ? run : (nb - kk);
+            if (run > 0) {
+              if (lane >= kk && lane < kk + run) { my_closed = 0ull; my_open = 0xff; }
+              g.f_n += 64 * run;
+              kk += run;
+              continue;
+            }
           }
-          nwin += complete;
-          last_end = start + wlen;
+          const uint64_t below = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(v_lt >> 32), kk) << 32) | (uint32_t)wv::readlane((int)(uint32_t)v_lt, kk);
+          const uint64_t above = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(v_gt >> 32), kk) << 32) | (uint32_t)wv::readlane((int)(uint32_t)v_gt, kk);
+          int nvalid = (n - 64 * k < 64) ? (n - 64 * k) : 64;
+          uint64_t closedmask, openmask;
+          int open_lane, open_type;
+          gate_fsm_step(0, g, below, above, 64 * k, nvalid, closedmask, openmask, open_lane, open_type);
+          if (open_lane != 0xff) {   // gate_impl.cc:164-180
+            const int start = pos0 + 64 * k + open_lane;
+            const int wlen = open_type ? EPC_WIN : RN16_WIN;
+            const int complete = (start + wlen <= n_total) ? 1 : 0;   // only complete windows reach the decoder (:223,:291)
+            if (lane == 0) {
+              Ls2Win *w = wb + start / LS2_WBUCKET;
+              if (w->tag != 0 && ((w->tag >> 8) == r + 1) && w->start != start) ctl->wb_clash = 1;   // (the table is cleared before every pass)
+              w->start = start;
+              w->tag = open_type | (complete << 1) | ((r + 1) << 8);
+            }
+            nwin += complete;
+            nepc += complete & open_type;
+            last_end = start + wlen;
+          }
+          if (lane == kk) { my_closed = closedmask; my_open = open_lane | (open_type << 8); }
+          kk += 1;
         }
-        if (lane == kk) { my_closed = closedmask; my_open = open_lane | (open_type << 8); }
-        if (kk == 63 || k == nsteps - 1) {
-          const int k0 = k & ~63;
-          if (k0 + lane <= k) { closed[k0 + lane] = my_closed; oinfo[k0 + lane] = my_open; }
-        }
+        if (in) { closed[k0 + lane] = my_closed; oinfo[k0 + lane] = my_open; }
       }
       if (lane == 0) {
         Ls2Fsm *f = a.fsm + cur;
-        f->unit = i; f->gen = r + 1; f->nwin = nwin; f->last_end = last_end;
+        f->unit = i; f->gen = r + 1; f->nwin = nwin; f->nepc = nepc; f->last_end = last_end;
         f->en[0] = g.f_n; f->en[1] = g.f_state; f->en[2] = g.f_pulses; f->en[3] = g.f_open; f->en[4] = g.f_ung; f->en[5] = g.f_type;
       }
       n_run++;
@@ -773,6 +809,9 @@ RFID_DEVICE void ls2_dc_unit(const Ls2Args &a, const int i, const bool first, co
   }
   mre = ls2_wave_min(mre);
   mim = ls2_wave_min(mim);
+  // (the chain's integer arithmetic needs start and end in one binade, see ls2_avg_piece)
+  if ((((wv::f2u(g.dcr_c) ^ sbr) | (wv::f2u(bre) ^ sbrB)) & 0xff800000u) != 0u) mre = 0;
+  if ((((wv::f2u(g.dci_c) ^ sbi) | (wv::f2u(bim) ^ sbiB)) & 0xff800000u) != 0u) mim = 0;
   if (lane == 0) {
     Ls2DcRun ru;
     ru.s[0] = sre; ru.s[1] = sim; ru.eA[0] = g.dcr_c; ru.eA[1] = g.dci_c; ru.eB[0] = bre; ru.eB[1] = bim;
@@ -868,36 +907,41 @@ RFID_DEVICE bool ls2_all_settled(const Ls2Ctl *ctl) {
   return ctl->fail == 0 && ctl->avg_count[LS2_AVG_ROUNDS] == 0 && ctl->fsm_count[LS2_FSM_ROUNDS] == 0 &&
          ctl->dc_count[LS2_DC_ROUNDS] == 0 && ctl->wb_clash == 0;
 }
-// one workgroup per trace: the number of complete windows before every piece (exclusive prefix sum), the trace's count
+// one workgroup per trace: the number of complete windows before every piece (exclusive prefix sums: all, EPC), the
+// trace's count, and the trace's places in the decoder's two lists
 RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_seq_kernel(Ls2Args a) {
   RFID_SHARED int shs[2 * LS2_CHAIN_THREADS];
+  RFID_SHARED int she[2 * LS2_CHAIN_THREADS];
   const Ls2Ctl *ctl = a.ctl;
   if (!ls2_all_settled(ctl)) return;
   const int tid = (int)threadIdx.x, s = (int)blockIdx.x;
   const int per = (a.max_b + LS2_CHAIN_THREADS - 1) / LS2_CHAIN_THREADS;
   const int j0 = tid * per, j1 = (j0 + per < a.max_b) ? (j0 + per) : a.max_b;
   const int base = s * a.max_b;
-  int agg = 0;
-  for (int j = j0; j < j1; ++j) if (a.piece[base + j].len > 0) agg += a.fsm[base + j].nwin;
+  int agg = 0, age = 0;
+  for (int j = j0; j < j1; ++j) if (a.piece[base + j].len > 0) { agg += a.fsm[base + j].nwin; age += a.fsm[base + j].nepc; }
   int cur = 0;
-  shs[tid] = agg;
+  shs[tid] = agg; she[tid] = age;
   wv::block_sync();
   for (int off = 1; off < LS2_CHAIN_THREADS; off <<= 1) {
-    int v = shs[cur * LS2_CHAIN_THREADS + tid];
-    if (tid >= off) v += shs[cur * LS2_CHAIN_THREADS + tid - off];
-    shs[(cur ^ 1) * LS2_CHAIN_THREADS + tid] = v;
+    int v = shs[cur * LS2_CHAIN_THREADS + tid], e = she[cur * LS2_CHAIN_THREADS + tid];
+    if (tid >= off) { v += shs[cur * LS2_CHAIN_THREADS + tid - off]; e += she[cur * LS2_CHAIN_THREADS + tid - off]; }
+    shs[(cur ^ 1) * LS2_CHAIN_THREADS + tid] = v; she[(cur ^ 1) * LS2_CHAIN_THREADS + tid] = e;
     cur ^= 1;
     wv::block_sync();
   }
   int run = (tid > 0) ? shs[cur * LS2_CHAIN_THREADS + tid - 1] : 0;
-  const int total = shs[cur * LS2_CHAIN_THREADS + LS2_CHAIN_THREADS - 1];
+  int rune = (tid > 0) ? she[cur * LS2_CHAIN_THREADS + tid - 1] : 0;
+  const int total = shs[cur * LS2_CHAIN_THREADS + LS2_CHAIN_THREADS - 1], total_e = she[cur * LS2_CHAIN_THREADS + LS2_CHAIN_THREADS - 1];
   for (int j = j0; j < j1; ++j) {
     if (a.piece[base + j].len <= 0) continue;
-    a.seq0[base + j] = run;
-    run += a.fsm[base + j].nwin;
+    a.seq0[2 * (base + j)] = run; a.seq0[2 * (base + j) + 1] = rune;
+    run += a.fsm[base + j].nwin; rune += a.fsm[base + j].nepc;
   }
   if (tid == 0) {
     a.wcount[s] = (total < a.wmax) ? total : a.wmax;
+    a.flat_base[2 * s] = wv::atomic_add(a.flat_count + 0, total - total_e);
+    a.flat_base[2 * s + 1] = wv::atomic_add(a.flat_count + 1, total_e);
     wv::atomic_add(&a.ctl->n_windows, total);
   }
 }
@@ -935,7 +979,8 @@ RFID_KERNEL(64) void ls2_assemble_kernel(Ls2Args a) {
     }
     const Ls2Win *wb = a.wb + (int64_t)s * a.wb_stride;
     const int b0 = pos0 / LS2_WBUCKET, b1 = (pos0 + n - 1) / LS2_WBUCKET;
-    int seq = wv::uniform(a.seq0[i]);
+    int seq = wv::uniform(a.seq0[2 * i]), seq_e = wv::uniform(a.seq0[2 * i + 1]);
+    const int fb0 = wv::uniform(a.flat_base[2 * s]), fb1 = wv::uniform(a.flat_base[2 * s + 1]);
     for (int bb = b0; bb <= b1; bb += 64) {
       const int b = bb + lane;
       Ls2Win w; w.start = 0; w.tag = 0; w.a_re = w.a_im = w.b_re = w.b_im = 0.0f;
@@ -944,25 +989,20 @@ RFID_KERNEL(64) void ls2_assemble_kernel(Ls2Args a) {
       const uint64_t m = wv::ballot(on);
       if (m == 0ull) continue;
       const int type = w.tag & 1;
+      const uint64_t me = wv::ballot(on && type != 0);
       rfid_window o;
       o.stream = s; o.seq = seq + wv::popc64(m & lt); o.start = w.start; o.type = type;
       o.dc_re = (useb[0] ? w.b_re : w.a_re) + shift[0];
       o.dc_im = (useb[1] ? w.b_im : w.a_im) + shift[1];
-      const bool put = on && o.seq < a.wmax;
-      if (put) a.wtab[(int64_t)s * a.wmax + o.seq] = o;
-      // places in the decoder's two lists: one atomic per list and 64 windows
-      const uint64_t m1 = wv::ballot(put && type != 0), m0 = wv::ballot(put && type == 0);
-      int c0 = 0, c1 = 0;
-      if (lane == 0) {
-        if (m0) c0 = wv::atomic_add(a.flat_count + 0, wv::popc64(m0));
-        if (m1) c1 = wv::atomic_add(a.flat_count + 1, wv::popc64(m1));
-      }
-      c0 = wv::uniform(c0); c1 = wv::uniform(c1);
-      if (put) {
-        const int slotw = type ? (c1 + wv::popc64(m1 & lt)) : (c0 + wv::popc64(m0 & lt));
+      if (on && o.seq < a.wmax) {
+        a.wtab[(int64_t)s * a.wmax + o.seq] = o;
+        // its place in the decoder's list: the trace's base + the windows of its type before it in the trace
+        const int before_e = seq_e + wv::popc64(me & lt);
+        const int slotw = type ? (fb1 + before_e) : (fb0 + (o.seq - before_e));
         if (slotw < a.flat_cap) a.flat[(int64_t)type * a.flat_cap + slotw] = o;
       }
       seq += wv::popc64(m);
+      seq_e += wv::popc64(me);
     }
   }
 }

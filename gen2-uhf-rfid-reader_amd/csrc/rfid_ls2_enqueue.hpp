@@ -35,7 +35,7 @@ inline Ls2Geometry ls2_geometry(int n_streams, int64_t n_dec, int min_piece = LS
 
 // work space: one allocation, carved up here (offsets in bytes, 256-byte aligned)
 struct Ls2Layout {
-  size_t cut, piece, nextv, prevv, amp, dadd, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, drun, dT, dlist, seq0, ctl, consumed, total;
+  size_t cut, piece, nextv, prevv, amp, dadd, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, drun, dT, dlist, seq0, flat_base, ctl, consumed, total;
 };
 inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_stride) {
   Ls2Layout L;
@@ -60,7 +60,8 @@ inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_strid
   L.drun = take(sizeof(Ls2DcRun) * NS);
   L.dT = take(sizeof(int) * 2 * NS);
   L.dlist = take(sizeof(int) * 2 * NS);
-  L.seq0 = take(sizeof(int) * NS);
+  L.seq0 = take(sizeof(int) * 2 * NS);
+  L.flat_base = take(sizeof(int) * 2 * B);
   L.ctl = take(sizeof(Ls2Ctl));
   L.consumed = take(sizeof(int) * B);
   L.total = off;
@@ -75,7 +76,7 @@ inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geomet
   a.arun = (Ls2AvgRun *)(base + L.arun); a.aT = (int *)(base + L.aT); a.alist = (int *)(base + L.alist); a.aover = (Ls2Aff *)(base + L.aover);
   a.fsm = (Ls2Fsm *)(base + L.fsm); a.wb = (Ls2Win *)(base + L.wb);
   a.drun = (Ls2DcRun *)(base + L.drun); a.dT = (int *)(base + L.dT); a.dlist = (int *)(base + L.dlist);
-  a.seq0 = (int *)(base + L.seq0); a.ctl = (Ls2Ctl *)(base + L.ctl); a.consumed = (int *)(base + L.consumed);
+  a.seq0 = (int *)(base + L.seq0); a.flat_base = (int *)(base + L.flat_base); a.ctl = (Ls2Ctl *)(base + L.ctl); a.consumed = (int *)(base + L.consumed);
 }
 
 #ifdef LS2_LAUNCH
@@ -94,7 +95,7 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true) {   // (search_cuts 
   a.round = 0;
   LS2_LAUNCH(ls2_pieces_kernel, (NS + 255) / 256, 1, 256, a);
   LS2_LAUNCH(ls2_check_kernel, 1, 1, 64, a);
-  const int rerun_grid = NS < 2048 ? NS : 2048;
+  const int rerun_grid = NS;   // (one wave per list entry; the waves past the list return at once)
   LS2_LAUNCH(ls2_avg_first_kernel, NS, 1, 64, a);
   LS2_LAUNCH(ls2_avg_chain_kernel, B, 1, LS2_CHAIN_THREADS, a);
   for (int r = 1; r <= LS2_AVG_ROUNDS; ++r) {
