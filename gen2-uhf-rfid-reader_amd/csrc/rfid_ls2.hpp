@@ -195,10 +195,11 @@ RFID_DEVICE bool chain_add_scan2(float ca, float cb2, float x, int lane, float &
   ob = wv::u2f(magb | sign);
   return wv::ballot(bad_t || bad_s || bad_c) == 0ull;
 }
-RFID_DEVICE void chain_add_auto2(float ca, float cb2, float x, int lane, float &oa, float &ob) {
-  if (__builtin_expect(chain_add_scan2(ca, cb2, x, lane, oa, ob), 1)) return;
+RFID_DEVICE bool chain_add_auto2(float ca, float cb2, float x, int lane, float &oa, float &ob) {   // true: the shared scan applied
+  if (__builtin_expect(chain_add_scan2(ca, cb2, x, lane, oa, ob), 1)) return true;
   oa = chain_add_auto(ca, x, lane);
   ob = chain_add_auto(cb2, x, lane);
+  return false;
 }
 
 // ---- 1. pieces -----------------------------------------------------------------------------------------------------
@@ -307,6 +308,7 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
   const uint32_t sbB = wv::f2u(sB);
   float avA = sA, avB = sB;
   int marg = ls2_margin(sA, sbA);
+  const bool e0_ok = ((sbA >> 23) & 0xffu) >= 25u && ((sbA >> 23) & 0xffu) != 255u && ((sbB >> 23) & 0xffu) >= 25u && ((sbB >> 23) & 0xffu) != 255u;
   const int nsteps = (n + 63) >> 6;
   constexpr int AHEAD = 4;
   float2 ybuf[AHEAD];
@@ -343,7 +345,8 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
           dbuf[u] = (idx < n) ? dc[idx] : 0.0f;
         }
         float vA, vB;
-        chain_add_auto2(avA, avB, d, lane, vA, vB);
+        const uint32_t cinA = wv::f2u(avA), cinB = wv::f2u(avB);
+        const bool scanned = chain_add_auto2(avA, avB, d, lane, vA, vB);
         avA = wv::readlane(vA, 63);
         avB = wv::readlane(vB, 63);
         if (wide) {
@@ -358,15 +361,33 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
         if (lane == (k & 63)) { my_lt = below; my_gt = above; }
         // margin: the partial sums of both variants against the powers of two, |x| against the threshold
         {
-          const int mA = ls2_margin(vA, sbA), mB = ls2_margin(vB, sbB);
           const uint32_t tb = wv::f2u(thresh), ab = wv::f2u(amp);
           int dv = (int)ab - (int)tb;
           dv = (dv < 0) ? -dv : dv;
-          const int sh = (int)((sbA >> 23) & 0xffu) - (int)((wv::f2u(vA) >> 23) & 0xffu);
-          int mV = ((tb >> 31) != 0u || sh < 0 || sh > 23) ? 0 : (((dv - 3) >> 1) >> sh);
-          mV = valid ? mV : 0x7fffffff;
-          int mm = (mA < mB) ? mA : mB;
-          mm = (mV < mm) ? mV : mm;
+          int mm;
+          if (scanned) {
+            // every partial sum of the step lies in its carry's binade (chain_add_scan): one shift for all lanes
+            const int shA = (int)((sbA >> 23) & 0xffu) - (int)((cinA >> 23) & 0xffu), shB = (int)((sbB >> 23) & 0xffu) - (int)((cinB >> 23) & 0xffu);
+            const bool good = e0_ok && (((cinA ^ sbA) | (cinB ^ sbB)) >> 31) == 0u && shA >= 0 && shA <= 23 && shB >= 0 && shB <= 23 &&
+                              (cinA & 0x7f800000u) != 0u && (cinB & 0x7f800000u) != 0u;
+            if (good) {
+              const int mA = (int)(wv::f2u(vA) & 0x7fffffu), mB = (int)(wv::f2u(vB) & 0x7fffffu);
+              const int uA = 0x800000 - mA, uB = 0x800000 - mB;
+              const int dA = ((mA < uA) ? mA : uA) >> shA, dB = ((mB < uB) ? mB : uB) >> shB;
+              const int mV = valid ? ((dv - 3) >> (1 + shA)) : 0x7fffffff;
+              mm = (dA < dB) ? dA : dB;
+              mm = (mV < mm) ? mV : mm;
+            } else {
+              mm = 0;
+            }
+          } else {
+            const int mA = ls2_margin(vA, sbA), mB = ls2_margin(vB, sbB);
+            const int sh = (int)((sbA >> 23) & 0xffu) - (int)((wv::f2u(vA) >> 23) & 0xffu);
+            int mV = ((tb >> 31) != 0u || sh < 0 || sh > 23) ? 0 : (((dv - 3) >> 1) >> sh);
+            mV = valid ? mV : 0x7fffffff;
+            mm = (mA < mB) ? mA : mB;
+            mm = (mV < mm) ? mV : mm;
+          }
           marg = (mm < marg) ? mm : marg;
         }
         if ((k & 63) == 63 || k == nsteps - 1) {
@@ -407,116 +428,162 @@ RFID_KERNEL(64) void ls2_avg_rerun_kernel(Ls2Args a) {
 
 // A piece's latest run as a function "true start -> true end", on the monotone integer image of binary32: T -> T + c[q],
 // q = parity of T (the run from s serves the starts s + even, the run from s + 1 ulp the starts s + odd).  Functions
-// of this form compose to the same form, so a trace's chain of pieces is ONE prefix scan.
-RFID_DEVICE Ls2Aff ls2_compose(const Ls2Aff f, const Ls2Aff g) {   // f first, then g
-  Ls2Aff r;
-  r.c0 = f.c0 + ((f.c0 & 1) ? g.c1 : g.c0);
-  r.c1 = f.c1 + (((1 + f.c1) & 1) ? g.c1 : g.c0);
+// of this form compose to the same form, so a trace's chain of pieces is ONE prefix scan.  (32-bit wrap-around
+// arithmetic: the true values fit, so sums modulo 2^32 are the true sums.)
+struct Ls2A32 { int c0, c1; };
+RFID_DEVICE Ls2A32 ls2_comp32(const Ls2A32 f, const Ls2A32 g) {   // f first, then g
+  Ls2A32 r;
+  r.c0 = (int)((uint32_t)f.c0 + (uint32_t)((f.c0 & 1) ? g.c1 : g.c0));
+  r.c1 = (int)((uint32_t)f.c1 + (uint32_t)(((1 + f.c1) & 1) ? g.c1 : g.c0));
   return r;
 }
-RFID_DEVICE Ls2Aff ls2_aff(float s, float eA, float eB) {
-  const int64_t os = ls2_ord(s), a0 = (int64_t)ls2_ord(eA) - os, a1 = (int64_t)ls2_ord(eB) - 1 - os;
-  Ls2Aff r;
-  // T even-distant from s -> a0, odd-distant -> a1
-  if (os & 1) { r.c0 = a1; r.c1 = a0; } else { r.c0 = a0; r.c1 = a1; }
+RFID_DEVICE Ls2A32 ls2_elem32(float s, float eA, float eB) {
+  const uint32_t os = (uint32_t)ls2_ord(s);
+  const int a0 = (int)((uint32_t)ls2_ord(eA) - os), a1 = (int)((uint32_t)ls2_ord(eB) - 1u - os);
+  Ls2A32 r;
+  if (os & 1u) { r.c0 = a1; r.c1 = a0; } else { r.c0 = a0; r.c1 = a1; }   // T even-distant from s -> a0, odd-distant -> a1
   return r;
 }
-// exclusive prefix "scan" of per-thread aggregates over one workgroup (thread t gets the composition of threads < t)
-RFID_DEVICE Ls2Aff ls2_block_exscan(Ls2Aff mine, Ls2Aff *sh /* [2][LS2_CHAIN_THREADS] */, int tid) {
-  int cur = 0;
-  sh[tid] = mine;
-  wv::block_sync();
-  for (int off = 1; off < LS2_CHAIN_THREADS; off <<= 1) {
-    Ls2Aff v = sh[cur * LS2_CHAIN_THREADS + tid];
-    if (tid >= off) v = ls2_compose(sh[cur * LS2_CHAIN_THREADS + tid - off], v);
-    sh[(cur ^ 1) * LS2_CHAIN_THREADS + tid] = v;
-    cur ^= 1;
-    wv::block_sync();
+RFID_DEVICE int ls2_apply32(const Ls2A32 f, int T) { return (int)((uint32_t)T + (uint32_t)((T & 1) ? f.c1 : f.c0)); }
+// inclusive scan over the 64 lanes in lane order (lane L: the composition of lanes 0..L)
+RFID_DEVICE Ls2A32 ls2_wave_incl(Ls2A32 v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    Ls2A32 o;
+    o.c0 = wv::shfl(v.c0, (lane - off) & 63); o.c1 = wv::shfl(v.c1, (lane - off) & 63);
+    const Ls2A32 c = ls2_comp32(o, v);
+    if (lane >= off) v = c;
   }
-  Ls2Aff ex; ex.c0 = 0; ex.c1 = 0;
-  if (tid > 0) ex = sh[cur * LS2_CHAIN_THREADS + tid - 1];
-  wv::block_sync();
-  return ex;
+  return v;
 }
+RFID_DEVICE Ls2A32 ls2_wave_excl(const Ls2A32 incl, int lane) {
+  Ls2A32 e;
+  e.c0 = wv::shfl(incl.c0, (lane - 1) & 63); e.c1 = wv::shfl(incl.c1, (lane - 1) & 63);
+  if (lane == 0) { e.c0 = 0; e.c1 = 0; }
+  return e;
+}
+constexpr int LS2_CHAIN_WAVES = LS2_CHAIN_THREADS / 64;
 
 // one workgroup per trace: every piece's true start from the chain of the latest runs; what is not proven goes on the
-// re-run list of this round.  A run that was made from six neighbouring starts knows its end for each of them exactly;
-// when the chain lands on one of those, that end replaces the prediction and the scan is repeated (a few times at most:
-// such pieces are rare), so that no error is handed downstream.
-RFID_DEVICE bool ls2_wide_end(const Ls2AvgRun &ru, int64_t D, int64_t &end_ord) {   // exact end for true start s + D, if known
+// re-run list of this round.  Sixteen waves, each over a contiguous run of the trace's slots, 64 slots at a time (lane =
+// slot: coalesced reads, a wave-level scan per 64), the waves' totals chained through LDS; a first sweep for the totals,
+// a second one for every piece's start.  A run that was made from six neighbouring starts knows its end for each of
+// them exactly: when the chain lands on one of those, that end replaces the prediction and the sweeps are repeated (a
+// few times at most: such pieces are rare), so that no error is handed downstream.
+RFID_DEVICE bool ls2_wide_end(const Ls2AvgRun &ru, int64_t D, int &end_ord) {   // exact end for true start s + D, if known
   if (!(ru.wide & 2) || D < LS2_WIDE_LO || D > LS2_WIDE_HI) return false;
   const float e = (D == 0) ? ru.eA : (D == 1) ? ru.eB : (D == -2) ? ru.ew[0] : (D == -1) ? ru.ew[1] : (D == 2) ? ru.ew[2] : ru.ew[3];
   end_ord = ls2_ord(e);
   return true;
 }
 RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_avg_chain_kernel(Ls2Args a) {
-  RFID_SHARED Ls2Aff sh[2 * LS2_CHAIN_THREADS];
-  RFID_SHARED int sh_changed[2];
+  RFID_SHARED Ls2A32 wagg[LS2_CHAIN_WAVES];
+  RFID_SHARED int sh_flag[2];
   Ls2Ctl *ctl = a.ctl;
   const int r = a.round;
   const int tid = (int)threadIdx.x, s = (int)blockIdx.x;
   if (ctl->fail != 0) return;
   if (r > 0 && ctl->avg_count[r - 1] == 0) return;   // settled in an earlier round (avg_count[r] stays 0)
   const int NS = a.n_streams * a.max_b;
-  const int per = (a.max_b + LS2_CHAIN_THREADS - 1) / LS2_CHAIN_THREADS;
-  const int j0 = tid * per, j1 = (j0 + per < a.max_b) ? (j0 + per) : a.max_b;
+  const int lane = wv::lane_id(), wave = wv::uniform(tid >> 6);
   const int base = s * a.max_b;
-  const bool any = a.piece[base].len > 0;                                  // (else: an empty trace)
-  const int64_t T0 = any ? (int64_t)ls2_ord(a.arun[base].s) : 0;           // the trace's first piece starts from the exact value
-  for (int j = j0; j < j1; ++j)
-    if (a.piece[base + j].len > 0) { const Ls2AvgRun ru = a.arun[base + j]; a.aover[base + j] = ls2_aff(ru.s, ru.eA, ru.eB); }
-  int64_t Tfirst = 0;
-  for (int it = 0; it < 4; ++it) {
-    Ls2Aff agg; agg.c0 = 0; agg.c1 = 0;
-    for (int j = j0; j < j1; ++j)
-      if (a.piece[base + j].len > 0) agg = ls2_compose(agg, a.aover[base + j]);
-    if (tid < 2) sh_changed[tid] = 0;
-    const Ls2Aff ex = ls2_block_exscan(agg, sh, tid);   // (its barriers also publish sh_changed)
-    Tfirst = T0 + ((T0 & 1) ? ex.c1 : ex.c0);
-    int64_t T = Tfirst;
-    bool changed = false;
-    for (int j = j0; j < j1; ++j) {
-      const int i = base + j;
-      if (a.piece[i].len <= 0) continue;
-      const Ls2AvgRun ru = a.arun[i];
-      Ls2Aff f = a.aover[i];
-      int64_t e_exact;
-      if (ls2_wide_end(ru, T - (int64_t)ls2_ord(ru.s), e_exact)) {
-        const int64_t want = e_exact - T;
-        int64_t &cq = (T & 1) ? f.c1 : f.c0;
-        if (cq != want) { cq = want; a.aover[i] = f; changed = true; }
-      }
-      T += (T & 1) ? f.c1 : f.c0;
-    }
-    if (changed) sh_changed[it & 1] = 1;
-    wv::block_sync();
-    const bool again = sh_changed[it & 1] != 0;
-    wv::block_sync();
-    if (!again) break;
-  }
-  if (!any) return;
-  int64_t T = Tfirst;
+  if (a.piece[base].len <= 0) return;                 // an empty trace
+  const int n_chunks = (a.max_b + 63) >> 6, cpw = (n_chunks + LS2_CHAIN_WAVES - 1) / LS2_CHAIN_WAVES;
+  const int c_lo = wave * cpw, c_hi = (c_lo + cpw < n_chunks) ? (c_lo + cpw) : n_chunks;
+  const int T0 = ls2_ord(a.arun[base].s);             // the trace's first piece starts from the exact value
   int n_rerun = 0;
-  for (int j = j0; j < j1; ++j) {
-    const int i = base + j;
-    if (a.piece[i].len <= 0) continue;
-    const Ls2AvgRun ru = a.arun[i];
-    const Ls2Aff f = a.aover[i];
-    const int64_t D = T - (int64_t)ls2_ord(ru.s);
-    const int64_t aD = (D < 0) ? -D : D;
-    a.aT[i] = (int)T;
-    // settled: the run started from the true value, or provably covers it (its votes included).  Anything else is run
-    // again from the true (or predicted) start -- also a piece whose END is known exactly from a neighbouring start: its
-    // votes are not.
-    if (D != 0 && !(aD + 4 <= (int64_t)ru.margin)) {
-      Ls2AvgRun *w = a.arun + i;
-      w->s = ls2_from_ord((int)T);
-      w->wide = (ru.margin < LS2_WIDE_BELOW || r >= 3) ? 1 : 0;
-      const int k = wv::atomic_add(&ctl->avg_count[r], 1);
-      a.alist[(int64_t)(r & 1) * NS + k] = i;
-      n_rerun++;
+  for (int it = 0; it < 6; ++it) {
+    // ---- sweep 1: this wave's total; are there runs with exactly known neighbouring ends at all? ----
+    Ls2A32 carry; carry.c0 = 0; carry.c1 = 0;
+    bool any_wide = false;
+    for (int c = c_lo; c < c_hi; ++c) {
+      const int j = 64 * c + lane;
+      const bool in = j < a.max_b && a.piece[base + j].len > 0;
+      Ls2A32 el; el.c0 = 0; el.c1 = 0;
+      if (in) {
+        const Ls2AvgRun *ru = a.arun + base + j;
+        if (it == 0) {
+          el = ls2_elem32(ru->s, ru->eA, ru->eB);
+          if (ru->wide & 2) { Ls2Aff o; o.c0 = el.c0; o.c1 = el.c1; a.aover[base + j] = o; any_wide = true; }
+        } else if (ru->wide & 2) {
+          const Ls2Aff o = a.aover[base + j];
+          el.c0 = (int)o.c0; el.c1 = (int)o.c1;
+          any_wide = true;
+        } else {
+          el = ls2_elem32(ru->s, ru->eA, ru->eB);
+        }
+      }
+      const Ls2A32 incl = ls2_wave_incl(el, lane);
+      Ls2A32 tot; tot.c0 = wv::readlane(incl.c0, 63); tot.c1 = wv::readlane(incl.c1, 63);
+      carry = ls2_comp32(carry, tot);
     }
-    T += (T & 1) ? f.c1 : f.c0;
+    if (tid < 2) sh_flag[tid] = 0;
+    if (lane == 0) wagg[wave] = carry;
+    wv::block_sync();
+    if (wv::ballot(any_wide) != 0ull && lane == 0) sh_flag[0] = 1;
+    Ls2A32 pre; pre.c0 = 0; pre.c1 = 0;
+    for (int w = 0; w < wave; ++w) pre = ls2_comp32(pre, wagg[w]);
+    wv::block_sync();
+    const bool wides = sh_flag[0] != 0;
+    // ---- sweep 2: every piece's true (or predicted) start; the last sweep also sorts the pieces ----
+    const bool last = !wides || it == 5;   // (no run with known neighbours: nothing can change; else decided below)
+    bool changed = false;
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 1 && (last || changed)) break;       // pass 1 = the sorting sweep after an unchanged pass 0
+      const bool sort = last || pass == 1;
+      Ls2A32 run = pre;
+      for (int c = c_lo; c < c_hi; ++c) {
+        const int j = 64 * c + lane, i = base + j;
+        const bool in = j < a.max_b && a.piece[i].len > 0;
+        Ls2A32 el; el.c0 = 0; el.c1 = 0;
+        Ls2AvgRun ru;
+        if (in) {
+          ru = a.arun[i];
+          if (ru.wide & 2) { const Ls2Aff o = a.aover[i]; el.c0 = (int)o.c0; el.c1 = (int)o.c1; }
+          else el = ls2_elem32(ru.s, ru.eA, ru.eB);
+        }
+        const Ls2A32 incl = ls2_wave_incl(el, lane);
+        const Ls2A32 upto = ls2_comp32(run, ls2_wave_excl(incl, lane));
+        const int T = ls2_apply32(upto, T0);
+        if (in) {
+          const int64_t D = (int64_t)T - (int64_t)ls2_ord(ru.s);
+          if (!sort) {
+            int e_exact;
+            if (ls2_wide_end(ru, D, e_exact)) {
+              const int want = (int)((uint32_t)e_exact - (uint32_t)T);
+              const int cq = (T & 1) ? el.c1 : el.c0;
+              if (cq != want) {
+                Ls2Aff o; o.c0 = (T & 1) ? el.c0 : want; o.c1 = (T & 1) ? want : el.c1;
+                a.aover[i] = o;
+                changed = true;
+              }
+            }
+          } else {
+            const int64_t aD = (D < 0) ? -D : D;
+            a.aT[i] = T;
+            // settled: the run started from the true value, or provably covers it (its votes included).  Anything else is
+            // run again from the true (or predicted) start -- also a piece whose END is known exactly from a neighbouring
+            // start: its votes are not.
+            if (D != 0 && !(aD + 4 <= (int64_t)ru.margin)) {
+              Ls2AvgRun *w = a.arun + i;
+              w->s = ls2_from_ord(T);
+              w->wide = (ru.margin < LS2_WIDE_BELOW || r >= 3) ? 1 : 0;
+              const int k = wv::atomic_add(&ctl->avg_count[r], 1);
+              a.alist[(int64_t)(r & 1) * NS + k] = i;
+              n_rerun++;
+            }
+          }
+        }
+        Ls2A32 tot; tot.c0 = wv::readlane(incl.c0, 63); tot.c1 = wv::readlane(incl.c1, 63);
+        run = ls2_comp32(run, tot);
+      }
+      if (sort) { it = 100; break; }
+      // did any wave put an exact end in?  then everything is swept again
+      if (wv::ballot(changed) != 0ull && lane == 0) sh_flag[1] = 1;
+      wv::block_sync();
+      changed = sh_flag[1] != 0;
+      wv::block_sync();
+    }
   }
   if (n_rerun) wv::atomic_add(&ctl->avg_reruns, n_rerun);
   if (tid == 0 && s == 0) ctl->avg_rounds = r + 1;
@@ -847,55 +914,71 @@ RFID_KERNEL(64) void ls2_dc_rerun_kernel(Ls2Args a) {
   for (int r = (int)blockIdx.x; r < cnt; r += (int)gridDim.x) ls2_dc_unit(a, wv::uniform(list[r]), false, lane, lds_dc, lds_tmp);
 }
 
-// one workgroup per trace: as ls2_avg_chain_kernel, over the units and the two components of dc_est
+// one workgroup per trace: as ls2_avg_chain_kernel, over the units (head slots) and the two components of dc_est
 RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_dc_chain_kernel(Ls2Args a) {
-  RFID_SHARED Ls2Aff sh[2 * LS2_CHAIN_THREADS];
+  RFID_SHARED Ls2A32 wagg[2 * LS2_CHAIN_WAVES];
   Ls2Ctl *ctl = a.ctl;
   const int r = a.round;
   const int tid = (int)threadIdx.x, s = (int)blockIdx.x;
   if (ctl->fail != 0 || ctl->avg_count[LS2_AVG_ROUNDS] != 0 || ctl->fsm_count[LS2_FSM_ROUNDS] != 0) return;
   if (r > 0 && ctl->dc_count[r - 1] == 0) return;
   const int NS = a.n_streams * a.max_b;
-  const int per = (a.max_b + LS2_CHAIN_THREADS - 1) / LS2_CHAIN_THREADS;
-  const int j0 = tid * per, j1 = (j0 + per < a.max_b) ? (j0 + per) : a.max_b;
+  const int lane = wv::lane_id(), wave = wv::uniform(tid >> 6);
   const int base = s * a.max_b;
-  int64_t T[2];
-  for (int c = 0; c < 2; ++c) {
-    Ls2Aff agg; agg.c0 = 0; agg.c1 = 0;
-    for (int j = j0; j < j1; ++j) {
-      if (a.piece[base + j].len <= 0 || a.fsm[base + j].head == 0) continue;
-      const Ls2DcRun &ru = a.drun[base + j];
-      agg = ls2_compose(agg, ls2_aff(ru.s[c], ru.eA[c], ru.eB[c]));
-    }
-    const Ls2Aff ex = ls2_block_exscan(agg, sh, tid);
-    const int64_t T0 = (a.piece[base].len > 0) ? ls2_ord(a.drun[base].s[c]) : 0;
-    T[c] = T0 + ((T0 & 1) ? ex.c1 : ex.c0);
-  }
   if (a.piece[base].len <= 0) return;
+  const int n_chunks = (a.max_b + 63) >> 6, cpw = (n_chunks + LS2_CHAIN_WAVES - 1) / LS2_CHAIN_WAVES;
+  const int c_lo = wave * cpw, c_hi = (c_lo + cpw < n_chunks) ? (c_lo + cpw) : n_chunks;
+  const int T0r = ls2_ord(a.drun[base].s[0]), T0i = ls2_ord(a.drun[base].s[1]);
+  // ---- sweep 1: this wave's totals ----
+  Ls2A32 cr, ci; cr.c0 = cr.c1 = 0; ci.c0 = ci.c1 = 0;
+  for (int c = c_lo; c < c_hi; ++c) {
+    const int j = 64 * c + lane, i = base + j;
+    const bool in = j < a.max_b && a.piece[i].len > 0 && a.fsm[i].head != 0;
+    Ls2A32 er, ei; er.c0 = er.c1 = 0; ei.c0 = ei.c1 = 0;
+    if (in) {
+      const Ls2DcRun *ru = a.drun + i;
+      er = ls2_elem32(ru->s[0], ru->eA[0], ru->eB[0]);
+      ei = ls2_elem32(ru->s[1], ru->eA[1], ru->eB[1]);
+    }
+    const Ls2A32 ir = ls2_wave_incl(er, lane), ii = ls2_wave_incl(ei, lane);
+    Ls2A32 tr, ti; tr.c0 = wv::readlane(ir.c0, 63); tr.c1 = wv::readlane(ir.c1, 63); ti.c0 = wv::readlane(ii.c0, 63); ti.c1 = wv::readlane(ii.c1, 63);
+    cr = ls2_comp32(cr, tr); ci = ls2_comp32(ci, ti);
+  }
+  if (lane == 0) { wagg[2 * wave] = cr; wagg[2 * wave + 1] = ci; }
+  wv::block_sync();
+  Ls2A32 rr, ri; rr.c0 = rr.c1 = 0; ri.c0 = ri.c1 = 0;
+  for (int w = 0; w < wave; ++w) { rr = ls2_comp32(rr, wagg[2 * w]); ri = ls2_comp32(ri, wagg[2 * w + 1]); }
+  // ---- sweep 2: every unit's true (or predicted) start; what is not proven goes on the re-run list ----
   int n_rerun = 0, n_units = 0;
-  for (int j = j0; j < j1; ++j) {
-    const int i = base + j;
-    if (a.piece[i].len <= 0 || a.fsm[i].head == 0) continue;
-    n_units++;
-    const Ls2DcRun ru = a.drun[i];
-    bool again = false;
-    for (int c = 0; c < 2; ++c) {
-      const int64_t D = T[c] - (int64_t)ls2_ord(ru.s[c]);
-      const int64_t aD = (D < 0) ? -D : D;
-      a.dT[2 * i + c] = (int)T[c];
-      if (D != 0 && !(aD + 4 <= (int64_t)ru.margin[c])) again = true;
+  for (int c = c_lo; c < c_hi; ++c) {
+    const int j = 64 * c + lane, i = base + j;
+    const bool in = j < a.max_b && a.piece[i].len > 0 && a.fsm[i].head != 0;
+    Ls2A32 er, ei; er.c0 = er.c1 = 0; ei.c0 = ei.c1 = 0;
+    Ls2DcRun ru;
+    if (in) {
+      ru = a.drun[i];
+      er = ls2_elem32(ru.s[0], ru.eA[0], ru.eB[0]);
+      ei = ls2_elem32(ru.s[1], ru.eA[1], ru.eB[1]);
     }
-    if (again) {
-      a.drun[i].s[0] = ls2_from_ord((int)T[0]);
-      a.drun[i].s[1] = ls2_from_ord((int)T[1]);
-      const int k = wv::atomic_add(&ctl->dc_count[r], 1);
-      a.dlist[(int64_t)(r & 1) * NS + k] = i;
-      n_rerun++;
+    const Ls2A32 ir = ls2_wave_incl(er, lane), ii = ls2_wave_incl(ei, lane);
+    const int Tr = ls2_apply32(ls2_comp32(rr, ls2_wave_excl(ir, lane)), T0r);
+    const int Ti = ls2_apply32(ls2_comp32(ri, ls2_wave_excl(ii, lane)), T0i);
+    if (in) {
+      n_units++;
+      const int64_t Dr = (int64_t)Tr - (int64_t)ls2_ord(ru.s[0]), Di = (int64_t)Ti - (int64_t)ls2_ord(ru.s[1]);
+      const int64_t aDr = (Dr < 0) ? -Dr : Dr, aDi = (Di < 0) ? -Di : Di;
+      a.dT[2 * i] = Tr; a.dT[2 * i + 1] = Ti;
+      const bool again = (Dr != 0 && !(aDr + 4 <= (int64_t)ru.margin[0])) || (Di != 0 && !(aDi + 4 <= (int64_t)ru.margin[1]));
+      if (again) {
+        a.drun[i].s[0] = ls2_from_ord(Tr);
+        a.drun[i].s[1] = ls2_from_ord(Ti);
+        const int k = wv::atomic_add(&ctl->dc_count[r], 1);
+        a.dlist[(int64_t)(r & 1) * NS + k] = i;
+        n_rerun++;
+      }
     }
-    for (int c = 0; c < 2; ++c) {
-      const Ls2Aff f = ls2_aff(ru.s[c], ru.eA[c], ru.eB[c]);
-      T[c] += (T[c] & 1) ? f.c1 : f.c0;
-    }
+    Ls2A32 tr, ti; tr.c0 = wv::readlane(ir.c0, 63); tr.c1 = wv::readlane(ir.c1, 63); ti.c0 = wv::readlane(ii.c0, 63); ti.c1 = wv::readlane(ii.c1, 63);
+    rr = ls2_comp32(rr, tr); ri = ls2_comp32(ri, ti);
   }
   if (n_rerun) wv::atomic_add(&ctl->dc_reruns, n_rerun);
   if (r == 0 && n_units) wv::atomic_add(&ctl->n_units, n_units);

@@ -77,11 +77,11 @@ def test_ls2_carrier_at_a_power_of_two(emu_mod, oracle_mod, synth_mod):
     many rounds, or give up and leave the trace to the sequential scan -- the result must be the sequential scan's, and
     avg_ampl at every cut the in-order recurrence's (a piece accepted with a shift scaled by the wrong binade's ulp would
     show here and nowhere else).  A longer trace of the same kind runs out of rounds: ok = 0, same result."""
-    t = synth_mod.make_trace(n_rounds=30, sigma=0.01, seed=5).samples
+    t = synth_mod.make_trace(n_rounds=12, sigma=0.01, seed=5).samples
     t = (t * np.complex64(0.64)).astype(np.complex64)
-    r = _check(emu_mod, oracle_mod, t[None, :])
-    assert r["ctl"]["avg_rounds"] >= 5 and r["ctl"]["n_pieces"] > 10, r["ctl"]
-    t = synth_mod.make_trace(n_rounds=70, sigma=0.01, seed=6).samples
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1)
+    assert r["ctl"]["avg_rounds"] >= 4 and r["ctl"]["n_pieces"] >= 7, r["ctl"]
+    t = synth_mod.make_trace(n_rounds=40, sigma=0.01, seed=6).samples
     t = (t * np.complex64(0.64)).astype(np.complex64)
     r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=0)
     assert r["ctl"]["avg_count9"] > 0, r["ctl"]
