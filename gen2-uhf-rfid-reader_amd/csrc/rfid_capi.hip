@@ -530,6 +530,29 @@ int rfid_selftest(rfid_ctx *c, int *n_failed) {
     }
   }
   (void)hipFree(d);
+  {
+    // the wave scan of the long-stream front end's chain (DPP row shifts / broadcasts with a non-commutative operation)
+    // against the same composition done one by one on the host
+    int hin[128], hout[256];
+    unsigned sd = 777u;
+    for (int i = 0; i < 128; ++i) { sd = sd * 1664525u + 1013904223u; hin[i] = (int)(sd >> 9) - (1 << 22); }
+    int *di = nullptr;
+    HIPCHK(c, hipMalloc((void **)&di, sizeof(hin) + sizeof(hout)));
+    HIPCHK(c, hipMemcpyAsync(di, hin, sizeof(hin), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(ls2_scan_selftest_kernel, dim3(1), dim3(64), 0, c->stream, (const int *)di, di + 128);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(hout, di + 128, sizeof(hout), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(di);
+    unsigned a0 = 0, a1 = 0;   // running composition, f then g: c[q] = f.c[q] + g.c[(q + f.c[q]) & 1]
+    for (int l = 0; l < 64; ++l) {
+      if (hout[4 * l + 2] != (int)a0 || hout[4 * l + 3] != (int)a1) bad++;
+      const unsigned g0 = (unsigned)hin[2 * l], g1 = (unsigned)hin[2 * l + 1];
+      const unsigned n0 = a0 + ((a0 & 1u) ? g1 : g0), n1 = a1 + (((1u + a1) & 1u) ? g1 : g0);
+      a0 = n0; a1 = n1;
+      if (hout[4 * l] != (int)a0 || hout[4 * l + 1] != (int)a1) bad++;
+    }
+  }
   if (n_failed) *n_failed = bad;
   if (bad) snprintf(c->err, sizeof(c->err), "selftest: %d primitive checks failed", bad);
   return RFID_OK;

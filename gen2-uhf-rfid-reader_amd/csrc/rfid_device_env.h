@@ -48,6 +48,12 @@ RFID_DEVICE int scan_add(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2 and 3
   return v;
 }
+// building blocks of a wave scan with any associative operation (lane order kept): the value N lanes down within the 16-lane
+// row, the last lane of the previous row (rows 1 and 3), lane 31 (rows 2 and 3), the lane below; lanes without a source get `fill`
+template <int N> RFID_DEVICE int dpp_row_shr(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x110 + N, 0xf, 0xf, false); }
+RFID_DEVICE int dpp_row_bcast15(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x142, 0xa, 0xf, false); }
+RFID_DEVICE int dpp_row_bcast31(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x143, 0xc, 0xf, false); }
+RFID_DEVICE int dpp_wave_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
 RFID_DEVICE float rint_f(float v) { return __builtin_rintf(v); }     // v_rndne_f32: to nearest, ties to even
 RFID_DEVICE float u2f(uint32_t u) { return __uint_as_float(u); }
 

@@ -1079,10 +1079,11 @@ struct LsCutArgs {
   int chunk;               // nominal unit length (decimated samples)
   int limit;               // search at most this far past the nominal boundary
   int max_b;               // boundaries per trace (row length of cut)
+  int quiet;               // carrier samples required right before a cut (LS_QUIET: the gate idles; ~WIN_LEN: avg_ampl is at rest)
   int *cut;                // [n_streams][max_b]: cut position for nominal boundary j (j >= 1), or -1
 };
 
-// one wave per (trace, nominal boundary j): the first position p >= j*chunk whose LS_QUIET preceding samples all have
+// one wave per (trace, nominal boundary j): the first position p >= j*chunk whose a.quiet preceding samples all have
 // |y|^2 >= 0.72 of the largest |y|^2 seen in the look-back region (carrier, no reader command), or -1
 RFID_KERNEL(64) void ls_cut_kernel(LsCutArgs a) {
   const int lane = wv::lane_id();
@@ -1094,7 +1095,7 @@ RFID_KERNEL(64) void ls_cut_kernel(LsCutArgs a) {
   int *out = a.cut + (int64_t)s * a.max_b + j;
   if (P >= n) { if (lane == 0) *out = -1; return; }
   const float2 *ys = a.y + (int64_t)s * a.y_stride;
-  int lo = P - LS_QUIET - 64;
+  int lo = P - a.quiet - 64;
   if (lo < 0) lo = 0;
   float ref = 0.0f;
   for (int base = lo; base < P; base += 64) {
@@ -1119,7 +1120,7 @@ RFID_KERNEL(64) void ls_cut_kernel(LsCutArgs a) {
     const uint64_t lowmask = wv::ballot(low);
     const uint64_t below = lowmask & lt;
     const int q = below ? (lane - 1 - (63 - __builtin_clzll(below))) : (run + lane);   // quiet samples right before i
-    const uint64_t hit = wv::ballot(i >= P && i < end && q >= LS_QUIET);
+    const uint64_t hit = wv::ballot(i >= P && i < end && q >= a.quiet);
     if (hit) found = base + wv::ffs64(hit);
     run = lowmask ? __builtin_clzll(lowmask) : (run + 64);   // quiet samples at the end of the step
   }

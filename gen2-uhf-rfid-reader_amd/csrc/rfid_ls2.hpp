@@ -41,6 +41,7 @@
 
 namespace rfidk {
 
+constexpr int LS2_FINE = 4;           // pieces per point of the idle-cut grid
 constexpr int LS2_WBUCKET = 320;      // two gate openings are at least RN16_WIN + T1_SAMPLES = 346 samples apart:
                                       // window records live in a per-trace table indexed by start / LS2_WBUCKET
 static_assert(LS2_WBUCKET <= RN16_WIN + T1_SAMPLES, "one window per bucket");
@@ -58,6 +59,7 @@ struct Ls2Ctl {   // control block in HBM, zeroed before every pass
   int fail;                   // != 0: the front end gave up (1 no cut, 2 avg_ampl, 3 state machine, 4 dc_est rounds exhausted)
   int ok;                     // 1: the window tables were produced (set last; the fallback scan skips itself on it)
   int n_pieces;               // pieces the traces were cut into
+  int n_heads;                // ... of them at idle cuts (or a trace's start): where the state-machine / dc_est passes can start
   int avg_count[LS2_MAXR];    // pieces on the re-run list after chain round r
   int fsm_count[LS2_MAXR];    // pieces appended to their predecessor in chain round r
   int dc_count[LS2_MAXR];     // units on the re-run list after chain round r
@@ -100,7 +102,9 @@ struct Ls2Args {
   const float2 *y; int64_t y_stride;
   const int64_t *lens; int64_t n_dec; int n_streams;
   int P, max_b;                 // nominal piece length; slots per trace
-  int *cut;                     // [NS] from ls_cut_kernel (slot 0 unused)
+  int Pc, max_bc;               // idle cuts are searched on a coarser grid: its step (= LS2_FINE * P), its points per trace
+  int *cut;                     // [n_streams][max_bc] from ls_cut_kernel (point 0 unused): where the gate idles
+  int *cutf;                    // [n_streams][max_b] from ls_cut_kernel: where avg_ampl is at rest (100 carrier samples before)
   Ls2Piece *piece;              // [NS]
   int *nextv, *prevv;           // [NS] next / previous slot in use of the same trace, -1 none
   float *amp, *dadd;            // [n_streams][y_stride]
@@ -150,6 +154,21 @@ RFID_DEVICE int ls2_margin(float v, uint32_t sb) {
   const int sh = e0 - e;
   const bool bad = (((b ^ sb) >> 31) != 0u) || sh < 0 || sh > 23 || e == 0 || e0 == 255 || e0 < 25;
   return bad ? 0 : (dist >> sh);
+}
+// the same for the two variants of one scanned step (chain_add_scan2 returned true: every partial sum lies in the binade of
+// its carry, so the shift is wave-uniform): min over both, 0 when a carry is of the wrong kind
+RFID_DEVICE int ls2_margin_scanned(float vA, float vB, uint32_t cinA, uint32_t cinB, uint32_t sbA, uint32_t sbB, bool e0_ok) {
+  const int shA = (int)((sbA >> 23) & 0xffu) - (int)((cinA >> 23) & 0xffu), shB = (int)((sbB >> 23) & 0xffu) - (int)((cinB >> 23) & 0xffu);
+  const bool good = e0_ok && (((cinA ^ sbA) | (cinB ^ sbB)) >> 31) == 0u && shA >= 0 && shA <= 23 && shB >= 0 && shB <= 23 &&
+                    (cinA & 0x7f800000u) != 0u && (cinB & 0x7f800000u) != 0u;
+  if (!good) return 0;
+  const int mA = (int)(wv::f2u(vA) & 0x7fffffu), mB = (int)(wv::f2u(vB) & 0x7fffffu);
+  const int uA = 0x800000 - mA, uB = 0x800000 - mB;
+  const int dA = ((mA < uA) ? mA : uA) >> shA, dB = ((mB < uB) ? mB : uB) >> shB;
+  return (dA < dB) ? dA : dB;
+}
+RFID_DEVICE bool ls2_e0_ok(uint32_t sbA, uint32_t sbB) {
+  return ((sbA >> 23) & 0xffu) >= 25u && ((sbA >> 23) & 0xffu) != 255u && ((sbB >> 23) & 0xffu) >= 25u && ((sbB >> 23) & 0xffu) != 255u;
 }
 RFID_DEVICE int ls2_wave_min(int v) {
 #pragma unroll
@@ -203,55 +222,76 @@ RFID_DEVICE bool chain_add_auto2(float ca, float cb2, float x, int lane, float &
 }
 
 // ---- 1. pieces -----------------------------------------------------------------------------------------------------
-// one thread per slot (trace s, grid point j): the piece that starts at the slot's cut and ends at the next cut in use
+// Where a trace is cut.  avg_ampl only needs a place where it is at rest (100 carrier samples before: ls_cut_kernel with
+// a short quiet zone, near every point of a grid of step P) -- short pieces keep every pass short.  The state machine
+// and dc_est can only start where the gate idles: those cuts come from ls_cut_kernel with the long quiet zone, searched
+// near every LS2_FINE-th grid point, and take the place of that grid point; the pieces that start there are "heads", the
+// others are scanned through from the head before them.  One thread per slot (trace s, grid point j): the piece from the slot's boundary to the next one in use.
+constexpr int LS2_REST = WIN_LEN + 28;   // carrier samples before a piece boundary: the amplitude ring holds carrier only, avg_ampl
+                                         // sits at the carrier's level (in its binade) -- away from such points it is on the move
+                                         // across binades and a run from a shifted start proves nothing
+RFID_DEVICE int ls2_boundary(const Ls2Args &a, const int *cut, const int *cutf, int n, int j, bool &head) {   // -1: slot not in use
+  const int J = j / LS2_FINE, q = j - J * LS2_FINE;
+  const int c = (J > 0) ? cut[J] : 0;
+  const bool found = (J == 0) ? (n > 0) : (c > 0 && c < n);
+  head = false;
+  if (q == 0 && found) { head = true; return c; }
+  const int p = (j > 0) ? cutf[j] : -1;
+  if (p <= 0 || p >= n) return -1;
+  if (found && p < c + a.P / 2) return -1;   // too close behind (or before) the idle cut that stands for this stretch's grid point
+  return p;
+}
 RFID_KERNEL(256) void ls2_pieces_kernel(Ls2Args a) {
   const int i = (int)(blockIdx.x * 256 + threadIdx.x);
   const int NS = a.n_streams * a.max_b;
   const int lane = wv::lane_id();
-  bool used = false;
+  bool used = false, is_head = false;
   if (i < NS) {
     const int s = i / a.max_b, j = i - s * a.max_b;
     const int n = ls2_trace_len(a, s);
-    const int *cut = a.cut + (int64_t)s * a.max_b;
-    auto at = [&](int jj) -> int {
-      if (jj == 0) return (n > 0) ? 0 : -1;
-      const int p = cut[jj];
-      return (p > 0 && p < n) ? p : -1;
-    };
-    const int p = at(j);
+    const int *cut = a.cut + (int64_t)s * a.max_bc;
+    const int *cutf = a.cutf + (int64_t)s * a.max_b;
+    bool head = false;
+    const int p = ls2_boundary(a, cut, cutf, n, j, head);
     Ls2Piece pc; pc.pos0 = 0; pc.len = 0;
     int nx = -1, pv = -1;
     if (p >= 0) {
       int end = n;
-      for (int j2 = j + 1; j2 < a.max_b; ++j2) { const int q = at(j2); if (q >= 0) { end = q; nx = s * a.max_b + j2; break; } }
-      for (int j2 = j - 1; j2 >= 0; --j2) if (at(j2) >= 0) { pv = s * a.max_b + j2; break; }
+      bool h2;
+      for (int j2 = j + 1; j2 < a.max_b; ++j2) { const int q = ls2_boundary(a, cut, cutf, n, j2, h2); if (q >= 0) { end = q; nx = s * a.max_b + j2; break; } }
+      for (int j2 = j - 1; j2 >= 0; --j2) if (ls2_boundary(a, cut, cutf, n, j2, h2) >= 0) { pv = s * a.max_b + j2; break; }
       pc.pos0 = p; pc.len = end - p;
-      if (a.hold_last && nx < 0) {   // the trace's last piece waits for more samples
-        pc.len = 0;
-        if (a.consumed) a.consumed[s] = p;
+      if (a.hold_last) {
+        // streaming: everything from the trace's last idle cut on waits for more samples
+        int last = 0;
+        for (int J = a.max_bc - 1; J >= 1; --J) { const int c = cut[J]; if (c > 0 && c < n) { last = c; break; } }
+        if (p >= last) pc.len = 0;
+        if (j == 0 && a.consumed) a.consumed[s] = last;
       }
     } else if (j == 0 && a.consumed) {
       a.consumed[s] = 0;
     }
     used = pc.len > 0;
+    is_head = used && head;
     a.piece[i] = pc;
     a.nextv[i] = nx;
     a.prevv[i] = pv;
     Ls2Fsm f;
-    f.head = used ? 1 : 0; f.unit = i; f.gen = -1; f.rerun = 0; f.nwin = 0; f.nepc = 0; f.last_end = -2147483647 - 1;
+    f.head = is_head ? 1 : 0; f.unit = i; f.gen = -1; f.rerun = 0; f.nwin = 0; f.nepc = 0; f.last_end = -2147483647 - 1;
     for (int k = 0; k < 6; ++k) { f.st[k] = 0; f.en[k] = 0; }
     a.fsm[i] = f;
     a.seq0[2 * i] = 0; a.seq0[2 * i + 1] = 0;
   }
-  const uint64_t m = wv::ballot(used);
+  const uint64_t m = wv::ballot(used), mh = wv::ballot(is_head);
   if (lane == 0 && m) wv::atomic_add(&a.ctl->n_pieces, wv::popc64(m));
+  if (lane == 0 && mh) wv::atomic_add(&a.ctl->n_heads, wv::popc64(mh));
 }
 
-// nothing to gain (no trace could be cut) -> the sequential scan; one thread
+// nothing to gain (no trace has an idle cut) -> the sequential scan; one thread
 RFID_KERNEL(64) void ls2_check_kernel(Ls2Args a) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   Ls2Ctl *c = a.ctl;
-  if (c->n_pieces <= 0 || (!a.force && c->n_pieces <= a.n_streams)) c->fail = 1;
+  if (c->n_heads <= 0 || (!a.force && c->n_heads <= a.n_streams)) c->fail = 1;
 }
 
 // ---- 2. avg_ampl ---------------------------------------------------------------------------------------------------
@@ -308,7 +348,7 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
   const uint32_t sbB = wv::f2u(sB);
   float avA = sA, avB = sB;
   int marg = ls2_margin(sA, sbA);
-  const bool e0_ok = ((sbA >> 23) & 0xffu) >= 25u && ((sbA >> 23) & 0xffu) != 255u && ((sbB >> 23) & 0xffu) >= 25u && ((sbB >> 23) & 0xffu) != 255u;
+  const bool e0_ok = ls2_e0_ok(sbA, sbB);
   const int nsteps = (n + 63) >> 6;
   constexpr int AHEAD = 4;
   float2 ybuf[AHEAD];
@@ -367,18 +407,11 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
           int mm;
           if (scanned) {
             // every partial sum of the step lies in its carry's binade (chain_add_scan): one shift for all lanes
-            const int shA = (int)((sbA >> 23) & 0xffu) - (int)((cinA >> 23) & 0xffu), shB = (int)((sbB >> 23) & 0xffu) - (int)((cinB >> 23) & 0xffu);
-            const bool good = e0_ok && (((cinA ^ sbA) | (cinB ^ sbB)) >> 31) == 0u && shA >= 0 && shA <= 23 && shB >= 0 && shB <= 23 &&
-                              (cinA & 0x7f800000u) != 0u && (cinB & 0x7f800000u) != 0u;
-            if (good) {
-              const int mA = (int)(wv::f2u(vA) & 0x7fffffu), mB = (int)(wv::f2u(vB) & 0x7fffffu);
-              const int uA = 0x800000 - mA, uB = 0x800000 - mB;
-              const int dA = ((mA < uA) ? mA : uA) >> shA, dB = ((mB < uB) ? mB : uB) >> shB;
+            mm = ls2_margin_scanned(vA, vB, cinA, cinB, sbA, sbB, e0_ok);
+            if (mm > 0) {
+              const int shA = (int)((sbA >> 23) & 0xffu) - (int)((cinA >> 23) & 0xffu);
               const int mV = valid ? ((dv - 3) >> (1 + shA)) : 0x7fffffff;
-              mm = (dA < dB) ? dA : dB;
               mm = (mV < mm) ? mV : mm;
-            } else {
-              mm = 0;
             }
           } else {
             const int mA = ls2_margin(vA, sbA), mB = ls2_margin(vB, sbB);
@@ -445,22 +478,31 @@ RFID_DEVICE Ls2A32 ls2_elem32(float s, float eA, float eB) {
   return r;
 }
 RFID_DEVICE int ls2_apply32(const Ls2A32 f, int T) { return (int)((uint32_t)T + (uint32_t)((T & 1) ? f.c1 : f.c0)); }
-// inclusive scan over the 64 lanes in lane order (lane L: the composition of lanes 0..L)
+// inclusive scan over the 64 lanes in lane order (lane L: the composition of lanes 0..L): four steps within the 16-lane
+// rows, two across them (the identity (0, 0) where a lane has no source)
 RFID_DEVICE Ls2A32 ls2_wave_incl(Ls2A32 v, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    Ls2A32 o;
-    o.c0 = wv::shfl(v.c0, (lane - off) & 63); o.c1 = wv::shfl(v.c1, (lane - off) & 63);
-    const Ls2A32 c = ls2_comp32(o, v);
-    if (lane >= off) v = c;
-  }
+  (void)lane;
+  Ls2A32 o;
+  o.c0 = wv::dpp_row_shr<1>(v.c0, 0); o.c1 = wv::dpp_row_shr<1>(v.c1, 0); v = ls2_comp32(o, v);
+  o.c0 = wv::dpp_row_shr<2>(v.c0, 0); o.c1 = wv::dpp_row_shr<2>(v.c1, 0); v = ls2_comp32(o, v);
+  o.c0 = wv::dpp_row_shr<4>(v.c0, 0); o.c1 = wv::dpp_row_shr<4>(v.c1, 0); v = ls2_comp32(o, v);
+  o.c0 = wv::dpp_row_shr<8>(v.c0, 0); o.c1 = wv::dpp_row_shr<8>(v.c1, 0); v = ls2_comp32(o, v);
+  o.c0 = wv::dpp_row_bcast15(v.c0, 0); o.c1 = wv::dpp_row_bcast15(v.c1, 0); v = ls2_comp32(o, v);
+  o.c0 = wv::dpp_row_bcast31(v.c0, 0); o.c1 = wv::dpp_row_bcast31(v.c1, 0); v = ls2_comp32(o, v);
   return v;
 }
 RFID_DEVICE Ls2A32 ls2_wave_excl(const Ls2A32 incl, int lane) {
+  (void)lane;
   Ls2A32 e;
-  e.c0 = wv::shfl(incl.c0, (lane - 1) & 63); e.c1 = wv::shfl(incl.c1, (lane - 1) & 63);
-  if (lane == 0) { e.c0 = 0; e.c1 = 0; }
+  e.c0 = wv::dpp_wave_shr1(incl.c0, 0); e.c1 = wv::dpp_wave_shr1(incl.c1, 0);
   return e;
+}
+// device self-test of the wave scan above (rfid_selftest): in[2 * lane], in[2 * lane + 1] -> inclusive scan, exclusive scan
+RFID_KERNEL(64) void ls2_scan_selftest_kernel(const int *in, int *out) {
+  const int lane = wv::lane_id();
+  Ls2A32 v; v.c0 = in[2 * lane]; v.c1 = in[2 * lane + 1];
+  const Ls2A32 i = ls2_wave_incl(v, lane), e = ls2_wave_excl(i, lane);
+  out[4 * lane] = i.c0; out[4 * lane + 1] = i.c1; out[4 * lane + 2] = e.c0; out[4 * lane + 3] = e.c1;
 }
 constexpr int LS2_CHAIN_WAVES = LS2_CHAIN_THREADS / 64;
 
@@ -792,6 +834,7 @@ RFID_DEVICE void ls2_dc_unit(const Ls2Args &a, const int i, const bool first, co
   g.dcr_c = sre; g.dci_c = sim;
   float bre = sreB, bim = simB;   // variant B's carries
   int mre = ls2_margin(sre, sbr), mim = ls2_margin(sim, sbi);
+  const bool e0r_ok = ls2_e0_ok(sbr, sbrB), e0i_ok = ls2_e0_ok(sbi, sbiB);
   Ls2Win *wb = a.wb + (int64_t)s * a.wb_stride;
   for (int cur = i;;) {
     const Ls2Piece pc = a.piece[cur];
@@ -845,12 +888,16 @@ RFID_DEVICE void ls2_dc_unit(const Ls2Args &a, const int i, const bool first, co
                            }
                          },
                          tre, tim);
-            chain_add_auto2(g.dcr_c, bre, tre, lane, ar, br);
-            chain_add_auto2(g.dci_c, bim, tim, lane, ai, bi);
+            const uint32_t cr0 = wv::f2u(g.dcr_c), cr1 = wv::f2u(bre), ci0 = wv::f2u(g.dci_c), ci1 = wv::f2u(bim);
+            const bool scr = chain_add_auto2(g.dcr_c, bre, tre, lane, ar, br);
+            const bool sci = chain_add_auto2(g.dci_c, bim, tim, lane, ai, bi);
             g.dcr_c = wv::readlane(ar, 63); bre = wv::readlane(br, 63);
             g.dci_c = wv::readlane(ai, 63); bim = wv::readlane(bi, 63);
-            const int m1 = ls2_margin(ar, sbr), m2 = ls2_margin(br, sbrB), m3 = ls2_margin(ai, sbi), m4 = ls2_margin(bi, sbiB);
-            const int mr = (m1 < m2) ? m1 : m2, mi = (m3 < m4) ? m3 : m4;
+            int mr, mi;
+            if (scr) mr = ls2_margin_scanned(ar, br, cr0, cr1, sbr, sbrB, e0r_ok);
+            else { const int m1 = ls2_margin(ar, sbr), m2 = ls2_margin(br, sbrB); mr = (m1 < m2) ? m1 : m2; }
+            if (sci) mi = ls2_margin_scanned(ai, bi, ci0, ci1, sbi, sbiB, e0i_ok);
+            else { const int m3 = ls2_margin(ai, sbi), m4 = ls2_margin(bi, sbiB); mi = (m3 < m4) ? m3 : m4; }
             mre = (mr < mre) ? mr : mre;
             mim = (mi < mim) ? mi : mim;
           } else {

@@ -10,23 +10,27 @@
 
 namespace rfidk {
 
-constexpr int LS2_TARGET_PIECES = 32768;   // pieces per pass to aim for (all traces together)
-constexpr int LS2_MIN_PIECE = 2048;        // ... of at least this many decimated samples (a cut needs LS_QUIET = 1615 idle ones before it)
+constexpr int LS2_TARGET_PIECES = 131072;  // pieces per pass to aim for (all traces together)
+constexpr int LS2_MIN_PIECE = 512;         // ... of at least this many decimated samples; idle cuts are searched every LS2_FINE pieces
+                                           // (a cut needs LS_QUIET = 1615 idle samples before it)
 
 struct Ls2Geometry {
-  int P = 0, max_b = 0, NS = 0;
+  int P = 0, max_b = 0, NS = 0;            // piece length, slots per trace, slots
+  int Pc = 0, max_bc = 0;                  // the idle-cut grid
   int64_t vstride = 0, wb_stride = 0;
 };
 // P: nominal piece length for `n_streams` traces of (at most) n_dec decimated samples; 0 = the traces are too short to cut
 inline Ls2Geometry ls2_geometry(int n_streams, int64_t n_dec, int min_piece = LS2_MIN_PIECE, int target = LS2_TARGET_PIECES) {
   Ls2Geometry g;
-  if (n_streams <= 0 || n_dec < 2 * (int64_t)min_piece) return g;
+  if (n_streams <= 0 || n_dec < 2 * (int64_t)LS2_FINE * min_piece) return g;
   int64_t P = ((int64_t)n_streams * n_dec + target - 1) / target;
   if (P < min_piece) P = min_piece;
   P = (P + 63) & ~63LL;
-  if (P > 0x3fffffff) return g;
+  if (P * LS2_FINE > 0x3fffffff) return g;
   g.P = (int)P;
-  g.max_b = (int)(n_dec / P) + 1;
+  g.Pc = (int)(P * LS2_FINE);
+  g.max_bc = (int)(n_dec / g.Pc) + 1;
+  g.max_b = g.max_bc * LS2_FINE;
   g.NS = n_streams * g.max_b;
   g.vstride = (n_dec >> 6) + g.max_b + 2;
   g.wb_stride = n_dec / LS2_WBUCKET + 2;
@@ -35,14 +39,15 @@ inline Ls2Geometry ls2_geometry(int n_streams, int64_t n_dec, int min_piece = LS
 
 // work space: one allocation, carved up here (offsets in bytes, 256-byte aligned)
 struct Ls2Layout {
-  size_t cut, piece, nextv, prevv, amp, dadd, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, drun, dT, dlist, seq0, flat_base, ctl, consumed, total;
+  size_t cut, cutf, piece, nextv, prevv, amp, dadd, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, drun, dT, dlist, seq0, flat_base, ctl, consumed, total;
 };
 inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_stride) {
   Ls2Layout L;
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
   const size_t NS = (size_t)g.NS, B = (size_t)n_streams;
-  L.cut = take(sizeof(int) * NS);
+  L.cut = take(sizeof(int) * B * (size_t)g.max_bc);
+  L.cutf = take(sizeof(int) * NS);
   L.piece = take(sizeof(Ls2Piece) * NS);
   L.nextv = take(sizeof(int) * NS);
   L.prevv = take(sizeof(int) * NS);
@@ -68,8 +73,8 @@ inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_strid
   return L;
 }
 inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geometry &g) {
-  a.P = g.P; a.max_b = g.max_b; a.vstride = g.vstride; a.wb_stride = g.wb_stride;
-  a.cut = (int *)(base + L.cut); a.piece = (Ls2Piece *)(base + L.piece);
+  a.P = g.P; a.max_b = g.max_b; a.Pc = g.Pc; a.max_bc = g.max_bc; a.vstride = g.vstride; a.wb_stride = g.wb_stride;
+  a.cut = (int *)(base + L.cut); a.cutf = (int *)(base + L.cutf); a.piece = (Ls2Piece *)(base + L.piece);
   a.nextv = (int *)(base + L.nextv); a.prevv = (int *)(base + L.prevv);
   a.amp = (float *)(base + L.amp); a.dadd = (float *)(base + L.dadd);
   a.votes = (uint64_t *)(base + L.votes); a.closed = (uint64_t *)(base + L.closed); a.openinfo = (int *)(base + L.openinfo);
@@ -86,11 +91,17 @@ inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geomet
 inline void ls2_enqueue(Ls2Args a, bool search_cuts = true) {   // (search_cuts = false: a.cut is given -- tests)
   const int NS = a.n_streams * a.max_b;
   const int B = a.n_streams;
-  if (a.max_b > 1 && search_cuts) {
+  if (a.max_bc > 1 && search_cuts) {
     LsCutArgs ca;
-    ca.y = a.y; ca.y_stride = a.y_stride; ca.lens = a.lens; ca.n_dec = a.n_dec; ca.chunk = a.P; ca.limit = a.P / 2;
-    ca.max_b = a.max_b; ca.cut = a.cut;
-    LS2_LAUNCH(ls_cut_kernel, a.max_b - 1, B, 64, ca);
+    ca.y = a.y; ca.y_stride = a.y_stride; ca.lens = a.lens; ca.n_dec = a.n_dec; ca.chunk = a.Pc; ca.limit = a.Pc / 2;
+    ca.max_b = a.max_bc; ca.cut = a.cut; ca.quiet = LS_QUIET;
+    LS2_LAUNCH(ls_cut_kernel, a.max_bc - 1, B, 64, ca);
+  }
+  {
+    LsCutArgs cf;
+    cf.y = a.y; cf.y_stride = a.y_stride; cf.lens = a.lens; cf.n_dec = a.n_dec; cf.chunk = a.P; cf.limit = a.P / 2;
+    cf.max_b = a.max_b; cf.cut = a.cutf; cf.quiet = LS2_REST;
+    LS2_LAUNCH(ls_cut_kernel, a.max_b - 1, B, 64, cf);
   }
   a.round = 0;
   LS2_LAUNCH(ls2_pieces_kernel, (NS + 255) / 256, 1, 256, a);

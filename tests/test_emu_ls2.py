@@ -55,7 +55,7 @@ def test_ls2_matches_oracle_and_avg_recurrence(emu_mod, oracle_mod, synth_mod):
     L = min(map(len, ts))
     r = _check(emu_mod, oracle_mod, np.stack([t[:L] for t in ts]), expect_ok=1)
     c = r["ctl"]
-    assert c["n_pieces"] >= 12 and c["n_units"] == c["n_pieces"] and c["n_windows"] == len(r["windows"])
+    assert c["n_pieces"] >= 60 and c["n_units"] == c["n_heads"] >= 12 and c["n_windows"] == len(r["windows"])
     del rng
 
 
@@ -67,24 +67,22 @@ def test_ls2_rerun_rounds_are_exercised(emu_mod, oracle_mod, synth_mod):
     assert r["ctl"]["dc_reruns"] > 0 and r["ctl"]["dc_rounds"] >= 2, r["ctl"]
     # few, long pieces: avg_ampl too
     r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, target=6)
-    assert r["ctl"]["n_pieces"] <= 8
+    assert r["ctl"]["n_pieces"] <= 8 and r["ctl"]["avg_reruns"] > 0, r["ctl"]
 
 
 def test_ls2_carrier_at_a_power_of_two(emu_mod, oracle_mod, synth_mod):
     """A carrier whose filtered amplitude is exactly 16.0: avg_ampl hovers at a binade edge, hardly any run is provable
     (pieces start in one binade and end in the other, partial sums sit next to the edge) and the chain only advances by
     runs from exact or neighbouring starts, a few pieces per round.  Whatever the front end then does -- settle after
-    many rounds, or give up and leave the trace to the sequential scan -- the result must be the sequential scan's, and
-    avg_ampl at every cut the in-order recurrence's (a piece accepted with a shift scaled by the wrong binade's ulp would
-    show here and nowhere else).  A longer trace of the same kind runs out of rounds: ok = 0, same result."""
+    many rounds (few, long pieces), or give up and leave the trace to the sequential scan -- the result must be the
+    sequential scan's, and avg_ampl at every cut the in-order recurrence's (a piece accepted with a shift scaled by the
+    wrong binade's ulp would show here and nowhere else)."""
     t = synth_mod.make_trace(n_rounds=12, sigma=0.01, seed=5).samples
     t = (t * np.complex64(0.64)).astype(np.complex64)
-    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1)
-    assert r["ctl"]["avg_rounds"] >= 4 and r["ctl"]["n_pieces"] >= 7, r["ctl"]
-    t = synth_mod.make_trace(n_rounds=40, sigma=0.01, seed=6).samples
-    t = (t * np.complex64(0.64)).astype(np.complex64)
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, target=8, min_piece=2048)
+    assert r["ctl"]["avg_rounds"] >= 4 and r["ctl"]["n_pieces"] >= 5, r["ctl"]
     r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=0)
-    assert r["ctl"]["avg_count9"] > 0, r["ctl"]
+    assert r["ctl"]["avg_count9"] > 0 and r["ctl"]["n_pieces"] > 20, r["ctl"]
 
 
 def test_ls2_ragged_batch_collisions_and_limits(emu_mod, oracle_mod, synth_mod):
@@ -108,15 +106,24 @@ def test_ls2_cuts_that_are_not_idle_are_withdrawn(emu_mod, oracle_mod, synth_mod
     state machine's end state does not meet the idle state assumed at the next cut (or the dc ring is not the last 48
     samples), the pieces are appended to their predecessors (n_units < n_pieces) and scanned through; avg_ampl needs no
     idle point at all.  Still the sequential scan, bit for bit."""
-    t = synth_mod.make_trace(n_rounds=6, sigma=0.02, seed=77, t1_jitter_raw=3).samples
+    t = synth_mod.make_trace(n_rounds=8, sigma=0.02, seed=77, t1_jitter_raw=3).samples
     o = oracle_mod.run_trace(t)
     n = len(t) // 5
-    opens = [int(p) for p in o.open_idx]
-    cuts = sorted({2048 + 13, opens[2] + 100, opens[3] + 251 + 20, opens[5] - 30, opens[6] + 1370 + 2, opens[8] - 400, n - 3000})
-    cuts = [c for c in cuts if 64 < c < n - 64]
-    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, cuts=cuts, min_piece=64, target=1 << 20)
+    Pc = 4 * 512
+    cand = []
+    for k, (p, ty) in enumerate(zip(o.open_idx, o.dumps["type"])):
+        wlen = 1370 if ty else 250
+        cand += [int(p) + 100, int(p) - 30, int(p) + wlen + 2, int(p) - 400, int(p) + wlen + 47]
+    cuts, seen = [], set()
+    for c in cand:                       # a forced cut stands for the grid point right before it
+        J = c // Pc
+        if 1 <= J and c % Pc < Pc // 2 and J not in seen and c < n - 64:
+            seen.add(J)
+            cuts.append(c)
+    assert len(cuts) >= 6
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, cuts=sorted(cuts))
     c = r["ctl"]
-    assert c["n_pieces"] == len(cuts) + 1 and c["n_units"] < c["n_pieces"] and c["fsm_rounds"] >= 2, c
+    assert c["n_heads"] == len(cuts) + 1 and c["n_units"] < c["n_heads"] and c["fsm_rounds"] >= 2, c
 
 
 def test_ls2_streaming_form_carries_the_gate_state(emu_mod, oracle_mod, synth_mod):

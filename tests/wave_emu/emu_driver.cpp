@@ -194,7 +194,7 @@ int emu_batch_process(const float *raw, int B, long stride, long n_raw, const in
 // The long-stream front end (rfid_ls2.hpp) in place of the sequential gate scan: mf -> pieces / avg_ampl / state machine /
 // dc_est / windows (the launch list of rfid_ls2_enqueue.hpp, as the library enqueues it) -> the sequential scan as the
 // skipped-or-not fallback -> decode -> stats.  min_piece / target shrink the pieces so that small traces are cut many
-// times.  ctl_out: the Ls2Ctl block as ints.  carry / hold_last = the streaming form (state_blob: GateState of trace 0 in
+// times.  cuts: test hook -- the idle-cut search is replaced by these positions (trace 0).  ctl_out: the Ls2Ctl block as ints.  carry / hold_last = the streaming form (state_blob: GateState of trace 0 in
 // and out, consumed[0] = first unprocessed sample).
 int emu_ls2_process(const float *raw, int B, long stride, long n_raw, const int64_t *lens, int fixed_q,
                     int max_num_queries, int number_unique_tags, rfid_window *windows,
@@ -247,8 +247,11 @@ int emu_ls2_process(const float *raw, int B, long stride, long n_raw, const int6
     a.carry = state_blob ? gstate.data() : nullptr; a.carry_out = state_blob ? gstate.data() : nullptr;
     a.hold_last = hold_last; a.force = state_blob ? 1 : 0;
     if (cuts) {   // test hook: cut trace 0 at the given positions (ascending) instead of searching idle points
-      for (int i = 0; i < geo.NS; ++i) a.cut[i] = -1;
-      for (int k = 0; k < n_cuts && k + 1 < geo.max_b; ++k) a.cut[k + 1] = cuts[k];
+      for (int i = 0; i < B * geo.max_bc; ++i) a.cut[i] = -1;
+      for (int k = 0; k < n_cuts; ++k) {   // (a cut stands for the grid point it lies behind, less than half a step away)
+        const int J = cuts[k] / geo.Pc;
+        if (J >= 1 && J < geo.max_bc && cuts[k] - J * geo.Pc < geo.Pc / 2) a.cut[J] = cuts[k];
+      }
     }
     ls2_enqueue(a, cuts == nullptr);
     ctl_host = *a.ctl;

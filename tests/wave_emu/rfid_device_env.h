@@ -121,6 +121,25 @@ static inline int scan_add(int v) {
   for (int i = 0; i <= lane_id(); ++i) acc += (int)(uint32_t)b[i];
   return acc;
 }
+template <int N> static inline int dpp_row_shr(int v, int fill) {
+  const uint64_t *b = emu::exchange((uint32_t)v);
+  const int l = lane_id();
+  return ((l & 15) >= N) ? (int)(uint32_t)b[l - N] : fill;
+}
+static inline int dpp_row_bcast15(int v, int fill) {
+  const uint64_t *b = emu::exchange((uint32_t)v);
+  const int l = lane_id(), row = l >> 4;
+  return (row == 1 || row == 3) ? (int)(uint32_t)b[16 * row - 1] : fill;
+}
+static inline int dpp_row_bcast31(int v, int fill) {
+  const uint64_t *b = emu::exchange((uint32_t)v);
+  return (lane_id() >= 32) ? (int)(uint32_t)b[31] : fill;
+}
+static inline int dpp_wave_shr1(int v, int fill) {
+  const uint64_t *b = emu::exchange((uint32_t)v);
+  const int l = lane_id();
+  return (l > 0) ? (int)(uint32_t)b[l - 1] : fill;
+}
 static inline float rint_f(float v) { return nearbyintf(v); }   // default rounding mode: to nearest, ties to even
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline float readlane(float v, int k) { return emu::u2f((uint32_t)emu::exchange(emu::f2u(v))[k & 63]); }
