@@ -277,6 +277,7 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
   HIPCHK(c, hipMemsetAsync(a.ctl, 0, sizeof(Ls2Ctl), c->stream));
   HIPCHK(c, hipMemsetAsync(a.consumed, 0, sizeof(int) * (size_t)c->B, c->stream));
   HIPCHK(c, hipMemsetAsync(a.wb, 0, sizeof(Ls2Win) * (size_t)c->B * (size_t)geo.wb_stride, c->stream));
+  HIPCHK(c, hipMemsetAsync(a.votes, 0, sizeof(uint64_t) * 2 * (size_t)c->B * (size_t)geo.vstride, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_flat_count, 0, 2 * sizeof(int), c->stream));
   ls2_stream = c->stream;
   ls2_enqueue(a);

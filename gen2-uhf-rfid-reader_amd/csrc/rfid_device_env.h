@@ -122,6 +122,8 @@ RFID_DEVICE void wave_sync() {
 }
 RFID_DEVICE int atomic_add(int *p, int v) { return atomicAdd(p, v); }
 RFID_DEVICE int atomic_min(int *p, int v) { return atomicMin(p, v); }
+RFID_DEVICE void atomic_or64(uint64_t *p, uint64_t v) { atomicOr(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v); }
+RFID_DEVICE void atomic_and64(uint64_t *p, uint64_t v) { atomicAnd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v); }
 // this wave's global stores are visible device-wide when this returns
 RFID_DEVICE void global_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
 // global load that bypasses the per-CU vector cache (device-coherent): for data another wave of

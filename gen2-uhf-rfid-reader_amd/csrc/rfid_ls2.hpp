@@ -84,11 +84,12 @@ struct Ls2Fsm {   // per slot
   int unit;       // slot of the head of the unit the piece belongs to
   int gen;        // generation of the state-machine launch that last covered the piece
   int rerun;      // (head) scan again in the next round
-  int nwin;       // complete windows opened in the piece
+  int nwin;       // (head) complete windows opened in the unit
   int nepc;       //   ... of them EPC windows
-  int last_end;   // end of the last window opened in the unit up to and including this piece (INT_MIN: none)
+  int last_end;   // (head) end of the unit's last window (INT_MIN: none)
+  int u1;         // (head) end of the unit: the next head's start, or the end of what is processed of the trace
   int st[6];      // (head) start state used: n_samples, signal_state, num_pulses, gate_open, n_to_ungate, wtype
-  int en[6];      // state after the piece
+  int en[6];      // (head) state after the unit
 };
 struct Ls2Win {   // one gate opening
   int start;
@@ -108,10 +109,11 @@ struct Ls2Args {
   Ls2Piece *piece;              // [NS]
   int *nextv, *prevv;           // [NS] next / previous slot in use of the same trace, -1 none
   float *amp, *dadd;            // [n_streams][y_stride]
-  uint64_t *votes;              // [n_streams][vstride][2]: below, above
-  uint64_t *closed;             // [n_streams][vstride]
-  int *openinfo;                // [n_streams][vstride]: lane | type << 8 of the step's opening, 0xff none
-  int64_t vstride;
+  uint64_t *votes;              // [n_streams][vstride][2]: below, above; bit b of word w = sample 64 w + b (zeroed before a pass)
+  uint64_t *closed;             // [n_streams][cstride]
+  int *openinfo;                // [n_streams][cstride]: lane | type << 8 of the step's opening, 0xff none
+  int64_t vstride;              // votes: one word per absolute 64-sample block of the trace
+  int64_t cstride;              // closed / openinfo: a unit's steps start at its first sample: (start >> 6) + k + its idle-grid index
   Ls2AvgRun *arun; int *aT;     // [NS]; aT = true start of the piece (monotone integer image)
   int *alist;                   // [2][NS]: the re-run list of chain round r at (r & 1)
   Ls2Aff *aover;                // [NS] chain scratch: a piece's function with an exact candidate end put in
@@ -277,7 +279,7 @@ RFID_KERNEL(256) void ls2_pieces_kernel(Ls2Args a) {
     a.nextv[i] = nx;
     a.prevv[i] = pv;
     Ls2Fsm f;
-    f.head = is_head ? 1 : 0; f.unit = i; f.gen = -1; f.rerun = 0; f.nwin = 0; f.nepc = 0; f.last_end = -2147483647 - 1;
+    f.head = is_head ? 1 : 0; f.unit = i; f.gen = -1; f.rerun = 0; f.nwin = 0; f.nepc = 0; f.last_end = -2147483647 - 1; f.u1 = 0;
     for (int k = 0; k < 6; ++k) { f.st[k] = 0; f.en[k] = 0; }
     a.fsm[i] = f;
     a.seq0[2 * i] = 0; a.seq0[2 * i + 1] = 0;
@@ -302,32 +304,35 @@ template <bool FIRST>
 RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
   const int s = i / a.max_b, j = i - s * a.max_b;
   const Ls2Piece pc = a.piece[i];
-  const int pos0 = wv::uniform(pc.pos0), n = wv::uniform(pc.len);
+  const int p0 = wv::uniform(pc.pos0), n = wv::uniform(pc.len);
   if (n <= 0) return;
-  const int64_t row = (int64_t)s * a.y_stride + pos0;
-  const float2 *ys = a.y + row;
-  float *ampc = a.amp + row, *dc = a.dadd + row;
-  uint64_t *votes = a.votes + 2 * ((int64_t)s * a.vstride + (pos0 >> 6) + j);
+  // The piece is walked in the trace's own 64-sample blocks (lane L of step k = sample 64 (w0 + k) + L), so that the votes
+  // of a sample land at the same bit whatever piece it belongs to; the first and last block are shared with the
+  // neighbours (their lanes outside the piece add +0 to the sums and cast no vote).
+  const int p1 = p0 + n, w0 = p0 >> 6, nsteps = ((p1 + 63) >> 6) - w0;
+  const int n_total = ls2_trace_len(a, s);
+  const int64_t row = (int64_t)s * a.y_stride;
+  const float2 *yr = a.y + row;
+  float *ampr = a.amp + row, *dr = a.dadd + row;
+  uint64_t *votes = a.votes + 2 * ((int64_t)s * a.vstride + w0);
+  const int base = 64 * w0;
   float sA;
   float a2 = 0.0f, a1 = 0.0f;   // amplitudes of the 128 samples before the step (the ring of gate_impl.cc:131 holds the last 100)
   if (FIRST) {
-    if (pos0 >= 128) {
-      const float2 p2 = ys[lane - 128], p1 = ys[lane - 64];
-      a2 = wv::hypot_f(p2.x, p2.y);
-      a1 = wv::hypot_f(p1.x, p1.y);
-    } else if (a.carry) {
-      // sample -k (k = 1..100) of the carried ring: win[(win_index - k) mod 100] (win_index = the oldest = next written)
-      const GateState *cs = a.carry + s;
-      const int wi = wv::uniform(cs->win_index);
-      const int k1 = 64 - lane, k2 = 128 - lane;
-      a1 = cs->win[(wi - k1 + 2 * WIN_LEN) % WIN_LEN];
-      a2 = (k2 <= WIN_LEN) ? cs->win[(wi - k2 + 2 * WIN_LEN) % WIN_LEN] : 0.0f;
-    }
+    // |x| of sample idx < base: from the samples, or (before the start of the trace) the carried ring / the fresh gate's zeros
+    auto hist = [&](int idx) -> float {
+      if (idx >= 0) { const float2 v = yr[idx]; return wv::hypot_f(v.x, v.y); }
+      if (!a.carry || idx < -WIN_LEN) return 0.0f;
+      const GateState *cs = a.carry + s;   // sample -k (k = 1..100): win[(win_index - k) mod 100] (win_index = the oldest = next written)
+      return cs->win[(cs->win_index + idx + 2 * WIN_LEN) % WIN_LEN];
+    };
+    a2 = hist(base - 128 + lane);
+    a1 = hist(base - 64 + lane);
     if (j == 0) {
       sA = a.carry ? wv::uniform(a.carry[s].avg_ampl) : 0.0f;   // the exact start of the trace
     } else {
-      // first guess: the ring mean (what avg_ampl is up to its rounding drift): lanes 28..63 of a2 and all of a1
-      float part = a1 + ((lane >= 28) ? a2 : 0.0f);
+      // first guess: the mean of the ring at the piece's first sample (what avg_ampl is up to its rounding drift)
+      float part = hist(p0 - WIN_LEN + lane) + ((lane < WIN_LEN - 64) ? hist(p0 - WIN_LEN + 64 + lane) : 0.0f);
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) part += wv::shfl_xor(part, off);
       sA = wv::uniform(part) / WIN_LEN_F;
@@ -349,15 +354,14 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
   float avA = sA, avB = sB;
   int marg = ls2_margin(sA, sbA);
   const bool e0_ok = ls2_e0_ok(sbA, sbB);
-  const int nsteps = (n + 63) >> 6;
   constexpr int AHEAD = 4;
   float2 ybuf[AHEAD];
   float abuf[AHEAD], dbuf[AHEAD];
 #pragma unroll
   for (int u = 0; u < AHEAD; ++u) {
-    const int idx = 64 * u + lane;
-    if (FIRST) ybuf[u] = (idx < n) ? ys[idx] : make_float2(0.0f, 0.0f);
-    else { abuf[u] = (idx < n) ? ampc[idx] : 0.0f; dbuf[u] = (idx < n) ? dc[idx] : 0.0f; }
+    const int idx = base + 64 * u + lane;
+    if (FIRST) ybuf[u] = (idx < n_total) ? yr[idx] : make_float2(0.0f, 0.0f);
+    else { const bool in = idx >= p0 && idx < p1; abuf[u] = in ? ampr[idx] : 0.0f; dbuf[u] = in ? dr[idx] : 0.0f; }
   }
   uint64_t my_lt = 0, my_gt = 0;   // lane (k & 63) keeps the votes of step k until 64 steps are stored together
   for (int kb = 0; kb < nsteps; kb += AHEAD) {
@@ -365,24 +369,26 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
     for (int u = 0; u < AHEAD; ++u) {
       const int k = kb + u;
       if (k < nsteps) {
-        const bool valid = 64 * k + lane < n;
+        const int idx = base + 64 * k + lane;
+        const bool valid = idx >= p0 && idx < p1;
         float amp, d;
         if (FIRST) {
           const float2 v = ybuf[u];
-          { const int idx = 64 * (k + AHEAD) + lane; ybuf[u] = (idx < n) ? ys[idx] : make_float2(0.0f, 0.0f); }
+          { const int nx = idx + 64 * AHEAD; ybuf[u] = (nx < n_total) ? yr[nx] : make_float2(0.0f, 0.0f); }
           amp = wv::hypot_f(v.x, v.y);
           // sample i - 100: lanes 0..35 take it from two steps back (lane + 28), lanes 36..63 from the previous step (lane - 36)
           const float o2 = wv::shfl(a2, (lane + 28) & 63), o1 = wv::shfl(a1, (lane - 36) & 63);
           const float old = (lane < 36) ? o2 : o1;
           const float nd = valid ? (amp - old) : 0.0f;
           d = div_const<WIN_LEN>(nd);
-          if (valid) { ampc[64 * k + lane] = amp; dc[64 * k + lane] = d; }
+          if (valid) { ampr[idx] = amp; dr[idx] = d; }
           a2 = a1; a1 = amp;
         } else {
           amp = abuf[u]; d = dbuf[u];
-          const int idx = 64 * (k + AHEAD) + lane;
-          abuf[u] = (idx < n) ? ampc[idx] : 0.0f;
-          dbuf[u] = (idx < n) ? dc[idx] : 0.0f;
+          const int nx = idx + 64 * AHEAD;
+          const bool in = nx >= p0 && nx < p1;
+          abuf[u] = in ? ampr[nx] : 0.0f;
+          dbuf[u] = in ? dr[nx] : 0.0f;
         }
         float vA, vB;
         const uint32_t cinA = wv::f2u(avA), cinB = wv::f2u(avB);
@@ -398,7 +404,6 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
         const float thresh = vA * THRESH_FRACTION;
         const uint64_t below = wv::ballot(valid && amp < thresh);
         const uint64_t above = wv::ballot(valid && amp > thresh);
-        if (lane == (k & 63)) { my_lt = below; my_gt = above; }
         // margin: the partial sums of both variants against the powers of two, |x| against the threshold
         {
           const uint32_t tb = wv::f2u(thresh), ab = wv::f2u(amp);
@@ -423,9 +428,23 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
           }
           marg = (mm < marg) ? mm : marg;
         }
+        // the votes: whole blocks are stored 64 at a time; the two blocks shared with the neighbouring pieces get this
+        // piece's bits put in (a re-run replaces its own bits only)
+        const bool shared = k == 0 || k == nsteps - 1;
+        if (shared) {
+          const uint64_t mine = wv::ballot(valid);
+          if (lane == 0) {
+            if (mine == ~0ull) { votes[2 * k] = below; votes[2 * k + 1] = above; }
+            else {
+              wv::atomic_and64(&votes[2 * k], ~mine); wv::atomic_or64(&votes[2 * k], below);
+              wv::atomic_and64(&votes[2 * k + 1], ~mine); wv::atomic_or64(&votes[2 * k + 1], above);
+            }
+          }
+        }
+        if (lane == (k & 63)) { my_lt = below; my_gt = above; }
         if ((k & 63) == 63 || k == nsteps - 1) {
-          const int k0 = k & ~63;
-          if (k0 + lane <= k) { votes[2 * (k0 + lane)] = my_lt; votes[2 * (k0 + lane) + 1] = my_gt; }
+          const int k0 = k & ~63, kl = k0 + lane;
+          if (kl <= k && kl != 0 && kl != nsteps - 1) { votes[2 * kl] = my_lt; votes[2 * kl + 1] = my_gt; }
         }
       }
     }
@@ -634,7 +653,9 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_avg_chain_kernel(Ls2Args a) {
 // ---- 3. state machine ----------------------------------------------------------------------------------------------
 constexpr int LS2_IDLE_N = GATE_N_SAT;   // the state at an idle cut: saturated count, POS_EDGE, no pulses, closed, next window an RN16
 
-// one wave per unit (head slot): the unit's pieces one after the other over the recorded votes; scalar work only
+// one wave per unit (head slot): from the head's first sample to the next head, over the recorded votes; scalar work only.
+// The unit's steps start at its first sample (step k = samples u0 + 64 k ..), the votes are kept per 64-sample block of
+// the trace: every step's two masks are cut out of two neighbouring words.
 RFID_KERNEL(64) void ls2_fsm_kernel(Ls2Args a) {
   Ls2Ctl *ctl = a.ctl;
   if (wv::uniform(ctl->fail) != 0) return;
@@ -648,8 +669,18 @@ RFID_KERNEL(64) void ls2_fsm_kernel(Ls2Args a) {
     Ls2Fsm *fh = a.fsm + i;
     if (wv::uniform(fh->head) == 0) continue;
     if (r > 0 && wv::uniform(fh->rerun) == 0) continue;
-    const int s = i / a.max_b;
+    const int s = i / a.max_b, J = (i - s * a.max_b) / LS2_FINE;
     const int n_total = ls2_trace_len(a, s);
+    // the unit: this piece and the ones behind it up to the next head
+    const int u0 = wv::uniform(a.piece[i].pos0);
+    int u1 = u0 + wv::uniform(a.piece[i].len);
+    for (int cur = i;;) {
+      const int nx = wv::uniform(a.nextv[cur]);
+      if (nx < 0 || wv::uniform(a.piece[nx].len) <= 0 || wv::uniform(a.fsm[nx].head) != 0) break;
+      if (lane == 0) a.fsm[nx].unit = i;
+      u1 = wv::uniform(a.piece[nx].pos0) + wv::uniform(a.piece[nx].len);
+      cur = nx;
+    }
     GateRegs g;
     g.avg_c = 0.0f; g.consumed = 0; g.stop = false;
     if (i == s * a.max_b) {   // the trace's first piece: the fresh gate, or the carried state
@@ -668,94 +699,92 @@ RFID_KERNEL(64) void ls2_fsm_kernel(Ls2Args a) {
       fh->st[0] = g.f_n; fh->st[1] = g.f_state; fh->st[2] = g.f_pulses; fh->st[3] = g.f_open; fh->st[4] = g.f_ung; fh->st[5] = g.f_type;
       fh->rerun = 0;
     }
-    int last_end = -2147483647 - 1;
-    int n_run = 0;
-    for (int cur = i;;) {
-      const Ls2Piece pc = a.piece[cur];
-      const int pos0 = wv::uniform(pc.pos0), n = wv::uniform(pc.len);
-      const int jc = cur - s * a.max_b;
-      const int64_t wbase = (int64_t)s * a.vstride + (pos0 >> 6) + jc;
-      const uint64_t *votes = a.votes + 2 * wbase;
-      uint64_t *closed = a.closed + wbase;
-      int *oinfo = a.openinfo + wbase;
-      Ls2Win *wb = a.wb + (int64_t)s * a.wb_stride;
-      const int nsteps = (n + 63) >> 6, nfull = n >> 6;
-      int nwin = 0, nepc = 0;
-      for (int k0 = 0; k0 < nsteps; k0 += 64) {
-        // 64 steps at a time: lane L holds the votes of step k0 + L and collects what that step leaves behind
-        const int nb = (nsteps - k0 < 64) ? (nsteps - k0) : 64;
-        const bool in = lane < nb;
-        const uint64_t v_lt = in ? votes[2 * (k0 + lane)] : 0ull;
-        const uint64_t v_gt = in ? votes[2 * (k0 + lane) + 1] : 0ull;
-        uint64_t my_closed = 0;
-        int my_open = 0xff;
-        // steps that cannot be skipped while the gate idles (closed, POS_EDGE, no command counted): any vote below the
-        // threshold, the partial step at the end, the lanes past the block
-        const uint64_t busy = wv::ballot(!(in && k0 + lane < nfull && v_lt == 0ull));
-        for (int kk = 0; kk < nb;) {
-          const int k = k0 + kk;
-          if (!g.f_open && g.f_state == 1 && g.f_pulses <= NUM_PULSES_CMD) {
-            // gate closed, nothing pending: every step without a sample below the threshold only counts samples
-            const uint64_t m = busy >> kk;
-            const int run = m ? wv::ffs64(m) : (64 - kk);
-            if (run > 0) {
-              if (lane >= kk && lane < kk + run) { my_closed = ~0ull; my_open = 0xff; }
-              const int64_t fn = (int64_t)g.f_n + 64ll * run;
-              g.f_n = (fn > GATE_N_SAT) ? GATE_N_SAT : (int)fn;
-              kk += run;
-              continue;
-            }
-          } else if (g.f_open) {
-            // inside a window: the steps that lie wholly inside it
-            const int rem = g.f_ung - g.f_n;
-            int run = (rem > 64) ? ((rem - 65) / 64 + 1) : 0;
-            const int room = nfull - k;
-            run = (run < room) ? run : room;
-            run = (run < nb - kk) ? run : (nb - kk);
-            if (run > 0) {
-              if (lane >= kk && lane < kk + run) { my_closed = 0ull; my_open = 0xff; }
-              g.f_n += 64 * run;
-              kk += run;
-              continue;
-            }
+    const int n = u1 - u0, off = u0 & 63;
+    const uint64_t *votes = a.votes + 2 * ((int64_t)s * a.vstride + (u0 >> 6));
+    const int64_t cbase = (int64_t)s * a.cstride + (u0 >> 6) + J;
+    uint64_t *closed = a.closed + cbase;
+    int *oinfo = a.openinfo + cbase;
+    Ls2Win *wb = a.wb + (int64_t)s * a.wb_stride;
+    const int nsteps = (n + 63) >> 6, nfull = n >> 6;
+    int nwin = 0, nepc = 0, last_end = -2147483647 - 1;
+    for (int k0 = 0; k0 < nsteps; k0 += 64) {
+      // 64 steps at a time: lane L holds the votes of step k0 + L and collects what that step leaves behind
+      const int nb = (nsteps - k0 < 64) ? (nsteps - k0) : 64;
+      const bool in = lane < nb;
+      uint64_t v_lt = in ? votes[2 * (k0 + lane)] : 0ull;        // (a unit's last word + 1 exists: vstride has the room)
+      uint64_t v_gt = in ? votes[2 * (k0 + lane) + 1] : 0ull;
+      if (off != 0) {
+        // step L = bits off.. of word L and bits ..off of word L + 1
+        const uint64_t x_lt = wv::uniform(votes[2 * (k0 + 64)]), x_gt = wv::uniform(votes[2 * (k0 + 64) + 1]);   // (word 64 of the block)
+        uint64_t n_lt = ((uint64_t)(uint32_t)wv::shfl((int)(uint32_t)(v_lt >> 32), (lane + 1) & 63) << 32) | (uint32_t)wv::shfl((int)(uint32_t)v_lt, (lane + 1) & 63);
+        uint64_t n_gt = ((uint64_t)(uint32_t)wv::shfl((int)(uint32_t)(v_gt >> 32), (lane + 1) & 63) << 32) | (uint32_t)wv::shfl((int)(uint32_t)v_gt, (lane + 1) & 63);
+        if (lane == 63) { n_lt = x_lt; n_gt = x_gt; }
+        v_lt = (v_lt >> off) | (n_lt << (64 - off));
+        v_gt = (v_gt >> off) | (n_gt << (64 - off));
+      }
+      uint64_t my_closed = 0;
+      int my_open = 0xff;
+      // steps that cannot be skipped while the gate idles (closed, POS_EDGE, no command counted): any vote below the
+      // threshold, the partial step at the end, the lanes past the block
+      const uint64_t busy = wv::ballot(!(in && k0 + lane < nfull && v_lt == 0ull));
+      for (int kk = 0; kk < nb;) {
+        const int k = k0 + kk;
+        if (!g.f_open && g.f_state == 1 && g.f_pulses <= NUM_PULSES_CMD) {
+          // gate closed, nothing pending: every step without a sample below the threshold only counts samples
+          const uint64_t m = busy >> kk;
+          const int run = m ? wv::ffs64(m) : (64 - kk);
+          if (run > 0) {
+            if (lane >= kk && lane < kk + run) { my_closed = ~0ull; my_open = 0xff; }
+            const int64_t fn = (int64_t)g.f_n + 64ll * run;
+            g.f_n = (fn > GATE_N_SAT) ? GATE_N_SAT : (int)fn;
+            kk += run;
+            continue;
           }
-          const uint64_t below = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(v_lt >> 32), kk) << 32) | (uint32_t)wv::readlane((int)(uint32_t)v_lt, kk);
-          const uint64_t above = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(v_gt >> 32), kk) << 32) | (uint32_t)wv::readlane((int)(uint32_t)v_gt, kk);
-          int nvalid = (n - 64 * k < 64) ? (n - 64 * k) : 64;
-          uint64_t closedmask, openmask;
-          int open_lane, open_type;
-          gate_fsm_step(0, g, below, above, 64 * k, nvalid, closedmask, openmask, open_lane, open_type);
-          if (open_lane != 0xff) {   // gate_impl.cc:164-180
-            const int start = pos0 + 64 * k + open_lane;
-            const int wlen = open_type ? EPC_WIN : RN16_WIN;
-            const int complete = (start + wlen <= n_total) ? 1 : 0;   // only complete windows reach the decoder (:223,:291)
-            if (lane == 0) {
-              Ls2Win *w = wb + start / LS2_WBUCKET;
-              if (w->tag != 0 && ((w->tag >> 8) == r + 1) && w->start != start) ctl->wb_clash = 1;   // (the table is cleared before every pass)
-              w->start = start;
-              w->tag = open_type | (complete << 1) | ((r + 1) << 8);
-            }
-            nwin += complete;
-            nepc += complete & open_type;
-            last_end = start + wlen;
+        } else if (g.f_open) {
+          // inside a window: the steps that lie wholly inside it
+          const int rem = g.f_ung - g.f_n;
+          int run = (rem > 64) ? ((rem - 65) / 64 + 1) : 0;
+          const int room = nfull - k;
+          run = (run < room) ? run : room;
+          run = (run < nb - kk) ? run : (nb - kk);
+          if (run > 0) {
+            if (lane >= kk && lane < kk + run) { my_closed = 0ull; my_open = 0xff; }
+            g.f_n += 64 * run;
+            kk += run;
+            continue;
           }
-          if (lane == kk) { my_closed = closedmask; my_open = open_lane | (open_type << 8); }
-          kk += 1;
         }
-        if (in) { closed[k0 + lane] = my_closed; oinfo[k0 + lane] = my_open; }
+        int nvalid = (n - 64 * k < 64) ? (n - 64 * k) : 64;
+        const uint64_t vm = (nvalid >= 64) ? ~0ull : ((1ull << nvalid) - 1ull);   // (the last step's word holds the next unit's votes too)
+        const uint64_t below = (((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(v_lt >> 32), kk) << 32) | (uint32_t)wv::readlane((int)(uint32_t)v_lt, kk)) & vm;
+        const uint64_t above = (((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(v_gt >> 32), kk) << 32) | (uint32_t)wv::readlane((int)(uint32_t)v_gt, kk)) & vm;
+        uint64_t closedmask, openmask;
+        int open_lane, open_type;
+        gate_fsm_step(0, g, below, above, 64 * k, nvalid, closedmask, openmask, open_lane, open_type);
+        if (open_lane != 0xff) {   // gate_impl.cc:164-180
+          const int start = u0 + 64 * k + open_lane;
+          const int wlen = open_type ? EPC_WIN : RN16_WIN;
+          const int complete = (start + wlen <= n_total) ? 1 : 0;   // only complete windows reach the decoder (:223,:291)
+          if (lane == 0) {
+            Ls2Win *w = wb + start / LS2_WBUCKET;
+            if (w->tag != 0 && ((w->tag >> 8) == r + 1) && w->start != start) ctl->wb_clash = 1;   // (the table is cleared before every pass)
+            w->start = start;
+            w->tag = open_type | (complete << 1) | ((r + 1) << 8);
+          }
+          nwin += complete;
+          nepc += complete & open_type;
+          last_end = start + wlen;
+        }
+        if (lane == kk) { my_closed = closedmask; my_open = open_lane | (open_type << 8); }
+        kk += 1;
       }
-      if (lane == 0) {
-        Ls2Fsm *f = a.fsm + cur;
-        f->unit = i; f->gen = r + 1; f->nwin = nwin; f->nepc = nepc; f->last_end = last_end;
-        f->en[0] = g.f_n; f->en[1] = g.f_state; f->en[2] = g.f_pulses; f->en[3] = g.f_open; f->en[4] = g.f_ung; f->en[5] = g.f_type;
-      }
-      n_run++;
-      const int nx = wv::uniform(a.nextv[cur]);
-      if (nx < 0) break;
-      if (wv::uniform(a.piece[nx].len) <= 0 || wv::uniform(a.fsm[nx].head) != 0) break;
-      cur = nx;
+      if (in) { closed[k0 + lane] = my_closed; oinfo[k0 + lane] = my_open; }
     }
-    if (lane == 0 && r > 0) wv::atomic_add(&ctl->fsm_reruns, n_run);
+    if (lane == 0) {
+      fh->unit = i; fh->gen = r + 1; fh->nwin = nwin; fh->nepc = nepc; fh->last_end = last_end; fh->u1 = u1;
+      fh->en[0] = g.f_n; fh->en[1] = g.f_state; fh->en[2] = g.f_pulses; fh->en[3] = g.f_open; fh->en[4] = g.f_ung; fh->en[5] = g.f_type;
+      if (r > 0) wv::atomic_add(&ctl->fsm_reruns, 1);
+    }
   }
 }
 
@@ -774,14 +803,15 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_fsm_chain_kernel(Ls2Args a) {
     if (a.piece[i].len <= 0 || a.fsm[i].head == 0) continue;
     const int p = a.prevv[i];
     if (p < 0) continue;
-    const Ls2Fsm &fp = a.fsm[p];
+    const int hp = a.fsm[p].unit;          // the unit the piece before this head belongs to
+    const Ls2Fsm &fp = a.fsm[hp];
     const Ls2Fsm &fi = a.fsm[i];
     bool same = fp.last_end <= a.piece[i].pos0 - DC_LEN;
     for (int k = 0; k < 6; ++k) same = same && (fp.en[k] == fi.st[k]);
     if (!same) {
       a.fsm[i].head = 0;
-      a.fsm[fp.unit].rerun = 1;   // (if that unit is appended to ITS predecessor in this round, the flag is stale: the
-      n_bad++;                    //  predecessor's unit is flagged by that very mismatch and scans through both)
+      a.fsm[hp].rerun = 1;   // (if that unit is appended to ITS predecessor in this round, the flag is stale: the
+      n_bad++;               //  predecessor's unit is flagged by that very mismatch and scans through both)
     }
   }
   if (n_bad) wv::atomic_add(&ctl->fsm_count[r], n_bad);
@@ -836,21 +866,20 @@ RFID_DEVICE void ls2_dc_unit(const Ls2Args &a, const int i, const bool first, co
   int mre = ls2_margin(sre, sbr), mim = ls2_margin(sim, sbi);
   const bool e0r_ok = ls2_e0_ok(sbr, sbrB), e0i_ok = ls2_e0_ok(sbi, sbiB);
   Ls2Win *wb = a.wb + (int64_t)s * a.wb_stride;
-  for (int cur = i;;) {
-    const Ls2Piece pc = a.piece[cur];
-    const int pos0 = wv::uniform(pc.pos0), n = wv::uniform(pc.len);
-    const int jc = cur - s * a.max_b;
-    const int64_t wbase = (int64_t)s * a.vstride + (pos0 >> 6) + jc;
-    const uint64_t *closed = a.closed + wbase;
-    const int *oinfo = a.openinfo + wbase;
+  {
+    // the unit: from the head's first sample to the next head (the state-machine pass left its end, its closed samples
+    // and its gate openings, step k = samples upos0 + 64 k ..)
+    const int pos0 = upos0, n = wv::uniform(a.fsm[i].u1) - upos0;
+    const int64_t cbase = (int64_t)s * a.cstride + (pos0 >> 6) + (i - s * a.max_b) / LS2_FINE;
+    const uint64_t *closed = a.closed + cbase;
+    const int *oinfo = a.openinfo + cbase;
     const float2 *ys = yrow + pos0;
     const int nsteps = (n + 63) >> 6;
     constexpr int AHEAD = 4;
     float2 buf[AHEAD];
 #pragma unroll
     for (int u = 0; u < AHEAD; ++u) { const int idx = 64 * u + lane; buf[u] = (idx < n) ? ys[idx] : make_float2(0.0f, 0.0f); }
-    // the samples of the step before the piece (x[i-48] of the first step's lanes 0..47 when everything around is closed)
-    float2 before = (pos0 + lane - 64 >= 0) ? ys[lane - 64] : make_float2(0.0f, 0.0f);
+    float2 before = make_float2(0.0f, 0.0f);   // the samples of the previous step
     uint64_t masks = 0;
     int oi_l = 0xff;
     for (int kb = 0; kb < nsteps; kb += AHEAD) {
@@ -916,10 +945,6 @@ RFID_DEVICE void ls2_dc_unit(const Ls2Args &a, const int i, const bool first, co
         }
       }
     }
-    const int nx = wv::uniform(a.nextv[cur]);
-    if (nx < 0) break;
-    if (wv::uniform(a.piece[nx].len) <= 0 || wv::uniform(a.fsm[nx].head) != 0) break;
-    cur = nx;
   }
   mre = ls2_wave_min(mre);
   mim = ls2_wave_min(mim);
@@ -1037,36 +1062,40 @@ RFID_DEVICE bool ls2_all_settled(const Ls2Ctl *ctl) {
   return ctl->fail == 0 && ctl->avg_count[LS2_AVG_ROUNDS] == 0 && ctl->fsm_count[LS2_FSM_ROUNDS] == 0 &&
          ctl->dc_count[LS2_DC_ROUNDS] == 0 && ctl->wb_clash == 0;
 }
-// one workgroup per trace: the number of complete windows before every piece (exclusive prefix sums: all, EPC), the
-// trace's count, and the trace's places in the decoder's two lists
+// one workgroup per trace: the number of complete windows before every unit (exclusive prefix sums: all, EPC), the trace's
+// count, and the trace's places in the decoder's two lists.  Sixteen waves over the slots as in the chain kernels.
 RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_seq_kernel(Ls2Args a) {
-  RFID_SHARED int shs[2 * LS2_CHAIN_THREADS];
-  RFID_SHARED int she[2 * LS2_CHAIN_THREADS];
+  RFID_SHARED int wtot[2 * LS2_CHAIN_WAVES];
   const Ls2Ctl *ctl = a.ctl;
   if (!ls2_all_settled(ctl)) return;
   const int tid = (int)threadIdx.x, s = (int)blockIdx.x;
-  const int per = (a.max_b + LS2_CHAIN_THREADS - 1) / LS2_CHAIN_THREADS;
-  const int j0 = tid * per, j1 = (j0 + per < a.max_b) ? (j0 + per) : a.max_b;
+  const int lane = wv::lane_id(), wave = wv::uniform(tid >> 6);
   const int base = s * a.max_b;
-  int agg = 0, age = 0;
-  for (int j = j0; j < j1; ++j) if (a.piece[base + j].len > 0) { agg += a.fsm[base + j].nwin; age += a.fsm[base + j].nepc; }
-  int cur = 0;
-  shs[tid] = agg; she[tid] = age;
-  wv::block_sync();
-  for (int off = 1; off < LS2_CHAIN_THREADS; off <<= 1) {
-    int v = shs[cur * LS2_CHAIN_THREADS + tid], e = she[cur * LS2_CHAIN_THREADS + tid];
-    if (tid >= off) { v += shs[cur * LS2_CHAIN_THREADS + tid - off]; e += she[cur * LS2_CHAIN_THREADS + tid - off]; }
-    shs[(cur ^ 1) * LS2_CHAIN_THREADS + tid] = v; she[(cur ^ 1) * LS2_CHAIN_THREADS + tid] = e;
-    cur ^= 1;
-    wv::block_sync();
+  const int n_chunks = (a.max_b + 63) >> 6, cpw = (n_chunks + LS2_CHAIN_WAVES - 1) / LS2_CHAIN_WAVES;
+  const int c_lo = wave * cpw, c_hi = (c_lo + cpw < n_chunks) ? (c_lo + cpw) : n_chunks;
+  int tw = 0, te = 0;
+  for (int c = c_lo; c < c_hi; ++c) {
+    const int j = 64 * c + lane, i = base + j;
+    const bool in = j < a.max_b && a.piece[i].len > 0 && a.fsm[i].head != 0;
+    const int nw = in ? a.fsm[i].nwin : 0, ne = in ? a.fsm[i].nepc : 0;
+    tw += wv::readlane(wv::scan_add(nw), 63);
+    te += wv::readlane(wv::scan_add(ne), 63);
   }
-  int run = (tid > 0) ? shs[cur * LS2_CHAIN_THREADS + tid - 1] : 0;
-  int rune = (tid > 0) ? she[cur * LS2_CHAIN_THREADS + tid - 1] : 0;
-  const int total = shs[cur * LS2_CHAIN_THREADS + LS2_CHAIN_THREADS - 1], total_e = she[cur * LS2_CHAIN_THREADS + LS2_CHAIN_THREADS - 1];
-  for (int j = j0; j < j1; ++j) {
-    if (a.piece[base + j].len <= 0) continue;
-    a.seq0[2 * (base + j)] = run; a.seq0[2 * (base + j) + 1] = rune;
-    run += a.fsm[base + j].nwin; rune += a.fsm[base + j].nepc;
+  if (lane == 0) { wtot[2 * wave] = tw; wtot[2 * wave + 1] = te; }
+  wv::block_sync();
+  int run = 0, rune = 0, total = 0, total_e = 0;
+  for (int w = 0; w < LS2_CHAIN_WAVES; ++w) {
+    if (w < wave) { run += wtot[2 * w]; rune += wtot[2 * w + 1]; }
+    total += wtot[2 * w]; total_e += wtot[2 * w + 1];
+  }
+  for (int c = c_lo; c < c_hi; ++c) {
+    const int j = 64 * c + lane, i = base + j;
+    const bool in = j < a.max_b && a.piece[i].len > 0 && a.fsm[i].head != 0;
+    const int nw = in ? a.fsm[i].nwin : 0, ne = in ? a.fsm[i].nepc : 0;
+    const int iw = wv::scan_add(nw), ie = wv::scan_add(ne);
+    if (in) { a.seq0[2 * i] = run + iw - nw; a.seq0[2 * i + 1] = rune + ie - ne; }
+    run += wv::readlane(iw, 63);
+    rune += wv::readlane(ie, 63);
   }
   if (tid == 0) {
     a.wcount[s] = (total < a.wmax) ? total : a.wmax;
@@ -1076,7 +1105,7 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_seq_kernel(Ls2Args a) {
   }
 }
 
-// one wave per piece: its windows (in order) -> the trace's window table, dc_est shifted to the unit's true start, and
+// one wave per unit: its windows (in order) -> the trace's window table, dc_est shifted to the unit's true start, and
 // the decoder's two lists
 RFID_KERNEL(64) void ls2_assemble_kernel(Ls2Args a) {
   Ls2Ctl *ctl = a.ctl;
@@ -1087,20 +1116,19 @@ RFID_KERNEL(64) void ls2_assemble_kernel(Ls2Args a) {
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   if (blockIdx.x == 0 && lane == 0) ctl->ok = 1;
   for (int i = (int)blockIdx.x; i < NS; i += (int)gridDim.x) {
-    const Ls2Piece pc = a.piece[i];
-    const int pos0 = wv::uniform(pc.pos0), n = wv::uniform(pc.len);
-    if (n <= 0) continue;
+    if (wv::uniform(a.piece[i].len) <= 0) continue;
     const Ls2Fsm *f = a.fsm + i;
-    if (wv::uniform(f->nwin) == 0) continue;
+    if (wv::uniform(f->head) == 0 || wv::uniform(f->nwin) == 0) continue;
+    const int pos0 = wv::uniform(a.piece[i].pos0), n = wv::uniform(f->u1) - pos0;
     const int s = i / a.max_b;
-    const int h = wv::uniform(f->unit), gen = wv::uniform(f->gen);
+    const int gen = wv::uniform(f->gen);
     // the unit's true start against the start its run used: D ulps (even: variant A + D, odd: variant B + D - 1)
-    const Ls2DcRun ru = a.drun[h];
+    const Ls2DcRun ru = a.drun[i];
     float shift[2];
     bool useb[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const int D = wv::uniform(a.dT[2 * h + c]) - ls2_ord(ru.s[c]);
+      const int D = wv::uniform(a.dT[2 * i + c]) - ls2_ord(ru.s[c]);
       useb[c] = (D & 1) != 0;
       const int De = useb[c] ? (D - 1) : D;
       const uint32_t e0 = (wv::f2u(ru.s[c]) >> 23) & 0xffu;
@@ -1147,9 +1175,7 @@ RFID_KERNEL(64) void ls2_carry_kernel(Ls2Args a) {
   const int lane = wv::lane_id();
   const int s = (int)blockIdx.x;
   const int base = s * a.max_b;
-  // the last piece in use
-  int last;
-  last = -1;
+  int last = -1;   // the last piece in use
   for (int j = a.max_b - 1; j >= 0; --j) if (wv::uniform(a.piece[base + j].len) > 0) { last = base + j; break; }
   if (last < 0) return;
   const Ls2Piece pc = a.piece[last];
@@ -1178,7 +1204,7 @@ RFID_KERNEL(64) void ls2_carry_kernel(Ls2Args a) {
     st->dcr_re[lane] = v.x; st->dcr_im[lane] = v.y;
   }
   if (lane == 0) {
-    const Ls2Fsm &f = a.fsm[last];
+    const Ls2Fsm &f = a.fsm[h];
     st->avg_ampl = avg_end; st->dc_re = dc_end[0]; st->dc_im = dc_end[1];
     st->n_samples = f.en[0]; st->signal_state = f.en[1]; st->num_pulses = f.en[2]; st->gate_open = f.en[3];
     st->n_to_ungate = f.en[4]; st->wtype = f.en[5];

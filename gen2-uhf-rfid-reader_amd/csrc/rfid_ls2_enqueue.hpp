@@ -17,7 +17,7 @@ constexpr int LS2_MIN_PIECE = 512;         // ... of at least this many decimate
 struct Ls2Geometry {
   int P = 0, max_b = 0, NS = 0;            // piece length, slots per trace, slots
   int Pc = 0, max_bc = 0;                  // the idle-cut grid
-  int64_t vstride = 0, wb_stride = 0;
+  int64_t vstride = 0, cstride = 0, wb_stride = 0;
 };
 // P: nominal piece length for `n_streams` traces of (at most) n_dec decimated samples; 0 = the traces are too short to cut
 inline Ls2Geometry ls2_geometry(int n_streams, int64_t n_dec, int min_piece = LS2_MIN_PIECE, int target = LS2_TARGET_PIECES) {
@@ -32,7 +32,8 @@ inline Ls2Geometry ls2_geometry(int n_streams, int64_t n_dec, int min_piece = LS
   g.max_bc = (int)(n_dec / g.Pc) + 1;
   g.max_b = g.max_bc * LS2_FINE;
   g.NS = n_streams * g.max_b;
-  g.vstride = (n_dec >> 6) + g.max_b + 2;
+  g.vstride = (n_dec >> 6) + 3;
+  g.cstride = (n_dec >> 6) + g.max_bc + 3;
   g.wb_stride = n_dec / LS2_WBUCKET + 2;
   return g;
 }
@@ -54,8 +55,8 @@ inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_strid
   L.amp = take(sizeof(float) * B * (size_t)y_stride);
   L.dadd = take(sizeof(float) * B * (size_t)y_stride);
   L.votes = take(sizeof(uint64_t) * 2 * B * (size_t)g.vstride);
-  L.closed = take(sizeof(uint64_t) * B * (size_t)g.vstride);
-  L.openinfo = take(sizeof(int) * B * (size_t)g.vstride);
+  L.closed = take(sizeof(uint64_t) * B * (size_t)g.cstride);
+  L.openinfo = take(sizeof(int) * B * (size_t)g.cstride);
   L.arun = take(sizeof(Ls2AvgRun) * NS);
   L.aT = take(sizeof(int) * NS);
   L.alist = take(sizeof(int) * 2 * NS);
@@ -73,7 +74,7 @@ inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_strid
   return L;
 }
 inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geometry &g) {
-  a.P = g.P; a.max_b = g.max_b; a.Pc = g.Pc; a.max_bc = g.max_bc; a.vstride = g.vstride; a.wb_stride = g.wb_stride;
+  a.P = g.P; a.max_b = g.max_b; a.Pc = g.Pc; a.max_bc = g.max_bc; a.vstride = g.vstride; a.cstride = g.cstride; a.wb_stride = g.wb_stride;
   a.cut = (int *)(base + L.cut); a.cutf = (int *)(base + L.cutf); a.piece = (Ls2Piece *)(base + L.piece);
   a.nextv = (int *)(base + L.nextv); a.prevv = (int *)(base + L.prevv);
   a.amp = (float *)(base + L.amp); a.dadd = (float *)(base + L.dadd);
@@ -85,7 +86,7 @@ inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geomet
 }
 
 #ifdef LS2_LAUNCH
-// One pass.  Before it (stream-ordered): Ls2Ctl, the window buckets (a.wb) and flat_count zeroed.  `a` complete but for
+// One pass.  Before it (stream-ordered): Ls2Ctl, the votes (a.votes), the window buckets (a.wb) and flat_count zeroed.  `a` complete but for
 // `round`.  After it: wtab / wcount / flat lists + Ls2Ctl::ok = 1, or ok = 0 (the caller's fallback scan, enqueued
 // behind with GateArgs::skip_if = &ctl->ok, then runs).
 inline void ls2_enqueue(Ls2Args a, bool search_cuts = true) {   // (search_cuts = false: a.cut is given -- tests)

@@ -201,6 +201,8 @@ static inline void set_priority_high() {}
 static inline void backoff() { emu::yield(); }
 static inline int atomic_add(int *p, int v) { int o = *p; *p = o + v; return o; }
 static inline int atomic_min(int *p, int v) { int o = *p; if (v < o) *p = v; return o; }
+static inline void atomic_or64(uint64_t *p, uint64_t v) { *p |= v; }
+static inline void atomic_and64(uint64_t *p, uint64_t v) { *p &= v; }
 static inline void global_release() {}
 static inline float2 load_coherent(const float2 *p) { return *p; }
 
