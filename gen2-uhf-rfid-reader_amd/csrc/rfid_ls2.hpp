@@ -537,6 +537,16 @@ RFID_DEVICE bool ls2_wide_end(const Ls2AvgRun &ru, int64_t D, int &end_ord) {   
   end_ord = ls2_ord(e);
   return true;
 }
+struct Ls2AvgRec { int len; float s, eA, eB; int margin, wide; };   // what the chain needs of a piece (fetched one chunk ahead)
+RFID_DEVICE Ls2AvgRec ls2_avg_rec(const Ls2Args &a, int base, int j) {
+  Ls2AvgRec r; r.len = 0; r.s = r.eA = r.eB = 0.0f; r.margin = 0; r.wide = 0;
+  if (j < a.max_b) {
+    r.len = a.piece[base + j].len;
+    const Ls2AvgRun *ru = a.arun + base + j;
+    r.s = ru->s; r.eA = ru->eA; r.eB = ru->eB; r.margin = ru->margin; r.wide = ru->wide;
+  }
+  return r;
+}
 RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_avg_chain_kernel(Ls2Args a) {
   RFID_SHARED Ls2A32 wagg[LS2_CHAIN_WAVES];
   RFID_SHARED int sh_flag[2];
@@ -557,21 +567,18 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_avg_chain_kernel(Ls2Args a) {
     // ---- sweep 1: this wave's total; are there runs with exactly known neighbouring ends at all? ----
     Ls2A32 carry; carry.c0 = 0; carry.c1 = 0;
     bool any_wide = false;
+    Ls2AvgRec nxt = ls2_avg_rec(a, base, 64 * c_lo + lane);
     for (int c = c_lo; c < c_hi; ++c) {
+      const Ls2AvgRec ru = nxt;
+      if (c + 1 < c_hi) nxt = ls2_avg_rec(a, base, 64 * (c + 1) + lane);
       const int j = 64 * c + lane;
-      const bool in = j < a.max_b && a.piece[base + j].len > 0;
       Ls2A32 el; el.c0 = 0; el.c1 = 0;
-      if (in) {
-        const Ls2AvgRun *ru = a.arun + base + j;
-        if (it == 0) {
-          el = ls2_elem32(ru->s, ru->eA, ru->eB);
-          if (ru->wide & 2) { Ls2Aff o; o.c0 = el.c0; o.c1 = el.c1; a.aover[base + j] = o; any_wide = true; }
-        } else if (ru->wide & 2) {
-          const Ls2Aff o = a.aover[base + j];
-          el.c0 = (int)o.c0; el.c1 = (int)o.c1;
+      if (ru.len > 0) {
+        el = ls2_elem32(ru.s, ru.eA, ru.eB);
+        if (ru.wide & 2) {
           any_wide = true;
-        } else {
-          el = ls2_elem32(ru->s, ru->eA, ru->eB);
+          if (it == 0) { Ls2Aff o; o.c0 = el.c0; o.c1 = el.c1; a.aover[base + j] = o; }
+          else { const Ls2Aff o = a.aover[base + j]; el.c0 = (int)o.c0; el.c1 = (int)o.c1; }
         }
       }
       const Ls2A32 incl = ls2_wave_incl(el, lane);
@@ -593,13 +600,14 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_avg_chain_kernel(Ls2Args a) {
       if (pass == 1 && (last || changed)) break;       // pass 1 = the sorting sweep after an unchanged pass 0
       const bool sort = last || pass == 1;
       Ls2A32 run = pre;
+      nxt = ls2_avg_rec(a, base, 64 * c_lo + lane);
       for (int c = c_lo; c < c_hi; ++c) {
+        const Ls2AvgRec ru = nxt;
+        if (c + 1 < c_hi) nxt = ls2_avg_rec(a, base, 64 * (c + 1) + lane);
         const int j = 64 * c + lane, i = base + j;
-        const bool in = j < a.max_b && a.piece[i].len > 0;
+        const bool in = ru.len > 0;
         Ls2A32 el; el.c0 = 0; el.c1 = 0;
-        Ls2AvgRun ru;
         if (in) {
-          ru = a.arun[i];
           if (ru.wide & 2) { const Ls2Aff o = a.aover[i]; el.c0 = (int)o.c0; el.c1 = (int)o.c1; }
           else el = ls2_elem32(ru.s, ru.eA, ru.eB);
         }
@@ -610,7 +618,7 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_avg_chain_kernel(Ls2Args a) {
           const int64_t D = (int64_t)T - (int64_t)ls2_ord(ru.s);
           if (!sort) {
             int e_exact;
-            if (ls2_wide_end(ru, D, e_exact)) {
+            if ((ru.wide & 2) && D >= LS2_WIDE_LO && D <= LS2_WIDE_HI && ls2_wide_end(a.arun[i], D, e_exact)) {
               const int want = (int)((uint32_t)e_exact - (uint32_t)T);
               const int cq = (T & 1) ? el.c1 : el.c0;
               if (cq != want) {
@@ -662,9 +670,10 @@ RFID_KERNEL(64) void ls2_fsm_kernel(Ls2Args a) {
   const int r = a.round;
   if (r == 0) { if (wv::uniform(ctl->avg_count[LS2_AVG_ROUNDS]) != 0) return; }
   else if (wv::uniform(ctl->fsm_count[r - 1]) == 0) return;
-  const int NS = a.n_streams * a.max_b;
   const int lane = wv::lane_id();
-  for (int i = (int)blockIdx.x; i < NS; i += (int)gridDim.x) {
+  const int NH = a.n_streams * a.max_bc;   // heads sit at every LS2_FINE-th slot only: one block per such slot (blocks indexed by
+  for (int b = (int)blockIdx.x; b < NH; b += (int)gridDim.x) {   // slot would all land on two of the eight XCDs)
+    const int i = (b / a.max_bc) * a.max_b + (b % a.max_bc) * LS2_FINE;
     if (wv::uniform(a.piece[i].len) <= 0) continue;
     Ls2Fsm *fh = a.fsm + i;
     if (wv::uniform(fh->head) == 0) continue;
@@ -968,9 +977,10 @@ RFID_KERNEL(64) void ls2_dc_first_kernel(Ls2Args a) {
   RFID_SHARED float2 lds_dc[DC_LEN];
   RFID_SHARED float2 lds_tmp[64];
   if (!ls2_fsm_settled(a.ctl)) return;
-  const int NS = a.n_streams * a.max_b;
   const int lane = wv::lane_id();
-  for (int i = (int)blockIdx.x; i < NS; i += (int)gridDim.x) {
+  const int NH = a.n_streams * a.max_bc;
+  for (int b = (int)blockIdx.x; b < NH; b += (int)gridDim.x) {
+    const int i = (b / a.max_bc) * a.max_b + (b % a.max_bc) * LS2_FINE;
     if (wv::uniform(a.piece[i].len) <= 0 || wv::uniform(a.fsm[i].head) == 0) continue;
     ls2_dc_unit(a, i, true, lane, lds_dc, lds_tmp);
   }
@@ -986,7 +996,19 @@ RFID_KERNEL(64) void ls2_dc_rerun_kernel(Ls2Args a) {
   for (int r = (int)blockIdx.x; r < cnt; r += (int)gridDim.x) ls2_dc_unit(a, wv::uniform(list[r]), false, lane, lds_dc, lds_tmp);
 }
 
-// one workgroup per trace: as ls2_avg_chain_kernel, over the units (head slots) and the two components of dc_est
+// one workgroup per trace: as ls2_avg_chain_kernel, over the units (heads: every LS2_FINE-th slot at most) and the two
+// components of dc_est
+struct Ls2DcRec { int on; Ls2DcRun ru; };
+RFID_DEVICE Ls2DcRec ls2_dc_rec(const Ls2Args &a, int base, int J) {
+  Ls2DcRec r; r.on = 0;
+  for (int c = 0; c < 2; ++c) { r.ru.s[c] = r.ru.eA[c] = r.ru.eB[c] = 0.0f; r.ru.margin[c] = 0; }
+  if (J < a.max_bc) {
+    const int i = base + J * LS2_FINE;
+    r.on = (a.piece[i].len > 0 && a.fsm[i].head != 0) ? 1 : 0;
+    r.ru = a.drun[i];
+  }
+  return r;
+}
 RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_dc_chain_kernel(Ls2Args a) {
   RFID_SHARED Ls2A32 wagg[2 * LS2_CHAIN_WAVES];
   Ls2Ctl *ctl = a.ctl;
@@ -998,19 +1020,19 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_dc_chain_kernel(Ls2Args a) {
   const int lane = wv::lane_id(), wave = wv::uniform(tid >> 6);
   const int base = s * a.max_b;
   if (a.piece[base].len <= 0) return;
-  const int n_chunks = (a.max_b + 63) >> 6, cpw = (n_chunks + LS2_CHAIN_WAVES - 1) / LS2_CHAIN_WAVES;
+  const int n_chunks = (a.max_bc + 63) >> 6, cpw = (n_chunks + LS2_CHAIN_WAVES - 1) / LS2_CHAIN_WAVES;
   const int c_lo = wave * cpw, c_hi = (c_lo + cpw < n_chunks) ? (c_lo + cpw) : n_chunks;
   const int T0r = ls2_ord(a.drun[base].s[0]), T0i = ls2_ord(a.drun[base].s[1]);
   // ---- sweep 1: this wave's totals ----
   Ls2A32 cr, ci; cr.c0 = cr.c1 = 0; ci.c0 = ci.c1 = 0;
+  Ls2DcRec nxt = ls2_dc_rec(a, base, 64 * c_lo + lane);
   for (int c = c_lo; c < c_hi; ++c) {
-    const int j = 64 * c + lane, i = base + j;
-    const bool in = j < a.max_b && a.piece[i].len > 0 && a.fsm[i].head != 0;
+    const Ls2DcRec rec = nxt;
+    if (c + 1 < c_hi) nxt = ls2_dc_rec(a, base, 64 * (c + 1) + lane);
     Ls2A32 er, ei; er.c0 = er.c1 = 0; ei.c0 = ei.c1 = 0;
-    if (in) {
-      const Ls2DcRun *ru = a.drun + i;
-      er = ls2_elem32(ru->s[0], ru->eA[0], ru->eB[0]);
-      ei = ls2_elem32(ru->s[1], ru->eA[1], ru->eB[1]);
+    if (rec.on) {
+      er = ls2_elem32(rec.ru.s[0], rec.ru.eA[0], rec.ru.eB[0]);
+      ei = ls2_elem32(rec.ru.s[1], rec.ru.eA[1], rec.ru.eB[1]);
     }
     const Ls2A32 ir = ls2_wave_incl(er, lane), ii = ls2_wave_incl(ei, lane);
     Ls2A32 tr, ti; tr.c0 = wv::readlane(ir.c0, 63); tr.c1 = wv::readlane(ir.c1, 63); ti.c0 = wv::readlane(ii.c0, 63); ti.c1 = wv::readlane(ii.c1, 63);
@@ -1022,13 +1044,15 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_dc_chain_kernel(Ls2Args a) {
   for (int w = 0; w < wave; ++w) { rr = ls2_comp32(rr, wagg[2 * w]); ri = ls2_comp32(ri, wagg[2 * w + 1]); }
   // ---- sweep 2: every unit's true (or predicted) start; what is not proven goes on the re-run list ----
   int n_rerun = 0, n_units = 0;
+  nxt = ls2_dc_rec(a, base, 64 * c_lo + lane);
   for (int c = c_lo; c < c_hi; ++c) {
-    const int j = 64 * c + lane, i = base + j;
-    const bool in = j < a.max_b && a.piece[i].len > 0 && a.fsm[i].head != 0;
+    const Ls2DcRec rec = nxt;
+    if (c + 1 < c_hi) nxt = ls2_dc_rec(a, base, 64 * (c + 1) + lane);
+    const int i = base + (64 * c + lane) * LS2_FINE;
+    const bool in = rec.on != 0;
+    const Ls2DcRun &ru = rec.ru;
     Ls2A32 er, ei; er.c0 = er.c1 = 0; ei.c0 = ei.c1 = 0;
-    Ls2DcRun ru;
     if (in) {
-      ru = a.drun[i];
       er = ls2_elem32(ru.s[0], ru.eA[0], ru.eB[0]);
       ei = ls2_elem32(ru.s[1], ru.eA[1], ru.eB[1]);
     }
@@ -1071,12 +1095,12 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_seq_kernel(Ls2Args a) {
   const int tid = (int)threadIdx.x, s = (int)blockIdx.x;
   const int lane = wv::lane_id(), wave = wv::uniform(tid >> 6);
   const int base = s * a.max_b;
-  const int n_chunks = (a.max_b + 63) >> 6, cpw = (n_chunks + LS2_CHAIN_WAVES - 1) / LS2_CHAIN_WAVES;
+  const int n_chunks = (a.max_bc + 63) >> 6, cpw = (n_chunks + LS2_CHAIN_WAVES - 1) / LS2_CHAIN_WAVES;
   const int c_lo = wave * cpw, c_hi = (c_lo + cpw < n_chunks) ? (c_lo + cpw) : n_chunks;
   int tw = 0, te = 0;
   for (int c = c_lo; c < c_hi; ++c) {
-    const int j = 64 * c + lane, i = base + j;
-    const bool in = j < a.max_b && a.piece[i].len > 0 && a.fsm[i].head != 0;
+    const int J = 64 * c + lane, i = base + J * LS2_FINE;
+    const bool in = J < a.max_bc && a.piece[i].len > 0 && a.fsm[i].head != 0;
     const int nw = in ? a.fsm[i].nwin : 0, ne = in ? a.fsm[i].nepc : 0;
     tw += wv::readlane(wv::scan_add(nw), 63);
     te += wv::readlane(wv::scan_add(ne), 63);
@@ -1089,8 +1113,8 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_seq_kernel(Ls2Args a) {
     total += wtot[2 * w]; total_e += wtot[2 * w + 1];
   }
   for (int c = c_lo; c < c_hi; ++c) {
-    const int j = 64 * c + lane, i = base + j;
-    const bool in = j < a.max_b && a.piece[i].len > 0 && a.fsm[i].head != 0;
+    const int J = 64 * c + lane, i = base + J * LS2_FINE;
+    const bool in = J < a.max_bc && a.piece[i].len > 0 && a.fsm[i].head != 0;
     const int nw = in ? a.fsm[i].nwin : 0, ne = in ? a.fsm[i].nepc : 0;
     const int iw = wv::scan_add(nw), ie = wv::scan_add(ne);
     if (in) { a.seq0[2 * i] = run + iw - nw; a.seq0[2 * i + 1] = rune + ie - ne; }
@@ -1111,11 +1135,12 @@ RFID_KERNEL(64) void ls2_assemble_kernel(Ls2Args a) {
   Ls2Ctl *ctl = a.ctl;
   if (!(wv::uniform(ctl->fail) == 0 && wv::uniform(ctl->avg_count[LS2_AVG_ROUNDS]) == 0 && wv::uniform(ctl->fsm_count[LS2_FSM_ROUNDS]) == 0 &&
         wv::uniform(ctl->dc_count[LS2_DC_ROUNDS]) == 0 && wv::uniform(ctl->wb_clash) == 0)) return;
-  const int NS = a.n_streams * a.max_b;
   const int lane = wv::lane_id();
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   if (blockIdx.x == 0 && lane == 0) ctl->ok = 1;
-  for (int i = (int)blockIdx.x; i < NS; i += (int)gridDim.x) {
+  const int NH = a.n_streams * a.max_bc;
+  for (int b = (int)blockIdx.x; b < NH; b += (int)gridDim.x) {
+    const int i = (b / a.max_bc) * a.max_b + (b % a.max_bc) * LS2_FINE;
     if (wv::uniform(a.piece[i].len) <= 0) continue;
     const Ls2Fsm *f = a.fsm + i;
     if (wv::uniform(f->head) == 0 || wv::uniform(f->nwin) == 0) continue;

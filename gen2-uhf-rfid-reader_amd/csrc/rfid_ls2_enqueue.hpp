@@ -90,7 +90,7 @@ inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geomet
 // `round`.  After it: wtab / wcount / flat lists + Ls2Ctl::ok = 1, or ok = 0 (the caller's fallback scan, enqueued
 // behind with GateArgs::skip_if = &ctl->ok, then runs).
 inline void ls2_enqueue(Ls2Args a, bool search_cuts = true) {   // (search_cuts = false: a.cut is given -- tests)
-  const int NS = a.n_streams * a.max_b;
+  const int NS = a.n_streams * a.max_b, NH = a.n_streams * a.max_bc;   // slots; slots that can be heads
   const int B = a.n_streams;
   if (a.max_bc > 1 && search_cuts) {
     LsCutArgs ca;
@@ -117,11 +117,11 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true) {   // (search_cuts 
   }
   for (int r = 0; r <= LS2_FSM_ROUNDS; ++r) {
     a.round = r;
-    LS2_LAUNCH(ls2_fsm_kernel, (r == 0) ? NS : rerun_grid, 1, 64, a);
+    LS2_LAUNCH(ls2_fsm_kernel, NH, 1, 64, a);
     LS2_LAUNCH(ls2_fsm_chain_kernel, B, 1, LS2_CHAIN_THREADS, a);
   }
   a.round = 0;
-  LS2_LAUNCH(ls2_dc_first_kernel, NS, 1, 64, a);
+  LS2_LAUNCH(ls2_dc_first_kernel, NH, 1, 64, a);
   LS2_LAUNCH(ls2_dc_chain_kernel, B, 1, LS2_CHAIN_THREADS, a);
   for (int r = 1; r <= LS2_DC_ROUNDS; ++r) {
     a.round = r;
@@ -130,7 +130,7 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true) {   // (search_cuts 
   }
   a.round = 0;
   LS2_LAUNCH(ls2_seq_kernel, B, 1, LS2_CHAIN_THREADS, a);
-  LS2_LAUNCH(ls2_assemble_kernel, NS < 8192 ? NS : 8192, 1, 64, a);
+  LS2_LAUNCH(ls2_assemble_kernel, NH, 1, 64, a);
   if (a.carry_out) LS2_LAUNCH(ls2_carry_kernel, B, 1, 64, a);
 }
 #endif
