@@ -275,6 +275,7 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
   a.carry = opt.carry ? c->d_gstate : nullptr; a.carry_out = opt.carry ? c->d_gstate : nullptr;
   a.hold_last = opt.hold_last ? 1 : 0; a.force = opt.force ? 1 : 0;
   HIPCHK(c, hipMemsetAsync(a.ctl, 0, sizeof(Ls2Ctl), c->stream));
+  HIPCHK(c, hipMemsetAsync(a.cflag, 0, sizeof(int) * (size_t)c->B * LS2_CHAIN_GMAX, c->stream));
   HIPCHK(c, hipMemsetAsync(a.consumed, 0, sizeof(int) * (size_t)c->B, c->stream));
   HIPCHK(c, hipMemsetAsync(a.wb, 0, sizeof(Ls2Win) * (size_t)c->B * (size_t)geo.wb_stride, c->stream));
   HIPCHK(c, hipMemsetAsync(a.votes, 0, sizeof(uint64_t) * 2 * (size_t)c->B * (size_t)geo.vstride, c->stream));

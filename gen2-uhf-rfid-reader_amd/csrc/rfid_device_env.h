@@ -122,6 +122,12 @@ RFID_DEVICE void wave_sync() {
 }
 RFID_DEVICE int atomic_add(int *p, int v) { return atomicAdd(p, v); }
 RFID_DEVICE int atomic_min(int *p, int v) { return atomicMin(p, v); }
+// hand-off between workgroups of one launch (those with lower block index are dispatched first): the publisher's earlier
+// global stores are visible to whoever has seen the flag
+RFID_DEVICE void publish(int *flag, int v) { __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+RFID_DEVICE void await(const int *flag, int v) {
+  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != v) __builtin_amdgcn_s_sleep(2);
+}
 RFID_DEVICE void atomic_or64(uint64_t *p, uint64_t v) { atomicOr(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v); }
 RFID_DEVICE void atomic_and64(uint64_t *p, uint64_t v) { atomicAnd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v); }
 // this wave's global stores are visible device-wide when this returns

@@ -52,6 +52,7 @@ constexpr int LS2_MAXR = 12;
 constexpr int LS2_WIDE_BELOW = 64;    // a piece whose margin is below this is re-run from six neighbouring start values at once
 constexpr int LS2_WIDE_LO = -2, LS2_WIDE_HI = 3;
 constexpr int LS2_CHAIN_THREADS = 1024;
+constexpr int LS2_CHAIN_GMAX = 64;     // workgroups per trace of a chain launch, at most
 
 struct Ls2Piece { int pos0, len; };   // len 0: slot not in use
 
@@ -60,7 +61,8 @@ struct Ls2Ctl {   // control block in HBM, zeroed before every pass
   int ok;                     // 1: the window tables were produced (set last; the fallback scan skips itself on it)
   int n_pieces;               // pieces the traces were cut into
   int n_heads;                // ... of them at idle cuts (or a trace's start): where the state-machine / dc_est passes can start
-  int avg_count[LS2_MAXR];    // pieces on the re-run list after chain round r
+  int avg_count[LS2_MAXR];    // what chain round r left to do: pieces on the re-run list + exact ends put in (the chain has to be redone)
+  int avg_list[LS2_MAXR];     //   ... the length of the list
   int fsm_count[LS2_MAXR];    // pieces appended to their predecessor in chain round r
   int dc_count[LS2_MAXR];     // units on the re-run list after chain round r
   int avg_reruns, fsm_reruns, dc_reruns;   // totals (report)
@@ -74,7 +76,8 @@ struct Ls2Ctl {   // control block in HBM, zeroed before every pass
 struct Ls2AvgRun {   // a piece's latest run
   float s, eA, eB;   // start used, end from it, end from s + 1 ulp
   int margin;        // (ulps of s)
-  int wide;          // in: run wide next time;  out (bit 1): ew[] holds the ends from s - 2, s - 1, s + 2, s + 3 ulps
+  int wide;          // bit 0 (chain -> run): run wide next time;  bit 1 (run -> chain): ew[] holds the ends from s - 2, s - 1, s + 2,
+                     // s + 3 ulps;  bit 2 (chain): aover[] holds this piece's function with one of those exact ends put in
   float ew[4];
   int pad_[3];
 };
@@ -132,6 +135,12 @@ struct Ls2Args {
   int force;                    // run even when no trace could be cut
   int *consumed;                // [n_streams]
   int round;
+  // the chain kernels run on several workgroups per trace: block b publishes the total of its slots, then waits for the
+  // blocks before it
+  int chain_g;                  // workgroups per trace of this launch
+  int stamp;                    // this launch's number within the pass (the flags are zeroed before a pass)
+  int *cflag;                   // [n_streams][LS2_CHAIN_GMAX]
+  int *cagg;                    // [n_streams][LS2_CHAIN_GMAX][4]
 };
 
 // ---- small helpers -----------------------------------------------------------------------------------------------
@@ -472,7 +481,7 @@ RFID_KERNEL(64) void ls2_avg_first_kernel(Ls2Args a) {
 RFID_KERNEL(64) void ls2_avg_rerun_kernel(Ls2Args a) {
   if (wv::uniform(a.ctl->fail) != 0) return;
   const int NS = a.n_streams * a.max_b;
-  const int cnt = wv::uniform(a.ctl->avg_count[a.round - 1]);
+  const int cnt = wv::uniform(a.ctl->avg_list[a.round - 1]);
   const int lane = wv::lane_id();
   const int *list = a.alist + (int64_t)((a.round - 1) & 1) * NS;
   for (int r = (int)blockIdx.x; r < cnt; r += (int)gridDim.x) ls2_avg_piece<false>(a, wv::uniform(list[r]), lane);   // (grid = NS: one each)
@@ -525,12 +534,13 @@ RFID_KERNEL(64) void ls2_scan_selftest_kernel(const int *in, int *out) {
 }
 constexpr int LS2_CHAIN_WAVES = LS2_CHAIN_THREADS / 64;
 
-// one workgroup per trace: every piece's true start from the chain of the latest runs; what is not proven goes on the
-// re-run list of this round.  Sixteen waves, each over a contiguous run of the trace's slots, 64 slots at a time (lane =
-// slot: coalesced reads, a wave-level scan per 64), the waves' totals chained through LDS; a first sweep for the totals,
-// a second one for every piece's start.  A run that was made from six neighbouring starts knows its end for each of
-// them exactly: when the chain lands on one of those, that end replaces the prediction and the sweeps are repeated (a
-// few times at most: such pieces are rare), so that no error is handed downstream.
+// The chain of a trace's pieces: every piece's true start from the latest runs; what is not proven goes on the re-run
+// list of this round.  chain_g workgroups per trace, each over a contiguous run of the trace's slots: sixteen waves, 64
+// slots at a time (lane = slot: coalesced reads, a wave-level scan per 64).  A first sweep for the workgroup's total, which
+// is published; the totals of the workgroups before it give its prefix; a second sweep for every piece's start.
+// A run that was made from six neighbouring starts knows its end for each of them exactly: when the chain lands on one of
+// those and the prediction used for it was off, the exact end is put into the piece's function (aover) and counted as
+// work left -- the next round's chain then carries no error from it.
 RFID_DEVICE bool ls2_wide_end(const Ls2AvgRun &ru, int64_t D, int &end_ord) {   // exact end for true start s + D, if known
   if (!(ru.wide & 2) || D < LS2_WIDE_LO || D > LS2_WIDE_HI) return false;
   const float e = (D == 0) ? ru.eA : (D == 1) ? ru.eB : (D == -2) ? ru.ew[0] : (D == -1) ? ru.ew[1] : (D == 2) ? ru.ew[2] : ru.ew[3];
@@ -547,115 +557,129 @@ RFID_DEVICE Ls2AvgRec ls2_avg_rec(const Ls2Args &a, int base, int j) {
   }
   return r;
 }
+// the slots of workgroup b of chain_g and of its wave `wave`, in chunks of 64
+RFID_DEVICE void ls2_chain_range(int n_slots, int g, int b, int wave, int &c_lo, int &c_hi) {
+  const int n_chunks = (n_slots + 63) >> 6, cpb = (n_chunks + g - 1) / g, cpw = (cpb + LS2_CHAIN_WAVES - 1) / LS2_CHAIN_WAVES;
+  const int b_lo = b * cpb, b_hi = (b_lo + cpb < n_chunks) ? (b_lo + cpb) : n_chunks;
+  c_lo = b_lo + wave * cpw;
+  c_hi = (c_lo + cpw < b_hi) ? (c_lo + cpw) : b_hi;
+  if (c_lo > c_hi) c_lo = c_hi;
+}
+// workgroup totals -> the composition of everything before this wave (NC scans at once; wagg: [NC][LS2_CHAIN_WAVES + 1] in LDS)
+template <int NC>
+RFID_DEVICE void ls2_chain_prefix(const Ls2Args &a, int s, int b, int wave, int lane, int tid, const Ls2A32 (&carry)[NC], Ls2A32 *wagg, Ls2A32 (&pre)[NC]) {
+  if (lane == 0)
+    for (int c = 0; c < NC; ++c) wagg[c * (LS2_CHAIN_WAVES + 1) + wave] = carry[c];
+  wv::block_sync();
+  if (tid == 0) {
+    int *ag = a.cagg + ((int64_t)s * LS2_CHAIN_GMAX + b) * 4;
+    for (int c = 0; c < NC; ++c) {
+      Ls2A32 t; t.c0 = 0; t.c1 = 0;
+      for (int w = 0; w < LS2_CHAIN_WAVES; ++w) t = ls2_comp32(t, wagg[c * (LS2_CHAIN_WAVES + 1) + w]);
+      ag[2 * c] = t.c0; ag[2 * c + 1] = t.c1;
+    }
+    wv::publish(a.cflag + (int64_t)s * LS2_CHAIN_GMAX + b, a.stamp);
+    Ls2A32 p[NC];
+    for (int c = 0; c < NC; ++c) { p[c].c0 = 0; p[c].c1 = 0; }
+    for (int b2 = 0; b2 < b; ++b2) {
+      wv::await(a.cflag + (int64_t)s * LS2_CHAIN_GMAX + b2, a.stamp);
+      const int *g2 = a.cagg + ((int64_t)s * LS2_CHAIN_GMAX + b2) * 4;
+      for (int c = 0; c < NC; ++c) { Ls2A32 t; t.c0 = g2[2 * c]; t.c1 = g2[2 * c + 1]; p[c] = ls2_comp32(p[c], t); }
+    }
+    for (int c = 0; c < NC; ++c) wagg[c * (LS2_CHAIN_WAVES + 1) + LS2_CHAIN_WAVES] = p[c];
+  }
+  wv::block_sync();
+  for (int c = 0; c < NC; ++c) {
+    pre[c] = wagg[c * (LS2_CHAIN_WAVES + 1) + LS2_CHAIN_WAVES];
+    for (int w = 0; w < wave; ++w) pre[c] = ls2_comp32(pre[c], wagg[c * (LS2_CHAIN_WAVES + 1) + w]);
+  }
+}
 RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_avg_chain_kernel(Ls2Args a) {
-  RFID_SHARED Ls2A32 wagg[LS2_CHAIN_WAVES];
-  RFID_SHARED int sh_flag[2];
+  RFID_SHARED Ls2A32 wagg[LS2_CHAIN_WAVES + 1];
   Ls2Ctl *ctl = a.ctl;
   const int r = a.round;
-  const int tid = (int)threadIdx.x, s = (int)blockIdx.x;
+  const int tid = (int)threadIdx.x, b = (int)blockIdx.x, s = (int)blockIdx.y;
   if (ctl->fail != 0) return;
   if (r > 0 && ctl->avg_count[r - 1] == 0) return;   // settled in an earlier round (avg_count[r] stays 0)
   const int NS = a.n_streams * a.max_b;
   const int lane = wv::lane_id(), wave = wv::uniform(tid >> 6);
   const int base = s * a.max_b;
   if (a.piece[base].len <= 0) return;                 // an empty trace
-  const int n_chunks = (a.max_b + 63) >> 6, cpw = (n_chunks + LS2_CHAIN_WAVES - 1) / LS2_CHAIN_WAVES;
-  const int c_lo = wave * cpw, c_hi = (c_lo + cpw < n_chunks) ? (c_lo + cpw) : n_chunks;
+  int c_lo, c_hi;
+  ls2_chain_range(a.max_b, a.chain_g, b, wave, c_lo, c_hi);
   const int T0 = ls2_ord(a.arun[base].s);             // the trace's first piece starts from the exact value
-  int n_rerun = 0;
-  for (int it = 0; it < 6; ++it) {
-    // ---- sweep 1: this wave's total; are there runs with exactly known neighbouring ends at all? ----
-    Ls2A32 carry; carry.c0 = 0; carry.c1 = 0;
-    bool any_wide = false;
-    Ls2AvgRec nxt = ls2_avg_rec(a, base, 64 * c_lo + lane);
-    for (int c = c_lo; c < c_hi; ++c) {
-      const Ls2AvgRec ru = nxt;
-      if (c + 1 < c_hi) nxt = ls2_avg_rec(a, base, 64 * (c + 1) + lane);
-      const int j = 64 * c + lane;
-      Ls2A32 el; el.c0 = 0; el.c1 = 0;
-      if (ru.len > 0) {
-        el = ls2_elem32(ru.s, ru.eA, ru.eB);
-        if (ru.wide & 2) {
-          any_wide = true;
-          if (it == 0) { Ls2Aff o; o.c0 = el.c0; o.c1 = el.c1; a.aover[base + j] = o; }
-          else { const Ls2Aff o = a.aover[base + j]; el.c0 = (int)o.c0; el.c1 = (int)o.c1; }
+  // ---- sweep 1: this wave's total ----
+  Ls2A32 carry[1]; carry[0].c0 = 0; carry[0].c1 = 0;
+  Ls2AvgRec nxt = ls2_avg_rec(a, base, 64 * c_lo + lane);
+  for (int c = c_lo; c < c_hi; ++c) {
+    const Ls2AvgRec ru = nxt;
+    if (c + 1 < c_hi) nxt = ls2_avg_rec(a, base, 64 * (c + 1) + lane);
+    Ls2A32 el; el.c0 = 0; el.c1 = 0;
+    if (ru.len > 0) {
+      if (ru.wide & 4) { const Ls2Aff o = a.aover[base + 64 * c + lane]; el.c0 = (int)o.c0; el.c1 = (int)o.c1; }
+      else el = ls2_elem32(ru.s, ru.eA, ru.eB);
+    }
+    const Ls2A32 incl = ls2_wave_incl(el, lane);
+    Ls2A32 tot; tot.c0 = wv::readlane(incl.c0, 63); tot.c1 = wv::readlane(incl.c1, 63);
+    carry[0] = ls2_comp32(carry[0], tot);
+  }
+  Ls2A32 pre[1];
+  ls2_chain_prefix<1>(a, s, b, wave, lane, tid, carry, wagg, pre);
+  // ---- sweep 2: every piece's true (or predicted) start ----
+  int n_rerun = 0, n_left = 0;
+  Ls2A32 run = pre[0];
+  nxt = ls2_avg_rec(a, base, 64 * c_lo + lane);
+  for (int c = c_lo; c < c_hi; ++c) {
+    const Ls2AvgRec ru = nxt;
+    if (c + 1 < c_hi) nxt = ls2_avg_rec(a, base, 64 * (c + 1) + lane);
+    const int i = base + 64 * c + lane;
+    const bool in = ru.len > 0;
+    Ls2A32 el; el.c0 = 0; el.c1 = 0;
+    if (in) {
+      if (ru.wide & 4) { const Ls2Aff o = a.aover[i]; el.c0 = (int)o.c0; el.c1 = (int)o.c1; }
+      else el = ls2_elem32(ru.s, ru.eA, ru.eB);
+    }
+    const Ls2A32 incl = ls2_wave_incl(el, lane);
+    const Ls2A32 upto = ls2_comp32(run, ls2_wave_excl(incl, lane));
+    const int T = ls2_apply32(upto, T0);
+    if (in) {
+      const int64_t D = (int64_t)T - (int64_t)ls2_ord(ru.s);
+      const int64_t aD = (D < 0) ? -D : D;
+      a.aT[i] = T;
+      int e_exact;
+      bool hold = false;
+      if (D != 0 && (ru.wide & 2) && D >= LS2_WIDE_LO && D <= LS2_WIDE_HI && ls2_wide_end(a.arun[i], D, e_exact)) {
+        // the end is known exactly: was it what the chain used?  else the starts behind this piece are off -- the exact
+        // end goes into the piece's function, the piece keeps its run, and the chain is redone in the next round (only
+        // then is the piece run again from its true start: for its votes)
+        const int want = (int)((uint32_t)e_exact - (uint32_t)T);
+        const int cq = (T & 1) ? el.c1 : el.c0;
+        if (cq != want) {
+          Ls2Aff o; o.c0 = (T & 1) ? el.c0 : want; o.c1 = (T & 1) ? want : el.c1;
+          a.aover[i] = o;
+          a.arun[i].wide = ru.wide | 4;
+          n_left++;
+          hold = true;
         }
       }
-      const Ls2A32 incl = ls2_wave_incl(el, lane);
-      Ls2A32 tot; tot.c0 = wv::readlane(incl.c0, 63); tot.c1 = wv::readlane(incl.c1, 63);
-      carry = ls2_comp32(carry, tot);
-    }
-    if (tid < 2) sh_flag[tid] = 0;
-    if (lane == 0) wagg[wave] = carry;
-    wv::block_sync();
-    if (wv::ballot(any_wide) != 0ull && lane == 0) sh_flag[0] = 1;
-    Ls2A32 pre; pre.c0 = 0; pre.c1 = 0;
-    for (int w = 0; w < wave; ++w) pre = ls2_comp32(pre, wagg[w]);
-    wv::block_sync();
-    const bool wides = sh_flag[0] != 0;
-    // ---- sweep 2: every piece's true (or predicted) start; the last sweep also sorts the pieces ----
-    const bool last = !wides || it == 5;   // (no run with known neighbours: nothing can change; else decided below)
-    bool changed = false;
-    for (int pass = 0; pass < 2; ++pass) {
-      if (pass == 1 && (last || changed)) break;       // pass 1 = the sorting sweep after an unchanged pass 0
-      const bool sort = last || pass == 1;
-      Ls2A32 run = pre;
-      nxt = ls2_avg_rec(a, base, 64 * c_lo + lane);
-      for (int c = c_lo; c < c_hi; ++c) {
-        const Ls2AvgRec ru = nxt;
-        if (c + 1 < c_hi) nxt = ls2_avg_rec(a, base, 64 * (c + 1) + lane);
-        const int j = 64 * c + lane, i = base + j;
-        const bool in = ru.len > 0;
-        Ls2A32 el; el.c0 = 0; el.c1 = 0;
-        if (in) {
-          if (ru.wide & 2) { const Ls2Aff o = a.aover[i]; el.c0 = (int)o.c0; el.c1 = (int)o.c1; }
-          else el = ls2_elem32(ru.s, ru.eA, ru.eB);
-        }
-        const Ls2A32 incl = ls2_wave_incl(el, lane);
-        const Ls2A32 upto = ls2_comp32(run, ls2_wave_excl(incl, lane));
-        const int T = ls2_apply32(upto, T0);
-        if (in) {
-          const int64_t D = (int64_t)T - (int64_t)ls2_ord(ru.s);
-          if (!sort) {
-            int e_exact;
-            if ((ru.wide & 2) && D >= LS2_WIDE_LO && D <= LS2_WIDE_HI && ls2_wide_end(a.arun[i], D, e_exact)) {
-              const int want = (int)((uint32_t)e_exact - (uint32_t)T);
-              const int cq = (T & 1) ? el.c1 : el.c0;
-              if (cq != want) {
-                Ls2Aff o; o.c0 = (T & 1) ? el.c0 : want; o.c1 = (T & 1) ? want : el.c1;
-                a.aover[i] = o;
-                changed = true;
-              }
-            }
-          } else {
-            const int64_t aD = (D < 0) ? -D : D;
-            a.aT[i] = T;
-            // settled: the run started from the true value, or provably covers it (its votes included).  Anything else is
-            // run again from the true (or predicted) start -- also a piece whose END is known exactly from a neighbouring
-            // start: its votes are not.
-            if (D != 0 && !(aD + 4 <= (int64_t)ru.margin)) {
-              Ls2AvgRun *w = a.arun + i;
-              w->s = ls2_from_ord(T);
-              w->wide = (ru.margin < LS2_WIDE_BELOW || r >= 3) ? 1 : 0;
-              const int k = wv::atomic_add(&ctl->avg_count[r], 1);
-              a.alist[(int64_t)(r & 1) * NS + k] = i;
-              n_rerun++;
-            }
-          }
-        }
-        Ls2A32 tot; tot.c0 = wv::readlane(incl.c0, 63); tot.c1 = wv::readlane(incl.c1, 63);
-        run = ls2_comp32(run, tot);
+      // settled: the run started from the true value, or provably covers it (its votes included).  Anything else is run
+      // again from the true (or predicted) start -- also a piece whose END is known exactly from a neighbouring start: its
+      // votes are not.
+      if (!hold && D != 0 && !(aD + 4 <= (int64_t)ru.margin)) {
+        Ls2AvgRun *w = a.arun + i;
+        w->s = ls2_from_ord(T);
+        w->wide = (ru.margin < LS2_WIDE_BELOW || r >= 3) ? 1 : 0;
+        const int k = wv::atomic_add(&ctl->avg_list[r], 1);
+        a.alist[(int64_t)(r & 1) * NS + k] = i;
+        n_rerun++;
       }
-      if (sort) { it = 100; break; }
-      // did any wave put an exact end in?  then everything is swept again
-      if (wv::ballot(changed) != 0ull && lane == 0) sh_flag[1] = 1;
-      wv::block_sync();
-      changed = sh_flag[1] != 0;
-      wv::block_sync();
     }
+    Ls2A32 tot; tot.c0 = wv::readlane(incl.c0, 63); tot.c1 = wv::readlane(incl.c1, 63);
+    run = ls2_comp32(run, tot);
   }
   if (n_rerun) wv::atomic_add(&ctl->avg_reruns, n_rerun);
-  if (tid == 0 && s == 0) ctl->avg_rounds = r + 1;
+  if (n_rerun + n_left) wv::atomic_add(&ctl->avg_count[r], n_rerun + n_left);
+  if (tid == 0 && s == 0 && b == 0) ctl->avg_rounds = r + 1;
 }
 
 // ---- 3. state machine ----------------------------------------------------------------------------------------------
@@ -799,32 +823,37 @@ RFID_KERNEL(64) void ls2_fsm_kernel(Ls2Args a) {
 
 // one workgroup per trace: does every unit start from the state its predecessor ended in, with the dc ring a cut assumes
 // (the 48 samples before it closed)?  A unit that does not is appended to its predecessor, which is scanned again.
-RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_fsm_chain_kernel(Ls2Args a) {
+RFID_KERNEL(256) void ls2_fsm_chain_kernel(Ls2Args a) {
   Ls2Ctl *ctl = a.ctl;
   const int r = a.round;
   if (ctl->fail != 0) return;
   if (r == 0) { if (ctl->avg_count[LS2_AVG_ROUNDS] != 0) return; }
   else if (ctl->fsm_count[r - 1] == 0) return;
-  const int s = (int)blockIdx.x;
-  int n_bad = 0;
-  for (int j = (int)threadIdx.x + 1; j < a.max_b; j += LS2_CHAIN_THREADS) {
-    const int i = s * a.max_b + j;
-    if (a.piece[i].len <= 0 || a.fsm[i].head == 0) continue;
-    const int p = a.prevv[i];
-    if (p < 0) continue;
-    const int hp = a.fsm[p].unit;          // the unit the piece before this head belongs to
-    const Ls2Fsm &fp = a.fsm[hp];
-    const Ls2Fsm &fi = a.fsm[i];
-    bool same = fp.last_end <= a.piece[i].pos0 - DC_LEN;
-    for (int k = 0; k < 6; ++k) same = same && (fp.en[k] == fi.st[k]);
-    if (!same) {
-      a.fsm[i].head = 0;
-      a.fsm[hp].rerun = 1;   // (if that unit is appended to ITS predecessor in this round, the flag is stale: the
-      n_bad++;               //  predecessor's unit is flagged by that very mismatch and scans through both)
+  const int NH = a.n_streams * a.max_bc;
+  const int lane = wv::lane_id();
+  const int b = (int)(blockIdx.x * 256 + threadIdx.x);
+  bool bad = false;
+  if (b < NH && (b % a.max_bc) != 0) {   // (a trace's first piece has no predecessor)
+    const int i = (b / a.max_bc) * a.max_b + (b % a.max_bc) * LS2_FINE;
+    if (a.piece[i].len > 0 && a.fsm[i].head != 0) {
+      const int p = a.prevv[i];
+      if (p >= 0) {
+        const int hp = a.fsm[p].unit;          // the unit the piece before this head belongs to
+        const Ls2Fsm &fp = a.fsm[hp];
+        const Ls2Fsm &fi = a.fsm[i];
+        bool same = fp.last_end <= a.piece[i].pos0 - DC_LEN;
+        for (int k = 0; k < 6; ++k) same = same && (fp.en[k] == fi.st[k]);
+        if (!same) {
+          a.fsm[i].head = 0;
+          a.fsm[hp].rerun = 1;   // (if that unit is appended to ITS predecessor in this round, the flag is stale: the
+          bad = true;            //  predecessor's unit is flagged by that very mismatch and scans through both)
+        }
+      }
     }
   }
-  if (n_bad) wv::atomic_add(&ctl->fsm_count[r], n_bad);
-  if (threadIdx.x == 0 && s == 0) ctl->fsm_rounds = r + 1;
+  const uint64_t m = wv::ballot(bad);
+  if (m && lane == 0) wv::atomic_add(&ctl->fsm_count[r], wv::popc64(m));
+  if (b == 0) ctl->fsm_rounds = r + 1;
 }
 
 // ---- 4. dc_est -----------------------------------------------------------------------------------------------------
@@ -1010,21 +1039,21 @@ RFID_DEVICE Ls2DcRec ls2_dc_rec(const Ls2Args &a, int base, int J) {
   return r;
 }
 RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_dc_chain_kernel(Ls2Args a) {
-  RFID_SHARED Ls2A32 wagg[2 * LS2_CHAIN_WAVES];
+  RFID_SHARED Ls2A32 wagg[2 * (LS2_CHAIN_WAVES + 1)];
   Ls2Ctl *ctl = a.ctl;
   const int r = a.round;
-  const int tid = (int)threadIdx.x, s = (int)blockIdx.x;
+  const int tid = (int)threadIdx.x, b = (int)blockIdx.x, s = (int)blockIdx.y;
   if (ctl->fail != 0 || ctl->avg_count[LS2_AVG_ROUNDS] != 0 || ctl->fsm_count[LS2_FSM_ROUNDS] != 0) return;
   if (r > 0 && ctl->dc_count[r - 1] == 0) return;
   const int NS = a.n_streams * a.max_b;
   const int lane = wv::lane_id(), wave = wv::uniform(tid >> 6);
   const int base = s * a.max_b;
   if (a.piece[base].len <= 0) return;
-  const int n_chunks = (a.max_bc + 63) >> 6, cpw = (n_chunks + LS2_CHAIN_WAVES - 1) / LS2_CHAIN_WAVES;
-  const int c_lo = wave * cpw, c_hi = (c_lo + cpw < n_chunks) ? (c_lo + cpw) : n_chunks;
+  int c_lo, c_hi;
+  ls2_chain_range(a.max_bc, a.chain_g, b, wave, c_lo, c_hi);
   const int T0r = ls2_ord(a.drun[base].s[0]), T0i = ls2_ord(a.drun[base].s[1]);
   // ---- sweep 1: this wave's totals ----
-  Ls2A32 cr, ci; cr.c0 = cr.c1 = 0; ci.c0 = ci.c1 = 0;
+  Ls2A32 carry[2]; carry[0].c0 = carry[0].c1 = 0; carry[1].c0 = carry[1].c1 = 0;
   Ls2DcRec nxt = ls2_dc_rec(a, base, 64 * c_lo + lane);
   for (int c = c_lo; c < c_hi; ++c) {
     const Ls2DcRec rec = nxt;
@@ -1036,12 +1065,11 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_dc_chain_kernel(Ls2Args a) {
     }
     const Ls2A32 ir = ls2_wave_incl(er, lane), ii = ls2_wave_incl(ei, lane);
     Ls2A32 tr, ti; tr.c0 = wv::readlane(ir.c0, 63); tr.c1 = wv::readlane(ir.c1, 63); ti.c0 = wv::readlane(ii.c0, 63); ti.c1 = wv::readlane(ii.c1, 63);
-    cr = ls2_comp32(cr, tr); ci = ls2_comp32(ci, ti);
+    carry[0] = ls2_comp32(carry[0], tr); carry[1] = ls2_comp32(carry[1], ti);
   }
-  if (lane == 0) { wagg[2 * wave] = cr; wagg[2 * wave + 1] = ci; }
-  wv::block_sync();
-  Ls2A32 rr, ri; rr.c0 = rr.c1 = 0; ri.c0 = ri.c1 = 0;
-  for (int w = 0; w < wave; ++w) { rr = ls2_comp32(rr, wagg[2 * w]); ri = ls2_comp32(ri, wagg[2 * w + 1]); }
+  Ls2A32 pre[2];
+  ls2_chain_prefix<2>(a, s, b, wave, lane, tid, carry, wagg, pre);
+  Ls2A32 rr = pre[0], ri = pre[1];
   // ---- sweep 2: every unit's true (or predicted) start; what is not proven goes on the re-run list ----
   int n_rerun = 0, n_units = 0;
   nxt = ls2_dc_rec(a, base, 64 * c_lo + lane);
@@ -1078,7 +1106,7 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_dc_chain_kernel(Ls2Args a) {
   }
   if (n_rerun) wv::atomic_add(&ctl->dc_reruns, n_rerun);
   if (r == 0 && n_units) wv::atomic_add(&ctl->n_units, n_units);
-  if (tid == 0 && s == 0) ctl->dc_rounds = r + 1;
+  if (tid == 0 && s == 0 && b == 0) ctl->dc_rounds = r + 1;
 }
 
 // ---- 5. windows ----------------------------------------------------------------------------------------------------
@@ -1086,17 +1114,18 @@ RFID_DEVICE bool ls2_all_settled(const Ls2Ctl *ctl) {
   return ctl->fail == 0 && ctl->avg_count[LS2_AVG_ROUNDS] == 0 && ctl->fsm_count[LS2_FSM_ROUNDS] == 0 &&
          ctl->dc_count[LS2_DC_ROUNDS] == 0 && ctl->wb_clash == 0;
 }
-// one workgroup per trace: the number of complete windows before every unit (exclusive prefix sums: all, EPC), the trace's
-// count, and the trace's places in the decoder's two lists.  Sixteen waves over the slots as in the chain kernels.
+// the number of complete windows before every unit (exclusive prefix sums: all, EPC), the trace's count, and the trace's
+// places in the decoder's two lists.  Workgroups and waves over the slots as in the chain kernels (sums: the pair (v, v)
+// composes by addition).
 RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_seq_kernel(Ls2Args a) {
-  RFID_SHARED int wtot[2 * LS2_CHAIN_WAVES];
+  RFID_SHARED Ls2A32 wagg[2 * (LS2_CHAIN_WAVES + 1)];
   const Ls2Ctl *ctl = a.ctl;
   if (!ls2_all_settled(ctl)) return;
-  const int tid = (int)threadIdx.x, s = (int)blockIdx.x;
+  const int tid = (int)threadIdx.x, b = (int)blockIdx.x, s = (int)blockIdx.y;
   const int lane = wv::lane_id(), wave = wv::uniform(tid >> 6);
   const int base = s * a.max_b;
-  const int n_chunks = (a.max_bc + 63) >> 6, cpw = (n_chunks + LS2_CHAIN_WAVES - 1) / LS2_CHAIN_WAVES;
-  const int c_lo = wave * cpw, c_hi = (c_lo + cpw < n_chunks) ? (c_lo + cpw) : n_chunks;
+  int c_lo, c_hi;
+  ls2_chain_range(a.max_bc, a.chain_g, b, wave, c_lo, c_hi);
   int tw = 0, te = 0;
   for (int c = c_lo; c < c_hi; ++c) {
     const int J = 64 * c + lane, i = base + J * LS2_FINE;
@@ -1105,13 +1134,10 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_seq_kernel(Ls2Args a) {
     tw += wv::readlane(wv::scan_add(nw), 63);
     te += wv::readlane(wv::scan_add(ne), 63);
   }
-  if (lane == 0) { wtot[2 * wave] = tw; wtot[2 * wave + 1] = te; }
-  wv::block_sync();
-  int run = 0, rune = 0, total = 0, total_e = 0;
-  for (int w = 0; w < LS2_CHAIN_WAVES; ++w) {
-    if (w < wave) { run += wtot[2 * w]; rune += wtot[2 * w + 1]; }
-    total += wtot[2 * w]; total_e += wtot[2 * w + 1];
-  }
+  Ls2A32 carry[2], pre[2];
+  carry[0].c0 = carry[0].c1 = tw; carry[1].c0 = carry[1].c1 = te;
+  ls2_chain_prefix<2>(a, s, b, wave, lane, tid, carry, wagg, pre);
+  int run = pre[0].c0, rune = pre[1].c0;
   for (int c = c_lo; c < c_hi; ++c) {
     const int J = 64 * c + lane, i = base + J * LS2_FINE;
     const bool in = J < a.max_bc && a.piece[i].len > 0 && a.fsm[i].head != 0;
@@ -1121,7 +1147,9 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_seq_kernel(Ls2Args a) {
     run += wv::readlane(iw, 63);
     rune += wv::readlane(ie, 63);
   }
-  if (tid == 0) {
+  // the last workgroup's last wave ends on the trace's totals
+  if (b == a.chain_g - 1 && wave == LS2_CHAIN_WAVES - 1 && lane == 0) {
+    const int total = run, total_e = rune;
     a.wcount[s] = (total < a.wmax) ? total : a.wmax;
     a.flat_base[2 * s] = wv::atomic_add(a.flat_count + 0, total - total_e);
     a.flat_base[2 * s + 1] = wv::atomic_add(a.flat_count + 1, total_e);

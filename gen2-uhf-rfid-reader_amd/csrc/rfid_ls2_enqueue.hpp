@@ -40,7 +40,7 @@ inline Ls2Geometry ls2_geometry(int n_streams, int64_t n_dec, int min_piece = LS
 
 // work space: one allocation, carved up here (offsets in bytes, 256-byte aligned)
 struct Ls2Layout {
-  size_t cut, cutf, piece, nextv, prevv, amp, dadd, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, drun, dT, dlist, seq0, flat_base, ctl, consumed, total;
+  size_t cut, cutf, piece, nextv, prevv, amp, dadd, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, drun, dT, dlist, seq0, flat_base, cflag, cagg, ctl, consumed, total;
 };
 inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_stride) {
   Ls2Layout L;
@@ -68,6 +68,8 @@ inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_strid
   L.dlist = take(sizeof(int) * 2 * NS);
   L.seq0 = take(sizeof(int) * 2 * NS);
   L.flat_base = take(sizeof(int) * 2 * B);
+  L.cflag = take(sizeof(int) * B * LS2_CHAIN_GMAX);
+  L.cagg = take(sizeof(int) * 4 * B * LS2_CHAIN_GMAX);
   L.ctl = take(sizeof(Ls2Ctl));
   L.consumed = take(sizeof(int) * B);
   L.total = off;
@@ -82,11 +84,14 @@ inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geomet
   a.arun = (Ls2AvgRun *)(base + L.arun); a.aT = (int *)(base + L.aT); a.alist = (int *)(base + L.alist); a.aover = (Ls2Aff *)(base + L.aover);
   a.fsm = (Ls2Fsm *)(base + L.fsm); a.wb = (Ls2Win *)(base + L.wb);
   a.drun = (Ls2DcRun *)(base + L.drun); a.dT = (int *)(base + L.dT); a.dlist = (int *)(base + L.dlist);
-  a.seq0 = (int *)(base + L.seq0); a.flat_base = (int *)(base + L.flat_base); a.ctl = (Ls2Ctl *)(base + L.ctl); a.consumed = (int *)(base + L.consumed);
+  a.seq0 = (int *)(base + L.seq0); a.flat_base = (int *)(base + L.flat_base); a.cflag = (int *)(base + L.cflag); a.cagg = (int *)(base + L.cagg); a.ctl = (Ls2Ctl *)(base + L.ctl); a.consumed = (int *)(base + L.consumed);
 }
 
+inline int &ls2_chain_slots() { static int v = 4096; return v; }   // slots per workgroup of a chain launch (tests shrink it)
+
 #ifdef LS2_LAUNCH
-// One pass.  Before it (stream-ordered): Ls2Ctl, the votes (a.votes), the window buckets (a.wb) and flat_count zeroed.  `a` complete but for
+// One pass.  Before it (stream-ordered): Ls2Ctl, the chain flags (a.cflag), the votes (a.votes), the window buckets (a.wb)
+// and flat_count zeroed.  `a` complete but for
 // `round`.  After it: wtab / wcount / flat lists + Ls2Ctl::ok = 1, or ok = 0 (the caller's fallback scan, enqueued
 // behind with GateArgs::skip_if = &ctl->ok, then runs).
 inline void ls2_enqueue(Ls2Args a, bool search_cuts = true) {   // (search_cuts = false: a.cut is given -- tests)
@@ -105,31 +110,41 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true) {   // (search_cuts 
     LS2_LAUNCH(ls_cut_kernel, a.max_b - 1, B, 64, cf);
   }
   a.round = 0;
+  a.stamp = 0;
   LS2_LAUNCH(ls2_pieces_kernel, (NS + 255) / 256, 1, 256, a);
   LS2_LAUNCH(ls2_check_kernel, 1, 1, 64, a);
   const int rerun_grid = NS;   // (one wave per list entry; the waves past the list return at once)
+  // workgroups per trace of the chain kernels: a few thousand slots each
+  auto chain_g = [](int slots) { const int per = ls2_chain_slots(); int g = (slots + per - 1) / per; return g < 1 ? 1 : (g > LS2_CHAIN_GMAX ? LS2_CHAIN_GMAX : g); };
+  const int g_avg = chain_g(a.max_b), g_dc = chain_g(a.max_bc);
   LS2_LAUNCH(ls2_avg_first_kernel, NS, 1, 64, a);
-  LS2_LAUNCH(ls2_avg_chain_kernel, B, 1, LS2_CHAIN_THREADS, a);
+  a.chain_g = g_avg; a.stamp++;
+  LS2_LAUNCH(ls2_avg_chain_kernel, g_avg, B, LS2_CHAIN_THREADS, a);
   for (int r = 1; r <= LS2_AVG_ROUNDS; ++r) {
     a.round = r;
     LS2_LAUNCH(ls2_avg_rerun_kernel, rerun_grid, 1, 64, a);
-    LS2_LAUNCH(ls2_avg_chain_kernel, B, 1, LS2_CHAIN_THREADS, a);
+    a.stamp++;
+    LS2_LAUNCH(ls2_avg_chain_kernel, g_avg, B, LS2_CHAIN_THREADS, a);
   }
   for (int r = 0; r <= LS2_FSM_ROUNDS; ++r) {
     a.round = r;
     LS2_LAUNCH(ls2_fsm_kernel, NH, 1, 64, a);
-    LS2_LAUNCH(ls2_fsm_chain_kernel, B, 1, LS2_CHAIN_THREADS, a);
+    LS2_LAUNCH(ls2_fsm_chain_kernel, (NH + 255) / 256, 1, 256, a);
   }
   a.round = 0;
+  a.chain_g = g_dc;
   LS2_LAUNCH(ls2_dc_first_kernel, NH, 1, 64, a);
-  LS2_LAUNCH(ls2_dc_chain_kernel, B, 1, LS2_CHAIN_THREADS, a);
+  a.stamp++;
+  LS2_LAUNCH(ls2_dc_chain_kernel, g_dc, B, LS2_CHAIN_THREADS, a);
   for (int r = 1; r <= LS2_DC_ROUNDS; ++r) {
     a.round = r;
     LS2_LAUNCH(ls2_dc_rerun_kernel, rerun_grid, 1, 64, a);
-    LS2_LAUNCH(ls2_dc_chain_kernel, B, 1, LS2_CHAIN_THREADS, a);
+    a.stamp++;
+    LS2_LAUNCH(ls2_dc_chain_kernel, g_dc, B, LS2_CHAIN_THREADS, a);
   }
   a.round = 0;
-  LS2_LAUNCH(ls2_seq_kernel, B, 1, LS2_CHAIN_THREADS, a);
+  a.stamp++;
+  LS2_LAUNCH(ls2_seq_kernel, g_dc, B, LS2_CHAIN_THREADS, a);
   LS2_LAUNCH(ls2_assemble_kernel, NH, 1, 64, a);
   if (a.carry_out) LS2_LAUNCH(ls2_carry_kernel, B, 1, 64, a);
 }

@@ -313,6 +313,8 @@ int emu_ls2_process(const float *raw, int B, long stride, long n_raw, const int6
   return ok;
 }
 int emu_ls2_ctl_words(void) { return (int)(sizeof(Ls2Ctl) / 4); }
+// slots per workgroup of the chain launches (the library: 4096): small values make the emulated traces span several workgroups
+void emu_ls2_chain_slots(int n) { ls2_chain_slots() = n; }
 
 // gate_scan_kernel in streaming mode (mode 1) on one call's worth of samples.
 // seek_type: -1 none, 0 SEEK_RN16, 1 SEEK_EPC applied before the scan (gate_impl.cc:112-123).

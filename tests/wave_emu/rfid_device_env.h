@@ -8,6 +8,8 @@
 // librfid_mi355x.so and is not a fallback of any kind: the product has no CPU path.
 #pragma once
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
 #include <ucontext.h>
@@ -201,6 +203,9 @@ static inline void set_priority_high() {}
 static inline void backoff() { emu::yield(); }
 static inline int atomic_add(int *p, int v) { int o = *p; *p = o + v; return o; }
 static inline int atomic_min(int *p, int v) { int o = *p; if (v < o) *p = v; return o; }
+static inline void publish(int *flag, int v) { *(volatile int *)flag = v; }
+// (the emulator runs the workgroups of a launch one after the other in index order: a flag of a lower block is set by now)
+static inline void await(const int *flag, int v) { if (*(const volatile int *)flag != v) { fprintf(stderr, "[emu] await on a flag that was never published\n"); abort(); } }
 static inline void atomic_or64(uint64_t *p, uint64_t v) { *p |= v; }
 static inline void atomic_and64(uint64_t *p, uint64_t v) { *p &= v; }
 static inline void global_release() {}
