@@ -56,8 +56,9 @@ struct rfid_ctx {
   Ls2Ctl *ls2_host = nullptr;     // page-locked copy of the control block of the last pass (report) + consumed[0]
   Ls2Ctl *d_ls2_ctl = nullptr;    // the control block of the last pass that ran the front end (device), else nullptr
   int ls2_P = 0;                  // its nominal piece length
+  int ls2_rounds[3] = {0, 0, 0};  // re-run rounds its launch list held per stage (avg_ampl, state machine, dc_est)
   int ls_mode = 1;                // 0 never, 1 automatic, 2 whenever a trace can be cut
-  double ls_fixed_ms = 0.35, ls_ns_per_sample = 0.025, seq_ns_per_sample = 10.2;   // cost model of the automatic choice
+  double ls_fixed_ms = 0.45, ls_ns_per_sample = 0.03, seq_ns_per_sample = 10.2;   // cost model of the automatic choice (ls_calibrate)
   // whole-chain streaming (rfid_stream_*)
   struct StreamIO {
     bool open = false;
@@ -238,6 +239,8 @@ size_t ls_workspace_bytes(int B, int64_t n_dec, int64_t y_stride) {
   return g.P ? ls2_layout(g, B, y_stride).total : 0;
 }
 
+int ls_calibrate(rfid_ctx *c);
+
 struct LsOpts {
   bool carry = false;       // the trace starts from c->d_gstate[trace] (streaming) instead of the fresh gate, and the state
                             // after the last processed piece is written back there
@@ -281,7 +284,7 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
   HIPCHK(c, hipMemsetAsync(a.votes, 0, sizeof(uint64_t) * 2 * (size_t)c->B * (size_t)geo.vstride, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_flat_count, 0, 2 * sizeof(int), c->stream));
   ls2_stream = c->stream;
-  ls2_enqueue(a);
+  ls2_enqueue(a, true, c->ls2_rounds);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(c->ls2_host, a.ctl, sizeof(Ls2Ctl), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync((char *)c->ls2_host + sizeof(Ls2Ctl), a.consumed, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -292,11 +295,11 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const Ls2Ctl &k = *c->ls2_host;
     fprintf(stderr, "[ls2] pieces %d P %d fail %d ok %d | avg:", k.n_pieces, geo.P, k.fail, k.ok);
-    for (int r = 0; r <= LS2_AVG_ROUNDS; ++r) fprintf(stderr, " %d", k.avg_count[r]);
+    for (int r = 0; r <= c->ls2_rounds[0]; ++r) fprintf(stderr, " %d", k.avg_count[r]);
     fprintf(stderr, " | fsm:");
-    for (int r = 0; r <= LS2_FSM_ROUNDS; ++r) fprintf(stderr, " %d", k.fsm_count[r]);
+    for (int r = 0; r <= c->ls2_rounds[1]; ++r) fprintf(stderr, " %d", k.fsm_count[r]);
     fprintf(stderr, " | dc:");
-    for (int r = 0; r <= LS2_DC_ROUNDS; ++r) fprintf(stderr, " %d", k.dc_count[r]);
+    for (int r = 0; r <= c->ls2_rounds[2]; ++r) fprintf(stderr, " %d", k.dc_count[r]);
     fprintf(stderr, " | units %d windows %d\n", k.n_units, k.n_windows);
     std::vector<Ls2AvgRun> ar((size_t)geo.NS);
     std::vector<int> aT((size_t)geo.NS);
@@ -322,6 +325,76 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
     for (int b = 0; b < 8; ++b) fprintf(stderr, " %ld", hist_d[b]);
     fprintf(stderr, "\n");
   }
+  return RFID_OK;
+}
+}  // namespace
+
+namespace {
+// The three numbers of ls_pays_off measured on the device at hand: a Gen2 trace of 64 slots (0.97 M raw samples) and one
+// four times as long are synthesised in HBM and each run through both front ends (whole passes, decoder and statistics
+// included on both sides).  ~20 ms, once per context; any failure leaves the defaults.
+int ls_calibrate(rfid_ctx *c) {
+  const int saved_mode = c->ls_mode;
+  rfid_synth_gen2_params p;
+  memset(&p, 0, sizeof(p));
+  p.leak_re = 0.7648f; p.leak_im = 0.6442f; p.h_re[0] = 0.06f; p.h_im[0] = 0.03f; p.n_tags = 1; p.tail_us = 200;
+  const int n_big = 256;
+  std::vector<rfid_synth_slot> slots((size_t)n_big);
+  for (int i = 0; i < n_big; ++i) {
+    rfid_synth_slot &s = slots[(size_t)i];
+    memset(&s, 0, sizeof(s));
+    s.cmd = (i == 0) ? 0 : 1; s.q = 0; s.n_tags = 1; s.has_epc = 1; s.tag[0] = 0;
+    s.rn16[0] = (uint16_t)(0x5a5a ^ (i * 2654435761u)); s.ack = s.rn16[0];
+    s.rn16_off_raw = 500; s.epc_off_raw = 500;
+    for (int k = 0; k < 4; ++k) s.epc[k] = 0x3000f00fu * (uint32_t)(i + k + 1);
+  }
+  int64_t L[2] = {0, 0};
+  if (rfid_synth_gen2_size(&p, slots.data(), n_big / 4, &L[0]) || rfid_synth_gen2_size(&p, slots.data(), n_big, &L[1])) return RFID_OK;
+  void *d = nullptr;
+  const int64_t stride = (L[1] + 1) & ~1LL;
+  if (hipMalloc(&d, sizeof(float2) * (size_t)stride) != hipSuccess) { (void)hipGetLastError(); return RFID_OK; }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+  double t_seq[2] = {0, 0}, t_ls[2] = {0, 0};
+  for (int k = 0; k < 2 && ok; ++k) {
+    int64_t n = 0;
+    ok = rfid_synth_gen2(c, &p, slots.data(), k ? n_big : n_big / 4, d, stride, 0.003f, 77u, 0, &n) == RFID_OK && n == L[k];
+    ok = ok && rfid_batch_plan(c, 1, L[k]) == RFID_OK;
+    for (int mode = 0; mode <= 2 && ok; mode += 2) {
+      c->ls_mode = mode;
+      float best = 1e30f;
+      for (int rep = 0; rep < 3 && ok; ++rep) {   // (the first pass warms up)
+        ok = hipEventRecord(e0, c->stream) == hipSuccess && rfid_batch_process(c, d, stride, L[k], nullptr, 0) == RFID_OK &&
+             hipEventRecord(e1, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+        float ms = 0.0f;
+        ok = ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+        if (rep > 0 && ms < best) best = ms;
+      }
+      if (mode == 2 && ok) ok = c->d_ls2_ctl != nullptr && c->ls2_host->ok != 0;   // (the front end must have taken the trace)
+      (mode ? t_ls : t_seq)[k] = best;
+    }
+  }
+  c->ls_mode = saved_mode;
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  free_plan(c);
+  c->d_ls2_ctl = nullptr;
+  if (!ok) { (void)hipGetLastError(); return RFID_OK; }
+  const double n0 = (double)(L[0] / DECIM), n1 = (double)(L[1] / DECIM);
+  const double slope = (t_ls[1] - t_ls[0]) / (n1 - n0);          // ms per decimated sample
+  const double fixed = t_ls[0] - slope * n0;
+  if (slope > 0.0 && fixed > 0.0 && t_seq[1] > 0.0) {
+    // long traces need more re-run rounds than these (their rounding drift grows with the square root of the length):
+    // half again on the slope
+    c->ls_ns_per_sample = 1.5 * slope * 1e6;
+    c->ls_fixed_ms = fixed;
+    c->seq_ns_per_sample = t_seq[1] / n1 * 1e6;
+  }
+  if (getenv("RFID_LS_DEBUG"))
+    fprintf(stderr, "[ls2] calibration: fused %.3f / %.3f ms, long-stream %.3f / %.3f ms for %.0f / %.0f samples -> %.2f ns/sample vs %.3f ms + %.4f ns/sample\n",
+            t_seq[0], t_seq[1], t_ls[0], t_ls[1], n0, n1, c->seq_ns_per_sample, c->ls_fixed_ms, c->ls_ns_per_sample);
   return RFID_OK;
 }
 }  // namespace
@@ -404,6 +477,10 @@ int rfid_ctx_create(const rfid_params *p, int device, rfid_ctx **out) {
     if (hipMemset(c->d_gate1, 0, sizeof(GateState)) != hipSuccess) { rc = RFID_ERR_HIP; break; }
   } while (0);
   if (rc != RFID_OK) { rfid_ctx_destroy(c); return rc; }
+  // the automatic choice between the two front ends works on rates measured here (RFID_LS_CALIBRATE=0: the defaults,
+  // measured on one MI355X)
+  const char *cal = getenv("RFID_LS_CALIBRATE");
+  if (c->ls_mode == 1 && !(cal && atoi(cal) == 0)) (void)ls_calibrate(c);
   *out = c;
   return RFID_OK;
 }
@@ -859,18 +936,17 @@ int rfid_batch_ls_report(const rfid_ctx *c, rfid_ls_report *out) {
   (void)hipSetDevice(c->device);
   if (hipStreamSynchronize(c->stream) != hipSuccess) return RFID_ERR_HIP;   // (the copy of the control block rides on the pass)
   const Ls2Ctl &k = *c->ls2_host;
-  const bool settled = k.fail == 0 && k.avg_count[LS2_AVG_ROUNDS] == 0 && k.fsm_count[LS2_FSM_ROUNDS] == 0 &&
-                       k.dc_count[LS2_DC_ROUNDS] == 0 && k.wb_clash == 0;
+  const int ra = c->ls2_rounds[0], rf = c->ls2_rounds[1], rd = c->ls2_rounds[2];
   out->pieces = k.n_pieces;
   out->units = k.n_units;
   out->chunk = c->ls2_P;
   out->avg_rounds = k.avg_rounds; out->avg_reruns = k.avg_reruns;
   out->fsm_rounds = k.fsm_rounds;
   out->dc_rounds = k.dc_rounds; out->dc_reruns = k.dc_reruns;
-  for (int r = 0; r <= LS2_FSM_ROUNDS; ++r) out->cuts_dropped += k.fsm_count[r];
+  for (int r = 0; r <= rf; ++r) out->cuts_dropped += k.fsm_count[r];
   out->windows = k.n_windows;
-  out->verified = (k.ok != 0 && settled) ? 1 : 0;
-  out->gave_up = out->verified ? 0 : (k.fail ? k.fail : (k.avg_count[LS2_AVG_ROUNDS] ? 2 : (k.fsm_count[LS2_FSM_ROUNDS] ? 3 : (k.dc_count[LS2_DC_ROUNDS] ? 4 : 5))));
+  out->verified = (k.ok != 0) ? 1 : 0;
+  out->gave_up = out->verified ? 0 : (k.fail ? k.fail : (k.avg_count[ra] ? 2 : (k.fsm_count[rf] ? 3 : (k.dc_count[rd] ? 4 : 5))));
   return RFID_OK;
 }
 

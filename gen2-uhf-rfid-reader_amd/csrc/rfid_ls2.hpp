@@ -135,6 +135,7 @@ struct Ls2Args {
   int force;                    // run even when no trace could be cut
   int *consumed;                // [n_streams]
   int round;
+  int avg_rounds, fsm_rounds, dc_rounds;   // re-run rounds enqueued behind the first pass of each stage (<= LS2_*_ROUNDS)
   // the chain kernels run on several workgroups per trace: block b publishes the total of its slots, then waits for the
   // blocks before it
   int chain_g;                  // workgroups per trace of this launch
@@ -692,7 +693,7 @@ RFID_KERNEL(64) void ls2_fsm_kernel(Ls2Args a) {
   Ls2Ctl *ctl = a.ctl;
   if (wv::uniform(ctl->fail) != 0) return;
   const int r = a.round;
-  if (r == 0) { if (wv::uniform(ctl->avg_count[LS2_AVG_ROUNDS]) != 0) return; }
+  if (r == 0) { if (wv::uniform(ctl->avg_count[a.avg_rounds]) != 0) return; }
   else if (wv::uniform(ctl->fsm_count[r - 1]) == 0) return;
   const int lane = wv::lane_id();
   const int NH = a.n_streams * a.max_bc;   // heads sit at every LS2_FINE-th slot only: one block per such slot (blocks indexed by
@@ -827,7 +828,7 @@ RFID_KERNEL(256) void ls2_fsm_chain_kernel(Ls2Args a) {
   Ls2Ctl *ctl = a.ctl;
   const int r = a.round;
   if (ctl->fail != 0) return;
-  if (r == 0) { if (ctl->avg_count[LS2_AVG_ROUNDS] != 0) return; }
+  if (r == 0) { if (ctl->avg_count[a.avg_rounds] != 0) return; }
   else if (ctl->fsm_count[r - 1] == 0) return;
   const int NH = a.n_streams * a.max_bc;
   const int lane = wv::lane_id();
@@ -999,13 +1000,13 @@ RFID_DEVICE void ls2_dc_unit(const Ls2Args &a, const int i, const bool first, co
   // processed piece always ends at an idle cut
 }
 
-RFID_DEVICE bool ls2_fsm_settled(const Ls2Ctl *ctl) {
-  return wv::uniform(ctl->fail) == 0 && wv::uniform(ctl->avg_count[LS2_AVG_ROUNDS]) == 0 && wv::uniform(ctl->fsm_count[LS2_FSM_ROUNDS]) == 0;
+RFID_DEVICE bool ls2_fsm_settled(const Ls2Args &a, const Ls2Ctl *ctl) {
+  return wv::uniform(ctl->fail) == 0 && wv::uniform(ctl->avg_count[a.avg_rounds]) == 0 && wv::uniform(ctl->fsm_count[a.fsm_rounds]) == 0;
 }
 RFID_KERNEL(64) void ls2_dc_first_kernel(Ls2Args a) {
   RFID_SHARED float2 lds_dc[DC_LEN];
   RFID_SHARED float2 lds_tmp[64];
-  if (!ls2_fsm_settled(a.ctl)) return;
+  if (!ls2_fsm_settled(a, a.ctl)) return;
   const int lane = wv::lane_id();
   const int NH = a.n_streams * a.max_bc;
   for (int b = (int)blockIdx.x; b < NH; b += (int)gridDim.x) {
@@ -1017,7 +1018,7 @@ RFID_KERNEL(64) void ls2_dc_first_kernel(Ls2Args a) {
 RFID_KERNEL(64) void ls2_dc_rerun_kernel(Ls2Args a) {
   RFID_SHARED float2 lds_dc[DC_LEN];
   RFID_SHARED float2 lds_tmp[64];
-  if (!ls2_fsm_settled(a.ctl)) return;
+  if (!ls2_fsm_settled(a, a.ctl)) return;
   const int NS = a.n_streams * a.max_b;
   const int cnt = wv::uniform(a.ctl->dc_count[a.round - 1]);
   const int lane = wv::lane_id();
@@ -1043,7 +1044,7 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_dc_chain_kernel(Ls2Args a) {
   Ls2Ctl *ctl = a.ctl;
   const int r = a.round;
   const int tid = (int)threadIdx.x, b = (int)blockIdx.x, s = (int)blockIdx.y;
-  if (ctl->fail != 0 || ctl->avg_count[LS2_AVG_ROUNDS] != 0 || ctl->fsm_count[LS2_FSM_ROUNDS] != 0) return;
+  if (ctl->fail != 0 || ctl->avg_count[a.avg_rounds] != 0 || ctl->fsm_count[a.fsm_rounds] != 0) return;
   if (r > 0 && ctl->dc_count[r - 1] == 0) return;
   const int NS = a.n_streams * a.max_b;
   const int lane = wv::lane_id(), wave = wv::uniform(tid >> 6);
@@ -1110,9 +1111,9 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_dc_chain_kernel(Ls2Args a) {
 }
 
 // ---- 5. windows ----------------------------------------------------------------------------------------------------
-RFID_DEVICE bool ls2_all_settled(const Ls2Ctl *ctl) {
-  return ctl->fail == 0 && ctl->avg_count[LS2_AVG_ROUNDS] == 0 && ctl->fsm_count[LS2_FSM_ROUNDS] == 0 &&
-         ctl->dc_count[LS2_DC_ROUNDS] == 0 && ctl->wb_clash == 0;
+RFID_DEVICE bool ls2_all_settled(const Ls2Args &a, const Ls2Ctl *ctl) {
+  return ctl->fail == 0 && ctl->avg_count[a.avg_rounds] == 0 && ctl->fsm_count[a.fsm_rounds] == 0 &&
+         ctl->dc_count[a.dc_rounds] == 0 && ctl->wb_clash == 0;
 }
 // the number of complete windows before every unit (exclusive prefix sums: all, EPC), the trace's count, and the trace's
 // places in the decoder's two lists.  Workgroups and waves over the slots as in the chain kernels (sums: the pair (v, v)
@@ -1120,7 +1121,7 @@ RFID_DEVICE bool ls2_all_settled(const Ls2Ctl *ctl) {
 RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_seq_kernel(Ls2Args a) {
   RFID_SHARED Ls2A32 wagg[2 * (LS2_CHAIN_WAVES + 1)];
   const Ls2Ctl *ctl = a.ctl;
-  if (!ls2_all_settled(ctl)) return;
+  if (!ls2_all_settled(a, ctl)) return;
   const int tid = (int)threadIdx.x, b = (int)blockIdx.x, s = (int)blockIdx.y;
   const int lane = wv::lane_id(), wave = wv::uniform(tid >> 6);
   const int base = s * a.max_b;
@@ -1161,8 +1162,8 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_seq_kernel(Ls2Args a) {
 // the decoder's two lists
 RFID_KERNEL(64) void ls2_assemble_kernel(Ls2Args a) {
   Ls2Ctl *ctl = a.ctl;
-  if (!(wv::uniform(ctl->fail) == 0 && wv::uniform(ctl->avg_count[LS2_AVG_ROUNDS]) == 0 && wv::uniform(ctl->fsm_count[LS2_FSM_ROUNDS]) == 0 &&
-        wv::uniform(ctl->dc_count[LS2_DC_ROUNDS]) == 0 && wv::uniform(ctl->wb_clash) == 0)) return;
+  if (!(wv::uniform(ctl->fail) == 0 && wv::uniform(ctl->avg_count[a.avg_rounds]) == 0 && wv::uniform(ctl->fsm_count[a.fsm_rounds]) == 0 &&
+        wv::uniform(ctl->dc_count[a.dc_rounds]) == 0 && wv::uniform(ctl->wb_clash) == 0)) return;
   const int lane = wv::lane_id();
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   if (blockIdx.x == 0 && lane == 0) ctl->ok = 1;
@@ -1223,8 +1224,8 @@ RFID_KERNEL(64) void ls2_assemble_kernel(Ls2Args a) {
 RFID_KERNEL(64) void ls2_carry_kernel(Ls2Args a) {
   const Ls2Ctl *ctl = a.ctl;
   if (!a.carry_out) return;
-  if (!(wv::uniform(ctl->fail) == 0 && wv::uniform(ctl->avg_count[LS2_AVG_ROUNDS]) == 0 && wv::uniform(ctl->fsm_count[LS2_FSM_ROUNDS]) == 0 &&
-        wv::uniform(ctl->dc_count[LS2_DC_ROUNDS]) == 0 && wv::uniform(ctl->wb_clash) == 0)) return;
+  if (!(wv::uniform(ctl->fail) == 0 && wv::uniform(ctl->avg_count[a.avg_rounds]) == 0 && wv::uniform(ctl->fsm_count[a.fsm_rounds]) == 0 &&
+        wv::uniform(ctl->dc_count[a.dc_rounds]) == 0 && wv::uniform(ctl->wb_clash) == 0)) return;
   const int lane = wv::lane_id();
   const int s = (int)blockIdx.x;
   const int base = s * a.max_b;

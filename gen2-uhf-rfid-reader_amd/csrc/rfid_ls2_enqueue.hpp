@@ -94,7 +94,7 @@ inline int &ls2_chain_slots() { static int v = 4096; return v; }   // slots per 
 // and flat_count zeroed.  `a` complete but for
 // `round`.  After it: wtab / wcount / flat lists + Ls2Ctl::ok = 1, or ok = 0 (the caller's fallback scan, enqueued
 // behind with GateArgs::skip_if = &ctl->ok, then runs).
-inline void ls2_enqueue(Ls2Args a, bool search_cuts = true) {   // (search_cuts = false: a.cut is given -- tests)
+inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nullptr) {   // (search_cuts = false: a.cut is given -- tests)
   const int NS = a.n_streams * a.max_b, NH = a.n_streams * a.max_bc;   // slots; slots that can be heads
   const int B = a.n_streams;
   if (a.max_bc > 1 && search_cuts) {
@@ -111,6 +111,10 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true) {   // (search_cuts 
   }
   a.round = 0;
   a.stamp = 0;
+  // rounds enqueued behind each stage's first pass: a round without work is two empty launches (~10 us), which only a
+  // short pass notices -- and short traces settle in few rounds (their rounding drift is small)
+  const bool small = NS < 32768;
+  a.avg_rounds = small ? 5 : LS2_AVG_ROUNDS; a.fsm_rounds = small ? 2 : LS2_FSM_ROUNDS; a.dc_rounds = small ? 4 : LS2_DC_ROUNDS;
   LS2_LAUNCH(ls2_pieces_kernel, (NS + 255) / 256, 1, 256, a);
   LS2_LAUNCH(ls2_check_kernel, 1, 1, 64, a);
   const int rerun_grid = NS;   // (one wave per list entry; the waves past the list return at once)
@@ -120,13 +124,13 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true) {   // (search_cuts 
   LS2_LAUNCH(ls2_avg_first_kernel, NS, 1, 64, a);
   a.chain_g = g_avg; a.stamp++;
   LS2_LAUNCH(ls2_avg_chain_kernel, g_avg, B, LS2_CHAIN_THREADS, a);
-  for (int r = 1; r <= LS2_AVG_ROUNDS; ++r) {
+  for (int r = 1; r <= a.avg_rounds; ++r) {
     a.round = r;
     LS2_LAUNCH(ls2_avg_rerun_kernel, rerun_grid, 1, 64, a);
     a.stamp++;
     LS2_LAUNCH(ls2_avg_chain_kernel, g_avg, B, LS2_CHAIN_THREADS, a);
   }
-  for (int r = 0; r <= LS2_FSM_ROUNDS; ++r) {
+  for (int r = 0; r <= a.fsm_rounds; ++r) {
     a.round = r;
     LS2_LAUNCH(ls2_fsm_kernel, NH, 1, 64, a);
     LS2_LAUNCH(ls2_fsm_chain_kernel, (NH + 255) / 256, 1, 256, a);
@@ -136,7 +140,7 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true) {   // (search_cuts 
   LS2_LAUNCH(ls2_dc_first_kernel, NH, 1, 64, a);
   a.stamp++;
   LS2_LAUNCH(ls2_dc_chain_kernel, g_dc, B, LS2_CHAIN_THREADS, a);
-  for (int r = 1; r <= LS2_DC_ROUNDS; ++r) {
+  for (int r = 1; r <= a.dc_rounds; ++r) {
     a.round = r;
     LS2_LAUNCH(ls2_dc_rerun_kernel, rerun_grid, 1, 64, a);
     a.stamp++;
@@ -147,6 +151,7 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true) {   // (search_cuts 
   LS2_LAUNCH(ls2_seq_kernel, g_dc, B, LS2_CHAIN_THREADS, a);
   LS2_LAUNCH(ls2_assemble_kernel, NH, 1, 64, a);
   if (a.carry_out) LS2_LAUNCH(ls2_carry_kernel, B, 1, 64, a);
+  if (rounds_out) { rounds_out[0] = a.avg_rounds; rounds_out[1] = a.fsm_rounds; rounds_out[2] = a.dc_rounds; }
 }
 #endif
 

@@ -56,7 +56,7 @@ def test_config2_full_size_multi_tag_inventory(oracle_mod, synth_mod):
         rep = ctx.batch_ls_report()
         print("long-stream report:", rep)
         assert rep["verified"] == 1 and rep["pieces"] > (1000 if not SMALL else 100) and not rep["gave_up"]
-        assert rep["windows"] == 2 * len(t.slots) and rep["avg_rounds"] <= 5 and rep["dc_rounds"] <= 5, rep
+        assert rep["windows"] == 2 * len(t.slots) and rep["avg_rounds"] <= 10 and rep["dc_rounds"] <= 8, rep
         w, r, _ = ctx.batch_windows()
         st = ctx.batch_stats()
         n_slots = len(t.slots)
@@ -166,8 +166,9 @@ def test_config4_hbm_capacity_shard(gpu_ctx, oracle_mod, synth_mod):
 
 def test_front_end_is_chosen_by_cost_estimate(synth_mod):
     """Mode 1 of rfid_batch_set_long_stream (the default): the long-stream front end runs when it is expected to beat the
-    fused one -- one trace of 80 inventory rounds (1.2 M raw samples) is cut into units; 128 replicas of it are not
-    (the fused front end serves up to 1024 traces side by side).  Same windows and results either way."""
+    fused one, by a cost model whose rates are measured on the device when the context is created -- one trace of 80
+    inventory rounds (1.2 M raw samples) is cut into pieces; 1024 replicas of it are not (the fused front end serves 1024
+    traces side by side, one per SIMD).  Same windows and results either way."""
     import rfid
     import torch
     t = synth_mod.make_trace(n_rounds=80, fixed_q=0, tag_ids=(0x3C,), sigma=0.0, seed=31, noise=False, render=False)
@@ -181,7 +182,7 @@ def test_front_end_is_chosen_by_cost_estimate(synth_mod):
         assert rep["verified"] == 1 and rep["units"] > 1 and ctx.batch_timing()["fused_front"] == 0, rep
         w1, r1, _ = ctx.batch_windows()
         assert ctx.batch_stats()[0]["n_epc_correct"] == len(t.slots)
-        B = 128
+        B = 1024
         many = data[: 2 * stride].repeat(B)
         torch.cuda.synchronize()
         ctx.batch_plan(B, L)
