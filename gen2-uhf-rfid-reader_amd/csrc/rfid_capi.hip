@@ -330,15 +330,15 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
 }  // namespace
 
 namespace {
-// The three numbers of ls_pays_off measured on the device at hand: a Gen2 trace of 64 slots (0.97 M raw samples) and one
-// four times as long are synthesised in HBM and each run through both front ends (whole passes, decoder and statistics
-// included on both sides).  ~20 ms, once per context; any failure leaves the defaults.
+// The three numbers of ls_pays_off measured on the device at hand: a Gen2 trace of 64 slots (0.97 M raw samples) alone,
+// and 16 noise replicas of one four times as long, are synthesised in HBM and run through both front ends (whole
+// passes, decoder and statistics included on both sides).  ~30 ms, once per context; any failure leaves the defaults.
 int ls_calibrate(rfid_ctx *c) {
   const int saved_mode = c->ls_mode;
   rfid_synth_gen2_params p;
   memset(&p, 0, sizeof(p));
   p.leak_re = 0.7648f; p.leak_im = 0.6442f; p.h_re[0] = 0.06f; p.h_im[0] = 0.03f; p.n_tags = 1; p.tail_us = 200;
-  const int n_big = 256;
+  const int n_big = 256, B_big = 16;
   std::vector<rfid_synth_slot> slots((size_t)n_big);
   for (int i = 0; i < n_big; ++i) {
     rfid_synth_slot &s = slots[(size_t)i];
@@ -350,27 +350,34 @@ int ls_calibrate(rfid_ctx *c) {
   }
   int64_t L[2] = {0, 0};
   if (rfid_synth_gen2_size(&p, slots.data(), n_big / 4, &L[0]) || rfid_synth_gen2_size(&p, slots.data(), n_big, &L[1])) return RFID_OK;
-  void *d = nullptr;
+  void *d_base = nullptr, *d_many = nullptr;
   const int64_t stride = (L[1] + 1) & ~1LL;
-  if (hipMalloc(&d, sizeof(float2) * (size_t)stride) != hipSuccess) { (void)hipGetLastError(); return RFID_OK; }
+  if (hipMalloc(&d_base, sizeof(float2) * (size_t)stride) != hipSuccess ||
+      hipMalloc(&d_many, sizeof(float2) * (size_t)stride * B_big) != hipSuccess) {
+    (void)hipGetLastError();
+    if (d_base) (void)hipFree(d_base);
+    return RFID_OK;
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
   double t_seq[2] = {0, 0}, t_ls[2] = {0, 0};
   for (int k = 0; k < 2 && ok; ++k) {
     int64_t n = 0;
-    ok = rfid_synth_gen2(c, &p, slots.data(), k ? n_big : n_big / 4, d, stride, 0.003f, 77u, 0, &n) == RFID_OK && n == L[k];
-    ok = ok && rfid_batch_plan(c, 1, L[k]) == RFID_OK;
+    const int B = k ? B_big : 1;
+    ok = rfid_synth_gen2(c, &p, slots.data(), k ? n_big : n_big / 4, d_base, stride, 0.0f, 77u, 0, &n) == RFID_OK && n == L[k];
+    ok = ok && rfid_synth_replicas(c, d_base, L[k], d_many, stride, B, 0.003f, 78u, 0) == RFID_OK;
+    ok = ok && rfid_batch_plan(c, B, L[k]) == RFID_OK;
     for (int mode = 0; mode <= 2 && ok; mode += 2) {
       c->ls_mode = mode;
       float best = 1e30f;
       for (int rep = 0; rep < 3 && ok; ++rep) {   // (the first pass warms up)
-        ok = hipEventRecord(e0, c->stream) == hipSuccess && rfid_batch_process(c, d, stride, L[k], nullptr, 0) == RFID_OK &&
+        ok = hipEventRecord(e0, c->stream) == hipSuccess && rfid_batch_process(c, d_many, stride, L[k], nullptr, 0) == RFID_OK &&
              hipEventRecord(e1, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
         float ms = 0.0f;
         ok = ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
         if (rep > 0 && ms < best) best = ms;
       }
-      if (mode == 2 && ok) ok = c->d_ls2_ctl != nullptr && c->ls2_host->ok != 0;   // (the front end must have taken the trace)
+      if (mode == 2 && ok) ok = c->d_ls2_ctl != nullptr && c->ls2_host->ok != 0;   // (the front end must have taken the traces)
       (mode ? t_ls : t_seq)[k] = best;
     }
   }
@@ -378,23 +385,24 @@ int ls_calibrate(rfid_ctx *c) {
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
   (void)hipStreamSynchronize(c->stream);
-  (void)hipFree(d);
+  (void)hipFree(d_base);
+  (void)hipFree(d_many);
   free_plan(c);
   c->d_ls2_ctl = nullptr;
   if (!ok) { (void)hipGetLastError(); return RFID_OK; }
-  const double n0 = (double)(L[0] / DECIM), n1 = (double)(L[1] / DECIM);
-  const double slope = (t_ls[1] - t_ls[0]) / (n1 - n0);          // ms per decimated sample
+  const double n0 = (double)(L[0] / DECIM), n1 = (double)(L[1] / DECIM), N1 = n1 * B_big;
+  const double slope = (t_ls[1] - t_ls[0]) / (N1 - n0);          // ms per decimated sample of all traces
   const double fixed = t_ls[0] - slope * n0;
   if (slope > 0.0 && fixed > 0.0 && t_seq[1] > 0.0) {
     // long traces need more re-run rounds than these (their rounding drift grows with the square root of the length):
-    // half again on the slope
-    c->ls_ns_per_sample = 1.5 * slope * 1e6;
+    // a quarter more on the slope
+    c->ls_ns_per_sample = 1.25 * slope * 1e6;
     c->ls_fixed_ms = fixed;
-    c->seq_ns_per_sample = t_seq[1] / n1 * 1e6;
+    c->seq_ns_per_sample = t_seq[1] / n1 * 1e6;   // (sixteen traces side by side take the time of one)
   }
   if (getenv("RFID_LS_DEBUG"))
-    fprintf(stderr, "[ls2] calibration: fused %.3f / %.3f ms, long-stream %.3f / %.3f ms for %.0f / %.0f samples -> %.2f ns/sample vs %.3f ms + %.4f ns/sample\n",
-            t_seq[0], t_seq[1], t_ls[0], t_ls[1], n0, n1, c->seq_ns_per_sample, c->ls_fixed_ms, c->ls_ns_per_sample);
+    fprintf(stderr, "[ls2] calibration: fused %.3f / %.3f ms, long-stream %.3f / %.3f ms for 1 x %.0f / %d x %.0f samples -> %.2f ns/sample of the longest trace vs %.3f ms + %.4f ns/sample of all\n",
+            t_seq[0], t_seq[1], t_ls[0], t_ls[1], n0, B_big, n1, c->seq_ns_per_sample, c->ls_fixed_ms, c->ls_ns_per_sample);
   return RFID_OK;
 }
 }  // namespace
