@@ -226,6 +226,27 @@ def streaming_leg(torch, rfid, wl, args, device):
         ctx.close()
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-execute this script once per GPU (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* as torch.distributed.run would set them), rank 0's stdout -- the one JSON line -- passed
+    through.  Returns the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=os.environ.get("MASTER_PORT", str(port)), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,6 +270,9 @@ def main():
     if args.warmup is None:
         args.warmup = 2 if args.config in ("1", "3stream") else 1
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))     # plain `python bench.py --gpus N`: start the N ranks ourselves
+
     import torch
     import rfid
     from rfid import synth
@@ -259,17 +283,21 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the receive path has no CPU fallback")
     if args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with "
-                         f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
-                         f"bench.py --gpus {args.gpus} ...")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # one process per GPU.  (RFID_BENCH_SHARE_DEVICES=1 + RFID_BENCH_BACKEND=gloo: several ranks on the devices at hand -- the
+    # multi-rank path on a one-GPU box; RCCL itself refuses two ranks per device.)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % n_dev if os.environ.get("RFID_BENCH_SHARE_DEVICES") else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
+    backend = os.environ.get("RFID_BENCH_BACKEND", "nccl")
     if world > 1 or os.environ.get("RFID_BENCH_FORCE_DIST"):   # (the env var lets a 1-GPU box exercise the RCCL path)
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    ctl_device = device if backend == "nccl" else torch.device("cpu")   # where the control-plane tensors live
     n_gpus = world
 
     if args.config == "1":
@@ -313,10 +341,13 @@ def main():
         step_s.append(time.perf_counter() - ts)
     barrier()
     elapsed = time.perf_counter() - t0
+    ms_by_rank = [1e3 * elapsed / args.steps]
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)     # control plane only: max time over ranks
-        elapsed = float(tt.item())
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=ctl_device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                  # control plane only: every rank's time; the job's = the slowest
+        ms_by_rank = [1e3 * float(t.item()) / args.steps for t in every]
+        elapsed = max(float(t.item()) for t in every)
 
     # ---- kernel durations: HIP events on the ctx stream around each launch, read in a separate (untimed)
     #      series of the same passes so that the event reads stay out of the timed region -----------------
@@ -406,6 +437,7 @@ def main():
         "roofline": roof(dominant),
         "roofline_by_kernel": {k: roof(k) for k in alg},
         "front_end_ms": round(k_ms["front_ms"], 4),
+        "ms_per_step_by_rank": [round(v, 4) for v in ms_by_rank],
     }
     rep = ctx.batch_ls_report()
     if rep["pieces"]:

@@ -28,6 +28,7 @@ class Context:
         self._h = h
         self.device = int(device)
         self._planned: Optional[Tuple[int, int]] = None
+        self._active = 0
 
     # -- lifetime ------------------------------------------------------------------------
     def close(self) -> None:
@@ -129,6 +130,8 @@ class Context:
     def stream_begin(self, max_chunk_raw: int) -> None:
         self._chk(self._lib.rfid_stream_begin(self._h, int(max_chunk_raw)))
         self._stream_cap = 4096
+        self._planned = (1, int(max_chunk_raw))   # (the stream runs on a one-trace plan of its own)
+        self._active = 1
 
     def stream_staging(self, idx: int) -> np.ndarray:
         """One of the two pinned staging buffers as a complex64 array (fill it, then pass a slice that starts at

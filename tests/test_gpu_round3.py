@@ -1,0 +1,122 @@
+"""GPU tests added in round 3: the launcher-free multi-rank bench, a stream with a stretch the long-stream front end
+cannot cut, non-finite samples."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import parity
+
+pytestmark = pytest.mark.gpu
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: the script re-executes itself once per rank and rank 0 prints the
+    one JSON line (n_gpus = 2, one time per rank, whole-job value).  On a one-GPU box both ranks share the device and the
+    control plane runs over gloo (RCCL refuses two ranks per device); the data path is the same."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(RFID_BENCH_SHARE_DEVICES="1", RFID_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(ROOT_DIR, "bench.py"), "--gpus", "2", "--streams", "48", "--steps", "2",
+                          "--warmup", "1", "--no-cpu-baseline", "--no-stream-leg"], cwd=ROOT_DIR, env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and len(d["ms_per_step_by_rank"]) == 2 and d["scaling"] == "weak"
+    assert d["parity_check"].startswith("ok") and d["value"] > 0
+    assert abs(d["ms_per_step"] - max(d["ms_per_step_by_rank"])) < 1e-3
+
+
+def _stream(ctx, x, chunk):
+    ws, rs = [], []
+    for pos in range(0, len(x), chunk):
+        w, r = ctx.stream_work(x[pos:pos + chunk])
+        ws.append(w); rs.append(r)
+    w, r = ctx.stream_work(flush=True)
+    ws.append(w); rs.append(r)
+    return np.concatenate(ws), np.concatenate(rs)
+
+
+def test_stream_with_a_stretch_that_cannot_be_cut(oracle_mod, synth_mod):
+    """rfid_stream_work over a stream whose middle is 0.35 s of noise without a carrier (no idle point of the gate for
+    far longer than a call holds back) and whose end is a carrier with readers' commands but hardly any quiet time: the
+    calls that cannot be cut go through the sequential scan from the carried state instead of failing, and the stream
+    stays usable.  Windows, dc_est, decoded fields and statistics equal the oracle's over the whole stream."""
+    import rfid
+    a = synth_mod.make_trace(n_rounds=12, seed=31, sigma=0.01).samples
+    b = synth_mod.make_trace(n_rounds=12, seed=32, sigma=0.01).samples
+    rng = np.random.default_rng(5)
+    gap = (0.02 * (rng.standard_normal(700_000) + 1j * rng.standard_normal(700_000))).astype(np.complex64)
+    x = np.concatenate([a, gap, b]).astype(np.complex64)
+    o = oracle_mod.run_trace(x)
+    ctx = rfid.Context(device=0)
+    try:
+        ctx.stream_begin(250_000)
+        w, r = _stream(ctx, x, 200_000)
+        assert len(w) == o.n_windows, (len(w), o.n_windows)
+        assert np.array_equal(w["start"], o.open_idx) and np.array_equal(w["type"], o.dumps["type"])
+        assert np.array_equal(w["dc_re"].view(np.uint32), o.dc.real.view(np.uint32))
+        assert np.array_equal(w["dc_im"].view(np.uint32), o.dc.imag.view(np.uint32))
+        fake = np.zeros(len(w), dtype=rfid.capi.WINDOW_DTYPE)
+        fake["start"], fake["type"], fake["dc_re"], fake["dc_im"] = w["start"], w["type"], w["dc_re"], w["dc_im"]
+        parity.compare_trace_fast(fake, r, None, o)
+        assert ctx.stats() == o.stats()
+        ctx.stream_end()
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("mode", [0, 2], ids=["fused", "long-stream"])
+def test_non_finite_samples_propagate_as_in_the_reference(oracle_mod, synth_mod, mode):
+    """The contract for samples that are not finite: nothing is rejected or sanitised -- they go through the matched
+    filter and the gate's recurrences exactly as through the reference's (gate_impl.cc:130-162: a NaN amplitude turns
+    avg_ampl into NaN for good, every threshold test then fails and the gate never opens again; an infinity becomes a
+    NaN when it leaves the 100-sample ring).  Window positions, types and dc_est are bit-identical to the oracle's, and
+    so is every decoded field of the windows that hold finite samples only; what the decoder makes of a window that
+    itself contains a non-finite sample is unspecified (the reference's own answer hangs on how std::max_element
+    orders NaNs)."""
+    import rfid
+    import torch
+    t = synth_mod.make_trace(n_rounds=6, sigma=0.01, seed=5).samples
+    clean = oracle_mod.run_trace(t)
+    cases = [("inf in the carrier", int(clean.open_idx[6]) * 5 - 2000, complex(np.inf, 0.0)),
+             ("nan inside a window", int(clean.open_idx[7]) * 5 + 300, complex(np.nan, 1.0)),
+             ("-inf inside a window", int(clean.open_idx[3]) * 5 + 100, complex(0.0, -np.inf))]
+    ctx = rfid.Context(device=0)
+    try:
+        ctx.batch_set_long_stream(mode)
+        for name, pos, val in cases:
+            x = t.copy()
+            x[pos] = np.complex64(val)
+            o = oracle_mod.run_trace(x)
+            L = len(x)
+            stride = (L + 1) & ~1
+            host = np.zeros((1, stride), dtype=np.complex64)
+            host[0, :L] = x
+            dev = torch.from_numpy(host.view(np.float32)).to("cuda:0")
+            ctx.batch_plan(1, L)
+            ctx.batch_process_ptr(dev.data_ptr(), stride, L, 0, want_scores=False)
+            ctx.batch_sync()
+            w, r, _ = ctx.batch_windows()
+            assert o.n_windows < clean.n_windows, name                  # (the gate does go blind behind the bad sample)
+            assert len(w) == o.n_windows, (name, len(w), o.n_windows)
+            assert np.array_equal(w["start"], o.open_idx) and np.array_equal(w["type"], o.dumps["type"]), name
+            assert np.array_equal(w["dc_re"].view(np.uint32), o.dc.real.view(np.uint32)), name
+            assert np.array_equal(w["dc_im"].view(np.uint32), o.dc.imag.view(np.uint32)), name
+            y = oracle_mod.fir(x)
+            assert np.array_equal(ctx.batch_mf_output(0).view(np.uint32), y.view(np.uint32)), name
+            for i in range(o.n_windows):
+                wlen = 1370 if o.dumps["type"][i] else 250
+                if not np.isfinite(y[o.open_idx[i]: o.open_idx[i] + wlen].view(np.float32)).all():
+                    continue
+                d = o.dumps[i]
+                assert r["index"][i] == d["index"] and r["n_bits"][i] == d["n_bits"], (name, i)
+                assert np.array_equal(rfid.unpack_bits(r["bits"][i], int(d["n_bits"])), d["bits"][: d["n_bits"]]), (name, i)
+                assert r["crc_ok"][i] == d["crc_ok"], (name, i)
+    finally:
+        ctx.close()
