@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <new>
 #include <vector>
@@ -78,6 +79,31 @@ struct rfid_ctx {
     std::vector<rfid_stream_window> out_w;   // windows completed but not yet delivered (caller arrays too small)
     std::vector<rfid_decode_result> out_r;
   } sio;
+  // look-ahead of the per-block calls (rfid_lookahead_enable): what rfid_mf_work's whole-chain pass left for the gate /
+  // decoder calls that follow
+  struct LookAhead {
+    struct Win {
+      int64_t start = 0;              // global decimated position of the opening sample
+      int type = 0, len = 0;
+      rfid_decode_result res;
+      std::vector<rfid_cf32> gated;   // in[i] - dc_est over the window
+      std::vector<float> m2;          // |.|^2 of those
+    };
+    bool on = false, flushed = false;
+    int64_t gate_pos = 0;             // decimated samples the gate calls have consumed
+    int64_t y0 = 0;                   // global position of yq[0]
+    std::deque<rfid_cf32> yq;         // matched-filter output handed out and not consumed by the gate yet
+    std::deque<Win> wins;             // windows the gate has not (completely) handed out yet
+    int emitted = 0;                  // samples of wins.front() already handed out (gate open)
+    std::deque<Win> dq;               // windows handed out by the gate, waiting for the decoder (results only)
+    int stall = 0;                    // gate calls in a row without progress and without new input
+    std::vector<float> last_m2;       // |.|^2 of what the last gate call wrote
+    // scratch of one whole-chain pass
+    DevBuf d_gated, d_m2;
+    rfid_cf32 *h_gated = nullptr; float *h_m2 = nullptr; rfid_cf32 *h_y = nullptr;
+    size_t h_cap = 0, h_ycap = 0;
+    int64_t want_y0 = 0; int want_yn = 0;   // matched-filter outputs (global positions) the current rfid_mf_work call returns
+  } la;
   rfid_window *d_swin = nullptr;  // one window
   int *d_scount = nullptr;
   rfid_decode_result *d_sres = nullptr;
@@ -117,6 +143,11 @@ struct rfid_ctx {
 namespace {
 
 void sio_free(rfid_ctx *c);   // (whole-chain streaming, below)
+int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush);
+void la_free(rfid_ctx *c);    // (look-ahead of the per-block calls)
+int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap, int *n_produced);
+int la_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap, int *n_consumed, int *n_written);
+bool la_decoder_result(rfid_ctx *c, const rfid_cf32 *in, int wlen, int type, rfid_decode_result *r);
 
 int fail(rfid_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
   if (c) {
@@ -497,6 +528,7 @@ int rfid_ctx_destroy(rfid_ctx *c) {
   if (!c) return RFID_ERR_INVALID;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  la_free(c);
   sio_free(c);
   free_plan(c);
   void *ptrs[] = {c->d_gate1, c->d_io, c->d_swin, c->d_scount, c->d_sres, c->d_sscores, c->s_in.p, c->s_out.p,
@@ -527,6 +559,7 @@ int rfid_ctx_reset(rfid_ctx *c) {
   init_reader_state(c);
   memset(c->mf_hist, 0, sizeof(c->mf_hist));
   c->mf_seen = 0;
+  if (c->la.on) { la_free(c); sio_free(c); }
   HIPCHK(c, hipMemsetAsync(c->d_gate1, 0, sizeof(GateState), c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return RFID_OK;
@@ -1180,6 +1213,7 @@ int rfid_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int
   *n_produced = 0;
   if (n_in == 0) return RFID_OK;
   HIPCHK(c, hipSetDevice(c->device));
+  if (c->la.on) return la_mf_work(c, in, n_in, out, out_cap, n_produced);
   // A decimating GNU Radio block produces output n once the whole group x[5n .. 5n+4] has arrived
   // (sync_decimator: noutput = ninput / decim), although y[n] only needs x[5n-24 .. 5n]: a stream of
   // N samples yields floor(N/5) outputs, the same as rfid_batch_mf / the fused front end.
@@ -1234,8 +1268,17 @@ int rfid_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, i
     const int type = (rs.gate_status == RFID_GATE_SEEK_EPC) ? 1 : 0;
     rs.gate_status = RFID_GATE_CLOSED;
     rs.n_samples_to_ungate = type ? EPC_WIN : RN16_WIN;
-    hipLaunchKernelGGL(gate_arm_kernel, dim3(1), dim3(64), 0, c->stream, c->d_gate1, rs.n_samples_to_ungate, type);
-    HIPCHK(c, hipGetLastError());   // (stream-ordered before the scan below: no host round trip)
+    if (!c->la.on) {
+      hipLaunchKernelGGL(gate_arm_kernel, dim3(1), dim3(64), 0, c->stream, c->d_gate1, rs.n_samples_to_ungate, type);
+      HIPCHK(c, hipGetLastError());   // (stream-ordered before the scan below: no host round trip)
+    }
+  }
+  if (c->la.on) {
+    // (the SEEK_* -> CLOSED arming above touched the per-call gate state only, which the look-ahead does not use)
+    if (rs.status != RFID_RUNNING) { c->la.gate_pos += n_in; c->la.last_m2.clear(); while (c->la.y0 < c->la.gate_pos && !c->la.yq.empty()) { c->la.yq.pop_front(); c->la.y0++; } return RFID_OK; }
+    if (n_in == 0) return RFID_OK;
+    if (!out || out_cap < n_in) return RFID_ERR_CAPACITY;
+    return la_gate_work(c, in, n_in, out, out_cap, n_consumed, n_written);
   }
   if (rs.status != RFID_RUNNING || n_in == 0) return RFID_OK;
   if (!out || out_cap < n_in) return RFID_ERR_CAPACITY;  // a call can emit up to n_in samples
@@ -1278,6 +1321,11 @@ int rfid_decoder_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, float *out_bit
   const int wlen = (type == RFID_DECODE_EPC) ? EPC_WIN : RN16_WIN;
   if (ung != wlen) return fail(c, RFID_ERR_STATE, "n_samples_to_ungate does not match decoder_status");
   if (type == RFID_DECODE_RN16 && (!out_bits || out_cap < 16)) return RFID_ERR_CAPACITY;
+  rfid_decode_result r;
+  rfid_scores sc;
+  memset(&sc, 0, sizeof(sc));
+  const bool from_la = c->la.on && !scores_out && la_decoder_result(c, in, wlen, type, &r);
+  if (!from_la) {
   int rc = grow(c, c->s_in, sizeof(float2) * (size_t)(wlen + 2));
   if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(c->s_in.p, in, sizeof(rfid_cf32) * (size_t)wlen, hipMemcpyHostToDevice, c->stream));
@@ -1292,11 +1340,10 @@ int rfid_decoder_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, float *out_bit
   memcpy(a.t_cand, c->t_cand, sizeof(a.t_cand));
   hipLaunchKernelGGL(decode_windows_kernel, dim3(1), dim3(64), 0, c->stream, a);
   HIPCHK(c, hipGetLastError());
-  rfid_decode_result r;
-  rfid_scores sc;
   HIPCHK(c, hipMemcpyAsync(&r, c->d_sres, sizeof(r), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(&sc, c->d_sscores, sizeof(sc), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   if (res_out) *res_out = r;
   if (scores_out) *scores_out = sc;
   if (type == RFID_DECODE_RN16) {
@@ -1424,6 +1471,17 @@ int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
     HIPCHK(c, hipGetLastError());
     c->d_lens = nullptr;
     c->last_n_raw = n_have;
+    if (c->la.on && c->la.want_yn > 0) {   // look-ahead: the filter outputs the current rfid_mf_work call hands out
+      const int64_t lo = c->la.want_y0 - io.raw_base / DECIM;
+      if (lo < 0 || lo + c->la.want_yn > n_out) return fail(c, RFID_ERR_STATE, "look-ahead: matched-filter outputs out of range");
+      if ((size_t)c->la.want_yn > c->la.h_ycap) {
+        if (c->la.h_y) (void)hipHostFree(c->la.h_y);
+        c->la.h_y = nullptr; c->la.h_ycap = 0;
+        HIPCHK(c, hipHostMalloc((void **)&c->la.h_y, sizeof(rfid_cf32) * (size_t)c->la.want_yn * 2, hipHostMallocDefault));
+        c->la.h_ycap = (size_t)c->la.want_yn * 2;
+      }
+      HIPCHK(c, hipMemcpyAsync(c->la.h_y, c->d_y + lo, sizeof(rfid_cf32) * (size_t)c->la.want_yn, hipMemcpyDeviceToHost, c->stream));
+    }
     // ---- gate: the pieces up to the last idle cut, from the carried state (the long-stream front end) ----
     LsOpts opt;
     opt.carry = true; opt.hold_last = !flush; opt.force = true;
@@ -1477,13 +1535,45 @@ int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
         std::vector<rfid_decode_result> r((size_t)wc);
         HIPCHK(c, hipMemcpyAsync(w.data(), c->d_wtab, sizeof(rfid_window) * (size_t)wc, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(r.data(), c->d_res, sizeof(rfid_decode_result) * (size_t)wc, hipMemcpyDeviceToHost, c->stream));
+        if (c->la.on) {
+          // look-ahead: the gated samples of these windows (in[i] - dc_est) and their |.|^2, formed on the device
+          const size_t cap = (size_t)wc * EPC_WIN;
+          if ((rc = grow(c, c->la.d_gated, sizeof(float2) * cap))) return rc;
+          if ((rc = grow(c, c->la.d_m2, sizeof(float) * cap))) return rc;
+          if (cap > c->la.h_cap) {
+            if (c->la.h_gated) (void)hipHostFree(c->la.h_gated);
+            if (c->la.h_m2) (void)hipHostFree(c->la.h_m2);
+            c->la.h_gated = nullptr; c->la.h_m2 = nullptr; c->la.h_cap = 0;
+            HIPCHK(c, hipHostMalloc((void **)&c->la.h_gated, sizeof(rfid_cf32) * cap * 2, hipHostMallocDefault));
+            HIPCHK(c, hipHostMalloc((void **)&c->la.h_m2, sizeof(float) * cap * 2, hipHostMallocDefault));
+            c->la.h_cap = cap * 2;
+          }
+          hipLaunchKernelGGL(gated_windows_kernel, dim3((unsigned)wc), dim3(256), 0, c->stream, (const rfid_window *)c->d_wtab,
+                             (const int *)c->d_wcount, c->wmax, (const float2 *)c->d_y, (float2 *)c->la.d_gated.p, (float *)c->la.d_m2.p);
+          HIPCHK(c, hipGetLastError());
+          HIPCHK(c, hipMemcpyAsync(c->la.h_gated, c->la.d_gated.p, sizeof(rfid_cf32) * cap, hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(c, hipMemcpyAsync(c->la.h_m2, c->la.d_m2.p, sizeof(float) * cap, hipMemcpyDeviceToHost, c->stream));
+        }
         HIPCHK(c, hipStreamSynchronize(c->stream));
         const int64_t n0 = io.raw_base / DECIM;
+        size_t goff = 0;
         for (int i = 0; i < wc; ++i) {
+          const rfid_window &wi = w[(size_t)i];
+          const int len = wi.type ? EPC_WIN : RN16_WIN;
+          if (c->la.on) {
+            // (the READER_STATE bookkeeping is done by the gate / decoder / reader calls that consume this window)
+            c->la.wins.emplace_back();
+            rfid_ctx::LookAhead::Win &q = c->la.wins.back();
+            q.start = n0 + wi.start; q.type = wi.type; q.len = len; q.res = r[(size_t)i];
+            q.gated.assign(c->la.h_gated + goff, c->la.h_gated + goff + len);
+            q.m2.assign(c->la.h_m2 + goff, c->la.h_m2 + goff + len);
+            goff += (size_t)len;
+            continue;
+          }
           if (!sio_account(c, r[(size_t)i])) break;   // TERMINATED: the gate swallows the rest (gate_impl.cc:125,198)
           rfid_stream_window sw;
-          sw.start = n0 + w[(size_t)i].start; sw.type = w[(size_t)i].type; sw.reserved_ = 0;
-          sw.dc_re = w[(size_t)i].dc_re; sw.dc_im = w[(size_t)i].dc_im;
+          sw.start = n0 + wi.start; sw.type = wi.type; sw.reserved_ = 0;
+          sw.dc_re = wi.dc_re; sw.dc_im = wi.dc_im;
           io.out_w.push_back(sw);
           io.out_r.push_back(r[(size_t)i]);
         }
@@ -1501,6 +1591,7 @@ int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
   io.tail_len = left;
   io.raw_base += DECIM * consumed;
   (void)n_windows;
+  if (c->la.on) HIPCHK(c, hipStreamSynchronize(c->stream));   // (the filter outputs for the caller have arrived)
   return RFID_OK;
 }
 }  // namespace
@@ -1621,6 +1712,161 @@ int rfid_stream_end(rfid_ctx *c) {
   if (c->sio.copy_stream) (void)hipStreamSynchronize(c->sio.copy_stream);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   sio_free(c);
+  return RFID_OK;
+}
+
+}  // extern "C"
+
+// ======================================================================================
+// (1c) look-ahead of the per-block calls (rfid_lookahead_enable)
+// ======================================================================================
+namespace {
+void la_free(rfid_ctx *c) {
+  rfid_ctx::LookAhead &la = c->la;
+  if (la.h_gated) (void)hipHostFree(la.h_gated);
+  if (la.h_m2) (void)hipHostFree(la.h_m2);
+  if (la.h_y) (void)hipHostFree(la.h_y);
+  if (la.d_gated.p) (void)hipFree(la.d_gated.p);
+  if (la.d_m2.p) (void)hipFree(la.d_m2.p);
+  la = rfid_ctx::LookAhead();
+}
+
+bool same_sample(const rfid_cf32 &a, const rfid_cf32 &b) { return memcmp(&a, &b, sizeof(a)) == 0; }
+
+// rfid_mf_work with the look-ahead on: the whole chain over what is held back + the new samples, in one submission
+int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap, int *n_produced) {
+  rfid_ctx::StreamIO &io = c->sio;
+  rfid_ctx::LookAhead &la = c->la;
+  if (!io.open || io.failed || la.flushed) return fail(c, RFID_ERR_STATE, "look-ahead: the stream has ended (rfid_ctx_reset starts a new one)");
+  if (n_in > io.max_chunk) return fail(c, RFID_ERR_CAPACITY, "look-ahead: rfid_mf_work call larger than the max_chunk_raw given to rfid_lookahead_enable");
+  const int64_t n_first = c->mf_seen / DECIM;
+  const int n_out = (int)((c->mf_seen + n_in) / DECIM - n_first);
+  if (n_out > out_cap || (n_out > 0 && !out)) return RFID_ERR_CAPACITY;
+  const int up = io.cur;
+  HIPCHK(c, hipEventSynchronize(io.ev_free[up]));   // (the call before last, processed long ago)
+  memcpy(io.h_pin[up], in, sizeof(rfid_cf32) * (size_t)n_in);
+  HIPCHK(c, hipMemcpyAsync(io.d_buf[up] + io.tail_max, io.h_pin[up], sizeof(rfid_cf32) * (size_t)n_in, hipMemcpyHostToDevice, c->stream));
+  io.cur ^= 1;
+  la.want_y0 = n_first; la.want_yn = n_out;
+  const int rc = sio_process(c, up, n_in, false);
+  la.want_yn = 0;
+  if (rc) { io.failed = true; return rc; }
+  if (n_out > 0) {
+    memcpy(out, la.h_y, sizeof(rfid_cf32) * (size_t)n_out);
+    la.yq.insert(la.yq.end(), la.h_y, la.h_y + n_out);
+  }
+  c->mf_seen += n_in;
+  la.stall = 0;
+  *n_produced = n_out;
+  return RFID_OK;
+}
+
+// rfid_gate_work with the look-ahead on (gate_impl.cc:127-199 answered from the windows the whole-chain pass found)
+int la_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap, int *n_consumed, int *n_written) {
+  (void)out_cap;
+  rfid_ctx::StreamIO &io = c->sio;
+  rfid_ctx::LookAhead &la = c->la;
+  rfid_reader_state &rs = c->rs;
+  *n_consumed = 0; *n_written = 0;
+  la.last_m2.clear();
+  const int64_t p = la.gate_pos;
+  // the input must be the matched filter's output at the gate's position
+  if (p < la.y0 || p + n_in > la.y0 + (int64_t)la.yq.size() || !same_sample(in[0], la.yq[(size_t)(p - la.y0)]) ||
+      !same_sample(in[n_in - 1], la.yq[(size_t)(p + n_in - 1 - la.y0)]))
+    return fail(c, RFID_ERR_STATE, "look-ahead: rfid_gate_work was not handed the matched filter's output at the gate's position");
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const int64_t frontier = io.raw_base / DECIM;   // the gate's doing is known for the samples before this position
+    int consumed = 0, written = 0;
+    bool open_after = false;
+    while (!la.wins.empty() && la.wins.front().start + la.wins.front().len <= p && la.emitted == 0) la.wins.pop_front();   // (never: windows are consumed in order)
+    if (!la.wins.empty() && (la.emitted > 0 || la.wins.front().start < p + n_in)) {
+      rfid_ctx::LookAhead::Win &w = la.wins.front();
+      if (la.emitted == 0 && w.len != rs.n_samples_to_ungate)
+        return fail(c, RFID_ERR_STATE, "look-ahead: the window the gate was armed for is not the next one of the RN16 / EPC alternation");
+      const int64_t from = w.start + la.emitted;           // first sample of the window still to hand out (>= p)
+      const int64_t upto = (w.start + w.len < p + n_in) ? (w.start + w.len) : (p + n_in);
+      written = (int)(upto - from);
+      memcpy(out, w.gated.data() + la.emitted, sizeof(rfid_cf32) * (size_t)written);
+      la.last_m2.assign(w.m2.begin() + la.emitted, w.m2.begin() + la.emitted + written);
+      la.emitted += written;
+      if (la.emitted == w.len) {                           // gate_impl.cc:189-194: closed, consume_each(i + 1)
+        consumed = (int)(w.start + w.len - p);
+        la.dq.push_back(std::move(w));
+        la.dq.back().gated.resize(2);                      // (the decoder call is checked against its first and last sample)
+        la.dq.back().gated[1] = la.dq.back().gated[0];
+        la.wins.pop_front();
+        la.emitted = 0;
+      } else {
+        consumed = n_in;
+        open_after = true;
+      }
+    } else {
+      // no opening in [p, p + n_in) as far as the gate's doing is known
+      const int64_t lim = (p + n_in < frontier) ? (p + n_in) : frontier;
+      consumed = (lim > p) ? (int)(lim - p) : 0;
+    }
+    if (consumed == 0 && written == 0 && !la.flushed) {
+      // nothing can be decided before more samples arrive.  The second such call in a row without new input: the
+      // stream has ended -- what is held back goes through now
+      if (++la.stall < 2) break;
+      la.want_yn = 0;
+      const int rc = (io.tail_len > 0) ? sio_process(c, io.cur, 0, true) : RFID_OK;
+      if (rc) { io.failed = true; return rc; }
+      la.flushed = true;   // (rfid_stream_work's flush: everything available is decided now)
+      continue;
+    }
+    if (consumed > 0 || written > 0) la.stall = 0;
+    // keep the state the window's last sample leaves: the dc ring etc. live on the device; here only what the blocks share
+    rs.gate_status = open_after ? RFID_GATE_OPEN : RFID_GATE_CLOSED;
+    // (the bit copy of the last handed-out sample identifies the decoder's input later)
+    if (written > 0 && !la.dq.empty() && !open_after) {
+      rfid_ctx::LookAhead::Win &d = la.dq.back();
+      d.gated[1] = out[written - 1];
+    }
+    la.gate_pos += consumed;
+    while (la.y0 < la.gate_pos && !la.yq.empty()) { la.yq.pop_front(); la.y0++; }
+    *n_consumed = consumed;
+    *n_written = written;
+    return RFID_OK;
+  }
+  return RFID_OK;
+}
+
+// rfid_decoder_work with the look-ahead on: the result of the window the gate handed out, when `in` is that window
+bool la_decoder_result(rfid_ctx *c, const rfid_cf32 *in, int wlen, int type, rfid_decode_result *r) {
+  rfid_ctx::LookAhead &la = c->la;
+  if (la.dq.empty()) return false;
+  const rfid_ctx::LookAhead::Win &w = la.dq.front();
+  if (w.len != wlen || w.type != type || w.gated.size() < 2 || !same_sample(in[0], w.gated[0]) || !same_sample(in[wlen - 1], w.gated[1])) return false;
+  *r = w.res;
+  la.dq.pop_front();
+  return true;
+}
+}  // namespace
+
+extern "C" {
+
+int rfid_lookahead_enable(rfid_ctx *c, int64_t max_chunk_raw) {
+  if (!c || max_chunk_raw < 1) return RFID_ERR_INVALID;
+  if (c->mf_seen != 0) return fail(c, RFID_ERR_STATE, "rfid_lookahead_enable: the stream has started");
+  la_free(c);
+  int64_t cap = max_chunk_raw;
+  if (cap < 5 * 4 * (int64_t)LS2_FINE * LS2_MIN_PIECE) cap = 5 * 4 * (int64_t)LS2_FINE * LS2_MIN_PIECE;
+  const rfid_reader_state keep = c->rs;            // rfid_stream_begin sets the whole-chain form's READER_STATE; these calls keep theirs
+  int rc = rfid_stream_begin(c, cap);
+  c->rs = keep;
+  if (rc) return rc;
+  c->sio.max_chunk = (max_chunk_raw < cap) ? cap : max_chunk_raw;
+  c->la.on = true;
+  return RFID_OK;
+}
+
+int rfid_gate_magn_squared(rfid_ctx *c, float *out, int cap, int *n) {
+  if (!c || !n || cap < 0 || (cap > 0 && !out)) return RFID_ERR_INVALID;
+  const int k = (int)c->la.last_m2.size();
+  *n = k;
+  if (k > cap) return RFID_ERR_CAPACITY;
+  if (k > 0) memcpy(out, c->la.last_m2.data(), sizeof(float) * (size_t)k);
   return RFID_OK;
 }
 

@@ -1127,6 +1127,26 @@ RFID_KERNEL(64) void ls_cut_kernel(LsCutArgs a) {
   if (lane == 0) *out = found;
 }
 
+// look-ahead of the per-block calls: the gated, DC-removed samples of the windows of a call, one after the other
+// (in[i] - dc_est, gate_impl.cc:176,187), and their squared magnitudes (:171,175,186: std::norm = re*re + im*im).
+// One workgroup per window; a window's place = the lengths of the windows before it.
+RFID_KERNEL(256) void gated_windows_kernel(const rfid_window *wtab, const int *wcount, int wmax, const float2 *y, float2 *out, float *m2) {
+  int n = *wcount;
+  if (n > wmax) n = wmax;
+  const int b = (int)blockIdx.x;
+  if (b >= n) return;
+  int off = 0;
+  for (int k = 0; k < b; ++k) off += wtab[k].type ? EPC_WIN : RN16_WIN;
+  const rfid_window w = wtab[b];
+  const int len = w.type ? EPC_WIN : RN16_WIN;
+  for (int i = (int)threadIdx.x; i < len; i += 256) {
+    const float2 v = y[w.start + i];
+    const float re = v.x - w.dc_re, im = v.y - w.dc_im;
+    out[off + i] = make_float2(re, im);
+    m2[off + i] = re * re + im * im;
+  }
+}
+
 // gate_impl.cc:112-123 for the streaming gate: SEEK_* -> CLOSED arms the next window (one launch, no host round trip)
 RFID_KERNEL(64) void gate_arm_kernel(GateState *st, int n_to_ungate, int wtype) {
   if (threadIdx.x == 0) { st->n_samples = 0; st->n_to_ungate = n_to_ungate; st->wtype = wtype; }

@@ -68,6 +68,7 @@ class RFID_BLOCK_API sts_flowgraph {
   reader::sptr d_reader;
   int d_chunk;
   long d_windows = 0;
+  int d_idle_calls = 0;
   bool d_keep_tx = false, d_keep_taps = false;
   std::vector<float> d_tx, d_txbuf, d_bits;
   std::vector<gr_complex> d_tap_mf, d_tap_gate;

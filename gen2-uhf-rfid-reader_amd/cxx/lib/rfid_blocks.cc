@@ -4,6 +4,9 @@
 // consume_each() / produce() / the return value exactly as the reference's blocks do
 // (lib/gate_impl.cc:79-83,198-199; lib/tag_decoder_impl.cc:72-76,266,395-396; lib/reader_impl.cc:194-198,378-379).
 // No sample arithmetic happens here and there is no CPU fallback: gate::make() throws without a gfx950 device.
+// The matched filter switches the library's look-ahead on (rfid_lookahead_enable): its general_work() then runs the
+// whole chain for the buffer on the device and the gate / tag_decoder calls are answered from what that left on the
+// host -- same counts, same bytes, ~6 device round trips per inventory slot less (RFID_LOOKAHEAD=0: off).
 #include <rfid/mi355x.h>
 
 #include <cstdio>
@@ -52,7 +55,8 @@ struct next_config { int device = 0; rfid_params p; bool set = false; } g_next;
 // construction to the stream of the most recent gate; a matched_filter binds to it too unless that stream already
 // has one -- then, or when no gate exists yet (apps/reader.py:75 builds the filter first), it waits for the next gate.
 thread_local stream_sptr g_current;
-thread_local std::vector<stream_sptr *> g_pending_filters;
+// (weak: a filter that dies before its gate appears -- on whatever thread -- simply drops out)
+thread_local std::vector<std::weak_ptr<stream_sptr>> g_pending_filters;
 
 int env_int(const char *name, int dflt) {
   const char *e = getenv(name);
@@ -85,10 +89,13 @@ class gate_impl : public gate {
                                   " (the MI355X receive path has no CPU fallback)");
     d_stream = s;
     g_current = s;
-    if (!g_pending_filters.empty()) {
-      *g_pending_filters.front() = s;
+    while (!g_pending_filters.empty()) {
+      std::shared_ptr<stream_sptr> slot = g_pending_filters.front().lock();
       g_pending_filters.erase(g_pending_filters.begin());
+      if (!slot) continue;             // that filter is gone
+      *slot = s;
       s->has_filter = true;
+      break;
     }
     gettimeofday(&s->mirror.reader_stats.start, nullptr);
     initialize_reader_state();   // lib/gate_impl.cc:69
@@ -107,8 +114,16 @@ class gate_impl : public gate {
     if (written > 0) {   // magn_squared_samples side channel (lib/gate_impl.cc:171,175,186)
       std::vector<float> &m2 = d_stream->mirror.magn_squared_samples;
       if (before != GATE_OPEN) m2.clear();
-      const gr_complex *o = (const gr_complex *)output_items[0];
-      for (int i = 0; i < written; ++i) m2.push_back(std::norm(o[i]));
+      const size_t at = m2.size();
+      m2.resize(at + (size_t)written);
+      int got = 0;
+      // formed on the device together with the gated samples (look-ahead); without the look-ahead the per-call gate path
+      // returns the samples only and the mirror is filled here with the reference's own expression
+      d_stream->check(rfid_gate_magn_squared(d_stream->ctx, m2.data() + at, written, &got), "rfid_gate_magn_squared");
+      if (got != written) {
+        const gr_complex *o = (const gr_complex *)output_items[0];
+        for (int i = 0; i < written; ++i) m2[at + (size_t)i] = std::norm(o[i]);
+      }
     }
     consume_each(consumed);   // lib/gate_impl.cc:198
     return written;           // :199
@@ -181,24 +196,30 @@ class matched_filter_impl : public matched_filter {
     for (const gr_complex &t : taps)
       if (t != gr_complex(1.0f, 0.0f)) throw mi355x::error(RFID_ERR_UNSUPPORTED, "only all-ones taps are built");
     if (g_current && !g_current->has_filter) { *d_slot = g_current; g_current->has_filter = true; }
-    else g_pending_filters.push_back(d_slot.get());
-  }
-  ~matched_filter_impl() {
-    for (size_t i = 0; i < g_pending_filters.size(); ++i)
-      if (g_pending_filters[i] == d_slot.get()) { g_pending_filters.erase(g_pending_filters.begin() + (long)i); break; }
+    else g_pending_filters.push_back(d_slot);
   }
   void forecast(int noutput_items, gr_vector_int &ninput_items_required) override { ninput_items_required[0] = noutput_items * 5; }
   int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
                    gr_vector_void_star &output_items) override {
     if (!*d_slot) throw mi355x::error(RFID_ERR_STATE, "gr::rfid::matched_filter: no gate constructed yet");
     stream &st = **d_slot;
+    // a decimator consumes what its output has room for (sync_decimator: noutput * decim), however much the scheduler offers
+    const int n_in = std::min(ninput_items[0], 5 * noutput_items);
+    if (!d_started) {
+      d_started = true;
+      if (env_int("RFID_LOOKAHEAD", 1) != 0) {
+        const int64_t cap = std::max<int64_t>(5 * (int64_t)noutput_items, ninput_items[0]) + 64;
+        st.check(rfid_lookahead_enable(st.ctx, cap), "rfid_lookahead_enable");
+      }
+    }
     int n_out = 0;
-    st.check(rfid_mf_work(st.ctx, (const rfid_cf32 *)input_items[0], ninput_items[0], (rfid_cf32 *)output_items[0],
+    st.check(rfid_mf_work(st.ctx, (const rfid_cf32 *)input_items[0], n_in, (rfid_cf32 *)output_items[0],
                           noutput_items, &n_out), "rfid_mf_work");
-    consume_each(ninput_items[0]);
+    consume_each(n_in);
     return n_out;
   }
-  std::unique_ptr<stream_sptr> d_slot;   // bound now or by the next gate
+  std::shared_ptr<stream_sptr> d_slot;   // bound now or by the next gate
+  bool d_started = false;
 };
 
 }  // namespace
@@ -256,9 +277,11 @@ void sts_flowgraph::reader_until_idle(int n_items) {
 
 void sts_flowgraph::run(const gr_complex *samples, size_t n) {
   reader_until_idle(0);   // START -> SEND_QUERY -> IDLE
+  // the buffers between the blocks: read positions move, the data does not (it is dropped when a buffer has been read up)
   std::vector<gr_complex> gq, dq, mf_out((size_t)d_chunk + 8), gate_out((size_t)d_chunk);
+  size_t g_rd = 0, d_rd = 0;
   size_t pos = 0;
-  while (pos < n || !gq.empty()) {
+  while (pos < n || g_rd < gq.size()) {
     if (pos < n) {
       const size_t take = (n - pos < (size_t)d_chunk * 5) ? (n - pos) : (size_t)d_chunk * 5;
       gr_vector_int nin(1, (int)take);
@@ -266,24 +289,27 @@ void sts_flowgraph::run(const gr_complex *samples, size_t n) {
       gr_vector_void_star out(1, mf_out.data());
       d_mf->minirt_begin_work();
       const int produced = d_mf->general_work((int)mf_out.size(), nin, in, out);
+      if (g_rd > 0) { gq.erase(gq.begin(), gq.begin() + (long)g_rd); g_rd = 0; }
       gq.insert(gq.end(), mf_out.begin(), mf_out.begin() + produced);
       if (d_keep_taps) d_tap_mf.insert(d_tap_mf.end(), mf_out.begin(), mf_out.begin() + produced);
-      pos += take;
+      pos += (size_t)d_mf->minirt_consumed();
     }
-    while (!gq.empty()) {
-      const int avail = (int)(gq.size() < (size_t)d_chunk ? gq.size() : (size_t)d_chunk);
+    while (g_rd < gq.size()) {
+      const size_t have = gq.size() - g_rd;
+      const int avail = (int)(have < (size_t)d_chunk ? have : (size_t)d_chunk);
       gr_vector_int nin(1, avail);
-      gr_vector_const_void_star in(1, gq.data());
+      gr_vector_const_void_star in(1, gq.data() + g_rd);
       gr_vector_void_star out(1, gate_out.data());
       d_gate->minirt_begin_work();
       const int written = d_gate->general_work(avail, nin, in, out);
       const int consumed = d_gate->minirt_consumed();
-      gq.erase(gq.begin(), gq.begin() + consumed);
+      g_rd += (size_t)consumed;
+      if (d_rd > 0 && d_rd == dq.size()) { dq.clear(); d_rd = 0; }
       dq.insert(dq.end(), gate_out.begin(), gate_out.begin() + written);
       if (d_keep_taps) d_tap_gate.insert(d_tap_gate.end(), gate_out.begin(), gate_out.begin() + written);
       for (;;) {
-        gr_vector_int dn(1, (int)dq.size());
-        gr_vector_const_void_star din(1, dq.data());
+        gr_vector_int dn(1, (int)(dq.size() - d_rd));
+        gr_vector_const_void_star din(1, dq.data() + d_rd);
         gr_vector_void_star dout(2, nullptr);
         dout[0] = d_bits.data();
         d_dec->minirt_begin_work();
@@ -291,10 +317,18 @@ void sts_flowgraph::run(const gr_complex *samples, size_t n) {
         const int dcons = d_dec->minirt_consumed();
         if (dcons == 0) break;
         d_windows++;
-        dq.erase(dq.begin(), dq.begin() + dcons);
+        d_rd += (size_t)dcons;
         reader_until_idle(d_dec->minirt_produced(0));
       }
-      if (consumed == 0) break;
+      if (consumed == 0 && written == 0) {
+        // the gate can decide nothing on what it has: more input first (at the end of the stream it is simply asked again:
+        // with the library's look-ahead the second such call in a row flushes what is held back)
+        if (pos < n) break;
+        if (++d_idle_calls > 4) { g_rd = gq.size(); break; }
+      } else {
+        d_idle_calls = 0;
+        if (consumed == 0) break;
+      }
     }
   }
 }

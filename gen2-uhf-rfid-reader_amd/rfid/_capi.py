@@ -102,6 +102,8 @@ SIGNATURES = {
     "rfid_stream_staging": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(C.c_int64)]),
     "rfid_stream_work": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _i64, C.POINTER(C.c_int64)]),
     "rfid_stream_end": (_i, [_vp]),
+    "rfid_lookahead_enable": (_i, [_vp, _i64]),
+    "rfid_gate_magn_squared": (_i, [_vp, _vp, _i, C.POINTER(_i)]),
     "rfid_batch_get_gated": (_i, [_vp, _i, _i, _vp, _i64, C.POINTER(C.c_int64)]),
     "rfid_batch_plan": (_i, [_vp, _i, _i64]),
     "rfid_batch_set_streams": (_i, [_vp, _i]),

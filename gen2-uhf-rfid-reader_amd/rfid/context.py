@@ -127,6 +127,10 @@ class Context:
         return cons.value, out[: wr.value].copy()
 
     # -- (1b) whole-chain streaming ------------------------------------------------------------------
+    def lookahead_enable(self, max_chunk_raw: int) -> None:
+        """The per-block calls (mf_work / gate_work / decoder_work) answered from one whole-chain pass per mf_work call."""
+        self._chk(self._lib.rfid_lookahead_enable(self._h, int(max_chunk_raw)))
+
     def stream_begin(self, max_chunk_raw: int) -> None:
         self._chk(self._lib.rfid_stream_begin(self._h, int(max_chunk_raw)))
         self._stream_cap = 4096

@@ -17,7 +17,7 @@ from . import blocks
 
 class reader_top_block:
     def __init__(self, source_path: Optional[str] = None, samples: Optional[np.ndarray] = None,
-                 device: int = 0, chunk: int = 8192, **params):
+                 device: int = 0, chunk: int = 8192, lookahead: bool = False, **params):
         # variables of apps/reader.py:52-65
         self.dac_rate = 1e6
         self.adc_rate = 100e6 / 50
@@ -38,6 +38,8 @@ class reader_top_block:
         self.ctx = self.gate.ctx
         assert self.matched_filter.ctx is self.ctx and self.tag_decoder.ctx is self.ctx and self.reader.ctx is self.ctx
         self.decoded = []        # (result, scores) per decoded window, for inspection
+        if lookahead:            # the library answers the gate / decoder calls from one whole-chain pass per filter call
+            self.ctx.lookahead_enable(self.chunk * self.decim)
 
     def _reader_until_idle(self, q: int) -> None:
         for _ in range(8):

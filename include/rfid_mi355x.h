@@ -190,6 +190,24 @@ RFID_API int rfid_gate_work(rfid_ctx *ctx, const rfid_cf32 *in, int n_in, rfid_c
 RFID_API int rfid_decoder_work(rfid_ctx *ctx, const rfid_cf32 *in, int n_in, float *out_bits,
                                int out_cap, int *n_consumed, int *n_produced,
                                rfid_decode_result *res, rfid_scores *scores);
+/* Look-ahead for the three per-block calls above.  Called block by block, every rfid_gate_work / rfid_decoder_work is
+ * a host <-> device round trip for a few hundred samples (~6 per inventory slot: slower than one CPU core).  With the
+ * look-ahead on, rfid_mf_work runs the WHOLE chain for the buffer it is handed (matched filter -> gate -> tag_decoder in
+ * one submission, the machinery of rfid_stream_work, state carried on the device) and keeps the filter output, the
+ * gate's windows -- their gated, DC-removed samples included -- and the decoder's results on the host; the gate / decoder
+ * calls that follow are answered from there when their input is the data this library itself handed out (the gate's
+ * input must be the matched filter's output, the decoder's input the gate's output: first and last sample of every
+ * call are compared; anything else is RFID_ERR_STATE), with the same consume / produce counts, outputs and READER_STATE
+ * transitions as without it (lib/gate_impl.cc:189-199, lib/tag_decoder_impl.cc:223,266,289,393-396).  The window types
+ * are those of the reference's own control flow (RN16, EPC, RN16, ...: after an RN16 the reader always ACKs).
+ * What lies behind the last idle point of the gate in the samples seen so far is not decided yet: a gate call consumes
+ * up to there and no further; two gate calls in a row that can make no progress without new input mean the stream has
+ * ended and flush what is left.  max_chunk_raw: the largest n_in rfid_mf_work will see.  Call before the
+ * first sample; rfid_ctx_reset switches it off. */
+RFID_API int rfid_lookahead_enable(rfid_ctx *ctx, int64_t max_chunk_raw);
+/* |out[i]|^2 of the samples the last rfid_gate_work wrote (READER_STATE::magn_squared_samples, lib/gate_impl.cc:171,175,186),
+ * computed on the device with the reference's expression re*re + im*im.  Look-ahead mode only (else *n = 0). */
+RFID_API int rfid_gate_magn_squared(rfid_ctx *ctx, float *out, int cap, int *n);
 /* reader_impl::general_work, state transitions only (gate_status / decoder_status /
  * n_queries_sent) without the transmit waveform (see rfid_reader_work_tx).  n_in = float items
  * available on the reader's input (16 after an RN16). */

@@ -120,3 +120,51 @@ def test_non_finite_samples_propagate_as_in_the_reference(oracle_mod, synth_mod,
                 assert r["crc_ok"][i] == d["crc_ok"], (name, i)
     finally:
         ctx.close()
+
+
+def test_block_by_block_calls_with_look_ahead_give_the_same_bytes(tmp_path, oracle_mod, synth_mod):
+    """rfid_reader_offline block by block (one C-ABI call per general_work) with the library's look-ahead on (default)
+    and off: the same report, the same reader output (--tx-out), matched-filter output and gated samples, byte for
+    byte, for a scheduler buffer of 65 536 and of 1 000 items -- and the oracle's report.  The look-ahead must also be
+    faster (it exists because the per-call path is slower than one CPU core)."""
+    import rfid
+    exe = os.path.join(rfid.capi.PKG_ROOT, "bin", "rfid_reader_offline")
+    t = synth_mod.make_trace(n_rounds=120, fixed_q=1, tag_ids=(0x27, 0x3C), seed=77, sigma=0.01, t1_jitter_raw=4, corrupt_rounds=(5,))
+    path = tmp_path / "t.bin"
+    rfid.batch.write_trace_file(str(path), t.samples)
+    o = oracle_mod.run_trace(t.samples, oracle_mod.config(fixed_q=1))
+    rates = {}
+    for chunk in ("65536", "1000"):
+        outs = {}
+        for la in ("1", "0"):
+            files = [tmp_path / f"{k}_{chunk}_{la}.bin" for k in ("tx", "mf", "gate")]
+            env = dict(os.environ, RFID_LOOKAHEAD=la)
+            out = subprocess.run([exe, str(path), "--fixed-q", "1", "--chunk", chunk, "--time", "--tx-out", str(files[0]),
+                                  "--mf-out", str(files[1]), "--gate-out", str(files[2])], capture_output=True, text=True,
+                                 timeout=900, env=env)
+            assert out.returncode == 0, out.stderr
+            assert out.stdout.startswith(o.print_results()), (chunk, la)
+            outs[la] = [open(f, "rb").read() for f in files]
+            rates[(chunk, la)] = float(out.stderr.split(" ms = ")[1].split(" Msamples/s")[0])
+        assert outs["1"][0] == outs["0"][0], "reader output differs"
+        assert outs["1"][1] == outs["0"][1], "matched-filter output differs"
+        assert outs["1"][2] == outs["0"][2], "gated samples differ"
+        y = np.frombuffer(outs["1"][1], dtype=np.complex64)
+        assert np.array_equal(y.view(np.uint32), oracle_mod.fir(t.samples).view(np.uint32))
+    print("block-by-block rates, Msamples/s:", rates)
+    assert rates[("65536", "1")] > 3 * rates[("65536", "0")]
+
+
+def test_python_flowgraph_with_look_ahead(oracle_mod, synth_mod):
+    """rfid.reader_top_block (the apps/reader.py topology on the ctypes binding) with the look-ahead: the oracle's report."""
+    import rfid
+    t = synth_mod.make_trace(n_rounds=20, seed=9, sigma=0.01).samples
+    o = oracle_mod.run_trace(t)
+    tb = rfid.reader_top_block(samples=t, chunk=20000, lookahead=True)
+    try:
+        tb.run()
+        assert tb.ctx.stats() == o.stats()
+        assert tb.ctx.print_results() == o.print_results()
+        assert len(tb.decoded) == o.n_windows
+    finally:
+        tb.ctx.close()
