@@ -1527,12 +1527,55 @@ int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
       c->ev_valid[2] = false;
       if ((rc = rfid_batch_decode(c, 0))) return rc;
       int wc = 0;
-      HIPCHK(c, hipMemcpyAsync(&wc, c->d_wcount, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
+      // look-ahead: a call's worth of windows is fetched speculatively together with their count (one synchronisation less)
+      const int LA_FETCH = 64;
+      std::vector<rfid_window> w;
+      std::vector<rfid_decode_result> r;
+      bool have_all = false;
+      if (c->la.on) {
+        const int nf = (LA_FETCH < c->wmax) ? LA_FETCH : c->wmax;
+        const size_t cap = (size_t)nf * EPC_WIN;
+        if ((rc = grow(c, c->la.d_gated, sizeof(float2) * cap))) return rc;
+        if ((rc = grow(c, c->la.d_m2, sizeof(float) * cap))) return rc;
+        if (cap > c->la.h_cap) {
+          if (c->la.h_gated) (void)hipHostFree(c->la.h_gated);
+          if (c->la.h_m2) (void)hipHostFree(c->la.h_m2);
+          c->la.h_gated = nullptr; c->la.h_m2 = nullptr; c->la.h_cap = 0;
+          HIPCHK(c, hipHostMalloc((void **)&c->la.h_gated, sizeof(rfid_cf32) * cap, hipHostMallocDefault));
+          HIPCHK(c, hipHostMalloc((void **)&c->la.h_m2, sizeof(float) * cap, hipHostMallocDefault));
+          c->la.h_cap = cap;
+        }
+        w.resize((size_t)nf); r.resize((size_t)nf);
+        hipLaunchKernelGGL(gated_windows_kernel, dim3((unsigned)nf), dim3(256), 0, c->stream, (const rfid_window *)c->d_wtab,
+                           (const int *)c->d_wcount, nf, (const float2 *)c->d_y, (float2 *)c->la.d_gated.p, (float *)c->la.d_m2.p);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&wc, c->d_wcount, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(w.data(), c->d_wtab, sizeof(rfid_window) * (size_t)nf, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(r.data(), c->d_res, sizeof(rfid_decode_result) * (size_t)nf, hipMemcpyDeviceToHost, c->stream));
+        // (the gated samples: as many as a call usually holds -- ~24 windows of 65 536 samples -- the rest below if need be)
+        const size_t usual = ((size_t)nf < 32 ? (size_t)nf : 32) * EPC_WIN;
+        HIPCHK(c, hipMemcpyAsync(c->la.h_gated, c->la.d_gated.p, sizeof(rfid_cf32) * usual, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->la.h_m2, c->la.d_m2.p, sizeof(float) * usual, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        size_t need = 0;
+        for (int i = 0; i < wc && i < nf; ++i) need += w[(size_t)i].type ? EPC_WIN : RN16_WIN;
+        have_all = wc <= nf && need <= usual;
+        if (wc <= nf && !have_all) {   // more gated samples than fetched
+          HIPCHK(c, hipMemcpyAsync(c->la.h_gated, c->la.d_gated.p, sizeof(rfid_cf32) * need, hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(c, hipMemcpyAsync(c->la.h_m2, c->la.d_m2.p, sizeof(float) * need, hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(c, hipStreamSynchronize(c->stream));
+          have_all = true;
+        }
+        if (have_all) { w.resize((size_t)wc); r.resize((size_t)wc); }
+      } else {
+        HIPCHK(c, hipMemcpyAsync(&wc, c->d_wcount, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+      }
       n_windows = wc;
       if (wc > 0) {
-        std::vector<rfid_window> w((size_t)wc);
-        std::vector<rfid_decode_result> r((size_t)wc);
+        if (!have_all) {
+        w.assign((size_t)wc, rfid_window());
+        r.assign((size_t)wc, rfid_decode_result());
         HIPCHK(c, hipMemcpyAsync(w.data(), c->d_wtab, sizeof(rfid_window) * (size_t)wc, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(r.data(), c->d_res, sizeof(rfid_decode_result) * (size_t)wc, hipMemcpyDeviceToHost, c->stream));
         if (c->la.on) {
@@ -1555,6 +1598,7 @@ int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
           HIPCHK(c, hipMemcpyAsync(c->la.h_m2, c->la.d_m2.p, sizeof(float) * cap, hipMemcpyDeviceToHost, c->stream));
         }
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
         const int64_t n0 = io.raw_base / DECIM;
         size_t goff = 0;
         for (int i = 0; i < wc; ++i) {
@@ -1744,8 +1788,15 @@ int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int o
   if (n_out > out_cap || (n_out > 0 && !out)) return RFID_ERR_CAPACITY;
   const int up = io.cur;
   HIPCHK(c, hipEventSynchronize(io.ev_free[up]));   // (the call before last, processed long ago)
-  memcpy(io.h_pin[up], in, sizeof(rfid_cf32) * (size_t)n_in);
-  HIPCHK(c, hipMemcpyAsync(io.d_buf[up] + io.tail_max, io.h_pin[up], sizeof(rfid_cf32) * (size_t)n_in, hipMemcpyHostToDevice, c->stream));
+  const rfid_cf32 *src = in;
+  bool pinned = false;   // page-locked memory of the caller's (rfid_host_alloc, hipHostMalloc / hipHostRegister)?  then no staging copy
+  {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, in) == hipSuccess) pinned = (attr.type == hipMemoryTypeHost);
+    else (void)hipGetLastError();
+  }
+  if (!pinned) { memcpy(io.h_pin[up], in, sizeof(rfid_cf32) * (size_t)n_in); src = io.h_pin[up]; }
+  HIPCHK(c, hipMemcpyAsync(io.d_buf[up] + io.tail_max, src, sizeof(rfid_cf32) * (size_t)n_in, hipMemcpyHostToDevice, c->stream));
   io.cur ^= 1;
   la.want_y0 = n_first; la.want_yn = n_out;
   const int rc = sio_process(c, up, n_in, false);
@@ -1860,6 +1911,13 @@ int rfid_lookahead_enable(rfid_ctx *c, int64_t max_chunk_raw) {
   c->la.on = true;
   return RFID_OK;
 }
+
+void *rfid_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+void rfid_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 int rfid_gate_magn_squared(rfid_ctx *c, float *out, int cap, int *n) {
   if (!c || !n || cap < 0 || (cap > 0 && !out)) return RFID_ERR_INVALID;

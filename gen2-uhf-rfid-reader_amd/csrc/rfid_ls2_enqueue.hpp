@@ -113,8 +113,9 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
   a.stamp = 0;
   // rounds enqueued behind each stage's first pass: a round without work is two empty launches (~10 us), which only a
   // short pass notices -- and short traces settle in few rounds (their rounding drift is small)
-  const bool small = NS < 32768;
-  a.avg_rounds = small ? 5 : LS2_AVG_ROUNDS; a.fsm_rounds = small ? 2 : LS2_FSM_ROUNDS; a.dc_rounds = small ? 4 : LS2_DC_ROUNDS;
+  const bool small = NS < 32768, tiny = NS < 1024;
+  a.avg_rounds = tiny ? 3 : (small ? 5 : LS2_AVG_ROUNDS); a.fsm_rounds = tiny ? 1 : (small ? 2 : LS2_FSM_ROUNDS);
+  a.dc_rounds = tiny ? 2 : (small ? 4 : LS2_DC_ROUNDS);
   LS2_LAUNCH(ls2_pieces_kernel, (NS + 255) / 256, 1, 256, a);
   LS2_LAUNCH(ls2_check_kernel, 1, 1, 64, a);
   const int rerun_grid = NS;   // (one wave per list entry; the waves past the list return at once)

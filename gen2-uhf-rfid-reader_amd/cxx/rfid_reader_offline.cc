@@ -66,7 +66,19 @@ int main(int argc, char **argv) {
   if (!f) { std::cerr << "cannot open " << path << "\n"; return 2; }
   const std::streamsize bytes = f.tellg();
   f.seekg(0);
-  std::vector<gr_complex> samples((size_t)(bytes / (std::streamsize)sizeof(gr_complex)));
+  // the trace goes into page-locked memory (what a file source of this library's own would hand out): the blocks' input
+  // then reaches the device without a staging copy.  Ordinary memory when that fails.
+  struct host_buf {
+    gr_complex *p = nullptr; size_t n = 0; bool locked = false;
+    ~host_buf() { if (locked) rfid_host_free(p); else delete[] p; }
+    gr_complex *data() { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+  } samples;
+  samples.n = (size_t)(bytes / (std::streamsize)sizeof(gr_complex));
+  samples.p = static_cast<gr_complex *>(rfid_host_alloc(samples.n * sizeof(gr_complex)));
+  samples.locked = samples.p != nullptr;
+  if (!samples.p) samples.p = new gr_complex[samples.n ? samples.n : 1];
   if (!samples.empty() && !f.read(reinterpret_cast<char *>(samples.data()), (std::streamsize)(samples.size() * sizeof(gr_complex)))) {
     std::cerr << "short read on " << path << "\n";
     return 2;

@@ -205,6 +205,10 @@ RFID_API int rfid_decoder_work(rfid_ctx *ctx, const rfid_cf32 *in, int n_in, flo
  * ended and flush what is left.  max_chunk_raw: the largest n_in rfid_mf_work will see.  Call before the
  * first sample; rfid_ctx_reset switches it off. */
 RFID_API int rfid_lookahead_enable(rfid_ctx *ctx, int64_t max_chunk_raw);
+/* Page-locked host memory (nullptr on failure): samples handed to rfid_mf_work (look-ahead) / rfid_stream_work from such
+ * memory -- or from any memory the caller page-locked himself -- go to the device without the staging copy. */
+RFID_API void *rfid_host_alloc(size_t bytes);
+RFID_API void rfid_host_free(void *p);
 /* |out[i]|^2 of the samples the last rfid_gate_work wrote (READER_STATE::magn_squared_samples, lib/gate_impl.cc:171,175,186),
  * computed on the device with the reference's expression re*re + im*im.  Look-ahead mode only (else *n = 0). */
 RFID_API int rfid_gate_magn_squared(rfid_ctx *ctx, float *out, int cap, int *n);
