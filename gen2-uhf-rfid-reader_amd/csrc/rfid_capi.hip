@@ -13,6 +13,7 @@
 #include <cstring>
 #include <deque>
 #include <map>
+#include <memory>
 #include <new>
 #include <vector>
 
@@ -24,6 +25,11 @@
 #define LS2_LAUNCH(kernel, gx, gy, block, args) \
   hipLaunchKernelGGL(rfidk::kernel, dim3((unsigned)(gx), (unsigned)(gy)), dim3((unsigned)(block)), 0, ls2_stream, args)
 static thread_local hipStream_t ls2_stream = nullptr;
+// RFID_LA_PROFILE=1: where the look-ahead's time goes (printed when the context is destroyed)
+static double g_la_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static long g_la_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static inline double la_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec; }
+struct LaTimer { int k; double t0; explicit LaTimer(int kk) : k(kk), t0(la_now()) {} ~LaTimer() { g_la_t[k] += la_now() - t0; g_la_n[k]++; } };
 #include "rfid_ls2_enqueue.hpp"
 
 using namespace rfidk;
@@ -86,8 +92,11 @@ struct rfid_ctx {
       int64_t start = 0;              // global decimated position of the opening sample
       int type = 0, len = 0;
       rfid_decode_result res;
-      std::vector<rfid_cf32> gated;   // in[i] - dc_est over the window
-      std::vector<float> m2;          // |.|^2 of those
+      // in[i] - dc_est over the window and |.|^2 of those: [off, off + len) of the block the whole-chain pass fetched
+      std::shared_ptr<std::vector<rfid_cf32>> gated;
+      std::shared_ptr<std::vector<float>> m2;
+      size_t off = 0;
+      rfid_cf32 first, last;          // (the decoder's input is recognised by them)
     };
     bool on = false, flushed = false;
     int64_t gate_pos = 0;             // decimated samples the gate calls have consumed
@@ -99,9 +108,10 @@ struct rfid_ctx {
     int stall = 0;                    // gate calls in a row without progress and without new input
     std::vector<float> last_m2;       // |.|^2 of what the last gate call wrote
     // scratch of one whole-chain pass
-    DevBuf d_gated, d_m2;
-    rfid_cf32 *h_gated = nullptr; float *h_m2 = nullptr; rfid_cf32 *h_y = nullptr;
+    DevBuf d_pack;                    // one packet per pass: count, window records, results, gated samples, |.|^2 (gated_windows_kernel)
+    char *h_pack = nullptr; rfid_cf32 *h_y = nullptr;   // page-locked
     size_t h_cap = 0, h_ycap = 0;
+    int n_hdr = 48;                   // windows the packet is sized for (follows what the calls hold)
     int64_t want_y0 = 0; int want_yn = 0;   // matched-filter outputs (global positions) the current rfid_mf_work call returns
   } la;
   rfid_window *d_swin = nullptr;  // one window
@@ -526,6 +536,9 @@ int rfid_ctx_create(const rfid_params *p, int device, rfid_ctx **out) {
 
 int rfid_ctx_destroy(rfid_ctx *c) {
   if (!c) return RFID_ERR_INVALID;
+  if (getenv("RFID_LA_PROFILE") && g_la_n[0])
+    fprintf(stderr, "[la] mf_work %ld calls %.2f ms (upload queued %.2f, whole-chain pass %.2f: enqueue %.2f, first sync %.2f) | gate_work %ld calls %.2f ms | decoder_work %ld calls %.2f ms | reader_work_tx %ld calls %.2f ms\n",
+            g_la_n[0], g_la_t[0], g_la_t[4], g_la_t[5], g_la_t[6], g_la_t[7], g_la_n[1], g_la_t[1], g_la_n[2], g_la_t[2], g_la_n[3], g_la_t[3]);
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   la_free(c);
@@ -813,6 +826,10 @@ int rfid_batch_decode(rfid_ctx *c, int want_scores) {
   memcpy(a.t_cand, c->t_cand, sizeof(a.t_cand));
   if (!c->ev_valid[2]) { HIPCHK(c, hipEventRecord(c->ev[2], c->stream)); c->ev_valid[2] = true; }
   int grid = c->decode_grid;
+  {   // (a small plan -- a stream call, a look-ahead pass -- holds few windows: no point in launching a chip's worth of waves)
+    const int64_t most = ((int64_t)c->wmax * c->B + 2) / 3 + 1;
+    if (grid > most) grid = (int)most;
+  }
   if (grid < 1) grid = 1;
   // EPC windows: 3 per wavefront
   a.list = c->d_flat + c->flat_cap; a.count = c->d_flat_count + 1;
@@ -1309,6 +1326,7 @@ int rfid_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, i
 
 int rfid_decoder_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, float *out_bits, int out_cap, int *n_consumed,
                       int *n_produced, rfid_decode_result *res_out, rfid_scores *scores_out) {
+  LaTimer tm(2);
   if (!c || n_in < 0 || (n_in > 0 && !in) || !n_consumed || !n_produced) return RFID_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   rfid_reader_state &rs = c->rs;
@@ -1458,6 +1476,7 @@ int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
   float2 *data = io.d_buf[b] + (io.tail_max - io.tail_len);   // first held-back (or new) sample
   int64_t consumed = 0;                                 // decimated samples processed
   int n_windows = 0;
+  bool y_ready = false;                                 // (look-ahead) a synchronisation has passed since the filter outputs were fetched
   c->d_ls2_ctl = nullptr;
   if (n_out > 0) {
     // ---- matched filter over everything available: y[n] = sum x[5n - 24 .. 5n], history in front of `data` ----
@@ -1486,11 +1505,15 @@ int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
     LsOpts opt;
     opt.carry = true; opt.hold_last = !flush; opt.force = true;
     int enq = 0;
+    const double t_e0 = la_now();
     int rc = ls_enqueue(c, n_out, opt, &enq);
     if (rc) return rc;
+    g_la_t[6] += la_now() - t_e0; g_la_n[6]++;
     bool ok = false;
     if (enq) {
+      const double t_s0 = la_now();
       HIPCHK(c, hipStreamSynchronize(c->stream));
+      g_la_t[7] += la_now() - t_s0; g_la_n[7]++;
       ok = c->ls2_host->ok != 0;
       if (ok) consumed = flush ? n_out : *(const int *)((const char *)c->ls2_host + sizeof(Ls2Ctl));
       if (ok && consumed <= 0) ok = false;
@@ -1527,77 +1550,65 @@ int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
       c->ev_valid[2] = false;
       if ((rc = rfid_batch_decode(c, 0))) return rc;
       int wc = 0;
-      // look-ahead: a call's worth of windows is fetched speculatively together with their count (one synchronisation less)
-      const int LA_FETCH = 64;
       std::vector<rfid_window> w;
       std::vector<rfid_decode_result> r;
-      bool have_all = false;
+      std::shared_ptr<std::vector<rfid_cf32>> blk_g;
+      std::shared_ptr<std::vector<float>> blk_m;
       if (c->la.on) {
-        const int nf = (LA_FETCH < c->wmax) ? LA_FETCH : c->wmax;
-        const size_t cap = (size_t)nf * EPC_WIN;
-        if ((rc = grow(c, c->la.d_gated, sizeof(float2) * cap))) return rc;
-        if ((rc = grow(c, c->la.d_m2, sizeof(float) * cap))) return rc;
-        if (cap > c->la.h_cap) {
-          if (c->la.h_gated) (void)hipHostFree(c->la.h_gated);
-          if (c->la.h_m2) (void)hipHostFree(c->la.h_m2);
-          c->la.h_gated = nullptr; c->la.h_m2 = nullptr; c->la.h_cap = 0;
-          HIPCHK(c, hipHostMalloc((void **)&c->la.h_gated, sizeof(rfid_cf32) * cap, hipHostMallocDefault));
-          HIPCHK(c, hipHostMalloc((void **)&c->la.h_m2, sizeof(float) * cap, hipHostMallocDefault));
-          c->la.h_cap = cap;
-        }
-        w.resize((size_t)nf); r.resize((size_t)nf);
-        hipLaunchKernelGGL(gated_windows_kernel, dim3((unsigned)nf), dim3(256), 0, c->stream, (const rfid_window *)c->d_wtab,
-                           (const int *)c->d_wcount, nf, (const float2 *)c->d_y, (float2 *)c->la.d_gated.p, (float *)c->la.d_m2.p);
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(&wc, c->d_wcount, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(w.data(), c->d_wtab, sizeof(rfid_window) * (size_t)nf, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(r.data(), c->d_res, sizeof(rfid_decode_result) * (size_t)nf, hipMemcpyDeviceToHost, c->stream));
-        // (the gated samples: as many as a call usually holds -- ~24 windows of 65 536 samples -- the rest below if need be)
-        const size_t usual = ((size_t)nf < 32 ? (size_t)nf : 32) * EPC_WIN;
-        HIPCHK(c, hipMemcpyAsync(c->la.h_gated, c->la.d_gated.p, sizeof(rfid_cf32) * usual, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->la.h_m2, c->la.d_m2.p, sizeof(float) * usual, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        size_t need = 0;
-        for (int i = 0; i < wc && i < nf; ++i) need += w[(size_t)i].type ? EPC_WIN : RN16_WIN;
-        have_all = wc <= nf && need <= usual;
-        if (wc <= nf && !have_all) {   // more gated samples than fetched
-          HIPCHK(c, hipMemcpyAsync(c->la.h_gated, c->la.d_gated.p, sizeof(rfid_cf32) * need, hipMemcpyDeviceToHost, c->stream));
-          HIPCHK(c, hipMemcpyAsync(c->la.h_m2, c->la.d_m2.p, sizeof(float) * need, hipMemcpyDeviceToHost, c->stream));
+        // look-ahead: one packet for the host -- count, window records, results, gated samples and their |.|^2, sized for what
+        // a call usually holds and fetched with ONE copy; a pass with more is fetched again with the right sizes
+        int n_hdr = c->la.n_hdr, usual = (n_hdr / 2 + 1) * (EPC_WIN + RN16_WIN);   // (the types alternate)
+        for (int attempt = 0; attempt < 2; ++attempt) {
+          const int cap = n_hdr * EPC_WIN;
+          const size_t hdr = GATED_HDR + (sizeof(rfid_window) + sizeof(rfid_decode_result)) * (size_t)n_hdr;
+          const size_t total = hdr + (sizeof(float2) + sizeof(float)) * (size_t)cap;
+          const size_t first = hdr + (sizeof(float2) + sizeof(float)) * (size_t)usual;
+          if ((rc = grow(c, c->la.d_pack, total))) return rc;
+          if (first > c->la.h_cap) {
+            if (c->la.h_pack) (void)hipHostFree(c->la.h_pack);
+            c->la.h_pack = nullptr; c->la.h_cap = 0;
+            HIPCHK(c, hipHostMalloc((void **)&c->la.h_pack, first, hipHostMallocDefault));
+            c->la.h_cap = first;
+          }
+          GatedPack gp;
+          gp.wtab = c->d_wtab; gp.wcount = c->d_wcount; gp.res = c->d_res; gp.wmax = n_hdr; gp.y = c->d_y;
+          gp.pack = (char *)c->la.d_pack.p; gp.n_hdr = n_hdr; gp.usual = usual; gp.cap = cap;
+          hipLaunchKernelGGL(gated_windows_kernel, dim3((unsigned)n_hdr), dim3(256), 0, c->stream, gp);
+          HIPCHK(c, hipGetLastError());
+          HIPCHK(c, hipMemcpyAsync(c->la.h_pack, c->la.d_pack.p, first, hipMemcpyDeviceToHost, c->stream));
           HIPCHK(c, hipStreamSynchronize(c->stream));
-          have_all = true;
+          y_ready = true;
+          wc = *(const int *)c->la.h_pack;
+          if (wc > c->wmax) wc = c->wmax;
+          const rfid_window *hw = (const rfid_window *)(c->la.h_pack + GATED_HDR);
+          const rfid_decode_result *hr = (const rfid_decode_result *)(hw + n_hdr);
+          size_t need = 0;
+          for (int i = 0; i < wc && i < n_hdr; ++i) need += hw[i].type ? EPC_WIN : RN16_WIN;
+          if (wc <= n_hdr && need <= (size_t)usual) {
+            if (wc + wc / 4 + 8 > c->la.n_hdr) c->la.n_hdr = wc + wc / 4 + 8;   // (the next calls hold about as many)
+            w.assign(hw, hw + wc); r.assign(hr, hr + wc);
+            const rfid_cf32 *g = (const rfid_cf32 *)(c->la.h_pack + hdr);
+            const float *m = (const float *)(g + usual);
+            blk_g = std::make_shared<std::vector<rfid_cf32>>(g, g + need);
+            blk_m = std::make_shared<std::vector<float>>(m, m + need);
+            break;
+          }
+          if (attempt == 1) return fail(c, RFID_ERR_CAPACITY, "look-ahead: window packet");
+          n_hdr = wc + 1; usual = n_hdr * EPC_WIN;   // (rare: more windows than the calls so far held -- all of them, all in the first part)
+          c->la.n_hdr = wc + wc / 4 + 8;
         }
-        if (have_all) { w.resize((size_t)wc); r.resize((size_t)wc); }
       } else {
         HIPCHK(c, hipMemcpyAsync(&wc, c->d_wcount, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
       }
       n_windows = wc;
       if (wc > 0) {
-        if (!have_all) {
-        w.assign((size_t)wc, rfid_window());
-        r.assign((size_t)wc, rfid_decode_result());
-        HIPCHK(c, hipMemcpyAsync(w.data(), c->d_wtab, sizeof(rfid_window) * (size_t)wc, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(r.data(), c->d_res, sizeof(rfid_decode_result) * (size_t)wc, hipMemcpyDeviceToHost, c->stream));
-        if (c->la.on) {
-          // look-ahead: the gated samples of these windows (in[i] - dc_est) and their |.|^2, formed on the device
-          const size_t cap = (size_t)wc * EPC_WIN;
-          if ((rc = grow(c, c->la.d_gated, sizeof(float2) * cap))) return rc;
-          if ((rc = grow(c, c->la.d_m2, sizeof(float) * cap))) return rc;
-          if (cap > c->la.h_cap) {
-            if (c->la.h_gated) (void)hipHostFree(c->la.h_gated);
-            if (c->la.h_m2) (void)hipHostFree(c->la.h_m2);
-            c->la.h_gated = nullptr; c->la.h_m2 = nullptr; c->la.h_cap = 0;
-            HIPCHK(c, hipHostMalloc((void **)&c->la.h_gated, sizeof(rfid_cf32) * cap * 2, hipHostMallocDefault));
-            HIPCHK(c, hipHostMalloc((void **)&c->la.h_m2, sizeof(float) * cap * 2, hipHostMallocDefault));
-            c->la.h_cap = cap * 2;
-          }
-          hipLaunchKernelGGL(gated_windows_kernel, dim3((unsigned)wc), dim3(256), 0, c->stream, (const rfid_window *)c->d_wtab,
-                             (const int *)c->d_wcount, c->wmax, (const float2 *)c->d_y, (float2 *)c->la.d_gated.p, (float *)c->la.d_m2.p);
-          HIPCHK(c, hipGetLastError());
-          HIPCHK(c, hipMemcpyAsync(c->la.h_gated, c->la.d_gated.p, sizeof(rfid_cf32) * cap, hipMemcpyDeviceToHost, c->stream));
-          HIPCHK(c, hipMemcpyAsync(c->la.h_m2, c->la.d_m2.p, sizeof(float) * cap, hipMemcpyDeviceToHost, c->stream));
-        }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!c->la.on) {
+          w.assign((size_t)wc, rfid_window());
+          r.assign((size_t)wc, rfid_decode_result());
+          HIPCHK(c, hipMemcpyAsync(w.data(), c->d_wtab, sizeof(rfid_window) * (size_t)wc, hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(c, hipMemcpyAsync(r.data(), c->d_res, sizeof(rfid_decode_result) * (size_t)wc, hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(c, hipStreamSynchronize(c->stream));
         }
         const int64_t n0 = io.raw_base / DECIM;
         size_t goff = 0;
@@ -1609,8 +1620,8 @@ int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
             c->la.wins.emplace_back();
             rfid_ctx::LookAhead::Win &q = c->la.wins.back();
             q.start = n0 + wi.start; q.type = wi.type; q.len = len; q.res = r[(size_t)i];
-            q.gated.assign(c->la.h_gated + goff, c->la.h_gated + goff + len);
-            q.m2.assign(c->la.h_m2 + goff, c->la.h_m2 + goff + len);
+            q.gated = blk_g; q.m2 = blk_m; q.off = goff;
+            q.first = (*blk_g)[goff]; q.last = (*blk_g)[goff + (size_t)len - 1];
             goff += (size_t)len;
             continue;
           }
@@ -1635,7 +1646,7 @@ int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
   io.tail_len = left;
   io.raw_base += DECIM * consumed;
   (void)n_windows;
-  if (c->la.on) HIPCHK(c, hipStreamSynchronize(c->stream));   // (the filter outputs for the caller have arrived)
+  if (c->la.on && !y_ready) HIPCHK(c, hipStreamSynchronize(c->stream));   // (the filter outputs for the caller have arrived)
   return RFID_OK;
 }
 }  // namespace
@@ -1767,11 +1778,9 @@ int rfid_stream_end(rfid_ctx *c) {
 namespace {
 void la_free(rfid_ctx *c) {
   rfid_ctx::LookAhead &la = c->la;
-  if (la.h_gated) (void)hipHostFree(la.h_gated);
-  if (la.h_m2) (void)hipHostFree(la.h_m2);
+  if (la.h_pack) (void)hipHostFree(la.h_pack);
   if (la.h_y) (void)hipHostFree(la.h_y);
-  if (la.d_gated.p) (void)hipFree(la.d_gated.p);
-  if (la.d_m2.p) (void)hipFree(la.d_m2.p);
+  if (la.d_pack.p) (void)hipFree(la.d_pack.p);
   la = rfid_ctx::LookAhead();
 }
 
@@ -1779,6 +1788,7 @@ bool same_sample(const rfid_cf32 &a, const rfid_cf32 &b) { return memcmp(&a, &b,
 
 // rfid_mf_work with the look-ahead on: the whole chain over what is held back + the new samples, in one submission
 int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap, int *n_produced) {
+  LaTimer tm(0);
   rfid_ctx::StreamIO &io = c->sio;
   rfid_ctx::LookAhead &la = c->la;
   if (!io.open || io.failed || la.flushed) return fail(c, RFID_ERR_STATE, "look-ahead: the stream has ended (rfid_ctx_reset starts a new one)");
@@ -1799,7 +1809,10 @@ int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int o
   HIPCHK(c, hipMemcpyAsync(io.d_buf[up] + io.tail_max, src, sizeof(rfid_cf32) * (size_t)n_in, hipMemcpyHostToDevice, c->stream));
   io.cur ^= 1;
   la.want_y0 = n_first; la.want_yn = n_out;
+  g_la_t[4] += la_now() - tm.t0; g_la_n[4]++;   // (upload queued)
+  const double t_sp = la_now();
   const int rc = sio_process(c, up, n_in, false);
+  g_la_t[5] += la_now() - t_sp; g_la_n[5]++;
   la.want_yn = 0;
   if (rc) { io.failed = true; return rc; }
   if (n_out > 0) {
@@ -1814,6 +1827,7 @@ int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int o
 
 // rfid_gate_work with the look-ahead on (gate_impl.cc:127-199 answered from the windows the whole-chain pass found)
 int la_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap, int *n_consumed, int *n_written) {
+  LaTimer tm(1);
   (void)out_cap;
   rfid_ctx::StreamIO &io = c->sio;
   rfid_ctx::LookAhead &la = c->la;
@@ -1837,14 +1851,14 @@ int la_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int
       const int64_t from = w.start + la.emitted;           // first sample of the window still to hand out (>= p)
       const int64_t upto = (w.start + w.len < p + n_in) ? (w.start + w.len) : (p + n_in);
       written = (int)(upto - from);
-      memcpy(out, w.gated.data() + la.emitted, sizeof(rfid_cf32) * (size_t)written);
-      la.last_m2.assign(w.m2.begin() + la.emitted, w.m2.begin() + la.emitted + written);
+      memcpy(out, w.gated->data() + w.off + la.emitted, sizeof(rfid_cf32) * (size_t)written);
+      la.last_m2.assign(w.m2->begin() + (long)(w.off + la.emitted), w.m2->begin() + (long)(w.off + la.emitted + written));
       la.emitted += written;
       if (la.emitted == w.len) {                           // gate_impl.cc:189-194: closed, consume_each(i + 1)
         consumed = (int)(w.start + w.len - p);
         la.dq.push_back(std::move(w));
-        la.dq.back().gated.resize(2);                      // (the decoder call is checked against its first and last sample)
-        la.dq.back().gated[1] = la.dq.back().gated[0];
+        la.dq.back().gated.reset();                        // (the decoder call is recognised by the window's first and last sample)
+        la.dq.back().m2.reset();
         la.wins.pop_front();
         la.emitted = 0;
       } else {
@@ -1869,11 +1883,6 @@ int la_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int
     if (consumed > 0 || written > 0) la.stall = 0;
     // keep the state the window's last sample leaves: the dc ring etc. live on the device; here only what the blocks share
     rs.gate_status = open_after ? RFID_GATE_OPEN : RFID_GATE_CLOSED;
-    // (the bit copy of the last handed-out sample identifies the decoder's input later)
-    if (written > 0 && !la.dq.empty() && !open_after) {
-      rfid_ctx::LookAhead::Win &d = la.dq.back();
-      d.gated[1] = out[written - 1];
-    }
     la.gate_pos += consumed;
     while (la.y0 < la.gate_pos && !la.yq.empty()) { la.yq.pop_front(); la.y0++; }
     *n_consumed = consumed;
@@ -1888,7 +1897,7 @@ bool la_decoder_result(rfid_ctx *c, const rfid_cf32 *in, int wlen, int type, rfi
   rfid_ctx::LookAhead &la = c->la;
   if (la.dq.empty()) return false;
   const rfid_ctx::LookAhead::Win &w = la.dq.front();
-  if (w.len != wlen || w.type != type || w.gated.size() < 2 || !same_sample(in[0], w.gated[0]) || !same_sample(in[wlen - 1], w.gated[1])) return false;
+  if (w.len != wlen || w.type != type || !same_sample(in[0], w.first) || !same_sample(in[wlen - 1], w.last)) return false;
   *r = w.res;
   la.dq.pop_front();
   return true;
@@ -2008,6 +2017,7 @@ int rfid_reader_tx_max(int dac_rate) {
 
 int rfid_reader_work_tx(rfid_ctx *c, int dac_rate, const float *in_bits, int n_in, float *out, int out_cap, int *n_consumed,
                         int *n_written) {
+  LaTimer tm(3);
   if (!c || dac_rate <= 0 || n_in < 0 || (!out && out_cap > 0) || out_cap < 0) return RFID_ERR_INVALID;
   static thread_local ReaderTx t;
   if (t.dac_rate != dac_rate || t.fixed_q != c->prm.fixed_q) build_reader_tx(t, dac_rate, c->prm.fixed_q);

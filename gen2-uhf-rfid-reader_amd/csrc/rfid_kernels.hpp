@@ -1127,23 +1127,44 @@ RFID_KERNEL(64) void ls_cut_kernel(LsCutArgs a) {
   if (lane == 0) *out = found;
 }
 
-// look-ahead of the per-block calls: the gated, DC-removed samples of the windows of a call, one after the other
-// (in[i] - dc_est, gate_impl.cc:176,187), and their squared magnitudes (:171,175,186: std::norm = re*re + im*im).
-// One workgroup per window; a window's place = the lengths of the windows before it.
-RFID_KERNEL(256) void gated_windows_kernel(const rfid_window *wtab, const int *wcount, int wmax, const float2 *y, float2 *out, float *m2) {
-  int n = *wcount;
-  if (n > wmax) n = wmax;
+// look-ahead of the per-block calls: ONE packet per whole-chain pass for the host -- the window count, the first n_hdr window
+// records and results, and the gated, DC-removed samples of the windows, one after the other (in[i] - dc_est,
+// gate_impl.cc:176,187) with their squared magnitudes (:171,175,186: std::norm = re*re + im*im).  The first `usual`
+// samples of both lie together right behind the header (what a call usually holds: one copy fetches it all), the rest
+// behind them.  One workgroup per window; a window's place = the lengths of the windows before it.
+struct GatedPack {
+  const rfid_window *wtab; const int *wcount; const rfid_decode_result *res; int wmax;   // wmax: windows to pack at most
+  const float2 *y;
+  char *pack;              // [hdr | g_lo[usual] | m_lo[usual] | g_hi[cap - usual] | m_hi[cap - usual]]
+  int n_hdr, usual, cap;
+};
+constexpr int GATED_HDR = 64;   // bytes in front of the window records (the count)
+RFID_DEVICE size_t gated_pack_hdr_bytes(int n_hdr) { return (size_t)GATED_HDR + (sizeof(rfid_window) + sizeof(rfid_decode_result)) * (size_t)n_hdr; }
+RFID_KERNEL(256) void gated_windows_kernel(GatedPack a) {
+  int n = *a.wcount;
   const int b = (int)blockIdx.x;
+  char *pk = a.pack;
+  rfid_window *hw = reinterpret_cast<rfid_window *>(pk + GATED_HDR);
+  rfid_decode_result *hr = reinterpret_cast<rfid_decode_result *>(hw + a.n_hdr);
+  if (b == 0 && threadIdx.x == 0) *reinterpret_cast<int *>(pk) = n;
+  if (n > a.wmax) n = a.wmax;
   if (b >= n) return;
+  if (b < a.n_hdr && threadIdx.x == 0) { hw[b] = a.wtab[b]; hr[b] = a.res[b]; }
+  float2 *g_lo = reinterpret_cast<float2 *>(pk + gated_pack_hdr_bytes(a.n_hdr));
+  float *m_lo = reinterpret_cast<float *>(g_lo + a.usual);
+  float2 *g_hi = reinterpret_cast<float2 *>(m_lo + a.usual);
+  float *m_hi = reinterpret_cast<float *>(g_hi + (a.cap - a.usual));
   int off = 0;
-  for (int k = 0; k < b; ++k) off += wtab[k].type ? EPC_WIN : RN16_WIN;
-  const rfid_window w = wtab[b];
+  for (int k = 0; k < b; ++k) off += a.wtab[k].type ? EPC_WIN : RN16_WIN;
+  const rfid_window w = a.wtab[b];
   const int len = w.type ? EPC_WIN : RN16_WIN;
   for (int i = (int)threadIdx.x; i < len; i += 256) {
-    const float2 v = y[w.start + i];
+    const float2 v = a.y[w.start + i];
     const float re = v.x - w.dc_re, im = v.y - w.dc_im;
-    out[off + i] = make_float2(re, im);
-    m2[off + i] = re * re + im * im;
+    const int k = off + i;
+    if (k >= a.cap) continue;
+    if (k < a.usual) { g_lo[k] = make_float2(re, im); m_lo[k] = re * re + im * im; }
+    else { g_hi[k - a.usual] = make_float2(re, im); m_hi[k - a.usual] = re * re + im * im; }
   }
 }
 

@@ -42,10 +42,13 @@ struct stream {
     READER_STATS &r = mirror.reader_stats;
     r.n_queries_sent = s.n_queries_sent; r.cur_inventory_round = s.cur_inventory_round;
     r.cur_slot_number = s.cur_slot_number; r.max_slot_number = s.max_slot_number;
-    r.max_inventory_round = MAX_INVENTORY_ROUND; r.n_epc_correct = s.n_epc_correct;
-    r.tag_reads.clear();
-    for (int id = 0; id < 256; ++id)
-      if (s.tag_reads[id]) r.tag_reads[id] = s.tag_reads[id];
+    r.max_inventory_round = MAX_INVENTORY_ROUND;
+    if (r.n_epc_correct != s.n_epc_correct || s.n_epc_correct == 0) {   // (tag_reads only changes with a correctly decoded EPC)
+      r.tag_reads.clear();
+      for (int id = 0; id < 256; ++id)
+        if (s.tag_reads[id]) r.tag_reads[id] = s.tag_reads[id];
+    }
+    r.n_epc_correct = s.n_epc_correct;
   }
 };
 typedef std::shared_ptr<stream> stream_sptr;
@@ -281,6 +284,9 @@ void sts_flowgraph::run(const gr_complex *samples, size_t n) {
   std::vector<gr_complex> gq, dq, mf_out((size_t)d_chunk + 8), gate_out((size_t)d_chunk);
   size_t g_rd = 0, d_rd = 0;
   size_t pos = 0;
+  gr_vector_int g_nin(1, 0), d_nin(1, 0);                       // (the per-call argument vectors, made once)
+  gr_vector_const_void_star g_in(1, nullptr), d_in(1, nullptr);
+  gr_vector_void_star g_out(1, nullptr), d_out(2, nullptr);
   while (pos < n || g_rd < gq.size()) {
     if (pos < n) {
       const size_t take = (n - pos < (size_t)d_chunk * 5) ? (n - pos) : (size_t)d_chunk * 5;
@@ -297,23 +303,18 @@ void sts_flowgraph::run(const gr_complex *samples, size_t n) {
     while (g_rd < gq.size()) {
       const size_t have = gq.size() - g_rd;
       const int avail = (int)(have < (size_t)d_chunk ? have : (size_t)d_chunk);
-      gr_vector_int nin(1, avail);
-      gr_vector_const_void_star in(1, gq.data() + g_rd);
-      gr_vector_void_star out(1, gate_out.data());
+      g_nin[0] = avail; g_in[0] = gq.data() + g_rd; g_out[0] = gate_out.data();
       d_gate->minirt_begin_work();
-      const int written = d_gate->general_work(avail, nin, in, out);
+      const int written = d_gate->general_work(avail, g_nin, g_in, g_out);
       const int consumed = d_gate->minirt_consumed();
       g_rd += (size_t)consumed;
       if (d_rd > 0 && d_rd == dq.size()) { dq.clear(); d_rd = 0; }
       dq.insert(dq.end(), gate_out.begin(), gate_out.begin() + written);
       if (d_keep_taps) d_tap_gate.insert(d_tap_gate.end(), gate_out.begin(), gate_out.begin() + written);
       for (;;) {
-        gr_vector_int dn(1, (int)(dq.size() - d_rd));
-        gr_vector_const_void_star din(1, dq.data() + d_rd);
-        gr_vector_void_star dout(2, nullptr);
-        dout[0] = d_bits.data();
+        d_nin[0] = (int)(dq.size() - d_rd); d_in[0] = dq.data() + d_rd; d_out[0] = d_bits.data();
         d_dec->minirt_begin_work();
-        d_dec->general_work((int)d_bits.size(), dn, din, dout);
+        d_dec->general_work((int)d_bits.size(), d_nin, d_in, d_out);
         const int dcons = d_dec->minirt_consumed();
         if (dcons == 0) break;
         d_windows++;
