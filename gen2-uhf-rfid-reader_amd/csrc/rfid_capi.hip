@@ -133,6 +133,7 @@ struct rfid_ctx {
   rfid_window *d_wtab = nullptr, *d_flat = nullptr;
   int wmax = 0, flat_cap = 0;
   int *d_wcount = nullptr, *d_flat_count = nullptr;
+  int *d_ticket = nullptr;   // RN16 pack counter of the decoder launch
   rfid_decode_result *d_res = nullptr;
   rfid_scores *d_scores = nullptr;
   rfid_stream_stats *d_stats = nullptr;
@@ -521,6 +522,7 @@ int rfid_ctx_create(const rfid_params *p, int device, rfid_ctx **out) {
         hipMalloc((void **)&c->d_io, 2 * sizeof(int)) != hipSuccess ||
         hipMalloc((void **)&c->d_swin, sizeof(rfid_window)) != hipSuccess ||
         hipMalloc((void **)&c->d_scount, sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&c->d_ticket, sizeof(int)) != hipSuccess ||
         hipMalloc((void **)&c->d_sres, sizeof(rfid_decode_result)) != hipSuccess ||
         hipMalloc((void **)&c->d_sscores, sizeof(rfid_scores)) != hipSuccess) { rc = RFID_ERR_HIP; break; }
     if (hipMemset(c->d_gate1, 0, sizeof(GateState)) != hipSuccess) { rc = RFID_ERR_HIP; break; }
@@ -544,7 +546,7 @@ int rfid_ctx_destroy(rfid_ctx *c) {
   la_free(c);
   sio_free(c);
   free_plan(c);
-  void *ptrs[] = {c->d_gate1, c->d_io, c->d_swin, c->d_scount, c->d_sres, c->d_sscores, c->s_in.p, c->s_out.p,
+  void *ptrs[] = {c->d_gate1, c->d_io, c->d_swin, c->d_scount, c->d_ticket, c->d_sres, c->d_sscores, c->s_in.p, c->s_out.p,
                   c->synth_tab.p, c->ls2_ws.p};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -831,13 +833,14 @@ int rfid_batch_decode(rfid_ctx *c, int want_scores) {
     if (grid > most) grid = (int)most;
   }
   if (grid < 1) grid = 1;
-  // EPC windows: 3 per wavefront
-  a.list = c->d_flat + c->flat_cap; a.count = c->d_flat_count + 1;
-  hipLaunchKernelGGL(decode_epc3_kernel, dim3((unsigned)grid), dim3(64), 0, c->stream, a);
-  HIPCHK(c, hipGetLastError());
-  // RN16 windows: 4 per wavefront
-  a.list = c->d_flat; a.count = c->d_flat_count;
-  hipLaunchKernelGGL(decode_rn16x4_kernel, dim3((unsigned)(grid * 2)), dim3(64), 0, c->stream, a);
+  // one launch: EPC windows 3 per wavefront, then RN16 windows 4 per wavefront drawn from a counter
+  DecodeAllArgs d;
+  d.epc = a; d.rn16 = a;
+  d.epc.list = c->d_flat + c->flat_cap; d.epc.count = c->d_flat_count + 1;
+  d.rn16.list = c->d_flat; d.rn16.count = c->d_flat_count;
+  d.ticket = c->d_ticket;
+  HIPCHK(c, hipMemsetAsync(c->d_ticket, 0, sizeof(int), c->stream));
+  hipLaunchKernelGGL(decode_all_kernel, dim3((unsigned)grid), dim3(64), 0, c->stream, d);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   c->ev_valid[3] = true;
@@ -1044,7 +1047,7 @@ int rfid_batch_timing_get(rfid_ctx *c, rfid_batch_timing *out) {
   out->mf_ms = ms[0]; out->gate_ms = ms[1]; out->decode_ms = ms[2]; out->stats_ms = ms[3];
   out->front_ms = (c->n_chunks_last > 0) ? front : (ms[0] + ms[1]);
   out->front_chunks = (c->n_chunks_last > 0) ? c->n_chunks_last : 1;
-  out->decode_launches = 2;
+  out->decode_launches = 1;
   out->fused_front = c->fused_last;
   out->reserved_ = 0;
   return RFID_OK;

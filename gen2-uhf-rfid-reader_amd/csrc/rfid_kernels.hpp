@@ -1457,7 +1457,7 @@ RFID_DEVICE void epc_uniformize(const DecodeListArgs &a, int pk, int total, cons
   }
 }
 
-RFID_KERNEL(64) void decode_epc3_kernel(DecodeListArgs a) {
+RFID_DEVICE void decode_epc3_body(const DecodeListArgs &a) {
   RFID_SHARED float m2[EPC_PACK * EPC_M2_STRIDE];   // |x|^2 of the 3 windows; later reused as complex samples
   RFID_SHARED float2 sy[EPC_PACK * SYNC_KEEP];
   RFID_SHARED float sc0[64];
@@ -1620,6 +1620,8 @@ RFID_KERNEL(64) void decode_epc3_kernel(DecodeListArgs a) {
   }
 }
 
+RFID_KERNEL(64) void decode_epc3_kernel(DecodeListArgs a) { decode_epc3_body(a); }
+
 // decode_rn16x4_kernel: FOUR RN16 windows per wavefront, one 16-lane row each, no LDS.  An RN16
 // decode touches 6x15 preamble taps and 32 half-bit samples; the lanes gather them straight
 // from global memory (8-byte loads, neighbouring lanes -> neighbouring addresses).
@@ -1634,13 +1636,18 @@ RFID_DEVICE float row_max16(float v) {   // maximum over the 16-lane row of the 
   return v;
 }
 
-RFID_KERNEL(64) void decode_rn16x4_kernel(DecodeListArgs a) {
+// ticket: nullptr = packs by workgroup index; else packs are drawn from this counter (workgroups that come out of the EPC
+// windows at different times take what is left)
+RFID_DEVICE void decode_rn16x4_body(const DecodeListArgs &a, int *ticket) {
   const int lane = wv::lane_id();
   int total = wv::uniform(*a.count);
   if (total > a.cap) total = a.cap;
   const int row = lane >> 4, t = lane & 15;
   const int n_packs = (total + RN16_PACK - 1) / RN16_PACK;
-  for (int pk = (int)blockIdx.x; pk < n_packs; pk += (int)gridDim.x) {
+  constexpr int TAKE = 8;   // packs per draw
+  for (int p0 = ticket ? wv::uniform((lane == 0) ? wv::atomic_add(ticket, TAKE) : 0) : (int)blockIdx.x; p0 < n_packs;
+       p0 = ticket ? wv::uniform((lane == 0) ? wv::atomic_add(ticket, TAKE) : 0) : (p0 + (int)gridDim.x))
+  for (int pk = p0; pk < n_packs && pk < (ticket ? p0 + TAKE : p0 + 1); ++pk) {
     const int w = pk * RN16_PACK + row;
     const bool on = w < total;
     const rfid_window wd = a.list[on ? w : (total - 1)];
@@ -1691,6 +1698,20 @@ RFID_KERNEL(64) void decode_rn16x4_kernel(DecodeListArgs a) {
       }
     }
   }
+}
+RFID_KERNEL(64) void decode_rn16x4_kernel(DecodeListArgs a) { decode_rn16x4_body(a, nullptr); }
+
+// tag_decoder in ONE launch: every persistent wave first takes its share of the EPC windows (three per wave and pass,
+// LDS-staged), then draws RN16 windows (four per wave, no LDS) from a common counter -- the waves that come out of the EPC
+// windows early do most of them, so the short RN16 pass fills the EPC pass's ragged end instead of paying a launch and
+// a ramp of its own.
+struct DecodeAllArgs {
+  DecodeListArgs epc, rn16;
+  int *ticket;              // zeroed before the launch
+};
+RFID_KERNEL(64) void decode_all_kernel(DecodeAllArgs a) {
+  decode_epc3_body(a.epc);
+  decode_rn16x4_body(a.rn16, a.ticket);
 }
 
 // =========================================================================================

@@ -164,10 +164,14 @@ int emu_batch_process(const float *raw, int B, long stride, long n_raw, const in
   DecodeListArgs da;
   da.y = y; da.y_stride = y_stride; da.cap = flat_cap; da.res = res.data(); da.scores = sc.data(); da.wmax = wmax;
   rfidh::t_candidates(da.t_cand, 400000);
-  da.list = flat.data() + flat_cap; da.count = &flat_count[1];
-  emu::launch(emu::Idx3{2, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { decode_epc3_kernel(da); });   // 2 persistent waves
-  da.list = flat.data(); da.count = &flat_count[0];
-  emu::launch(emu::Idx3{2, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { decode_rn16x4_kernel(da); });
+  {   // the one-launch tag_decoder, as rfid_batch_decode launches it (2 persistent waves here)
+    DecodeAllArgs all;
+    int ticket = 0;
+    all.epc = da; all.rn16 = da; all.ticket = &ticket;
+    all.epc.list = flat.data() + flat_cap; all.epc.count = &flat_count[1];
+    all.rn16.list = flat.data(); all.rn16.count = &flat_count[0];
+    emu::launch(emu::Idx3{2, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { decode_all_kernel(all); });
+  }
 
   StatsArgs sa;
   sa.res = res.data(); sa.wcount = wcount.data(); sa.wmax = wmax; sa.n_streams = B;
