@@ -64,6 +64,7 @@ struct rfid_ctx {
   Ls2Ctl *d_ls2_ctl = nullptr;    // the control block of the last pass that ran the front end (device), else nullptr
   int ls2_P = 0;                  // its nominal piece length
   int ls2_rounds[3] = {0, 0, 0};  // re-run rounds its launch list held per stage (avg_ampl, state machine, dc_est)
+  bool ls2_generous = false;      // a pass ran out of rounds once: the launch lists hold the full number of rounds from then on
   int ls_mode = 1;                // 0 never, 1 automatic, 2 whenever a trace can be cut
   double ls_fixed_ms = 0.45, ls_ns_per_sample = 0.03, seq_ns_per_sample = 10.2;   // cost model of the automatic choice (ls_calibrate)
   // whole-chain streaming (rfid_stream_*)
@@ -296,6 +297,12 @@ struct LsOpts {
 // GateArgs::skip_if = &ctl->ok, or synchronises and looks at c->ls2_host.
 int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
   *enqueued = 0;
+  // (a look at the last pass's control block, if that pass is over: one that ran out of rounds -- not one that found no
+  // cut -- makes the following passes enqueue the full number of rounds)
+  if (c->d_ls2_ctl && c->ls2_host && hipStreamQuery(c->stream) == hipSuccess && c->ls2_host->fail == 0 && c->ls2_host->ok == 0 &&
+      c->ls2_host->n_pieces > 0)
+    c->ls2_generous = true;
+  (void)hipGetLastError();
   c->d_ls2_ctl = nullptr;
   const Ls2Geometry geo = ls2_geometry(c->B, n_dec);
   if (geo.P == 0 || c->B > 65535) return RFID_OK;
@@ -326,7 +333,7 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
   HIPCHK(c, hipMemsetAsync(a.votes, 0, sizeof(uint64_t) * 2 * (size_t)c->B * (size_t)geo.vstride, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_flat_count, 0, 2 * sizeof(int), c->stream));
   ls2_stream = c->stream;
-  ls2_enqueue(a, true, c->ls2_rounds);
+  ls2_enqueue(a, true, c->ls2_rounds, c->ls2_generous);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(c->ls2_host, a.ctl, sizeof(Ls2Ctl), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync((char *)c->ls2_host + sizeof(Ls2Ctl), a.consumed, sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -94,7 +94,7 @@ inline int &ls2_chain_slots() { static int v = 4096; return v; }   // slots per 
 // and flat_count zeroed.  `a` complete but for
 // `round`.  After it: wtab / wcount / flat lists + Ls2Ctl::ok = 1, or ok = 0 (the caller's fallback scan, enqueued
 // behind with GateArgs::skip_if = &ctl->ok, then runs).
-inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nullptr) {   // (search_cuts = false: a.cut is given -- tests)
+inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nullptr, bool generous = false) {   // (search_cuts = false: a.cut is given -- tests)
   const int NS = a.n_streams * a.max_b, NH = a.n_streams * a.max_bc;   // slots; slots that can be heads
   const int B = a.n_streams;
   if (a.max_bc > 1 && search_cuts) {
@@ -112,10 +112,11 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
   a.round = 0;
   a.stamp = 0;
   // rounds enqueued behind each stage's first pass: a round without work is two empty launches (~10 us), which only a
-  // short pass notices -- and short traces settle in few rounds (their rounding drift is small)
-  const bool small = NS < 32768, tiny = NS < 1024;
-  a.avg_rounds = tiny ? 3 : (small ? 5 : LS2_AVG_ROUNDS); a.fsm_rounds = tiny ? 1 : (small ? 2 : LS2_FSM_ROUNDS);
-  a.dc_rounds = tiny ? 2 : (small ? 4 : LS2_DC_ROUNDS);
+  // short pass notices -- and short traces settle in few rounds (their rounding drift is small).  `generous`: the caller
+  // saw a pass run out of rounds (the sequential scan took over): the full count from then on
+  const bool small = NS < 32768 && !generous, tiny = NS < 1024 && !generous;
+  a.avg_rounds = tiny ? 3 : (small ? 4 : LS2_AVG_ROUNDS); a.fsm_rounds = (tiny || small) ? 1 : LS2_FSM_ROUNDS;
+  a.dc_rounds = (tiny || small) ? 2 : LS2_DC_ROUNDS;
   LS2_LAUNCH(ls2_pieces_kernel, (NS + 255) / 256, 1, 256, a);
   LS2_LAUNCH(ls2_check_kernel, 1, 1, 64, a);
   const int rerun_grid = NS;   // (one wave per list entry; the waves past the list return at once)

@@ -169,3 +169,36 @@ def test_python_flowgraph_with_look_ahead(oracle_mod, synth_mod):
         assert len(tb.decoded) == o.n_windows
     finally:
         tb.ctx.close()
+
+
+def test_short_passes_start_with_few_rounds_and_escalate(oracle_mod, synth_mod):
+    """A short pass enqueues few re-run rounds (a round without work is two empty launches, which only a short pass
+    notices).  A trace that needs more -- 8 % noise: dc_est passes close to powers of two all the time -- runs out of
+    them: the front end gives up, the sequential scan behind it gives the (identical) result, and from the next pass on
+    the library enqueues the full number of rounds: then the front end settles."""
+    import rfid
+    import torch
+    t = synth_mod.make_trace(n_rounds=20, sigma=0.08, seed=9).samples
+    o = oracle_mod.run_trace(t)
+    L = len(t)
+    stride = (L + 1) & ~1
+    host = np.zeros((1, stride), dtype=np.complex64)
+    host[0, :L] = t
+    dev = torch.from_numpy(host.view(np.float32)).to("cuda:0")
+    ctx = rfid.Context(device=0)
+    try:
+        ctx.batch_set_long_stream(2)
+        ctx.batch_plan(1, L)
+        reps = []
+        for _ in range(3):
+            ctx.batch_process_ptr(dev.data_ptr(), stride, L, 0, want_scores=True)
+            ctx.batch_sync()
+            reps.append(ctx.batch_ls_report())
+            w, r, s = ctx.batch_windows(want_scores=True)
+            parity.compare_trace(w, r, s, ctx.batch_stats()[0], o)
+        print([(x["verified"], x["gave_up"], x["avg_rounds"], x["dc_rounds"]) for x in reps])
+        assert reps[-1]["verified"] == 1, reps
+        if reps[0]["verified"] == 0:
+            assert reps[0]["gave_up"] in (2, 3, 4), reps[0]
+    finally:
+        ctx.close()

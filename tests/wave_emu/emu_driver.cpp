@@ -205,7 +205,7 @@ int emu_ls2_process(const float *raw, int B, long stride, long n_raw, const int6
                     rfid_decode_result *results, rfid_scores *scores, long cap, long *n_windows,
                     rfid_stream_stats *stats, int min_piece, int target, int *ctl_out, int ctl_cap,
                     void *state_blob, int hold_last, int *consumed_out, int *pieces_out, int pieces_cap,
-                    const int *cuts, int n_cuts, int y_skip) {
+                    const int *cuts, int n_cuts, int y_skip, int generous) {
   const long n_dec_all = n_raw / DECIM;
   const long n_dec = n_dec_all - y_skip;   // (y_skip: leading outputs that only exist to give the filter its history)
   long y_stride = (n_dec_all + 1) & ~1L;
@@ -257,7 +257,7 @@ int emu_ls2_process(const float *raw, int B, long stride, long n_raw, const int6
         if (J >= 1 && J < geo.max_bc && cuts[k] - J * geo.Pc < geo.Pc / 2) a.cut[J] = cuts[k];
       }
     }
-    ls2_enqueue(a, cuts == nullptr);
+    ls2_enqueue(a, cuts == nullptr, nullptr, generous != 0);
     ctl_host = *a.ctl;
     ok = a.ctl->ok;
     if (consumed_out) consumed_out[0] = a.consumed[0];
