@@ -283,6 +283,7 @@ size_t ls_workspace_bytes(int B, int64_t n_dec, int64_t y_stride) {
 }
 
 int ls_calibrate(rfid_ctx *c);
+void ls_note_last_pass(rfid_ctx *c);
 
 struct LsOpts {
   bool carry = false;       // the trace starts from c->d_gstate[trace] (streaming) instead of the fresh gate, and the state
@@ -295,14 +296,16 @@ struct LsOpts {
 // applicable here (traces too short, no work space) -- nothing was launched.  Whether the pass produced the window
 // tables is known on the device only (Ls2Ctl::ok); the caller enqueues the sequential scan behind it with
 // GateArgs::skip_if = &ctl->ok, or synchronises and looks at c->ls2_host.
-int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
-  *enqueued = 0;
-  // (a look at the last pass's control block, if that pass is over: one that ran out of rounds -- not one that found no
-  // cut -- makes the following passes enqueue the full number of rounds)
-  if (c->d_ls2_ctl && c->ls2_host && hipStreamQuery(c->stream) == hipSuccess && c->ls2_host->fail == 0 && c->ls2_host->ok == 0 &&
-      c->ls2_host->n_pieces > 0)
+// A look at the last pass's control block, if that pass is over (called before a pass enqueues anything): one that ran
+// out of rounds -- not one that found no cut -- makes the following passes enqueue the full number of rounds.
+void ls_note_last_pass(rfid_ctx *c) {
+  if (c->ls2_generous || !c->d_ls2_ctl || !c->ls2_host) return;
+  if (hipStreamQuery(c->stream) == hipSuccess && c->ls2_host->fail == 0 && c->ls2_host->ok == 0 && c->ls2_host->n_pieces > 0)
     c->ls2_generous = true;
   (void)hipGetLastError();
+}
+int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
+  *enqueued = 0;
   c->d_ls2_ctl = nullptr;
   const Ls2Geometry geo = ls2_geometry(c->B, n_dec);
   if (geo.P == 0 || c->B > 65535) return RFID_OK;
@@ -882,6 +885,7 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
   if (!c || !d_raw || n_raw < 0 || raw_stride < n_raw) return RFID_ERR_INVALID;
   if (!c->B) return RFID_ERR_STATE;
   if (n_raw > c->max_raw) return RFID_ERR_CAPACITY;
+  ls_note_last_pass(c);
   const int64_t n_out = n_raw / DECIM;
   const int64_t tiles = (n_out + MF_TILE - 1) / MF_TILE;
   // measured on MI355X (1024 traces): the overlap paid off while the gate scan took 4 ms (-5 %), but the
@@ -890,7 +894,6 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
   int nch = 1;
   if (const char *e = getenv("RFID_FRONT_CHUNKS")) nch = atoi(e);
   if (nch > rfid_ctx::MAX_CHUNKS) nch = rfid_ctx::MAX_CHUNKS;
-  c->d_ls2_ctl = nullptr;
   if (nch < 2 && ls_applicable(c, c->B, n_out)) {
     // few long traces: matched filter, then the gate scan as the long-stream front end -- every launch of it enqueued
     // here, the sequential scan behind them as the fallback that skips itself when the front end succeeded
@@ -902,6 +905,7 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
     if ((rc = rfid_batch_decode(c, want_scores))) return rc;
     return rfid_batch_stats(c);
   }
+  c->d_ls2_ctl = nullptr;   // (this pass does not run the long-stream front end)
   if (nch < 2 && raw_stride >= 2 && !getenv("RFID_FRONT_UNFUSED")) {
     // default: fused front end -- the gate's producer waves run the matched filter themselves
     // (one read of the raw samples, one write of y for the decoder, no second pass over y)
@@ -1487,7 +1491,7 @@ int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
   int64_t consumed = 0;                                 // decimated samples processed
   int n_windows = 0;
   bool y_ready = false;                                 // (look-ahead) a synchronisation has passed since the filter outputs were fetched
-  c->d_ls2_ctl = nullptr;
+  ls_note_last_pass(c);
   if (n_out > 0) {
     // ---- matched filter over everything available: y[n] = sum x[5n - 24 .. 5n], history in front of `data` ----
     MfArgs a;

@@ -197,7 +197,7 @@ def test_short_passes_start_with_few_rounds_and_escalate(oracle_mod, synth_mod):
             w, r, s = ctx.batch_windows(want_scores=True)
             parity.compare_trace(w, r, s, ctx.batch_stats()[0], o)
         print([(x["verified"], x["gave_up"], x["avg_rounds"], x["dc_rounds"]) for x in reps])
-        assert reps[-1]["verified"] == 1, reps
+        assert reps[-1]["verified"] == 1, str(reps)
         if reps[0]["verified"] == 0:
             assert reps[0]["gave_up"] in (2, 3, 4), reps[0]
     finally:
