@@ -388,6 +388,13 @@ def main():
         key = {"mf_boxcar25_decim5": "mf_ms", "gate_scan": "gate_ms", "tag_decoder": "decode_ms"}
         n_launch = {"mf_boxcar25_decim5": launches["front_chunks"], "gate_scan": launches["front_chunks"],
                     "tag_decoder": launches["decode_launches"]}
+    rep = ctx.batch_ls_report()
+    if rep["pieces"] and not fused:
+        # the gate ran as the long-stream front end: its launch sequence (cut searches, avg_ampl / state machine / dc_est
+        # rounds, assembly, the self-skipping sequential scan behind them) is timed and priced as ONE unit
+        alg = {("gate_long_stream" if k == "gate_scan" else k): v for k, v in alg.items()}
+        key = {("gate_long_stream" if k == "gate_scan" else k): v for k, v in key.items()}
+        n_launch = {("gate_long_stream" if k == "gate_scan" else k): (1 if k == "gate_scan" else v) for k, v in n_launch.items()}
     traffic, traffic_source = {}, None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
@@ -439,7 +446,6 @@ def main():
         "front_end_ms": round(k_ms["front_ms"], 4),
         "ms_per_step_by_rank": [round(v, 4) for v in ms_by_rank],
     }
-    rep = ctx.batch_ls_report()
     if rep["pieces"]:
         out["long_stream"] = dict(rep, note="traces cut along time into pieces processed at once (avg_ampl, state machine, dc_est) "
                                   "from guessed start values; accepted only when every piece's run is exact or provably covers its "

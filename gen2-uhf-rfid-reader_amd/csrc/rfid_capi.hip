@@ -26,8 +26,8 @@
   hipLaunchKernelGGL(rfidk::kernel, dim3((unsigned)(gx), (unsigned)(gy)), dim3((unsigned)(block)), 0, ls2_stream, args)
 static thread_local hipStream_t ls2_stream = nullptr;
 // RFID_LA_PROFILE=1: where the look-ahead's time goes (printed when the context is destroyed)
-static double g_la_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-static long g_la_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static double g_la_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+static long g_la_n[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 static inline double la_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec; }
 struct LaTimer { int k; double t0; explicit LaTimer(int kk) : k(kk), t0(la_now()) {} ~LaTimer() { g_la_t[k] += la_now() - t0; g_la_n[k]++; } };
 #include "rfid_ls2_enqueue.hpp"
@@ -85,24 +85,63 @@ struct rfid_ctx {
     int64_t raw_base = 0;         // global raw index of the first held-back sample (multiple of 5)
     std::vector<rfid_stream_window> out_w;   // windows completed but not yet delivered (caller arrays too small)
     std::vector<rfid_decode_result> out_r;
+    // a whole-chain pass that has been enqueued (sio_submit) and not looked at yet (sio_collect)
+    struct Pass {
+      bool active = false;
+      int b = 0;                  // the buffer it works on
+      int64_t n_have = 0, n_out = 0;
+      bool flush = false;
+      bool enq = false;           // the long-stream front end was enqueued
+      bool prefetched = false;    // (look-ahead) decoder + window packet were enqueued behind it, assuming it succeeds
+      int n_hdr = 0, usual = 0;   //   ... with these packet sizes
+    } pass;
+    hipEvent_t ev_y = nullptr;    // (look-ahead) the filter outputs of the submitted pass have reached the host
   } sio;
   // look-ahead of the per-block calls (rfid_lookahead_enable): what rfid_mf_work's whole-chain pass left for the gate /
   // decoder calls that follow
   struct LookAhead {
+    // the gated samples and their |.|^2 of one pass's windows, one after the other.  The blocks (and the blocks of filter
+    // outputs below) are recycled: a fresh half-megabyte vector per call is an mmap + a page fault per 4 KB
+    struct Blk { std::vector<rfid_cf32> g; std::vector<float> m; };
+    std::vector<Blk *> pool;
+    std::shared_ptr<Blk> take_blk() {
+      Blk *b;
+      if (pool.empty()) b = new Blk; else { b = pool.back(); pool.pop_back(); }
+      return std::shared_ptr<Blk>(b, [this](Blk *p) { pool.push_back(p); });
+    }
     struct Win {
       int64_t start = 0;              // global decimated position of the opening sample
       int type = 0, len = 0;
       rfid_decode_result res;
       // in[i] - dc_est over the window and |.|^2 of those: [off, off + len) of the block the whole-chain pass fetched
-      std::shared_ptr<std::vector<rfid_cf32>> gated;
-      std::shared_ptr<std::vector<float>> m2;
+      std::shared_ptr<Blk> blk;
       size_t off = 0;
       rfid_cf32 first, last;          // (the decoder's input is recognised by them)
     };
     bool on = false, flushed = false;
     int64_t gate_pos = 0;             // decimated samples the gate calls have consumed
-    int64_t y0 = 0;                   // global position of yq[0]
-    std::deque<rfid_cf32> yq;         // matched-filter output handed out and not consumed by the gate yet
+    // matched-filter output handed out and not (all) consumed by the gate yet: one block per rfid_mf_work call
+    struct YBlk { int64_t y0 = 0; std::vector<rfid_cf32> v; };
+    std::deque<YBlk> yq;
+    int64_t y_end = 0;                // global position behind the last block
+    const rfid_cf32 *y_at(int64_t pos) const {   // nullptr: not held
+      for (const YBlk &b : yq) if (pos >= b.y0 && pos < b.y0 + (int64_t)b.v.size()) return &b.v[(size_t)(pos - b.y0)];
+      return nullptr;
+    }
+    std::vector<std::vector<rfid_cf32>> y_pool;
+    void y_drop_before(int64_t pos) {
+      while (!yq.empty() && yq.front().y0 + (int64_t)yq.front().v.size() <= pos) {
+        if (y_pool.size() < 8) y_pool.push_back(std::move(yq.front().v));
+        yq.pop_front();
+      }
+    }
+    void y_push(int64_t y0, const rfid_cf32 *v, size_t n) {
+      yq.emplace_back();
+      if (!y_pool.empty()) { yq.back().v = std::move(y_pool.back()); y_pool.pop_back(); }
+      yq.back().y0 = y0;
+      yq.back().v.assign(v, v + n);
+      y_end = y0 + (int64_t)n;
+    }
     std::deque<Win> wins;             // windows the gate has not (completely) handed out yet
     int emitted = 0;                  // samples of wins.front() already handed out (gate open)
     std::deque<Win> dq;               // windows handed out by the gate, waiting for the decoder (results only)
@@ -156,6 +195,8 @@ namespace {
 
 void sio_free(rfid_ctx *c);   // (whole-chain streaming, below)
 int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush);
+int sio_submit(rfid_ctx *c, int b, int64_t n_new, bool flush);
+int sio_collect(rfid_ctx *c);
 void la_free(rfid_ctx *c);    // (look-ahead of the per-block calls)
 int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap, int *n_produced);
 int la_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap, int *n_consumed, int *n_written);
@@ -329,17 +370,11 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
   a.wtab = c->d_wtab; a.wmax = c->wmax; a.wcount = c->d_wcount; a.flat = c->d_flat; a.flat_count = c->d_flat_count; a.flat_cap = c->flat_cap;
   a.carry = opt.carry ? c->d_gstate : nullptr; a.carry_out = opt.carry ? c->d_gstate : nullptr;
   a.hold_last = opt.hold_last ? 1 : 0; a.force = opt.force ? 1 : 0;
-  HIPCHK(c, hipMemsetAsync(a.ctl, 0, sizeof(Ls2Ctl), c->stream));
-  HIPCHK(c, hipMemsetAsync(a.cflag, 0, sizeof(int) * (size_t)c->B * LS2_CHAIN_GMAX, c->stream));
-  HIPCHK(c, hipMemsetAsync(a.consumed, 0, sizeof(int) * (size_t)c->B, c->stream));
-  HIPCHK(c, hipMemsetAsync(a.wb, 0, sizeof(Ls2Win) * (size_t)c->B * (size_t)geo.wb_stride, c->stream));
-  HIPCHK(c, hipMemsetAsync(a.votes, 0, sizeof(uint64_t) * 2 * (size_t)c->B * (size_t)geo.vstride, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->d_flat_count, 0, 2 * sizeof(int), c->stream));
   ls2_stream = c->stream;
   ls2_enqueue(a, true, c->ls2_rounds, c->ls2_generous);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(c->ls2_host, a.ctl, sizeof(Ls2Ctl), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync((char *)c->ls2_host + sizeof(Ls2Ctl), a.consumed, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  // (the control block and, right behind it, consumed[0])
+  HIPCHK(c, hipMemcpyAsync(c->ls2_host, a.ctl, sizeof(Ls2Ctl) + sizeof(int), hipMemcpyDeviceToHost, c->stream));
   c->d_ls2_ctl = a.ctl;
   c->ls2_P = geo.P;
   *enqueued = 1;
@@ -549,8 +584,9 @@ int rfid_ctx_create(const rfid_params *p, int device, rfid_ctx **out) {
 int rfid_ctx_destroy(rfid_ctx *c) {
   if (!c) return RFID_ERR_INVALID;
   if (getenv("RFID_LA_PROFILE") && g_la_n[0])
-    fprintf(stderr, "[la] mf_work %ld calls %.2f ms (upload queued %.2f, whole-chain pass %.2f: enqueue %.2f, first sync %.2f) | gate_work %ld calls %.2f ms | decoder_work %ld calls %.2f ms | reader_work_tx %ld calls %.2f ms\n",
-            g_la_n[0], g_la_t[0], g_la_t[4], g_la_t[5], g_la_t[6], g_la_t[7], g_la_n[1], g_la_t[1], g_la_n[2], g_la_t[2], g_la_n[3], g_la_t[3]);
+    fprintf(stderr, "[la] mf_work %ld calls %.2f ms (upload queued %.2f, pass enqueued %.2f, wait for the filter outputs %.2f, previous pass collected %.2f: of it waiting %.2f) | "
+            "gate_work %ld calls %.2f ms | decoder_work %ld calls %.2f ms | reader_work_tx %ld calls %.2f ms\n",
+            g_la_n[0], g_la_t[0], g_la_t[4], g_la_t[5], g_la_t[8], g_la_t[6], g_la_t[7], g_la_n[1], g_la_t[1], g_la_n[2], g_la_t[2], g_la_n[3], g_la_t[3]);
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   la_free(c);
@@ -1306,7 +1342,7 @@ int rfid_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, i
   }
   if (c->la.on) {
     // (the SEEK_* -> CLOSED arming above touched the per-call gate state only, which the look-ahead does not use)
-    if (rs.status != RFID_RUNNING) { c->la.gate_pos += n_in; c->la.last_m2.clear(); while (c->la.y0 < c->la.gate_pos && !c->la.yq.empty()) { c->la.yq.pop_front(); c->la.y0++; } return RFID_OK; }
+    if (rs.status != RFID_RUNNING) { c->la.gate_pos += n_in; c->la.last_m2.clear(); c->la.y_drop_before(c->la.gate_pos); return RFID_OK; }
     if (n_in == 0) return RFID_OK;
     if (!out || out_cap < n_in) return RFID_ERR_CAPACITY;
     return la_gate_work(c, in, n_in, out, out_cap, n_consumed, n_written);
@@ -1445,6 +1481,7 @@ const int SIO_HIST = 28;   // raw samples kept before the held-back tail: 24 of 
 
 void sio_free(rfid_ctx *c) {
   rfid_ctx::StreamIO &io = c->sio;
+  if (io.open && c->stream) (void)hipStreamSynchronize(c->stream);   // (a submitted pass may still be running on these buffers)
   for (int i = 0; i < 2; ++i) {
     if (io.d_buf[i]) (void)hipFree(io.d_buf[i]);
     if (io.h_pin[i]) (void)hipHostFree(io.h_pin[i]);
@@ -1454,6 +1491,9 @@ void sio_free(rfid_ctx *c) {
   }
   if (io.copy_stream) (void)hipStreamDestroy(io.copy_stream);
   io.copy_stream = nullptr;
+  if (io.ev_y) (void)hipEventDestroy(io.ev_y);
+  io.ev_y = nullptr;
+  io.pass.active = false;
   io.open = false;
   io.failed = false;
 }
@@ -1483,15 +1523,52 @@ bool sio_account(rfid_ctx *c, const rfid_decode_result &r) {
 }
 
 // processes the chunk that sits in d_buf[b]: [SIO_HIST history | tail_len held back | n_new new] ending at tail_max + n_new
-int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
+// (look-ahead) the packet for the host: window count, window records, results, gated samples and their |.|^2 -- sized for
+// what a call usually holds and fetched with ONE copy
+int sio_enqueue_packet(rfid_ctx *c, int n_hdr, int usual, const int *only_if) {
+  const int cap = n_hdr * EPC_WIN;
+  const size_t hdr = GATED_HDR + (sizeof(rfid_window) + sizeof(rfid_decode_result)) * (size_t)n_hdr;
+  const size_t total = hdr + (sizeof(float2) + sizeof(float)) * (size_t)cap;
+  const size_t first = hdr + (sizeof(float2) + sizeof(float)) * (size_t)usual;
+  // (both buffers with room to spare: the window count creeps up and down from call to call, and every re-allocation
+  // synchronises the device)
+  if (total > c->la.d_pack.cap) {
+    int rc = grow(c, c->la.d_pack, total + total / 2);
+    if (rc) return rc;
+  }
+  if (first > c->la.h_cap) {
+    if (c->la.h_pack) (void)hipHostFree(c->la.h_pack);
+    c->la.h_pack = nullptr; c->la.h_cap = 0;
+    HIPCHK(c, hipHostMalloc((void **)&c->la.h_pack, first + first / 2, hipHostMallocDefault));
+    c->la.h_cap = first + first / 2;
+  }
+  GatedPack gp;
+  gp.wtab = c->d_wtab; gp.wcount = c->d_wcount; gp.res = c->d_res; gp.wmax = n_hdr; gp.y = c->d_y;
+  gp.pack = (char *)c->la.d_pack.p; gp.n_hdr = n_hdr; gp.usual = usual; gp.cap = cap;
+  gp.only_if = only_if;
+  hipLaunchKernelGGL(gated_windows_kernel, dim3((unsigned)n_hdr), dim3(256), 0, c->stream, gp);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->la.h_pack, c->la.d_pack.p, first, hipMemcpyDeviceToHost, c->stream));
+  return RFID_OK;
+}
+
+// One whole-chain pass over the raw samples of buffer b (the held-back ones in front of the n_new new ones), in two
+// halves.  sio_submit enqueues everything that needs no decision of the host: matched filter, (look-ahead: the copy of
+// the filter outputs the current call hands out, io.ev_y behind it,) the long-stream front end from the carried gate
+// state and -- look-ahead only, on the assumption that the front end succeeds -- the decoder and the packet of results.
+// sio_collect waits for the pass, runs the sequential scan where the front end left something over, fetches the
+// results, and moves what was not processed in front of the other buffer.  rfid_stream_work does both in one call; the
+// look-ahead of the per-block calls collects a pass when the next rfid_mf_work call arrives, so that the device works
+// on a call's samples while the scheduler hands out the windows of the call before.
+int sio_submit(rfid_ctx *c, int b, int64_t n_new, bool flush) {
   rfid_ctx::StreamIO &io = c->sio;
-  const int64_t n_have = io.tail_len + n_new;          // raw samples available beyond the history
-  const int64_t n_out = n_have / DECIM;
+  rfid_ctx::StreamIO::Pass &ps = io.pass;
+  ps = rfid_ctx::StreamIO::Pass();
+  ps.b = b; ps.flush = flush;
+  ps.n_have = io.tail_len + n_new;          // raw samples available beyond the history
+  ps.n_out = ps.n_have / DECIM;
+  const int64_t n_have = ps.n_have, n_out = ps.n_out;
   float2 *data = io.d_buf[b] + (io.tail_max - io.tail_len);   // first held-back (or new) sample
-  int64_t consumed = 0;                                 // decimated samples processed
-  int n_windows = 0;
-  bool y_ready = false;                                 // (look-ahead) a synchronisation has passed since the filter outputs were fetched
-  ls_note_last_pass(c);
   if (n_out > 0) {
     // ---- matched filter over everything available: y[n] = sum x[5n - 24 .. 5n], history in front of `data` ----
     MfArgs a;
@@ -1515,19 +1592,50 @@ int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
       }
       HIPCHK(c, hipMemcpyAsync(c->la.h_y, c->d_y + lo, sizeof(rfid_cf32) * (size_t)c->la.want_yn, hipMemcpyDeviceToHost, c->stream));
     }
+  }
+  if (c->la.on) HIPCHK(c, hipEventRecord(io.ev_y, c->stream));
+  if (n_out > 0) {
     // ---- gate: the pieces up to the last idle cut, from the carried state (the long-stream front end) ----
     LsOpts opt;
     opt.carry = true; opt.hold_last = !flush; opt.force = true;
     int enq = 0;
-    const double t_e0 = la_now();
     int rc = ls_enqueue(c, n_out, opt, &enq);
     if (rc) return rc;
-    g_la_t[6] += la_now() - t_e0; g_la_n[6]++;
+    ps.enq = enq != 0;
+    if (ps.enq && c->la.on) {
+      // look-ahead: nearly every pass ends with the front end's tables -- decode them and pack the results right behind
+      // it (a pass that ends otherwise is decoded and packed again by sio_collect)
+      c->ev_valid[2] = false;
+      if ((rc = rfid_batch_decode(c, 0))) return rc;
+      ps.n_hdr = c->la.n_hdr; ps.usual = (ps.n_hdr / 2 + 1) * (EPC_WIN + RN16_WIN);   // (the types alternate)
+      if ((rc = sio_enqueue_packet(c, ps.n_hdr, ps.usual, &c->d_ls2_ctl->ok))) return rc;   // (packed only if the front end made the tables)
+      ps.prefetched = true;
+    }
+  }
+  ps.active = true;
+  return RFID_OK;
+}
+
+int sio_collect(rfid_ctx *c) {
+  rfid_ctx::StreamIO &io = c->sio;
+  rfid_ctx::StreamIO::Pass &ps = io.pass;
+  if (!ps.active) return RFID_OK;
+  ps.active = false;
+  const int b = ps.b;
+  const bool flush = ps.flush;
+  const int64_t n_have = ps.n_have, n_out = ps.n_out;
+  float2 *data = io.d_buf[b] + (io.tail_max - io.tail_len);
+  int64_t consumed = 0;                                 // decimated samples processed
+  int n_windows = 0;
+  {
+    const double t_s0 = la_now();
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    g_la_t[7] += la_now() - t_s0; g_la_n[7]++;
+  }
+  ls_note_last_pass(c);
+  if (n_out > 0) {
     bool ok = false;
-    if (enq) {
-      const double t_s0 = la_now();
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      g_la_t[7] += la_now() - t_s0; g_la_n[7]++;
+    if (ps.enq) {
       ok = c->ls2_host->ok != 0;
       if (ok) consumed = flush ? n_out : *(const int *)((const char *)c->ls2_host + sizeof(Ls2Ctl));
       if (ok && consumed <= 0) ok = false;
@@ -1543,6 +1651,7 @@ int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
     if (!ok) consumed = 0;
     const int64_t seq_end = flush ? n_out : (n_out - EPC_WIN);
     const bool tail_too_long = DECIM * (n_out - consumed) + (n_have - DECIM * n_out) + SIO_HIST > io.tail_max;
+    bool prefetched = ps.prefetched && ok;   // the packet behind the pass holds the front end's windows
     if ((!ok || tail_too_long) && seq_end > consumed) {
       if (!ok) {
         HIPCHK(c, hipMemsetAsync(c->d_flat_count, 0, 2 * sizeof(int), c->stream));
@@ -1557,41 +1666,29 @@ int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
       HIPCHK(c, hipGetLastError());
       consumed = seq_end;
       ok = true;
+      prefetched = false;   // (more windows than the packet behind the pass knows: decode and pack again)
     }
-    const bool done = ok;
-    if (done) {
-      // ---- decode what the gate found, fetch it ----
-      c->ev_valid[2] = false;
-      if ((rc = rfid_batch_decode(c, 0))) return rc;
+    if (ok) {
+      // ---- decode what the gate found (unless that is done), fetch it ----
+      int rc;
+      if (!prefetched) {
+        c->ev_valid[2] = false;
+        if ((rc = rfid_batch_decode(c, 0))) return rc;
+      }
       int wc = 0;
       std::vector<rfid_window> w;
       std::vector<rfid_decode_result> r;
-      std::shared_ptr<std::vector<rfid_cf32>> blk_g;
-      std::shared_ptr<std::vector<float>> blk_m;
+      std::shared_ptr<rfid_ctx::LookAhead::Blk> blk;
       if (c->la.on) {
-        // look-ahead: one packet for the host -- count, window records, results, gated samples and their |.|^2, sized for what
-        // a call usually holds and fetched with ONE copy; a pass with more is fetched again with the right sizes
-        int n_hdr = c->la.n_hdr, usual = (n_hdr / 2 + 1) * (EPC_WIN + RN16_WIN);   // (the types alternate)
+        // a pass with more windows (or more gated samples) than the packet was sized for is fetched again with the right sizes
+        int n_hdr = prefetched ? ps.n_hdr : c->la.n_hdr;
+        int usual = prefetched ? ps.usual : (n_hdr / 2 + 1) * (EPC_WIN + RN16_WIN);   // (the types alternate)
         for (int attempt = 0; attempt < 2; ++attempt) {
-          const int cap = n_hdr * EPC_WIN;
           const size_t hdr = GATED_HDR + (sizeof(rfid_window) + sizeof(rfid_decode_result)) * (size_t)n_hdr;
-          const size_t total = hdr + (sizeof(float2) + sizeof(float)) * (size_t)cap;
-          const size_t first = hdr + (sizeof(float2) + sizeof(float)) * (size_t)usual;
-          if ((rc = grow(c, c->la.d_pack, total))) return rc;
-          if (first > c->la.h_cap) {
-            if (c->la.h_pack) (void)hipHostFree(c->la.h_pack);
-            c->la.h_pack = nullptr; c->la.h_cap = 0;
-            HIPCHK(c, hipHostMalloc((void **)&c->la.h_pack, first, hipHostMallocDefault));
-            c->la.h_cap = first;
+          if (!(attempt == 0 && prefetched)) {
+            if ((rc = sio_enqueue_packet(c, n_hdr, usual, nullptr))) return rc;
+            HIPCHK(c, hipStreamSynchronize(c->stream));
           }
-          GatedPack gp;
-          gp.wtab = c->d_wtab; gp.wcount = c->d_wcount; gp.res = c->d_res; gp.wmax = n_hdr; gp.y = c->d_y;
-          gp.pack = (char *)c->la.d_pack.p; gp.n_hdr = n_hdr; gp.usual = usual; gp.cap = cap;
-          hipLaunchKernelGGL(gated_windows_kernel, dim3((unsigned)n_hdr), dim3(256), 0, c->stream, gp);
-          HIPCHK(c, hipGetLastError());
-          HIPCHK(c, hipMemcpyAsync(c->la.h_pack, c->la.d_pack.p, first, hipMemcpyDeviceToHost, c->stream));
-          HIPCHK(c, hipStreamSynchronize(c->stream));
-          y_ready = true;
           wc = *(const int *)c->la.h_pack;
           if (wc > c->wmax) wc = c->wmax;
           const rfid_window *hw = (const rfid_window *)(c->la.h_pack + GATED_HDR);
@@ -1603,8 +1700,9 @@ int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
             w.assign(hw, hw + wc); r.assign(hr, hr + wc);
             const rfid_cf32 *g = (const rfid_cf32 *)(c->la.h_pack + hdr);
             const float *m = (const float *)(g + usual);
-            blk_g = std::make_shared<std::vector<rfid_cf32>>(g, g + need);
-            blk_m = std::make_shared<std::vector<float>>(m, m + need);
+            blk = c->la.take_blk();
+            blk->g.assign(g, g + need);
+            blk->m.assign(m, m + need);
             break;
           }
           if (attempt == 1) return fail(c, RFID_ERR_CAPACITY, "look-ahead: window packet");
@@ -1634,8 +1732,8 @@ int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
             c->la.wins.emplace_back();
             rfid_ctx::LookAhead::Win &q = c->la.wins.back();
             q.start = n0 + wi.start; q.type = wi.type; q.len = len; q.res = r[(size_t)i];
-            q.gated = blk_g; q.m2 = blk_m; q.off = goff;
-            q.first = (*blk_g)[goff]; q.last = (*blk_g)[goff + (size_t)len - 1];
+            q.blk = blk; q.off = goff;
+            q.first = blk->g[goff]; q.last = blk->g[goff + (size_t)len - 1];
             goff += (size_t)len;
             continue;
           }
@@ -1660,8 +1758,13 @@ int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
   io.tail_len = left;
   io.raw_base += DECIM * consumed;
   (void)n_windows;
-  if (c->la.on && !y_ready) HIPCHK(c, hipStreamSynchronize(c->stream));   // (the filter outputs for the caller have arrived)
   return RFID_OK;
+}
+
+int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
+  int rc = sio_submit(c, b, n_new, flush);
+  if (rc) return rc;
+  return sio_collect(c);
 }
 }  // namespace
 
@@ -1676,7 +1779,10 @@ int rfid_stream_begin(rfid_ctx *c, int64_t max_chunk_raw) {
   // held back per call: at most a few (stretched) pieces of the largest call's grid -- more goes through the sequential scan
   int64_t piece = (max_chunk_raw / DECIM + LS2_TARGET_PIECES - 1) / LS2_TARGET_PIECES;
   if (piece < LS2_MIN_PIECE) piece = LS2_MIN_PIECE;
-  io.tail_max = ((DECIM * 6 * piece + DECIM * (int64_t)EPC_WIN + SIO_HIST + 63) & ~63LL);
+  // (three steps of the idle-cut grid when calls are long: an inventory round has one idle stretch, a grid point may miss
+  // it; what does not fit goes through the sequential scan, which a short call can afford and a long one cannot)
+  const int64_t hold = (max_chunk_raw >= DECIM * 48 * piece) ? 3 * LS2_FINE * piece : 6 * piece;
+  io.tail_max = ((DECIM * hold + DECIM * (int64_t)EPC_WIN + SIO_HIST + 63) & ~63LL);
   io.max_chunk = max_chunk_raw;
   int rc = rfid_batch_plan(c, 1, io.tail_max + max_chunk_raw);
   if (rc) return rc;
@@ -1691,7 +1797,8 @@ int rfid_stream_begin(rfid_ctx *c, int64_t max_chunk_raw) {
     }
     if (hipMemsetAsync(io.d_buf[i], 0, sizeof(float2) * (size_t)io.tail_max, c->stream) != hipSuccess) { sio_free(c); return RFID_ERR_HIP; }
   }
-  if (hipStreamCreateWithFlags(&io.copy_stream, hipStreamNonBlocking) != hipSuccess) { sio_free(c); return RFID_ERR_HIP; }
+  if (hipStreamCreateWithFlags(&io.copy_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&io.ev_y, hipEventDisableTiming) != hipSuccess) { sio_free(c); return RFID_ERR_HIP; }
   // fresh blocks: gate_impl ctor state (zeros), READER_STATE after START -> SEND_QUERY (reader_impl.cc:218-288)
   init_reader_state(c);
   c->rs.n_queries_sent = 1;
@@ -1795,6 +1902,9 @@ void la_free(rfid_ctx *c) {
   if (la.h_pack) (void)hipHostFree(la.h_pack);
   if (la.h_y) (void)hipHostFree(la.h_y);
   if (la.d_pack.p) (void)hipFree(la.d_pack.p);
+  la.wins.clear(); la.dq.clear();   // (their blocks go back to the pool, which is emptied next)
+  for (rfid_ctx::LookAhead::Blk *b : la.pool) delete b;
+  la.pool.clear();
   la = rfid_ctx::LookAhead();
 }
 
@@ -1810,6 +1920,14 @@ int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int o
   const int64_t n_first = c->mf_seen / DECIM;
   const int n_out = (int)((c->mf_seen + n_in) / DECIM - n_first);
   if (n_out > out_cap || (n_out > 0 && !out)) return RFID_ERR_CAPACITY;
+  // the pass the previous call left on the device is over by now (the scheduler handed out a call's worth of windows
+  // meanwhile): its windows, and how far the gate's doing is known
+  if (io.pass.active) {
+    const double t_c0 = la_now();
+    const int rc = sio_collect(c);
+    g_la_t[6] += la_now() - t_c0; g_la_n[6]++;
+    if (rc) { io.failed = true; return rc; }
+  }
   const int up = io.cur;
   HIPCHK(c, hipEventSynchronize(io.ev_free[up]));   // (the call before last, processed long ago)
   const rfid_cf32 *src = in;
@@ -1825,13 +1943,18 @@ int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int o
   la.want_y0 = n_first; la.want_yn = n_out;
   g_la_t[4] += la_now() - tm.t0; g_la_n[4]++;   // (upload queued)
   const double t_sp = la_now();
-  const int rc = sio_process(c, up, n_in, false);
+  const int rc = sio_submit(c, up, n_in, false);
   g_la_t[5] += la_now() - t_sp; g_la_n[5]++;
   la.want_yn = 0;
   if (rc) { io.failed = true; return rc; }
+  {
+    const double t_y0 = la_now();
+    HIPCHK(c, hipEventSynchronize(io.ev_y));        // the filter outputs of this call (the rest of the pass runs on)
+    g_la_t[8] += la_now() - t_y0; g_la_n[8]++;
+  }
   if (n_out > 0) {
     memcpy(out, la.h_y, sizeof(rfid_cf32) * (size_t)n_out);
-    la.yq.insert(la.yq.end(), la.h_y, la.h_y + n_out);
+    la.y_push(n_first, la.h_y, (size_t)n_out);
   }
   c->mf_seen += n_in;
   la.stall = 0;
@@ -1850,10 +1973,10 @@ int la_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int
   la.last_m2.clear();
   const int64_t p = la.gate_pos;
   // the input must be the matched filter's output at the gate's position
-  if (p < la.y0 || p + n_in > la.y0 + (int64_t)la.yq.size() || !same_sample(in[0], la.yq[(size_t)(p - la.y0)]) ||
-      !same_sample(in[n_in - 1], la.yq[(size_t)(p + n_in - 1 - la.y0)]))
+  const rfid_cf32 *y_first = la.y_at(p), *y_last = la.y_at(p + n_in - 1);
+  if (!y_first || !y_last || !same_sample(in[0], *y_first) || !same_sample(in[n_in - 1], *y_last))
     return fail(c, RFID_ERR_STATE, "look-ahead: rfid_gate_work was not handed the matched filter's output at the gate's position");
-  for (int attempt = 0; attempt < 2; ++attempt) {
+  for (int attempt = 0; attempt < 3; ++attempt) {
     const int64_t frontier = io.raw_base / DECIM;   // the gate's doing is known for the samples before this position
     int consumed = 0, written = 0;
     bool open_after = false;
@@ -1865,14 +1988,13 @@ int la_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int
       const int64_t from = w.start + la.emitted;           // first sample of the window still to hand out (>= p)
       const int64_t upto = (w.start + w.len < p + n_in) ? (w.start + w.len) : (p + n_in);
       written = (int)(upto - from);
-      memcpy(out, w.gated->data() + w.off + la.emitted, sizeof(rfid_cf32) * (size_t)written);
-      la.last_m2.assign(w.m2->begin() + (long)(w.off + la.emitted), w.m2->begin() + (long)(w.off + la.emitted + written));
+      memcpy(out, w.blk->g.data() + w.off + la.emitted, sizeof(rfid_cf32) * (size_t)written);
+      la.last_m2.assign(w.blk->m.begin() + (long)(w.off + la.emitted), w.blk->m.begin() + (long)(w.off + la.emitted + written));
       la.emitted += written;
       if (la.emitted == w.len) {                           // gate_impl.cc:189-194: closed, consume_each(i + 1)
         consumed = (int)(w.start + w.len - p);
         la.dq.push_back(std::move(w));
-        la.dq.back().gated.reset();                        // (the decoder call is recognised by the window's first and last sample)
-        la.dq.back().m2.reset();
+        la.dq.back().blk.reset();                          // (the decoder call is recognised by the window's first and last sample)
         la.wins.pop_front();
         la.emitted = 0;
       } else {
@@ -1888,6 +2010,14 @@ int la_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int
       // nothing can be decided before more samples arrive.  The second such call in a row without new input: the
       // stream has ended -- what is held back goes through now
       if (++la.stall < 2) break;
+      if (io.pass.active) {
+        // (the last rfid_mf_work call's pass has not been looked at: the scheduler came back here instead of bringing
+        // more input)
+        const int rc = sio_collect(c);
+        if (rc) { io.failed = true; return rc; }
+        la.stall = 0;
+        continue;
+      }
       la.want_yn = 0;
       const int rc = (io.tail_len > 0) ? sio_process(c, io.cur, 0, true) : RFID_OK;
       if (rc) { io.failed = true; return rc; }
@@ -1898,7 +2028,7 @@ int la_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int
     // keep the state the window's last sample leaves: the dc ring etc. live on the device; here only what the blocks share
     rs.gate_status = open_after ? RFID_GATE_OPEN : RFID_GATE_CLOSED;
     la.gate_pos += consumed;
-    while (la.y0 < la.gate_pos && !la.yq.empty()) { la.yq.pop_front(); la.y0++; }
+    la.y_drop_before(la.gate_pos);
     *n_consumed = consumed;
     *n_written = written;
     return RFID_OK;

@@ -1137,11 +1137,13 @@ struct GatedPack {
   const float2 *y;
   char *pack;              // [hdr | g_lo[usual] | m_lo[usual] | g_hi[cap - usual] | m_hi[cap - usual]]
   int n_hdr, usual, cap;
+  const int *only_if;      // optional: pack nothing (count 0) unless *only_if != 0
 };
 constexpr int GATED_HDR = 64;   // bytes in front of the window records (the count)
 RFID_DEVICE size_t gated_pack_hdr_bytes(int n_hdr) { return (size_t)GATED_HDR + (sizeof(rfid_window) + sizeof(rfid_decode_result)) * (size_t)n_hdr; }
 RFID_KERNEL(256) void gated_windows_kernel(GatedPack a) {
   int n = *a.wcount;
+  if (a.only_if && *a.only_if == 0) n = 0;
   const int b = (int)blockIdx.x;
   char *pk = a.pack;
   rfid_window *hw = reinterpret_cast<rfid_window *>(pk + GATED_HDR);

@@ -233,6 +233,22 @@ RFID_DEVICE bool chain_add_auto2(float ca, float cb2, float x, int lane, float &
   return false;
 }
 
+// ---- 0. what a pass expects zeroed: the control block, the chain flags, consumed[], the votes, the window buckets, the
+//         counters of the decoder's lists -- one launch instead of six fills ---------------------------------------------
+static_assert(sizeof(Ls2Ctl) == 256, "Ls2Ctl and consumed[] are fetched with one copy (rfid_ls2_enqueue.hpp lays them out back to back)");
+RFID_KERNEL(256) void ls2_clear_kernel(Ls2Args a) {
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+  const int64_t B = a.n_streams;
+  auto zero4 = [&](void *p, int64_t words) { uint32_t *q = (uint32_t *)p; for (int64_t i = tid; i < words; i += nth) q[i] = 0u; };
+  auto zero8 = [&](void *p, int64_t words) { uint64_t *q = (uint64_t *)p; for (int64_t i = tid; i < words; i += nth) q[i] = 0ull; };
+  zero4(a.ctl, (int64_t)(sizeof(Ls2Ctl) / 4));
+  zero4(a.cflag, B * LS2_CHAIN_GMAX);
+  zero4(a.consumed, B);
+  zero4(a.flat_count, 2);
+  zero8(a.votes, 2 * B * a.vstride);
+  zero8(a.wb, (int64_t)(sizeof(Ls2Win) / 8) * B * a.wb_stride);
+}
+
 // ---- 1. pieces -----------------------------------------------------------------------------------------------------
 // Where a trace is cut.  avg_ampl only needs a place where it is at rest (100 carrier samples before: ls_cut_kernel with
 // a short quiet zone, near every point of a grid of step P) -- short pieces keep every pass short.  The state machine

@@ -90,13 +90,19 @@ inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geomet
 inline int &ls2_chain_slots() { static int v = 4096; return v; }   // slots per workgroup of a chain launch (tests shrink it)
 
 #ifdef LS2_LAUNCH
-// One pass.  Before it (stream-ordered): Ls2Ctl, the chain flags (a.cflag), the votes (a.votes), the window buckets (a.wb)
-// and flat_count zeroed.  `a` complete but for
+// One pass (its first launch zeroes Ls2Ctl, the chain flags, the votes, the window buckets and flat_count).  `a` complete but for
 // `round`.  After it: wtab / wcount / flat lists + Ls2Ctl::ok = 1, or ok = 0 (the caller's fallback scan, enqueued
 // behind with GateArgs::skip_if = &ctl->ok, then runs).
 inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nullptr, bool generous = false) {   // (search_cuts = false: a.cut is given -- tests)
   const int NS = a.n_streams * a.max_b, NH = a.n_streams * a.max_bc;   // slots; slots that can be heads
   const int B = a.n_streams;
+  {
+    const int64_t words = 2 * (int64_t)B * a.vstride + 3 * (int64_t)B * a.wb_stride;
+    int64_t g = (words + 4 * 256 - 1) / (4 * 256);   // (four words per thread)
+    if (g < 1) g = 1;
+    if (g > 8192) g = 8192;
+    LS2_LAUNCH(ls2_clear_kernel, (int)g, 1, 256, a);
+  }
   if (a.max_bc > 1 && search_cuts) {
     LsCutArgs ca;
     ca.y = a.y; ca.y_stride = a.y_stride; ca.lens = a.lens; ca.n_dec = a.n_dec; ca.chunk = a.Pc; ca.limit = a.Pc / 2;
