@@ -173,7 +173,8 @@ struct rfid_ctx {
   rfid_window *d_wtab = nullptr, *d_flat = nullptr;
   int wmax = 0, flat_cap = 0;
   int *d_wcount = nullptr, *d_flat_count = nullptr;
-  int *d_ticket = nullptr;   // RN16 pack counter of the decoder launch
+  int *d_ticket = nullptr;   // RN16 pack counters of the decoder launches (two, used alternately)
+  int ticket_flip = 0;
   rfid_decode_result *d_res = nullptr;
   rfid_scores *d_scores = nullptr;
   rfid_stream_stats *d_stats = nullptr;
@@ -567,10 +568,10 @@ int rfid_ctx_create(const rfid_params *p, int device, rfid_ctx **out) {
         hipMalloc((void **)&c->d_io, 2 * sizeof(int)) != hipSuccess ||
         hipMalloc((void **)&c->d_swin, sizeof(rfid_window)) != hipSuccess ||
         hipMalloc((void **)&c->d_scount, sizeof(int)) != hipSuccess ||
-        hipMalloc((void **)&c->d_ticket, sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&c->d_ticket, 2 * sizeof(int)) != hipSuccess ||
         hipMalloc((void **)&c->d_sres, sizeof(rfid_decode_result)) != hipSuccess ||
         hipMalloc((void **)&c->d_sscores, sizeof(rfid_scores)) != hipSuccess) { rc = RFID_ERR_HIP; break; }
-    if (hipMemset(c->d_gate1, 0, sizeof(GateState)) != hipSuccess) { rc = RFID_ERR_HIP; break; }
+    if (hipMemset(c->d_gate1, 0, sizeof(GateState)) != hipSuccess || hipMemset(c->d_ticket, 0, 2 * sizeof(int)) != hipSuccess) { rc = RFID_ERR_HIP; break; }
   } while (0);
   if (rc != RFID_OK) { rfid_ctx_destroy(c); return rc; }
   // the automatic choice between the two front ends works on rates measured here (RFID_LS_CALIBRATE=0: the defaults,
@@ -884,8 +885,9 @@ int rfid_batch_decode(rfid_ctx *c, int want_scores) {
   d.epc = a; d.rn16 = a;
   d.epc.list = c->d_flat + c->flat_cap; d.epc.count = c->d_flat_count + 1;
   d.rn16.list = c->d_flat; d.rn16.count = c->d_flat_count;
-  d.ticket = c->d_ticket;
-  HIPCHK(c, hipMemsetAsync(c->d_ticket, 0, sizeof(int), c->stream));
+  d.ticket = c->d_ticket + (c->ticket_flip & 1);        // (both zero after rfid_ctx_create; every launch zeroes the other one)
+  d.ticket_next = c->d_ticket + ((c->ticket_flip & 1) ^ 1);
+  c->ticket_flip ^= 1;
   hipLaunchKernelGGL(decode_all_kernel, dim3((unsigned)grid), dim3(64), 0, c->stream, d);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[3], c->stream));

@@ -1709,9 +1709,12 @@ RFID_KERNEL(64) void decode_rn16x4_kernel(DecodeListArgs a) { decode_rn16x4_body
 // a ramp of its own.
 struct DecodeAllArgs {
   DecodeListArgs epc, rn16;
-  int *ticket;              // zeroed before the launch
+  int *ticket;              // zero at the start of the launch
+  int *ticket_next;         // the next launch's counter: zeroed here (the launches alternate between two counters, so no
+                            // fill is needed between them)
 };
 RFID_KERNEL(64) void decode_all_kernel(DecodeAllArgs a) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *a.ticket_next = 0;
   decode_epc3_body(a.epc);
   decode_rn16x4_body(a.rn16, a.ticket);
 }

@@ -12,6 +12,9 @@ for cfg in 1 2 3stream 4shard; do
   timeout 600 python bench.py --config $cfg > $O/bench_$cfg.json 2> $O/bench_$cfg.err
 done
 timeout 300 python bench.py --streams 4096 --no-cpu-baseline --no-stream-leg > $O/bench_1_4096_traces.json 2> $O/bench_1_4096.err
+# the profiled runs: without the front-end calibration rfid_ctx_create does (two small batches through both front ends --
+# their launches would sit in the per-kernel averages); the choice of front end is the same for these workloads
+export RFID_LS_CALIBRATE=0
 for cfg in 1 2 3stream 4shard; do
   ( cd /tmp; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$cfg -o t -- python $R/bench.py --config $cfg --steps 5 --warmup 2 --no-cpu-baseline --no-stream-leg > $O/trace_$cfg.log 2>&1 )
   cp $O/trace_$cfg/t_kernel_stats.csv $O/kernel_stats_$cfg.csv 2>/dev/null
@@ -41,6 +44,7 @@ for k in sorted(agg):
 PY
 done
 bash profiles/tools/pmc_inst.sh > $O/sq_counters.txt 2> $O/pmc_inst.err
+unset RFID_LS_CALIBRATE
 { echo "== profiles/tools/dropin_rates.py"; timeout 600 python profiles/tools/dropin_rates.py; echo "== profiles/tools/la_profile.py"; timeout 300 python profiles/tools/la_profile.py; } > $O/drop_in_path.txt 2>&1
 timeout 600 python profiles/tools/front_end_crossover.py > $O/crossover.txt 2>&1
 rm -rf $O/trace_* $O/pmc_*_FETCH_SIZE $O/pmc_*_WRITE_SIZE

@@ -166,8 +166,8 @@ int emu_batch_process(const float *raw, int B, long stride, long n_raw, const in
   rfidh::t_candidates(da.t_cand, 400000);
   {   // the one-launch tag_decoder, as rfid_batch_decode launches it (2 persistent waves here)
     DecodeAllArgs all;
-    int ticket = 0;
-    all.epc = da; all.rn16 = da; all.ticket = &ticket;
+    int ticket = 0, ticket_next = 0;
+    all.epc = da; all.rn16 = da; all.ticket = &ticket; all.ticket_next = &ticket_next;
     all.epc.list = flat.data() + flat_cap; all.epc.count = &flat_count[1];
     all.rn16.list = flat.data(); all.rn16.count = &flat_count[0];
     emu::launch(emu::Idx3{2, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { decode_all_kernel(all); });
