@@ -1901,6 +1901,7 @@ int rfid_stream_end(rfid_ctx *c) {
 namespace {
 void la_free(rfid_ctx *c) {
   rfid_ctx::LookAhead &la = c->la;
+  if (la.on && c->stream) (void)hipStreamSynchronize(c->stream);   // (a submitted pass may still be copying into these buffers)
   if (la.h_pack) (void)hipHostFree(la.h_pack);
   if (la.h_y) (void)hipHostFree(la.h_y);
   if (la.d_pack.p) (void)hipFree(la.d_pack.p);
