@@ -1055,6 +1055,7 @@ int rfid_batch_ls_report(const rfid_ctx *c, rfid_ls_report *out) {
   out->dc_rounds = k.dc_rounds; out->dc_reruns = k.dc_reruns;
   for (int r = 0; r <= rf; ++r) out->cuts_dropped += k.fsm_count[r];
   out->windows = k.n_windows;
+  out->dc_pieces = k.n_dc_pieces;
   out->verified = (k.ok != 0) ? 1 : 0;
   out->gave_up = out->verified ? 0 : (k.fail ? k.fail : (k.avg_count[ra] ? 2 : (k.fsm_count[rf] ? 3 : (k.dc_count[rd] ? 4 : 5))));
   return RFID_OK;

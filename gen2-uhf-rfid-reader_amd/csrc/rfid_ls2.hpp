@@ -70,7 +70,8 @@ struct Ls2Ctl {   // control block in HBM, zeroed before every pass
   int n_units;                // units (runs of pieces scanned in one go) at the end
   int n_windows;              // complete windows
   int wb_clash;               // two openings in one bucket (cannot happen; checked all the same -> fail)
-  int reserved_[3];
+  int n_dc_pieces;            // dc_est pieces (>= n_units: a unit is cut again behind the gate openings)
+  int reserved_[2];
 };
 
 struct Ls2AvgRun {   // a piece's latest run
@@ -97,7 +98,9 @@ struct Ls2Fsm {   // per slot
 struct Ls2Win {   // one gate opening
   int start;
   int tag;        // type | complete << 1 | gen << 8;  0: empty
-  float a_re, a_im, b_re, b_im;   // dc_est at the opening from the unit's run: variant A, variant B
+  float a_re, a_im, b_re, b_im;   // dc_est at the opening from the run of the dc_est piece it lies in: variant A, variant B
+  int piece;      // ... that piece's slot
+  int pad_;
 };
 
 struct Ls2Aff { int64_t c0, c1; };
@@ -123,6 +126,10 @@ struct Ls2Args {
   Ls2Fsm *fsm;                  // [NS]
   Ls2Win *wb; int64_t wb_stride;   // [n_streams][wb_stride]
   Ls2DcRun *drun; int *dT;      // [NS], [NS][2]
+  int *dcut, *dend;             // [NS] the dc_est piece of the slot: its first sample; dend = 1: the slot has one, 0: none
+  int dc_fine;                  // 1: units are cut again behind gate openings (short passes: the longest run sets their pace);
+                                // 0: one dc_est piece per unit (fewer, longer runs settle in fewer rounds when the carrier
+                                // sits next to a power of two)
   int *dlist;                   // [2][NS]
   int *seq0;                    // [NS][2] complete windows of the trace before the piece: all, EPC
   int *flat_base;               // [n_streams][2] the trace's first place in the decoder's RN16 / EPC list
@@ -874,9 +881,240 @@ RFID_KERNEL(256) void ls2_fsm_chain_kernel(Ls2Args a) {
 }
 
 // ---- 4. dc_est -----------------------------------------------------------------------------------------------------
-// One wave per unit: dc_est += (x - dc_samples[dc_index]) / 48 over the closed samples (gate_impl.cc:139-143), from the
-// unit's start value and from 1 ulp above it (per component), the back wave's arithmetic value for value; dc_est at
-// every opening (:176) goes to the window's record.
+// dc_est += (x - dc_samples[dc_index]) / 48 over the closed samples (gate_impl.cc:139-143).  Its ring holds the last 48
+// CLOSED samples, so a run can start wherever the 48 samples before were all closed (the ring is then those samples):
+// at a unit's head -- and right behind every gate opening: the gate opens T1 = 97 carrier samples after the last pulse
+// of a command (:164-180), all of them closed, the opening sample included, and dc_est sits at the carrier's level
+// there.  So a unit is cut again behind the first opening of each of its pieces (if it has one): these are the dc_est
+// pieces -- a few hundred closed samples between two windows instead of whole units.  (Cutting at the pieces' own
+// boundaries does not work: in a Gen2 round the carrier rests almost only INSIDE the reply windows, where the gate is
+// open and the ring holds samples from before the window.)
+// where the dc_est piece of slot j starts: 0 = the slot has none
+RFID_DEVICE int ls2_dc_cut(const Ls2Args &a, const int j) {
+  if (a.piece[j].len <= 0) return 0;
+  const int h = a.fsm[j].unit;
+  if (a.fsm[h].head == 0) return 0;
+  const int upos0 = a.piece[h].pos0, u1 = a.fsm[h].u1;
+  if (j == h) return 0;   // (the head's piece starts at the unit's first sample: ls2_dc_cut_kernel)
+  const int p = a.piece[j].pos0, pe = p + a.piece[j].len;
+  if (p >= u1) return 0;
+  const int s = j / a.max_b;
+  const int64_t cbase = (int64_t)s * a.cstride + (upos0 >> 6) + (h - s * a.max_b) / LS2_FINE;
+  const int *oinfo = a.openinfo + cbase;
+  const uint64_t *cl = a.closed + cbase;
+  const int k0 = (p - upos0) >> 6, k1 = ((pe < u1 ? pe : u1) - upos0 + 63) >> 6;
+  for (int k = k0; k < k1; ++k) {
+    const int ol = oinfo[k] & 0xff;
+    if (ol == 0xff) continue;
+    const int op = upos0 + 64 * k + ol;            // the opening sample
+    const int c = op + 1;                          // the piece starts behind it
+    if (op < p || c >= pe || c >= u1) continue;
+    // the 48 samples before the cut closed?  (by construction; checked all the same)
+    const int lo = c - upos0 - DC_LEN;
+    if (lo < 0) continue;
+    const int w = lo >> 6, sh = lo & 63;
+    uint64_t v = cl[w] >> sh;
+    if (sh > 64 - DC_LEN) v |= cl[w + 1] << (64 - sh);
+    constexpr uint64_t ALL = (1ull << DC_LEN) - 1ull;
+    if ((v & ALL) == ALL) return c;
+  }
+  return 0;
+}
+// one thread per slot: where its dc_est piece starts (dend = 1: it has one; the run finds its own end)
+RFID_DEVICE bool ls2_fsm_settled(const Ls2Args &a, const Ls2Ctl *ctl);
+RFID_KERNEL(256) void ls2_dc_cut_kernel(Ls2Args a) {
+  if (!ls2_fsm_settled(a, a.ctl)) return;
+  const int j = (int)(blockIdx.x * 256 + threadIdx.x);
+  const int NS = a.n_streams * a.max_b;
+  if (j >= NS) return;
+  int cut = 0, on = 0;
+  if (a.piece[j].len > 0) {
+    const int h = a.fsm[j].unit;
+    if (j == h) {
+      if (a.fsm[h].head != 0 && a.piece[h].pos0 < a.fsm[h].u1) { cut = a.piece[h].pos0; on = 1; }
+    } else if (a.dc_fine) {
+      cut = ls2_dc_cut(a, j);
+      on = (cut > 0) ? 1 : 0;
+    }
+    // (a head's own piece may hold an opening too: that cut belongs to no slot, the head's run goes through it)
+  }
+  a.dcut[j] = cut;
+  a.dend[j] = on;
+}
+// the end of the dc_est piece of slot j (unit h): the next piece's first sample, or the unit's end.  The whole wave looks.
+RFID_DEVICE int ls2_dc_end(const Ls2Args &a, const int j, const int h, const int lane) {
+  const int u1 = wv::uniform(a.fsm[h].u1);
+  if (!a.dc_fine) return u1;
+  const int lim = (j / a.max_b + 1) * a.max_b;
+  for (int k0 = j + 1; k0 < lim; k0 += 64) {
+    const int k = k0 + lane;
+    bool stop = k >= lim, cut = false;
+    if (!stop && a.piece[k].len > 0) {
+      if (a.fsm[k].unit != h) stop = true;
+      else cut = a.dend[k] > 0;
+    }
+    const uint64_t m = wv::ballot(stop || cut);
+    if (m == 0ull) continue;
+    const int f = wv::ffs64(m);
+    const int c = wv::readlane(cut ? a.dcut[k] : u1, f);
+    return c;
+  }
+  return u1;
+}
+
+// One wave per dc_est piece: the sums from the piece's start value and from 1 ulp above it (per component), the back
+// wave's arithmetic value for value; dc_est at every opening (:176) goes to the window's record.
+RFID_DEVICE void ls2_dc_piece(const Ls2Args &a, const int j, const bool first, const int lane, float2 *lds_dc, float2 *lds_tmp) {
+  const int s = j / a.max_b;
+  const int h = wv::uniform(a.fsm[j].unit);                 // the unit's head: the unit's steps are counted from its first sample
+  const int upos0 = wv::uniform(a.piece[h].pos0);
+  const int p0 = wv::uniform(a.dcut[j]), p1 = ls2_dc_end(a, j, h, lane);
+  const float2 *yrow = a.y + (int64_t)s * a.y_stride;
+  GateBackRegs g;
+  g.run_closed = 0; g.ring_stale = 0; g.prev_yv = make_float2(0.0f, 0.0f);
+  g.win_seq = 0; g.n_complete = 0; g.written = 0; g.pos0 = upos0; g.strm = s;
+  g.dc_index = 0;
+  float sre, sim;
+  wv::wave_sync();   // (the previous piece's LDS reads are over)
+  if (j == s * a.max_b) {   // the trace's first piece: the fresh gate (all zero) or the carried state, exactly
+    if (a.carry) {
+      const GateState *cs = a.carry + s;
+      if (lane < DC_LEN) lds_dc[lane] = make_float2(cs->dcr_re[lane], cs->dcr_im[lane]);
+      g.dc_index = wv::uniform(cs->dc_index);
+      sre = wv::uniform(cs->dc_re); sim = wv::uniform(cs->dc_im);
+    } else {
+      if (lane < DC_LEN) lds_dc[lane] = make_float2(0.0f, 0.0f);
+      sre = 0.0f; sim = 0.0f;
+    }
+  } else {
+    // the ring holds the 48 samples before the piece; first guess of dc_est = their mean
+    float2 v = make_float2(0.0f, 0.0f);
+    if (lane < DC_LEN) { v = yrow[p0 - DC_LEN + lane]; lds_dc[lane] = v; }
+    if (first) {
+      float pr = v.x, pi = v.y;   // (lanes >= 48 hold zeros)
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) { pr += wv::shfl_xor(pr, off); pi += wv::shfl_xor(pi, off); }
+      sre = wv::uniform(pr) / DC_LEN_F; sim = wv::uniform(pi) / DC_LEN_F;
+    } else {
+      sre = 0.0f; sim = 0.0f;
+    }
+  }
+  if (!first) { sre = wv::uniform(a.drun[j].s[0]); sim = wv::uniform(a.drun[j].s[1]); }
+  wv::wave_sync();
+  const uint32_t sbr = wv::f2u(sre), sbi = wv::f2u(sim);
+  const float sreB = ls2_from_ord(ls2_ord(sre) + 1), simB = ls2_from_ord(ls2_ord(sim) + 1);
+  const uint32_t sbrB = wv::f2u(sreB), sbiB = wv::f2u(simB);
+  g.dcr_c = sre; g.dci_c = sim;
+  float bre = sreB, bim = simB;   // variant B's carries
+  int mre = ls2_margin(sre, sbr), mim = ls2_margin(sim, sbi);
+  const bool e0r_ok = ls2_e0_ok(sbr, sbrB), e0i_ok = ls2_e0_ok(sbi, sbiB);
+  Ls2Win *wb = a.wb + (int64_t)s * a.wb_stride;
+  {
+    // the unit's steps k0 .. k1 - 1 hold the piece (step k = samples upos0 + 64 k ..: the state-machine pass left the
+    // closed samples and the gate opening of every step); the lanes of the first / last step that lie outside it
+    // count as not closed -- they belong to the neighbours
+    const int n_unit = wv::uniform(a.fsm[h].u1) - upos0;
+    const int rel0 = p0 - upos0, rel1 = p1 - upos0;
+    const int k0 = rel0 >> 6, k1 = (rel1 + 63) >> 6, nsteps_unit = (n_unit + 63) >> 6;
+    const int64_t cbase = (int64_t)s * a.cstride + (upos0 >> 6) + (h - s * a.max_b) / LS2_FINE;
+    const uint64_t *closed = a.closed + cbase;
+    const int *oinfo = a.openinfo + cbase;
+    const float2 *ys = yrow + upos0;
+    constexpr int AHEAD = 4;
+    float2 buf[AHEAD];
+#pragma unroll
+    for (int u = 0; u < AHEAD; ++u) { const int idx = 64 * (k0 + u) + lane; buf[u] = (idx < n_unit) ? ys[idx] : make_float2(0.0f, 0.0f); }
+    float2 before = make_float2(0.0f, 0.0f);   // the samples of the previous step
+    if (k0 > 0) before = ys[64 * (k0 - 1) + lane];
+    uint64_t masks = 0;
+    int oi_l = 0xff;
+    for (int kb = k0; kb < k1; kb += AHEAD) {
+#pragma unroll
+      for (int u = 0; u < AHEAD; ++u) {
+        const int k = kb + u;
+        if (k < k1) {
+          if ((k & 63) == 0 || k == k0) {
+            const int blk = k & ~63;
+            const bool in = blk + lane < nsteps_unit;
+            masks = in ? closed[blk + lane] : 0ull;
+            oi_l = in ? oinfo[blk + lane] : 0xff;
+          }
+          const float2 yv = buf[u];
+          { const int idx = 64 * (k + AHEAD) + lane; buf[u] = (idx < n_unit) ? ys[idx] : make_float2(0.0f, 0.0f); }
+          const int kk = k & 63;
+          int lo = 0, hi = 64;
+          uint64_t closedmask = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(masks >> 32), kk) << 32) |
+                                (uint32_t)wv::readlane((int)(uint32_t)masks, kk);
+          if (__builtin_expect(k == k0 || k == k1 - 1, 0)) {   // the piece's first / last step: only its own lanes
+            lo = (k == k0) ? (rel0 & 63) : 0;
+            hi = (rel1 - 64 * k < 64) ? (rel1 - 64 * k) : 64;
+            closedmask &= lane_range(lo, hi);
+          }
+          const int oi = wv::readlane(oi_l, kk);
+          float ar, ai, br, bi;   // dc_est after every sample of the step, variants A and B
+          if (closedmask != 0) {
+            float tre, tim;
+            gate_dc_incr(g, closedmask, 0ull, hi, yv, lane, lds_dc, lds_tmp,
+                         [&](float &qre, float &qim) {
+                           // (x - x[i-48]) / 48 as the producer wave forms it: x[i-48] from the previous step's lanes 16..63
+                           // or this step's lanes 0..15
+                           const int src = (lane < DC_LEN) ? (lane + 64 - DC_LEN) : (lane - DC_LEN);
+                           const float pre = wv::shfl(before.x, src), pim = wv::shfl(before.y, src);
+                           const float cre = wv::shfl(yv.x, src), cim = wv::shfl(yv.y, src);
+                           const float nr = yv.x - ((lane < DC_LEN) ? pre : cre), ni = yv.y - ((lane < DC_LEN) ? pim : cim);
+                           if (__builtin_expect(wv::ballot(!(div_const_ok(nr) && div_const_ok(ni))) == 0, 1)) {
+                             qre = div_const_fast<DC_LEN>(nr); qim = div_const_fast<DC_LEN>(ni);
+                           } else {
+                             qre = wv::fdiv(nr, DC_LEN_F); qim = wv::fdiv(ni, DC_LEN_F);
+                           }
+                         },
+                         tre, tim);
+            const uint32_t cr0 = wv::f2u(g.dcr_c), cr1 = wv::f2u(bre), ci0 = wv::f2u(g.dci_c), ci1 = wv::f2u(bim);
+            const bool scr = chain_add_auto2(g.dcr_c, bre, tre, lane, ar, br);
+            const bool sci = chain_add_auto2(g.dci_c, bim, tim, lane, ai, bi);
+            g.dcr_c = wv::readlane(ar, 63); bre = wv::readlane(br, 63);
+            g.dci_c = wv::readlane(ai, 63); bim = wv::readlane(bi, 63);
+            int mr, mi;
+            if (scr) mr = ls2_margin_scanned(ar, br, cr0, cr1, sbr, sbrB, e0r_ok);
+            else { const int m1 = ls2_margin(ar, sbr), m2 = ls2_margin(br, sbrB); mr = (m1 < m2) ? m1 : m2; }
+            if (sci) mi = ls2_margin_scanned(ai, bi, ci0, ci1, sbi, sbiB, e0i_ok);
+            else { const int m3 = ls2_margin(ai, sbi), m4 = ls2_margin(bi, sbiB); mi = (m3 < m4) ? m3 : m4; }
+            mre = (mr < mre) ? mr : mre;
+            mim = (mi < mim) ? mi : mim;
+          } else {
+            g.run_closed = 0;   // no closed sample of the piece in this step (inside a window): dc_est, the ring and its index do not move
+            ar = g.dcr_c; ai = g.dci_c; br = bre; bi = bim;
+          }
+          before = yv;
+          const int ol = oi & 0xff;
+          if (ol != 0xff && ol >= lo && ol < hi) {   // a window opened at a sample of the piece: dc_est at that sample (the opening sample is still closed)
+            const float war = wv::readlane(ar, ol), wai = wv::readlane(ai, ol), wbr = wv::readlane(br, ol), wbi = wv::readlane(bi, ol);
+            if (lane == 0) {
+              Ls2Win *w = wb + (upos0 + 64 * k + ol) / LS2_WBUCKET;
+              w->a_re = war; w->a_im = wai; w->b_re = wbr; w->b_im = wbi; w->piece = j;
+            }
+          }
+        }
+      }
+    }
+  }
+  mre = ls2_wave_min(mre);
+  mim = ls2_wave_min(mim);
+  // (the chain's integer arithmetic needs start and end in one binade, see ls2_avg_piece)
+  if ((((wv::f2u(g.dcr_c) ^ sbr) | (wv::f2u(bre) ^ sbrB)) & 0xff800000u) != 0u) mre = 0;
+  if ((((wv::f2u(g.dci_c) ^ sbi) | (wv::f2u(bim) ^ sbiB)) & 0xff800000u) != 0u) mim = 0;
+  if (lane == 0) {
+    Ls2DcRun ru;
+    ru.s[0] = sre; ru.s[1] = sim; ru.eA[0] = g.dcr_c; ru.eA[1] = g.dci_c; ru.eB[0] = bre; ru.eB[1] = bim;
+    ru.margin[0] = mre; ru.margin[1] = mim;
+    a.drun[j] = ru;
+  }
+  // streaming: the dc ring after the trace's last processed piece is rebuilt from the samples (ls2_carry_kernel): a
+  // processed piece always ends at an idle cut
+}
+
+// the same for a whole unit (Ls2Args::dc_fine = 0: long passes, where the number of rounds matters more than the longest
+// run): from the head's first sample to the next head, no partial steps
 RFID_DEVICE void ls2_dc_unit(const Ls2Args &a, const int i, const bool first, const int lane, float2 *lds_dc, float2 *lds_tmp) {
   const int s = i / a.max_b;
   const Ls2Piece p0 = a.piece[i];
@@ -994,7 +1232,7 @@ RFID_DEVICE void ls2_dc_unit(const Ls2Args &a, const int i, const bool first, co
             const float war = wv::readlane(ar, ol), wai = wv::readlane(ai, ol), wbr = wv::readlane(br, ol), wbi = wv::readlane(bi, ol);
             if (lane == 0) {
               Ls2Win *w = wb + (pos0 + 64 * k + ol) / LS2_WBUCKET;
-              w->a_re = war; w->a_im = wai; w->b_re = wbr; w->b_im = wbi;
+              w->a_re = war; w->a_im = wai; w->b_re = wbr; w->b_im = wbi; w->piece = i;
             }
           }
         }
@@ -1024,11 +1262,15 @@ RFID_KERNEL(64) void ls2_dc_first_kernel(Ls2Args a) {
   RFID_SHARED float2 lds_tmp[64];
   if (!ls2_fsm_settled(a, a.ctl)) return;
   const int lane = wv::lane_id();
-  const int NH = a.n_streams * a.max_bc;
-  for (int b = (int)blockIdx.x; b < NH; b += (int)gridDim.x) {
-    const int i = (b / a.max_bc) * a.max_b + (b % a.max_bc) * LS2_FINE;
-    if (wv::uniform(a.piece[i].len) <= 0 || wv::uniform(a.fsm[i].head) == 0) continue;
-    ls2_dc_unit(a, i, true, lane, lds_dc, lds_tmp);
+  const int NH = a.n_streams * a.max_bc, NS = a.dc_fine ? a.n_streams * a.max_b : NH;   // (whole units: the idle-grid slots only)
+  for (int b = (int)blockIdx.x; b < NS; b += (int)gridDim.x) {
+    // block -> slot: the idle-grid slots first, then the slots one, two, ... behind them (slots in their own order
+    // would put the units' heads, every LS2_FINE-th slot, on two of the eight XCDs)
+    const int q = b / NH, hb = b - q * NH;
+    const int j = (hb / a.max_bc) * a.max_b + (hb % a.max_bc) * LS2_FINE + q;
+    if (wv::uniform(a.dend[j]) <= 0) continue;
+    if (a.dc_fine) ls2_dc_piece(a, j, true, lane, lds_dc, lds_tmp);
+    else ls2_dc_unit(a, j, true, lane, lds_dc, lds_tmp);
   }
 }
 RFID_KERNEL(64) void ls2_dc_rerun_kernel(Ls2Args a) {
@@ -1039,19 +1281,21 @@ RFID_KERNEL(64) void ls2_dc_rerun_kernel(Ls2Args a) {
   const int cnt = wv::uniform(a.ctl->dc_count[a.round - 1]);
   const int lane = wv::lane_id();
   const int *list = a.dlist + (int64_t)((a.round - 1) & 1) * NS;
-  for (int r = (int)blockIdx.x; r < cnt; r += (int)gridDim.x) ls2_dc_unit(a, wv::uniform(list[r]), false, lane, lds_dc, lds_tmp);
+  for (int r = (int)blockIdx.x; r < cnt; r += (int)gridDim.x) {
+    if (a.dc_fine) ls2_dc_piece(a, wv::uniform(list[r]), false, lane, lds_dc, lds_tmp);
+    else ls2_dc_unit(a, wv::uniform(list[r]), false, lane, lds_dc, lds_tmp);
+  }
 }
 
-// one workgroup per trace: as ls2_avg_chain_kernel, over the units (heads: every LS2_FINE-th slot at most) and the two
-// components of dc_est
+// as ls2_avg_chain_kernel, over the dc_est pieces and the two components of dc_est
 struct Ls2DcRec { int on; Ls2DcRun ru; };
 RFID_DEVICE Ls2DcRec ls2_dc_rec(const Ls2Args &a, int base, int J) {
   Ls2DcRec r; r.on = 0;
   for (int c = 0; c < 2; ++c) { r.ru.s[c] = r.ru.eA[c] = r.ru.eB[c] = 0.0f; r.ru.margin[c] = 0; }
-  if (J < a.max_bc) {
-    const int i = base + J * LS2_FINE;
-    r.on = (a.piece[i].len > 0 && a.fsm[i].head != 0) ? 1 : 0;
-    r.ru = a.drun[i];
+  if (J < (a.dc_fine ? a.max_b : a.max_bc)) {
+    const int i = base + (a.dc_fine ? J : J * LS2_FINE);
+    r.on = (a.dend[i] > 0) ? 1 : 0;
+    if (r.on) r.ru = a.drun[i];
   }
   return r;
 }
@@ -1067,7 +1311,7 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_dc_chain_kernel(Ls2Args a) {
   const int base = s * a.max_b;
   if (a.piece[base].len <= 0) return;
   int c_lo, c_hi;
-  ls2_chain_range(a.max_bc, a.chain_g, b, wave, c_lo, c_hi);
+  ls2_chain_range(a.dc_fine ? a.max_b : a.max_bc, a.chain_g, b, wave, c_lo, c_hi);
   const int T0r = ls2_ord(a.drun[base].s[0]), T0i = ls2_ord(a.drun[base].s[1]);
   // ---- sweep 1: this wave's totals ----
   Ls2A32 carry[2]; carry[0].c0 = carry[0].c1 = 0; carry[1].c0 = carry[1].c1 = 0;
@@ -1088,12 +1332,12 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_dc_chain_kernel(Ls2Args a) {
   ls2_chain_prefix<2>(a, s, b, wave, lane, tid, carry, wagg, pre);
   Ls2A32 rr = pre[0], ri = pre[1];
   // ---- sweep 2: every unit's true (or predicted) start; what is not proven goes on the re-run list ----
-  int n_rerun = 0, n_units = 0;
+  int n_rerun = 0, n_units = 0, n_dc = 0;
   nxt = ls2_dc_rec(a, base, 64 * c_lo + lane);
   for (int c = c_lo; c < c_hi; ++c) {
     const Ls2DcRec rec = nxt;
     if (c + 1 < c_hi) nxt = ls2_dc_rec(a, base, 64 * (c + 1) + lane);
-    const int i = base + (64 * c + lane) * LS2_FINE;
+    const int i = base + (64 * c + lane) * (a.dc_fine ? 1 : LS2_FINE);
     const bool in = rec.on != 0;
     const Ls2DcRun &ru = rec.ru;
     Ls2A32 er, ei; er.c0 = er.c1 = 0; ei.c0 = ei.c1 = 0;
@@ -1105,7 +1349,8 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_dc_chain_kernel(Ls2Args a) {
     const int Tr = ls2_apply32(ls2_comp32(rr, ls2_wave_excl(ir, lane)), T0r);
     const int Ti = ls2_apply32(ls2_comp32(ri, ls2_wave_excl(ii, lane)), T0i);
     if (in) {
-      n_units++;
+      if (r == 0 && a.fsm[i].unit == i) n_units++;
+      n_dc++;
       const int64_t Dr = (int64_t)Tr - (int64_t)ls2_ord(ru.s[0]), Di = (int64_t)Ti - (int64_t)ls2_ord(ru.s[1]);
       const int64_t aDr = (Dr < 0) ? -Dr : Dr, aDi = (Di < 0) ? -Di : Di;
       a.dT[2 * i] = Tr; a.dT[2 * i + 1] = Ti;
@@ -1123,6 +1368,7 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_dc_chain_kernel(Ls2Args a) {
   }
   if (n_rerun) wv::atomic_add(&ctl->dc_reruns, n_rerun);
   if (r == 0 && n_units) wv::atomic_add(&ctl->n_units, n_units);
+  if (r == 0 && n_dc) wv::atomic_add(&ctl->n_dc_pieces, n_dc);
   if (tid == 0 && s == 0 && b == 0) ctl->dc_rounds = r + 1;
 }
 
@@ -1192,32 +1438,35 @@ RFID_KERNEL(64) void ls2_assemble_kernel(Ls2Args a) {
     const int pos0 = wv::uniform(a.piece[i].pos0), n = wv::uniform(f->u1) - pos0;
     const int s = i / a.max_b;
     const int gen = wv::uniform(f->gen);
-    // the unit's true start against the start its run used: D ulps (even: variant A + D, odd: variant B + D - 1)
-    const Ls2DcRun ru = a.drun[i];
-    float shift[2];
-    bool useb[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int D = wv::uniform(a.dT[2 * i + c]) - ls2_ord(ru.s[c]);
-      useb[c] = (D & 1) != 0;
-      const int De = useb[c] ? (D - 1) : D;
-      const uint32_t e0 = (wv::f2u(ru.s[c]) >> 23) & 0xffu;
-      const float u0 = (e0 >= 25u) ? wv::u2f((e0 - 23u) << 23) : 0.0f;   // (D != 0 was only accepted with a margin, i.e. e0 >= 25)
-      shift[c] = (float)De * u0;
-    }
     const Ls2Win *wb = a.wb + (int64_t)s * a.wb_stride;
     const int b0 = pos0 / LS2_WBUCKET, b1 = (pos0 + n - 1) / LS2_WBUCKET;
     int seq = wv::uniform(a.seq0[2 * i]), seq_e = wv::uniform(a.seq0[2 * i + 1]);
     const int fb0 = wv::uniform(a.flat_base[2 * s]), fb1 = wv::uniform(a.flat_base[2 * s + 1]);
     for (int bb = b0; bb <= b1; bb += 64) {
       const int b = bb + lane;
-      Ls2Win w; w.start = 0; w.tag = 0; w.a_re = w.a_im = w.b_re = w.b_im = 0.0f;
+      Ls2Win w; w.start = 0; w.tag = 0; w.a_re = w.a_im = w.b_re = w.b_im = 0.0f; w.piece = 0; w.pad_ = 0;
       if (b <= b1) w = wb[b];
       const bool on = b <= b1 && (w.tag >> 8) == gen && (w.tag & 2) != 0 && w.start >= pos0 && w.start < pos0 + n;
       const uint64_t m = wv::ballot(on);
       if (m == 0ull) continue;
       const int type = w.tag & 1;
       const uint64_t me = wv::ballot(on && type != 0);
+      // the true start of the window's dc_est piece against the start its run used: D ulps (even: variant A + D, odd:
+      // variant B + D - 1)
+      float shift[2] = {0.0f, 0.0f};
+      bool useb[2] = {false, false};
+      if (on) {
+        const Ls2DcRun ru = a.drun[w.piece];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int D = a.dT[2 * w.piece + c] - ls2_ord(ru.s[c]);
+          useb[c] = (D & 1) != 0;
+          const int De = useb[c] ? (D - 1) : D;
+          const uint32_t e0 = (wv::f2u(ru.s[c]) >> 23) & 0xffu;
+          const float u0 = (e0 >= 25u) ? wv::u2f((e0 - 23u) << 23) : 0.0f;   // (D != 0 was only accepted with a margin, i.e. e0 >= 25)
+          shift[c] = (float)De * u0;
+        }
+      }
       rfid_window o;
       o.stream = s; o.seq = seq + wv::popc64(m & lt); o.start = w.start; o.type = type;
       o.dc_re = (useb[0] ? w.b_re : w.a_re) + shift[0];
@@ -1258,10 +1507,12 @@ RFID_KERNEL(64) void ls2_carry_kernel(Ls2Args a) {
   const int Da = wv::uniform(a.aT[last]) - ls2_ord(ar.s);
   const float avg_end = ls2_from_ord(ls2_ord((Da & 1) ? ar.eB : ar.eA) + ((Da & 1) ? (Da - 1) : Da));
   const int h = wv::uniform(a.fsm[last].unit);
-  const Ls2DcRun dr = a.drun[h];
+  int hd = last;   // the last dc_est piece: the one of the last slot that has one (the unit's head at the latest)
+  while (hd != h && wv::uniform(a.dend[hd]) <= 0) hd = wv::uniform(a.prevv[hd]);
+  const Ls2DcRun dr = a.drun[hd];
   float dc_end[2];
   for (int c = 0; c < 2; ++c) {
-    const int D = wv::uniform(a.dT[2 * h + c]) - ls2_ord(dr.s[c]);
+    const int D = wv::uniform(a.dT[2 * hd + c]) - ls2_ord(dr.s[c]);
     dc_end[c] = ls2_from_ord(ls2_ord((D & 1) ? dr.eB[c] : dr.eA[c]) + ((D & 1) ? (D - 1) : D));
   }
   for (int k = lane; k < WIN_LEN; k += 64) {

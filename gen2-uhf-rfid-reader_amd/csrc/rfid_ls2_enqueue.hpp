@@ -40,7 +40,7 @@ inline Ls2Geometry ls2_geometry(int n_streams, int64_t n_dec, int min_piece = LS
 
 // work space: one allocation, carved up here (offsets in bytes, 256-byte aligned)
 struct Ls2Layout {
-  size_t cut, cutf, piece, nextv, prevv, amp, dadd, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, drun, dT, dlist, seq0, flat_base, cflag, cagg, ctl, consumed, total;
+  size_t cut, cutf, piece, nextv, prevv, amp, dadd, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, drun, dT, dcut, dend, dlist, seq0, flat_base, cflag, cagg, ctl, consumed, total;
 };
 inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_stride) {
   Ls2Layout L;
@@ -65,6 +65,8 @@ inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_strid
   L.wb = take(sizeof(Ls2Win) * B * (size_t)g.wb_stride);
   L.drun = take(sizeof(Ls2DcRun) * NS);
   L.dT = take(sizeof(int) * 2 * NS);
+  L.dcut = take(sizeof(int) * NS);
+  L.dend = take(sizeof(int) * NS);
   L.dlist = take(sizeof(int) * 2 * NS);
   L.seq0 = take(sizeof(int) * 2 * NS);
   L.flat_base = take(sizeof(int) * 2 * B);
@@ -83,7 +85,7 @@ inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geomet
   a.votes = (uint64_t *)(base + L.votes); a.closed = (uint64_t *)(base + L.closed); a.openinfo = (int *)(base + L.openinfo);
   a.arun = (Ls2AvgRun *)(base + L.arun); a.aT = (int *)(base + L.aT); a.alist = (int *)(base + L.alist); a.aover = (Ls2Aff *)(base + L.aover);
   a.fsm = (Ls2Fsm *)(base + L.fsm); a.wb = (Ls2Win *)(base + L.wb);
-  a.drun = (Ls2DcRun *)(base + L.drun); a.dT = (int *)(base + L.dT); a.dlist = (int *)(base + L.dlist);
+  a.drun = (Ls2DcRun *)(base + L.drun); a.dT = (int *)(base + L.dT); a.dcut = (int *)(base + L.dcut); a.dend = (int *)(base + L.dend); a.dlist = (int *)(base + L.dlist);
   a.seq0 = (int *)(base + L.seq0); a.flat_base = (int *)(base + L.flat_base); a.cflag = (int *)(base + L.cflag); a.cagg = (int *)(base + L.cagg); a.ctl = (Ls2Ctl *)(base + L.ctl); a.consumed = (int *)(base + L.consumed);
 }
 
@@ -93,7 +95,7 @@ inline int &ls2_chain_slots() { static int v = 4096; return v; }   // slots per 
 // One pass (its first launch zeroes Ls2Ctl, the chain flags, the votes, the window buckets and flat_count).  `a` complete but for
 // `round`.  After it: wtab / wcount / flat lists + Ls2Ctl::ok = 1, or ok = 0 (the caller's fallback scan, enqueued
 // behind with GateArgs::skip_if = &ctl->ok, then runs).
-inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nullptr, bool generous = false) {   // (search_cuts = false: a.cut is given -- tests)
+inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nullptr, bool generous = false, int dc_fine = -1) {   // (search_cuts = false: a.cut is given -- tests)
   const int NS = a.n_streams * a.max_b, NH = a.n_streams * a.max_bc;   // slots; slots that can be heads
   const int B = a.n_streams;
   {
@@ -123,12 +125,15 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
   const bool small = NS < 32768 && !generous, tiny = NS < 1024 && !generous;
   a.avg_rounds = tiny ? 3 : (small ? 4 : LS2_AVG_ROUNDS); a.fsm_rounds = (tiny || small) ? 1 : LS2_FSM_ROUNDS;
   a.dc_rounds = (tiny || small) ? 2 : LS2_DC_ROUNDS;
+  // short passes run at the pace of their longest dc_est run: there the units are cut again behind the gate openings
+  // (test hook: dc_fine = 0 / 1 says so itself)
+  a.dc_fine = (dc_fine < 0) ? (small ? 1 : 0) : dc_fine;
   LS2_LAUNCH(ls2_pieces_kernel, (NS + 255) / 256, 1, 256, a);
   LS2_LAUNCH(ls2_check_kernel, 1, 1, 64, a);
   const int rerun_grid = NS;   // (one wave per list entry; the waves past the list return at once)
   // workgroups per trace of the chain kernels: a few thousand slots each
   auto chain_g = [](int slots) { const int per = ls2_chain_slots(); int g = (slots + per - 1) / per; return g < 1 ? 1 : (g > LS2_CHAIN_GMAX ? LS2_CHAIN_GMAX : g); };
-  const int g_avg = chain_g(a.max_b), g_dc = chain_g(a.max_bc);
+  const int g_avg = chain_g(a.max_b), g_seq = chain_g(a.max_bc);   // (pieces: any slot; units: idle-grid slots)
   LS2_LAUNCH(ls2_avg_first_kernel, NS, 1, 64, a);
   a.chain_g = g_avg; a.stamp++;
   LS2_LAUNCH(ls2_avg_chain_kernel, g_avg, B, LS2_CHAIN_THREADS, a);
@@ -144,8 +149,10 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
     LS2_LAUNCH(ls2_fsm_chain_kernel, (NH + 255) / 256, 1, 256, a);
   }
   a.round = 0;
+  const int g_dc = a.dc_fine ? g_avg : g_seq;
   a.chain_g = g_dc;
-  LS2_LAUNCH(ls2_dc_first_kernel, NH, 1, 64, a);
+  LS2_LAUNCH(ls2_dc_cut_kernel, (NS + 255) / 256, 1, 256, a);
+  LS2_LAUNCH(ls2_dc_first_kernel, a.dc_fine ? NS : NH, 1, 64, a);
   a.stamp++;
   LS2_LAUNCH(ls2_dc_chain_kernel, g_dc, B, LS2_CHAIN_THREADS, a);
   for (int r = 1; r <= a.dc_rounds; ++r) {
@@ -156,7 +163,8 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
   }
   a.round = 0;
   a.stamp++;
-  LS2_LAUNCH(ls2_seq_kernel, g_dc, B, LS2_CHAIN_THREADS, a);
+  a.chain_g = g_seq;
+  LS2_LAUNCH(ls2_seq_kernel, g_seq, B, LS2_CHAIN_THREADS, a);
   LS2_LAUNCH(ls2_assemble_kernel, NH, 1, 64, a);
   if (a.carry_out) LS2_LAUNCH(ls2_carry_kernel, B, 1, 64, a);
   if (rounds_out) { rounds_out[0] = a.avg_rounds; rounds_out[1] = a.fsm_rounds; rounds_out[2] = a.dc_rounds; }

@@ -145,12 +145,13 @@ typedef struct rfid_ls_report {
   int32_t avg_reruns;       /*   pieces run again from their predicted start because their first run did not cover it */
   int32_t fsm_rounds;       /* state machine: rounds */
   int32_t dc_rounds;        /* dc_est: chain rounds */
-  int32_t dc_reruns;        /*   unit re-runs */
+  int32_t dc_reruns;        /*   piece re-runs */
   int32_t verified;         /* 1: accepted -- every piece's latest run is exact or proven: the sequential scan, bit for bit */
   int32_t gave_up;          /* != 0: the sequential scan ran instead (1 no trace could be cut, 2 / 3 / 4: avg_ampl / state
                              * machine / dc_est not settled within the round limit) */
   int32_t cuts_dropped;     /* cut points withdrawn because the state machine (or the dc ring) was not idle there */
   int32_t windows;          /* complete windows found */
+  int32_t dc_pieces;        /* pieces of the dc_est pass (>= units: a unit is cut again behind gate openings) */
 } rfid_ls_report;
 
 typedef struct rfid_ctx rfid_ctx;

@@ -56,6 +56,8 @@ def test_ls2_matches_oracle_and_avg_recurrence(emu_mod, oracle_mod, synth_mod):
     r = _check(emu_mod, oracle_mod, np.stack([t[:L] for t in ts]), expect_ok=1)
     c = r["ctl"]
     assert c["n_pieces"] >= 60 and c["n_units"] == c["n_heads"] >= 12 and c["n_windows"] == len(r["windows"])
+    # dc_est restarts behind gate openings too (at most one cut per piece): more pieces than units
+    assert c["n_units"] < c["n_dc_pieces"] <= c["n_pieces"], c
     del rng
 
 
@@ -63,12 +65,17 @@ def test_ls2_rerun_rounds_are_exercised(emu_mod, oracle_mod, synth_mod):
     """Noise of 8 % of the carrier makes dc_est pass close to powers of two inside pieces: some runs do not cover their
     true start and are repeated from it (dc_reruns > 0) -- the result is still the sequential scan."""
     t = synth_mod.make_trace(n_rounds=20, sigma=0.08, seed=9).samples
-    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1)
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, dc_fine=0)
     assert r["ctl"]["dc_reruns"] > 0 and r["ctl"]["dc_rounds"] >= 3, r["ctl"]
-    # a short pass enqueues few rounds to begin with (empty launches cost it most): here they do not suffice, the front
-    # end says so and the sequential scan gives the result -- the library then enqueues the full number from the next pass on
-    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=0, generous=False)
-    assert r["ctl"]["dc_count2"] > 0, r["ctl"]
+    # a short pass enqueues few rounds to begin with (empty launches cost it most) and cuts its units again behind the
+    # gate openings (its pace is its longest dc_est run): here that does not suffice -- a run of pieces that cross a
+    # binade settles one piece per round -- the front end says so and the sequential scan gives the result; the library
+    # then enqueues the full number of rounds and whole units from the next pass on
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=0, generous=False, dc_fine=-1)
+    assert r["ctl"]["dc_count2"] > 0 and r["ctl"]["n_dc_pieces"] > r["ctl"]["n_units"], r["ctl"]
+    # (cut behind the openings, all rounds: still more pieces in a row than rounds)
+    r = _check(emu_mod, oracle_mod, t[None, :], dc_fine=1)
+    assert r["ctl"]["n_dc_pieces"] > r["ctl"]["n_units"] and (r["ok"] or r["ctl"]["dc_count7"] > 0), r["ctl"]
     # few, long pieces: avg_ampl too
     r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, target=6)
     assert r["ctl"]["n_pieces"] <= 8 and r["ctl"]["avg_reruns"] > 0, r["ctl"]

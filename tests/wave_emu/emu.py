@@ -67,11 +67,11 @@ def batch_process(raw: np.ndarray, lens=None, fixed_q=0, max_num_queries=1000, n
 LS2_CTL_FIELDS = (["fail", "ok", "n_pieces", "n_heads"] + [f"avg_count{r}" for r in range(12)] + [f"avg_list{r}" for r in range(12)] + [f"fsm_count{r}" for r in range(12)] +
                   [f"dc_count{r}" for r in range(12)] +
                   ["avg_reruns", "fsm_reruns", "dc_reruns", "avg_rounds", "fsm_rounds", "dc_rounds", "n_units", "n_windows",
-                   "wb_clash"])
+                   "wb_clash", "n_dc_pieces"])
 
 
 def ls2_process(raw: np.ndarray, lens=None, fixed_q=0, max_num_queries=1000, number_unique_tags=100, min_piece=512,
-                target=131072, state=None, hold_last=False, cuts=None, y_skip=0, chain_slots=64, generous=True):
+                target=131072, state=None, hold_last=False, cuts=None, y_skip=0, chain_slots=64, generous=True, dc_fine=1):
     """batch_process() with the long-stream front end (rfid_ls2.hpp) in place of the sequential gate scan.
     -> dict(windows, results, scores, stats, ctl, ok[, consumed])"""
     raw = np.ascontiguousarray(raw, dtype=np.complex64)
@@ -107,7 +107,7 @@ def ls2_process(raw: np.ndarray, lens=None, fixed_q=0, max_num_queries=1000, num
         C.c_void_p(ctl.ctypes.data), nw,
         C.c_void_p(state.ctypes.data) if state is not None else None, 1 if hold_last else 0, C.c_void_p(consumed.ctypes.data),
         C.c_void_p(pcs.ctypes.data), len(pcs) - 1,
-        C.c_void_p(cuts_arr.ctypes.data) if cuts_arr is not None else None, 0 if cuts_arr is None else len(cuts_arr), int(y_skip), 1 if generous else 0)
+        C.c_void_p(cuts_arr.ctypes.data) if cuts_arr is not None else None, 0 if cuts_arr is None else len(cuts_arr), int(y_skip), 1 if generous else 0, int(dc_fine))
     k = n.value
     npc = int(np.argmax(pcs[:, 0] < 0)) if (pcs[:, 0] < 0).any() else len(pcs)
     return dict(windows=windows[:k], results=results[:k], scores=scores[:k], stats=stats, ok=int(ok),

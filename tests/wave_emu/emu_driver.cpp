@@ -205,7 +205,7 @@ int emu_ls2_process(const float *raw, int B, long stride, long n_raw, const int6
                     rfid_decode_result *results, rfid_scores *scores, long cap, long *n_windows,
                     rfid_stream_stats *stats, int min_piece, int target, int *ctl_out, int ctl_cap,
                     void *state_blob, int hold_last, int *consumed_out, int *pieces_out, int pieces_cap,
-                    const int *cuts, int n_cuts, int y_skip, int generous) {
+                    const int *cuts, int n_cuts, int y_skip, int generous, int dc_fine) {
   const long n_dec_all = n_raw / DECIM;
   const long n_dec = n_dec_all - y_skip;   // (y_skip: leading outputs that only exist to give the filter its history)
   long y_stride = (n_dec_all + 1) & ~1L;
@@ -257,7 +257,7 @@ int emu_ls2_process(const float *raw, int B, long stride, long n_raw, const int6
         if (J >= 1 && J < geo.max_bc && cuts[k] - J * geo.Pc < geo.Pc / 2) a.cut[J] = cuts[k];
       }
     }
-    ls2_enqueue(a, cuts == nullptr, nullptr, generous != 0);
+    ls2_enqueue(a, cuts == nullptr, nullptr, generous != 0, dc_fine);
     ctl_host = *a.ctl;
     ok = a.ctl->ok;
     if (consumed_out) consumed_out[0] = a.consumed[0];
@@ -269,8 +269,10 @@ int emu_ls2_process(const float *raw, int B, long stride, long n_raw, const int6
         const int h = a.fsm[i].unit;
         o[0] = i / geo.max_b; o[1] = a.piece[i].pos0; o[2] = a.piece[i].len;
         float f = ls2_from_ord(a.aT[i]); memcpy(&o[3], &f, 4);
-        f = ls2_from_ord(a.dT[2 * h]); memcpy(&o[4], &f, 4);
-        f = ls2_from_ord(a.dT[2 * h + 1]); memcpy(&o[5], &f, 4);
+        int hd = i;   // the dc_est piece of the last slot up to here that has one
+        while (hd != h && a.dend[hd] <= 0) hd = a.prevv[hd];
+        f = ls2_from_ord(a.dT[2 * hd]); memcpy(&o[4], &f, 4);
+        f = ls2_from_ord(a.dT[2 * hd + 1]); memcpy(&o[5], &f, 4);
         o[6] = h; o[7] = i;
       }
       if (k < pieces_cap) pieces_out[8 * k] = -1;
