@@ -1085,9 +1085,8 @@ struct LsCutArgs {
 
 // one wave per (trace, nominal boundary j): the first position p >= j*chunk whose a.quiet preceding samples all have
 // |y|^2 >= 0.72 of the largest |y|^2 seen in the look-back region (carrier, no reader command), or -1
-RFID_KERNEL(64) void ls_cut_kernel(LsCutArgs a) {
+RFID_DEVICE void ls_cut_body(const LsCutArgs &a, const int s, const int j) {
   const int lane = wv::lane_id();
-  const int s = (int)blockIdx.y, j = (int)blockIdx.x + 1;
   int64_t n64 = a.n_dec;
   if (a.lens) { int64_t r = a.lens[s]; if (r < 0) r = 0; n64 = r / DECIM; if (n64 > a.n_dec) n64 = a.n_dec; }
   const int n = (int)n64;
@@ -1125,6 +1124,15 @@ RFID_KERNEL(64) void ls_cut_kernel(LsCutArgs a) {
     run = lowmask ? __builtin_clzll(lowmask) : (run + 64);   // quiet samples at the end of the step
   }
   if (lane == 0) *out = found;
+}
+RFID_KERNEL(64) void ls_cut_kernel(LsCutArgs a) { ls_cut_body(a, (int)blockIdx.y, (int)blockIdx.x + 1); }
+// two searches in one launch (the long-stream front end looks for idle cuts on a coarse grid and for rest points on a
+// fine one): blockIdx.y < n_streams: a, else b
+struct LsCut2Args { LsCutArgs a, b; int n_streams; };
+RFID_KERNEL(64) void ls_cut2_kernel(LsCut2Args p) {
+  const int y = (int)blockIdx.y, j = (int)blockIdx.x + 1;
+  if (y < p.n_streams) { if (j < p.a.max_b) ls_cut_body(p.a, y, j); }
+  else if (j < p.b.max_b) ls_cut_body(p.b, y - p.n_streams, j);
 }
 
 // look-ahead of the per-block calls: ONE packet per whole-chain pass for the host -- the window count, the first n_hdr window

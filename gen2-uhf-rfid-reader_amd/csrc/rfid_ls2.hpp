@@ -322,11 +322,11 @@ RFID_KERNEL(256) void ls2_pieces_kernel(Ls2Args a) {
   if (lane == 0 && mh) wv::atomic_add(&a.ctl->n_heads, wv::popc64(mh));
 }
 
-// nothing to gain (no trace has an idle cut) -> the sequential scan; one thread
-RFID_KERNEL(64) void ls2_check_kernel(Ls2Args a) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  Ls2Ctl *c = a.ctl;
-  if (c->n_heads <= 0 || (!a.force && c->n_heads <= a.n_streams)) c->fail = 1;
+// nothing to gain (no trace has an idle cut) -> the sequential scan.  Known once ls2_pieces_kernel is through: the first
+// launch behind it looks (every wave for itself) and leaves the verdict in Ls2Ctl::fail for the launches that follow
+RFID_DEVICE bool ls2_nothing_to_gain(const Ls2Args &a) {
+  const int nh = wv::uniform(a.ctl->n_heads);
+  return nh <= 0 || (!a.force && nh <= a.n_streams);
 }
 
 // ---- 2. avg_ampl ---------------------------------------------------------------------------------------------------
@@ -497,9 +497,12 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
 }
 
 RFID_KERNEL(64) void ls2_avg_first_kernel(Ls2Args a) {
-  if (wv::uniform(a.ctl->fail) != 0) return;
-  const int NS = a.n_streams * a.max_b;
   const int lane = wv::lane_id();
+  if (ls2_nothing_to_gain(a)) {
+    if (blockIdx.x == 0 && lane == 0) a.ctl->fail = 1;
+    return;
+  }
+  const int NS = a.n_streams * a.max_b;
   for (int i = (int)blockIdx.x; i < NS; i += (int)gridDim.x) ls2_avg_piece<true>(a, i, lane);
 }
 RFID_KERNEL(64) void ls2_avg_rerun_kernel(Ls2Args a) {

@@ -105,17 +105,22 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
     if (g > 8192) g = 8192;
     LS2_LAUNCH(ls2_clear_kernel, (int)g, 1, 256, a);
   }
-  if (a.max_bc > 1 && search_cuts) {
-    LsCutArgs ca;
+  {
+    // idle cuts on the coarse grid (unless given: tests) and rest points on the fine one
+    LsCutArgs ca, cf;
     ca.y = a.y; ca.y_stride = a.y_stride; ca.lens = a.lens; ca.n_dec = a.n_dec; ca.chunk = a.Pc; ca.limit = a.Pc / 2;
     ca.max_b = a.max_bc; ca.cut = a.cut; ca.quiet = LS_QUIET;
-    LS2_LAUNCH(ls_cut_kernel, a.max_bc - 1, B, 64, ca);
-  }
-  {
-    LsCutArgs cf;
-    cf.y = a.y; cf.y_stride = a.y_stride; cf.lens = a.lens; cf.n_dec = a.n_dec; cf.chunk = a.P; cf.limit = a.P / 2;
-    cf.max_b = a.max_b; cf.cut = a.cutf; cf.quiet = LS2_REST;
-    LS2_LAUNCH(ls_cut_kernel, a.max_b - 1, B, 64, cf);
+    cf = ca;
+    cf.chunk = a.P; cf.limit = a.P / 2; cf.max_b = a.max_b; cf.cut = a.cutf; cf.quiet = LS2_REST;
+    const bool coarse = a.max_bc > 1 && search_cuts;
+    if (coarse && 2 * B <= 65535) {
+      LsCut2Args c2;
+      c2.a = ca; c2.b = cf; c2.n_streams = B;
+      LS2_LAUNCH(ls_cut2_kernel, a.max_b - 1, 2 * B, 64, c2);
+    } else {
+      if (coarse) LS2_LAUNCH(ls_cut_kernel, a.max_bc - 1, B, 64, ca);
+      LS2_LAUNCH(ls_cut_kernel, a.max_b - 1, B, 64, cf);
+    }
   }
   a.round = 0;
   a.stamp = 0;
@@ -129,7 +134,6 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
   // (test hook: dc_fine = 0 / 1 says so itself)
   a.dc_fine = (dc_fine < 0) ? (small ? 1 : 0) : dc_fine;
   LS2_LAUNCH(ls2_pieces_kernel, (NS + 255) / 256, 1, 256, a);
-  LS2_LAUNCH(ls2_check_kernel, 1, 1, 64, a);
   const int rerun_grid = NS;   // (one wave per list entry; the waves past the list return at once)
   // workgroups per trace of the chain kernels: a few thousand slots each
   auto chain_g = [](int slots) { const int per = ls2_chain_slots(); int g = (slots + per - 1) / per; return g < 1 ? 1 : (g > LS2_CHAIN_GMAX ? LS2_CHAIN_GMAX : g); };
