@@ -146,6 +146,7 @@ struct rfid_ctx {
     int emitted = 0;                  // samples of wins.front() already handed out (gate open)
     std::deque<Win> dq;               // windows handed out by the gate, waiting for the decoder (results only)
     int stall = 0;                    // gate calls in a row without progress and without new input
+    bool soft_done = false;           // ... and the held-back samples went through the sequential scan since the last input
     std::vector<float> last_m2;       // |.|^2 of what the last gate call wrote
     // scratch of one whole-chain pass
     DevBuf d_pack;                    // one packet per pass: count, window records, results, gated samples, |.|^2 (gated_windows_kernel)
@@ -1962,6 +1963,7 @@ int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int o
   }
   c->mf_seen += n_in;
   la.stall = 0;
+  la.soft_done = false;
   *n_produced = n_out;
   return RFID_OK;
 }
@@ -1980,7 +1982,7 @@ int la_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int
   const rfid_cf32 *y_first = la.y_at(p), *y_last = la.y_at(p + n_in - 1);
   if (!y_first || !y_last || !same_sample(in[0], *y_first) || !same_sample(in[n_in - 1], *y_last))
     return fail(c, RFID_ERR_STATE, "look-ahead: rfid_gate_work was not handed the matched filter's output at the gate's position");
-  for (int attempt = 0; attempt < 3; ++attempt) {
+  for (int attempt = 0; attempt < 4; ++attempt) {
     const int64_t frontier = io.raw_base / DECIM;   // the gate's doing is known for the samples before this position
     int consumed = 0, written = 0;
     bool open_after = false;
@@ -2011,22 +2013,28 @@ int la_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int
       consumed = (lim > p) ? (int)(lim - p) : 0;
     }
     if (consumed == 0 && written == 0 && !la.flushed) {
-      // nothing can be decided before more samples arrive.  The second such call in a row without new input: the
-      // stream has ended -- what is held back goes through now
-      if (++la.stall < 2) break;
-      if (io.pass.active) {
-        // (the last rfid_mf_work call's pass has not been looked at: the scheduler came back here instead of bringing
-        // more input)
+      // nothing can be decided before more samples arrive.  A scheduler may well ask again without bringing any (GNU
+      // Radio wakes a block when its downstream neighbour has consumed, or on a timer): asking never ends the stream.
+      ++la.stall;
+      if (la.stall >= 2 && io.pass.active) {
+        // the last rfid_mf_work call's pass has not been looked at: the scheduler came back here instead of bringing
+        // more input
         const int rc = sio_collect(c);
         if (rc) { io.failed = true; return rc; }
-        la.stall = 0;
         continue;
       }
-      la.want_yn = 0;
-      const int rc = (io.tail_len > 0) ? sio_process(c, io.cur, 0, true) : RFID_OK;
-      if (rc) { io.failed = true; return rc; }
-      la.flushed = true;   // (rfid_stream_work's flush: everything available is decided now)
-      continue;
+      if (la.stall >= 3 && !la.soft_done && io.tail_len / DECIM > 2 * (int64_t)EPC_WIN) {
+        // the input has paused: what is held back behind the last idle cut goes through the sequential scan, up to
+        // one EPC window before its end (a window that opens there is complete, rfid_stream_work's rule); the
+        // stream goes on from the carried state when input comes.  Once per pause.
+        la.soft_done = true;
+        la.want_yn = 0;
+        const int rc = sio_process(c, io.cur, 0, false);
+        if (rc) { io.failed = true; return rc; }
+        io.cur ^= 1;   // (what is still held back now sits in front of the other buffer's upload area)
+        continue;
+      }
+      break;
     }
     if (consumed > 0 || written > 0) la.stall = 0;
     // keep the state the window's last sample leaves: the dc ring etc. live on the device; here only what the blocks share
@@ -2053,6 +2061,24 @@ bool la_decoder_result(rfid_ctx *c, const rfid_cf32 *in, int wlen, int type, rfi
 }  // namespace
 
 extern "C" {
+
+int rfid_lookahead_flush(rfid_ctx *c) {
+  if (!c) return RFID_ERR_INVALID;
+  rfid_ctx::StreamIO &io = c->sio;
+  rfid_ctx::LookAhead &la = c->la;
+  if (!la.on || la.flushed) return RFID_OK;   // (without look-ahead nothing is held back)
+  if (!io.open || io.failed) return fail(c, RFID_ERR_STATE, "rfid_lookahead_flush: the stream has failed or was closed");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = sio_collect(c);
+  if (!rc && io.tail_len > 0) {
+    la.want_yn = 0;
+    rc = sio_process(c, io.cur, 0, true);   // rfid_stream_work's flush: everything available is decided now
+  }
+  if (rc) { io.failed = true; return rc; }
+  la.flushed = true;
+  la.stall = 0;
+  return RFID_OK;
+}
 
 int rfid_lookahead_enable(rfid_ctx *c, int64_t max_chunk_raw) {
   if (!c || max_chunk_raw < 1) return RFID_ERR_INVALID;

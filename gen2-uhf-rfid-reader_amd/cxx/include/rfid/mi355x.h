@@ -69,6 +69,7 @@ class RFID_BLOCK_API sts_flowgraph {
   int d_chunk;
   long d_windows = 0;
   int d_idle_calls = 0;
+  bool d_flushed = false;
   bool d_keep_tx = false, d_keep_taps = false;
   std::vector<float> d_tx, d_txbuf, d_bits;
   std::vector<gr_complex> d_tap_mf, d_tap_gate;

@@ -322,9 +322,14 @@ void sts_flowgraph::run(const gr_complex *samples, size_t n) {
         reader_until_idle(d_dec->minirt_produced(0));
       }
       if (consumed == 0 && written == 0) {
-        // the gate can decide nothing on what it has: more input first (at the end of the stream it is simply asked again:
-        // with the library's look-ahead the second such call in a row flushes what is held back)
+        // the gate can decide nothing on what it has: more input first.  At the end of the input the library is told so
+        // (with its look-ahead on, what it still holds back is decided then), and the gate asked again
         if (pos < n) break;
+        if (!d_flushed) {
+          d_flushed = true;
+          if (rfid_ctx *ctx = current_context()) (void)rfid_lookahead_flush(ctx);
+          continue;
+        }
         if (++d_idle_calls > 4) { g_rd = gq.size(); break; }
       } else {
         d_idle_calls = 0;

@@ -131,6 +131,10 @@ class Context:
         """The per-block calls (mf_work / gate_work / decoder_work) answered from one whole-chain pass per mf_work call."""
         self._chk(self._lib.rfid_lookahead_enable(self._h, int(max_chunk_raw)))
 
+    def lookahead_flush(self) -> None:
+        """End of the input: what the look-ahead still holds back is decided now (the gate / decoder calls hand it out)."""
+        self._chk(self._lib.rfid_lookahead_flush(self._h))
+
     def stream_begin(self, max_chunk_raw: int) -> None:
         self._chk(self._lib.rfid_stream_begin(self._h, int(max_chunk_raw)))
         self._stream_cap = 4096

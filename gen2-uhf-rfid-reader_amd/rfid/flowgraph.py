@@ -57,15 +57,18 @@ class reader_top_block:
         gq = np.zeros(0, dtype=np.complex64)          # gate input buffer
         pos = 0
         n = len(self.samples)
+        flushed = False
         while pos < n or len(gq):
             if pos < n:
                 blk = self.samples[pos:pos + self.chunk * self.decim]
                 pos += len(blk)
                 y = self.matched_filter.work(blk)
                 gq = np.concatenate([gq, y]) if len(gq) else y
+            progressed = False
             while len(gq):
                 take = gq[: self.chunk]
                 consumed, out = self.gate.general_work(take)
+                progressed = progressed or consumed > 0 or len(out) > 0
                 gq = gq[consumed:]
                 if len(out):
                     dq = np.concatenate([dq, out]) if len(dq) else out
@@ -78,8 +81,12 @@ class reader_top_block:
                     self._reader_until_idle(len(bits))
                 if consumed == 0:
                     break
-            if pos >= n and not len(gq):
-                break
+            if pos >= n:
+                if not len(gq) or (flushed and not progressed):
+                    break
+                if not flushed:
+                    self.ctx.lookahead_flush()       # the source has run dry: what the look-ahead holds back is decided now
+                    flushed = True
 
     def start(self) -> None:          # gr.top_block.start() analogue (apps/reader.py:123)
         self.run()

@@ -201,11 +201,18 @@ RFID_API int rfid_decoder_work(rfid_ctx *ctx, const rfid_cf32 *in, int n_in, flo
  * call are compared; anything else is RFID_ERR_STATE), with the same consume / produce counts, outputs and READER_STATE
  * transitions as without it (lib/gate_impl.cc:189-199, lib/tag_decoder_impl.cc:223,266,289,393-396).  The window types
  * are those of the reference's own control flow (RN16, EPC, RN16, ...: after an RN16 the reader always ACKs).
+ * The pass of a rfid_mf_work call stays on the device when the call returns (it waits for its own filter outputs only)
+ * and is looked at by the next rfid_mf_work call -- or by the second gate call in a row that could decide nothing.
  * What lies behind the last idle point of the gate in the samples seen so far is not decided yet: a gate call consumes
- * up to there and no further; two gate calls in a row that can make no progress without new input mean the stream has
- * ended and flush what is left.  max_chunk_raw: the largest n_in rfid_mf_work will see.  Call before the
- * first sample; rfid_ctx_reset switches it off. */
+ * up to there and no further, and returns (0 consumed, 0 written) when it can decide nothing -- as often as it is asked
+ * (asking never ends the stream; when the input pauses, the third such call puts what is held back through the
+ * sequential scan, up to one EPC window before its end).  max_chunk_raw: the largest n_in rfid_mf_work will see.  Call
+ * before the first sample; rfid_ctx_reset switches it off. */
 RFID_API int rfid_lookahead_enable(rfid_ctx *ctx, int64_t max_chunk_raw);
+/* End of the input (a file source has run dry): everything still held back is decided now; the gate / decoder / reader
+ * calls that follow hand it out.  rfid_mf_work fails with RFID_ERR_STATE afterwards.  No-op without look-ahead.  A
+ * flowgraph that never calls it leaves the last <= 20 ms of signal undecided. */
+RFID_API int rfid_lookahead_flush(rfid_ctx *ctx);
 /* Page-locked host memory (nullptr on failure): samples handed to rfid_mf_work (look-ahead) / rfid_stream_work from such
  * memory -- or from any memory the caller page-locked himself -- go to the device without the staging copy. */
 RFID_API void *rfid_host_alloc(size_t bytes);

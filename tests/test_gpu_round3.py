@@ -202,3 +202,66 @@ def test_short_passes_start_with_few_rounds_and_escalate(oracle_mod, synth_mod):
             assert reps[0]["gave_up"] in (2, 3, 4), reps[0]
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_look_ahead_with_ragged_scheduler_calls(oracle_mod, synth_mod, seed):
+    """The per-block calls with look-ahead, driven like a scheduler whose buffers never have the same fill twice: filter
+    calls of 1 000 .. 150 000 raw samples, gate calls handed 50 .. 30 000 items of what is available, the gate asked again
+    at random although it just said it can decide nothing (which makes it collect the pending pass and, the third time,
+    put the held-back samples through the sequential scan -- never end the stream); at the end of the input the library
+    is told so (rfid_lookahead_flush).  Every decoded window, the statistics and the report equal the oracle's."""
+    import rfid
+    rng = np.random.default_rng(seed)
+    t = synth_mod.make_trace(n_rounds=40, seed=20 + seed, sigma=0.01, fixed_q=1, tag_ids=(0x11, 0x2A), t1_jitter_raw=4,
+                             corrupt_rounds=(7,)).samples
+    o = oracle_mod.run_trace(t, oracle_mod.config(fixed_q=1))
+    tb = rfid.reader_top_block(samples=t, chunk=30000, lookahead=True, fixed_q=1)
+    try:
+        tb._reader_until_idle(0)
+        gq = np.zeros(0, dtype=np.complex64)
+        dq = np.zeros(0, dtype=np.complex64)
+        pos, n, idle, flushed = 0, len(t), 0, False
+        while pos < n or len(gq):
+            if pos < n:
+                blk = t[pos:pos + int(rng.integers(1000, 150001))]
+                pos += len(blk)
+                y = tb.matched_filter.work(blk)
+                gq = np.concatenate([gq, y]) if len(gq) else y
+            while len(gq):
+                take = gq[: int(rng.integers(50, 30001))]
+                consumed, out = tb.gate.general_work(take)
+                gq = gq[consumed:]
+                if len(out):
+                    dq = np.concatenate([dq, out]) if len(dq) else out
+                while True:
+                    dcons, bits, res, sc = tb.tag_decoder.general_work(dq)
+                    if dcons == 0:
+                        break
+                    tb.decoded.append((res, sc))
+                    dq = dq[dcons:]
+                    tb._reader_until_idle(len(bits))
+                if consumed == 0 and len(out) == 0:
+                    if pos < n:
+                        if rng.random() < 0.6:
+                            break                   # back to the source, as a scheduler does
+                        idle += 1                   # ... or ask again all the same: that must not end the stream
+                        if idle > 6:
+                            idle = 0
+                            break
+                    elif not flushed:
+                        tb.ctx.lookahead_flush()    # the source has run dry
+                        flushed = True
+                    else:
+                        gq = gq[:0]                 # (what is left lies behind the last window: the gate swallowed it)
+                else:
+                    idle = 0
+        assert tb.ctx.stats() == o.stats()
+        assert tb.ctx.print_results() == o.print_results()
+        assert len(tb.decoded) == o.n_windows
+        for (res, sc), d in zip(tb.decoded, o.dumps):
+            assert res["n_bits"] == d["n_bits"] and res["crc_ok"] == d["crc_ok"] and res["index"] == d["index"]
+            assert np.array_equal(rfid.unpack_bits(res["bits"], int(d["n_bits"])), d["bits"][: d["n_bits"]])
+    finally:
+        tb.ctx.close()
