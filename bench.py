@@ -33,7 +33,8 @@ sys.path.insert(0, os.path.join(ROOT, "gen2-uhf-rfid-reader_amd"))
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
+HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s) -- `frac` is priced against this
+HBM_ACHIEVABLE_GBS = 6300.0   # what a plain streaming kernel reaches on this part (same guide) -- `frac_of_achievable`
 RN16_WIN, EPC_WIN = 250, 1370
 PER_WINDOW_WS = 24 * 3 + 48 + 144      # window table + two compact lists + result + scores (bytes)
 
@@ -226,95 +227,10 @@ def streaming_leg(torch, rfid, wl, args, device):
         ctx.close()
 
 
-def spawn_ranks(n: int) -> int:
-    """`python bench.py --gpus N` without a launcher: re-execute this script once per GPU (RANK / LOCAL_RANK /
-    WORLD_SIZE / MASTER_* as torch.distributed.run would set them), rank 0's stdout -- the one JSON line -- passed
-    through.  Returns the worst exit code."""
-    import socket
-    import subprocess
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=os.environ.get("MASTER_PORT", str(port)), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
-    return rc
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None)
-    ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", default="1", choices=["1", "2", "3stream", "4shard"])
-    ap.add_argument("--streams", type=int, default=None, help="traces per GPU (configs 1 / 4shard)")
-    ap.add_argument("--rounds", type=int, default=None, help="inventory rounds of the single trace (configs 2 / 3stream)")
-    ap.add_argument("--tags", type=int, default=8, help="tags in the field (config 2)")
-    ap.add_argument("--hbm-frac", type=float, default=0.90, help="4shard: fraction of the free HBM to fill")
-    ap.add_argument("--sigma", type=float, default=0.002)
-    ap.add_argument("--seed", type=int, default=1000)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-stream-leg", action="store_true")
-    ap.add_argument("--stream-replicas", type=int, default=160, help="replicas concatenated into the host-resident stream")
-    ap.add_argument("--stream-chunk", type=int, default=32_000_000, help="raw samples per rfid_stream_work call")
-    args = ap.parse_args()
-    if args.steps is None:
-        args.steps = 10 if args.config in ("1", "3stream") else 3
-    if args.warmup is None:
-        args.warmup = 2 if args.config in ("1", "3stream") else 1
-
-    if args.gpus > 1 and "RANK" not in os.environ:
-        raise SystemExit(spawn_ranks(args.gpus))     # plain `python bench.py --gpus N`: start the N ranks ourselves
-
-    import torch
-    import rfid
-    from rfid import synth
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the receive path has no CPU fallback")
-    if args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # one process per GPU.  (RFID_BENCH_SHARE_DEVICES=1 + RFID_BENCH_BACKEND=gloo: several ranks on the devices at hand -- the
-    # multi-rank path on a one-GPU box; RCCL itself refuses two ranks per device.)
-    n_dev = torch.cuda.device_count()
-    dev_index = local_rank % n_dev if os.environ.get("RFID_BENCH_SHARE_DEVICES") else local_rank
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
-    dist = None
-    backend = os.environ.get("RFID_BENCH_BACKEND", "nccl")
-    if world > 1 or os.environ.get("RFID_BENCH_FORCE_DIST"):   # (the env var lets a 1-GPU box exercise the RCCL path)
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    ctl_device = device if backend == "nccl" else torch.device("cpu")   # where the control-plane tensors live
-    n_gpus = world
-
-    if args.config == "1":
-        wl = workload_replicas(torch, rfid, synth, args, device, rank, args.streams or 1024, "configs[1]")
-    elif args.config == "4shard":
-        B = args.streams
-        if B is None:
-            free, _ = torch.cuda.mem_get_info(device)
-            L0 = 1076066
-            per_trace = 8 * (L0 + 2) + 8 * (L0 // 5 + 2) + (L0 // 5 // 347 + 2) * PER_WINDOW_WS + 1056 + 1016
-            B = max(1, int(free * args.hbm_frac / per_trace))
-        wl = workload_replicas(torch, rfid, synth, args, device, rank, B, "configs[4], the per-GPU shard")
-    elif args.config == "2":
-        wl = workload_single_trace(torch, rfid, synth, args, device, rank, 4, args.rounds or 10000, args.tags, "configs[2]")
-    else:
-        wl = workload_single_trace(torch, rfid, synth, args, device, rank, 0, args.rounds or 2000, 1,
-                                   "configs[3], the per-GPU workload")
+def measure(torch, wl, steps, warmup, barrier, gather_elapsed=None, n_series=None):
+    """`warmup` untimed passes, then exactly `steps` timed passes of the workload's whole chain (bracketed by
+    `barrier()`), then an untimed series of the same passes read out through HIP events per kernel.
+    -> dict(elapsed, step_s, k_ms, k_min, k_med, alg, key, n_launch, rep, st, parity_ok, parity_text, roof, ...)"""
     ctx, data, stride, L, B = wl["ctx"], wl["data"], wl["stride"], wl["L"], wl["B"]
     ctx.batch_plan(B, L)
     ptr = data.data_ptr()
@@ -323,38 +239,38 @@ def main():
         ctx.batch_process_ptr(ptr, stride, L, 0, want_scores=False)
         ctx.batch_sync()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # ---- the timed region: exactly `steps` passes, nothing else ----------------------------------
-    step_s = []
+    # ---- the timed region: exactly `steps` passes, nothing else.  The passes are enqueued back to back and waited for
+    #      once (the library runs a pass's decoder + statistics beside the next pass's front end when the device has room
+    #      for a second set of result tables -- as a caller with batch after batch would have it); every pass is complete,
+    #      its results included, when the region ends ----------------------------------------------------------
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
+        ctx.batch_process_ptr(ptr, stride, L, 0, want_scores=False)
+    ctx.batch_sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # one pass at a time (submitted and waited for): the spread over passes, outside the timed region
+    step_s = []
+    for _ in range(max(3, min(steps, 10))):
         ts = time.perf_counter()
         step()
         step_s.append(time.perf_counter() - ts)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ms_by_rank = [1e3 * elapsed / args.steps]
-    if dist is not None:
-        mine = torch.tensor([elapsed], dtype=torch.float64, device=ctl_device)
-        every = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine)                  # control plane only: every rank's time; the job's = the slowest
-        ms_by_rank = [1e3 * float(t.item()) / args.steps for t in every]
-        elapsed = max(float(t.item()) for t in every)
+    ms_by_rank = [1e3 * elapsed / steps]
+    if gather_elapsed is not None:
+        every = gather_elapsed(elapsed)               # control plane only: every rank's time; the job's = the slowest
+        ms_by_rank = [1e3 * t / steps for t in every]
+        elapsed = max(every)
 
     # ---- kernel durations: HIP events on the ctx stream around each launch, read in a separate (untimed)
     #      series of the same passes so that the event reads stay out of the timed region -----------------
     k_series = {"mf_ms": [], "gate_ms": [], "decode_ms": [], "stats_ms": [], "front_ms": []}
     launches = {"front_chunks": 1, "decode_launches": 2}
     fused = False
-    for _ in range(max(3, min(args.steps, 20))):
+    for _ in range(n_series if n_series is not None else max(3, min(steps, 20))):
         step()
         t = ctx.batch_timing()
         for k in k_series:
@@ -414,13 +330,181 @@ def main():
         ach = alg[name] / (dur * 1e-3) / 1e9 if dur > 0 else 0.0
         tr = traffic.get(name)
         return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": (int(tr / nl) if tr else None),
+                "frac": round(ach / HBM_PEAK_GBS, 4),
+                "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": round(ach / HBM_ACHIEVABLE_GBS, 4),
+                "traffic": (int(tr / nl) if tr else None),
                 "traffic_source": traffic_source if tr else None,
                 "algorithmic_bytes": int(alg[name] / nl), "launches_per_step": nl,
                 "avg_launch_ms": round(dur / nl, 4), "ms_per_step": round(dur, 4),
                 "min_ms_per_step": round(k_min[key[name]], 4), "median_ms_per_step": round(k_med[key[name]], 4),
                 "timing": "HIP events on the library's stream around each launch, %d untimed passes after the timed region"
                           % len(k_series["gate_ms"])}
+
+    return dict(elapsed=elapsed, step_s=step_s, ms_by_rank=ms_by_rank, k_ms=k_ms, alg=alg, key=key, roof=roof, rep=rep, st=st,
+                n_epc_ok=n_epc_ok, n_windows=n_windows, n_rn16=n_rn16, n_epc=n_epc, parity_ok=parity_ok, parity_text=parity_text)
+
+
+def other_configs(torch, rfid, synth, args, device, rank):
+    """configs[3] (per-GPU stream: one RX stream, 2 000 rounds) and configs[2] (one FIXED_Q=4 trace of 10 000 rounds, 17.6 GB;
+    only when >= 40 GB of HBM are free) measured like the headline -- untimed warm-up, a few timed passes, the per-kernel
+    series, the workload's result check -- and reported compactly."""
+    import copy
+    res = {}
+    specs = [("configs[3] per GPU", dict(fixed_q=0, n_rounds=2000, n_tags=1, steps=10, warmup=2))]
+    free, _ = torch.cuda.mem_get_info(device)
+    if free >= 40e9:
+        specs.append(("configs[2]", dict(fixed_q=4, n_rounds=10000, n_tags=8, steps=3, warmup=1)))
+    else:
+        res["configs[2]"] = {"skipped": "%.0f GB of HBM free, 40 needed" % (free / 1e9)}
+    for name, sp in specs:
+        a = copy.copy(args)
+        t0 = time.perf_counter()
+        try:
+            wl = workload_single_trace(torch, rfid, synth, a, device, rank, sp["fixed_q"], sp["n_rounds"], sp["n_tags"], name)
+        except Exception as e:      # (a full device: the headline line must still be printed)
+            res[name] = {"skipped": "workload not built: %r" % (e,)}
+            continue
+        try:
+            m = measure(torch, wl, sp["steps"], sp["warmup"], torch.cuda.synchronize, None, n_series=3)
+            el = m["elapsed"] / sp["steps"]
+            entry = {"workload": wl["describe"], "steps": sp["steps"], "warmup": sp["warmup"],
+                     "ms_per_step": round(1e3 * el, 4), "value": round(wl["L"] / el / 1e6, 2), "unit": "Msamples/s",
+                     "epc_decodes_per_s": round(m["n_epc_ok"] / el, 1), "windows_per_step": m["n_windows"],
+                     "parity_check": m["parity_text"],
+                     "roofline_by_kernel": {k: {f: m["roof"](k)[f] for f in ("ms_per_step", "achieved", "frac", "frac_of_achievable",
+                                                                             "algorithmic_bytes")} for k in m["alg"]},
+                     "setup_s": round(time.perf_counter() - t0, 2)}
+            if m["rep"]["pieces"]:
+                entry["long_stream"] = {k: m["rep"][k] for k in ("pieces", "units", "avg_rounds", "dc_rounds", "verified", "gave_up")
+                                        if k in m["rep"]}
+            if not m["parity_ok"]:
+                entry["FAILED"] = True
+            res[name] = entry
+        finally:
+            wl["ctx"].close()
+            del wl
+            torch.cuda.empty_cache()
+    return res
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-execute this script once per GPU (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* as torch.distributed.run would set them), rank 0's stdout -- the one JSON line -- passed
+    through.  Returns the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=os.environ.get("MASTER_PORT", str(port)), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="1", choices=["1", "2", "3stream", "4shard"])
+    ap.add_argument("--streams", type=int, default=None, help="traces per GPU (configs 1 / 4shard)")
+    ap.add_argument("--rounds", type=int, default=None, help="inventory rounds of the single trace (configs 2 / 3stream)")
+    ap.add_argument("--tags", type=int, default=8, help="tags in the field (config 2)")
+    ap.add_argument("--hbm-frac", type=float, default=0.90, help="4shard: fraction of the free HBM to fill")
+    ap.add_argument("--sigma", type=float, default=0.002)
+    ap.add_argument("--seed", type=int, default=1000)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stream-leg", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short configs[2] / configs[3] measurements")
+    ap.add_argument("--stream-replicas", type=int, default=160, help="replicas concatenated into the host-resident stream")
+    ap.add_argument("--stream-chunk", type=int, default=32_000_000, help="raw samples per rfid_stream_work call")
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 10 if args.config in ("1", "3stream") else 3
+    if args.warmup is None:
+        args.warmup = 2 if args.config in ("1", "3stream") else 1
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))     # plain `python bench.py --gpus N`: start the N ranks ourselves
+
+    import torch
+    import rfid
+    from rfid import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the receive path has no CPU fallback")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # one process per GPU.  (RFID_BENCH_SHARE_DEVICES=1 + RFID_BENCH_BACKEND=gloo: several ranks on the devices at hand -- the
+    # multi-rank path on a one-GPU box; RCCL itself refuses two ranks per device.)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % n_dev if os.environ.get("RFID_BENCH_SHARE_DEVICES") else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    dist = None
+    backend = os.environ.get("RFID_BENCH_BACKEND", "nccl")
+    if world > 1 or os.environ.get("RFID_BENCH_FORCE_DIST"):   # (the env var lets a 1-GPU box exercise the RCCL path)
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    ctl_device = device if backend == "nccl" else torch.device("cpu")   # where the control-plane tensors live
+    n_gpus = world
+
+    if args.config == "1":
+        wl = workload_replicas(torch, rfid, synth, args, device, rank, args.streams or 1024, "configs[1]")
+    elif args.config == "4shard":
+        B = args.streams
+        if B is None:
+            free, _ = torch.cuda.mem_get_info(device)
+            L0 = 1076066
+            per_trace = 8 * (L0 + 2) + 8 * (L0 // 5 + 2) + (L0 // 5 // 347 + 2) * PER_WINDOW_WS + 1056 + 1016
+            B = max(1, int(free * args.hbm_frac / per_trace))
+        wl = workload_replicas(torch, rfid, synth, args, device, rank, B, "configs[4], the per-GPU shard")
+    elif args.config == "2":
+        wl = workload_single_trace(torch, rfid, synth, args, device, rank, 4, args.rounds or 10000, args.tags, "configs[2]")
+    else:
+        wl = workload_single_trace(torch, rfid, synth, args, device, rank, 0, args.rounds or 2000, 1,
+                                   "configs[3], the per-GPU workload")
+    ctx, data, stride, L, B = wl["ctx"], wl["data"], wl["stride"], wl["L"], wl["B"]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def gather_elapsed(elapsed):
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=ctl_device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        return [float(t.item()) for t in every]
+
+    m = measure(torch, wl, args.steps, args.warmup, barrier, gather_elapsed if dist is not None else None)
+    elapsed, step_s, k_ms, alg, key, roof, rep = m["elapsed"], m["step_s"], m["k_ms"], m["alg"], m["key"], m["roof"], m["rep"]
+    n_epc_ok, n_windows, n_rn16, n_epc = m["n_epc_ok"], m["n_windows"], m["n_rn16"], m["n_epc"]
+    parity_ok, parity_text = m["parity_ok"], m["parity_text"]
+
+    # every rank's check and device, gathered over the control plane: the job fails if ANY rank's results are wrong
+    dev_name = torch.cuda.get_device_name(device)
+    devices = ["%s (cuda:%d)" % (dev_name, dev_index)]
+    parity_by_rank = [parity_text]
+    if dist is not None:
+        got = [None] * world
+        dist.all_gather_object(got, {"device": devices[0], "parity": parity_text, "ok": bool(parity_ok)})
+        devices = [g["device"] for g in got]
+        parity_by_rank = [g["parity"] for g in got]
+        parity_ok = all(g["ok"] for g in got)
 
     dominant = max(alg, key=lambda k: k_ms[key[k]])
     total_raw = float(B) * L * args.steps * n_gpus
@@ -430,7 +514,8 @@ def main():
         "unit": "Msamples/s",
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "min_ms_per_step": round(min(step_s) * 1e3, 4), "median_ms_per_step": round(statistics.median(step_s) * 1e3, 4),
+        "single_pass_ms": {"min": round(min(step_s) * 1e3, 4), "median": round(statistics.median(step_s) * 1e3, 4),
+                           "note": "one pass submitted and waited for at a time (no overlap between passes), outside the timed region"},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl["describe"], "streams_per_gpu": B, "raw_samples_per_stream": L,
@@ -440,11 +525,15 @@ def main():
         "decoder_gated_msamples_per_s": round((n_rn16 * RN16_WIN + n_epc * EPC_WIN) / (k_ms["decode_ms"] * 1e-3) / 1e6, 1)
         if k_ms["decode_ms"] > 0 else None,
         "windows_per_step": n_windows,
-        "parity_check": parity_text,
+        "parity_check": parity_text if all(t == parity_text for t in parity_by_rank) else
+                        "; ".join("rank %d: %s" % (r, t) for r, t in enumerate(parity_by_rank)),
         "roofline": roof(dominant),
         "roofline_by_kernel": {k: roof(k) for k in alg},
         "front_end_ms": round(k_ms["front_ms"], 4),
-        "ms_per_step_by_rank": [round(v, 4) for v in ms_by_rank],
+        "ms_per_step_by_rank": [round(v, 4) for v in m["ms_by_rank"]],
+        "devices_by_rank": devices,
+        "control_plane": ("torch.distributed/%s: barrier + all_gather of the ranks' times and checks" % backend) if dist is not None
+                         else "single process",
     }
     if rep["pieces"]:
         out["long_stream"] = dict(rep, note="traces cut along time into pieces processed at once (avg_ampl, state machine, dc_est) "
@@ -456,6 +545,10 @@ def main():
                                 "x_realtime_at_2Msps": round(L / (elapsed / args.steps) / 2e6, 1)}
     if rank == 0 and args.config == "1" and not args.no_stream_leg:
         out["streaming"] = streaming_leg(torch, rfid, wl, args, device)
+    if rank == 0 and args.config == "1" and not args.no_other_configs:
+        # the other single-GPU BASELINE configurations, each a short measurement of its own OUTSIDE the headline's timed
+        # region (rank 0's GPU only): configs[3]'s per-GPU stream always, configs[2] when the device has room for it
+        out["other_configs"] = other_configs(torch, rfid, synth, args, device, rank)
     if rank == 0 and not args.no_cpu_baseline:
         # rank 0 only (N = 1 and N > 1 alike): the same host serves all ranks
         x, what = wl["sample"]()
@@ -469,6 +562,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if not parity_ok:
+        sys.stderr.write("bench.py: result check FAILED: %s\n" % "; ".join("rank %d: %s" % (r, t) for r, t in enumerate(parity_by_rank)))
         raise SystemExit(2)
 
 

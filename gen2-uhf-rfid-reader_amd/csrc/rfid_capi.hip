@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <ctime>
+#include <pthread.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -67,10 +68,15 @@ struct rfid_ctx {
   bool ls2_generous = false;      // a pass ran out of rounds once: the launch lists hold the full number of rounds from then on
   int ls_mode = 1;                // 0 never, 1 automatic, 2 whenever a trace can be cut
   double ls_fixed_ms = 0.45, ls_ns_per_sample = 0.03, seq_ns_per_sample = 10.2;   // cost model of the automatic choice (ls_calibrate)
+  bool ls_calibrated = false;     // the three numbers were measured on this device (or that was tried, or is not wanted)
   // whole-chain streaming (rfid_stream_*)
   struct StreamIO {
     bool open = false;
     bool failed = false;          // a call failed half-way: the stream has to be begun again
+    bool ymode = false;           // the stream's samples are matched-filter OUTPUTS (400 ksps): the look-ahead keyed on the gate's
+                                  // input, for a flowgraph whose filter is not this library's; d_buf then holds y, no filter runs
+    int dec() const { return ymode ? 1 : DECIM; }          // stream samples per decimated sample
+    int hist() const { return ymode ? 0 : 28; }            // stream samples kept in front of the held-back tail (SIO_HIST)
     int64_t max_chunk = 0, tail_max = 0;
     float2 *d_buf[2] = {nullptr, nullptr};
     rfid_cf32 *h_pin[2] = {nullptr, nullptr};
@@ -92,6 +98,8 @@ struct rfid_ctx {
       int64_t n_have = 0, n_out = 0;
       bool flush = false;
       bool enq = false;           // the long-stream front end was enqueued
+      bool small = false;         // a short pass: the sequential scan over [0, seq_end) was enqueued instead (no launch list)
+      int64_t seq_end = 0;
       bool prefetched = false;    // (look-ahead) decoder + window packet were enqueued behind it, assuming it succeeds
       int n_hdr = 0, usual = 0;   //   ... with these packet sizes
     } pass;
@@ -120,6 +128,7 @@ struct rfid_ctx {
     };
     bool on = false, flushed = false;
     int64_t gate_pos = 0;             // decimated samples the gate calls have consumed
+    int64_t up_end = 0;               // (gate-keyed) global position behind the last sample uploaded
     // matched-filter output handed out and not (all) consumed by the gate yet: one block per rfid_mf_work call
     struct YBlk { int64_t y0 = 0; std::vector<rfid_cf32> v; };
     std::deque<YBlk> yq;
@@ -170,6 +179,8 @@ struct rfid_ctx {
   int B_plan = 0;   // traces the workspace was planned for; 0 = no plan
   int64_t max_raw = 0, y_stride = 0;
   float2 *d_y = nullptr;
+  float2 *y_view = nullptr;       // (ymode stream) where the current pass's decimated samples lie instead of d_y
+  float2 *y() const { return y_view ? y_view : d_y; }
   GateState *d_gstate = nullptr;
   rfid_window *d_wtab = nullptr, *d_flat = nullptr;
   int wmax = 0, flat_cap = 0;
@@ -188,6 +199,22 @@ struct rfid_ctx {
   static const int MAX_CHUNKS = 16;
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_mf[MAX_CHUNKS + 1], ev_gate[2 * MAX_CHUNKS], ev_pass = nullptr, ev_front_end = nullptr;
+  // Decoder + statistics of pass k beside the front end of pass k + 1 (rfid_batch_process, fused front end): a second set
+  // of everything the front end writes and the decoder reads (the matched-filter output and the window / result tables), used
+  // alternately; the decoder and the statistics kernel of a pass run on stream2 behind that pass's front end.  Allocated by
+  // rfid_batch_plan when the device has the room (RFID_OVERLAP=0: never).
+  struct ResultSet {
+    float2 *d_y = nullptr;
+    rfid_window *d_wtab = nullptr, *d_flat = nullptr;
+    int *d_wcount = nullptr, *d_flat_count = nullptr;
+    rfid_decode_result *d_res = nullptr;
+    rfid_stream_stats *d_stats = nullptr;
+  } alt;
+  bool alt_have = false;
+  hipEvent_t ev_fe_done = nullptr, ev_tail_done[2] = {nullptr, nullptr};
+  bool tail_recorded[2] = {false, false};   // ev_tail_done[i] has been recorded (set i's decoder / statistics were enqueued on stream2)
+  int set_idx = 0;                          // which of the two sets c->d_* currently name
+  hipStream_t tail_stream = nullptr;        // where rfid_batch_decode / rfid_batch_stats enqueue (c->stream, or stream2 in an overlapped pass)
   int n_chunks_last = 0;   // > 0 when the last pass used the overlapped path
   int fused_last = 0;      // 1 when the last rfid_batch_process pass used front_end_fused_kernel
   float front_ms = 0.0f;
@@ -279,8 +306,26 @@ void free_plan(rfid_ctx *c) {
   c->d_y = nullptr; c->d_gstate = nullptr; c->d_wtab = nullptr; c->d_flat = nullptr;
   c->d_wcount = nullptr; c->d_flat_count = nullptr; c->d_res = nullptr; c->d_scores = nullptr;
   c->d_stats = nullptr;
+  void *aptrs[] = {c->alt.d_y, c->alt.d_wtab, c->alt.d_flat, c->alt.d_wcount, c->alt.d_flat_count, c->alt.d_res, c->alt.d_stats};
+  for (void *p : aptrs)
+    if (p) (void)hipFree(p);
+  c->alt = rfid_ctx::ResultSet();
+  c->alt_have = false;
+  c->tail_recorded[0] = c->tail_recorded[1] = false;
+  c->set_idx = 0;
   c->B = 0;
   c->B_plan = 0;
+}
+
+// every pass that is not itself an overlapped one, and every look at the results, first lets the context's main stream wait
+// for what overlapped passes left on stream2
+int join_tails(rfid_ctx *c) {
+  for (int i = 0; i < 2; ++i)
+    if (c->tail_recorded[i]) {
+      if (hipStreamWaitEvent(c->stream, c->ev_tail_done[i], 0) != hipSuccess) return RFID_ERR_HIP;
+      c->tail_recorded[i] = false;
+    }
+  return RFID_OK;
 }
 
 // slot/round roll-over of tag_decoder_impl.cc:330-343 / :369-383 (and :269-288)
@@ -310,15 +355,31 @@ double ls_now_ms() {
 // seq_ns_per_sample per decimated sample of the LONGEST trace; the long-stream front end costs a fixed string of short
 // launches plus ls_ns_per_sample per decimated sample of ALL traces.  The three numbers are measured on the device at
 // hand when the context is created (rfid_ctx_create: ls_calibrate).
-bool ls_pays_off(const rfid_ctx *c, int B, int64_t n_dec) {
-  const double t_seq = 1e-6 * c->seq_ns_per_sample * (double)n_dec * (double)((B + 1023) / 1024);
-  const double t_ls = c->ls_fixed_ms + 1e-6 * c->ls_ns_per_sample * (double)B * (double)n_dec;
-  return t_ls < 0.9 * t_seq;
+void ls_calibrate_lazily(rfid_ctx *c);
+bool ls_pays_off(rfid_ctx *c, int B, int64_t n_dec) {
+  for (int pass = 0; pass < 2; ++pass) {
+    const double t_seq = 1e-6 * c->seq_ns_per_sample * (double)n_dec * (double)((B + 1023) / 1024);
+    const double t_ls = c->ls_fixed_ms + 1e-6 * c->ls_ns_per_sample * (double)B * (double)n_dec;
+    // The built-in numbers (one MI355X) decide the clear cases -- one long trace, a thousand traces.  Only a shape near
+    // the crossover is worth the ~60 ms of measuring both front ends on the device at hand, once per device and process.
+    if (pass == 0 && !c->ls_calibrated && t_ls > 0.33 * t_seq && t_ls < 3.0 * t_seq) { ls_calibrate_lazily(c); continue; }
+    return t_ls < 0.9 * t_seq;
+  }
+  return false;
 }
-bool ls_applicable(const rfid_ctx *c, int B, int64_t n_dec) {
+bool ls_applicable(rfid_ctx *c, int B, int64_t n_dec) {
   if (c->ls_mode == 0 || B > 4096) return false;
   if (ls2_geometry(B, n_dec).P == 0) return false;
   return c->ls_mode == 2 || ls_pays_off(c, B, n_dec);
+}
+// for the work-space reservation of rfid_batch_plan: could a pass of this shape take the long-stream front end?  (Never
+// measures anything: a plan -- every rfid_stream_begin makes one -- must not cost a calibration.)
+bool ls_may_apply(const rfid_ctx *c, int B, int64_t n_dec) {
+  if (c->ls_mode == 0 || B > 4096) return false;
+  if (ls2_geometry(B, n_dec).P == 0) return false;
+  const double t_seq = 1e-6 * c->seq_ns_per_sample * (double)n_dec * (double)((B + 1023) / 1024);
+  const double t_ls = c->ls_fixed_ms + 1e-6 * c->ls_ns_per_sample * (double)B * (double)n_dec;
+  return c->ls_mode == 2 || t_ls < 3.0 * t_seq;
 }
 size_t ls_workspace_bytes(int B, int64_t n_dec, int64_t y_stride) {
   const Ls2Geometry g = ls2_geometry(B, n_dec);
@@ -367,7 +428,7 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
   }
   Ls2Args a;
   memset(&a, 0, sizeof(a));
-  a.y = c->d_y; a.y_stride = c->y_stride; a.lens = c->d_lens; a.n_dec = n_dec; a.n_streams = c->B;
+  a.y = c->y(); a.y_stride = c->y_stride; a.lens = c->d_lens; a.n_dec = n_dec; a.n_streams = c->B;
   ls2_bind(a, (char *)c->ls2_ws.p, L, geo);
   a.wtab = c->d_wtab; a.wmax = c->wmax; a.wcount = c->d_wcount; a.flat = c->d_flat; a.flat_count = c->d_flat_count; a.flat_cap = c->flat_cap;
   a.carry = opt.carry ? c->d_gstate : nullptr; a.carry_out = opt.carry ? c->d_gstate : nullptr;
@@ -489,10 +550,40 @@ int ls_calibrate(rfid_ctx *c) {
     c->ls_fixed_ms = fixed;
     c->seq_ns_per_sample = t_seq[1] / n1 * 1e6;   // (sixteen traces side by side take the time of one)
   }
+  c->ls_calibrated = true;
   if (getenv("RFID_LS_DEBUG"))
     fprintf(stderr, "[ls2] calibration: fused %.3f / %.3f ms, long-stream %.3f / %.3f ms for 1 x %.0f / %d x %.0f samples -> %.2f ns/sample of the longest trace vs %.3f ms + %.4f ns/sample of all\n",
             t_seq[0], t_seq[1], t_ls[0], t_ls[1], n0, B_big, n1, c->seq_ns_per_sample, c->ls_fixed_ms, c->ls_ns_per_sample);
   return RFID_OK;
+}
+
+// The cost model's numbers for the device of `c`, measured when a decision first needs them (ls_pays_off): on a context of
+// their own -- the measurement plans and frees batches -- and kept per device for the life of the process.
+// RFID_LS_CALIBRATE=0 keeps the built-in numbers (profiled runs: a fixed choice of the front end).
+struct LsCalCache { bool done = false, ok = false; double fixed_ms = 0, ns_all = 0, ns_seq = 0; };
+LsCalCache g_ls_cal[64];
+pthread_mutex_t g_ls_cal_mu = PTHREAD_MUTEX_INITIALIZER;
+void ls_calibrate_lazily(rfid_ctx *c) {
+  c->ls_calibrated = true;                 // (whatever comes of it: tried once per context)
+  const char *cal = getenv("RFID_LS_CALIBRATE");
+  if ((cal && atoi(cal) == 0) || c->device < 0 || c->device >= 64) return;
+  pthread_mutex_lock(&g_ls_cal_mu);
+  LsCalCache &k = g_ls_cal[c->device];
+  if (!k.done) {
+    k.done = true;
+    rfid_ctx *t = nullptr;
+    if (rfid_ctx_create(&c->prm, c->device, &t) == RFID_OK && t) {
+      t->ls_calibrated = true;             // (its own decisions use what it has)
+      t->ls_mode = 1;
+      if (ls_calibrate(t) == RFID_OK && t->ls_calibrated) {
+        k.ok = true; k.fixed_ms = t->ls_fixed_ms; k.ns_all = t->ls_ns_per_sample; k.ns_seq = t->seq_ns_per_sample;
+      }
+      (void)rfid_ctx_destroy(t);
+      (void)hipSetDevice(c->device);
+    }
+  }
+  if (k.ok) { c->ls_fixed_ms = k.fixed_ms; c->ls_ns_per_sample = k.ns_all; c->seq_ns_per_sample = k.ns_seq; }
+  pthread_mutex_unlock(&g_ls_cal_mu);
 }
 }  // namespace
 
@@ -562,7 +653,10 @@ int rfid_ctx_create(const rfid_params *p, int device, rfid_ctx **out) {
       if (hipEventCreate(&c->ev_mf[i]) != hipSuccess) rc = RFID_ERR_HIP;
     for (int i = 0; i < 2 * rfid_ctx::MAX_CHUNKS && !rc; ++i)
       if (hipEventCreate(&c->ev_gate[i]) != hipSuccess) rc = RFID_ERR_HIP;
-    if (!rc && (hipEventCreate(&c->ev_pass) != hipSuccess || hipEventCreate(&c->ev_front_end) != hipSuccess))
+    if (!rc && (hipEventCreate(&c->ev_pass) != hipSuccess || hipEventCreate(&c->ev_front_end) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_fe_done, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_tail_done[0], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_tail_done[1], hipEventDisableTiming) != hipSuccess))
       rc = RFID_ERR_HIP;
     if (rc) break;
     if (hipMalloc((void **)&c->d_gate1, sizeof(GateState)) != hipSuccess ||
@@ -575,10 +669,8 @@ int rfid_ctx_create(const rfid_params *p, int device, rfid_ctx **out) {
     if (hipMemset(c->d_gate1, 0, sizeof(GateState)) != hipSuccess || hipMemset(c->d_ticket, 0, 2 * sizeof(int)) != hipSuccess) { rc = RFID_ERR_HIP; break; }
   } while (0);
   if (rc != RFID_OK) { rfid_ctx_destroy(c); return rc; }
-  // the automatic choice between the two front ends works on rates measured here (RFID_LS_CALIBRATE=0: the defaults,
-  // measured on one MI355X)
-  const char *cal = getenv("RFID_LS_CALIBRATE");
-  if (c->ls_mode == 1 && !(cal && atoi(cal) == 0)) (void)ls_calibrate(c);
+  // (the cost model behind the automatic choice of the front end is measured on this device when a shape near the
+  // crossover first asks for it: ls_calibrate_lazily)
   *out = c;
   return RFID_OK;
 }
@@ -609,6 +701,9 @@ int rfid_ctx_destroy(rfid_ctx *c) {
       if (c->ev_gate[i]) (void)hipEventDestroy(c->ev_gate[i]);
     if (c->ev_pass) (void)hipEventDestroy(c->ev_pass);
     if (c->ev_front_end) (void)hipEventDestroy(c->ev_front_end);
+    if (c->ev_fe_done) (void)hipEventDestroy(c->ev_fe_done);
+    for (int i = 0; i < 2; ++i)
+      if (c->ev_tail_done[i]) (void)hipEventDestroy(c->ev_tail_done[i]);
     (void)hipStreamDestroy(c->stream2);
   }
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -782,9 +877,38 @@ int rfid_batch_plan(rfid_ctx *c, int n_streams, int64_t max_raw) {
     return fail(c, RFID_ERR_HIP, "rfid_batch_plan: workspace allocation", e);
   }
   c->B = c->B_plan = n_streams;
+  {
+    // the second result set (see rfid_ctx::ResultSet): only where it is small beside what is free -- a batch that fills the
+    // HBM (BASELINE configs[4]) keeps one set and the plain sequence
+    const char *ov = getenv("RFID_OVERLAP");
+    const size_t need = sizeof(float2) * (size_t)c->y_stride * n_streams + (sizeof(rfid_window) * 3 + sizeof(rfid_decode_result)) * (size_t)c->flat_cap +
+                        sizeof(rfid_stream_stats) * (size_t)n_streams;
+    size_t free_b = 0, total_b = 0;
+    if (!(ov && atoi(ov) == 0) && n_streams >= 64 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < free_b / 8) {
+      hipError_t e2 = hipSuccess;
+      auto alloc2 = [&](void **p, size_t bytes) { if (e2 == hipSuccess) e2 = hipMalloc(p, bytes ? bytes : 1); };
+      alloc2((void **)&c->alt.d_y, sizeof(float2) * (size_t)c->y_stride * n_streams);
+      alloc2((void **)&c->alt.d_wtab, sizeof(rfid_window) * (size_t)c->flat_cap);
+      alloc2((void **)&c->alt.d_flat, sizeof(rfid_window) * 2 * (size_t)c->flat_cap);
+      alloc2((void **)&c->alt.d_wcount, sizeof(int) * (size_t)n_streams);
+      alloc2((void **)&c->alt.d_flat_count, 2 * sizeof(int));
+      alloc2((void **)&c->alt.d_res, sizeof(rfid_decode_result) * (size_t)c->flat_cap);
+      alloc2((void **)&c->alt.d_stats, sizeof(rfid_stream_stats) * (size_t)n_streams);
+      if (e2 == hipSuccess) e2 = hipMemset(c->alt.d_wcount, 0, sizeof(int) * (size_t)n_streams);
+      if (e2 == hipSuccess) e2 = hipMemset(c->alt.d_flat_count, 0, 2 * sizeof(int));
+      if (e2 == hipSuccess) c->alt_have = true;
+      else {
+        (void)hipGetLastError();
+        void *aptrs[] = {c->alt.d_y, c->alt.d_wtab, c->alt.d_flat, c->alt.d_wcount, c->alt.d_flat_count, c->alt.d_res, c->alt.d_stats};
+        for (void *p : aptrs)
+          if (p) (void)hipFree(p);
+        c->alt = rfid_ctx::ResultSet();
+      }
+    }
+  }
   // the long-stream front end's work space, when this shape can take that path: reserved here so that a planned batch
   // does not meet an allocation in its passes (a pass that finds none falls back to the sequential scan)
-  if (ls_applicable(c, n_streams, n_dec)) {
+  if (ls_may_apply(c, n_streams, n_dec)) {
     const size_t need = ls_workspace_bytes(n_streams, n_dec, c->y_stride);
     if (need > c->ls2_ws.cap) {
       if (c->ls2_ws.p) (void)hipFree(c->ls2_ws.p);
@@ -814,6 +938,7 @@ int rfid_batch_mf(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64_t n_
   if (!c->B) return RFID_ERR_STATE;
   if (n_raw > c->max_raw) return RFID_ERR_CAPACITY;
   HIPCHK(c, hipSetDevice(c->device));
+  { int rj = join_tails(c); if (rj) return rj; }
   c->d_lens = (const int64_t *)d_lens;
   c->last_n_raw = n_raw;
   MfArgs a;
@@ -843,6 +968,7 @@ static int rfid_batch_gate_impl(rfid_ctx *c, const int *skip_if) {
   if (!c) return RFID_ERR_INVALID;
   if (!c->B) return RFID_ERR_STATE;
   HIPCHK(c, hipSetDevice(c->device));
+  { int rj = join_tails(c); if (rj) return rj; }
   // fresh gate per trace (gate_impl ctor, gate_impl.cc:41-70): all-zero state; the kernel
   // arms n_samples_to_ungate for the first RN16 itself
   HIPCHK(c, hipMemsetAsync(c->d_gstate, 0, sizeof(GateState) * (size_t)c->B, c->stream));
@@ -871,10 +997,12 @@ int rfid_batch_decode(rfid_ctx *c, int want_scores) {
   if (!c->B) return RFID_ERR_STATE;
   HIPCHK(c, hipSetDevice(c->device));
   DecodeListArgs a;
-  a.y = c->d_y; a.y_stride = c->y_stride; a.cap = c->flat_cap; a.res = c->d_res;
+  a.y = c->y(); a.y_stride = c->y_stride; a.cap = c->flat_cap; a.res = c->d_res;
   a.scores = want_scores ? c->d_scores : nullptr; a.wmax = c->wmax;
   memcpy(a.t_cand, c->t_cand, sizeof(a.t_cand));
-  if (!c->ev_valid[2]) { HIPCHK(c, hipEventRecord(c->ev[2], c->stream)); c->ev_valid[2] = true; }
+  hipStream_t ts = c->tail_stream ? c->tail_stream : c->stream;
+  if (!c->tail_stream) { int rj = join_tails(c); if (rj) return rj; }
+  if (!c->ev_valid[2]) { HIPCHK(c, hipEventRecord(c->ev[2], ts)); c->ev_valid[2] = true; }
   int grid = c->decode_grid;
   {   // (a small plan -- a stream call, a look-ahead pass -- holds few windows: no point in launching a chip's worth of waves)
     const int64_t most = ((int64_t)c->wmax * c->B + 2) / 3 + 1;
@@ -889,9 +1017,9 @@ int rfid_batch_decode(rfid_ctx *c, int want_scores) {
   d.ticket = c->d_ticket + (c->ticket_flip & 1);        // (both zero after rfid_ctx_create; every launch zeroes the other one)
   d.ticket_next = c->d_ticket + ((c->ticket_flip & 1) ^ 1);
   c->ticket_flip ^= 1;
-  hipLaunchKernelGGL(decode_all_kernel, dim3((unsigned)grid), dim3(64), 0, c->stream, d);
+  hipLaunchKernelGGL(decode_all_kernel, dim3((unsigned)grid), dim3(64), 0, ts, d);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+  HIPCHK(c, hipEventRecord(c->ev[3], ts));
   c->ev_valid[3] = true;
   return RFID_OK;
 }
@@ -905,11 +1033,13 @@ int rfid_batch_stats(rfid_ctx *c) {
   a.max_slot_number = (int)pow(2, c->prm.fixed_q);
   a.max_num_queries = c->prm.max_num_queries; a.number_unique_tags = c->prm.number_unique_tags;
   a.out = c->d_stats;
-  if (!c->ev_valid[3]) { HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->ev_valid[3] = true; }
+  hipStream_t ts = c->tail_stream ? c->tail_stream : c->stream;
+  if (!c->tail_stream) { int rj = join_tails(c); if (rj) return rj; }
+  if (!c->ev_valid[3]) { HIPCHK(c, hipEventRecord(c->ev[3], ts)); c->ev_valid[3] = true; }
   // one wave per trace; sixteen when a trace can hold thousands of windows (few long traces)
-  hipLaunchKernelGGL(stream_stats_kernel, dim3((unsigned)c->B), dim3(c->wmax > 2048 ? 64 * STATS_MAX_WAVES : 64), 0, c->stream, a);
+  hipLaunchKernelGGL(stream_stats_kernel, dim3((unsigned)c->B), dim3(c->wmax > 2048 ? 64 * STATS_MAX_WAVES : 64), 0, ts, a);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+  HIPCHK(c, hipEventRecord(c->ev[4], ts));
   c->ev_valid[4] = true;
   return RFID_OK;
 }
@@ -952,6 +1082,21 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
     c->d_lens = (const int64_t *)d_lens;
     c->last_n_raw = n_raw;
     c->n_chunks_last = 0;
+    const bool overlap = c->alt_have && !want_scores;
+    if (overlap) {
+      // this pass works on the set the pass before last used; its decoder and statistics (stream2) must be through with it
+      std::swap(c->d_y, c->alt.d_y); std::swap(c->d_wtab, c->alt.d_wtab); std::swap(c->d_flat, c->alt.d_flat);
+      std::swap(c->d_wcount, c->alt.d_wcount); std::swap(c->d_flat_count, c->alt.d_flat_count);
+      std::swap(c->d_res, c->alt.d_res); std::swap(c->d_stats, c->alt.d_stats);
+      c->set_idx ^= 1;
+      if (c->tail_recorded[c->set_idx]) {
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_tail_done[c->set_idx], 0));
+        c->tail_recorded[c->set_idx] = false;
+      }
+    } else {
+      int rj = join_tails(c);
+      if (rj) return rj;
+    }
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));   // mf_ms = 0: the filter runs inside the gate launch
     HIPCHK(c, hipMemsetAsync(c->d_gstate, 0, sizeof(GateState) * (size_t)c->B, c->stream));
@@ -969,6 +1114,20 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     c->ev_valid[0] = c->ev_valid[1] = c->ev_valid[2] = true;
     c->fused_last = 1;
+    if (overlap) {
+      // decoder + statistics of this pass on stream2, behind this front end; the next pass's front end does not wait for them
+      HIPCHK(c, hipEventRecord(c->ev_fe_done, c->stream));
+      HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fe_done, 0));
+      c->tail_stream = c->stream2;
+      c->ev_valid[2] = false;           // (ev[2] is re-recorded on stream2: the decoder's time starts when it can start)
+      int rc = rfid_batch_decode(c, 0);
+      if (!rc) rc = rfid_batch_stats(c);
+      c->tail_stream = nullptr;
+      if (rc) return rc;
+      HIPCHK(c, hipEventRecord(c->ev_tail_done[c->set_idx], c->stream2));
+      c->tail_recorded[c->set_idx] = true;
+      return RFID_OK;
+    }
     int rc = rfid_batch_decode(c, want_scores);
     if (rc) return rc;
     return rfid_batch_stats(c);
@@ -1109,6 +1268,7 @@ int rfid_batch_get_stats(rfid_ctx *c, rfid_stream_stats *out, int n_streams) {
   if (!c->B) return RFID_ERR_STATE;
   if (n_streams > c->B) n_streams = c->B;
   HIPCHK(c, hipSetDevice(c->device));
+  { int rj = join_tails(c); if (rj) return rj; }
   HIPCHK(c, hipMemcpyAsync(out, c->d_stats, sizeof(rfid_stream_stats) * (size_t)n_streams, hipMemcpyDeviceToHost,
                            c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1120,6 +1280,7 @@ int rfid_batch_get_windows(rfid_ctx *c, rfid_window *windows, rfid_decode_result
   if (!c || !n) return RFID_ERR_INVALID;
   if (!c->B) return RFID_ERR_STATE;
   HIPCHK(c, hipSetDevice(c->device));
+  { int rj = join_tails(c); if (rj) return rj; }
   std::vector<int> wc((size_t)c->B);
   HIPCHK(c, hipMemcpyAsync(wc.data(), c->d_wcount, sizeof(int) * (size_t)c->B, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1150,6 +1311,8 @@ int rfid_batch_get_windows(rfid_ctx *c, rfid_window *windows, rfid_decode_result
 int rfid_batch_device_ptrs(rfid_ctx *c, void **d_mf_out, int64_t *mf_stride, void **d_stats, void **d_flat_count) {
   if (!c) return RFID_ERR_INVALID;
   if (!c->B) return RFID_ERR_STATE;
+  // (the buffers of the LAST pass; with the second result set in use they alternate from pass to pass)
+  { int rj = join_tails(c); if (rj) return rj; }
   if (d_mf_out) *d_mf_out = c->d_y;
   if (mf_stride) *mf_stride = c->y_stride;
   if (d_stats) *d_stats = c->d_stats;
@@ -1161,6 +1324,7 @@ int rfid_batch_get_mf(rfid_ctx *c, int stream, rfid_cf32 *out, int64_t cap, int6
   if (!c || !out || !n) return RFID_ERR_INVALID;
   if (!c->B || stream < 0 || stream >= c->B) return RFID_ERR_STATE;
   HIPCHK(c, hipSetDevice(c->device));
+  { int rj = join_tails(c); if (rj) return rj; }
   int64_t n_raw = c->last_n_raw;
   if (c->d_lens) {
     int64_t l = 0;
@@ -1183,6 +1347,7 @@ int rfid_batch_get_gated(rfid_ctx *c, int stream, int seq, rfid_cf32 *out, int64
   if (!c || !out || !n || seq < 0) return RFID_ERR_INVALID;
   if (!c->B || stream < 0 || stream >= c->B || seq >= c->wmax) return RFID_ERR_STATE;
   HIPCHK(c, hipSetDevice(c->device));
+  { int rj = join_tails(c); if (rj) return rj; }
   int wc = 0;
   rfid_window w;
   HIPCHK(c, hipMemcpyAsync(&wc, c->d_wcount + stream, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1284,7 +1449,21 @@ int rfid_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int
   *n_produced = 0;
   if (n_in == 0) return RFID_OK;
   HIPCHK(c, hipSetDevice(c->device));
-  if (c->la.on) return la_mf_work(c, in, n_in, out, out_cap, n_produced);
+  if (c->la.on) {
+    if (c->sio.ymode) return fail(c, RFID_ERR_STATE, "look-ahead: keyed on the gate's input (rfid_lookahead_enable_gate), rfid_mf_work has no part in it");
+    // a call larger than the max_chunk_raw the look-ahead was sized for goes through in pieces (multiples of the decimation)
+    const int64_t piece = (c->sio.max_chunk / DECIM) * DECIM;
+    int done = 0, made = 0;
+    while (done < n_in) {
+      const int take = (int)((n_in - done < piece) ? (n_in - done) : piece);
+      int k = 0;
+      const int rc = la_mf_work(c, in + done, take, out ? out + made : out, out_cap - made, &k);
+      if (rc) { *n_produced = made; return rc; }
+      done += take; made += k;
+    }
+    *n_produced = made;
+    return RFID_OK;
+  }
   // A decimating GNU Radio block produces output n once the whole group x[5n .. 5n+4] has arrived
   // (sync_decimator: noutput = ninput / decim), although y[n] only needs x[5n-24 .. 5n]: a stream of
   // N samples yields floor(N/5) outputs, the same as rfid_batch_mf / the fused front end.
@@ -1396,7 +1575,12 @@ int rfid_decoder_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, float *out_bit
   rfid_decode_result r;
   rfid_scores sc;
   memset(&sc, 0, sizeof(sc));
-  const bool from_la = c->la.on && !scores_out && la_decoder_result(c, in, wlen, type, &r);
+  // look-ahead: the window the gate handed out is retired whenever a decoder call consumes it -- with scores wanted the
+  // device decodes it again (the cached pass kept no scores), but the entry goes all the same
+  rfid_decode_result r_la;
+  const bool in_la = c->la.on && la_decoder_result(c, in, wlen, type, &r_la);
+  const bool from_la = in_la && !scores_out;
+  if (from_la) r = r_la;
   if (!from_la) {
   int rc = grow(c, c->s_in, sizeof(float2) * (size_t)(wlen + 2));
   if (rc) return rc;
@@ -1481,7 +1665,9 @@ int rfid_reader_work(rfid_ctx *c, int n_in, int *n_consumed) {  // reader_impl.c
 // (1b) whole-chain streaming
 // ======================================================================================
 namespace {
+const int64_t SIO_SMALL_DEC = 32768;   // decimated samples below which a pass takes the sequential scan (sio_submit)
 const int SIO_HIST = 28;   // raw samples kept before the held-back tail: 24 of filter history + the decimation group
+                           // (= rfid_ctx::StreamIO::hist() of a raw stream)
 
 void sio_free(rfid_ctx *c) {
   rfid_ctx::StreamIO &io = c->sio;
@@ -1500,6 +1686,8 @@ void sio_free(rfid_ctx *c) {
   io.pass.active = false;
   io.open = false;
   io.failed = false;
+  io.ymode = false;
+  c->y_view = nullptr;
 }
 
 // READER_STATE bookkeeping for one decoded window, as the blocks do it call by call (tag_decoder_impl.cc:267-388,
@@ -1547,7 +1735,7 @@ int sio_enqueue_packet(rfid_ctx *c, int n_hdr, int usual, const int *only_if) {
     c->la.h_cap = first + first / 2;
   }
   GatedPack gp;
-  gp.wtab = c->d_wtab; gp.wcount = c->d_wcount; gp.res = c->d_res; gp.wmax = n_hdr; gp.y = c->d_y;
+  gp.wtab = c->d_wtab; gp.wcount = c->d_wcount; gp.res = c->d_res; gp.wmax = n_hdr; gp.y = c->y();
   gp.pack = (char *)c->la.d_pack.p; gp.n_hdr = n_hdr; gp.usual = usual; gp.cap = cap;
   gp.only_if = only_if;
   hipLaunchKernelGGL(gated_windows_kernel, dim3((unsigned)n_hdr), dim3(256), 0, c->stream, gp);
@@ -1570,10 +1758,15 @@ int sio_submit(rfid_ctx *c, int b, int64_t n_new, bool flush) {
   ps = rfid_ctx::StreamIO::Pass();
   ps.b = b; ps.flush = flush;
   ps.n_have = io.tail_len + n_new;          // raw samples available beyond the history
-  ps.n_out = ps.n_have / DECIM;
+  ps.n_out = ps.n_have / io.dec();
   const int64_t n_have = ps.n_have, n_out = ps.n_out;
   float2 *data = io.d_buf[b] + (io.tail_max - io.tail_len);   // first held-back (or new) sample
-  if (n_out > 0) {
+  if (io.ymode) {
+    // the stream's samples ARE the matched filter's outputs (gate-keyed look-ahead): the pass reads them where they lie
+    c->y_view = data;
+    c->d_lens = nullptr;
+    c->last_n_raw = DECIM * n_out;
+  } else if (n_out > 0) {
     // ---- matched filter over everything available: y[n] = sum x[5n - 24 .. 5n], history in front of `data` ----
     MfArgs a;
     a.x = data - SIO_HIST; a.x_stride = SIO_HIST + n_have; a.n_raw = SIO_HIST + n_have; a.lens = nullptr;
@@ -1598,7 +1791,34 @@ int sio_submit(rfid_ctx *c, int b, int64_t n_new, bool flush) {
     }
   }
   if (c->la.on) HIPCHK(c, hipEventRecord(io.ev_y, c->stream));
-  if (n_out > 0) {
+  if (n_out > 0 && n_out < SIO_SMALL_DEC) {
+    // ---- a short pass (a scheduler's 8 k-item buffer, a small file): the long-stream front end is a string of ~45 launches
+    //      that one trace of this length does not repay -- the sequential scan (one launch, ~10 ns per sample) goes over it
+    //      from the carried state, up to one EPC window before the end of what is there (a window that opens before that
+    //      point is complete, rfid_stream_work's rule for what the front end cannot take); decoder and packet right behind ----
+    ps.small = true;
+    ps.seq_end = flush ? n_out : (n_out - EPC_WIN);
+    if (ps.seq_end > 0) {
+      HIPCHK(c, hipMemsetAsync(c->d_flat_count, 0, 2 * sizeof(int), c->stream));
+      HIPCHK(c, hipMemsetAsync(&c->d_gstate->win_seq, 0, sizeof(int), c->stream));   // windows are numbered per call
+      HIPCHK(c, hipMemsetAsync(c->d_wcount, 0, sizeof(int), c->stream));
+      c->d_ls2_ctl = nullptr;
+      GateArgs g = {};
+      g.y = c->y(); g.y_stride = c->y_stride; g.n_dec = n_out; g.lens = nullptr; g.pos0 = 0; g.chunk_len = ps.seq_end;
+      g.state = c->d_gstate; g.n_streams = 1; g.wtab = c->d_wtab; g.wmax = c->wmax; g.wcount = c->d_wcount;
+      g.flat = c->d_flat; g.flat_count = c->d_flat_count; g.flat_cap = c->flat_cap; g.mode = 0;
+      hipLaunchKernelGGL(gate_scan_kernel, dim3(1), dim3(GATE_THREADS), 0, c->stream, g);
+      HIPCHK(c, hipGetLastError());
+      c->ev_valid[2] = false;
+      int rc = rfid_batch_decode(c, 0);
+      if (rc) return rc;
+      if (c->la.on) {
+        ps.n_hdr = c->la.n_hdr; ps.usual = (ps.n_hdr / 2 + 1) * (EPC_WIN + RN16_WIN);
+        if ((rc = sio_enqueue_packet(c, ps.n_hdr, ps.usual, nullptr))) return rc;
+      }
+      ps.prefetched = true;   // (decoded -- and, with the look-ahead, packed -- behind the scan)
+    }
+  } else if (n_out > 0) {
     // ---- gate: the pieces up to the last idle cut, from the carried state (the long-stream front end) ----
     LsOpts opt;
     opt.carry = true; opt.hold_last = !flush; opt.force = true;
@@ -1639,7 +1859,10 @@ int sio_collect(rfid_ctx *c) {
   ls_note_last_pass(c);
   if (n_out > 0) {
     bool ok = false;
-    if (ps.enq) {
+    if (ps.small) {
+      ok = ps.seq_end > 0;
+      consumed = ok ? ps.seq_end : 0;
+    } else if (ps.enq) {
       ok = c->ls2_host->ok != 0;
       if (ok) consumed = flush ? n_out : *(const int *)((const char *)c->ls2_host + sizeof(Ls2Ctl));
       if (ok && consumed <= 0) ok = false;
@@ -1654,16 +1877,16 @@ int sio_collect(rfid_ctx *c) {
     // inside it, the gate open.  At the end of the stream: everything.
     if (!ok) consumed = 0;
     const int64_t seq_end = flush ? n_out : (n_out - EPC_WIN);
-    const bool tail_too_long = DECIM * (n_out - consumed) + (n_have - DECIM * n_out) + SIO_HIST > io.tail_max;
+    const bool tail_too_long = io.dec() * (n_out - consumed) + (n_have - io.dec() * n_out) + io.hist() > io.tail_max;
     bool prefetched = ps.prefetched && ok;   // the packet behind the pass holds the front end's windows
-    if ((!ok || tail_too_long) && seq_end > consumed) {
+    if (!ps.small && (!ok || tail_too_long) && seq_end > consumed) {
       if (!ok) {
         HIPCHK(c, hipMemsetAsync(c->d_flat_count, 0, 2 * sizeof(int), c->stream));
         HIPCHK(c, hipMemsetAsync(&c->d_gstate->win_seq, 0, sizeof(int), c->stream));   // windows are numbered per call
         HIPCHK(c, hipMemsetAsync(c->d_wcount, 0, sizeof(int), c->stream));
       }
       GateArgs g = {};
-      g.y = c->d_y; g.y_stride = c->y_stride; g.n_dec = n_out; g.lens = nullptr; g.pos0 = consumed; g.chunk_len = seq_end - consumed;
+      g.y = c->y(); g.y_stride = c->y_stride; g.n_dec = n_out; g.lens = nullptr; g.pos0 = consumed; g.chunk_len = seq_end - consumed;
       g.state = c->d_gstate; g.n_streams = 1; g.wtab = c->d_wtab; g.wmax = c->wmax; g.wcount = c->d_wcount;
       g.flat = c->d_flat; g.flat_count = c->d_flat_count; g.flat_cap = c->flat_cap; g.mode = 0;
       hipLaunchKernelGGL(gate_scan_kernel, dim3(1), dim3(GATE_THREADS), 0, c->stream, g);
@@ -1726,7 +1949,7 @@ int sio_collect(rfid_ctx *c) {
           HIPCHK(c, hipMemcpyAsync(r.data(), c->d_res, sizeof(rfid_decode_result) * (size_t)wc, hipMemcpyDeviceToHost, c->stream));
           HIPCHK(c, hipStreamSynchronize(c->stream));
         }
-        const int64_t n0 = io.raw_base / DECIM;
+        const int64_t n0 = io.raw_base / io.dec();
         size_t goff = 0;
         for (int i = 0; i < wc; ++i) {
           const rfid_window &wi = w[(size_t)i];
@@ -1752,15 +1975,16 @@ int sio_collect(rfid_ctx *c) {
     }
   }
   // ---- what was not processed moves in front of the other buffer's upload area, history included ----
-  const int64_t left = n_have - DECIM * consumed;
-  if (left + SIO_HIST > io.tail_max)   // (cannot happen: the sequential scan above leaves EPC_WIN samples at most)
+  const int64_t left = n_have - io.dec() * consumed;
+  if (left + io.hist() > io.tail_max)   // (cannot happen: the sequential scan above leaves EPC_WIN samples at most)
     return fail(c, RFID_ERR_CAPACITY, "rfid_stream_work: hold-back capacity exceeded");
   const int o = b ^ 1;
-  HIPCHK(c, hipMemcpyAsync(io.d_buf[o] + (io.tail_max - left - SIO_HIST), data + DECIM * consumed - SIO_HIST,
-                           sizeof(float2) * (size_t)(left + SIO_HIST), hipMemcpyDeviceToDevice, c->stream));
+  if (left + io.hist() > 0)
+    HIPCHK(c, hipMemcpyAsync(io.d_buf[o] + (io.tail_max - left - io.hist()), data + io.dec() * consumed - io.hist(),
+                             sizeof(float2) * (size_t)(left + io.hist()), hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipEventRecord(io.ev_free[b], c->stream));
   io.tail_len = left;
-  io.raw_base += DECIM * consumed;
+  io.raw_base += io.dec() * consumed;
   (void)n_windows;
   return RFID_OK;
 }
@@ -1774,22 +1998,28 @@ int sio_process(rfid_ctx *c, int b, int64_t n_new, bool flush) {
 
 extern "C" {
 
-int rfid_stream_begin(rfid_ctx *c, int64_t max_chunk_raw) {
-  if (!c || max_chunk_raw < 5 * 4 * LS2_MIN_PIECE) return RFID_ERR_INVALID;   // a chunk must hold a few pieces
+}  // extern "C"
+namespace {
+// rfid_stream_begin; ymode: the stream's samples are matched-filter outputs (max_chunk_raw counts those)
+int sio_begin(rfid_ctx *c, int64_t max_chunk_raw, bool ymode) {
+  const int dec = ymode ? 1 : DECIM, hist = ymode ? 0 : SIO_HIST;
+  if (!c || max_chunk_raw < dec * 4 * LS2_MIN_PIECE) return RFID_ERR_INVALID;   // a chunk must hold a few pieces
   HIPCHK(c, hipSetDevice(c->device));
   rfid_ctx::StreamIO &io = c->sio;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   sio_free(c);
   // held back per call: at most a few (stretched) pieces of the largest call's grid -- more goes through the sequential scan
-  int64_t piece = (max_chunk_raw / DECIM + LS2_TARGET_PIECES - 1) / LS2_TARGET_PIECES;
+  int64_t piece = (max_chunk_raw / dec + LS2_TARGET_PIECES - 1) / LS2_TARGET_PIECES;
   if (piece < LS2_MIN_PIECE) piece = LS2_MIN_PIECE;
   // (three steps of the idle-cut grid when calls are long: an inventory round has one idle stretch, a grid point may miss
   // it; what does not fit goes through the sequential scan, which a short call can afford and a long one cannot)
-  const int64_t hold = (max_chunk_raw >= DECIM * 48 * piece) ? 3 * LS2_FINE * piece : 6 * piece;
-  io.tail_max = ((DECIM * hold + DECIM * (int64_t)EPC_WIN + SIO_HIST + 63) & ~63LL);
+  const int64_t hold = (max_chunk_raw >= dec * 48 * piece) ? 3 * LS2_FINE * piece : 6 * piece;
+  io.tail_max = ((dec * hold + dec * (int64_t)EPC_WIN + hist + 63) & ~63LL);
   io.max_chunk = max_chunk_raw;
-  int rc = rfid_batch_plan(c, 1, io.tail_max + max_chunk_raw);
+  // (the plan's sizes follow the decimated sample count: a ymode stream of N samples is planned like 5 N raw ones)
+  int rc = rfid_batch_plan(c, 1, (DECIM / dec) * (io.tail_max + max_chunk_raw));
   if (rc) return rc;
+  io.ymode = ymode;
   for (int i = 0; i < 2; ++i) {
     if (hipMalloc((void **)&io.d_buf[i], sizeof(float2) * (size_t)(io.tail_max + max_chunk_raw)) != hipSuccess ||
         hipHostMalloc((void **)&io.h_pin[i], sizeof(rfid_cf32) * (size_t)max_chunk_raw, hipHostMallocDefault) != hipSuccess ||
@@ -1814,6 +2044,9 @@ int rfid_stream_begin(rfid_ctx *c, int64_t max_chunk_raw) {
   io.open = true;
   return RFID_OK;
 }
+}  // namespace
+extern "C" {
+int rfid_stream_begin(rfid_ctx *c, int64_t max_chunk_raw) { return sio_begin(c, max_chunk_raw, false); }
 
 int rfid_stream_staging(rfid_ctx *c, int idx, rfid_cf32 **host, int64_t *cap) {
   if (!c || idx < 0 || idx > 1 || !host) return RFID_ERR_INVALID;
@@ -1978,12 +2211,45 @@ int la_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int
   *n_consumed = 0; *n_written = 0;
   la.last_m2.clear();
   const int64_t p = la.gate_pos;
-  // the input must be the matched filter's output at the gate's position
-  const rfid_cf32 *y_first = la.y_at(p), *y_last = la.y_at(p + n_in - 1);
-  if (!y_first || !y_last || !same_sample(in[0], *y_first) || !same_sample(in[n_in - 1], *y_last))
-    return fail(c, RFID_ERR_STATE, "look-ahead: rfid_gate_work was not handed the matched filter's output at the gate's position");
+  if (!io.ymode) {
+    // the input must be the matched filter's output at the gate's position
+    const rfid_cf32 *y_first = la.y_at(p), *y_last = la.y_at(p + n_in - 1);
+    if (!y_first || !y_last || !same_sample(in[0], *y_first) || !same_sample(in[n_in - 1], *y_last))
+      return fail(c, RFID_ERR_STATE, "look-ahead: rfid_gate_work was not handed the matched filter's output at the gate's position");
+  } else if (p + n_in > la.up_end) {
+    // gate-keyed: the filter is somebody else's; whatever of this call's input the device has not seen yet (the scheduler
+    // shows unconsumed samples again, the new ones come behind them) is uploaded and goes through gate -> tag_decoder in
+    // one submission -- at most max_chunk samples per call, the rest when it is shown again
+    if (!io.open || io.failed || la.flushed) return fail(c, RFID_ERR_STATE, "look-ahead: the stream has ended (rfid_ctx_reset starts a new one)");
+    if (la.up_end < p) return fail(c, RFID_ERR_STATE, "look-ahead: the gate's input skipped samples");
+    int64_t n_new = p + n_in - la.up_end;
+    if (n_new > io.max_chunk) n_new = io.max_chunk;
+    const rfid_cf32 *fresh = in + (la.up_end - p);
+    if (io.pass.active) {                     // the pass of the call before: over by now
+      const int rc = sio_collect(c);
+      if (rc) { io.failed = true; return rc; }
+    }
+    const int up = io.cur;
+    HIPCHK(c, hipEventSynchronize(io.ev_free[up]));
+    const rfid_cf32 *src = fresh;
+    bool pinned = false;
+    {
+      hipPointerAttribute_t attr;
+      if (hipPointerGetAttributes(&attr, fresh) == hipSuccess) pinned = (attr.type == hipMemoryTypeHost);
+      else (void)hipGetLastError();
+    }
+    if (!pinned) { memcpy(io.h_pin[up], fresh, sizeof(rfid_cf32) * (size_t)n_new); src = io.h_pin[up]; }
+    HIPCHK(c, hipMemcpyAsync(io.d_buf[up] + io.tail_max, src, sizeof(rfid_cf32) * (size_t)n_new, hipMemcpyHostToDevice, c->stream));
+    io.cur ^= 1;
+    la.want_yn = 0;
+    const int rc = sio_submit(c, up, n_new, false);
+    if (rc) { io.failed = true; return rc; }
+    la.up_end += n_new;
+    la.stall = 0;
+    la.soft_done = false;
+  }
   for (int attempt = 0; attempt < 4; ++attempt) {
-    const int64_t frontier = io.raw_base / DECIM;   // the gate's doing is known for the samples before this position
+    const int64_t frontier = io.raw_base / io.dec();   // the gate's doing is known for the samples before this position
     int consumed = 0, written = 0;
     bool open_after = false;
     while (!la.wins.empty() && la.wins.front().start + la.wins.front().len <= p && la.emitted == 0) la.wins.pop_front();   // (never: windows are consumed in order)
@@ -2023,7 +2289,7 @@ int la_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int
         if (rc) { io.failed = true; return rc; }
         continue;
       }
-      if (la.stall >= 3 && !la.soft_done && io.tail_len / DECIM > 2 * (int64_t)EPC_WIN) {
+      if (la.stall >= 3 && !la.soft_done && io.tail_len / io.dec() > 2 * (int64_t)EPC_WIN) {
         // the input has paused: what is held back behind the last idle cut goes through the sequential scan, up to
         // one EPC window before its end (a window that opens there is complete, rfid_stream_work's rule); the
         // stream goes on from the carried state when input comes.  Once per pause.
@@ -2051,11 +2317,19 @@ int la_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int
 // rfid_decoder_work with the look-ahead on: the result of the window the gate handed out, when `in` is that window
 bool la_decoder_result(rfid_ctx *c, const rfid_cf32 *in, int wlen, int type, rfid_decode_result *r) {
   rfid_ctx::LookAhead &la = c->la;
-  if (la.dq.empty()) return false;
-  const rfid_ctx::LookAhead::Win &w = la.dq.front();
-  if (w.len != wlen || w.type != type || !same_sample(in[0], w.first) || !same_sample(in[wlen - 1], w.last)) return false;
-  *r = w.res;
-  la.dq.pop_front();
+  // the windows are decoded in the order the gate handed them out: the call's window is the oldest entry, or -- if a
+  // window was skipped by the caller -- a later one, and what lies before it is stale
+  size_t hit = la.dq.size();
+  for (size_t i = 0; i < la.dq.size(); ++i) {
+    const rfid_ctx::LookAhead::Win &w = la.dq[i];
+    if (w.len == wlen && w.type == type && same_sample(in[0], w.first) && same_sample(in[wlen - 1], w.last)) { hit = i; break; }
+  }
+  if (hit == la.dq.size()) {
+    while (la.dq.size() > 64) la.dq.pop_front();   // (a caller that decodes something else altogether: the queue stays bounded)
+    return false;
+  }
+  *r = la.dq[hit].res;
+  la.dq.erase(la.dq.begin(), la.dq.begin() + (long)hit + 1);
   return true;
 }
 }  // namespace
@@ -2094,6 +2368,29 @@ int rfid_lookahead_enable(rfid_ctx *c, int64_t max_chunk_raw) {
   c->la.on = true;
   return RFID_OK;
 }
+
+int rfid_lookahead_enable_gate(rfid_ctx *c, int64_t max_items) {
+  if (!c || max_items < 1) return RFID_ERR_INVALID;
+  if (c->mf_seen != 0 || c->la.gate_pos != 0) return fail(c, RFID_ERR_STATE, "rfid_lookahead_enable_gate: the stream has started");
+  la_free(c);
+  int64_t cap = max_items;
+  if (cap < 4 * (int64_t)LS2_FINE * LS2_MIN_PIECE) cap = 4 * (int64_t)LS2_FINE * LS2_MIN_PIECE;
+  const rfid_reader_state keep = c->rs;
+  int rc = sio_begin(c, cap, true);
+  c->rs = keep;
+  if (rc) return rc;
+  c->la.on = true;
+  return RFID_OK;
+}
+
+int rfid_lookahead_pending(const rfid_ctx *c, int *gate_windows, int *decoder_windows) {
+  if (!c) return RFID_ERR_INVALID;
+  if (gate_windows) *gate_windows = (int)c->la.wins.size();
+  if (decoder_windows) *decoder_windows = (int)c->la.dq.size();
+  return RFID_OK;
+}
+
+int rfid_abi_version(void) { return RFID_MI355X_ABI; }
 
 void *rfid_host_alloc(size_t bytes) {
   void *p = nullptr;

@@ -201,9 +201,16 @@ RFID_DEVICE float div_const_fast(float x) {
   const float q1 = x * rc;
   return wv::fma_f(wv::fma_f(-q1, c, x), rc, q1);
 }
+// the lanes whose operand div_const_fast must not see, as a vote mask.  (A vote over a conjunction of compares costs two
+// extra vector instructions -- the compiler materialises the lane predicate and compares it again; votes over single
+// compares, combined on the scalar unit, cost none.)
+RFID_DEVICE uint64_t div_const_bad(float x) {
+  const uint32_t u = wv::f2u(x);
+  return wv::ballot(((u & 0x7fffffffu) - 0x0d800000u) >= (0x7f800000u - 0x0d800000u)) & wv::ballot(u != 0u);
+}
 template <int C>
 RFID_DEVICE float div_const(float x) {   // wave-uniform choice of the path
-  if (__builtin_expect(wv::ballot(!div_const_ok(x)) == 0, 1)) return div_const_fast<C>(x);
+  if (__builtin_expect(div_const_bad(x) == 0, 1)) return div_const_fast<C>(x);
   return wv::fdiv(x, (float)C);
 }
 
@@ -249,14 +256,17 @@ RFID_DEVICE bool chain_add_scan(float carry, float x, int lane, float &out) {
   const float r = wv::rint_f(t);                                  // to nearest, ties to even
   const float frac = t - r;                                       // exact
   const bool bad_t = !(__builtin_fabsf(t) < 4194304.0f);
-  const bool tie = !bad_t && __builtin_fabsf(frac) == 0.5f;
+  const bool half = __builtin_fabsf(frac) == 0.5f;
+  const bool tie = !bad_t && half;
   int R = wv::f2i(bad_t ? 0.0f : r);
-  const uint64_t tiemask = wv::ballot(tie);
+  // (votes over single compares, combined on the scalar unit: see div_const_bad)
+  const uint64_t badmask_t = wv::ballot(bad_t);
+  const uint64_t tiemask = wv::ballot(half) & ~badmask_t;
   if (tiemask != 0ull) {
     // ties: d/u = I + 1/2 with I = floor(d/u) = r - (frac < 0); the sum takes I + ((S + I) & 1)
     const int I = R - ((frac < 0.0f) ? 1 : 0);
-    const uint64_t rodd = wv::ballot(!tie && (R & 1));            // parity toggles of the other samples
-    const uint64_t iodd = wv::ballot(tie && (I & 1));
+    const uint64_t rodd = wv::ballot((R & 1) != 0) & ~tiemask;    // parity toggles of the other samples
+    const uint64_t iodd = wv::ballot((I & 1) != 0) & tiemask;
     const uint64_t Q = prefix_xor64(rodd);                        // toggles accumulated up to and including sample k
     // parity of S before sample k = (toggles up to k-1) ^ (toggles up to the last tie before k, or the carry's
     // parity if there is none): the second term is a fill-forward of Q from the tie positions = the carry
@@ -269,10 +279,10 @@ RFID_DEVICE bool chain_add_scan(float carry, float x, int lane, float &out) {
     R = tie ? (I + (int)((up >> lane) & 1ull)) : R;
   }
   const uint32_t mag = (cb & 0x7fffffffu) + (uint32_t)wv::scan_add(R);
-  const bool bad_s = ((mag ^ cb) & 0x7f800000u) != 0u || (mag & 0x007fffffu) == 0u;
-  const bool bad_c = e_b < 23u || e_b > 254u;
+  const uint64_t badmask_s = wv::ballot(((mag ^ cb) & 0x7f800000u) != 0u) | wv::ballot((mag & 0x007fffffu) == 0u);
+  const bool bad_c = e_b < 23u || e_b > 254u;   // (wave-uniform)
   out = wv::u2f(mag | sign);
-  return wv::ballot(bad_t || bad_s || bad_c) == 0ull;
+  return (badmask_t | badmask_s) == 0ull && !bad_c;
 }
 
 // in-order sum, scan when it is provably exact, else the chain
@@ -326,20 +336,39 @@ struct GateBackRegs {
 struct GateSlot {
   float amp[64];   // |x|                                   (gate_impl.cc:130)    producer -> consumer
   float d[64];     // (|x| - win_samples[win_index]) / 100   (gate_impl.cc:131)    producer -> consumer
-  // consumer -> back (two 16-byte records, written by lane 0)
-  alignas(16) int b_flags;                  //   bit 0 some sample of the step is "closed" (updates dc_est), bit 1 the scan stops after this step
-  int b_nvalid;                             //   samples of the step that were consumed
-  uint64_t b_closedmask;                    //   the closed samples (gate_impl.cc:139-143)
+  // consumer -> back (16-byte records, written by lane 0; the second one in streaming mode only)
+  alignas(16) int b_word;                   //   bit 0 some sample of the step is "closed" (updates dc_est), bit 1 the scan stops after this
+  int b_pad0_;                              //   step, bit 2 some sample lies inside an open window; bits 8..15 samples of the step that
+  uint64_t b_closedmask;                    //   were consumed; bits 16..23 lane of the gate opening of the step (0xff: none), bit 24 its type
+                                            //   b_closedmask: the closed samples (gate_impl.cc:139-143)
   uint64_t b_openmask;                      //   lanes inside an open window (streaming: their gated samples are emitted)
-  int b_open;                               //   gate openings of the step: lane | type << 8 | (lane2 | type2 << 8) << 16, 0xff = none
-  int b_pad_;
+  int b_pad1_[2];
   float2 yv[64];   // the samples themselves
-  float tre[64];   // dc_est increments of the step's samples: the producer's speculative (x - x[i-48]) / 48 -- exact
+  float tre[64];   // dc_est increments of the step's samples: the filter wave's speculative (x - x[i-48]) / 48 -- exact
   float tim[64];   //   whenever the previous 48 samples were all "closed" (gate_impl.cc:141) -- else the back wave recomputes them
+  int spec_bad;    // != 0: some difference of the step is outside the range of the 3-instruction constant division -- the
+  int pad_[3];     //   speculative increments are not to be used (the back wave forms them from the ring, with wv::fdiv)
 };
 
 // ---- producer wave: everything that is lane-parallel ---------------------------------------
-RFID_DEVICE void gate_produce(GateSlot &slot, float2 yv_in, float2 &prev_yv, int pos, int n, int lane,
+// speculative dc_est increments of one step, formed by the FILTER wave (the role with time to spare: it waits for a free
+// slot a third of the time): (x_i - x_{i-48}) / 48 with x_{i-48} from the previous step (lanes 0..47 <- its lanes 16..63)
+// or from this one (lanes 48..63 <- lanes 0..15).  Branch-free -- a branch here would make the compiler wait for ALL
+// of the filter wave's raw-sample loads in flight: the constant division always takes its 3-instruction form, and a
+// vote tells the back wave when that form was not valid for some lane (then it does not use these values).
+RFID_DEVICE void gate_spec_dc(GateSlot &slot, float2 yv, float2 &prev_yv, int lane) {
+  const int src = (lane < DC_LEN) ? (lane + 64 - DC_LEN) : (lane - DC_LEN);
+  const float pre = wv::shfl(prev_yv.x, src), pim = wv::shfl(prev_yv.y, src);
+  const float cre = wv::shfl(yv.x, src), cim = wv::shfl(yv.y, src);
+  const float ore = (lane < DC_LEN) ? pre : cre, oim = (lane < DC_LEN) ? pim : cim;
+  const float nr = yv.x - ore, ni = yv.y - oim;
+  slot.tre[lane] = div_const_fast<DC_LEN>(nr);
+  slot.tim[lane] = div_const_fast<DC_LEN>(ni);
+  slot.spec_bad = ((div_const_bad(nr) | div_const_bad(ni)) != 0ull) ? 1 : 0;   // (every lane stores the same word)
+  prev_yv = yv;
+}
+
+RFID_DEVICE void gate_produce(GateSlot &slot, float2 yv_in, int pos, int n, int lane,
                               float *lds_win, int &win_index) {
   const int nvalid = (n - pos < 64) ? (n - pos) : 64;
   const bool valid = lane < nvalid;
@@ -354,30 +383,11 @@ RFID_DEVICE void gate_produce(GateSlot &slot, float2 yv_in, float2 &prev_yv, int
   wv::wave_sync();
   win_index += nvalid;
   if (win_index >= WIN_LEN) win_index -= WIN_LEN;
-  // x[i-48]: lanes 0..47 take it from the previous step (its lanes 16..63), lanes 48..63 from
-  // this step (lanes 0..15)
-  const int src = (lane < DC_LEN) ? (lane + 64 - DC_LEN) : (lane - DC_LEN);
-  const float pre = wv::shfl(prev_yv.x, src), pim = wv::shfl(prev_yv.y, src);
-  const float cre = wv::shfl(yv.x, src), cim = wv::shfl(yv.y, src);
-  const float ore = (lane < DC_LEN) ? pre : cre, oim = (lane < DC_LEN) ? pim : cim;
-  const float nr = yv.x - ore, ni = yv.y - oim;
-  // the three divisions by constants (gate_impl.cc:131,141), one wave-uniform choice of the path
-  float d, tre, tim;
-  if (__builtin_expect(wv::ballot(!(div_const_ok(nd) && div_const_ok(nr) && div_const_ok(ni))) == 0, 1)) {
-    d = div_const_fast<WIN_LEN>(nd);
-    tre = div_const_fast<DC_LEN>(nr);
-    tim = div_const_fast<DC_LEN>(ni);
-  } else {
-    d = wv::fdiv(nd, WIN_LEN_F);
-    tre = wv::fdiv(nr, DC_LEN_F);
-    tim = wv::fdiv(ni, DC_LEN_F);
-  }
+  // the division by a constant (gate_impl.cc:131), one wave-uniform choice of the path
+  const float d = div_const<WIN_LEN>(nd);
   slot.amp[lane] = amp;
   slot.d[lane] = d;
-  // (slot.yv was written by the filter wave; lanes past the end of the call hold zeros there)
-  slot.tre[lane] = tre;
-  slot.tim[lane] = tim;
-  prev_yv = yv;
+  // (slot.yv, the speculative dc_est increments: written by the filter wave; lanes past the end of the call hold zeros there)
 }
 
 // a gate opening at lane `ol` of the step that starts at `pos`: dc_est is the in-order sum at
@@ -392,15 +402,48 @@ RFID_DEVICE void gate_record_window(const GateArgs &a, GateBackRegs &g, int ol, 
       rfid_window w;
       w.stream = g.strm; w.seq = g.win_seq; w.start = start; w.type = wtype;
       w.dc_re = odr; w.dc_im = odi;
+      // (one store, not waited for.  The decoder's compact lists are filled from these records when the scan of the trace
+      // is over -- gate_flat_lists: a list slot drawn per opening is a returning atomic in the back wave's path, ~5 000
+      // cycles twice per inventory round when a thousand traces draw from the two counters at once)
       a.wtab[(int64_t)s * a.wmax + g.win_seq] = w;
-      if (a.flat) {
-        const int slotw = wv::atomic_add(a.flat_count + wtype, 1);
-        if (slotw < a.flat_cap) a.flat[(int64_t)wtype * a.flat_cap + slotw] = w;
-      }
     }
     g.n_complete++;
   }
   g.win_seq++;
+}
+
+// The windows [first, first + cnt) of this trace's row of the window table, just written by this wave, go into the
+// decoder's two compact lists (by type; any order): one slot draw per type and trace.
+RFID_DEVICE void gate_flat_lists(const GateArgs &a, int s, int first, int cnt, int lane) {
+  if (!a.flat || cnt <= 0) return;
+  wv::global_release();   // this wave's records have arrived
+  const rfid_window *row = a.wtab + (int64_t)s * a.wmax;
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int n1 = 0;
+  for (int j0 = 0; j0 < cnt; j0 += 64) {
+    const int j = j0 + lane;
+    const int ty = (j < cnt) ? wv::load_coherent_i32(&row[first + j].type) : 0;
+    n1 += wv::popc64(wv::ballot(ty != 0));
+  }
+  int base = 0;
+  if (lane < 2) {
+    const int want = lane ? n1 : (cnt - n1);
+    if (want > 0) base = wv::atomic_add(a.flat_count + lane, want);
+  }
+  const int base0 = wv::readlane(base, 0), base1 = wv::readlane(base, 1);
+  int done0 = 0, done1 = 0;
+  for (int j0 = 0; j0 < cnt; j0 += 64) {
+    const int j = j0 + lane;
+    rfid_window w;
+    w.type = 0;
+    if (j < cnt) w = wv::load_coherent_window(&row[first + j]);
+    const uint64_t m1 = wv::ballot(j < cnt && w.type != 0), m0 = wv::ballot(j < cnt && w.type == 0);
+    if (j < cnt) {
+      const int slotw = w.type ? (base1 + done1 + wv::popc64(m1 & lt)) : (base0 + done0 + wv::popc64(m0 & lt));
+      if (slotw < a.flat_cap) a.flat[(int64_t)(w.type ? 1 : 0) * a.flat_cap + slotw] = w;
+    }
+    done0 += wv::popc64(m0); done1 += wv::popc64(m1);
+  }
 }
 
 // One step (64 samples, the first `nvalid` of them valid) through the edge / pulse / window state machine of
@@ -534,20 +577,20 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateSlot *slot, co
     // back to back (a wave's LDS reads execute in order, and the producer wrote the slot
     // before it advanced the sequence word), and only then is the sequence word looked at.
     // Usually not even that: the previous step already fetched this slot (see below).
-    if (nx.step == k && wv::uniform(nx.sq) > k) {
-      f_amp = nx.amp; f_d = nx.d;
-    } else {
-      for (;;) {
-        const int sq = wv::lds_peek(seq);
-        f_amp = slot->amp[lane]; f_d = slot->d[lane];
-        if (wv::uniform(sq) > k) break;
-        wv::backoff();
-      }
+    if (!(nx.step == k && wv::uniform(nx.sq) > k)) {
+      // (rare) wait for the producer, then fetch this step's slot the way the next one is fetched below: every value the
+      // step works on comes out of wv::lds_prefetch, the compiler has no LDS read of its own to wait for where the two
+      // paths meet (it would wait for ALL outstanding LDS operations there, the hand-over stores of the last step included)
+      while (wv::lds_load(seq) <= k) wv::backoff();
+      wv::lds_prefetch(seq, &slot->amp[lane], nx.sq, nx.amp, nx.d);
+      wv::lds_prefetch_wait<0>(nx.sq, nx.amp, nx.d);
     }
+    f_amp = nx.amp; f_d = nx.d;
     // fetch step k+1 now: the producer is normally more than one step ahead, and the reads
-    // complete while this step is worked on (the sequence word tells the next call whether they count)
-    nx.sq = wv::lds_peek(seq);
-    nx.amp = slot_next->amp[lane]; nx.d = slot_next->d[lane];
+    // complete while this step is worked on (the sequence word tells the next call whether they count).  Not waited
+    // for here: the caller's loop does that behind the hand-over of this step (wv::lds_prefetch_wait).
+    static_assert(offsetof(GateSlot, d) - offsetof(GateSlot, amp) == 256, "ds_read2st64: amp and d 64 words apart");
+    wv::lds_prefetch(seq, &slot_next->amp[lane], nx.sq, nx.amp, nx.d);
     nx.step = k + 1;
   }
   // avg_ampl after every sample (gate_impl.cc:130-134): the in-order sum in its integer-scan form where that is
@@ -557,16 +600,18 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateSlot *slot, co
   const float avg = chain_add_auto(g.avg_c, f_d, lane);
   g.avg_c = wv::readlane(avg, 63);   // the lanes past the end of the call add +0
   const float thresh = avg * THRESH_FRACTION;
-  const uint64_t below = wv::ballot(lane < nvalid && f_amp < thresh);
-  const uint64_t above = wv::ballot(lane < nvalid && f_amp > thresh);
+  const uint64_t vmask = lane_range(0, nvalid);
+  const uint64_t below = wv::ballot(f_amp < thresh) & vmask;
+  const uint64_t above = wv::ballot(f_amp > thresh) & vmask;
   uint64_t closedmask, openmask;
   int open_lane, open_type;
   gate_fsm_step(a.mode, g, below, above, pos, nvalid, closedmask, openmask, open_lane, open_type);
   // streaming mode stopped inside the step: avg_ampl carries only over the samples actually consumed
   if (g.stop) g.avg_c = (nvalid > 0) ? wv::readlane(avg, nvalid - 1) : avg_in;
   // hand the step to the back wave (lane 0 writes after this wave's earlier LDS writes: in-order queue)
-  wv::lds_store_desc(&slot->b_flags, ((closedmask != 0) ? 1 : 0) | (g.stop ? 2 : 0), nvalid, closedmask, openmask,
-                     open_lane | (open_type << 8), lane);
+  if (a.mode != 0) wv::lds_store_rec(reinterpret_cast<int *>(&slot->b_openmask), 0, openmask, lane);
+  wv::lds_store_rec(&slot->b_word, ((closedmask != 0) ? 1 : 0) | (g.stop ? 2 : 0) | ((openmask != 0) ? 4 : 0) | (nvalid << 8) |
+                                       (open_lane << 16) | (open_type << 24), closedmask, lane);
 }
 
 // ---- back wave: the dc ring, dc_est and what hangs on it ------------------------------------------
@@ -579,11 +624,14 @@ RFID_DEVICE void gate_consume(const GateArgs &a, GateRegs &g, GateSlot *slot, co
 // the ring), ring upkeep, the two in-order sums; dcr / dci = dc_est after every sample of the step
 // (first half: the increments of the step's closed samples and the ring upkeep; shared with the long-stream front end's
 // dc_est pass, which sums them from two start values at once)
+// -> true: the increments are the speculative ones (spec was called), false: they were formed here from the ring
 template <class Spec>
-RFID_DEVICE void gate_dc_incr(GateBackRegs &g, uint64_t closedmask, uint64_t openmask, int nvalid, float2 yv, int lane,
-                              float2 *lds_dc, float2 *lds_tmp, Spec spec, float &tre, float &tim) {
+RFID_DEVICE bool gate_dc_incr(GateBackRegs &g, uint64_t closedmask, uint64_t openmask, int nvalid, float2 yv, int lane,
+                              float2 *lds_dc, float2 *lds_tmp, Spec spec, float &tre, float &tim, bool spec_ok = true) {
   const int cnt = wv::popc64(closedmask);
-  if (__builtin_expect(cnt == 64 && openmask == 0 && g.run_closed >= DC_LEN, 1)) {
+  bool used_spec = false;
+  if (__builtin_expect(cnt == 64 && openmask == 0 && g.run_closed >= DC_LEN && spec_ok, 1)) {
+    used_spec = true;
     // the 48 samples before every lane were closed too: dc_samples[dc_index] is x[i-48] and the speculative
     // increments are the reference's; the ring itself is left alone
     spec(tre, tim);
@@ -620,7 +668,7 @@ RFID_DEVICE void gate_dc_incr(GateBackRegs &g, uint64_t closedmask, uint64_t ope
     }
     const float nr = yv.x - old.x, ni = yv.y - old.y;
     float qr, qi;
-    if (__builtin_expect(wv::ballot(!(div_const_ok(nr) && div_const_ok(ni))) == 0, 1)) {
+    if (__builtin_expect((div_const_bad(nr) | div_const_bad(ni)) == 0, 1)) {
       qr = div_const_fast<DC_LEN>(nr); qi = div_const_fast<DC_LEN>(ni);
     } else {
       qr = wv::fdiv(nr, DC_LEN_F); qi = wv::fdiv(ni, DC_LEN_F);
@@ -647,12 +695,34 @@ RFID_DEVICE void gate_dc_incr(GateBackRegs &g, uint64_t closedmask, uint64_t ope
     }
   }
   g.prev_yv = yv;
+  return used_spec;
+}
+// The two in-order sums of a step when only their END values are wanted (no gate opening in the step, batch mode): the
+// 64 addends of a component lie in LDS in sample order; every even lane adds up the real parts, every odd lane the
+// imaginary parts, each by itself with 64 plain dependent adds out of registers -- half the vector instructions of the
+// two 63-step DPP chains (chain_add2) and a third of their latency (a dependent v_add_f32 issues every ~4.5 cycles, a
+// dependent DPP add every 12.5).  The arithmetic is the same left-to-right sum: (((carry + x_0) + x_1) + ...) + x_63.
+RFID_DEVICE void chain_add2_ends(float &cr, float &ci, const float *re, const float *im, int lane) {
+  const float4 *src = reinterpret_cast<const float4 *>((lane & 1) ? im : re);
+  float4 v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = src[j];
+  float sum = (lane & 1) ? ci : cr;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    sum = sum + v[j].x;
+    sum = sum + v[j].y;
+    sum = sum + v[j].z;
+    sum = sum + v[j].w;
+  }
+  cr = wv::readlane(sum, 0);
+  ci = wv::readlane(sum, 1);
 }
 template <bool SCAN, class Spec>
 RFID_DEVICE void gate_dc_step(GateBackRegs &g, uint64_t closedmask, uint64_t openmask, int nvalid, float2 yv, int lane,
-                              float2 *lds_dc, float2 *lds_tmp, Spec spec, float &dcr, float &dci) {
+                              float2 *lds_dc, float2 *lds_tmp, Spec spec, float &dcr, float &dci, bool spec_ok = true) {
   float tre, tim;
-  gate_dc_incr(g, closedmask, openmask, nvalid, yv, lane, lds_dc, lds_tmp, spec, tre, tim);
+  gate_dc_incr(g, closedmask, openmask, nvalid, yv, lane, lds_dc, lds_tmp, spec, tre, tim, spec_ok);
   if (SCAN) {
     // (ls_dc_kernel: one wave per unit, bound by the latency of its own sums.  In the back wave of the 4-wave
     // pipeline the two interleaved chains are faster: 2.45 vs 2.69 ms for the fused front end)
@@ -667,13 +737,34 @@ RFID_DEVICE void gate_dc_step(GateBackRegs &g, uint64_t closedmask, uint64_t ope
 
 RFID_DEVICE void gate_back(const GateArgs &a, GateBackRegs &g, const GateSlot *slot, int pos, int n_total, int row, int lane,
                            float2 *lds_dc, float2 *lds_tmp, bool &stop) {
-  int flags, nvalid, open;
+  int word, w1 = 0;
   uint64_t closedmask, openmask;
-  wv::lds_load_desc(&slot->b_flags, flags, nvalid, closedmask, openmask, open);
+  const int spec_bad_v = wv::lds_peek(&slot->spec_bad);   // (rides on the descriptor's round trip)
+  wv::lds_load_rec(&slot->b_word, word, closedmask);
+  const int flags = word & 7, nvalid = (word >> 8) & 0xff, open = (word >> 16) & 0x1ff;   // lane | type << 8
+  // (batch mode only needs to know WHETHER samples lie inside a window: gate_dc_incr's test for a wholly closed step)
+  if (a.mode != 0) wv::lds_load_rec(reinterpret_cast<const int *>(&slot->b_openmask), w1, openmask);
+  else openmask = (flags & 4) ? 1ull : 0ull;
+  const bool spec_ok = wv::uniform(spec_bad_v) == 0;
   float dcr, dci;
-  if (flags & 1) {
+  const bool lanes_wanted = (open & 0xff) != 0xff || a.mode == 1;   // dc_est at a gate opening / under the gated samples
+  if ((flags & 1) && !lanes_wanted) {
+    // only dc_est after the step is wanted: sums out of registers (chain_add2_ends)
+    float tre = 0.0f, tim = 0.0f;
+    const bool spec = gate_dc_incr(g, closedmask, openmask, nvalid, slot->yv[lane], lane, lds_dc, lds_tmp,
+                                   [&](float &, float &) {}, tre, tim, spec_ok);
+    const float *re = slot->tre, *im = slot->tim;
+    if (!spec) {
+      float *t = reinterpret_cast<float *>(lds_tmp);   // (gate_dc_incr is through with it)
+      t[lane] = tre; t[64 + lane] = tim;
+      wv::wave_sync();
+      re = t; im = t + 64;
+    }
+    chain_add2_ends(g.dcr_c, g.dci_c, re, im, lane);
+    dcr = g.dcr_c; dci = g.dci_c;
+  } else if (flags & 1) {
     gate_dc_step<false>(g, closedmask, openmask, nvalid, slot->yv[lane], lane, lds_dc, lds_tmp,
-                 [&](float &tre, float &tim) { tre = slot->tre[lane]; tim = slot->tim[lane]; }, dcr, dci);
+                 [&](float &tre, float &tim) { tre = slot->tre[lane]; tim = slot->tim[lane]; }, dcr, dci, spec_ok);
   } else {
     // the step lies entirely inside a window: dc_est, the ring and its index do not move
     g.run_closed = 0;
@@ -720,7 +811,7 @@ struct GateShared {          // per trace
   GateSlot slots[GATE_SLOTS];
   float win[WIN_LEN + 4];    // the producer wave's working copy of gate_impl::win_samples
   float2 dc[DC_LEN];         // gate_impl::dc_samples (back wave)
-  float2 tmp[64];
+  alignas(16) float2 tmp[64];
   float4 rawtile[64 * GATE_RAW_LD];   // fused front end: the 344 raw samples one step's matched filter needs (+ padding)
   int fir_seq;               // steps whose samples are in the slot (filter wave)
   int prod_seq;              // steps the producer wave is through with
@@ -794,17 +885,8 @@ RFID_DEVICE float2 gate_fir_step(const GateRawRegs &r, float4 *tile4, int lane, 
   }
   wv::wave_sync();
   const float2 *tile = reinterpret_cast<const float2 *>(tile4);
-  float2 v[NTAPS];
-#pragma unroll
-  for (int k = 0; k < NTAPS; ++k) v[k] = tile[DECIM * lane + k];
-  wv::lds_wait();   // all 25 reads in flight together: one LDS round trip instead of ten
-  float re = 0.0f, im = 0.0f;
-#pragma unroll
-  for (int k = 0; k < NTAPS; ++k) {
-    re = re + v[k].x;
-    im = im + v[k].y;
-  }
-  return make_float2(re, im);
+  static_assert(NTAPS == 25, "lds_sum25_in_order");
+  return wv::lds_sum25_in_order(&tile[DECIM * lane]);   // single ds_read_b64s, never ds_read2_b64 (half the LDS rate)
 }
 
 template <bool FUSED>
@@ -846,6 +928,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
     // fused front end: raw samples in, matched filter here, y written for the decoder;
     // stage kernels / streaming: y in
     bool stopped = false;
+    float2 prev_yv = make_float2(0.0f, 0.0f);   // the samples of the previous step (x[i-48] of the speculative dc_est increments)
     if (FUSED) {
       const float2 *xs = a.raw + (int64_t)strm * a.raw_stride;
       const bool vec = a.raw_vec_ok != 0;
@@ -888,6 +971,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
             gate_load_raw<decltype(interior)::value>(buf[u], xs, hi_idx, rbase + (int64_t)(k + GATE_RAW_DEPTH) * 64 * DECIM, lane, vec);
             yw[64 * k + lane] = yv;
             sh.slots[k % GATE_SLOTS].yv[lane] = yv;
+            gate_spec_dc(sh.slots[k % GATE_SLOTS], yv, prev_yv, lane);
             wv::lds_store(&sh.fir_seq, k + 1, lane);   // after the slot's data (in-order LDS queue)
           }
         };
@@ -904,6 +988,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
         if (64 * k + lane < n) yw[64 * k + lane] = yv;
         else yv = make_float2(0.0f, 0.0f);
         sh.slots[k % GATE_SLOTS].yv[lane] = yv;
+        gate_spec_dc(sh.slots[k % GATE_SLOTS], yv, prev_yv, lane);
         wv::lds_store(&sh.fir_seq, k + 1, lane);
       }
       wv::global_release();                       // the consumer's write-back re-reads y
@@ -931,6 +1016,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
             }
             if (!stopped) {
               sh.slots[k % GATE_SLOTS].yv[lane] = cur[u];
+              gate_spec_dc(sh.slots[k % GATE_SLOTS], cur[u], prev_yv, lane);
               wv::lds_store(&sh.fir_seq, k + 1, lane);
             }
           }
@@ -945,7 +1031,6 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
     for (int j = lane; j < WIN_LEN; j += 64) sh.win[j] = st->win[j];
     int win_index = win_index0;
     wv::wave_sync();
-    float2 prev_yv = make_float2(0.0f, 0.0f);
     bool stopped = false;
     int fir_seen = 0;    // sh.fir_seq as last read (it only grows)
     for (int k = 0; k < nsteps && !stopped; ++k) {
@@ -958,7 +1043,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
       }
       if (!stopped) {
         GateSlot &slot = sh.slots[k % GATE_SLOTS];
-        gate_produce(slot, slot.yv[lane], prev_yv, 64 * k, n, lane, sh.win, win_index);
+        gate_produce(slot, slot.yv[lane], 64 * k, n, lane, sh.win, win_index);
         wv::lds_store(&sh.prod_seq, k + 1, lane);   // after the slot's data (in-order LDS queue)
       }
     }
@@ -1005,13 +1090,14 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
     if (lane < DC_LEN) { st->dcr_re[lane] = lds_dc[lane].x; st->dcr_im[lane] = lds_dc[lane].y; }
     if (lane == 0) {
       st->dc_re = g.dcr_c; st->dc_im = g.dci_c; st->win_seq = g.win_seq; st->dc_index = g.dc_index;
-      if (a.mode == 0) {
-        const int before = (pos0 > 0) ? a.wcount[row] : 0;   // windows recorded by earlier chunks
-        const int tot = before + g.n_complete;
-        a.wcount[row] = (tot < a.wmax) ? tot : a.wmax;
-      } else {
-        a.io[1] = g.written;
-      }
+      if (a.mode != 0) a.io[1] = g.written;
+    }
+    if (a.mode == 0) {
+      const int before = (pos0 > 0) ? wv::uniform(a.wcount[row]) : 0;   // windows recorded by earlier chunks
+      int tot = before + g.n_complete;
+      tot = (tot < a.wmax) ? tot : a.wmax;
+      if (lane == 0) a.wcount[row] = tot;
+      gate_flat_lists(a, row, before, tot - before, lane);
     }
   } else {
     // ================= consumer: the edge / pulse / window state machine ============================================
@@ -1029,6 +1115,7 @@ RFID_DEVICE void gate_scan_body(const GateArgs &a) {
       // (waits until step k went through the producer wave)
       gate_consume(a, g, &sh.slots[k % GATE_SLOTS], &sh.slots[(k + 1) % GATE_SLOTS], nx, &sh.prod_seq, k, 64 * k, n, lane);
       wv::lds_store(&sh.fsm_seq, k + 1, lane);   // step k handed to the back wave
+      wv::lds_prefetch_wait<2>(nx.sq, nx.amp, nx.d);   // the slot of step k + 1, fetched when this step began: two LDS stores since
     }
     wv::lds_store(&sh.fsm_done, 1, lane);
     if (g.stop) wv::lds_store(&sh.stop, 1, lane);
@@ -1750,6 +1837,7 @@ struct StatsArgs {
 // counting, each wave over its own contiguous share of the windows (a trace may hold hundreds of thousands: a one-lane
 // replay cost 40 ms for the 320 000 windows of a 10 000-round inventory, one wave 4 ms).
 constexpr int STATS_MAX_WAVES = 16;
+constexpr int STATS_UNROLL = 4;
 RFID_KERNEL(64 * STATS_MAX_WAVES) void stream_stats_kernel(StatsArgs a) {
   RFID_SHARED int hist[256];
   RFID_SHARED int first[256];      // index of the first CRC-verified read of each tag id
@@ -1769,16 +1857,25 @@ RFID_KERNEL(64 * STATS_MAX_WAVES) void stream_stats_kernel(StatsArgs a) {
   const int seg = (((nw + nwv - 1) / nwv) + 63) & ~63;            // windows per wave
   const int k0 = wave * seg, k1 = (k0 + seg < nw) ? (k0 + seg) : nw;
   // ---- pass 1: first reads of every id; EPC windows per wave ----
+  // (four 64-window batches per turn, their loads in flight together: with few long traces a wave walks tens of
+  // thousands of 48-byte records and is bound by the latency of one batch after the other)
   int epc_mine = 0;
-  for (int base = k0; base < k1; base += 64) {
-    const int k = base + lane;
-    int v = 0;
-    if (k < k1) {
-      const rfid_decode_result &r = rs[k];
-      v = (r.type & 1) | ((r.crc_ok & 1) << 1) | ((r.tag_id & 255) << 2);
-      if ((v & 3) == 3) wv::atomic_min(&first[(v >> 2) & 255], k);
+  for (int base = k0; base < k1; base += 64 * STATS_UNROLL) {
+    int v[STATS_UNROLL];
+#pragma unroll
+    for (int u = 0; u < STATS_UNROLL; ++u) {
+      const int k = base + 64 * u + lane;
+      v[u] = 0;
+      if (k < k1) {
+        const rfid_decode_result &r = rs[k];
+        v[u] = (r.type & 1) | ((r.crc_ok & 1) << 1) | ((r.tag_id & 255) << 2);
+      }
     }
-    epc_mine += wv::popc64(wv::ballot((v & 1) != 0));
+#pragma unroll
+    for (int u = 0; u < STATS_UNROLL; ++u) {
+      if ((v[u] & 3) == 3) wv::atomic_min(&first[(v[u] >> 2) & 255], base + 64 * u + lane);
+      epc_mine += wv::popc64(wv::ballot((v[u] & 1) != 0));
+    }
   }
   if (lane == 0) epc_cnt[wave] = epc_mine;
   wv::block_sync();
@@ -1833,16 +1930,23 @@ RFID_KERNEL(64 * STATS_MAX_WAVES) void stream_stats_kernel(StatsArgs a) {
   // ---- pass 2: counts over the windows before the cut-off ----
   int n_epc = 0, n_ok = 0;
   const int k1t = (k1 < k_term) ? k1 : k_term;
-  for (int base = k0; base < k1t; base += 64) {
-    const int k = base + lane;
-    int v = 0;
-    if (k < k1t) {
-      const rfid_decode_result &r = rs[k];
-      v = (r.type & 1) | ((r.crc_ok & 1) << 1) | ((r.tag_id & 255) << 2);
-      if ((v & 3) == 3) wv::atomic_add(&hist[(v >> 2) & 255], 1);   // tag_decoder_impl.cc:356-364
+  for (int base = k0; base < k1t; base += 64 * STATS_UNROLL) {
+    int v[STATS_UNROLL];
+#pragma unroll
+    for (int u = 0; u < STATS_UNROLL; ++u) {
+      const int k = base + 64 * u + lane;
+      v[u] = 0;
+      if (k < k1t) {
+        const rfid_decode_result &r = rs[k];
+        v[u] = (r.type & 1) | ((r.crc_ok & 1) << 1) | ((r.tag_id & 255) << 2);
+      }
     }
-    n_epc += wv::popc64(wv::ballot((v & 1) != 0));
-    n_ok += wv::popc64(wv::ballot((v & 3) == 3));                     // :346
+#pragma unroll
+    for (int u = 0; u < STATS_UNROLL; ++u) {
+      if ((v[u] & 3) == 3) wv::atomic_add(&hist[(v[u] >> 2) & 255], 1);   // tag_decoder_impl.cc:356-364
+      n_epc += wv::popc64(wv::ballot((v[u] & 1) != 0));
+      n_ok += wv::popc64(wv::ballot((v[u] & 3) == 3));                     // :346
+    }
   }
   if (lane == 0) { wv::atomic_add(&sh_nepc, n_epc); wv::atomic_add(&sh_nok, n_ok); }
   wv::block_sync();

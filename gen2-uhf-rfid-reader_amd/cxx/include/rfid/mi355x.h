@@ -50,6 +50,8 @@ RFID_BLOCK_API rfid_ctx *current_context();
 // available until nothing moves (the reference's README recommends GR_SCHEDULER=STS, README.md:40)
 class RFID_BLOCK_API sts_flowgraph {
  public:
+  // mf may be null: the flowgraph of apps/reader.py as it stands, whose matched filter is GNU Radio's own block -- run()
+  // is then handed that filter's OUTPUT (400 ksps) and feeds the gate with it
   sts_flowgraph(matched_filter::sptr mf, gate::sptr g, tag_decoder::sptr d, reader::sptr r, int chunk = 8192);
   void run(const gr_complex *samples, size_t n);
   long windows_decoded() const { return d_windows; }

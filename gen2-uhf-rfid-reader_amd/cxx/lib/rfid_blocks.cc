@@ -7,6 +7,9 @@
 // The matched filter switches the library's look-ahead on (rfid_lookahead_enable): its general_work() then runs the
 // whole chain for the buffer on the device and the gate / tag_decoder calls are answered from what that left on the
 // host -- same counts, same bytes, ~6 device round trips per inventory slot less (RFID_LOOKAHEAD=0: off).
+// A gate WITHOUT a matched_filter block of this library in front of it -- apps/reader.py:75 as it stands instantiates
+// GNU Radio's own filter.fir_filter_ccc -- switches the look-ahead on keyed on its own input
+// (rfid_lookahead_enable_gate): gate -> tag_decoder over every buffer it is shown, in one submission.
 #include <rfid/mi355x.h>
 
 #include <cstdio>
@@ -109,6 +112,13 @@ class gate_impl : public gate {
   int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
                    gr_vector_void_star &output_items) override {
     const int n_items = std::min(ninput_items[0], noutput_items);   // lib/gate_impl.cc:91
+    if (!d_started) {
+      d_started = true;
+      // no matched_filter block of this library feeds this gate (it would have switched the look-ahead on itself): the
+      // filter is somebody else's, the look-ahead is keyed on the gate's input
+      if (!d_stream->has_filter && env_int("RFID_LOOKAHEAD", 1) != 0)
+        d_stream->check(rfid_lookahead_enable_gate(d_stream->ctx, std::max(n_items, 16384)), "rfid_lookahead_enable_gate");
+    }
     const GATE_STATUS before = d_stream->mirror.gate_status;
     int consumed = 0, written = 0;
     d_stream->check(rfid_gate_work(d_stream->ctx, (const rfid_cf32 *)input_items[0], n_items, (rfid_cf32 *)output_items[0],
@@ -132,6 +142,7 @@ class gate_impl : public gate {
     return written;           // :199
   }
   stream_sptr d_stream;
+  bool d_started = false;
 };
 
 // ---- tag_decoder ------------------------------------------------------------------------------------
@@ -279,9 +290,17 @@ void sts_flowgraph::reader_until_idle(int n_items) {
 }
 
 void sts_flowgraph::run(const gr_complex *samples, size_t n) {
+  d_flushed = false; d_idle_calls = 0;   // (a flowgraph may be run again)
+  // this flowgraph's own stream (not "the most recent gate of the thread": two flowgraphs may live on one thread)
+  gate_impl *own_gate = dynamic_cast<gate_impl *>(d_gate.get());
+  rfid_ctx *own_ctx = own_gate ? own_gate->d_stream->ctx : current_context();
+  const size_t in_per_out = d_mf ? 5 : 1;   // without a matched_filter block `samples` are filter OUTPUTS (a filter of the caller's)
   reader_until_idle(0);   // START -> SEND_QUERY -> IDLE
   // the buffers between the blocks: read positions move, the data does not (it is dropped when a buffer has been read up)
-  std::vector<gr_complex> gq, dq, mf_out((size_t)d_chunk + 8), gate_out((size_t)d_chunk);
+  // (a gate fed by somebody else's filter is shown what it has not consumed yet AND what came in since, as a scheduler's
+  // buffer does: up to two chunks)
+  const size_t gate_view = d_mf ? (size_t)d_chunk : 2 * (size_t)d_chunk;
+  std::vector<gr_complex> gq, dq, mf_out((size_t)d_chunk + 8), gate_out(gate_view);
   size_t g_rd = 0, d_rd = 0;
   size_t pos = 0;
   gr_vector_int g_nin(1, 0), d_nin(1, 0);                       // (the per-call argument vectors, made once)
@@ -289,20 +308,26 @@ void sts_flowgraph::run(const gr_complex *samples, size_t n) {
   gr_vector_void_star g_out(1, nullptr), d_out(2, nullptr);
   while (pos < n || g_rd < gq.size()) {
     if (pos < n) {
-      const size_t take = (n - pos < (size_t)d_chunk * 5) ? (n - pos) : (size_t)d_chunk * 5;
-      gr_vector_int nin(1, (int)take);
-      gr_vector_const_void_star in(1, samples + pos);
-      gr_vector_void_star out(1, mf_out.data());
-      d_mf->minirt_begin_work();
-      const int produced = d_mf->general_work((int)mf_out.size(), nin, in, out);
+      const size_t take = (n - pos < (size_t)d_chunk * in_per_out) ? (n - pos) : (size_t)d_chunk * in_per_out;
       if (g_rd > 0) { gq.erase(gq.begin(), gq.begin() + (long)g_rd); g_rd = 0; }
-      gq.insert(gq.end(), mf_out.begin(), mf_out.begin() + produced);
-      if (d_keep_taps) d_tap_mf.insert(d_tap_mf.end(), mf_out.begin(), mf_out.begin() + produced);
-      pos += (size_t)d_mf->minirt_consumed();
+      if (d_mf) {
+        gr_vector_int nin(1, (int)take);
+        gr_vector_const_void_star in(1, samples + pos);
+        gr_vector_void_star out(1, mf_out.data());
+        d_mf->minirt_begin_work();
+        const int produced = d_mf->general_work((int)mf_out.size(), nin, in, out);
+        gq.insert(gq.end(), mf_out.begin(), mf_out.begin() + produced);
+        if (d_keep_taps) d_tap_mf.insert(d_tap_mf.end(), mf_out.begin(), mf_out.begin() + produced);
+        pos += (size_t)d_mf->minirt_consumed();
+      } else {   // the upstream filter's output buffer
+        gq.insert(gq.end(), samples + pos, samples + pos + take);
+        if (d_keep_taps) d_tap_mf.insert(d_tap_mf.end(), samples + pos, samples + pos + take);
+        pos += take;
+      }
     }
     while (g_rd < gq.size()) {
       const size_t have = gq.size() - g_rd;
-      const int avail = (int)(have < (size_t)d_chunk ? have : (size_t)d_chunk);
+      const int avail = (int)(have < gate_view ? have : gate_view);
       g_nin[0] = avail; g_in[0] = gq.data() + g_rd; g_out[0] = gate_out.data();
       d_gate->minirt_begin_work();
       const int written = d_gate->general_work(avail, g_nin, g_in, g_out);
@@ -327,7 +352,7 @@ void sts_flowgraph::run(const gr_complex *samples, size_t n) {
         if (pos < n) break;
         if (!d_flushed) {
           d_flushed = true;
-          if (rfid_ctx *ctx = current_context()) (void)rfid_lookahead_flush(ctx);
+          if (own_ctx) (void)rfid_lookahead_flush(own_ctx);
           continue;
         }
         if (++d_idle_calls > 4) { g_rd = gq.size(); break; }

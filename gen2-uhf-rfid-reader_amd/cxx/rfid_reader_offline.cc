@@ -12,6 +12,11 @@
 //                       [--gate-out FILE]  gated samples, complex64            (file_sink_gate, :70)
 //                       [--whole-chain N]  instead of block-by-block calls: rfid_stream_work, N raw samples per call
 //                                          (matched filter -> gate -> tag_decoder in one submission, state on the device)
+//                       [--host-fir]       apps/reader.py as it stands: the matched filter is NOT a block of this library (there
+//                                          it is GNU Radio's filter.fir_filter_ccc, apps/reader.py:75) -- here a plain host loop
+//                                          over the whole file, y[n] = sum_{k=0..24} x[5n-24+k], k ascending -- and only
+//                                          gate, tag_decoder and reader are made; the gate is fed the filter's output
+//                                          buffer by buffer
 //                       [--time]           print the run's wall time and rate to stderr
 //
 // TRACE_FILE: headerless little-endian interleaved float32 I,Q at 2 Msps (apps/reader.py:102).
@@ -37,7 +42,7 @@ int main(int argc, char **argv) {
   const char *path = nullptr, *tx_path = nullptr, *mf_path = nullptr, *gate_path = nullptr;
   int device = 0, chunk = 8192;
   long whole_chain = 0;
-  bool show_time = false;
+  bool show_time = false, host_fir = false;
   int fixed_q = gr::rfid::FIXED_Q, max_q = gr::rfid::MAX_NUM_QUERIES, uniq = gr::rfid::NUMBER_UNIQUE_TAGS;
   for (int i = 1; i < argc; ++i) {
     auto need = [&](const char *flag) -> const char * {
@@ -54,6 +59,7 @@ int main(int argc, char **argv) {
     else if (!std::strcmp(argv[i], "--gate-out")) gate_path = need("--gate-out");
     else if (!std::strcmp(argv[i], "--whole-chain")) whole_chain = std::atol(need("--whole-chain"));
     else if (!std::strcmp(argv[i], "--time")) show_time = true;
+    else if (!std::strcmp(argv[i], "--host-fir")) host_fir = true;
     else if (argv[i][0] == '-') { std::cerr << "unknown option " << argv[i] << "\n"; return 2; }
     else path = argv[i];
   }
@@ -92,8 +98,29 @@ int main(int argc, char **argv) {
     const int decim = 5;
     const std::vector<gr_complex> num_taps(25, gr_complex(1.0f, 0.0f));
     // blocks of apps/reader.py:75-78, same order, same arguments (the gate owns the shared reader state)
-    matched_filter::sptr mf = matched_filter::make(decim, num_taps);   // (built before the gate, as at :75)
+    matched_filter::sptr mf;
+    std::vector<gr_complex> y_host;
+    double fir_secs = 0.0;
+    if (host_fir) {
+      // somebody else's filter (apps/reader.py:75: filter.fir_filter_ccc(decim, num_taps)): history of 24 zeros, one output
+      // per complete group of 5 inputs, taps all one -- summed in tap order
+      const auto f0 = std::chrono::steady_clock::now();
+      const size_t n_out = samples.size() / (size_t)decim;
+      y_host.resize(n_out);
+      const gr_complex *x = samples.data();
+      for (size_t n = 0; n < n_out; ++n) {
+        float re = 0.0f, im = 0.0f;
+        const long first = (long)(5 * n) - 24;
+        for (long k = first < 0 ? -first : 0; k < 25; ++k) { re = re + x[first + k].real(); im = im + x[first + k].imag(); }
+        y_host[n] = gr_complex(re, im);
+      }
+      fir_secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - f0).count();
+    } else {
+      mf = matched_filter::make(decim, num_taps);   // (built before the gate, as at :75)
+    }
+    const auto c0 = std::chrono::steady_clock::now();
     gate::sptr gate_blk = gate::make(int(adc_rate / decim));
+    const double make_secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
     tag_decoder::sptr dec = tag_decoder::make(int(adc_rate / decim));
     reader::sptr reader_blk = reader::make(int(adc_rate / decim), int(dac_rate));
     mi355x::sts_flowgraph tb(mf, gate_blk, dec, reader_blk, chunk);
@@ -104,6 +131,7 @@ int main(int argc, char **argv) {
     if (whole_chain > 0) {
       // the same blocks' stream, fed chunk by chunk through the whole-chain call of the C-ABI
       rfid_ctx *ctx = mi355x::current_context();
+      if ((size_t)whole_chain > samples.size()) whole_chain = (long)samples.size();   // (no staging for more than the file holds)
       if (whole_chain < 200000) whole_chain = 200000;
       int st = rfid_stream_begin(ctx, whole_chain);
       if (st != RFID_OK) throw mi355x::error(st, std::string("rfid_stream_begin: ") + rfid_last_error(ctx));
@@ -126,6 +154,9 @@ int main(int argc, char **argv) {
         pos += n;
       }
       rfid_stream_end(ctx);
+    } else if (host_fir) {
+      tb.run(y_host.data(), y_host.size());
+      n_windows = tb.windows_decoded();
     } else {
       tb.run(samples.data(), samples.size());
       n_windows = tb.windows_decoded();
@@ -133,9 +164,11 @@ int main(int argc, char **argv) {
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     reader_blk->print_results();   // apps/reader.py:130
     if (show_time)
-      std::cerr << "rfid_reader_offline: " << samples.size() << " raw samples, " << n_windows << " windows in " << secs * 1e3
+      std::cerr << "rfid_reader_offline: gate::make (the context) " << make_secs * 1e3 << " ms; " << samples.size() << " raw samples, " << n_windows << " windows in " << secs * 1e3
                 << " ms = " << (double)samples.size() / secs / 1e6 << " Msamples/s ("
-                << (whole_chain > 0 ? "whole-chain calls" : "block-by-block calls") << ")\n";
+                << (whole_chain > 0 ? "whole-chain calls" : host_fir ? "block-by-block calls, gate / tag_decoder / reader only; the host's own FIR loop took "
+                                                                      + std::to_string(fir_secs * 1e3) + " ms before that"
+                                                                    : std::string("block-by-block calls")) << ")\n";
     if (getenv("RFID_PRINT_READER_STATE"))   // the reference's global, for tests of the mirror
       std::cout << "reader_state: n_queries_sent=" << reader_state->reader_stats.n_queries_sent
                 << " n_epc_correct=" << reader_state->reader_stats.n_epc_correct

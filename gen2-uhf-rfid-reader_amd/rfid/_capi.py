@@ -103,6 +103,9 @@ SIGNATURES = {
     "rfid_stream_work": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _i64, C.POINTER(C.c_int64)]),
     "rfid_stream_end": (_i, [_vp]),
     "rfid_lookahead_enable": (_i, [_vp, _i64]),
+    "rfid_lookahead_enable_gate": (_i, [_vp, _i64]),
+    "rfid_lookahead_pending": (_i, [_vp, _ip, _ip]),
+    "rfid_abi_version": (_i, []),
     "rfid_lookahead_flush": (_i, [_vp]),
     "rfid_host_alloc": (_vp, [C.c_size_t]),
     "rfid_host_free": (None, [_vp]),

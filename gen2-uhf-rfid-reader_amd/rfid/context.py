@@ -130,6 +130,21 @@ class Context:
     def lookahead_enable(self, max_chunk_raw: int) -> None:
         """The per-block calls (mf_work / gate_work / decoder_work) answered from one whole-chain pass per mf_work call."""
         self._chk(self._lib.rfid_lookahead_enable(self._h, int(max_chunk_raw)))
+        self._planned = (1, int(max_chunk_raw))   # (the look-ahead runs on a one-trace plan of its own: any batch plan is gone)
+        self._active = 1
+
+    def lookahead_enable_gate(self, max_items: int) -> None:
+        """The same keyed on the gate's input (a flowgraph whose matched filter is not this library's): gate_work uploads
+        what is new in its input and runs gate -> tag_decoder over it in one submission."""
+        self._chk(self._lib.rfid_lookahead_enable_gate(self._h, int(max_items)))
+        self._planned = (1, 5 * int(max_items))   # (the look-ahead runs on a one-trace plan of its own: any batch plan is gone)
+        self._active = 1
+
+    def lookahead_pending(self):
+        """-> (windows found and not yet handed out by gate_work, windows handed out and waiting for decoder_work)."""
+        a, b = C.c_int(0), C.c_int(0)
+        self._chk(self._lib.rfid_lookahead_pending(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def lookahead_flush(self) -> None:
         """End of the input: what the look-ahead still holds back is decided now (the gate / decoder calls hand it out)."""

@@ -40,6 +40,7 @@ extern "C" {
 #endif
 
 #define RFID_API __attribute__((visibility("default")))
+#define RFID_MI355X_ABI 4   /* see rfid_abi_version() */
 
 typedef enum rfid_status {
   RFID_OK = 0,
@@ -167,6 +168,9 @@ RFID_API int rfid_ctx_reset(rfid_ctx *ctx);
 RFID_API const char *rfid_strerror(int status);
 RFID_API const char *rfid_last_error(const rfid_ctx *ctx);
 RFID_API const char *rfid_version(void);
+/* RFID_MI355X_ABI of the library that was loaded: it changes whenever a struct of this header changes size or layout
+ * (4: rfid_ls_report has 13 fields since round 3).  A caller built against another value must not pass structs. */
+RFID_API int rfid_abi_version(void);
 /* device self-test of the wave-level primitives the kernels rely on (DPP wave shift,
  * IEEE division, double sqrt).  0 = all good, >0 = number of failing checks. */
 RFID_API int rfid_selftest(rfid_ctx *ctx, int *n_failed);
@@ -209,6 +213,20 @@ RFID_API int rfid_decoder_work(rfid_ctx *ctx, const rfid_cf32 *in, int n_in, flo
  * sequential scan, up to one EPC window before its end).  max_chunk_raw: the largest n_in rfid_mf_work will see.  Call
  * before the first sample; rfid_ctx_reset switches it off. */
 RFID_API int rfid_lookahead_enable(rfid_ctx *ctx, int64_t max_chunk_raw);
+/* The same look-ahead keyed on the GATE's input, for a flowgraph whose matched filter is not this library's --
+ * apps/reader.py:75 instantiates GNU Radio's own filter.fir_filter_ccc, so with that file unchanged the first buffer
+ * this library sees is the gate's (apps/reader.py:76,106-107).  rfid_gate_work then uploads whatever part of its input
+ * the device has not seen yet (a scheduler shows unconsumed samples again; the new ones lie behind them), runs
+ * gate -> tag_decoder over it in one submission from the carried state, and answers this and the following gate /
+ * decoder calls from the cache, exactly as above (same consume / produce counts, outputs and READER_STATE transitions,
+ * same rules for what is undecided, rfid_lookahead_flush at the end of the input).  There is no restriction on where the
+ * gate's input comes from; rfid_mf_work is not to be called on such a context.  max_items: decimated samples the device
+ * takes per call at most (a larger call is taken in parts).  Call before the first sample. */
+RFID_API int rfid_lookahead_enable_gate(rfid_ctx *ctx, int64_t max_items);
+/* windows the look-ahead holds: found by the passes and not yet (completely) handed out by rfid_gate_work /
+ * handed out and waiting for their rfid_decoder_work call (a decoder call retires its window whether or not it asks for
+ * scores).  Both stay small in a running flowgraph. */
+RFID_API int rfid_lookahead_pending(const rfid_ctx *ctx, int *gate_windows, int *decoder_windows);
 /* End of the input (a file source has run dry): everything still held back is decided now; the gate / decoder / reader
  * calls that follow hand it out.  rfid_mf_work fails with RFID_ERR_STATE afterwards.  No-op without look-ahead.  A
  * flowgraph that never calls it leaves the last <= 20 ms of signal undecided. */

@@ -13,6 +13,7 @@ for rounds in (71, 2000):
     rfid.batch.write_trace_file(path, t)
     tt = oracle.time_trace(t, reps=3, cfg=oracle.config(max_num_queries=1 << 30))
     print("%d rounds, %d raw samples: oracle on one core %.1f Msamples/s" % (rounds, len(t), 3 * len(t) / tt["total_s"] / 1e6))
-    for extra, la in (([], "1"), (["--chunk", "65536"], "1"), (["--chunk", "65536"], "0"), (["--chunk", "262144"], "1"), (["--whole-chain", "4000000"], "1"), (["--whole-chain", "32000000"], "1")):
+    for extra, la in (([], "1"), ([], "0"), (["--chunk", "65536"], "1"), (["--chunk", "65536"], "0"), (["--chunk", "262144"], "1"), (["--whole-chain", "4000000"], "1"), (["--whole-chain", "32000000"], "1"),
+                      (["--host-fir"], "1"), (["--host-fir", "--chunk", "65536"], "1"), (["--host-fir", "--chunk", "65536"], "0")):
         out = subprocess.run([exe, path, "--time", "--max-queries", "100000000"] + extra, capture_output=True, text=True, timeout=600, env=dict(os.environ, RFID_LOOKAHEAD=la))
-        print("   ", " ".join(extra) or "(default --chunk 8192)", "look-ahead" if la == "1" else "no look-ahead", "->", out.stderr.strip().split("windows in ")[-1], "|", out.stdout.split("\n")[5] if out.returncode == 0 else out.stderr)
+        print("   ", " ".join(extra) or "(default --chunk 8192)", "look-ahead" if la == "1" else "no look-ahead", "->", out.stderr.strip().split("rfid_reader_offline: ")[-1], "|", out.stdout.split("\n")[5] if out.returncode == 0 else out.stderr)

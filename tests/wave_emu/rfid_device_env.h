@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <stdint.h>
+#include "rfid_mi355x.h"
 #include <string.h>
 #include <ucontext.h>
 
@@ -186,6 +187,25 @@ static inline int lds_load(const int *p) { return (int)(uint32_t)emu::exchange((
 static inline int lds_peek(const int *p) { return *(const volatile int *)p; }
 static inline void lds_store(int *p, int v, int lane) { emu::wave_barrier(); if (lane == 0) *(volatile int *)p = v; }
 static inline uint64_t lds_load64(const uint64_t *p) { return emu::exchange(*(const volatile uint64_t *)p)[0]; }
+static inline void lds_store_rec(int *p, int w0, uint64_t m, int lane) {
+  emu::wave_barrier();
+  if (lane == 0) {
+    volatile uint32_t *q = (volatile uint32_t *)p;
+    q[0] = (uint32_t)w0; q[1] = 0u; q[2] = (uint32_t)m; q[3] = (uint32_t)(m >> 32);
+  }
+}
+static inline void lds_load_rec(const int *p, int &w0, uint64_t &m) {
+  w0 = lds_load(p); m = lds_load64((const uint64_t *)(p + 2));
+}
+static inline void lds_prefetch(const int *seq, const float *pair, int &sq, float &a, float &b) {
+  sq = *(const volatile int *)seq; a = *(const volatile float *)pair; b = *(const volatile float *)(pair + 64);
+}
+template <int N> static inline void lds_prefetch_wait(int &, float &, float &) {}
+static inline float2 lds_sum25_in_order(const float2 *p) {
+  float re = 0.0f, im = 0.0f;
+  for (int k = 0; k < 25; ++k) { re = re + p[k].x; im = im + p[k].y; }
+  return make_float2(re, im);
+}
 static inline void lds_store_desc(int *p, int flags, int nvalid, uint64_t m0, uint64_t m1, int info, int lane) {
   emu::wave_barrier();
   if (lane == 0) {
@@ -200,6 +220,7 @@ static inline void lds_load_desc(const int *p, int &flags, int &nvalid, uint64_t
   info = lds_load(p + 6);
 }
 static inline void set_priority_high() {}
+template <int P> static inline void set_priority() {}
 static inline void backoff() { emu::yield(); }
 static inline int atomic_add(int *p, int v) { int o = *p; *p = o + v; return o; }
 static inline int atomic_min(int *p, int v) { int o = *p; if (v < o) *p = v; return o; }
@@ -210,5 +231,7 @@ static inline void atomic_or64(uint64_t *p, uint64_t v) { *p |= v; }
 static inline void atomic_and64(uint64_t *p, uint64_t v) { *p &= v; }
 static inline void global_release() {}
 static inline float2 load_coherent(const float2 *p) { return *p; }
+static inline int load_coherent_i32(const int *p) { return *p; }
+static inline rfid_window load_coherent_window(const rfid_window *p) { return *p; }
 
 }  // namespace wv
