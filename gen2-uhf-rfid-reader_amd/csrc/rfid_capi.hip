@@ -55,6 +55,7 @@ struct rfid_ctx {
   rfid_reader_state rs;
 
   // ---- streaming ----
+  void *d_small = nullptr;        // one allocation behind the small buffers below
   GateState *d_gate1 = nullptr;   // gate state of the single streaming RX stream
   int *d_io = nullptr;            // [2]
   DevBuf s_in, s_out;
@@ -193,6 +194,7 @@ struct rfid_ctx {
   const int64_t *d_lens = nullptr;  // of the last rfid_batch_mf
   int64_t last_n_raw = 0;
   int decode_grid = 0;
+  int n_cus = 256;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool ev_valid[5] = {false, false, false, false, false};
   // overlapped front end: matched filter on `stream`, gate scan on `stream2`, time-chunked
@@ -211,9 +213,15 @@ struct rfid_ctx {
     rfid_stream_stats *d_stats = nullptr;
   } alt;
   bool alt_have = false;
+  void *plan_blk = nullptr, *alt_blk = nullptr;   // the two allocations behind the plan's buffers (rfid_batch_plan)
   hipEvent_t ev_fe_done = nullptr, ev_tail_done[2] = {nullptr, nullptr};
   bool tail_recorded[2] = {false, false};   // ev_tail_done[i] has been recorded (set i's decoder / statistics were enqueued on stream2)
   int set_idx = 0;                          // which of the two sets c->d_* currently name
+  // (long-stream passes: only the matched-filter output alternates -- the filter of pass k + 1 beside the front end of pass k)
+  void *alt_y_blk = nullptr;                // a second matched-filter output buffer alone (plans too small for a whole second set)
+  hipEvent_t ev_y_free[2] = {nullptr, nullptr};
+  bool y_recorded[2] = {false, false};
+  int y_idx = 0;
   hipStream_t tail_stream = nullptr;        // where rfid_batch_decode / rfid_batch_stats enqueue (c->stream, or stream2 in an overlapped pass)
   int n_chunks_last = 0;   // > 0 when the last pass used the overlapped path
   int fused_last = 0;      // 1 when the last rfid_batch_process pass used front_end_fused_kernel
@@ -299,16 +307,15 @@ void init_reader_state(rfid_ctx *c) {  // global_vars.cc:34-54
 }
 
 void free_plan(rfid_ctx *c) {
-  void *ptrs[] = {c->d_y, c->d_gstate, c->d_wtab, c->d_flat, c->d_wcount, c->d_flat_count,
-                  c->d_res, c->d_scores, c->d_stats};
-  for (void *p : ptrs)
-    if (p) (void)hipFree(p);
+  if (c->plan_blk) (void)hipFree(c->plan_blk);
+  if (c->alt_blk) (void)hipFree(c->alt_blk);
+  if (c->alt_y_blk) (void)hipFree(c->alt_y_blk);
+  c->plan_blk = nullptr; c->alt_blk = nullptr; c->alt_y_blk = nullptr;
+  c->y_recorded[0] = c->y_recorded[1] = false;
+  c->y_idx = 0;
   c->d_y = nullptr; c->d_gstate = nullptr; c->d_wtab = nullptr; c->d_flat = nullptr;
   c->d_wcount = nullptr; c->d_flat_count = nullptr; c->d_res = nullptr; c->d_scores = nullptr;
   c->d_stats = nullptr;
-  void *aptrs[] = {c->alt.d_y, c->alt.d_wtab, c->alt.d_flat, c->alt.d_wcount, c->alt.d_flat_count, c->alt.d_res, c->alt.d_stats};
-  for (void *p : aptrs)
-    if (p) (void)hipFree(p);
   c->alt = rfid_ctx::ResultSet();
   c->alt_have = false;
   c->tail_recorded[0] = c->tail_recorded[1] = false;
@@ -624,10 +631,26 @@ int rfid_ctx_create(const rfid_params *p, int device, rfid_ctx **out) {
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return RFID_ERR_NO_DEVICE;
   if (device < 0 || device >= n_dev) return RFID_ERR_NO_DEVICE;
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return RFID_ERR_NO_DEVICE;
-  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return RFID_ERR_NO_DEVICE;
+  // (the device's properties are looked up once per process: the query costs milliseconds)
+  static pthread_mutex_t prop_mu = PTHREAD_MUTEX_INITIALIZER;
+  static struct { bool known, gfx950; int cus; } dev_info[64];
+  bool is_gfx950 = false;
+  if (device < 64) {
+    pthread_mutex_lock(&prop_mu);
+    if (!dev_info[device].known) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        dev_info[device].known = true;
+        dev_info[device].gfx950 = strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+        dev_info[device].cus = prop.multiProcessorCount;
+      }
+    }
+    is_gfx950 = dev_info[device].known && dev_info[device].gfx950;
+    pthread_mutex_unlock(&prop_mu);
+  }
+  if (!is_gfx950) return RFID_ERR_NO_DEVICE;
   rfid_ctx *c = new (std::nothrow) rfid_ctx();
+  if (c) c->n_cus = dev_info[device].cus;
   if (!c) return RFID_ERR_CAPACITY;
   c->prm = *p;
   c->device = device;
@@ -649,24 +672,30 @@ int rfid_ctx_create(const rfid_params *p, int device, rfid_ctx **out) {
     if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { rc = RFID_ERR_HIP; break; }
     for (int i = 0; i <= rfid_ctx::MAX_CHUNKS; ++i) c->ev_mf[i] = nullptr;
     for (int i = 0; i < 2 * rfid_ctx::MAX_CHUNKS; ++i) c->ev_gate[i] = nullptr;
-    for (int i = 0; i <= rfid_ctx::MAX_CHUNKS && !rc; ++i)
-      if (hipEventCreate(&c->ev_mf[i]) != hipSuccess) rc = RFID_ERR_HIP;
-    for (int i = 0; i < 2 * rfid_ctx::MAX_CHUNKS && !rc; ++i)
-      if (hipEventCreate(&c->ev_gate[i]) != hipSuccess) rc = RFID_ERR_HIP;
+    // (ev_mf / ev_gate: the time-chunked front end's, RFID_FRONT_CHUNKS -- made when that path first runs)
     if (!rc && (hipEventCreate(&c->ev_pass) != hipSuccess || hipEventCreate(&c->ev_front_end) != hipSuccess ||
                 hipEventCreateWithFlags(&c->ev_fe_done, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&c->ev_tail_done[0], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&c->ev_tail_done[1], hipEventDisableTiming) != hipSuccess))
+                hipEventCreateWithFlags(&c->ev_tail_done[1], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_y_free[0], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_y_free[1], hipEventDisableTiming) != hipSuccess))
       rc = RFID_ERR_HIP;
     if (rc) break;
-    if (hipMalloc((void **)&c->d_gate1, sizeof(GateState)) != hipSuccess ||
-        hipMalloc((void **)&c->d_io, 2 * sizeof(int)) != hipSuccess ||
-        hipMalloc((void **)&c->d_swin, sizeof(rfid_window)) != hipSuccess ||
-        hipMalloc((void **)&c->d_scount, sizeof(int)) != hipSuccess ||
-        hipMalloc((void **)&c->d_ticket, 2 * sizeof(int)) != hipSuccess ||
-        hipMalloc((void **)&c->d_sres, sizeof(rfid_decode_result)) != hipSuccess ||
-        hipMalloc((void **)&c->d_sscores, sizeof(rfid_scores)) != hipSuccess) { rc = RFID_ERR_HIP; break; }
-    if (hipMemset(c->d_gate1, 0, sizeof(GateState)) != hipSuccess || hipMemset(c->d_ticket, 0, 2 * sizeof(int)) != hipSuccess) { rc = RFID_ERR_HIP; break; }
+    {
+      // the context's small device buffers, carved out of one zeroed allocation (256-byte slots)
+      char *blk = nullptr;
+      const size_t slot = 256, n_slots = 4 + 1 + 1 + 1 + 1 + 1 + 1;   // GateState: 1 016 bytes = 4 slots
+      if (hipMalloc((void **)&blk, slot * n_slots) != hipSuccess || hipMemset(blk, 0, slot * n_slots) != hipSuccess) { rc = RFID_ERR_HIP; c->d_small = blk; break; }
+      static_assert(sizeof(GateState) <= 4 * 256 && sizeof(rfid_scores) <= 256 && sizeof(rfid_decode_result) <= 256, "slots");
+      c->d_small = blk;
+      c->d_gate1 = (GateState *)blk;
+      c->d_io = (int *)(blk + 4 * slot);
+      c->d_swin = (rfid_window *)(blk + 5 * slot);
+      c->d_scount = (int *)(blk + 6 * slot);
+      c->d_ticket = (int *)(blk + 7 * slot);
+      c->d_sres = (rfid_decode_result *)(blk + 8 * slot);
+      c->d_sscores = (rfid_scores *)(blk + 9 * slot);
+    }
   } while (0);
   if (rc != RFID_OK) { rfid_ctx_destroy(c); return rc; }
   // (the cost model behind the automatic choice of the front end is measured on this device when a shape near the
@@ -677,17 +706,16 @@ int rfid_ctx_create(const rfid_params *p, int device, rfid_ctx **out) {
 
 int rfid_ctx_destroy(rfid_ctx *c) {
   if (!c) return RFID_ERR_INVALID;
-  if (getenv("RFID_LA_PROFILE") && g_la_n[0])
+  if (getenv("RFID_LA_PROFILE") && (g_la_n[0] || g_la_n[1]))
     fprintf(stderr, "[la] mf_work %ld calls %.2f ms (upload queued %.2f, pass enqueued %.2f, wait for the filter outputs %.2f, previous pass collected %.2f: of it waiting %.2f) | "
-            "gate_work %ld calls %.2f ms | decoder_work %ld calls %.2f ms | reader_work_tx %ld calls %.2f ms\n",
-            g_la_n[0], g_la_t[0], g_la_t[4], g_la_t[5], g_la_t[8], g_la_t[6], g_la_t[7], g_la_n[1], g_la_t[1], g_la_n[2], g_la_t[2], g_la_n[3], g_la_t[3]);
+            "gate_work %ld calls %.2f ms | decoder_work %ld calls %.2f ms | reader_work_tx %ld calls %.2f ms | lookahead_enable %.2f ms\n",
+            g_la_n[0], g_la_t[0], g_la_t[4], g_la_t[5], g_la_t[8], g_la_t[6], g_la_t[7], g_la_n[1], g_la_t[1], g_la_n[2], g_la_t[2], g_la_n[3], g_la_t[3], g_la_t[9]);
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   la_free(c);
   sio_free(c);
   free_plan(c);
-  void *ptrs[] = {c->d_gate1, c->d_io, c->d_swin, c->d_scount, c->d_ticket, c->d_sres, c->d_sscores, c->s_in.p, c->s_out.p,
-                  c->synth_tab.p, c->ls2_ws.p};
+  void *ptrs[] = {c->d_small, c->s_in.p, c->s_out.p, c->synth_tab.p, c->ls2_ws.p};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->ls2_host) (void)hipHostFree(c->ls2_host);
@@ -702,8 +730,10 @@ int rfid_ctx_destroy(rfid_ctx *c) {
     if (c->ev_pass) (void)hipEventDestroy(c->ev_pass);
     if (c->ev_front_end) (void)hipEventDestroy(c->ev_front_end);
     if (c->ev_fe_done) (void)hipEventDestroy(c->ev_fe_done);
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
       if (c->ev_tail_done[i]) (void)hipEventDestroy(c->ev_tail_done[i]);
+      if (c->ev_y_free[i]) (void)hipEventDestroy(c->ev_y_free[i]);
+    }
     (void)hipStreamDestroy(c->stream2);
   }
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -858,19 +888,27 @@ int rfid_batch_plan(rfid_ctx *c, int n_streams, int64_t max_raw) {
   // B (= "a plan exists") is set only after every allocation succeeded: a failed plan leaves the
   // context unplanned (free_plan), so later rfid_batch_* calls return RFID_ERR_STATE instead of
   // launching on null workspace pointers
+  // one allocation per result set, carved up (256-byte aligned pieces): a plan -- every rfid_stream_begin and
+  // rfid_lookahead_enable makes one -- costs one hipMalloc, not nine
   hipError_t e = hipSuccess;
-  auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 1); };
-  alloc((void **)&c->d_y, sizeof(float2) * (size_t)c->y_stride * n_streams);
-  alloc((void **)&c->d_gstate, sizeof(GateState) * (size_t)n_streams);
-  alloc((void **)&c->d_wtab, sizeof(rfid_window) * (size_t)c->flat_cap);
-  alloc((void **)&c->d_flat, sizeof(rfid_window) * 2 * (size_t)c->flat_cap);
-  alloc((void **)&c->d_wcount, sizeof(int) * (size_t)n_streams);
-  alloc((void **)&c->d_flat_count, 2 * sizeof(int));
-  alloc((void **)&c->d_res, sizeof(rfid_decode_result) * (size_t)c->flat_cap);
-  alloc((void **)&c->d_scores, sizeof(rfid_scores) * (size_t)c->flat_cap);
-  alloc((void **)&c->d_stats, sizeof(rfid_stream_stats) * (size_t)n_streams);
-  if (e == hipSuccess) e = hipMemset(c->d_wcount, 0, sizeof(int) * (size_t)n_streams);
-  if (e == hipSuccess) e = hipMemset(c->d_flat_count, 0, 2 * sizeof(int));
+  auto up256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t sz_y = up256(sizeof(float2) * (size_t)c->y_stride * n_streams), sz_g = up256(sizeof(GateState) * (size_t)n_streams),
+               sz_w = up256(sizeof(rfid_window) * (size_t)c->flat_cap), sz_f = up256(sizeof(rfid_window) * 2 * (size_t)c->flat_cap),
+               sz_c = up256(sizeof(int) * (size_t)n_streams), sz_fc = 256, sz_r = up256(sizeof(rfid_decode_result) * (size_t)c->flat_cap),
+               sz_sc = up256(sizeof(rfid_scores) * (size_t)c->flat_cap), sz_st = up256(sizeof(rfid_stream_stats) * (size_t)n_streams);
+  const size_t sz_set = sz_y + sz_w + sz_f + sz_c + sz_fc + sz_r + sz_st;     // what a result set holds
+  auto bind_set = [&](char *b, float2 *&y, rfid_window *&w, rfid_window *&f, int *&wc, int *&fc, rfid_decode_result *&r, rfid_stream_stats *&st) {
+    y = (float2 *)b; b += sz_y; w = (rfid_window *)b; b += sz_w; f = (rfid_window *)b; b += sz_f; wc = (int *)b; b += sz_c;
+    fc = (int *)b; b += sz_fc; r = (rfid_decode_result *)b; b += sz_r; st = (rfid_stream_stats *)b; b += sz_st;
+    return b;
+  };
+  e = hipMalloc(&c->plan_blk, sz_set + sz_g + sz_sc);
+  if (e == hipSuccess) {
+    char *b = bind_set((char *)c->plan_blk, c->d_y, c->d_wtab, c->d_flat, c->d_wcount, c->d_flat_count, c->d_res, c->d_stats);
+    c->d_gstate = (GateState *)b; b += sz_g;
+    c->d_scores = (rfid_scores *)b;
+    e = hipMemset(c->d_wcount, 0, sz_c + sz_fc);   // (the window counts and, right behind them, the two list counters)
+  }
   if (e != hipSuccess) {
     (void)hipGetLastError();   // clear the sticky allocation error
     free_plan(c);
@@ -885,23 +923,16 @@ int rfid_batch_plan(rfid_ctx *c, int n_streams, int64_t max_raw) {
                         sizeof(rfid_stream_stats) * (size_t)n_streams;
     size_t free_b = 0, total_b = 0;
     if (!(ov && atoi(ov) == 0) && n_streams >= 64 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < free_b / 8) {
-      hipError_t e2 = hipSuccess;
-      auto alloc2 = [&](void **p, size_t bytes) { if (e2 == hipSuccess) e2 = hipMalloc(p, bytes ? bytes : 1); };
-      alloc2((void **)&c->alt.d_y, sizeof(float2) * (size_t)c->y_stride * n_streams);
-      alloc2((void **)&c->alt.d_wtab, sizeof(rfid_window) * (size_t)c->flat_cap);
-      alloc2((void **)&c->alt.d_flat, sizeof(rfid_window) * 2 * (size_t)c->flat_cap);
-      alloc2((void **)&c->alt.d_wcount, sizeof(int) * (size_t)n_streams);
-      alloc2((void **)&c->alt.d_flat_count, 2 * sizeof(int));
-      alloc2((void **)&c->alt.d_res, sizeof(rfid_decode_result) * (size_t)c->flat_cap);
-      alloc2((void **)&c->alt.d_stats, sizeof(rfid_stream_stats) * (size_t)n_streams);
-      if (e2 == hipSuccess) e2 = hipMemset(c->alt.d_wcount, 0, sizeof(int) * (size_t)n_streams);
-      if (e2 == hipSuccess) e2 = hipMemset(c->alt.d_flat_count, 0, 2 * sizeof(int));
+      hipError_t e2 = hipMalloc(&c->alt_blk, sz_set);
+      if (e2 == hipSuccess) {
+        bind_set((char *)c->alt_blk, c->alt.d_y, c->alt.d_wtab, c->alt.d_flat, c->alt.d_wcount, c->alt.d_flat_count, c->alt.d_res, c->alt.d_stats);
+        e2 = hipMemset(c->alt.d_wcount, 0, sz_c + sz_fc);
+      }
       if (e2 == hipSuccess) c->alt_have = true;
       else {
         (void)hipGetLastError();
-        void *aptrs[] = {c->alt.d_y, c->alt.d_wtab, c->alt.d_flat, c->alt.d_wcount, c->alt.d_flat_count, c->alt.d_res, c->alt.d_stats};
-        for (void *p : aptrs)
-          if (p) (void)hipFree(p);
+        if (c->alt_blk) (void)hipFree(c->alt_blk);
+        c->alt_blk = nullptr;
         c->alt = rfid_ctx::ResultSet();
       }
     }
@@ -909,6 +940,16 @@ int rfid_batch_plan(rfid_ctx *c, int n_streams, int64_t max_raw) {
   // the long-stream front end's work space, when this shape can take that path: reserved here so that a planned batch
   // does not meet an allocation in its passes (a pass that finds none falls back to the sequential scan)
   if (ls_may_apply(c, n_streams, n_dec)) {
+    {
+      // ... and a second matched-filter output buffer for the filter of the next pass (unless a whole second set exists, or
+      // this is a stream's own plan: n_dec of a stream call is small and its passes do not overlap)
+      const char *ov = getenv("RFID_OVERLAP");
+      size_t free_b = 0, total_b = 0;
+      if (!c->alt_have && !(ov && atoi(ov) == 0) && sz_y >= ((size_t)16 << 20) && hipMemGetInfo(&free_b, &total_b) == hipSuccess && sz_y < free_b / 8) {
+        if (hipMalloc(&c->alt_y_blk, sz_y) == hipSuccess) c->alt.d_y = (float2 *)c->alt_y_blk;
+        else { (void)hipGetLastError(); c->alt_y_blk = nullptr; }
+      }
+    }
     const size_t need = ls_workspace_bytes(n_streams, n_dec, c->y_stride);
     if (need > c->ls2_ws.cap) {
       if (c->ls2_ws.p) (void)hipFree(c->ls2_ws.p);
@@ -917,10 +958,8 @@ int rfid_batch_plan(rfid_ctx *c, int n_streams, int64_t max_raw) {
       else { (void)hipGetLastError(); c->ls2_ws.p = nullptr; }
     }
   }
-  hipDeviceProp_t prop;
-  HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
   // persistent decoders: the EPC kernel holds 18.6 KiB of LDS per single-wave workgroup -> 8 per CU
-  c->decode_grid = prop.multiProcessorCount * 8;
+  c->decode_grid = c->n_cus * 8;
   for (int i = 0; i < 5; ++i) c->ev_valid[i] = false;
   return RFID_OK;
 }
@@ -933,12 +972,16 @@ int rfid_batch_set_streams(rfid_ctx *c, int n_streams) {
   return RFID_OK;
 }
 
+static int batch_mf_on(rfid_ctx *c, hipStream_t stream, const void *d_raw, int64_t raw_stride, int64_t n_raw, const void *d_lens);
 int rfid_batch_mf(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64_t n_raw, const void *d_lens) {
   if (!c || !d_raw || n_raw < 0 || raw_stride < n_raw) return RFID_ERR_INVALID;
   if (!c->B) return RFID_ERR_STATE;
   if (n_raw > c->max_raw) return RFID_ERR_CAPACITY;
   HIPCHK(c, hipSetDevice(c->device));
   { int rj = join_tails(c); if (rj) return rj; }
+  return batch_mf_on(c, c->stream, d_raw, raw_stride, n_raw, d_lens);
+}
+static int batch_mf_on(rfid_ctx *c, hipStream_t stream, const void *d_raw, int64_t raw_stride, int64_t n_raw, const void *d_lens) {
   c->d_lens = (const int64_t *)d_lens;
   c->last_n_raw = n_raw;
   MfArgs a;
@@ -948,18 +991,18 @@ int rfid_batch_mf(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64_t n_
   a.y = c->d_y; a.y_stride = c->y_stride; a.tile0 = 0; a.stream0 = 0;
   c->n_chunks_last = 0;
   c->fused_last = 0;
-  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  HIPCHK(c, hipEventRecord(c->ev[0], stream));
   const int64_t tiles = (a.n_out + MF_TILE - 1) / MF_TILE;
   if (tiles > 0) {
     for (int s0 = 0; s0 < c->B; s0 += 65535) {   // gridDim.y limit
       a.stream0 = s0;
       const int ns = (c->B - s0 < 65535) ? (c->B - s0) : 65535;
       hipLaunchKernelGGL(mf_boxcar25_decim5_kernel, dim3((unsigned)tiles, (unsigned)ns), dim3(MF_THREADS), 0,
-                         c->stream, a);
+                         stream, a);
       HIPCHK(c, hipGetLastError());
     }
   }
-  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  HIPCHK(c, hipEventRecord(c->ev[1], stream));
   c->ev_valid[0] = c->ev_valid[1] = true;
   return RFID_OK;
 }
@@ -1066,13 +1109,36 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
   if (nch < 2 && ls_applicable(c, c->B, n_out)) {
     // few long traces: matched filter, then the gate scan as the long-stream front end -- every launch of it enqueued
     // here, the sequential scan behind them as the fallback that skips itself when the front end succeeded
-    int rc = rfid_batch_mf(c, d_raw, raw_stride, n_raw, d_lens);
-    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rj = join_tails(c); if (rj) return rj; }
+    int rc;
+    const bool ahead = c->alt.d_y != nullptr;
+    if (ahead) {
+      // The matched filter is bound by the HBM, the long-stream front end behind it by its instruction streams: with a second
+      // matched-filter output buffer the filter of THIS pass runs on stream2 while the front end / decoder / statistics of the
+      // pass before are still at work on the main stream (passes enqueued back to back); the main stream only waits for it.
+      std::swap(c->d_y, c->alt.d_y);
+      c->y_idx ^= 1;
+      if (c->y_recorded[c->y_idx]) {      // the pass before last read this buffer: through with it?
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_y_free[c->y_idx], 0));
+        c->y_recorded[c->y_idx] = false;
+      }
+      if ((rc = batch_mf_on(c, c->stream2, d_raw, raw_stride, n_raw, d_lens))) return rc;
+      HIPCHK(c, hipEventRecord(c->ev_fe_done, c->stream2));
+      HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fe_done, 0));
+    } else if ((rc = batch_mf_on(c, c->stream, d_raw, raw_stride, n_raw, d_lens))) {
+      return rc;
+    }
     int enq = 0;
     if ((rc = ls_enqueue(c, n_out, LsOpts(), &enq))) return rc;
     if ((rc = rfid_batch_gate_impl(c, enq ? &c->d_ls2_ctl->ok : nullptr))) return rc;
     if ((rc = rfid_batch_decode(c, want_scores))) return rc;
-    return rfid_batch_stats(c);
+    if ((rc = rfid_batch_stats(c))) return rc;
+    if (ahead) {
+      HIPCHK(c, hipEventRecord(c->ev_y_free[c->y_idx], c->stream));
+      c->y_recorded[c->y_idx] = true;
+    }
+    return RFID_OK;
   }
   c->d_ls2_ctl = nullptr;   // (this pass does not run the long-stream front end)
   if (nch < 2 && raw_stride >= 2 && !getenv("RFID_FRONT_UNFUSED")) {
@@ -1141,6 +1207,11 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
     return rfid_batch_stats(c);
   }
   HIPCHK(c, hipSetDevice(c->device));
+  { int rj = join_tails(c); if (rj) return rj; }
+  if (!c->ev_mf[0]) {
+    for (int i = 0; i <= rfid_ctx::MAX_CHUNKS; ++i) HIPCHK(c, hipEventCreate(&c->ev_mf[i]));
+    for (int i = 0; i < 2 * rfid_ctx::MAX_CHUNKS; ++i) HIPCHK(c, hipEventCreate(&c->ev_gate[i]));
+  }
   c->d_lens = (const int64_t *)d_lens;
   c->last_n_raw = n_raw;
   const int64_t tiles_per_chunk = (tiles + nch - 1) / nch;
@@ -2355,6 +2426,7 @@ int rfid_lookahead_flush(rfid_ctx *c) {
 }
 
 int rfid_lookahead_enable(rfid_ctx *c, int64_t max_chunk_raw) {
+  LaTimer tm(9);
   if (!c || max_chunk_raw < 1) return RFID_ERR_INVALID;
   if (c->mf_seen != 0) return fail(c, RFID_ERR_STATE, "rfid_lookahead_enable: the stream has started");
   la_free(c);
@@ -2370,6 +2442,7 @@ int rfid_lookahead_enable(rfid_ctx *c, int64_t max_chunk_raw) {
 }
 
 int rfid_lookahead_enable_gate(rfid_ctx *c, int64_t max_items) {
+  LaTimer tm(9);
   if (!c || max_items < 1) return RFID_ERR_INVALID;
   if (c->mf_seen != 0 || c->la.gate_pos != 0) return fail(c, RFID_ERR_STATE, "rfid_lookahead_enable_gate: the stream has started");
   la_free(c);

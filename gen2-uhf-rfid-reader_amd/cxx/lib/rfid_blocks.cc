@@ -221,8 +221,10 @@ class matched_filter_impl : public matched_filter {
     const int n_in = std::min(ninput_items[0], 5 * noutput_items);
     if (!d_started) {
       d_started = true;
+      // the look-ahead's staging is sized for a scheduler buffer of 64 k items (GNU Radio's default is 32 k complex items); a
+      // larger call goes through in pieces inside rfid_mf_work, so a scheduler with bigger buffers cannot make it fail
       if (env_int("RFID_LOOKAHEAD", 1) != 0) {
-        const int64_t cap = std::max<int64_t>(5 * (int64_t)noutput_items, ninput_items[0]) + 64;
+        const int64_t cap = std::max<int64_t>(std::min<int64_t>(std::max<int64_t>(5 * (int64_t)noutput_items, ninput_items[0]), 5 * 262144), 5 * 8192) + 64;
         st.check(rfid_lookahead_enable(st.ctx, cap), "rfid_lookahead_enable");
       }
     }
