@@ -916,13 +916,15 @@ int rfid_batch_plan(rfid_ctx *c, int n_streams, int64_t max_raw) {
   }
   c->B = c->B_plan = n_streams;
   {
-    // the second result set (see rfid_ctx::ResultSet): only where it is small beside what is free -- a batch that fills the
-    // HBM (BASELINE configs[4]) keeps one set and the plain sequence
+    // the second result set (see rfid_ctx::ResultSet): opt-in (RFID_OVERLAP=2) and only where it is small beside what is
+    // free.  Measured on configs[1] (profiles/r04/overlap.txt): the decoder's waves beside the next front end take their
+    // instruction slots from it -- -1.5 % per pass on one box, +3 % on another (a decoder wave that gets to a CU first keeps
+    // the front end's workgroup out until it is through) -- not a default.
     const char *ov = getenv("RFID_OVERLAP");
     const size_t need = sizeof(float2) * (size_t)c->y_stride * n_streams + (sizeof(rfid_window) * 3 + sizeof(rfid_decode_result)) * (size_t)c->flat_cap +
                         sizeof(rfid_stream_stats) * (size_t)n_streams;
     size_t free_b = 0, total_b = 0;
-    if (!(ov && atoi(ov) == 0) && n_streams >= 64 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < free_b / 8) {
+    if (ov && atoi(ov) >= 2 && n_streams >= 64 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < free_b / 8) {
       hipError_t e2 = hipMalloc(&c->alt_blk, sz_set);
       if (e2 == hipSuccess) {
         bind_set((char *)c->alt_blk, c->alt.d_y, c->alt.d_wtab, c->alt.d_flat, c->alt.d_wcount, c->alt.d_flat_count, c->alt.d_res, c->alt.d_stats);

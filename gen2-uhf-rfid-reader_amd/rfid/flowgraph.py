@@ -15,9 +15,25 @@ from . import _capi as capi
 from . import blocks
 
 
+def fir_filter_ccc_ones(x: np.ndarray, decim: int = 5, n_taps: int = 25) -> np.ndarray:
+    """Somebody else's matched filter: what filter.fir_filter_ccc(5, [1]*25) (apps/reader.py:65,75) computes, in plain
+    numpy on the host -- history of n_taps - 1 zeros, one output per complete group of `decim` inputs, the taps (all one)
+    summed in tap order in binary32.  For the flowgraph whose filter is NOT this library's block (external_filter=True)."""
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    n_out = len(x) // decim
+    xp = np.concatenate([np.zeros(n_taps - 1, dtype=np.complex64), x])
+    re = np.zeros(n_out, dtype=np.float32)
+    im = np.zeros(n_out, dtype=np.float32)
+    for k in range(n_taps):
+        seg = xp[k: k + decim * n_out: decim]
+        re = re + seg.real
+        im = im + seg.imag
+    return (re + 1j * im).astype(np.complex64)
+
+
 class reader_top_block:
     def __init__(self, source_path: Optional[str] = None, samples: Optional[np.ndarray] = None,
-                 device: int = 0, chunk: int = 8192, lookahead: bool = False, **params):
+                 device: int = 0, chunk: int = 8192, lookahead: bool = False, external_filter: bool = False, **params):
         # variables of apps/reader.py:52-65
         self.dac_rate = 1e6
         self.adc_rate = 100e6 / 50
@@ -31,14 +47,19 @@ class reader_top_block:
         self.samples = np.ascontiguousarray(samples, dtype=np.complex64)
         # the blocks of apps/reader.py:75-78, in that order and with those arguments (device / params are what
         # the reference fixes at compile time); the gate owns the stream, the others bind to it (rfid/blocks.py)
-        self.matched_filter = blocks.matched_filter(self.decim, self.num_taps)
+        # external_filter: apps/reader.py as it stands -- the matched filter is GNU Radio's own block, not this library's;
+        # here fir_filter_ccc_ones() on the host, and only gate / tag_decoder / reader are made
+        self.external_filter = bool(external_filter)
+        self.matched_filter = None if external_filter else blocks.matched_filter(self.decim, self.num_taps)
         self.gate = blocks.gate(int(self.adc_rate / self.decim), device=device, **params)
         self.tag_decoder = blocks.tag_decoder(int(self.adc_rate / self.decim))
         self.reader = blocks.reader(int(self.adc_rate / self.decim), int(self.dac_rate))
         self.ctx = self.gate.ctx
-        assert self.matched_filter.ctx is self.ctx and self.tag_decoder.ctx is self.ctx and self.reader.ctx is self.ctx
+        assert (external_filter or self.matched_filter.ctx is self.ctx) and self.tag_decoder.ctx is self.ctx and self.reader.ctx is self.ctx
         self.decoded = []        # (result, scores) per decoded window, for inspection
-        if lookahead:            # the library answers the gate / decoder calls from one whole-chain pass per filter call
+        if lookahead and external_filter:   # ... keyed on the gate's own input: gate -> tag_decoder per buffer it is shown
+            self.ctx.lookahead_enable_gate(2 * self.chunk)
+        elif lookahead:          # the library answers the gate / decoder calls from one whole-chain pass per filter call
             self.ctx.lookahead_enable(self.chunk * self.decim)
 
     def _reader_until_idle(self, q: int) -> None:
@@ -56,17 +77,20 @@ class reader_top_block:
         dq = np.zeros(0, dtype=np.complex64)          # decoder input buffer
         gq = np.zeros(0, dtype=np.complex64)          # gate input buffer
         pos = 0
-        n = len(self.samples)
+        src = fir_filter_ccc_ones(self.samples, self.decim, len(self.num_taps)) if self.external_filter else self.samples
+        per = 1 if self.external_filter else self.decim
+        view = 2 * self.chunk if self.external_filter else self.chunk   # (a gate behind a foreign filter sees a scheduler's buffer:
+        n = len(src)                                                     #  what it has not consumed yet and what came in since)
         flushed = False
         while pos < n or len(gq):
             if pos < n:
-                blk = self.samples[pos:pos + self.chunk * self.decim]
+                blk = src[pos:pos + self.chunk * per]
                 pos += len(blk)
-                y = self.matched_filter.work(blk)
+                y = blk if self.external_filter else self.matched_filter.work(blk)
                 gq = np.concatenate([gq, y]) if len(gq) else y
             progressed = False
             while len(gq):
-                take = gq[: self.chunk]
+                take = gq[:view]
                 consumed, out = self.gate.general_work(take)
                 progressed = progressed or consumed > 0 or len(out) > 0
                 gq = gq[consumed:]

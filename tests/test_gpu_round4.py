@@ -132,7 +132,7 @@ def test_gate_keyed_look_ahead_through_the_c_abi(oracle_mod, synth_mod):
 
 
 def test_passes_enqueued_back_to_back_keep_their_results_apart(oracle_mod, synth_mod):
-    """With room for a second set of result tables, the decoder + statistics of pass k run (on a second stream) beside
+    """With a second set of result tables (RFID_OVERLAP=2), the decoder + statistics of pass k run (on a second stream) beside
     the front end of pass k + 1.  Passes over two DIFFERENT batches enqueued back to back without a sync in between: what
     the getters return afterwards is the last pass's, bit for bit what a context without the second set returns."""
     import torch
@@ -155,7 +155,7 @@ def test_passes_enqueued_back_to_back_keep_their_results_apart(oracle_mod, synth
         o = [oracle_mod.run_trace(b[i, :L]) for i in range(4)]
         want.append(o)
     got = {}
-    for overlap in ("1", "0"):
+    for overlap in ("2", "0"):
         os.environ["RFID_OVERLAP"] = overlap
         try:
             ctx = rfid.Context(device=0)
@@ -174,10 +174,30 @@ def test_passes_enqueued_back_to_back_keep_their_results_apart(oracle_mod, synth
             ctx.close()
         finally:
             os.environ.pop("RFID_OVERLAP", None)
-    for a, b in zip(got["1"], got["0"]):
+    for a, b in zip(got["2"], got["0"]):
         assert a.tobytes() == b.tobytes()
-    st0, _, _, st1, _, _ = got["1"]
+    st0, _, _, st1, _, _ = got["2"]
     for i in range(B):
         assert st0[i]["n_epc_correct"] == want[0][i % 4].state.n_epc_correct and st0[i]["n_windows"] == want[0][i % 4].n_windows
         assert st1[i]["n_epc_correct"] == want[1][i % 4].state.n_epc_correct and st1[i]["n_windows"] == want[1][i % 4].n_windows
         assert st1[i]["tag_reads"][0x21] == want[1][i % 4].state.n_epc_correct
+
+
+def test_python_flowgraph_with_a_foreign_filter(oracle_mod, synth_mod):
+    """rfid.reader_top_block(external_filter=True): the filter is numpy on the host (as GNU Radio's own block would be in
+    apps/reader.py), the library sees gate / tag_decoder / reader only; with and without the gate-keyed look-ahead the
+    oracle's report -- and the host filter IS the oracle's FIR, bit for bit."""
+    import rfid
+    from rfid.flowgraph import fir_filter_ccc_ones
+    t = synth_mod.make_trace(n_rounds=12, seed=19, sigma=0.01).samples
+    assert np.array_equal(fir_filter_ccc_ones(t).view(np.uint32), oracle_mod.fir(t).view(np.uint32))
+    o = oracle_mod.run_trace(t)
+    for la in (True, False):
+        tb = rfid.reader_top_block(samples=t, chunk=6000, lookahead=la, external_filter=True)
+        try:
+            tb.run()
+            assert tb.ctx.stats() == o.stats(), la
+            assert tb.ctx.print_results() == o.print_results()
+            assert len(tb.decoded) == o.n_windows
+        finally:
+            tb.ctx.close()
