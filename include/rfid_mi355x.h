@@ -210,8 +210,9 @@ RFID_API int rfid_decoder_work(rfid_ctx *ctx, const rfid_cf32 *in, int n_in, flo
  * What lies behind the last idle point of the gate in the samples seen so far is not decided yet: a gate call consumes
  * up to there and no further, and returns (0 consumed, 0 written) when it can decide nothing -- as often as it is asked
  * (asking never ends the stream; when the input pauses, the third such call puts what is held back through the
- * sequential scan, up to one EPC window before its end).  max_chunk_raw: the largest n_in rfid_mf_work will see.  Call
- * before the first sample; rfid_ctx_reset switches it off. */
+ * sequential scan, up to one EPC window before its end).  max_chunk_raw: what the staging is sized for (a larger
+ * rfid_mf_work call goes through in pieces).  Call before the first sample; rfid_ctx_reset switches it off.  Like
+ * rfid_stream_begin it runs on a one-trace plan of its own: any rfid_batch_plan of the context is replaced. */
 RFID_API int rfid_lookahead_enable(rfid_ctx *ctx, int64_t max_chunk_raw);
 /* The same look-ahead keyed on the GATE's input, for a flowgraph whose matched filter is not this library's --
  * apps/reader.py:75 instantiates GNU Radio's own filter.fir_filter_ccc, so with that file unchanged the first buffer
