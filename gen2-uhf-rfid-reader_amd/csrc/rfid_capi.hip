@@ -128,6 +128,8 @@ struct rfid_ctx {
       rfid_cf32 first, last;          // (the decoder's input is recognised by them)
     };
     bool on = false, flushed = false;
+    bool flush_req = false;           // (gate-keyed) the end of the input was announced: carried out by the first gate call that brings
+                                      // nothing new and can decide nothing (the library only knows the samples the gate was shown)
     int64_t gate_pos = 0;             // decimated samples the gate calls have consumed
     int64_t up_end = 0;               // (gate-keyed) global position behind the last sample uploaded
     // matched-filter output handed out and not (all) consumed by the gate yet: one block per rfid_mf_work call
@@ -2373,6 +2375,19 @@ int la_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int
         io.cur ^= 1;   // (what is still held back now sits in front of the other buffer's upload area)
         continue;
       }
+      if (la.flush_req && la.stall >= 3 && p + n_in <= la.up_end) {
+        // gate-keyed, the end of the input was announced, and the scheduler keeps showing nothing the device has not seen:
+        // now everything held back is decided (rfid_stream_work's flush)
+        int rc = sio_collect(c);
+        if (!rc && io.tail_len > 0) {
+          la.want_yn = 0;
+          rc = sio_process(c, io.cur, 0, true);
+        }
+        if (rc) { io.failed = true; return rc; }
+        la.flushed = true;
+        la.stall = 0;
+        continue;
+      }
       break;
     }
     if (consumed > 0 || written > 0) la.stall = 0;
@@ -2415,6 +2430,12 @@ int rfid_lookahead_flush(rfid_ctx *c) {
   rfid_ctx::LookAhead &la = c->la;
   if (!la.on || la.flushed) return RFID_OK;   // (without look-ahead nothing is held back)
   if (!io.open || io.failed) return fail(c, RFID_ERR_STATE, "rfid_lookahead_flush: the stream has failed or was closed");
+  if (io.ymode) {
+    // keyed on the gate: the library has seen only what the gate was shown; the flush is carried out once gate calls keep
+    // showing nothing new and can decide nothing (a scheduler shows a block everything its buffer holds)
+    la.flush_req = true;
+    return RFID_OK;
+  }
   HIPCHK(c, hipSetDevice(c->device));
   int rc = sio_collect(c);
   if (!rc && io.tail_len > 0) {

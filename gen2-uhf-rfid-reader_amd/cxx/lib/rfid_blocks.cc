@@ -329,7 +329,11 @@ void sts_flowgraph::run(const gr_complex *samples, size_t n) {
     }
     while (g_rd < gq.size()) {
       const size_t have = gq.size() - g_rd;
-      const int avail = (int)(have < gate_view ? have : gate_view);
+      // (at the end of the input the gate is shown everything that is left: the library's gate-keyed look-ahead only knows
+      // the samples the gate was shown)
+      const size_t show = (pos >= n || have < gate_view) ? have : gate_view;
+      if (gate_out.size() < show) gate_out.resize(show);
+      const int avail = (int)show;
       g_nin[0] = avail; g_in[0] = gq.data() + g_rd; g_out[0] = gate_out.data();
       d_gate->minirt_begin_work();
       const int written = d_gate->general_work(avail, g_nin, g_in, g_out);

@@ -82,6 +82,7 @@ class reader_top_block:
         view = 2 * self.chunk if self.external_filter else self.chunk   # (a gate behind a foreign filter sees a scheduler's buffer:
         n = len(src)                                                     #  what it has not consumed yet and what came in since)
         flushed = False
+        idle = 0
         while pos < n or len(gq):
             if pos < n:
                 blk = src[pos:pos + self.chunk * per]
@@ -90,7 +91,7 @@ class reader_top_block:
                 gq = np.concatenate([gq, y]) if len(gq) else y
             progressed = False
             while len(gq):
-                take = gq[:view]
+                take = gq if pos >= n else gq[:view]      # (at the end of the input the gate is shown everything that is left)
                 consumed, out = self.gate.general_work(take)
                 progressed = progressed or consumed > 0 or len(out) > 0
                 gq = gq[consumed:]
@@ -106,7 +107,8 @@ class reader_top_block:
                 if consumed == 0:
                     break
             if pos >= n:
-                if not len(gq) or (flushed and not progressed):
+                idle = 0 if progressed else idle + 1
+                if not len(gq) or (flushed and idle > 4):     # (a gate-keyed look-ahead carries the flush out on the third idle call)
                     break
                 if not flushed:
                     self.ctx.lookahead_flush()       # the source has run dry: what the look-ahead holds back is decided now

@@ -222,7 +222,11 @@ RFID_API int rfid_lookahead_enable(rfid_ctx *ctx, int64_t max_chunk_raw);
  * decoder calls from the cache, exactly as above (same consume / produce counts, outputs and READER_STATE transitions,
  * same rules for what is undecided, rfid_lookahead_flush at the end of the input).  There is no restriction on where the
  * gate's input comes from; rfid_mf_work is not to be called on such a context.  max_items: decimated samples the device
- * takes per call at most (a larger call is taken in parts).  Call before the first sample. */
+ * takes per call at most (a larger call is taken in parts).  Call before the first sample.  The end of the input
+ * (rfid_lookahead_flush) is carried out once rfid_gate_work calls behind it (the third in a row) show nothing the device has not seen
+ * and can decide nothing: the library knows only the samples the gate was shown, so the scheduler shows the gate everything
+ * its buffer holds (as GNU Radio does) before the stream counts as ended; samples shown for the first time after that are
+ * RFID_ERR_STATE. */
 RFID_API int rfid_lookahead_enable_gate(rfid_ctx *ctx, int64_t max_items);
 /* windows the look-ahead holds: found by the passes and not yet (completely) handed out by rfid_gate_work /
  * handed out and waiting for their rfid_decoder_work call (a decoder call retires its window whether or not it asks for

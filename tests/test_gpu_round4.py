@@ -77,8 +77,11 @@ def test_gate_keyed_look_ahead_offline_binary(tmp_path, oracle_mod, synth_mod):
         assert got[2] == ref[2], ("gated samples differ", key)
 
 
-def test_gate_keyed_look_ahead_through_the_c_abi(oracle_mod, synth_mod):
-    """The same through the ctypes binding, with a scheduler that shows the gate ragged views of its input (unconsumed
+@pytest.mark.parametrize("early_flush", [False, True])
+def test_gate_keyed_look_ahead_through_the_c_abi(oracle_mod, synth_mod, early_flush):
+    """(early_flush: the end of the input is announced while the gate has not been shown all of it yet -- found by
+    profiles/tools/fuzz_lookahead.py: the library knows only the samples the gate was shown, so the flush is carried out
+    once gate calls keep showing nothing new.)  The same through the ctypes binding, with a scheduler that shows the gate ragged views of its input (unconsumed
     samples again, new ones behind them) and decoder calls that ask for scores: windows, bits, statistics equal the
     oracle's and the queue of windows waiting for their decoder call stays bounded (every decoder call retires its window)."""
     import rfid
@@ -96,7 +99,9 @@ def test_gate_keyed_look_ahead_through_the_c_abi(oracle_mod, synth_mod):
         while True:
             if shown < len(y):
                 shown = min(len(y), shown + int(rng.integers(500, 9000)))
-            view = y[pos:min(shown, pos + 30000)]
+            view = y[pos:min(shown, pos + (7000 if early_flush else 30000))]
+            if early_flush and shown >= len(y) and not flushed:
+                ctx.lookahead_flush(); flushed = True            # (some 20000 samples before the last one the gate has been shown)
             cons, out = ctx.gate_work(view) if len(view) else (0, np.zeros(0, np.complex64))
             pos += cons
             dq = np.concatenate([dq, out])
