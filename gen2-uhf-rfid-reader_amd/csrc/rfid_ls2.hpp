@@ -189,6 +189,26 @@ RFID_DEVICE int ls2_margin_scanned(float vA, float vB, uint32_t cinA, uint32_t c
 RFID_DEVICE bool ls2_e0_ok(uint32_t sbA, uint32_t sbB) {
   return ((sbA >> 23) & 0xffu) >= 25u && ((sbA >> 23) & 0xffu) != 255u && ((sbB >> 23) & 0xffu) >= 25u && ((sbB >> 23) & 0xffu) != 255u;
 }
+// The margin of the steps that run in the START's binade (nearly all of them: a piece starts at the carrier's level) without
+// per-step arithmetic: every lane keeps the least and the greatest mantissa its partial sums took (two instructions per
+// variant and step); the distance to the binade's ends is formed once per piece -- min over the samples of
+// min(m, 2^23 - m) = min(least m, 2^23 - greatest m), so the margin is the same number as ls2_margin_scanned's.
+struct Ls2MantRange { int lo, hi; };
+RFID_DEVICE void ls2_range_init(Ls2MantRange &r) { r.lo = 0x800000; r.hi = 0; }
+RFID_DEVICE void ls2_range_add(Ls2MantRange &r, float v) {
+  const int m = (int)(wv::f2u(v) & 0x7fffffu);
+  r.lo = (m < r.lo) ? m : r.lo;
+  r.hi = (m > r.hi) ? m : r.hi;
+}
+RFID_DEVICE int ls2_range_margin(const Ls2MantRange &a, const Ls2MantRange &b) {   // (lane-local; no step recorded: 2^23)
+  const int da = (a.lo < 0x800000 - a.hi) ? a.lo : (0x800000 - a.hi), db = (b.lo < 0x800000 - b.hi) ? b.lo : (0x800000 - b.hi);
+  return (da < db) ? da : db;
+}
+// a scanned step whose two carries lie in the binade (and have the sign) of their variants' starts: ls2_margin_scanned's
+// `good` holds and both shifts are 0
+RFID_DEVICE bool ls2_in_start_binade(uint32_t cinA, uint32_t cinB, uint32_t sbA, uint32_t sbB, bool e0_ok) {
+  return e0_ok && (((cinA ^ sbA) | (cinB ^ sbB)) & 0xff800000u) == 0u;
+}
 RFID_DEVICE int ls2_wave_min(int v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) { const int o = wv::shfl_xor(v, off); v = (o < v) ? o : v; }
@@ -344,6 +364,7 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
   // neighbours (their lanes outside the piece add +0 to the sums and cast no vote).
   const int p1 = p0 + n, w0 = p0 >> 6, nsteps = ((p1 + 63) >> 6) - w0;
   const int n_total = ls2_trace_len(a, s);
+  const int last_idx = n_total - 1;   // (n_total >= p1 > 0)
   const int64_t row = (int64_t)s * a.y_stride;
   const float2 *yr = a.y + row;
   float *ampr = a.amp + row, *dr = a.dadd + row;
@@ -387,27 +408,33 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
   float avA = sA, avB = sB;
   int marg = ls2_margin(sA, sbA);
   const bool e0_ok = ls2_e0_ok(sbA, sbB);
+  Ls2MantRange rgA, rgB;              // steps in the start's binade: the mantissas' range and the least |x|-to-threshold distance,
+  ls2_range_init(rgA); ls2_range_init(rgB);   // lane by lane; the margin they stand for is formed behind the loop
+  int min_dv = 0x7fffffff;
   constexpr int AHEAD = 4;
   float2 ybuf[AHEAD];
   float abuf[AHEAD], dbuf[AHEAD];
 #pragma unroll
   for (int u = 0; u < AHEAD; ++u) {
     const int idx = base + 64 * u + lane;
-    if (FIRST) ybuf[u] = (idx < n_total) ? yr[idx] : make_float2(0.0f, 0.0f);
-    else { const bool in = idx >= p0 && idx < p1; abuf[u] = in ? ampr[idx] : 0.0f; dbuf[u] = in ? dr[idx] : 0.0f; }
+    // (loads past the end of the trace are clamped, not predicated: their lanes are not `valid` and add +0; an unconditional
+    // load lands in the register the step reads it from -- no copies at the loop's end that would wait for all of them)
+    if (FIRST) ybuf[u] = yr[(idx < n_total) ? idx : last_idx];
+    else { const int ix = (idx < p0) ? p0 : ((idx < p1) ? idx : (p1 - 1)); abuf[u] = ampr[ix]; dbuf[u] = dr[ix]; }
   }
   uint64_t my_lt = 0, my_gt = 0;   // lane (k & 63) keeps the votes of step k until 64 steps are stored together
-  for (int kb = 0; kb < nsteps; kb += AHEAD) {
-#pragma unroll
-    for (int u = 0; u < AHEAD; ++u) {
-      const int k = kb + u;
-      if (k < nsteps) {
+  // one step.  The groups of AHEAD steps that are complete run without a condition around a step: every buffer is read and
+  // loaded again in place, and the loop's only waits are counted ones for the oldest load.  (With the steps guarded one by one
+  // the compiler kept the fresh loads in other registers and copied them at the loop's end -- behind a wait for ALL of them:
+  // the read-ahead was one step deep, not four.)  The last, incomplete group reads what is left of the buffers.
+  auto step = [&](const int k, float2 &yb, float &ab_, float &db_, const bool reload) {
+      {
         const int idx = base + 64 * k + lane;
         const bool valid = idx >= p0 && idx < p1;
         float amp, d;
         if (FIRST) {
-          const float2 v = ybuf[u];
-          { const int nx = idx + 64 * AHEAD; ybuf[u] = (nx < n_total) ? yr[nx] : make_float2(0.0f, 0.0f); }
+          const float2 v = yb;
+          if (reload) { const int nx = idx + 64 * AHEAD; yb = yr[(nx < n_total) ? nx : last_idx]; }
           amp = wv::hypot_f(v.x, v.y);
           // sample i - 100: lanes 0..35 take it from two steps back (lane + 28), lanes 36..63 from the previous step (lane - 36)
           const float o2 = wv::shfl(a2, (lane + 28) & 63), o1 = wv::shfl(a1, (lane - 36) & 63);
@@ -417,11 +444,13 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
           if (valid) { ampr[idx] = amp; dr[idx] = d; }
           a2 = a1; a1 = amp;
         } else {
-          amp = abuf[u]; d = dbuf[u];
-          const int nx = idx + 64 * AHEAD;
-          const bool in = nx >= p0 && nx < p1;
-          abuf[u] = in ? ampr[nx] : 0.0f;
-          dbuf[u] = in ? dr[nx] : 0.0f;
+          amp = valid ? ab_ : 0.0f; d = valid ? db_ : 0.0f;
+          if (reload) {
+            const int nx = idx + 64 * AHEAD;
+            const int ix = (nx < p1) ? nx : (p1 - 1);     // (nx >= p0: behind this step)
+            ab_ = ampr[ix];
+            db_ = dr[ix];
+          }
         }
         float vA, vB;
         const uint32_t cinA = wv::f2u(avA), cinB = wv::f2u(avB);
@@ -442,24 +471,30 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
           const uint32_t tb = wv::f2u(thresh), ab = wv::f2u(amp);
           int dv = (int)ab - (int)tb;
           dv = (dv < 0) ? -dv : dv;
-          int mm;
-          if (scanned) {
-            // every partial sum of the step lies in its carry's binade (chain_add_scan): one shift for all lanes
-            mm = ls2_margin_scanned(vA, vB, cinA, cinB, sbA, sbB, e0_ok);
-            if (mm > 0) {
-              const int shA = (int)((sbA >> 23) & 0xffu) - (int)((cinA >> 23) & 0xffu);
-              const int mV = valid ? ((dv - 3) >> (1 + shA)) : 0x7fffffff;
+          if (scanned && ls2_in_start_binade(cinA, cinB, sbA, sbB, e0_ok)) {
+            ls2_range_add(rgA, vA); ls2_range_add(rgB, vB);
+            const int dvv = valid ? dv : 0x7fffffff;
+            min_dv = (dvv < min_dv) ? dvv : min_dv;
+          } else {
+            int mm;
+            if (scanned) {
+              // every partial sum of the step lies in its carry's binade (chain_add_scan): one shift for all lanes
+              mm = ls2_margin_scanned(vA, vB, cinA, cinB, sbA, sbB, e0_ok);
+              if (mm > 0) {
+                const int shA = (int)((sbA >> 23) & 0xffu) - (int)((cinA >> 23) & 0xffu);
+                const int mV = valid ? ((dv - 3) >> (1 + shA)) : 0x7fffffff;
+                mm = (mV < mm) ? mV : mm;
+              }
+            } else {
+              const int mA = ls2_margin(vA, sbA), mB = ls2_margin(vB, sbB);
+              const int sh = (int)((sbA >> 23) & 0xffu) - (int)((wv::f2u(vA) >> 23) & 0xffu);
+              int mV = ((tb >> 31) != 0u || sh < 0 || sh > 23) ? 0 : (((dv - 3) >> 1) >> sh);
+              mV = valid ? mV : 0x7fffffff;
+              mm = (mA < mB) ? mA : mB;
               mm = (mV < mm) ? mV : mm;
             }
-          } else {
-            const int mA = ls2_margin(vA, sbA), mB = ls2_margin(vB, sbB);
-            const int sh = (int)((sbA >> 23) & 0xffu) - (int)((wv::f2u(vA) >> 23) & 0xffu);
-            int mV = ((tb >> 31) != 0u || sh < 0 || sh > 23) ? 0 : (((dv - 3) >> 1) >> sh);
-            mV = valid ? mV : 0x7fffffff;
-            mm = (mA < mB) ? mA : mB;
-            mm = (mV < mm) ? mV : mm;
+            marg = (mm < marg) ? mm : marg;
           }
-          marg = (mm < marg) ? mm : marg;
         }
         // the votes: whole blocks are stored 64 at a time; the two blocks shared with the neighbouring pieces get this
         // piece's bits put in (a re-run replaces its own bits only)
@@ -480,7 +515,20 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
           if (kl <= k && kl != 0 && kl != nsteps - 1) { votes[2 * kl] = my_lt; votes[2 * kl + 1] = my_gt; }
         }
       }
-    }
+  };
+  int kb = 0;
+  for (; kb + AHEAD <= nsteps; kb += AHEAD) {
+#pragma unroll
+    for (int u = 0; u < AHEAD; ++u) step(kb + u, ybuf[u], abuf[u], dbuf[u], true);
+  }
+#pragma unroll
+  for (int u = 0; u < AHEAD - 1; ++u)
+    if (kb + u < nsteps) step(kb + u, ybuf[u], abuf[u], dbuf[u], false);
+  {
+    const int mb = ls2_range_margin(rgA, rgB);
+    const int mv = (min_dv == 0x7fffffff) ? min_dv : ((min_dv - 3) >> 1);
+    const int mf = (mv < mb) ? mv : mb;
+    marg = (mf < marg) ? mf : marg;
   }
   marg = ls2_wave_min(marg);
   // the chain works on the integer image of binary32, where a shift by D ulps of the start is a shift by D at the end only
@@ -503,7 +551,13 @@ RFID_KERNEL(64) void ls2_avg_first_kernel(Ls2Args a) {
     return;
   }
   const int NS = a.n_streams * a.max_b;
-  for (int i = (int)blockIdx.x; i < NS; i += (int)gridDim.x) ls2_avg_piece<true>(a, i, lane);
+  // workgroup b runs on XCD b mod 8: each XCD takes one contiguous eighth of the slots (grid = 8 * ceil(NS / 8)).  Slots in
+  // their own order put every LS2_FINE-th slot -- the heads, whose pieces are the long ones (a rest point too close behind an
+  // idle cut is dropped) -- on two of the eight XCDs, which then finish last; and neighbouring pieces share their
+  // first / last vote block and the 128 samples of history, which now sit in one L2.
+  const int per = (NS + 7) >> 3;
+  const int b = (int)blockIdx.x, i = (b & 7) * per + (b >> 3);
+  if ((b >> 3) < per && i < NS) ls2_avg_piece<true>(a, i, lane);
 }
 RFID_KERNEL(64) void ls2_avg_rerun_kernel(Ls2Args a) {
   if (wv::uniform(a.ctl->fail) != 0) return;
@@ -1011,6 +1065,8 @@ RFID_DEVICE void ls2_dc_piece(const Ls2Args &a, const int j, const bool first, c
   float bre = sreB, bim = simB;   // variant B's carries
   int mre = ls2_margin(sre, sbr), mim = ls2_margin(sim, sbi);
   const bool e0r_ok = ls2_e0_ok(sbr, sbrB), e0i_ok = ls2_e0_ok(sbi, sbiB);
+  Ls2MantRange rgrA, rgrB, rgiA, rgiB;   // (see ls2_avg_piece)
+  ls2_range_init(rgrA); ls2_range_init(rgrB); ls2_range_init(rgiA); ls2_range_init(rgiB);
   Ls2Win *wb = a.wb + (int64_t)s * a.wb_stride;
   {
     // the unit's steps k0 .. k1 - 1 hold the piece (step k = samples upos0 + 64 k ..: the state-machine pass left the
@@ -1077,13 +1133,20 @@ RFID_DEVICE void ls2_dc_piece(const Ls2Args &a, const int j, const bool first, c
             const bool sci = chain_add_auto2(g.dci_c, bim, tim, lane, ai, bi);
             g.dcr_c = wv::readlane(ar, 63); bre = wv::readlane(br, 63);
             g.dci_c = wv::readlane(ai, 63); bim = wv::readlane(bi, 63);
-            int mr, mi;
-            if (scr) mr = ls2_margin_scanned(ar, br, cr0, cr1, sbr, sbrB, e0r_ok);
-            else { const int m1 = ls2_margin(ar, sbr), m2 = ls2_margin(br, sbrB); mr = (m1 < m2) ? m1 : m2; }
-            if (sci) mi = ls2_margin_scanned(ai, bi, ci0, ci1, sbi, sbiB, e0i_ok);
-            else { const int m3 = ls2_margin(ai, sbi), m4 = ls2_margin(bi, sbiB); mi = (m3 < m4) ? m3 : m4; }
-            mre = (mr < mre) ? mr : mre;
-            mim = (mi < mim) ? mi : mim;
+            if (scr && ls2_in_start_binade(cr0, cr1, sbr, sbrB, e0r_ok)) { ls2_range_add(rgrA, ar); ls2_range_add(rgrB, br); }
+            else {
+              int mr;
+              if (scr) mr = ls2_margin_scanned(ar, br, cr0, cr1, sbr, sbrB, e0r_ok);
+              else { const int m1 = ls2_margin(ar, sbr), m2 = ls2_margin(br, sbrB); mr = (m1 < m2) ? m1 : m2; }
+              mre = (mr < mre) ? mr : mre;
+            }
+            if (sci && ls2_in_start_binade(ci0, ci1, sbi, sbiB, e0i_ok)) { ls2_range_add(rgiA, ai); ls2_range_add(rgiB, bi); }
+            else {
+              int mi;
+              if (sci) mi = ls2_margin_scanned(ai, bi, ci0, ci1, sbi, sbiB, e0i_ok);
+              else { const int m3 = ls2_margin(ai, sbi), m4 = ls2_margin(bi, sbiB); mi = (m3 < m4) ? m3 : m4; }
+              mim = (mi < mim) ? mi : mim;
+            }
           } else {
             g.run_closed = 0;   // no closed sample of the piece in this step (inside a window): dc_est, the ring and its index do not move
             ar = g.dcr_c; ai = g.dci_c; br = bre; bi = bim;
@@ -1101,6 +1164,8 @@ RFID_DEVICE void ls2_dc_piece(const Ls2Args &a, const int j, const bool first, c
       }
     }
   }
+  { const int m = ls2_range_margin(rgrA, rgrB); mre = (m < mre) ? m : mre; }
+  { const int m = ls2_range_margin(rgiA, rgiB); mim = (m < mim) ? m : mim; }
   mre = ls2_wave_min(mre);
   mim = ls2_wave_min(mim);
   // (the chain's integer arithmetic needs start and end in one binade, see ls2_avg_piece)
@@ -1161,6 +1226,8 @@ RFID_DEVICE void ls2_dc_unit(const Ls2Args &a, const int i, const bool first, co
   float bre = sreB, bim = simB;   // variant B's carries
   int mre = ls2_margin(sre, sbr), mim = ls2_margin(sim, sbi);
   const bool e0r_ok = ls2_e0_ok(sbr, sbrB), e0i_ok = ls2_e0_ok(sbi, sbiB);
+  Ls2MantRange rgrA, rgrB, rgiA, rgiB;   // (see ls2_avg_piece)
+  ls2_range_init(rgrA); ls2_range_init(rgrB); ls2_range_init(rgiA); ls2_range_init(rgiB);
   Ls2Win *wb = a.wb + (int64_t)s * a.wb_stride;
   {
     // the unit: from the head's first sample to the next head (the state-machine pass left its end, its closed samples
@@ -1218,13 +1285,20 @@ RFID_DEVICE void ls2_dc_unit(const Ls2Args &a, const int i, const bool first, co
             const bool sci = chain_add_auto2(g.dci_c, bim, tim, lane, ai, bi);
             g.dcr_c = wv::readlane(ar, 63); bre = wv::readlane(br, 63);
             g.dci_c = wv::readlane(ai, 63); bim = wv::readlane(bi, 63);
-            int mr, mi;
-            if (scr) mr = ls2_margin_scanned(ar, br, cr0, cr1, sbr, sbrB, e0r_ok);
-            else { const int m1 = ls2_margin(ar, sbr), m2 = ls2_margin(br, sbrB); mr = (m1 < m2) ? m1 : m2; }
-            if (sci) mi = ls2_margin_scanned(ai, bi, ci0, ci1, sbi, sbiB, e0i_ok);
-            else { const int m3 = ls2_margin(ai, sbi), m4 = ls2_margin(bi, sbiB); mi = (m3 < m4) ? m3 : m4; }
-            mre = (mr < mre) ? mr : mre;
-            mim = (mi < mim) ? mi : mim;
+            if (scr && ls2_in_start_binade(cr0, cr1, sbr, sbrB, e0r_ok)) { ls2_range_add(rgrA, ar); ls2_range_add(rgrB, br); }
+            else {
+              int mr;
+              if (scr) mr = ls2_margin_scanned(ar, br, cr0, cr1, sbr, sbrB, e0r_ok);
+              else { const int m1 = ls2_margin(ar, sbr), m2 = ls2_margin(br, sbrB); mr = (m1 < m2) ? m1 : m2; }
+              mre = (mr < mre) ? mr : mre;
+            }
+            if (sci && ls2_in_start_binade(ci0, ci1, sbi, sbiB, e0i_ok)) { ls2_range_add(rgiA, ai); ls2_range_add(rgiB, bi); }
+            else {
+              int mi;
+              if (sci) mi = ls2_margin_scanned(ai, bi, ci0, ci1, sbi, sbiB, e0i_ok);
+              else { const int m3 = ls2_margin(ai, sbi), m4 = ls2_margin(bi, sbiB); mi = (m3 < m4) ? m3 : m4; }
+              mim = (mi < mim) ? mi : mim;
+            }
           } else {
             g.run_closed = 0;   // the step lies entirely inside a window: dc_est, the ring and its index do not move
             ar = g.dcr_c; ai = g.dci_c; br = bre; bi = bim;
@@ -1242,6 +1316,8 @@ RFID_DEVICE void ls2_dc_unit(const Ls2Args &a, const int i, const bool first, co
       }
     }
   }
+  { const int m = ls2_range_margin(rgrA, rgrB); mre = (m < mre) ? m : mre; }
+  { const int m = ls2_range_margin(rgiA, rgiB); mim = (m < mim) ? m : mim; }
   mre = ls2_wave_min(mre);
   mim = ls2_wave_min(mim);
   // (the chain's integer arithmetic needs start and end in one binade, see ls2_avg_piece)

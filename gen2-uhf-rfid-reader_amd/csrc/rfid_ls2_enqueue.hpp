@@ -138,7 +138,7 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
   // workgroups per trace of the chain kernels: a few thousand slots each
   auto chain_g = [](int slots) { const int per = ls2_chain_slots(); int g = (slots + per - 1) / per; return g < 1 ? 1 : (g > LS2_CHAIN_GMAX ? LS2_CHAIN_GMAX : g); };
   const int g_avg = chain_g(a.max_b), g_seq = chain_g(a.max_bc);   // (pieces: any slot; units: idle-grid slots)
-  LS2_LAUNCH(ls2_avg_first_kernel, NS, 1, 64, a);
+  LS2_LAUNCH(ls2_avg_first_kernel, 8 * ((NS + 7) / 8), 1, 64, a);   // (one wave per slot, an eighth of the slots per XCD)
   a.chain_g = g_avg; a.stamp++;
   LS2_LAUNCH(ls2_avg_chain_kernel, g_avg, B, LS2_CHAIN_THREADS, a);
   for (int r = 1; r <= a.avg_rounds; ++r) {
