@@ -218,7 +218,7 @@ RFID_DEVICE int ls2_wave_min(int v) {
 // The in-order sums of one step's addends from TWO carries in one go (variants A and B of a run): everything that
 // depends on the addends and the binade only is shared (see chain_add_scan), the parities at ties and the prefix sums
 // are per carry.  false: not both in one binade, or a partial sum left it -- the caller takes chain_add_auto twice.
-RFID_DEVICE bool chain_add_scan2(float ca, float cb2, float x, int lane, float &oa, float &ob) {
+RFID_DEVICE bool chain_add_scan2_dual(float ca, float cb2, float x, int lane, float &oa, float &ob) {
   const uint32_t ba = wv::f2u(ca), bb = wv::f2u(cb2);
   if (((ba ^ bb) & 0xff800000u) != 0u) return false;
   const uint32_t e_b = (ba >> 23) & 0xffu;
@@ -252,6 +252,52 @@ RFID_DEVICE bool chain_add_scan2(float ca, float cb2, float x, int lane, float &
   oa = wv::u2f(maga | sign);
   ob = wv::u2f(magb | sign);
   return wv::ballot(bad_t || bad_s || bad_c) == 0ull;
+}
+// The same at the price of ONE scan.  The two carries differ by dm units of the binade's grid (variant B starts one ulp above
+// A); the integers R_j that the addends contribute do not depend on the carry except at ties, where only its parity
+// counts -- so while dm is EVEN both variants take the same R_j and B's partial sums are A's + dm, lane for lane; and a
+// step without a tie is the same integers whatever dm is.  Only a step that has a tie while dm is odd needs both scans --
+// and it leaves dm even (A takes I + a, B takes I + 1 - a: dm becomes 2 - 2a), after which it stays even as long as the
+// sums stay in one binade: a piece pays the second scan once.  (B in the binade with a non-zero mantissa: A is, and A's
+// mantissa + dm lies in [1, 2^23 - 1].)
+RFID_DEVICE bool chain_add_scan2(float ca, float cb2, float x, int lane, float &oa, float &ob) {
+  const uint32_t ba = wv::f2u(ca), bb = wv::f2u(cb2);
+  if (((ba ^ bb) & 0xff800000u) != 0u) return false;
+  const int dm = (int)(bb & 0x7fffffffu) - (int)(ba & 0x7fffffffu);   // (wave-uniform)
+  const uint32_t e_b = (ba >> 23) & 0xffu;
+  const uint32_t sign = ba & 0x80000000u;
+  const float scale = wv::u2f(((277u - e_b) & 0xffu) << 23);
+  const float t = sign ? -(x * scale) : (x * scale);
+  const float r = wv::rint_f(t);
+  const float frac = t - r;
+  const bool bad_t = !(__builtin_fabsf(t) < 4194304.0f);
+  const bool half = __builtin_fabsf(frac) == 0.5f;
+  const bool tie = !bad_t && half;
+  int R = wv::f2i(bad_t ? 0.0f : r);
+  const uint64_t badmask_t = wv::ballot(bad_t);
+  const uint64_t tiemask = wv::ballot(half) & ~badmask_t;
+  if (tiemask != 0ull) {
+    if (dm & 1) return chain_add_scan2_dual(ca, cb2, x, lane, oa, ob);
+    // (chain_add_scan's ties, from A's parity -- B's is the same)
+    const int I = R - ((frac < 0.0f) ? 1 : 0);
+    const uint64_t rodd = wv::ballot((R & 1) != 0) & ~tiemask;
+    const uint64_t iodd = wv::ballot((I & 1) != 0) & tiemask;
+    const uint64_t Q = prefix_xor64(rodd);
+    const uint64_t gen = tiemask & Q, X = gen | ~tiemask;
+    const uint64_t sum = X + gen + (uint64_t)(ba & 1u);
+    const uint64_t W = X ^ gen ^ sum;
+    const uint64_t par = (Q << 1) ^ W;
+    const uint64_t up = (par ^ iodd) & tiemask;
+    R = tie ? (I + (int)((up >> lane) & 1ull)) : R;
+  }
+  const uint32_t maga = (ba & 0x7fffffffu) + (uint32_t)wv::scan_add(R);
+  const uint32_t m = maga & 0x007fffffu;
+  const uint64_t badmask_s = wv::ballot(((maga ^ ba) & 0x7f800000u) != 0u) | wv::ballot(m == 0u) |
+                             wv::ballot((uint32_t)((int)m + dm - 1) >= 0x007fffffu);
+  const bool bad_c = e_b < 23u || e_b > 254u;
+  oa = wv::u2f(maga | sign);
+  ob = wv::u2f((uint32_t)((int)maga + dm) | sign);
+  return (badmask_t | badmask_s) == 0ull && !bad_c;
 }
 RFID_DEVICE bool chain_add_auto2(float ca, float cb2, float x, int lane, float &oa, float &ob) {   // true: the shared scan applied
   if (__builtin_expect(chain_add_scan2(ca, cb2, x, lane, oa, ob), 1)) return true;
@@ -1240,23 +1286,26 @@ RFID_DEVICE void ls2_dc_unit(const Ls2Args &a, const int i, const bool first, co
     const int nsteps = (n + 63) >> 6;
     constexpr int AHEAD = 4;
     float2 buf[AHEAD];
+    // (loads clamped, not predicated, and the complete groups of AHEAD steps without a condition around a step: see
+    // ls2_avg_piece.  Samples past the unit's end are not closed -- nvalid -- whatever their value.)
+    const int last_idx = n - 1;
 #pragma unroll
-    for (int u = 0; u < AHEAD; ++u) { const int idx = 64 * u + lane; buf[u] = (idx < n) ? ys[idx] : make_float2(0.0f, 0.0f); }
+    for (int u = 0; u < AHEAD; ++u) { const int idx = 64 * u + lane; buf[u] = ys[(idx < n) ? idx : last_idx]; }
     float2 before = make_float2(0.0f, 0.0f);   // the samples of the previous step
     uint64_t masks = 0;
     int oi_l = 0xff;
-    for (int kb = 0; kb < nsteps; kb += AHEAD) {
-#pragma unroll
-      for (int u = 0; u < AHEAD; ++u) {
-        const int k = kb + u;
-        if (k < nsteps) {
+    auto step = [&](const int k, float2 &yb, const bool reload) {
+        {
           if ((k & 63) == 0) {
             const bool in = k + lane < nsteps;
-            masks = in ? closed[k + lane] : 0ull;
-            oi_l = in ? oinfo[k + lane] : 0xff;
+            const int kx = in ? (k + lane) : (nsteps - 1);
+            const uint64_t mk = closed[kx];
+            const int ok = oinfo[kx];
+            masks = in ? mk : 0ull;
+            oi_l = in ? ok : 0xff;
           }
-          const float2 yv = buf[u];
-          { const int idx = 64 * (k + AHEAD) + lane; buf[u] = (idx < n) ? ys[idx] : make_float2(0.0f, 0.0f); }
+          const float2 yv = yb;
+          if (reload) { const int idx = 64 * (k + AHEAD) + lane; yb = ys[(idx < n) ? idx : last_idx]; }
           const int kk = k & 63;
           const uint64_t closedmask = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(masks >> 32), kk) << 32) |
                                       (uint32_t)wv::readlane((int)(uint32_t)masks, kk);
@@ -1313,8 +1362,15 @@ RFID_DEVICE void ls2_dc_unit(const Ls2Args &a, const int i, const bool first, co
             }
           }
         }
-      }
+    };
+    int kb = 0;
+    for (; kb + AHEAD <= nsteps; kb += AHEAD) {
+#pragma unroll
+      for (int u = 0; u < AHEAD; ++u) step(kb + u, buf[u], true);
     }
+#pragma unroll
+    for (int u = 0; u < AHEAD - 1; ++u)
+      if (kb + u < nsteps) step(kb + u, buf[u], false);
   }
   { const int m = ls2_range_margin(rgrA, rgrB); mre = (m < mre) ? m : mre; }
   { const int m = ls2_range_margin(rgiA, rgiB); mim = (m < mim) ? m : mim; }
