@@ -863,6 +863,48 @@ int rfid_selftest(rfid_ctx *c, int *n_failed) {
       if (hout[4 * l] != (int)a0 || hout[4 * l + 1] != (int)a1) bad++;
     }
   }
+  {
+    // the in-order sums of one step from two carries at once (rfid_ls2.hpp, chain_add_scan2): carries one ulp apart (a
+    // piece's two variants), two apart and equal (what a tie leaves), addends with exact half-ulp multiples (ties) on
+    // some lanes, next to a power of two (the sums leave the binade: the chains take over) -- against the host's
+    // sequential sums, bit for bit
+    float *dx = nullptr;
+    HIPCHK(c, hipMalloc((void **)&dx, sizeof(float) * (64 + 129)));
+    unsigned sd = 4242u;
+    auto rnd = [&]() { sd = sd * 1664525u + 1013904223u; return (float)(sd >> 8) * (1.0f / 16777216.0f); };
+    int scanned_rounds = 0;
+    for (int round = 0; round < 48; ++round) {
+      const float bases[6] = {23.456789f, 0.7071f, -19.12345f, 16.000002f, 31.99999f, 3.0e5f};
+      const float ca = bases[round % 6];
+      uint32_t bits; memcpy(&bits, &ca, 4);
+      const int du = (round / 6) % 4;                         // cb = ca + {1, 2, 0, 1} ulps (in the monotone integer image)
+      uint32_t bb = bits + (uint32_t)((ca < 0.0f) ? -(int)((du == 3) ? 1 : ((du == 2) ? 0 : du + 1)) : (int)((du == 3) ? 1 : ((du == 2) ? 0 : du + 1)));
+      float cb; memcpy(&cb, &bb, 4);
+      const float u = ldexpf(1.0f, ilogbf(fabsf(ca)) - 23);   // ulp of the carries' binade
+      float hx[64];
+      for (int i = 0; i < 64; ++i) {
+        hx[i] = (rnd() - 0.5f) * 200.0f * u * (float)(1 + i % 5);
+        if ((round & 1) && i % 7 == 3) hx[i] = ((float)((int)(rnd() * 40.0f) - 20) + 0.5f) * u;      // ties
+        if (round >= 24 && i % 11 == 5) hx[i] = ((float)((int)(rnd() * 9.0f) - 4) + 0.5f) * u;
+      }
+      HIPCHK(c, hipMemcpyAsync(dx, hx, sizeof(hx), hipMemcpyHostToDevice, c->stream));
+      hipLaunchKernelGGL(ls2_scan2_selftest_kernel, dim3(1), dim3(64), 0, c->stream, (const float *)dx, ca, cb, dx + 64);
+      HIPCHK(c, hipGetLastError());
+      float out[129];
+      HIPCHK(c, hipMemcpyAsync(out, dx + 64, sizeof(out), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      volatile float sa = ca, sb = cb;
+      for (int i = 0; i < 64; ++i) {
+        sa = sa + hx[i]; sb = sb + hx[i];
+        float ea = sa, eb = sb;
+        if (memcmp(&ea, &out[i], 4)) bad++;
+        if (memcmp(&eb, &out[64 + i], 4)) bad++;
+      }
+      if (out[128] != 0.0f) scanned_rounds++;
+    }
+    (void)hipFree(dx);
+    if (scanned_rounds < 16) bad++;                           // (the shared scan must be what most of these rounds took)
+  }
   if (n_failed) *n_failed = bad;
   if (bad) snprintf(c->err, sizeof(c->err), "selftest: %d primitive checks failed", bad);
   return RFID_OK;

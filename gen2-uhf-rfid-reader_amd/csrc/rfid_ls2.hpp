@@ -480,8 +480,10 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
         float amp, d;
         if (FIRST) {
           const float2 v = yb;
-          if (reload) { const int nx = idx + 64 * AHEAD; yb = yr[(nx < n_total) ? nx : last_idx]; }
           amp = wv::hypot_f(v.x, v.y);
+          // (the buffer is loaded again once its value is used up: the load lands in the same register -- issued before
+          // that, the compiler kept it elsewhere and copied it at the loop's end behind a wait for all loads in flight)
+          if (reload) { const int nx = idx + 64 * AHEAD; yb = yr[(nx < n_total) ? nx : last_idx]; }
           // sample i - 100: lanes 0..35 take it from two steps back (lane + 28), lanes 36..63 from the previous step (lane - 36)
           const float o2 = wv::shfl(a2, (lane + 28) & 63), o1 = wv::shfl(a1, (lane - 36) & 63);
           const float old = (lane < 36) ? o2 : o1;
@@ -658,6 +660,16 @@ RFID_KERNEL(64) void ls2_scan_selftest_kernel(const int *in, int *out) {
   Ls2A32 v; v.c0 = in[2 * lane]; v.c1 = in[2 * lane + 1];
   const Ls2A32 i = ls2_wave_incl(v, lane), e = ls2_wave_excl(i, lane);
   out[4 * lane] = i.c0; out[4 * lane + 1] = i.c1; out[4 * lane + 2] = e.c0; out[4 * lane + 3] = e.c1;
+}
+// device self-test of the two-variant in-order sum (chain_add_auto2: one scan for both carries where that is provably the
+// same arithmetic, two scans at a piece's first tie, the chains else): out[lane], out[64 + lane] = the sums from ca / cb,
+// out[128] = 1 when the shared scan applied
+RFID_KERNEL(64) void ls2_scan2_selftest_kernel(const float *x, float ca, float cb, float *out) {
+  const int lane = wv::lane_id();
+  float oa, ob;
+  const bool scanned = chain_add_auto2(ca, cb, x[lane], lane, oa, ob);
+  out[lane] = oa; out[64 + lane] = ob;
+  if (lane == 0) out[128] = scanned ? 1.0f : 0.0f;
 }
 constexpr int LS2_CHAIN_WAVES = LS2_CHAIN_THREADS / 64;
 

@@ -166,11 +166,12 @@ def test_ls2_streaming_form_carries_the_gate_state(emu_mod, oracle_mod, synth_mo
 
 
 def test_chain_add_auto2_equals_two_sequential_sums(emu_mod):
-    """The in-order sums from two carries one ulp apart in ONE pass (shared conversion of the addends, per-carry tie
-    parities): each must equal the plain sequential binary32 sum from its carry -- ties, binade edges, zeros, both signs."""
+    """The in-order sums from two carries a few ulps apart in ONE pass (one scan while their distance is even or the step has no
+    tie, two at the tie that makes it even): each must equal the plain sequential binary32 sum from its carry -- ties, binade
+    edges, zeros, both signs."""
     rng = np.random.default_rng(11)
     n_scanned = 0
-    for trial in range(200):
+    for trial in range(600):
         carry = np.float32(rng.choice([23.456789, -19.12345, 31.99999, 16.000002, 0.0, 1e-30, -15.99999, 3.0e5, 25.0, 8.5, -0.75, 15.999999]))
         scale = float(rng.choice([1e-4, 1e-3, 1e-2, 0.3, 1e-8, 1e3]))
         x = (rng.standard_normal(64) * scale).astype(np.float32)
@@ -180,8 +181,12 @@ def test_chain_add_auto2_equals_two_sequential_sums(emu_mod):
         if kind == 2:
             x[rng.integers(0, 64)] = 0.0
             x[5] = -0.0
-        cb = np.nextafter(carry, np.float32(np.inf)) if carry >= 0 else np.nextafter(carry, np.float32(0))
-        if carry == 0:
+        # the second carry: one ulp above the first (a run's two variants at its start), or what ties leave of that: equal, two
+        # apart (one scan serves both while the distance is even), and other small distances
+        cb = carry
+        for _ in range((1, 1, 2, 0, 3, 4)[trial % 6]):
+            cb = np.nextafter(cb, np.float32(np.inf))
+        if carry == 0 and cb == 0:
             cb = np.float32(np.nextafter(np.float32(0), np.float32(1)))
         oa, ob, sc = emu_mod.chain_scan2(x, float(carry), float(cb))
         n_scanned += sc
@@ -190,4 +195,4 @@ def test_chain_add_auto2_equals_two_sequential_sums(emu_mod):
             for i in range(64):
                 acc = np.float32(acc + x[i])
                 assert got[i].view(np.uint32) == acc.view(np.uint32), (trial, float(c0), i)
-    assert n_scanned > 40
+    assert n_scanned > 120
