@@ -227,9 +227,14 @@ def streaming_leg(torch, rfid, wl, args, device):
         ctx.close()
 
 
+WAKE_S = 0.08      # seconds of the workload's own passes before the warm-up steps (see measure())
+
+
 def measure(torch, wl, steps, warmup, barrier, gather_elapsed=None, n_series=None, back_to_back=True):
-    """`warmup` untimed passes, then exactly `steps` timed passes of the workload's whole chain (bracketed by
-    `barrier()`), then an untimed series of the same passes read out through HIP events per kernel.
+    """`warmup` untimed passes, then exactly `steps` timed passes of the workload's whole chain, enqueued one behind the other
+    and waited for once (bracketed by `barrier()`, which synchronises the device; back_to_back=False: every pass waited for
+    by itself, as rounds 1-3 timed it -- the profiled runs use that, a kernel trace then holds no queueing), then an untimed
+    series of the same passes read out through HIP events per kernel.
     -> dict(elapsed, step_s, k_ms, k_min, k_med, alg, key, n_launch, rep, st, parity_ok, parity_text, roof, ...)"""
     ctx, data, stride, L, B = wl["ctx"], wl["data"], wl["stride"], wl["L"], wl["B"]
     ctx.batch_plan(B, L)
@@ -239,17 +244,31 @@ def measure(torch, wl, steps, warmup, barrier, gather_elapsed=None, n_series=Non
         ctx.batch_process_ptr(ptr, stride, L, 0, want_scores=False)
         ctx.batch_sync()
 
+    # the device's clocks: a GPU that has idled through the host's set-up work (planning a trace, building contexts) takes some
+    # tens of ms of load to reach its sustained clocks -- 5 warm-up passes of 2.7 ms end before that, and the first ten passes
+    # then run 3 % slower than every later one (profiles/r04/bench_warm.txt).  The same passes are run for WAKE_S of wall
+    # time before the W warm-up steps; neither is timed.
+    wake_t0, wake_n = time.perf_counter(), 0
+    while time.perf_counter() - wake_t0 < WAKE_S and wake_n < 400:
+        step()
+        wake_n += 1
+    wake_ms = 1e3 * (time.perf_counter() - wake_t0)
     for _ in range(warmup):
         step()
 
-    # ---- the timed region: exactly `steps` passes, nothing else (each submitted and waited for, as in every round) ----
+    # ---- the timed region: exactly `steps` passes, nothing else -------------------------------------------------------
     step_s = []
     barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        ts = time.perf_counter()
-        step()
-        step_s.append(time.perf_counter() - ts)
+    if back_to_back:
+        for _ in range(steps):
+            ctx.batch_process_ptr(ptr, stride, L, 0, want_scores=False)
+        ctx.batch_sync()
+    else:
+        for _ in range(steps):
+            ts = time.perf_counter()
+            step()
+            step_s.append(time.perf_counter() - ts)
     barrier()
     elapsed = time.perf_counter() - t0
     ms_by_rank = [1e3 * elapsed / steps]
@@ -270,16 +289,16 @@ def measure(torch, wl, steps, warmup, barrier, gather_elapsed=None, n_series=Non
             k_series[k].append(t[k])
         launches = {"front_chunks": int(t["front_chunks"]), "decode_launches": int(t["decode_launches"])}
         fused = bool(t["fused_front"])
-    # the same passes enqueued back to back and waited for once (outside the timed region): what a caller with batch after
-    # batch sees -- the library then runs the matched filter of a long-stream pass beside the front end of the pass before
+    # the same passes each waited for by itself (outside the timed region; how rounds 1-3 timed a step): the host's wait and
+    # the next submission then lie between two passes -- and the matched filter of a long-stream pass cannot run beside the
+    # front end of the pass before
     torch.cuda.synchronize()
-    b2b_ms = None
     if back_to_back:
-        tb0 = time.perf_counter()
         for _ in range(steps):
-            ctx.batch_process_ptr(ptr, stride, L, 0, want_scores=False)
-        ctx.batch_sync()
-        b2b_ms = 1e3 * (time.perf_counter() - tb0) / steps
+            ts = time.perf_counter()
+            step()
+            step_s.append(time.perf_counter() - ts)
+    b2b_ms = (1e3 * elapsed / steps) if back_to_back else None
     k_ms = {k: statistics.fmean(v) for k, v in k_series.items()}
     k_min = {k: min(v) for k, v in k_series.items()}
     k_med = {k: statistics.median(v) for k, v in k_series.items()}
@@ -343,7 +362,7 @@ def measure(torch, wl, steps, warmup, barrier, gather_elapsed=None, n_series=Non
                 "timing": "HIP events on the library's stream around each launch, %d untimed passes after the timed region"
                           % len(k_series["gate_ms"])}
 
-    return dict(elapsed=elapsed, step_s=step_s, b2b_ms=b2b_ms, ms_by_rank=ms_by_rank, k_ms=k_ms, alg=alg, key=key, roof=roof, rep=rep, st=st,
+    return dict(elapsed=elapsed, step_s=step_s, b2b_ms=b2b_ms, wake={"passes": wake_n, "ms": round(wake_ms, 1)}, ms_by_rank=ms_by_rank, k_ms=k_ms, alg=alg, key=key, roof=roof, rep=rep, st=st,
                 n_epc_ok=n_epc_ok, n_windows=n_windows, n_rn16=n_rn16, n_epc=n_epc, parity_ok=parity_ok, parity_text=parity_text)
 
 
@@ -372,7 +391,7 @@ def other_configs(torch, rfid, synth, args, device, rank):
             el = m["elapsed"] / sp["steps"]
             entry = {"workload": wl["describe"], "steps": sp["steps"], "warmup": sp["warmup"],
                      "ms_per_step": round(1e3 * el, 4), "value": round(wl["L"] / el / 1e6, 2), "unit": "Msamples/s",
-                     "ms_per_step_back_to_back": None if m["b2b_ms"] is None else round(m["b2b_ms"], 4),
+                     "ms_per_step_each_waited_for": round(1e3 * statistics.fmean(m["step_s"]), 4),
                      "epc_decodes_per_s": round(m["n_epc_ok"] / el, 1), "windows_per_step": m["n_windows"],
                      "parity_check": m["parity_text"],
                      "roofline_by_kernel": {k: {f: m["roof"](k)[f] for f in ("ms_per_step", "achieved", "frac", "frac_of_achievable",
@@ -428,7 +447,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stream-leg", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short configs[2] / configs[3] measurements")
-    ap.add_argument("--no-back-to-back", action="store_true", help="skip the untimed series of passes enqueued back to back (profiled runs)")
+    ap.add_argument("--no-back-to-back", action="store_true", help="time every pass waited for by itself (as rounds 1-3 did) instead of the K passes enqueued one behind the other: the profiled runs use it, a kernel trace then holds no queueing")
     ap.add_argument("--stream-replicas", type=int, default=160, help="replicas concatenated into the host-resident stream")
     ap.add_argument("--stream-chunk", type=int, default=32_000_000, help="raw samples per rfid_stream_work call")
     args = ap.parse_args()
@@ -520,10 +539,13 @@ def main():
         "unit": "Msamples/s",
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "min_ms_per_step": round(min(step_s) * 1e3, 4), "median_ms_per_step": round(statistics.median(step_s) * 1e3, 4),
-        "passes_back_to_back": None if m["b2b_ms"] is None else
-                               {"ms_per_step": round(m["b2b_ms"], 4),
-                                "note": "the same K passes enqueued without a wait in between, one wait at the end; outside the timed region"},
+        "timed_region": ("the K passes enqueued one behind the other, one wait at the end (barrier + device synchronisation on both sides)"
+                         if m["b2b_ms"] is not None else "every pass waited for by itself (--no-back-to-back)"),
+        "device_wake": dict(m["wake"], note="the same passes run for %.0f ms of wall time before the W warm-up steps (the device's clocks after the host's set-up work); untimed" % (1e3 * WAKE_S)),
+        "passes_each_waited_for": {"ms_per_step": round(statistics.fmean(step_s) * 1e3, 4), "min_ms_per_step": round(min(step_s) * 1e3, 4),
+                                   "median_ms_per_step": round(statistics.median(step_s) * 1e3, 4),
+                                   "note": ("the same K passes, each submitted and waited for by itself (the timed region of rounds 1-3); "
+                                            "outside the timed region" if m["b2b_ms"] is not None else "this IS the timed region")},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl["describe"], "streams_per_gpu": B, "raw_samples_per_stream": L,
