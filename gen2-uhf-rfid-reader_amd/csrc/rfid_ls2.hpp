@@ -960,6 +960,135 @@ RFID_KERNEL(64) void ls2_fsm_kernel(Ls2Args a) {
   }
 }
 
+// The same with one LANE per unit (long passes).  The scalar unit is shared by a CU's four SIMDs and issues one instruction
+// per cycle: with tens of thousands of units ls2_fsm_kernel is bound by exactly that (configs[2]: 338 M scalar instructions,
+// 1.3 M per CU = the kernel's 0.62 ms).  Here the state machine of gate_fsm_step runs on the vector unit, 64 units per
+// instruction; a lane walks its unit step by step -- the steps of an idle gate and the inside of a window are taken in
+// runs, as above -- and fetches the vote words one step ahead.  No wave-level operation below the first line: lanes come and
+// go as their units end.
+#ifndef LS2_FSM_LANES_N
+#define LS2_FSM_LANES_N 16
+#endif
+#ifndef LS2_FSM_GROUP_N
+#define LS2_FSM_GROUP_N 16
+#endif
+constexpr int LS2_FSM_GROUP = LS2_FSM_GROUP_N;   // steps whose vote words are fetched together
+constexpr int LS2_FSM_LANES = LS2_FSM_LANES_N;   // units per wave: a wave's pace is its slowest lane's and the walk is bound by the latency of
+                                      // its scattered loads, so fewer units per wave and more waves per CU
+RFID_KERNEL(64) void ls2_fsm_lanes_kernel(Ls2Args a) {
+  Ls2Ctl *ctl = a.ctl;
+  if (ctl->fail != 0) return;
+  const int r = a.round;
+  if (r == 0) { if (ctl->avg_count[a.avg_rounds] != 0) return; }
+  else if (ctl->fsm_count[r - 1] == 0) return;
+  const int NH = a.n_streams * a.max_bc;
+  if ((int)threadIdx.x >= LS2_FSM_LANES) return;
+  const int b = (int)(blockIdx.x * LS2_FSM_LANES + threadIdx.x);
+  if (b >= NH) return;
+  const int i = (b / a.max_bc) * a.max_b + (b % a.max_bc) * LS2_FINE;
+  if (a.piece[i].len <= 0) return;
+  Ls2Fsm *fh = a.fsm + i;
+  if (fh->head == 0) return;
+  if (r > 0 && fh->rerun == 0) return;
+  const int s = i / a.max_b, J = (i - s * a.max_b) / LS2_FINE;
+  const int n_total = ls2_trace_len(a, s);
+  const int u0 = a.piece[i].pos0;
+  int u1 = u0 + a.piece[i].len;
+  for (int cur = i;;) {
+    const int nx = a.nextv[cur];
+    if (nx < 0 || a.piece[nx].len <= 0 || a.fsm[nx].head != 0) break;
+    a.fsm[nx].unit = i;
+    u1 = a.piece[nx].pos0 + a.piece[nx].len;
+    cur = nx;
+  }
+  GateRegs g;
+  g.avg_c = 0.0f; g.consumed = 0; g.stop = false;
+  if (i == s * a.max_b) {
+    if (a.carry) {
+      const GateState *cs = a.carry + s;
+      g.f_n = cs->n_samples; g.f_state = cs->signal_state; g.f_pulses = cs->num_pulses;
+      g.f_open = cs->gate_open; g.f_ung = cs->n_to_ungate; g.f_type = cs->wtype;
+    } else {
+      g.f_n = 0; g.f_state = 0; g.f_pulses = 0; g.f_open = 0; g.f_ung = 0; g.f_type = 0;
+    }
+    if (g.f_ung == 0) g.f_ung = g.f_type ? EPC_WIN : RN16_WIN;
+  } else {
+    g.f_n = LS2_IDLE_N; g.f_state = 1; g.f_pulses = 0; g.f_open = 0; g.f_ung = RN16_WIN; g.f_type = 0;
+  }
+  fh->st[0] = g.f_n; fh->st[1] = g.f_state; fh->st[2] = g.f_pulses; fh->st[3] = g.f_open; fh->st[4] = g.f_ung; fh->st[5] = g.f_type;
+  fh->rerun = 0;
+  const int n = u1 - u0, off = u0 & 63;
+  const uint64_t *votes = a.votes + 2 * ((int64_t)s * a.vstride + (u0 >> 6));
+  const int64_t cbase = (int64_t)s * a.cstride + (u0 >> 6) + J;
+  uint64_t *closed = a.closed + cbase;
+  int *oinfo = a.openinfo + cbase;
+  Ls2Win *wb = a.wb + (int64_t)s * a.wb_stride;
+  const int nsteps = (n + 63) >> 6, nfull = n >> 6;
+  int nwin = 0, nepc = 0, last_end = -2147483647 - 1;
+  // step k = bits off.. of word k and bits ..off of word k + 1 (a unit's last word + 1 exists: vstride has the room).  The
+  // words of LS2_FSM_GROUP steps are fetched together -- one memory latency per group, not per step (a lane's loads are its
+  // own: 64 cache lines per instruction, nothing hides them but other lanes' instructions)
+  int k = 0;
+  while (k < nsteps) {
+    const int kg = k;
+    uint64_t wl[LS2_FSM_GROUP + 1], wg[LS2_FSM_GROUP + 1];
+#pragma unroll
+    for (int u = 0; u <= LS2_FSM_GROUP; ++u) {
+      const int idx = (kg + u < nsteps) ? (kg + u) : nsteps;
+      wl[u] = votes[2 * idx]; wg[u] = votes[2 * idx + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < LS2_FSM_GROUP; ++u) {
+      if (k != kg + u || k >= nsteps) continue;   // (a window took the steps up to k in one go, or the unit has ended)
+      const uint64_t v_lt = off ? ((wl[u] >> off) | (wl[u + 1] << (64 - off))) : wl[u];
+      const uint64_t v_gt = off ? ((wg[u] >> off) | (wg[u + 1] << (64 - off))) : wg[u];
+      if (!g.f_open && g.f_state == 1 && g.f_pulses <= NUM_PULSES_CMD && k < nfull && v_lt == 0ull) {
+        // gate closed, nothing pending, no sample below the threshold: the step only counts samples
+        closed[k] = ~0ull; oinfo[k] = 0xff;
+        const int fn = g.f_n + 64;
+        g.f_n = (fn > GATE_N_SAT) ? GATE_N_SAT : fn;
+        k += 1;
+        continue;
+      }
+      if (g.f_open) {
+        // inside a window: the steps that lie wholly inside it need no votes
+        const int rem = g.f_ung - g.f_n;
+        int run = (rem > 64) ? ((rem - 65) / 64 + 1) : 0;
+        const int room = nfull - k;
+        run = (run < room) ? run : room;
+        if (run > 0) {
+          for (int q = 0; q < run; ++q) { closed[k + q] = 0ull; oinfo[k + q] = 0xff; }
+          g.f_n += 64 * run;
+          k += run;
+          continue;
+        }
+      }
+      int nvalid = (n - 64 * k < 64) ? (n - 64 * k) : 64;
+      const uint64_t vm = (nvalid >= 64) ? ~0ull : ((1ull << nvalid) - 1ull);   // (the last step's word holds the next unit's votes too)
+      uint64_t closedmask, openmask;
+      int open_lane, open_type;
+      gate_fsm_step(0, g, v_lt & vm, v_gt & vm, 64 * k, nvalid, closedmask, openmask, open_lane, open_type);
+      if (open_lane != 0xff) {   // gate_impl.cc:164-180
+        const int start = u0 + 64 * k + open_lane;
+        const int wlen = open_type ? EPC_WIN : RN16_WIN;
+        const int complete = (start + wlen <= n_total) ? 1 : 0;
+        Ls2Win *w = wb + start / LS2_WBUCKET;
+        if (w->tag != 0 && ((w->tag >> 8) == r + 1) && w->start != start) ctl->wb_clash = 1;
+        w->start = start;
+        w->tag = open_type | (complete << 1) | ((r + 1) << 8);
+        nwin += complete;
+        nepc += complete & open_type;
+        last_end = start + wlen;
+      }
+      closed[k] = closedmask; oinfo[k] = open_lane | (open_type << 8);
+      k += 1;
+    }
+  }
+  fh->unit = i; fh->gen = r + 1; fh->nwin = nwin; fh->nepc = nepc; fh->last_end = last_end; fh->u1 = u1;
+  fh->en[0] = g.f_n; fh->en[1] = g.f_state; fh->en[2] = g.f_pulses; fh->en[3] = g.f_open; fh->en[4] = g.f_ung; fh->en[5] = g.f_type;
+  if (r > 0) wv::atomic_add(&ctl->fsm_reruns, 1);
+}
+
 // one workgroup per trace: does every unit start from the state its predecessor ended in, with the dc ring a cut assumes
 // (the 48 samples before it closed)?  A unit that does not is appended to its predecessor, which is scanned again.
 RFID_KERNEL(256) void ls2_fsm_chain_kernel(Ls2Args a) {

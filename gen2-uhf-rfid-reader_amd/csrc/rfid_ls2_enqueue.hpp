@@ -89,6 +89,7 @@ inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geomet
   a.seq0 = (int *)(base + L.seq0); a.flat_base = (int *)(base + L.flat_base); a.cflag = (int *)(base + L.cflag); a.cagg = (int *)(base + L.cagg); a.ctl = (Ls2Ctl *)(base + L.ctl); a.consumed = (int *)(base + L.consumed);
 }
 
+inline int &ls2_fsm_lanes_min() { static int v = 8192; return v; }   // from this many possible heads on the state machine runs one lane per unit (tests: 0 / a huge number)
 inline int &ls2_chain_slots() { static int v = 4096; return v; }   // slots per workgroup of a chain launch (tests shrink it)
 
 #ifdef LS2_LAUNCH
@@ -134,7 +135,10 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
   // (test hook: dc_fine = 0 / 1 says so itself)
   a.dc_fine = (dc_fine < 0) ? (small ? 1 : 0) : dc_fine;
   LS2_LAUNCH(ls2_pieces_kernel, (NS + 255) / 256, 1, 256, a);
-  const int rerun_grid = NS;   // (one wave per list entry; the waves past the list return at once)
+  // re-run launches: one wave per list entry, the waves loop when the list is longer than the grid.  The grid used to be the
+  // slot count: 130 000 workgroups that return at once cost 28 us per launch, and most of a pass's sixteen re-run launches
+  // have little or nothing to do.  (A first avg_ampl round may hold most pieces: below 32 768 workgroups it ran slower.)
+  auto rerun_grid = [&](int round, int most) { const int g = (round == 1) ? most : most / 2; return (NS < g) ? NS : g; };
   // workgroups per trace of the chain kernels: a few thousand slots each
   auto chain_g = [](int slots) { const int per = ls2_chain_slots(); int g = (slots + per - 1) / per; return g < 1 ? 1 : (g > LS2_CHAIN_GMAX ? LS2_CHAIN_GMAX : g); };
   const int g_avg = chain_g(a.max_b), g_seq = chain_g(a.max_bc);   // (pieces: any slot; units: idle-grid slots)
@@ -143,13 +147,14 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
   LS2_LAUNCH(ls2_avg_chain_kernel, g_avg, B, LS2_CHAIN_THREADS, a);
   for (int r = 1; r <= a.avg_rounds; ++r) {
     a.round = r;
-    LS2_LAUNCH(ls2_avg_rerun_kernel, rerun_grid, 1, 64, a);
+    LS2_LAUNCH(ls2_avg_rerun_kernel, rerun_grid(r, 32768), 1, 64, a);
     a.stamp++;
     LS2_LAUNCH(ls2_avg_chain_kernel, g_avg, B, LS2_CHAIN_THREADS, a);
   }
   for (int r = 0; r <= a.fsm_rounds; ++r) {
     a.round = r;
-    LS2_LAUNCH(ls2_fsm_kernel, NH, 1, 64, a);
+    if (NH >= ls2_fsm_lanes_min()) LS2_LAUNCH(ls2_fsm_lanes_kernel, (NH + LS2_FSM_LANES - 1) / LS2_FSM_LANES, 1, 64, a);
+    else LS2_LAUNCH(ls2_fsm_kernel, NH, 1, 64, a);
     LS2_LAUNCH(ls2_fsm_chain_kernel, (NH + 255) / 256, 1, 256, a);
   }
   a.round = 0;
@@ -161,7 +166,7 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
   LS2_LAUNCH(ls2_dc_chain_kernel, g_dc, B, LS2_CHAIN_THREADS, a);
   for (int r = 1; r <= a.dc_rounds; ++r) {
     a.round = r;
-    LS2_LAUNCH(ls2_dc_rerun_kernel, rerun_grid, 1, 64, a);
+    LS2_LAUNCH(ls2_dc_rerun_kernel, rerun_grid(r, 16384), 1, 64, a);
     a.stamp++;
     LS2_LAUNCH(ls2_dc_chain_kernel, g_dc, B, LS2_CHAIN_THREADS, a);
   }

@@ -96,8 +96,10 @@ def test_ls2_carrier_at_a_power_of_two(emu_mod, oracle_mod, synth_mod):
     assert r["ctl"]["avg_count9"] > 0 and r["ctl"]["n_pieces"] > 20, r["ctl"]
 
 
-def test_ls2_ragged_batch_collisions_and_limits(emu_mod, oracle_mod, synth_mod):
-    """Per-trace lengths (one trace cut inside a slot, one too short to be cut, one empty), FIXED_Q = 2 collisions."""
+@pytest.mark.parametrize("fsm_lanes", [False, True])
+def test_ls2_ragged_batch_collisions_and_limits(emu_mod, oracle_mod, synth_mod, fsm_lanes):
+    """Per-trace lengths (one trace cut inside a slot, one too short to be cut, one empty), FIXED_Q = 2 collisions.
+    (fsm_lanes: the state machine in its one-lane-per-unit form, which the library takes on long passes.)"""
     kw = dict(fixed_q=2, tag_ids=(0x11, 0x22, 0x33), sigma=0.01, t1_jitter_raw=5)
     traces = [synth_mod.make_trace(n_rounds=r, seed=900 + r, **kw).samples for r in (4, 3, 1)]
     L = max(map(len, traces))
@@ -108,11 +110,12 @@ def test_ls2_ragged_batch_collisions_and_limits(emu_mod, oracle_mod, synth_mod):
         lens.append(len(t))
     lens.append(0)
     lens[1] -= 12345
-    r = _check(emu_mod, oracle_mod, raw, lens=lens, cfg_kw=dict(fixed_q=2), expect_ok=1)
+    r = _check(emu_mod, oracle_mod, raw, lens=lens, cfg_kw=dict(fixed_q=2), expect_ok=1, fsm_lanes=fsm_lanes)
     assert r["stats"][3]["n_windows"] == 0
 
 
-def test_ls2_cuts_that_are_not_idle_are_withdrawn(emu_mod, oracle_mod, synth_mod):
+@pytest.mark.parametrize("fsm_lanes", [False, True])
+def test_ls2_cuts_that_are_not_idle_are_withdrawn(emu_mod, oracle_mod, synth_mod, fsm_lanes):
     """Cut points forced to arbitrary places -- inside reader commands, inside open windows, right behind a window: the
     state machine's end state does not meet the idle state assumed at the next cut (or the dc ring is not the last 48
     samples), the pieces are appended to their predecessors (n_units < n_pieces) and scanned through; avg_ampl needs no
@@ -132,12 +135,13 @@ def test_ls2_cuts_that_are_not_idle_are_withdrawn(emu_mod, oracle_mod, synth_mod
             seen.add(J)
             cuts.append(c)
     assert len(cuts) >= 6
-    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, cuts=sorted(cuts))
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, cuts=sorted(cuts), fsm_lanes=fsm_lanes)
     c = r["ctl"]
     assert c["n_heads"] == len(cuts) + 1 and c["n_units"] < c["n_heads"] and c["fsm_rounds"] >= 2, c
 
 
-def test_ls2_streaming_form_carries_the_gate_state(emu_mod, oracle_mod, synth_mod):
+@pytest.mark.parametrize("fsm_lanes", [False, True])
+def test_ls2_streaming_form_carries_the_gate_state(emu_mod, oracle_mod, synth_mod, fsm_lanes):
     """The form rfid_stream_work uses: a call processes up to its last idle cut (hold_last), leaves the gate state there
     (rings rebuilt from the samples, recurrences from the chains) and the next call starts from it.  Two calls over one
     trace give the windows of the sequential scan over the whole trace."""
@@ -145,11 +149,11 @@ def test_ls2_streaming_form_carries_the_gate_state(emu_mod, oracle_mod, synth_mo
     o = oracle_mod.run_trace(t)
     state = np.zeros(emu_mod.lib().emu_gate_state_size(), dtype=np.uint8)
     half = (len(t) // 2) // 5 * 5
-    r1 = emu_mod.ls2_process(t[None, :half], state=state, hold_last=True)
+    r1 = emu_mod.ls2_process(t[None, :half], state=state, hold_last=True, fsm_lanes=fsm_lanes)
     assert r1["ok"] == 1 and 0 < r1["consumed"] < half // 5
     c1 = r1["consumed"]
     # the second call: 25 raw samples early, so that the matched filter has its history (the 5 leading outputs are skipped)
-    r2 = emu_mod.ls2_process(t[None, 5 * c1 - 25:], state=state, hold_last=False, y_skip=5)
+    r2 = emu_mod.ls2_process(t[None, 5 * c1 - 25:], state=state, hold_last=False, y_skip=5, fsm_lanes=fsm_lanes)
     assert r2["ok"] == 1
     k = len(r1["windows"])
     assert k > 4 and len(r2["windows"]) > 4

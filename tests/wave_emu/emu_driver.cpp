@@ -321,6 +321,8 @@ int emu_ls2_process(const float *raw, int B, long stride, long n_raw, const int6
 int emu_ls2_ctl_words(void) { return (int)(sizeof(Ls2Ctl) / 4); }
 // slots per workgroup of the chain launches (the library: 4096): small values make the emulated traces span several workgroups
 void emu_ls2_chain_slots(int n) { ls2_chain_slots() = n; }
+// from how many possible heads on the state machine takes its one-lane-per-unit form (the library: 8192)
+void emu_ls2_fsm_lanes_min(int n) { ls2_fsm_lanes_min() = n; }
 
 // gate_scan_kernel in streaming mode (mode 1) on one call's worth of samples.
 // seek_type: -1 none, 0 SEEK_RN16, 1 SEEK_EPC applied before the scan (gate_impl.cc:112-123).
