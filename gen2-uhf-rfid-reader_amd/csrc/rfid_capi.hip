@@ -191,6 +191,8 @@ struct rfid_ctx {
   int *d_ticket = nullptr;   // RN16 pack counters of the decoder launches (two, used alternately)
   int ticket_flip = 0;
   rfid_decode_result *d_res = nullptr;
+  int *d_sum = nullptr;                          // plans of few, long traces: a one-word summary per result for the statistics kernel
+  const rfid_decode_result *sum_of = nullptr;    // (rfid_kernels.hpp, stats_summary()); sum_of: the result table they were last written for
   rfid_scores *d_scores = nullptr;
   rfid_stream_stats *d_stats = nullptr;
   const int64_t *d_lens = nullptr;  // of the last rfid_batch_mf
@@ -312,6 +314,8 @@ void free_plan(rfid_ctx *c) {
   if (c->plan_blk) (void)hipFree(c->plan_blk);
   if (c->alt_blk) (void)hipFree(c->alt_blk);
   if (c->alt_y_blk) (void)hipFree(c->alt_y_blk);
+  if (c->d_sum) (void)hipFree(c->d_sum);
+  c->d_sum = nullptr; c->sum_of = nullptr;
   c->plan_blk = nullptr; c->alt_blk = nullptr; c->alt_y_blk = nullptr;
   c->y_recorded[0] = c->y_recorded[1] = false;
   c->y_idx = 0;
@@ -959,6 +963,11 @@ int rfid_batch_plan(rfid_ctx *c, int n_streams, int64_t max_raw) {
     return fail(c, RFID_ERR_HIP, "rfid_batch_plan: workspace allocation", e);
   }
   c->B = c->B_plan = n_streams;
+  if (c->wmax > 2048) {
+    // few, long traces: the statistics kernel is one workgroup per trace, and 48-byte results through one CU are its whole
+    // time (0.36 ms for configs[2]'s 320 000 windows); the decoder leaves the word it needs of each (doing without is fine)
+    if (hipMalloc((void **)&c->d_sum, sizeof(int) * ((size_t)c->flat_cap + 4)) != hipSuccess) { (void)hipGetLastError(); c->d_sum = nullptr; }
+  }
   {
     // the second result set (see rfid_ctx::ResultSet): opt-in (RFID_OVERLAP=2) and only where it is small beside what is
     // free.  Measured on configs[1] (profiles/r04/overlap.txt): the decoder's waves beside the next front end take their
@@ -1088,6 +1097,8 @@ int rfid_batch_decode(rfid_ctx *c, int want_scores) {
   DecodeListArgs a;
   a.y = c->y(); a.y_stride = c->y_stride; a.cap = c->flat_cap; a.res = c->d_res;
   a.scores = want_scores ? c->d_scores : nullptr; a.wmax = c->wmax;
+  a.sum = c->alt_have ? nullptr : c->d_sum;   // (one array: not with two result sets in flight)
+  c->sum_of = a.sum ? c->d_res : nullptr;
   memcpy(a.t_cand, c->t_cand, sizeof(a.t_cand));
   hipStream_t ts = c->tail_stream ? c->tail_stream : c->stream;
   if (!c->tail_stream) { int rj = join_tails(c); if (rj) return rj; }
@@ -1119,6 +1130,7 @@ int rfid_batch_stats(rfid_ctx *c) {
   HIPCHK(c, hipSetDevice(c->device));
   StatsArgs a;
   a.res = c->d_res; a.wcount = c->d_wcount; a.wmax = c->wmax; a.n_streams = c->B;
+  a.sum = (c->d_sum && c->sum_of == c->d_res) ? c->d_sum : nullptr;   // (the summaries rfid_batch_decode left of THESE results)
   a.max_slot_number = (int)pow(2, c->prm.fixed_q);
   a.max_num_queries = c->prm.max_num_queries; a.number_unique_tags = c->prm.number_unique_tags;
   a.out = c->d_stats;

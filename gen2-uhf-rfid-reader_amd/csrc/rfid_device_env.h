@@ -121,6 +121,11 @@ RFID_DEVICE void wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// four consecutive ints from a 16-byte aligned address in one load
+RFID_DEVICE void load4_i32(const int *p, int &a, int &b, int &c, int &d) {
+  const int4 q = *reinterpret_cast<const int4 *>(p);
+  a = q.x; b = q.y; c = q.z; d = q.w;
+}
 RFID_DEVICE int atomic_add(int *p, int v) { return atomicAdd(p, v); }
 RFID_DEVICE int atomic_min(int *p, int v) { return atomicMin(p, v); }
 // hand-off between workgroups of one launch (those with lower block index are dispatched first): the publisher's earlier

@@ -1493,7 +1493,11 @@ struct DecodeListArgs {
   rfid_scores *scores;      // nullable
   int wmax;
   float t_cand[N_TCAND];
+  int *sum;                 // nullable, [n_streams][wmax]: what stream_stats_kernel needs of a result in one word (stats_summary())
 };
+// type | crc_ok << 1 | (tag_id & 255) << 2: all the statistics kernel reads of a 48-byte result.  With few, long traces that
+// kernel is one workgroup walking hundreds of thousands of results -- through one CU's 64 bytes per cycle
+RFID_DEVICE int stats_summary(const rfid_decode_result &r) { return (r.type & 1) | ((r.crc_ok & 1) << 1) | ((r.tag_id & 255) << 2); }
 
 constexpr int EPC_PACK = 3;
 constexpr int EPC_GRP = N_TCAND;            // 20 lanes per window
@@ -1705,7 +1709,7 @@ RFID_DEVICE void decode_epc3_body(const DecodeListArgs &a) {
         for (int i = 0; i < 8; ++i) id |= (int)((b1 >> (40 + i)) & 1ull) << (7 - i);
         r.tag_id = id;
       }
-      if (lane == 0) a.res[cur.slot[q]] = r;
+      if (lane == 0) { a.res[cur.slot[q]] = r; if (a.sum) a.sum[cur.slot[q]] = stats_summary(r); }
       if (a.scores) {
         rfid_scores *sc = a.scores + cur.slot[q];
         if (g == q && t < N_SYNC) sc->corr[t] = corr;
@@ -1786,6 +1790,7 @@ RFID_DEVICE void decode_rn16x4_body(const DecodeListArgs &a, int *ticket) {
         r.bits[0] = (uint32_t)bits; r.bits[1] = r.bits[2] = r.bits[3] = 0u;
         r.n_bits = 16; r.crc_ok = 0; r.tag_id = -1;
         a.res[slot] = r;
+        if (a.sum) a.sum[slot] = stats_summary(r);
       }
       if (a.scores) {
         rfid_scores *sc = a.scores + slot;
@@ -1827,6 +1832,7 @@ struct StatsArgs {
   int max_num_queries;
   int number_unique_tags;
   rfid_stream_stats *out;         // [n_streams]
+  const int *sum;                 // nullable: the results' one-word summaries (DecodeListArgs::sum), read instead of `res`
 };
 
 // One workgroup per trace (one wavefront, or sixteen when traces hold many windows: the host picks), 64 windows per
@@ -1860,7 +1866,28 @@ RFID_KERNEL(64 * STATS_MAX_WAVES) void stream_stats_kernel(StatsArgs a) {
   // (four 64-window batches per turn, their loads in flight together: with few long traces a wave walks tens of
   // thousands of 48-byte records and is bound by the latency of one batch after the other)
   int epc_mine = 0;
-  for (int base = k0; base < k1; base += 64 * STATS_UNROLL) {
+  const int *sm = a.sum ? (a.sum + (int64_t)s * a.wmax) : nullptr;
+  const bool sm_vec = sm && (((uintptr_t)sm) & 15u) == 0u;
+  // four summaries per lane and load (16 bytes: a wave's load is 1 KB in one piece), zeros from `limit` on
+  auto fetch4 = [&](const int k, const int limit, int (&w)[4]) {
+    if (sm_vec && k + 3 < limit) wv::load4_i32(sm + k, w[0], w[1], w[2], w[3]);
+    else { for (int j = 0; j < 4; ++j) w[j] = (k + j < limit) ? sm[k + j] : 0; }
+  };
+  if (sm) {
+    for (int base = k0; base < k1; base += 256 * STATS_UNROLL) {
+      int w[STATS_UNROLL][4];
+#pragma unroll
+      for (int u = 0; u < STATS_UNROLL; ++u) fetch4(base + 256 * u + 4 * lane, k1, w[u]);
+#pragma unroll
+      for (int u = 0; u < STATS_UNROLL; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if ((w[u][j] & 3) == 3) wv::atomic_min(&first[(w[u][j] >> 2) & 255], base + 256 * u + 4 * lane + j);
+          epc_mine += wv::popc64(wv::ballot((w[u][j] & 1) != 0));
+        }
+    }
+  }
+  for (int base = k0; base < k1 && !sm; base += 64 * STATS_UNROLL) {
     int v[STATS_UNROLL];
 #pragma unroll
     for (int u = 0; u < STATS_UNROLL; ++u) {
@@ -1892,7 +1919,7 @@ RFID_KERNEL(64 * STATS_MAX_WAVES) void stream_stats_kernel(StatsArgs a) {
       int seen = 0;
       for (int base = k0; base < k1; base += 64) {
         const int k = base + lane;
-        const bool is_epc = (k < k1) && (rs[k].type & 1);
+        const bool is_epc = (k < k1) && ((sm ? sm[k] : rs[k].type) & 1);
         const uint64_t epc = wv::ballot(is_epc);
         const int c = wv::popc64(epc);
         if (seen + c >= need) {
@@ -1930,7 +1957,22 @@ RFID_KERNEL(64 * STATS_MAX_WAVES) void stream_stats_kernel(StatsArgs a) {
   // ---- pass 2: counts over the windows before the cut-off ----
   int n_epc = 0, n_ok = 0;
   const int k1t = (k1 < k_term) ? k1 : k_term;
-  for (int base = k0; base < k1t; base += 64 * STATS_UNROLL) {
+  if (sm) {
+    for (int base = k0; base < k1t; base += 256 * STATS_UNROLL) {
+      int w[STATS_UNROLL][4];
+#pragma unroll
+      for (int u = 0; u < STATS_UNROLL; ++u) fetch4(base + 256 * u + 4 * lane, k1t, w[u]);
+#pragma unroll
+      for (int u = 0; u < STATS_UNROLL; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if ((w[u][j] & 3) == 3) wv::atomic_add(&hist[(w[u][j] >> 2) & 255], 1);
+          n_epc += wv::popc64(wv::ballot((w[u][j] & 1) != 0));
+          n_ok += wv::popc64(wv::ballot((w[u][j] & 3) == 3));
+        }
+    }
+  }
+  for (int base = k0; base < k1t && !sm; base += 64 * STATS_UNROLL) {
     int v[STATS_UNROLL];
 #pragma unroll
     for (int u = 0; u < STATS_UNROLL; ++u) {

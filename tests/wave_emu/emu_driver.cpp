@@ -163,6 +163,7 @@ int emu_batch_process(const float *raw, int B, long stride, long n_raw, const in
 
   DecodeListArgs da;
   da.y = y; da.y_stride = y_stride; da.cap = flat_cap; da.res = res.data(); da.scores = sc.data(); da.wmax = wmax;
+  da.sum = nullptr;   // (the statistics kernel reads the results themselves here; emu_ls2_process runs it on the one-word summaries)
   rfidh::t_candidates(da.t_cand, 400000);
   {   // the one-launch tag_decoder, as rfid_batch_decode launches it (2 persistent waves here)
     DecodeAllArgs all;
@@ -176,7 +177,7 @@ int emu_batch_process(const float *raw, int B, long stride, long n_raw, const in
   StatsArgs sa;
   sa.res = res.data(); sa.wcount = wcount.data(); sa.wmax = wmax; sa.n_streams = B;
   sa.max_slot_number = 1 << fixed_q; sa.max_num_queries = max_num_queries;
-  sa.number_unique_tags = number_unique_tags; sa.out = stats;
+  sa.number_unique_tags = number_unique_tags; sa.out = stats; sa.sum = nullptr;
   emu::launch(emu::Idx3{(unsigned)B, 1, 1}, emu::Idx3{256, 1, 1}, [&]() { stream_stats_kernel(sa); });   // four waves share a trace's windows
 
   long total = 0;
@@ -289,8 +290,11 @@ int emu_ls2_process(const float *raw, int B, long stride, long n_raw, const int6
   }
   if (state_blob) memcpy(state_blob, gstate.data(), sizeof(GateState));
 
+  std::vector<float4> sums4((size_t)flat_cap / 4 + 2);   // (16-byte aligned: the statistics kernel's 16-byte loads)
+  struct { int *p; int *data() { return p; } } sums = {reinterpret_cast<int *>(sums4.data())};
   DecodeListArgs da;
   da.y = y; da.y_stride = y_stride; da.cap = flat_cap; da.res = res.data(); da.scores = sc.data(); da.wmax = wmax;
+  da.sum = sums.data();
   rfidh::t_candidates(da.t_cand, 400000);
   da.list = flat.data() + flat_cap; da.count = &flat_count[1];
   emu::launch(emu::Idx3{2, 1, 1}, emu::Idx3{64, 1, 1}, [&]() { decode_epc3_kernel(da); });
@@ -300,7 +304,7 @@ int emu_ls2_process(const float *raw, int B, long stride, long n_raw, const int6
   StatsArgs sa;
   sa.res = res.data(); sa.wcount = wcount.data(); sa.wmax = wmax; sa.n_streams = B;
   sa.max_slot_number = 1 << fixed_q; sa.max_num_queries = max_num_queries;
-  sa.number_unique_tags = number_unique_tags; sa.out = stats;
+  sa.number_unique_tags = number_unique_tags; sa.out = stats; sa.sum = sums.data();
   emu::launch(emu::Idx3{(unsigned)B, 1, 1}, emu::Idx3{256, 1, 1}, [&]() { stream_stats_kernel(sa); });
 
   long total = 0;

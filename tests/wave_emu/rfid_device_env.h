@@ -222,6 +222,7 @@ static inline void lds_load_desc(const int *p, int &flags, int &nvalid, uint64_t
 static inline void set_priority_high() {}
 template <int P> static inline void set_priority() {}
 static inline void backoff() { emu::yield(); }
+static inline void load4_i32(const int *p, int &a, int &b, int &c, int &d) { a = p[0]; b = p[1]; c = p[2]; d = p[3]; }
 static inline int atomic_add(int *p, int v) { int o = *p; *p = o + v; return o; }
 static inline int atomic_min(int *p, int v) { int o = *p; if (v < o) *p = v; return o; }
 static inline void publish(int *flag, int v) { *(volatile int *)flag = v; }
