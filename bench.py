@@ -522,6 +522,12 @@ def main():
 
     # every rank's check and device, gathered over the control plane: the job fails if ANY rank's results are wrong
     dev_name = torch.cuda.get_device_name(device)
+    try:      # (a box without the amdgpu.ids table gives an empty marketing name: the architecture and the CU count say which part it is)
+        pr = torch.cuda.get_device_properties(device)
+        arch = getattr(pr, "gcnArchName", "") or ""
+        dev_name = ("%s %s, %d CUs, %.0f GB" % (dev_name, arch.split(":")[0], pr.multi_processor_count, pr.total_memory / 1e9)).strip()
+    except Exception:
+        pass
     devices = ["%s (cuda:%d)" % (dev_name, dev_index)]
     parity_by_rank = [parity_text]
     if dist is not None:
