@@ -447,6 +447,11 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
   a.carry = opt.carry ? c->d_gstate : nullptr; a.carry_out = opt.carry ? c->d_gstate : nullptr;
   a.hold_last = opt.hold_last ? 1 : 0; a.force = opt.force ? 1 : 0;
   ls2_stream = c->stream;
+  {   // test hook: from how many possible heads on the state machine takes its one-lane-per-unit form (default 8192)
+    static const int lanes_min_default = ls2_fsm_lanes_min();
+    const char *e = getenv("RFID_LS2_FSM_LANES_MIN");
+    ls2_fsm_lanes_min() = e ? atoi(e) : lanes_min_default;
+  }
   ls2_enqueue(a, true, c->ls2_rounds, c->ls2_generous);
   HIPCHK(c, hipGetLastError());
   // (the control block and, right behind it, consumed[0])

@@ -1,7 +1,7 @@
 # developer aid: rfid_batch_process through the long-stream front end (forced) and the fused one on random small ragged
 # batches -- trace counts, lengths, noise up to 8 %, truncation points -- against the oracle: windows, dc_est, scores,
 # statistics.  The long-stream passes may give up (noise): the sequential scan behind them must give the same bytes.
-import sys
+import os, sys
 sys.path.insert(0, "tests"); sys.path.insert(0, "gen2-uhf-rfid-reader_amd"); sys.path.insert(0, ".")
 import numpy as np
 import torch; torch.cuda.is_available()
@@ -28,7 +28,11 @@ def run(seed):
     cfg = oracle.config(fixed_q=fixed_q, max_num_queries=1 << 30)
     refs = [oracle.run_trace(host[b, : lens[b]], cfg) for b in range(B)]
     verdicts = []
-    for mode in (2, 0, 2):
+    for k, mode in enumerate((2, 0, 2)):
+        # (the second long-stream context runs the state machine in its one-lane-per-unit form, which the library takes on
+        # long passes only)
+        if k == 2: os.environ["RFID_LS2_FSM_LANES_MIN"] = "0"
+        else: os.environ.pop("RFID_LS2_FSM_LANES_MIN", None)
         ctx = rfid.Context(device=0, fixed_q=fixed_q, max_num_queries=1 << 30)
         try:
             ctx.batch_set_long_stream(mode)

@@ -71,8 +71,8 @@ def test_stream_with_a_stretch_that_cannot_be_cut(oracle_mod, synth_mod):
         ctx.close()
 
 
-@pytest.mark.parametrize("mode", [0, 2], ids=["fused", "long-stream"])
-def test_non_finite_samples_propagate_as_in_the_reference(oracle_mod, synth_mod, mode):
+@pytest.mark.parametrize("mode", [0, 2, 3], ids=["fused", "long-stream", "long-stream-fsm-on-lanes"])
+def test_non_finite_samples_propagate_as_in_the_reference(oracle_mod, synth_mod, mode, monkeypatch):
     """The contract for samples that are not finite: nothing is rejected or sanitised -- they go through the matched
     filter and the gate's recurrences exactly as through the reference's (gate_impl.cc:130-162: a NaN amplitude turns
     avg_ampl into NaN for good, every threshold test then fails and the gate never opens again; an infinity becomes a
@@ -87,6 +87,9 @@ def test_non_finite_samples_propagate_as_in_the_reference(oracle_mod, synth_mod,
     cases = [("inf in the carrier", int(clean.open_idx[6]) * 5 - 2000, complex(np.inf, 0.0)),
              ("nan inside a window", int(clean.open_idx[7]) * 5 + 300, complex(np.nan, 1.0)),
              ("-inf inside a window", int(clean.open_idx[3]) * 5 + 100, complex(0.0, -np.inf))]
+    if mode == 3:      # (the state machine's one-lane-per-unit form, which the library takes on long passes only)
+        monkeypatch.setenv("RFID_LS2_FSM_LANES_MIN", "0")
+        mode = 2
     ctx = rfid.Context(device=0)
     try:
         ctx.batch_set_long_stream(mode)
