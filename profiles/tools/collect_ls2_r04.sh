@@ -35,3 +35,5 @@ for k in sorted(agg):
 PY
 rm -rf $O/trace_* $O/pmc_2_FETCH_SIZE $O/pmc_2_WRITE_SIZE
 ls -la $O
+unset RFID_LS_CALIBRATE
+timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_1.json 2> $O/bench_1.err
