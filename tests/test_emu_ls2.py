@@ -200,3 +200,21 @@ def test_chain_add_auto2_equals_two_sequential_sums(emu_mod):
                 acc = np.float32(acc + x[i])
                 assert got[i].view(np.uint32) == acc.view(np.uint32), (trial, float(c0), i)
     assert n_scanned > 120
+
+
+@pytest.mark.parametrize("kw", [dict(max_num_queries=7), dict(number_unique_tags=1), dict(max_num_queries=2, number_unique_tags=2)])
+def test_ls2_statistics_from_summaries_with_the_terminated_cut_off(emu_mod, oracle_mod, synth_mod, kw):
+    """The statistics kernel on the decoder's one-word summaries (what the library does for few, long traces; the emulated
+    long-stream chain runs it so) with the reader's stop conditions inside the trace: the queries limit (the cut-off index is
+    searched in the summaries), the distinct-tag limit, both."""
+    t = synth_mod.make_trace(n_rounds=14, sigma=0.01, seed=321, fixed_q=1, tag_ids=(0x31, 0x52)).samples
+    assert oracle_mod.run_trace(t, oracle_mod.config(fixed_q=1)).state.n_unique_tags == 2     # (the limits below do cut the run)
+    r = emu_mod.ls2_process(t[None, :], fixed_q=1, **kw)
+    assert r["ok"] == 1
+    o = oracle_mod.run_trace(t, oracle_mod.config(fixed_q=1, **kw))
+    st = r["stats"][0]
+    assert st["status"] == o.state.status == 1
+    assert 0 < st["n_windows_used"] == o.n_windows < st["n_windows"]
+    for k in ("n_queries_sent", "cur_inventory_round", "cur_slot_number", "n_epc_correct", "n_unique_tags"):
+        assert st[k] == getattr(o.state, k), k
+    assert np.array_equal(st["tag_reads"], np.array(o.state.tag_reads[:], dtype=np.int32))
