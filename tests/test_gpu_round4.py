@@ -206,3 +206,34 @@ def test_python_flowgraph_with_a_foreign_filter(oracle_mod, synth_mod):
             assert len(tb.decoded) == o.n_windows
         finally:
             tb.ctx.close()
+
+
+@pytest.mark.parametrize("kw", [dict(max_num_queries=300), dict(number_unique_tags=1), dict()])
+def test_statistics_of_a_long_trace_from_the_decoders_summaries(oracle_mod, synth_mod, kw):
+    """A plan whose traces can hold more than 2 048 windows: the decoder leaves a one-word summary of every result and the
+    statistics kernel (one workgroup per trace) reads those, 16 bytes per lane, instead of the 48-byte results.  Counts, tag
+    reads and the TERMINATED cut-off (queries limit inside the trace, distinct-tag limit, none) equal the oracle's."""
+    import torch
+    import rfid
+    t = synth_mod.make_trace(n_rounds=260, sigma=0.01, seed=97, fixed_q=1, tag_ids=(0x31, 0x52), t1_jitter_raw=3).samples
+    L = len(t)
+    assert L // 5 // 347 > 2048                      # (the plan's window capacity per trace)
+    o = oracle_mod.run_trace(t, oracle_mod.config(fixed_q=1, **kw))
+    stride = (L + 1) & ~1
+    host = np.zeros((1, stride), dtype=np.complex64)
+    host[0, :L] = t
+    dev = torch.from_numpy(host.view(np.float32)).to("cuda:0")
+    ctx = rfid.Context(device=0, fixed_q=1, **kw)
+    try:
+        ctx.batch_plan(1, L)
+        for _ in range(2):
+            ctx.batch_process_ptr(dev.data_ptr(), stride, L, 0, want_scores=False)
+        ctx.batch_sync()
+        st = ctx.batch_stats()[0]
+        assert st["n_windows_used"] == o.n_windows and st["n_windows"] >= o.n_windows
+        assert st["status"] == o.state.status
+        for k in ("n_queries_sent", "cur_inventory_round", "cur_slot_number", "n_epc_correct", "n_unique_tags"):
+            assert st[k] == getattr(o.state, k), k
+        assert np.array_equal(st["tag_reads"], np.array(o.state.tag_reads[:], dtype=np.int32))
+    finally:
+        ctx.close()
