@@ -7,10 +7,10 @@ import csv, collections, glob, sys
 agg=collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/c/f_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "rfidk::ls2" in r["Kernel_Name"] or "rfidk::mf" in r["Kernel_Name"]:
+        if "rfidk::" in r["Kernel_Name"] and "synth" not in r["Kernel_Name"]:
             agg[(r["Kernel_Name"].split("(")[0].replace("rfidk::",""), r["Counter_Name"])].append(float(r["Counter_Value"]))
 for k in sorted(agg):
-    if "chain" in k[0] or "seq" in k[0] or "clear" in k[0] or "assemble" in k[0] or "pieces" in k[0] or "dc_cut" in k[0]: continue
+    if "seq" in k[0] or "clear" in k[0] or "assemble" in k[0] or "pieces" in k[0] or "dc_cut" in k[0]: continue
     v = agg[k]; print("%-26s %-20s n=%3d first=%14.0f sum=%14.0f" % (k[0], k[1], len(v), v[0], sum(v)))
 PY
 rm -rf $OUT/c
