@@ -579,14 +579,16 @@ def main():
     if B == 1:
         out["single_stream"] = {"raw_msamples_per_s": round(L / (elapsed / args.steps) / 1e6, 2),
                                 "x_realtime_at_2Msps": round(L / (elapsed / args.steps) / 2e6, 1)}
-    if rank == 0 and args.config == "1" and not args.no_stream_leg:
+    # the legs below belong to the single-GPU line (the contract's cpu_baseline is "on rank 0 at N = 1 only"; with N > 1 the
+    # other ranks would sit in the closing barrier while rank 0 works through them)
+    solo = n_gpus == 1
+    if rank == 0 and solo and args.config == "1" and not args.no_stream_leg:
         out["streaming"] = streaming_leg(torch, rfid, wl, args, device)
-    if rank == 0 and args.config == "1" and not args.no_other_configs:
+    if rank == 0 and solo and args.config == "1" and not args.no_other_configs:
         # the other single-GPU BASELINE configurations, each a short measurement of its own OUTSIDE the headline's timed
         # region (rank 0's GPU only): configs[3]'s per-GPU stream always, configs[2] when the device has room for it
         out["other_configs"] = other_configs(torch, rfid, synth, args, device, rank)
-    if rank == 0 and not args.no_cpu_baseline:
-        # rank 0 only (N = 1 and N > 1 alike): the same host serves all ranks
+    if rank == 0 and solo and not args.no_cpu_baseline:
         x, what = wl["sample"]()
         out["cpu_baseline"] = cpu_baseline(x, args.cpu_seconds, fixed_q=wl["fixed_q"], what=what)
     elif rank == 0:
