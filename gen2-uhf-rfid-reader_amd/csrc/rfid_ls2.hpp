@@ -103,7 +103,7 @@ struct Ls2Win {   // one gate opening
   int pad_;
 };
 
-struct Ls2Aff { int64_t c0, c1; };
+struct Ls2Aff { int c0, c1; int tstar; int pad_; };   // a piece's function with the exact end for the start `tstar` put in (the entry of tstar's parity)
 
 struct Ls2Args {
   const float2 *y; int64_t y_stride;
@@ -755,7 +755,7 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_avg_chain_kernel(Ls2Args a) {
     if (c + 1 < c_hi) nxt = ls2_avg_rec(a, base, 64 * (c + 1) + lane);
     Ls2A32 el; el.c0 = 0; el.c1 = 0;
     if (ru.len > 0) {
-      if (ru.wide & 4) { const Ls2Aff o = a.aover[base + 64 * c + lane]; el.c0 = (int)o.c0; el.c1 = (int)o.c1; }
+      if (ru.wide & 4) { const Ls2Aff o = a.aover[base + 64 * c + lane]; el.c0 = o.c0; el.c1 = o.c1; }
       else el = ls2_elem32(ru.s, ru.eA, ru.eB);
     }
     const Ls2A32 incl = ls2_wave_incl(el, lane);
@@ -774,8 +774,9 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_avg_chain_kernel(Ls2Args a) {
     const int i = base + 64 * c + lane;
     const bool in = ru.len > 0;
     Ls2A32 el; el.c0 = 0; el.c1 = 0;
+    int tstar = 0;
     if (in) {
-      if (ru.wide & 4) { const Ls2Aff o = a.aover[i]; el.c0 = (int)o.c0; el.c1 = (int)o.c1; }
+      if (ru.wide & 4) { const Ls2Aff o = a.aover[i]; el.c0 = o.c0; el.c1 = o.c1; tstar = o.tstar; }
       else el = ls2_elem32(ru.s, ru.eA, ru.eB);
     }
     const Ls2A32 incl = ls2_wave_incl(el, lane);
@@ -794,12 +795,22 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_avg_chain_kernel(Ls2Args a) {
         const int want = (int)((uint32_t)e_exact - (uint32_t)T);
         const int cq = (T & 1) ? el.c1 : el.c0;
         if (cq != want) {
-          Ls2Aff o; o.c0 = (T & 1) ? el.c0 : want; o.c1 = (T & 1) ? want : el.c1;
+          Ls2Aff o; o.c0 = (T & 1) ? el.c0 : want; o.c1 = (T & 1) ? want : el.c1; o.tstar = T; o.pad_ = 0;
           a.aover[i] = o;
           a.arun[i].wide = ru.wide | 4;
           n_left++;
           hold = true;
         }
+      }
+      // A function with an exact end put in serves the start it was made for.  When a later chain lands on another start of
+      // that parity -- the piece's own (D = 0: its end is eA), or one its margin covers -- the entry is not this start's: the
+      // plain function comes back and the chain is redone.  (Found with an experiment that changed the order in which pieces
+      // settle, profiles/r04/ls2_second_half.txt: a piece that settled with D = 0 kept the end of a start two ulps off, and
+      // every start behind it was two ulps off, in a pass that reported success.  The full-size parity tests never met it.)
+      const bool will_list = !hold && D != 0 && !(aD + 4 <= (int64_t)ru.margin);
+      if ((ru.wide & 4) && T != tstar && !hold && !will_list) {
+        a.arun[i].wide = ru.wide & ~4;
+        n_left++;
       }
       // settled: the run started from the true value, or provably covers it (its votes included).  Anything else is run
       // again from the true (or predicted) start -- also a piece whose END is known exactly from a neighbouring start: its

@@ -218,3 +218,16 @@ def test_ls2_statistics_from_summaries_with_the_terminated_cut_off(emu_mod, orac
     for k in ("n_queries_sent", "cur_inventory_round", "cur_slot_number", "n_epc_correct", "n_unique_tags"):
         assert st[k] == getattr(o.state, k), k
     assert np.array_equal(st["tag_reads"], np.array(o.state.tag_reads[:], dtype=np.int32))
+
+
+@pytest.mark.parametrize("seed,scale,kw", [(2, 0.64, {}), (2, 0.32, {}), (6, 0.64, dict(target=8, min_piece=2048)), (6, 0.6401, {})])
+def test_ls2_exact_end_put_into_a_function_serves_its_own_start_only(emu_mod, oracle_mod, synth_mod, seed, scale, kw):
+    """Carriers at a power of two again, the seeds on which the chain once ACCEPTED wrong starts: a piece run from six
+    neighbouring starts has its exact end for the start the chain landed on put into its function (Ls2Aff); when the next
+    chain lands on another start of the same parity -- the piece's own, D = 0 -- that entry is not this start's end.  The
+    pass reported success with up to 33 piece starts two ulps off.  Now the plain function comes back and the chain is
+    redone: every start equals the in-order recurrence, windows and scores the oracle's."""
+    t = synth_mod.make_trace(n_rounds=8, sigma=0.01, seed=seed).samples
+    t = (t * np.complex64(scale)).astype(np.complex64)
+    r = _check(emu_mod, oracle_mod, t[None, :], **kw)      # (checks avg_ampl at every cut whenever the pass was accepted)
+    assert r["ok"] == 1, r["ctl"]
