@@ -52,7 +52,9 @@ def run(seed):
 
 ok = bad = 0
 ver = []
-for seed in range(40):
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 0          # fuzz_batch.py [first seed [count]]
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+for seed in range(first, first + count):
     try:
         ver += run(seed)
         ok += 1
