@@ -9,13 +9,15 @@ import rfid, parity
 from rfid import synth
 from oracle import oracle
 
+LONG = len(sys.argv) > 3 and sys.argv[3] == "long"      # fuzz_batch.py first count long: one or two traces of 60 .. 300 rounds
+
 def run(seed):
     rng = np.random.default_rng(seed)
-    B = int(rng.integers(1, 6))
+    B = int(rng.integers(1, 3)) if LONG else int(rng.integers(1, 6))
     sigma = float(rng.choice([0.002, 0.01, 0.03, 0.08]))
     fixed_q = int(rng.integers(0, 3))
     tags = tuple(int(x) for x in rng.choice(np.arange(1, 200), size=int(rng.integers(1, 4)), replace=False))
-    traces = [synth.make_trace(n_rounds=int(rng.integers(3, 40)), seed=int(rng.integers(1, 1 << 30)), sigma=sigma, fixed_q=fixed_q,
+    traces = [synth.make_trace(n_rounds=int(rng.integers(60, 300) if LONG else rng.integers(3, 40)), seed=int(rng.integers(1, 1 << 30)), sigma=sigma, fixed_q=fixed_q,
                                tag_ids=tags, t1_jitter_raw=int(rng.integers(0, 6))).samples for _ in range(B)]
     lens = [int(len(t) - rng.integers(0, min(len(t) // 2, 40000))) if rng.random() < 0.5 else len(t) for t in traces]
     L = max(map(len, traces))
