@@ -26,7 +26,7 @@ for k in sorted(agg):
     wa = sum(w) / len(w) if w else 0.0
     print("%s,%d,%.1f,%.1f,%.1f,%.1f,%.0f" % (k, max(len(f), len(w)), fa, wa, sum(f), sum(w), (2 * fa + wa) * 1024))
 PY
-bash scratch/sqset.sh final_a "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" > $O/sq_config2_a.txt 2>&1
-bash scratch/sqset.sh final_b "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" > $O/sq_config2_b.txt 2>&1
+bash profiles/tools/sq_counters_config2.sh final_a "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" > $O/sq_config2_a.txt 2>&1
+bash profiles/tools/sq_counters_config2.sh final_b "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" > $O/sq_config2_b.txt 2>&1
 rm -rf $O/trace_1 $O/pmc_1_FETCH_SIZE $O/pmc_1_WRITE_SIZE
 ls $O
