@@ -224,6 +224,10 @@ struct rfid_ctx {
   // (long-stream passes: only the matched-filter output alternates -- the filter of pass k + 1 beside the front end of pass k)
   void *alt_y_blk = nullptr;                // a second matched-filter output buffer alone (plans too small for a whole second set)
   hipEvent_t ev_y_free[2] = {nullptr, nullptr};
+  // long-stream passes enqueued back to back: points of a pass behind which most of the device idles (0: the small avg_ampl
+  // rounds, 1: the dc_est re-runs, 2: the decoder): the next pass's matched filter runs in parts, the later ones behind them
+  hipEvent_t ev_gap[3] = {nullptr, nullptr, nullptr};
+  bool gap_recorded[3] = {false, false, false};
   bool y_recorded[2] = {false, false};
   int y_idx = 0;
   hipStream_t tail_stream = nullptr;        // where rfid_batch_decode / rfid_batch_stats enqueue (c->stream, or stream2 in an overlapped pass)
@@ -408,6 +412,7 @@ struct LsOpts {
   bool hold_last = false;   // leave each trace's last piece unprocessed (streaming: whatever follows the last idle cut
                             // waits for more samples)
   bool force = false;       // run even when no trace could be cut more than once
+  bool marks = false;       // record c->ev_gap[0 / 1] at the list's two quiet points (rfid_batch_process with a second filter buffer)
 };
 // Enqueues one pass of the front end over c->d_y (n_dec decimated samples per trace, c->d_lens).  *enqueued = 0: not
 // applicable here (traces too short, no work space) -- nothing was launched.  Whether the pass produced the window
@@ -452,7 +457,12 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
     const char *e = getenv("RFID_LS2_FSM_LANES_MIN");
     ls2_fsm_lanes_min() = e ? atoi(e) : lanes_min_default;
   }
-  ls2_enqueue(a, true, c->ls2_rounds, c->ls2_generous);
+  auto mark = [](void *p, int pt) {
+    rfid_ctx *cc = (rfid_ctx *)p;
+    if (hipEventRecord(cc->ev_gap[pt], cc->stream) == hipSuccess) cc->gap_recorded[pt] = true;
+    else (void)hipGetLastError();
+  };
+  ls2_enqueue(a, true, c->ls2_rounds, c->ls2_generous, -1, opt.marks ? +mark : nullptr, c);
   HIPCHK(c, hipGetLastError());
   // (the control block and, right behind it, consumed[0])
   HIPCHK(c, hipMemcpyAsync(c->ls2_host, a.ctl, sizeof(Ls2Ctl) + sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -689,7 +699,10 @@ int rfid_ctx_create(const rfid_params *p, int device, rfid_ctx **out) {
                 hipEventCreateWithFlags(&c->ev_tail_done[0], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&c->ev_tail_done[1], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&c->ev_y_free[0], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&c->ev_y_free[1], hipEventDisableTiming) != hipSuccess))
+                hipEventCreateWithFlags(&c->ev_y_free[1], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_gap[0], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_gap[1], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_gap[2], hipEventDisableTiming) != hipSuccess))
       rc = RFID_ERR_HIP;
     if (rc) break;
     {
@@ -744,7 +757,9 @@ int rfid_ctx_destroy(rfid_ctx *c) {
     for (int i = 0; i < 2; ++i) {
       if (c->ev_tail_done[i]) (void)hipEventDestroy(c->ev_tail_done[i]);
       if (c->ev_y_free[i]) (void)hipEventDestroy(c->ev_y_free[i]);
+      if (c->ev_gap[i]) (void)hipEventDestroy(c->ev_gap[i]);
     }
+    if (c->ev_gap[2]) (void)hipEventDestroy(c->ev_gap[2]);
     (void)hipStreamDestroy(c->stream2);
   }
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1032,7 +1047,8 @@ int rfid_batch_set_streams(rfid_ctx *c, int n_streams) {
   return RFID_OK;
 }
 
-static int batch_mf_on(rfid_ctx *c, hipStream_t stream, const void *d_raw, int64_t raw_stride, int64_t n_raw, const void *d_lens);
+static int batch_mf_on(rfid_ctx *c, hipStream_t stream, const void *d_raw, int64_t raw_stride, int64_t n_raw, const void *d_lens,
+                       int n_parts = 1, const hipEvent_t *part_waits = nullptr, const bool *part_have = nullptr);
 int rfid_batch_mf(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64_t n_raw, const void *d_lens) {
   if (!c || !d_raw || n_raw < 0 || raw_stride < n_raw) return RFID_ERR_INVALID;
   if (!c->B) return RFID_ERR_STATE;
@@ -1041,7 +1057,9 @@ int rfid_batch_mf(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64_t n_
   { int rj = join_tails(c); if (rj) return rj; }
   return batch_mf_on(c, c->stream, d_raw, raw_stride, n_raw, d_lens);
 }
-static int batch_mf_on(rfid_ctx *c, hipStream_t stream, const void *d_raw, int64_t raw_stride, int64_t n_raw, const void *d_lens) {
+// n_parts > 1: the output tiles in that many launches, launch i >= 1 behind part_waits[i - 1] (when part_have[i - 1])
+static int batch_mf_on(rfid_ctx *c, hipStream_t stream, const void *d_raw, int64_t raw_stride, int64_t n_raw, const void *d_lens,
+                       int n_parts, const hipEvent_t *part_waits, const bool *part_have) {
   c->d_lens = (const int64_t *)d_lens;
   c->last_n_raw = n_raw;
   MfArgs a;
@@ -1053,11 +1071,25 @@ static int batch_mf_on(rfid_ctx *c, hipStream_t stream, const void *d_raw, int64
   c->fused_last = 0;
   HIPCHK(c, hipEventRecord(c->ev[0], stream));
   const int64_t tiles = (a.n_out + MF_TILE - 1) / MF_TILE;
-  if (tiles > 0) {
+  if (n_parts < 1 || tiles < 1024 * (int64_t)n_parts) n_parts = 1;
+  // (shares of the parts in percent: what the quiet stretches behind the points take, profiles/r04/ls2_second_half.txt)
+  int share[8] = {45, 40, 15, 0, 0, 0, 0, 0};
+  if (n_parts > 8) n_parts = 8;
+  if (const char *e = getenv("RFID_MF_SPLIT")) { int k = 0; for (const char *q = e; *q && k < 8; ++k) { share[k] = atoi(q); while (*q && *q != ',') ++q; if (*q) ++q; } }
+  else if (n_parts != 3) for (int k = 0; k < 8; ++k) share[k] = (k < n_parts) ? 100 / n_parts : 0;
+  int64_t t_next = 0;
+  int acc = 0;
+  for (int part = 0; part < n_parts && tiles > 0; ++part) {
+    acc += share[part];
+    const int64_t t_lo = t_next, t_hi = (part == n_parts - 1 || acc >= 100) ? tiles : (tiles * acc / 100);
+    t_next = t_hi;
+    if (t_lo >= t_hi) continue;
+    if (part > 0 && part_waits && part_have && part_have[part - 1]) HIPCHK(c, hipStreamWaitEvent(stream, part_waits[part - 1], 0));
+    a.tile0 = t_lo;
     for (int s0 = 0; s0 < c->B; s0 += 65535) {   // gridDim.y limit
       a.stream0 = s0;
       const int ns = (c->B - s0 < 65535) ? (c->B - s0) : 65535;
-      hipLaunchKernelGGL(mf_boxcar25_decim5_kernel, dim3((unsigned)tiles, (unsigned)ns), dim3(MF_THREADS), 0,
+      hipLaunchKernelGGL(mf_boxcar25_decim5_kernel, dim3((unsigned)(t_hi - t_lo), (unsigned)ns), dim3(MF_THREADS), 0,
                          stream, a);
       HIPCHK(c, hipGetLastError());
     }
@@ -1186,15 +1218,27 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_y_free[c->y_idx], 0));
         c->y_recorded[c->y_idx] = false;
       }
-      if ((rc = batch_mf_on(c, c->stream2, d_raw, raw_stride, n_raw, d_lens))) return rc;
+      // ... in three parts (45 / 40 / 15 % of the output tiles): the first at once, the others behind the two points of the pass
+      // before from where on most of the device idles (its small avg_ampl rounds and state machine; its dc_est re-runs, assembly
+      // and decoder) -- beside the big launches, which move 2 - 4 TB/s themselves, the filter gains little.  Measured on
+      // configs[2], passes enqueued back to back: 10.37 - 10.43 -> 10.06 - 10.07 ms (profiles/r04/ls2_second_half.txt; RFID_MF_PARTS /
+      // RFID_MF_SPLIT are the experiment's knobs).
+      static const int mf_parts = getenv("RFID_MF_PARTS") ? atoi(getenv("RFID_MF_PARTS")) : 3;
+      if ((rc = batch_mf_on(c, c->stream2, d_raw, raw_stride, n_raw, d_lens, mf_parts, c->ev_gap, c->gap_recorded))) return rc;
       HIPCHK(c, hipEventRecord(c->ev_fe_done, c->stream2));
       HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fe_done, 0));
     } else if ((rc = batch_mf_on(c, c->stream, d_raw, raw_stride, n_raw, d_lens))) {
       return rc;
     }
     int enq = 0;
-    if ((rc = ls_enqueue(c, n_out, LsOpts(), &enq))) return rc;
+    LsOpts lo;
+    lo.marks = ahead;
+    if ((rc = ls_enqueue(c, n_out, lo, &enq))) return rc;
     if ((rc = rfid_batch_gate_impl(c, enq ? &c->d_ls2_ctl->ok : nullptr))) return rc;
+    if (ahead) {
+      if (hipEventRecord(c->ev_gap[2], c->stream) == hipSuccess) c->gap_recorded[2] = true;
+      else (void)hipGetLastError();
+    }
     if ((rc = rfid_batch_decode(c, want_scores))) return rc;
     if ((rc = rfid_batch_stats(c))) return rc;
     if (ahead) {

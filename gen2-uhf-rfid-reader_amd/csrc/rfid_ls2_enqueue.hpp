@@ -96,7 +96,11 @@ inline int &ls2_chain_slots() { static int v = 4096; return v; }   // slots per 
 // One pass (its first launch zeroes Ls2Ctl, the chain flags, the votes, the window buckets and flat_count).  `a` complete but for
 // `round`.  After it: wtab / wcount / flat lists + Ls2Ctl::ok = 1, or ok = 0 (the caller's fallback scan, enqueued
 // behind with GateArgs::skip_if = &ctl->ok, then runs).
-inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nullptr, bool generous = false, int dc_fine = -1) {   // (search_cuts = false: a.cut is given -- tests)
+// mark / mark_arg: optional call-back at two points of the list (0: behind the first avg_ampl re-run round, 1: behind the first
+// dc_est pass) -- from there on the launches are small and most of the device idles; the library records events there and
+// lets parts of the NEXT pass's matched filter start behind them
+inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nullptr, bool generous = false, int dc_fine = -1,
+                        void (*mark)(void *, int) = nullptr, void *mark_arg = nullptr) {   // (search_cuts = false: a.cut is given -- tests)
   const int NS = a.n_streams * a.max_b, NH = a.n_streams * a.max_bc;   // slots; slots that can be heads
   const int B = a.n_streams;
   {
@@ -150,6 +154,7 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
     LS2_LAUNCH(ls2_avg_rerun_kernel, rerun_grid(r, 32768), 1, 64, a);
     a.stamp++;
     LS2_LAUNCH(ls2_avg_chain_kernel, g_avg, B, LS2_CHAIN_THREADS, a);
+    if (r == 1 && mark) mark(mark_arg, 0);
   }
   for (int r = 0; r <= a.fsm_rounds; ++r) {
     a.round = r;
@@ -164,6 +169,7 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
   LS2_LAUNCH(ls2_dc_first_kernel, a.dc_fine ? NS : NH, 1, 64, a);
   a.stamp++;
   LS2_LAUNCH(ls2_dc_chain_kernel, g_dc, B, LS2_CHAIN_THREADS, a);
+  if (mark) mark(mark_arg, 1);
   for (int r = 1; r <= a.dc_rounds; ++r) {
     a.round = r;
     LS2_LAUNCH(ls2_dc_rerun_kernel, rerun_grid(r, 16384), 1, 64, a);

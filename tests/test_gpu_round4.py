@@ -237,3 +237,44 @@ def test_statistics_of_a_long_trace_from_the_decoders_summaries(oracle_mod, synt
         assert np.array_equal(st["tag_reads"], np.array(o.state.tag_reads[:], dtype=np.int32))
     finally:
         ctx.close()
+
+
+def test_long_stream_passes_back_to_back_with_the_filter_in_parts(oracle_mod, synth_mod):
+    """Long-stream passes enqueued one behind the other: the matched filter of pass k + 1 runs on the second stream into a second
+    output buffer, in three parts, the later ones behind events the pass before records where its launches get small.  Two
+    different traces alternate without a wait in between; what the getters return behind the last pass (and behind one more)
+    is that trace's own result, window for window the oracle's."""
+    import torch
+    import rfid
+    ts = [synth_mod.make_trace(n_rounds=600, sigma=0.01, seed=300 + k, fixed_q=1, tag_ids=(0x21 + k, 0x44), t1_jitter_raw=2).samples for k in range(2)]
+    L = min(len(t) for t in ts)
+    assert L // 5 * 8 >= (16 << 20) and (L // 5 + 511) // 512 >= 3 * 1024      # a second filter buffer is made; the filter runs in parts
+    refs = [oracle_mod.run_trace(t[:L], oracle_mod.config(fixed_q=1, max_num_queries=1 << 30)) for t in ts]
+    stride = (L + 1) & ~1
+    devs = []
+    for t in ts:
+        host = np.zeros((1, stride), dtype=np.complex64)
+        host[0, :L] = t[:L]
+        devs.append(torch.from_numpy(host.view(np.float32)).to("cuda:0"))
+    ctx = rfid.Context(device=0, fixed_q=1, max_num_queries=1 << 30)
+    try:
+        ctx.batch_set_long_stream(2)
+        ctx.batch_plan(1, L)
+        for k in (0, 1, 0, 0, 1, 0, 1):
+            ctx.batch_process_ptr(devs[k].data_ptr(), stride, L, 0, want_scores=False)
+        ctx.batch_sync()
+        for last in (1, 0):
+            if last == 0:
+                ctx.batch_process_ptr(devs[0].data_ptr(), stride, L, 0, want_scores=False)
+                ctx.batch_sync()
+            assert ctx.batch_ls_report()["verified"] == 1
+            w, r, _ = ctx.batch_windows()
+            o = refs[last]
+            assert len(w) == o.n_windows
+            assert np.array_equal(w["start"], o.open_idx) and np.array_equal(w["type"], o.dumps["type"])
+            assert np.array_equal(w["dc_re"].view(np.uint32), o.dc.real.view(np.uint32))
+            assert np.array_equal(w["dc_im"].view(np.uint32), o.dc.imag.view(np.uint32))
+            assert np.array_equal(r["crc_ok"], o.dumps["crc_ok"]) and np.array_equal(r["index"], o.dumps["index"])
+            assert ctx.batch_stats()[0]["n_epc_correct"] == o.state.n_epc_correct
+    finally:
+        ctx.close()
