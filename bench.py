@@ -452,7 +452,7 @@ def main():
     ap.add_argument("--stream-chunk", type=int, default=32_000_000, help="raw samples per rfid_stream_work call")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 10 if args.config in ("1", "3stream") else 3
+        args.steps = 10 if args.config in ("1", "3stream") else (6 if args.config == "2" else 3)
     if args.warmup is None:
         args.warmup = 2 if args.config in ("1", "3stream") else 1
 
