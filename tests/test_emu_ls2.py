@@ -231,3 +231,27 @@ def test_ls2_exact_end_put_into_a_function_serves_its_own_start_only(emu_mod, or
     t = (t * np.complex64(scale)).astype(np.complex64)
     r = _check(emu_mod, oracle_mod, t[None, :], **kw)      # (checks avg_ampl at every cut whenever the pass was accepted)
     assert r["ok"] == 1, r["ctl"]
+
+
+@pytest.mark.parametrize("seed,lanes", [(7002, False), (7034, True)])
+def test_ls2_streaming_form_when_the_second_call_gives_up(emu_mod, oracle_mod, synth_mod, seed, lanes):
+    """The streaming form with a carrier at a power of two: the first call's front end is accepted and carries the gate state,
+    the second call's runs out of rounds and the sequential scan takes the call from the carried state (its windows
+    numbered from 0, as the front end numbers a call's windows): together the windows and dc_est values of the sequential
+    scan over the whole trace."""
+    t = synth_mod.make_trace(n_rounds=12, sigma=0.01, seed=seed, t1_jitter_raw=2).samples
+    t = (t * np.complex64(0.64)).astype(np.complex64)
+    o = oracle_mod.run_trace(t)
+    state = np.zeros(emu_mod.lib().emu_gate_state_size(), dtype=np.uint8)
+    cutp = (len(t) // 2) // 5 * 5
+    r1 = emu_mod.ls2_process(t[None, :cutp], state=state, hold_last=True, fsm_lanes=lanes)
+    if r1["ok"] != 1 or r1["consumed"] <= 0:
+        pytest.skip("the first call was not accepted on this seed")
+    c1 = r1["consumed"]
+    r2 = emu_mod.ls2_process(t[None, 5 * c1 - 25:], state=state, hold_last=False, y_skip=5, fsm_lanes=lanes, generous=False)
+    assert r2["ok"] == 0, r2["ctl"]
+    assert np.array_equal(np.concatenate([r1["windows"]["start"], r2["windows"]["start"] + c1]), o.open_idx)
+    assert np.array_equal(np.concatenate([r1["windows"]["type"], r2["windows"]["type"]]), o.dumps["type"])
+    for f, ref in (("dc_re", o.dc.real), ("dc_im", o.dc.imag)):
+        got = np.concatenate([r1["windows"][f], r2["windows"][f]])
+        assert np.array_equal(got.view(np.uint32), ref.astype(np.float32).view(np.uint32)), f

@@ -281,6 +281,7 @@ int emu_ls2_process(const float *raw, int B, long stride, long n_raw, const int6
   }
   if (ctl_out) memcpy(ctl_out, &ctl_host, sizeof(int) * (size_t)((int)(sizeof(Ls2Ctl) / 4) < ctl_cap ? (int)(sizeof(Ls2Ctl) / 4) : ctl_cap));
   if (!ok && !hold_last) {   // the fallback the library enqueues behind the front end (GateArgs::skip_if)
+    if (state_blob) gstate[0].win_seq = 0;   // (a call's windows are numbered from 0, as the front end numbers them)
     GateArgs ga = {};
     ga.y = y; ga.y_stride = y_stride; ga.n_dec = n_dec; ga.lens = lens; ga.state = gstate.data(); ga.n_streams = B;
     ga.wtab = wtab.data(); ga.wmax = wmax; ga.wcount = wcount.data(); ga.flat = flat.data();
