@@ -1073,7 +1073,7 @@ static int batch_mf_on(rfid_ctx *c, hipStream_t stream, const void *d_raw, int64
   const int64_t tiles = (a.n_out + MF_TILE - 1) / MF_TILE;
   if (n_parts < 1 || tiles < 1024 * (int64_t)n_parts) n_parts = 1;
   // (shares of the parts in percent: what the quiet stretches behind the points take, profiles/r04/ls2_second_half.txt)
-  int share[8] = {45, 40, 15, 0, 0, 0, 0, 0};
+  int share[8] = {35, 45, 20, 0, 0, 0, 0, 0};
   if (n_parts > 8) n_parts = 8;
   if (const char *e = getenv("RFID_MF_SPLIT")) { int k = 0; for (const char *q = e; *q && k < 8; ++k) { share[k] = atoi(q); while (*q && *q != ',') ++q; if (*q) ++q; } }
   else if (n_parts != 3) for (int k = 0; k < 8; ++k) share[k] = (k < n_parts) ? 100 / n_parts : 0;
@@ -1218,10 +1218,11 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_y_free[c->y_idx], 0));
         c->y_recorded[c->y_idx] = false;
       }
-      // ... in three parts (45 / 40 / 15 % of the output tiles): the first at once, the others behind the two points of the pass
+      // ... in three parts (35 / 45 / 20 % of the output tiles): the first at once, the others behind the two points of the pass
       // before from where on most of the device idles (its small avg_ampl rounds and state machine; its dc_est re-runs, assembly
       // and decoder) -- beside the big launches, which move 2 - 4 TB/s themselves, the filter gains little.  Measured on
-      // configs[2], passes enqueued back to back: 10.37 - 10.43 -> 10.06 - 10.07 ms (profiles/r04/ls2_second_half.txt; RFID_MF_PARTS /
+      // configs[2], passes enqueued back to back: 10.4 -> 10.07 ms, and 9.5 - 9.6 with chain launches of 512 instead of 1 024 threads
+      // (which starved beside the filter) (profiles/r04/ls2_second_half.txt; RFID_MF_PARTS /
       // RFID_MF_SPLIT are the experiment's knobs).
       static const int mf_parts = getenv("RFID_MF_PARTS") ? atoi(getenv("RFID_MF_PARTS")) : 3;
       if ((rc = batch_mf_on(c, c->stream2, d_raw, raw_stride, n_raw, d_lens, mf_parts, c->ev_gap, c->gap_recorded))) return rc;

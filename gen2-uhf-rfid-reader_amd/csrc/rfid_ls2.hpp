@@ -51,7 +51,7 @@ constexpr int LS2_DC_ROUNDS = 7;
 constexpr int LS2_MAXR = 12;
 constexpr int LS2_WIDE_BELOW = 64;    // a piece whose margin is below this is re-run from six neighbouring start values at once
 constexpr int LS2_WIDE_LO = -2, LS2_WIDE_HI = 3;
-constexpr int LS2_CHAIN_THREADS = 1024;
+constexpr int LS2_CHAIN_THREADS = 512;      // (1 024-thread workgroups need a CU with sixteen free wave slots at once: beside the next pass's matched filter a chain launch of 25 us then took 400 - 650 us)
 constexpr int LS2_CHAIN_GMAX = 64;     // workgroups per trace of a chain launch, at most
 
 struct Ls2Piece { int pos0, len; };   // len 0: slot not in use

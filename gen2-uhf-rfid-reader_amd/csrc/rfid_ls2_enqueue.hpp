@@ -90,7 +90,7 @@ inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geomet
 }
 
 inline int &ls2_fsm_lanes_min() { static int v = 8192; return v; }   // from this many possible heads on the state machine runs one lane per unit (tests: 0 / a huge number)
-inline int &ls2_chain_slots() { static int v = 4096; return v; }   // slots per workgroup of a chain launch (tests shrink it)
+inline int &ls2_chain_slots() { static int v = 2048; return v; }   // slots per workgroup of a chain launch (tests shrink it)
 
 #ifdef LS2_LAUNCH
 // One pass (its first launch zeroes Ls2Ctl, the chain flags, the votes, the window buckets and flat_count).  `a` complete but for
