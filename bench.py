@@ -281,14 +281,15 @@ def measure(torch, wl, steps, warmup, barrier, gather_elapsed=None, n_series=Non
     #      series of the same passes so that the event reads stay out of the timed region -----------------
     k_series = {"mf_ms": [], "gate_ms": [], "decode_ms": [], "stats_ms": [], "front_ms": []}
     launches = {"front_chunks": 1, "decode_launches": 2}
-    fused = False
+    fused = ls_fused = False
     for _ in range(n_series if n_series is not None else max(3, min(steps, 20))):
         step()
         t = ctx.batch_timing()
         for k in k_series:
             k_series[k].append(t[k])
         launches = {"front_chunks": int(t["front_chunks"]), "decode_launches": int(t["decode_launches"])}
-        fused = bool(t["fused_front"])
+        fused = int(t["fused_front"]) == 1          # front_end_fused_kernel (many traces)
+        ls_fused = int(t["fused_front"]) == 2       # the long-stream front end with its fused first pass (few, long traces)
     # the same passes each waited for by itself (outside the timed region; how rounds 1-3 timed a step): the host's wait and
     # the next submission then lie between two passes -- and the matched filter of a long-stream pass cannot run beside the
     # front end of the pass before
@@ -327,7 +328,14 @@ def measure(torch, wl, steps, warmup, barrier, gather_elapsed=None, n_series=Non
         n_launch = {"mf_boxcar25_decim5": launches["front_chunks"], "gate_scan": launches["front_chunks"],
                     "tag_decoder": launches["decode_launches"]}
     rep = ctx.batch_ls_report()
-    if rep["pieces"] and not fused:
+    if ls_fused:
+        # the long-stream front end, matched filter inside its first launch (round 5): the whole launch sequence -- fused first
+        # pass, chains, re-runs, state machine, dc_est, assembly, the self-skipping fallback -- is timed and priced as ONE unit
+        # that reads every raw sample once, writes y once for the decoder and writes the window records
+        alg = {"front_long_stream": B * (8.0 * L + 8.0 * n_dec) + 24.0 * n_windows, "tag_decoder": dec_bytes}
+        key = {"front_long_stream": "gate_ms", "tag_decoder": "decode_ms"}
+        n_launch = {"front_long_stream": 1, "tag_decoder": launches["decode_launches"]}
+    elif rep["pieces"] and not fused:
         # the gate ran as the long-stream front end: its launch sequence (cut searches, avg_ampl / state machine / dc_est
         # rounds, assembly, the self-skipping sequential scan behind them) is timed and priced as ONE unit
         alg = {("gate_long_stream" if k == "gate_scan" else k): v for k, v in alg.items()}

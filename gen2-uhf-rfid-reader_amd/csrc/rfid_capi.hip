@@ -68,6 +68,7 @@ struct rfid_ctx {
   int ls2_rounds[3] = {0, 0, 0};  // re-run rounds its launch list held per stage (avg_ampl, state machine, dc_est)
   bool ls2_generous = false;      // a pass ran out of rounds once: the launch lists hold the full number of rounds from then on
   int ls_mode = 1;                // 0 never, 1 automatic, 2 whenever a trace can be cut
+  bool ls_fused = true;           // rfid_batch_process: the long-stream front end filters the raw samples itself (ls2_front_kernel)
   double ls_fixed_ms = 0.45, ls_ns_per_sample = 0.03, seq_ns_per_sample = 10.2;   // cost model of the automatic choice (ls_calibrate)
   bool ls_calibrated = false;     // the three numbers were measured on this device (or that was tried, or is not wanted)
   // whole-chain streaming (rfid_stream_*)
@@ -413,6 +414,9 @@ struct LsOpts {
                             // waits for more samples)
   bool force = false;       // run even when no trace could be cut more than once
   bool marks = false;       // record c->ev_gap[0 / 1] at the list's two quiet points (rfid_batch_process with a second filter buffer)
+  // the fused first pass (ls2_front_kernel): the raw samples in HBM -- the matched filter runs inside the front end's first
+  // launch and writes c->d_y; nullptr: c->d_y holds the filter's output already
+  const void *raw = nullptr; int64_t raw_stride = 0;
 };
 // Enqueues one pass of the front end over c->d_y (n_dec decimated samples per trace, c->d_lens).  *enqueued = 0: not
 // applicable here (traces too short, no work space) -- nothing was launched.  Whether the pass produced the window
@@ -451,6 +455,12 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
   a.wtab = c->d_wtab; a.wmax = c->wmax; a.wcount = c->d_wcount; a.flat = c->d_flat; a.flat_count = c->d_flat_count; a.flat_cap = c->flat_cap;
   a.carry = opt.carry ? c->d_gstate : nullptr; a.carry_out = opt.carry ? c->d_gstate : nullptr;
   a.hold_last = opt.hold_last ? 1 : 0; a.force = opt.force ? 1 : 0;
+  if (opt.raw) {
+    a.fused = 1;
+    a.raw = (const float2 *)opt.raw; a.raw_stride = opt.raw_stride;
+    a.raw_vec_ok = ((opt.raw_stride & 1) == 0 && (((uintptr_t)opt.raw) & 15) == 0) ? 1 : 0;
+    a.y_w = c->d_y;
+  }
   ls2_stream = c->stream;
   {   // test hook: from how many possible heads on the state machine takes its one-lane-per-unit form (default 8192)
     static const int lanes_min_default = ls2_fsm_lanes_min();
@@ -681,6 +691,7 @@ int rfid_ctx_create(const rfid_params *p, int device, rfid_ctx **out) {
     const int m = atoi(e);
     c->ls_mode = m < 0 ? 0 : (m > 2 ? 2 : m);
   }
+  if (const char *e = getenv("RFID_LS_FUSED")) c->ls_fused = atoi(e) != 0;
   init_reader_state(c);
   memset(c->mf_hist, 0, sizeof(c->mf_hist));
   int rc = RFID_OK;
@@ -1207,6 +1218,42 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
     HIPCHK(c, hipSetDevice(c->device));
     { int rj = join_tails(c); if (rj) return rj; }
     int rc;
+    // The fused first pass (round 5, the default for traces that start from the fresh gate): no matched-filter launch -- the
+    // front end's first launch filters the raw samples itself (ls2_front_kernel), one sweep over the raw samples instead of the
+    // filter's and three over its output.  When the front end gives up the sequential scan behind it needs all of y: a filter
+    // launch and the scan are enqueued behind the list, both skipping themselves on Ls2Ctl::ok.
+    if (c->ls_fused && raw_stride >= 2) {
+      c->d_lens = (const int64_t *)d_lens;
+      c->last_n_raw = n_raw;
+      c->n_chunks_last = 0;
+      HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+      HIPCHK(c, hipEventRecord(c->ev[1], c->stream));   // mf_ms = 0: the filter runs inside the front end's first launch
+      c->ev_valid[0] = c->ev_valid[1] = true;
+      int enq = 0;
+      LsOpts lo;
+      lo.raw = d_raw; lo.raw_stride = raw_stride;
+      if ((rc = ls_enqueue(c, n_out, lo, &enq))) return rc;
+      if (enq) {
+        c->fused_last = 2;
+        MfFallbackArgs f;
+        f.m.x = (const float2 *)d_raw; f.m.x_stride = raw_stride; f.m.n_raw = n_raw; f.m.lens = c->d_lens;
+        f.m.n_out = n_out; f.m.in_off = -(NTAPS - 1);
+        f.m.vec_ok = ((raw_stride & 1) == 0 && (((uintptr_t)d_raw) & 15) == 0) ? 1 : 0;
+        f.m.y = c->d_y; f.m.y_stride = c->y_stride; f.m.tile0 = 0; f.m.stream0 = 0;
+        f.skip_if = &c->d_ls2_ctl->ok; f.n_tiles = tiles;
+        const int64_t gx = (tiles < 4096) ? tiles : 4096;
+        for (int s0 = 0; s0 < c->B && gx > 0; s0 += 65535) {
+          f.m.stream0 = s0;
+          const int ns = (c->B - s0 < 65535) ? (c->B - s0) : 65535;
+          hipLaunchKernelGGL(mf_fallback_kernel, dim3((unsigned)gx, (unsigned)ns), dim3(MF_THREADS), 0, c->stream, f);
+          HIPCHK(c, hipGetLastError());
+        }
+        if ((rc = rfid_batch_gate_impl(c, &c->d_ls2_ctl->ok))) return rc;
+        if ((rc = rfid_batch_decode(c, want_scores))) return rc;
+        return rfid_batch_stats(c);
+      }
+      // (no work space: the plain sequence below)
+    }
     const bool ahead = c->alt.d_y != nullptr;
     if (ahead) {
       // The matched filter is bound by the HBM, the long-stream front end behind it by its instruction streams: with a second

@@ -66,11 +66,9 @@ struct MfArgs {
   int stream0;          // first trace of this launch (gridDim.y <= 65535 traces per launch)
 };
 
-RFID_KERNEL(MF_THREADS) void mf_boxcar25_decim5_kernel(MfArgs a) {
-  RFID_SHARED float4 tile4[MF_RAW / 2 + 2];
+RFID_DEVICE void mf_tile(const MfArgs &a, const int b, const int64_t tile_idx, float4 *tile4) {
   float2 *tile = reinterpret_cast<float2 *>(tile4);
   const int tid = (int)threadIdx.x;
-  const int b = (int)blockIdx.y + a.stream0;
   int64_t n_raw = a.n_raw, n_out = a.n_out;
   if (a.lens) {
     n_raw = a.lens[b];
@@ -78,7 +76,7 @@ RFID_KERNEL(MF_THREADS) void mf_boxcar25_decim5_kernel(MfArgs a) {
     if (n_raw < 0) n_raw = 0;
     n_out = n_raw / DECIM;
   }
-  const int64_t n0 = ((int64_t)blockIdx.x + a.tile0) * MF_TILE;
+  const int64_t n0 = tile_idx * MF_TILE;
   if (n0 >= n_out) return;
   const float2 *xs = a.x + (int64_t)b * a.x_stride;
   const int64_t r0 = n0 * DECIM + a.in_off;
@@ -115,6 +113,23 @@ RFID_KERNEL(MF_THREADS) void mf_boxcar25_decim5_kernel(MfArgs a) {
       im = im + v.y;
     }
     if (n < n_out) ys[n] = make_float2(re, im);
+  }
+}
+RFID_KERNEL(MF_THREADS) void mf_boxcar25_decim5_kernel(MfArgs a) {
+  RFID_SHARED float4 tile4[MF_RAW / 2 + 2];
+  mf_tile(a, (int)blockIdx.y + a.stream0, (int64_t)blockIdx.x + a.tile0, tile4);
+}
+// The same behind a pass that normally needs no filter launch (the long-stream front end with its fused first pass filters
+// inside ls2_front_kernel; when it gives the pass up, y is incomplete and the sequential scan behind it needs all of it):
+// does nothing when *skip_if != 0 -- a fixed, small grid whose workgroups walk the tiles, so that the usual, skipped case
+// costs a few microseconds whatever the length of the traces.
+struct MfFallbackArgs { MfArgs m; const int *skip_if; int64_t n_tiles; };
+RFID_KERNEL(MF_THREADS) void mf_fallback_kernel(MfFallbackArgs f) {
+  RFID_SHARED float4 tile4[MF_RAW / 2 + 2];
+  if (f.skip_if && *f.skip_if != 0) return;
+  for (int64_t t = blockIdx.x; t < f.n_tiles; t += gridDim.x) {
+    mf_tile(f.m, (int)blockIdx.y + f.m.stream0, t, tile4);
+    wv::block_sync();   // (the tile is written again)
   }
 }
 

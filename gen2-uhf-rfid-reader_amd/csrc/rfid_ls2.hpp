@@ -57,7 +57,8 @@ constexpr int LS2_CHAIN_GMAX = 64;     // workgroups per trace of a chain launch
 struct Ls2Piece { int pos0, len; };   // len 0: slot not in use
 
 struct Ls2Ctl {   // control block in HBM, zeroed before every pass
-  int fail;                   // != 0: the front end gave up (1 no cut, 2 avg_ampl, 3 state machine, 4 dc_est rounds exhausted)
+  int fail;                   // != 0: the front end gave up (1 no cut, 2 avg_ampl, 3 state machine, 4 dc_est rounds exhausted, 5 the
+                              // fused first pass met a stretch without a rest point)
   int ok;                     // 1: the window tables were produced (set last; the fallback scan skips itself on it)
   int n_pieces;               // pieces the traces were cut into
   int n_heads;                // ... of them at idle cuts (or a trace's start): where the state-machine / dc_est passes can start
@@ -114,7 +115,7 @@ struct Ls2Args {
   int *cutf;                    // [n_streams][max_b] from ls_cut_kernel: where avg_ampl is at rest (100 carrier samples before)
   Ls2Piece *piece;              // [NS]
   int *nextv, *prevv;           // [NS] next / previous slot in use of the same trace, -1 none
-  float *amp, *dadd;            // [n_streams][y_stride]
+  float *amp;                   // [n_streams][y_stride]: |x| of every sample (the re-runs form the addends (|x| - ring)/100 again from it)
   uint64_t *votes;              // [n_streams][vstride][2]: below, above; bit b of word w = sample 64 w + b (zeroed before a pass)
   uint64_t *closed;             // [n_streams][cstride]
   int *openinfo;                // [n_streams][cstride]: lane | type << 8 of the step's opening, 0xff none
@@ -149,6 +150,18 @@ struct Ls2Args {
   int stamp;                    // this launch's number within the pass (the flags are zeroed before a pass)
   int *cflag;                   // [n_streams][LS2_CHAIN_GMAX]
   int *cagg;                    // [n_streams][LS2_CHAIN_GMAX][4]
+  // fused first pass (ls2_front_kernel): the matched filter runs inside the first avg_ampl pass, from the raw 2 Msps samples;
+  // y is written for the passes behind it and the decoder.  The avg_ampl pieces then lie on block boundaries the pass finds
+  // itself, the units of the state machine / dc_est passes on idle cuts found afterwards (ls2_idle_cut_kernel): two piece
+  // tables -- `piece / nextv / prevv` for avg_ampl, `upiece / unextv / uprevv` for the units (heads at the idle cuts, on the idle
+  // grid's slots; the slots between them empty, or cut at the avg_ampl pieces' starts where dc_fine wants pieces inside the
+  // units); the unit kernels get a copy of the arguments with the second table in the first one's place
+  int fused;                    // 0: y is given (cut searches on y);  1: fused first pass, avg_ampl view;  2: ... the units' view
+  const float2 *raw; int64_t raw_stride; int raw_vec_ok;
+  float2 *y_w;                  // [n_streams][y_stride], written (the same memory as y)
+  uint64_t *lowm;               // [n_streams][cstride]: per 64-sample block of the trace, the samples that are not carrier (the
+                                // memory of `closed`, which the state machine only writes later)
+  Ls2Piece *upiece; int *unextv, *uprevv;   // [NS]
 };
 
 // ---- small helpers -----------------------------------------------------------------------------------------------
@@ -337,7 +350,7 @@ RFID_DEVICE int ls2_boundary(const Ls2Args &a, const int *cut, const int *cutf, 
   const bool found = (J == 0) ? (n > 0) : (c > 0 && c < n);
   head = false;
   if (q == 0 && found) { head = true; return c; }
-  const int p = (j > 0) ? cutf[j] : -1;
+  const int p = (j > 0 && cutf) ? cutf[j] : -1;
   if (p <= 0 || p >= n) return -1;
   if (found && p < c + a.P / 2) return -1;   // too close behind (or before) the idle cut that stands for this stretch's grid point
   return p;
@@ -351,7 +364,7 @@ RFID_KERNEL(256) void ls2_pieces_kernel(Ls2Args a) {
     const int s = i / a.max_b, j = i - s * a.max_b;
     const int n = ls2_trace_len(a, s);
     const int *cut = a.cut + (int64_t)s * a.max_bc;
-    const int *cutf = a.cutf + (int64_t)s * a.max_b;
+    const int *cutf = a.cutf ? a.cutf + (int64_t)s * a.max_b : nullptr;
     bool head = false;
     const int p = ls2_boundary(a, cut, cutf, n, j, head);
     Ls2Piece pc; pc.pos0 = 0; pc.len = 0;
@@ -384,7 +397,7 @@ RFID_KERNEL(256) void ls2_pieces_kernel(Ls2Args a) {
     a.seq0[2 * i] = 0; a.seq0[2 * i + 1] = 0;
   }
   const uint64_t m = wv::ballot(used), mh = wv::ballot(is_head);
-  if (lane == 0 && m) wv::atomic_add(&a.ctl->n_pieces, wv::popc64(m));
+  if (lane == 0 && m && a.fused != 2) wv::atomic_add(&a.ctl->n_pieces, wv::popc64(m));   // (the units' view: the avg_ampl pieces were counted)
   if (lane == 0 && mh) wv::atomic_add(&a.ctl->n_heads, wv::popc64(mh));
 }
 
@@ -396,9 +409,10 @@ RFID_DEVICE bool ls2_nothing_to_gain(const Ls2Args &a) {
 }
 
 // ---- 2. avg_ampl ---------------------------------------------------------------------------------------------------
-// One wave per piece.  FIRST: |x| and the addends from the samples (and into HBM), start value guessed; later rounds: the
-// pieces of the re-run list from their predicted start, |x| and the addends from HBM.  Same arithmetic as the producer /
-// consumer waves of the gate scan, value for value (gate_impl.cc:130-136).
+// One wave per piece.  FIRST: |x| from the samples (and into HBM), start value guessed; later rounds: the pieces of the
+// re-run list from their predicted start, |x| from HBM; the addends (|x| - ring)/100 are formed from |x| both times (until
+// round 5 they were kept in HBM too: 4 B per sample written and read again for a subtraction and a three-instruction
+// division).  Same arithmetic as the producer / consumer waves of the gate scan, value for value (gate_impl.cc:130-136).
 template <bool FIRST>
 RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
   const int s = i / a.max_b, j = i - s * a.max_b;
@@ -413,7 +427,7 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
   const int last_idx = n_total - 1;   // (n_total >= p1 > 0)
   const int64_t row = (int64_t)s * a.y_stride;
   const float2 *yr = a.y + row;
-  float *ampr = a.amp + row, *dr = a.dadd + row;
+  float *ampr = a.amp + row;
   uint64_t *votes = a.votes + 2 * ((int64_t)s * a.vstride + w0);
   const int base = 64 * w0;
   float sA;
@@ -438,6 +452,16 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
       sA = wv::uniform(part) / WIN_LEN_F;
     }
   } else {
+    // |x| of the samples before the step from the first pass's record (every piece's first pass is through); before the start of
+    // the trace the carried ring / the fresh gate's zeros
+    auto hist = [&](int idx) -> float {
+      if (idx >= 0) return ampr[idx];
+      if (!a.carry || idx < -WIN_LEN) return 0.0f;
+      const GateState *cs = a.carry + s;
+      return cs->win[(cs->win_index + idx + 2 * WIN_LEN) % WIN_LEN];
+    };
+    a2 = hist(base - 128 + lane);
+    a1 = hist(base - 64 + lane);
     sA = wv::uniform(a.arun[i].s);
   }
   // a piece that passes so close to a power of two that hardly any shift is provable is run from six neighbouring start
@@ -459,21 +483,21 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
   int min_dv = 0x7fffffff;
   constexpr int AHEAD = 4;
   float2 ybuf[AHEAD];
-  float abuf[AHEAD], dbuf[AHEAD];
+  float abuf[AHEAD];
 #pragma unroll
   for (int u = 0; u < AHEAD; ++u) {
     const int idx = base + 64 * u + lane;
     // (loads past the end of the trace are clamped, not predicated: their lanes are not `valid` and add +0; an unconditional
     // load lands in the register the step reads it from -- no copies at the loop's end that would wait for all of them)
     if (FIRST) ybuf[u] = yr[(idx < n_total) ? idx : last_idx];
-    else { const int ix = (idx < p0) ? p0 : ((idx < p1) ? idx : (p1 - 1)); abuf[u] = ampr[ix]; dbuf[u] = dr[ix]; }
+    else abuf[u] = ampr[(idx < n_total) ? idx : last_idx];   // (the step's lanes outside the piece too: they are the ring of the samples behind them)
   }
   uint64_t my_lt = 0, my_gt = 0;   // lane (k & 63) keeps the votes of step k until 64 steps are stored together
   // one step.  The groups of AHEAD steps that are complete run without a condition around a step: every buffer is read and
   // loaded again in place, and the loop's only waits are counted ones for the oldest load.  (With the steps guarded one by one
   // the compiler kept the fresh loads in other registers and copied them at the loop's end -- behind a wait for ALL of them:
   // the read-ahead was one step deep, not four.)  The last, incomplete group reads what is left of the buffers.
-  auto step = [&](const int k, float2 &yb, float &ab_, float &db_, const bool reload) {
+  auto step = [&](const int k, float2 &yb, float &ab_, const bool reload) {
       {
         const int idx = base + 64 * k + lane;
         const bool valid = idx >= p0 && idx < p1;
@@ -484,21 +508,18 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
           // (the buffer is loaded again once its value is used up: the load lands in the same register -- issued before
           // that, the compiler kept it elsewhere and copied it at the loop's end behind a wait for all loads in flight)
           if (reload) { const int nx = idx + 64 * AHEAD; yb = yr[(nx < n_total) ? nx : last_idx]; }
+          if (valid) ampr[idx] = amp;
+        } else {
+          amp = ab_;
+          if (reload) { const int nx = idx + 64 * AHEAD; ab_ = ampr[(nx < n_total) ? nx : last_idx]; }
+        }
+        {
           // sample i - 100: lanes 0..35 take it from two steps back (lane + 28), lanes 36..63 from the previous step (lane - 36)
           const float o2 = wv::shfl(a2, (lane + 28) & 63), o1 = wv::shfl(a1, (lane - 36) & 63);
           const float old = (lane < 36) ? o2 : o1;
           const float nd = valid ? (amp - old) : 0.0f;
           d = div_const<WIN_LEN>(nd);
-          if (valid) { ampr[idx] = amp; dr[idx] = d; }
           a2 = a1; a1 = amp;
-        } else {
-          amp = valid ? ab_ : 0.0f; d = valid ? db_ : 0.0f;
-          if (reload) {
-            const int nx = idx + 64 * AHEAD;
-            const int ix = (nx < p1) ? nx : (p1 - 1);     // (nx >= p0: behind this step)
-            ab_ = ampr[ix];
-            db_ = dr[ix];
-          }
         }
         float vA, vB;
         const uint32_t cinA = wv::f2u(avA), cinB = wv::f2u(avB);
@@ -567,11 +588,11 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
   int kb = 0;
   for (; kb + AHEAD <= nsteps; kb += AHEAD) {
 #pragma unroll
-    for (int u = 0; u < AHEAD; ++u) step(kb + u, ybuf[u], abuf[u], dbuf[u], true);
+    for (int u = 0; u < AHEAD; ++u) step(kb + u, ybuf[u], abuf[u], true);
   }
 #pragma unroll
   for (int u = 0; u < AHEAD - 1; ++u)
-    if (kb + u < nsteps) step(kb + u, ybuf[u], abuf[u], dbuf[u], false);
+    if (kb + u < nsteps) step(kb + u, ybuf[u], abuf[u], false);
   {
     const int mb = ls2_range_margin(rgA, rgB);
     const int mv = (min_dv == 0x7fffffff) ? min_dv : ((min_dv - 3) >> 1);
@@ -614,6 +635,290 @@ RFID_KERNEL(64) void ls2_avg_rerun_kernel(Ls2Args a) {
   const int lane = wv::lane_id();
   const int *list = a.alist + (int64_t)((a.round - 1) & 1) * NS;
   for (int r = (int)blockIdx.x; r < cnt; r += (int)gridDim.x) ls2_avg_piece<false>(a, wv::uniform(list[r]), lane);   // (grid = NS: one each)
+}
+
+// ---- 2a. the FUSED first pass (round 5): matched filter + piece boundaries + avg_ampl in ONE sweep over the raw samples ----
+// The matched filter is bound by the HBM (8 B in per raw sample), the first avg_ampl pass by its instruction streams; as two
+// launches they ran one after the other (3.6 + 0.35 (cut searches over y) + 2.0 ms for configs[2]) and y was written, then read
+// three times.  Here every wave filters the samples of its own piece (the filter wave's arithmetic of the fused front end,
+// gate_fir_step: the 344 raw samples of a 64-output block through an LDS tile, 25 in-order adds per lane), writes y for the
+// passes behind it and the decoder, and goes on with |x| and the sums out of registers: the loads of one wave's next blocks
+// are in flight while the SIMD's other waves add.
+//
+// Without y there is no cut search before the pass, so the pieces lie where the pass itself finds the carrier at rest, by
+// a rule that is a pure function of the three 64-sample blocks in front of a block boundary -- which is what makes two
+// waves agree on it without talking: slot j's piece starts at the first block boundary b in [j P, j P + P/2] whose two
+// preceding blocks hold carrier only ("quiet": no sample with |y|^2 < 0.7225 of the largest |y|^2 of its own and the
+// preceding block -- 0.85 of the amplitude, as in ls_cut_body), the slot is not in use when there is none.  The wave of
+// slot j filters three blocks in front of j P to find its start (nothing is written from there); the wave of the piece
+// before runs on through every block up to that same boundary: it evaluates the same rule on the same values.  Every
+// block's not-carrier mask goes to HBM (8 B per 64 samples) and ls2_idle_cut_kernel finds the units' idle cuts in them.
+constexpr int LS2_FRONT_PRE = 3;         // blocks filtered in front of a slot's grid point: one for its maximum, two that must be quiet
+#ifndef LS2_FRONT_AHEAD_N
+#define LS2_FRONT_AHEAD_N 2
+#endif
+constexpr int LS2_FRONT_AHEAD = LS2_FRONT_AHEAD_N;   // blocks of raw samples in flight per wave (12 VGPRs each)
+constexpr int LS2_FRONT_GIVE_UP = 32;    // a piece that has found no rest point within this many nominal lengths gives the pass up (the sequential scan takes over)
+constexpr float LS2_CARRIER_FRAC2 = 0.7225f;
+
+RFID_DEVICE uint32_t ls2_wave_max_bits(uint32_t v) {   // (values below 2^31: bit patterns of non-negative binary32 numbers)
+  int x = (int)v, o;
+  o = wv::dpp_row_shr<1>(x, 0); x = (o > x) ? o : x;
+  o = wv::dpp_row_shr<2>(x, 0); x = (o > x) ? o : x;
+  o = wv::dpp_row_shr<4>(x, 0); x = (o > x) ? o : x;
+  o = wv::dpp_row_shr<8>(x, 0); x = (o > x) ? o : x;
+  o = wv::dpp_row_bcast15(x, 0); x = (o > x) ? o : x;
+  o = wv::dpp_row_bcast31(x, 0); x = (o > x) ? o : x;
+  return (uint32_t)wv::readlane(x, 63);
+}
+
+RFID_DEVICE void ls2_front_piece(const Ls2Args &a, const int i, const int lane, float4 *tile4) {
+  const int s = i / a.max_b, j = i - s * a.max_b;
+  const int n_total = ls2_trace_len(a, s);
+  const int64_t G64 = (int64_t)j * a.P;
+  Ls2Piece none; none.pos0 = 0; none.len = 0;
+  if (G64 >= n_total) { if (lane == 0) { a.piece[i] = none; a.cutf[i] = -1; } return; }
+  const int kg = (int)(G64 >> 6);                                    // the block that starts at the slot's grid point
+  const int klim = (int)((G64 + a.P / 2) >> 6);                      // the last block boundary this slot's piece may start at
+  const int k0 = (j == 0) ? 0 : (kg - LS2_FRONT_PRE);                // (P >= 512: kg >= 8)
+  const int64_t row = (int64_t)s * a.y_stride;
+  float2 *yw = a.y_w + row;
+  float *ampr = a.amp + row;
+  uint64_t *lowm = a.lowm + (int64_t)s * a.cstride;
+  const float2 *xs = a.raw + (int64_t)s * a.raw_stride;
+  const bool vec = a.raw_vec_ok != 0;
+  const int64_t hi_idx = vec ? ((a.raw_stride - 2) & ~(int64_t)1) : (a.raw_stride - 2);
+  const int64_t rbase = -(int64_t)(NTAPS - 1);                       // raw index of the window of output 0
+
+  // ---- state of the search for block boundaries (all wave-uniform but a2 / a1) ----
+  float a2 = 0.0f, a1 = 0.0f;          // |x| of the two blocks before the current one (the ring of gate_impl.cc:131 holds the last 100)
+  uint32_t Mprev = 0u;                 // the previous block's largest |y|^2 (bit pattern)
+  bool qprev = false, qcur = false;    // the two blocks before the current boundary: carrier only?
+  bool running = (j == 0);             // inside the piece (the trace's first piece starts at sample 0, from the exact state)
+  int kb = 0;                          // the piece's first block
+  int jn = j + 1;                      // the next slot whose start range has not gone by
+  int64_t Gn = G64 + a.P;
+  const int64_t give_up64 = ((int64_t)LS2_FRONT_GIVE_UP * a.P) >> 6;
+  const int give_up = (give_up64 > 0x3fffffff) ? 0x3fffffff : (int)give_up64;
+  // ---- state of the piece's sums (ls2_avg_piece) ----
+  float sA = 0.0f, sB, avA, avB;
+  uint32_t sbA, sbB;
+  int marg, min_dv = 0x7fffffff;
+  bool e0_ok;
+  Ls2MantRange rgA, rgB;
+  uint64_t my_lt = 0, my_gt = 0;
+  uint64_t *votes = a.votes + 2 * ((int64_t)s * a.vstride);
+  auto begin_piece = [&](const int kfirst) {
+    kb = kfirst;
+    running = true;
+    sB = ls2_from_ord(ls2_ord(sA) + 1);
+    sbA = wv::f2u(sA); sbB = wv::f2u(sB);
+    avA = sA; avB = sB;
+    marg = ls2_margin(sA, sbA);
+    e0_ok = ls2_e0_ok(sbA, sbB);
+    ls2_range_init(rgA); ls2_range_init(rgB);
+    votes += 2 * (int64_t)kfirst;
+  };
+  if (j == 0) begin_piece(0);          // sA = +0: the fresh gate (gate_impl.cc:45)
+  int end = 0, rc = 0;                 // rc: 1 the piece has ended at `end`, 2 the slot is not in use, 3 given up
+
+  GateRawRegs buf[LS2_FRONT_AHEAD];
+#pragma unroll
+  for (int u = 0; u < LS2_FRONT_AHEAD; ++u) {
+    gate_load_raw(buf[u], xs, hi_idx, rbase + (int64_t)(k0 + u) * 64 * DECIM, lane, vec);
+    wv::compiler_fence();
+  }
+  auto block = [&](const int k, GateRawRegs &rb) -> int {
+    const float2 yv = gate_fir_step(rb, tile4, lane, k == 0);
+    gate_load_raw(rb, xs, hi_idx, rbase + (int64_t)(k + LS2_FRONT_AHEAD) * 64 * DECIM, lane, vec);
+    const int idx = 64 * k + lane;
+    const bool valid = idx < n_total;
+    const float amp = wv::hypot_f(yv.x, yv.y);
+    // carrier or not: against the largest |y|^2 of this block and the one before (a NaN does not count as the largest)
+    const float m2 = yv.x * yv.x + yv.y * yv.y;
+    const uint32_t Mk = ls2_wave_max_bits((valid && m2 == m2) ? wv::f2u(m2) : 0u);
+    const float theta = LS2_CARRIER_FRAC2 * wv::u2f((Mk > Mprev) ? Mk : Mprev);
+    const uint64_t lowmask = wv::ballot(!valid) | wv::ballot(m2 < theta);
+    if (running) {
+      if (valid) { yw[idx] = yv; ampr[idx] = amp; }
+      if (lane == 0) lowm[k] = lowmask;
+      // sample i - 100: lanes 0..35 take it from two blocks back (lane + 28), lanes 36..63 from the previous block (lane - 36)
+      const float o2 = wv::shfl(a2, (lane + 28) & 63), o1 = wv::shfl(a1, (lane - 36) & 63);
+      const float old = (lane < 36) ? o2 : o1;
+      const float nd = valid ? (amp - old) : 0.0f;
+      const float d = div_const<WIN_LEN>(nd);
+      float vA, vB;
+      const uint32_t cinA = wv::f2u(avA), cinB = wv::f2u(avB);
+      const bool scanned = chain_add_auto2(avA, avB, d, lane, vA, vB);
+      avA = wv::readlane(vA, 63);
+      avB = wv::readlane(vB, 63);
+      const float thresh = vA * THRESH_FRACTION;
+      const uint64_t below = wv::ballot(valid && amp < thresh);
+      const uint64_t above = wv::ballot(valid && amp > thresh);
+      {   // margin: the partial sums of both variants against the powers of two, |x| against the threshold (ls2_avg_piece)
+        const uint32_t tb = wv::f2u(thresh), ab = wv::f2u(amp);
+        int dv = (int)ab - (int)tb;
+        dv = (dv < 0) ? -dv : dv;
+        if (scanned && ls2_in_start_binade(cinA, cinB, sbA, sbB, e0_ok)) {
+          ls2_range_add(rgA, vA); ls2_range_add(rgB, vB);
+          const int dvv = valid ? dv : 0x7fffffff;
+          min_dv = (dvv < min_dv) ? dvv : min_dv;
+        } else {
+          int mm;
+          if (scanned) {
+            mm = ls2_margin_scanned(vA, vB, cinA, cinB, sbA, sbB, e0_ok);
+            if (mm > 0) {
+              const int shA = (int)((sbA >> 23) & 0xffu) - (int)((cinA >> 23) & 0xffu);
+              const int mV = valid ? ((dv - 3) >> (1 + shA)) : 0x7fffffff;
+              mm = (mV < mm) ? mV : mm;
+            }
+          } else {
+            const int mA = ls2_margin(vA, sbA), mB = ls2_margin(vB, sbB);
+            const int sh = (int)((sbA >> 23) & 0xffu) - (int)((wv::f2u(vA) >> 23) & 0xffu);
+            int mV = ((tb >> 31) != 0u || sh < 0 || sh > 23) ? 0 : (((dv - 3) >> 1) >> sh);
+            mV = valid ? mV : 0x7fffffff;
+            mm = (mA < mB) ? mA : mB;
+            mm = (mV < mm) ? mV : mm;
+          }
+          marg = (mm < marg) ? mm : marg;
+        }
+      }
+      // the votes: lane (kk & 63) keeps those of block kb + kk until 64 blocks are stored together (every block belongs to
+      // one piece only: plain stores)
+      const int kk = k - kb;
+      if (lane == (kk & 63)) { my_lt = below; my_gt = above; }
+    }
+    a2 = a1; a1 = amp;
+    qprev = qcur; qcur = (lowmask == 0ull); Mprev = Mk;
+    // ---- the boundary behind this block ----
+    const int kn = k + 1;
+    int r = 0;
+    if (!running) {
+      if ((int64_t)64 * kn >= n_total) r = 2;
+      else if (kn >= kg && qcur && qprev) {
+        // the piece starts here: the ring is the last 100 samples (36 of the block before the last, the last block), first
+        // guess of avg_ampl = its mean
+        float part = a1 + ((lane >= 64 - (WIN_LEN - 64)) ? a2 : 0.0f);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) part += wv::shfl_xor(part, off);
+        sA = wv::uniform(part) / WIN_LEN_F;
+        begin_piece(kn);
+      } else if (kn >= klim) r = 2;
+    } else {
+      const int kk = k - kb;
+      if ((int64_t)64 * kn >= n_total) { end = n_total; r = 1; }
+      else {
+        while ((int64_t)64 * kn > Gn + a.P / 2) { jn++; Gn += a.P; }
+        if ((int64_t)64 * kn >= Gn && qcur && qprev) { end = 64 * kn; r = 1; }
+        else if (kn - kb >= give_up) r = 3;
+      }
+      if ((kk & 63) == 63 || r == 1) {
+        const int kl = (kk & ~63) + lane;
+        if (kl <= kk) { votes[2 * kl] = my_lt; votes[2 * kl + 1] = my_gt; }
+      }
+    }
+    return r;
+  };
+  for (int k = k0; rc == 0;) {
+#pragma unroll
+    for (int u = 0; u < LS2_FRONT_AHEAD; ++u) {
+      rc = block(k, buf[u]);
+      ++k;
+      if (rc != 0) break;
+    }
+  }
+  if (rc != 1) {
+    if (lane == 0) {
+      a.piece[i] = none; a.cutf[i] = -1;
+      if (rc == 3) a.ctl->fail = 5;
+    }
+    return;
+  }
+  {
+    const int mb = ls2_range_margin(rgA, rgB);
+    const int mv = (min_dv == 0x7fffffff) ? min_dv : ((min_dv - 3) >> 1);
+    const int mf = (mv < mb) ? mv : mb;
+    marg = (mf < marg) ? mf : marg;
+  }
+  marg = ls2_wave_min(marg);
+  if ((((wv::f2u(avA) ^ sbA) | (wv::f2u(avB) ^ sbB)) & 0xff800000u) != 0u) marg = 0;   // (start and end in one binade: see ls2_avg_piece)
+  if (lane == 0) {
+    Ls2AvgRun r;
+    r.s = sA; r.eA = avA; r.eB = avB; r.margin = marg;
+    r.wide = 0;
+    r.ew[0] = r.ew[1] = r.ew[2] = r.ew[3] = 0.0f;
+    r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
+    a.arun[i] = r;
+    Ls2Piece pc; pc.pos0 = 64 * kb; pc.len = end - 64 * kb;
+    a.piece[i] = pc;
+    a.cutf[i] = 64 * kb;
+  }
+}
+#ifndef LS2_FRONT_OCC_N
+#define LS2_FRONT_OCC_N 0
+#endif
+#if LS2_FRONT_OCC_N > 0
+RFID_KERNEL_OCC(64, LS2_FRONT_OCC_N)
+#else
+RFID_KERNEL(64)
+#endif
+void ls2_front_kernel(Ls2Args a) {
+  RFID_SHARED float4 tile4[64 * GATE_RAW_LD];
+  const int lane = wv::lane_id();
+  const int NS = a.n_streams * a.max_b;
+  const int per = (NS + 7) >> 3;                       // (an eighth of the slots per XCD, as ls2_avg_first_kernel)
+  const int b = (int)blockIdx.x, i = (b & 7) * per + (b >> 3);
+  if ((b >> 3) < per && i < NS) ls2_front_piece(a, i, lane, tile4);
+}
+// the avg_ampl pieces' links (one thread per slot)
+RFID_KERNEL(256) void ls2_link_kernel(Ls2Args a) {
+  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  const int NS = a.n_streams * a.max_b;
+  const int lane = wv::lane_id();
+  bool used = false;
+  if (i < NS) {
+    const int s = i / a.max_b, j = i - s * a.max_b;
+    used = a.piece[i].len > 0;
+    int nx = -1, pv = -1;
+    if (used) {
+      const int n = ls2_trace_len(a, s);
+      for (int j2 = j + 1; j2 < a.max_b && (int64_t)j2 * a.P < n; ++j2) if (a.piece[s * a.max_b + j2].len > 0) { nx = s * a.max_b + j2; break; }
+      for (int j2 = j - 1; j2 >= 0; --j2) if (a.piece[s * a.max_b + j2].len > 0) { pv = s * a.max_b + j2; break; }
+    }
+    a.nextv[i] = nx;
+    a.prevv[i] = pv;
+  }
+  const uint64_t m = wv::ballot(used);
+  if (lane == 0 && m) wv::atomic_add(&a.ctl->n_pieces, wv::popc64(m));
+}
+// the units' idle cuts from the blocks' not-carrier masks: for every point J >= 1 of the idle grid the first position p in
+// [J Pc, J Pc + Pc/2) whose LS_QUIET preceding samples are all carrier, or -1 (what ls_cut_body finds in y; samples past the
+// end of the trace are not carrier).  One thread per point: ~(LS_QUIET + Pc/2) / 64 words.
+RFID_KERNEL(256) void ls2_idle_cut_kernel(Ls2Args a) {
+  const int t = (int)(blockIdx.x * 256 + threadIdx.x);
+  const int NH = a.n_streams * a.max_bc;
+  if (t >= NH) return;
+  const int s = t / a.max_bc, J = t - s * a.max_bc;
+  if (J == 0) return;
+  int *out = a.cut + (int64_t)s * a.max_bc + J;
+  const int n = ls2_trace_len(a, s);
+  const int64_t P64 = (int64_t)J * a.Pc;
+  if (P64 >= n) { *out = -1; return; }
+  const int Pn = (int)P64;
+  int lo = Pn - LS_QUIET - 64;
+  if (lo < 0) lo = 0;
+  int64_t end64 = P64 + a.Pc / 2;
+  const int end = (end64 > n) ? n : (int)end64;
+  const uint64_t *lowm = a.lowm + (int64_t)s * a.cstride;
+  int pall = lo & ~63;        // behind the last sample known not to be carrier (the look-back starts here)
+  int found = -1;
+  for (int w = lo >> 6; 64 * w < end; ++w) {
+    const uint64_t m = lowm[w];
+    if (m) pall = 64 * w + 64 - (int)__builtin_clzll(m);
+    const int p = (Pn > pall + LS_QUIET) ? Pn : (pall + LS_QUIET);
+    if (p <= 64 * (w + 1)) { found = (p < end) ? p : -1; break; }
+  }
+  *out = found;
 }
 
 // A piece's latest run as a function "true start -> true end", on the monotone integer image of binary32: T -> T + c[q],
@@ -739,6 +1044,10 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_avg_chain_kernel(Ls2Args a) {
   const int r = a.round;
   const int tid = (int)threadIdx.x, b = (int)blockIdx.x, s = (int)blockIdx.y;
   if (ctl->fail != 0) return;
+  if (a.fused && r == 0 && ls2_nothing_to_gain(a)) {   // (the fused first pass ran before the idle cuts were known; else ls2_avg_first_kernel looks)
+    if (tid == 0 && b == 0 && s == 0) ctl->fail = 1;
+    return;
+  }
   if (r > 0 && ctl->avg_count[r - 1] == 0) return;   // settled in an earlier round (avg_count[r] stays 0)
   const int NS = a.n_streams * a.max_b;
   const int lane = wv::lane_id(), wave = wv::uniform(tid >> 6);
@@ -1441,8 +1750,29 @@ RFID_DEVICE void ls2_dc_unit(const Ls2Args &a, const int i, const bool first, co
     // (loads clamped, not predicated, and the complete groups of AHEAD steps without a condition around a step: see
     // ls2_avg_piece.  Samples past the unit's end are not closed -- nvalid -- whatever their value.)
     const int last_idx = n - 1;
+    // Only the steps that hold closed samples are read: more than half of a Gen2 round lies inside the two reply windows,
+    // where dc_est does not move (gate_impl.cc:139: the update sits in the closed branch) -- until round 5 every step of y was
+    // loaded all the same (3.7 GB per pass of configs[2] for 1.7 GB that are used).  Which steps those are is known 64 steps
+    // ahead (nz_cur / nz_nxt: one bit per step of this and the next 64-step block); a step that is not needed loads the unit's
+    // first samples again instead -- an unconditional load from a line that is in the cache: no branch around a load, the
+    // read-ahead's registers and counted waits stay as they are (see ls2_avg_piece).  (The samples of the step before a closed
+    // step are only looked at when that step was closed itself: gate_dc_incr takes x[i-48] from them while run_closed >= 48.)
+    uint64_t nz_cur = 0, nz_nxt = 0;
+    auto nz_of = [&](const int k64) -> uint64_t {   // bit b: step k64 + b holds closed samples
+      const bool in = k64 + lane < nsteps;
+      const uint64_t mk = closed[in ? (k64 + lane) : (nsteps - 1)];
+      return wv::ballot(in && mk != 0ull);
+    };
+    nz_cur = nz_of(0);
+    nz_nxt = nz_of(64);
+    auto load_step = [&](const int q, const int blk) -> float2 {   // the samples of step q (blk: the 64-step block the caller is in)
+      const uint64_t nz = ((q >> 6) == blk) ? nz_cur : nz_nxt;
+      const int b0 = ((nz >> (q & 63)) & 1ull) ? 64 * q : 0;
+      const int idx = b0 + lane;
+      return ys[(idx < n) ? idx : last_idx];
+    };
 #pragma unroll
-    for (int u = 0; u < AHEAD; ++u) { const int idx = 64 * u + lane; buf[u] = ys[(idx < n) ? idx : last_idx]; }
+    for (int u = 0; u < AHEAD; ++u) buf[u] = load_step(u, 0);
     float2 before = make_float2(0.0f, 0.0f);   // the samples of the previous step
     uint64_t masks = 0;
     int oi_l = 0xff;
@@ -1455,9 +1785,10 @@ RFID_DEVICE void ls2_dc_unit(const Ls2Args &a, const int i, const bool first, co
             const int ok = oinfo[kx];
             masks = in ? mk : 0ull;
             oi_l = in ? ok : 0xff;
+            if (k > 0) { nz_cur = nz_nxt; nz_nxt = nz_of(k + 64); }
           }
           const float2 yv = yb;
-          if (reload) { const int idx = 64 * (k + AHEAD) + lane; yb = ys[(idx < n) ? idx : last_idx]; }
+          if (reload) yb = load_step(k + AHEAD, k >> 6);
           const int kk = k & 63;
           const uint64_t closedmask = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(masks >> 32), kk) << 32) |
                                       (uint32_t)wv::readlane((int)(uint32_t)masks, kk);

@@ -40,7 +40,7 @@ inline Ls2Geometry ls2_geometry(int n_streams, int64_t n_dec, int min_piece = LS
 
 // work space: one allocation, carved up here (offsets in bytes, 256-byte aligned)
 struct Ls2Layout {
-  size_t cut, cutf, piece, nextv, prevv, amp, dadd, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, drun, dT, dcut, dend, dlist, seq0, flat_base, cflag, cagg, ctl, consumed, total;
+  size_t cut, cutf, piece, nextv, prevv, upiece, unextv, uprevv, amp, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, drun, dT, dcut, dend, dlist, seq0, flat_base, cflag, cagg, ctl, consumed, total;
 };
 inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_stride) {
   Ls2Layout L;
@@ -52,8 +52,10 @@ inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_strid
   L.piece = take(sizeof(Ls2Piece) * NS);
   L.nextv = take(sizeof(int) * NS);
   L.prevv = take(sizeof(int) * NS);
+  L.upiece = take(sizeof(Ls2Piece) * NS);
+  L.unextv = take(sizeof(int) * NS);
+  L.uprevv = take(sizeof(int) * NS);
   L.amp = take(sizeof(float) * B * (size_t)y_stride);
-  L.dadd = take(sizeof(float) * B * (size_t)y_stride);
   L.votes = take(sizeof(uint64_t) * 2 * B * (size_t)g.vstride);
   L.closed = take(sizeof(uint64_t) * B * (size_t)g.cstride);
   L.openinfo = take(sizeof(int) * B * (size_t)g.cstride);
@@ -81,7 +83,9 @@ inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geomet
   a.P = g.P; a.max_b = g.max_b; a.Pc = g.Pc; a.max_bc = g.max_bc; a.vstride = g.vstride; a.cstride = g.cstride; a.wb_stride = g.wb_stride;
   a.cut = (int *)(base + L.cut); a.cutf = (int *)(base + L.cutf); a.piece = (Ls2Piece *)(base + L.piece);
   a.nextv = (int *)(base + L.nextv); a.prevv = (int *)(base + L.prevv);
-  a.amp = (float *)(base + L.amp); a.dadd = (float *)(base + L.dadd);
+  a.upiece = (Ls2Piece *)(base + L.upiece); a.unextv = (int *)(base + L.unextv); a.uprevv = (int *)(base + L.uprevv);
+  a.amp = (float *)(base + L.amp);
+  a.lowm = (uint64_t *)(base + L.closed);   // (fused first pass: the blocks' not-carrier masks live there until the state machine runs)
   a.votes = (uint64_t *)(base + L.votes); a.closed = (uint64_t *)(base + L.closed); a.openinfo = (int *)(base + L.openinfo);
   a.arun = (Ls2AvgRun *)(base + L.arun); a.aT = (int *)(base + L.aT); a.alist = (int *)(base + L.alist); a.aover = (Ls2Aff *)(base + L.aover);
   a.fsm = (Ls2Fsm *)(base + L.fsm); a.wb = (Ls2Win *)(base + L.wb);
@@ -103,6 +107,14 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
                         void (*mark)(void *, int) = nullptr, void *mark_arg = nullptr) {   // (search_cuts = false: a.cut is given -- tests)
   const int NS = a.n_streams * a.max_b, NH = a.n_streams * a.max_bc;   // slots; slots that can be heads
   const int B = a.n_streams;
+  const bool fused = a.fused != 0;
+  a.fused = fused ? 1 : 0;
+  // the fused first pass keeps two piece tables (Ls2Args::fused): the unit kernels get the arguments with the units' table
+  // (its slots between the idle cuts: empty, or -- where the dc_est stage wants pieces, dc_fine -- cut at the avg_ampl pieces' starts)
+  auto U = [fused](Ls2Args x) {
+    if (fused) { x.piece = x.upiece; x.nextv = x.unextv; x.prevv = x.uprevv; if (!x.dc_fine) x.cutf = nullptr; x.fused = 2; }
+    return x;
+  };
   {
     const int64_t words = 2 * (int64_t)B * a.vstride + 3 * (int64_t)B * a.wb_stride;
     int64_t g = (words + 4 * 256 - 1) / (4 * 256);   // (four words per thread)
@@ -110,7 +122,7 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
     if (g > 8192) g = 8192;
     LS2_LAUNCH(ls2_clear_kernel, (int)g, 1, 256, a);
   }
-  {
+  if (!fused) {
     // idle cuts on the coarse grid (unless given: tests) and rest points on the fine one
     LsCutArgs ca, cf;
     ca.y = a.y; ca.y_stride = a.y_stride; ca.lens = a.lens; ca.n_dec = a.n_dec; ca.chunk = a.Pc; ca.limit = a.Pc / 2;
@@ -138,7 +150,16 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
   // short passes run at the pace of their longest dc_est run: there the units are cut again behind the gate openings
   // (test hook: dc_fine = 0 / 1 says so itself)
   a.dc_fine = (dc_fine < 0) ? (small ? 1 : 0) : dc_fine;
-  LS2_LAUNCH(ls2_pieces_kernel, (NS + 255) / 256, 1, 256, a);
+  if (fused) {
+    // matched filter + piece boundaries + the first avg_ampl pass in one sweep over the raw samples; then the pieces' links,
+    // the idle cuts from the blocks' not-carrier masks (unless given: tests) and the units' table from them
+    LS2_LAUNCH(ls2_front_kernel, 8 * ((NS + 7) / 8), 1, 64, a);
+    LS2_LAUNCH(ls2_link_kernel, (NS + 255) / 256, 1, 256, a);
+    if (a.max_bc > 1 && search_cuts) LS2_LAUNCH(ls2_idle_cut_kernel, (NH + 255) / 256, 1, 256, a);
+    LS2_LAUNCH(ls2_pieces_kernel, (NS + 255) / 256, 1, 256, U(a));
+  } else {
+    LS2_LAUNCH(ls2_pieces_kernel, (NS + 255) / 256, 1, 256, a);
+  }
   // re-run launches: one wave per list entry, the waves loop when the list is longer than the grid.  The grid used to be the
   // slot count: 130 000 workgroups that return at once cost 28 us per launch, and most of a pass's sixteen re-run launches
   // have little or nothing to do.  (A first avg_ampl round may hold most pieces: below 32 768 workgroups it ran slower.)
@@ -146,7 +167,7 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
   // workgroups per trace of the chain kernels: a few thousand slots each
   auto chain_g = [](int slots) { const int per = ls2_chain_slots(); int g = (slots + per - 1) / per; return g < 1 ? 1 : (g > LS2_CHAIN_GMAX ? LS2_CHAIN_GMAX : g); };
   const int g_avg = chain_g(a.max_b), g_seq = chain_g(a.max_bc);   // (pieces: any slot; units: idle-grid slots)
-  LS2_LAUNCH(ls2_avg_first_kernel, 8 * ((NS + 7) / 8), 1, 64, a);   // (one wave per slot, an eighth of the slots per XCD)
+  if (!fused) LS2_LAUNCH(ls2_avg_first_kernel, 8 * ((NS + 7) / 8), 1, 64, a);   // (one wave per slot, an eighth of the slots per XCD)
   a.chain_g = g_avg; a.stamp++;
   LS2_LAUNCH(ls2_avg_chain_kernel, g_avg, B, LS2_CHAIN_THREADS, a);
   for (int r = 1; r <= a.avg_rounds; ++r) {
@@ -158,30 +179,30 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
   }
   for (int r = 0; r <= a.fsm_rounds; ++r) {
     a.round = r;
-    if (NH >= ls2_fsm_lanes_min()) LS2_LAUNCH(ls2_fsm_lanes_kernel, (NH + LS2_FSM_LANES - 1) / LS2_FSM_LANES, 1, 64, a);
-    else LS2_LAUNCH(ls2_fsm_kernel, NH, 1, 64, a);
-    LS2_LAUNCH(ls2_fsm_chain_kernel, (NH + 255) / 256, 1, 256, a);
+    if (NH >= ls2_fsm_lanes_min()) LS2_LAUNCH(ls2_fsm_lanes_kernel, (NH + LS2_FSM_LANES - 1) / LS2_FSM_LANES, 1, 64, U(a));
+    else LS2_LAUNCH(ls2_fsm_kernel, NH, 1, 64, U(a));
+    LS2_LAUNCH(ls2_fsm_chain_kernel, (NH + 255) / 256, 1, 256, U(a));
   }
   a.round = 0;
   const int g_dc = a.dc_fine ? g_avg : g_seq;
   a.chain_g = g_dc;
-  LS2_LAUNCH(ls2_dc_cut_kernel, (NS + 255) / 256, 1, 256, a);
-  LS2_LAUNCH(ls2_dc_first_kernel, a.dc_fine ? NS : NH, 1, 64, a);
+  LS2_LAUNCH(ls2_dc_cut_kernel, (NS + 255) / 256, 1, 256, U(a));
+  LS2_LAUNCH(ls2_dc_first_kernel, a.dc_fine ? NS : NH, 1, 64, U(a));
   a.stamp++;
-  LS2_LAUNCH(ls2_dc_chain_kernel, g_dc, B, LS2_CHAIN_THREADS, a);
+  LS2_LAUNCH(ls2_dc_chain_kernel, g_dc, B, LS2_CHAIN_THREADS, U(a));
   if (mark) mark(mark_arg, 1);
   for (int r = 1; r <= a.dc_rounds; ++r) {
     a.round = r;
-    LS2_LAUNCH(ls2_dc_rerun_kernel, rerun_grid(r, 16384), 1, 64, a);
+    LS2_LAUNCH(ls2_dc_rerun_kernel, rerun_grid(r, 16384), 1, 64, U(a));
     a.stamp++;
-    LS2_LAUNCH(ls2_dc_chain_kernel, g_dc, B, LS2_CHAIN_THREADS, a);
+    LS2_LAUNCH(ls2_dc_chain_kernel, g_dc, B, LS2_CHAIN_THREADS, U(a));
   }
   a.round = 0;
   a.stamp++;
   a.chain_g = g_seq;
-  LS2_LAUNCH(ls2_seq_kernel, g_seq, B, LS2_CHAIN_THREADS, a);
-  LS2_LAUNCH(ls2_assemble_kernel, NH, 1, 64, a);
-  if (a.carry_out) LS2_LAUNCH(ls2_carry_kernel, B, 1, 64, a);
+  LS2_LAUNCH(ls2_seq_kernel, g_seq, B, LS2_CHAIN_THREADS, U(a));
+  LS2_LAUNCH(ls2_assemble_kernel, NH, 1, 64, U(a));
+  if (a.carry_out) LS2_LAUNCH(ls2_carry_kernel, B, 1, 64, U(a));
   if (rounds_out) { rounds_out[0] = a.avg_rounds; rounds_out[1] = a.fsm_rounds; rounds_out[2] = a.dc_rounds; }
 }
 #endif

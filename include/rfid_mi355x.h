@@ -129,7 +129,8 @@ typedef struct rfid_batch_timing {
   int32_t front_chunks; /* launches of each of the two front-end kernels in the pass (1 = not chunked) */
   int32_t decode_launches; /* 2: one EPC launch, one RN16 launch */
   int32_t fused_front;  /* 1: rfid_batch_process ran the fused front end (matched filter inside the gate launch:
-                           mf_ms = 0, gate_ms = the fused kernel) */
+                           mf_ms = 0, gate_ms = the fused kernel); 2: the long-stream front end with the matched filter inside
+                           its first launch (few, long traces: mf_ms = 0, gate_ms = its whole launch list) */
   int32_t reserved_;
 } rfid_batch_timing;
 
@@ -149,7 +150,8 @@ typedef struct rfid_ls_report {
   int32_t dc_reruns;        /*   piece re-runs */
   int32_t verified;         /* 1: accepted -- every piece's latest run is exact or proven: the sequential scan, bit for bit */
   int32_t gave_up;          /* != 0: the sequential scan ran instead (1 no trace could be cut, 2 / 3 / 4: avg_ampl / state
-                             * machine / dc_est not settled within the round limit) */
+                             * machine / dc_est not settled within the round limit, 5: the first pass met a stretch of 32
+                             * nominal piece lengths without 128 carrier samples in a row) */
   int32_t cuts_dropped;     /* cut points withdrawn because the state machine (or the dc ring) was not idle there */
   int32_t windows;          /* complete windows found */
   int32_t dc_pieces;        /* pieces of the dc_est pass (>= units: a unit is cut again behind gate openings) */

@@ -45,7 +45,14 @@ def _check(emu_mod, oracle_mod, raw2d, lens=None, cfg_kw=None, check_avg=True, e
     return r
 
 
-def test_ls2_matches_oracle_and_avg_recurrence(emu_mod, oracle_mod, synth_mod):
+FUSED = pytest.mark.parametrize("fused", [False, True], ids=["y-given", "fused-first-pass"])
+# fused: the first avg_ampl pass runs the matched filter itself from the raw samples and finds its own piece boundaries
+# (ls2_front_kernel: what rfid_batch_process takes for fresh traces); else y is filtered first and the cut searches run on it
+# (the streaming / look-ahead form).  Whole units in the dc_est stage when fused (its units' table holds no pieces).
+
+
+@FUSED
+def test_ls2_matches_oracle_and_avg_recurrence(emu_mod, oracle_mod, synth_mod, fused):
     """Two traces of different carrier level / phase / noise, cut into ~10 pieces each: accepted, and identical to the
     sequential scan; avg_ampl at every cut equals the in-order recurrence."""
     rng = np.random.default_rng(3)
@@ -53,35 +60,40 @@ def test_ls2_matches_oracle_and_avg_recurrence(emu_mod, oracle_mod, synth_mod):
     for k, (sigma, leak) in enumerate([(0.01, 14.9 * np.exp(0.91j)), (0.03, 3.8 * np.exp(3.4j))]):
         ts.append(synth_mod.make_trace(n_rounds=16, sigma=sigma, seed=200 + k, leak=leak, t1_jitter_raw=4).samples)
     L = min(map(len, ts))
-    r = _check(emu_mod, oracle_mod, np.stack([t[:L] for t in ts]), expect_ok=1)
+    r = _check(emu_mod, oracle_mod, np.stack([t[:L] for t in ts]), expect_ok=1, fused=fused)
     c = r["ctl"]
     assert c["n_pieces"] >= 60 and c["n_units"] == c["n_heads"] >= 12 and c["n_windows"] == len(r["windows"])
     # dc_est restarts behind gate openings too (at most one cut per piece): more pieces than units
     assert c["n_units"] < c["n_dc_pieces"] <= c["n_pieces"], c
+    if fused:
+        assert all(pc[1] % 64 == 0 for pc in r["pieces"])        # its pieces lie on block boundaries
     del rng
 
 
-def test_ls2_rerun_rounds_are_exercised(emu_mod, oracle_mod, synth_mod):
+@FUSED
+def test_ls2_rerun_rounds_are_exercised(emu_mod, oracle_mod, synth_mod, fused):
     """Noise of 8 % of the carrier makes dc_est pass close to powers of two inside pieces: some runs do not cover their
     true start and are repeated from it (dc_reruns > 0) -- the result is still the sequential scan."""
     t = synth_mod.make_trace(n_rounds=20, sigma=0.08, seed=9).samples
-    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, dc_fine=0)
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, dc_fine=0, fused=fused)
     assert r["ctl"]["dc_reruns"] > 0 and r["ctl"]["dc_rounds"] >= 3, r["ctl"]
+
     # a short pass enqueues few rounds to begin with (empty launches cost it most) and cuts its units again behind the
     # gate openings (its pace is its longest dc_est run): here that does not suffice -- a run of pieces that cross a
     # binade settles one piece per round -- the front end says so and the sequential scan gives the result; the library
     # then enqueues the full number of rounds and whole units from the next pass on
-    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=0, generous=False, dc_fine=-1)
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=0, generous=False, dc_fine=-1, fused=fused)
     assert r["ctl"]["dc_count2"] > 0 and r["ctl"]["n_dc_pieces"] > r["ctl"]["n_units"], r["ctl"]
     # (cut behind the openings, all rounds: still more pieces in a row than rounds)
-    r = _check(emu_mod, oracle_mod, t[None, :], dc_fine=1)
+    r = _check(emu_mod, oracle_mod, t[None, :], dc_fine=1, fused=fused)
     assert r["ctl"]["n_dc_pieces"] > r["ctl"]["n_units"] and (r["ok"] or r["ctl"]["dc_count7"] > 0), r["ctl"]
     # few, long pieces: avg_ampl too
-    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, target=6)
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, target=6, fused=fused)
     assert r["ctl"]["n_pieces"] <= 8 and r["ctl"]["avg_reruns"] > 0, r["ctl"]
 
 
-def test_ls2_carrier_at_a_power_of_two(emu_mod, oracle_mod, synth_mod):
+@FUSED
+def test_ls2_carrier_at_a_power_of_two(emu_mod, oracle_mod, synth_mod, fused):
     """A carrier whose filtered amplitude is exactly 16.0: avg_ampl hovers at a binade edge, hardly any run is provable
     (pieces start in one binade and end in the other, partial sums sit next to the edge) and the chain only advances by
     runs from exact or neighbouring starts, a few pieces per round.  Whatever the front end then does -- settle after
@@ -90,14 +102,15 @@ def test_ls2_carrier_at_a_power_of_two(emu_mod, oracle_mod, synth_mod):
     wrong binade's ulp would show here and nowhere else)."""
     t = synth_mod.make_trace(n_rounds=12, sigma=0.01, seed=5).samples
     t = (t * np.complex64(0.64)).astype(np.complex64)
-    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, target=8, min_piece=2048)
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, target=8, min_piece=2048, fused=fused)
     assert r["ctl"]["avg_rounds"] >= 4 and r["ctl"]["n_pieces"] >= 5, r["ctl"]
-    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=0)
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=0, fused=fused)
     assert r["ctl"]["avg_count9"] > 0 and r["ctl"]["n_pieces"] > 20, r["ctl"]
 
 
+@FUSED
 @pytest.mark.parametrize("fsm_lanes", [False, True])
-def test_ls2_ragged_batch_collisions_and_limits(emu_mod, oracle_mod, synth_mod, fsm_lanes):
+def test_ls2_ragged_batch_collisions_and_limits(emu_mod, oracle_mod, synth_mod, fsm_lanes, fused):
     """Per-trace lengths (one trace cut inside a slot, one too short to be cut, one empty), FIXED_Q = 2 collisions.
     (fsm_lanes: the state machine in its one-lane-per-unit form, which the library takes on long passes.)"""
     kw = dict(fixed_q=2, tag_ids=(0x11, 0x22, 0x33), sigma=0.01, t1_jitter_raw=5)
@@ -110,12 +123,13 @@ def test_ls2_ragged_batch_collisions_and_limits(emu_mod, oracle_mod, synth_mod, 
         lens.append(len(t))
     lens.append(0)
     lens[1] -= 12345
-    r = _check(emu_mod, oracle_mod, raw, lens=lens, cfg_kw=dict(fixed_q=2), expect_ok=1, fsm_lanes=fsm_lanes)
+    r = _check(emu_mod, oracle_mod, raw, lens=lens, cfg_kw=dict(fixed_q=2), expect_ok=1, fsm_lanes=fsm_lanes, fused=fused)
     assert r["stats"][3]["n_windows"] == 0
 
 
+@FUSED
 @pytest.mark.parametrize("fsm_lanes", [False, True])
-def test_ls2_cuts_that_are_not_idle_are_withdrawn(emu_mod, oracle_mod, synth_mod, fsm_lanes):
+def test_ls2_cuts_that_are_not_idle_are_withdrawn(emu_mod, oracle_mod, synth_mod, fsm_lanes, fused):
     """Cut points forced to arbitrary places -- inside reader commands, inside open windows, right behind a window: the
     state machine's end state does not meet the idle state assumed at the next cut (or the dc ring is not the last 48
     samples), the pieces are appended to their predecessors (n_units < n_pieces) and scanned through; avg_ampl needs no
@@ -135,7 +149,7 @@ def test_ls2_cuts_that_are_not_idle_are_withdrawn(emu_mod, oracle_mod, synth_mod
             seen.add(J)
             cuts.append(c)
     assert len(cuts) >= 6
-    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, cuts=sorted(cuts), fsm_lanes=fsm_lanes)
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, cuts=sorted(cuts), fsm_lanes=fsm_lanes, fused=fused)
     c = r["ctl"]
     assert c["n_heads"] == len(cuts) + 1 and c["n_units"] < c["n_heads"] and c["fsm_rounds"] >= 2, c
 
@@ -202,14 +216,15 @@ def test_chain_add_auto2_equals_two_sequential_sums(emu_mod):
     assert n_scanned > 120
 
 
+@FUSED
 @pytest.mark.parametrize("kw", [dict(max_num_queries=7), dict(number_unique_tags=1), dict(max_num_queries=2, number_unique_tags=2)])
-def test_ls2_statistics_from_summaries_with_the_terminated_cut_off(emu_mod, oracle_mod, synth_mod, kw):
+def test_ls2_statistics_from_summaries_with_the_terminated_cut_off(emu_mod, oracle_mod, synth_mod, kw, fused):
     """The statistics kernel on the decoder's one-word summaries (what the library does for few, long traces; the emulated
     long-stream chain runs it so) with the reader's stop conditions inside the trace: the queries limit (the cut-off index is
     searched in the summaries), the distinct-tag limit, both."""
     t = synth_mod.make_trace(n_rounds=14, sigma=0.01, seed=321, fixed_q=1, tag_ids=(0x31, 0x52)).samples
     assert oracle_mod.run_trace(t, oracle_mod.config(fixed_q=1)).state.n_unique_tags == 2     # (the limits below do cut the run)
-    r = emu_mod.ls2_process(t[None, :], fixed_q=1, **kw)
+    r = emu_mod.ls2_process(t[None, :], fixed_q=1, fused=fused, **kw)
     assert r["ok"] == 1
     o = oracle_mod.run_trace(t, oracle_mod.config(fixed_q=1, **kw))
     st = r["stats"][0]
@@ -220,8 +235,9 @@ def test_ls2_statistics_from_summaries_with_the_terminated_cut_off(emu_mod, orac
     assert np.array_equal(st["tag_reads"], np.array(o.state.tag_reads[:], dtype=np.int32))
 
 
+@FUSED
 @pytest.mark.parametrize("seed,scale,kw", [(2, 0.64, {}), (2, 0.32, {}), (6, 0.64, dict(target=8, min_piece=2048)), (6, 0.6401, {})])
-def test_ls2_exact_end_put_into_a_function_serves_its_own_start_only(emu_mod, oracle_mod, synth_mod, seed, scale, kw):
+def test_ls2_exact_end_put_into_a_function_serves_its_own_start_only(emu_mod, oracle_mod, synth_mod, seed, scale, kw, fused):
     """Carriers at a power of two again, the seeds on which the chain once ACCEPTED wrong starts: a piece run from six
     neighbouring starts has its exact end for the start the chain landed on put into its function (Ls2Aff); when the next
     chain lands on another start of the same parity -- the piece's own, D = 0 -- that entry is not this start's end.  The
@@ -229,8 +245,9 @@ def test_ls2_exact_end_put_into_a_function_serves_its_own_start_only(emu_mod, or
     redone: every start equals the in-order recurrence, windows and scores the oracle's."""
     t = synth_mod.make_trace(n_rounds=8, sigma=0.01, seed=seed).samples
     t = (t * np.complex64(scale)).astype(np.complex64)
-    r = _check(emu_mod, oracle_mod, t[None, :], **kw)      # (checks avg_ampl at every cut whenever the pass was accepted)
-    assert r["ok"] == 1, r["ctl"]
+    r = _check(emu_mod, oracle_mod, t[None, :], fused=fused, **kw)      # (checks avg_ampl at every cut whenever the pass was accepted)
+    if not fused:      # (the seeds were picked on the unfused pieces; the fused pass cuts elsewhere and may settle or give up)
+        assert r["ok"] == 1, r["ctl"]
 
 
 @pytest.mark.parametrize("seed,lanes", [(7002, False), (7034, True)])

@@ -71,7 +71,8 @@ LS2_CTL_FIELDS = (["fail", "ok", "n_pieces", "n_heads"] + [f"avg_count{r}" for r
 
 
 def ls2_process(raw: np.ndarray, lens=None, fixed_q=0, max_num_queries=1000, number_unique_tags=100, min_piece=512,
-                target=131072, state=None, hold_last=False, cuts=None, y_skip=0, chain_slots=64, generous=True, dc_fine=1, fsm_lanes=False):
+                target=131072, state=None, hold_last=False, cuts=None, y_skip=0, chain_slots=64, generous=True, dc_fine=1, fsm_lanes=False,
+                fused=False):
     """batch_process() with the long-stream front end (rfid_ls2.hpp) in place of the sequential gate scan.
     -> dict(windows, results, scores, stats, ctl, ok[, consumed])"""
     raw = np.ascontiguousarray(raw, dtype=np.complex64)
@@ -108,7 +109,9 @@ def ls2_process(raw: np.ndarray, lens=None, fixed_q=0, max_num_queries=1000, num
         C.c_void_p(ctl.ctypes.data), nw,
         C.c_void_p(state.ctypes.data) if state is not None else None, 1 if hold_last else 0, C.c_void_p(consumed.ctypes.data),
         C.c_void_p(pcs.ctypes.data), len(pcs) - 1,
-        C.c_void_p(cuts_arr.ctypes.data) if cuts_arr is not None else None, 0 if cuts_arr is None else len(cuts_arr), int(y_skip), 1 if generous else 0, int(dc_fine))
+        C.c_void_p(cuts_arr.ctypes.data) if cuts_arr is not None else None, 0 if cuts_arr is None else len(cuts_arr), int(y_skip), 1 if generous else 0, int(dc_fine),
+        1 if fused else 0)
+    assert ok >= 0
     k = n.value
     npc = int(np.argmax(pcs[:, 0] < 0)) if (pcs[:, 0] < 0).any() else len(pcs)
     return dict(windows=windows[:k], results=results[:k], scores=scores[:k], stats=stats, ok=int(ok),

@@ -206,7 +206,7 @@ int emu_ls2_process(const float *raw, int B, long stride, long n_raw, const int6
                     rfid_decode_result *results, rfid_scores *scores, long cap, long *n_windows,
                     rfid_stream_stats *stats, int min_piece, int target, int *ctl_out, int ctl_cap,
                     void *state_blob, int hold_last, int *consumed_out, int *pieces_out, int pieces_cap,
-                    const int *cuts, int n_cuts, int y_skip, int generous, int dc_fine) {
+                    const int *cuts, int n_cuts, int y_skip, int generous, int dc_fine, int fused) {
   const long n_dec_all = n_raw / DECIM;
   const long n_dec = n_dec_all - y_skip;   // (y_skip: leading outputs that only exist to give the filter its history)
   long y_stride = (n_dec_all + 1) & ~1L;
@@ -232,8 +232,14 @@ int emu_ls2_process(const float *raw, int B, long stride, long n_raw, const int6
   ma.vec_ok = ((stride & 1) == 0 && (((uintptr_t)raw) & 15) == 0) ? 1 : 0;
   ma.y = y0; ma.y_stride = y_stride; ma.tile0 = 0; ma.stream0 = 0;
   const long tiles = (n_dec_all + MF_TILE - 1) / MF_TILE;
-  if (tiles > 0)
-    emu::launch(emu::Idx3{(unsigned)tiles, (unsigned)B, 1}, emu::Idx3{MF_THREADS, 1, 1}, [&]() { mf_boxcar25_decim5_kernel(ma); });
+  // fused: the long-stream front end's first pass runs the matched filter itself (ls2_front_kernel), as rfid_batch_process does
+  // for fresh traces; y is only filtered here when that pass is not taken or gives up
+  auto run_mf = [&]() {
+    if (tiles > 0)
+      emu::launch(emu::Idx3{(unsigned)tiles, (unsigned)B, 1}, emu::Idx3{MF_THREADS, 1, 1}, [&]() { mf_boxcar25_decim5_kernel(ma); });
+  };
+  if (fused && (state_blob || hold_last || y_skip)) return -1;
+  if (!fused) run_mf();
 
   const Ls2Geometry geo = ls2_geometry(B, n_dec, min_piece, target);
   std::vector<char> ws;
@@ -251,6 +257,9 @@ int emu_ls2_process(const float *raw, int B, long stride, long n_raw, const int6
     a.wtab = wtab.data(); a.wmax = wmax; a.wcount = wcount.data(); a.flat = flat.data(); a.flat_count = flat_count; a.flat_cap = flat_cap;
     a.carry = state_blob ? gstate.data() : nullptr; a.carry_out = state_blob ? gstate.data() : nullptr;
     a.hold_last = hold_last; a.force = state_blob ? 1 : 0;
+    if (fused) {
+      a.fused = 1; a.raw = reinterpret_cast<const float2 *>(raw); a.raw_stride = stride; a.raw_vec_ok = ma.vec_ok; a.y_w = y;
+    }
     if (cuts) {   // test hook: cut trace 0 at the given positions (ascending) instead of searching idle points
       for (int i = 0; i < B * geo.max_bc; ++i) a.cut[i] = -1;
       for (int k = 0; k < n_cuts; ++k) {   // (a cut stands for the grid point it lies behind, less than half a step away)
@@ -267,9 +276,10 @@ int emu_ls2_process(const float *raw, int B, long stride, long n_raw, const int6
       for (int i = 0; i < geo.NS && k < pieces_cap; ++i) {
         if (a.piece[i].len <= 0) continue;
         int *o = pieces_out + 8 * k++;
-        const int h = a.fsm[i].unit;
         o[0] = i / geo.max_b; o[1] = a.piece[i].pos0; o[2] = a.piece[i].len;
         float f = ls2_from_ord(a.aT[i]); memcpy(&o[3], &f, 4);
+        if (fused) { o[4] = o[5] = 0; o[6] = -1; o[7] = i; continue; }   // (the avg_ampl pieces are not the units' pieces there)
+        const int h = a.fsm[i].unit;
         int hd = i;   // the dc_est piece of the last slot up to here that has one
         while (hd != h && a.dend[hd] <= 0) hd = a.prevv[hd];
         f = ls2_from_ord(a.dT[2 * hd]); memcpy(&o[4], &f, 4);
@@ -280,7 +290,9 @@ int emu_ls2_process(const float *raw, int B, long stride, long n_raw, const int6
     }
   }
   if (ctl_out) memcpy(ctl_out, &ctl_host, sizeof(int) * (size_t)((int)(sizeof(Ls2Ctl) / 4) < ctl_cap ? (int)(sizeof(Ls2Ctl) / 4) : ctl_cap));
+  if (fused && geo.P == 0) run_mf();
   if (!ok && !hold_last) {   // the fallback the library enqueues behind the front end (GateArgs::skip_if)
+    if (fused && geo.P > 0) run_mf();   // (the fused first pass may have given up half-way: the library filters again, MfArgs::skip_if)
     if (state_blob) gstate[0].win_seq = 0;   // (a call's windows are numbered from 0, as the front end numbers them)
     GateArgs ga = {};
     ga.y = y; ga.y_stride = y_stride; ga.n_dec = n_dec; ga.lens = lens; ga.state = gstate.data(); ga.n_streams = B;
