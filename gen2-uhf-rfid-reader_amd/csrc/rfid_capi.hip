@@ -44,8 +44,29 @@ struct DevBuf {
 
 }  // namespace
 
+// Everything the environment can change, read ONCE when a context is created (rfid_ctx_create -> knobs_from_env) and kept
+// here; rfid_ctx_set_knob changes a value of a living context (what the tests and the A/B scripts do).  One table
+// (g_knob_table below) names them: INTEGRATION.md section 13 is that table.
+struct RfidKnobs {
+  int long_stream = 1;     // RFID_LONG_STREAM       0 never, 1 automatic (cost model), 2 whenever a trace can be cut
+  int ls_fused = 1;        // RFID_LS_FUSED          long-stream front end: 1 the matched filter inside its first launch, 0 round 4's list
+  int overlap = 1;         // RFID_OVERLAP           0 one stream only, 1 the next pass's first launches on the second stream, 2 ... and a
+                           //                        second result set (decoder beside the next front end; fused front end, many traces)
+  int ls_calibrate = 1;    // RFID_LS_CALIBRATE      0: keep the built-in cost model (profiled runs)
+  int ls_debug = 0;        // RFID_LS_DEBUG          1: what the long-stream rounds did, on stderr (synchronises every pass)
+  int la_profile = 0;      // RFID_LA_PROFILE        1: where the look-ahead's host time went, on stderr when the context is destroyed
+  // ---- test hooks ----
+  int front_unfused = 0;   // RFID_FRONT_UNFUSED     1: many traces through the stage kernels instead of front_end_fused_kernel
+  int front_chunks = 1;    // RFID_FRONT_CHUNKS      2..16: the time-chunked stage kernels on two streams (round 1's overlap)
+  int fsm_lanes_min = -1;  // RFID_LS2_FSM_LANES_MIN from how many possible units on the state machine runs one lane per unit (-1: 8192)
+  // ---- experiment knobs of round 4's list (RFID_LS_FUSED=0), kept for its A/B tables ----
+  int mf_parts = 3;        // RFID_MF_PARTS          1..8 launches of the next pass's matched filter
+  int mf_split[8] = {35, 45, 20, 0, 0, 0, 0, 0};   // RFID_MF_SPLIT  their shares in percent (comma list, each 0..100, sum <= 100 + rest to the last)
+};
+
 struct rfid_ctx {
   rfid_params prm;
+  RfidKnobs knobs;
   int device = 0;
   hipStream_t stream = nullptr;
   char err[512];
@@ -62,13 +83,17 @@ struct rfid_ctx {
   DevBuf synth_tab;               // slot table of rfid_synth_gen2
   // long-stream front end (few long traces cut along time into concurrently processed pieces, rfid_ls2.hpp)
   DevBuf ls2_ws;                  // its work space (one allocation, carved up by ls2_layout)
+  DevBuf ls2_ws_alt;              // a second one (rfid_batch_plan, where the device has the room): with it and a second matched-filter
+                                  // output buffer the first launches of pass k + 1 -- the fused first pass: they touch the raw samples,
+                                  // y and the work space only -- run on stream2 beside the rest of pass k; the two are used alternately
+  bool ls2_mark_failed = false, ls2_gap_marks = false;   // (scratch of ls_enqueue's call-back)
+  bool y_touched = false;         // work outside that protocol has used c->d_y on the main stream since the last such pass
   Ls2Ctl *ls2_host = nullptr;     // page-locked copy of the control block of the last pass (report) + consumed[0]
   Ls2Ctl *d_ls2_ctl = nullptr;    // the control block of the last pass that ran the front end (device), else nullptr
   int ls2_P = 0;                  // its nominal piece length
   int ls2_rounds[3] = {0, 0, 0};  // re-run rounds its launch list held per stage (avg_ampl, state machine, dc_est)
   bool ls2_generous = false;      // a pass ran out of rounds once: the launch lists hold the full number of rounds from then on
   int ls_mode = 1;                // 0 never, 1 automatic, 2 whenever a trace can be cut
-  bool ls_fused = true;           // rfid_batch_process: the long-stream front end filters the raw samples itself (ls2_front_kernel)
   double ls_fixed_ms = 0.45, ls_ns_per_sample = 0.03, seq_ns_per_sample = 10.2;   // cost model of the automatic choice (ls_calibrate)
   bool ls_calibrated = false;     // the three numbers were measured on this device (or that was tried, or is not wanted)
   // whole-chain streaming (rfid_stream_*)
@@ -258,6 +283,45 @@ int fail(rfid_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
   return code;
 }
 
+struct KnobEntry { const char *name, *env; int RfidKnobs::*field; int lo, hi; };
+const KnobEntry g_knob_table[] = {
+  {"long_stream", "RFID_LONG_STREAM", &RfidKnobs::long_stream, 0, 2},
+  {"ls_fused", "RFID_LS_FUSED", &RfidKnobs::ls_fused, 0, 1},
+  {"overlap", "RFID_OVERLAP", &RfidKnobs::overlap, 0, 2},
+  {"ls_calibrate", "RFID_LS_CALIBRATE", &RfidKnobs::ls_calibrate, 0, 1},
+  {"ls_debug", "RFID_LS_DEBUG", &RfidKnobs::ls_debug, 0, 1},
+  {"la_profile", "RFID_LA_PROFILE", &RfidKnobs::la_profile, 0, 1},
+  {"front_unfused", "RFID_FRONT_UNFUSED", &RfidKnobs::front_unfused, 0, 1},
+  {"front_chunks", "RFID_FRONT_CHUNKS", &RfidKnobs::front_chunks, 1, rfid_ctx::MAX_CHUNKS},
+  {"fsm_lanes_min", "RFID_LS2_FSM_LANES_MIN", &RfidKnobs::fsm_lanes_min, -1, 1 << 30},
+  {"mf_parts", "RFID_MF_PARTS", &RfidKnobs::mf_parts, 1, 8},
+};
+int clamp_int(long v, int lo, int hi) { return (int)(v < lo ? lo : (v > hi ? hi : v)); }
+// the environment, once per context: values out of range are clamped, anything that is not a number is ignored
+void knobs_from_env(RfidKnobs &k) {
+  for (const KnobEntry &e : g_knob_table) {
+    const char *v = getenv(e.env);
+    if (!v || !*v) continue;
+    char *end = nullptr;
+    const long x = strtol(v, &end, 10);
+    if (end == v) continue;
+    k.*(e.field) = clamp_int(x, e.lo, e.hi);
+  }
+  if (const char *v = getenv("RFID_MF_SPLIT")) {   // "35,45,20": at most eight shares, each 0..100; what is missing to 100 goes to the last launch
+    int share[8] = {0, 0, 0, 0, 0, 0, 0, 0}, n = 0, sum = 0;
+    bool ok = true;
+    for (const char *q = v; *q && n < 8 && ok;) {
+      char *end = nullptr;
+      const long x = strtol(q, &end, 10);
+      if (end == q || x < 0 || x > 100) { ok = false; break; }
+      share[n++] = (int)x; sum += (int)x;
+      q = end;
+      if (*q == ',') ++q; else if (*q) ok = false;
+    }
+    if (ok && n > 0 && sum <= 100) for (int i = 0; i < 8; ++i) k.mf_split[i] = share[i];
+  }
+}
+
 #define HIPCHK(c, call)                                                     \
   do {                                                                      \
     hipError_t e__ = (call);                                                \
@@ -324,6 +388,7 @@ void free_plan(rfid_ctx *c) {
   c->plan_blk = nullptr; c->alt_blk = nullptr; c->alt_y_blk = nullptr;
   c->y_recorded[0] = c->y_recorded[1] = false;
   c->y_idx = 0;
+  c->y_touched = false;
   c->d_y = nullptr; c->d_gstate = nullptr; c->d_wtab = nullptr; c->d_flat = nullptr;
   c->d_wcount = nullptr; c->d_flat_count = nullptr; c->d_res = nullptr; c->d_scores = nullptr;
   c->d_stats = nullptr;
@@ -414,6 +479,8 @@ struct LsOpts {
                             // waits for more samples)
   bool force = false;       // run even when no trace could be cut more than once
   bool marks = false;       // record c->ev_gap[0 / 1] at the list's two quiet points (rfid_batch_process with a second filter buffer)
+  bool ahead = false;       // (fused first pass) its launches on stream2 and in the work space the pass before did not use; the rest of the
+                            // list on the main stream behind them
   // the fused first pass (ls2_front_kernel): the raw samples in HBM -- the matched filter runs inside the front end's first
   // launch and writes c->d_y; nullptr: c->d_y holds the filter's output already
   const void *raw = nullptr; int64_t raw_stride = 0;
@@ -436,6 +503,8 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
   const Ls2Geometry geo = ls2_geometry(c->B, n_dec);
   if (geo.P == 0 || c->B > 65535) return RFID_OK;
   const Ls2Layout L = ls2_layout(geo, c->B, c->y_stride);
+  const bool ahead = opt.ahead && opt.raw && c->ls2_ws.cap >= L.total && c->ls2_ws_alt.cap >= L.total;
+  if (opt.ahead && !ahead) return RFID_OK;   // (the caller takes the pass without the second stream)
   if (L.total > c->ls2_ws.cap) {
     // (normally reserved by rfid_batch_plan; a pass that needs it all the same must not fail on a full device)
     if (c->ls2_ws.p) { (void)hipFree(c->ls2_ws.p); c->ls2_ws.p = nullptr; c->ls2_ws.cap = 0; }
@@ -451,6 +520,7 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
   Ls2Args a;
   memset(&a, 0, sizeof(a));
   a.y = c->y(); a.y_stride = c->y_stride; a.lens = c->d_lens; a.n_dec = n_dec; a.n_streams = c->B;
+  if (ahead) std::swap(c->ls2_ws, c->ls2_ws_alt);   // (alternating with the matched-filter output buffers: nothing below returns without a pass)
   ls2_bind(a, (char *)c->ls2_ws.p, L, geo);
   a.wtab = c->d_wtab; a.wmax = c->wmax; a.wcount = c->d_wcount; a.flat = c->d_flat; a.flat_count = c->d_flat_count; a.flat_cap = c->flat_cap;
   a.carry = opt.carry ? c->d_gstate : nullptr; a.carry_out = opt.carry ? c->d_gstate : nullptr;
@@ -461,29 +531,47 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
     a.raw_vec_ok = ((opt.raw_stride & 1) == 0 && (((uintptr_t)opt.raw) & 15) == 0) ? 1 : 0;
     a.y_w = c->d_y;
   }
-  ls2_stream = c->stream;
+  ls2_stream = ahead ? c->stream2 : c->stream;
+  a.keep_flat_count = ahead ? 1 : 0;
+#ifdef LS2_CHEAT
+  a.cheat_sigma = getenv("RFID_LS_CHEAT") ? atoi(getenv("RFID_LS_CHEAT")) : 0;   // (EXPERIMENT build only)
+#endif
   {   // test hook: from how many possible heads on the state machine takes its one-lane-per-unit form (default 8192)
     static const int lanes_min_default = ls2_fsm_lanes_min();
-    const char *e = getenv("RFID_LS2_FSM_LANES_MIN");
-    ls2_fsm_lanes_min() = e ? atoi(e) : lanes_min_default;
+    ls2_fsm_lanes_min() = (c->knobs.fsm_lanes_min >= 0) ? c->knobs.fsm_lanes_min : lanes_min_default;
   }
   auto mark = [](void *p, int pt) {
     rfid_ctx *cc = (rfid_ctx *)p;
+    if (pt == 2) {
+      // the fused first pass is enqueued: the rest of the list goes to the main stream, behind it (and behind the pass before,
+      // whose decoder reads the list counters that this pass's window assembly counts up from zero)
+      if (ls2_stream == cc->stream2) {
+        if (hipEventRecord(cc->ev_fe_done, cc->stream2) != hipSuccess || hipStreamWaitEvent(cc->stream, cc->ev_fe_done, 0) != hipSuccess ||
+            hipMemsetAsync(cc->d_flat_count, 0, 2 * sizeof(int), cc->stream) != hipSuccess) cc->ls2_mark_failed = true;
+        ls2_stream = cc->stream;
+      }
+      return;
+    }
+    if (!cc->ls2_gap_marks) return;
     if (hipEventRecord(cc->ev_gap[pt], cc->stream) == hipSuccess) cc->gap_recorded[pt] = true;
     else (void)hipGetLastError();
   };
-  ls2_enqueue(a, true, c->ls2_rounds, c->ls2_generous, -1, opt.marks ? +mark : nullptr, c);
+  c->ls2_mark_failed = false;
+  c->ls2_gap_marks = opt.marks;
+  ls2_enqueue(a, true, c->ls2_rounds, c->ls2_generous, -1, (opt.marks || ahead) ? +mark : nullptr, c);
+  ls2_stream = c->stream;
   HIPCHK(c, hipGetLastError());
+  if (c->ls2_mark_failed) return fail(c, RFID_ERR_HIP, "long-stream front end: stream hand-over");
   // (the control block and, right behind it, consumed[0])
   HIPCHK(c, hipMemcpyAsync(c->ls2_host, a.ctl, sizeof(Ls2Ctl) + sizeof(int), hipMemcpyDeviceToHost, c->stream));
   c->d_ls2_ctl = a.ctl;
   c->ls2_P = geo.P;
   *enqueued = 1;
-  if (getenv("RFID_LS_DEBUG")) {   // what the rounds did: per-round counts, margins against the shifts they had to cover
+  if (c->knobs.ls_debug) {   // what the rounds did: per-round counts, margins against the shifts they had to cover
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const Ls2Ctl &k = *c->ls2_host;
     fprintf(stderr, "[ls2] pieces %d P %d fail %d ok %d | avg:", k.n_pieces, geo.P, k.fail, k.ok);
-    for (int r = 0; r <= c->ls2_rounds[0]; ++r) fprintf(stderr, " %d", k.avg_count[r]);
+    for (int r = 0; r <= c->ls2_rounds[0]; ++r) fprintf(stderr, " %d/%d", k.avg_count[r], k.avg_list[r]);
     fprintf(stderr, " | fsm:");
     for (int r = 0; r <= c->ls2_rounds[1]; ++r) fprintf(stderr, " %d", k.fsm_count[r]);
     fprintf(stderr, " | dc:");
@@ -497,6 +585,20 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
     HIPCHK(c, hipMemcpy(pc.data(), a.piece, sizeof(Ls2Piece) * pc.size(), hipMemcpyDeviceToHost));
     long hist_m[8] = {0}, hist_d[8] = {0};
     int shown = 0;
+    {
+      long hist_len[6] = {0}; int max_len = 0; long n_wide = 0, n_over = 0;
+      for (int i = 0; i < geo.NS; ++i) {
+        const int len = pc[(size_t)i].len;
+        if (len <= 0) continue;
+        if (len > max_len) max_len = len;
+        const int q = (int)(4.0 * len / geo.P);   // quarters of the nominal length
+        hist_len[q < 2 ? 0 : (q < 4 ? 1 : (q < 6 ? 2 : (q < 8 ? 3 : (q < 16 ? 4 : 5))))]++;
+        if (ar[(size_t)i].wide & 2) n_wide++;
+        if (ar[(size_t)i].wide & 4) n_over++;
+      }
+      fprintf(stderr, "[ls2] piece lengths in P (< 0.5, < 1, < 1.5, < 2, < 4, more): %ld %ld %ld %ld %ld %ld, longest %d; last run wide: %ld, exact end put in: %ld\n",
+              hist_len[0], hist_len[1], hist_len[2], hist_len[3], hist_len[4], hist_len[5], max_len, n_wide, n_over);
+    }
     for (int i = 0; i < geo.NS; ++i) {
       if (pc[(size_t)i].len <= 0) continue;
       uint32_t u; memcpy(&u, &ar[(size_t)i].s, 4);
@@ -589,7 +691,7 @@ int ls_calibrate(rfid_ctx *c) {
     c->seq_ns_per_sample = t_seq[1] / n1 * 1e6;   // (sixteen traces side by side take the time of one)
   }
   c->ls_calibrated = true;
-  if (getenv("RFID_LS_DEBUG"))
+  if (c->knobs.ls_debug)
     fprintf(stderr, "[ls2] calibration: fused %.3f / %.3f ms, long-stream %.3f / %.3f ms for 1 x %.0f / %d x %.0f samples -> %.2f ns/sample of the longest trace vs %.3f ms + %.4f ns/sample of all\n",
             t_seq[0], t_seq[1], t_ls[0], t_ls[1], n0, B_big, n1, c->seq_ns_per_sample, c->ls_fixed_ms, c->ls_ns_per_sample);
   return RFID_OK;
@@ -603,8 +705,7 @@ LsCalCache g_ls_cal[64];
 pthread_mutex_t g_ls_cal_mu = PTHREAD_MUTEX_INITIALIZER;
 void ls_calibrate_lazily(rfid_ctx *c) {
   c->ls_calibrated = true;                 // (whatever comes of it: tried once per context)
-  const char *cal = getenv("RFID_LS_CALIBRATE");
-  if ((cal && atoi(cal) == 0) || c->device < 0 || c->device >= 64) return;
+  if (!c->knobs.ls_calibrate || c->device < 0 || c->device >= 64) return;
   pthread_mutex_lock(&g_ls_cal_mu);
   LsCalCache &k = g_ls_cal[c->device];
   if (!k.done) {
@@ -687,11 +788,8 @@ int rfid_ctx_create(const rfid_params *p, int device, rfid_ctx **out) {
   c->device = device;
   c->err[0] = 0;
   compute_t_cand(c->t_cand, p->sample_rate);
-  if (const char *e = getenv("RFID_LONG_STREAM")) {
-    const int m = atoi(e);
-    c->ls_mode = m < 0 ? 0 : (m > 2 ? 2 : m);
-  }
-  if (const char *e = getenv("RFID_LS_FUSED")) c->ls_fused = atoi(e) != 0;
+  knobs_from_env(c->knobs);   // the one place where RFID_* variables are read
+  c->ls_mode = c->knobs.long_stream;
   init_reader_state(c);
   memset(c->mf_hist, 0, sizeof(c->mf_hist));
   int rc = RFID_OK;
@@ -741,7 +839,7 @@ int rfid_ctx_create(const rfid_params *p, int device, rfid_ctx **out) {
 
 int rfid_ctx_destroy(rfid_ctx *c) {
   if (!c) return RFID_ERR_INVALID;
-  if (getenv("RFID_LA_PROFILE") && (g_la_n[0] || g_la_n[1]))
+  if (c->knobs.la_profile && (g_la_n[0] || g_la_n[1]))
     fprintf(stderr, "[la] mf_work %ld calls %.2f ms (upload queued %.2f, pass enqueued %.2f, wait for the filter outputs %.2f, previous pass collected %.2f: of it waiting %.2f) | "
             "gate_work %ld calls %.2f ms | decoder_work %ld calls %.2f ms | reader_work_tx %ld calls %.2f ms | lookahead_enable %.2f ms\n",
             g_la_n[0], g_la_t[0], g_la_t[4], g_la_t[5], g_la_t[8], g_la_t[6], g_la_t[7], g_la_n[1], g_la_t[1], g_la_n[2], g_la_t[2], g_la_n[3], g_la_t[3], g_la_t[9]);
@@ -750,7 +848,7 @@ int rfid_ctx_destroy(rfid_ctx *c) {
   la_free(c);
   sio_free(c);
   free_plan(c);
-  void *ptrs[] = {c->d_small, c->s_in.p, c->s_out.p, c->synth_tab.p, c->ls2_ws.p};
+  void *ptrs[] = {c->d_small, c->s_in.p, c->s_out.p, c->synth_tab.p, c->ls2_ws.p, c->ls2_ws_alt.p};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->ls2_host) (void)hipHostFree(c->ls2_host);
@@ -1004,11 +1102,10 @@ int rfid_batch_plan(rfid_ctx *c, int n_streams, int64_t max_raw) {
     // free.  Measured on configs[1] (profiles/r04/overlap.txt): the decoder's waves beside the next front end take their
     // instruction slots from it -- -1.5 % per pass on one box, +3 % on another (a decoder wave that gets to a CU first keeps
     // the front end's workgroup out until it is through) -- not a default.
-    const char *ov = getenv("RFID_OVERLAP");
     const size_t need = sizeof(float2) * (size_t)c->y_stride * n_streams + (sizeof(rfid_window) * 3 + sizeof(rfid_decode_result)) * (size_t)c->flat_cap +
                         sizeof(rfid_stream_stats) * (size_t)n_streams;
     size_t free_b = 0, total_b = 0;
-    if (ov && atoi(ov) >= 2 && n_streams >= 64 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < free_b / 8) {
+    if (c->knobs.overlap >= 2 && n_streams >= 64 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < free_b / 8) {
       hipError_t e2 = hipMalloc(&c->alt_blk, sz_set);
       if (e2 == hipSuccess) {
         bind_set((char *)c->alt_blk, c->alt.d_y, c->alt.d_wtab, c->alt.d_flat, c->alt.d_wcount, c->alt.d_flat_count, c->alt.d_res, c->alt.d_stats);
@@ -1029,9 +1126,8 @@ int rfid_batch_plan(rfid_ctx *c, int n_streams, int64_t max_raw) {
     {
       // ... and a second matched-filter output buffer for the filter of the next pass (unless a whole second set exists, or
       // this is a stream's own plan: n_dec of a stream call is small and its passes do not overlap)
-      const char *ov = getenv("RFID_OVERLAP");
       size_t free_b = 0, total_b = 0;
-      if (!c->alt_have && !(ov && atoi(ov) == 0) && sz_y >= ((size_t)16 << 20) && hipMemGetInfo(&free_b, &total_b) == hipSuccess && sz_y < free_b / 8) {
+      if (!c->alt_have && c->knobs.overlap != 0 && sz_y >= ((size_t)16 << 20) && hipMemGetInfo(&free_b, &total_b) == hipSuccess && sz_y < free_b / 8) {
         if (hipMalloc(&c->alt_y_blk, sz_y) == hipSuccess) c->alt.d_y = (float2 *)c->alt_y_blk;
         else { (void)hipGetLastError(); c->alt_y_blk = nullptr; }
       }
@@ -1042,6 +1138,17 @@ int rfid_batch_plan(rfid_ctx *c, int n_streams, int64_t max_raw) {
       c->ls2_ws.p = nullptr; c->ls2_ws.cap = 0;
       if (hipMalloc(&c->ls2_ws.p, need) == hipSuccess) c->ls2_ws.cap = need;
       else { (void)hipGetLastError(); c->ls2_ws.p = nullptr; }
+    }
+    // ... and a second work space beside the second filter output buffer (the fused first pass of the next pass beside the
+    // rest of this one, rfid_batch_process), where it is small beside what is free
+    if (c->alt.d_y && !c->alt_have && c->knobs.ls_fused && (c->knobs.overlap != 0) && c->ls2_ws.p && need > c->ls2_ws_alt.cap) {
+      size_t free_b = 0, total_b = 0;
+      if (c->ls2_ws_alt.p) (void)hipFree(c->ls2_ws_alt.p);
+      c->ls2_ws_alt.p = nullptr; c->ls2_ws_alt.cap = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < free_b / 8) {
+        if (hipMalloc(&c->ls2_ws_alt.p, need) == hipSuccess) c->ls2_ws_alt.cap = need;
+        else { (void)hipGetLastError(); c->ls2_ws_alt.p = nullptr; }
+      }
     }
   }
   // persistent decoders: the EPC kernel holds 18.6 KiB of LDS per single-wave workgroup -> 8 per CU
@@ -1066,6 +1173,7 @@ int rfid_batch_mf(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64_t n_
   if (n_raw > c->max_raw) return RFID_ERR_CAPACITY;
   HIPCHK(c, hipSetDevice(c->device));
   { int rj = join_tails(c); if (rj) return rj; }
+  c->y_touched = true;
   return batch_mf_on(c, c->stream, d_raw, raw_stride, n_raw, d_lens);
 }
 // n_parts > 1: the output tiles in that many launches, launch i >= 1 behind part_waits[i - 1] (when part_have[i - 1])
@@ -1084,10 +1192,14 @@ static int batch_mf_on(rfid_ctx *c, hipStream_t stream, const void *d_raw, int64
   const int64_t tiles = (a.n_out + MF_TILE - 1) / MF_TILE;
   if (n_parts < 1 || tiles < 1024 * (int64_t)n_parts) n_parts = 1;
   // (shares of the parts in percent: what the quiet stretches behind the points take, profiles/r04/ls2_second_half.txt)
-  int share[8] = {35, 45, 20, 0, 0, 0, 0, 0};
+  int share[8];
   if (n_parts > 8) n_parts = 8;
-  if (const char *e = getenv("RFID_MF_SPLIT")) { int k = 0; for (const char *q = e; *q && k < 8; ++k) { share[k] = atoi(q); while (*q && *q != ',') ++q; if (*q) ++q; } }
-  else if (n_parts != 3) for (int k = 0; k < 8; ++k) share[k] = (k < n_parts) ? 100 / n_parts : 0;
+  for (int k = 0; k < 8; ++k) share[k] = c->knobs.mf_split[k];
+  {   // (the default shares are for three launches; another count without shares of its own: equal parts)
+    int given = 0;
+    for (int k = 0; k < 8; ++k) given += share[k] > 0;
+    if (given != n_parts) for (int k = 0; k < 8; ++k) share[k] = (k < n_parts) ? 100 / n_parts : 0;
+  }
   int64_t t_next = 0;
   int acc = 0;
   for (int part = 0; part < n_parts && tiles > 0; ++part) {
@@ -1134,7 +1246,7 @@ static int rfid_batch_gate_impl(rfid_ctx *c, const int *skip_if) {
   return RFID_OK;
 }
 int rfid_batch_gate(rfid_ctx *c) {
-  if (c) c->d_ls2_ctl = nullptr;
+  if (c) { c->d_ls2_ctl = nullptr; c->y_touched = true; }
   return rfid_batch_gate_impl(c, nullptr);
 }
 
@@ -1209,9 +1321,7 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
   // measured on MI355X (1024 traces): the overlap paid off while the gate scan took 4 ms (-5 %), but the
   // scan is slowed down by anything that shares its SIMDs; since it runs in 2.9 ms the plain sequence is
   // faster, so chunking is opt-in (RFID_FRONT_CHUNKS=8)
-  int nch = 1;
-  if (const char *e = getenv("RFID_FRONT_CHUNKS")) nch = atoi(e);
-  if (nch > rfid_ctx::MAX_CHUNKS) nch = rfid_ctx::MAX_CHUNKS;
+  const int nch = c->knobs.front_chunks;
   if (nch < 2 && ls_applicable(c, c->B, n_out)) {
     // few long traces: matched filter, then the gate scan as the long-stream front end -- every launch of it enqueued
     // here, the sequential scan behind them as the fallback that skips itself when the front end succeeded
@@ -1222,17 +1332,44 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
     // front end's first launch filters the raw samples itself (ls2_front_kernel), one sweep over the raw samples instead of the
     // filter's and three over its output.  When the front end gives up the sequential scan behind it needs all of y: a filter
     // launch and the scan are enqueued behind the list, both skipping themselves on Ls2Ctl::ok.
-    if (c->ls_fused && raw_stride >= 2) {
+    if (c->knobs.ls_fused && raw_stride >= 2) {
       c->d_lens = (const int64_t *)d_lens;
       c->last_n_raw = n_raw;
       c->n_chunks_last = 0;
+      // Passes enqueued back to back: with a second matched-filter output buffer and a second work space (rfid_batch_plan) the
+      // fused first pass of THIS pass -- bound by the HBM, and touching nothing but the raw samples, y and its work space --
+      // runs on stream2 beside the rest of the pass before (re-run rounds, state machine, dc_est, decoder: instruction- and
+      // latency-bound launches that leave most of the HBM's bandwidth unused); the rest of this pass follows on the main
+      // stream.  The buffers alternate; a buffer is written again only when the pass before last is through with it.
+      const bool ahead = c->alt.d_y != nullptr && c->ls2_ws_alt.p != nullptr && !c->alt_have && (c->knobs.overlap != 0);
+      if (ahead) {
+        std::swap(c->d_y, c->alt.d_y);
+        c->y_idx ^= 1;
+        if (c->y_touched) {   // (something outside this protocol used a buffer on the main stream: wait for all of it)
+          HIPCHK(c, hipEventRecord(c->ev_pass, c->stream));
+          HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_pass, 0));
+          c->y_touched = false;
+        }
+        if (c->y_recorded[c->y_idx]) {
+          HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_y_free[c->y_idx], 0));
+          c->y_recorded[c->y_idx] = false;
+        }
+      }
       HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
       HIPCHK(c, hipEventRecord(c->ev[1], c->stream));   // mf_ms = 0: the filter runs inside the front end's first launch
       c->ev_valid[0] = c->ev_valid[1] = true;
       int enq = 0;
       LsOpts lo;
-      lo.raw = d_raw; lo.raw_stride = raw_stride;
+      lo.raw = d_raw; lo.raw_stride = raw_stride; lo.ahead = ahead;
       if ((rc = ls_enqueue(c, n_out, lo, &enq))) return rc;
+      if (!enq && ahead) {
+        // (not applicable with the second stream after all: the buffers go back, the pass runs on the main stream alone)
+        std::swap(c->d_y, c->alt.d_y); c->y_idx ^= 1;
+        c->y_touched = true;
+        lo.ahead = false;
+        if ((rc = ls_enqueue(c, n_out, lo, &enq))) return rc;
+      }
+      const bool ahead_now = ahead && lo.ahead;
       if (enq) {
         c->fused_last = 2;
         MfFallbackArgs f;
@@ -1250,7 +1387,14 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
         }
         if ((rc = rfid_batch_gate_impl(c, &c->d_ls2_ctl->ok))) return rc;
         if ((rc = rfid_batch_decode(c, want_scores))) return rc;
-        return rfid_batch_stats(c);
+        if ((rc = rfid_batch_stats(c))) return rc;
+        if (ahead_now) {
+          HIPCHK(c, hipEventRecord(c->ev_y_free[c->y_idx], c->stream));
+          c->y_recorded[c->y_idx] = true;
+        } else {
+          c->y_touched = true;
+        }
+        return RFID_OK;
       }
       // (no work space: the plain sequence below)
     }
@@ -1271,12 +1415,12 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
       // configs[2], passes enqueued back to back: 10.4 -> 10.07 ms, and 9.5 - 9.6 with chain launches of 512 instead of 1 024 threads
       // (which starved beside the filter) (profiles/r04/ls2_second_half.txt; RFID_MF_PARTS /
       // RFID_MF_SPLIT are the experiment's knobs).
-      static const int mf_parts = getenv("RFID_MF_PARTS") ? atoi(getenv("RFID_MF_PARTS")) : 3;
-      if ((rc = batch_mf_on(c, c->stream2, d_raw, raw_stride, n_raw, d_lens, mf_parts, c->ev_gap, c->gap_recorded))) return rc;
+      if ((rc = batch_mf_on(c, c->stream2, d_raw, raw_stride, n_raw, d_lens, c->knobs.mf_parts, c->ev_gap, c->gap_recorded))) return rc;
       HIPCHK(c, hipEventRecord(c->ev_fe_done, c->stream2));
       HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fe_done, 0));
-    } else if ((rc = batch_mf_on(c, c->stream, d_raw, raw_stride, n_raw, d_lens))) {
-      return rc;
+    } else {
+      c->y_touched = true;
+      if ((rc = batch_mf_on(c, c->stream, d_raw, raw_stride, n_raw, d_lens))) return rc;
     }
     int enq = 0;
     LsOpts lo;
@@ -1296,7 +1440,8 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
     return RFID_OK;
   }
   c->d_ls2_ctl = nullptr;   // (this pass does not run the long-stream front end)
-  if (nch < 2 && raw_stride >= 2 && !getenv("RFID_FRONT_UNFUSED")) {
+  c->y_touched = true;
+  if (nch < 2 && raw_stride >= 2 && !c->knobs.front_unfused) {
     // default: fused front end -- the gate's producer waves run the matched filter themselves
     // (one read of the raw samples, one write of y for the decoder, no second pass over y)
     HIPCHK(c, hipSetDevice(c->device));
@@ -1423,6 +1568,24 @@ int rfid_batch_set_long_stream(rfid_ctx *c, int mode) {
   if (!c || mode < 0 || mode > 2) return RFID_ERR_INVALID;
   c->ls_mode = mode;
   return RFID_OK;
+}
+
+int rfid_ctx_set_knob(rfid_ctx *c, const char *name, int value) {
+  if (!c || !name) return RFID_ERR_INVALID;
+  for (const KnobEntry &e : g_knob_table)
+    if (strcmp(name, e.name) == 0) {
+      if (value < e.lo || value > e.hi) return RFID_ERR_INVALID;
+      c->knobs.*(e.field) = value;
+      if (e.field == &RfidKnobs::long_stream) c->ls_mode = value;
+      return RFID_OK;
+    }
+  return RFID_ERR_INVALID;
+}
+int rfid_ctx_get_knob(const rfid_ctx *c, const char *name, int *value) {
+  if (!c || !name || !value) return RFID_ERR_INVALID;
+  for (const KnobEntry &e : g_knob_table)
+    if (strcmp(name, e.name) == 0) { *value = (e.field == &RfidKnobs::long_stream) ? c->ls_mode : c->knobs.*(e.field); return RFID_OK; }
+  return RFID_ERR_INVALID;
 }
 
 int rfid_batch_ls_report(const rfid_ctx *c, rfid_ls_report *out) {

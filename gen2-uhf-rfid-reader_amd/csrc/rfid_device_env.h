@@ -134,6 +134,16 @@ RFID_DEVICE void publish(int *flag, int v) { __hip_atomic_store(flag, v, __ATOMI
 RFID_DEVICE void await(const int *flag, int v) {
   while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != v) __builtin_amdgcn_s_sleep(2);
 }
+RFID_DEVICE int atomic_max(int *p, int v) { return atomicMax(p, v); }
+// one 8-byte word handed from one workgroup of a launch to another: device-coherent, and NOTHING else is ordered by it (no
+// release / acquire: on this part those write back / invalidate the XCD's whole L2 -- once per wave of a 130 000-wave launch
+// that made the launch 3x slower).  Whatever belongs together has to sit in the one word.
+RFID_DEVICE uint64_t load_u64_agent(const uint64_t *p) {
+  return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+RFID_DEVICE void store_u64_agent(uint64_t *p, uint64_t v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 RFID_DEVICE void atomic_or64(uint64_t *p, uint64_t v) { atomicOr(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v); }
 RFID_DEVICE void atomic_and64(uint64_t *p, uint64_t v) { atomicAnd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v); }
 // this wave's global stores are visible device-wide when this returns

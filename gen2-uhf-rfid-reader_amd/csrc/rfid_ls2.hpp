@@ -45,7 +45,8 @@ constexpr int LS2_FINE = 4;           // pieces per point of the idle-cut grid
 constexpr int LS2_WBUCKET = 320;      // two gate openings are at least RN16_WIN + T1_SAMPLES = 346 samples apart:
                                       // window records live in a per-trace table indexed by start / LS2_WBUCKET
 static_assert(LS2_WBUCKET <= RN16_WIN + T1_SAMPLES, "one window per bucket");
-constexpr int LS2_AVG_ROUNDS = 9;     // re-run rounds after the first pass, per recurrence (a round without work costs two empty launches)
+constexpr int LS2_AVG_ROUNDS = 11;    // re-run rounds after the first pass, per recurrence (a round without work costs two empty launches; configs[2]
+                                      // settles in 5 rounds on y-given pieces and in 8 on the fused first pass's, profiles/r05/ls2_rounds.txt)
 constexpr int LS2_FSM_ROUNDS = 3;
 constexpr int LS2_DC_ROUNDS = 7;
 constexpr int LS2_MAXR = 12;
@@ -162,9 +163,29 @@ struct Ls2Args {
   uint64_t *lowm;               // [n_streams][cstride]: per 64-sample block of the trace, the samples that are not carrier (the
                                 // memory of `closed`, which the state machine only writes later)
   Ls2Piece *upiece; int *unextv, *uprevv;   // [NS]
+  int keep_flat_count;          // 1: ls2_clear_kernel leaves the decoder's list counters alone (the caller zeroes them)
+  // the fused first pass's look-back (ls2_front_kernel): what the slots before have found out about avg_ampl, for the first guess
+  uint64_t *lb_fn;              // [NS] the slot's piece as a function of its start value (c0 | (c1 ^ 2^31) << 32); 0: not there yet
+  uint64_t *lb_end;             // [NS] avg_ampl behind the slot's piece (integer image, != 0) | drift << 32; 0: not known (yet)
+  int *lb_water;                // [n_streams] 1 + the highest slot of the trace whose lb_end is known (0: none yet)
+#ifdef LS2_CHEAT
+  int cheat_sigma;
+#endif
 };
 
 // ---- small helpers -----------------------------------------------------------------------------------------------
+// Passes enqueued back to back: the launches behind the first pass of a pass (chains, re-runs, state machine, dc_est) share the
+// device with the NEXT pass's first pass; most of them are short strings of dependent instructions in few waves, and a wave
+// that shares its SIMD with four or five waves of the big kernel gets every fifth issue slot.  LS2_TAIL_PRIO_N > 0: they
+// raise their waves' priority (s_setprio) -- measured in profiles/r05/ls2_overlap.txt
+#ifndef LS2_TAIL_PRIO_N
+#define LS2_TAIL_PRIO_N 0
+#endif
+RFID_DEVICE void ls2_tail_prio() {
+#if LS2_TAIL_PRIO_N > 0
+  wv::set_priority<LS2_TAIL_PRIO_N>();
+#endif
+}
 RFID_DEVICE int ls2_ord(float f) {   // monotone integer image of a binary32 value: distance = ulps
   const uint32_t u = wv::f2u(f);
   return (u & 0x80000000u) ? -(int)(u & 0x7fffffffu) : (int)u;
@@ -330,7 +351,8 @@ RFID_KERNEL(256) void ls2_clear_kernel(Ls2Args a) {
   zero4(a.ctl, (int64_t)(sizeof(Ls2Ctl) / 4));
   zero4(a.cflag, B * LS2_CHAIN_GMAX);
   zero4(a.consumed, B);
-  zero4(a.flat_count, 2);
+  if (a.fused) { zero8(a.lb_fn, B * a.max_b); zero8(a.lb_end, B * a.max_b); zero4(a.lb_water, B); }
+  if (!a.keep_flat_count) zero4(a.flat_count, 2);   // (a first pass that runs beside the pass before: its decoder still reads them)
   zero8(a.votes, 2 * B * a.vstride);
   zero8(a.wb, (int64_t)(sizeof(Ls2Win) / 8) * B * a.wb_stride);
 }
@@ -629,6 +651,7 @@ RFID_KERNEL(64) void ls2_avg_first_kernel(Ls2Args a) {
   if ((b >> 3) < per && i < NS) ls2_avg_piece<true>(a, i, lane);
 }
 RFID_KERNEL(64) void ls2_avg_rerun_kernel(Ls2Args a) {
+  ls2_tail_prio();
   if (wv::uniform(a.ctl->fail) != 0) return;
   const int NS = a.n_streams * a.max_b;
   const int cnt = wv::uniform(a.ctl->avg_list[a.round - 1]);
@@ -637,6 +660,44 @@ RFID_KERNEL(64) void ls2_avg_rerun_kernel(Ls2Args a) {
   for (int r = (int)blockIdx.x; r < cnt; r += (int)gridDim.x) ls2_avg_piece<false>(a, wv::uniform(list[r]), lane);   // (grid = NS: one each)
 }
 
+// A piece's latest run as a function "true start -> true end", on the monotone integer image of binary32: T -> T + c[q],
+// q = parity of T (the run from s serves the starts s + even, the run from s + 1 ulp the starts s + odd).  Functions
+// of this form compose to the same form, so a trace's chain of pieces is ONE prefix scan.  (32-bit wrap-around
+// arithmetic: the true values fit, so sums modulo 2^32 are the true sums.)
+struct Ls2A32 { int c0, c1; };
+RFID_DEVICE Ls2A32 ls2_comp32(const Ls2A32 f, const Ls2A32 g) {   // f first, then g
+  Ls2A32 r;
+  r.c0 = (int)((uint32_t)f.c0 + (uint32_t)((f.c0 & 1) ? g.c1 : g.c0));
+  r.c1 = (int)((uint32_t)f.c1 + (uint32_t)(((1 + f.c1) & 1) ? g.c1 : g.c0));
+  return r;
+}
+RFID_DEVICE Ls2A32 ls2_elem32(float s, float eA, float eB) {
+  const uint32_t os = (uint32_t)ls2_ord(s);
+  const int a0 = (int)((uint32_t)ls2_ord(eA) - os), a1 = (int)((uint32_t)ls2_ord(eB) - 1u - os);
+  Ls2A32 r;
+  if (os & 1u) { r.c0 = a1; r.c1 = a0; } else { r.c0 = a0; r.c1 = a1; }   // T even-distant from s -> a0, odd-distant -> a1
+  return r;
+}
+RFID_DEVICE int ls2_apply32(const Ls2A32 f, int T) { return (int)((uint32_t)T + (uint32_t)((T & 1) ? f.c1 : f.c0)); }
+// inclusive scan over the 64 lanes in lane order (lane L: the composition of lanes 0..L): four steps within the 16-lane
+// rows, two across them (the identity (0, 0) where a lane has no source)
+RFID_DEVICE Ls2A32 ls2_wave_incl(Ls2A32 v, int lane) {
+  (void)lane;
+  Ls2A32 o;
+  o.c0 = wv::dpp_row_shr<1>(v.c0, 0); o.c1 = wv::dpp_row_shr<1>(v.c1, 0); v = ls2_comp32(o, v);
+  o.c0 = wv::dpp_row_shr<2>(v.c0, 0); o.c1 = wv::dpp_row_shr<2>(v.c1, 0); v = ls2_comp32(o, v);
+  o.c0 = wv::dpp_row_shr<4>(v.c0, 0); o.c1 = wv::dpp_row_shr<4>(v.c1, 0); v = ls2_comp32(o, v);
+  o.c0 = wv::dpp_row_shr<8>(v.c0, 0); o.c1 = wv::dpp_row_shr<8>(v.c1, 0); v = ls2_comp32(o, v);
+  o.c0 = wv::dpp_row_bcast15(v.c0, 0); o.c1 = wv::dpp_row_bcast15(v.c1, 0); v = ls2_comp32(o, v);
+  o.c0 = wv::dpp_row_bcast31(v.c0, 0); o.c1 = wv::dpp_row_bcast31(v.c1, 0); v = ls2_comp32(o, v);
+  return v;
+}
+RFID_DEVICE Ls2A32 ls2_wave_excl(const Ls2A32 incl, int lane) {
+  (void)lane;
+  Ls2A32 e;
+  e.c0 = wv::dpp_wave_shr1(incl.c0, 0); e.c1 = wv::dpp_wave_shr1(incl.c1, 0);
+  return e;
+}
 // ---- 2a. the FUSED first pass (round 5): matched filter + piece boundaries + avg_ampl in ONE sweep over the raw samples ----
 // The matched filter is bound by the HBM (8 B in per raw sample), the first avg_ampl pass by its instruction streams; as two
 // launches they ran one after the other (3.6 + 0.35 (cut searches over y) + 2.0 ms for configs[2]) and y was written, then read
@@ -672,12 +733,69 @@ RFID_DEVICE uint32_t ls2_wave_max_bits(uint32_t v) {   // (values below 2^31: bi
   return (uint32_t)wv::readlane(x, 63);
 }
 
+// The look-back of the fused first pass: a better first guess.  The mean of the amplitude ring is what avg_ampl is up to the
+// rounding errors of all additions so far -- a random walk that is ~5 000 ulps off after 4e8 samples, which is why two
+// thirds of configs[2]'s pieces had to be run a second time (a guess proves nothing beyond the distance of the nearest
+// partial sum to a power of two, a few thousand ulps).  But that drift moves slowly: ~17 ulps per piece.  So every wave
+// leaves behind what it has found out -- its piece as a function of the start value (Ls2A32) as soon as it is through,
+// and, once the functions of the slots before it reach back to a slot that knows its start, avg_ampl behind its own
+// piece and its drift (true start - ring mean) -- and a wave that begins takes the drift of the newest slot that knows
+// it (Ls2Args::lb_water): off by the walk over the ~4 000 pieces in flight (~1 100 ulps), not by the whole past.  Exactly
+// the single-pass scan with decoupled look-back -- but only for the GUESS: functions of pieces whose runs are not proven are
+// off by an ulp or two, nothing here is trusted, the chain kernels behind this pass prove every start as before.
+// (Workgroup b takes slot b: the dispatch order is the trace's order, a wave only ever waits for slots before its own.)
+#ifndef LS2_LB_N
+#define LS2_LB_N 1
+#endif
+constexpr bool LS2_LB = LS2_LB_N != 0;   // (0: experiment builds without the look-back; slots then an eighth per XCD as ls2_avg_first_kernel)
+#ifndef LS2_LB_WINDOWS_N
+#define LS2_LB_WINDOWS_N 64
+#endif
+constexpr int LS2_LB_WINDOWS = LS2_LB_WINDOWS_N;   // at most this many steps back (4 096 slots: more than are in flight)
+// (one 8-byte word per slot and kind, written once with a device-coherent store and read with device-coherent loads: no
+// flag beside the data, no release / acquire -- see wv::store_u64_agent)
+RFID_DEVICE void ls2_lb_publish_fn(const Ls2Args &a, const int i, const Ls2A32 f, const int lane) {
+  if (LS2_LB && lane == 0) wv::store_u64_agent(a.lb_fn + i, (uint64_t)(uint32_t)f.c0 | ((uint64_t)((uint32_t)f.c1 ^ 0x80000000u) << 32));
+}
+// avg_ampl (integer image) at the first sample of slot j >= 1 of the trace whose slot 0 is `base`: the functions of the slots
+// before it, back to the nearest one that knows the value behind its piece.  64 slots per step, in the trace's order over
+// the lanes.  NEVER waits: a slot on the way that has not published anything yet (its wave is still at work) ends the attempt
+// (false) -- waiting would hold this wave's place on the device until the slowest of the waves before it is through, and the
+// whole launch would run in lock step.  So only a wave that happens to finish behind everything in front of it comes to know
+// its start; with pieces of 1 .. 1.5 nominal lengths that is every few hundredth, which is all the guesses need.
+
+RFID_DEVICE bool ls2_lb_start(const Ls2Args &a, const int base, const int j, const int lane, int &t_start) {
+  Ls2A32 acc; acc.c0 = 0; acc.c1 = 0;     // the slots behind the window (already accounted for)
+  int k = j - 1;
+  for (int it = 0; it < LS2_LB_WINDOWS; ++it, k -= 64) {
+    const int slot = k - 63 + lane;
+    const bool in = slot >= 0;
+    const uint64_t we = in ? wv::load_u64_agent(a.lb_end + base + slot) : 0ull;
+    const uint64_t wf = in ? wv::load_u64_agent(a.lb_fn + base + slot) : (1ull << 63);   // (before the trace: the identity)
+    const uint64_t pm = wv::ballot(we != 0ull);
+    const int q = pm ? (63 - (int)__builtin_clzll(pm)) : -1;      // the newest slot of the window that knows its end
+    if (wv::ballot(lane > q && wf == 0ull) != 0ull) return false; // a slot in between is still at work
+    Ls2A32 el; el.c0 = 0; el.c1 = 0;
+    if (lane > q) { el.c0 = (int)(uint32_t)wf; el.c1 = (int)((uint32_t)(wf >> 32) ^ 0x80000000u); }
+    const Ls2A32 inc = ls2_wave_incl(el, lane);
+    Ls2A32 tot; tot.c0 = wv::readlane(inc.c0, 63); tot.c1 = wv::readlane(inc.c1, 63);
+    if (q >= 0) {
+      const int t_end = wv::readlane((int)(uint32_t)we, q);
+      t_start = ls2_apply32(acc, ls2_apply32(tot, t_end));
+      return true;
+    }
+    acc = ls2_comp32(tot, acc);
+    if (k - 63 <= 0) return false;   // (slot 0 has not published its end: an empty or all-zero trace)
+  }
+  return false;
+}
 RFID_DEVICE void ls2_front_piece(const Ls2Args &a, const int i, const int lane, float4 *tile4) {
   const int s = i / a.max_b, j = i - s * a.max_b;
   const int n_total = ls2_trace_len(a, s);
   const int64_t G64 = (int64_t)j * a.P;
   Ls2Piece none; none.pos0 = 0; none.len = 0;
-  if (G64 >= n_total) { if (lane == 0) { a.piece[i] = none; a.cutf[i] = -1; } return; }
+  Ls2A32 ident; ident.c0 = 0; ident.c1 = 0;
+  if (G64 >= n_total) { if (lane == 0) { a.piece[i] = none; a.cutf[i] = -1; } ls2_lb_publish_fn(a, i, ident, lane); return; }
   const int kg = (int)(G64 >> 6);                                    // the block that starts at the slot's grid point
   const int klim = (int)((G64 + a.P / 2) >> 6);                      // the last block boundary this slot's piece may start at
   const int k0 = (j == 0) ? 0 : (kg - LS2_FRONT_PRE);                // (P >= 512: kg >= 8)
@@ -727,6 +845,13 @@ RFID_DEVICE void ls2_front_piece(const Ls2Args &a, const int i, const int lane, 
   for (int u = 0; u < LS2_FRONT_AHEAD; ++u) {
     gate_load_raw(buf[u], xs, hi_idx, rbase + (int64_t)(k0 + u) * 64 * DECIM, lane, vec);
     wv::compiler_fence();
+  }
+  // the drift of the newest slot of this trace that knows it (the loads above are in flight meanwhile)
+  int drift = 0, g_ord = 0;
+  if (LS2_LB && j > 0) {
+    const int w = wv::uniform(wv::load_coherent_i32(a.lb_water + s));
+    if (w > 0 && w <= j) drift = wv::uniform((int)(uint32_t)(wv::load_u64_agent(a.lb_end + s * a.max_b + w - 1) >> 32));
+    if (drift > (1 << 20) || drift < -(1 << 20)) drift = 0;
   }
   auto block = [&](const int k, GateRawRegs &rb) -> int {
     const float2 yv = gate_fir_step(rb, tile4, lane, k == 0);
@@ -802,6 +927,21 @@ RFID_DEVICE void ls2_front_piece(const Ls2Args &a, const int i, const int lane, 
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) part += wv::shfl_xor(part, off);
         sA = wv::uniform(part) / WIN_LEN_F;
+        g_ord = ls2_ord(sA);
+        // ... + the drift another slot has found (see ls2_lb_start), while that leaves the value an ordinary positive number
+        if (drift != 0 && (wv::f2u(sA) >> 23) >= 25u && (wv::f2u(sA) >> 23) < 255u) {
+          const float t = ls2_from_ord(g_ord + drift);
+          if (((wv::f2u(t) ^ wv::f2u(sA)) >> 31) == 0u && (wv::f2u(t) >> 23) >= 25u && (wv::f2u(t) >> 23) < 255u) sA = t;
+        }
+#ifdef LS2_CHEAT
+        // EXPERIMENT ONLY (never in the product build): what a first guess that is off by ~cheat_sigma ulps instead of the rounding
+        // drift's ~5 000 would save -- the start the PREVIOUS pass over the same trace found for this slot, plus noise
+        if (a.cheat_sigma > 0 && a.aT[i] != 0) {
+          uint32_t h = (uint32_t)i * 2654435761u; float u = 0.0f;
+          for (int q = 0; q < 4; ++q) { h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; u += (float)(h & 0xffffu) * (1.0f / 65536.0f); }
+          sA = ls2_from_ord(a.aT[i] + (int)((u - 2.0f) * 1.7320508f * (float)a.cheat_sigma));
+        }
+#endif
         begin_piece(kn);
       } else if (kn >= klim) r = 2;
     } else {
@@ -832,6 +972,7 @@ RFID_DEVICE void ls2_front_piece(const Ls2Args &a, const int i, const int lane, 
       a.piece[i] = none; a.cutf[i] = -1;
       if (rc == 3) a.ctl->fail = 5;
     }
+    ls2_lb_publish_fn(a, i, ident, lane);
     return;
   }
   {
@@ -853,6 +994,21 @@ RFID_DEVICE void ls2_front_piece(const Ls2Args &a, const int i, const int lane, 
     a.piece[i] = pc;
     a.cutf[i] = 64 * kb;
   }
+  // what the slots behind this one can use (see ls2_lb_start)
+  if (LS2_LB) {
+    const Ls2A32 f = ls2_elem32(sA, avA, avB);
+    int t_start = ls2_ord(sA);
+    bool known = true;
+    if (j > 0) {
+      ls2_lb_publish_fn(a, i, f, lane);
+      known = ls2_lb_start(a, s * a.max_b, j, lane, t_start);
+    }
+    const int t_end = ls2_apply32(f, t_start);
+    if (known && t_end != 0 && lane == 0) {
+      wv::store_u64_agent(a.lb_end + i, (uint64_t)(uint32_t)t_end | ((uint64_t)(uint32_t)((j == 0) ? 0 : (t_start - g_ord)) << 32));
+      if (j > 0) wv::atomic_max(a.lb_water + s, j + 1);
+    }
+  }
 }
 #ifndef LS2_FRONT_OCC_N
 #define LS2_FRONT_OCC_N 0
@@ -866,9 +1022,9 @@ void ls2_front_kernel(Ls2Args a) {
   RFID_SHARED float4 tile4[64 * GATE_RAW_LD];
   const int lane = wv::lane_id();
   const int NS = a.n_streams * a.max_b;
-  const int per = (NS + 7) >> 3;                       // (an eighth of the slots per XCD, as ls2_avg_first_kernel)
-  const int b = (int)blockIdx.x, i = (b & 7) * per + (b >> 3);
-  if ((b >> 3) < per && i < NS) ls2_front_piece(a, i, lane, tile4);
+  int i = (int)blockIdx.x;                             // (slots in dispatch order: the look-back looks at lower slots only)
+  if (!LS2_LB) { const int per = (NS + 7) >> 3; i = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3); if (((int)blockIdx.x >> 3) >= per) return; }
+  if (i < NS) ls2_front_piece(a, i, lane, tile4);
 }
 // the avg_ampl pieces' links (one thread per slot)
 RFID_KERNEL(256) void ls2_link_kernel(Ls2Args a) {
@@ -921,44 +1077,6 @@ RFID_KERNEL(256) void ls2_idle_cut_kernel(Ls2Args a) {
   *out = found;
 }
 
-// A piece's latest run as a function "true start -> true end", on the monotone integer image of binary32: T -> T + c[q],
-// q = parity of T (the run from s serves the starts s + even, the run from s + 1 ulp the starts s + odd).  Functions
-// of this form compose to the same form, so a trace's chain of pieces is ONE prefix scan.  (32-bit wrap-around
-// arithmetic: the true values fit, so sums modulo 2^32 are the true sums.)
-struct Ls2A32 { int c0, c1; };
-RFID_DEVICE Ls2A32 ls2_comp32(const Ls2A32 f, const Ls2A32 g) {   // f first, then g
-  Ls2A32 r;
-  r.c0 = (int)((uint32_t)f.c0 + (uint32_t)((f.c0 & 1) ? g.c1 : g.c0));
-  r.c1 = (int)((uint32_t)f.c1 + (uint32_t)(((1 + f.c1) & 1) ? g.c1 : g.c0));
-  return r;
-}
-RFID_DEVICE Ls2A32 ls2_elem32(float s, float eA, float eB) {
-  const uint32_t os = (uint32_t)ls2_ord(s);
-  const int a0 = (int)((uint32_t)ls2_ord(eA) - os), a1 = (int)((uint32_t)ls2_ord(eB) - 1u - os);
-  Ls2A32 r;
-  if (os & 1u) { r.c0 = a1; r.c1 = a0; } else { r.c0 = a0; r.c1 = a1; }   // T even-distant from s -> a0, odd-distant -> a1
-  return r;
-}
-RFID_DEVICE int ls2_apply32(const Ls2A32 f, int T) { return (int)((uint32_t)T + (uint32_t)((T & 1) ? f.c1 : f.c0)); }
-// inclusive scan over the 64 lanes in lane order (lane L: the composition of lanes 0..L): four steps within the 16-lane
-// rows, two across them (the identity (0, 0) where a lane has no source)
-RFID_DEVICE Ls2A32 ls2_wave_incl(Ls2A32 v, int lane) {
-  (void)lane;
-  Ls2A32 o;
-  o.c0 = wv::dpp_row_shr<1>(v.c0, 0); o.c1 = wv::dpp_row_shr<1>(v.c1, 0); v = ls2_comp32(o, v);
-  o.c0 = wv::dpp_row_shr<2>(v.c0, 0); o.c1 = wv::dpp_row_shr<2>(v.c1, 0); v = ls2_comp32(o, v);
-  o.c0 = wv::dpp_row_shr<4>(v.c0, 0); o.c1 = wv::dpp_row_shr<4>(v.c1, 0); v = ls2_comp32(o, v);
-  o.c0 = wv::dpp_row_shr<8>(v.c0, 0); o.c1 = wv::dpp_row_shr<8>(v.c1, 0); v = ls2_comp32(o, v);
-  o.c0 = wv::dpp_row_bcast15(v.c0, 0); o.c1 = wv::dpp_row_bcast15(v.c1, 0); v = ls2_comp32(o, v);
-  o.c0 = wv::dpp_row_bcast31(v.c0, 0); o.c1 = wv::dpp_row_bcast31(v.c1, 0); v = ls2_comp32(o, v);
-  return v;
-}
-RFID_DEVICE Ls2A32 ls2_wave_excl(const Ls2A32 incl, int lane) {
-  (void)lane;
-  Ls2A32 e;
-  e.c0 = wv::dpp_wave_shr1(incl.c0, 0); e.c1 = wv::dpp_wave_shr1(incl.c1, 0);
-  return e;
-}
 // device self-test of the wave scan above (rfid_selftest): in[2 * lane], in[2 * lane + 1] -> inclusive scan, exclusive scan
 RFID_KERNEL(64) void ls2_scan_selftest_kernel(const int *in, int *out) {
   const int lane = wv::lane_id();
@@ -1039,6 +1157,7 @@ RFID_DEVICE void ls2_chain_prefix(const Ls2Args &a, int s, int b, int wave, int 
   }
 }
 RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_avg_chain_kernel(Ls2Args a) {
+  ls2_tail_prio();
   RFID_SHARED Ls2A32 wagg[LS2_CHAIN_WAVES + 1];
   Ls2Ctl *ctl = a.ctl;
   const int r = a.round;
@@ -1148,6 +1267,7 @@ constexpr int LS2_IDLE_N = GATE_N_SAT;   // the state at an idle cut: saturated 
 // The unit's steps start at its first sample (step k = samples u0 + 64 k ..), the votes are kept per 64-sample block of
 // the trace: every step's two masks are cut out of two neighbouring words.
 RFID_KERNEL(64) void ls2_fsm_kernel(Ls2Args a) {
+  ls2_tail_prio();
   Ls2Ctl *ctl = a.ctl;
   if (wv::uniform(ctl->fail) != 0) return;
   const int r = a.round;
@@ -1296,6 +1416,7 @@ constexpr int LS2_FSM_GROUP = LS2_FSM_GROUP_N;   // steps whose vote words are f
 constexpr int LS2_FSM_LANES = LS2_FSM_LANES_N;   // units per wave: a wave's pace is its slowest lane's and the walk is bound by the latency of
                                       // its scattered loads, so fewer units per wave and more waves per CU
 RFID_KERNEL(64) void ls2_fsm_lanes_kernel(Ls2Args a) {
+  ls2_tail_prio();
   Ls2Ctl *ctl = a.ctl;
   if (ctl->fail != 0) return;
   const int r = a.round;
@@ -1412,6 +1533,7 @@ RFID_KERNEL(64) void ls2_fsm_lanes_kernel(Ls2Args a) {
 // one workgroup per trace: does every unit start from the state its predecessor ended in, with the dc ring a cut assumes
 // (the 48 samples before it closed)?  A unit that does not is appended to its predecessor, which is scanned again.
 RFID_KERNEL(256) void ls2_fsm_chain_kernel(Ls2Args a) {
+  ls2_tail_prio();
   Ls2Ctl *ctl = a.ctl;
   const int r = a.round;
   if (ctl->fail != 0) return;
@@ -1487,6 +1609,7 @@ RFID_DEVICE int ls2_dc_cut(const Ls2Args &a, const int j) {
 // one thread per slot: where its dc_est piece starts (dend = 1: it has one; the run finds its own end)
 RFID_DEVICE bool ls2_fsm_settled(const Ls2Args &a, const Ls2Ctl *ctl);
 RFID_KERNEL(256) void ls2_dc_cut_kernel(Ls2Args a) {
+  ls2_tail_prio();
   if (!ls2_fsm_settled(a, a.ctl)) return;
   const int j = (int)(blockIdx.x * 256 + threadIdx.x);
   const int NS = a.n_streams * a.max_b;
@@ -1876,6 +1999,7 @@ RFID_DEVICE bool ls2_fsm_settled(const Ls2Args &a, const Ls2Ctl *ctl) {
   return wv::uniform(ctl->fail) == 0 && wv::uniform(ctl->avg_count[a.avg_rounds]) == 0 && wv::uniform(ctl->fsm_count[a.fsm_rounds]) == 0;
 }
 RFID_KERNEL(64) void ls2_dc_first_kernel(Ls2Args a) {
+  ls2_tail_prio();
   RFID_SHARED float2 lds_dc[DC_LEN];
   RFID_SHARED float2 lds_tmp[64];
   if (!ls2_fsm_settled(a, a.ctl)) return;
@@ -1892,6 +2016,7 @@ RFID_KERNEL(64) void ls2_dc_first_kernel(Ls2Args a) {
   }
 }
 RFID_KERNEL(64) void ls2_dc_rerun_kernel(Ls2Args a) {
+  ls2_tail_prio();
   RFID_SHARED float2 lds_dc[DC_LEN];
   RFID_SHARED float2 lds_tmp[64];
   if (!ls2_fsm_settled(a, a.ctl)) return;
@@ -1918,6 +2043,7 @@ RFID_DEVICE Ls2DcRec ls2_dc_rec(const Ls2Args &a, int base, int J) {
   return r;
 }
 RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_dc_chain_kernel(Ls2Args a) {
+  ls2_tail_prio();
   RFID_SHARED Ls2A32 wagg[2 * (LS2_CHAIN_WAVES + 1)];
   Ls2Ctl *ctl = a.ctl;
   const int r = a.round;
@@ -1999,6 +2125,7 @@ RFID_DEVICE bool ls2_all_settled(const Ls2Args &a, const Ls2Ctl *ctl) {
 // places in the decoder's two lists.  Workgroups and waves over the slots as in the chain kernels (sums: the pair (v, v)
 // composes by addition).
 RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_seq_kernel(Ls2Args a) {
+  ls2_tail_prio();
   RFID_SHARED Ls2A32 wagg[2 * (LS2_CHAIN_WAVES + 1)];
   const Ls2Ctl *ctl = a.ctl;
   if (!ls2_all_settled(a, ctl)) return;
@@ -2041,6 +2168,7 @@ RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_seq_kernel(Ls2Args a) {
 // one wave per unit: its windows (in order) -> the trace's window table, dc_est shifted to the unit's true start, and
 // the decoder's two lists
 RFID_KERNEL(64) void ls2_assemble_kernel(Ls2Args a) {
+  ls2_tail_prio();
   Ls2Ctl *ctl = a.ctl;
   if (!(wv::uniform(ctl->fail) == 0 && wv::uniform(ctl->avg_count[a.avg_rounds]) == 0 && wv::uniform(ctl->fsm_count[a.fsm_rounds]) == 0 &&
         wv::uniform(ctl->dc_count[a.dc_rounds]) == 0 && wv::uniform(ctl->wb_clash) == 0)) return;

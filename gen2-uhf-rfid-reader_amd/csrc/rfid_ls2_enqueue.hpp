@@ -40,7 +40,7 @@ inline Ls2Geometry ls2_geometry(int n_streams, int64_t n_dec, int min_piece = LS
 
 // work space: one allocation, carved up here (offsets in bytes, 256-byte aligned)
 struct Ls2Layout {
-  size_t cut, cutf, piece, nextv, prevv, upiece, unextv, uprevv, amp, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, drun, dT, dcut, dend, dlist, seq0, flat_base, cflag, cagg, ctl, consumed, total;
+  size_t cut, cutf, piece, nextv, prevv, upiece, unextv, uprevv, lb_fn, lb_end, lb_water, amp, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, drun, dT, dcut, dend, dlist, seq0, flat_base, cflag, cagg, ctl, consumed, total;
 };
 inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_stride) {
   Ls2Layout L;
@@ -55,6 +55,9 @@ inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_strid
   L.upiece = take(sizeof(Ls2Piece) * NS);
   L.unextv = take(sizeof(int) * NS);
   L.uprevv = take(sizeof(int) * NS);
+  L.lb_fn = take(sizeof(uint64_t) * NS);
+  L.lb_end = take(sizeof(uint64_t) * NS);
+  L.lb_water = take(sizeof(int) * B);
   L.amp = take(sizeof(float) * B * (size_t)y_stride);
   L.votes = take(sizeof(uint64_t) * 2 * B * (size_t)g.vstride);
   L.closed = take(sizeof(uint64_t) * B * (size_t)g.cstride);
@@ -84,6 +87,7 @@ inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geomet
   a.cut = (int *)(base + L.cut); a.cutf = (int *)(base + L.cutf); a.piece = (Ls2Piece *)(base + L.piece);
   a.nextv = (int *)(base + L.nextv); a.prevv = (int *)(base + L.prevv);
   a.upiece = (Ls2Piece *)(base + L.upiece); a.unextv = (int *)(base + L.unextv); a.uprevv = (int *)(base + L.uprevv);
+  a.lb_fn = (uint64_t *)(base + L.lb_fn); a.lb_end = (uint64_t *)(base + L.lb_end); a.lb_water = (int *)(base + L.lb_water);
   a.amp = (float *)(base + L.amp);
   a.lowm = (uint64_t *)(base + L.closed);   // (fused first pass: the blocks' not-carrier masks live there until the state machine runs)
   a.votes = (uint64_t *)(base + L.votes); a.closed = (uint64_t *)(base + L.closed); a.openinfo = (int *)(base + L.openinfo);
@@ -100,9 +104,11 @@ inline int &ls2_chain_slots() { static int v = 2048; return v; }   // slots per 
 // One pass (its first launch zeroes Ls2Ctl, the chain flags, the votes, the window buckets and flat_count).  `a` complete but for
 // `round`.  After it: wtab / wcount / flat lists + Ls2Ctl::ok = 1, or ok = 0 (the caller's fallback scan, enqueued
 // behind with GateArgs::skip_if = &ctl->ok, then runs).
-// mark / mark_arg: optional call-back at two points of the list (0: behind the first avg_ampl re-run round, 1: behind the first
+// mark / mark_arg: optional call-back at points of the list (0: behind the first avg_ampl re-run round, 1: behind the first
 // dc_est pass) -- from there on the launches are small and most of the device idles; the library records events there and
-// lets parts of the NEXT pass's matched filter start behind them
+// lets parts of the NEXT pass's matched filter start behind them; 2 (fused first pass only): behind the launches that touch
+// nothing but the raw samples, y and the pass's own work space -- the library runs those on a second stream, beside the rest
+// of the pass before, and changes streams here
 inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nullptr, bool generous = false, int dc_fine = -1,
                         void (*mark)(void *, int) = nullptr, void *mark_arg = nullptr) {   // (search_cuts = false: a.cut is given -- tests)
   const int NS = a.n_streams * a.max_b, NH = a.n_streams * a.max_bc;   // slots; slots that can be heads
@@ -157,6 +163,7 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
     LS2_LAUNCH(ls2_link_kernel, (NS + 255) / 256, 1, 256, a);
     if (a.max_bc > 1 && search_cuts) LS2_LAUNCH(ls2_idle_cut_kernel, (NH + 255) / 256, 1, 256, a);
     LS2_LAUNCH(ls2_pieces_kernel, (NS + 255) / 256, 1, 256, U(a));
+    if (mark) mark(mark_arg, 2);   // (everything up to here works on the raw samples and this pass's work space only)
   } else {
     LS2_LAUNCH(ls2_pieces_kernel, (NS + 255) / 256, 1, 256, a);
   }

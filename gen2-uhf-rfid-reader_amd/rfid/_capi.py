@@ -115,6 +115,8 @@ SIGNATURES = {
     "rfid_batch_set_streams": (_i, [_vp, _i]),
     "rfid_batch_set_long_stream": (_i, [_vp, _i]),
     "rfid_batch_ls_report": (_i, [_vp, _vp]),
+    "rfid_ctx_set_knob": (_i, [_vp, C.c_char_p, _i]),
+    "rfid_ctx_get_knob": (_i, [_vp, C.c_char_p, _ip]),
     "rfid_batch_mf": (_i, [_vp, _vp, _i64, _i64, _vp]),
     "rfid_batch_gate": (_i, [_vp]),
     "rfid_batch_decode": (_i, [_vp, _i]),

@@ -220,6 +220,16 @@ class Context:
         """0: never cut traces along time, 1: automatic (few long traces), 2: whenever possible."""
         self._chk(self._lib.rfid_batch_set_long_stream(self._h, int(mode)))
 
+    def set_knob(self, name: str, value: int) -> None:
+        """One of the switches the environment sets at context creation, by its lower-case name
+        without the RFID_ prefix: ctx.set_knob("ls_fused", 0)."""
+        self._chk(self._lib.rfid_ctx_set_knob(self._h, name.encode(), int(value)))
+
+    def get_knob(self, name: str) -> int:
+        v = C.c_int(0)
+        self._chk(self._lib.rfid_ctx_get_knob(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
+
     def batch_ls_report(self) -> dict:
         r = capi.LsReport()
         self._chk(self._lib.rfid_batch_ls_report(self._h, C.byref(r)))

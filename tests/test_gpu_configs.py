@@ -87,13 +87,13 @@ def test_config2_full_size_multi_tag_inventory(oracle_mod, synth_mod):
         assert ctx.batch_timing()["fused_front"] == 1 and ctx.batch_ls_report()["pieces"] == 0
         w2, r2, _ = ctx.batch_windows()
         assert w2.tobytes() == w.tobytes() and r2.tobytes() == r.tobytes()
-        os.environ["RFID_FRONT_UNFUSED"] = "1"
+        ctx.set_knob("front_unfused", 1)      # (RFID_FRONT_UNFUSED is read when a context is created; this one lives already)
         try:
             ctx.batch_process_ptr(data.data_ptr(), stride, L, 0, want_scores=False)
             ctx.batch_sync()
             assert ctx.batch_timing()["fused_front"] == 0
         finally:
-            del os.environ["RFID_FRONT_UNFUSED"]
+            ctx.set_knob("front_unfused", 0)
         w3, r3, _ = ctx.batch_windows()
         assert w3.tobytes() == w.tobytes() and r3.tobytes() == r.tobytes()
     finally:

@@ -190,9 +190,11 @@ def test_front_end_time_chunking_matches_single_launch(gpu_ctx, oracle_mod, synt
     streams, gate state carried from chunk to chunk -- identical results."""
     t = synth_mod.make_trace(n_rounds=9, seed=88, sigma=0.02).samples
     raw = np.stack([t, np.roll(t, 7)])
-    monkeypatch.setenv("RFID_FRONT_CHUNKS", "4")
-    w, r, s, st = _run_batch(gpu_ctx, raw)
-    monkeypatch.delenv("RFID_FRONT_CHUNKS")
+    gpu_ctx.set_knob("front_chunks", 4)      # (what RFID_FRONT_CHUNKS=4 sets when a context is created)
+    try:
+        w, r, s, st = _run_batch(gpu_ctx, raw)
+    finally:
+        gpu_ctx.set_knob("front_chunks", 1)
     assert gpu_ctx.batch_timing()["front_chunks"] == 4
     for b, (wb, rb, sb) in enumerate(parity.split_by_stream(w, r, s, 2)):
         parity.compare_trace(wb, rb, sb, st[b], oracle_mod.run_trace(raw[b]))

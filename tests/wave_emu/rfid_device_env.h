@@ -225,6 +225,9 @@ static inline void backoff() { emu::yield(); }
 static inline void load4_i32(const int *p, int &a, int &b, int &c, int &d) { a = p[0]; b = p[1]; c = p[2]; d = p[3]; }
 static inline int atomic_add(int *p, int v) { int o = *p; *p = o + v; return o; }
 static inline int atomic_min(int *p, int v) { int o = *p; if (v < o) *p = v; return o; }
+static inline int atomic_max(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
+static inline uint64_t load_u64_agent(const uint64_t *p) { return *(const volatile uint64_t *)p; }
+static inline void store_u64_agent(uint64_t *p, uint64_t v) { *(volatile uint64_t *)p = v; }
 static inline void publish(int *flag, int v) { *(volatile int *)flag = v; }
 // (the emulator runs the workgroups of a launch one after the other in index order: a flag of a lower block is set by now)
 static inline void await(const int *flag, int v) { if (*(const volatile int *)flag != v) { fprintf(stderr, "[emu] await on a flag that was never published\n"); abort(); } }
