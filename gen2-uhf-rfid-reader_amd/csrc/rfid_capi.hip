@@ -115,6 +115,9 @@ struct rfid_ctx {
     int pend_idx = 0;
     int64_t pend_new = 0;         // its new samples (at offset tail_max)
     int64_t tail_len = 0;         // raw samples held back by the last processed chunk, placed right before tail_max in d_buf[pend_idx / cur]
+                                  // (look-ahead: negative when the exact per-call scan has consumed into the samples behind tail_max)
+    int64_t acc_new = 0;          // (look-ahead) samples uploaded behind tail_max of d_buf[cur] by the calls since the last pass was submitted
+    hipEvent_t ev_hist = nullptr; // (look-ahead) the filter history in front of the other buffer's upload area is in place
     int64_t raw_base = 0;         // global raw index of the first held-back sample (multiple of 5)
     std::vector<rfid_stream_window> out_w;   // windows completed but not yet delivered (caller arrays too small)
     std::vector<rfid_decode_result> out_r;
@@ -184,6 +187,12 @@ struct rfid_ctx {
     int emitted = 0;                  // samples of wins.front() already handed out (gate open)
     std::deque<Win> dq;               // windows handed out by the gate, waiting for the decoder (results only)
     int stall = 0;                    // gate calls in a row without progress and without new input
+    int64_t coalesce = 65536;         // decimated samples that gather before a pass is submitted (rfid_lookahead_set_coalesce)
+    bool patient = true;              // a gate call that can decide nothing answers (0, 0) once per arrival of new samples (the scheduler's
+                                      // queues grow as needed); false: it decides at once (bounded buffers, rfid_lookahead_set_scheduler)
+    bool tail_tried = false;          // a pass has gone over everything the device holds since the last new sample (and left the rest)
+    bool exact_open = false;          // the exact per-call scan (la_exact_step) has left a window open: it goes on until the window closes
+    DevBuf d_ycall;                   // the filter outputs of one rfid_mf_work call (device)
     bool soft_done = false;           // ... and the held-back samples went through the sequential scan since the last input
     std::vector<float> last_m2;       // |.|^2 of what the last gate call wrote
     // scratch of one whole-chain pass
@@ -2072,6 +2081,9 @@ void sio_free(rfid_ctx *c) {
   io.copy_stream = nullptr;
   if (io.ev_y) (void)hipEventDestroy(io.ev_y);
   io.ev_y = nullptr;
+  if (io.ev_hist) (void)hipEventDestroy(io.ev_hist);
+  io.ev_hist = nullptr;
+  io.acc_new = 0;
   io.pass.active = false;
   io.open = false;
   io.failed = false;
@@ -2421,14 +2433,15 @@ int sio_begin(rfid_ctx *c, int64_t max_chunk_raw, bool ymode) {
     if (hipMemsetAsync(io.d_buf[i], 0, sizeof(float2) * (size_t)io.tail_max, c->stream) != hipSuccess) { sio_free(c); return RFID_ERR_HIP; }
   }
   if (hipStreamCreateWithFlags(&io.copy_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&io.ev_y, hipEventDisableTiming) != hipSuccess) { sio_free(c); return RFID_ERR_HIP; }
+      hipEventCreateWithFlags(&io.ev_y, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&io.ev_hist, hipEventDisableTiming) != hipSuccess) { sio_free(c); return RFID_ERR_HIP; }
   // fresh blocks: gate_impl ctor state (zeros), READER_STATE after START -> SEND_QUERY (reader_impl.cc:218-288)
   init_reader_state(c);
   c->rs.n_queries_sent = 1;
   c->rs.gen2_logic_status = RFID_IDLE;
   HIPCHK(c, hipMemsetAsync(c->d_gstate, 0, sizeof(GateState), c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  io.cur = 0; io.pending = false; io.pend_new = 0; io.tail_len = 0; io.raw_base = 0;
+  io.cur = 0; io.pending = false; io.pend_new = 0; io.tail_len = 0; io.raw_base = 0; io.acc_new = 0;
   io.out_w.clear(); io.out_r.clear();
   io.open = true;
   return RFID_OK;
@@ -2529,15 +2542,80 @@ void la_free(rfid_ctx *c) {
   if (la.h_pack) (void)hipHostFree(la.h_pack);
   if (la.h_y) (void)hipHostFree(la.h_y);
   if (la.d_pack.p) (void)hipFree(la.d_pack.p);
+  if (la.d_ycall.p) (void)hipFree(la.d_ycall.p);
   la.wins.clear(); la.dq.clear();   // (their blocks go back to the pool, which is emptied next)
   for (rfid_ctx::LookAhead::Blk *b : la.pool) delete b;
   la.pool.clear();
   la = rfid_ctx::LookAhead();
 }
 
+// ---- round 5: the calls gather, the passes are big ---------------------------------------------------------------------
+// Until round 4 every rfid_mf_work (gate-keyed: rfid_gate_work) call ran a whole-chain pass over its own buffer: at GNU
+// Radio's default of 8 192 items per buffer that is a launch list and a packet fetch per 20 ms of signal -- 167 Msamples/s,
+// a third of one CPU core.  Now a call only UPLOADS its new samples behind what the device already holds (and, keyed on
+// the filter, filters them: its outputs are what the call returns) on the copy stream; a pass over everything pending
+// is submitted once LookAhead::coalesce decimated samples have gathered (65 536 unless the adaptor knows the scheduler's
+// buffers to be smaller, rfid_lookahead_set_coalesce), and runs on the main stream while the next calls upload into the
+// other buffer.  The gate's answers come from the passes as before; what changes is when a gate call that can decide
+// nothing makes the device decide: at once when it is shown 2 x coalesce items or more (a bounded buffer must drain),
+// and at the latest when it is asked a second time without anything new having arrived (the input has paused, or
+// ended: a scheduler calls a block again when its upstream neighbour is done) -- then the pending pass is collected,
+// a pass goes over what is still pending, and what even that leaves undecided (the stretch behind the last idle cut)
+// goes through the EXACT per-call scan (la_exact_step: the streaming form of gate_scan_kernel, the reference's loop sample
+// by sample from the carried state).  So a gate call returns (0, 0) at most once per arrival of new samples, every
+// sample is consumed whether or not anybody calls rfid_lookahead_flush, and the end of the input needs no announcement.
+
+// uploads n new stream samples (raw ones, or filter outputs when keyed on the gate) behind what is pending in d_buf[cur]
+int la_submit_pending(rfid_ctx *c);
+int la_append(rfid_ctx *c, const rfid_cf32 *src, int64_t n) {
+  rfid_ctx::StreamIO &io = c->sio;
+  if (io.acc_new + n > io.max_chunk) {   // no room behind what is pending: that goes into a pass first
+    const int rc = la_submit_pending(c);
+    if (rc) return rc;
+  }
+  const int up = io.cur;
+  if (io.acc_new == 0) {
+    HIPCHK(c, hipEventSynchronize(io.ev_free[up]));                       // the pass that last ran on this buffer has been collected
+    HIPCHK(c, hipStreamWaitEvent(io.copy_stream, io.ev_hist, 0));         // ... and the history in front of its upload area is in place
+  }
+  bool pinned = false;   // page-locked memory of the caller's (rfid_host_alloc, hipHostMalloc / hipHostRegister)?  then no staging copy
+  {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, src) == hipSuccess) pinned = (attr.type == hipMemoryTypeHost);
+    else (void)hipGetLastError();
+  }
+  if (!pinned) { memcpy(io.h_pin[up] + io.acc_new, src, sizeof(rfid_cf32) * (size_t)n); src = io.h_pin[up] + io.acc_new; }
+  HIPCHK(c, hipMemcpyAsync(io.d_buf[up] + io.tail_max + io.acc_new, src, sizeof(rfid_cf32) * (size_t)n, hipMemcpyHostToDevice, io.copy_stream));
+  HIPCHK(c, hipEventRecord(io.ev_up[up], io.copy_stream));
+  io.acc_new += n;
+  return RFID_OK;
+}
+// a pass over everything the device holds and has not decided: the held-back stretch + what the calls have uploaded since
+int la_submit_pending(rfid_ctx *c) {
+  rfid_ctx::StreamIO &io = c->sio;
+  if (io.pass.active) {                     // (its held-back stretch is what this pass starts with)
+    const int rc = sio_collect(c);
+    if (rc) { io.failed = true; return rc; }
+  }
+  const int up = io.cur;
+  if (io.acc_new > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, io.ev_up[up], 0));
+  // the filter history of the calls that follow goes in front of the other buffer's upload area right away (sio_collect
+  // copies the held-back stretch there later: the same samples), so that they need not wait for this pass
+  if (io.hist() > 0)
+    HIPCHK(c, hipMemcpyAsync(io.d_buf[up ^ 1] + (io.tail_max - io.hist()), io.d_buf[up] + (io.tail_max + io.acc_new - io.hist()),
+                             sizeof(float2) * (size_t)io.hist(), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(io.ev_hist, c->stream));
+  c->la.want_yn = 0;
+  const int rc = sio_submit(c, up, io.acc_new, false);
+  if (rc) { io.failed = true; return rc; }
+  io.acc_new = 0;
+  io.cur ^= 1;
+  return RFID_OK;
+}
+
 bool same_sample(const rfid_cf32 &a, const rfid_cf32 &b) { return memcmp(&a, &b, sizeof(a)) == 0; }
 
-// rfid_mf_work with the look-ahead on: the whole chain over what is held back + the new samples, in one submission
+// rfid_mf_work with the look-ahead on: the call's samples go to the device, its filter outputs come back
 int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap, int *n_produced) {
   LaTimer tm(0);
   rfid_ctx::StreamIO &io = c->sio;
@@ -2547,50 +2625,127 @@ int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int o
   const int64_t n_first = c->mf_seen / DECIM;
   const int n_out = (int)((c->mf_seen + n_in) / DECIM - n_first);
   if (n_out > out_cap || (n_out > 0 && !out)) return RFID_ERR_CAPACITY;
-  // the pass the previous call left on the device is over by now (the scheduler handed out a call's worth of windows
-  // meanwhile): its windows, and how far the gate's doing is known
-  if (io.pass.active) {
-    const double t_c0 = la_now();
-    const int rc = sio_collect(c);
-    g_la_t[6] += la_now() - t_c0; g_la_n[6]++;
-    if (rc) { io.failed = true; return rc; }
-  }
-  const int up = io.cur;
-  HIPCHK(c, hipEventSynchronize(io.ev_free[up]));   // (the call before last, processed long ago)
-  const rfid_cf32 *src = in;
-  bool pinned = false;   // page-locked memory of the caller's (rfid_host_alloc, hipHostMalloc / hipHostRegister)?  then no staging copy
-  {
-    hipPointerAttribute_t attr;
-    if (hipPointerGetAttributes(&attr, in) == hipSuccess) pinned = (attr.type == hipMemoryTypeHost);
-    else (void)hipGetLastError();
-  }
-  if (!pinned) { memcpy(io.h_pin[up], in, sizeof(rfid_cf32) * (size_t)n_in); src = io.h_pin[up]; }
-  HIPCHK(c, hipMemcpyAsync(io.d_buf[up] + io.tail_max, src, sizeof(rfid_cf32) * (size_t)n_in, hipMemcpyHostToDevice, c->stream));
-  io.cur ^= 1;
-  la.want_y0 = n_first; la.want_yn = n_out;
-  g_la_t[4] += la_now() - tm.t0; g_la_n[4]++;   // (upload queued)
-  const double t_sp = la_now();
-  const int rc = sio_submit(c, up, n_in, false);
-  g_la_t[5] += la_now() - t_sp; g_la_n[5]++;
-  la.want_yn = 0;
+  int rc = la_append(c, in, n_in);
   if (rc) { io.failed = true; return rc; }
-  {
-    const double t_y0 = la_now();
-    HIPCHK(c, hipEventSynchronize(io.ev_y));        // the filter outputs of this call (the rest of the pass runs on)
-    g_la_t[8] += la_now() - t_y0; g_la_n[8]++;
-  }
+  g_la_t[4] += la_now() - tm.t0; g_la_n[4]++;   // (upload queued)
   if (n_out > 0) {
+    // y[n] = sum x[5n - 24 .. 5n] for this call's outputs: the matched filter over the new samples, whose history lies in
+    // front of them in the buffer, on the copy stream (the pass before may still be at work on the main stream)
+    const double t_sp = la_now();
+    if ((rc = grow(c, la.d_ycall, sizeof(float2) * (size_t)(n_out + 2)))) return rc;
+    if ((size_t)n_out > la.h_ycap) {
+      if (la.h_y) (void)hipHostFree(la.h_y);
+      la.h_y = nullptr; la.h_ycap = 0;
+      HIPCHK(c, hipHostMalloc((void **)&la.h_y, sizeof(rfid_cf32) * (size_t)n_out * 2, hipHostMallocDefault));
+      la.h_ycap = (size_t)n_out * 2;
+    }
+    MfArgs a;
+    a.x = io.d_buf[io.cur] + io.tail_max + (io.acc_new - n_in) - SIO_HIST;     // (raw sample mf_seen - 28)
+    a.x_stride = SIO_HIST + n_in; a.n_raw = SIO_HIST + n_in; a.lens = nullptr;
+    a.n_out = n_out; a.in_off = (int)(DECIM * n_first - c->mf_seen) + SIO_HIST - (NTAPS - 1);   // 0 .. 4
+    a.vec_ok = ((((uintptr_t)a.x) & 15) == 0 && (a.in_off % 2) == 0) ? 1 : 0;
+    a.y = (float2 *)la.d_ycall.p; a.y_stride = n_out; a.tile0 = 0; a.stream0 = 0;
+    const int tiles = (n_out + MF_TILE - 1) / MF_TILE;
+    hipLaunchKernelGGL(mf_boxcar25_decim5_kernel, dim3((unsigned)tiles, 1), dim3(MF_THREADS), 0, io.copy_stream, a);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(la.h_y, la.d_ycall.p, sizeof(rfid_cf32) * (size_t)n_out, hipMemcpyDeviceToHost, io.copy_stream));
+    HIPCHK(c, hipEventRecord(io.ev_y, io.copy_stream));
+    g_la_t[5] += la_now() - t_sp; g_la_n[5]++;
+    const double t_y0 = la_now();
+    HIPCHK(c, hipEventSynchronize(io.ev_y));
+    g_la_t[8] += la_now() - t_y0; g_la_n[8]++;
     memcpy(out, la.h_y, sizeof(rfid_cf32) * (size_t)n_out);
     la.y_push(n_first, la.h_y, (size_t)n_out);
   }
   c->mf_seen += n_in;
   la.stall = 0;
-  la.soft_done = false;
+  la.tail_tried = false;
+  if (!la.exact_open && io.acc_new / DECIM >= la.coalesce) {
+    const double t_c0 = la_now();
+    rc = la_submit_pending(c);
+    g_la_t[6] += la_now() - t_c0; g_la_n[6]++;
+    if (rc) return rc;
+  }
   *n_produced = n_out;
   return RFID_OK;
 }
 
-// rfid_gate_work with the look-ahead on (gate_impl.cc:127-199 answered from the windows the whole-chain pass found)
+// The exact per-call scan over what the device holds undecided (the held-back stretch and what has been uploaded behind
+// it), at most the n_in samples the gate was shown: gate_scan_kernel in its streaming form from the carried gate state --
+// gate_impl.cc:127-196 sample by sample, stopping behind a window that closes (:189-194) -- the gated samples fetched, the
+// stream's base moved behind what was consumed.  This is what rfid_gate_work does without the look-ahead, on the
+// look-ahead's buffers and state.
+int la_exact_step(rfid_ctx *c, int n_in, rfid_cf32 *out, int *consumed, int *written, bool *open_after) {
+  rfid_ctx::StreamIO &io = c->sio;
+  rfid_ctx::LookAhead &la = c->la;
+  rfid_reader_state &rs = c->rs;
+  *consumed = 0; *written = 0; *open_after = false;
+  const int b = io.cur;
+  if (io.acc_new > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, io.ev_up[b], 0));
+  // The carried state stands at the passes' frontier.  The gate itself may be further on: a pass that stopped inside a window
+  // (the sequential scan goes up to one EPC window before the end of what it has; a window that opens before that point is
+  // complete and on record) has left the gate OPEN there, and the gate call that handed the window out has consumed up to its
+  // end.  Those samples are scanned first with their output thrown away: the window runs out exactly at the gate's position.
+  const int64_t skip = la.gate_pos - io.raw_base / io.dec();
+  if (skip < 0) return fail(c, RFID_ERR_STATE, "look-ahead: the gate is behind what the passes have decided");
+  const int64_t n_avail = (io.tail_len + io.acc_new) / io.dec() - skip;
+  const int n_use = (int)((n_avail < n_in) ? n_avail : n_in);
+  if (n_use <= 0) return RFID_OK;
+  const int n_scan = (int)skip + n_use;
+  float2 *data = io.d_buf[b] + (io.tail_max - io.tail_len);
+  const float2 *ysrc = data;
+  if (!io.ymode) {
+    MfArgs m;
+    m.x = data - SIO_HIST; m.x_stride = SIO_HIST + (int64_t)DECIM * n_scan; m.n_raw = m.x_stride; m.lens = nullptr;
+    m.n_out = n_scan; m.in_off = SIO_HIST - (NTAPS - 1);
+    m.vec_ok = ((((uintptr_t)m.x) & 15) == 0) ? 1 : 0;
+    m.y = c->d_y; m.y_stride = c->y_stride; m.tile0 = 0; m.stream0 = 0;
+    hipLaunchKernelGGL(mf_boxcar25_decim5_kernel, dim3((unsigned)((n_scan + MF_TILE - 1) / MF_TILE), 1), dim3(MF_THREADS), 0, c->stream, m);
+    HIPCHK(c, hipGetLastError());
+    ysrc = c->d_y;
+  }
+  int rc = grow(c, c->s_out, sizeof(float2) * (size_t)(n_scan + 2));
+  if (rc) return rc;
+  GateArgs a = {};
+  a.lens = nullptr; a.pos0 = 0; a.state = c->d_gstate; a.n_streams = 1; a.mode = 1;
+  a.gated = (float2 *)c->s_out.p; a.gated_cap = n_scan; a.io = c->d_io;
+  int iov[2] = {0, 0}, open_now = 0;
+  if (skip > 0) {
+    a.y = ysrc; a.y_stride = skip; a.n_dec = skip; a.chunk_len = skip;
+    hipLaunchKernelGGL(gate_scan_kernel, dim3(1), dim3(GATE_THREADS), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(iov, c->d_io, sizeof(iov), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&open_now, &c->d_gstate->gate_open, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (iov[0] != (int)skip || open_now) return fail(c, RFID_ERR_STATE, "look-ahead: the window the passes left open does not end where the gate stands");
+    // (the decoder and the reader have run since that window was handed out: the gate is armed for what they ask for now)
+    hipLaunchKernelGGL(gate_arm_kernel, dim3(1), dim3(64), 0, c->stream, c->d_gstate, rs.n_samples_to_ungate, (rs.n_samples_to_ungate == EPC_WIN) ? 1 : 0);
+    HIPCHK(c, hipGetLastError());
+    io.raw_base += (int64_t)io.dec() * skip;
+    io.tail_len -= (int64_t)io.dec() * skip;
+  }
+  a.y = ysrc + skip; a.y_stride = n_use; a.n_dec = n_use; a.chunk_len = n_use;
+  hipLaunchKernelGGL(gate_scan_kernel, dim3(1), dim3(GATE_THREADS), 0, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(iov, c->d_io, sizeof(iov), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&open_now, &c->d_gstate->gate_open, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (iov[1] > 0) HIPCHK(c, hipMemcpy(out, c->s_out.p, sizeof(rfid_cf32) * (size_t)iov[1], hipMemcpyDeviceToHost));
+  if (iov[1] > 0 && !open_now) {
+    // a window has closed: the decoder and the reader run next and arm the gate for the other kind (gate_impl.cc:112-123:
+    // n_samples = 0, the window's length) -- here at once, as the batch form of the scan does at the window's last sample
+    const int next_type = (rs.n_samples_to_ungate == EPC_WIN) ? 0 : 1;
+    hipLaunchKernelGGL(gate_arm_kernel, dim3(1), dim3(64), 0, c->stream, c->d_gstate, next_type ? EPC_WIN : RN16_WIN, next_type);
+    HIPCHK(c, hipGetLastError());
+  }
+  io.raw_base += (int64_t)io.dec() * iov[0];
+  io.tail_len -= (int64_t)io.dec() * iov[0];      // (may go below zero: into the samples behind tail_max)
+  la.exact_open = open_now != 0;
+  *consumed = iov[0]; *written = iov[1]; *open_after = open_now != 0;
+  return RFID_OK;
+}
+
+// rfid_gate_work with the look-ahead on (gate_impl.cc:127-199 answered from the windows the whole-chain passes found)
 int la_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap, int *n_consumed, int *n_written) {
   LaTimer tm(1);
   (void)out_cap;
@@ -2607,37 +2762,20 @@ int la_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int
       return fail(c, RFID_ERR_STATE, "look-ahead: rfid_gate_work was not handed the matched filter's output at the gate's position");
   } else if (p + n_in > la.up_end) {
     // gate-keyed: the filter is somebody else's; whatever of this call's input the device has not seen yet (the scheduler
-    // shows unconsumed samples again, the new ones come behind them) is uploaded and goes through gate -> tag_decoder in
-    // one submission -- at most max_chunk samples per call, the rest when it is shown again
+    // shows unconsumed samples again, the new ones come behind them) is uploaded -- at most max_chunk samples per call,
+    // the rest when it is shown again
     if (!io.open || io.failed || la.flushed) return fail(c, RFID_ERR_STATE, "look-ahead: the stream has ended (rfid_ctx_reset starts a new one)");
     if (la.up_end < p) return fail(c, RFID_ERR_STATE, "look-ahead: the gate's input skipped samples");
     int64_t n_new = p + n_in - la.up_end;
     if (n_new > io.max_chunk) n_new = io.max_chunk;
-    const rfid_cf32 *fresh = in + (la.up_end - p);
-    if (io.pass.active) {                     // the pass of the call before: over by now
-      const int rc = sio_collect(c);
-      if (rc) { io.failed = true; return rc; }
-    }
-    const int up = io.cur;
-    HIPCHK(c, hipEventSynchronize(io.ev_free[up]));
-    const rfid_cf32 *src = fresh;
-    bool pinned = false;
-    {
-      hipPointerAttribute_t attr;
-      if (hipPointerGetAttributes(&attr, fresh) == hipSuccess) pinned = (attr.type == hipMemoryTypeHost);
-      else (void)hipGetLastError();
-    }
-    if (!pinned) { memcpy(io.h_pin[up], fresh, sizeof(rfid_cf32) * (size_t)n_new); src = io.h_pin[up]; }
-    HIPCHK(c, hipMemcpyAsync(io.d_buf[up] + io.tail_max, src, sizeof(rfid_cf32) * (size_t)n_new, hipMemcpyHostToDevice, c->stream));
-    io.cur ^= 1;
-    la.want_yn = 0;
-    const int rc = sio_submit(c, up, n_new, false);
+    int rc = la_append(c, in + (la.up_end - p), n_new);
     if (rc) { io.failed = true; return rc; }
     la.up_end += n_new;
     la.stall = 0;
-    la.soft_done = false;
+    la.tail_tried = false;
+    if (!la.exact_open && io.acc_new >= la.coalesce && (rc = la_submit_pending(c))) return rc;
   }
-  for (int attempt = 0; attempt < 4; ++attempt) {
+  for (int attempt = 0; attempt < 8; ++attempt) {
     const int64_t frontier = io.raw_base / io.dec();   // the gate's doing is known for the samples before this position
     int consumed = 0, written = 0;
     bool open_after = false;
@@ -2662,49 +2800,43 @@ int la_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int
         consumed = n_in;
         open_after = true;
       }
-    } else {
+    } else if (!la.exact_open) {
       // no opening in [p, p + n_in) as far as the gate's doing is known
       const int64_t lim = (p + n_in < frontier) ? (p + n_in) : frontier;
       consumed = (lim > p) ? (int)(lim - p) : 0;
     }
     if (consumed == 0 && written == 0 && !la.flushed) {
-      // nothing can be decided before more samples arrive.  A scheduler may well ask again without bringing any (GNU
-      // Radio wakes a block when its downstream neighbour has consumed, or on a timer): asking never ends the stream.
-      ++la.stall;
-      if (la.stall >= 2 && io.pass.active) {
-        // the last rfid_mf_work call's pass has not been looked at: the scheduler came back here instead of bringing
-        // more input
+      // Nothing can be decided from what the passes have found so far.  The first such answer since new samples arrived is
+      // (0, 0): the scheduler brings more (and the pass that is under way goes on undisturbed).  Asked again without
+      // anything new -- the input has paused or ended -- or shown as much as a bounded buffer can hold, the device decides
+      // now: the pass under way is waited for, then a pass goes over whatever is pending, then the exact scan takes the rest.
+      if (attempt == 0) ++la.stall;
+      // (a pass that has finished meanwhile is looked at whoever asks: its windows are what the gate hands out next)
+      if (!la.exact_open && io.pass.active && hipStreamQuery(c->stream) == hipSuccess) {
         const int rc = sio_collect(c);
         if (rc) { io.failed = true; return rc; }
         continue;
       }
-      if (la.stall >= 3 && !la.soft_done && io.tail_len / io.dec() > 2 * (int64_t)EPC_WIN) {
-        // the input has paused: what is held back behind the last idle cut goes through the sequential scan, up to
-        // one EPC window before its end (a window that opens there is complete, rfid_stream_work's rule); the
-        // stream goes on from the carried state when input comes.  Once per pause.
-        la.soft_done = true;
-        la.want_yn = 0;
-        const int rc = sio_process(c, io.cur, 0, false);
+      (void)hipGetLastError();   // (hipErrorNotReady is no error)
+      const bool force = !la.patient || la.stall >= 2 || la.flush_req || n_in >= 2 * la.coalesce || la.exact_open;
+      if (!force) break;
+      if (!la.exact_open && io.pass.active) {
+        const int rc = sio_collect(c);
         if (rc) { io.failed = true; return rc; }
-        io.cur ^= 1;   // (what is still held back now sits in front of the other buffer's upload area)
         continue;
       }
-      if (la.flush_req && la.stall >= 3 && p + n_in <= la.up_end) {
-        // gate-keyed, the end of the input was announced, and the scheduler keeps showing nothing the device has not seen:
-        // now everything held back is decided (rfid_stream_work's flush)
-        int rc = sio_collect(c);
-        if (!rc && io.tail_len > 0) {
-          la.want_yn = 0;
-          rc = sio_process(c, io.cur, 0, true);
-        }
+      if (!la.exact_open && (io.acc_new > 0 || (!la.tail_tried && io.tail_len / io.dec() > 0))) {
+        la.tail_tried = true;
+        int rc = la_submit_pending(c);
+        if (!rc) rc = sio_collect(c);
         if (rc) { io.failed = true; return rc; }
-        la.flushed = true;
-        la.stall = 0;
         continue;
       }
-      break;
+      const int rc = la_exact_step(c, n_in, out, &consumed, &written, &open_after);
+      if (rc) { io.failed = true; return rc; }
+      if (consumed == 0 && written == 0) break;
     }
-    if (consumed > 0 || written > 0) la.stall = 0;
+    la.stall = 0;
     // keep the state the window's last sample leaves: the dc ring etc. live on the device; here only what the blocks share
     rs.gate_status = open_after ? RFID_GATE_OPEN : RFID_GATE_CLOSED;
     la.gate_pos += consumed;
@@ -2744,14 +2876,17 @@ int rfid_lookahead_flush(rfid_ctx *c) {
   rfid_ctx::LookAhead &la = c->la;
   if (!la.on || la.flushed) return RFID_OK;   // (without look-ahead nothing is held back)
   if (!io.open || io.failed) return fail(c, RFID_ERR_STATE, "rfid_lookahead_flush: the stream has failed or was closed");
-  if (io.ymode) {
-    // keyed on the gate: the library has seen only what the gate was shown; the flush is carried out once gate calls keep
-    // showing nothing new and can decide nothing (a scheduler shows a block everything its buffer holds)
+  if (io.ymode || la.exact_open) {
+    // keyed on the gate: the library has seen only what the gate was shown; the next gate call that brings nothing new and
+    // can decide nothing makes the device decide everything it holds (a scheduler shows a block everything its buffer
+    // holds).  (Since round 5 such a call does that anyway the second time it is asked: the announcement saves one call.)
     la.flush_req = true;
     return RFID_OK;
   }
   HIPCHK(c, hipSetDevice(c->device));
-  int rc = sio_collect(c);
+  int rc = RFID_OK;
+  if (io.acc_new > 0) rc = la_submit_pending(c);
+  if (!rc) rc = sio_collect(c);
   if (!rc && io.tail_len > 0) {
     la.want_yn = 0;
     rc = sio_process(c, io.cur, 0, true);   // rfid_stream_work's flush: everything available is decided now
@@ -2762,19 +2897,22 @@ int rfid_lookahead_flush(rfid_ctx *c) {
   return RFID_OK;
 }
 
+// room for what gathers before a pass (LookAhead::coalesce) and the largest call behind it
+static const int64_t LA_COALESCE_DEFAULT = 65536, LA_CALL_ROOM = 16384;
+
 int rfid_lookahead_enable(rfid_ctx *c, int64_t max_chunk_raw) {
   LaTimer tm(9);
   if (!c || max_chunk_raw < 1) return RFID_ERR_INVALID;
   if (c->mf_seen != 0) return fail(c, RFID_ERR_STATE, "rfid_lookahead_enable: the stream has started");
   la_free(c);
-  int64_t cap = max_chunk_raw;
-  if (cap < 5 * 4 * (int64_t)LS2_FINE * LS2_MIN_PIECE) cap = 5 * 4 * (int64_t)LS2_FINE * LS2_MIN_PIECE;
+  int64_t cap = max_chunk_raw + DECIM * LA_COALESCE_DEFAULT;
+  if (cap < DECIM * (LA_COALESCE_DEFAULT + LA_CALL_ROOM)) cap = DECIM * (LA_COALESCE_DEFAULT + LA_CALL_ROOM);
   const rfid_reader_state keep = c->rs;            // rfid_stream_begin sets the whole-chain form's READER_STATE; these calls keep theirs
   int rc = rfid_stream_begin(c, cap);
   c->rs = keep;
   if (rc) return rc;
-  c->sio.max_chunk = (max_chunk_raw < cap) ? cap : max_chunk_raw;
   c->la.on = true;
+  c->la.coalesce = LA_COALESCE_DEFAULT;
   return RFID_OK;
 }
 
@@ -2783,13 +2921,58 @@ int rfid_lookahead_enable_gate(rfid_ctx *c, int64_t max_items) {
   if (!c || max_items < 1) return RFID_ERR_INVALID;
   if (c->mf_seen != 0 || c->la.gate_pos != 0) return fail(c, RFID_ERR_STATE, "rfid_lookahead_enable_gate: the stream has started");
   la_free(c);
-  int64_t cap = max_items;
-  if (cap < 4 * (int64_t)LS2_FINE * LS2_MIN_PIECE) cap = 4 * (int64_t)LS2_FINE * LS2_MIN_PIECE;
+  int64_t cap = max_items + LA_COALESCE_DEFAULT;
+  if (cap < LA_COALESCE_DEFAULT + LA_CALL_ROOM) cap = LA_COALESCE_DEFAULT + LA_CALL_ROOM;
   const rfid_reader_state keep = c->rs;
   int rc = sio_begin(c, cap, true);
   c->rs = keep;
   if (rc) return rc;
   c->la.on = true;
+  c->la.coalesce = LA_COALESCE_DEFAULT;
+  return RFID_OK;
+}
+
+int rfid_lookahead_drain(rfid_ctx *c) {
+  if (!c) return RFID_ERR_INVALID;
+  rfid_ctx::StreamIO &io = c->sio;
+  rfid_ctx::LookAhead &la = c->la;
+  if (!la.on) return RFID_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = RFID_OK;
+  if (io.open && !io.failed && !la.flushed) {
+    // everything the device holds is decided as at the end of a stream (a window the exact scan has left open is incomplete:
+    // it never reaches the decoder, tag_decoder_impl.cc:223,291)
+    if (io.acc_new > 0) rc = la_submit_pending(c);
+    if (!rc) rc = sio_collect(c);
+    if (!rc && !la.exact_open && io.tail_len > 0) {
+      la.want_yn = 0;
+      rc = sio_process(c, io.cur, 0, true);
+    }
+    if (rc) { io.failed = true; return rc; }
+  }
+  // the windows no call will fetch any more: READER_STATE as the decoder / reader calls would have left it
+  for (const rfid_ctx::LookAhead::Win &w : la.dq) if (!sio_account(c, w.res)) break;
+  for (const rfid_ctx::LookAhead::Win &w : la.wins) if (!sio_account(c, w.res)) break;
+  la.dq.clear(); la.wins.clear(); la.emitted = 0;
+  la.flushed = true;
+  return RFID_OK;
+}
+
+int rfid_lookahead_set_scheduler(rfid_ctx *c, int64_t gate_buffer_items) {
+  if (!c || gate_buffer_items < 0) return RFID_ERR_INVALID;
+  if (!c->la.on) return fail(c, RFID_ERR_STATE, "rfid_lookahead_set_scheduler: the look-ahead is not on");
+  if (gate_buffer_items == 0) { c->la.patient = true; c->la.coalesce = LA_COALESCE_DEFAULT; return RFID_OK; }
+  c->la.patient = false;
+  return rfid_lookahead_set_coalesce(c, gate_buffer_items / 4);
+}
+
+int rfid_lookahead_set_coalesce(rfid_ctx *c, int64_t items) {
+  if (!c || items < 1) return RFID_ERR_INVALID;
+  if (!c->la.on) return fail(c, RFID_ERR_STATE, "rfid_lookahead_set_coalesce: the look-ahead is not on");
+  const int64_t most = c->sio.max_chunk / c->sio.dec() / 2;
+  if (items < 1024) items = 1024;
+  if (items > most) items = most;
+  c->la.coalesce = items;
   return RFID_OK;
 }
 

@@ -76,6 +76,37 @@ class RFID_BLOCK_API sts_flowgraph {
   std::vector<float> d_tx, d_txbuf, d_bits;
   std::vector<gr_complex> d_tap_mf, d_tap_gate;
 };
+
+// The same flowgraph under GNU Radio's scheduling RULES (gnuradio-runtime/lib/block_executor.cc), one thread, blocks in turn:
+// buffers between the blocks hold `buffer_items` items and no more; a block is called with what its input buffer holds and
+// the room its output buffer has, noutput_items halved while forecast() asks for more input than there is; a block that
+// neither consumed nor produced is not called again before new input has arrived or its upstream neighbour is done;
+// a block whose neighbour is done and which can do nothing more is done itself; when all are, stop() is called on
+// every block -- nobody tells anybody that the input has ended.  (What a real runtime does with the reference's blocks
+// and apps/reader.py:120-131; used by the tests for the end of the input and small buffers.)
+class RFID_BLOCK_API bounded_flowgraph {
+ public:
+  bounded_flowgraph(matched_filter::sptr mf, gate::sptr g, tag_decoder::sptr d, reader::sptr r, int buffer_items = 8192);
+  void run(const gr_complex *samples, size_t n);
+  long windows_decoded() const { return d_windows; }
+  bool stalled() const { return d_deadlock; }            // the flowgraph stopped with input left and nobody able to move
+  void keep_tx(bool on) { d_keep_tx = on; }
+  const std::vector<float> &tx_samples() const { return d_tx; }
+  void keep_taps(bool on) { d_keep_taps = on; }
+  const std::vector<gr_complex> &tap_matched_filter() const { return d_tap_mf; }
+  const std::vector<gr_complex> &tap_gate() const { return d_tap_gate; }
+
+ private:
+  matched_filter::sptr d_mf;
+  gate::sptr d_gate;
+  tag_decoder::sptr d_dec;
+  reader::sptr d_reader;
+  int d_cap;
+  long d_windows = 0;
+  bool d_deadlock = false, d_keep_tx = false, d_keep_taps = false;
+  std::vector<float> d_tx;
+  std::vector<gr_complex> d_tap_mf, d_tap_gate;
+};
 #endif
 
 }  // namespace mi355x

@@ -64,6 +64,20 @@ thread_local stream_sptr g_current;
 // (weak: a filter that dies before its gate appears -- on whatever thread -- simply drops out)
 thread_local std::vector<std::weak_ptr<stream_sptr>> g_pending_filters;
 
+// items the scheduler's buffer on a block's input / output side holds (0: unknown or not bounded)
+#ifdef GR_RFID_MINIRT
+int input_buffer_items(gr::block *b) { return b->minirt_input_capacity(); }
+int output_buffer_items(gr::block *b) { return b->minirt_output_capacity(); }
+#else
+int input_buffer_items(gr::block *b) { return b->detail() ? b->detail()->input(0)->max_possible_items_available() : 0; }
+int output_buffer_items(gr::block *b) { return b->detail() ? b->detail()->output(0)->bufsize() : 0; }
+#endif
+// The look-ahead lets 65 536 decimated samples gather before a pass is submitted; a gate that can never be shown that
+// many (its input buffer holds C items) is told C / 4: a gate call shown half its buffer decides at once, the pipeline drains
+void tell_buffers(rfid_ctx *ctx, int gate_input_items) {
+  if (gate_input_items > 0) (void)rfid_lookahead_set_scheduler(ctx, gate_input_items);
+}
+
 int env_int(const char *name, int dflt) {
   const char *e = getenv(name);
   return (e && *e) ? atoi(e) : dflt;
@@ -116,8 +130,10 @@ class gate_impl : public gate {
       d_started = true;
       // no matched_filter block of this library feeds this gate (it would have switched the look-ahead on itself): the
       // filter is somebody else's, the look-ahead is keyed on the gate's input
-      if (!d_stream->has_filter && env_int("RFID_LOOKAHEAD", 1) != 0)
+      if (!d_stream->has_filter && env_int("RFID_LOOKAHEAD", 1) != 0) {
         d_stream->check(rfid_lookahead_enable_gate(d_stream->ctx, std::max(n_items, 16384)), "rfid_lookahead_enable_gate");
+        tell_buffers(d_stream->ctx, input_buffer_items(this));
+      }
     }
     const GATE_STATUS before = d_stream->mirror.gate_status;
     int consumed = 0, written = 0;
@@ -140,6 +156,19 @@ class gate_impl : public gate {
     }
     consume_each(consumed);   // lib/gate_impl.cc:198
     return written;           // :199
+  }
+  // The flowgraph has stopped (apps/reader.py:131).  Under a scheduler that went on calling the blocks until none could
+  // move there is nothing left to do: every sample was consumed (the gate's second fruitless call decides what is held
+  // back, see rfid_lookahead_enable).  A scheduler that gave up earlier leaves windows in the library that no call will
+  // fetch any more: they are decided and accounted here (READER_STATE as the decoder / reader calls would have left it), so
+  // that print_results() -- called after stop(), apps/reader.py:130-131 in either order -- counts them.
+  bool stop() override {
+    if (d_started) {
+      (void)rfid_lookahead_flush(d_stream->ctx);
+      (void)rfid_lookahead_drain(d_stream->ctx);
+      d_stream->refresh();
+    }
+    return true;
   }
   stream_sptr d_stream;
   bool d_started = false;
@@ -226,6 +255,7 @@ class matched_filter_impl : public matched_filter {
       if (env_int("RFID_LOOKAHEAD", 1) != 0) {
         const int64_t cap = std::max<int64_t>(std::min<int64_t>(std::max<int64_t>(5 * (int64_t)noutput_items, ninput_items[0]), 5 * 262144), 5 * 8192) + 64;
         st.check(rfid_lookahead_enable(st.ctx, cap), "rfid_lookahead_enable");
+        tell_buffers(st.ctx, output_buffer_items(this));     // (this block's output buffer is the gate's input)
       }
     }
     int n_out = 0;
@@ -233,6 +263,10 @@ class matched_filter_impl : public matched_filter {
                           noutput_items, &n_out), "rfid_mf_work");
     consume_each(n_in);
     return n_out;
+  }
+  bool stop() override {   // (see gate_impl::stop)
+    if (d_started && *d_slot) (void)rfid_lookahead_flush((**d_slot).ctx);
+    return true;
   }
   std::shared_ptr<stream_sptr> d_slot;   // bound now or by the next gate
   bool d_started = false;
@@ -368,6 +402,139 @@ void sts_flowgraph::run(const gr_complex *samples, size_t n) {
       }
     }
   }
+}
+
+// ---- GNU Radio's scheduling rules, one thread (see rfid/mi355x.h) -----------------------------------------------------
+bounded_flowgraph::bounded_flowgraph(matched_filter::sptr mf, gate::sptr g, tag_decoder::sptr d, reader::sptr r, int buffer_items)
+    : d_mf(mf), d_gate(g), d_dec(d), d_reader(r), d_cap(buffer_items < 2048 ? 2048 : buffer_items) {   // (a buffer holds an EPC window: 1 370 items)
+  if (d_mf) d_mf->minirt_set_buffers(d_cap, d_cap);
+  d_gate->minirt_set_buffers(d_cap, d_cap);
+  d_dec->minirt_set_buffers(d_cap, d_cap);
+  d_reader->minirt_set_buffers(d_cap, 0);
+}
+
+namespace {
+struct edge_state { bool done = false; };   // the block that writes the buffer is done
+// one block of the flowgraph as the executor sees it
+struct node {
+  gr::block *blk = nullptr;
+  bool done = false, stalled = false, source_like = false;   // source_like: forecast() asks for nothing (the reader)
+  size_t stalled_at = 0;
+};
+}  // namespace
+
+void bounded_flowgraph::run(const gr_complex *samples, size_t n) {
+  d_deadlock = false;
+  const size_t C = (size_t)d_cap;
+  std::vector<gr_complex> e_src, e_mf, e_gate;     // source -> (filter | gate), filter -> gate, gate -> decoder
+  std::vector<float> e_bits;                       // decoder -> reader
+  std::vector<float> txbuf((size_t)rfid_reader_tx_max(1000000) * 4, 0.0f);
+  std::vector<gr_complex> outbuf(C + 8);
+  std::vector<float> bitbuf(C + 8);
+  size_t pos = 0;
+  bool src_done = false;
+  node nm, ng, nd, nr;
+  nm.blk = d_mf.get(); ng.blk = d_gate.get(); nd.blk = d_dec.get(); nr.blk = d_reader.get(); nr.source_like = true;
+  if (!d_mf) nm.done = true;
+  for (gr::block *b : {nm.blk, ng.blk, nd.blk, nr.blk}) if (b) b->start();
+  const bool trace = env_int("RFID_BOUNDED_TRACE", 0) != 0;   // every general_work call on stderr
+  // runs one block once if the rules allow it; -> true when it was called and moved something
+  auto turn = [&](node &nd_, size_t n_in_avail, bool in_done, size_t out_room, const void *in_ptr, void *out0, void *out1,
+                  int &consumed, int &produced) -> bool {
+    consumed = 0; produced = 0;
+    if (nd_.done) return false;
+    if (n_in_avail == 0 && in_done && !nd_.source_like) { nd_.done = true; return false; }   // block_executor.cc: no input left, upstream done
+    if (out_room == 0) return false;                                                         // blocked on output
+    int noutput = (int)out_room;
+    gr_vector_int req(1, 0);
+    for (;;) {
+      nd_.blk->forecast(noutput, req);
+      if ((size_t)req[0] <= n_in_avail) break;
+      if (noutput > 1) { noutput /= 2; continue; }          // "try again with half the output"
+      if (in_done) nd_.done = true;                         // not enough input and no more coming
+      return false;                                         // blocked on input
+    }
+    // a block that could do nothing is left alone until new input arrives or its upstream neighbour is done
+    if (nd_.stalled && !nd_.source_like && n_in_avail == nd_.stalled_at && !in_done) return false;
+    gr_vector_int nin(1, (int)n_in_avail);
+    gr_vector_const_void_star in(1, in_ptr);
+    gr_vector_void_star out(2, nullptr);
+    out[0] = out0; out[1] = out1;
+    nd_.blk->minirt_begin_work();
+    const int ret = nd_.blk->general_work(noutput, nin, in, out);
+    consumed = nd_.blk->minirt_consumed();
+    produced = (ret == gr::block::WORK_CALLED_PRODUCE) ? nd_.blk->minirt_produced(0) : (ret > 0 ? ret : 0);
+    if (trace) fprintf(stderr, "[bounded] %-14s in %6zu%s room %6zu noutput %6d -> consumed %6d produced %6d (gen2 %d gate %d)\n", nd_.blk->name().c_str(), n_in_avail,
+                       in_done ? " (upstream done)" : "", out_room, noutput, consumed, produced, (int)reader_state->gen2_logic_status, (int)reader_state->gate_status);
+    if (ret == gr::block::WORK_DONE) { nd_.done = true; return false; }
+    if (consumed == 0 && produced == 0) {
+      // nothing moved.  Its upstream neighbour was done when the call was made: nothing ever will, the block is done
+      // (block_executor.cc: were_done).  Else it waits for new input (or for the neighbour to finish).
+      if (in_done) { nd_.done = true; return false; }
+      nd_.stalled = true; nd_.stalled_at = n_in_avail;
+      return false;
+    }
+    nd_.stalled = false;
+    return true;
+  };
+  // The reader asks for no input (forecast: 0, lib/reader_impl.cc:194-198): a runtime calls it whenever its output has room, i.e.
+  // again and again until it has nothing to send -- its turn is that: until a call moves nothing (START -> SEND_QUERY -> IDLE
+  // before the first sample arrives; ACK, then the carrier, behind an RN16)
+  auto reader_turn = [&]() -> bool {
+    bool any = false;
+    for (int it = 0; it < 8; ++it) {
+      int rc_ = 0, rp_ = 0;
+      const bool m = turn(nr, e_bits.size(), nd.done, txbuf.size(), e_bits.data(), txbuf.data(), nullptr, rc_, rp_);
+      if (rc_ > 0) e_bits.erase(e_bits.begin(), e_bits.begin() + rc_);
+      if (rp_ > 0 && d_keep_tx) d_tx.insert(d_tx.end(), txbuf.begin(), txbuf.begin() + rp_);
+      if (!m) break;
+      any = true;
+    }
+    return any;
+  };
+  reader_turn();
+  for (long round = 0;; ++round) {
+    bool moved = false;
+    // ---- file source ----
+    if (!src_done) {
+      std::vector<gr_complex> &e0 = e_src;
+      const size_t room = C - e0.size();
+      const size_t take = (n - pos < room) ? (n - pos) : room;
+      if (take > 0) { e0.insert(e0.end(), samples + pos, samples + pos + take); pos += take; moved = true; }
+      else if (pos >= n) { src_done = true; moved = true; }   // (a file source hands out its last items, the call after that says WORK_DONE)
+    }
+    int cons = 0, prod = 0;
+    // ---- matched filter ----
+    if (d_mf) {
+      if (turn(nm, e_src.size(), src_done, C - e_mf.size(), e_src.data(), outbuf.data(), nullptr, cons, prod)) moved = true;
+      if (cons > 0) e_src.erase(e_src.begin(), e_src.begin() + cons);
+      if (prod > 0) { e_mf.insert(e_mf.end(), outbuf.begin(), outbuf.begin() + prod); if (d_keep_taps) d_tap_mf.insert(d_tap_mf.end(), outbuf.begin(), outbuf.begin() + prod); }
+    }
+    // ---- gate ----
+    {
+      std::vector<gr_complex> &gi = d_mf ? e_mf : e_src;
+      const bool gi_done = d_mf ? nm.done : src_done;
+      if (turn(ng, gi.size(), gi_done, C - e_gate.size(), gi.data(), outbuf.data(), nullptr, cons, prod)) moved = true;
+      if (cons > 0) { if (!d_mf && d_keep_taps) d_tap_mf.insert(d_tap_mf.end(), gi.begin(), gi.begin() + cons); gi.erase(gi.begin(), gi.begin() + cons); }
+      if (prod > 0) { e_gate.insert(e_gate.end(), outbuf.begin(), outbuf.begin() + prod); if (d_keep_taps) d_tap_gate.insert(d_tap_gate.end(), outbuf.begin(), outbuf.begin() + prod); }
+    }
+    // ---- tag_decoder ----
+    {
+      if (turn(nd, e_gate.size(), ng.done, C - e_bits.size(), e_gate.data(), bitbuf.data(), outbuf.data(), cons, prod)) moved = true;
+      if (cons > 0) { e_gate.erase(e_gate.begin(), e_gate.begin() + cons); d_windows++; }
+      if (prod > 0) e_bits.insert(e_bits.end(), bitbuf.begin(), bitbuf.begin() + prod);
+    }
+    // ---- reader (its output goes to a file sink that takes everything) ----
+    if (reader_turn()) moved = true;
+    const bool all_done = src_done && nm.done && ng.done && nd.done && nr.done;
+    if (all_done) break;
+    if (!moved) {
+      // nobody could move: with input left somewhere that is a flowgraph that hangs under a real runtime
+      if (!(e_src.empty() && e_mf.empty() && e_gate.empty() && e_bits.empty() && src_done)) d_deadlock = !(ng.done && nd.done);
+      break;
+    }
+  }
+  for (gr::block *b : {nm.blk, ng.blk, nd.blk, nr.blk}) if (b) b->stop();
 }
 #endif
 

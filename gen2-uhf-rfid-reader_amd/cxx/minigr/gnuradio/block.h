@@ -49,6 +49,9 @@ class block {
   }
   virtual int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
                            gr_vector_void_star &output_items) = 0;
+  // gr::block::start / stop (called by the runtime when the flowgraph starts / has stopped: gnuradio/block.h)
+  virtual bool start() { return true; }
+  virtual bool stop() { return true; }
   void consume_each(int how_many_items) { d_consumed = how_many_items; }
   void produce(int which_output, int how_many_items) {
     if ((size_t)which_output >= d_produced.size()) d_produced.resize((size_t)which_output + 1, 0);
@@ -58,6 +61,11 @@ class block {
   void minirt_begin_work() { d_consumed = 0; d_produced.assign(d_produced.size(), 0); }
   int minirt_consumed() const { return d_consumed; }
   int minirt_produced(int port) const { return (size_t)port < d_produced.size() ? d_produced[(size_t)port] : 0; }
+  // what GNU Radio's block_detail tells a block about its buffers (detail()->input(0)->max_possible_items_available(),
+  // detail()->output(0)->bufsize()): items, 0 = not bounded (the single-threaded scheduler's queues grow as needed)
+  void minirt_set_buffers(int input_items, int output_items) { d_in_cap = input_items; d_out_cap = output_items; }
+  int minirt_input_capacity() const { return d_in_cap; }
+  int minirt_output_capacity() const { return d_out_cap; }
 
  protected:
   block() {}   // for virtual inheritance (class X : virtual public gr::block)
@@ -67,6 +75,7 @@ class block {
   std::string d_name;
   io_signature::sptr d_in, d_out;
   int d_consumed = 0;
+  int d_in_cap = 0, d_out_cap = 0;
   std::vector<int> d_produced = std::vector<int>(2, 0);
 };
 

@@ -17,6 +17,12 @@
 //                                          over the whole file, y[n] = sum_{k=0..24} x[5n-24+k], k ascending -- and only
 //                                          gate, tag_decoder and reader are made; the gate is fed the filter's output
 //                                          buffer by buffer
+//                       [--scheduler sts|bounded]  sts (default): the single-threaded scheduler of rfid/mi355x.h, queues between the
+//                                          blocks as long as they need to be, --chunk items read per turn; bounded: GNU Radio's
+//                                          scheduling rules (bounded buffers of --buffer items, forecast, a block that could do nothing
+//                                          left alone until new input arrives or its neighbour is done, stop() at the end and nothing
+//                                          else: mi355x::bounded_flowgraph)
+//                       [--buffer N]       items per buffer of the bounded scheduler (default 8192: 64 KB of gr_complex)
 //                       [--time]           print the run's wall time and rate to stderr
 //
 // TRACE_FILE: headerless little-endian interleaved float32 I,Q at 2 Msps (apps/reader.py:102).
@@ -42,7 +48,8 @@ int main(int argc, char **argv) {
   const char *path = nullptr, *tx_path = nullptr, *mf_path = nullptr, *gate_path = nullptr;
   int device = 0, chunk = 8192;
   long whole_chain = 0;
-  bool show_time = false, host_fir = false;
+  bool show_time = false, host_fir = false, bounded = false;
+  int buffer_items = 8192;
   int fixed_q = gr::rfid::FIXED_Q, max_q = gr::rfid::MAX_NUM_QUERIES, uniq = gr::rfid::NUMBER_UNIQUE_TAGS;
   for (int i = 1; i < argc; ++i) {
     auto need = [&](const char *flag) -> const char * {
@@ -60,6 +67,8 @@ int main(int argc, char **argv) {
     else if (!std::strcmp(argv[i], "--whole-chain")) whole_chain = std::atol(need("--whole-chain"));
     else if (!std::strcmp(argv[i], "--time")) show_time = true;
     else if (!std::strcmp(argv[i], "--host-fir")) host_fir = true;
+    else if (!std::strcmp(argv[i], "--scheduler")) { const char *v = need("--scheduler"); bounded = !std::strcmp(v, "bounded"); if (!bounded && std::strcmp(v, "sts")) { std::cerr << "--scheduler sts|bounded\n"; return 2; } }
+    else if (!std::strcmp(argv[i], "--buffer")) buffer_items = std::atoi(need("--buffer"));
     else if (argv[i][0] == '-') { std::cerr << "unknown option " << argv[i] << "\n"; return 2; }
     else path = argv[i];
   }
@@ -124,8 +133,10 @@ int main(int argc, char **argv) {
     tag_decoder::sptr dec = tag_decoder::make(int(adc_rate / decim));
     reader::sptr reader_blk = reader::make(int(adc_rate / decim), int(dac_rate));
     mi355x::sts_flowgraph tb(mf, gate_blk, dec, reader_blk, chunk);
-    tb.keep_tx(tx_path != nullptr);
-    tb.keep_taps(mf_path != nullptr || gate_path != nullptr);
+    mi355x::bounded_flowgraph tbb(mf, gate_blk, dec, reader_blk, bounded ? buffer_items : 0);
+    if (!bounded) { if (mf) mf->minirt_set_buffers(0, 0); gate_blk->minirt_set_buffers(0, 0); dec->minirt_set_buffers(0, 0); reader_blk->minirt_set_buffers(0, 0); }
+    tb.keep_tx(tx_path != nullptr); tbb.keep_tx(tx_path != nullptr);
+    tb.keep_taps(mf_path != nullptr || gate_path != nullptr); tbb.keep_taps(mf_path != nullptr || gate_path != nullptr);
     const auto t0 = std::chrono::steady_clock::now();
     long n_windows = 0;
     if (whole_chain > 0) {
@@ -154,6 +165,10 @@ int main(int argc, char **argv) {
         pos += n;
       }
       rfid_stream_end(ctx);
+    } else if (bounded) {
+      if (host_fir) tbb.run(y_host.data(), y_host.size()); else tbb.run(samples.data(), samples.size());
+      n_windows = tbb.windows_decoded();
+      if (tbb.stalled()) { std::cerr << "rfid_reader_offline: the bounded scheduler stopped with input left and no block able to move\n"; return 4; }
     } else if (host_fir) {
       tb.run(y_host.data(), y_host.size());
       n_windows = tb.windows_decoded();
@@ -174,9 +189,9 @@ int main(int argc, char **argv) {
                 << " n_epc_correct=" << reader_state->reader_stats.n_epc_correct
                 << " unique=" << reader_state->reader_stats.tag_reads.size()
                 << " gate_status=" << reader_state->gate_status << " windows=" << n_windows << "\n";
-    if (tx_path && !dump(tx_path, tb.tx_samples())) { std::cerr << "cannot write " << tx_path << "\n"; return 2; }
-    if (mf_path && !dump(mf_path, tb.tap_matched_filter())) { std::cerr << "cannot write " << mf_path << "\n"; return 2; }
-    if (gate_path && !dump(gate_path, tb.tap_gate())) { std::cerr << "cannot write " << gate_path << "\n"; return 2; }
+    if (tx_path && !dump(tx_path, bounded ? tbb.tx_samples() : tb.tx_samples())) { std::cerr << "cannot write " << tx_path << "\n"; return 2; }
+    if (mf_path && !dump(mf_path, bounded ? tbb.tap_matched_filter() : tb.tap_matched_filter())) { std::cerr << "cannot write " << mf_path << "\n"; return 2; }
+    if (gate_path && !dump(gate_path, bounded ? tbb.tap_gate() : tb.tap_gate())) { std::cerr << "cannot write " << gate_path << "\n"; return 2; }
   } catch (const gr::rfid::mi355x::error &e) {
     std::cerr << "rfid_reader_offline: " << e.what() << "\n";
     return e.status == RFID_ERR_NO_DEVICE ? 3 : 4;

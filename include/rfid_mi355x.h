@@ -207,14 +207,22 @@ RFID_API int rfid_decoder_work(rfid_ctx *ctx, const rfid_cf32 *in, int n_in, flo
  * call are compared; anything else is RFID_ERR_STATE), with the same consume / produce counts, outputs and READER_STATE
  * transitions as without it (lib/gate_impl.cc:189-199, lib/tag_decoder_impl.cc:223,266,289,393-396).  The window types
  * are those of the reference's own control flow (RN16, EPC, RN16, ...: after an RN16 the reader always ACKs).
- * The pass of a rfid_mf_work call stays on the device when the call returns (it waits for its own filter outputs only)
- * and is looked at by the next rfid_mf_work call -- or by the second gate call in a row that could decide nothing.
- * What lies behind the last idle point of the gate in the samples seen so far is not decided yet: a gate call consumes
- * up to there and no further, and returns (0 consumed, 0 written) when it can decide nothing -- as often as it is asked
- * (asking never ends the stream; when the input pauses, the third such call puts what is held back through the
- * sequential scan, up to one EPC window before its end).  max_chunk_raw: what the staging is sized for (a larger
- * rfid_mf_work call goes through in pieces).  Call before the first sample; rfid_ctx_reset switches it off.  Like
- * rfid_stream_begin it runs on a one-trace plan of its own: any rfid_batch_plan of the context is replaced. */
+ * Since round 5 the calls GATHER: a rfid_mf_work call uploads and filters its own samples (its outputs are what it
+ * returns) and a whole-chain pass over everything pending is submitted once 65 536 decimated samples have gathered
+ * (rfid_lookahead_set_coalesce) -- a pass per 8 192-item scheduler buffer was a third of one CPU core's speed.  The pass
+ * stays on the device while the next calls upload into the other buffer.
+ * What lies behind the last idle point of the gate in the samples the passes have seen is not decided yet: a gate call
+ * consumes up to there and no further.  A gate call that can decide nothing returns (0 consumed, 0 written) ONCE per
+ * arrival of new samples -- the scheduler brings more; asked again without anything new (the input has paused or ended:
+ * a scheduler calls a block again when its upstream neighbour is done), or shown 2 x the gathering threshold or more
+ * (a bounded buffer must drain), it makes the device decide at once: the pass under way is waited for, a pass goes
+ * over whatever is pending, and what even that leaves undecided goes through the exact per-call scan (the streaming
+ * gate_scan_kernel from the carried state: gate_impl.cc:127-196 sample by sample, as without the look-ahead).  Every
+ * sample is consumed and every window handed out whether or not rfid_lookahead_flush is ever called.
+ * max_chunk_raw: the largest rfid_mf_work call to expect (a larger one goes through in pieces); the staging holds what
+ * gathers + one such call.  Call before the first sample; rfid_ctx_reset switches it off.  Like rfid_stream_begin it runs
+ * on a one-trace plan of its own: any rfid_batch_plan of the context is replaced.  (A reader that answers tags in
+ * real time cannot wait for 164 ms of signal to gather: RFID_LOOKAHEAD=0 / no rfid_lookahead_enable is the path for that.) */
 RFID_API int rfid_lookahead_enable(rfid_ctx *ctx, int64_t max_chunk_raw);
 /* The same look-ahead keyed on the GATE's input, for a flowgraph whose matched filter is not this library's --
  * apps/reader.py:75 instantiates GNU Radio's own filter.fir_filter_ccc, so with that file unchanged the first buffer
@@ -224,20 +232,34 @@ RFID_API int rfid_lookahead_enable(rfid_ctx *ctx, int64_t max_chunk_raw);
  * decoder calls from the cache, exactly as above (same consume / produce counts, outputs and READER_STATE transitions,
  * same rules for what is undecided, rfid_lookahead_flush at the end of the input).  There is no restriction on where the
  * gate's input comes from; rfid_mf_work is not to be called on such a context.  max_items: decimated samples the device
- * takes per call at most (a larger call is taken in parts).  Call before the first sample.  The end of the input
- * (rfid_lookahead_flush) is carried out once rfid_gate_work calls behind it (the third in a row) show nothing the device has not seen
- * and can decide nothing: the library knows only the samples the gate was shown, so the scheduler shows the gate everything
- * its buffer holds (as GNU Radio does) before the stream counts as ended; samples shown for the first time after that are
- * RFID_ERR_STATE. */
+ * takes per call at most (a larger call is taken in parts).  Call before the first sample.  The end of the input needs
+ * no announcement (see above: the second fruitless call decides everything); rfid_lookahead_flush saves that one call. */
 RFID_API int rfid_lookahead_enable_gate(rfid_ctx *ctx, int64_t max_items);
+/* How many decimated samples gather before a whole-chain pass is submitted (default 65 536; clamped to [1 024, half the
+ * staging]).  An adaptor that knows its scheduler's buffers tells the library here: with input buffers of C items the
+ * gate can never be shown more than C, so it asks for C / 4 (a gate call shown 2 x this many items decides at once). */
+RFID_API int rfid_lookahead_set_coalesce(rfid_ctx *ctx, int64_t items);
+/* What the adaptor knows about its scheduler: the buffer on the gate's input side holds gate_buffer_items items and no more
+ * (GNU Radio: detail()->input(0)->max_possible_items_available(); 65 536-byte buffers = 8 192 items by default), or 0: the
+ * queues between the blocks grow as needed (the single-threaded scheduler of rfid/mi355x.h).  Bounded: a quarter of the
+ * buffer gathers before a pass, and a gate call that can decide nothing never answers (0, 0) -- it makes the device
+ * decide at once (a block that moves nothing is, depending on the runtime, polled again at once or left alone for good:
+ * neither helps anything gather).  Unbounded (the default): (0, 0) once per arrival of new samples, see above. */
+RFID_API int rfid_lookahead_set_scheduler(rfid_ctx *ctx, int64_t gate_buffer_items);
 /* windows the look-ahead holds: found by the passes and not yet (completely) handed out by rfid_gate_work /
  * handed out and waiting for their rfid_decoder_work call (a decoder call retires its window whether or not it asks for
  * scores).  Both stay small in a running flowgraph. */
 RFID_API int rfid_lookahead_pending(const rfid_ctx *ctx, int *gate_windows, int *decoder_windows);
 /* End of the input (a file source has run dry): everything still held back is decided now; the gate / decoder / reader
- * calls that follow hand it out.  rfid_mf_work fails with RFID_ERR_STATE afterwards.  No-op without look-ahead.  A
- * flowgraph that never calls it leaves the last <= 20 ms of signal undecided. */
+ * calls that follow hand it out.  rfid_mf_work fails with RFID_ERR_STATE afterwards.  No-op without look-ahead.
+ * Optional since round 5: a flowgraph that never calls it loses nothing (the gate's second fruitless call decides what
+ * is held back), it only pays that one extra call. */
 RFID_API int rfid_lookahead_flush(rfid_ctx *ctx);
+/* The flowgraph has stopped (gr::block::stop()) and no gate / decoder call will come any more: whatever the device still
+ * holds is decided as at the end of a stream, and the windows nobody fetched are accounted in READER_STATE as the decoder /
+ * reader calls would have accounted them, so that rfid_print_results counts them.  Under a scheduler that calls the blocks
+ * until none can move there is nothing left to do here; it is the safety net for one that gives up earlier. */
+RFID_API int rfid_lookahead_drain(rfid_ctx *ctx);
 /* Page-locked host memory (nullptr on failure): samples handed to rfid_mf_work (look-ahead) / rfid_stream_work from such
  * memory -- or from any memory the caller page-locked himself -- go to the device without the staging copy. */
 RFID_API void *rfid_host_alloc(size_t bytes);

@@ -1,0 +1,109 @@
+"""Round 5, on the MI355X: the drop-in under a scheduler that behaves like GNU Radio's -- bounded buffers, nobody announces the
+end of the input -- and the gathering of calls into big passes; the switches read once per context."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _exe():
+    import rfid
+    return os.path.join(rfid.capi.PKG_ROOT, "bin", "rfid_reader_offline")
+
+
+def _run(exe, path, tmp_path, tag, extra, env=None):
+    files = [tmp_path / f"{k}_{tag}.bin" for k in ("tx", "mf", "gate")]
+    out = subprocess.run([exe, str(path), "--time", "--tx-out", str(files[0]), "--mf-out", str(files[1]), "--gate-out", str(files[2])] + extra,
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, **(env or {})))
+    assert out.returncode == 0, (tag, out.stderr[-2000:])
+    return out.stdout, [open(f, "rb").read() for f in files]
+
+
+@pytest.mark.parametrize("cut_behind_last_rn16", [False, True], ids=["whole-trace", "ends-behind-an-RN16-window"])
+def test_bounded_scheduler_small_buffers_both_keyings(tmp_path, oracle_mod, synth_mod, cut_behind_last_rn16):
+    """mi355x::bounded_flowgraph: GNU Radio's scheduling rules on one thread -- buffers of 8 192 items and no more, forecast, a
+    block that could do nothing is left alone until new input arrives or its neighbour is done, stop() at the end and nothing
+    else (nobody calls rfid_lookahead_flush before the blocks have stopped being called).  Both keyings of the look-ahead (the
+    library's matched_filter block in front of the gate; somebody else's filter, as apps/reader.py:75 has it): the report, the
+    reader's output and the gated samples are byte for byte those of the per-call path and the oracle's -- the last window
+    included, also when the trace ends a few samples behind a complete RN16 window (inside the stretch that the look-ahead's
+    passes leave undecided: the exact per-call scan takes it)."""
+    import rfid
+    exe = _exe()
+    t = synth_mod.make_trace(n_rounds=40, fixed_q=1, tag_ids=(0x27, 0x3C), seed=78, sigma=0.01, t1_jitter_raw=4, corrupt_rounds=(7,))
+    x = t.samples
+    cfg = oracle_mod.config(fixed_q=1)
+    if cut_behind_last_rn16:
+        o_full = oracle_mod.run_trace(x, cfg)
+        rn = [int(s) for s, ty in zip(o_full.open_idx, o_full.dumps["type"]) if ty == 0]
+        x = x[: 5 * (rn[-1] + 250 + 9)]          # the last RN16 window is complete, 9 decimated samples follow
+    o = oracle_mod.run_trace(x, cfg)
+    assert o.n_windows > 40 and (not cut_behind_last_rn16 or o.dumps["type"][-1] == 0)
+    path = tmp_path / "t.bin"
+    rfid.batch.write_trace_file(str(path), x)
+    outs = {}
+    for name, extra, env in (("percall", ["--chunk", "8192"], {"RFID_LOOKAHEAD": "0"}),
+                             ("bounded_mf", ["--scheduler", "bounded", "--buffer", "8192"], None),
+                             ("bounded_hostfir", ["--scheduler", "bounded", "--buffer", "8192", "--host-fir"], None),
+                             ("bounded_mf_4096", ["--scheduler", "bounded", "--buffer", "4096"], None),
+                             ("sts_mf_8192", ["--chunk", "8192"], None),
+                             ("sts_hostfir_8192", ["--chunk", "8192", "--host-fir"], None)):
+        stdout, files = _run(exe, path, tmp_path, name, ["--fixed-q", "1"] + extra, env)
+        assert stdout.startswith(o.print_results()), (name, stdout[-800:])
+        outs[name] = files
+    ref = outs["percall"]
+    for key, got in outs.items():
+        assert got[0] == ref[0], ("reader output differs", key)
+        assert got[1] == ref[1], ("filter output differs", key)
+        assert got[2] == ref[2], ("gated samples differ", key)
+    # the gated samples ARE the oracle's windows, the last one included
+    g = np.frombuffer(ref[2], dtype=np.complex64)
+    want = sum(1370 if ty else 250 for ty in o.dumps["type"])
+    assert len(g) >= want
+
+
+def test_calls_gather_into_big_passes(tmp_path, oracle_mod, synth_mod):
+    """The single-threaded scheduler reading 8 192 items per turn (GNU Radio's default buffer): since round 5 the calls only
+    upload (and filter) their samples, a whole-chain pass runs once 65 536 decimated samples have gathered.  Same bytes as with
+    big buffers; the rate is in profiles/r05/drop_in_path.txt."""
+    import rfid
+    exe = _exe()
+    t = synth_mod.make_trace(n_rounds=300, seed=11, sigma=0.004, corrupt_rounds=(36,))
+    o = oracle_mod.run_trace(t.samples, oracle_mod.config(max_num_queries=1 << 30))
+    path = tmp_path / "t.bin"
+    rfid.batch.write_trace_file(str(path), t.samples)
+    outs = {}
+    for name, extra in (("8192", ["--chunk", "8192"]), ("65536", ["--chunk", "65536"]), ("hostfir_8192", ["--chunk", "8192", "--host-fir"]),
+                        ("1000", ["--chunk", "1000"])):
+        stdout, files = _run(exe, path, tmp_path, name, ["--max-queries", "100000000"] + extra)
+        assert stdout.startswith(o.print_results()), (name, stdout[-800:])
+        outs[name] = files
+    for key, got in outs.items():
+        assert got == outs["65536"], key
+
+
+def test_knobs_are_read_once_and_settable(synth_mod):
+    """The RFID_* switches are read when a context is created; rfid_ctx_set_knob changes one of a living context."""
+    import rfid
+    os.environ["RFID_LS_FUSED"] = "0"
+    try:
+        ctx = rfid.Context(device=0)
+    finally:
+        del os.environ["RFID_LS_FUSED"]
+    try:
+        assert ctx.get_knob("ls_fused") == 0 and ctx.get_knob("overlap") == 1 and ctx.get_knob("front_chunks") == 1
+        os.environ["RFID_LS_FUSED"] = "1"          # (changing the environment now changes nothing)
+        try:
+            assert ctx.get_knob("ls_fused") == 0
+        finally:
+            del os.environ["RFID_LS_FUSED"]
+        ctx.set_knob("ls_fused", 1)
+        assert ctx.get_knob("ls_fused") == 1
+        for bad in (("front_chunks", 99), ("overlap", -1), ("no_such_knob", 1)):
+            with pytest.raises(rfid.capi.RfidError):
+                ctx.set_knob(*bad)
+    finally:
+        ctx.close()
