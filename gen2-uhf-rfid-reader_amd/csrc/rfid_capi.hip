@@ -27,8 +27,8 @@
   hipLaunchKernelGGL(rfidk::kernel, dim3((unsigned)(gx), (unsigned)(gy)), dim3((unsigned)(block)), 0, ls2_stream, args)
 static thread_local hipStream_t ls2_stream = nullptr;
 // RFID_LA_PROFILE=1: where the look-ahead's time goes (printed when the context is destroyed)
-static double g_la_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-static long g_la_n[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+static double g_la_t[16] = {0};
+static long g_la_n[16] = {0};
 static inline double la_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec; }
 struct LaTimer { int k; double t0; explicit LaTimer(int kk) : k(kk), t0(la_now()) {} ~LaTimer() { g_la_t[k] += la_now() - t0; g_la_n[k]++; } };
 #include "rfid_ls2_enqueue.hpp"
@@ -192,7 +192,9 @@ struct rfid_ctx {
                                       // queues grow as needed); false: it decides at once (bounded buffers, rfid_lookahead_set_scheduler)
     bool tail_tried = false;          // a pass has gone over everything the device holds since the last new sample (and left the rest)
     bool exact_open = false;          // the exact per-call scan (la_exact_step) has left a window open: it goes on until the window closes
-    DevBuf d_ycall;                   // the filter outputs of one rfid_mf_work call (device)
+    const rfid_cf32 *pin_next = nullptr; bool pin_was = false;   // where the last uploaded call's samples ended, and whether they were page-locked
+    int *h_flag = nullptr;            // page-locked word the device writes behind a call's filter outputs (host_flag_kernel)
+    int flag_seq = 0;
     bool soft_done = false;           // ... and the held-back samples went through the sequential scan since the last input
     std::vector<float> last_m2;       // |.|^2 of what the last gate call wrote
     // scratch of one whole-chain pass
@@ -849,9 +851,11 @@ int rfid_ctx_create(const rfid_params *p, int device, rfid_ctx **out) {
 int rfid_ctx_destroy(rfid_ctx *c) {
   if (!c) return RFID_ERR_INVALID;
   if (c->knobs.la_profile && (g_la_n[0] || g_la_n[1]))
-    fprintf(stderr, "[la] mf_work %ld calls %.2f ms (upload queued %.2f, pass enqueued %.2f, wait for the filter outputs %.2f, previous pass collected %.2f: of it waiting %.2f) | "
-            "gate_work %ld calls %.2f ms | decoder_work %ld calls %.2f ms | reader_work_tx %ld calls %.2f ms | lookahead_enable %.2f ms\n",
-            g_la_n[0], g_la_t[0], g_la_t[4], g_la_t[5], g_la_t[8], g_la_t[6], g_la_t[7], g_la_n[1], g_la_t[1], g_la_n[2], g_la_t[2], g_la_n[3], g_la_t[3], g_la_t[9]);
+    fprintf(stderr, "[la] mf_work %ld calls %.2f ms (upload queued %.2f, the call's filter enqueued %.2f, wait for its outputs %.2f, passes submitted from here %.2f) | "
+            "gate_work %ld calls %.2f ms | decoder_work %ld calls %.2f ms | reader_work_tx %ld calls %.2f ms | lookahead_enable %.2f ms | "
+            "%ld passes: collected %.2f ms (waiting for the device %.2f, fetching windows %.2f), submitted %.2f ms (front end's launch list %.2f)\n",
+            g_la_n[0], g_la_t[0], g_la_t[4], g_la_t[5], g_la_t[8], g_la_t[6], g_la_n[1], g_la_t[1], g_la_n[2], g_la_t[2], g_la_n[3], g_la_t[3], g_la_t[9],
+            g_la_n[10], g_la_t[10], g_la_t[7], g_la_t[12], g_la_t[11], g_la_t[13]);
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   la_free(c);
@@ -2064,6 +2068,10 @@ int rfid_reader_work(rfid_ctx *c, int n_in, int *n_consumed) {  // reader_impl.c
 // ======================================================================================
 namespace {
 const int64_t SIO_SMALL_DEC = 32768;   // decimated samples below which a pass takes the sequential scan (sio_submit)
+// (with the look-ahead's 65 536-sample passes too: the sequential scan over such a pass -- one launch, 0.65 ms -- instead of the
+// front end's list -- ~50 launches, 0.25 ms of device, 0.1 ms of the host's time to enqueue -- was measured: the scheduler's
+// calls then wait for the device, 393 -> 310 Msamples/s at 8 192-item buffers, profiles/r05/drop_in_path.txt)
+const int64_t SIO_SMALL_DEC_LA = 32768;
 const int SIO_HIST = 28;   // raw samples kept before the held-back tail: 24 of filter history + the decimation group
                            // (= rfid_ctx::StreamIO::hist() of a raw stream)
 
@@ -2154,6 +2162,7 @@ int sio_enqueue_packet(rfid_ctx *c, int n_hdr, int usual, const int *only_if) {
 // look-ahead of the per-block calls collects a pass when the next rfid_mf_work call arrives, so that the device works
 // on a call's samples while the scheduler hands out the windows of the call before.
 int sio_submit(rfid_ctx *c, int b, int64_t n_new, bool flush) {
+  LaTimer tm_submit(11);
   rfid_ctx::StreamIO &io = c->sio;
   rfid_ctx::StreamIO::Pass &ps = io.pass;
   ps = rfid_ctx::StreamIO::Pass();
@@ -2192,7 +2201,7 @@ int sio_submit(rfid_ctx *c, int b, int64_t n_new, bool flush) {
     }
   }
   if (c->la.on) HIPCHK(c, hipEventRecord(io.ev_y, c->stream));
-  if (n_out > 0 && n_out < SIO_SMALL_DEC) {
+  if (n_out > 0 && n_out < (c->la.on ? SIO_SMALL_DEC_LA : SIO_SMALL_DEC)) {
     // ---- a short pass (a scheduler's 8 k-item buffer, a small file): the long-stream front end is a string of ~45 launches
     //      that one trace of this length does not repay -- the sequential scan (one launch, ~10 ns per sample) goes over it
     //      from the carried state, up to one EPC window before the end of what is there (a window that opens before that
@@ -2224,7 +2233,9 @@ int sio_submit(rfid_ctx *c, int b, int64_t n_new, bool flush) {
     LsOpts opt;
     opt.carry = true; opt.hold_last = !flush; opt.force = true;
     int enq = 0;
+    const double t_ls0 = la_now();
     int rc = ls_enqueue(c, n_out, opt, &enq);
+    g_la_t[13] += la_now() - t_ls0; g_la_n[13]++;
     if (rc) return rc;
     ps.enq = enq != 0;
     if (ps.enq && c->la.on) {
@@ -2245,6 +2256,7 @@ int sio_collect(rfid_ctx *c) {
   rfid_ctx::StreamIO &io = c->sio;
   rfid_ctx::StreamIO::Pass &ps = io.pass;
   if (!ps.active) return RFID_OK;
+  LaTimer tm_collect(10);
   ps.active = false;
   const int b = ps.b;
   const bool flush = ps.flush;
@@ -2307,6 +2319,7 @@ int sio_collect(rfid_ctx *c) {
       std::vector<rfid_window> w;
       std::vector<rfid_decode_result> r;
       std::shared_ptr<rfid_ctx::LookAhead::Blk> blk;
+      LaTimer tm_fetch(12);
       if (c->la.on) {
         // a pass with more windows (or more gated samples) than the packet was sized for is fetched again with the right sizes
         int n_hdr = prefetched ? ps.n_hdr : c->la.n_hdr;
@@ -2542,7 +2555,7 @@ void la_free(rfid_ctx *c) {
   if (la.h_pack) (void)hipHostFree(la.h_pack);
   if (la.h_y) (void)hipHostFree(la.h_y);
   if (la.d_pack.p) (void)hipFree(la.d_pack.p);
-  if (la.d_ycall.p) (void)hipFree(la.d_ycall.p);
+  if (la.h_flag) (void)hipHostFree(la.h_flag);
   la.wins.clear(); la.dq.clear();   // (their blocks go back to the pool, which is emptied next)
   for (rfid_ctx::LookAhead::Blk *b : la.pool) delete b;
   la.pool.clear();
@@ -2579,11 +2592,13 @@ int la_append(rfid_ctx *c, const rfid_cf32 *src, int64_t n) {
     HIPCHK(c, hipStreamWaitEvent(io.copy_stream, io.ev_hist, 0));         // ... and the history in front of its upload area is in place
   }
   bool pinned = false;   // page-locked memory of the caller's (rfid_host_alloc, hipHostMalloc / hipHostRegister)?  then no staging copy
-  {
+  if (src == c->la.pin_next) pinned = c->la.pin_was;   // (a call that goes on where the last one ended: a scheduler walking through one buffer;
+  else {                                               //  a wrong guess costs a staging copy or a slower transfer, never a wrong one)
     hipPointerAttribute_t attr;
     if (hipPointerGetAttributes(&attr, src) == hipSuccess) pinned = (attr.type == hipMemoryTypeHost);
     else (void)hipGetLastError();
   }
+  c->la.pin_next = src + n; c->la.pin_was = pinned;
   if (!pinned) { memcpy(io.h_pin[up] + io.acc_new, src, sizeof(rfid_cf32) * (size_t)n); src = io.h_pin[up] + io.acc_new; }
   HIPCHK(c, hipMemcpyAsync(io.d_buf[up] + io.tail_max + io.acc_new, src, sizeof(rfid_cf32) * (size_t)n, hipMemcpyHostToDevice, io.copy_stream));
   HIPCHK(c, hipEventRecord(io.ev_up[up], io.copy_stream));
@@ -2632,7 +2647,10 @@ int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int o
     // y[n] = sum x[5n - 24 .. 5n] for this call's outputs: the matched filter over the new samples, whose history lies in
     // front of them in the buffer, on the copy stream (the pass before may still be at work on the main stream)
     const double t_sp = la_now();
-    if ((rc = grow(c, la.d_ycall, sizeof(float2) * (size_t)(n_out + 2)))) return rc;
+    if (!la.h_flag) {
+      HIPCHK(c, hipHostMalloc((void **)&la.h_flag, 64, hipHostMallocDefault));
+      *la.h_flag = 0;
+    }
     if ((size_t)n_out > la.h_ycap) {
       if (la.h_y) (void)hipHostFree(la.h_y);
       la.h_y = nullptr; la.h_ycap = 0;
@@ -2644,15 +2662,29 @@ int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int o
     a.x_stride = SIO_HIST + n_in; a.n_raw = SIO_HIST + n_in; a.lens = nullptr;
     a.n_out = n_out; a.in_off = (int)(DECIM * n_first - c->mf_seen) + SIO_HIST - (NTAPS - 1);   // 0 .. 4
     a.vec_ok = ((((uintptr_t)a.x) & 15) == 0 && (a.in_off % 2) == 0) ? 1 : 0;
-    a.y = (float2 *)la.d_ycall.p; a.y_stride = n_out; a.tile0 = 0; a.stream0 = 0;
+    // the outputs go straight into page-locked host memory (the device writes it over the bus: no copy to set up), a word
+    // behind them says they are there, and the host spins on that word (an event's wake-up costs more than the filter)
+    a.y = (float2 *)la.h_y; a.y_stride = n_out; a.tile0 = 0; a.stream0 = 0;
     const int tiles = (n_out + MF_TILE - 1) / MF_TILE;
     hipLaunchKernelGGL(mf_boxcar25_decim5_kernel, dim3((unsigned)tiles, 1), dim3(MF_THREADS), 0, io.copy_stream, a);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(la.h_y, la.d_ycall.p, sizeof(rfid_cf32) * (size_t)n_out, hipMemcpyDeviceToHost, io.copy_stream));
-    HIPCHK(c, hipEventRecord(io.ev_y, io.copy_stream));
+    const int seq = ++la.flag_seq;
+    hipLaunchKernelGGL(host_flag_kernel, dim3(1), dim3(64), 0, io.copy_stream, la.h_flag, seq);
+    HIPCHK(c, hipGetLastError());
     g_la_t[5] += la_now() - t_sp; g_la_n[5]++;
     const double t_y0 = la_now();
-    HIPCHK(c, hipEventSynchronize(io.ev_y));
+    {
+      volatile int *fl = la.h_flag;
+      long spins = 0;
+      while (*fl != seq) {
+        __builtin_ia32_pause();
+        if (++spins > 2000000L) {      // (~ tens of ms: something is wrong or very slow -- wait the ordinary way)
+          HIPCHK(c, hipStreamSynchronize(io.copy_stream));
+          break;
+        }
+      }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
     g_la_t[8] += la_now() - t_y0; g_la_n[8]++;
     memcpy(out, la.h_y, sizeof(rfid_cf32) * (size_t)n_out);
     la.y_push(n_first, la.h_y, (size_t)n_out);

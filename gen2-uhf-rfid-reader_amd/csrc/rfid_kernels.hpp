@@ -119,6 +119,11 @@ RFID_KERNEL(MF_THREADS) void mf_boxcar25_decim5_kernel(MfArgs a) {
   RFID_SHARED float4 tile4[MF_RAW / 2 + 2];
   mf_tile(a, (int)blockIdx.y + a.stream0, (int64_t)blockIdx.x + a.tile0, tile4);
 }
+// a word for the host behind the launches in front of it on the stream (page-locked host memory the device writes directly):
+// the host spins on it instead of paying an event's wake-up (look-ahead: a scheduler call waits for its filter outputs)
+RFID_KERNEL(64) void host_flag_kernel(int *flag, int v) {
+  if (threadIdx.x == 0) { __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+}
 // The same behind a pass that normally needs no filter launch (the long-stream front end with its fused first pass filters
 // inside ls2_front_kernel; when it gives the pass up, y is incomplete and the sequential scan behind it needs all of it):
 // does nothing when *skip_if != 0 -- a fixed, small grid whose workgroups walk the tiles, so that the usual, skipped case

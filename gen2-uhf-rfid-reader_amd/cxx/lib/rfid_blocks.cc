@@ -335,7 +335,10 @@ void sts_flowgraph::run(const gr_complex *samples, size_t n) {
   // the buffers between the blocks: read positions move, the data does not (it is dropped when a buffer has been read up)
   // (a gate fed by somebody else's filter is shown what it has not consumed yet AND what came in since, as a scheduler's
   // buffer does: up to two chunks)
+  // ... unless the gate has just said that it can decide nothing on what it was shown: then it is shown everything that has
+  // arrived (these queues are not bounded; mi355x::bounded_flowgraph is the scheduler with bounded ones)
   const size_t gate_view = d_mf ? (size_t)d_chunk : 2 * (size_t)d_chunk;
+  bool gate_stalled = false;
   std::vector<gr_complex> gq, dq, mf_out((size_t)d_chunk + 8), gate_out(gate_view);
   size_t g_rd = 0, d_rd = 0;
   size_t pos = 0;
@@ -345,7 +348,9 @@ void sts_flowgraph::run(const gr_complex *samples, size_t n) {
   while (pos < n || g_rd < gq.size()) {
     if (pos < n) {
       const size_t take = (n - pos < (size_t)d_chunk * in_per_out) ? (n - pos) : (size_t)d_chunk * in_per_out;
-      if (g_rd > 0) { gq.erase(gq.begin(), gq.begin() + (long)g_rd); g_rd = 0; }
+      // (what has been read is dropped once it is most of the queue: the gate may leave tens of thousands of items standing
+      // while a pass gathers, and moving them once per 8 192-item turn was a third of the run)
+      if (g_rd > 0 && (g_rd == gq.size() || g_rd >= gq.size() / 2 + 65536)) { gq.erase(gq.begin(), gq.begin() + (long)g_rd); g_rd = 0; }
       if (d_mf) {
         gr_vector_int nin(1, (int)take);
         gr_vector_const_void_star in(1, samples + pos);
@@ -365,7 +370,7 @@ void sts_flowgraph::run(const gr_complex *samples, size_t n) {
       const size_t have = gq.size() - g_rd;
       // (at the end of the input the gate is shown everything that is left: the library's gate-keyed look-ahead only knows
       // the samples the gate was shown)
-      const size_t show = (pos >= n || have < gate_view) ? have : gate_view;
+      const size_t show = (pos >= n || have < gate_view || gate_stalled) ? have : gate_view;
       if (gate_out.size() < show) gate_out.resize(show);
       const int avail = (int)show;
       g_nin[0] = avail; g_in[0] = gq.data() + g_rd; g_out[0] = gate_out.data();
@@ -386,6 +391,7 @@ void sts_flowgraph::run(const gr_complex *samples, size_t n) {
         d_rd += (size_t)dcons;
         reader_until_idle(d_dec->minirt_produced(0));
       }
+      gate_stalled = (consumed == 0 && written == 0);
       if (consumed == 0 && written == 0) {
         // the gate can decide nothing on what it has: more input first.  At the end of the input the library is told so
         // (with its look-ahead on, what it still holds back is decided then), and the gate asked again
