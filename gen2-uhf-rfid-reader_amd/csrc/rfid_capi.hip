@@ -96,6 +96,8 @@ struct rfid_ctx {
   int ls_mode = 1;                // 0 never, 1 automatic, 2 whenever a trace can be cut
   double ls_fixed_ms = 0.45, ls_ns_per_sample = 0.03, seq_ns_per_sample = 10.2;   // cost model of the automatic choice (ls_calibrate)
   bool ls_calibrated = false;     // the three numbers were measured on this device (or that was tried, or is not wanted)
+  bool ls_measured = false;       // ls_calibrate really measured them (it leaves the built-in numbers when an allocation or a pass fails)
+  bool plan_for_stream = false;   // the plan being made is a stream's own (rfid_stream_begin / look-ahead): no second filter-output buffer
   // whole-chain streaming (rfid_stream_*)
   struct StreamIO {
     bool open = false;
@@ -700,6 +702,7 @@ int ls_calibrate(rfid_ctx *c) {
     c->ls_ns_per_sample = 1.25 * slope * 1e6;
     c->ls_fixed_ms = fixed;
     c->seq_ns_per_sample = t_seq[1] / n1 * 1e6;   // (sixteen traces side by side take the time of one)
+    c->ls_measured = true;
   }
   c->ls_calibrated = true;
   if (c->knobs.ls_debug)
@@ -725,7 +728,7 @@ void ls_calibrate_lazily(rfid_ctx *c) {
     if (rfid_ctx_create(&c->prm, c->device, &t) == RFID_OK && t) {
       t->ls_calibrated = true;             // (its own decisions use what it has)
       t->ls_mode = 1;
-      if (ls_calibrate(t) == RFID_OK && t->ls_calibrated) {
+      if (ls_calibrate(t) == RFID_OK && t->ls_measured) {   // (a measurement that bailed out leaves nothing to cache: the built-in numbers stay)
         k.ok = true; k.fixed_ms = t->ls_fixed_ms; k.ns_all = t->ls_ns_per_sample; k.ns_seq = t->seq_ns_per_sample;
       }
       (void)rfid_ctx_destroy(t);
@@ -1140,7 +1143,7 @@ int rfid_batch_plan(rfid_ctx *c, int n_streams, int64_t max_raw) {
       // ... and a second matched-filter output buffer for the filter of the next pass (unless a whole second set exists, or
       // this is a stream's own plan: n_dec of a stream call is small and its passes do not overlap)
       size_t free_b = 0, total_b = 0;
-      if (!c->alt_have && c->knobs.overlap != 0 && sz_y >= ((size_t)16 << 20) && hipMemGetInfo(&free_b, &total_b) == hipSuccess && sz_y < free_b / 8) {
+      if (!c->alt_have && !c->plan_for_stream && c->knobs.overlap != 0 && sz_y >= ((size_t)16 << 20) && hipMemGetInfo(&free_b, &total_b) == hipSuccess && sz_y < free_b / 8) {
         if (hipMalloc(&c->alt_y_blk, sz_y) == hipSuccess) c->alt.d_y = (float2 *)c->alt_y_blk;
         else { (void)hipGetLastError(); c->alt_y_blk = nullptr; }
       }
@@ -2431,7 +2434,9 @@ int sio_begin(rfid_ctx *c, int64_t max_chunk_raw, bool ymode) {
   io.tail_max = ((dec * hold + dec * (int64_t)EPC_WIN + hist + 63) & ~63LL);
   io.max_chunk = max_chunk_raw;
   // (the plan's sizes follow the decimated sample count: a ymode stream of N samples is planned like 5 N raw ones)
+  c->plan_for_stream = true;     // (a stream's passes do not overlap one another's matched filters: no second output buffer for it)
   int rc = rfid_batch_plan(c, 1, (DECIM / dec) * (io.tail_max + max_chunk_raw));
+  c->plan_for_stream = false;
   if (rc) return rc;
   io.ymode = ymode;
   for (int i = 0; i < 2; ++i) {

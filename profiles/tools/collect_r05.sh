@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 5: the records behind DESIGN.md / README.md -- bench lines of every configuration's per-GPU workload, rocprofv3 kernel
+# stats and PMC traffic of configs[1], configs[2] and configs[3]'s stream, the GPU test log
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+O=gpurun_out/${1:-final_r05}; mkdir -p $O
+export TMPDIR=/tmp RFID_LS_CALIBRATE=0
+( timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -6 ) > $O/pytest_gpu.log
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+for cfg in 1 2 3stream 4shard; do
+  python bench.py --config $cfg --no-cpu-baseline --no-stream-leg --no-other-configs > $O/bench_$cfg.json 2> $O/bench_$cfg.err
+done
+python bench.py --config 1 --streams 4096 --no-cpu-baseline --no-stream-leg --no-other-configs > $O/bench_1_4096_traces.json 2>> $O/bench_1.err
+for cfg in 1 2 3stream; do
+  CFG=$cfg bash profiles/tools/r05_stats2.sh ${1:-final_r05} $cfg > /dev/null 2>&1
+  bash profiles/tools/r05_pmc.sh ${1:-final_r05} $cfg > /dev/null 2>&1
+done
+ls -la $O

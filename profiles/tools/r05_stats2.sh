@@ -8,7 +8,7 @@ cp $O/t_$tag/t_kernel_stats.csv $O/kernel_stats_$tag.csv 2>/dev/null
 python - $O/kernel_stats_$tag.csv $tag <<'PY' | tee $O/stats_$tag.txt
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "rfidk" in r["Name"] and "synth" not in r["Name"]]
-passes = float([r for r in rows if "decode_all" in r["Name"]][0]["Calls"])
+passes = float([r for r in rows if "decode_all" in r["Name"] or "decode_epc3" in r["Name"]][0]["Calls"])
 tot = 0.0
 print("==", sys.argv[2], "(%d passes)" % passes)
 for r in rows:
