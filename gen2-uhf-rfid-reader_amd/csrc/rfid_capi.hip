@@ -27,8 +27,8 @@
   hipLaunchKernelGGL(rfidk::kernel, dim3((unsigned)(gx), (unsigned)(gy)), dim3((unsigned)(block)), 0, ls2_stream, args)
 static thread_local hipStream_t ls2_stream = nullptr;
 // RFID_LA_PROFILE=1: where the look-ahead's time goes (printed when the context is destroyed)
-static double g_la_t[16] = {0};
-static long g_la_n[16] = {0};
+static double g_la_t[20] = {0};
+static long g_la_n[20] = {0};
 static inline double la_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec; }
 struct LaTimer { int k; double t0; explicit LaTimer(int kk) : k(kk), t0(la_now()) {} ~LaTimer() { g_la_t[k] += la_now() - t0; g_la_n[k]++; } };
 #include "rfid_ls2_enqueue.hpp"
@@ -195,16 +195,23 @@ struct rfid_ctx {
     bool tail_tried = false;          // a pass has gone over everything the device holds since the last new sample (and left the rest)
     bool exact_open = false;          // the exact per-call scan (la_exact_step) has left a window open: it goes on until the window closes
     const rfid_cf32 *pin_next = nullptr; bool pin_was = false;   // where the last uploaded call's samples ended, and whether they were page-locked
-    int *h_flag = nullptr;            // page-locked word the device writes behind a call's filter outputs (host_flag_kernel)
+    int *h_flag = nullptr;            // page-locked word the device writes behind a call's filter outputs (mf_upload_kernel)
+    int *d_done = nullptr;            // ... and its counter of workgroups through
     int flag_seq = 0;
+    // rfid_lookahead_set_late_outputs: a rfid_mf_work call hands out the filter outputs of the call BEFORE it (they are long
+    // there), its own are fetched by the next call: no call waits for the device
+    bool late = false;
+    int64_t pend_y0 = 0;              // global position of the first output held back
+    int pend_n = 0, pend_off = 0;     // outputs of the last call that had any / of those handed out already
+    int pend_seq = 0; bool pend_ready = false;   // the flag value that says they are in h_y / seen
+    int pend_half = 0;                // the half of h_y they are in
     bool soft_done = false;           // ... and the held-back samples went through the sequential scan since the last input
     std::vector<float> last_m2;       // |.|^2 of what the last gate call wrote
     // scratch of one whole-chain pass
-    DevBuf d_pack;                    // one packet per pass: count, window records, results, gated samples, |.|^2 (gated_windows_kernel)
-    char *h_pack = nullptr; rfid_cf32 *h_y = nullptr;   // page-locked
+    char *h_pack = nullptr;           // page-locked: one packet per pass -- count, window records, results, gated samples, |.|^2 (gated_windows_kernel)
+    rfid_cf32 *h_y = nullptr;         // page-locked: filter outputs of the calls (two halves)
     size_t h_cap = 0, h_ycap = 0;
     int n_hdr = 48;                   // windows the packet is sized for (follows what the calls hold)
-    int64_t want_y0 = 0; int want_yn = 0;   // matched-filter outputs (global positions) the current rfid_mf_work call returns
   } la;
   rfid_window *d_swin = nullptr;  // one window
   int *d_scount = nullptr;
@@ -856,9 +863,10 @@ int rfid_ctx_destroy(rfid_ctx *c) {
   if (c->knobs.la_profile && (g_la_n[0] || g_la_n[1]))
     fprintf(stderr, "[la] mf_work %ld calls %.2f ms (upload queued %.2f, the call's filter enqueued %.2f, wait for its outputs %.2f, passes submitted from here %.2f) | "
             "gate_work %ld calls %.2f ms | decoder_work %ld calls %.2f ms | reader_work_tx %ld calls %.2f ms | lookahead_enable %.2f ms | "
-            "%ld passes: collected %.2f ms (waiting for the device %.2f, fetching windows %.2f), submitted %.2f ms (front end's launch list %.2f)\n",
+            "%ld passes: collected %.2f ms (waiting for the device %.2f, fetching windows %.2f), submitted %.2f ms (the pass's filter %.2f, front end's launch list %.2f, "
+            "decoder %.2f, packet of results %.2f)\n",
             g_la_n[0], g_la_t[0], g_la_t[4], g_la_t[5], g_la_t[8], g_la_t[6], g_la_n[1], g_la_t[1], g_la_n[2], g_la_t[2], g_la_n[3], g_la_t[3], g_la_t[9],
-            g_la_n[10], g_la_t[10], g_la_t[7], g_la_t[12], g_la_t[11], g_la_t[13]);
+            g_la_n[10], g_la_t[10], g_la_t[7], g_la_t[12], g_la_t[11], g_la_t[14], g_la_t[13], g_la_t[15], g_la_t[16]);
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   la_free(c);
@@ -1852,12 +1860,16 @@ extern "C" {
 int rfid_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap, int *n_produced) {
   if (!c || n_in < 0 || (n_in > 0 && !in) || !n_produced) return RFID_ERR_INVALID;
   *n_produced = 0;
-  if (n_in == 0) return RFID_OK;
+  if (n_in == 0 && !(c->la.on && c->la.late && c->la.pend_n > 0)) return RFID_OK;
   HIPCHK(c, hipSetDevice(c->device));
   if (c->la.on) {
     if (c->sio.ymode) return fail(c, RFID_ERR_STATE, "look-ahead: keyed on the gate's input (rfid_lookahead_enable_gate), rfid_mf_work has no part in it");
     // a call larger than the max_chunk_raw the look-ahead was sized for goes through in pieces (multiples of the decimation)
     const int64_t piece = (c->sio.max_chunk / DECIM) * DECIM;
+    if (c->la.late) {   // (late outputs: one call, one set of outputs held back)
+      if (n_in > piece) return fail(c, RFID_ERR_CAPACITY, "look-ahead with late outputs: a rfid_mf_work call takes at most the max_chunk_raw given to rfid_lookahead_enable");
+      return la_mf_work(c, in, n_in, out, out_cap, n_produced);
+    }
     int done = 0, made = 0;
     while (done < n_in) {
       const int take = (int)((n_in - done < piece) ? (n_in - done) : piece);
@@ -2130,29 +2142,23 @@ bool sio_account(rfid_ctx *c, const rfid_decode_result &r) {
 // (look-ahead) the packet for the host: window count, window records, results, gated samples and their |.|^2 -- sized for
 // what a call usually holds and fetched with ONE copy
 int sio_enqueue_packet(rfid_ctx *c, int n_hdr, int usual, const int *only_if) {
-  const int cap = n_hdr * EPC_WIN;
   const size_t hdr = GATED_HDR + (sizeof(rfid_window) + sizeof(rfid_decode_result)) * (size_t)n_hdr;
-  const size_t total = hdr + (sizeof(float2) + sizeof(float)) * (size_t)cap;
   const size_t first = hdr + (sizeof(float2) + sizeof(float)) * (size_t)usual;
-  // (both buffers with room to spare: the window count creeps up and down from call to call, and every re-allocation
-  // synchronises the device)
-  if (total > c->la.d_pack.cap) {
-    int rc = grow(c, c->la.d_pack, total + total / 2);
-    if (rc) return rc;
-  }
+  // (with room to spare: the window count creeps up and down from call to call, and every re-allocation synchronises the device)
   if (first > c->la.h_cap) {
-    if (c->la.h_pack) (void)hipHostFree(c->la.h_pack);
+    if (c->la.h_pack) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(c->la.h_pack); }
     c->la.h_pack = nullptr; c->la.h_cap = 0;
     HIPCHK(c, hipHostMalloc((void **)&c->la.h_pack, first + first / 2, hipHostMallocDefault));
     c->la.h_cap = first + first / 2;
   }
+  // the kernel writes the packet into page-locked host memory itself (half a megabyte over the bus at the end of a pass): a
+  // device-side packet + hipMemcpyAsync cost the submitting call ~90 us of host time per pass
   GatedPack gp;
   gp.wtab = c->d_wtab; gp.wcount = c->d_wcount; gp.res = c->d_res; gp.wmax = n_hdr; gp.y = c->y();
-  gp.pack = (char *)c->la.d_pack.p; gp.n_hdr = n_hdr; gp.usual = usual; gp.cap = cap;
+  gp.pack = c->la.h_pack; gp.n_hdr = n_hdr; gp.usual = usual;
   gp.only_if = only_if;
   hipLaunchKernelGGL(gated_windows_kernel, dim3((unsigned)n_hdr), dim3(256), 0, c->stream, gp);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(c->la.h_pack, c->la.d_pack.p, first, hipMemcpyDeviceToHost, c->stream));
   return RFID_OK;
 }
 
@@ -2191,19 +2197,9 @@ int sio_submit(rfid_ctx *c, int b, int64_t n_new, bool flush) {
     HIPCHK(c, hipGetLastError());
     c->d_lens = nullptr;
     c->last_n_raw = n_have;
-    if (c->la.on && c->la.want_yn > 0) {   // look-ahead: the filter outputs the current rfid_mf_work call hands out
-      const int64_t lo = c->la.want_y0 - io.raw_base / DECIM;
-      if (lo < 0 || lo + c->la.want_yn > n_out) return fail(c, RFID_ERR_STATE, "look-ahead: matched-filter outputs out of range");
-      if ((size_t)c->la.want_yn > c->la.h_ycap) {
-        if (c->la.h_y) (void)hipHostFree(c->la.h_y);
-        c->la.h_y = nullptr; c->la.h_ycap = 0;
-        HIPCHK(c, hipHostMalloc((void **)&c->la.h_y, sizeof(rfid_cf32) * (size_t)c->la.want_yn * 2, hipHostMallocDefault));
-        c->la.h_ycap = (size_t)c->la.want_yn * 2;
-      }
-      HIPCHK(c, hipMemcpyAsync(c->la.h_y, c->d_y + lo, sizeof(rfid_cf32) * (size_t)c->la.want_yn, hipMemcpyDeviceToHost, c->stream));
-    }
   }
   if (c->la.on) HIPCHK(c, hipEventRecord(io.ev_y, c->stream));
+  g_la_t[14] += la_now() - tm_submit.t0; g_la_n[14]++;
   if (n_out > 0 && n_out < (c->la.on ? SIO_SMALL_DEC_LA : SIO_SMALL_DEC)) {
     // ---- a short pass (a scheduler's 8 k-item buffer, a small file): the long-stream front end is a string of ~45 launches
     //      that one trace of this length does not repay -- the sequential scan (one launch, ~10 ns per sample) goes over it
@@ -2245,9 +2241,13 @@ int sio_submit(rfid_ctx *c, int b, int64_t n_new, bool flush) {
       // look-ahead: nearly every pass ends with the front end's tables -- decode them and pack the results right behind
       // it (a pass that ends otherwise is decoded and packed again by sio_collect)
       c->ev_valid[2] = false;
+      const double t_d0 = la_now();
       if ((rc = rfid_batch_decode(c, 0))) return rc;
+      const double t_d1 = la_now();
+      g_la_t[15] += t_d1 - t_d0; g_la_n[15]++;
       ps.n_hdr = c->la.n_hdr; ps.usual = (ps.n_hdr / 2 + 1) * (EPC_WIN + RN16_WIN);   // (the types alternate)
       if ((rc = sio_enqueue_packet(c, ps.n_hdr, ps.usual, &c->d_ls2_ctl->ok))) return rc;   // (packed only if the front end made the tables)
+      g_la_t[16] += la_now() - t_d1; g_la_n[16]++;
       ps.prefetched = true;
     }
   }
@@ -2559,8 +2559,8 @@ void la_free(rfid_ctx *c) {
   if (la.on && c->stream) (void)hipStreamSynchronize(c->stream);   // (a submitted pass may still be copying into these buffers)
   if (la.h_pack) (void)hipHostFree(la.h_pack);
   if (la.h_y) (void)hipHostFree(la.h_y);
-  if (la.d_pack.p) (void)hipFree(la.d_pack.p);
   if (la.h_flag) (void)hipHostFree(la.h_flag);
+  if (la.d_done) (void)hipFree(la.d_done);
   la.wins.clear(); la.dq.clear();   // (their blocks go back to the pool, which is emptied next)
   for (rfid_ctx::LookAhead::Blk *b : la.pool) delete b;
   la.pool.clear();
@@ -2585,7 +2585,9 @@ void la_free(rfid_ctx *c) {
 
 // uploads n new stream samples (raw ones, or filter outputs when keyed on the gate) behind what is pending in d_buf[cur]
 int la_submit_pending(rfid_ctx *c);
-int la_append(rfid_ctx *c, const rfid_cf32 *src, int64_t n) {
+// staged != nullptr: no transfer is queued -- *staged is where the samples lie in page-locked memory (the caller's kernel reads
+// them from there and puts them into d_buf itself, and records ev_up behind it)
+int la_append(rfid_ctx *c, const rfid_cf32 *src, int64_t n, const rfid_cf32 **staged = nullptr) {
   rfid_ctx::StreamIO &io = c->sio;
   if (io.acc_new + n > io.max_chunk) {   // no room behind what is pending: that goes into a pass first
     const int rc = la_submit_pending(c);
@@ -2596,17 +2598,25 @@ int la_append(rfid_ctx *c, const rfid_cf32 *src, int64_t n) {
     HIPCHK(c, hipEventSynchronize(io.ev_free[up]));                       // the pass that last ran on this buffer has been collected
     HIPCHK(c, hipStreamWaitEvent(io.copy_stream, io.ev_hist, 0));         // ... and the history in front of its upload area is in place
   }
-  bool pinned = false;   // page-locked memory of the caller's (rfid_host_alloc, hipHostMalloc / hipHostRegister)?  then no staging copy
-  if (src == c->la.pin_next) pinned = c->la.pin_was;   // (a call that goes on where the last one ended: a scheduler walking through one buffer;
-  else {                                               //  a wrong guess costs a staging copy or a slower transfer, never a wrong one)
-    hipPointerAttribute_t attr;
-    if (hipPointerGetAttributes(&attr, src) == hipSuccess) pinned = (attr.type == hipMemoryTypeHost);
-    else (void)hipGetLastError();
+  // page-locked memory of the caller's (rfid_host_alloc, hipHostMalloc / hipHostRegister)?  then no staging copy -- but only where the
+  // call does not return before the device has read the samples (it waits for its own filter outputs, which lie behind
+  // the upload): a gate-keyed call and one with late outputs return at once, and the scheduler may reuse its buffer
+  bool pinned = false;
+  if (!io.ymode && !c->la.late) {
+    if (src == c->la.pin_next) pinned = c->la.pin_was;   // (a call that goes on where the last one ended: a scheduler walking through one buffer;
+    else {                                               //  a wrong guess costs a staging copy or a slower transfer, never a wrong one)
+      hipPointerAttribute_t attr;
+      if (hipPointerGetAttributes(&attr, src) == hipSuccess) pinned = (attr.type == hipMemoryTypeHost);
+      else (void)hipGetLastError();
+    }
+    c->la.pin_next = src + n; c->la.pin_was = pinned;
   }
-  c->la.pin_next = src + n; c->la.pin_was = pinned;
   if (!pinned) { memcpy(io.h_pin[up] + io.acc_new, src, sizeof(rfid_cf32) * (size_t)n); src = io.h_pin[up] + io.acc_new; }
-  HIPCHK(c, hipMemcpyAsync(io.d_buf[up] + io.tail_max + io.acc_new, src, sizeof(rfid_cf32) * (size_t)n, hipMemcpyHostToDevice, io.copy_stream));
-  HIPCHK(c, hipEventRecord(io.ev_up[up], io.copy_stream));
+  if (staged) *staged = src;
+  else {
+    HIPCHK(c, hipMemcpyAsync(io.d_buf[up] + io.tail_max + io.acc_new, src, sizeof(rfid_cf32) * (size_t)n, hipMemcpyHostToDevice, io.copy_stream));
+    HIPCHK(c, hipEventRecord(io.ev_up[up], io.copy_stream));
+  }
   io.acc_new += n;
   return RFID_OK;
 }
@@ -2625,7 +2635,6 @@ int la_submit_pending(rfid_ctx *c) {
     HIPCHK(c, hipMemcpyAsync(io.d_buf[up ^ 1] + (io.tail_max - io.hist()), io.d_buf[up] + (io.tail_max + io.acc_new - io.hist()),
                              sizeof(float2) * (size_t)io.hist(), hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipEventRecord(io.ev_hist, c->stream));
-  c->la.want_yn = 0;
   const int rc = sio_submit(c, up, io.acc_new, false);
   if (rc) { io.failed = true; return rc; }
   io.acc_new = 0;
@@ -2635,19 +2644,73 @@ int la_submit_pending(rfid_ctx *c) {
 
 bool same_sample(const rfid_cf32 &a, const rfid_cf32 &b) { return memcmp(&a, &b, sizeof(a)) == 0; }
 
-// rfid_mf_work with the look-ahead on: the call's samples go to the device, its filter outputs come back
+// rfid_mf_work with the look-ahead on: the call's samples go to the device, its filter outputs come back -- with late
+// outputs (rfid_lookahead_set_late_outputs) one call later
+namespace {
+// spins until the device has written `seq` behind the filter outputs in h_y
+int la_wait_flag(rfid_ctx *c, int seq) {
+  volatile int *fl = c->la.h_flag;
+  long spins = 0;
+  while (*fl - seq < 0) {            // (sequence numbers only grow: a later call's flag covers this one's too)
+    __builtin_ia32_pause();
+    if (++spins > 2000000L) {        // (~ tens of ms: something is wrong or very slow -- wait the ordinary way)
+      HIPCHK(c, hipStreamSynchronize(c->sio.copy_stream));
+      break;
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return RFID_OK;
+}
+}  // namespace
 int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap, int *n_produced) {
   LaTimer tm(0);
   rfid_ctx::StreamIO &io = c->sio;
   rfid_ctx::LookAhead &la = c->la;
-  if (!io.open || io.failed || la.flushed) return fail(c, RFID_ERR_STATE, "look-ahead: the stream has ended (rfid_ctx_reset starts a new one)");
+  const bool deliver_only = la.late && n_in == 0;   // (what is held back is handed out after the end of the stream too)
+  if (!io.open || io.failed || (la.flushed && !deliver_only))
+    return fail(c, RFID_ERR_STATE, "look-ahead: the stream has ended (rfid_ctx_reset starts a new one)");
   if (n_in > io.max_chunk) return fail(c, RFID_ERR_CAPACITY, "look-ahead: rfid_mf_work call larger than the max_chunk_raw given to rfid_lookahead_enable");
   const int64_t n_first = c->mf_seen / DECIM;
   const int n_out = (int)((c->mf_seen + n_in) / DECIM - n_first);
-  if (n_out > out_cap || (n_out > 0 && !out)) return RFID_ERR_CAPACITY;
-  int rc = la_append(c, in, n_in);
-  if (rc) { io.failed = true; return rc; }
-  g_la_t[4] += la_now() - tm.t0; g_la_n[4]++;   // (upload queued)
+  int give = 0;
+  if (la.late) {
+    const int held = la.pend_n - la.pend_off;
+    give = (held < out_cap) ? held : out_cap;
+    if (give > 0 && !out) return RFID_ERR_CAPACITY;
+    if (n_in > 0 && give < held)
+      return fail(c, RFID_ERR_CAPACITY, "look-ahead: rfid_mf_work with new samples while the outputs held back do not fit (rfid_mf_pending: fetch them first, n_in = 0)");
+  } else if (n_out > out_cap || (n_out > 0 && !out)) return RFID_ERR_CAPACITY;
+  int rc = RFID_OK;
+  const rfid_cf32 *staged = nullptr;   // with outputs to make: the filter's launch fetches the samples itself (mf_upload_kernel)
+  if (n_in > 0) {
+    rc = la_append(c, in, n_in, n_out > 0 ? &staged : nullptr);
+    if (rc) { io.failed = true; return rc; }
+  }
+  g_la_t[4] += la_now() - tm.t0; g_la_n[4]++;   // (samples staged)
+  // the outputs of the call before: the device wrote them (into the other half of h_y) while the scheduler ran the other blocks
+  auto hand_out = [&]() -> int {
+    const double t_y0 = la_now();
+    const rfid_cf32 *from = la.h_y + (size_t)la.pend_half * (la.h_ycap / 2);
+    if (!la.pend_ready) {
+      const int rc2 = la_wait_flag(c, la.pend_seq);
+      if (rc2) return rc2;
+      la.pend_ready = true;
+      la.y_push(la.pend_y0, from, (size_t)la.pend_n);
+    }
+    g_la_t[8] += la_now() - t_y0; g_la_n[8]++;
+    memcpy(out, from + la.pend_off, sizeof(rfid_cf32) * (size_t)give);
+    la.pend_off += give;
+    if (la.pend_off == la.pend_n) { la.pend_n = 0; la.pend_off = 0; }
+    return RFID_OK;
+  };
+  // (they are fetched BEHIND this call's launch -- the device starts on the new samples while the host copies the old outputs --
+  // unless there is no launch, or h_y has to grow first)
+  bool handed = give == 0;
+  if (!handed && (n_out == 0 || (size_t)n_out > la.h_ycap / 2)) {
+    rc = hand_out();
+    if (rc) return rc;
+    handed = true;
+  }
   if (n_out > 0) {
     // y[n] = sum x[5n - 24 .. 5n] for this call's outputs: the matched filter over the new samples, whose history lies in
     // front of them in the buffer, on the copy stream (the pass before may still be at work on the main stream)
@@ -2655,55 +2718,65 @@ int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int o
     if (!la.h_flag) {
       HIPCHK(c, hipHostMalloc((void **)&la.h_flag, 64, hipHostMallocDefault));
       *la.h_flag = 0;
+      HIPCHK(c, hipMalloc((void **)&la.d_done, 64));
+      HIPCHK(c, hipMemsetAsync(la.d_done, 0, 64, io.copy_stream));
     }
-    if ((size_t)n_out > la.h_ycap) {
-      if (la.h_y) (void)hipHostFree(la.h_y);
+    if ((size_t)n_out > la.h_ycap / 2) {   // two halves: this call's outputs, and those of the call before (late outputs)
+      if (la.h_y) { HIPCHK(c, hipStreamSynchronize(io.copy_stream)); (void)hipHostFree(la.h_y); }
       la.h_y = nullptr; la.h_ycap = 0;
-      HIPCHK(c, hipHostMalloc((void **)&la.h_y, sizeof(rfid_cf32) * (size_t)n_out * 2, hipHostMallocDefault));
-      la.h_ycap = (size_t)n_out * 2;
+      HIPCHK(c, hipHostMalloc((void **)&la.h_y, sizeof(rfid_cf32) * (size_t)n_out * 4, hipHostMallocDefault));
+      la.h_ycap = (size_t)n_out * 4;
     }
-    MfArgs a;
-    a.x = io.d_buf[io.cur] + io.tail_max + (io.acc_new - n_in) - SIO_HIST;     // (raw sample mf_seen - 28)
-    a.x_stride = SIO_HIST + n_in; a.n_raw = SIO_HIST + n_in; a.lens = nullptr;
-    a.n_out = n_out; a.in_off = (int)(DECIM * n_first - c->mf_seen) + SIO_HIST - (NTAPS - 1);   // 0 .. 4
-    a.vec_ok = ((((uintptr_t)a.x) & 15) == 0 && (a.in_off % 2) == 0) ? 1 : 0;
+    const int half = la.late ? (la.pend_half ^ 1) : 0;
+    rfid_cf32 *y_here = la.h_y + (size_t)half * (la.h_ycap / 2);
+    // ONE launch: the samples come out of page-locked memory, go into the buffer the passes read and through the filter;
     // the outputs go straight into page-locked host memory (the device writes it over the bus: no copy to set up), a word
-    // behind them says they are there, and the host spins on that word (an event's wake-up costs more than the filter)
-    a.y = (float2 *)la.h_y; a.y_stride = n_out; a.tile0 = 0; a.stream0 = 0;
-    const int tiles = (n_out + MF_TILE - 1) / MF_TILE;
-    hipLaunchKernelGGL(mf_boxcar25_decim5_kernel, dim3((unsigned)tiles, 1), dim3(MF_THREADS), 0, io.copy_stream, a);
-    HIPCHK(c, hipGetLastError());
+    // behind them says they are there, and the host spins on that word (an event's wake-up costs more than the filter).
+    // (Until the middle of round 5: a transfer, the filter's launch and a launch for the word -- the hand-over from the copy
+    // engine to the kernel queue alone was ~15 of the ~40 us a call's samples took through the device.)
+    MfUploadArgs a;
+    a.src = (const float2 *)staged;
+    a.x = io.d_buf[io.cur] + io.tail_max + (io.acc_new - n_in) - SIO_HIST;     // (raw sample mf_seen - 28)
+    a.hist = SIO_HIST; a.n_new = n_in;
+    a.n_out = n_out; a.in_off = (int)(DECIM * n_first - c->mf_seen) + SIO_HIST - (NTAPS - 1);   // 0 .. 4
+    a.y = (float2 *)y_here;
+    a.done = la.d_done; a.flag = la.h_flag;
     const int seq = ++la.flag_seq;
-    hipLaunchKernelGGL(host_flag_kernel, dim3(1), dim3(64), 0, io.copy_stream, la.h_flag, seq);
+    a.seq = seq;
+    const int tiles = (n_out + MF_TILE - 1) / MF_TILE;
+    hipLaunchKernelGGL(mf_upload_kernel, dim3((unsigned)tiles), dim3(MF_THREADS), 0, io.copy_stream, a);
     HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(io.ev_up[io.cur], io.copy_stream));
     g_la_t[5] += la_now() - t_sp; g_la_n[5]++;
-    const double t_y0 = la_now();
-    {
-      volatile int *fl = la.h_flag;
-      long spins = 0;
-      while (*fl != seq) {
-        __builtin_ia32_pause();
-        if (++spins > 2000000L) {      // (~ tens of ms: something is wrong or very slow -- wait the ordinary way)
-          HIPCHK(c, hipStreamSynchronize(io.copy_stream));
-          break;
-        }
+    if (la.late) {
+      if (!handed) {
+        rc = hand_out();
+        if (rc) return rc;
+        handed = true;
       }
-      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      la.pend_y0 = n_first; la.pend_n = n_out; la.pend_off = 0; la.pend_seq = seq; la.pend_ready = false; la.pend_half = half;
+    } else {
+      const double t_y0 = la_now();
+      rc = la_wait_flag(c, seq);
+      if (rc) return rc;
+      g_la_t[8] += la_now() - t_y0; g_la_n[8]++;
+      memcpy(out, y_here, sizeof(rfid_cf32) * (size_t)n_out);
+      la.y_push(n_first, y_here, (size_t)n_out);
+      give = n_out;
     }
-    g_la_t[8] += la_now() - t_y0; g_la_n[8]++;
-    memcpy(out, la.h_y, sizeof(rfid_cf32) * (size_t)n_out);
-    la.y_push(n_first, la.h_y, (size_t)n_out);
   }
   c->mf_seen += n_in;
-  la.stall = 0;
-  la.tail_tried = false;
-  if (!la.exact_open && io.acc_new / DECIM >= la.coalesce) {
+  if (n_in > 0) {
+    la.stall = 0;
+    la.tail_tried = false;
+  }
+  if (!la.flushed && !la.exact_open && io.acc_new / DECIM >= la.coalesce) {
     const double t_c0 = la_now();
     rc = la_submit_pending(c);
     g_la_t[6] += la_now() - t_c0; g_la_n[6]++;
     if (rc) return rc;
   }
-  *n_produced = n_out;
+  *n_produced = give;
   return RFID_OK;
 }
 
@@ -2925,7 +2998,6 @@ int rfid_lookahead_flush(rfid_ctx *c) {
   if (io.acc_new > 0) rc = la_submit_pending(c);
   if (!rc) rc = sio_collect(c);
   if (!rc && io.tail_len > 0) {
-    la.want_yn = 0;
     rc = sio_process(c, io.cur, 0, true);   // rfid_stream_work's flush: everything available is decided now
   }
   if (rc) { io.failed = true; return rc; }
@@ -2982,8 +3054,7 @@ int rfid_lookahead_drain(rfid_ctx *c) {
     if (io.acc_new > 0) rc = la_submit_pending(c);
     if (!rc) rc = sio_collect(c);
     if (!rc && !la.exact_open && io.tail_len > 0) {
-      la.want_yn = 0;
-      rc = sio_process(c, io.cur, 0, true);
+        rc = sio_process(c, io.cur, 0, true);
     }
     if (rc) { io.failed = true; return rc; }
   }
@@ -3001,6 +3072,20 @@ int rfid_lookahead_set_scheduler(rfid_ctx *c, int64_t gate_buffer_items) {
   if (gate_buffer_items == 0) { c->la.patient = true; c->la.coalesce = LA_COALESCE_DEFAULT; return RFID_OK; }
   c->la.patient = false;
   return rfid_lookahead_set_coalesce(c, gate_buffer_items / 4);
+}
+
+int rfid_lookahead_set_late_outputs(rfid_ctx *c, int on) {
+  if (!c) return RFID_ERR_INVALID;
+  if (!c->la.on || c->sio.ymode) return fail(c, RFID_ERR_STATE, "rfid_lookahead_set_late_outputs: needs the look-ahead keyed on rfid_mf_work");
+  if (c->la.pend_n > 0) return fail(c, RFID_ERR_STATE, "rfid_lookahead_set_late_outputs: outputs are held back (fetch them first)");
+  c->la.late = on != 0;
+  return RFID_OK;
+}
+
+int rfid_mf_pending(const rfid_ctx *c, int *n_outputs) {
+  if (!c || !n_outputs) return RFID_ERR_INVALID;
+  *n_outputs = c->la.on ? (c->la.pend_n - c->la.pend_off) : 0;
+  return RFID_OK;
 }
 
 int rfid_lookahead_set_coalesce(rfid_ctx *c, int64_t items) {

@@ -144,6 +144,9 @@ RFID_DEVICE uint64_t load_u64_agent(const uint64_t *p) {
 RFID_DEVICE void store_u64_agent(uint64_t *p, uint64_t v) {
   __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// a word in page-locked host memory, behind everything this wave has written (system scope)
+RFID_DEVICE void system_release_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); }   // this thread's stores, out to host memory
+RFID_DEVICE void store_i32_system_release(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 RFID_DEVICE void atomic_or64(uint64_t *p, uint64_t v) { atomicOr(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v); }
 RFID_DEVICE void atomic_and64(uint64_t *p, uint64_t v) { atomicAnd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v); }
 // this wave's global stores are visible device-wide when this returns

@@ -119,10 +119,64 @@ RFID_KERNEL(MF_THREADS) void mf_boxcar25_decim5_kernel(MfArgs a) {
   RFID_SHARED float4 tile4[MF_RAW / 2 + 2];
   mf_tile(a, (int)blockIdx.y + a.stream0, (int64_t)blockIdx.x + a.tile0, tile4);
 }
-// a word for the host behind the launches in front of it on the stream (page-locked host memory the device writes directly):
-// the host spins on it instead of paying an event's wake-up (look-ahead: a scheduler call waits for its filter outputs)
-RFID_KERNEL(64) void host_flag_kernel(int *flag, int v) {
-  if (threadIdx.x == 0) { __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+// Look-ahead, one rfid_mf_work call: the call's new raw samples come straight out of page-locked host memory -- no copy
+// engine in front of the filter, whose hand-over to the kernel queue was half of the call's way through the device.  Every
+// workgroup stages the window of its tile (the samples in front of the call from the device buffer, the new ones over the
+// bus), puts the new ones where the passes expect them, filters (mf_tile's sums) and writes its outputs to page-locked
+// memory; the last workgroup done tells the spinning host.
+struct MfUploadArgs {
+  const float2 *src;    // page-locked host memory: the call's n_new raw samples
+  float2 *x;            // device: x[0 .. hist) the samples in front of the call (there), x[hist + i] <- src[i]
+  int hist, n_new;
+  int n_out, in_off;    // output n = sum x[5 n + in_off .. + 24], 0 <= in_off < 5
+  float2 *y;            // page-locked host memory: the n_out outputs
+  int *done;            // device counter of the workgroups through (0 between launches)
+  int *flag, seq;       // page-locked word <- seq when everything is written
+};
+RFID_KERNEL(MF_THREADS) void mf_upload_kernel(MfUploadArgs a) {
+  RFID_SHARED float4 tile4[MF_RAW / 2 + 2];
+  float2 *tile = reinterpret_cast<float2 *>(tile4);
+  const int tid = (int)threadIdx.x, t = (int)blockIdx.x, T = (int)gridDim.x;
+  const int n_raw = a.hist + a.n_new;
+  const int r0 = t * (MF_TILE * DECIM) + a.in_off;
+  // the windows of neighbouring tiles share NTAPS - DECIM samples: a tile stores what its window has behind those (tile 0: all new ones)
+  const int c_lo = (t == 0) ? a.hist : r0 + (NTAPS - DECIM);
+  for (int j = tid; j < MF_RAW; j += MF_THREADS) {
+    const int r = r0 + j;
+    float2 v = make_float2(0.0f, 0.0f);
+    if (r < n_raw) {
+      if (r < a.hist) v = a.x[r];
+      else {
+        v = a.src[r - a.hist];
+        if (r >= c_lo) a.x[r] = v;
+      }
+    }
+    tile[j] = v;
+  }
+  if (t == T - 1)   // (behind the last window: the samples that wait for their group of five to complete)
+    for (int r = r0 + MF_RAW + tid; r < n_raw; r += MF_THREADS) a.x[r] = a.src[r - a.hist];
+  wv::block_sync();
+#pragma unroll
+  for (int rep = 0; rep < MF_TILE / MF_THREADS; ++rep) {
+    const int o = tid + rep * MF_THREADS;
+    const int n = t * MF_TILE + o;
+    float re = 0.0f, im = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NTAPS; ++k) {
+      const float2 v = tile[DECIM * o + k];
+      re = re + v.x;
+      im = im + v.y;
+    }
+    if (n < a.n_out) a.y[n] = make_float2(re, im);
+  }
+  wv::system_release_fence();
+  wv::block_sync();
+  if (tid == 0) {
+    if (wv::atomic_add(a.done, 1) == T - 1) {
+      *a.done = 0;
+      wv::store_i32_system_release(a.flag, a.seq);
+    }
+  }
 }
 // The same behind a pass that normally needs no filter launch (the long-stream front end with its fused first pass filters
 // inside ls2_front_kernel; when it gives the pass up, y is incomplete and the sequential scan behind it needs all of it):
@@ -1250,8 +1304,8 @@ RFID_KERNEL(64) void ls_cut2_kernel(LsCut2Args p) {
 struct GatedPack {
   const rfid_window *wtab; const int *wcount; const rfid_decode_result *res; int wmax;   // wmax: windows to pack at most
   const float2 *y;
-  char *pack;              // [hdr | g_lo[usual] | m_lo[usual] | g_hi[cap - usual] | m_hi[cap - usual]]
-  int n_hdr, usual, cap;
+  char *pack;              // page-locked host memory, written over the bus: [hdr | g[usual] | m[usual]] (what does not fit is left out:
+  int n_hdr, usual;        //  the host sees it from the records and asks again with the right sizes)
   const int *only_if;      // optional: pack nothing (count 0) unless *only_if != 0
 };
 constexpr int GATED_HDR = 64;   // bytes in front of the window records (the count)
@@ -1269,8 +1323,6 @@ RFID_KERNEL(256) void gated_windows_kernel(GatedPack a) {
   if (b < a.n_hdr && threadIdx.x == 0) { hw[b] = a.wtab[b]; hr[b] = a.res[b]; }
   float2 *g_lo = reinterpret_cast<float2 *>(pk + gated_pack_hdr_bytes(a.n_hdr));
   float *m_lo = reinterpret_cast<float *>(g_lo + a.usual);
-  float2 *g_hi = reinterpret_cast<float2 *>(m_lo + a.usual);
-  float *m_hi = reinterpret_cast<float *>(g_hi + (a.cap - a.usual));
   int off = 0;
   for (int k = 0; k < b; ++k) off += a.wtab[k].type ? EPC_WIN : RN16_WIN;
   const rfid_window w = a.wtab[b];
@@ -1279,9 +1331,7 @@ RFID_KERNEL(256) void gated_windows_kernel(GatedPack a) {
     const float2 v = a.y[w.start + i];
     const float re = v.x - w.dc_re, im = v.y - w.dc_im;
     const int k = off + i;
-    if (k >= a.cap) continue;
     if (k < a.usual) { g_lo[k] = make_float2(re, im); m_lo[k] = re * re + im * im; }
-    else { g_hi[k - a.usual] = make_float2(re, im); m_hi[k - a.usual] = re * re + im * im; }
   }
 }
 

@@ -116,7 +116,6 @@ struct Ls2Args {
   int *cutf;                    // [n_streams][max_b] from ls_cut_kernel: where avg_ampl is at rest (100 carrier samples before)
   Ls2Piece *piece;              // [NS]
   int *nextv, *prevv;           // [NS] next / previous slot in use of the same trace, -1 none
-  float *amp;                   // [n_streams][y_stride]: |x| of every sample (the re-runs form the addends (|x| - ring)/100 again from it)
   uint64_t *votes;              // [n_streams][vstride][2]: below, above; bit b of word w = sample 64 w + b (zeroed before a pass)
   uint64_t *closed;             // [n_streams][cstride]
   int *openinfo;                // [n_streams][cstride]: lane | type << 8 of the step's opening, 0xff none
@@ -449,21 +448,21 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
   const int last_idx = n_total - 1;   // (n_total >= p1 > 0)
   const int64_t row = (int64_t)s * a.y_stride;
   const float2 *yr = a.y + row;
-  float *ampr = a.amp + row;
   uint64_t *votes = a.votes + 2 * ((int64_t)s * a.vstride + w0);
   const int base = 64 * w0;
   float sA;
   float a2 = 0.0f, a1 = 0.0f;   // amplitudes of the 128 samples before the step (the ring of gate_impl.cc:131 holds the last 100)
+  // |x| of sample idx < base: from the samples (formed again wherever it is needed -- a record of it would be 4 bytes written
+  // per sample for the few pieces that run twice), or (before the start of the trace) the carried ring / the fresh gate's zeros
+  auto hist = [&](int idx) -> float {
+    if (idx >= 0) { const float2 v = yr[idx]; return wv::hypot_f(v.x, v.y); }
+    if (!a.carry || idx < -WIN_LEN) return 0.0f;
+    const GateState *cs = a.carry + s;   // sample -k (k = 1..100): win[(win_index - k) mod 100] (win_index = the oldest = next written)
+    return cs->win[(cs->win_index + idx + 2 * WIN_LEN) % WIN_LEN];
+  };
+  a2 = hist(base - 128 + lane);
+  a1 = hist(base - 64 + lane);
   if (FIRST) {
-    // |x| of sample idx < base: from the samples, or (before the start of the trace) the carried ring / the fresh gate's zeros
-    auto hist = [&](int idx) -> float {
-      if (idx >= 0) { const float2 v = yr[idx]; return wv::hypot_f(v.x, v.y); }
-      if (!a.carry || idx < -WIN_LEN) return 0.0f;
-      const GateState *cs = a.carry + s;   // sample -k (k = 1..100): win[(win_index - k) mod 100] (win_index = the oldest = next written)
-      return cs->win[(cs->win_index + idx + 2 * WIN_LEN) % WIN_LEN];
-    };
-    a2 = hist(base - 128 + lane);
-    a1 = hist(base - 64 + lane);
     if (j == 0) {
       sA = a.carry ? wv::uniform(a.carry[s].avg_ampl) : 0.0f;   // the exact start of the trace
     } else {
@@ -474,16 +473,6 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
       sA = wv::uniform(part) / WIN_LEN_F;
     }
   } else {
-    // |x| of the samples before the step from the first pass's record (every piece's first pass is through); before the start of
-    // the trace the carried ring / the fresh gate's zeros
-    auto hist = [&](int idx) -> float {
-      if (idx >= 0) return ampr[idx];
-      if (!a.carry || idx < -WIN_LEN) return 0.0f;
-      const GateState *cs = a.carry + s;
-      return cs->win[(cs->win_index + idx + 2 * WIN_LEN) % WIN_LEN];
-    };
-    a2 = hist(base - 128 + lane);
-    a1 = hist(base - 64 + lane);
     sA = wv::uniform(a.arun[i].s);
   }
   // a piece that passes so close to a power of two that hardly any shift is provable is run from six neighbouring start
@@ -505,35 +494,30 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
   int min_dv = 0x7fffffff;
   constexpr int AHEAD = 4;
   float2 ybuf[AHEAD];
-  float abuf[AHEAD];
 #pragma unroll
   for (int u = 0; u < AHEAD; ++u) {
     const int idx = base + 64 * u + lane;
     // (loads past the end of the trace are clamped, not predicated: their lanes are not `valid` and add +0; an unconditional
-    // load lands in the register the step reads it from -- no copies at the loop's end that would wait for all of them)
-    if (FIRST) ybuf[u] = yr[(idx < n_total) ? idx : last_idx];
-    else abuf[u] = ampr[(idx < n_total) ? idx : last_idx];   // (the step's lanes outside the piece too: they are the ring of the samples behind them)
+    // load lands in the register the step reads it from -- no copies at the loop's end that would wait for all of them;
+    // the step's lanes outside the piece too: they are the ring of the samples behind them)
+    ybuf[u] = yr[(idx < n_total) ? idx : last_idx];
   }
   uint64_t my_lt = 0, my_gt = 0;   // lane (k & 63) keeps the votes of step k until 64 steps are stored together
   // one step.  The groups of AHEAD steps that are complete run without a condition around a step: every buffer is read and
   // loaded again in place, and the loop's only waits are counted ones for the oldest load.  (With the steps guarded one by one
   // the compiler kept the fresh loads in other registers and copied them at the loop's end -- behind a wait for ALL of them:
   // the read-ahead was one step deep, not four.)  The last, incomplete group reads what is left of the buffers.
-  auto step = [&](const int k, float2 &yb, float &ab_, const bool reload) {
+  auto step = [&](const int k, float2 &yb, const bool reload) {
       {
         const int idx = base + 64 * k + lane;
         const bool valid = idx >= p0 && idx < p1;
         float amp, d;
-        if (FIRST) {
+        {
           const float2 v = yb;
           amp = wv::hypot_f(v.x, v.y);
           // (the buffer is loaded again once its value is used up: the load lands in the same register -- issued before
           // that, the compiler kept it elsewhere and copied it at the loop's end behind a wait for all loads in flight)
           if (reload) { const int nx = idx + 64 * AHEAD; yb = yr[(nx < n_total) ? nx : last_idx]; }
-          if (valid) ampr[idx] = amp;
-        } else {
-          amp = ab_;
-          if (reload) { const int nx = idx + 64 * AHEAD; ab_ = ampr[(nx < n_total) ? nx : last_idx]; }
         }
         {
           // sample i - 100: lanes 0..35 take it from two steps back (lane + 28), lanes 36..63 from the previous step (lane - 36)
@@ -610,11 +594,11 @@ RFID_DEVICE void ls2_avg_piece(const Ls2Args &a, const int i, const int lane) {
   int kb = 0;
   for (; kb + AHEAD <= nsteps; kb += AHEAD) {
 #pragma unroll
-    for (int u = 0; u < AHEAD; ++u) step(kb + u, ybuf[u], abuf[u], true);
+    for (int u = 0; u < AHEAD; ++u) step(kb + u, ybuf[u], true);
   }
 #pragma unroll
   for (int u = 0; u < AHEAD - 1; ++u)
-    if (kb + u < nsteps) step(kb + u, ybuf[u], abuf[u], false);
+    if (kb + u < nsteps) step(kb + u, ybuf[u], false);
   {
     const int mb = ls2_range_margin(rgA, rgB);
     const int mv = (min_dv == 0x7fffffff) ? min_dv : ((min_dv - 3) >> 1);
@@ -801,7 +785,6 @@ RFID_DEVICE void ls2_front_piece(const Ls2Args &a, const int i, const int lane, 
   const int k0 = (j == 0) ? 0 : (kg - LS2_FRONT_PRE);                // (P >= 512: kg >= 8)
   const int64_t row = (int64_t)s * a.y_stride;
   float2 *yw = a.y_w + row;
-  float *ampr = a.amp + row;
   uint64_t *lowm = a.lowm + (int64_t)s * a.cstride;
   const float2 *xs = a.raw + (int64_t)s * a.raw_stride;
   const bool vec = a.raw_vec_ok != 0;
@@ -865,7 +848,7 @@ RFID_DEVICE void ls2_front_piece(const Ls2Args &a, const int i, const int lane, 
     const float theta = LS2_CARRIER_FRAC2 * wv::u2f((Mk > Mprev) ? Mk : Mprev);
     const uint64_t lowmask = wv::ballot(!valid) | wv::ballot(m2 < theta);
     if (running) {
-      if (valid) { yw[idx] = yv; ampr[idx] = amp; }
+      if (valid) yw[idx] = yv;
       if (lane == 0) lowm[k] = lowmask;
       // sample i - 100: lanes 0..35 take it from two blocks back (lane + 28), lanes 36..63 from the previous block (lane - 36)
       const float o2 = wv::shfl(a2, (lane + 28) & 63), o1 = wv::shfl(a1, (lane - 36) & 63);
@@ -2247,7 +2230,6 @@ RFID_KERNEL(64) void ls2_carry_kernel(Ls2Args a) {
   const int end = wv::uniform(pc.pos0) + wv::uniform(pc.len);
   GateState *st = a.carry_out + s;
   const float2 *yrow = a.y + (int64_t)s * a.y_stride;
-  const float *amp = a.amp + (int64_t)s * a.y_stride;
   // avg_ampl after the piece: its true start through its latest run
   const Ls2AvgRun ar = a.arun[last];
   const int Da = wv::uniform(a.aT[last]) - ls2_ord(ar.s);
@@ -2263,7 +2245,9 @@ RFID_KERNEL(64) void ls2_carry_kernel(Ls2Args a) {
   }
   for (int k = lane; k < WIN_LEN; k += 64) {
     const int idx = end - WIN_LEN + k;
-    st->win[k] = (idx >= 0) ? amp[idx] : 0.0f;
+    float w = 0.0f;
+    if (idx >= 0) { const float2 v = yrow[idx]; w = wv::hypot_f(v.x, v.y); }
+    st->win[k] = w;
   }
   if (lane < DC_LEN) {
     const int idx = end - DC_LEN + lane;

@@ -10,7 +10,10 @@
 
 namespace rfidk {
 
-constexpr int LS2_TARGET_PIECES = 131072;  // pieces per pass to aim for (all traces together)
+#ifndef LS2_TARGET_PIECES_N                // (experiment builds: make EXTRA_DEFS=-DLS2_TARGET_PIECES_N=...)
+#define LS2_TARGET_PIECES_N 131072
+#endif
+constexpr int LS2_TARGET_PIECES = LS2_TARGET_PIECES_N;  // pieces per pass to aim for (all traces together)
 constexpr int LS2_MIN_PIECE = 512;         // ... of at least this many decimated samples; idle cuts are searched every LS2_FINE pieces
                                            // (a cut needs LS_QUIET = 1615 idle samples before it)
 
@@ -40,7 +43,7 @@ inline Ls2Geometry ls2_geometry(int n_streams, int64_t n_dec, int min_piece = LS
 
 // work space: one allocation, carved up here (offsets in bytes, 256-byte aligned)
 struct Ls2Layout {
-  size_t cut, cutf, piece, nextv, prevv, upiece, unextv, uprevv, lb_fn, lb_end, lb_water, amp, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, drun, dT, dcut, dend, dlist, seq0, flat_base, cflag, cagg, ctl, consumed, total;
+  size_t cut, cutf, piece, nextv, prevv, upiece, unextv, uprevv, lb_fn, lb_end, lb_water, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, drun, dT, dcut, dend, dlist, seq0, flat_base, cflag, cagg, ctl, consumed, total;
 };
 inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_stride) {
   Ls2Layout L;
@@ -58,7 +61,6 @@ inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_strid
   L.lb_fn = take(sizeof(uint64_t) * NS);
   L.lb_end = take(sizeof(uint64_t) * NS);
   L.lb_water = take(sizeof(int) * B);
-  L.amp = take(sizeof(float) * B * (size_t)y_stride);
   L.votes = take(sizeof(uint64_t) * 2 * B * (size_t)g.vstride);
   L.closed = take(sizeof(uint64_t) * B * (size_t)g.cstride);
   L.openinfo = take(sizeof(int) * B * (size_t)g.cstride);
@@ -88,7 +90,6 @@ inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geomet
   a.nextv = (int *)(base + L.nextv); a.prevv = (int *)(base + L.prevv);
   a.upiece = (Ls2Piece *)(base + L.upiece); a.unextv = (int *)(base + L.unextv); a.uprevv = (int *)(base + L.uprevv);
   a.lb_fn = (uint64_t *)(base + L.lb_fn); a.lb_end = (uint64_t *)(base + L.lb_end); a.lb_water = (int *)(base + L.lb_water);
-  a.amp = (float *)(base + L.amp);
   a.lowm = (uint64_t *)(base + L.closed);   // (fused first pass: the blocks' not-carrier masks live there until the state machine runs)
   a.votes = (uint64_t *)(base + L.votes); a.closed = (uint64_t *)(base + L.closed); a.openinfo = (int *)(base + L.openinfo);
   a.arun = (Ls2AvgRun *)(base + L.arun); a.aT = (int *)(base + L.aT); a.alist = (int *)(base + L.alist); a.aover = (Ls2Aff *)(base + L.aover);

@@ -241,13 +241,23 @@ class matched_filter_impl : public matched_filter {
     if (g_current && !g_current->has_filter) { *d_slot = g_current; g_current->has_filter = true; }
     else g_pending_filters.push_back(d_slot);
   }
-  void forecast(int noutput_items, gr_vector_int &ninput_items_required) override { ninput_items_required[0] = noutput_items * 5; }
+  // outputs of the last call the library still holds (late outputs, see general_work)
+  int held_back() const {
+    int n = 0;
+    if (d_late && *d_slot) (void)rfid_mf_pending((**d_slot).ctx, &n);
+    return n;
+  }
+  // a decimator by 5 -- except while outputs are held back: they need no input to be handed out (so a runtime calls the block
+  // once more when its source is done, block_executor.cc: a block whose forecast is met is called)
+  void forecast(int noutput_items, gr_vector_int &ninput_items_required) override {
+    ninput_items_required[0] = held_back() > 0 ? 0 : noutput_items * 5;
+  }
   int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
                    gr_vector_void_star &output_items) override {
     if (!*d_slot) throw mi355x::error(RFID_ERR_STATE, "gr::rfid::matched_filter: no gate constructed yet");
     stream &st = **d_slot;
     // a decimator consumes what its output has room for (sync_decimator: noutput * decim), however much the scheduler offers
-    const int n_in = std::min(ninput_items[0], 5 * noutput_items);
+    int n_in = std::min(ninput_items[0], 5 * noutput_items);
     if (!d_started) {
       d_started = true;
       // the look-ahead's staging is sized for a scheduler buffer of 64 k items (GNU Radio's default is 32 k complex items); a
@@ -256,7 +266,19 @@ class matched_filter_impl : public matched_filter {
         const int64_t cap = std::max<int64_t>(std::min<int64_t>(std::max<int64_t>(5 * (int64_t)noutput_items, ninput_items[0]), 5 * 262144), 5 * 8192) + 64;
         st.check(rfid_lookahead_enable(st.ctx, cap), "rfid_lookahead_enable");
         tell_buffers(st.ctx, output_buffer_items(this));     // (this block's output buffer is the gate's input)
+        // Late outputs (rfid_lookahead_set_late_outputs): a call returns the filter outputs of the call before it, which
+        // the device finished while the scheduler ran the other blocks, instead of waiting ~28 us for its own
+        // (RFID_MF_LATE_OUTPUTS=0: every call returns its own)
+        if (env_int("RFID_MF_LATE_OUTPUTS", 1) != 0) {
+          st.check(rfid_lookahead_set_late_outputs(st.ctx, 1), "rfid_lookahead_set_late_outputs");
+          d_late = true;
+          d_call_max = (int)std::min<int64_t>(((cap - 64) / 5) * 5, 0x7fffffff);
+        }
       }
+    }
+    if (d_late) {
+      if (n_in > d_call_max) n_in = d_call_max;
+      if (held_back() > noutput_items) n_in = 0;   // (no room for all that is held back: that first, in parts)
     }
     int n_out = 0;
     st.check(rfid_mf_work(st.ctx, (const rfid_cf32 *)input_items[0], n_in, (rfid_cf32 *)output_items[0],
@@ -269,7 +291,8 @@ class matched_filter_impl : public matched_filter {
     return true;
   }
   std::shared_ptr<stream_sptr> d_slot;   // bound now or by the next gate
-  bool d_started = false;
+  bool d_started = false, d_late = false;
+  int d_call_max = 0;
 };
 
 }  // namespace
@@ -345,8 +368,14 @@ void sts_flowgraph::run(const gr_complex *samples, size_t n) {
   gr_vector_int g_nin(1, 0), d_nin(1, 0);                       // (the per-call argument vectors, made once)
   gr_vector_const_void_star g_in(1, nullptr), d_in(1, nullptr);
   gr_vector_void_star g_out(1, nullptr), d_out(2, nullptr);
-  while (pos < n || g_rd < gq.size()) {
-    if (pos < n) {
+  // (a matched_filter block with late outputs holds the outputs of its last call: it is called until it has handed them out)
+  auto mf_holds = [&]() -> bool {
+    int held = 0;
+    if (d_mf && own_ctx) (void)rfid_mf_pending(own_ctx, &held);
+    return held > 0;
+  };
+  while (pos < n || g_rd < gq.size() || mf_holds()) {
+    if (pos < n || mf_holds()) {
       const size_t take = (n - pos < (size_t)d_chunk * in_per_out) ? (n - pos) : (size_t)d_chunk * in_per_out;
       // (what has been read is dropped once it is most of the queue: the gate may leave tens of thousands of items standing
       // while a pass gathers, and moving them once per 8 192-item turn was a third of the run)
@@ -395,7 +424,7 @@ void sts_flowgraph::run(const gr_complex *samples, size_t n) {
       if (consumed == 0 && written == 0) {
         // the gate can decide nothing on what it has: more input first.  At the end of the input the library is told so
         // (with its look-ahead on, what it still holds back is decided then), and the gate asked again
-        if (pos < n) break;
+        if (pos < n || mf_holds()) break;
         if (!d_flushed) {
           d_flushed = true;
           if (own_ctx) (void)rfid_lookahead_flush(own_ctx);
@@ -449,7 +478,7 @@ void bounded_flowgraph::run(const gr_complex *samples, size_t n) {
                   int &consumed, int &produced) -> bool {
     consumed = 0; produced = 0;
     if (nd_.done) return false;
-    if (n_in_avail == 0 && in_done && !nd_.source_like) { nd_.done = true; return false; }   // block_executor.cc: no input left, upstream done
+    // (no input left and the upstream neighbour done: the block is done unless its forecast() asks for nothing -- below)
     if (out_room == 0) return false;                                                         // blocked on output
     int noutput = (int)out_room;
     gr_vector_int req(1, 0);

@@ -48,7 +48,7 @@ int main(int argc, char **argv) {
   const char *path = nullptr, *tx_path = nullptr, *mf_path = nullptr, *gate_path = nullptr;
   int device = 0, chunk = 8192;
   long whole_chain = 0;
-  bool show_time = false, host_fir = false, bounded = false;
+  bool show_time = false, host_fir = false, bounded = false, pageable = false;
   int buffer_items = 8192;
   int fixed_q = gr::rfid::FIXED_Q, max_q = gr::rfid::MAX_NUM_QUERIES, uniq = gr::rfid::NUMBER_UNIQUE_TAGS;
   for (int i = 1; i < argc; ++i) {
@@ -67,6 +67,7 @@ int main(int argc, char **argv) {
     else if (!std::strcmp(argv[i], "--whole-chain")) whole_chain = std::atol(need("--whole-chain"));
     else if (!std::strcmp(argv[i], "--time")) show_time = true;
     else if (!std::strcmp(argv[i], "--host-fir")) host_fir = true;
+    else if (!std::strcmp(argv[i], "--pageable")) pageable = true;   // the trace in ordinary memory (what a GNU Radio buffer is)
     else if (!std::strcmp(argv[i], "--scheduler")) { const char *v = need("--scheduler"); bounded = !std::strcmp(v, "bounded"); if (!bounded && std::strcmp(v, "sts")) { std::cerr << "--scheduler sts|bounded\n"; return 2; } }
     else if (!std::strcmp(argv[i], "--buffer")) buffer_items = std::atoi(need("--buffer"));
     else if (argv[i][0] == '-') { std::cerr << "unknown option " << argv[i] << "\n"; return 2; }
@@ -91,7 +92,7 @@ int main(int argc, char **argv) {
     bool empty() const { return n == 0; }
   } samples;
   samples.n = (size_t)(bytes / (std::streamsize)sizeof(gr_complex));
-  samples.p = static_cast<gr_complex *>(rfid_host_alloc(samples.n * sizeof(gr_complex)));
+  samples.p = pageable ? nullptr : static_cast<gr_complex *>(rfid_host_alloc(samples.n * sizeof(gr_complex)));
   samples.locked = samples.p != nullptr;
   if (!samples.p) samples.p = new gr_complex[samples.n ? samples.n : 1];
   if (!samples.empty() && !f.read(reinterpret_cast<char *>(samples.data()), (std::streamsize)(samples.size() * sizeof(gr_complex)))) {

@@ -107,6 +107,8 @@ SIGNATURES = {
     "rfid_lookahead_pending": (_i, [_vp, _ip, _ip]),
     "rfid_lookahead_set_coalesce": (_i, [_vp, _i64]),
     "rfid_lookahead_drain": (_i, [_vp]),
+    "rfid_lookahead_set_late_outputs": (_i, [_vp, _i]),
+    "rfid_mf_pending": (_i, [_vp, _ip]),
     "rfid_lookahead_set_scheduler": (_i, [_vp, _i64]),
     "rfid_abi_version": (_i, []),
     "rfid_lookahead_flush": (_i, [_vp]),

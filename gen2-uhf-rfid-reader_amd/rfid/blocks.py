@@ -56,7 +56,9 @@ class matched_filter(_Block):
     def __init__(self, decim: int = 5, taps=(1,) * 25, ctx: Optional[Context] = None):
         if decim != 5 or len(taps) != 25 or any(complex(t) != 1 for t in taps):
             raise ValueError("only fir_filter_ccc(5, [1]*25) is built (apps/reader.py:65,75)")
-        if ctx is None and _bind.current is not None and not _bind.has_filter:
+        # (a gate built before its filter takes it -- unless its stream is closed already, or it said that its filter is
+        # somebody else's: filter_is_external())
+        if ctx is None and _bind.current is not None and not _bind.has_filter and getattr(_bind.current, "_h", None):
             ctx = _bind.current
             _bind.has_filter = True
         super().__init__(ctx)
@@ -78,6 +80,12 @@ class gate(_Block):
         _bind.has_filter = False
         if _bind.pending_filters:
             _bind.pending_filters.pop(0).ctx = ctx
+            _bind.has_filter = True
+
+    def filter_is_external(self) -> None:
+        """This gate is fed by a filter that is not this library's (apps/reader.py:75 as it stands): a rfid.matched_filter built
+        later belongs to the NEXT gate, not to this one."""
+        if _bind.current is self.ctx:
             _bind.has_filter = True
 
     def general_work(self, x) -> Tuple[int, np.ndarray]:

@@ -83,12 +83,26 @@ class Context:
         return buf.raw[: n.value].decode()
 
     # -- (1) streaming, host buffers ---------------------------------------------------------
-    def mf_work(self, x) -> np.ndarray:
+    def mf_work(self, x, out_cap: Optional[int] = None) -> np.ndarray:
+        """rfid_mf_work.  With late outputs (lookahead_set_late_outputs) the call returns what the call before it made;
+        out_cap: the room the caller's output buffer has (default: this call's outputs, or everything held back)."""
         x = _c64(x)
-        out = np.empty(len(x) // 5 + 2, dtype=np.complex64)
+        if out_cap is None:
+            out_cap = max(len(x) // 5 + 2, self.mf_pending())
+        out = np.empty(max(int(out_cap), 1), dtype=np.complex64)
         n = C.c_int(0)
-        self._chk(self._lib.rfid_mf_work(self._h, x.ctypes.data, len(x), out.ctypes.data, len(out), C.byref(n)))
+        self._chk(self._lib.rfid_mf_work(self._h, x.ctypes.data if len(x) else None, len(x), out.ctypes.data, int(out_cap), C.byref(n)))
         return out[: n.value].copy()
+
+    def lookahead_set_late_outputs(self, on: bool = True) -> None:
+        """mf_work returns the filter outputs of the call before it (no call waits for the device); mf_work(empty) fetches
+        what is held back at the end of the input."""
+        self._chk(self._lib.rfid_lookahead_set_late_outputs(self._h, 1 if on else 0))
+
+    def mf_pending(self) -> int:
+        n = C.c_int(0)
+        self._chk(self._lib.rfid_mf_pending(self._h, C.byref(n)))
+        return n.value
 
     def gate_work(self, x) -> Tuple[int, np.ndarray]:
         """-> (consumed, gated samples), as gate_impl::general_work's consume_each()/output."""

@@ -52,6 +52,8 @@ class reader_top_block:
         self.external_filter = bool(external_filter)
         self.matched_filter = None if external_filter else blocks.matched_filter(self.decim, self.num_taps)
         self.gate = blocks.gate(int(self.adc_rate / self.decim), device=device, **params)
+        if external_filter:
+            self.gate.filter_is_external()
         self.tag_decoder = blocks.tag_decoder(int(self.adc_rate / self.decim))
         self.reader = blocks.reader(int(self.adc_rate / self.decim), int(self.dac_rate))
         self.ctx = self.gate.ctx

@@ -239,6 +239,21 @@ RFID_API int rfid_lookahead_enable_gate(rfid_ctx *ctx, int64_t max_items);
  * staging]).  An adaptor that knows its scheduler's buffers tells the library here: with input buffers of C items the
  * gate can never be shown more than C, so it asks for C / 4 (a gate call shown 2 x this many items decides at once). */
 RFID_API int rfid_lookahead_set_coalesce(rfid_ctx *ctx, int64_t items);
+/* Late filter outputs (look-ahead keyed on rfid_mf_work only; off by default).  A rfid_mf_work call that returns its own
+ * outputs waits for an upload, a filter launch and the way back: ~28 us per call, a third of a block-by-block run at GNU
+ * Radio's default buffers.  With late outputs on, a call uploads and filters its samples as before but RETURNS THE OUTPUTS
+ * OF THE CALL BEFORE IT -- the device wrote them into page-locked memory while the scheduler ran the other blocks -- and
+ * keeps its own for the next call: *n_produced is then what that earlier call made, not n_in / 5 of this one.  A gr::block
+ * may do that (general_work consumes and produces what it says): the adaptor's forecast() asks for no input while
+ * outputs are held back, so a scheduler calls the block once more at the end of the input -- with n_in = 0, which hands
+ * out what is held back (also after rfid_lookahead_flush) and does nothing else.  Outputs held back must fit the call
+ * that brings new samples (RFID_ERR_CAPACITY otherwise, nothing consumed): an adaptor whose output room is smaller than
+ * rfid_mf_pending() calls with n_in = 0 first (they are handed out in parts then).  A call takes at most the max_chunk_raw
+ * given to rfid_lookahead_enable.  The gate / decoder calls see no difference: the gate is shown the filter's outputs a
+ * call later, the passes run over what was uploaded. */
+RFID_API int rfid_lookahead_set_late_outputs(rfid_ctx *ctx, int on);
+/* filter outputs a late-outputs context holds back (0 otherwise) */
+RFID_API int rfid_mf_pending(const rfid_ctx *ctx, int *n_outputs);
 /* What the adaptor knows about its scheduler: the buffer on the gate's input side holds gate_buffer_items items and no more
  * (GNU Radio: detail()->input(0)->max_possible_items_available(); 65 536-byte buffers = 8 192 items by default), or 0: the
  * queues between the blocks grow as needed (the single-threaded scheduler of rfid/mi355x.h).  Bounded: a quarter of the

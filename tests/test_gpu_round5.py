@@ -50,6 +50,8 @@ def test_bounded_scheduler_small_buffers_both_keyings(tmp_path, oracle_mod, synt
                              ("bounded_hostfir", ["--scheduler", "bounded", "--buffer", "8192", "--host-fir"], None),
                              ("bounded_mf_4096", ["--scheduler", "bounded", "--buffer", "4096"], None),
                              ("sts_mf_8192", ["--chunk", "8192"], None),
+                             ("sts_mf_8192_own_outputs", ["--chunk", "8192"], {"RFID_MF_LATE_OUTPUTS": "0"}),
+                             ("bounded_mf_own_outputs", ["--scheduler", "bounded", "--buffer", "8192"], {"RFID_MF_LATE_OUTPUTS": "0"}),
                              ("sts_hostfir_8192", ["--chunk", "8192", "--host-fir"], None)):
         stdout, files = _run(exe, path, tmp_path, name, ["--fixed-q", "1"] + extra, env)
         assert stdout.startswith(o.print_results()), (name, stdout[-800:])
@@ -107,3 +109,84 @@ def test_knobs_are_read_once_and_settable(synth_mod):
                 ctx.set_knob(*bad)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_late_filter_outputs_through_the_c_abi(oracle_mod, synth_mod, seed):
+    """rfid_lookahead_set_late_outputs: a rfid_mf_work call returns the filter outputs of the call before it and holds its own
+    back (no call waits for the device).  Driven like a scheduler with ragged buffers and, every now and then, an output
+    buffer too small for what is held back (the outputs then come in parts, through calls that bring no new samples);
+    nobody announces the end of the input.  The filter outputs concatenated are those of calls that return their own, and
+    every decoded window, the statistics and the report equal the oracle's."""
+    import rfid
+    rng = np.random.default_rng(100 + seed)
+    t = synth_mod.make_trace(n_rounds=40, seed=40 + seed, sigma=0.01, fixed_q=1, tag_ids=(0x11, 0x2A), t1_jitter_raw=4,
+                             corrupt_rounds=(9,)).samples
+    o = oracle_mod.run_trace(t, oracle_mod.config(fixed_q=1))
+    ref = rfid.Context(device=0, fixed_q=1)
+    try:
+        y_ref = ref.mf_work(t)                                   # (no look-ahead: every call returns its own outputs)
+    finally:
+        ref.close()
+    tb = rfid.reader_top_block(samples=t, chunk=30000, lookahead=True, fixed_q=1)
+    try:
+        ctx = tb.ctx
+        ctx.lookahead_set_late_outputs(True)
+        tb._reader_until_idle(0)
+        ys = []
+        gq = np.zeros(0, dtype=np.complex64)
+        dq = np.zeros(0, dtype=np.complex64)
+        pos, n, asked_dry = 0, len(t), 0
+        first = True
+        while pos < n or len(gq) or ctx.mf_pending():
+            if pos < n or ctx.mf_pending():
+                held = ctx.mf_pending()
+                room = held if rng.random() < 0.7 else int(rng.integers(1, held + 2))
+                if held > room or pos >= n:
+                    blk = t[:0]                                  # what is held back first (in parts when the room is short)
+                else:
+                    blk = t[pos:pos + int(rng.integers(1000, 150001))]
+                if first:
+                    assert held == 0
+                pos += len(blk)
+                y = ctx.mf_work(blk, out_cap=max(room, 1))
+                assert len(y) == min(held, max(room, 1))         # ... never this call's own
+                if first and len(blk) >= 5:
+                    assert ctx.mf_pending() == len(blk) // 5
+                    with pytest.raises(rfid.capi.RfidError):     # new samples while what is held back does not fit: refused,
+                        ctx.mf_work(t[pos:pos + 100], out_cap=ctx.mf_pending() - 1)   # nothing consumed
+                    assert ctx.mf_pending() == len(blk) // 5
+                    first = False
+                ys.append(y)
+                gq = np.concatenate([gq, y]) if len(gq) else y
+            while len(gq):
+                take = gq[: int(rng.integers(50, 30001))]
+                consumed, out = tb.gate.general_work(take)
+                gq = gq[consumed:]
+                if len(out):
+                    dq = np.concatenate([dq, out]) if len(dq) else out
+                while True:
+                    dcons, bits, res, sc = tb.tag_decoder.general_work(dq)
+                    if dcons == 0:
+                        break
+                    tb.decoded.append((res, sc))
+                    dq = dq[dcons:]
+                    tb._reader_until_idle(len(bits))
+                if consumed == 0 and len(out) == 0:
+                    if pos < n or ctx.mf_pending():
+                        break                                    # back to the source / the filter
+                    asked_dry += 1                               # the input has ended: asked again, the gate decides what is left
+                    if asked_dry > 6:
+                        gq = gq[:0]                              # (what is left lies behind the last window)
+                else:
+                    asked_dry = 0
+        got = np.concatenate(ys)
+        assert got.tobytes() == y_ref[: len(got)].tobytes() and len(got) == len(t) // 5
+        assert ctx.stats() == o.stats()
+        assert ctx.print_results() == o.print_results()
+        assert len(tb.decoded) == o.n_windows
+        for (res, sc), d in zip(tb.decoded, o.dumps):
+            assert res["n_bits"] == d["n_bits"] and res["crc_ok"] == d["crc_ok"] and res["index"] == d["index"]
+            assert np.array_equal(rfid.unpack_bits(res["bits"], int(d["n_bits"])), d["bits"][: d["n_bits"]])
+    finally:
+        tb.ctx.close()

@@ -228,6 +228,8 @@ static inline int atomic_min(int *p, int v) { int o = *p; if (v < o) *p = v; ret
 static inline int atomic_max(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
 static inline uint64_t load_u64_agent(const uint64_t *p) { return *(const volatile uint64_t *)p; }
 static inline void store_u64_agent(uint64_t *p, uint64_t v) { *(volatile uint64_t *)p = v; }
+static inline void system_release_fence() {}
+static inline void store_i32_system_release(int *p, int v) { *(volatile int *)p = v; }
 static inline void publish(int *flag, int v) { *(volatile int *)flag = v; }
 // (the emulator runs the workgroups of a launch one after the other in index order: a flag of a lower block is set by now)
 static inline void await(const int *flag, int v) { if (*(const volatile int *)flag != v) { fprintf(stderr, "[emu] await on a flag that was never published\n"); abort(); } }
