@@ -193,6 +193,10 @@ struct rfid_ctx {
     bool patient = true;              // a gate call that can decide nothing answers (0, 0) once per arrival of new samples (the scheduler's
                                       // queues grow as needed); false: it decides at once (bounded buffers, rfid_lookahead_set_scheduler)
     bool tail_tried = false;          // a pass has gone over everything the device holds since the last new sample (and left the rest)
+    // rfid_lookahead_set_consume_ahead: the gate takes everything it is shown (the device has it all), the windows follow when the
+    // passes have found them -- the gate's input buffer never fills, whatever its size
+    bool consume_ahead = false;
+    bool need_arm = false;            // a window was handed out completely: the next one waits for the decoder / reader to arm the gate
     bool exact_open = false;          // the exact per-call scan (la_exact_step) has left a window open: it goes on until the window closes
     const rfid_cf32 *pin_next = nullptr; bool pin_was = false;   // where the last uploaded call's samples ended, and whether they were page-locked
     int *h_flag = nullptr;            // page-locked word the device writes behind a call's filter outputs (mf_upload_kernel)
@@ -291,6 +295,7 @@ int sio_collect(rfid_ctx *c);
 void la_free(rfid_ctx *c);    // (look-ahead of the per-block calls)
 int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap, int *n_produced);
 int la_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap, int *n_consumed, int *n_written);
+int la_gate_swallow(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap, int *n_consumed, int *n_written);
 bool la_decoder_result(rfid_ctx *c, const rfid_cf32 *in, int wlen, int type, rfid_decode_result *r);
 
 int fail(rfid_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
@@ -1935,6 +1940,7 @@ int rfid_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, i
     const int type = (rs.gate_status == RFID_GATE_SEEK_EPC) ? 1 : 0;
     rs.gate_status = RFID_GATE_CLOSED;
     rs.n_samples_to_ungate = type ? EPC_WIN : RN16_WIN;
+    c->la.need_arm = false;
     if (!c->la.on) {
       hipLaunchKernelGGL(gate_arm_kernel, dim3(1), dim3(64), 0, c->stream, c->d_gate1, rs.n_samples_to_ungate, type);
       HIPCHK(c, hipGetLastError());   // (stream-ordered before the scan below: no host round trip)
@@ -1943,6 +1949,10 @@ int rfid_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, i
   if (c->la.on) {
     // (the SEEK_* -> CLOSED arming above touched the per-call gate state only, which the look-ahead does not use)
     if (rs.status != RFID_RUNNING) { c->la.gate_pos += n_in; c->la.last_m2.clear(); c->la.y_drop_before(c->la.gate_pos); return RFID_OK; }
+    if (c->la.consume_ahead) {   // (a call without input hands out what the passes have found meanwhile)
+      if (!out || out_cap < 1) return RFID_ERR_CAPACITY;
+      return la_gate_swallow(c, in, n_in, out, out_cap, n_consumed, n_written);
+    }
     if (n_in == 0) return RFID_OK;
     if (!out || out_cap < n_in) return RFID_ERR_CAPACITY;
     return la_gate_work(c, in, n_in, out, out_cap, n_consumed, n_written);
@@ -2642,6 +2652,18 @@ int la_submit_pending(rfid_ctx *c) {
   return RFID_OK;
 }
 
+// enough has gathered for a pass -- and the pass before is through (or there is none), or the staging is nearly full
+bool la_should_submit(rfid_ctx *c) {
+  rfid_ctx::StreamIO &io = c->sio;
+  rfid_ctx::LookAhead &la = c->la;
+  const int64_t have = io.acc_new / io.dec();
+  if (la.flushed || la.exact_open || have < la.coalesce) return false;
+  if (!io.pass.active) return true;
+  if (hipStreamQuery(c->stream) == hipSuccess) return true;
+  (void)hipGetLastError();   // (hipErrorNotReady is no error)
+  return have >= 4 * la.coalesce || io.acc_new + io.dec() * 16384 > io.max_chunk;
+}
+
 bool same_sample(const rfid_cf32 &a, const rfid_cf32 &b) { return memcmp(&a, &b, sizeof(a)) == 0; }
 
 // rfid_mf_work with the look-ahead on: the call's samples go to the device, its filter outputs come back -- with late
@@ -2770,7 +2792,7 @@ int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int o
     la.stall = 0;
     la.tail_tried = false;
   }
-  if (!la.flushed && !la.exact_open && io.acc_new / DECIM >= la.coalesce) {
+  if (la_should_submit(c)) {
     const double t_c0 = la_now();
     rc = la_submit_pending(c);
     g_la_t[6] += la_now() - t_c0; g_la_n[6]++;
@@ -2883,7 +2905,7 @@ int la_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int
     la.up_end += n_new;
     la.stall = 0;
     la.tail_tried = false;
-    if (!la.exact_open && io.acc_new >= la.coalesce && (rc = la_submit_pending(c))) return rc;
+    if (la_should_submit(c) && (rc = la_submit_pending(c))) return rc;
   }
   for (int attempt = 0; attempt < 8; ++attempt) {
     const int64_t frontier = io.raw_base / io.dec();   // the gate's doing is known for the samples before this position
@@ -2958,6 +2980,82 @@ int la_gate_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int
   return RFID_OK;
 }
 
+// rfid_gate_work with the look-ahead on and rfid_lookahead_set_consume_ahead: the gate CONSUMES everything it is shown -- the
+// device has the samples (the filter call uploaded them; keyed on the gate: this call does) -- and hands out the windows
+// when the passes have found them, one window per call at most and the next one only once the decoder / reader calls have
+// armed the gate for it (gate_impl.cc:112-123: the order of the reference's single-threaded flowgraph).  What the gate
+// writes is what it writes without this -- the same windows, the same samples --; what changes is that consuming does not
+// wait for deciding, so the scheduler's buffer in front of the gate never fills and the passes gather 65 536 samples
+// whatever its size.  Nothing is forced here: the end of the input is told by the adaptor, which can see it
+// (rfid_gate_forecast, rfid_lookahead_flush).
+int la_gate_swallow(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap, int *n_consumed, int *n_written) {
+  LaTimer tm(1);
+  rfid_ctx::StreamIO &io = c->sio;
+  rfid_ctx::LookAhead &la = c->la;
+  rfid_reader_state &rs = c->rs;
+  *n_consumed = 0; *n_written = 0;
+  la.last_m2.clear();
+  const int64_t p = la.gate_pos;
+  int consumed = 0;
+  if (n_in > 0) {
+    if (!io.ymode) {
+      // the input must be the matched filter's output at the gate's position
+      const rfid_cf32 *y_first = la.y_at(p), *y_last = la.y_at(p + n_in - 1);
+      if (!y_first || !y_last || !same_sample(in[0], *y_first) || !same_sample(in[n_in - 1], *y_last))
+        return fail(c, RFID_ERR_STATE, "look-ahead: rfid_gate_work was not handed the matched filter's output at the gate's position");
+      consumed = n_in;
+    } else {
+      // gate-keyed: everything shown is new (what was shown before was consumed); at most max_chunk samples per call
+      if (!io.open || io.failed || la.flushed) return fail(c, RFID_ERR_STATE, "look-ahead: the stream has ended (rfid_ctx_reset starts a new one)");
+      if (la.up_end != p) return fail(c, RFID_ERR_STATE, "look-ahead: the gate's input skipped samples");
+      const int64_t take = (n_in < io.max_chunk) ? n_in : io.max_chunk;
+      int rc = la_append(c, in, take);
+      if (rc) { io.failed = true; return rc; }
+      la.up_end += take;
+      consumed = (int)take;
+      if (la_should_submit(c) && (rc = la_submit_pending(c))) return rc;
+    }
+  }
+  // a pass that has finished meanwhile: its windows are what the gate hands out next
+  if (io.pass.active && hipStreamQuery(c->stream) == hipSuccess) {
+    const int rc = sio_collect(c);
+    if (rc) { io.failed = true; return rc; }
+  }
+  (void)hipGetLastError();   // (hipErrorNotReady is no error)
+  int written = 0;
+  if (!la.wins.empty()) {
+    rfid_ctx::LookAhead::Win &w = la.wins.front();
+    bool go = la.emitted > 0;
+    if (!go && !la.need_arm) {
+      if (w.len != rs.n_samples_to_ungate)
+        return fail(c, RFID_ERR_STATE, "look-ahead: the window the gate was armed for is not the next one of the RN16 / EPC alternation");
+      go = true;
+    }
+    if (go) {
+      written = w.len - la.emitted;
+      if (written > out_cap) written = out_cap;
+      memcpy(out, w.blk->g.data() + w.off + la.emitted, sizeof(rfid_cf32) * (size_t)written);
+      la.last_m2.assign(w.blk->m.begin() + (long)(w.off + la.emitted), w.blk->m.begin() + (long)(w.off + la.emitted + written));
+      la.emitted += written;
+      if (la.emitted == w.len) {                           // gate_impl.cc:189-194: closed
+        la.dq.push_back(std::move(w));
+        la.dq.back().blk.reset();                          // (the decoder call is recognised by the window's first and last sample)
+        la.wins.pop_front();
+        la.emitted = 0;
+        la.need_arm = true;
+        rs.gate_status = RFID_GATE_CLOSED;
+      } else {
+        rs.gate_status = RFID_GATE_OPEN;
+      }
+    }
+  }
+  la.gate_pos += consumed;
+  la.y_drop_before(la.gate_pos);
+  *n_consumed = consumed;
+  *n_written = written;
+  return RFID_OK;
+}
+
 // rfid_decoder_work with the look-ahead on: the result of the window the gate handed out, when `in` is that window
 bool la_decoder_result(rfid_ctx *c, const rfid_cf32 *in, int wlen, int type, rfid_decode_result *r) {
   rfid_ctx::LookAhead &la = c->la;
@@ -2986,7 +3084,7 @@ int rfid_lookahead_flush(rfid_ctx *c) {
   rfid_ctx::LookAhead &la = c->la;
   if (!la.on || la.flushed) return RFID_OK;   // (without look-ahead nothing is held back)
   if (!io.open || io.failed) return fail(c, RFID_ERR_STATE, "rfid_lookahead_flush: the stream has failed or was closed");
-  if (io.ymode || la.exact_open) {
+  if ((io.ymode && !la.consume_ahead) || la.exact_open) {
     // keyed on the gate: the library has seen only what the gate was shown; the next gate call that brings nothing new and
     // can decide nothing makes the device decide everything it holds (a scheduler shows a block everything its buffer
     // holds).  (Since round 5 such a call does that anyway the second time it is asked: the announcement saves one call.)
@@ -3007,15 +3105,17 @@ int rfid_lookahead_flush(rfid_ctx *c) {
 }
 
 // room for what gathers before a pass (LookAhead::coalesce) and the largest call behind it
-static const int64_t LA_COALESCE_DEFAULT = 65536, LA_CALL_ROOM = 16384;
+// (the staging holds LA_GATHER_MAX x the threshold: while the pass before is still at work the calls go on gathering -- a pass's
+// cost is mostly its launch list, so a device that is behind gets fewer, bigger passes instead of a host that waits for it)
+static const int64_t LA_COALESCE_DEFAULT = 65536, LA_CALL_ROOM = 16384, LA_GATHER_MAX = 4;
 
 int rfid_lookahead_enable(rfid_ctx *c, int64_t max_chunk_raw) {
   LaTimer tm(9);
   if (!c || max_chunk_raw < 1) return RFID_ERR_INVALID;
   if (c->mf_seen != 0) return fail(c, RFID_ERR_STATE, "rfid_lookahead_enable: the stream has started");
   la_free(c);
-  int64_t cap = max_chunk_raw + DECIM * LA_COALESCE_DEFAULT;
-  if (cap < DECIM * (LA_COALESCE_DEFAULT + LA_CALL_ROOM)) cap = DECIM * (LA_COALESCE_DEFAULT + LA_CALL_ROOM);
+  int64_t cap = max_chunk_raw + DECIM * LA_GATHER_MAX * LA_COALESCE_DEFAULT;
+  if (cap < DECIM * (LA_GATHER_MAX * LA_COALESCE_DEFAULT + LA_CALL_ROOM)) cap = DECIM * (LA_GATHER_MAX * LA_COALESCE_DEFAULT + LA_CALL_ROOM);
   const rfid_reader_state keep = c->rs;            // rfid_stream_begin sets the whole-chain form's READER_STATE; these calls keep theirs
   int rc = rfid_stream_begin(c, cap);
   c->rs = keep;
@@ -3030,8 +3130,8 @@ int rfid_lookahead_enable_gate(rfid_ctx *c, int64_t max_items) {
   if (!c || max_items < 1) return RFID_ERR_INVALID;
   if (c->mf_seen != 0 || c->la.gate_pos != 0) return fail(c, RFID_ERR_STATE, "rfid_lookahead_enable_gate: the stream has started");
   la_free(c);
-  int64_t cap = max_items + LA_COALESCE_DEFAULT;
-  if (cap < LA_COALESCE_DEFAULT + LA_CALL_ROOM) cap = LA_COALESCE_DEFAULT + LA_CALL_ROOM;
+  int64_t cap = max_items + LA_GATHER_MAX * LA_COALESCE_DEFAULT;
+  if (cap < LA_GATHER_MAX * LA_COALESCE_DEFAULT + LA_CALL_ROOM) cap = LA_GATHER_MAX * LA_COALESCE_DEFAULT + LA_CALL_ROOM;
   const rfid_reader_state keep = c->rs;
   int rc = sio_begin(c, cap, true);
   c->rs = keep;
@@ -3072,6 +3172,33 @@ int rfid_lookahead_set_scheduler(rfid_ctx *c, int64_t gate_buffer_items) {
   if (gate_buffer_items == 0) { c->la.patient = true; c->la.coalesce = LA_COALESCE_DEFAULT; return RFID_OK; }
   c->la.patient = false;
   return rfid_lookahead_set_coalesce(c, gate_buffer_items / 4);
+}
+
+int rfid_lookahead_set_consume_ahead(rfid_ctx *c, int on) {
+  if (!c) return RFID_ERR_INVALID;
+  if (!c->la.on) return fail(c, RFID_ERR_STATE, "rfid_lookahead_set_consume_ahead: the look-ahead is not on");
+  if (c->la.gate_pos != 0 || c->la.up_end != 0) return fail(c, RFID_ERR_STATE, "rfid_lookahead_set_consume_ahead: before the first gate call");
+  c->la.consume_ahead = on != 0;
+  if (on) { c->la.patient = true; c->la.coalesce = LA_COALESCE_DEFAULT; }   // (the gathering does not depend on the scheduler's buffers then)
+  return RFID_OK;
+}
+
+int rfid_gate_forecast(const rfid_ctx *c, int upstream_done, int *needs_input) {
+  if (!c || !needs_input) return RFID_ERR_INVALID;
+  *needs_input = 1;
+  const rfid_ctx::LookAhead &la = c->la;
+  if (!la.on || !la.consume_ahead) return RFID_OK;
+  if (c->rs.status != RFID_RUNNING) return RFID_OK;        // (terminated: the gate swallows its input, gate_impl.cc:125,198)
+  if (!la.wins.empty()) {
+    // a window lies ready: handed out when the gate is armed for it (or being armed by the call: SEEK_*), at once when it is open
+    const int st = c->rs.gate_status;
+    if (la.emitted > 0 || !la.need_arm || st == RFID_GATE_SEEK_EPC || st == RFID_GATE_SEEK_RN16 || upstream_done) *needs_input = 0;
+    return RFID_OK;
+  }
+  // the input has ended and the device still holds samples nobody has decided about: a call (without input) is told so and decides
+  if (upstream_done && !la.flushed && c->sio.open && !c->sio.failed &&
+      (c->sio.acc_new > 0 || c->sio.pass.active || c->sio.tail_len > 0)) *needs_input = 0;
+  return RFID_OK;
 }
 
 int rfid_lookahead_set_late_outputs(rfid_ctx *c, int on) {

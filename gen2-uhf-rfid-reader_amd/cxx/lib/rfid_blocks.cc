@@ -29,6 +29,7 @@ struct stream {
   rfid_params params;
   READER_STATE mirror;
   bool has_filter = false;   // a matched_filter block is bound to this stream
+  bool consume_ahead = false;   // the gate takes everything it is shown, the windows follow (rfid_lookahead_set_consume_ahead)
   ~stream() { if (ctx) rfid_ctx_destroy(ctx); if (reader_state == &mirror) reader_state = nullptr; }
   void check(int st, const char *what) const {
     if (st != RFID_OK)
@@ -64,6 +65,11 @@ thread_local stream_sptr g_current;
 // (weak: a filter that dies before its gate appears -- on whatever thread -- simply drops out)
 thread_local std::vector<std::weak_ptr<stream_sptr>> g_pending_filters;
 
+int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+
 // items the scheduler's buffer on a block's input / output side holds (0: unknown or not bounded)
 #ifdef GR_RFID_MINIRT
 int input_buffer_items(gr::block *b) { return b->minirt_input_capacity(); }
@@ -72,16 +78,23 @@ int output_buffer_items(gr::block *b) { return b->minirt_output_capacity(); }
 int input_buffer_items(gr::block *b) { return b->detail() ? b->detail()->input(0)->max_possible_items_available() : 0; }
 int output_buffer_items(gr::block *b) { return b->detail() ? b->detail()->output(0)->bufsize() : 0; }
 #endif
-// The look-ahead lets 65 536 decimated samples gather before a pass is submitted; a gate that can never be shown that
-// many (its input buffer holds C items) is told C / 4: a gate call shown half its buffer decides at once, the pipeline drains
-void tell_buffers(rfid_ctx *ctx, int gate_input_items) {
-  if (gate_input_items > 0) (void)rfid_lookahead_set_scheduler(ctx, gate_input_items);
+// the block's upstream neighbour has finished: what its input buffer holds is all there will be
+#ifdef GR_RFID_MINIRT
+bool upstream_done(const gr::block *b) { return b->minirt_input_done(); }
+#else
+bool upstream_done(const gr::block *b) { return b->detail() && b->detail()->input(0)->done(); }
+#endif
+// The look-ahead lets 65 536 decimated samples gather before a pass is submitted; a gate that can never be shown that many
+// (its input buffer holds C items) CONSUMES AHEAD (rfid_lookahead_set_consume_ahead: it takes everything it is shown -- the
+// device has it -- and hands out the windows when the passes have found them; -> true) or, with RFID_GATE_CONSUME_AHEAD=0, is
+// told C / 4 (rfid_lookahead_set_scheduler: a gate call that can decide nothing decides at once, the pipeline drains)
+bool tell_buffers(rfid_ctx *ctx, int gate_input_items) {
+  if (gate_input_items <= 0) return false;
+  if (env_int("RFID_GATE_CONSUME_AHEAD", 1) != 0 && rfid_lookahead_set_consume_ahead(ctx, 1) == RFID_OK) return true;
+  (void)rfid_lookahead_set_scheduler(ctx, gate_input_items);
+  return false;
 }
 
-int env_int(const char *name, int dflt) {
-  const char *e = getenv(name);
-  return (e && *e) ? atoi(e) : dflt;
-}
 
 stream_sptr current_or_throw(const char *who) {
   if (!g_current)
@@ -121,18 +134,28 @@ class gate_impl : public gate {
     initialize_reader_state();   // lib/gate_impl.cc:69
   }
   void forecast(int noutput_items, gr_vector_int &ninput_items_required) override {
-    ninput_items_required[0] = noutput_items;   // lib/gate_impl.cc:79-83
+    int needs_input = 1;   // (consume-ahead: not while a window lies ready, or the input has ended and samples are undecided)
+    if (d_stream->consume_ahead) (void)rfid_gate_forecast(d_stream->ctx, upstream_done(this) ? 1 : 0, &needs_input);
+    ninput_items_required[0] = needs_input ? noutput_items : 0;   // lib/gate_impl.cc:79-83
   }
   int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
                    gr_vector_void_star &output_items) override {
-    const int n_items = std::min(ninput_items[0], noutput_items);   // lib/gate_impl.cc:91
+    int n_items = std::min(ninput_items[0], noutput_items);   // lib/gate_impl.cc:91
     if (!d_started) {
       d_started = true;
       // no matched_filter block of this library feeds this gate (it would have switched the look-ahead on itself): the
       // filter is somebody else's, the look-ahead is keyed on the gate's input
       if (!d_stream->has_filter && env_int("RFID_LOOKAHEAD", 1) != 0) {
         d_stream->check(rfid_lookahead_enable_gate(d_stream->ctx, std::max(n_items, 16384)), "rfid_lookahead_enable_gate");
-        tell_buffers(d_stream->ctx, input_buffer_items(this));
+        d_stream->consume_ahead = tell_buffers(d_stream->ctx, input_buffer_items(this));
+      }
+    }
+    if (d_stream->consume_ahead) {
+      n_items = ninput_items[0];   // everything: what the gate writes does not depend on how much it is shown
+      // the end of the input: nobody announces it, but a block can see it -- everything the device holds is decided now
+      if (n_items == 0 && !d_told_end && upstream_done(this)) {
+        d_told_end = true;
+        d_stream->check(rfid_lookahead_flush(d_stream->ctx), "rfid_lookahead_flush");
       }
     }
     const GATE_STATUS before = d_stream->mirror.gate_status;
@@ -171,7 +194,7 @@ class gate_impl : public gate {
     return true;
   }
   stream_sptr d_stream;
-  bool d_started = false;
+  bool d_started = false, d_told_end = false;
 };
 
 // ---- tag_decoder ------------------------------------------------------------------------------------
@@ -265,7 +288,7 @@ class matched_filter_impl : public matched_filter {
       if (env_int("RFID_LOOKAHEAD", 1) != 0) {
         const int64_t cap = std::max<int64_t>(std::min<int64_t>(std::max<int64_t>(5 * (int64_t)noutput_items, ninput_items[0]), 5 * 262144), 5 * 8192) + 64;
         st.check(rfid_lookahead_enable(st.ctx, cap), "rfid_lookahead_enable");
-        tell_buffers(st.ctx, output_buffer_items(this));     // (this block's output buffer is the gate's input)
+        st.consume_ahead = tell_buffers(st.ctx, output_buffer_items(this));     // (this block's output buffer is the gate's input)
         // Late outputs (rfid_lookahead_set_late_outputs): a call returns the filter outputs of the call before it, which
         // the device finished while the scheduler ran the other blocks, instead of waiting ~28 us for its own
         // (RFID_MF_LATE_OUTPUTS=0: every call returns its own)
@@ -482,6 +505,7 @@ void bounded_flowgraph::run(const gr_complex *samples, size_t n) {
     if (out_room == 0) return false;                                                         // blocked on output
     int noutput = (int)out_room;
     gr_vector_int req(1, 0);
+    nd_.blk->minirt_set_input_done(in_done);     // (what detail()->input(0)->done() tells a block)
     for (;;) {
       nd_.blk->forecast(noutput, req);
       if ((size_t)req[0] <= n_in_avail) break;
@@ -489,8 +513,9 @@ void bounded_flowgraph::run(const gr_complex *samples, size_t n) {
       if (in_done) nd_.done = true;                         // not enough input and no more coming
       return false;                                         // blocked on input
     }
-    // a block that could do nothing is left alone until new input arrives or its upstream neighbour is done
-    if (nd_.stalled && !nd_.source_like && n_in_avail == nd_.stalled_at && !in_done) return false;
+    // a block that could do nothing is left alone until new input arrives or its upstream neighbour is done -- unless it asks
+    // for no input: such a block is never blocked on input, a runtime calls it again at once (READY_NO_OUTPUT)
+    if (nd_.stalled && !nd_.source_like && req[0] > 0 && n_in_avail == nd_.stalled_at && !in_done) return false;
     gr_vector_int nin(1, (int)n_in_avail);
     gr_vector_const_void_star in(1, in_ptr);
     gr_vector_void_star out(2, nullptr);
@@ -503,9 +528,11 @@ void bounded_flowgraph::run(const gr_complex *samples, size_t n) {
                        in_done ? " (upstream done)" : "", out_room, noutput, consumed, produced, (int)reader_state->gen2_logic_status, (int)reader_state->gate_status);
     if (ret == gr::block::WORK_DONE) { nd_.done = true; return false; }
     if (consumed == 0 && produced == 0) {
-      // nothing moved.  Its upstream neighbour was done when the call was made: nothing ever will, the block is done
-      // (block_executor.cc: were_done).  Else it waits for new input (or for the neighbour to finish).
-      if (in_done) { nd_.done = true; return false; }
+      // nothing moved.  Its upstream neighbour was done when the call was made and the block asked for input: nothing ever
+      // will, the block is done (it would be asked again and again until the flowgraph is stopped: the reference's tag_decoder
+      // ends like that on an incomplete last window).  A block that asked for nothing (a gate waiting for the decoder / reader
+      // to arm it) is simply called again in the next round.  Else it waits for new input (or for the neighbour to finish).
+      if (in_done && req[0] > 0) { nd_.done = true; return false; }
       nd_.stalled = true; nd_.stalled_at = n_in_avail;
       return false;
     }

@@ -64,6 +64,9 @@ class block {
   // what GNU Radio's block_detail tells a block about its buffers (detail()->input(0)->max_possible_items_available(),
   // detail()->output(0)->bufsize()): items, 0 = not bounded (the single-threaded scheduler's queues grow as needed)
   void minirt_set_buffers(int input_items, int output_items) { d_in_cap = input_items; d_out_cap = output_items; }
+  // ... and about its upstream neighbour (detail()->input(0)->done()): it has finished, what is in the buffer is all there will be
+  void minirt_set_input_done(bool done) { d_in_done = done; }
+  bool minirt_input_done() const { return d_in_done; }
   int minirt_input_capacity() const { return d_in_cap; }
   int minirt_output_capacity() const { return d_out_cap; }
 
@@ -76,6 +79,7 @@ class block {
   io_signature::sptr d_in, d_out;
   int d_consumed = 0;
   int d_in_cap = 0, d_out_cap = 0;
+  bool d_in_done = false;
   std::vector<int> d_produced = std::vector<int>(2, 0);
 };
 

@@ -109,6 +109,8 @@ SIGNATURES = {
     "rfid_lookahead_drain": (_i, [_vp]),
     "rfid_lookahead_set_late_outputs": (_i, [_vp, _i]),
     "rfid_mf_pending": (_i, [_vp, _ip]),
+    "rfid_lookahead_set_consume_ahead": (_i, [_vp, _i]),
+    "rfid_gate_forecast": (_i, [_vp, _i, _ip]),
     "rfid_lookahead_set_scheduler": (_i, [_vp, _i64]),
     "rfid_abi_version": (_i, []),
     "rfid_lookahead_flush": (_i, [_vp]),

@@ -261,6 +261,23 @@ RFID_API int rfid_mf_pending(const rfid_ctx *ctx, int *n_outputs);
  * decide at once (a block that moves nothing is, depending on the runtime, polled again at once or left alone for good:
  * neither helps anything gather).  Unbounded (the default): (0, 0) once per arrival of new samples, see above. */
 RFID_API int rfid_lookahead_set_scheduler(rfid_ctx *ctx, int64_t gate_buffer_items);
+/* Consume ahead (either keying; off by default; before the first gate call).  As described above, a gate call consumes up to
+ * the point its windows are known and no further -- under a scheduler with small bounded buffers the buffer in front of
+ * the gate is then full of samples the device already has, and nothing gathers.  With consume-ahead on, rfid_gate_work
+ * CONSUMES EVERYTHING IT IS SHOWN (keyed on the gate: uploads it) and hands out the windows when the passes have found
+ * them: the same windows, the same samples, in the same order, one window per call at most, the next one only after the
+ * decoder / reader calls have armed the gate for it (gate_impl.cc:112-123) -- only *n_consumed no longer says where the
+ * windows lie.  A call may bring no input (n_in = 0; out_cap >= 1): it hands out what has become known.  Nothing is forced in
+ * this mode, so the adaptor must do two things a gr::block can do: (1) forecast() through rfid_gate_forecast -- the gate
+ * needs no input while a window lies ready for it, or when its upstream neighbour is done and the device still holds
+ * undecided samples; (2) when general_work is called with its upstream done and no input left, call rfid_lookahead_flush
+ * (which then decides everything, whatever the keying) before rfid_gate_work.  rfid_lookahead_set_scheduler's bounded mode
+ * is switched off by it (the gathering threshold goes back to 65 536). */
+RFID_API int rfid_lookahead_set_consume_ahead(rfid_ctx *ctx, int on);
+/* forecast() of a consume-ahead gate: *needs_input = 0 when a rfid_gate_work call can do something without input (see above),
+ * 1 otherwise (always 1 without consume-ahead: the reference's forecast, gate_impl.cc:79-83).  upstream_done: the block that
+ * feeds the gate has finished (GNU Radio: detail()->input(0)->done()). */
+RFID_API int rfid_gate_forecast(const rfid_ctx *ctx, int upstream_done, int *needs_input);
 /* windows the look-ahead holds: found by the passes and not yet (completely) handed out by rfid_gate_work /
  * handed out and waiting for their rfid_decoder_work call (a decoder call retires its window whether or not it asks for
  * scores).  Both stay small in a running flowgraph. */

@@ -26,7 +26,8 @@ def _run(exe, path, tmp_path, tag, extra, env=None):
 def test_bounded_scheduler_small_buffers_both_keyings(tmp_path, oracle_mod, synth_mod, cut_behind_last_rn16):
     """mi355x::bounded_flowgraph: GNU Radio's scheduling rules on one thread -- buffers of 8 192 items and no more, forecast, a
     block that could do nothing is left alone until new input arrives or its neighbour is done, stop() at the end and nothing
-    else (nobody calls rfid_lookahead_flush before the blocks have stopped being called).  Both keyings of the look-ahead (the
+    else (nobody tells the blocks that the input has ended; the gate's adaptor sees its upstream neighbour finish).  The gate
+    consumes ahead (rfid_lookahead_set_consume_ahead: the default of the adaptors under bounded buffers) or decides at once.  Both keyings of the look-ahead (the
     library's matched_filter block in front of the gate; somebody else's filter, as apps/reader.py:75 has it): the report, the
     reader's output and the gated samples are byte for byte those of the per-call path and the oracle's -- the last window
     included, also when the trace ends a few samples behind a complete RN16 window (inside the stretch that the look-ahead's
@@ -49,6 +50,10 @@ def test_bounded_scheduler_small_buffers_both_keyings(tmp_path, oracle_mod, synt
                              ("bounded_mf", ["--scheduler", "bounded", "--buffer", "8192"], None),
                              ("bounded_hostfir", ["--scheduler", "bounded", "--buffer", "8192", "--host-fir"], None),
                              ("bounded_mf_4096", ["--scheduler", "bounded", "--buffer", "4096"], None),
+                             ("bounded_hostfir_4096", ["--scheduler", "bounded", "--buffer", "4096", "--host-fir"], None),
+                             # (the gate deciding at once instead of consuming ahead: rfid_lookahead_set_scheduler's bounded mode)
+                             ("bounded_mf_decide_at_once", ["--scheduler", "bounded", "--buffer", "8192"], {"RFID_GATE_CONSUME_AHEAD": "0"}),
+                             ("bounded_hostfir_decide_at_once", ["--scheduler", "bounded", "--buffer", "8192", "--host-fir"], {"RFID_GATE_CONSUME_AHEAD": "0"}),
                              ("sts_mf_8192", ["--chunk", "8192"], None),
                              ("sts_mf_8192_own_outputs", ["--chunk", "8192"], {"RFID_MF_LATE_OUTPUTS": "0"}),
                              ("bounded_mf_own_outputs", ["--scheduler", "bounded", "--buffer", "8192"], {"RFID_MF_LATE_OUTPUTS": "0"}),
