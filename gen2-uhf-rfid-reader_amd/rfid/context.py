@@ -104,14 +104,28 @@ class Context:
         self._chk(self._lib.rfid_mf_pending(self._h, C.byref(n)))
         return n.value
 
-    def gate_work(self, x) -> Tuple[int, np.ndarray]:
-        """-> (consumed, gated samples), as gate_impl::general_work's consume_each()/output."""
+    def gate_work(self, x, out_cap: Optional[int] = None) -> Tuple[int, np.ndarray]:
+        """-> (consumed, gated samples), as gate_impl::general_work's consume_each()/output.  out_cap: the room of the caller's
+        output buffer (default: as many items as the call is shown; a consume-ahead gate may be called without input)."""
         x = _c64(x)
-        out = np.empty(max(len(x), 1), dtype=np.complex64)
+        if out_cap is None:
+            out_cap = max(len(x), 1)
+        out = np.empty(max(int(out_cap), 1), dtype=np.complex64)
         cons, wr = C.c_int(0), C.c_int(0)
-        self._chk(self._lib.rfid_gate_work(self._h, x.ctypes.data, len(x), out.ctypes.data, len(out),
+        self._chk(self._lib.rfid_gate_work(self._h, x.ctypes.data if len(x) else None, len(x), out.ctypes.data, int(out_cap),
                                            C.byref(cons), C.byref(wr)))
         return cons.value, out[: wr.value].copy()
+
+    def lookahead_set_consume_ahead(self, on: bool = True) -> None:
+        """gate_work consumes everything it is shown; the windows follow when the passes have found them (gate_forecast says
+        when a call without input has something to hand out; lookahead_flush at the end of the input)."""
+        self._chk(self._lib.rfid_lookahead_set_consume_ahead(self._h, 1 if on else 0))
+
+    def gate_forecast(self, upstream_done: bool = False) -> bool:
+        """-> True when the gate needs input to do anything (the reference's forecast), False when a call without input can."""
+        n = C.c_int(1)
+        self._chk(self._lib.rfid_gate_forecast(self._h, 1 if upstream_done else 0, C.byref(n)))
+        return n.value != 0
 
     def decoder_work(self, x):
         """-> (consumed, port-0 floats, result record or None, scores record or None)."""

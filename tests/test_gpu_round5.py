@@ -195,3 +195,80 @@ def test_late_filter_outputs_through_the_c_abi(oracle_mod, synth_mod, seed):
             assert np.array_equal(rfid.unpack_bits(res["bits"], int(d["n_bits"])), d["bits"][: d["n_bits"]])
     finally:
         tb.ctx.close()
+
+
+@pytest.mark.parametrize("keyed_on", ["filter", "gate"])
+@pytest.mark.parametrize("seed", [1, 2])
+def test_gate_consumes_ahead_through_the_c_abi(oracle_mod, synth_mod, keyed_on, seed):
+    """rfid_lookahead_set_consume_ahead: the gate takes everything it is shown and hands out the windows when the passes have found
+    them -- one window per call at most, in parts when the output buffer is short, the next one only after the decoder / reader
+    calls have armed the gate.  Driven like a scheduler with ragged, small buffers that honours rfid_gate_forecast and tells the
+    library the end of the input when it sees it (as the C++ adaptor does from detail()->input(0)->done()).  Every decoded
+    window, the statistics and the report equal the oracle's, the gated samples are the oracle's windows minus their dc estimates."""
+    import rfid
+    rng = np.random.default_rng(200 + seed)
+    t = synth_mod.make_trace(n_rounds=60, seed=60 + seed, sigma=0.01, fixed_q=1, tag_ids=(0x11, 0x2A), t1_jitter_raw=4,
+                             corrupt_rounds=(9,)).samples
+    o = oracle_mod.run_trace(t, oracle_mod.config(fixed_q=1))
+    from rfid.flowgraph import fir_filter_ccc_ones
+    y_all = fir_filter_ccc_ones(t)
+    # what the gate writes: in[i] - dc_est over every window (gate_impl.cc:171-186), from the oracle's openings and dc estimates
+    parts = []
+    for s0, ty, dc in zip(o.open_idx, o.dumps["type"], o.dc):
+        w = y_all[int(s0): int(s0) + (1370 if ty else 250)]
+        parts.append((w.real - np.float32(dc.real)).astype(np.float32) + 1j * (w.imag - np.float32(dc.imag)).astype(np.float32))
+    gated_ref = np.concatenate(parts).astype(np.complex64)
+    ext = keyed_on == "gate"
+    tb = rfid.reader_top_block(samples=t, chunk=8192, lookahead=True, external_filter=ext, fixed_q=1)
+    try:
+        ctx = tb.ctx
+        ctx.lookahead_set_consume_ahead(True)
+        tb._reader_until_idle(0)
+        gq = np.zeros(0, dtype=np.complex64)
+        dq = np.zeros(0, dtype=np.complex64)
+        gated = []
+        pos, n = 0, (len(y_all) if ext else len(t))
+        told_end = False
+        spins = 0
+        while True:
+            if pos < n:
+                step = int(rng.integers(200, 9000)) * (1 if ext else 5)
+                blk = (y_all if ext else t)[pos:pos + step]
+                pos += len(blk)
+                y = blk if ext else tb.matched_filter.work(blk)
+                gq = np.concatenate([gq, y]) if len(gq) else y
+            src_done = pos >= n
+            # the gate: called when it has input, or when it says it can do something without
+            if len(gq) or not ctx.gate_forecast(upstream_done=src_done):
+                if not len(gq) and src_done and not told_end:
+                    ctx.lookahead_flush()
+                    told_end = True
+                take = gq[: int(rng.integers(50, 8193))]
+                consumed, out = ctx.gate_work(take, out_cap=int(rng.integers(100, 3000)))
+                assert consumed == len(take)                     # everything it is shown
+                gq = gq[consumed:]
+                if len(out):
+                    gated.append(out)
+                    dq = np.concatenate([dq, out]) if len(dq) else out
+                spins = spins + 1 if (consumed == 0 and len(out) == 0) else 0
+                assert spins < 1000
+            while True:
+                dcons, bits, res, sc = tb.tag_decoder.general_work(dq)
+                if dcons == 0:
+                    break
+                tb.decoded.append((res, sc))
+                dq = dq[dcons:]
+                tb._reader_until_idle(len(bits))
+            if src_done and not len(gq) and told_end and ctx.gate_forecast(upstream_done=True):
+                break
+        assert ctx.stats() == o.stats()
+        assert ctx.print_results() == o.print_results()
+        assert len(tb.decoded) == o.n_windows
+        for (res, sc), d in zip(tb.decoded, o.dumps):
+            assert res["n_bits"] == d["n_bits"] and res["crc_ok"] == d["crc_ok"] and res["index"] == d["index"]
+            assert np.array_equal(rfid.unpack_bits(res["bits"], int(d["n_bits"])), d["bits"][: d["n_bits"]])
+        g = np.concatenate(gated)
+        assert len(g) == sum(1370 if ty else 250 for ty in o.dumps["type"])
+        assert g.tobytes() == gated_ref.tobytes()
+    finally:
+        tb.ctx.close()
