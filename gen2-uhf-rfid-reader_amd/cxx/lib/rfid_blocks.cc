@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 namespace gr {
 namespace rfid {
@@ -30,6 +31,10 @@ struct stream {
   READER_STATE mirror;
   bool has_filter = false;   // a matched_filter block is bound to this stream
   bool consume_ahead = false;   // the gate takes everything it is shown, the windows follow (rfid_lookahead_set_consume_ahead)
+  // one context, four blocks: under a thread-per-block runtime their calls come from four threads -- serialised here (a context
+  // is not re-entrant).  The ORDER of the calls is the flowgraph's business: the reference shares READER_STATE between its
+  // blocks without any lock and recommends the single-threaded scheduler (README.md:40, GR_SCHEDULER=STS).
+  std::recursive_mutex mu;
   ~stream() { if (ctx) rfid_ctx_destroy(ctx); if (reader_state == &mirror) reader_state = nullptr; }
   void check(int st, const char *what) const {
     if (st != RFID_OK)
@@ -135,11 +140,13 @@ class gate_impl : public gate {
   }
   void forecast(int noutput_items, gr_vector_int &ninput_items_required) override {
     int needs_input = 1;   // (consume-ahead: not while a window lies ready, or the input has ended and samples are undecided)
+    std::lock_guard<std::recursive_mutex> lk(d_stream->mu);
     if (d_stream->consume_ahead) (void)rfid_gate_forecast(d_stream->ctx, upstream_done(this) ? 1 : 0, &needs_input);
     ninput_items_required[0] = needs_input ? noutput_items : 0;   // lib/gate_impl.cc:79-83
   }
   int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
                    gr_vector_void_star &output_items) override {
+    std::lock_guard<std::recursive_mutex> lk(d_stream->mu);
     int n_items = std::min(ninput_items[0], noutput_items);   // lib/gate_impl.cc:91
     if (!d_started) {
       d_started = true;
@@ -186,6 +193,7 @@ class gate_impl : public gate {
   // fetch any more: they are decided and accounted here (READER_STATE as the decoder / reader calls would have left it), so
   // that print_results() -- called after stop(), apps/reader.py:130-131 in either order -- counts them.
   bool stop() override {
+    std::lock_guard<std::recursive_mutex> lk(d_stream->mu);
     if (d_started) {
       (void)rfid_lookahead_flush(d_stream->ctx);
       (void)rfid_lookahead_drain(d_stream->ctx);
@@ -213,6 +221,7 @@ class tag_decoder_impl : public tag_decoder {
   int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
                    gr_vector_void_star &output_items) override {
     int consumed = 0, produced0 = 0;
+    std::lock_guard<std::recursive_mutex> lk(d_stream->mu);
     d_stream->check(rfid_decoder_work(d_stream->ctx, (const rfid_cf32 *)input_items[0], ninput_items[0], (float *)output_items[0],
                                       noutput_items, &consumed, &produced0, nullptr, nullptr), "rfid_decoder_work");
     d_stream->refresh();
@@ -235,6 +244,7 @@ class reader_impl : public reader {
   int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
                    gr_vector_void_star &output_items) override {
     int consumed = 0, written = 0;
+    std::lock_guard<std::recursive_mutex> lk(d_stream->mu);
     d_stream->check(rfid_reader_work_tx(d_stream->ctx, d_dac_rate, (const float *)input_items[0], ninput_items[0],
                                         (float *)output_items[0], noutput_items, &consumed, &written), "rfid_reader_work_tx");
     d_stream->refresh();
@@ -244,6 +254,7 @@ class reader_impl : public reader {
   void print_results() override {   // lib/reader_impl.cc:173-192
     std::vector<char> buf(1 << 15);
     int len = 0;
+    std::lock_guard<std::recursive_mutex> lk(d_stream->mu);
     d_stream->check(rfid_print_results(d_stream->ctx, buf.data(), (int)buf.size(), &len), "rfid_print_results");
     fwrite(buf.data(), 1, (size_t)len, stdout);
     fflush(stdout);
@@ -267,7 +278,10 @@ class matched_filter_impl : public matched_filter {
   // outputs of the last call the library still holds (late outputs, see general_work)
   int held_back() const {
     int n = 0;
-    if (d_late && *d_slot) (void)rfid_mf_pending((**d_slot).ctx, &n);
+    if (d_late && *d_slot) {
+      std::lock_guard<std::recursive_mutex> lk((**d_slot).mu);
+      (void)rfid_mf_pending((**d_slot).ctx, &n);
+    }
     return n;
   }
   // a decimator by 5 -- except while outputs are held back: they need no input to be handed out (so a runtime calls the block
@@ -279,6 +293,7 @@ class matched_filter_impl : public matched_filter {
                    gr_vector_void_star &output_items) override {
     if (!*d_slot) throw mi355x::error(RFID_ERR_STATE, "gr::rfid::matched_filter: no gate constructed yet");
     stream &st = **d_slot;
+    std::lock_guard<std::recursive_mutex> lk(st.mu);
     // a decimator consumes what its output has room for (sync_decimator: noutput * decim), however much the scheduler offers
     int n_in = std::min(ninput_items[0], 5 * noutput_items);
     if (!d_started) {
@@ -310,7 +325,7 @@ class matched_filter_impl : public matched_filter {
     return n_out;
   }
   bool stop() override {   // (see gate_impl::stop)
-    if (d_started && *d_slot) (void)rfid_lookahead_flush((**d_slot).ctx);
+    if (d_started && *d_slot) { std::lock_guard<std::recursive_mutex> lk((**d_slot).mu); (void)rfid_lookahead_flush((**d_slot).ctx); }
     return true;
   }
   std::shared_ptr<stream_sptr> d_slot;   // bound now or by the next gate
