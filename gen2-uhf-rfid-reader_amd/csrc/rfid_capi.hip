@@ -205,10 +205,11 @@ struct rfid_ctx {
     // rfid_lookahead_set_late_outputs: a rfid_mf_work call hands out the filter outputs of the call BEFORE it (they are long
     // there), its own are fetched by the next call: no call waits for the device
     bool late = false;
-    int64_t pend_y0 = 0;              // global position of the first output held back
-    int pend_n = 0, pend_off = 0;     // outputs of the last call that had any / of those handed out already
-    int pend_seq = 0; bool pend_ready = false;   // the flag value that says they are in h_y / seen
-    int pend_half = 0;                // the half of h_y they are in
+    // the sets of outputs held back, oldest first: at most LATE_SLOTS - 1 when a call arrives (it launches into the free slot)
+    struct Held { int64_t y0 = 0; int n = 0, off = 0, seq = 0, slot = 0; bool ready = false; };   // position, count, handed out, flag value, slot of h_y, seen
+    static const int LATE_SLOTS = 3;
+    std::deque<Held> held;
+    int held_total() const { int t = 0; for (const Held &h : held) t += h.n - h.off; return t; }
     bool soft_done = false;           // ... and the held-back samples went through the sequential scan since the last input
     std::vector<float> last_m2;       // |.|^2 of what the last gate call wrote
     // scratch of one whole-chain pass
@@ -1865,7 +1866,7 @@ extern "C" {
 int rfid_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap, int *n_produced) {
   if (!c || n_in < 0 || (n_in > 0 && !in) || !n_produced) return RFID_ERR_INVALID;
   *n_produced = 0;
-  if (n_in == 0 && !(c->la.on && c->la.late && c->la.pend_n > 0)) return RFID_OK;
+  if (n_in == 0 && !(c->la.on && c->la.late && !c->la.held.empty())) return RFID_OK;
   HIPCHK(c, hipSetDevice(c->device));
   if (c->la.on) {
     if (c->sio.ymode) return fail(c, RFID_ERR_STATE, "look-ahead: keyed on the gate's input (rfid_lookahead_enable_gate), rfid_mf_work has no part in it");
@@ -2686,6 +2687,8 @@ int la_wait_flag(rfid_ctx *c, int seq) {
 }  // namespace
 int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int out_cap, int *n_produced) {
   LaTimer tm(0);
+  typedef rfid_ctx::LookAhead::Held Held;
+  const int SLOTS = rfid_ctx::LookAhead::LATE_SLOTS;
   rfid_ctx::StreamIO &io = c->sio;
   rfid_ctx::LookAhead &la = c->la;
   const bool deliver_only = la.late && n_in == 0;   // (what is held back is handed out after the end of the stream too)
@@ -2694,13 +2697,21 @@ int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int o
   if (n_in > io.max_chunk) return fail(c, RFID_ERR_CAPACITY, "look-ahead: rfid_mf_work call larger than the max_chunk_raw given to rfid_lookahead_enable");
   const int64_t n_first = c->mf_seen / DECIM;
   const int n_out = (int)((c->mf_seen + n_in) / DECIM - n_first);
-  int give = 0;
+  const size_t part = la.h_ycap / (size_t)SLOTS;           // outputs one slot of h_y holds
+  const bool grow = n_out > 0 && (size_t)n_out > part;     // (h_y is allocated anew: nothing may be held back in the old one)
+  // Late outputs: up to SLOTS - 1 sets are held back when a call arrives; it launches its own filter into the free slot first
+  // and then hands out whatever the device has finished -- so a call's outputs have two calls' time to get through the device
+  // (one call's time was about what they need: the calls still waited ~10 us each).  What MUST be handed out before the launch:
+  // the oldest set when all other slots are taken, everything when h_y has to grow.
+  int must = 0;
+  if (la.late && n_out > 0) {
+    if (grow) must = la.held_total();
+    else if ((int)la.held.size() >= SLOTS) must = la.held.front().n - la.held.front().off;
+  }
   if (la.late) {
-    const int held = la.pend_n - la.pend_off;
-    give = (held < out_cap) ? held : out_cap;
-    if (give > 0 && !out) return RFID_ERR_CAPACITY;
-    if (n_in > 0 && give < held)
+    if (must > out_cap)
       return fail(c, RFID_ERR_CAPACITY, "look-ahead: rfid_mf_work with new samples while the outputs held back do not fit (rfid_mf_pending: fetch them first, n_in = 0)");
+    if (!la.held.empty() && !out) return RFID_ERR_CAPACITY;
   } else if (n_out > out_cap || (n_out > 0 && !out)) return RFID_ERR_CAPACITY;
   int rc = RFID_OK;
   const rfid_cf32 *staged = nullptr;   // with outputs to make: the filter's launch fetches the samples itself (mf_upload_kernel)
@@ -2709,29 +2720,34 @@ int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int o
     if (rc) { io.failed = true; return rc; }
   }
   g_la_t[4] += la_now() - tm.t0; g_la_n[4]++;   // (samples staged)
-  // the outputs of the call before: the device wrote them (into the other half of h_y) while the scheduler ran the other blocks
-  auto hand_out = [&]() -> int {
-    const double t_y0 = la_now();
-    const rfid_cf32 *from = la.h_y + (size_t)la.pend_half * (la.h_ycap / 2);
-    if (!la.pend_ready) {
-      const int rc2 = la_wait_flag(c, la.pend_seq);
-      if (rc2) return rc2;
-      la.pend_ready = true;
-      la.y_push(la.pend_y0, from, (size_t)la.pend_n);
+  int give = 0;
+  // hands out (part of) the oldest set; wait: for the device if it is not through with it yet.  -> false: nothing handed out
+  auto hand_out_oldest = [&](bool wait, int &err) -> bool {
+    err = RFID_OK;
+    if (la.held.empty() || give >= out_cap) return false;
+    Held &h = la.held.front();
+    const rfid_cf32 *from = la.h_y + (size_t)h.slot * (la.h_ycap / (size_t)SLOTS);
+    if (!h.ready) {
+      if (!wait && *(volatile int *)la.h_flag - h.seq < 0) return false;
+      const double t_y0 = la_now();
+      err = la_wait_flag(c, h.seq);
+      g_la_t[8] += la_now() - t_y0; g_la_n[8]++;
+      if (err) return false;
+      h.ready = true;
+      la.y_push(h.y0, from, (size_t)h.n);
     }
-    g_la_t[8] += la_now() - t_y0; g_la_n[8]++;
-    memcpy(out, from + la.pend_off, sizeof(rfid_cf32) * (size_t)give);
-    la.pend_off += give;
-    if (la.pend_off == la.pend_n) { la.pend_n = 0; la.pend_off = 0; }
-    return RFID_OK;
+    int k = h.n - h.off;
+    if (k > out_cap - give) k = out_cap - give;
+    memcpy(out + give, from + h.off, sizeof(rfid_cf32) * (size_t)k);
+    give += k;
+    h.off += k;
+    if (h.off == h.n) la.held.pop_front();
+    return true;
   };
-  // (they are fetched BEHIND this call's launch -- the device starts on the new samples while the host copies the old outputs --
-  // unless there is no launch, or h_y has to grow first)
-  bool handed = give == 0;
-  if (!handed && (n_out == 0 || (size_t)n_out > la.h_ycap / 2)) {
-    rc = hand_out();
-    if (rc) return rc;
-    handed = true;
+  while (must > 0) {                     // (must <= out_cap: these fit)
+    const int before = give;
+    if (!hand_out_oldest(true, rc)) { if (rc) return rc; break; }
+    must -= give - before;
   }
   if (n_out > 0) {
     // y[n] = sum x[5n - 24 .. 5n] for this call's outputs: the matched filter over the new samples, whose history lies in
@@ -2743,14 +2759,21 @@ int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int o
       HIPCHK(c, hipMalloc((void **)&la.d_done, 64));
       HIPCHK(c, hipMemsetAsync(la.d_done, 0, 64, io.copy_stream));
     }
-    if ((size_t)n_out > la.h_ycap / 2) {   // two halves: this call's outputs, and those of the call before (late outputs)
+    if (grow) {   // SLOTS parts: this call's outputs and those of the calls before (late outputs)
       if (la.h_y) { HIPCHK(c, hipStreamSynchronize(io.copy_stream)); (void)hipHostFree(la.h_y); }
       la.h_y = nullptr; la.h_ycap = 0;
-      HIPCHK(c, hipHostMalloc((void **)&la.h_y, sizeof(rfid_cf32) * (size_t)n_out * 4, hipHostMallocDefault));
-      la.h_ycap = (size_t)n_out * 4;
+      const size_t want = (size_t)(n_out < 8192 ? 16384 : 2 * n_out);
+      HIPCHK(c, hipHostMalloc((void **)&la.h_y, sizeof(rfid_cf32) * want * (size_t)SLOTS, hipHostMallocDefault));
+      la.h_ycap = want * (size_t)SLOTS;
     }
-    const int half = la.late ? (la.pend_half ^ 1) : 0;
-    rfid_cf32 *y_here = la.h_y + (size_t)half * (la.h_ycap / 2);
+    int slot = 0;
+    if (la.late) {
+      bool used[8] = {false, false, false, false, false, false, false, false};
+      for (const Held &h : la.held) used[h.slot] = true;
+      while (slot < SLOTS && used[slot]) ++slot;
+      if (slot >= SLOTS) return fail(c, RFID_ERR_STATE, "look-ahead: no free slot for the filter outputs");
+    }
+    rfid_cf32 *y_here = la.h_y + (size_t)slot * (la.h_ycap / (size_t)SLOTS);
     // ONE launch: the samples come out of page-locked memory, go into the buffer the passes read and through the filter;
     // the outputs go straight into page-locked host memory (the device writes it over the bus: no copy to set up), a word
     // behind them says they are there, and the host spins on that word (an event's wake-up costs more than the filter).
@@ -2771,12 +2794,9 @@ int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int o
     HIPCHK(c, hipEventRecord(io.ev_up[io.cur], io.copy_stream));
     g_la_t[5] += la_now() - t_sp; g_la_n[5]++;
     if (la.late) {
-      if (!handed) {
-        rc = hand_out();
-        if (rc) return rc;
-        handed = true;
-      }
-      la.pend_y0 = n_first; la.pend_n = n_out; la.pend_off = 0; la.pend_seq = seq; la.pend_ready = false; la.pend_half = half;
+      Held h;
+      h.y0 = n_first; h.n = n_out; h.off = 0; h.seq = seq; h.slot = slot; h.ready = false;
+      la.held.push_back(h);
     } else {
       const double t_y0 = la_now();
       rc = la_wait_flag(c, seq);
@@ -2787,11 +2807,17 @@ int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int o
       give = n_out;
     }
   }
-  c->mf_seen += n_in;
-  if (n_in > 0) {
-    la.stall = 0;
-    la.tail_tried = false;
+  if (la.late) {
+    // whatever the device has finished, oldest first, as far as the room goes; a call that brought nothing and has handed out
+    // nothing yet waits for the oldest set (a scheduler that calls a block must see it move)
+    for (;;) {
+      const bool wait = n_in == 0 && give == 0;
+      if (!hand_out_oldest(wait, rc)) { if (rc) return rc; break; }
+    }
   }
+  c->mf_seen += n_in;
+  if (n_in > 0 || give > 0) la.stall = 0;   // (outputs handed out late are new input for the gate: it may answer (0, 0) once more)
+  if (n_in > 0) la.tail_tried = false;
   if (la_should_submit(c)) {
     const double t_c0 = la_now();
     rc = la_submit_pending(c);
@@ -3204,14 +3230,21 @@ int rfid_gate_forecast(const rfid_ctx *c, int upstream_done, int *needs_input) {
 int rfid_lookahead_set_late_outputs(rfid_ctx *c, int on) {
   if (!c) return RFID_ERR_INVALID;
   if (!c->la.on || c->sio.ymode) return fail(c, RFID_ERR_STATE, "rfid_lookahead_set_late_outputs: needs the look-ahead keyed on rfid_mf_work");
-  if (c->la.pend_n > 0) return fail(c, RFID_ERR_STATE, "rfid_lookahead_set_late_outputs: outputs are held back (fetch them first)");
+  if (!c->la.held.empty()) return fail(c, RFID_ERR_STATE, "rfid_lookahead_set_late_outputs: outputs are held back (fetch them first)");
   c->la.late = on != 0;
   return RFID_OK;
 }
 
 int rfid_mf_pending(const rfid_ctx *c, int *n_outputs) {
   if (!c || !n_outputs) return RFID_ERR_INVALID;
-  *n_outputs = c->la.on ? (c->la.pend_n - c->la.pend_off) : 0;
+  *n_outputs = c->la.on ? c->la.held_total() : 0;
+  return RFID_OK;
+}
+
+int rfid_mf_must_fetch(const rfid_ctx *c, int *n_outputs) {
+  if (!c || !n_outputs) return RFID_ERR_INVALID;
+  *n_outputs = 0;
+  if (c->la.on && (int)c->la.held.size() >= rfid_ctx::LookAhead::LATE_SLOTS) *n_outputs = c->la.held.front().n - c->la.held.front().off;
   return RFID_OK;
 }
 

@@ -11,6 +11,10 @@
 // GNU Radio's own filter.fir_filter_ccc -- switches the look-ahead on keyed on its own input
 // (rfid_lookahead_enable_gate): gate -> tag_decoder over every buffer it is shown, in one submission.
 #include <rfid/mi355x.h>
+#ifndef GR_RFID_MINIRT   // a real GNU Radio: what a block may ask its runtime about its buffers (input_buffer_items, upstream_done below)
+#include <gnuradio/block_detail.h>
+#include <gnuradio/buffer.h>
+#endif
 
 #include <cstdio>
 #include <cstdlib>
@@ -316,7 +320,9 @@ class matched_filter_impl : public matched_filter {
     }
     if (d_late) {
       if (n_in > d_call_max) n_in = d_call_max;
-      if (held_back() > noutput_items) n_in = 0;   // (no room for all that is held back: that first, in parts)
+      int must = 0;                                 // (no room for what has to go first: that alone, in parts)
+      (void)rfid_mf_must_fetch(st.ctx, &must);
+      if (must > noutput_items) n_in = 0;
     }
     int n_out = 0;
     st.check(rfid_mf_work(st.ctx, (const rfid_cf32 *)input_items[0], n_in, (rfid_cf32 *)output_items[0],

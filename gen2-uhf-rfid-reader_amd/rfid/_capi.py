@@ -109,6 +109,7 @@ SIGNATURES = {
     "rfid_lookahead_drain": (_i, [_vp]),
     "rfid_lookahead_set_late_outputs": (_i, [_vp, _i]),
     "rfid_mf_pending": (_i, [_vp, _ip]),
+    "rfid_mf_must_fetch": (_i, [_vp, _ip]),
     "rfid_lookahead_set_consume_ahead": (_i, [_vp, _i]),
     "rfid_gate_forecast": (_i, [_vp, _i, _ip]),
     "rfid_lookahead_set_scheduler": (_i, [_vp, _i64]),

@@ -240,20 +240,24 @@ RFID_API int rfid_lookahead_enable_gate(rfid_ctx *ctx, int64_t max_items);
  * gate can never be shown more than C, so it asks for C / 4 (a gate call shown 2 x this many items decides at once). */
 RFID_API int rfid_lookahead_set_coalesce(rfid_ctx *ctx, int64_t items);
 /* Late filter outputs (look-ahead keyed on rfid_mf_work only; off by default).  A rfid_mf_work call that returns its own
- * outputs waits for an upload, a filter launch and the way back: ~28 us per call, a third of a block-by-block run at GNU
- * Radio's default buffers.  With late outputs on, a call uploads and filters its samples as before but RETURNS THE OUTPUTS
- * OF THE CALL BEFORE IT -- the device wrote them into page-locked memory while the scheduler ran the other blocks -- and
- * keeps its own for the next call: *n_produced is then what that earlier call made, not n_in / 5 of this one.  A gr::block
- * may do that (general_work consumes and produces what it says): the adaptor's forecast() asks for no input while
- * outputs are held back, so a scheduler calls the block once more at the end of the input -- with n_in = 0, which hands
- * out what is held back (also after rfid_lookahead_flush) and does nothing else.  Outputs held back must fit the call
- * that brings new samples (RFID_ERR_CAPACITY otherwise, nothing consumed): an adaptor whose output room is smaller than
- * rfid_mf_pending() calls with n_in = 0 first (they are handed out in parts then).  A call takes at most the max_chunk_raw
- * given to rfid_lookahead_enable.  The gate / decoder calls see no difference: the gate is shown the filter's outputs a
- * call later, the passes run over what was uploaded. */
+ * outputs waits for its samples' way through the device: ~17-28 us per call, a third of a block-by-block run at GNU Radio's
+ * default buffers.  With late outputs on, a call stages and filters its samples as before but RETURNS OUTPUTS OF THE CALLS
+ * BEFORE IT -- whatever the device has finished meanwhile, oldest first, as far as out_cap goes -- and holds its own back:
+ * *n_produced is what earlier calls made, not n_in / 5 of this one (it may be 0: the call has consumed its input all the
+ * same).  A gr::block may do that (general_work consumes and produces what it says): the adaptor's forecast() asks for no
+ * input while outputs are held back, so a scheduler calls the block again at the end of the input -- with n_in = 0: such a
+ * call hands out what is held back (waiting for the device if need be: it always hands out something; also after
+ * rfid_lookahead_flush) and does nothing else.  At most three sets of outputs are held back: a call that brings new
+ * samples while three are held needs room for the rest of the oldest (RFID_ERR_CAPACITY otherwise, nothing consumed) -- an
+ * adaptor whose output room is smaller than rfid_mf_pending() simply calls with n_in = 0 first.  A call takes at most the
+ * max_chunk_raw given to rfid_lookahead_enable.  The gate / decoder calls see no difference: the gate is shown the
+ * filter's outputs a call or two later, the passes run over what was uploaded. */
 RFID_API int rfid_lookahead_set_late_outputs(rfid_ctx *ctx, int on);
 /* filter outputs a late-outputs context holds back (0 otherwise) */
 RFID_API int rfid_mf_pending(const rfid_ctx *ctx, int *n_outputs);
+/* ... and how many of them the next call must have room for if it brings new samples (0 unless three sets are held back: then
+ * what is left of the oldest) */
+RFID_API int rfid_mf_must_fetch(const rfid_ctx *ctx, int *n_outputs);
 /* What the adaptor knows about its scheduler: the buffer on the gate's input side holds gate_buffer_items items and no more
  * (GNU Radio: detail()->input(0)->max_possible_items_available(); 65 536-byte buffers = 8 192 items by default), or 0: the
  * queues between the blocks grow as needed (the single-threaded scheduler of rfid/mi355x.h).  Bounded: a quarter of the

@@ -118,9 +118,10 @@ def test_knobs_are_read_once_and_settable(synth_mod):
 
 @pytest.mark.parametrize("seed", [1, 2])
 def test_late_filter_outputs_through_the_c_abi(oracle_mod, synth_mod, seed):
-    """rfid_lookahead_set_late_outputs: a rfid_mf_work call returns the filter outputs of the call before it and holds its own
-    back (no call waits for the device).  Driven like a scheduler with ragged buffers and, every now and then, an output
-    buffer too small for what is held back (the outputs then come in parts, through calls that bring no new samples);
+    """rfid_lookahead_set_late_outputs: a rfid_mf_work call returns filter outputs of the calls before it -- whatever the device
+    has finished, oldest first -- and holds its own back (no call waits for the device; up to three sets are held).  Driven
+    like a scheduler with ragged buffers and, every now and then, an output buffer too small for what is held back (the
+    outputs then come in parts, through calls that bring no new samples);
     nobody announces the end of the input.  The filter outputs concatenated are those of calls that return their own, and
     every decoded window, the statistics and the report equal the oracle's."""
     import rfid
@@ -142,7 +143,19 @@ def test_late_filter_outputs_through_the_c_abi(oracle_mod, synth_mod, seed):
         gq = np.zeros(0, dtype=np.complex64)
         dq = np.zeros(0, dtype=np.complex64)
         pos, n, asked_dry = 0, len(t), 0
-        first = True
+        # up to three sets of outputs are held back; a fourth call with new samples must have room for the oldest: refused
+        # otherwise, nothing consumed
+        for k in range(3):
+            blk = t[pos:pos + 5000]
+            pos += len(blk)
+            y = ctx.mf_work(blk, out_cap=1)
+            assert len(y) <= 1 and ctx.mf_pending() == (k + 1) * 1000 - sum(len(v) for v in ys) - len(y)
+            ys.append(y)
+            gq = np.concatenate([gq, y]) if len(gq) else y
+        held = ctx.mf_pending()
+        with pytest.raises(rfid.capi.RfidError):
+            ctx.mf_work(t[pos:pos + 5000], out_cap=10)
+        assert ctx.mf_pending() == held
         while pos < n or len(gq) or ctx.mf_pending():
             if pos < n or ctx.mf_pending():
                 held = ctx.mf_pending()
@@ -151,17 +164,11 @@ def test_late_filter_outputs_through_the_c_abi(oracle_mod, synth_mod, seed):
                     blk = t[:0]                                  # what is held back first (in parts when the room is short)
                 else:
                     blk = t[pos:pos + int(rng.integers(1000, 150001))]
-                if first:
-                    assert held == 0
                 pos += len(blk)
                 y = ctx.mf_work(blk, out_cap=max(room, 1))
-                assert len(y) == min(held, max(room, 1))         # ... never this call's own
-                if first and len(blk) >= 5:
-                    assert ctx.mf_pending() == len(blk) // 5
-                    with pytest.raises(rfid.capi.RfidError):     # new samples while what is held back does not fit: refused,
-                        ctx.mf_work(t[pos:pos + 100], out_cap=ctx.mf_pending() - 1)   # nothing consumed
-                    assert ctx.mf_pending() == len(blk) // 5
-                    first = False
+                assert len(y) <= min(held, max(room, 1))         # ... never this call's own
+                assert len(blk) or len(y) or not held            # a call without new samples hands out something
+                assert ctx.mf_pending() == held - len(y) + (len(t[:pos]) // 5 - len(t[:pos - len(blk)]) // 5)
                 ys.append(y)
                 gq = np.concatenate([gq, y]) if len(gq) else y
             while len(gq):
