@@ -345,10 +345,12 @@ def measure(torch, wl, steps, warmup, barrier, gather_elapsed=None, n_series=Non
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pt = json.load(f)
-        if pt.get("streams") == B and pt.get("raw_per_stream") == L:
-            traffic = pt.get("hbm_bytes_per_step", {})
-            traffic_source = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of "
-                              "this workload (%s); a committed cross-reference, NOT measured in this run" % pt.get("source", "?"))
+        for ent in [pt] + list(pt.get("other_workloads", [])):     # (configs[1]; configs[2] and configs[3]'s stream since round 5)
+            if ent.get("streams") == B and ent.get("raw_per_stream") == L:
+                traffic = ent.get("hbm_bytes_per_step", {})
+                traffic_source = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of "
+                                  "this workload (%s); a committed cross-reference, NOT measured in this run" % ent.get("source", "?"))
+                break
     except Exception:
         pass
 
@@ -403,7 +405,8 @@ def other_configs(torch, rfid, synth, args, device, rank):
                      "epc_decodes_per_s": round(m["n_epc_ok"] / el, 1), "windows_per_step": m["n_windows"],
                      "parity_check": m["parity_text"],
                      "roofline_by_kernel": {k: {f: m["roof"](k)[f] for f in ("ms_per_step", "achieved", "frac", "frac_of_achievable",
-                                                                             "algorithmic_bytes")} for k in m["alg"]},
+                                                                             "algorithmic_bytes", "traffic", "traffic_source")}
+                                            for k in m["alg"]},
                      "setup_s": round(time.perf_counter() - t0, 2)}
             if m["rep"]["pieces"]:
                 entry["long_stream"] = {k: m["rep"][k] for k in ("pieces", "units", "avg_rounds", "dc_rounds", "verified", "gave_up")
