@@ -279,3 +279,33 @@ def test_gate_consumes_ahead_through_the_c_abi(oracle_mod, synth_mod, keyed_on, 
         assert g.tobytes() == gated_ref.tobytes()
     finally:
         tb.ctx.close()
+
+
+@pytest.mark.parametrize("limit", [["--max-queries", "25"], ["--unique-tags", "1"]], ids=["max-queries", "unique-tags"])
+def test_reader_terminates_alike_under_every_scheduler(tmp_path, oracle_mod, synth_mod, limit):
+    """MAX_NUM_QUERIES / NUMBER_UNIQUE_TAGS reached in the middle of the trace (gate_impl.cc:101-109: the gate swallows the rest):
+    the report, the reader's output and the gated samples of the per-call path, of the single-threaded scheduler and of GNU
+    Radio's rules with bounded buffers -- the gate consuming ahead or deciding at once, both keyings -- are the same bytes,
+    and the report is the oracle's."""
+    import rfid
+    exe = _exe()
+    t = synth_mod.make_trace(n_rounds=60, fixed_q=1, tag_ids=(0x27, 0x3C), seed=91, sigma=0.01, t1_jitter_raw=4)
+    kw = dict(max_num_queries=25) if limit[0] == "--max-queries" else dict(number_unique_tags=1)
+    o = oracle_mod.run_trace(t.samples, oracle_mod.config(fixed_q=1, **kw))
+    full = oracle_mod.run_trace(t.samples, oracle_mod.config(fixed_q=1, max_num_queries=1 << 30))
+    assert 0 < o.n_windows < full.n_windows                      # (the limit bites)
+    path = tmp_path / "t.bin"
+    rfid.batch.write_trace_file(str(path), t.samples)
+    outs = {}
+    for name, extra, env in (("percall", ["--chunk", "8192"], {"RFID_LOOKAHEAD": "0"}),
+                             ("sts_mf", ["--chunk", "8192"], None),
+                             ("sts_hostfir", ["--chunk", "8192", "--host-fir"], None),
+                             ("bounded_mf", ["--scheduler", "bounded", "--buffer", "8192"], None),
+                             ("bounded_hostfir", ["--scheduler", "bounded", "--buffer", "8192", "--host-fir"], None),
+                             ("bounded_hostfir_decide_at_once", ["--scheduler", "bounded", "--buffer", "8192", "--host-fir"], {"RFID_GATE_CONSUME_AHEAD": "0"})):
+        stdout, files = _run(exe, path, tmp_path, name, ["--fixed-q", "1"] + limit + extra, env)
+        assert stdout.startswith(o.print_results()), (name, stdout[-800:])
+        outs[name] = files
+    for key, got in outs.items():
+        assert got[0] == outs["percall"][0], ("reader output differs", key)
+        assert got[2] == outs["percall"][2], ("gated samples differ", key)
