@@ -26,6 +26,11 @@
 #define LS2_LAUNCH(kernel, gx, gy, block, args) \
   hipLaunchKernelGGL(rfidk::kernel, dim3((unsigned)(gx), (unsigned)(gy)), dim3((unsigned)(block)), 0, ls2_stream, args)
 static thread_local hipStream_t ls2_stream = nullptr;
+// (experiment knob front_lds_kb: dynamic LDS the first pass's workgroups ask for on top of their own -- fewer of its one-wave
+// workgroups per CU, so the small launches of the pass before find wave slots beside it)
+static thread_local unsigned ls2_front_lds = 0;
+#define LS2_LAUNCH_FRONT(kernel, gx, gy, block, args) \
+  hipLaunchKernelGGL(rfidk::kernel, dim3((unsigned)(gx), (unsigned)(gy)), dim3((unsigned)(block)), ls2_front_lds, ls2_stream, args)
 // RFID_LA_PROFILE=1: where the look-ahead's time goes (printed when the context is destroyed)
 static double g_la_t[20] = {0};
 static long g_la_n[20] = {0};
@@ -60,6 +65,7 @@ struct RfidKnobs {
   int front_chunks = 1;    // RFID_FRONT_CHUNKS      2..16: the time-chunked stage kernels on two streams (round 1's overlap)
   int fsm_lanes_min = -1;  // RFID_LS2_FSM_LANES_MIN from how many possible units on the state machine runs one lane per unit (-1: 8192)
   // ---- experiment knobs of round 4's list (RFID_LS_FUSED=0), kept for its A/B tables ----
+  int front_lds_kb = -1;   // RFID_LS_FRONT_LDS_KB   0..64: extra LDS per workgroup of the long-stream first pass (caps its waves per CU); -1: 10 for long traces
   int mf_parts = 3;        // RFID_MF_PARTS          1..8 launches of the next pass's matched filter
   int mf_split[8] = {35, 45, 20, 0, 0, 0, 0, 0};   // RFID_MF_SPLIT  their shares in percent (comma list, each 0..100, sum <= 100 + rest to the last)
 };
@@ -320,6 +326,7 @@ const KnobEntry g_knob_table[] = {
   {"front_unfused", "RFID_FRONT_UNFUSED", &RfidKnobs::front_unfused, 0, 1},
   {"front_chunks", "RFID_FRONT_CHUNKS", &RfidKnobs::front_chunks, 1, rfid_ctx::MAX_CHUNKS},
   {"fsm_lanes_min", "RFID_LS2_FSM_LANES_MIN", &RfidKnobs::fsm_lanes_min, -1, 1 << 30},
+  {"front_lds_kb", "RFID_LS_FRONT_LDS_KB", &RfidKnobs::front_lds_kb, -1, 64},
   {"mf_parts", "RFID_MF_PARTS", &RfidKnobs::mf_parts, 1, 8},
 };
 int clamp_int(long v, int lo, int hi) { return (int)(v < lo ? lo : (v > hi ? hi : v)); }
@@ -558,6 +565,15 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
     a.y_w = c->d_y;
   }
   ls2_stream = ahead ? c->stream2 : c->stream;
+  // The first pass's one-wave workgroups would take every wave slot of the chip; launched beside the rest of the pass before
+  // (re-run rounds, state machine, dc_est: a few waves each, one launch waiting for the other) they ask for 10 KB of LDS
+  // they do not use -- 12 instead of 16 of them per CU, and the small launches find room at once: configs[2] back to back
+  // 8.17 -> 7.6 ms, each pass waited for unchanged (profiles/r05/ls2_fused_front.txt, 7.).  Not for short streams, whose
+  // first pass is a few rounds of waves and on the critical path (configs[3]: 10 183 pieces).
+  {
+    const int kb = (c->knobs.front_lds_kb >= 0) ? c->knobs.front_lds_kb : ((geo.NS >= 32768) ? 10 : 0);
+    ls2_front_lds = (unsigned)kb * 1024u;
+  }
   a.keep_flat_count = ahead ? 1 : 0;
 #ifdef LS2_CHEAT
   a.cheat_sigma = getenv("RFID_LS_CHEAT") ? atoi(getenv("RFID_LS_CHEAT")) : 0;   // (EXPERIMENT build only)

@@ -6,6 +6,9 @@
 // before including this file.
 #pragma once
 #include <stddef.h>
+#ifndef LS2_LAUNCH_FRONT   // (the includer may give the first pass's launch a form of its own)
+#define LS2_LAUNCH_FRONT LS2_LAUNCH
+#endif
 #include <stdint.h>
 
 namespace rfidk {
@@ -160,7 +163,7 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
   if (fused) {
     // matched filter + piece boundaries + the first avg_ampl pass in one sweep over the raw samples; then the pieces' links,
     // the idle cuts from the blocks' not-carrier masks (unless given: tests) and the units' table from them
-    LS2_LAUNCH(ls2_front_kernel, 8 * ((NS + 7) / 8), 1, 64, a);
+    LS2_LAUNCH_FRONT(ls2_front_kernel, 8 * ((NS + 7) / 8), 1, 64, a);
     LS2_LAUNCH(ls2_link_kernel, (NS + 255) / 256, 1, 256, a);
     if (a.max_bc > 1 && search_cuts) LS2_LAUNCH(ls2_idle_cut_kernel, (NH + 255) / 256, 1, 256, a);
     LS2_LAUNCH(ls2_pieces_kernel, (NS + 255) / 256, 1, 256, U(a));
