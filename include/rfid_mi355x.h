@@ -242,7 +242,8 @@ RFID_API int rfid_lookahead_set_coalesce(rfid_ctx *ctx, int64_t items);
 /* Late filter outputs (look-ahead keyed on rfid_mf_work only; off by default).  A rfid_mf_work call that returns its own
  * outputs waits for its samples' way through the device: ~17-28 us per call, a third of a block-by-block run at GNU Radio's
  * default buffers.  With late outputs on, a call stages and filters its samples as before but RETURNS OUTPUTS OF THE CALLS
- * BEFORE IT -- whatever the device has finished meanwhile, oldest first, as far as out_cap goes -- and holds its own back:
+ * BEFORE IT -- whatever the device has finished meanwhile, oldest first, as far as out_cap goes -- and holds its own back
+ * (unless the device is through with them before the call returns):
  * *n_produced is what earlier calls made, not n_in / 5 of this one (it may be 0: the call has consumed its input all the
  * same).  A gr::block may do that (general_work consumes and produces what it says): the adaptor's forecast() asks for no
  * input while outputs are held back, so a scheduler calls the block again at the end of the input -- with n_in = 0: such a
