@@ -65,6 +65,7 @@ struct RfidKnobs {
   int front_chunks = 1;    // RFID_FRONT_CHUNKS      2..16: the time-chunked stage kernels on two streams (round 1's overlap)
   int fsm_lanes_min = -1;  // RFID_LS2_FSM_LANES_MIN from how many possible units on the state machine runs one lane per unit (-1: 8192)
   // ---- experiment knobs of round 4's list (RFID_LS_FUSED=0), kept for its A/B tables ----
+  int la_upload_kernel = 1;  // RFID_LA_UPLOAD_KERNEL  look-ahead: 1 a call's samples are fetched from page-locked memory by a launch, 0 by a transfer
   int front_lds_kb = -1;   // RFID_LS_FRONT_LDS_KB   0..64: extra LDS per workgroup of the long-stream first pass (caps its waves per CU); -1: 10 for long traces
   int mf_parts = 3;        // RFID_MF_PARTS          1..8 launches of the next pass's matched filter
   int mf_split[8] = {35, 45, 20, 0, 0, 0, 0, 0};   // RFID_MF_SPLIT  their shares in percent (comma list, each 0..100, sum <= 100 + rest to the last)
@@ -326,6 +327,7 @@ const KnobEntry g_knob_table[] = {
   {"front_unfused", "RFID_FRONT_UNFUSED", &RfidKnobs::front_unfused, 0, 1},
   {"front_chunks", "RFID_FRONT_CHUNKS", &RfidKnobs::front_chunks, 1, rfid_ctx::MAX_CHUNKS},
   {"fsm_lanes_min", "RFID_LS2_FSM_LANES_MIN", &RfidKnobs::fsm_lanes_min, -1, 1 << 30},
+  {"la_upload_kernel", "RFID_LA_UPLOAD_KERNEL", &RfidKnobs::la_upload_kernel, 0, 1},
   {"front_lds_kb", "RFID_LS_FRONT_LDS_KB", &RfidKnobs::front_lds_kb, -1, 64},
   {"mf_parts", "RFID_MF_PARTS", &RfidKnobs::mf_parts, 1, 8},
 };
@@ -2641,7 +2643,14 @@ int la_append(rfid_ctx *c, const rfid_cf32 *src, int64_t n, const rfid_cf32 **st
   if (!pinned) { memcpy(io.h_pin[up] + io.acc_new, src, sizeof(rfid_cf32) * (size_t)n); src = io.h_pin[up] + io.acc_new; }
   if (staged) *staged = src;
   else {
-    HIPCHK(c, hipMemcpyAsync(io.d_buf[up] + io.tail_max + io.acc_new, src, sizeof(rfid_cf32) * (size_t)n, hipMemcpyHostToDevice, io.copy_stream));
+    if (c->knobs.la_upload_kernel && n <= (1 << 22)) {   // (a launch that reads the page-locked samples over the bus: less host time than a transfer)
+      UploadArgs ua;
+      ua.src = (const float2 *)src; ua.dst = io.d_buf[up] + io.tail_max + io.acc_new; ua.n = (int)n;
+      hipLaunchKernelGGL(upload_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, io.copy_stream, ua);
+      HIPCHK(c, hipGetLastError());
+    } else {
+      HIPCHK(c, hipMemcpyAsync(io.d_buf[up] + io.tail_max + io.acc_new, src, sizeof(rfid_cf32) * (size_t)n, hipMemcpyHostToDevice, io.copy_stream));
+    }
     HIPCHK(c, hipEventRecord(io.ev_up[up], io.copy_stream));
   }
   io.acc_new += n;

@@ -119,6 +119,24 @@ RFID_KERNEL(MF_THREADS) void mf_boxcar25_decim5_kernel(MfArgs a) {
   RFID_SHARED float4 tile4[MF_RAW / 2 + 2];
   mf_tile(a, (int)blockIdx.y + a.stream0, (int64_t)blockIdx.x + a.tile0, tile4);
 }
+// Look-ahead keyed on the gate: a call's new samples (the foreign filter's outputs, staged in page-locked memory) fetched over the
+// bus by a launch -- cheaper for the calling thread than setting up a transfer of a few kilobytes (every thread's loads first)
+struct UploadArgs { const float2 *src; float2 *dst; int n; };
+RFID_KERNEL(256) void upload_kernel(UploadArgs a) {
+  constexpr int PER = 4;
+  const int base = (int)blockIdx.x * 256 * PER + (int)threadIdx.x;
+  float2 v[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int i = base + u * 256;
+    v[u] = (i < a.n) ? a.src[i] : make_float2(0.0f, 0.0f);
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int i = base + u * 256;
+    if (i < a.n) a.dst[i] = v[u];
+  }
+}
 // Look-ahead, one rfid_mf_work call: the call's new raw samples come straight out of page-locked host memory -- no copy
 // engine in front of the filter, whose hand-over to the kernel queue was half of the call's way through the device.  Every
 // workgroup stages the window of its tile (the samples in front of the call from the device buffer, the new ones over the
