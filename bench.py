@@ -23,6 +23,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import re
 import statistics
 import sys
 import time
@@ -230,6 +231,149 @@ def streaming_leg(torch, rfid, wl, args, device):
 WAKE_S = 0.08      # seconds of the workload's own passes before the warm-up steps (see measure())
 
 
+# ---------------------------------------------------------------------------------------------------
+# device_state: what the device's clocks / power / temperature were around the timed region.  Boxes of the pool differ by
+# +-3-7 % on an untouched kernel (2.40 -> 2.56 ms); this is what lets a reader attribute that.  sysfs only
+# (readable by an ordinary user), sampled by a thread every few ms while the timed region runs; rocm-smi once, outside it.
+# ---------------------------------------------------------------------------------------------------
+def _sysfs_card(torch, device):
+    """The /sys/class/drm/cardN/device directory of `device` (matched by PCI address; else the index-th amdgpu card)."""
+    import glob
+    cards = []
+    for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        try:
+            if open(os.path.join(d, "vendor")).read().strip() == "0x1002" and os.path.exists(os.path.join(d, "pp_dpm_sclk")):
+                cards.append(d)
+        except OSError:
+            continue
+    try:
+        pr = torch.cuda.get_device_properties(device)
+        want = "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        for d in cards:
+            if want in os.path.realpath(d):
+                return d
+    except Exception:
+        pass
+    idx = device.index or 0
+    return cards[idx] if idx < len(cards) else (cards[0] if cards else None)
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def _dpm_current(text):
+    """'0: 132Mhz\n1: 2400Mhz *' -> 2400 (the starred level; a single level counts as current)."""
+    if not text:
+        return None
+    lines = [ln for ln in text.splitlines() if ln.strip()]
+    pick = [ln for ln in lines if "*" in ln] or (lines if len(lines) == 1 else [])
+    if not pick:
+        return None
+    m = re.search(r"(\d+(?:\.\d+)?)\s*[Mm][Hh]z", pick[0])
+    return float(m.group(1)) if m else None
+
+
+class DeviceStateSampler:
+    """Samples sclk / mclk / power / temperature from sysfs on a thread while a region runs."""
+
+    def __init__(self, torch, device, period_s=0.004):
+        import glob
+        self.card = _sysfs_card(torch, device)
+        self.period = period_s
+        self.samples = []
+        self._stop = False
+        self._thread = None
+        self.hwmon = None
+        if self.card:
+            hw = sorted(glob.glob(os.path.join(self.card, "hwmon", "hwmon*")))
+            self.hwmon = hw[0] if hw else None
+
+    def _one(self):
+        c, h = self.card, self.hwmon
+        s = {"t": time.perf_counter()}
+        if c:
+            s["sclk_mhz"] = _dpm_current(_read(os.path.join(c, "pp_dpm_sclk")))
+            s["mclk_mhz"] = _dpm_current(_read(os.path.join(c, "pp_dpm_mclk")))
+            b = _read(os.path.join(c, "gpu_busy_percent"))
+            s["busy_pct"] = int(b) if b and b.isdigit() else None
+        if h:
+            for key, names, scale in (("power_w", ("power1_average", "power1_input"), 1e-6),
+                                      ("temp_edge_c", ("temp1_input",), 1e-3), ("temp_junction_c", ("temp2_input",), 1e-3),
+                                      ("temp_mem_c", ("temp3_input",), 1e-3)):
+                for n in names:
+                    v = _read(os.path.join(h, n))
+                    if v and v.lstrip("-").isdigit():
+                        s[key] = round(int(v) * scale, 1)
+                        break
+        return s
+
+    def start(self):
+        if not self.card:
+            return
+        import threading
+
+        def loop():
+            while not self._stop:
+                self.samples.append(self._one())
+                time.sleep(self.period)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join(timeout=1.0)
+
+    def summary(self, t0=None, t1=None):
+        ss = [s for s in self.samples if (t0 is None or s["t"] >= t0) and (t1 is None or s["t"] <= t1)] or self.samples
+        out = {"samples": len(ss), "period_ms": round(1e3 * self.period, 1)}
+        for key in ("sclk_mhz", "mclk_mhz", "power_w", "temp_edge_c", "temp_junction_c", "temp_mem_c", "busy_pct"):
+            v = [s[key] for s in ss if s.get(key) is not None]
+            if v:
+                out[key] = {"min": min(v), "median": statistics.median(v), "max": max(v)}
+        return out
+
+
+def device_state_static(torch, device):
+    """Power cap, clock table, driver / runtime versions: read once, outside every timed region."""
+    card = _sysfs_card(torch, device)
+    out = {"sysfs": card}
+    if card:
+        import glob
+        hw = sorted(glob.glob(os.path.join(card, "hwmon", "hwmon*")))
+        if hw:
+            for n in ("power1_cap", "power1_cap_max", "power1_cap_default"):
+                v = _read(os.path.join(hw[0], n))
+                if v and v.isdigit():
+                    out[n + "_w"] = round(int(v) * 1e-6, 1)
+        for n in ("pp_dpm_sclk", "pp_dpm_mclk", "pp_dpm_fclk"):
+            v = _read(os.path.join(card, n))
+            if v:
+                out[n] = " | ".join(ln.strip() for ln in v.splitlines())
+        out["power_dpm_force_performance_level"] = _read(os.path.join(card, "power_dpm_force_performance_level"))
+        out["vbios_version"] = _read(os.path.join(card, "vbios_version"))
+    out["amdgpu_driver"] = _read("/sys/module/amdgpu/version")
+    out["kernel"] = os.uname().release
+    out["hip_runtime"] = getattr(torch.version, "hip", None)
+    out["torch"] = torch.__version__
+    try:
+        import subprocess
+        r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--showperflevel", "--showmaxpower", "--json"],
+                           capture_output=True, text=True, timeout=20)
+        if r.returncode == 0 and r.stdout.strip():
+            j = json.loads(r.stdout.strip().splitlines()[-1])
+            k = "card%d" % (device.index or 0)
+            out["rocm_smi_idle"] = j.get(k, j)
+    except Exception as e:
+        out["rocm_smi_idle"] = "unavailable: %r" % (e,)
+    return out
+
+
 def measure(torch, wl, steps, warmup, barrier, gather_elapsed=None, n_series=None, back_to_back=True):
     """`warmup` untimed passes, then exactly `steps` timed passes of the workload's whole chain, enqueued one behind the other
     and waited for once (bracketed by `barrier()`, which synchronises the device; back_to_back=False: every pass waited for
@@ -258,6 +402,8 @@ def measure(torch, wl, steps, warmup, barrier, gather_elapsed=None, n_series=Non
 
     # ---- the timed region: exactly `steps` passes, nothing else -------------------------------------------------------
     step_s = []
+    sampler = DeviceStateSampler(torch, data.device)      # (a thread reading sysfs every 4 ms: clocks / power / temperature)
+    sampler.start()
     barrier()
     t0 = time.perf_counter()
     if back_to_back:
@@ -271,6 +417,8 @@ def measure(torch, wl, steps, warmup, barrier, gather_elapsed=None, n_series=Non
             step_s.append(time.perf_counter() - ts)
     barrier()
     elapsed = time.perf_counter() - t0
+    sampler.stop()
+    dev_state = sampler.summary(t0, t0 + elapsed)
     ms_by_rank = [1e3 * elapsed / steps]
     if gather_elapsed is not None:
         every = gather_elapsed(elapsed)               # control plane only: every rank's time; the job's = the slowest
@@ -372,7 +520,7 @@ def measure(torch, wl, steps, warmup, barrier, gather_elapsed=None, n_series=Non
                 "timing": "HIP events on the library's stream around each launch, %d untimed passes after the timed region"
                           % len(k_series["gate_ms"])}
 
-    return dict(elapsed=elapsed, step_s=step_s, b2b_ms=b2b_ms, wake={"passes": wake_n, "ms": round(wake_ms, 1)}, ms_by_rank=ms_by_rank, k_ms=k_ms, alg=alg, key=key, roof=roof, rep=rep, st=st,
+    return dict(elapsed=elapsed, step_s=step_s, b2b_ms=b2b_ms, dev_state=dev_state, wake={"passes": wake_n, "ms": round(wake_ms, 1)}, ms_by_rank=ms_by_rank, k_ms=k_ms, alg=alg, key=key, roof=roof, rep=rep, st=st,
                 n_epc_ok=n_epc_ok, n_windows=n_windows, n_rn16=n_rn16, n_epc=n_epc, parity_ok=parity_ok, parity_text=parity_text)
 
 
@@ -403,7 +551,7 @@ def other_configs(torch, rfid, synth, args, device, rank):
                      "ms_per_step": round(1e3 * el, 4), "value": round(wl["L"] / el / 1e6, 2), "unit": "Msamples/s",
                      "ms_per_step_each_waited_for": round(1e3 * statistics.fmean(m["step_s"]), 4),
                      "epc_decodes_per_s": round(m["n_epc_ok"] / el, 1), "windows_per_step": m["n_windows"],
-                     "parity_check": m["parity_text"],
+                     "parity_check": m["parity_text"], "device_state": m["dev_state"],
                      "roofline_by_kernel": {k: {f: m["roof"](k)[f] for f in ("ms_per_step", "achieved", "frac", "frac_of_achievable",
                                                                              "algorithmic_bytes", "traffic", "traffic_source")}
                                             for k in m["alg"]},
@@ -502,6 +650,7 @@ def main():
     ctl_device = device if backend == "nccl" else torch.device("cpu")   # where the control-plane tensors live
     n_gpus = world
 
+    dev_static = device_state_static(torch, device) if rank == 0 else {}
     if args.config == "1":
         wl = workload_replicas(torch, rfid, synth, args, device, rank, args.streams or 1024, "configs[1]")
     elif args.config == "4shard":
@@ -586,6 +735,9 @@ def main():
         "devices_by_rank": devices,
         "control_plane": ("torch.distributed/%s: barrier + all_gather of the ranks' times and checks" % backend) if dist is not None
                          else "single process",
+        "device_state": dict(during_timed_region=m["dev_state"], **dev_static,
+                             note="rank 0's device; during_timed_region = sysfs (pp_dpm_sclk / pp_dpm_mclk starred level, hwmon power and "
+                                  "temperatures) sampled by a thread while the K timed passes ran; the rest read once before the workload was built"),
     }
     if rep["pieces"]:
         out["long_stream"] = dict(rep, note="traces cut along time into pieces processed at once (avg_ampl, state machine, dc_est) "
