@@ -64,6 +64,7 @@ struct RfidKnobs {
   int front_unfused = 0;   // RFID_FRONT_UNFUSED     1: many traces through the stage kernels instead of front_end_fused_kernel
   int front_chunks = 1;    // RFID_FRONT_CHUNKS      2..16: the time-chunked stage kernels on two streams (round 1's overlap)
   int fsm_lanes_min = -1;  // RFID_LS2_FSM_LANES_MIN from how many possible units on the state machine runs one lane per unit (-1: 8192)
+  int dc_rounds = -1;      // RFID_LS2_DC_ROUNDS     0..64: dc_est rounds a long-stream pass enqueues (-1: by its size / what the passes before needed)
   // ---- experiment knobs of round 4's list (RFID_LS_FUSED=0), kept for its A/B tables ----
   int la_upload_kernel = 1;  // RFID_LA_UPLOAD_KERNEL  look-ahead: 1 a call's samples are fetched from page-locked memory by a launch, 0 by a transfer
   int front_lds_kb = -1;   // RFID_LS_FRONT_LDS_KB   0..64: extra LDS per workgroup of the long-stream first pass (caps its waves per CU); -1: 10 for long traces
@@ -100,6 +101,8 @@ struct rfid_ctx {
   int ls2_P = 0;                  // its nominal piece length
   int ls2_rounds[3] = {0, 0, 0};  // re-run rounds its launch list held per stage (avg_ampl, state machine, dc_est)
   bool ls2_generous = false;      // a pass ran out of rounds once: the launch lists hold the full number of rounds from then on
+  int ls2_dc_need = -1;           // dc_est rounds the next pass enqueues (-1: by its size): what the passes before needed + 2; twice that
+                                  // where the finishing walk had to take units (sums that hover at a binade edge: SURVEY 8(d)'s noisy traces)
   int ls_mode = 1;                // 0 never, 1 automatic, 2 whenever a trace can be cut
   double ls_fixed_ms = 0.45, ls_ns_per_sample = 0.03, seq_ns_per_sample = 10.2;   // cost model of the automatic choice (ls_calibrate)
   bool ls_calibrated = false;     // the three numbers were measured on this device (or that was tried, or is not wanted)
@@ -327,6 +330,7 @@ const KnobEntry g_knob_table[] = {
   {"front_unfused", "RFID_FRONT_UNFUSED", &RfidKnobs::front_unfused, 0, 1},
   {"front_chunks", "RFID_FRONT_CHUNKS", &RfidKnobs::front_chunks, 1, rfid_ctx::MAX_CHUNKS},
   {"fsm_lanes_min", "RFID_LS2_FSM_LANES_MIN", &RfidKnobs::fsm_lanes_min, -1, 1 << 30},
+  {"dc_rounds", "RFID_LS2_DC_ROUNDS", &RfidKnobs::dc_rounds, -1, 64},
   {"la_upload_kernel", "RFID_LA_UPLOAD_KERNEL", &RfidKnobs::la_upload_kernel, 0, 1},
   {"front_lds_kb", "RFID_LS_FRONT_LDS_KB", &RfidKnobs::front_lds_kb, -1, 64},
   {"mf_parts", "RFID_MF_PARTS", &RfidKnobs::mf_parts, 1, 8},
@@ -499,9 +503,9 @@ bool ls_may_apply(const rfid_ctx *c, int B, int64_t n_dec) {
   const double t_ls = c->ls_fixed_ms + 1e-6 * c->ls_ns_per_sample * (double)B * (double)n_dec;
   return c->ls_mode == 2 || t_ls < 3.0 * t_seq;
 }
-size_t ls_workspace_bytes(int B, int64_t n_dec, int64_t y_stride) {
+size_t ls_workspace_bytes(int B, int64_t n_dec, int64_t y_stride, int wmax) {
   const Ls2Geometry g = ls2_geometry(B, n_dec);
-  return g.P ? ls2_layout(g, B, y_stride).total : 0;
+  return g.P ? ls2_layout(g, B, y_stride, wmax).total : 0;
 }
 
 int ls_calibrate(rfid_ctx *c);
@@ -527,9 +531,17 @@ struct LsOpts {
 // A look at the last pass's control block, if that pass is over (called before a pass enqueues anything): one that ran
 // out of rounds -- not one that found no cut -- makes the following passes enqueue the full number of rounds.
 void ls_note_last_pass(rfid_ctx *c) {
-  if (c->ls2_generous || !c->d_ls2_ctl || !c->ls2_host) return;
-  if (hipStreamQuery(c->stream) == hipSuccess && c->ls2_host->fail == 0 && c->ls2_host->ok == 0 && c->ls2_host->n_pieces > 0)
-    c->ls2_generous = true;
+  if (!c->d_ls2_ctl || !c->ls2_host) return;
+  if (hipStreamQuery(c->stream) == hipSuccess) {
+    const Ls2Ctl &k = *c->ls2_host;
+    if (!c->ls2_generous && k.fail == 0 && k.ok == 0 && k.n_pieces > 0) c->ls2_generous = true;
+    if (k.fail == 0 && k.n_pieces > 0 && k.dc_rounds > 0) {
+      // dc_est: as many rounds as that pass used, + 2; where its rounds ran out and the finishing walk took units, twice its rounds
+      int want = (k.dc_finished > 0) ? 2 * (c->ls2_rounds[2] + 1) : (k.dc_rounds + 1);
+      if (want > LS2_DC_MAXR) want = LS2_DC_MAXR;
+      if (want > c->ls2_dc_need) c->ls2_dc_need = want;
+    }
+  }
   (void)hipGetLastError();
 }
 int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
@@ -537,7 +549,7 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
   c->d_ls2_ctl = nullptr;
   const Ls2Geometry geo = ls2_geometry(c->B, n_dec);
   if (geo.P == 0 || c->B > 65535) return RFID_OK;
-  const Ls2Layout L = ls2_layout(geo, c->B, c->y_stride);
+  const Ls2Layout L = ls2_layout(geo, c->B, c->y_stride, c->wmax);
   const bool ahead = opt.ahead && opt.raw && c->ls2_ws.cap >= L.total && c->ls2_ws_alt.cap >= L.total;
   if (opt.ahead && !ahead) return RFID_OK;   // (the caller takes the pass without the second stream)
   if (L.total > c->ls2_ws.cap) {
@@ -577,9 +589,6 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
     ls2_front_lds = (unsigned)kb * 1024u;
   }
   a.keep_flat_count = ahead ? 1 : 0;
-#ifdef LS2_CHEAT
-  a.cheat_sigma = getenv("RFID_LS_CHEAT") ? atoi(getenv("RFID_LS_CHEAT")) : 0;   // (EXPERIMENT build only)
-#endif
   {   // test hook: from how many possible heads on the state machine takes its one-lane-per-unit form (default 8192)
     static const int lanes_min_default = ls2_fsm_lanes_min();
     ls2_fsm_lanes_min() = (c->knobs.fsm_lanes_min >= 0) ? c->knobs.fsm_lanes_min : lanes_min_default;
@@ -602,7 +611,7 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
   };
   c->ls2_mark_failed = false;
   c->ls2_gap_marks = opt.marks;
-  ls2_enqueue(a, true, c->ls2_rounds, c->ls2_generous, -1, (opt.marks || ahead) ? +mark : nullptr, c);
+  ls2_enqueue(a, true, c->ls2_rounds, c->ls2_generous, (c->knobs.dc_rounds >= 0) ? c->knobs.dc_rounds : c->ls2_dc_need, (opt.marks || ahead) ? +mark : nullptr, c);
   ls2_stream = c->stream;
   HIPCHK(c, hipGetLastError());
   if (c->ls2_mark_failed) return fail(c, RFID_ERR_HIP, "long-stream front end: stream hand-over");
@@ -658,6 +667,30 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
     fprintf(stderr, "\n[ls2] |D| histogram (same bins):");
     for (int b = 0; b < 8; ++b) fprintf(stderr, " %ld", hist_d[b]);
     fprintf(stderr, "\n");
+    {   // dc_est: where the units' true starts lay in their windows (offset from the centre of the latest run), what is settled
+      const size_t NHh = (size_t)c->B * (size_t)geo.max_bc;
+      std::vector<int> dT(2 * NHh), dcen(2 * NHh), dstat(NHh);
+      HIPCHK(c, hipMemcpy(dT.data(), a.dT, sizeof(int) * dT.size(), hipMemcpyDeviceToHost));
+      HIPCHK(c, hipMemcpy(dcen.data(), a.dcen, sizeof(int) * dcen.size(), hipMemcpyDeviceToHost));
+      HIPCHK(c, hipMemcpy(dstat.data(), a.dstat, sizeof(int) * dstat.size(), hipMemcpyDeviceToHost));
+      long units = 0, settled = 0, hd[2][8] = {{0}};
+      for (size_t t = 0; t < NHh; ++t) {
+        if (!(dstat[t] & 4)) continue;
+        units++;
+        if ((dstat[t] & 3) == 3) settled++;
+        for (int q = 0; q < 2; ++q) {
+          const long D = labs((long)dT[2 * t + q] - (long)dcen[2 * t + q]);
+          int bd = 0; for (long v = D; v > 0 && bd < 7; v >>= 3) bd++;
+          hd[q][bd]++;
+        }
+      }
+      fprintf(stderr, "[ls2] dc_est: %ld units, %ld settled, finishing walk took %d, rounds used %d of %d enqueued\n", units, settled, k.dc_finished, k.dc_rounds, c->ls2_rounds[2] + 1);
+      for (int q = 0; q < 2; ++q) {
+        fprintf(stderr, "[ls2] dc_est %s |true start - centre of the latest run| (0, <8, <64, <512, <4096, <32768, <262144, more):", q ? "im" : "re");
+        for (int b = 0; b < 8; ++b) fprintf(stderr, " %ld", hd[q][b]);
+        fprintf(stderr, "\n");
+      }
+    }
   }
   return RFID_OK;
 }
@@ -1180,7 +1213,7 @@ int rfid_batch_plan(rfid_ctx *c, int n_streams, int64_t max_raw) {
         else { (void)hipGetLastError(); c->alt_y_blk = nullptr; }
       }
     }
-    const size_t need = ls_workspace_bytes(n_streams, n_dec, c->y_stride);
+    const size_t need = ls_workspace_bytes(n_streams, n_dec, c->y_stride, c->wmax);
     if (need > c->ls2_ws.cap) {
       if (c->ls2_ws.p) (void)hipFree(c->ls2_ws.p);
       c->ls2_ws.p = nullptr; c->ls2_ws.cap = 0;
@@ -1652,9 +1685,9 @@ int rfid_batch_ls_report(const rfid_ctx *c, rfid_ls_report *out) {
   out->dc_rounds = k.dc_rounds; out->dc_reruns = k.dc_reruns;
   for (int r = 0; r <= rf; ++r) out->cuts_dropped += k.fsm_count[r];
   out->windows = k.n_windows;
-  out->dc_pieces = k.n_dc_pieces;
+  out->dc_finished = k.dc_finished;
   out->verified = (k.ok != 0) ? 1 : 0;
-  out->gave_up = out->verified ? 0 : (k.fail ? k.fail : (k.avg_count[ra] ? 2 : (k.fsm_count[rf] ? 3 : (k.dc_count[rd] ? 4 : 5))));
+  out->gave_up = out->verified ? 0 : (k.fail ? k.fail : (k.avg_count[ra] ? 2 : (k.fsm_count[rf] ? 3 : (k.dc_count[rd] ? 4 : 5))));   // (4: not reached since round 6 -- the finishing walk settles what the rounds leave)
   return RFID_OK;
 }
 

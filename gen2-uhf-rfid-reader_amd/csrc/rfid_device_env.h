@@ -282,6 +282,13 @@ RFID_DEVICE void lds_store(int *p, int v, int lane) {
   if (lane == 0) *q = v;
   asm volatile("" ::: "memory");
 }
+// acc += q on both components at once (v_pk_add_f32: two IEEE binary32 additions, each rounded by itself)
+RFID_DEVICE void pk_add(float2 &acc, const float2 q) {
+  rfid_f32x2 a = {acc.x, acc.y};
+  const rfid_f32x2 b = {q.x, q.y};
+  a = a + b;
+  acc.x = a.x; acc.y = a.y;
+}
 RFID_DEVICE void set_priority_high() { __builtin_amdgcn_s_setprio(3); }
 template <int P> RFID_DEVICE void set_priority() { __builtin_amdgcn_s_setprio(P); }   // 0 (default) .. 3
 RFID_DEVICE void backoff() { __builtin_amdgcn_s_sleep(1); }

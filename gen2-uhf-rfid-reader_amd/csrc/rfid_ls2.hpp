@@ -57,25 +57,27 @@ constexpr int LS2_CHAIN_GMAX = 64;     // workgroups per trace of a chain launch
 
 struct Ls2Piece { int pos0, len; };   // len 0: slot not in use
 
+constexpr int LS2_DC_MAXR = 64;   // dc_est rounds a pass can enqueue at most (a round without work: five empty launches)
 struct Ls2Ctl {   // control block in HBM, zeroed before every pass
-  int fail;                   // != 0: the front end gave up (1 no cut, 2 avg_ampl, 3 state machine, 4 dc_est rounds exhausted, 5 the
-                              // fused first pass met a stretch without a rest point)
+  int fail;                   // != 0: the front end gave up (1 no cut, 2 avg_ampl, 3 state machine rounds exhausted, 5 the fused first
+                              // pass met a stretch without a rest point, 6 / 7 dc_est: table overflow / a trace without a first unit -- cannot happen)
   int ok;                     // 1: the window tables were produced (set last; the fallback scan skips itself on it)
   int n_pieces;               // pieces the traces were cut into
   int n_heads;                // ... of them at idle cuts (or a trace's start): where the state-machine / dc_est passes can start
   int avg_count[LS2_MAXR];    // what chain round r left to do: pieces on the re-run list + exact ends put in (the chain has to be redone)
   int avg_list[LS2_MAXR];     //   ... the length of the list
   int fsm_count[LS2_MAXR];    // pieces appended to their predecessor in chain round r
-  int dc_count[LS2_MAXR];     // units on the re-run list after chain round r
   int avg_reruns, fsm_reruns, dc_reruns;   // totals (report)
   int avg_rounds, fsm_rounds, dc_rounds;   // launches that had work (report)
   int n_units;                // units (runs of pieces scanned in one go) at the end
   int n_windows;              // complete windows
   int wb_clash;               // two openings in one bucket (cannot happen; checked all the same -> fail)
-  int n_dc_pieces;            // dc_est pieces (>= n_units: a unit is cut again behind the gate openings)
-  int reserved_[2];
+  int n_dc_pieces;            // dc_est runs of the first round (= n_units since round 6)
+  int dc_open_alloc;          // places handed out in Ls2Args::dcand
+  int dc_finished;            // units the finishing walk took (the rounds were used up: the partial fallback)
+  int dc_count[LS2_DC_MAXR + 1];   // units not settled after chain round r
+  int reserved_[11];
 };
-
 struct Ls2AvgRun {   // a piece's latest run
   float s, eA, eB;   // start used, end from it, end from s + 1 ulp
   int margin;        // (ulps of s)
@@ -84,7 +86,6 @@ struct Ls2AvgRun {   // a piece's latest run
   float ew[4];
   int pad_[3];
 };
-struct Ls2DcRun { float s[2], eA[2], eB[2]; int margin[2]; };
 struct Ls2Fsm {   // per slot
   int head;       // the piece starts a unit (scanned from the idle state, or from the trace's start state)
   int unit;       // slot of the head of the unit the piece belongs to
@@ -100,9 +101,9 @@ struct Ls2Fsm {   // per slot
 struct Ls2Win {   // one gate opening
   int start;
   int tag;        // type | complete << 1 | gen << 8;  0: empty
-  float a_re, a_im, b_re, b_im;   // dc_est at the opening from the run of the dc_est piece it lies in: variant A, variant B
-  int piece;      // ... that piece's slot
-  int pad_;
+  int slot;       // where dc_est at the opening lies for each of the unit's 64 candidate starts: Ls2Args::dcand[slot][64]
+  int unit;       // ... that unit's idle-grid slot
+  int pad_[4];
 };
 
 struct Ls2Aff { int c0, c1; int tstar; int pad_; };   // a piece's function with the exact end for the start `tstar` put in (the entry of tstar's parity)
@@ -126,12 +127,18 @@ struct Ls2Args {
   Ls2Aff *aover;                // [NS] chain scratch: a piece's function with an exact candidate end put in
   Ls2Fsm *fsm;                  // [NS]
   Ls2Win *wb; int64_t wb_stride;   // [n_streams][wb_stride]
-  Ls2DcRun *drun; int *dT;      // [NS], [NS][2]
-  int *dcut, *dend;             // [NS] the dc_est piece of the slot: its first sample; dend = 1: the slot has one, 0: none
-  int dc_fine;                  // 1: units are cut again behind gate openings (short passes: the longest run sets their pace);
-                                // 0: one dc_est piece per unit (fewer, longer runs settle in fewer rounds when the carrier
-                                // sits next to a power of two)
-  int *dlist;                   // [2][NS]
+  // dc_est (section 4): per idle-grid slot t = trace * max_bc + J (NH of them); lane = candidate start
+  int *dT;                      // [NH][2] the unit's start value (re, im; ord images) from the latest chain: true when settled, else predicted
+  int *dcen;                    // [NH][2] centre of the unit's latest run: candidate j started at centre + j - 32 ulps
+  int *dtab;                    // [NH][2][64] dc_est behind the unit for each candidate
+  int *dstat;                   // [NH] bit 0 / 1: re / im settled, bit 2: the slot holds a unit (zeroed before a pass)
+  int *dwbase;                  // [NH] the unit's first place in dcand
+  float2 *dcand; int dcand_cap; // [dcand_cap][64] dc_est at a gate opening for each candidate
+  // the chain's levels: nodes of 64 children (level 1: blocks of units, level 2: groups of blocks); per node the centre of its
+  // first child, its table on that window, which entries are exact, whether it holds anything, and its entry value from the walk
+  int dcb_n1, dcb_n2, dcb_top;  // nodes per trace of level 1 / 2; the level the walk runs over (2 when a trace has more than 64 blocks)
+  int *n1cen, *n1tab, *n1val, *n1ent; uint64_t *n1exm;
+  int *n2cen, *n2tab, *n2val, *n2ent; uint64_t *n2exm;
   int *seq0;                    // [NS][2] complete windows of the trace before the piece: all, EPC
   int *flat_base;               // [n_streams][2] the trace's first place in the decoder's RN16 / EPC list
   rfid_window *wtab; int wmax; int *wcount;
@@ -167,9 +174,6 @@ struct Ls2Args {
   uint64_t *lb_fn;              // [NS] the slot's piece as a function of its start value (c0 | (c1 ^ 2^31) << 32); 0: not there yet
   uint64_t *lb_end;             // [NS] avg_ampl behind the slot's piece (integer image, != 0) | drift << 32; 0: not known (yet)
   int *lb_water;                // [n_streams] 1 + the highest slot of the trace whose lb_end is known (0: none yet)
-#ifdef LS2_CHEAT
-  int cheat_sigma;
-#endif
 };
 
 // ---- small helpers -----------------------------------------------------------------------------------------------
@@ -341,7 +345,7 @@ RFID_DEVICE bool chain_add_auto2(float ca, float cb2, float x, int lane, float &
 
 // ---- 0. what a pass expects zeroed: the control block, the chain flags, consumed[], the votes, the window buckets, the
 //         counters of the decoder's lists -- one launch instead of six fills ---------------------------------------------
-static_assert(sizeof(Ls2Ctl) == 256, "Ls2Ctl and consumed[] are fetched with one copy (rfid_ls2_enqueue.hpp lays them out back to back)");
+static_assert(sizeof(Ls2Ctl) == 512, "Ls2Ctl and consumed[] are fetched with one copy (rfid_ls2_enqueue.hpp lays them out back to back)");
 RFID_KERNEL(256) void ls2_clear_kernel(Ls2Args a) {
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
   const int64_t B = a.n_streams;
@@ -350,6 +354,7 @@ RFID_KERNEL(256) void ls2_clear_kernel(Ls2Args a) {
   zero4(a.ctl, (int64_t)(sizeof(Ls2Ctl) / 4));
   zero4(a.cflag, B * LS2_CHAIN_GMAX);
   zero4(a.consumed, B);
+  zero4(a.dstat, B * a.max_bc);
   if (a.fused) { zero8(a.lb_fn, B * a.max_b); zero8(a.lb_end, B * a.max_b); zero4(a.lb_water, B); }
   if (!a.keep_flat_count) zero4(a.flat_count, 2);   // (a first pass that runs beside the pass before: its decoder still reads them)
   zero8(a.votes, 2 * B * a.vstride);
@@ -916,15 +921,6 @@ RFID_DEVICE void ls2_front_piece(const Ls2Args &a, const int i, const int lane, 
           const float t = ls2_from_ord(g_ord + drift);
           if (((wv::f2u(t) ^ wv::f2u(sA)) >> 31) == 0u && (wv::f2u(t) >> 23) >= 25u && (wv::f2u(t) >> 23) < 255u) sA = t;
         }
-#ifdef LS2_CHEAT
-        // EXPERIMENT ONLY (never in the product build): what a first guess that is off by ~cheat_sigma ulps instead of the rounding
-        // drift's ~5 000 would save -- the start the PREVIOUS pass over the same trace found for this slot, plus noise
-        if (a.cheat_sigma > 0 && a.aT[i] != 0) {
-          uint32_t h = (uint32_t)i * 2654435761u; float u = 0.0f;
-          for (int q = 0; q < 4; ++q) { h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; u += (float)(h & 0xffffu) * (1.0f / 65536.0f); }
-          sA = ls2_from_ord(a.aT[i] + (int)((u - 2.0f) * 1.7320508f * (float)a.cheat_sigma));
-        }
-#endif
         begin_piece(kn);
       } else if (kn >= klim) r = 2;
     } else {
@@ -1550,103 +1546,66 @@ RFID_KERNEL(256) void ls2_fsm_chain_kernel(Ls2Args a) {
 }
 
 // ---- 4. dc_est -----------------------------------------------------------------------------------------------------
-// dc_est += (x - dc_samples[dc_index]) / 48 over the closed samples (gate_impl.cc:139-143).  Its ring holds the last 48
-// CLOSED samples, so a run can start wherever the 48 samples before were all closed (the ring is then those samples):
-// at a unit's head -- and right behind every gate opening: the gate opens T1 = 97 carrier samples after the last pulse
-// of a command (:164-180), all of them closed, the opening sample included, and dc_est sits at the carrier's level
-// there.  So a unit is cut again behind the first opening of each of its pieces (if it has one): these are the dc_est
-// pieces -- a few hundred closed samples between two windows instead of whole units.  (Cutting at the pieces' own
-// boundaries does not work: in a Gen2 round the carrier rests almost only INSIDE the reply windows, where the gate is
-// open and the ring holds samples from before the window.)
-// where the dc_est piece of slot j starts: 0 = the slot has none
-RFID_DEVICE int ls2_dc_cut(const Ls2Args &a, const int j) {
-  if (a.piece[j].len <= 0) return 0;
-  const int h = a.fsm[j].unit;
-  if (a.fsm[h].head == 0) return 0;
-  const int upos0 = a.piece[h].pos0, u1 = a.fsm[h].u1;
-  if (j == h) return 0;   // (the head's piece starts at the unit's first sample: ls2_dc_cut_kernel)
-  const int p = a.piece[j].pos0, pe = p + a.piece[j].len;
-  if (p >= u1) return 0;
-  const int s = j / a.max_b;
-  const int64_t cbase = (int64_t)s * a.cstride + (upos0 >> 6) + (h - s * a.max_b) / LS2_FINE;
-  const int *oinfo = a.openinfo + cbase;
-  const uint64_t *cl = a.closed + cbase;
-  const int k0 = (p - upos0) >> 6, k1 = ((pe < u1 ? pe : u1) - upos0 + 63) >> 6;
-  for (int k = k0; k < k1; ++k) {
-    const int ol = oinfo[k] & 0xff;
-    if (ol == 0xff) continue;
-    const int op = upos0 + 64 * k + ol;            // the opening sample
-    const int c = op + 1;                          // the piece starts behind it
-    if (op < p || c >= pe || c >= u1) continue;
-    // the 48 samples before the cut closed?  (by construction; checked all the same)
-    const int lo = c - upos0 - DC_LEN;
-    if (lo < 0) continue;
-    const int w = lo >> 6, sh = lo & 63;
-    uint64_t v = cl[w] >> sh;
-    if (sh > 64 - DC_LEN) v |= cl[w + 1] << (64 - sh);
-    constexpr uint64_t ALL = (1ull << DC_LEN) - 1ull;
-    if ((v & ALL) == ALL) return c;
-  }
-  return 0;
-}
-// one thread per slot: where its dc_est piece starts (dend = 1: it has one; the run finds its own end)
-RFID_DEVICE bool ls2_fsm_settled(const Ls2Args &a, const Ls2Ctl *ctl);
-RFID_KERNEL(256) void ls2_dc_cut_kernel(Ls2Args a) {
-  ls2_tail_prio();
-  if (!ls2_fsm_settled(a, a.ctl)) return;
-  const int j = (int)(blockIdx.x * 256 + threadIdx.x);
-  const int NS = a.n_streams * a.max_b;
-  if (j >= NS) return;
-  int cut = 0, on = 0;
-  if (a.piece[j].len > 0) {
-    const int h = a.fsm[j].unit;
-    if (j == h) {
-      if (a.fsm[h].head != 0 && a.piece[h].pos0 < a.fsm[h].u1) { cut = a.piece[h].pos0; on = 1; }
-    } else if (a.dc_fine) {
-      cut = ls2_dc_cut(a, j);
-      on = (cut > 0) ? 1 : 0;
-    }
-    // (a head's own piece may hold an opening too: that cut belongs to no slot, the head's run goes through it)
-  }
-  a.dcut[j] = cut;
-  a.dend[j] = on;
-}
-// the end of the dc_est piece of slot j (unit h): the next piece's first sample, or the unit's end.  The whole wave looks.
-RFID_DEVICE int ls2_dc_end(const Ls2Args &a, const int j, const int h, const int lane) {
-  const int u1 = wv::uniform(a.fsm[h].u1);
-  if (!a.dc_fine) return u1;
-  const int lim = (j / a.max_b + 1) * a.max_b;
-  for (int k0 = j + 1; k0 < lim; k0 += 64) {
-    const int k = k0 + lane;
-    bool stop = k >= lim, cut = false;
-    if (!stop && a.piece[k].len > 0) {
-      if (a.fsm[k].unit != h) stop = true;
-      else cut = a.dend[k] > 0;
-    }
-    const uint64_t m = wv::ballot(stop || cut);
-    if (m == 0ull) continue;
-    const int f = wv::ffs64(m);
-    const int c = wv::readlane(cut ? a.dcut[k] : u1, f);
-    return c;
-  }
-  return u1;
-}
+// dc_est += (x - dc_samples[dc_index]) / 48 over the closed samples (gate_impl.cc:139-143), two in-order binary32 sums (re, im).
+// Its ring holds the last 48 CLOSED samples, so a run can start wherever the 48 samples before were all closed: at a unit's
+// head (an idle cut).  What a run cannot know is the VALUE it starts from: the ring's mean is dc_est up to the rounding
+// drift of all additions before (hundreds to thousands of ulps late in a long trace).
+//
+// Rounds 2 - 5 ran every unit from its guess and from one ulp above it, lane = sample, and proved a shifted start by a margin: the
+// smallest distance of any partial sum from a power of two.  That proof collapses under noise.  dc_est is a moving average of
+// the carrier's components; whenever one of them lies within a few standard deviations of the average's noise of a power of
+// two -- SURVEY 8(d)'s own stress model does: 25 sin(0.7) = 16.105 with the average's noise at 0.05 (sigma = 0.03) and 0.10
+// (0.06) -- the sums hover ACROSS the binade edge for the whole trace, every unit's margin is a few ulps, nothing is ever
+// proven, and what a start value does to the end is no longer a shift: on the two sides of the edge the additions round on
+// different grids, two trajectories D ulps apart come out D +- a few apart.  profiles/r06/noise_sweep.txt: at sigma = 0.03 and
+// 0.06 every pass of configs[2] / configs[3] gave up in this stage and took the sequential scan (570x / 117x slower).
+//
+// So this stage no longer proves anything about shifted starts; it KNOWS.  Lane = candidate start: the 64 lanes of a unit's
+// wave carry 64 neighbouring start values (centre - 32 .. centre + 31 ulps, per component), the step's 64 increments are
+// formed lane = sample as before (gate_dc_incr: the reference's (x - ring) / 48, value for value), laid into LDS, and every
+// lane adds all 64 of them in order to its own pair of sums -- 64 plain dependent v_pk_add_f32 out of broadcast LDS reads,
+// about half the instructions of the two-variant scan with its tie and margin logic, and each lane's sum IS the
+// reference's sum for that start: no binade argument, no ties, no margins.  A unit leaves its 64 ends per component (its
+// TABLE) and dc_est at every gate opening for all 64 candidates.
+//
+// The chain.  A unit is the function "start value -> end value", known exactly on its 64-candidate window; outside the window
+// it is continued as a shift from the nearest candidate (a guess, flagged inexact).  Tables compose by lookup -- lane j of
+// (g after f) is g[f[j]], ONE wave shuffle when the table lies across the lanes -- so the trace's chain of units is evaluated
+// in levels of 64: up (blocks of 64 units -> block tables -> groups of 64 blocks), a walk over the top level from the trace's
+// exact start, down (every block's entry value -> every unit's start value).  A unit is SETTLED when everything before it is
+// and its own start lies inside its window: its table entry, its openings' dc_est and the next unit's start are then
+// exact.  The settled units are a prefix of the trace; everything behind the first unsettled unit is run again, centred on
+// the start value the chain predicts for it (exact for that first unit, a guess behind it).  Away from binade edges the
+// continuation IS exact, so the second round settles everything (the first round's centres -- the ring means -- are off by
+// the drift); where the sums hover at an edge the prediction behind the frontier is off by a few ulps per unit, the window
+// catches that for some thousand units, and the frontier advances by that much per round.  When the enqueued rounds are used
+// up, ls2_dcb_finish_kernel takes what is left -- only the unsettled units, one after the other from the proven value at the
+// frontier, each run from its exact start: the partial fallback (settled units keep their results; the pass costs its clean
+// time plus the sequential time of the unsettled units, never the whole sequential gate scan).
+constexpr int LS2_DCB_HALF = 32;      // candidate j (= lane) of a unit starts at its centre + j - 32 ulps
 
-// One wave per dc_est piece: the sums from the piece's start value and from 1 ulp above it (per component), the back
-// wave's arithmetic value for value; dc_est at every opening (:176) goes to the window's record.
-RFID_DEVICE void ls2_dc_piece(const Ls2Args &a, const int j, const bool first, const int lane, float2 *lds_dc, float2 *lds_tmp) {
-  const int s = j / a.max_b;
-  const int h = wv::uniform(a.fsm[j].unit);                 // the unit's head: the unit's steps are counted from its first sample
-  const int upos0 = wv::uniform(a.piece[h].pos0);
-  const int p0 = wv::uniform(a.dcut[j]), p1 = ls2_dc_end(a, j, h, lane);
+RFID_DEVICE bool ls2_fsm_settled(const Ls2Args &a, const Ls2Ctl *ctl) {
+  return wv::uniform(ctl->fail) == 0 && wv::uniform(ctl->avg_count[a.avg_rounds]) == 0 && wv::uniform(ctl->fsm_count[a.fsm_rounds]) == 0;
+}
+// idle-grid slot t = trace * max_bc + J  ->  piece slot
+RFID_DEVICE int ls2_dcb_slot(const Ls2Args &a, const int t) { const int s = t / a.max_bc; return s * a.max_b + (t - s * a.max_bc) * LS2_FINE; }
+
+// One unit (idle-grid slot t) from 64 neighbouring start values per component: lane j from centre + j - 32 ulps.
+// have_centre: (cre, cim) is the centre (ord images); else the trace's exact start (its first unit) or the ring's mean.
+// -> end_re / end_im: lane j's dc_est behind the unit (ord images); also left in a.dtab, the centre in a.dcen
+RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_centre, int cre, int cim, const bool reserve, const int lane,
+                              float2 *lds_dc, float2 *lds_tmp, float2 *lds_q, int &end_re, int &end_im) {
+  const int s = t / a.max_bc;
+  const int i = ls2_dcb_slot(a, t);
+  const int upos0 = wv::uniform(a.piece[i].pos0);
   const float2 *yrow = a.y + (int64_t)s * a.y_stride;
   GateBackRegs g;
   g.run_closed = 0; g.ring_stale = 0; g.prev_yv = make_float2(0.0f, 0.0f);
   g.win_seq = 0; g.n_complete = 0; g.written = 0; g.pos0 = upos0; g.strm = s;
-  g.dc_index = 0;
-  float sre, sim;
-  wv::wave_sync();   // (the previous piece's LDS reads are over)
-  if (j == s * a.max_b) {   // the trace's first piece: the fresh gate (all zero) or the carried state, exactly
+  g.dc_index = 0; g.dcr_c = 0.0f; g.dci_c = 0.0f;
+  wv::wave_sync();   // (the previous unit's LDS reads are over)
+  if (i == s * a.max_b) {   // the trace's first unit: the fresh gate (all zero) or the carried state, exactly
+    float sre = 0.0f, sim = 0.0f;
     if (a.carry) {
       const GateState *cs = a.carry + s;
       if (lane < DC_LEN) lds_dc[lane] = make_float2(cs->dcr_re[lane], cs->dcr_im[lane]);
@@ -1654,215 +1613,55 @@ RFID_DEVICE void ls2_dc_piece(const Ls2Args &a, const int j, const bool first, c
       sre = wv::uniform(cs->dc_re); sim = wv::uniform(cs->dc_im);
     } else {
       if (lane < DC_LEN) lds_dc[lane] = make_float2(0.0f, 0.0f);
-      sre = 0.0f; sim = 0.0f;
     }
+    cre = ls2_ord(sre); cim = ls2_ord(sim);
   } else {
-    // the ring holds the 48 samples before the piece; first guess of dc_est = their mean
+    // an idle cut: the ring holds the 48 samples before it; without a centre: their mean
     float2 v = make_float2(0.0f, 0.0f);
-    if (lane < DC_LEN) { v = yrow[p0 - DC_LEN + lane]; lds_dc[lane] = v; }
-    if (first) {
+    if (lane < DC_LEN) { v = yrow[upos0 - DC_LEN + lane]; lds_dc[lane] = v; }
+    if (!have_centre) {
       float pr = v.x, pi = v.y;   // (lanes >= 48 hold zeros)
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) { pr += wv::shfl_xor(pr, off); pi += wv::shfl_xor(pi, off); }
-      sre = wv::uniform(pr) / DC_LEN_F; sim = wv::uniform(pi) / DC_LEN_F;
-    } else {
-      sre = 0.0f; sim = 0.0f;
+      cre = ls2_ord(wv::uniform(pr) / DC_LEN_F); cim = ls2_ord(wv::uniform(pi) / DC_LEN_F);
     }
   }
-  if (!first) { sre = wv::uniform(a.drun[j].s[0]); sim = wv::uniform(a.drun[j].s[1]); }
   wv::wave_sync();
-  const uint32_t sbr = wv::f2u(sre), sbi = wv::f2u(sim);
-  const float sreB = ls2_from_ord(ls2_ord(sre) + 1), simB = ls2_from_ord(ls2_ord(sim) + 1);
-  const uint32_t sbrB = wv::f2u(sreB), sbiB = wv::f2u(simB);
-  g.dcr_c = sre; g.dci_c = sim;
-  float bre = sreB, bim = simB;   // variant B's carries
-  int mre = ls2_margin(sre, sbr), mim = ls2_margin(sim, sbi);
-  const bool e0r_ok = ls2_e0_ok(sbr, sbrB), e0i_ok = ls2_e0_ok(sbi, sbiB);
-  Ls2MantRange rgrA, rgrB, rgiA, rgiB;   // (see ls2_avg_piece)
-  ls2_range_init(rgrA); ls2_range_init(rgrB); ls2_range_init(rgiA); ls2_range_init(rgiB);
+  float2 acc = make_float2(ls2_from_ord(cre + lane - LS2_DCB_HALF), ls2_from_ord(cim + lane - LS2_DCB_HALF));
   Ls2Win *wb = a.wb + (int64_t)s * a.wb_stride;
+  // where the unit's gate openings go in a.dcand: reserved once (complete windows + the one a trace may end in)
+  int wslot = 0;
+  if (reserve) {
+    const int want = wv::uniform(a.fsm[i].nwin) + 1;
+    int got = 0;
+    if (lane == 0) got = wv::atomic_add(&a.ctl->dc_open_alloc, want);
+    wslot = wv::uniform(got);
+    if (lane == 0) a.dwbase[t] = wslot;
+    if (wslot + want > a.dcand_cap) { if (lane == 0) a.ctl->fail = 6; wslot = -1; }   // (cannot happen: the capacity is every window + a spare per unit)
+  } else {
+    wslot = wv::uniform(a.dwbase[t]);
+    if (wslot + wv::uniform(a.fsm[i].nwin) + 1 > a.dcand_cap) wslot = -1;
+  }
   {
-    // the unit's steps k0 .. k1 - 1 hold the piece (step k = samples upos0 + 64 k ..: the state-machine pass left the
-    // closed samples and the gate opening of every step); the lanes of the first / last step that lie outside it
-    // count as not closed -- they belong to the neighbours
-    const int n_unit = wv::uniform(a.fsm[h].u1) - upos0;
-    const int rel0 = p0 - upos0, rel1 = p1 - upos0;
-    const int k0 = rel0 >> 6, k1 = (rel1 + 63) >> 6, nsteps_unit = (n_unit + 63) >> 6;
-    const int64_t cbase = (int64_t)s * a.cstride + (upos0 >> 6) + (h - s * a.max_b) / LS2_FINE;
+    // the unit: from the head's first sample to the next head (the state-machine pass left its end, its closed samples and its
+    // gate openings, step k = samples upos0 + 64 k ..)
+    const int n = wv::uniform(a.fsm[i].u1) - upos0;
+    const int64_t cbase = (int64_t)s * a.cstride + (upos0 >> 6) + (i - s * a.max_b) / LS2_FINE;
     const uint64_t *closed = a.closed + cbase;
     const int *oinfo = a.openinfo + cbase;
     const float2 *ys = yrow + upos0;
-    constexpr int AHEAD = 4;
-    float2 buf[AHEAD];
-#pragma unroll
-    for (int u = 0; u < AHEAD; ++u) { const int idx = 64 * (k0 + u) + lane; buf[u] = (idx < n_unit) ? ys[idx] : make_float2(0.0f, 0.0f); }
-    float2 before = make_float2(0.0f, 0.0f);   // the samples of the previous step
-    if (k0 > 0) before = ys[64 * (k0 - 1) + lane];
-    uint64_t masks = 0;
-    int oi_l = 0xff;
-    for (int kb = k0; kb < k1; kb += AHEAD) {
-#pragma unroll
-      for (int u = 0; u < AHEAD; ++u) {
-        const int k = kb + u;
-        if (k < k1) {
-          if ((k & 63) == 0 || k == k0) {
-            const int blk = k & ~63;
-            const bool in = blk + lane < nsteps_unit;
-            masks = in ? closed[blk + lane] : 0ull;
-            oi_l = in ? oinfo[blk + lane] : 0xff;
-          }
-          const float2 yv = buf[u];
-          { const int idx = 64 * (k + AHEAD) + lane; buf[u] = (idx < n_unit) ? ys[idx] : make_float2(0.0f, 0.0f); }
-          const int kk = k & 63;
-          int lo = 0, hi = 64;
-          uint64_t closedmask = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(masks >> 32), kk) << 32) |
-                                (uint32_t)wv::readlane((int)(uint32_t)masks, kk);
-          if (__builtin_expect(k == k0 || k == k1 - 1, 0)) {   // the piece's first / last step: only its own lanes
-            lo = (k == k0) ? (rel0 & 63) : 0;
-            hi = (rel1 - 64 * k < 64) ? (rel1 - 64 * k) : 64;
-            closedmask &= lane_range(lo, hi);
-          }
-          const int oi = wv::readlane(oi_l, kk);
-          float ar, ai, br, bi;   // dc_est after every sample of the step, variants A and B
-          if (closedmask != 0) {
-            float tre, tim;
-            gate_dc_incr(g, closedmask, 0ull, hi, yv, lane, lds_dc, lds_tmp,
-                         [&](float &qre, float &qim) {
-                           // (x - x[i-48]) / 48 as the producer wave forms it: x[i-48] from the previous step's lanes 16..63
-                           // or this step's lanes 0..15
-                           const int src = (lane < DC_LEN) ? (lane + 64 - DC_LEN) : (lane - DC_LEN);
-                           const float pre = wv::shfl(before.x, src), pim = wv::shfl(before.y, src);
-                           const float cre = wv::shfl(yv.x, src), cim = wv::shfl(yv.y, src);
-                           const float nr = yv.x - ((lane < DC_LEN) ? pre : cre), ni = yv.y - ((lane < DC_LEN) ? pim : cim);
-                           if (__builtin_expect(wv::ballot(!(div_const_ok(nr) && div_const_ok(ni))) == 0, 1)) {
-                             qre = div_const_fast<DC_LEN>(nr); qim = div_const_fast<DC_LEN>(ni);
-                           } else {
-                             qre = wv::fdiv(nr, DC_LEN_F); qim = wv::fdiv(ni, DC_LEN_F);
-                           }
-                         },
-                         tre, tim);
-            const uint32_t cr0 = wv::f2u(g.dcr_c), cr1 = wv::f2u(bre), ci0 = wv::f2u(g.dci_c), ci1 = wv::f2u(bim);
-            const bool scr = chain_add_auto2(g.dcr_c, bre, tre, lane, ar, br);
-            const bool sci = chain_add_auto2(g.dci_c, bim, tim, lane, ai, bi);
-            g.dcr_c = wv::readlane(ar, 63); bre = wv::readlane(br, 63);
-            g.dci_c = wv::readlane(ai, 63); bim = wv::readlane(bi, 63);
-            if (scr && ls2_in_start_binade(cr0, cr1, sbr, sbrB, e0r_ok)) { ls2_range_add(rgrA, ar); ls2_range_add(rgrB, br); }
-            else {
-              int mr;
-              if (scr) mr = ls2_margin_scanned(ar, br, cr0, cr1, sbr, sbrB, e0r_ok);
-              else { const int m1 = ls2_margin(ar, sbr), m2 = ls2_margin(br, sbrB); mr = (m1 < m2) ? m1 : m2; }
-              mre = (mr < mre) ? mr : mre;
-            }
-            if (sci && ls2_in_start_binade(ci0, ci1, sbi, sbiB, e0i_ok)) { ls2_range_add(rgiA, ai); ls2_range_add(rgiB, bi); }
-            else {
-              int mi;
-              if (sci) mi = ls2_margin_scanned(ai, bi, ci0, ci1, sbi, sbiB, e0i_ok);
-              else { const int m3 = ls2_margin(ai, sbi), m4 = ls2_margin(bi, sbiB); mi = (m3 < m4) ? m3 : m4; }
-              mim = (mi < mim) ? mi : mim;
-            }
-          } else {
-            g.run_closed = 0;   // no closed sample of the piece in this step (inside a window): dc_est, the ring and its index do not move
-            ar = g.dcr_c; ai = g.dci_c; br = bre; bi = bim;
-          }
-          before = yv;
-          const int ol = oi & 0xff;
-          if (ol != 0xff && ol >= lo && ol < hi) {   // a window opened at a sample of the piece: dc_est at that sample (the opening sample is still closed)
-            const float war = wv::readlane(ar, ol), wai = wv::readlane(ai, ol), wbr = wv::readlane(br, ol), wbi = wv::readlane(bi, ol);
-            if (lane == 0) {
-              Ls2Win *w = wb + (upos0 + 64 * k + ol) / LS2_WBUCKET;
-              w->a_re = war; w->a_im = wai; w->b_re = wbr; w->b_im = wbi; w->piece = j;
-            }
-          }
-        }
-      }
-    }
-  }
-  { const int m = ls2_range_margin(rgrA, rgrB); mre = (m < mre) ? m : mre; }
-  { const int m = ls2_range_margin(rgiA, rgiB); mim = (m < mim) ? m : mim; }
-  mre = ls2_wave_min(mre);
-  mim = ls2_wave_min(mim);
-  // (the chain's integer arithmetic needs start and end in one binade, see ls2_avg_piece)
-  if ((((wv::f2u(g.dcr_c) ^ sbr) | (wv::f2u(bre) ^ sbrB)) & 0xff800000u) != 0u) mre = 0;
-  if ((((wv::f2u(g.dci_c) ^ sbi) | (wv::f2u(bim) ^ sbiB)) & 0xff800000u) != 0u) mim = 0;
-  if (lane == 0) {
-    Ls2DcRun ru;
-    ru.s[0] = sre; ru.s[1] = sim; ru.eA[0] = g.dcr_c; ru.eA[1] = g.dci_c; ru.eB[0] = bre; ru.eB[1] = bim;
-    ru.margin[0] = mre; ru.margin[1] = mim;
-    a.drun[j] = ru;
-  }
-  // streaming: the dc ring after the trace's last processed piece is rebuilt from the samples (ls2_carry_kernel): a
-  // processed piece always ends at an idle cut
-}
-
-// the same for a whole unit (Ls2Args::dc_fine = 0: long passes, where the number of rounds matters more than the longest
-// run): from the head's first sample to the next head, no partial steps
-RFID_DEVICE void ls2_dc_unit(const Ls2Args &a, const int i, const bool first, const int lane, float2 *lds_dc, float2 *lds_tmp) {
-  const int s = i / a.max_b;
-  const Ls2Piece p0 = a.piece[i];
-  const int upos0 = wv::uniform(p0.pos0);
-  const float2 *yrow = a.y + (int64_t)s * a.y_stride;
-  GateBackRegs g;
-  g.run_closed = 0; g.ring_stale = 0; g.prev_yv = make_float2(0.0f, 0.0f);
-  g.win_seq = 0; g.n_complete = 0; g.written = 0; g.pos0 = upos0; g.strm = s;
-  g.dc_index = 0;
-  float sre, sim;
-  wv::wave_sync();   // (the previous unit's LDS reads are over)
-  if (i == s * a.max_b) {   // the trace's first piece: the fresh gate (all zero) or the carried state, exactly
-    if (a.carry) {
-      const GateState *cs = a.carry + s;
-      if (lane < DC_LEN) lds_dc[lane] = make_float2(cs->dcr_re[lane], cs->dcr_im[lane]);
-      g.dc_index = wv::uniform(cs->dc_index);
-      sre = wv::uniform(cs->dc_re); sim = wv::uniform(cs->dc_im);
-    } else {
-      if (lane < DC_LEN) lds_dc[lane] = make_float2(0.0f, 0.0f);
-      sre = 0.0f; sim = 0.0f;
-    }
-  } else {
-    // an idle cut: the ring holds the 48 samples before it; first guess of dc_est = their mean
-    float2 v = make_float2(0.0f, 0.0f);
-    if (lane < DC_LEN) { v = yrow[upos0 - DC_LEN + lane]; lds_dc[lane] = v; }
-    if (first) {
-      float pr = v.x, pi = v.y;   // (lanes >= 48 hold zeros)
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) { pr += wv::shfl_xor(pr, off); pi += wv::shfl_xor(pi, off); }
-      sre = wv::uniform(pr) / DC_LEN_F; sim = wv::uniform(pi) / DC_LEN_F;
-    } else {
-      sre = 0.0f; sim = 0.0f;
-    }
-  }
-  if (!first) { sre = wv::uniform(a.drun[i].s[0]); sim = wv::uniform(a.drun[i].s[1]); }
-  wv::wave_sync();
-  const uint32_t sbr = wv::f2u(sre), sbi = wv::f2u(sim);
-  const float sreB = ls2_from_ord(ls2_ord(sre) + 1), simB = ls2_from_ord(ls2_ord(sim) + 1);
-  const uint32_t sbrB = wv::f2u(sreB), sbiB = wv::f2u(simB);
-  g.dcr_c = sre; g.dci_c = sim;
-  float bre = sreB, bim = simB;   // variant B's carries
-  int mre = ls2_margin(sre, sbr), mim = ls2_margin(sim, sbi);
-  const bool e0r_ok = ls2_e0_ok(sbr, sbrB), e0i_ok = ls2_e0_ok(sbi, sbiB);
-  Ls2MantRange rgrA, rgrB, rgiA, rgiB;   // (see ls2_avg_piece)
-  ls2_range_init(rgrA); ls2_range_init(rgrB); ls2_range_init(rgiA); ls2_range_init(rgiB);
-  Ls2Win *wb = a.wb + (int64_t)s * a.wb_stride;
-  {
-    // the unit: from the head's first sample to the next head (the state-machine pass left its end, its closed samples
-    // and its gate openings, step k = samples upos0 + 64 k ..)
-    const int pos0 = upos0, n = wv::uniform(a.fsm[i].u1) - upos0;
-    const int64_t cbase = (int64_t)s * a.cstride + (pos0 >> 6) + (i - s * a.max_b) / LS2_FINE;
-    const uint64_t *closed = a.closed + cbase;
-    const int *oinfo = a.openinfo + cbase;
-    const float2 *ys = yrow + pos0;
     const int nsteps = (n + 63) >> 6;
     constexpr int AHEAD = 4;
     float2 buf[AHEAD];
     // (loads clamped, not predicated, and the complete groups of AHEAD steps without a condition around a step: see
     // ls2_avg_piece.  Samples past the unit's end are not closed -- nvalid -- whatever their value.)
     const int last_idx = n - 1;
-    // Only the steps that hold closed samples are read: more than half of a Gen2 round lies inside the two reply windows,
-    // where dc_est does not move (gate_impl.cc:139: the update sits in the closed branch) -- until round 5 every step of y was
-    // loaded all the same (3.7 GB per pass of configs[2] for 1.7 GB that are used).  Which steps those are is known 64 steps
+    // Only the steps that hold closed samples are read: more than half of a Gen2 round lies inside the two reply windows, where
+    // dc_est does not move (gate_impl.cc:139: the update sits in the closed branch).  Which steps those are is known 64 steps
     // ahead (nz_cur / nz_nxt: one bit per step of this and the next 64-step block); a step that is not needed loads the unit's
     // first samples again instead -- an unconditional load from a line that is in the cache: no branch around a load, the
-    // read-ahead's registers and counted waits stay as they are (see ls2_avg_piece).  (The samples of the step before a closed
-    // step are only looked at when that step was closed itself: gate_dc_incr takes x[i-48] from them while run_closed >= 48.)
+    // read-ahead's registers and counted waits stay as they are.  (The samples of the step before a closed step are only looked
+    // at when that step was closed itself: gate_dc_incr takes x[i-48] from them while run_closed >= 48.)
     uint64_t nz_cur = 0, nz_nxt = 0;
     auto nz_of = [&](const int k64) -> uint64_t {   // bit b: step k64 + b holds closed samples
       const bool in = k64 + lane < nsteps;
@@ -1882,75 +1681,79 @@ RFID_DEVICE void ls2_dc_unit(const Ls2Args &a, const int i, const bool first, co
     float2 before = make_float2(0.0f, 0.0f);   // the samples of the previous step
     uint64_t masks = 0;
     int oi_l = 0xff;
+    int nopen = 0;
+    const float4 *q4 = reinterpret_cast<const float4 *>(lds_q);
     auto step = [&](const int k, float2 &yb, const bool reload) {
-        {
-          if ((k & 63) == 0) {
-            const bool in = k + lane < nsteps;
-            const int kx = in ? (k + lane) : (nsteps - 1);
-            const uint64_t mk = closed[kx];
-            const int ok = oinfo[kx];
-            masks = in ? mk : 0ull;
-            oi_l = in ? ok : 0xff;
-            if (k > 0) { nz_cur = nz_nxt; nz_nxt = nz_of(k + 64); }
+      if ((k & 63) == 0) {
+        const bool in = k + lane < nsteps;
+        const int kx = in ? (k + lane) : (nsteps - 1);
+        const uint64_t mk = closed[kx];
+        const int ok = oinfo[kx];
+        masks = in ? mk : 0ull;
+        oi_l = in ? ok : 0xff;
+        if (k > 0) { nz_cur = nz_nxt; nz_nxt = nz_of(k + 64); }
+      }
+      const float2 yv = yb;
+      if (reload) yb = load_step(k + AHEAD, k >> 6);
+      const int kk = k & 63;
+      const uint64_t closedmask = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(masks >> 32), kk) << 32) |
+                                  (uint32_t)wv::readlane((int)(uint32_t)masks, kk);
+      const int oi = wv::readlane(oi_l, kk);
+      const int nvalid = (n - 64 * k < 64) ? (n - 64 * k) : 64;
+      const int ol = oi & 0xff;
+      if (closedmask != 0) {
+        float tre, tim;
+        gate_dc_incr(g, closedmask, 0ull, nvalid, yv, lane, lds_dc, lds_tmp,
+                     [&](float &qre, float &qim) {
+                       // (x - x[i-48]) / 48 as the producer wave forms it: x[i-48] from the previous step's lanes 16..63
+                       // or this step's lanes 0..15
+                       const int src = (lane < DC_LEN) ? (lane + 64 - DC_LEN) : (lane - DC_LEN);
+                       const float pre = wv::shfl(before.x, src), pim = wv::shfl(before.y, src);
+                       const float cr2 = wv::shfl(yv.x, src), ci2 = wv::shfl(yv.y, src);
+                       const float nr = yv.x - ((lane < DC_LEN) ? pre : cr2), ni = yv.y - ((lane < DC_LEN) ? pim : ci2);
+                       if (__builtin_expect(wv::ballot(!(div_const_ok(nr) && div_const_ok(ni))) == 0, 1)) {
+                         qre = div_const_fast<DC_LEN>(nr); qim = div_const_fast<DC_LEN>(ni);
+                       } else {
+                         qre = wv::fdiv(nr, DC_LEN_F); qim = wv::fdiv(ni, DC_LEN_F);
+                       }
+                     },
+                     tre, tim);
+        // the step's 64 increments in sample order (samples that are not closed: +0), added in that order by every lane to
+        // its own candidate
+        wv::wave_sync();   // (the reads of the step before are over)
+        lds_q[lane] = make_float2(tre, tim);
+        wv::wave_sync();
+        if (__builtin_expect(ol == 0xff, 1)) {
+#pragma unroll
+          for (int j = 0; j < 32; ++j) {
+            const float4 qq = q4[j];
+            wv::pk_add(acc, make_float2(qq.x, qq.y));
+            wv::pk_add(acc, make_float2(qq.z, qq.w));
           }
-          const float2 yv = yb;
-          if (reload) yb = load_step(k + AHEAD, k >> 6);
-          const int kk = k & 63;
-          const uint64_t closedmask = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(masks >> 32), kk) << 32) |
-                                      (uint32_t)wv::readlane((int)(uint32_t)masks, kk);
-          const int oi = wv::readlane(oi_l, kk);
-          const int nvalid = (n - 64 * k < 64) ? (n - 64 * k) : 64;
-          float ar, ai, br, bi;   // dc_est after every sample of the step, variants A and B
-          if (closedmask != 0) {
-            float tre, tim;
-            gate_dc_incr(g, closedmask, 0ull, nvalid, yv, lane, lds_dc, lds_tmp,
-                         [&](float &qre, float &qim) {
-                           // (x - x[i-48]) / 48 as the producer wave forms it: x[i-48] from the previous step's lanes 16..63
-                           // or this step's lanes 0..15
-                           const int src = (lane < DC_LEN) ? (lane + 64 - DC_LEN) : (lane - DC_LEN);
-                           const float pre = wv::shfl(before.x, src), pim = wv::shfl(before.y, src);
-                           const float cre = wv::shfl(yv.x, src), cim = wv::shfl(yv.y, src);
-                           const float nr = yv.x - ((lane < DC_LEN) ? pre : cre), ni = yv.y - ((lane < DC_LEN) ? pim : cim);
-                           if (__builtin_expect(wv::ballot(!(div_const_ok(nr) && div_const_ok(ni))) == 0, 1)) {
-                             qre = div_const_fast<DC_LEN>(nr); qim = div_const_fast<DC_LEN>(ni);
-                           } else {
-                             qre = wv::fdiv(nr, DC_LEN_F); qim = wv::fdiv(ni, DC_LEN_F);
-                           }
-                         },
-                         tre, tim);
-            const uint32_t cr0 = wv::f2u(g.dcr_c), cr1 = wv::f2u(bre), ci0 = wv::f2u(g.dci_c), ci1 = wv::f2u(bim);
-            const bool scr = chain_add_auto2(g.dcr_c, bre, tre, lane, ar, br);
-            const bool sci = chain_add_auto2(g.dci_c, bim, tim, lane, ai, bi);
-            g.dcr_c = wv::readlane(ar, 63); bre = wv::readlane(br, 63);
-            g.dci_c = wv::readlane(ai, 63); bim = wv::readlane(bi, 63);
-            if (scr && ls2_in_start_binade(cr0, cr1, sbr, sbrB, e0r_ok)) { ls2_range_add(rgrA, ar); ls2_range_add(rgrB, br); }
-            else {
-              int mr;
-              if (scr) mr = ls2_margin_scanned(ar, br, cr0, cr1, sbr, sbrB, e0r_ok);
-              else { const int m1 = ls2_margin(ar, sbr), m2 = ls2_margin(br, sbrB); mr = (m1 < m2) ? m1 : m2; }
-              mre = (mr < mre) ? mr : mre;
-            }
-            if (sci && ls2_in_start_binade(ci0, ci1, sbi, sbiB, e0i_ok)) { ls2_range_add(rgiA, ai); ls2_range_add(rgiB, bi); }
-            else {
-              int mi;
-              if (sci) mi = ls2_margin_scanned(ai, bi, ci0, ci1, sbi, sbiB, e0i_ok);
-              else { const int m3 = ls2_margin(ai, sbi), m4 = ls2_margin(bi, sbiB); mi = (m3 < m4) ? m3 : m4; }
-              mim = (mi < mim) ? mi : mim;
-            }
-          } else {
-            g.run_closed = 0;   // the step lies entirely inside a window: dc_est, the ring and its index do not move
-            ar = g.dcr_c; ai = g.dci_c; br = bre; bi = bim;
+        } else {
+          // a window opened at sample `ol` of this step: dc_est right behind that sample (the opening sample is still
+          // closed, gate_impl.cc:164-180), for every candidate
+          float2 snap = acc;
+          for (int j = 0; j < 64; ++j) {
+            wv::pk_add(acc, lds_q[j]);
+            if (j == ol) snap = acc;
           }
-          before = yv;
-          if ((oi & 0xff) != 0xff) {   // a window opened in this step: dc_est at that sample (the opening sample is still closed)
-            const int ol = oi & 0xff;
-            const float war = wv::readlane(ar, ol), wai = wv::readlane(ai, ol), wbr = wv::readlane(br, ol), wbi = wv::readlane(bi, ol);
-            if (lane == 0) {
-              Ls2Win *w = wb + (pos0 + 64 * k + ol) / LS2_WBUCKET;
-              w->a_re = war; w->a_im = wai; w->b_re = wbr; w->b_im = wbi; w->piece = i;
-            }
+          if (wslot >= 0) a.dcand[(int64_t)(wslot + nopen) * 64 + lane] = snap;
+          if (lane == 0) {
+            Ls2Win *w = wb + (upos0 + 64 * k + ol) / LS2_WBUCKET;
+            w->slot = (wslot >= 0) ? (wslot + nopen) : 0; w->unit = t;
           }
+          nopen++;
         }
+      } else {
+        g.run_closed = 0;   // the step lies entirely inside a window: dc_est, the ring and its index do not move
+        if (ol != 0xff) {   // (an opening sample is closed itself: not reached)
+          if (wslot >= 0) a.dcand[(int64_t)(wslot + nopen) * 64 + lane] = acc;
+          if (lane == 0) { Ls2Win *w = wb + (upos0 + 64 * k + ol) / LS2_WBUCKET; w->slot = (wslot >= 0) ? (wslot + nopen) : 0; w->unit = t; }
+          nopen++;
+        }
+      }
+      before = yv;
     };
     int kb = 0;
     for (; kb + AHEAD <= nsteps; kb += AHEAD) {
@@ -1961,142 +1764,266 @@ RFID_DEVICE void ls2_dc_unit(const Ls2Args &a, const int i, const bool first, co
     for (int u = 0; u < AHEAD - 1; ++u)
       if (kb + u < nsteps) step(kb + u, buf[u], false);
   }
-  { const int m = ls2_range_margin(rgrA, rgrB); mre = (m < mre) ? m : mre; }
-  { const int m = ls2_range_margin(rgiA, rgiB); mim = (m < mim) ? m : mim; }
-  mre = ls2_wave_min(mre);
-  mim = ls2_wave_min(mim);
-  // (the chain's integer arithmetic needs start and end in one binade, see ls2_avg_piece)
-  if ((((wv::f2u(g.dcr_c) ^ sbr) | (wv::f2u(bre) ^ sbrB)) & 0xff800000u) != 0u) mre = 0;
-  if ((((wv::f2u(g.dci_c) ^ sbi) | (wv::f2u(bim) ^ sbiB)) & 0xff800000u) != 0u) mim = 0;
-  if (lane == 0) {
-    Ls2DcRun ru;
-    ru.s[0] = sre; ru.s[1] = sim; ru.eA[0] = g.dcr_c; ru.eA[1] = g.dci_c; ru.eB[0] = bre; ru.eB[1] = bim;
-    ru.margin[0] = mre; ru.margin[1] = mim;
-    a.drun[i] = ru;
-  }
-  // streaming: the dc ring after the trace's last processed piece is rebuilt from the samples (ls2_carry_kernel): a
-  // processed piece always ends at an idle cut
+  end_re = ls2_ord(acc.x); end_im = ls2_ord(acc.y);
+  a.dtab[(int64_t)(2 * t) * 64 + lane] = end_re;
+  a.dtab[(int64_t)(2 * t + 1) * 64 + lane] = end_im;
+  if (lane == 0) { a.dcen[2 * t] = cre; a.dcen[2 * t + 1] = cim; }
 }
 
-RFID_DEVICE bool ls2_fsm_settled(const Ls2Args &a, const Ls2Ctl *ctl) {
-  return wv::uniform(ctl->fail) == 0 && wv::uniform(ctl->avg_count[a.avg_rounds]) == 0 && wv::uniform(ctl->fsm_count[a.fsm_rounds]) == 0;
-}
-RFID_KERNEL(64) void ls2_dc_first_kernel(Ls2Args a) {
+// round 0: every unit from its guess; round r > 0: every unit behind the settled prefix again, centred on the start value the
+// chain of round r - 1 predicted for it.  One wave per idle-grid slot.
+RFID_KERNEL(64) void ls2_dcb_run_kernel(Ls2Args a) {
   ls2_tail_prio();
   RFID_SHARED float2 lds_dc[DC_LEN];
   RFID_SHARED float2 lds_tmp[64];
-  if (!ls2_fsm_settled(a, a.ctl)) return;
-  const int lane = wv::lane_id();
-  const int NH = a.n_streams * a.max_bc, NS = a.dc_fine ? a.n_streams * a.max_b : NH;   // (whole units: the idle-grid slots only)
-  for (int b = (int)blockIdx.x; b < NS; b += (int)gridDim.x) {
-    // block -> slot: the idle-grid slots first, then the slots one, two, ... behind them (slots in their own order
-    // would put the units' heads, every LS2_FINE-th slot, on two of the eight XCDs)
-    const int q = b / NH, hb = b - q * NH;
-    const int j = (hb / a.max_bc) * a.max_b + (hb % a.max_bc) * LS2_FINE + q;
-    if (wv::uniform(a.dend[j]) <= 0) continue;
-    if (a.dc_fine) ls2_dc_piece(a, j, true, lane, lds_dc, lds_tmp);
-    else ls2_dc_unit(a, j, true, lane, lds_dc, lds_tmp);
-  }
-}
-RFID_KERNEL(64) void ls2_dc_rerun_kernel(Ls2Args a) {
-  ls2_tail_prio();
-  RFID_SHARED float2 lds_dc[DC_LEN];
-  RFID_SHARED float2 lds_tmp[64];
-  if (!ls2_fsm_settled(a, a.ctl)) return;
-  const int NS = a.n_streams * a.max_b;
-  const int cnt = wv::uniform(a.ctl->dc_count[a.round - 1]);
-  const int lane = wv::lane_id();
-  const int *list = a.dlist + (int64_t)((a.round - 1) & 1) * NS;
-  for (int r = (int)blockIdx.x; r < cnt; r += (int)gridDim.x) {
-    if (a.dc_fine) ls2_dc_piece(a, wv::uniform(list[r]), false, lane, lds_dc, lds_tmp);
-    else ls2_dc_unit(a, wv::uniform(list[r]), false, lane, lds_dc, lds_tmp);
-  }
-}
-
-// as ls2_avg_chain_kernel, over the dc_est pieces and the two components of dc_est
-struct Ls2DcRec { int on; Ls2DcRun ru; };
-RFID_DEVICE Ls2DcRec ls2_dc_rec(const Ls2Args &a, int base, int J) {
-  Ls2DcRec r; r.on = 0;
-  for (int c = 0; c < 2; ++c) { r.ru.s[c] = r.ru.eA[c] = r.ru.eB[c] = 0.0f; r.ru.margin[c] = 0; }
-  if (J < (a.dc_fine ? a.max_b : a.max_bc)) {
-    const int i = base + (a.dc_fine ? J : J * LS2_FINE);
-    r.on = (a.dend[i] > 0) ? 1 : 0;
-    if (r.on) r.ru = a.drun[i];
-  }
-  return r;
-}
-RFID_KERNEL(LS2_CHAIN_THREADS) void ls2_dc_chain_kernel(Ls2Args a) {
-  ls2_tail_prio();
-  RFID_SHARED Ls2A32 wagg[2 * (LS2_CHAIN_WAVES + 1)];
+  RFID_SHARED float4 lds_q4[32];
+  float2 *lds_q = reinterpret_cast<float2 *>(lds_q4);
   Ls2Ctl *ctl = a.ctl;
+  if (!ls2_fsm_settled(a, ctl)) return;
   const int r = a.round;
-  const int tid = (int)threadIdx.x, b = (int)blockIdx.x, s = (int)blockIdx.y;
-  if (ctl->fail != 0 || ctl->avg_count[a.avg_rounds] != 0 || ctl->fsm_count[a.fsm_rounds] != 0) return;
-  if (r > 0 && ctl->dc_count[r - 1] == 0) return;
-  const int NS = a.n_streams * a.max_b;
-  const int lane = wv::lane_id(), wave = wv::uniform(tid >> 6);
-  const int base = s * a.max_b;
-  if (a.piece[base].len <= 0) return;
-  int c_lo, c_hi;
-  ls2_chain_range(a.dc_fine ? a.max_b : a.max_bc, a.chain_g, b, wave, c_lo, c_hi);
-  const int T0r = ls2_ord(a.drun[base].s[0]), T0i = ls2_ord(a.drun[base].s[1]);
-  // ---- sweep 1: this wave's totals ----
-  Ls2A32 carry[2]; carry[0].c0 = carry[0].c1 = 0; carry[1].c0 = carry[1].c1 = 0;
-  Ls2DcRec nxt = ls2_dc_rec(a, base, 64 * c_lo + lane);
-  for (int c = c_lo; c < c_hi; ++c) {
-    const Ls2DcRec rec = nxt;
-    if (c + 1 < c_hi) nxt = ls2_dc_rec(a, base, 64 * (c + 1) + lane);
-    Ls2A32 er, ei; er.c0 = er.c1 = 0; ei.c0 = ei.c1 = 0;
-    if (rec.on) {
-      er = ls2_elem32(rec.ru.s[0], rec.ru.eA[0], rec.ru.eB[0]);
-      ei = ls2_elem32(rec.ru.s[1], rec.ru.eA[1], rec.ru.eB[1]);
+  if (r > 0 && wv::uniform(ctl->dc_count[r - 1]) == 0) return;
+  const int lane = wv::lane_id();
+  const int NH = a.n_streams * a.max_bc;
+  int n_run = 0;
+  for (int t = (int)blockIdx.x; t < NH; t += (int)gridDim.x) {
+    const int i = ls2_dcb_slot(a, t);
+    if (r == 0) {
+      if (wv::uniform(a.piece[i].len) <= 0 || wv::uniform(a.fsm[i].head) == 0 || wv::uniform(a.piece[i].pos0) >= wv::uniform(a.fsm[i].u1)) continue;
+    } else {
+      const int st = wv::uniform(a.dstat[t]);
+      if (!(st & 4) || (st & 3) == 3) continue;
     }
-    const Ls2A32 ir = ls2_wave_incl(er, lane), ii = ls2_wave_incl(ei, lane);
-    Ls2A32 tr, ti; tr.c0 = wv::readlane(ir.c0, 63); tr.c1 = wv::readlane(ir.c1, 63); ti.c0 = wv::readlane(ii.c0, 63); ti.c1 = wv::readlane(ii.c1, 63);
-    carry[0] = ls2_comp32(carry[0], tr); carry[1] = ls2_comp32(carry[1], ti);
+    int er, ei;
+    ls2_dcb_unit(a, t, r > 0, (r > 0) ? wv::uniform(a.dT[2 * t]) : 0, (r > 0) ? wv::uniform(a.dT[2 * t + 1]) : 0, r == 0, lane, lds_dc, lds_tmp, lds_q, er, ei);
+    if (r == 0 && lane == 0) a.dstat[t] = 4;
+    n_run++;
   }
-  Ls2A32 pre[2];
-  ls2_chain_prefix<2>(a, s, b, wave, lane, tid, carry, wagg, pre);
-  Ls2A32 rr = pre[0], ri = pre[1];
-  // ---- sweep 2: every unit's true (or predicted) start; what is not proven goes on the re-run list ----
-  int n_rerun = 0, n_units = 0, n_dc = 0;
-  nxt = ls2_dc_rec(a, base, 64 * c_lo + lane);
-  for (int c = c_lo; c < c_hi; ++c) {
-    const Ls2DcRec rec = nxt;
-    if (c + 1 < c_hi) nxt = ls2_dc_rec(a, base, 64 * (c + 1) + lane);
-    const int i = base + (64 * c + lane) * (a.dc_fine ? 1 : LS2_FINE);
-    const bool in = rec.on != 0;
-    const Ls2DcRun &ru = rec.ru;
-    Ls2A32 er, ei; er.c0 = er.c1 = 0; ei.c0 = ei.c1 = 0;
-    if (in) {
-      er = ls2_elem32(ru.s[0], ru.eA[0], ru.eB[0]);
-      ei = ls2_elem32(ru.s[1], ru.eA[1], ru.eB[1]);
-    }
-    const Ls2A32 ir = ls2_wave_incl(er, lane), ii = ls2_wave_incl(ei, lane);
-    const int Tr = ls2_apply32(ls2_comp32(rr, ls2_wave_excl(ir, lane)), T0r);
-    const int Ti = ls2_apply32(ls2_comp32(ri, ls2_wave_excl(ii, lane)), T0i);
-    if (in) {
-      if (r == 0 && a.fsm[i].unit == i) n_units++;
-      n_dc++;
-      const int64_t Dr = (int64_t)Tr - (int64_t)ls2_ord(ru.s[0]), Di = (int64_t)Ti - (int64_t)ls2_ord(ru.s[1]);
-      const int64_t aDr = (Dr < 0) ? -Dr : Dr, aDi = (Di < 0) ? -Di : Di;
-      a.dT[2 * i] = Tr; a.dT[2 * i + 1] = Ti;
-      const bool again = (Dr != 0 && !(aDr + 4 <= (int64_t)ru.margin[0])) || (Di != 0 && !(aDi + 4 <= (int64_t)ru.margin[1]));
-      if (again) {
-        a.drun[i].s[0] = ls2_from_ord(Tr);
-        a.drun[i].s[1] = ls2_from_ord(Ti);
-        const int k = wv::atomic_add(&ctl->dc_count[r], 1);
-        a.dlist[(int64_t)(r & 1) * NS + k] = i;
-        n_rerun++;
-      }
-    }
-    Ls2A32 tr, ti; tr.c0 = wv::readlane(ir.c0, 63); tr.c1 = wv::readlane(ir.c1, 63); ti.c0 = wv::readlane(ii.c0, 63); ti.c1 = wv::readlane(ii.c1, 63);
-    rr = ls2_comp32(rr, tr); ri = ls2_comp32(ri, ti);
+  if (r > 0 && n_run && lane == 0) wv::atomic_add(&ctl->dc_reruns, n_run);
+}
+
+// ---- the chain of tables ----
+// v -> the end of a node (unit, block, group) whose table lies across the lanes (lane j: the end for the start cen + j - 32):
+// inside the window a lookup; outside, the nearest candidate's end shifted along (a guess: ex goes false).  exm: the
+// candidates whose ends are themselves exact (a block's table entry is exact only if every lookup inside the block hit).
+RFID_DEVICE void ls2_dcb_apply(int &v, bool &ex, const int tab, const uint64_t exm, const int cen) {
+  const int o = (int)((uint32_t)v - (uint32_t)cen + (uint32_t)LS2_DCB_HALF);
+  const int oc = (o < 0) ? 0 : ((o > 63) ? 63 : o);
+  const int e = wv::shfl(tab, oc);
+  ex = ex && (o == oc) && (((exm >> oc) & 1ull) != 0ull);
+  v = (int)((uint32_t)e + (uint32_t)(o - oc));
+}
+// what a level's nodes are made of: level 1 = blocks of 64 units, level 2 = groups of 64 blocks
+struct Ls2DcbKids { const int *cen; const int *tab; const uint64_t *exm; const int *val; int per_trace; };
+template <int L>
+RFID_DEVICE Ls2DcbKids ls2_dcb_kids(const Ls2Args &a) {
+  Ls2DcbKids k;
+  if (L == 1) { k.cen = a.dcen; k.tab = a.dtab; k.exm = nullptr; k.val = nullptr; k.per_trace = a.max_bc; }
+  else { k.cen = a.n1cen; k.tab = a.n1tab; k.exm = a.n1exm; k.val = a.n1val; k.per_trace = a.dcb_n1; }
+  return k;
+}
+// up: the 64 children of node `node` of level L composed in order -> the node's table (on the window of its first child)
+template <int L>
+RFID_DEVICE void ls2_dcb_up(const Ls2Args &a, const int node, const int lane) {
+  const Ls2DcbKids kd = ls2_dcb_kids<L>(a);
+  const int nper = (L == 1) ? a.dcb_n1 : a.dcb_n2;
+  int *ocen = (L == 1) ? a.n1cen : a.n2cen; int *otab = (L == 1) ? a.n1tab : a.n2tab;
+  uint64_t *oexm = (L == 1) ? a.n1exm : a.n2exm; int *oval = (L == 1) ? a.n1val : a.n2val;
+  const int s = node / nper, k = node - s * nper;
+  const int ch0 = s * kd.per_trace + 64 * k;
+  const bool in = 64 * k + lane < kd.per_trace;
+  int valid = 0, cre = 0, cim = 0;
+  if (in) {
+    valid = (L == 1) ? ((a.dstat[ch0 + lane] >> 2) & 1) : kd.val[ch0 + lane];
+    if (valid) { cre = kd.cen[2 * (ch0 + lane)]; cim = kd.cen[2 * (ch0 + lane) + 1]; }
   }
-  if (n_rerun) wv::atomic_add(&ctl->dc_reruns, n_rerun);
-  if (r == 0 && n_units) wv::atomic_add(&ctl->n_units, n_units);
-  if (r == 0 && n_dc) wv::atomic_add(&ctl->n_dc_pieces, n_dc);
-  if (tid == 0 && s == 0 && b == 0) ctl->dc_rounds = r + 1;
+  const uint64_t m = wv::ballot(valid != 0);
+  if (m == 0ull) { if (lane == 0) oval[node] = 0; return; }
+  int l = wv::ffs64(m);
+  const int bre = wv::readlane(cre, l), bim = wv::readlane(cim, l);
+  int vre = bre + lane - LS2_DCB_HALF, vim = bim + lane - LS2_DCB_HALF;
+  bool exr = true, exi = true;
+  auto fetch = [&](const int c, int &tr, int &ti, uint64_t &er, uint64_t &ei) {
+    tr = kd.tab[(int64_t)(2 * (ch0 + c)) * 64 + lane]; ti = kd.tab[(int64_t)(2 * (ch0 + c) + 1) * 64 + lane];
+    er = kd.exm ? wv::uniform(kd.exm[2 * (ch0 + c)]) : ~0ull; ei = kd.exm ? wv::uniform(kd.exm[2 * (ch0 + c) + 1]) : ~0ull;
+  };
+  int tr, ti; uint64_t er, ei;
+  fetch(l, tr, ti, er, ei);
+  for (;;) {
+    const uint64_t rest = (l >= 63) ? 0ull : (m & ~((2ull << l) - 1ull));
+    const int ln = rest ? wv::ffs64(rest) : -1;
+    int ntr = 0, nti = 0; uint64_t ner = 0, nei = 0;
+    if (ln >= 0) fetch(ln, ntr, nti, ner, nei);   // (one child ahead: the loads do not depend on the walk)
+    ls2_dcb_apply(vre, exr, tr, er, wv::readlane(cre, l));
+    ls2_dcb_apply(vim, exi, ti, ei, wv::readlane(cim, l));
+    if (ln < 0) break;
+    l = ln; tr = ntr; ti = nti; er = ner; ei = nei;
+  }
+  otab[(int64_t)(2 * node) * 64 + lane] = vre;
+  otab[(int64_t)(2 * node + 1) * 64 + lane] = vim;
+  const uint64_t mr = wv::ballot(exr), mi = wv::ballot(exi);
+  if (lane == 0) { ocen[2 * node] = bre; ocen[2 * node + 1] = bim; oexm[2 * node] = mr; oexm[2 * node + 1] = mi; oval[node] = 1; }
+}
+RFID_KERNEL(64) void ls2_dcb_up1_kernel(Ls2Args a) {
+  ls2_tail_prio();
+  Ls2Ctl *ctl = a.ctl;
+  if (!ls2_fsm_settled(a, ctl)) return;
+  if (a.round > 0 && wv::uniform(ctl->dc_count[a.round - 1]) == 0) return;
+  const int lane = wv::lane_id();
+  const int N = a.n_streams * a.dcb_n1;
+  for (int node = (int)blockIdx.x; node < N; node += (int)gridDim.x) ls2_dcb_up<1>(a, node, lane);
+}
+RFID_KERNEL(64) void ls2_dcb_up2_kernel(Ls2Args a) {
+  ls2_tail_prio();
+  Ls2Ctl *ctl = a.ctl;
+  if (!ls2_fsm_settled(a, ctl)) return;
+  if (a.round > 0 && wv::uniform(ctl->dc_count[a.round - 1]) == 0) return;
+  const int lane = wv::lane_id();
+  const int N = a.n_streams * a.dcb_n2;
+  for (int node = (int)blockIdx.x; node < N; node += (int)gridDim.x) ls2_dcb_up<2>(a, node, lane);
+}
+// the walk over a trace's top-level nodes from its exact start (the centre of its first unit): every node's entry value.
+// One wave per trace; the values are wave-uniform.
+RFID_KERNEL(64) void ls2_dcb_top_kernel(Ls2Args a) {
+  ls2_tail_prio();
+  Ls2Ctl *ctl = a.ctl;
+  if (!ls2_fsm_settled(a, ctl)) return;
+  const int r = a.round;
+  if (r > 0 && wv::uniform(ctl->dc_count[r - 1]) == 0) return;
+  const int lane = wv::lane_id();
+  const int s = (int)blockIdx.x;
+  const int t0 = s * a.max_bc;
+  if (s == 0 && lane == 0) ctl->dc_rounds = r + 1;
+  if (!(wv::uniform(a.dstat[t0]) & 4)) return;   // an empty trace
+  const bool two = a.dcb_top == 2;
+  const int nper = two ? a.dcb_n2 : a.dcb_n1;
+  const int *cen = two ? a.n2cen : a.n1cen; const int *tab = two ? a.n2tab : a.n1tab;
+  const uint64_t *exm = two ? a.n2exm : a.n1exm; const int *val = two ? a.n2val : a.n1val;
+  int *ent = two ? a.n2ent : a.n1ent;
+  int Tre = wv::uniform(a.dcen[2 * t0]), Tim = wv::uniform(a.dcen[2 * t0 + 1]);
+  bool exr = true, exi = true;
+  const int n0 = s * nper;
+  int tr = tab[(int64_t)(2 * n0) * 64 + lane], ti = tab[(int64_t)(2 * n0 + 1) * 64 + lane];
+  for (int k = 0; k < nper; ++k) {
+    const int node = n0 + k;
+    int ntr = 0, nti = 0;
+    if (k + 1 < nper) { ntr = tab[(int64_t)(2 * (node + 1)) * 64 + lane]; nti = tab[(int64_t)(2 * (node + 1) + 1) * 64 + lane]; }
+    if (wv::uniform(val[node]) != 0) {
+      if (lane == 0) { ent[4 * node] = Tre; ent[4 * node + 1] = Tim; ent[4 * node + 2] = exr ? 1 : 0; ent[4 * node + 3] = exi ? 1 : 0; }
+      ls2_dcb_apply(Tre, exr, tr, wv::uniform(exm[2 * node]), wv::uniform(cen[2 * node]));
+      ls2_dcb_apply(Tim, exi, ti, wv::uniform(exm[2 * node + 1]), wv::uniform(cen[2 * node + 1]));
+    }
+    tr = ntr; ti = nti;
+  }
+}
+// down: from a node's entry value to its children's.  Level 1: the children are the units -- their start values (a.dT),
+// which of them are settled, how many are not (Ls2Ctl::dc_count[round]).
+template <int L>
+RFID_DEVICE void ls2_dcb_down(const Ls2Args &a, const int node, const int lane, int &n_uns, int &n_units) {
+  const Ls2DcbKids kd = ls2_dcb_kids<L>(a);
+  const int nper = (L == 1) ? a.dcb_n1 : a.dcb_n2;
+  const int *nval = (L == 1) ? a.n1val : a.n2val; const int *nent = (L == 1) ? a.n1ent : a.n2ent;
+  if (wv::uniform(nval[node]) == 0) return;
+  const int s = node / nper, k = node - s * nper;
+  const int ch0 = s * kd.per_trace + 64 * k;
+  const bool in = 64 * k + lane < kd.per_trace;
+  int valid = 0, cre = 0, cim = 0;
+  if (in) {
+    valid = (L == 1) ? ((a.dstat[ch0 + lane] >> 2) & 1) : kd.val[ch0 + lane];
+    if (valid) { cre = kd.cen[2 * (ch0 + lane)]; cim = kd.cen[2 * (ch0 + lane) + 1]; }
+  }
+  const uint64_t m = wv::ballot(valid != 0);
+  if (m == 0ull) return;
+  int Tre = wv::uniform(nent[4 * node]), Tim = wv::uniform(nent[4 * node + 1]);
+  bool exr = wv::uniform(nent[4 * node + 2]) != 0, exi = wv::uniform(nent[4 * node + 3]) != 0;
+  auto fetch = [&](const int c, int &tr, int &ti, uint64_t &er, uint64_t &ei) {
+    tr = kd.tab[(int64_t)(2 * (ch0 + c)) * 64 + lane]; ti = kd.tab[(int64_t)(2 * (ch0 + c) + 1) * 64 + lane];
+    er = kd.exm ? wv::uniform(kd.exm[2 * (ch0 + c)]) : ~0ull; ei = kd.exm ? wv::uniform(kd.exm[2 * (ch0 + c) + 1]) : ~0ull;
+  };
+  int l = wv::ffs64(m);
+  int tr, ti; uint64_t er, ei;
+  fetch(l, tr, ti, er, ei);
+  for (;;) {
+    const uint64_t rest = (l >= 63) ? 0ull : (m & ~((2ull << l) - 1ull));
+    const int ln = rest ? wv::ffs64(rest) : -1;
+    int ntr = 0, nti = 0; uint64_t ner = 0, nei = 0;
+    if (ln >= 0) fetch(ln, ntr, nti, ner, nei);
+    const int c_re = wv::readlane(cre, l), c_im = wv::readlane(cim, l);
+    const int c = ch0 + l;
+    if (L == 1) {
+      const int o_re = (int)((uint32_t)Tre - (uint32_t)c_re + (uint32_t)LS2_DCB_HALF), o_im = (int)((uint32_t)Tim - (uint32_t)c_im + (uint32_t)LS2_DCB_HALF);
+      const int bits = ((exr && o_re >= 0 && o_re < 64) ? 1 : 0) | ((exi && o_im >= 0 && o_im < 64) ? 2 : 0);
+      if (lane == 0) { a.dT[2 * c] = Tre; a.dT[2 * c + 1] = Tim; a.dstat[c] = 4 | bits; }
+      n_units++;
+      n_uns += (bits != 3) ? 1 : 0;
+    } else {
+      if (lane == 0) { int *e = a.n1ent + 4 * c; e[0] = Tre; e[1] = Tim; e[2] = exr ? 1 : 0; e[3] = exi ? 1 : 0; }
+    }
+    ls2_dcb_apply(Tre, exr, tr, er, c_re);
+    ls2_dcb_apply(Tim, exi, ti, ei, c_im);
+    if (ln < 0) break;
+    l = ln; tr = ntr; ti = nti; er = ner; ei = nei;
+  }
+}
+RFID_KERNEL(64) void ls2_dcb_down2_kernel(Ls2Args a) {
+  ls2_tail_prio();
+  Ls2Ctl *ctl = a.ctl;
+  if (!ls2_fsm_settled(a, ctl)) return;
+  if (a.round > 0 && wv::uniform(ctl->dc_count[a.round - 1]) == 0) return;
+  const int lane = wv::lane_id();
+  const int N = a.n_streams * a.dcb_n2;
+  int u0 = 0, u1 = 0;
+  for (int node = (int)blockIdx.x; node < N; node += (int)gridDim.x) ls2_dcb_down<2>(a, node, lane, u0, u1);
+}
+RFID_KERNEL(64) void ls2_dcb_down1_kernel(Ls2Args a) {
+  ls2_tail_prio();
+  Ls2Ctl *ctl = a.ctl;
+  if (!ls2_fsm_settled(a, ctl)) return;
+  const int r = a.round;
+  if (r > 0 && wv::uniform(ctl->dc_count[r - 1]) == 0) return;
+  const int lane = wv::lane_id();
+  const int N = a.n_streams * a.dcb_n1;
+  int n_uns = 0, n_units = 0;
+  for (int node = (int)blockIdx.x; node < N; node += (int)gridDim.x) ls2_dcb_down<1>(a, node, lane, n_uns, n_units);
+  if (lane == 0) {
+    if (n_uns) wv::atomic_add(&ctl->dc_count[r], n_uns);
+    if (r == 0 && n_units) { wv::atomic_add(&ctl->n_units, n_units); wv::atomic_add(&ctl->n_dc_pieces, n_units); }
+  }
+}
+// The enqueued rounds are used up and units are still unsettled: one wave per trace takes them one after the other from the
+// proven value at the frontier, each from its exact start (candidate 32 of a run centred on it).  Settled units keep their
+// results; the launches behind (window sequence numbers, assembly) then find everything settled.
+RFID_KERNEL(64) void ls2_dcb_finish_kernel(Ls2Args a) {
+  ls2_tail_prio();
+  RFID_SHARED float2 lds_dc[DC_LEN];
+  RFID_SHARED float2 lds_tmp[64];
+  RFID_SHARED float4 lds_q4[32];
+  float2 *lds_q = reinterpret_cast<float2 *>(lds_q4);
+  Ls2Ctl *ctl = a.ctl;
+  if (!ls2_fsm_settled(a, ctl)) return;
+  if (wv::uniform(ctl->dc_count[a.dc_rounds]) == 0) return;
+  const int lane = wv::lane_id();
+  const int s = (int)blockIdx.x;
+  const int t0 = s * a.max_bc;
+  int first = -1;
+  for (int k0 = 0; k0 < a.max_bc && first < 0; k0 += 64) {
+    const int k = k0 + lane;
+    const int st = (k < a.max_bc) ? a.dstat[t0 + k] : 0;
+    const uint64_t m = wv::ballot((st & 4) != 0 && (st & 3) != 3);
+    if (m) first = k0 + wv::ffs64(m);
+  }
+  if (first < 0) return;
+  int Tre = wv::uniform(a.dT[2 * (t0 + first)]), Tim = wv::uniform(a.dT[2 * (t0 + first) + 1]);   // (exact: everything before is settled)
+  int fixed = 0;
+  for (int k = first; k < a.max_bc; ++k) {
+    const int t = t0 + k;
+    if (!(wv::uniform(a.dstat[t]) & 4)) continue;
+    int er, ei;
+    ls2_dcb_unit(a, t, true, Tre, Tim, false, lane, lds_dc, lds_tmp, lds_q, er, ei);
+    if (lane == 0) { a.dT[2 * t] = Tre; a.dT[2 * t + 1] = Tim; a.dstat[t] = 7; }
+    Tre = wv::readlane(er, LS2_DCB_HALF); Tim = wv::readlane(ei, LS2_DCB_HALF);
+    fixed++;
+  }
+  if (lane == 0 && fixed) { wv::atomic_add(&ctl->dc_count[a.dc_rounds], -fixed); wv::atomic_add(&ctl->dc_finished, fixed); }
 }
 
 // ---- 5. windows ----------------------------------------------------------------------------------------------------
@@ -2173,33 +2100,25 @@ RFID_KERNEL(64) void ls2_assemble_kernel(Ls2Args a) {
     const int fb0 = wv::uniform(a.flat_base[2 * s]), fb1 = wv::uniform(a.flat_base[2 * s + 1]);
     for (int bb = b0; bb <= b1; bb += 64) {
       const int b = bb + lane;
-      Ls2Win w; w.start = 0; w.tag = 0; w.a_re = w.a_im = w.b_re = w.b_im = 0.0f; w.piece = 0; w.pad_ = 0;
+      Ls2Win w; w.start = 0; w.tag = 0; w.slot = 0; w.unit = 0; w.pad_[0] = w.pad_[1] = w.pad_[2] = w.pad_[3] = 0;
       if (b <= b1) w = wb[b];
       const bool on = b <= b1 && (w.tag >> 8) == gen && (w.tag & 2) != 0 && w.start >= pos0 && w.start < pos0 + n;
       const uint64_t m = wv::ballot(on);
       if (m == 0ull) continue;
       const int type = w.tag & 1;
       const uint64_t me = wv::ballot(on && type != 0);
-      // the true start of the window's dc_est piece against the start its run used: D ulps (even: variant A + D, odd:
-      // variant B + D - 1)
-      float shift[2] = {0.0f, 0.0f};
-      bool useb[2] = {false, false};
+      // dc_est at the opening: the unit's run left it for each of its 64 candidate starts; the chain says which one the true
+      // start is (the unit is settled: inside the window), per component
+      float dcr = 0.0f, dci = 0.0f;
       if (on) {
-        const Ls2DcRun ru = a.drun[w.piece];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const int D = a.dT[2 * w.piece + c] - ls2_ord(ru.s[c]);
-          useb[c] = (D & 1) != 0;
-          const int De = useb[c] ? (D - 1) : D;
-          const uint32_t e0 = (wv::f2u(ru.s[c]) >> 23) & 0xffu;
-          const float u0 = (e0 >= 25u) ? wv::u2f((e0 - 23u) << 23) : 0.0f;   // (D != 0 was only accepted with a margin, i.e. e0 >= 25)
-          shift[c] = (float)De * u0;
-        }
+        const int o_re = a.dT[2 * w.unit] - a.dcen[2 * w.unit] + LS2_DCB_HALF, o_im = a.dT[2 * w.unit + 1] - a.dcen[2 * w.unit + 1] + LS2_DCB_HALF;
+        dcr = a.dcand[(int64_t)w.slot * 64 + (o_re & 63)].x;
+        dci = a.dcand[(int64_t)w.slot * 64 + (o_im & 63)].y;
       }
       rfid_window o;
       o.stream = s; o.seq = seq + wv::popc64(m & lt); o.start = w.start; o.type = type;
-      o.dc_re = (useb[0] ? w.b_re : w.a_re) + shift[0];
-      o.dc_im = (useb[1] ? w.b_im : w.a_im) + shift[1];
+      o.dc_re = dcr;
+      o.dc_im = dci;
       if (on && o.seq < a.wmax) {
         a.wtab[(int64_t)s * a.wmax + o.seq] = o;
         // its place in the decoder's list: the trace's base + the windows of its type before it in the trace
@@ -2235,13 +2154,12 @@ RFID_KERNEL(64) void ls2_carry_kernel(Ls2Args a) {
   const int Da = wv::uniform(a.aT[last]) - ls2_ord(ar.s);
   const float avg_end = ls2_from_ord(ls2_ord((Da & 1) ? ar.eB : ar.eA) + ((Da & 1) ? (Da - 1) : Da));
   const int h = wv::uniform(a.fsm[last].unit);
-  int hd = last;   // the last dc_est piece: the one of the last slot that has one (the unit's head at the latest)
-  while (hd != h && wv::uniform(a.dend[hd]) <= 0) hd = wv::uniform(a.prevv[hd]);
-  const Ls2DcRun dr = a.drun[hd];
+  // dc_est behind the last unit: its table at the candidate the chain found to be its true start
+  const int tl = s * a.max_bc + (h - base) / LS2_FINE;
   float dc_end[2];
   for (int c = 0; c < 2; ++c) {
-    const int D = wv::uniform(a.dT[2 * hd + c]) - ls2_ord(dr.s[c]);
-    dc_end[c] = ls2_from_ord(ls2_ord((D & 1) ? dr.eB[c] : dr.eA[c]) + ((D & 1) ? (D - 1) : D));
+    const int o = wv::uniform(a.dT[2 * tl + c]) - wv::uniform(a.dcen[2 * tl + c]) + LS2_DCB_HALF;
+    dc_end[c] = ls2_from_ord(wv::uniform(a.dtab[(int64_t)(2 * tl + c) * 64 + (o & 63)]));
   }
   for (int k = lane; k < WIN_LEN; k += 64) {
     const int idx = end - WIN_LEN + k;

@@ -24,6 +24,7 @@ struct Ls2Geometry {
   int P = 0, max_b = 0, NS = 0;            // piece length, slots per trace, slots
   int Pc = 0, max_bc = 0;                  // the idle-cut grid
   int64_t vstride = 0, cstride = 0, wb_stride = 0;
+  int n1 = 0, n2 = 0;                      // dc_est chain: blocks of 64 idle-grid slots per trace, groups of 64 blocks
 };
 // P: nominal piece length for `n_streams` traces of (at most) n_dec decimated samples; 0 = the traces are too short to cut
 inline Ls2Geometry ls2_geometry(int n_streams, int64_t n_dec, int min_piece = LS2_MIN_PIECE, int target = LS2_TARGET_PIECES) {
@@ -41,14 +42,18 @@ inline Ls2Geometry ls2_geometry(int n_streams, int64_t n_dec, int min_piece = LS
   g.vstride = (n_dec >> 6) + 3;
   g.cstride = (n_dec >> 6) + g.max_bc + 3;
   g.wb_stride = n_dec / LS2_WBUCKET + 2;
+  g.n1 = (g.max_bc + 63) / 64;
+  g.n2 = (g.n1 + 63) / 64;
   return g;
 }
 
 // work space: one allocation, carved up here (offsets in bytes, 256-byte aligned)
 struct Ls2Layout {
-  size_t cut, cutf, piece, nextv, prevv, upiece, unextv, uprevv, lb_fn, lb_end, lb_water, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, drun, dT, dcut, dend, dlist, seq0, flat_base, cflag, cagg, ctl, consumed, total;
+  size_t cut, cutf, piece, nextv, prevv, upiece, unextv, uprevv, lb_fn, lb_end, lb_water, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, dT, dcen, dtab, dstat, dwbase, dcand, n1cen, n1tab, n1val, n1ent, n1exm, n2cen, n2tab, n2val, n2ent, n2exm, seq0, flat_base, cflag, cagg, ctl, consumed, total;
+  int dcand_cap;
 };
-inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_stride) {
+// wmax: complete windows a trace can hold (the caller's window table): sizes the dc_est stage's table of gate openings
+inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_stride, int wmax) {
   Ls2Layout L;
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -73,11 +78,18 @@ inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_strid
   L.aover = take(sizeof(Ls2Aff) * NS);
   L.fsm = take(sizeof(Ls2Fsm) * NS);
   L.wb = take(sizeof(Ls2Win) * B * (size_t)g.wb_stride);
-  L.drun = take(sizeof(Ls2DcRun) * NS);
-  L.dT = take(sizeof(int) * 2 * NS);
-  L.dcut = take(sizeof(int) * NS);
-  L.dend = take(sizeof(int) * NS);
-  L.dlist = take(sizeof(int) * 2 * NS);
+  const size_t NH = B * (size_t)g.max_bc, N1 = B * (size_t)g.n1, N2 = B * (size_t)g.n2;
+  L.dT = take(sizeof(int) * 2 * NH);
+  L.dcen = take(sizeof(int) * 2 * NH);
+  L.dtab = take(sizeof(int) * 2 * 64 * NH);
+  L.dstat = take(sizeof(int) * NH);
+  L.dwbase = take(sizeof(int) * NH);
+  L.dcand_cap = (int)(B * (size_t)(wmax > 0 ? wmax : 0) + NH + 8);   // every window + the one a trace may end in, per unit
+  L.dcand = take(sizeof(float2) * 64 * (size_t)L.dcand_cap);
+  L.n1cen = take(sizeof(int) * 2 * N1); L.n1tab = take(sizeof(int) * 2 * 64 * N1); L.n1val = take(sizeof(int) * N1);
+  L.n1ent = take(sizeof(int) * 4 * N1); L.n1exm = take(sizeof(uint64_t) * 2 * N1);
+  L.n2cen = take(sizeof(int) * 2 * N2); L.n2tab = take(sizeof(int) * 2 * 64 * N2); L.n2val = take(sizeof(int) * N2);
+  L.n2ent = take(sizeof(int) * 4 * N2); L.n2exm = take(sizeof(uint64_t) * 2 * N2);
   L.seq0 = take(sizeof(int) * 2 * NS);
   L.flat_base = take(sizeof(int) * 2 * B);
   L.cflag = take(sizeof(int) * B * LS2_CHAIN_GMAX);
@@ -87,6 +99,7 @@ inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_strid
   L.total = off;
   return L;
 }
+inline int &ls2_dcb_top_min();
 inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geometry &g) {
   a.P = g.P; a.max_b = g.max_b; a.Pc = g.Pc; a.max_bc = g.max_bc; a.vstride = g.vstride; a.cstride = g.cstride; a.wb_stride = g.wb_stride;
   a.cut = (int *)(base + L.cut); a.cutf = (int *)(base + L.cutf); a.piece = (Ls2Piece *)(base + L.piece);
@@ -97,12 +110,17 @@ inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geomet
   a.votes = (uint64_t *)(base + L.votes); a.closed = (uint64_t *)(base + L.closed); a.openinfo = (int *)(base + L.openinfo);
   a.arun = (Ls2AvgRun *)(base + L.arun); a.aT = (int *)(base + L.aT); a.alist = (int *)(base + L.alist); a.aover = (Ls2Aff *)(base + L.aover);
   a.fsm = (Ls2Fsm *)(base + L.fsm); a.wb = (Ls2Win *)(base + L.wb);
-  a.drun = (Ls2DcRun *)(base + L.drun); a.dT = (int *)(base + L.dT); a.dcut = (int *)(base + L.dcut); a.dend = (int *)(base + L.dend); a.dlist = (int *)(base + L.dlist);
+  a.dT = (int *)(base + L.dT); a.dcen = (int *)(base + L.dcen); a.dtab = (int *)(base + L.dtab); a.dstat = (int *)(base + L.dstat);
+  a.dwbase = (int *)(base + L.dwbase); a.dcand = (float2 *)(base + L.dcand); a.dcand_cap = L.dcand_cap;
+  a.dcb_n1 = g.n1; a.dcb_n2 = g.n2; a.dcb_top = (g.n1 > ls2_dcb_top_min()) ? 2 : 1;
+  a.n1cen = (int *)(base + L.n1cen); a.n1tab = (int *)(base + L.n1tab); a.n1val = (int *)(base + L.n1val); a.n1ent = (int *)(base + L.n1ent); a.n1exm = (uint64_t *)(base + L.n1exm);
+  a.n2cen = (int *)(base + L.n2cen); a.n2tab = (int *)(base + L.n2tab); a.n2val = (int *)(base + L.n2val); a.n2ent = (int *)(base + L.n2ent); a.n2exm = (uint64_t *)(base + L.n2exm);
   a.seq0 = (int *)(base + L.seq0); a.flat_base = (int *)(base + L.flat_base); a.cflag = (int *)(base + L.cflag); a.cagg = (int *)(base + L.cagg); a.ctl = (Ls2Ctl *)(base + L.ctl); a.consumed = (int *)(base + L.consumed);
 }
 
 inline int &ls2_fsm_lanes_min() { static int v = 8192; return v; }   // from this many possible heads on the state machine runs one lane per unit (tests: 0 / a huge number)
-inline int &ls2_chain_slots() { static int v = 2048; return v; }   // slots per workgroup of a chain launch (tests shrink it)
+inline int &ls2_chain_slots() { static int v = 2048; return v; }
+inline int &ls2_dcb_top_min() { static int v = 64; return v; }   // the dc_est chain walks over groups of blocks when a trace has more blocks than this (tests: 0)   // slots per workgroup of a chain launch (tests shrink it)
 
 #ifdef LS2_LAUNCH
 // One pass (its first launch zeroes Ls2Ctl, the chain flags, the votes, the window buckets and flat_count).  `a` complete but for
@@ -113,7 +131,8 @@ inline int &ls2_chain_slots() { static int v = 2048; return v; }   // slots per 
 // lets parts of the NEXT pass's matched filter start behind them; 2 (fused first pass only): behind the launches that touch
 // nothing but the raw samples, y and the pass's own work space -- the library runs those on a second stream, beside the rest
 // of the pass before, and changes streams here
-inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nullptr, bool generous = false, int dc_fine = -1,
+// dc_rounds: dc_est rounds to enqueue (< 0: by the pass's size; the library passes what the passes before needed)
+inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nullptr, bool generous = false, int dc_rounds = -1,
                         void (*mark)(void *, int) = nullptr, void *mark_arg = nullptr) {   // (search_cuts = false: a.cut is given -- tests)
   const int NS = a.n_streams * a.max_b, NH = a.n_streams * a.max_bc;   // slots; slots that can be heads
   const int B = a.n_streams;
@@ -122,7 +141,7 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
   // the fused first pass keeps two piece tables (Ls2Args::fused): the unit kernels get the arguments with the units' table
   // (its slots between the idle cuts: empty, or -- where the dc_est stage wants pieces, dc_fine -- cut at the avg_ampl pieces' starts)
   auto U = [fused](Ls2Args x) {
-    if (fused) { x.piece = x.upiece; x.nextv = x.unextv; x.prevv = x.uprevv; if (!x.dc_fine) x.cutf = nullptr; x.fused = 2; }
+    if (fused) { x.piece = x.upiece; x.nextv = x.unextv; x.prevv = x.uprevv; x.cutf = nullptr; x.fused = 2; }
     return x;
   };
   {
@@ -156,10 +175,12 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
   // saw a pass run out of rounds (the sequential scan took over): the full count from then on
   const bool small = NS < 32768 && !generous, tiny = NS < 1024 && !generous;
   a.avg_rounds = tiny ? 3 : (small ? 4 : LS2_AVG_ROUNDS); a.fsm_rounds = (tiny || small) ? 1 : LS2_FSM_ROUNDS;
-  a.dc_rounds = (tiny || small) ? 2 : LS2_DC_ROUNDS;
-  // short passes run at the pace of their longest dc_est run: there the units are cut again behind the gate openings
-  // (test hook: dc_fine = 0 / 1 says so itself)
-  a.dc_fine = (dc_fine < 0) ? (small ? 1 : 0) : dc_fine;
+  // dc_est: away from binade edges round 1 settles everything (round 0's centres are off by the rounding drift); sums that hover
+  // at an edge advance some thousand units per round.  What the rounds leave, ls2_dcb_finish_kernel takes one unit after
+  // the other; the library asks for as many rounds as the passes before needed (+ a few) from then on
+  a.dc_rounds = (dc_rounds >= 0) ? dc_rounds : (generous ? 24 : ((tiny || small) ? 3 : LS2_DC_ROUNDS));
+  if (a.dc_rounds < 0) a.dc_rounds = 0;
+  if (a.dc_rounds > LS2_DC_MAXR) a.dc_rounds = LS2_DC_MAXR;
   if (fused) {
     // matched filter + piece boundaries + the first avg_ampl pass in one sweep over the raw samples; then the pieces' links,
     // the idle cuts from the blocks' not-carrier masks (unless given: tests) and the units' table from them
@@ -194,19 +215,22 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
     else LS2_LAUNCH(ls2_fsm_kernel, NH, 1, 64, U(a));
     LS2_LAUNCH(ls2_fsm_chain_kernel, (NH + 255) / 256, 1, 256, U(a));
   }
-  a.round = 0;
-  const int g_dc = a.dc_fine ? g_avg : g_seq;
-  a.chain_g = g_dc;
-  LS2_LAUNCH(ls2_dc_cut_kernel, (NS + 255) / 256, 1, 256, U(a));
-  LS2_LAUNCH(ls2_dc_first_kernel, a.dc_fine ? NS : NH, 1, 64, U(a));
-  a.stamp++;
-  LS2_LAUNCH(ls2_dc_chain_kernel, g_dc, B, LS2_CHAIN_THREADS, U(a));
-  if (mark) mark(mark_arg, 1);
-  for (int r = 1; r <= a.dc_rounds; ++r) {
-    a.round = r;
-    LS2_LAUNCH(ls2_dc_rerun_kernel, rerun_grid(r, 16384), 1, 64, U(a));
-    a.stamp++;
-    LS2_LAUNCH(ls2_dc_chain_kernel, g_dc, B, LS2_CHAIN_THREADS, U(a));
+  // dc_est: every unit from 64 neighbouring start values at once (lane = candidate), the chain of their tables in levels of
+  // 64 (up, a walk over the top level, down); round r > 0 runs what is not settled again, centred on the chain's prediction
+  {
+    const int N1 = B * a.dcb_n1, N2 = B * a.dcb_n2;
+    for (int r = 0; r <= a.dc_rounds; ++r) {
+      a.round = r;
+      LS2_LAUNCH(ls2_dcb_run_kernel, NH, 1, 64, U(a));
+      LS2_LAUNCH(ls2_dcb_up1_kernel, N1, 1, 64, U(a));
+      if (a.dcb_top == 2) LS2_LAUNCH(ls2_dcb_up2_kernel, N2, 1, 64, U(a));
+      LS2_LAUNCH(ls2_dcb_top_kernel, B, 1, 64, U(a));
+      if (a.dcb_top == 2) LS2_LAUNCH(ls2_dcb_down2_kernel, N2, 1, 64, U(a));
+      LS2_LAUNCH(ls2_dcb_down1_kernel, N1, 1, 64, U(a));
+      if (r == 0 && mark) mark(mark_arg, 1);
+    }
+    a.round = 0;
+    LS2_LAUNCH(ls2_dcb_finish_kernel, B, 1, 64, U(a));
   }
   a.round = 0;
   a.stamp++;

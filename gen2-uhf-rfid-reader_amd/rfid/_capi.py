@@ -54,7 +54,7 @@ class SynthGen2Params(C.Structure):
 
 class LsReport(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("pieces", "units", "chunk", "avg_rounds", "avg_reruns", "fsm_rounds", "dc_rounds",
-                                         "dc_reruns", "verified", "gave_up", "cuts_dropped", "windows", "dc_pieces")]
+                                         "dc_reruns", "verified", "gave_up", "cuts_dropped", "windows", "dc_finished")]
 
 
 class BatchTiming(C.Structure):

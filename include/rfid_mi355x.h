@@ -40,7 +40,7 @@ extern "C" {
 #endif
 
 #define RFID_API __attribute__((visibility("default")))
-#define RFID_MI355X_ABI 4   /* see rfid_abi_version() */
+#define RFID_MI355X_ABI 5   /* see rfid_abi_version() */
 
 typedef enum rfid_status {
   RFID_OK = 0,
@@ -136,8 +136,9 @@ typedef struct rfid_batch_timing {
 
 /* what the long-stream front end did in the last rfid_batch_process pass (all zero when it was not used).  The front
  * end cuts each trace along time into pieces at idle points of the gate and processes all pieces at once: avg_ampl, then
- * the state machine, then dc_est, each from guessed start values whose runs are PROVEN to cover the true ones (or run
- * again); see csrc/rfid_ls2.hpp. */
+ * the state machine -- from guessed start values whose runs are PROVEN to cover the true ones (or run again) -- then dc_est,
+ * every unit from 64 neighbouring start values at once and the chain of their tables from the trace's exact start (round 6);
+ * see csrc/rfid_ls2.hpp. */
 typedef struct rfid_ls_report {
   int32_t pieces;           /* pieces the traces were cut into */
   int32_t units;            /* runs of pieces scanned in one go by the state-machine / dc_est passes (= pieces unless a cut
@@ -146,15 +147,18 @@ typedef struct rfid_ls_report {
   int32_t avg_rounds;       /* avg_ampl: chain rounds that had work (1 = every guess was proven at once) */
   int32_t avg_reruns;       /*   pieces run again from their predicted start because their first run did not cover it */
   int32_t fsm_rounds;       /* state machine: rounds */
-  int32_t dc_rounds;        /* dc_est: chain rounds */
-  int32_t dc_reruns;        /*   piece re-runs */
+  int32_t dc_rounds;        /* dc_est: rounds that had work (2: the first round's centres, the ring means, were off by the rounding
+                             * drift; more: the sums hover at a binade edge and the settled prefix grew round by round) */
+  int32_t dc_reruns;        /*   unit runs after the first round */
   int32_t verified;         /* 1: accepted -- every piece's latest run is exact or proven: the sequential scan, bit for bit */
-  int32_t gave_up;          /* != 0: the sequential scan ran instead (1 no trace could be cut, 2 / 3 / 4: avg_ampl / state
-                             * machine / dc_est not settled within the round limit, 5: the first pass met a stretch of 32
-                             * nominal piece lengths without 128 carrier samples in a row) */
+  int32_t gave_up;          /* != 0: the sequential scan ran instead (1 no trace could be cut, 2 / 3: avg_ampl / state machine not
+                             * settled within the round limit, 5: the first pass met a stretch of 32 nominal piece lengths
+                             * without 128 carrier samples in a row).  dc_est never gives a pass up: see dc_finished */
   int32_t cuts_dropped;     /* cut points withdrawn because the state machine (or the dc ring) was not idle there */
   int32_t windows;          /* complete windows found */
-  int32_t dc_pieces;        /* pieces of the dc_est pass (>= units: a unit is cut again behind gate openings) */
+  int32_t dc_finished;      /* dc_est units that were not settled when the enqueued rounds were used up and went through the
+                             * finishing walk (one after the other from the proven value before them; the settled units kept
+                             * their results): the partial fallback.  0: the rounds sufficed */
 } rfid_ls_report;
 
 typedef struct rfid_ctx rfid_ctx;
@@ -171,7 +175,7 @@ RFID_API const char *rfid_strerror(int status);
 RFID_API const char *rfid_last_error(const rfid_ctx *ctx);
 RFID_API const char *rfid_version(void);
 /* RFID_MI355X_ABI of the library that was loaded: it changes whenever a struct of this header changes size or layout
- * (4: rfid_ls_report has 13 fields since round 3).  A caller built against another value must not pass structs. */
+ * (4: rfid_ls_report has 13 fields since round 3; 5: its last field is dc_finished since round 6).  A caller built against another value must not pass structs. */
 RFID_API int rfid_abi_version(void);
 /* device self-test of the wave-level primitives the kernels rely on (DPP wave shift,
  * IEEE division, double sqrt).  0 = all good, >0 = number of failing checks. */

@@ -66,8 +66,9 @@ def test_ls2_matches_oracle_and_avg_recurrence(emu_mod, oracle_mod, synth_mod, f
     r = _check(emu_mod, oracle_mod, np.stack([t[:L] for t in ts]), expect_ok=1, fused=fused)
     c = r["ctl"]
     assert c["n_pieces"] >= 60 and c["n_units"] == c["n_heads"] >= 12 and c["n_windows"] == len(r["windows"])
-    # dc_est restarts behind gate openings too (at most one cut per piece): more pieces than units
-    assert c["n_units"] < c["n_dc_pieces"] <= c["n_pieces"], c
+    # dc_est: every unit from 64 neighbouring starts; the first round's centres (ring means) are off by the rounding drift, the
+    # second round's are the chain's predictions: two rounds, nothing left for the finishing walk
+    assert c["n_units"] == c["n_dc_pieces"] and c["dc_rounds"] <= 3 and c["dc_finished"] == 0, c
     if fused:
         assert all(pc[1] % 64 == 0 for pc in r["pieces"])        # its pieces lie on block boundaries
     del rng
@@ -75,26 +76,41 @@ def test_ls2_matches_oracle_and_avg_recurrence(emu_mod, oracle_mod, synth_mod, f
 
 @FUSED
 def test_ls2_rerun_rounds_are_exercised(emu_mod, oracle_mod, synth_mod, fused):
-    """Noise of 8 % of the carrier makes dc_est pass close to powers of two inside pieces: some runs do not cover their
-    true start and are repeated from it (dc_reruns > 0) -- the result is still the sequential scan."""
+    """Noise of 8 % of the carrier: dc_est's imaginary part (25 sin 0.7 = 16.1) hovers ACROSS 16.0 all along the trace -- what a
+    start value does to a unit's end is then no shift any more, nothing about a shifted start is provable, and until round 5 such a
+    pass gave up (profiles/r06/noise_sweep.txt).  Every unit is run from 64 neighbouring starts and the chain of their tables is
+    exact wherever the true start lies inside the window: units are run again (dc_reruns > 0), the pass is ACCEPTED, and the
+    result is the sequential scan's."""
     t = synth_mod.make_trace(n_rounds=20, sigma=0.08, seed=9).samples
-    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, dc_fine=0, fused=fused)
-    assert r["ctl"]["dc_reruns"] > 0 and r["ctl"]["dc_rounds"] >= 3, r["ctl"]
-
-    # a short pass enqueues few rounds to begin with (empty launches cost it most) and cuts its units again behind the
-    # gate openings (its pace is its longest dc_est run): here that does not suffice -- a run of pieces that cross a
-    # binade settles one piece per round -- the front end says so and the sequential scan gives the result; the library
-    # then enqueues the full number of rounds and whole units from the next pass on
-    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=0, generous=False, dc_fine=-1, fused=fused)
-    assert r["ctl"]["dc_count2"] > 0 and r["ctl"]["n_dc_pieces"] > r["ctl"]["n_units"], r["ctl"]
-    # (cut behind the openings, all rounds: still more pieces in a row than rounds)
-    r = _check(emu_mod, oracle_mod, t[None, :], dc_fine=1, fused=fused)
-    assert r["ctl"]["n_dc_pieces"] > r["ctl"]["n_units"] and (r["ok"] or r["ctl"]["dc_count7"] > 0), r["ctl"]
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, fused=fused)
+    assert r["ctl"]["dc_reruns"] > 0 and r["ctl"]["dc_rounds"] >= 2 and r["ctl"]["dc_finished"] == 0, r["ctl"]
+    # one round only (the ring means, off by the drift, are all the chain gets): whatever is not settled -- everything behind
+    # the first unit whose true start lies outside its window -- goes through the finishing walk, one unit after the other from
+    # the proven value before it.  Still accepted, still the sequential scan (the partial fallback, not the whole-pass one)
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, dc_rounds=0, fused=fused)
+    assert r["ctl"]["dc_finished"] >= 3 and r["ctl"]["dc_count0"] == 0, r["ctl"]      # (the walk takes what it settles off the count)
+    # the chain's second level (groups of 64 blocks of 64 units: traces of more than 4 096 idle-grid slots), the finishing walk
+    # behind one round of it
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, dc_two_levels=True, fused=fused)
+    assert r["ctl"]["dc_reruns"] > 0 and r["ctl"]["dc_finished"] == 0, r["ctl"]
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, dc_two_levels=True, dc_rounds=0, fused=fused)
+    assert r["ctl"]["dc_finished"] >= 3, r["ctl"]
     # few, long pieces: avg_ampl too
     r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, target=6, fused=fused)
     # (the fused first pass guesses with the drift its look-back has found -- on the emulator, where workgroups run one after
     # the other, the slot before has always finished: hardly a piece is left to run again)
     assert r["ctl"]["n_pieces"] <= 8 and (fused or r["ctl"]["avg_reruns"] > 0), r["ctl"]
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(dc_rounds=0), dict(dc_two_levels=True)], ids=["rounds", "finishing-walk", "two-levels"])
+def test_ls2_dc_est_chain_over_several_blocks(emu_mod, oracle_mod, synth_mod, kw):
+    """Pieces of 64 samples: 235 idle-grid slots = four blocks of the dc_est chain (most slots empty, the units spread over the
+    blocks), on the trace whose dc_est hovers across 16.0: the tables' chain through empty nodes, several blocks and -- forced --
+    the second level must still give the sequential scan's dc_est at every gate opening."""
+    t = synth_mod.make_trace(n_rounds=20, sigma=0.08, seed=9).samples
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, min_piece=64, check_avg=False, **kw)
+    c = r["ctl"]
+    assert c["n_units"] >= 20 and c["dc_count0"] + c["dc_finished"] > 0, c
 
 
 @FUSED

@@ -65,13 +65,12 @@ def batch_process(raw: np.ndarray, lens=None, fixed_q=0, max_num_queries=1000, n
 
 
 LS2_CTL_FIELDS = (["fail", "ok", "n_pieces", "n_heads"] + [f"avg_count{r}" for r in range(12)] + [f"avg_list{r}" for r in range(12)] + [f"fsm_count{r}" for r in range(12)] +
-                  [f"dc_count{r}" for r in range(12)] +
                   ["avg_reruns", "fsm_reruns", "dc_reruns", "avg_rounds", "fsm_rounds", "dc_rounds", "n_units", "n_windows",
-                   "wb_clash", "n_dc_pieces"])
+                   "wb_clash", "n_dc_pieces", "dc_open_alloc", "dc_finished"] + [f"dc_count{r}" for r in range(65)])
 
 
 def ls2_process(raw: np.ndarray, lens=None, fixed_q=0, max_num_queries=1000, number_unique_tags=100, min_piece=512,
-                target=131072, state=None, hold_last=False, cuts=None, y_skip=0, chain_slots=64, generous=True, dc_fine=1, fsm_lanes=False,
+                target=131072, state=None, hold_last=False, cuts=None, y_skip=0, chain_slots=64, generous=True, dc_rounds=-1, fsm_lanes=False, dc_two_levels=False,
                 fused=False):
     """batch_process() with the long-stream front end (rfid_ls2.hpp) in place of the sequential gate scan.
     -> dict(windows, results, scores, stats, ctl, ok[, consumed])"""
@@ -94,6 +93,7 @@ def ls2_process(raw: np.ndarray, lens=None, fixed_q=0, max_num_queries=1000, num
     if lens is not None:
         lens_arr = np.ascontiguousarray(lens, dtype=np.int64)
     lib().emu_ls2_fsm_lanes_min(0 if fsm_lanes else 1 << 30)
+    lib().emu_ls2_dcb_top_min(0 if dc_two_levels else 64)   # (the dc_est chain's second level, as on traces of more than 4 096 idle-grid slots)
     lib().emu_ls2_chain_slots(int(chain_slots))   # (several workgroups per trace in the chain launches, as on long traces)
     nw = lib().emu_ls2_ctl_words()
     ctl = np.zeros(nw, dtype=np.int32)
@@ -109,7 +109,7 @@ def ls2_process(raw: np.ndarray, lens=None, fixed_q=0, max_num_queries=1000, num
         C.c_void_p(ctl.ctypes.data), nw,
         C.c_void_p(state.ctypes.data) if state is not None else None, 1 if hold_last else 0, C.c_void_p(consumed.ctypes.data),
         C.c_void_p(pcs.ctypes.data), len(pcs) - 1,
-        C.c_void_p(cuts_arr.ctypes.data) if cuts_arr is not None else None, 0 if cuts_arr is None else len(cuts_arr), int(y_skip), 1 if generous else 0, int(dc_fine),
+        C.c_void_p(cuts_arr.ctypes.data) if cuts_arr is not None else None, 0 if cuts_arr is None else len(cuts_arr), int(y_skip), 1 if generous else 0, int(dc_rounds),
         1 if fused else 0)
     assert ok >= 0
     k = n.value

@@ -206,7 +206,7 @@ int emu_ls2_process(const float *raw, int B, long stride, long n_raw, const int6
                     rfid_decode_result *results, rfid_scores *scores, long cap, long *n_windows,
                     rfid_stream_stats *stats, int min_piece, int target, int *ctl_out, int ctl_cap,
                     void *state_blob, int hold_last, int *consumed_out, int *pieces_out, int pieces_cap,
-                    const int *cuts, int n_cuts, int y_skip, int generous, int dc_fine, int fused) {
+                    const int *cuts, int n_cuts, int y_skip, int generous, int dc_rounds, int fused) {
   const long n_dec_all = n_raw / DECIM;
   const long n_dec = n_dec_all - y_skip;   // (y_skip: leading outputs that only exist to give the filter its history)
   long y_stride = (n_dec_all + 1) & ~1L;
@@ -247,7 +247,7 @@ int emu_ls2_process(const float *raw, int B, long stride, long n_raw, const int6
   memset(&ctl_host, 0, sizeof(ctl_host));
   int ok = 0;
   if (geo.P > 0) {
-    const Ls2Layout L = ls2_layout(geo, B, y_stride);
+    const Ls2Layout L = ls2_layout(geo, B, y_stride, wmax);
     ws.assign(L.total + 256, 0);
     char *base = ws.data() + (256 - ((uintptr_t)ws.data() & 255));
     Ls2Args a;
@@ -267,7 +267,7 @@ int emu_ls2_process(const float *raw, int B, long stride, long n_raw, const int6
         if (J >= 1 && J < geo.max_bc && cuts[k] - J * geo.Pc < geo.Pc / 2) a.cut[J] = cuts[k];
       }
     }
-    ls2_enqueue(a, cuts == nullptr, nullptr, generous != 0, dc_fine);
+    ls2_enqueue(a, cuts == nullptr, nullptr, generous != 0, dc_rounds);
     ctl_host = *a.ctl;
     ok = a.ctl->ok;
     if (consumed_out) consumed_out[0] = a.consumed[0];
@@ -280,10 +280,9 @@ int emu_ls2_process(const float *raw, int B, long stride, long n_raw, const int6
         float f = ls2_from_ord(a.aT[i]); memcpy(&o[3], &f, 4);
         if (fused) { o[4] = o[5] = 0; o[6] = -1; o[7] = i; continue; }   // (the avg_ampl pieces are not the units' pieces there)
         const int h = a.fsm[i].unit;
-        int hd = i;   // the dc_est piece of the last slot up to here that has one
-        while (hd != h && a.dend[hd] <= 0) hd = a.prevv[hd];
-        f = ls2_from_ord(a.dT[2 * hd]); memcpy(&o[4], &f, 4);
-        f = ls2_from_ord(a.dT[2 * hd + 1]); memcpy(&o[5], &f, 4);
+        const int tu = (h / geo.max_b) * geo.max_bc + (h % geo.max_b) / LS2_FINE;   // the unit's idle-grid slot: its dc_est start
+        f = ls2_from_ord(a.dT[2 * tu]); memcpy(&o[4], &f, 4);
+        f = ls2_from_ord(a.dT[2 * tu + 1]); memcpy(&o[5], &f, 4);
         o[6] = h; o[7] = i;
       }
       if (k < pieces_cap) pieces_out[8 * k] = -1;
@@ -338,6 +337,7 @@ int emu_ls2_process(const float *raw, int B, long stride, long n_raw, const int6
 int emu_ls2_ctl_words(void) { return (int)(sizeof(Ls2Ctl) / 4); }
 // slots per workgroup of the chain launches (the library: 4096): small values make the emulated traces span several workgroups
 void emu_ls2_chain_slots(int n) { ls2_chain_slots() = n; }
+void emu_ls2_dcb_top_min(int n) { ls2_dcb_top_min() = n; }
 // from how many possible heads on the state machine takes its one-lane-per-unit form (the library: 8192)
 void emu_ls2_fsm_lanes_min(int n) { ls2_fsm_lanes_min() = n; }
 

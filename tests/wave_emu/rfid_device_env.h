@@ -219,6 +219,10 @@ static inline void lds_load_desc(const int *p, int &flags, int &nvalid, uint64_t
   m0 = lds_load64((const uint64_t *)(p + 2)); m1 = lds_load64((const uint64_t *)(p + 4));
   info = lds_load(p + 6);
 }
+static inline void pk_add(float2 &acc, const float2 q) {
+  volatile float x = acc.x + q.x, y = acc.y + q.y;   // (two binary32 additions, each rounded by itself)
+  acc.x = x; acc.y = y;
+}
 static inline void set_priority_high() {}
 template <int P> static inline void set_priority() {}
 static inline void backoff() { emu::yield(); }
