@@ -160,18 +160,23 @@ def workload_single_trace(torch, rfid, synth, args, device, rank, fixed_q, n_rou
 
     def check(st):
         # every single-responder slot's EPC must be CRC-verified; collided / empty slots decode noise and pass the
-        # 16-bit CRC by chance with probability 2^-16 each (a handful among 10^5 such slots)
-        extra = int(st[0]["n_epc_correct"]) - n_valid
+        # 16-bit CRC by chance with probability 2^-16 each (a handful among 10^5 such slots).  At SURVEY 8(d)'s stress noise
+        # levels the weakest tag's frames fail now and then in the reference's decoder too (sigma = 0.06: 18 of 50 887 in
+        # configs[2], the oracle's count): a few per mille may miss there; tests/test_gpu_configs.py compares every window with the oracle
         reads = st[0]["tag_reads"].astype(np.int64)
-        ok = bool(st[0]["n_windows"] == 2 * n_slots and 0 <= extra <= 12
-                  and (reads >= hist).all() and int((reads - hist).sum()) == extra
+        missed = int(np.maximum(hist - reads, 0).sum())
+        extra = int(np.maximum(reads - hist, 0).sum())
+        allow = int(n_valid * (0.003 if args.sigma >= 0.05 else (0.0005 if args.sigma >= 0.02 else 0.0)))
+        ok = bool(st[0]["n_windows"] == 2 * n_slots and 0 <= extra <= 12 and missed <= allow
+                  and int(st[0]["n_epc_correct"]) == n_valid - missed + extra
                   and st[0]["n_queries_sent"] == n_slots + 1
                   and st[0]["cur_inventory_round"] == n_slots // (1 << fixed_q) + 1)
-        return ok, ("ok: %d slots -> %d RN16 + %d EPC windows, all %d single-responder EPCs CRC-verified with the slot "
+        return ok, ("ok: %d slots -> %d RN16 + %d EPC windows, %s single-responder EPCs CRC-verified with the slot "
                     "table's tag ids (+%d chance CRC passes among the %d collided/empty slots)"
-                    % (n_slots, n_slots, n_slots, n_valid, extra, n_slots - n_valid)
+                    % (n_slots, n_slots, n_slots, ("all %d" % n_valid) if missed == 0 else ("%d of %d (sigma=%g: %d lost to noise, <= %d allowed)" % (n_valid - missed, n_valid, args.sigma, missed, allow)),
+                       extra, n_slots - n_valid)
                     if ok else "FAILED: windows %d (want %d), EPC ok %d (want >= %d)"
-                    % (int(st[0]["n_windows"]), 2 * n_slots, int(st[0]["n_epc_correct"]), n_valid))
+                    % (int(st[0]["n_windows"]), 2 * n_slots, int(st[0]["n_epc_correct"]), n_valid - allow))
 
     def sample():
         n = min(L, 24_000_000)     # the first ~1 750 slots of the trace

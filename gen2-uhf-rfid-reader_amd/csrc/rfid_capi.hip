@@ -64,7 +64,7 @@ struct RfidKnobs {
   int front_unfused = 0;   // RFID_FRONT_UNFUSED     1: many traces through the stage kernels instead of front_end_fused_kernel
   int front_chunks = 1;    // RFID_FRONT_CHUNKS      2..16: the time-chunked stage kernels on two streams (round 1's overlap)
   int fsm_lanes_min = -1;  // RFID_LS2_FSM_LANES_MIN from how many possible units on the state machine runs one lane per unit (-1: 8192)
-  int dc_rounds = -1;      // RFID_LS2_DC_ROUNDS     0..64: dc_est rounds a long-stream pass enqueues (-1: by its size / what the passes before needed)
+  int dc_rounds = -1;      // RFID_LS2_DC_ROUNDS     0..64: dc_est rounds a long-stream pass enqueues behind the first (-1: 3; what they leave, the finishing walk takes)
   // ---- experiment knobs of round 4's list (RFID_LS_FUSED=0), kept for its A/B tables ----
   int la_upload_kernel = 1;  // RFID_LA_UPLOAD_KERNEL  look-ahead: 1 a call's samples are fetched from page-locked memory by a launch, 0 by a transfer
   int front_lds_kb = -1;   // RFID_LS_FRONT_LDS_KB   0..64: extra LDS per workgroup of the long-stream first pass (caps its waves per CU); -1: 10 for long traces
@@ -101,8 +101,6 @@ struct rfid_ctx {
   int ls2_P = 0;                  // its nominal piece length
   int ls2_rounds[3] = {0, 0, 0};  // re-run rounds its launch list held per stage (avg_ampl, state machine, dc_est)
   bool ls2_generous = false;      // a pass ran out of rounds once: the launch lists hold the full number of rounds from then on
-  int ls2_dc_need = -1;           // dc_est rounds the next pass enqueues (-1: by its size): what the passes before needed + 2; twice that
-                                  // where the finishing walk had to take units (sums that hover at a binade edge: SURVEY 8(d)'s noisy traces)
   int ls_mode = 1;                // 0 never, 1 automatic, 2 whenever a trace can be cut
   double ls_fixed_ms = 0.45, ls_ns_per_sample = 0.03, seq_ns_per_sample = 10.2;   // cost model of the automatic choice (ls_calibrate)
   bool ls_calibrated = false;     // the three numbers were measured on this device (or that was tried, or is not wanted)
@@ -535,12 +533,6 @@ void ls_note_last_pass(rfid_ctx *c) {
   if (hipStreamQuery(c->stream) == hipSuccess) {
     const Ls2Ctl &k = *c->ls2_host;
     if (!c->ls2_generous && k.fail == 0 && k.ok == 0 && k.n_pieces > 0) c->ls2_generous = true;
-    if (k.fail == 0 && k.n_pieces > 0 && k.dc_rounds > 0) {
-      // dc_est: as many rounds as that pass used, + 2; where its rounds ran out and the finishing walk took units, twice its rounds
-      int want = (k.dc_finished > 0) ? 2 * (c->ls2_rounds[2] + 1) : (k.dc_rounds + 1);
-      if (want > LS2_DC_MAXR) want = LS2_DC_MAXR;
-      if (want > c->ls2_dc_need) c->ls2_dc_need = want;
-    }
   }
   (void)hipGetLastError();
 }
@@ -611,7 +603,7 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
   };
   c->ls2_mark_failed = false;
   c->ls2_gap_marks = opt.marks;
-  ls2_enqueue(a, true, c->ls2_rounds, c->ls2_generous, (c->knobs.dc_rounds >= 0) ? c->knobs.dc_rounds : c->ls2_dc_need, (opt.marks || ahead) ? +mark : nullptr, c);
+  ls2_enqueue(a, true, c->ls2_rounds, c->ls2_generous, c->knobs.dc_rounds, (opt.marks || ahead) ? +mark : nullptr, c);
   ls2_stream = c->stream;
   HIPCHK(c, hipGetLastError());
   if (c->ls2_mark_failed) return fail(c, RFID_ERR_HIP, "long-stream front end: stream hand-over");

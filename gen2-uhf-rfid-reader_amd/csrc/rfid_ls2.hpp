@@ -48,7 +48,7 @@ static_assert(LS2_WBUCKET <= RN16_WIN + T1_SAMPLES, "one window per bucket");
 constexpr int LS2_AVG_ROUNDS = 11;    // re-run rounds after the first pass, per recurrence (a round without work costs two empty launches; configs[2]
                                       // settles in 5 rounds on y-given pieces and in 8 on the fused first pass's, profiles/r05/ls2_rounds.txt)
 constexpr int LS2_FSM_ROUNDS = 3;
-constexpr int LS2_DC_ROUNDS = 7;
+constexpr int LS2_DC_ROUNDS = 3;      // dc_est rounds behind the first: away from binade edges the second settles everything; what hovers at an edge is left to the finishing walk
 constexpr int LS2_MAXR = 12;
 constexpr int LS2_WIDE_BELOW = 64;    // a piece whose margin is below this is re-run from six neighbouring start values at once
 constexpr int LS2_WIDE_LO = -2, LS2_WIDE_HI = 3;
@@ -131,14 +131,16 @@ struct Ls2Args {
   int *dT;                      // [NH][2] the unit's start value (re, im; ord images) from the latest chain: true when settled, else predicted
   int *dcen;                    // [NH][2] centre of the unit's latest run: candidate j started at centre + j - 32 ulps
   int *dtab;                    // [NH][2][64] dc_est behind the unit for each candidate
-  int *dstat;                   // [NH] bit 0 / 1: re / im settled, bit 2: the slot holds a unit (zeroed before a pass)
+  int *dstat;                   // [NH] bit 0 / 1: re / im settled, bit 2: the slot holds a unit, bit 3: its latest run does not cover the start predicted for it (zeroed before a pass)
+  int *dfront;                  // [n_streams] the trace's first idle-grid slot whose unit is not settled (after a chain; INT_MAX: none)
+  int *dmar;                    // [NH][2] how far from its centre a start may lie for the unit's end to be a plain shift of candidate 32's / 33's (ulps; 0: nowhere)
   int *dwbase;                  // [NH] the unit's first place in dcand
   float2 *dcand; int dcand_cap; // [dcand_cap][64] dc_est at a gate opening for each candidate
   // the chain's levels: nodes of 64 children (level 1: blocks of units, level 2: groups of blocks); per node the centre of its
   // first child, its table on that window, which entries are exact, whether it holds anything, and its entry value from the walk
   int dcb_n1, dcb_n2, dcb_top;  // nodes per trace of level 1 / 2; the level the walk runs over (2 when a trace has more than 64 blocks)
-  int *n1cen, *n1tab, *n1val, *n1ent; uint64_t *n1exm;
-  int *n2cen, *n2tab, *n2val, *n2ent; uint64_t *n2exm;
+  int *n1cen, *n1tab, *n1val, *n1ent, *n1mar; uint64_t *n1exm;
+  int *n2cen, *n2tab, *n2val, *n2ent, *n2mar; uint64_t *n2exm;
   int *seq0;                    // [NS][2] complete windows of the trace before the piece: all, EPC
   int *flat_base;               // [n_streams][2] the trace's first place in the decoder's RN16 / EPC list
   rfid_window *wtab; int wmax; int *wcount;
@@ -1583,6 +1585,8 @@ RFID_KERNEL(256) void ls2_fsm_chain_kernel(Ls2Args a) {
 // frontier, each run from its exact start: the partial fallback (settled units keep their results; the pass costs its clean
 // time plus the sequential time of the unsettled units, never the whole sequential gate scan).
 constexpr int LS2_DCB_HALF = 32;      // candidate j (= lane) of a unit starts at its centre + j - 32 ulps
+constexpr int LS2_DCB_AHEAD = 4096;    // re-run rounds look this many idle-grid slots behind a trace's frontier
+constexpr int LS2_DCB_SLACK = 48;     // taken off a run's margin: the estimate of the partial sums is off by < 33 ulps, + the proof's own 4, + spare
 
 RFID_DEVICE bool ls2_fsm_settled(const Ls2Args &a, const Ls2Ctl *ctl) {
   return wv::uniform(ctl->fail) == 0 && wv::uniform(ctl->avg_count[a.avg_rounds]) == 0 && wv::uniform(ctl->fsm_count[a.fsm_rounds]) == 0;
@@ -1628,6 +1632,16 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
   }
   wv::wave_sync();
   float2 acc = make_float2(ls2_from_ord(cre + lane - LS2_DCB_HALF), ls2_from_ord(cim + lane - LS2_DCB_HALF));
+  // The margin of candidate 32's run (rounds 2 - 5 proved every shifted start with it; here it EXTENDS the table): while every
+  // partial sum of the run stays at least m ulps of the start's binade away from every power of two (and in no binade above the
+  // start's), a start D ulps off, |D| + slack <= m, D even, gives the same trajectory shifted by D -- rfid_ls2.hpp's header.  Odd D:
+  // the same from candidate 33.  So outside the 64-candidate window the unit's end is still KNOWN wherever the margin reaches --
+  // away from binade edges that is thousands of ulps, and the first round settles nearly everything; where the sums hover at an
+  // edge the margin is nothing and only the window counts.  The partial sums are looked at lane = sample: candidate 32's value
+  // before the step + a prefix sum of the step's increments -- an estimate of the in-order sums, off by at most the step's
+  // accumulated rounding (LS2_DCB_SLACK covers it).
+  const uint32_t sbr = wv::f2u(ls2_from_ord(cre)), sbi = wv::f2u(ls2_from_ord(cim));
+  int mre = ls2_margin(ls2_from_ord(cre), sbr), mim = ls2_margin(ls2_from_ord(cim), sbi);
   Ls2Win *wb = a.wb + (int64_t)s * a.wb_stride;
   // where the unit's gate openings go in a.dcand: reserved once (complete windows + the one a trace may end in)
   int wslot = 0;
@@ -1718,6 +1732,12 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
                        }
                      },
                      tre, tim);
+        {
+          const float c32r = wv::readlane(acc.x, LS2_DCB_HALF), c32i = wv::readlane(acc.y, LS2_DCB_HALF);
+          const int m1 = ls2_margin(c32r + wv::scan_add_f(tre), sbr), m2 = ls2_margin(c32i + wv::scan_add_f(tim), sbi);
+          mre = (m1 < mre) ? m1 : mre;
+          mim = (m2 < mim) ? m2 : mim;
+        }
         // the step's 64 increments in sample order (samples that are not closed: +0), added in that order by every lane to
         // its own candidate
         wv::wave_sync();   // (the reads of the step before are over)
@@ -1765,6 +1785,13 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
       if (kb + u < nsteps) step(kb + u, buf[u], false);
   }
   end_re = ls2_ord(acc.x); end_im = ls2_ord(acc.y);
+  {
+    mre = ls2_wave_min(mre) - LS2_DCB_SLACK; mim = ls2_wave_min(mim) - LS2_DCB_SLACK;
+    // (the chain works on the integer image of binary32: a shift by D at the start is a shift by D at the end only if both lie in one binade)
+    if (((wv::f2u(wv::readlane(acc.x, LS2_DCB_HALF)) ^ sbr) & 0xff800000u) != 0u || mre < 0) mre = 0;
+    if (((wv::f2u(wv::readlane(acc.y, LS2_DCB_HALF)) ^ sbi) & 0xff800000u) != 0u || mim < 0) mim = 0;
+    if (lane == 0) { a.dmar[2 * t] = mre; a.dmar[2 * t + 1] = mim; }
+  }
   a.dtab[(int64_t)(2 * t) * 64 + lane] = end_re;
   a.dtab[(int64_t)(2 * t + 1) * 64 + lane] = end_im;
   if (lane == 0) { a.dcen[2 * t] = cre; a.dcen[2 * t + 1] = cim; }
@@ -1790,8 +1817,11 @@ RFID_KERNEL(64) void ls2_dcb_run_kernel(Ls2Args a) {
     if (r == 0) {
       if (wv::uniform(a.piece[i].len) <= 0 || wv::uniform(a.fsm[i].head) == 0 || wv::uniform(a.piece[i].pos0) >= wv::uniform(a.fsm[i].u1)) continue;
     } else {
+      // again: the units whose latest run does not cover the start the chain predicts for them -- within LS2_DCB_AHEAD slots of
+      // the trace's frontier (where sums hover at a binade edge the predictions far behind the frontier are not worth a run yet)
       const int st = wv::uniform(a.dstat[t]);
-      if (!(st & 4) || (st & 3) == 3) continue;
+      if (!(st & 4) || (st & 3) == 3 || !(st & 8)) continue;
+      if (t > wv::uniform(a.dfront[t / a.max_bc]) + LS2_DCB_AHEAD) continue;
     }
     int er, ei;
     ls2_dcb_unit(a, t, r > 0, (r > 0) ? wv::uniform(a.dT[2 * t]) : 0, (r > 0) ? wv::uniform(a.dT[2 * t + 1]) : 0, r == 0, lane, lds_dc, lds_tmp, lds_q, er, ei);
@@ -1805,20 +1835,26 @@ RFID_KERNEL(64) void ls2_dcb_run_kernel(Ls2Args a) {
 // v -> the end of a node (unit, block, group) whose table lies across the lanes (lane j: the end for the start cen + j - 32):
 // inside the window a lookup; outside, the nearest candidate's end shifted along (a guess: ex goes false).  exm: the
 // candidates whose ends are themselves exact (a block's table entry is exact only if every lookup inside the block hit).
-RFID_DEVICE void ls2_dcb_apply(int &v, bool &ex, const int tab, const uint64_t exm, const int cen) {
-  const int o = (int)((uint32_t)v - (uint32_t)cen + (uint32_t)LS2_DCB_HALF);
-  const int oc = (o < 0) ? 0 : ((o > 63) ? 63 : o);
+RFID_DEVICE void ls2_dcb_apply(int &v, bool &ex, const int tab, const uint64_t exm, const int cen, const int mar) {
+  const int D = (int)((uint32_t)v - (uint32_t)cen);
+  const int o = D + LS2_DCB_HALF;
+  const int aD = (D < 0) ? -D : D;
+  const bool inw = o >= 0 && o < 64;
+  // outside the window but inside the margin: candidate 32's end (33's for an odd distance) shifted along -- exact
+  const bool far = !inw && D != (int)0x80000000 && aD <= mar;
+  const int par = D & 1;
+  const int oc = inw ? o : (far ? (LS2_DCB_HALF + par) : ((o < 0) ? 0 : 63));
   const int e = wv::shfl(tab, oc);
-  ex = ex && (o == oc) && (((exm >> oc) & 1ull) != 0ull);
+  ex = ex && (inw || far) && (((exm >> oc) & 1ull) != 0ull);
   v = (int)((uint32_t)e + (uint32_t)(o - oc));
 }
 // what a level's nodes are made of: level 1 = blocks of 64 units, level 2 = groups of 64 blocks
-struct Ls2DcbKids { const int *cen; const int *tab; const uint64_t *exm; const int *val; int per_trace; };
+struct Ls2DcbKids { const int *cen; const int *tab; const uint64_t *exm; const int *val; const int *mar; int per_trace; };
 template <int L>
 RFID_DEVICE Ls2DcbKids ls2_dcb_kids(const Ls2Args &a) {
   Ls2DcbKids k;
-  if (L == 1) { k.cen = a.dcen; k.tab = a.dtab; k.exm = nullptr; k.val = nullptr; k.per_trace = a.max_bc; }
-  else { k.cen = a.n1cen; k.tab = a.n1tab; k.exm = a.n1exm; k.val = a.n1val; k.per_trace = a.dcb_n1; }
+  if (L == 1) { k.cen = a.dcen; k.tab = a.dtab; k.exm = nullptr; k.val = nullptr; k.mar = a.dmar; k.per_trace = a.max_bc; }
+  else { k.cen = a.n1cen; k.tab = a.n1tab; k.exm = a.n1exm; k.val = a.n1val; k.mar = a.n1mar; k.per_trace = a.dcb_n1; }
   return k;
 }
 // up: the 64 children of node `node` of level L composed in order -> the node's table (on the window of its first child)
@@ -1827,14 +1863,14 @@ RFID_DEVICE void ls2_dcb_up(const Ls2Args &a, const int node, const int lane) {
   const Ls2DcbKids kd = ls2_dcb_kids<L>(a);
   const int nper = (L == 1) ? a.dcb_n1 : a.dcb_n2;
   int *ocen = (L == 1) ? a.n1cen : a.n2cen; int *otab = (L == 1) ? a.n1tab : a.n2tab;
-  uint64_t *oexm = (L == 1) ? a.n1exm : a.n2exm; int *oval = (L == 1) ? a.n1val : a.n2val;
+  uint64_t *oexm = (L == 1) ? a.n1exm : a.n2exm; int *oval = (L == 1) ? a.n1val : a.n2val; int *omar = (L == 1) ? a.n1mar : a.n2mar;
   const int s = node / nper, k = node - s * nper;
   const int ch0 = s * kd.per_trace + 64 * k;
   const bool in = 64 * k + lane < kd.per_trace;
-  int valid = 0, cre = 0, cim = 0;
+  int valid = 0, cre = 0, cim = 0, mre = 0, mim = 0;
   if (in) {
     valid = (L == 1) ? ((a.dstat[ch0 + lane] >> 2) & 1) : kd.val[ch0 + lane];
-    if (valid) { cre = kd.cen[2 * (ch0 + lane)]; cim = kd.cen[2 * (ch0 + lane) + 1]; }
+    if (valid) { cre = kd.cen[2 * (ch0 + lane)]; cim = kd.cen[2 * (ch0 + lane) + 1]; mre = kd.mar[2 * (ch0 + lane)]; mim = kd.mar[2 * (ch0 + lane) + 1]; }
   }
   const uint64_t m = wv::ballot(valid != 0);
   if (m == 0ull) { if (lane == 0) oval[node] = 0; return; }
@@ -1842,9 +1878,15 @@ RFID_DEVICE void ls2_dcb_up(const Ls2Args &a, const int node, const int lane) {
   const int bre = wv::readlane(cre, l), bim = wv::readlane(cim, l);
   int vre = bre + lane - LS2_DCB_HALF, vim = bim + lane - LS2_DCB_HALF;
   bool exr = true, exi = true;
+  int nmr = 0x3fffffff, nmi = 0x3fffffff;   // the node's own margin: how far from ITS centre an entry value may lie (see below)
   auto fetch = [&](const int c, int &tr, int &ti, uint64_t &er, uint64_t &ei) {
     tr = kd.tab[(int64_t)(2 * (ch0 + c)) * 64 + lane]; ti = kd.tab[(int64_t)(2 * (ch0 + c) + 1) * 64 + lane];
     er = kd.exm ? wv::uniform(kd.exm[2 * (ch0 + c)]) : ~0ull; ei = kd.exm ? wv::uniform(kd.exm[2 * (ch0 + c) + 1]) : ~0ull;
+  };
+  auto dev = [&](const int v, const int c) -> int {   // how far candidates 32 / 33 of the node are from the child's centre when they reach it
+    const int d0 = wv::readlane(v, LS2_DCB_HALF) - c, d1 = wv::readlane(v, LS2_DCB_HALF + 1) - c;
+    const int a0 = (d0 < 0) ? -d0 : d0, a1 = (d1 < 0) ? -d1 : d1;
+    return (a0 > a1) ? a0 : a1;
   };
   int tr, ti; uint64_t er, ei;
   fetch(l, tr, ti, er, ei);
@@ -1853,15 +1895,26 @@ RFID_DEVICE void ls2_dcb_up(const Ls2Args &a, const int node, const int lane) {
     const int ln = rest ? wv::ffs64(rest) : -1;
     int ntr = 0, nti = 0; uint64_t ner = 0, nei = 0;
     if (ln >= 0) fetch(ln, ntr, nti, ner, nei);   // (one child ahead: the loads do not depend on the walk)
-    ls2_dcb_apply(vre, exr, tr, er, wv::readlane(cre, l));
-    ls2_dcb_apply(vim, exi, ti, ei, wv::readlane(cim, l));
+    const int c_re = wv::readlane(cre, l), c_im = wv::readlane(cim, l), m_re = wv::readlane(mre, l), m_im = wv::readlane(mim, l);
+    // an entry value D off the node's centre reaches this child D + dev off the child's: a plain shift all the way while that
+    // stays inside every child's margin
+    { const int q = m_re - dev(vre, c_re) - 1; nmr = (q < nmr) ? q : nmr; }
+    { const int q = m_im - dev(vim, c_im) - 1; nmi = (q < nmi) ? q : nmi; }
+    ls2_dcb_apply(vre, exr, tr, er, c_re, m_re);
+    ls2_dcb_apply(vim, exi, ti, ei, c_im, m_im);
     if (ln < 0) break;
     l = ln; tr = ntr; ti = nti; er = ner; ei = nei;
   }
   otab[(int64_t)(2 * node) * 64 + lane] = vre;
   otab[(int64_t)(2 * node + 1) * 64 + lane] = vim;
   const uint64_t mr = wv::ballot(exr), mi = wv::ballot(exi);
-  if (lane == 0) { ocen[2 * node] = bre; ocen[2 * node + 1] = bim; oexm[2 * node] = mr; oexm[2 * node + 1] = mi; oval[node] = 1; }
+  const uint64_t both = 3ull << LS2_DCB_HALF;   // (the shift goes out from candidates 32 / 33: their own ends must be exact)
+  if ((mr & both) != both || nmr < 0) nmr = 0;
+  if ((mi & both) != both || nmi < 0) nmi = 0;
+  if (lane == 0) {
+    ocen[2 * node] = bre; ocen[2 * node + 1] = bim; oexm[2 * node] = mr; oexm[2 * node + 1] = mi; oval[node] = 1;
+    omar[2 * node] = nmr; omar[2 * node + 1] = nmi;
+  }
 }
 RFID_KERNEL(64) void ls2_dcb_up1_kernel(Ls2Args a) {
   ls2_tail_prio();
@@ -1893,11 +1946,12 @@ RFID_KERNEL(64) void ls2_dcb_top_kernel(Ls2Args a) {
   const int s = (int)blockIdx.x;
   const int t0 = s * a.max_bc;
   if (s == 0 && lane == 0) ctl->dc_rounds = r + 1;
+  if (lane == 0) a.dfront[s] = 0x7fffffff;
   if (!(wv::uniform(a.dstat[t0]) & 4)) return;   // an empty trace
   const bool two = a.dcb_top == 2;
   const int nper = two ? a.dcb_n2 : a.dcb_n1;
   const int *cen = two ? a.n2cen : a.n1cen; const int *tab = two ? a.n2tab : a.n1tab;
-  const uint64_t *exm = two ? a.n2exm : a.n1exm; const int *val = two ? a.n2val : a.n1val;
+  const uint64_t *exm = two ? a.n2exm : a.n1exm; const int *val = two ? a.n2val : a.n1val; const int *mar = two ? a.n2mar : a.n1mar;
   int *ent = two ? a.n2ent : a.n1ent;
   int Tre = wv::uniform(a.dcen[2 * t0]), Tim = wv::uniform(a.dcen[2 * t0 + 1]);
   bool exr = true, exi = true;
@@ -1909,8 +1963,8 @@ RFID_KERNEL(64) void ls2_dcb_top_kernel(Ls2Args a) {
     if (k + 1 < nper) { ntr = tab[(int64_t)(2 * (node + 1)) * 64 + lane]; nti = tab[(int64_t)(2 * (node + 1) + 1) * 64 + lane]; }
     if (wv::uniform(val[node]) != 0) {
       if (lane == 0) { ent[4 * node] = Tre; ent[4 * node + 1] = Tim; ent[4 * node + 2] = exr ? 1 : 0; ent[4 * node + 3] = exi ? 1 : 0; }
-      ls2_dcb_apply(Tre, exr, tr, wv::uniform(exm[2 * node]), wv::uniform(cen[2 * node]));
-      ls2_dcb_apply(Tim, exi, ti, wv::uniform(exm[2 * node + 1]), wv::uniform(cen[2 * node + 1]));
+      ls2_dcb_apply(Tre, exr, tr, wv::uniform(exm[2 * node]), wv::uniform(cen[2 * node]), wv::uniform(mar[2 * node]));
+      ls2_dcb_apply(Tim, exi, ti, wv::uniform(exm[2 * node + 1]), wv::uniform(cen[2 * node + 1]), wv::uniform(mar[2 * node + 1]));
     }
     tr = ntr; ti = nti;
   }
@@ -1918,7 +1972,7 @@ RFID_KERNEL(64) void ls2_dcb_top_kernel(Ls2Args a) {
 // down: from a node's entry value to its children's.  Level 1: the children are the units -- their start values (a.dT),
 // which of them are settled, how many are not (Ls2Ctl::dc_count[round]).
 template <int L>
-RFID_DEVICE void ls2_dcb_down(const Ls2Args &a, const int node, const int lane, int &n_uns, int &n_units) {
+RFID_DEVICE void ls2_dcb_down(const Ls2Args &a, const int node, const int lane, int &n_uns, int &n_units, int &first_uns) {
   const Ls2DcbKids kd = ls2_dcb_kids<L>(a);
   const int nper = (L == 1) ? a.dcb_n1 : a.dcb_n2;
   const int *nval = (L == 1) ? a.n1val : a.n2val; const int *nent = (L == 1) ? a.n1ent : a.n2ent;
@@ -1926,10 +1980,10 @@ RFID_DEVICE void ls2_dcb_down(const Ls2Args &a, const int node, const int lane, 
   const int s = node / nper, k = node - s * nper;
   const int ch0 = s * kd.per_trace + 64 * k;
   const bool in = 64 * k + lane < kd.per_trace;
-  int valid = 0, cre = 0, cim = 0;
+  int valid = 0, cre = 0, cim = 0, mre = 0, mim = 0;
   if (in) {
     valid = (L == 1) ? ((a.dstat[ch0 + lane] >> 2) & 1) : kd.val[ch0 + lane];
-    if (valid) { cre = kd.cen[2 * (ch0 + lane)]; cim = kd.cen[2 * (ch0 + lane) + 1]; }
+    if (valid) { cre = kd.cen[2 * (ch0 + lane)]; cim = kd.cen[2 * (ch0 + lane) + 1]; mre = kd.mar[2 * (ch0 + lane)]; mim = kd.mar[2 * (ch0 + lane) + 1]; }
   }
   const uint64_t m = wv::ballot(valid != 0);
   if (m == 0ull) return;
@@ -1947,19 +2001,25 @@ RFID_DEVICE void ls2_dcb_down(const Ls2Args &a, const int node, const int lane, 
     const int ln = rest ? wv::ffs64(rest) : -1;
     int ntr = 0, nti = 0; uint64_t ner = 0, nei = 0;
     if (ln >= 0) fetch(ln, ntr, nti, ner, nei);
-    const int c_re = wv::readlane(cre, l), c_im = wv::readlane(cim, l);
+    const int c_re = wv::readlane(cre, l), c_im = wv::readlane(cim, l), m_re = wv::readlane(mre, l), m_im = wv::readlane(mim, l);
     const int c = ch0 + l;
     if (L == 1) {
-      const int o_re = (int)((uint32_t)Tre - (uint32_t)c_re + (uint32_t)LS2_DCB_HALF), o_im = (int)((uint32_t)Tim - (uint32_t)c_im + (uint32_t)LS2_DCB_HALF);
-      const int bits = ((exr && o_re >= 0 && o_re < 64) ? 1 : 0) | ((exi && o_im >= 0 && o_im < 64) ? 2 : 0);
-      if (lane == 0) { a.dT[2 * c] = Tre; a.dT[2 * c + 1] = Tim; a.dstat[c] = 4 | bits; }
+      // settled: everything before is, and the unit's own start lies inside its window or its margin (its end, and dc_est at its
+      // gate openings, are then known: a table entry, or candidate 32's / 33's shifted along)
+      const int D_re = (int)((uint32_t)Tre - (uint32_t)c_re), D_im = (int)((uint32_t)Tim - (uint32_t)c_im);
+      const bool k_re = (D_re >= -LS2_DCB_HALF && D_re < LS2_DCB_HALF) || (D_re != (int)0x80000000 && ((D_re < 0) ? -D_re : D_re) <= m_re);
+      const bool k_im = (D_im >= -LS2_DCB_HALF && D_im < LS2_DCB_HALF) || (D_im != (int)0x80000000 && ((D_im < 0) ? -D_im : D_im) <= m_im);
+      const int bits = ((exr && k_re) ? 1 : 0) | ((exi && k_im) ? 2 : 0);
+      // (bit 3: the unit's latest run does not cover the start predicted for it -- it is run again, centred on that; a unit whose
+      // run does cover it only waits for the units before it)
+      if (lane == 0) { a.dT[2 * c] = Tre; a.dT[2 * c + 1] = Tim; a.dstat[c] = 4 | bits | ((k_re && k_im) ? 0 : 8); }
       n_units++;
-      n_uns += (bits != 3) ? 1 : 0;
+      if (bits != 3) { if (n_uns == 0) first_uns = c; n_uns++; }
     } else {
       if (lane == 0) { int *e = a.n1ent + 4 * c; e[0] = Tre; e[1] = Tim; e[2] = exr ? 1 : 0; e[3] = exi ? 1 : 0; }
     }
-    ls2_dcb_apply(Tre, exr, tr, er, c_re);
-    ls2_dcb_apply(Tim, exi, ti, ei, c_im);
+    ls2_dcb_apply(Tre, exr, tr, er, c_re, m_re);
+    ls2_dcb_apply(Tim, exi, ti, ei, c_im, m_im);
     if (ln < 0) break;
     l = ln; tr = ntr; ti = nti; er = ner; ei = nei;
   }
@@ -1971,8 +2031,8 @@ RFID_KERNEL(64) void ls2_dcb_down2_kernel(Ls2Args a) {
   if (a.round > 0 && wv::uniform(ctl->dc_count[a.round - 1]) == 0) return;
   const int lane = wv::lane_id();
   const int N = a.n_streams * a.dcb_n2;
-  int u0 = 0, u1 = 0;
-  for (int node = (int)blockIdx.x; node < N; node += (int)gridDim.x) ls2_dcb_down<2>(a, node, lane, u0, u1);
+  int u0 = 0, u1 = 0, u2 = 0;
+  for (int node = (int)blockIdx.x; node < N; node += (int)gridDim.x) ls2_dcb_down<2>(a, node, lane, u0, u1, u2);
 }
 RFID_KERNEL(64) void ls2_dcb_down1_kernel(Ls2Args a) {
   ls2_tail_prio();
@@ -1983,47 +2043,99 @@ RFID_KERNEL(64) void ls2_dcb_down1_kernel(Ls2Args a) {
   const int lane = wv::lane_id();
   const int N = a.n_streams * a.dcb_n1;
   int n_uns = 0, n_units = 0;
-  for (int node = (int)blockIdx.x; node < N; node += (int)gridDim.x) ls2_dcb_down<1>(a, node, lane, n_uns, n_units);
+  for (int node = (int)blockIdx.x; node < N; node += (int)gridDim.x) {
+    int nu = 0, first_uns = 0;
+    ls2_dcb_down<1>(a, node, lane, nu, n_units, first_uns);
+    if (nu && lane == 0) wv::atomic_min(a.dfront + first_uns / a.max_bc, first_uns);   // the trace's frontier: its first unit that is not settled
+    n_uns += nu;
+  }
   if (lane == 0) {
     if (n_uns) wv::atomic_add(&ctl->dc_count[r], n_uns);
     if (r == 0 && n_units) { wv::atomic_add(&ctl->n_units, n_units); wv::atomic_add(&ctl->n_dc_pieces, n_units); }
   }
 }
-// The enqueued rounds are used up and units are still unsettled: one wave per trace takes them one after the other from the
-// proven value at the frontier, each from its exact start (candidate 32 of a run centred on it).  Settled units keep their
-// results; the launches behind (window sequence numbers, assembly) then find everything settled.
-RFID_KERNEL(64) void ls2_dcb_finish_kernel(Ls2Args a) {
+// The enqueued rounds are used up and units are still unsettled (sums that hover at a binade edge: what a start value does to
+// a unit's end is then no shift, the window catches the chain's prediction for a few units only, and exactness can only walk
+// along the trace).  One workgroup of sixteen waves per trace walks: per turn the sixteen idle-grid slots behind the frontier
+// are run at once -- the first from its exact start, the others centred on the last chain's prediction moved along by what the
+// frontier has turned out to be off -- then wave 0 goes through their tables from the exact value: as far as each start lies
+// inside its unit's window (or margin) the units are settled and the frontier moves on; the first miss is the next turn's first
+// unit.  At least one unit per turn, up to sixteen.  Settled units keep their results: the pass costs its clean time plus this
+// walk over the unsettled units -- the partial fallback; the launches behind (window sequence numbers, assembly) find everything
+// settled.
+constexpr int LS2_DCB_FIN_WAVES = 16;
+RFID_KERNEL(64 * LS2_DCB_FIN_WAVES) void ls2_dcb_finish_kernel(Ls2Args a) {
   ls2_tail_prio();
-  RFID_SHARED float2 lds_dc[DC_LEN];
-  RFID_SHARED float2 lds_tmp[64];
-  RFID_SHARED float4 lds_q4[32];
-  float2 *lds_q = reinterpret_cast<float2 *>(lds_q4);
+  RFID_SHARED float2 lds_dc[LS2_DCB_FIN_WAVES][DC_LEN];
+  RFID_SHARED float2 lds_tmp[LS2_DCB_FIN_WAVES][64];
+  RFID_SHARED float4 lds_q4[LS2_DCB_FIN_WAVES][32];
+  RFID_SHARED int sh_tab[LS2_DCB_FIN_WAVES][2][64];
+  RFID_SHARED int sh_cen[LS2_DCB_FIN_WAVES][2], sh_mar[LS2_DCB_FIN_WAVES][2], sh_on[LS2_DCB_FIN_WAVES];
+  RFID_SHARED int sh_pos, sh_T[2], sh_corr[2], sh_fixed;
   Ls2Ctl *ctl = a.ctl;
   if (!ls2_fsm_settled(a, ctl)) return;
-  if (wv::uniform(ctl->dc_count[a.dc_rounds]) == 0) return;
-  const int lane = wv::lane_id();
+  if (ctl->dc_count[a.dc_rounds] == 0) return;
+  const int tid = (int)threadIdx.x, lane = wv::lane_id(), wave = wv::uniform(tid >> 6);
   const int s = (int)blockIdx.x;
   const int t0 = s * a.max_bc;
-  int first = -1;
-  for (int k0 = 0; k0 < a.max_bc && first < 0; k0 += 64) {
-    const int k = k0 + lane;
-    const int st = (k < a.max_bc) ? a.dstat[t0 + k] : 0;
-    const uint64_t m = wv::ballot((st & 4) != 0 && (st & 3) != 3);
-    if (m) first = k0 + wv::ffs64(m);
+  if (wave == 0) {   // the frontier: the trace's first unit that is not settled (its start value from the last chain is exact)
+    int first = -1;
+    for (int k0 = 0; k0 < a.max_bc && first < 0; k0 += 64) {
+      const int k = k0 + lane;
+      const int st = (k < a.max_bc) ? a.dstat[t0 + k] : 0;
+      const uint64_t m = wv::ballot((st & 4) != 0 && (st & 3) != 3);
+      if (m) first = k0 + wv::ffs64(m);
+    }
+    if (lane == 0) {
+      sh_pos = first; sh_fixed = 0; sh_corr[0] = 0; sh_corr[1] = 0;
+      if (first >= 0) { sh_T[0] = a.dT[2 * (t0 + first)]; sh_T[1] = a.dT[2 * (t0 + first) + 1]; }
+    }
   }
-  if (first < 0) return;
-  int Tre = wv::uniform(a.dT[2 * (t0 + first)]), Tim = wv::uniform(a.dT[2 * (t0 + first) + 1]);   // (exact: everything before is settled)
-  int fixed = 0;
-  for (int k = first; k < a.max_bc; ++k) {
+  wv::block_sync();
+  for (;;) {
+    const int pos = sh_pos;
+    if (pos < 0 || pos >= a.max_bc) break;
+    const int k = pos + wave;
     const int t = t0 + k;
-    if (!(wv::uniform(a.dstat[t]) & 4)) continue;
-    int er, ei;
-    ls2_dcb_unit(a, t, true, Tre, Tim, false, lane, lds_dc, lds_tmp, lds_q, er, ei);
-    if (lane == 0) { a.dT[2 * t] = Tre; a.dT[2 * t + 1] = Tim; a.dstat[t] = 7; }
-    Tre = wv::readlane(er, LS2_DCB_HALF); Tim = wv::readlane(ei, LS2_DCB_HALF);
-    fixed++;
+    const bool on = k < a.max_bc && (wv::uniform(a.dstat[(k < a.max_bc) ? t : t0]) & 4) != 0;
+    if (on) {
+      // wave 0's unit starts from the exact value; the others from the last chain's prediction + what the frontier was off by
+      const int cre = (wave == 0) ? sh_T[0] : (wv::uniform(a.dT[2 * t]) + sh_corr[0]);
+      const int cim = (wave == 0) ? sh_T[1] : (wv::uniform(a.dT[2 * t + 1]) + sh_corr[1]);
+      int er, ei;
+      ls2_dcb_unit(a, t, true, cre, cim, false, lane, lds_dc[wave], lds_tmp[wave], reinterpret_cast<float2 *>(lds_q4[wave]), er, ei);
+      sh_tab[wave][0][lane] = er; sh_tab[wave][1][lane] = ei;
+      if (lane == 0) { sh_cen[wave][0] = a.dcen[2 * t]; sh_cen[wave][1] = a.dcen[2 * t + 1]; sh_mar[wave][0] = a.dmar[2 * t]; sh_mar[wave][1] = a.dmar[2 * t + 1]; }
+    }
+    if (lane == 0) sh_on[wave] = on ? 1 : 0;
+    wv::block_sync();
+    if (wave == 0) {
+      int Tre = sh_T[0], Tim = sh_T[1];
+      int w = 0, fixed = 0;
+      int corr_re = sh_corr[0], corr_im = sh_corr[1];
+      for (; w < LS2_DCB_FIN_WAVES && pos + w < a.max_bc; ++w) {
+        if (!wv::uniform(sh_on[w])) continue;   // (a slot without a unit)
+        const int tw = t0 + pos + w;
+        const int c_re = wv::uniform(sh_cen[w][0]), c_im = wv::uniform(sh_cen[w][1]), m_re = wv::uniform(sh_mar[w][0]), m_im = wv::uniform(sh_mar[w][1]);
+        const int D_re = (int)((uint32_t)Tre - (uint32_t)c_re), D_im = (int)((uint32_t)Tim - (uint32_t)c_im);
+        const bool k_re = (D_re >= -LS2_DCB_HALF && D_re < LS2_DCB_HALF) || (D_re != (int)0x80000000 && ((D_re < 0) ? -D_re : D_re) <= m_re);
+        const bool k_im = (D_im >= -LS2_DCB_HALF && D_im < LS2_DCB_HALF) || (D_im != (int)0x80000000 && ((D_im < 0) ? -D_im : D_im) <= m_im);
+        if (!(k_re && k_im)) {
+          // a miss: this unit's true start is known now -- the next turn's first unit; the predictions behind move along with it
+          if (w > 0) { corr_re += (int)((uint32_t)Tre - (uint32_t)c_re); corr_im += (int)((uint32_t)Tim - (uint32_t)c_im); }
+          break;
+        }
+        if (lane == 0) { a.dT[2 * tw] = Tre; a.dT[2 * tw + 1] = Tim; a.dstat[tw] = 7; }
+        fixed++;
+        bool exr = true, exi = true;
+        ls2_dcb_apply(Tre, exr, sh_tab[w][0][lane], ~0ull, c_re, m_re);
+        ls2_dcb_apply(Tim, exi, sh_tab[w][1][lane], ~0ull, c_im, m_im);
+      }
+      if (lane == 0) { sh_pos = pos + w; sh_T[0] = Tre; sh_T[1] = Tim; sh_corr[0] = corr_re; sh_corr[1] = corr_im; sh_fixed += fixed; }
+    }
+    wv::block_sync();
   }
-  if (lane == 0 && fixed) { wv::atomic_add(&ctl->dc_count[a.dc_rounds], -fixed); wv::atomic_add(&ctl->dc_finished, fixed); }
+  if (tid == 0 && sh_fixed) { wv::atomic_add(&ctl->dc_count[a.dc_rounds], -sh_fixed); wv::atomic_add(&ctl->dc_finished, sh_fixed); }
 }
 
 // ---- 5. windows ----------------------------------------------------------------------------------------------------
@@ -2111,9 +2223,21 @@ RFID_KERNEL(64) void ls2_assemble_kernel(Ls2Args a) {
       // start is (the unit is settled: inside the window), per component
       float dcr = 0.0f, dci = 0.0f;
       if (on) {
-        const int o_re = a.dT[2 * w.unit] - a.dcen[2 * w.unit] + LS2_DCB_HALF, o_im = a.dT[2 * w.unit + 1] - a.dcen[2 * w.unit + 1] + LS2_DCB_HALF;
-        dcr = a.dcand[(int64_t)w.slot * 64 + (o_re & 63)].x;
-        dci = a.dcand[(int64_t)w.slot * 64 + (o_im & 63)].y;
+        float dc[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int cen = a.dcen[2 * w.unit + c];
+          const int D = a.dT[2 * w.unit + c] - cen;
+          const bool inw = D >= -LS2_DCB_HALF && D < LS2_DCB_HALF;
+          // inside the window: that candidate's own value; else (inside the margin) candidate 32's / 33's run shifted by the even rest
+          // of the distance, in ulps of the START's binade (the trajectory is shifted as a whole: rfid_ls2.hpp's header)
+          const int par = D & 1;
+          const float2 v = a.dcand[(int64_t)w.slot * 64 + (inw ? (D + LS2_DCB_HALF) : (LS2_DCB_HALF + par))];
+          const uint32_t e0 = (wv::f2u(ls2_from_ord(cen)) >> 23) & 0xffu;
+          const float u0 = (e0 >= 25u) ? wv::u2f((e0 - 23u) << 23) : 0.0f;
+          dc[c] = (c ? v.y : v.x) + (inw ? 0.0f : (float)(D - par) * u0);
+        }
+        dcr = dc[0]; dci = dc[1];
       }
       rfid_window o;
       o.stream = s; o.seq = seq + wv::popc64(m & lt); o.start = w.start; o.type = type;
@@ -2158,8 +2282,11 @@ RFID_KERNEL(64) void ls2_carry_kernel(Ls2Args a) {
   const int tl = s * a.max_bc + (h - base) / LS2_FINE;
   float dc_end[2];
   for (int c = 0; c < 2; ++c) {
-    const int o = wv::uniform(a.dT[2 * tl + c]) - wv::uniform(a.dcen[2 * tl + c]) + LS2_DCB_HALF;
-    dc_end[c] = ls2_from_ord(wv::uniform(a.dtab[(int64_t)(2 * tl + c) * 64 + (o & 63)]));
+    const int D = wv::uniform(a.dT[2 * tl + c]) - wv::uniform(a.dcen[2 * tl + c]);
+    const bool inw = D >= -LS2_DCB_HALF && D < LS2_DCB_HALF;
+    const int par = D & 1;
+    const int e = wv::uniform(a.dtab[(int64_t)(2 * tl + c) * 64 + (inw ? (D + LS2_DCB_HALF) : (LS2_DCB_HALF + par))]);
+    dc_end[c] = ls2_from_ord(inw ? e : (e + (D - par)));   // (a unit with a margin ends in the binade it starts in)
   }
   for (int k = lane; k < WIN_LEN; k += 64) {
     const int idx = end - WIN_LEN + k;

@@ -49,7 +49,7 @@ inline Ls2Geometry ls2_geometry(int n_streams, int64_t n_dec, int min_piece = LS
 
 // work space: one allocation, carved up here (offsets in bytes, 256-byte aligned)
 struct Ls2Layout {
-  size_t cut, cutf, piece, nextv, prevv, upiece, unextv, uprevv, lb_fn, lb_end, lb_water, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, dT, dcen, dtab, dstat, dwbase, dcand, n1cen, n1tab, n1val, n1ent, n1exm, n2cen, n2tab, n2val, n2ent, n2exm, seq0, flat_base, cflag, cagg, ctl, consumed, total;
+  size_t cut, cutf, piece, nextv, prevv, upiece, unextv, uprevv, lb_fn, lb_end, lb_water, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, dT, dcen, dtab, dstat, dfront, dmar, dwbase, dcand, n1cen, n1tab, n1val, n1ent, n1mar, n1exm, n2cen, n2tab, n2val, n2ent, n2mar, n2exm, seq0, flat_base, cflag, cagg, ctl, consumed, total;
   int dcand_cap;
 };
 // wmax: complete windows a trace can hold (the caller's window table): sizes the dc_est stage's table of gate openings
@@ -83,13 +83,15 @@ inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_strid
   L.dcen = take(sizeof(int) * 2 * NH);
   L.dtab = take(sizeof(int) * 2 * 64 * NH);
   L.dstat = take(sizeof(int) * NH);
+  L.dmar = take(sizeof(int) * 2 * NH);
+  L.dfront = take(sizeof(int) * B);
   L.dwbase = take(sizeof(int) * NH);
   L.dcand_cap = (int)(B * (size_t)(wmax > 0 ? wmax : 0) + NH + 8);   // every window + the one a trace may end in, per unit
   L.dcand = take(sizeof(float2) * 64 * (size_t)L.dcand_cap);
   L.n1cen = take(sizeof(int) * 2 * N1); L.n1tab = take(sizeof(int) * 2 * 64 * N1); L.n1val = take(sizeof(int) * N1);
-  L.n1ent = take(sizeof(int) * 4 * N1); L.n1exm = take(sizeof(uint64_t) * 2 * N1);
+  L.n1ent = take(sizeof(int) * 4 * N1); L.n1mar = take(sizeof(int) * 2 * N1); L.n1exm = take(sizeof(uint64_t) * 2 * N1);
   L.n2cen = take(sizeof(int) * 2 * N2); L.n2tab = take(sizeof(int) * 2 * 64 * N2); L.n2val = take(sizeof(int) * N2);
-  L.n2ent = take(sizeof(int) * 4 * N2); L.n2exm = take(sizeof(uint64_t) * 2 * N2);
+  L.n2ent = take(sizeof(int) * 4 * N2); L.n2mar = take(sizeof(int) * 2 * N2); L.n2exm = take(sizeof(uint64_t) * 2 * N2);
   L.seq0 = take(sizeof(int) * 2 * NS);
   L.flat_base = take(sizeof(int) * 2 * B);
   L.cflag = take(sizeof(int) * B * LS2_CHAIN_GMAX);
@@ -110,11 +112,11 @@ inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geomet
   a.votes = (uint64_t *)(base + L.votes); a.closed = (uint64_t *)(base + L.closed); a.openinfo = (int *)(base + L.openinfo);
   a.arun = (Ls2AvgRun *)(base + L.arun); a.aT = (int *)(base + L.aT); a.alist = (int *)(base + L.alist); a.aover = (Ls2Aff *)(base + L.aover);
   a.fsm = (Ls2Fsm *)(base + L.fsm); a.wb = (Ls2Win *)(base + L.wb);
-  a.dT = (int *)(base + L.dT); a.dcen = (int *)(base + L.dcen); a.dtab = (int *)(base + L.dtab); a.dstat = (int *)(base + L.dstat);
+  a.dT = (int *)(base + L.dT); a.dcen = (int *)(base + L.dcen); a.dtab = (int *)(base + L.dtab); a.dstat = (int *)(base + L.dstat); a.dmar = (int *)(base + L.dmar); a.dfront = (int *)(base + L.dfront);
   a.dwbase = (int *)(base + L.dwbase); a.dcand = (float2 *)(base + L.dcand); a.dcand_cap = L.dcand_cap;
   a.dcb_n1 = g.n1; a.dcb_n2 = g.n2; a.dcb_top = (g.n1 > ls2_dcb_top_min()) ? 2 : 1;
-  a.n1cen = (int *)(base + L.n1cen); a.n1tab = (int *)(base + L.n1tab); a.n1val = (int *)(base + L.n1val); a.n1ent = (int *)(base + L.n1ent); a.n1exm = (uint64_t *)(base + L.n1exm);
-  a.n2cen = (int *)(base + L.n2cen); a.n2tab = (int *)(base + L.n2tab); a.n2val = (int *)(base + L.n2val); a.n2ent = (int *)(base + L.n2ent); a.n2exm = (uint64_t *)(base + L.n2exm);
+  a.n1cen = (int *)(base + L.n1cen); a.n1tab = (int *)(base + L.n1tab); a.n1val = (int *)(base + L.n1val); a.n1ent = (int *)(base + L.n1ent); a.n1mar = (int *)(base + L.n1mar); a.n1exm = (uint64_t *)(base + L.n1exm);
+  a.n2cen = (int *)(base + L.n2cen); a.n2tab = (int *)(base + L.n2tab); a.n2val = (int *)(base + L.n2val); a.n2ent = (int *)(base + L.n2ent); a.n2mar = (int *)(base + L.n2mar); a.n2exm = (uint64_t *)(base + L.n2exm);
   a.seq0 = (int *)(base + L.seq0); a.flat_base = (int *)(base + L.flat_base); a.cflag = (int *)(base + L.cflag); a.cagg = (int *)(base + L.cagg); a.ctl = (Ls2Ctl *)(base + L.ctl); a.consumed = (int *)(base + L.consumed);
 }
 
@@ -178,7 +180,7 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
   // dc_est: away from binade edges round 1 settles everything (round 0's centres are off by the rounding drift); sums that hover
   // at an edge advance some thousand units per round.  What the rounds leave, ls2_dcb_finish_kernel takes one unit after
   // the other; the library asks for as many rounds as the passes before needed (+ a few) from then on
-  a.dc_rounds = (dc_rounds >= 0) ? dc_rounds : (generous ? 24 : ((tiny || small) ? 3 : LS2_DC_ROUNDS));
+  a.dc_rounds = (dc_rounds >= 0) ? dc_rounds : LS2_DC_ROUNDS;
   if (a.dc_rounds < 0) a.dc_rounds = 0;
   if (a.dc_rounds > LS2_DC_MAXR) a.dc_rounds = LS2_DC_MAXR;
   if (fused) {
@@ -230,7 +232,7 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
       if (r == 0 && mark) mark(mark_arg, 1);
     }
     a.round = 0;
-    LS2_LAUNCH(ls2_dcb_finish_kernel, B, 1, 64, U(a));
+    LS2_LAUNCH(ls2_dcb_finish_kernel, B, 1, 64 * LS2_DCB_FIN_WAVES, U(a));
   }
   a.round = 0;
   a.stamp++;

@@ -124,6 +124,12 @@ static inline int scan_add(int v) {
   for (int i = 0; i <= lane_id(); ++i) acc += (int)(uint32_t)b[i];
   return acc;
 }
+static inline float scan_add_f(float v) {   // (an estimate on the device too: any order of the additions will do)
+  const uint64_t *b = emu::exchange(emu::f2u(v));
+  float acc = 0.0f;
+  for (int i = 0; i <= lane_id(); ++i) acc += emu::u2f((uint32_t)b[i]);
+  return acc;
+}
 template <int N> static inline int dpp_row_shr(int v, int fill) {
   const uint64_t *b = emu::exchange((uint32_t)v);
   const int l = lane_id();
