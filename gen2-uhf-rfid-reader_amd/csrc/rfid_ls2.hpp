@@ -138,6 +138,7 @@ struct Ls2Args {
   float2 *dcand; int dcand_cap; // [dcand_cap][64] dc_est at a gate opening for each candidate
   // the chain's levels: nodes of 64 children (level 1: blocks of units, level 2: groups of blocks); per node the centre of its
   // first child, its table on that window, which entries are exact, whether it holds anything, and its entry value from the walk
+  int dcb_bias;                 // test hook: ulps added to the first round's centres (the ring means), as the rounding drift of a long trace would
   int dcb_n1, dcb_n2, dcb_top;  // nodes per trace of level 1 / 2; the level the walk runs over (2 when a trace has more than 64 blocks)
   int *n1cen, *n1tab, *n1val, *n1ent, *n1mar; uint64_t *n1exm;
   int *n2cen, *n2tab, *n2val, *n2ent, *n2mar; uint64_t *n2exm;
@@ -1627,7 +1628,7 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
       float pr = v.x, pi = v.y;   // (lanes >= 48 hold zeros)
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) { pr += wv::shfl_xor(pr, off); pi += wv::shfl_xor(pi, off); }
-      cre = ls2_ord(wv::uniform(pr) / DC_LEN_F); cim = ls2_ord(wv::uniform(pi) / DC_LEN_F);
+      cre = ls2_ord(wv::uniform(pr) / DC_LEN_F) + a.dcb_bias; cim = ls2_ord(wv::uniform(pi) / DC_LEN_F) - a.dcb_bias;
     }
   }
   wv::wave_sync();
@@ -1875,7 +1876,12 @@ RFID_DEVICE void ls2_dcb_up(const Ls2Args &a, const int node, const int lane) {
   const uint64_t m = wv::ballot(valid != 0);
   if (m == 0ull) { if (lane == 0) oval[node] = 0; return; }
   int l = wv::ffs64(m);
-  const int bre = wv::readlane(cre, l), bim = wv::readlane(cim, l);
+  // the node's window: round 0 around its first child's centre; later around the value the last chain found it entered at --
+  // the first child's centre is a ring mean, off by the rounding drift, and an entry value outside the window passes exactly
+  // only where EVERY child's margin covers it
+  const int *pent = (L == 1) ? a.n1ent : a.n2ent;
+  const bool recentre = a.round > 0 && wv::uniform(oval[node]) != 0;
+  const int bre = recentre ? wv::uniform(pent[4 * node]) : wv::readlane(cre, l), bim = recentre ? wv::uniform(pent[4 * node + 1]) : wv::readlane(cim, l);
   int vre = bre + lane - LS2_DCB_HALF, vim = bim + lane - LS2_DCB_HALF;
   bool exr = true, exi = true;
   int nmr = 0x3fffffff, nmi = 0x3fffffff;   // the node's own margin: how far from ITS centre an entry value may lie (see below)
@@ -2086,9 +2092,30 @@ RFID_KERNEL(64 * LS2_DCB_FIN_WAVES) void ls2_dcb_finish_kernel(Ls2Args a) {
       const uint64_t m = wv::ballot((st & 4) != 0 && (st & 3) != 3);
       if (m) first = k0 + wv::ffs64(m);
     }
+    // its exact start: the end of the settled unit before it (that unit's start is exact and inside its window or margin).  NOT the
+    // start the chain wrote for it: that came through the tables of whole blocks, and a block's table may have missed where
+    // every unit inside it, walked one by one, was hit
+    int Tre = 0, Tim = 0;
+    if (first >= 0) {
+      int prev = -1;
+      for (int k1 = first; k1 > 0 && prev < 0; k1 -= 64) {   // the slots k1 - 64 .. k1 - 1
+        const int k = k1 - 64 + lane;
+        const uint64_t m = wv::ballot(k >= 0 && (a.dstat[t0 + ((k >= 0) ? k : 0)] & 4) != 0);
+        if (m) prev = k1 - 64 + (63 - (int)__builtin_clzll(m));
+      }
+      if (prev < 0) { Tre = wv::uniform(a.dcen[2 * (t0 + first)]); Tim = wv::uniform(a.dcen[2 * (t0 + first) + 1]); }   // (the trace's first unit: its centre is the exact start)
+      else {
+        const int tp = t0 + prev;
+        Tre = wv::uniform(a.dT[2 * tp]); Tim = wv::uniform(a.dT[2 * tp + 1]);
+        bool exr = true, exi = true;
+        ls2_dcb_apply(Tre, exr, a.dtab[(int64_t)(2 * tp) * 64 + lane], ~0ull, wv::uniform(a.dcen[2 * tp]), wv::uniform(a.dmar[2 * tp]));
+        ls2_dcb_apply(Tim, exi, a.dtab[(int64_t)(2 * tp + 1) * 64 + lane], ~0ull, wv::uniform(a.dcen[2 * tp + 1]), wv::uniform(a.dmar[2 * tp + 1]));
+        if (!(exr && exi)) { if (lane == 0) ctl->fail = 7; first = -1; }   // (a settled unit's end is exact by definition)
+      }
+    }
     if (lane == 0) {
       sh_pos = first; sh_fixed = 0; sh_corr[0] = 0; sh_corr[1] = 0;
-      if (first >= 0) { sh_T[0] = a.dT[2 * (t0 + first)]; sh_T[1] = a.dT[2 * (t0 + first) + 1]; }
+      if (first >= 0) { sh_corr[0] = Tre - a.dT[2 * (t0 + first)]; sh_corr[1] = Tim - a.dT[2 * (t0 + first) + 1]; sh_T[0] = Tre; sh_T[1] = Tim; }
     }
   }
   wv::block_sync();

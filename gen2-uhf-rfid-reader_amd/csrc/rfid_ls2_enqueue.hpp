@@ -102,6 +102,7 @@ inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_strid
   return L;
 }
 inline int &ls2_dcb_top_min();
+inline int &ls2_dcb_bias();
 inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geometry &g) {
   a.P = g.P; a.max_b = g.max_b; a.Pc = g.Pc; a.max_bc = g.max_bc; a.vstride = g.vstride; a.cstride = g.cstride; a.wb_stride = g.wb_stride;
   a.cut = (int *)(base + L.cut); a.cutf = (int *)(base + L.cutf); a.piece = (Ls2Piece *)(base + L.piece);
@@ -114,7 +115,7 @@ inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geomet
   a.fsm = (Ls2Fsm *)(base + L.fsm); a.wb = (Ls2Win *)(base + L.wb);
   a.dT = (int *)(base + L.dT); a.dcen = (int *)(base + L.dcen); a.dtab = (int *)(base + L.dtab); a.dstat = (int *)(base + L.dstat); a.dmar = (int *)(base + L.dmar); a.dfront = (int *)(base + L.dfront);
   a.dwbase = (int *)(base + L.dwbase); a.dcand = (float2 *)(base + L.dcand); a.dcand_cap = L.dcand_cap;
-  a.dcb_n1 = g.n1; a.dcb_n2 = g.n2; a.dcb_top = (g.n1 > ls2_dcb_top_min()) ? 2 : 1;
+  a.dcb_n1 = g.n1; a.dcb_n2 = g.n2; a.dcb_top = (g.n1 > ls2_dcb_top_min()) ? 2 : 1; a.dcb_bias = ls2_dcb_bias();
   a.n1cen = (int *)(base + L.n1cen); a.n1tab = (int *)(base + L.n1tab); a.n1val = (int *)(base + L.n1val); a.n1ent = (int *)(base + L.n1ent); a.n1mar = (int *)(base + L.n1mar); a.n1exm = (uint64_t *)(base + L.n1exm);
   a.n2cen = (int *)(base + L.n2cen); a.n2tab = (int *)(base + L.n2tab); a.n2val = (int *)(base + L.n2val); a.n2ent = (int *)(base + L.n2ent); a.n2mar = (int *)(base + L.n2mar); a.n2exm = (uint64_t *)(base + L.n2exm);
   a.seq0 = (int *)(base + L.seq0); a.flat_base = (int *)(base + L.flat_base); a.cflag = (int *)(base + L.cflag); a.cagg = (int *)(base + L.cagg); a.ctl = (Ls2Ctl *)(base + L.ctl); a.consumed = (int *)(base + L.consumed);
@@ -122,7 +123,8 @@ inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geomet
 
 inline int &ls2_fsm_lanes_min() { static int v = 8192; return v; }   // from this many possible heads on the state machine runs one lane per unit (tests: 0 / a huge number)
 inline int &ls2_chain_slots() { static int v = 2048; return v; }
-inline int &ls2_dcb_top_min() { static int v = 64; return v; }   // the dc_est chain walks over groups of blocks when a trace has more blocks than this (tests: 0)   // slots per workgroup of a chain launch (tests shrink it)
+inline int &ls2_dcb_top_min() { static int v = 64; return v; }
+inline int &ls2_dcb_bias() { static int v = 0; return v; }   // (tests: Ls2Args::dcb_bias)   // the dc_est chain walks over groups of blocks when a trace has more blocks than this (tests: 0)   // slots per workgroup of a chain launch (tests shrink it)
 
 #ifdef LS2_LAUNCH
 // One pass (its first launch zeroes Ls2Ctl, the chain flags, the votes, the window buckets and flat_count).  `a` complete but for

@@ -113,6 +113,24 @@ def test_ls2_dc_est_chain_over_several_blocks(emu_mod, oracle_mod, synth_mod, kw
     assert c["n_units"] >= 20 and c["dc_count0"] + c["dc_finished"] > 0, c
 
 
+@pytest.mark.parametrize("sigma,bias", [(0.03, 300), (0.01, 5000), (0.002, 1000)])
+@pytest.mark.parametrize("kw", [dict(), dict(dc_two_levels=True), dict(dc_rounds=0), dict(dc_rounds=1)], ids=["rounds", "two-levels", "walk-only", "one-round"])
+def test_ls2_dc_est_far_starts_margins_and_reruns(emu_mod, oracle_mod, synth_mod, sigma, bias, kw):
+    """What a LONG trace does to the dc_est stage, on a short one: the first round's centres (the ring means) are moved `bias`
+    ulps off (the rounding drift of 10^8 additions), so that every unit's true start lies far outside its 64-candidate window.
+    Units whose sums keep away from binade edges are settled all the same -- candidate 32's / 33's run shifted along, as far as
+    the run's margin reaches; the others are run again, centred on the chain's prediction, and the blocks' windows move to
+    where the last chain found their entry values.  (This is where round 6's first GPU run went wrong: a block's table had
+    missed, every unit inside it -- walked one by one -- was settled, and the finishing walk took the value the chain had
+    written for the first unit BEHIND the block for exact.  It now takes the end of the settled unit before it.)"""
+    t = synth_mod.make_trace(n_rounds=30, sigma=sigma, seed=11, leak=1.0 * np.exp(0.6j)).samples
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, min_piece=64, check_avg=False, dc_bias=bias, **kw)
+    c = r["ctl"]
+    assert c["n_units"] >= 30 and c["fail"] == 0, c
+    if kw.get("dc_rounds", 3) >= 1 and "dc_two_levels" not in kw:
+        assert c["dc_finished"] == 0 and c["dc_rounds"] <= 3, c          # (the second round settles everything away from binade edges)
+
+
 @FUSED
 def test_ls2_carrier_at_a_power_of_two(emu_mod, oracle_mod, synth_mod, fused):
     """A carrier whose filtered amplitude is exactly 16.0: avg_ampl hovers at a binade edge, hardly any run is provable
