@@ -141,8 +141,9 @@ def workload_single_trace(torch, rfid, synth, args, device, rank, fixed_q, n_rou
     """One long trace built in HBM from its slot table (different tags / seed per rank)."""
     tag_ids = tuple(((0x11 + 0x10 * k + rank) & 0xFF) for k in range(n_tags))
     t0 = time.perf_counter()
+    kw = {} if args.leak_phase is None else {"leak": complex(np.cos(args.leak_phase), np.sin(args.leak_phase))}
     t = synth.make_trace(n_rounds=n_rounds, fixed_q=fixed_q, tag_ids=tag_ids, sigma=0.0, seed=args.seed + rank,
-                         noise=False, render=False)
+                         noise=False, render=False, **kw)
     plan_s = time.perf_counter() - t0
     ctx = rfid.Context(device=device.index, fixed_q=fixed_q, max_num_queries=(1 << 31) - 2)
     L = ctx.synth_gen2_size(t.plan)
@@ -186,8 +187,9 @@ def workload_single_trace(torch, rfid, synth, args, device, rank, fixed_q, n_rou
     return dict(ctx=ctx, data=data, stride=stride, L=L, B=1, fixed_q=fixed_q, check=check, sample=sample,
                 describe="%s: one RX trace per GPU, FIXED_Q=%d (%d slots/round), %d rounds, %d tags (collisions and "
                          "empty slots included), FM0 40 kHz BLF @ 2 Msps: %d raw I/Q samples (%.1f GB), sigma=%g, built in "
-                         "HBM by rfid_synth_gen2 from a %d-slot table (host planning %.1f s)"
-                         % (tag, fixed_q, 1 << fixed_q, n_rounds, n_tags, L, 8e-9 * L, args.sigma, n_slots, plan_s))
+                         "HBM by rfid_synth_gen2 from a %d-slot table (host planning %.1f s)%s"
+                         % (tag, fixed_q, 1 << fixed_q, n_rounds, n_tags, L, 8e-9 * L, args.sigma, n_slots, plan_s,
+                            "" if args.leak_phase is None else ", carrier leak phase %g rad" % args.leak_phase))
 
 
 def streaming_leg(torch, rfid, wl, args, device):
@@ -606,6 +608,8 @@ def main():
     ap.add_argument("--tags", type=int, default=8, help="tags in the field (config 2)")
     ap.add_argument("--hbm-frac", type=float, default=0.90, help="4shard: fraction of the free HBM to fill")
     ap.add_argument("--sigma", type=float, default=0.002)
+    ap.add_argument("--leak-phase", type=float, default=None, help="configs 2 / 3stream: phase (rad) of the carrier leak L = e^{j phase} (SURVEY 8(d): 0.7); "
+                    "0.7 puts 25 sin(0.7) = 16.1 next to a power of two, where dc_est hovers across the binade edge under noise")
     ap.add_argument("--seed", type=int, default=1000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

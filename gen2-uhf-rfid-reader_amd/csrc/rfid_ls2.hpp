@@ -48,7 +48,7 @@ static_assert(LS2_WBUCKET <= RN16_WIN + T1_SAMPLES, "one window per bucket");
 constexpr int LS2_AVG_ROUNDS = 11;    // re-run rounds after the first pass, per recurrence (a round without work costs two empty launches; configs[2]
                                       // settles in 5 rounds on y-given pieces and in 8 on the fused first pass's, profiles/r05/ls2_rounds.txt)
 constexpr int LS2_FSM_ROUNDS = 3;
-constexpr int LS2_DC_ROUNDS = 3;      // dc_est rounds behind the first: away from binade edges the second settles everything; what hovers at an edge is left to the finishing walk
+constexpr int LS2_DC_ROUNDS = 10;     // dc_est rounds behind the first that a long pass enqueues (rfid_ls2_enqueue.hpp)
 constexpr int LS2_MAXR = 12;
 constexpr int LS2_WIDE_BELOW = 64;    // a piece whose margin is below this is re-run from six neighbouring start values at once
 constexpr int LS2_WIDE_LO = -2, LS2_WIDE_HI = 3;
@@ -2077,7 +2077,7 @@ RFID_KERNEL(64 * LS2_DCB_FIN_WAVES) void ls2_dcb_finish_kernel(Ls2Args a) {
   RFID_SHARED float4 lds_q4[LS2_DCB_FIN_WAVES][32];
   RFID_SHARED int sh_tab[LS2_DCB_FIN_WAVES][2][64];
   RFID_SHARED int sh_cen[LS2_DCB_FIN_WAVES][2], sh_mar[LS2_DCB_FIN_WAVES][2], sh_on[LS2_DCB_FIN_WAVES];
-  RFID_SHARED int sh_pos, sh_T[2], sh_corr[2], sh_fixed;
+  RFID_SHARED int sh_pos, sh_T[2], sh_corr[2], sh_fixed, sh_waves;
   Ls2Ctl *ctl = a.ctl;
   if (!ls2_fsm_settled(a, ctl)) return;
   if (ctl->dc_count[a.dc_rounds] == 0) return;
@@ -2114,7 +2114,7 @@ RFID_KERNEL(64 * LS2_DCB_FIN_WAVES) void ls2_dcb_finish_kernel(Ls2Args a) {
       }
     }
     if (lane == 0) {
-      sh_pos = first; sh_fixed = 0; sh_corr[0] = 0; sh_corr[1] = 0;
+      sh_pos = first; sh_fixed = 0; sh_corr[0] = 0; sh_corr[1] = 0; sh_waves = LS2_DCB_FIN_WAVES;
       if (first >= 0) { sh_corr[0] = Tre - a.dT[2 * (t0 + first)]; sh_corr[1] = Tim - a.dT[2 * (t0 + first) + 1]; sh_T[0] = Tre; sh_T[1] = Tim; }
     }
   }
@@ -2124,7 +2124,9 @@ RFID_KERNEL(64 * LS2_DCB_FIN_WAVES) void ls2_dcb_finish_kernel(Ls2Args a) {
     if (pos < 0 || pos >= a.max_bc) break;
     const int k = pos + wave;
     const int t = t0 + k;
-    const bool on = k < a.max_bc && (wv::uniform(a.dstat[(k < a.max_bc) ? t : t0]) & 4) != 0;
+    // (as many waves as the last turn's reach suggests: sixteen waves of one CU share its LDS, whose return path is what a unit's
+    // run is bound by -- where only the first two or three units of a turn are hit, the others only slow them down)
+    const bool on = wave < sh_waves && k < a.max_bc && (wv::uniform(a.dstat[(k < a.max_bc) ? t : t0]) & 4) != 0;
     if (on) {
       // wave 0's unit starts from the exact value; the others from the last chain's prediction + what the frontier was off by
       const int cre = (wave == 0) ? sh_T[0] : (wv::uniform(a.dT[2 * t]) + sh_corr[0]);
@@ -2140,7 +2142,8 @@ RFID_KERNEL(64 * LS2_DCB_FIN_WAVES) void ls2_dcb_finish_kernel(Ls2Args a) {
       int Tre = sh_T[0], Tim = sh_T[1];
       int w = 0, fixed = 0;
       int corr_re = sh_corr[0], corr_im = sh_corr[1];
-      for (; w < LS2_DCB_FIN_WAVES && pos + w < a.max_bc; ++w) {
+      const int nact = sh_waves;
+      for (; w < nact && pos + w < a.max_bc; ++w) {
         if (!wv::uniform(sh_on[w])) continue;   // (a slot without a unit)
         const int tw = t0 + pos + w;
         const int c_re = wv::uniform(sh_cen[w][0]), c_im = wv::uniform(sh_cen[w][1]), m_re = wv::uniform(sh_mar[w][0]), m_im = wv::uniform(sh_mar[w][1]);
@@ -2158,7 +2161,11 @@ RFID_KERNEL(64 * LS2_DCB_FIN_WAVES) void ls2_dcb_finish_kernel(Ls2Args a) {
         ls2_dcb_apply(Tre, exr, sh_tab[w][0][lane], ~0ull, c_re, m_re);
         ls2_dcb_apply(Tim, exi, sh_tab[w][1][lane], ~0ull, c_im, m_im);
       }
-      if (lane == 0) { sh_pos = pos + w; sh_T[0] = Tre; sh_T[1] = Tim; sh_corr[0] = corr_re; sh_corr[1] = corr_im; sh_fixed += fixed; }
+      if (lane == 0) {
+        sh_pos = pos + w; sh_T[0] = Tre; sh_T[1] = Tim; sh_corr[0] = corr_re; sh_corr[1] = corr_im; sh_fixed += fixed;
+        const int nw = 2 * w + 2;
+        sh_waves = (nw > LS2_DCB_FIN_WAVES) ? LS2_DCB_FIN_WAVES : nw;
+      }
     }
     wv::block_sync();
   }

@@ -179,10 +179,12 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
   // saw a pass run out of rounds (the sequential scan took over): the full count from then on
   const bool small = NS < 32768 && !generous, tiny = NS < 1024 && !generous;
   a.avg_rounds = tiny ? 3 : (small ? 4 : LS2_AVG_ROUNDS); a.fsm_rounds = (tiny || small) ? 1 : LS2_FSM_ROUNDS;
-  // dc_est: away from binade edges round 1 settles everything (round 0's centres are off by the rounding drift); sums that hover
-  // at an edge advance some thousand units per round.  What the rounds leave, ls2_dcb_finish_kernel takes one unit after
-  // the other; the library asks for as many rounds as the passes before needed (+ a few) from then on
-  a.dc_rounds = (dc_rounds >= 0) ? dc_rounds : LS2_DC_ROUNDS;
+  // dc_est rounds behind the first.  Away from binade edges the first round settles every unit whose margin covers the rounding
+  // drift; the few others (a partial sum next to a power of two: ~5 %) are run again centred on the chain's prediction, which is
+  // off by an ulp or two per such unit it came through -- the blocks' windows (+- 32) catch that for some thousand units per
+  // round: 2 rounds for a stream of a few thousand units, up to ~8 for configs[2]'s 32 000 (a round here is six small launches
+  // and a handful of unit runs).  Sums that hover at a binade edge do not settle by rounds at all; the finishing walk takes them
+  a.dc_rounds = (dc_rounds >= 0) ? dc_rounds : ((tiny || small) ? 2 : LS2_DC_ROUNDS);
   if (a.dc_rounds < 0) a.dc_rounds = 0;
   if (a.dc_rounds > LS2_DC_MAXR) a.dc_rounds = LS2_DC_MAXR;
   if (fused) {
