@@ -1586,6 +1586,7 @@ RFID_KERNEL(256) void ls2_fsm_chain_kernel(Ls2Args a) {
 // frontier, each run from its exact start: the partial fallback (settled units keep their results; the pass costs its clean
 // time plus the sequential time of the unsettled units, never the whole sequential gate scan).
 constexpr int LS2_DCB_HALF = 32;      // candidate j (= lane) of a unit starts at its centre + j - 32 ulps
+constexpr int LS2_DCB_DESCENTS = 1024;  // nodes a chain walk goes through child by child where their tables miss, per wave and launch
 constexpr int LS2_DCB_AHEAD = 4096;    // re-run rounds look this many idle-grid slots behind a trace's frontier
 constexpr int LS2_DCB_SLACK = 48;     // taken off a run's margin: the estimate of the partial sums is off by < 33 ulps, + the proof's own 4, + spare
 
@@ -1818,11 +1819,15 @@ RFID_KERNEL(64) void ls2_dcb_run_kernel(Ls2Args a) {
     if (r == 0) {
       if (wv::uniform(a.piece[i].len) <= 0 || wv::uniform(a.fsm[i].head) == 0 || wv::uniform(a.piece[i].pos0) >= wv::uniform(a.fsm[i].u1)) continue;
     } else {
-      // again: the units whose latest run does not cover the start the chain predicts for them -- within LS2_DCB_AHEAD slots of
-      // the trace's frontier (where sums hover at a binade edge the predictions far behind the frontier are not worth a run yet)
+      // again: the units whose latest run does not cover the start the chain predicts for them.  A unit that was run again twice and
+      // is STILL not covered has sums that hover at a binade edge (no margin, and the prediction is off by more than the window
+      // however often it is renewed): from then on only within LS2_DCB_AHEAD slots of the trace's frontier -- runs far behind it are
+      // wasted there (bits 4 - 6 of dstat: how often the unit was run again)
       const int st = wv::uniform(a.dstat[t]);
       if (!(st & 4) || (st & 3) == 3 || !(st & 8)) continue;
-      if (t > wv::uniform(a.dfront[t / a.max_bc]) + LS2_DCB_AHEAD) continue;
+      const int again = (st >> 4) & 7;
+      if (again >= 2 && t > wv::uniform(a.dfront[t / a.max_bc]) + LS2_DCB_AHEAD) continue;
+      if (lane == 0) a.dstat[t] = (st & ~0x70) | (((again < 7) ? again + 1 : 7) << 4);
     }
     int er, ei;
     ls2_dcb_unit(a, t, r > 0, (r > 0) ? wv::uniform(a.dT[2 * t]) : 0, (r > 0) ? wv::uniform(a.dT[2 * t + 1]) : 0, r == 0, lane, lds_dc, lds_tmp, lds_q, er, ei);
@@ -1857,6 +1862,33 @@ RFID_DEVICE Ls2DcbKids ls2_dcb_kids(const Ls2Args &a) {
   if (L == 1) { k.cen = a.dcen; k.tab = a.dtab; k.exm = nullptr; k.val = nullptr; k.mar = a.dmar; k.per_trace = a.max_bc; }
   else { k.cen = a.n1cen; k.tab = a.n1tab; k.exm = a.n1exm; k.val = a.n1val; k.mar = a.n1mar; k.per_trace = a.dcb_n1; }
   return k;
+}
+// A node's table misses (the entry value lies outside its window and its margin) where its CHILDREN, gone through one by one,
+// may all be hit: the walk then descends -- (T, ex) through the children of node `node` of level L in order, a level-2 node's
+// children (blocks) through their own tables first and through THEIR children where those miss too.  Wave-uniform values; the
+// children's tables lie across the lanes.  `budget`: descents the caller still allows (sums that hover at a binade edge miss
+// everywhere: a walk over every unit of a long trace in one wave is what the rounds are there to avoid).
+template <int L>
+RFID_DEVICE void ls2_dcb_through(const Ls2Args &a, const int node, int &Tre, int &Tim, bool &exr, bool &exi, const int lane, int &budget) {
+  const Ls2DcbKids kd = ls2_dcb_kids<L>(a);
+  const int nper = (L == 1) ? a.dcb_n1 : a.dcb_n2;
+  const int s = node / nper, k = node - s * nper;
+  const int ch0 = s * kd.per_trace + 64 * k;
+  const int nch = (kd.per_trace - 64 * k < 64) ? (kd.per_trace - 64 * k) : 64;
+  for (int c = 0; c < nch; ++c) {
+    const int ch = ch0 + c;
+    const int valid = (L == 1) ? ((wv::uniform(a.dstat[ch]) >> 2) & 1) : wv::uniform(kd.val[ch]);
+    if (!valid) continue;
+    int T2r = Tre, T2i = Tim; bool e2r = exr, e2i = exi;
+    ls2_dcb_apply(T2r, e2r, kd.tab[(int64_t)(2 * ch) * 64 + lane], kd.exm ? wv::uniform(kd.exm[2 * ch]) : ~0ull, wv::uniform(kd.cen[2 * ch]), wv::uniform(kd.mar[2 * ch]));
+    ls2_dcb_apply(T2i, e2i, kd.tab[(int64_t)(2 * ch + 1) * 64 + lane], kd.exm ? wv::uniform(kd.exm[2 * ch + 1]) : ~0ull, wv::uniform(kd.cen[2 * ch + 1]), wv::uniform(kd.mar[2 * ch + 1]));
+    if (L == 2 && ((exr && !e2r) || (exi && !e2i)) && budget > 0) {
+      budget--;
+      T2r = Tre; T2i = Tim; e2r = exr; e2i = exi;
+      ls2_dcb_through<1>(a, ch, T2r, T2i, e2r, e2i, lane, budget);
+    }
+    Tre = T2r; Tim = T2i; exr = e2r; exi = e2i;
+  }
 }
 // up: the 64 children of node `node` of level L composed in order -> the node's table (on the window of its first child)
 template <int L>
@@ -1961,6 +1993,7 @@ RFID_KERNEL(64) void ls2_dcb_top_kernel(Ls2Args a) {
   int *ent = two ? a.n2ent : a.n1ent;
   int Tre = wv::uniform(a.dcen[2 * t0]), Tim = wv::uniform(a.dcen[2 * t0 + 1]);
   bool exr = true, exi = true;
+  int budget = LS2_DCB_DESCENTS;
   const int n0 = s * nper;
   int tr = tab[(int64_t)(2 * n0) * 64 + lane], ti = tab[(int64_t)(2 * n0 + 1) * 64 + lane];
   for (int k = 0; k < nper; ++k) {
@@ -1969,8 +2002,17 @@ RFID_KERNEL(64) void ls2_dcb_top_kernel(Ls2Args a) {
     if (k + 1 < nper) { ntr = tab[(int64_t)(2 * (node + 1)) * 64 + lane]; nti = tab[(int64_t)(2 * (node + 1) + 1) * 64 + lane]; }
     if (wv::uniform(val[node]) != 0) {
       if (lane == 0) { ent[4 * node] = Tre; ent[4 * node + 1] = Tim; ent[4 * node + 2] = exr ? 1 : 0; ent[4 * node + 3] = exi ? 1 : 0; }
-      ls2_dcb_apply(Tre, exr, tr, wv::uniform(exm[2 * node]), wv::uniform(cen[2 * node]), wv::uniform(mar[2 * node]));
-      ls2_dcb_apply(Tim, exi, ti, wv::uniform(exm[2 * node + 1]), wv::uniform(cen[2 * node + 1]), wv::uniform(mar[2 * node + 1]));
+      int T2r = Tre, T2i = Tim; bool e2r = exr, e2i = exi;
+      ls2_dcb_apply(T2r, e2r, tr, wv::uniform(exm[2 * node]), wv::uniform(cen[2 * node]), wv::uniform(mar[2 * node]));
+      ls2_dcb_apply(T2i, e2i, ti, wv::uniform(exm[2 * node + 1]), wv::uniform(cen[2 * node + 1]), wv::uniform(mar[2 * node + 1]));
+      if (((exr && !e2r) || (exi && !e2i)) && budget > 0) {
+        // the node's table missed an exact entry value: through its children one by one (they may all be hit)
+        budget--;
+        T2r = Tre; T2i = Tim; e2r = exr; e2i = exi;
+        if (two) ls2_dcb_through<2>(a, node, T2r, T2i, e2r, e2i, lane, budget);
+        else ls2_dcb_through<1>(a, node, T2r, T2i, e2r, e2i, lane, budget);
+      }
+      Tre = T2r; Tim = T2i; exr = e2r; exi = e2i;
     }
     tr = ntr; ti = nti;
   }
@@ -2000,6 +2042,7 @@ RFID_DEVICE void ls2_dcb_down(const Ls2Args &a, const int node, const int lane, 
     er = kd.exm ? wv::uniform(kd.exm[2 * (ch0 + c)]) : ~0ull; ei = kd.exm ? wv::uniform(kd.exm[2 * (ch0 + c) + 1]) : ~0ull;
   };
   int l = wv::ffs64(m);
+  int budget = 64;
   int tr, ti; uint64_t er, ei;
   fetch(l, tr, ti, er, ei);
   for (;;) {
@@ -2018,14 +2061,23 @@ RFID_DEVICE void ls2_dcb_down(const Ls2Args &a, const int node, const int lane, 
       const int bits = ((exr && k_re) ? 1 : 0) | ((exi && k_im) ? 2 : 0);
       // (bit 3: the unit's latest run does not cover the start predicted for it -- it is run again, centred on that; a unit whose
       // run does cover it only waits for the units before it)
-      if (lane == 0) { a.dT[2 * c] = Tre; a.dT[2 * c + 1] = Tim; a.dstat[c] = 4 | bits | ((k_re && k_im) ? 0 : 8); }
+      if (lane == 0) { a.dT[2 * c] = Tre; a.dT[2 * c + 1] = Tim; a.dstat[c] = 4 | bits | ((k_re && k_im) ? 0 : 8) | (a.dstat[c] & 0x70); }
       n_units++;
       if (bits != 3) { if (n_uns == 0) first_uns = c; n_uns++; }
     } else {
       if (lane == 0) { int *e = a.n1ent + 4 * c; e[0] = Tre; e[1] = Tim; e[2] = exr ? 1 : 0; e[3] = exi ? 1 : 0; }
     }
-    ls2_dcb_apply(Tre, exr, tr, er, c_re, m_re);
-    ls2_dcb_apply(Tim, exi, ti, ei, c_im, m_im);
+    {
+      int T2r = Tre, T2i = Tim; bool e2r = exr, e2i = exi;
+      ls2_dcb_apply(T2r, e2r, tr, er, c_re, m_re);
+      ls2_dcb_apply(T2i, e2i, ti, ei, c_im, m_im);
+      if (L == 2 && ((exr && !e2r) || (exi && !e2i)) && budget > 0) {   // (the block's table missed: through its units one by one)
+        budget--;
+        T2r = Tre; T2i = Tim; e2r = exr; e2i = exi;
+        ls2_dcb_through<1>(a, c, T2r, T2i, e2r, e2i, lane, budget);
+      }
+      Tre = T2r; Tim = T2i; exr = e2r; exi = e2i;
+    }
     if (ln < 0) break;
     l = ln; tr = ntr; ti = nti; er = ner; ei = nei;
   }
