@@ -1874,20 +1874,49 @@ RFID_DEVICE void ls2_dcb_through(const Ls2Args &a, const int node, int &Tre, int
   const int nper = (L == 1) ? a.dcb_n1 : a.dcb_n2;
   const int s = node / nper, k = node - s * nper;
   const int ch0 = s * kd.per_trace + 64 * k;
-  const int nch = (kd.per_trace - 64 * k < 64) ? (kd.per_trace - 64 * k) : 64;
-  for (int c = 0; c < nch; ++c) {
-    const int ch = ch0 + c;
-    const int valid = (L == 1) ? ((wv::uniform(a.dstat[ch]) >> 2) & 1) : wv::uniform(kd.val[ch]);
-    if (!valid) continue;
-    int T2r = Tre, T2i = Tim; bool e2r = exr, e2i = exi;
-    ls2_dcb_apply(T2r, e2r, kd.tab[(int64_t)(2 * ch) * 64 + lane], kd.exm ? wv::uniform(kd.exm[2 * ch]) : ~0ull, wv::uniform(kd.cen[2 * ch]), wv::uniform(kd.mar[2 * ch]));
-    ls2_dcb_apply(T2i, e2i, kd.tab[(int64_t)(2 * ch + 1) * 64 + lane], kd.exm ? wv::uniform(kd.exm[2 * ch + 1]) : ~0ull, wv::uniform(kd.cen[2 * ch + 1]), wv::uniform(kd.mar[2 * ch + 1]));
-    if (L == 2 && ((exr && !e2r) || (exi && !e2i)) && budget > 0) {
-      budget--;
-      T2r = Tre; T2i = Tim; e2r = exr; e2i = exi;
-      ls2_dcb_through<1>(a, ch, T2r, T2i, e2r, e2i, lane, budget);
+  const bool in = 64 * k + lane < kd.per_trace;
+  // the children's centres, margins and which of them exist: one load per lane; their tables four children ahead of the walk
+  // (none of the loads depends on the walk)
+  int valid = 0, cre = 0, cim = 0, mre = 0, mim = 0;
+  if (in) {
+    valid = (L == 1) ? ((a.dstat[ch0 + lane] >> 2) & 1) : kd.val[ch0 + lane];
+    if (valid) { cre = kd.cen[2 * (ch0 + lane)]; cim = kd.cen[2 * (ch0 + lane) + 1]; mre = kd.mar[2 * (ch0 + lane)]; mim = kd.mar[2 * (ch0 + lane) + 1]; }
+  }
+  uint64_t er_l = ~0ull, ei_l = ~0ull;
+  if (kd.exm && in && valid) { er_l = kd.exm[2 * (ch0 + lane)]; ei_l = kd.exm[2 * (ch0 + lane) + 1]; }
+  const uint64_t m = wv::ballot(valid != 0);
+  if (m == 0ull) return;
+  constexpr int AH = 4;
+  int tr[AH], ti[AH], lq[AH];
+  uint64_t rest = m;
+#pragma unroll
+  for (int u = 0; u < AH; ++u) {
+    lq[u] = rest ? wv::ffs64(rest) : -1;
+    if (rest) rest &= rest - 1ull;
+    const int c = (lq[u] >= 0) ? lq[u] : 0;
+    tr[u] = kd.tab[(int64_t)(2 * (ch0 + c)) * 64 + lane]; ti[u] = kd.tab[(int64_t)(2 * (ch0 + c) + 1) * 64 + lane];
+  }
+  for (;;) {
+#pragma unroll
+    for (int u = 0; u < AH; ++u) {
+      const int l = lq[u];
+      if (l < 0) return;
+      const int t_re = tr[u], t_im = ti[u];
+      lq[u] = rest ? wv::ffs64(rest) : -1;
+      if (rest) rest &= rest - 1ull;
+      { const int c = (lq[u] >= 0) ? lq[u] : 0; tr[u] = kd.tab[(int64_t)(2 * (ch0 + c)) * 64 + lane]; ti[u] = kd.tab[(int64_t)(2 * (ch0 + c) + 1) * 64 + lane]; }
+      const uint64_t er = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(er_l >> 32), l) << 32) | (uint32_t)wv::readlane((int)(uint32_t)er_l, l);
+      const uint64_t ei = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(ei_l >> 32), l) << 32) | (uint32_t)wv::readlane((int)(uint32_t)ei_l, l);
+      int T2r = Tre, T2i = Tim; bool e2r = exr, e2i = exi;
+      ls2_dcb_apply(T2r, e2r, t_re, er, wv::readlane(cre, l), wv::readlane(mre, l));
+      ls2_dcb_apply(T2i, e2i, t_im, ei, wv::readlane(cim, l), wv::readlane(mim, l));
+      if (L == 2 && ((exr && !e2r) || (exi && !e2i)) && budget > 0) {
+        budget--;
+        T2r = Tre; T2i = Tim; e2r = exr; e2i = exi;
+        ls2_dcb_through<1>(a, ch0 + l, T2r, T2i, e2r, e2i, lane, budget);
+      }
+      Tre = T2r; Tim = T2i; exr = e2r; exi = e2i;
     }
-    Tre = T2r; Tim = T2i; exr = e2r; exi = e2i;
   }
 }
 // up: the 64 children of node `node` of level L composed in order -> the node's table (on the window of its first child)
@@ -1926,22 +1955,33 @@ RFID_DEVICE void ls2_dcb_up(const Ls2Args &a, const int node, const int lane) {
     const int a0 = (d0 < 0) ? -d0 : d0, a1 = (d1 < 0) ? -d1 : d1;
     return (a0 > a1) ? a0 : a1;
   };
-  int tr, ti; uint64_t er, ei;
-  fetch(l, tr, ti, er, ei);
-  for (;;) {
-    const uint64_t rest = (l >= 63) ? 0ull : (m & ~((2ull << l) - 1ull));
-    const int ln = rest ? wv::ffs64(rest) : -1;
-    int ntr = 0, nti = 0; uint64_t ner = 0, nei = 0;
-    if (ln >= 0) fetch(ln, ntr, nti, ner, nei);   // (one child ahead: the loads do not depend on the walk)
-    const int c_re = wv::readlane(cre, l), c_im = wv::readlane(cim, l), m_re = wv::readlane(mre, l), m_im = wv::readlane(mim, l);
-    // an entry value D off the node's centre reaches this child D + dev off the child's: a plain shift all the way while that
-    // stays inside every child's margin
-    { const int q = m_re - dev(vre, c_re) - 1; nmr = (q < nmr) ? q : nmr; }
-    { const int q = m_im - dev(vim, c_im) - 1; nmi = (q < nmi) ? q : nmi; }
-    ls2_dcb_apply(vre, exr, tr, er, c_re, m_re);
-    ls2_dcb_apply(vim, exi, ti, ei, c_im, m_im);
-    if (ln < 0) break;
-    l = ln; tr = ntr; ti = nti; er = ner; ei = nei;
+  // (the children's tables four ahead of the walk: the loads do not depend on it)
+  constexpr int AH = 4;
+  int tr[AH], ti[AH], lq[AH]; uint64_t er[AH], ei[AH];
+  uint64_t rest = m;
+#pragma unroll
+  for (int u = 0; u < AH; ++u) {
+    lq[u] = rest ? wv::ffs64(rest) : -1;
+    if (rest) rest &= rest - 1ull;
+    fetch((lq[u] >= 0) ? lq[u] : l, tr[u], ti[u], er[u], ei[u]);
+  }
+  for (bool more = true; more;) {
+#pragma unroll
+    for (int u = 0; u < AH; ++u) {
+      const int lc = lq[u];
+      if (lc < 0) { more = false; break; }
+      const int t_re = tr[u], t_im = ti[u]; const uint64_t e_re = er[u], e_im = ei[u];
+      lq[u] = rest ? wv::ffs64(rest) : -1;
+      if (rest) rest &= rest - 1ull;
+      fetch((lq[u] >= 0) ? lq[u] : l, tr[u], ti[u], er[u], ei[u]);
+      const int c_re = wv::readlane(cre, lc), c_im = wv::readlane(cim, lc), m_re = wv::readlane(mre, lc), m_im = wv::readlane(mim, lc);
+      // an entry value D off the node's centre reaches this child D + dev off the child's: a plain shift all the way while that
+      // stays inside every child's margin
+      { const int q = m_re - dev(vre, c_re) - 1; nmr = (q < nmr) ? q : nmr; }
+      { const int q = m_im - dev(vim, c_im) - 1; nmi = (q < nmi) ? q : nmi; }
+      ls2_dcb_apply(vre, exr, t_re, e_re, c_re, m_re);
+      ls2_dcb_apply(vim, exi, t_im, e_im, c_im, m_im);
+    }
   }
   otab[(int64_t)(2 * node) * 64 + lane] = vre;
   otab[(int64_t)(2 * node + 1) * 64 + lane] = vim;
@@ -2041,45 +2081,56 @@ RFID_DEVICE void ls2_dcb_down(const Ls2Args &a, const int node, const int lane, 
     tr = kd.tab[(int64_t)(2 * (ch0 + c)) * 64 + lane]; ti = kd.tab[(int64_t)(2 * (ch0 + c) + 1) * 64 + lane];
     er = kd.exm ? wv::uniform(kd.exm[2 * (ch0 + c)]) : ~0ull; ei = kd.exm ? wv::uniform(kd.exm[2 * (ch0 + c) + 1]) : ~0ull;
   };
-  int l = wv::ffs64(m);
+  const int l0 = wv::ffs64(m);
   int budget = 64;
-  int tr, ti; uint64_t er, ei;
-  fetch(l, tr, ti, er, ei);
-  for (;;) {
-    const uint64_t rest = (l >= 63) ? 0ull : (m & ~((2ull << l) - 1ull));
-    const int ln = rest ? wv::ffs64(rest) : -1;
-    int ntr = 0, nti = 0; uint64_t ner = 0, nei = 0;
-    if (ln >= 0) fetch(ln, ntr, nti, ner, nei);
-    const int c_re = wv::readlane(cre, l), c_im = wv::readlane(cim, l), m_re = wv::readlane(mre, l), m_im = wv::readlane(mim, l);
-    const int c = ch0 + l;
-    if (L == 1) {
-      // settled: everything before is, and the unit's own start lies inside its window or its margin (its end, and dc_est at its
-      // gate openings, are then known: a table entry, or candidate 32's / 33's shifted along)
-      const int D_re = (int)((uint32_t)Tre - (uint32_t)c_re), D_im = (int)((uint32_t)Tim - (uint32_t)c_im);
-      const bool k_re = (D_re >= -LS2_DCB_HALF && D_re < LS2_DCB_HALF) || (D_re != (int)0x80000000 && ((D_re < 0) ? -D_re : D_re) <= m_re);
-      const bool k_im = (D_im >= -LS2_DCB_HALF && D_im < LS2_DCB_HALF) || (D_im != (int)0x80000000 && ((D_im < 0) ? -D_im : D_im) <= m_im);
-      const int bits = ((exr && k_re) ? 1 : 0) | ((exi && k_im) ? 2 : 0);
-      // (bit 3: the unit's latest run does not cover the start predicted for it -- it is run again, centred on that; a unit whose
-      // run does cover it only waits for the units before it)
-      if (lane == 0) { a.dT[2 * c] = Tre; a.dT[2 * c + 1] = Tim; a.dstat[c] = 4 | bits | ((k_re && k_im) ? 0 : 8) | (a.dstat[c] & 0x70); }
-      n_units++;
-      if (bits != 3) { if (n_uns == 0) first_uns = c; n_uns++; }
-    } else {
-      if (lane == 0) { int *e = a.n1ent + 4 * c; e[0] = Tre; e[1] = Tim; e[2] = exr ? 1 : 0; e[3] = exi ? 1 : 0; }
-    }
-    {
-      int T2r = Tre, T2i = Tim; bool e2r = exr, e2i = exi;
-      ls2_dcb_apply(T2r, e2r, tr, er, c_re, m_re);
-      ls2_dcb_apply(T2i, e2i, ti, ei, c_im, m_im);
-      if (L == 2 && ((exr && !e2r) || (exi && !e2i)) && budget > 0) {   // (the block's table missed: through its units one by one)
-        budget--;
-        T2r = Tre; T2i = Tim; e2r = exr; e2i = exi;
-        ls2_dcb_through<1>(a, c, T2r, T2i, e2r, e2i, lane, budget);
+  // (the children's tables four ahead of the walk: the loads do not depend on it)
+  constexpr int AH = 4;
+  int tr[AH], ti[AH], lq[AH]; uint64_t er[AH], ei[AH];
+  uint64_t rest = m;
+#pragma unroll
+  for (int u = 0; u < AH; ++u) {
+    lq[u] = rest ? wv::ffs64(rest) : -1;
+    if (rest) rest &= rest - 1ull;
+    fetch((lq[u] >= 0) ? lq[u] : l0, tr[u], ti[u], er[u], ei[u]);
+  }
+  for (bool more = true; more;) {
+#pragma unroll
+    for (int u = 0; u < AH; ++u) {
+      const int l = lq[u];
+      if (l < 0) { more = false; break; }
+      const int t_re = tr[u], t_im = ti[u]; const uint64_t e_re = er[u], e_im = ei[u];
+      lq[u] = rest ? wv::ffs64(rest) : -1;
+      if (rest) rest &= rest - 1ull;
+      fetch((lq[u] >= 0) ? lq[u] : l0, tr[u], ti[u], er[u], ei[u]);
+      const int c_re = wv::readlane(cre, l), c_im = wv::readlane(cim, l), m_re = wv::readlane(mre, l), m_im = wv::readlane(mim, l);
+      const int c = ch0 + l;
+      if (L == 1) {
+        // settled: everything before is, and the unit's own start lies inside its window or its margin (its end, and dc_est at its
+        // gate openings, are then known: a table entry, or candidate 32's / 33's shifted along)
+        const int D_re = (int)((uint32_t)Tre - (uint32_t)c_re), D_im = (int)((uint32_t)Tim - (uint32_t)c_im);
+        const bool k_re = (D_re >= -LS2_DCB_HALF && D_re < LS2_DCB_HALF) || (D_re != (int)0x80000000 && ((D_re < 0) ? -D_re : D_re) <= m_re);
+        const bool k_im = (D_im >= -LS2_DCB_HALF && D_im < LS2_DCB_HALF) || (D_im != (int)0x80000000 && ((D_im < 0) ? -D_im : D_im) <= m_im);
+        const int bits = ((exr && k_re) ? 1 : 0) | ((exi && k_im) ? 2 : 0);
+        // (bit 3: the unit's latest run does not cover the start predicted for it -- it is run again, centred on that; a unit whose
+        // run does cover it only waits for the units before it)
+        if (lane == 0) { a.dT[2 * c] = Tre; a.dT[2 * c + 1] = Tim; a.dstat[c] = 4 | bits | ((k_re && k_im) ? 0 : 8) | (a.dstat[c] & 0x70); }
+        n_units++;
+        if (bits != 3) { if (n_uns == 0) first_uns = c; n_uns++; }
+      } else {
+        if (lane == 0) { int *e = a.n1ent + 4 * c; e[0] = Tre; e[1] = Tim; e[2] = exr ? 1 : 0; e[3] = exi ? 1 : 0; }
       }
-      Tre = T2r; Tim = T2i; exr = e2r; exi = e2i;
+      {
+        int T2r = Tre, T2i = Tim; bool e2r = exr, e2i = exi;
+        ls2_dcb_apply(T2r, e2r, t_re, e_re, c_re, m_re);
+        ls2_dcb_apply(T2i, e2i, t_im, e_im, c_im, m_im);
+        if (L == 2 && ((exr && !e2r) || (exi && !e2i)) && budget > 0) {   // (the block's table missed: through its units one by one)
+          budget--;
+          T2r = Tre; T2i = Tim; e2r = exr; e2i = exi;
+          ls2_dcb_through<1>(a, c, T2r, T2i, e2r, e2i, lane, budget);
+        }
+        Tre = T2r; Tim = T2i; exr = e2r; exi = e2i;
+      }
     }
-    if (ln < 0) break;
-    l = ln; tr = ntr; ti = nti; er = ner; ei = nei;
   }
 }
 RFID_KERNEL(64) void ls2_dcb_down2_kernel(Ls2Args a) {
