@@ -1644,6 +1644,9 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
   // accumulated rounding (LS2_DCB_SLACK covers it).
   const uint32_t sbr = wv::f2u(ls2_from_ord(cre)), sbi = wv::f2u(ls2_from_ord(cim));
   int mre = ls2_margin(ls2_from_ord(cre), sbr), mim = ls2_margin(ls2_from_ord(cim), sbi);
+  const bool e0r_ok = ls2_e0_ok(sbr, sbr), e0i_ok = ls2_e0_ok(sbi, sbi);
+  Ls2MantRange rgr, rgi;
+  ls2_range_init(rgr); ls2_range_init(rgi);
   Ls2Win *wb = a.wb + (int64_t)s * a.wb_stride;
   // where the unit's gate openings go in a.dcand: reserved once (complete windows + the one a trace may end in)
   int wslot = 0;
@@ -1736,9 +1739,13 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
                      tre, tim);
         {
           const float c32r = wv::readlane(acc.x, LS2_DCB_HALF), c32i = wv::readlane(acc.y, LS2_DCB_HALF);
-          const int m1 = ls2_margin(c32r + wv::scan_add_f(tre), sbr), m2 = ls2_margin(c32i + wv::scan_add_f(tim), sbi);
-          mre = (m1 < mre) ? m1 : mre;
-          mim = (m2 < mim) ? m2 : mim;
+          const float pr = c32r + wv::scan_add_f(tre), pi = c32i + wv::scan_add_f(tim);
+          // (nearly every step stays in the start's binade: there the margin is the range of the mantissas, formed once behind the
+          // loop -- ls2_range_margin, as in ls2_avg_piece)
+          if (__builtin_expect(wv::ballot(((wv::f2u(pr) ^ sbr) & 0xff800000u) != 0u) == 0ull && e0r_ok, 1)) ls2_range_add(rgr, pr);
+          else { const int m1 = ls2_margin(pr, sbr); mre = (m1 < mre) ? m1 : mre; }
+          if (__builtin_expect(wv::ballot(((wv::f2u(pi) ^ sbi) & 0xff800000u) != 0u) == 0ull && e0i_ok, 1)) ls2_range_add(rgi, pi);
+          else { const int m2 = ls2_margin(pi, sbi); mim = (m2 < mim) ? m2 : mim; }
         }
         // the step's 64 increments in sample order (samples that are not closed: +0), added in that order by every lane to
         // its own candidate
@@ -1788,6 +1795,8 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
   }
   end_re = ls2_ord(acc.x); end_im = ls2_ord(acc.y);
   {
+    { const int q = ls2_range_margin(rgr, rgr); mre = (q < mre) ? q : mre; }
+    { const int q = ls2_range_margin(rgi, rgi); mim = (q < mim) ? q : mim; }
     mre = ls2_wave_min(mre) - LS2_DCB_SLACK; mim = ls2_wave_min(mim) - LS2_DCB_SLACK;
     // (the chain works on the integer image of binary32: a shift by D at the start is a shift by D at the end only if both lie in one binade)
     if (((wv::f2u(wv::readlane(acc.x, LS2_DCB_HALF)) ^ sbr) & 0xff800000u) != 0u || mre < 0) mre = 0;
@@ -1841,6 +1850,7 @@ RFID_KERNEL(64) void ls2_dcb_run_kernel(Ls2Args a) {
 // v -> the end of a node (unit, block, group) whose table lies across the lanes (lane j: the end for the start cen + j - 32):
 // inside the window a lookup; outside, the nearest candidate's end shifted along (a guess: ex goes false).  exm: the
 // candidates whose ends are themselves exact (a block's table entry is exact only if every lookup inside the block hit).
+template <bool UNIFORM = false>   // UNIFORM: v is the same in every lane (a walk): the lookup is a v_readlane instead of a ds_bpermute round trip
 RFID_DEVICE void ls2_dcb_apply(int &v, bool &ex, const int tab, const uint64_t exm, const int cen, const int mar) {
   const int D = (int)((uint32_t)v - (uint32_t)cen);
   const int o = D + LS2_DCB_HALF;
@@ -1850,7 +1860,7 @@ RFID_DEVICE void ls2_dcb_apply(int &v, bool &ex, const int tab, const uint64_t e
   const bool far = !inw && D != (int)0x80000000 && aD <= mar;
   const int par = D & 1;
   const int oc = inw ? o : (far ? (LS2_DCB_HALF + par) : ((o < 0) ? 0 : 63));
-  const int e = wv::shfl(tab, oc);
+  const int e = UNIFORM ? wv::readlane(tab, wv::uniform(oc)) : wv::shfl(tab, oc);
   ex = ex && (inw || far) && (((exm >> oc) & 1ull) != 0ull);
   v = (int)((uint32_t)e + (uint32_t)(o - oc));
 }
@@ -1908,8 +1918,8 @@ RFID_DEVICE void ls2_dcb_through(const Ls2Args &a, const int node, int &Tre, int
       const uint64_t er = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(er_l >> 32), l) << 32) | (uint32_t)wv::readlane((int)(uint32_t)er_l, l);
       const uint64_t ei = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(ei_l >> 32), l) << 32) | (uint32_t)wv::readlane((int)(uint32_t)ei_l, l);
       int T2r = Tre, T2i = Tim; bool e2r = exr, e2i = exi;
-      ls2_dcb_apply(T2r, e2r, t_re, er, wv::readlane(cre, l), wv::readlane(mre, l));
-      ls2_dcb_apply(T2i, e2i, t_im, ei, wv::readlane(cim, l), wv::readlane(mim, l));
+      ls2_dcb_apply<true>(T2r, e2r, t_re, er, wv::readlane(cre, l), wv::readlane(mre, l));
+      ls2_dcb_apply<true>(T2i, e2i, t_im, ei, wv::readlane(cim, l), wv::readlane(mim, l));
       if (L == 2 && ((exr && !e2r) || (exi && !e2i)) && budget > 0) {
         budget--;
         T2r = Tre; T2i = Tim; e2r = exr; e2i = exi;
@@ -2043,8 +2053,8 @@ RFID_KERNEL(64) void ls2_dcb_top_kernel(Ls2Args a) {
     if (wv::uniform(val[node]) != 0) {
       if (lane == 0) { ent[4 * node] = Tre; ent[4 * node + 1] = Tim; ent[4 * node + 2] = exr ? 1 : 0; ent[4 * node + 3] = exi ? 1 : 0; }
       int T2r = Tre, T2i = Tim; bool e2r = exr, e2i = exi;
-      ls2_dcb_apply(T2r, e2r, tr, wv::uniform(exm[2 * node]), wv::uniform(cen[2 * node]), wv::uniform(mar[2 * node]));
-      ls2_dcb_apply(T2i, e2i, ti, wv::uniform(exm[2 * node + 1]), wv::uniform(cen[2 * node + 1]), wv::uniform(mar[2 * node + 1]));
+      ls2_dcb_apply<true>(T2r, e2r, tr, wv::uniform(exm[2 * node]), wv::uniform(cen[2 * node]), wv::uniform(mar[2 * node]));
+      ls2_dcb_apply<true>(T2i, e2i, ti, wv::uniform(exm[2 * node + 1]), wv::uniform(cen[2 * node + 1]), wv::uniform(mar[2 * node + 1]));
       if (((exr && !e2r) || (exi && !e2i)) && budget > 0) {
         // the node's table missed an exact entry value: through its children one by one (they may all be hit)
         budget--;
@@ -2121,8 +2131,8 @@ RFID_DEVICE void ls2_dcb_down(const Ls2Args &a, const int node, const int lane, 
       }
       {
         int T2r = Tre, T2i = Tim; bool e2r = exr, e2i = exi;
-        ls2_dcb_apply(T2r, e2r, t_re, e_re, c_re, m_re);
-        ls2_dcb_apply(T2i, e2i, t_im, e_im, c_im, m_im);
+        ls2_dcb_apply<true>(T2r, e2r, t_re, e_re, c_re, m_re);
+        ls2_dcb_apply<true>(T2i, e2i, t_im, e_im, c_im, m_im);
         if (L == 2 && ((exr && !e2r) || (exi && !e2i)) && budget > 0) {   // (the block's table missed: through its units one by one)
           budget--;
           T2r = Tre; T2i = Tim; e2r = exr; e2i = exi;
@@ -2211,8 +2221,8 @@ RFID_KERNEL(64 * LS2_DCB_FIN_WAVES) void ls2_dcb_finish_kernel(Ls2Args a) {
         const int tp = t0 + prev;
         Tre = wv::uniform(a.dT[2 * tp]); Tim = wv::uniform(a.dT[2 * tp + 1]);
         bool exr = true, exi = true;
-        ls2_dcb_apply(Tre, exr, a.dtab[(int64_t)(2 * tp) * 64 + lane], ~0ull, wv::uniform(a.dcen[2 * tp]), wv::uniform(a.dmar[2 * tp]));
-        ls2_dcb_apply(Tim, exi, a.dtab[(int64_t)(2 * tp + 1) * 64 + lane], ~0ull, wv::uniform(a.dcen[2 * tp + 1]), wv::uniform(a.dmar[2 * tp + 1]));
+        ls2_dcb_apply<true>(Tre, exr, a.dtab[(int64_t)(2 * tp) * 64 + lane], ~0ull, wv::uniform(a.dcen[2 * tp]), wv::uniform(a.dmar[2 * tp]));
+        ls2_dcb_apply<true>(Tim, exi, a.dtab[(int64_t)(2 * tp + 1) * 64 + lane], ~0ull, wv::uniform(a.dcen[2 * tp + 1]), wv::uniform(a.dmar[2 * tp + 1]));
         if (!(exr && exi)) { if (lane == 0) ctl->fail = 7; first = -1; }   // (a settled unit's end is exact by definition)
       }
     }
@@ -2261,8 +2271,8 @@ RFID_KERNEL(64 * LS2_DCB_FIN_WAVES) void ls2_dcb_finish_kernel(Ls2Args a) {
         if (lane == 0) { a.dT[2 * tw] = Tre; a.dT[2 * tw + 1] = Tim; a.dstat[tw] = 7; }
         fixed++;
         bool exr = true, exi = true;
-        ls2_dcb_apply(Tre, exr, sh_tab[w][0][lane], ~0ull, c_re, m_re);
-        ls2_dcb_apply(Tim, exi, sh_tab[w][1][lane], ~0ull, c_im, m_im);
+        ls2_dcb_apply<true>(Tre, exr, sh_tab[w][0][lane], ~0ull, c_re, m_re);
+        ls2_dcb_apply<true>(Tim, exi, sh_tab[w][1][lane], ~0ull, c_im, m_im);
       }
       if (lane == 0) {
         sh_pos = pos + w; sh_T[0] = Tre; sh_T[1] = Tim; sh_corr[0] = corr_re; sh_corr[1] = corr_im; sh_fixed += fixed;
