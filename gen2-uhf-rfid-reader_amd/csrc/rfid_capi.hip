@@ -54,7 +54,6 @@ struct DevBuf {
 // (g_knob_table below) names them: INTEGRATION.md section 13 is that table.
 struct RfidKnobs {
   int long_stream = 1;     // RFID_LONG_STREAM       0 never, 1 automatic (cost model), 2 whenever a trace can be cut
-  int ls_fused = 1;        // RFID_LS_FUSED          long-stream front end: 1 the matched filter inside its first launch, 0 round 4's list
   int overlap = 1;         // RFID_OVERLAP           0 one stream only, 1 the next pass's first launches on the second stream, 2 ... and a
                            //                        second result set (decoder beside the next front end; fused front end, many traces)
   int ls_calibrate = 1;    // RFID_LS_CALIBRATE      0: keep the built-in cost model (profiled runs)
@@ -65,11 +64,8 @@ struct RfidKnobs {
   int front_chunks = 1;    // RFID_FRONT_CHUNKS      2..16: the time-chunked stage kernels on two streams (round 1's overlap)
   int fsm_lanes_min = -1;  // RFID_LS2_FSM_LANES_MIN from how many possible units on the state machine runs one lane per unit (-1: 8192)
   int dc_rounds = -1;      // RFID_LS2_DC_ROUNDS     0..64: dc_est rounds a long-stream pass enqueues behind the first (-1: 3; what they leave, the finishing walk takes)
-  // ---- experiment knobs of round 4's list (RFID_LS_FUSED=0), kept for its A/B tables ----
   int la_upload_kernel = 1;  // RFID_LA_UPLOAD_KERNEL  look-ahead: 1 a call's samples are fetched from page-locked memory by a launch, 0 by a transfer
   int front_lds_kb = -1;   // RFID_LS_FRONT_LDS_KB   0..64: extra LDS per workgroup of the long-stream first pass (caps its waves per CU); -1: 10 for long traces
-  int mf_parts = 3;        // RFID_MF_PARTS          1..8 launches of the next pass's matched filter
-  int mf_split[8] = {35, 45, 20, 0, 0, 0, 0, 0};   // RFID_MF_SPLIT  their shares in percent (comma list, each 0..100, sum <= 100 + rest to the last)
 };
 
 struct rfid_ctx {
@@ -94,7 +90,7 @@ struct rfid_ctx {
   DevBuf ls2_ws_alt;              // a second one (rfid_batch_plan, where the device has the room): with it and a second matched-filter
                                   // output buffer the first launches of pass k + 1 -- the fused first pass: they touch the raw samples,
                                   // y and the work space only -- run on stream2 beside the rest of pass k; the two are used alternately
-  bool ls2_mark_failed = false, ls2_gap_marks = false;   // (scratch of ls_enqueue's call-back)
+  bool ls2_mark_failed = false;   // (scratch of ls_enqueue's call-back)
   bool y_touched = false;         // work outside that protocol has used c->d_y on the main stream since the last such pass
   Ls2Ctl *ls2_host = nullptr;     // page-locked copy of the control block of the last pass (report) + consumed[0]
   Ls2Ctl *d_ls2_ctl = nullptr;    // the control block of the last pass that ran the front end (device), else nullptr
@@ -283,10 +279,6 @@ struct rfid_ctx {
   // (long-stream passes: only the matched-filter output alternates -- the filter of pass k + 1 beside the front end of pass k)
   void *alt_y_blk = nullptr;                // a second matched-filter output buffer alone (plans too small for a whole second set)
   hipEvent_t ev_y_free[2] = {nullptr, nullptr};
-  // long-stream passes enqueued back to back: points of a pass behind which most of the device idles (0: the small avg_ampl
-  // rounds, 1: the dc_est re-runs, 2: the decoder): the next pass's matched filter runs in parts, the later ones behind them
-  hipEvent_t ev_gap[3] = {nullptr, nullptr, nullptr};
-  bool gap_recorded[3] = {false, false, false};
   bool y_recorded[2] = {false, false};
   int y_idx = 0;
   hipStream_t tail_stream = nullptr;        // where rfid_batch_decode / rfid_batch_stats enqueue (c->stream, or stream2 in an overlapped pass)
@@ -320,7 +312,6 @@ int fail(rfid_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
 struct KnobEntry { const char *name, *env; int RfidKnobs::*field; int lo, hi; };
 const KnobEntry g_knob_table[] = {
   {"long_stream", "RFID_LONG_STREAM", &RfidKnobs::long_stream, 0, 2},
-  {"ls_fused", "RFID_LS_FUSED", &RfidKnobs::ls_fused, 0, 1},
   {"overlap", "RFID_OVERLAP", &RfidKnobs::overlap, 0, 2},
   {"ls_calibrate", "RFID_LS_CALIBRATE", &RfidKnobs::ls_calibrate, 0, 1},
   {"ls_debug", "RFID_LS_DEBUG", &RfidKnobs::ls_debug, 0, 1},
@@ -331,7 +322,6 @@ const KnobEntry g_knob_table[] = {
   {"dc_rounds", "RFID_LS2_DC_ROUNDS", &RfidKnobs::dc_rounds, -1, 64},
   {"la_upload_kernel", "RFID_LA_UPLOAD_KERNEL", &RfidKnobs::la_upload_kernel, 0, 1},
   {"front_lds_kb", "RFID_LS_FRONT_LDS_KB", &RfidKnobs::front_lds_kb, -1, 64},
-  {"mf_parts", "RFID_MF_PARTS", &RfidKnobs::mf_parts, 1, 8},
 };
 int clamp_int(long v, int lo, int hi) { return (int)(v < lo ? lo : (v > hi ? hi : v)); }
 // the environment, once per context: values out of range are clamped, anything that is not a number is ignored
@@ -343,19 +333,6 @@ void knobs_from_env(RfidKnobs &k) {
     const long x = strtol(v, &end, 10);
     if (end == v) continue;
     k.*(e.field) = clamp_int(x, e.lo, e.hi);
-  }
-  if (const char *v = getenv("RFID_MF_SPLIT")) {   // "35,45,20": at most eight shares, each 0..100; what is missing to 100 goes to the last launch
-    int share[8] = {0, 0, 0, 0, 0, 0, 0, 0}, n = 0, sum = 0;
-    bool ok = true;
-    for (const char *q = v; *q && n < 8 && ok;) {
-      char *end = nullptr;
-      const long x = strtol(q, &end, 10);
-      if (end == q || x < 0 || x > 100) { ok = false; break; }
-      share[n++] = (int)x; sum += (int)x;
-      q = end;
-      if (*q == ',') ++q; else if (*q) ok = false;
-    }
-    if (ok && n > 0 && sum <= 100) for (int i = 0; i < 8; ++i) k.mf_split[i] = share[i];
   }
 }
 
@@ -515,7 +492,6 @@ struct LsOpts {
   bool hold_last = false;   // leave each trace's last piece unprocessed (streaming: whatever follows the last idle cut
                             // waits for more samples)
   bool force = false;       // run even when no trace could be cut more than once
-  bool marks = false;       // record c->ev_gap[0 / 1] at the list's two quiet points (rfid_batch_process with a second filter buffer)
   bool ahead = false;       // (fused first pass) its launches on stream2 and in the work space the pass before did not use; the rest of the
                             // list on the main stream behind them
   // the fused first pass (ls2_front_kernel): the raw samples in HBM -- the matched filter runs inside the front end's first
@@ -597,13 +573,9 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
       }
       return;
     }
-    if (!cc->ls2_gap_marks) return;
-    if (hipEventRecord(cc->ev_gap[pt], cc->stream) == hipSuccess) cc->gap_recorded[pt] = true;
-    else (void)hipGetLastError();
   };
   c->ls2_mark_failed = false;
-  c->ls2_gap_marks = opt.marks;
-  ls2_enqueue(a, true, c->ls2_rounds, c->ls2_generous, c->knobs.dc_rounds, (opt.marks || ahead) ? +mark : nullptr, c);
+  ls2_enqueue(a, true, c->ls2_rounds, c->ls2_generous, c->knobs.dc_rounds, ahead ? +mark : nullptr, c);
   ls2_stream = c->stream;
   HIPCHK(c, hipGetLastError());
   if (c->ls2_mark_failed) return fail(c, RFID_ERR_HIP, "long-stream front end: stream hand-over");
@@ -878,10 +850,7 @@ int rfid_ctx_create(const rfid_params *p, int device, rfid_ctx **out) {
                 hipEventCreateWithFlags(&c->ev_tail_done[0], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&c->ev_tail_done[1], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&c->ev_y_free[0], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&c->ev_y_free[1], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&c->ev_gap[0], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&c->ev_gap[1], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&c->ev_gap[2], hipEventDisableTiming) != hipSuccess))
+                hipEventCreateWithFlags(&c->ev_y_free[1], hipEventDisableTiming) != hipSuccess))
       rc = RFID_ERR_HIP;
     if (rc) break;
     {
@@ -939,9 +908,7 @@ int rfid_ctx_destroy(rfid_ctx *c) {
     for (int i = 0; i < 2; ++i) {
       if (c->ev_tail_done[i]) (void)hipEventDestroy(c->ev_tail_done[i]);
       if (c->ev_y_free[i]) (void)hipEventDestroy(c->ev_y_free[i]);
-      if (c->ev_gap[i]) (void)hipEventDestroy(c->ev_gap[i]);
     }
-    if (c->ev_gap[2]) (void)hipEventDestroy(c->ev_gap[2]);
     (void)hipStreamDestroy(c->stream2);
   }
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1214,7 +1181,7 @@ int rfid_batch_plan(rfid_ctx *c, int n_streams, int64_t max_raw) {
     }
     // ... and a second work space beside the second filter output buffer (the fused first pass of the next pass beside the
     // rest of this one, rfid_batch_process), where it is small beside what is free
-    if (c->alt.d_y && !c->alt_have && c->knobs.ls_fused && (c->knobs.overlap != 0) && c->ls2_ws.p && need > c->ls2_ws_alt.cap) {
+    if (c->alt.d_y && !c->alt_have && (c->knobs.overlap != 0) && c->ls2_ws.p && need > c->ls2_ws_alt.cap) {
       size_t free_b = 0, total_b = 0;
       if (c->ls2_ws_alt.p) (void)hipFree(c->ls2_ws_alt.p);
       c->ls2_ws_alt.p = nullptr; c->ls2_ws_alt.cap = 0;
@@ -1238,8 +1205,7 @@ int rfid_batch_set_streams(rfid_ctx *c, int n_streams) {
   return RFID_OK;
 }
 
-static int batch_mf_on(rfid_ctx *c, hipStream_t stream, const void *d_raw, int64_t raw_stride, int64_t n_raw, const void *d_lens,
-                       int n_parts = 1, const hipEvent_t *part_waits = nullptr, const bool *part_have = nullptr);
+static int batch_mf_on(rfid_ctx *c, hipStream_t stream, const void *d_raw, int64_t raw_stride, int64_t n_raw, const void *d_lens);
 int rfid_batch_mf(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64_t n_raw, const void *d_lens) {
   if (!c || !d_raw || n_raw < 0 || raw_stride < n_raw) return RFID_ERR_INVALID;
   if (!c->B) return RFID_ERR_STATE;
@@ -1249,9 +1215,7 @@ int rfid_batch_mf(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64_t n_
   c->y_touched = true;
   return batch_mf_on(c, c->stream, d_raw, raw_stride, n_raw, d_lens);
 }
-// n_parts > 1: the output tiles in that many launches, launch i >= 1 behind part_waits[i - 1] (when part_have[i - 1])
-static int batch_mf_on(rfid_ctx *c, hipStream_t stream, const void *d_raw, int64_t raw_stride, int64_t n_raw, const void *d_lens,
-                       int n_parts, const hipEvent_t *part_waits, const bool *part_have) {
+static int batch_mf_on(rfid_ctx *c, hipStream_t stream, const void *d_raw, int64_t raw_stride, int64_t n_raw, const void *d_lens) {
   c->d_lens = (const int64_t *)d_lens;
   c->last_n_raw = n_raw;
   MfArgs a;
@@ -1263,32 +1227,11 @@ static int batch_mf_on(rfid_ctx *c, hipStream_t stream, const void *d_raw, int64
   c->fused_last = 0;
   HIPCHK(c, hipEventRecord(c->ev[0], stream));
   const int64_t tiles = (a.n_out + MF_TILE - 1) / MF_TILE;
-  if (n_parts < 1 || tiles < 1024 * (int64_t)n_parts) n_parts = 1;
-  // (shares of the parts in percent: what the quiet stretches behind the points take, profiles/r04/ls2_second_half.txt)
-  int share[8];
-  if (n_parts > 8) n_parts = 8;
-  for (int k = 0; k < 8; ++k) share[k] = c->knobs.mf_split[k];
-  {   // (the default shares are for three launches; another count without shares of its own: equal parts)
-    int given = 0;
-    for (int k = 0; k < 8; ++k) given += share[k] > 0;
-    if (given != n_parts) for (int k = 0; k < 8; ++k) share[k] = (k < n_parts) ? 100 / n_parts : 0;
-  }
-  int64_t t_next = 0;
-  int acc = 0;
-  for (int part = 0; part < n_parts && tiles > 0; ++part) {
-    acc += share[part];
-    const int64_t t_lo = t_next, t_hi = (part == n_parts - 1 || acc >= 100) ? tiles : (tiles * acc / 100);
-    t_next = t_hi;
-    if (t_lo >= t_hi) continue;
-    if (part > 0 && part_waits && part_have && part_have[part - 1]) HIPCHK(c, hipStreamWaitEvent(stream, part_waits[part - 1], 0));
-    a.tile0 = t_lo;
-    for (int s0 = 0; s0 < c->B; s0 += 65535) {   // gridDim.y limit
-      a.stream0 = s0;
-      const int ns = (c->B - s0 < 65535) ? (c->B - s0) : 65535;
-      hipLaunchKernelGGL(mf_boxcar25_decim5_kernel, dim3((unsigned)(t_hi - t_lo), (unsigned)ns), dim3(MF_THREADS), 0,
-                         stream, a);
-      HIPCHK(c, hipGetLastError());
-    }
+  for (int s0 = 0; s0 < c->B && tiles > 0; s0 += 65535) {   // gridDim.y limit
+    a.stream0 = s0;
+    const int ns = (c->B - s0 < 65535) ? (c->B - s0) : 65535;
+    hipLaunchKernelGGL(mf_boxcar25_decim5_kernel, dim3((unsigned)tiles, (unsigned)ns), dim3(MF_THREADS), 0, stream, a);
+    HIPCHK(c, hipGetLastError());
   }
   HIPCHK(c, hipEventRecord(c->ev[1], stream));
   c->ev_valid[0] = c->ev_valid[1] = true;
@@ -1405,7 +1348,7 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
     // front end's first launch filters the raw samples itself (ls2_front_kernel), one sweep over the raw samples instead of the
     // filter's and three over its output.  When the front end gives up the sequential scan behind it needs all of y: a filter
     // launch and the scan are enqueued behind the list, both skipping themselves on Ls2Ctl::ok.
-    if (c->knobs.ls_fused && raw_stride >= 2) {
+    if (raw_stride >= 2) {
       c->d_lens = (const int64_t *)d_lens;
       c->last_n_raw = n_raw;
       c->n_chunks_last = 0;
@@ -1471,46 +1414,16 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
       }
       // (no work space: the plain sequence below)
     }
-    const bool ahead = c->alt.d_y != nullptr;
-    if (ahead) {
-      // The matched filter is bound by the HBM, the long-stream front end behind it by its instruction streams: with a second
-      // matched-filter output buffer the filter of THIS pass runs on stream2 while the front end / decoder / statistics of the
-      // pass before are still at work on the main stream (passes enqueued back to back); the main stream only waits for it.
-      std::swap(c->d_y, c->alt.d_y);
-      c->y_idx ^= 1;
-      if (c->y_recorded[c->y_idx]) {      // the pass before last read this buffer: through with it?
-        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_y_free[c->y_idx], 0));
-        c->y_recorded[c->y_idx] = false;
-      }
-      // ... in three parts (35 / 45 / 20 % of the output tiles): the first at once, the others behind the two points of the pass
-      // before from where on most of the device idles (its small avg_ampl rounds and state machine; its dc_est re-runs, assembly
-      // and decoder) -- beside the big launches, which move 2 - 4 TB/s themselves, the filter gains little.  Measured on
-      // configs[2], passes enqueued back to back: 10.4 -> 10.07 ms, and 9.5 - 9.6 with chain launches of 512 instead of 1 024 threads
-      // (which starved beside the filter) (profiles/r04/ls2_second_half.txt; RFID_MF_PARTS /
-      // RFID_MF_SPLIT are the experiment's knobs).
-      if ((rc = batch_mf_on(c, c->stream2, d_raw, raw_stride, n_raw, d_lens, c->knobs.mf_parts, c->ev_gap, c->gap_recorded))) return rc;
-      HIPCHK(c, hipEventRecord(c->ev_fe_done, c->stream2));
-      HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fe_done, 0));
-    } else {
-      c->y_touched = true;
-      if ((rc = batch_mf_on(c, c->stream, d_raw, raw_stride, n_raw, d_lens))) return rc;
-    }
+    // (rows of a single raw sample, or no work space for the fused first pass: the matched filter by itself, then the front end over
+    // its output -- the list the streaming calls use)
+    c->y_touched = true;
+    if ((rc = batch_mf_on(c, c->stream, d_raw, raw_stride, n_raw, d_lens))) return rc;
     int enq = 0;
     LsOpts lo;
-    lo.marks = ahead;
     if ((rc = ls_enqueue(c, n_out, lo, &enq))) return rc;
     if ((rc = rfid_batch_gate_impl(c, enq ? &c->d_ls2_ctl->ok : nullptr))) return rc;
-    if (ahead) {
-      if (hipEventRecord(c->ev_gap[2], c->stream) == hipSuccess) c->gap_recorded[2] = true;
-      else (void)hipGetLastError();
-    }
     if ((rc = rfid_batch_decode(c, want_scores))) return rc;
-    if ((rc = rfid_batch_stats(c))) return rc;
-    if (ahead) {
-      HIPCHK(c, hipEventRecord(c->ev_y_free[c->y_idx], c->stream));
-      c->y_recorded[c->y_idx] = true;
-    }
-    return RFID_OK;
+    return rfid_batch_stats(c);
   }
   c->d_ls2_ctl = nullptr;   // (this pass does not run the long-stream front end)
   c->y_touched = true;

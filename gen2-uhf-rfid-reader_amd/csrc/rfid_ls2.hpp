@@ -184,14 +184,7 @@ struct Ls2Args {
 // device with the NEXT pass's first pass; most of them are short strings of dependent instructions in few waves, and a wave
 // that shares its SIMD with four or five waves of the big kernel gets every fifth issue slot.  LS2_TAIL_PRIO_N > 0: they
 // raise their waves' priority (s_setprio) -- measured in profiles/r05/ls2_overlap.txt
-#ifndef LS2_TAIL_PRIO_N
-#define LS2_TAIL_PRIO_N 0
-#endif
-RFID_DEVICE void ls2_tail_prio() {
-#if LS2_TAIL_PRIO_N > 0
-  wv::set_priority<LS2_TAIL_PRIO_N>();
-#endif
-}
+RFID_DEVICE void ls2_tail_prio() {}   // (s_setprio 2 / 3 for these launches: measured, no gain -- profiles/r05/ls2_fused_front.txt)
 RFID_DEVICE int ls2_ord(float f) {   // monotone integer image of a binary32 value: distance = ulps
   const uint32_t u = wv::f2u(f);
   return (u & 0x80000000u) ? -(int)(u & 0x7fffffffu) : (int)u;
@@ -707,10 +700,7 @@ RFID_DEVICE Ls2A32 ls2_wave_excl(const Ls2A32 incl, int lane) {
 // before runs on through every block up to that same boundary: it evaluates the same rule on the same values.  Every
 // block's not-carrier mask goes to HBM (8 B per 64 samples) and ls2_idle_cut_kernel finds the units' idle cuts in them.
 constexpr int LS2_FRONT_PRE = 3;         // blocks filtered in front of a slot's grid point: one for its maximum, two that must be quiet
-#ifndef LS2_FRONT_AHEAD_N
-#define LS2_FRONT_AHEAD_N 2
-#endif
-constexpr int LS2_FRONT_AHEAD = LS2_FRONT_AHEAD_N;   // blocks of raw samples in flight per wave (12 VGPRs each)
+constexpr int LS2_FRONT_AHEAD = 2;   // blocks of raw samples in flight per wave (12 VGPRs each)
 constexpr int LS2_FRONT_GIVE_UP = 32;    // a piece that has found no rest point within this many nominal lengths gives the pass up (the sequential scan takes over)
 constexpr float LS2_CARRIER_FRAC2 = 0.7225f;
 
@@ -736,14 +726,8 @@ RFID_DEVICE uint32_t ls2_wave_max_bits(uint32_t v) {   // (values below 2^31: bi
 // the single-pass scan with decoupled look-back -- but only for the GUESS: functions of pieces whose runs are not proven are
 // off by an ulp or two, nothing here is trusted, the chain kernels behind this pass prove every start as before.
 // (Workgroup b takes slot b: the dispatch order is the trace's order, a wave only ever waits for slots before its own.)
-#ifndef LS2_LB_N
-#define LS2_LB_N 1
-#endif
-constexpr bool LS2_LB = LS2_LB_N != 0;   // (0: experiment builds without the look-back; slots then an eighth per XCD as ls2_avg_first_kernel)
-#ifndef LS2_LB_WINDOWS_N
-#define LS2_LB_WINDOWS_N 64
-#endif
-constexpr int LS2_LB_WINDOWS = LS2_LB_WINDOWS_N;   // at most this many steps back (4 096 slots: more than are in flight)
+constexpr bool LS2_LB = true;
+constexpr int LS2_LB_WINDOWS = 64;   // at most this many steps back (4 096 slots: more than are in flight)
 // (one 8-byte word per slot and kind, written once with a device-coherent store and read with device-coherent loads: no
 // flag beside the data, no release / acquire -- see wv::store_u64_agent)
 RFID_DEVICE void ls2_lb_publish_fn(const Ls2Args &a, const int i, const Ls2A32 f, const int lane) {
@@ -992,15 +976,7 @@ RFID_DEVICE void ls2_front_piece(const Ls2Args &a, const int i, const int lane, 
     }
   }
 }
-#ifndef LS2_FRONT_OCC_N
-#define LS2_FRONT_OCC_N 0
-#endif
-#if LS2_FRONT_OCC_N > 0
-RFID_KERNEL_OCC(64, LS2_FRONT_OCC_N)
-#else
-RFID_KERNEL(64)
-#endif
-void ls2_front_kernel(Ls2Args a) {
+RFID_KERNEL(64) void ls2_front_kernel(Ls2Args a) {
   RFID_SHARED float4 tile4[64 * GATE_RAW_LD];
   const int lane = wv::lane_id();
   const int NS = a.n_streams * a.max_b;
@@ -1388,14 +1364,8 @@ RFID_KERNEL(64) void ls2_fsm_kernel(Ls2Args a) {
 // instruction; a lane walks its unit step by step -- the steps of an idle gate and the inside of a window are taken in
 // runs, as above -- and fetches the vote words one step ahead.  No wave-level operation below the first line: lanes come and
 // go as their units end.
-#ifndef LS2_FSM_LANES_N
-#define LS2_FSM_LANES_N 16
-#endif
-#ifndef LS2_FSM_GROUP_N
-#define LS2_FSM_GROUP_N 16
-#endif
-constexpr int LS2_FSM_GROUP = LS2_FSM_GROUP_N;   // steps whose vote words are fetched together
-constexpr int LS2_FSM_LANES = LS2_FSM_LANES_N;   // units per wave: a wave's pace is its slowest lane's and the walk is bound by the latency of
+constexpr int LS2_FSM_GROUP = 16;   // steps whose vote words are fetched together
+constexpr int LS2_FSM_LANES = 16;   // units per wave: a wave's pace is its slowest lane's and the walk is bound by the latency of
                                       // its scattered loads, so fewer units per wave and more waves per CU
 RFID_KERNEL(64) void ls2_fsm_lanes_kernel(Ls2Args a) {
   ls2_tail_prio();

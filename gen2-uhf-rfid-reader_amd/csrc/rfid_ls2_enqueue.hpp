@@ -13,10 +13,7 @@
 
 namespace rfidk {
 
-#ifndef LS2_TARGET_PIECES_N                // (experiment builds: make EXTRA_DEFS=-DLS2_TARGET_PIECES_N=...)
-#define LS2_TARGET_PIECES_N 131072
-#endif
-constexpr int LS2_TARGET_PIECES = LS2_TARGET_PIECES_N;  // pieces per pass to aim for (all traces together)
+constexpr int LS2_TARGET_PIECES = 131072;  // pieces per pass to aim for (all traces together)
 constexpr int LS2_MIN_PIECE = 512;         // ... of at least this many decimated samples; idle cuts are searched every LS2_FINE pieces
                                            // (a cut needs LS_QUIET = 1615 idle samples before it)
 
@@ -130,11 +127,9 @@ inline int &ls2_dcb_bias() { static int v = 0; return v; }   // (tests: Ls2Args:
 // One pass (its first launch zeroes Ls2Ctl, the chain flags, the votes, the window buckets and flat_count).  `a` complete but for
 // `round`.  After it: wtab / wcount / flat lists + Ls2Ctl::ok = 1, or ok = 0 (the caller's fallback scan, enqueued
 // behind with GateArgs::skip_if = &ctl->ok, then runs).
-// mark / mark_arg: optional call-back at points of the list (0: behind the first avg_ampl re-run round, 1: behind the first
-// dc_est pass) -- from there on the launches are small and most of the device idles; the library records events there and
-// lets parts of the NEXT pass's matched filter start behind them; 2 (fused first pass only): behind the launches that touch
-// nothing but the raw samples, y and the pass's own work space -- the library runs those on a second stream, beside the rest
-// of the pass before, and changes streams here
+// mark / mark_arg: optional call-back (fused first pass only; point 2: behind the launches that touch nothing but the raw samples,
+// y and the pass's own work space -- the library runs those on a second stream, beside the rest of the pass before, and changes
+// streams here)
 // dc_rounds: dc_est rounds to enqueue (< 0: by the pass's size; the library passes what the passes before needed)
 inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nullptr, bool generous = false, int dc_rounds = -1,
                         void (*mark)(void *, int) = nullptr, void *mark_arg = nullptr) {   // (search_cuts = false: a.cut is given -- tests)
@@ -213,7 +208,6 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
     LS2_LAUNCH(ls2_avg_rerun_kernel, rerun_grid(r, 32768), 1, 64, a);
     a.stamp++;
     LS2_LAUNCH(ls2_avg_chain_kernel, g_avg, B, LS2_CHAIN_THREADS, a);
-    if (r == 1 && mark) mark(mark_arg, 0);
   }
   for (int r = 0; r <= a.fsm_rounds; ++r) {
     a.round = r;
@@ -233,7 +227,6 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
       LS2_LAUNCH(ls2_dcb_top_kernel, B, 1, 64, U(a));
       if (a.dcb_top == 2) LS2_LAUNCH(ls2_dcb_down2_kernel, N2, 1, 64, U(a));
       LS2_LAUNCH(ls2_dcb_down1_kernel, N1, 1, 64, U(a));
-      if (r == 0 && mark) mark(mark_arg, 1);
     }
     a.round = 0;
     LS2_LAUNCH(ls2_dcb_finish_kernel, B, 1, 64 * LS2_DCB_FIN_WAVES, U(a));

@@ -250,7 +250,7 @@ class Context:
 
     def set_knob(self, name: str, value: int) -> None:
         """One of the switches the environment sets at context creation, by its lower-case name
-        without the RFID_ prefix: ctx.set_knob("ls_fused", 0)."""
+        without the RFID_ prefix: ctx.set_knob("overlap", 0)."""
         self._chk(self._lib.rfid_ctx_set_knob(self._h, name.encode(), int(value)))
 
     def get_knob(self, name: str) -> int:

@@ -397,11 +397,11 @@ RFID_API int rfid_batch_process(rfid_ctx *ctx, const void *d_raw, int64_t raw_st
  * rfid_batch_ls_report synchronises with the pass. */
 RFID_API int rfid_batch_set_long_stream(rfid_ctx *ctx, int mode);
 RFID_API int rfid_batch_ls_report(const rfid_ctx *ctx, rfid_ls_report *out);
-/* The switches the environment can set (INTEGRATION.md section 13 lists them: RFID_LONG_STREAM, RFID_LS_FUSED, RFID_OVERLAP,
- * RFID_LS_CALIBRATE, RFID_LS_DEBUG, RFID_LA_PROFILE, the test hooks RFID_FRONT_UNFUSED / RFID_FRONT_CHUNKS /
- * RFID_LS2_FSM_LANES_MIN and round 4's experiment knobs RFID_MF_PARTS / RFID_MF_SPLIT).  The environment is read ONCE,
+/* The switches the environment can set (INTEGRATION.md section 13 lists them: RFID_LONG_STREAM, RFID_OVERLAP,
+ * RFID_LS_CALIBRATE, RFID_LS_DEBUG, RFID_LA_PROFILE, RFID_LA_UPLOAD_KERNEL, RFID_LS_FRONT_LDS_KB and the test hooks
+ * RFID_FRONT_UNFUSED / RFID_FRONT_CHUNKS / RFID_LS2_FSM_LANES_MIN / RFID_LS2_DC_ROUNDS).  The environment is read ONCE,
  * by rfid_ctx_create; these two change / read a value of a living context by its lower-case name without the RFID_
- * prefix ("ls_fused", "front_chunks", ...; LS2_FSM_LANES_MIN is "fsm_lanes_min").  RFID_ERR_INVALID: unknown name or a
+ * prefix ("overlap", "front_chunks", ...; LS2_FSM_LANES_MIN is "fsm_lanes_min", LS2_DC_ROUNDS "dc_rounds").  RFID_ERR_INVALID: unknown name or a
  * value outside the knob's range.  A change that concerns buffers (overlap) takes effect with the next rfid_batch_plan. */
 RFID_API int rfid_ctx_set_knob(rfid_ctx *ctx, const char *name, int value);
 RFID_API int rfid_ctx_get_knob(const rfid_ctx *ctx, const char *name, int *value);

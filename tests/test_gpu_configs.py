@@ -179,8 +179,8 @@ def test_front_end_is_chosen_by_cost_estimate(synth_mod):
         ctx.batch_process_ptr(data.data_ptr(), stride, L, 0, want_scores=False)
         ctx.batch_sync()
         rep = ctx.batch_ls_report()
-        # (fused_front 2: the long-stream front end, matched filter inside its first launch -- the default since round 5; 0 with RFID_LS_FUSED=0)
-        assert rep["verified"] == 1 and rep["units"] > 1 and ctx.batch_timing()["fused_front"] in (0, 2), rep
+        # (fused_front 2: the long-stream front end, matched filter inside its first launch -- since round 5)
+        assert rep["verified"] == 1 and rep["units"] > 1 and ctx.batch_timing()["fused_front"] == 2, rep
         w1, r1, _ = ctx.batch_windows()
         assert ctx.batch_stats()[0]["n_epc_correct"] == len(t.slots)
         B = 1024

@@ -239,17 +239,17 @@ def test_statistics_of_a_long_trace_from_the_decoders_summaries(oracle_mod, synt
         ctx.close()
 
 
-@pytest.mark.parametrize("fused", ["1", "0"], ids=["fused-first-pass", "filter-in-parts"])
-def test_long_stream_passes_back_to_back_with_the_filter_in_parts(oracle_mod, synth_mod, fused, monkeypatch):
-    """Long-stream passes enqueued one behind the other.  fused (the default since round 5): the first launches of pass k + 1 --
-    the fused first pass, which filters the raw samples itself -- run on the second stream beside the rest of pass k, into the
-    second matched-filter output buffer and the second work space.  Not fused (RFID_LS_FUSED=0, round 4's form): the matched
-    filter of pass k + 1 runs there, in three parts, the later ones behind events the pass before records where its launches
-    get small.  Two different traces alternate without a wait in between; what the getters return behind the last pass (and
-    behind one more) is that trace's own result, window for window the oracle's."""
+@pytest.mark.parametrize("overlap", ["1", "0"], ids=["second-stream", "one-stream"])
+def test_long_stream_passes_back_to_back_with_the_filter_in_parts(oracle_mod, synth_mod, overlap, monkeypatch):
+    """Long-stream passes enqueued one behind the other: the first launches of pass k + 1 -- the fused first pass, which filters
+    the raw samples itself -- run on the second stream beside the rest of pass k, into the second matched-filter output buffer and
+    the second work space (RFID_OVERLAP=0: everything on one stream, one buffer).  Two different traces alternate without a wait
+    in between; what the getters return behind the last pass (and behind one more) is that trace's own result, window for
+    window the oracle's.  (Round 4's form -- the matched filter of the next pass in three launches behind events of the pass
+    before -- went with its knobs in round 6.)"""
     import torch
     import rfid
-    monkeypatch.setenv("RFID_LS_FUSED", fused)      # (read when the context is created)
+    monkeypatch.setenv("RFID_OVERLAP", overlap)      # (read when the context is created)
     ts = [synth_mod.make_trace(n_rounds=600, sigma=0.01, seed=300 + k, fixed_q=1, tag_ids=(0x21 + k, 0x44), t1_jitter_raw=2).samples for k in range(2)]
     L = min(len(t) for t in ts)
     assert L // 5 * 8 >= (16 << 20) and (L // 5 + 511) // 512 >= 3 * 1024      # a second filter buffer is made; the filter runs in parts

@@ -95,20 +95,20 @@ def test_calls_gather_into_big_passes(tmp_path, oracle_mod, synth_mod):
 def test_knobs_are_read_once_and_settable(synth_mod):
     """The RFID_* switches are read when a context is created; rfid_ctx_set_knob changes one of a living context."""
     import rfid
-    os.environ["RFID_LS_FUSED"] = "0"
+    os.environ["RFID_OVERLAP"] = "0"
     try:
         ctx = rfid.Context(device=0)
     finally:
-        del os.environ["RFID_LS_FUSED"]
+        del os.environ["RFID_OVERLAP"]
     try:
-        assert ctx.get_knob("ls_fused") == 0 and ctx.get_knob("overlap") == 1 and ctx.get_knob("front_chunks") == 1
-        os.environ["RFID_LS_FUSED"] = "1"          # (changing the environment now changes nothing)
+        assert ctx.get_knob("overlap") == 0 and ctx.get_knob("long_stream") == 1 and ctx.get_knob("front_chunks") == 1
+        os.environ["RFID_OVERLAP"] = "1"          # (changing the environment now changes nothing)
         try:
-            assert ctx.get_knob("ls_fused") == 0
+            assert ctx.get_knob("overlap") == 0
         finally:
-            del os.environ["RFID_LS_FUSED"]
-        ctx.set_knob("ls_fused", 1)
-        assert ctx.get_knob("ls_fused") == 1
+            del os.environ["RFID_OVERLAP"]
+        ctx.set_knob("overlap", 1)
+        assert ctx.get_knob("overlap") == 1
         for bad in (("front_chunks", 99), ("overlap", -1), ("no_such_knob", 1)):
             with pytest.raises(rfid.capi.RfidError):
                 ctx.set_knob(*bad)
