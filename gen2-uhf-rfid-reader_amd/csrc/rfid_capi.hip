@@ -34,8 +34,10 @@ static thread_local unsigned ls2_front_lds = 0;
 // RFID_LA_PROFILE=1: where the look-ahead's time goes (printed when the context is destroyed)
 static double g_la_t[20] = {0};
 static long g_la_n[20] = {0};
+static bool g_la_on = false;   // some context was created with RFID_LA_PROFILE=1 (the counters are a process-wide developer aid: not for several profiled contexts in different threads at once)
+static inline void la_count(int k, double dt) { if (g_la_on) { g_la_t[k] += dt; g_la_n[k]++; } }
 static inline double la_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec; }
-struct LaTimer { int k; double t0; explicit LaTimer(int kk) : k(kk), t0(la_now()) {} ~LaTimer() { g_la_t[k] += la_now() - t0; g_la_n[k]++; } };
+struct LaTimer { int k; double t0; explicit LaTimer(int kk) : k(kk), t0(g_la_on ? la_now() : 0.0) {} ~LaTimer() { if (g_la_on) la_count(k, la_now() - t0); } };
 #include "rfid_ls2_enqueue.hpp"
 
 using namespace rfidk;
@@ -202,7 +204,6 @@ struct rfid_ctx {
     bool consume_ahead = false;
     bool need_arm = false;            // a window was handed out completely: the next one waits for the decoder / reader to arm the gate
     bool exact_open = false;          // the exact per-call scan (la_exact_step) has left a window open: it goes on until the window closes
-    const rfid_cf32 *pin_next = nullptr; bool pin_was = false;   // where the last uploaded call's samples ended, and whether they were page-locked
     int *h_flag = nullptr;            // page-locked word the device writes behind a call's filter outputs (mf_upload_kernel)
     int *d_done = nullptr;            // ... and its counter of workgroups through
     int flag_seq = 0;
@@ -340,6 +341,12 @@ void knobs_from_env(RfidKnobs &k) {
   do {                                                                      \
     hipError_t e__ = (call);                                                \
     if (e__ != hipSuccess) return fail((c), RFID_ERR_HIP, #call, e__);      \
+  } while (0)
+
+#define HIPCHK_T(c, call)                                                   \
+  do {                                                                      \
+    hipError_t e__ = (call);                                                \
+    if (e__ != hipSuccess) { (c)->y_touched = true; return fail((c), RFID_ERR_HIP, #call, e__); } \
   } while (0)
 
 int grow(rfid_ctx *c, DevBuf &b, size_t bytes) {
@@ -831,6 +838,7 @@ int rfid_ctx_create(const rfid_params *p, int device, rfid_ctx **out) {
   c->err[0] = 0;
   compute_t_cand(c->t_cand, p->sample_rate);
   knobs_from_env(c->knobs);   // the one place where RFID_* variables are read
+  if (c->knobs.la_profile) g_la_on = true;
   c->ls_mode = c->knobs.long_stream;
   init_reader_state(c);
   memset(c->mf_hist, 0, sizeof(c->mf_hist));
@@ -1357,33 +1365,36 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
       // runs on stream2 beside the rest of the pass before (re-run rounds, state machine, dc_est, decoder: instruction- and
       // latency-bound launches that leave most of the HBM's bandwidth unused); the rest of this pass follows on the main
       // stream.  The buffers alternate; a buffer is written again only when the pass before last is through with it.
+      // (an error anywhere below may leave the alternating buffers / work spaces swapped without a pass behind them: HIPCHK_T marks
+      // the context so that the next pass waits for everything enqueued so far before its second stream starts, whichever
+      // buffers it gets)
       const bool ahead = c->alt.d_y != nullptr && c->ls2_ws_alt.p != nullptr && !c->alt_have && (c->knobs.overlap != 0);
       if (ahead) {
         std::swap(c->d_y, c->alt.d_y);
         c->y_idx ^= 1;
         if (c->y_touched) {   // (something outside this protocol used a buffer on the main stream: wait for all of it)
-          HIPCHK(c, hipEventRecord(c->ev_pass, c->stream));
-          HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_pass, 0));
+          HIPCHK_T(c, hipEventRecord(c->ev_pass, c->stream));
+          HIPCHK_T(c, hipStreamWaitEvent(c->stream2, c->ev_pass, 0));
           c->y_touched = false;
         }
         if (c->y_recorded[c->y_idx]) {
-          HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_y_free[c->y_idx], 0));
+          HIPCHK_T(c, hipStreamWaitEvent(c->stream2, c->ev_y_free[c->y_idx], 0));
           c->y_recorded[c->y_idx] = false;
         }
       }
-      HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-      HIPCHK(c, hipEventRecord(c->ev[1], c->stream));   // mf_ms = 0: the filter runs inside the front end's first launch
+      HIPCHK_T(c, hipEventRecord(c->ev[0], c->stream));
+      HIPCHK_T(c, hipEventRecord(c->ev[1], c->stream));   // mf_ms = 0: the filter runs inside the front end's first launch
       c->ev_valid[0] = c->ev_valid[1] = true;
       int enq = 0;
       LsOpts lo;
       lo.raw = d_raw; lo.raw_stride = raw_stride; lo.ahead = ahead;
-      if ((rc = ls_enqueue(c, n_out, lo, &enq))) return rc;
+      if ((rc = ls_enqueue(c, n_out, lo, &enq))) { c->y_touched = true; return rc; }
       if (!enq && ahead) {
         // (not applicable with the second stream after all: the buffers go back, the pass runs on the main stream alone)
         std::swap(c->d_y, c->alt.d_y); c->y_idx ^= 1;
         c->y_touched = true;
         lo.ahead = false;
-        if ((rc = ls_enqueue(c, n_out, lo, &enq))) return rc;
+        if ((rc = ls_enqueue(c, n_out, lo, &enq))) { c->y_touched = true; return rc; }
       }
       const bool ahead_now = ahead && lo.ahead;
       if (enq) {
@@ -1399,13 +1410,11 @@ int rfid_batch_process(rfid_ctx *c, const void *d_raw, int64_t raw_stride, int64
           f.m.stream0 = s0;
           const int ns = (c->B - s0 < 65535) ? (c->B - s0) : 65535;
           hipLaunchKernelGGL(mf_fallback_kernel, dim3((unsigned)gx, (unsigned)ns), dim3(MF_THREADS), 0, c->stream, f);
-          HIPCHK(c, hipGetLastError());
+          HIPCHK_T(c, hipGetLastError());
         }
-        if ((rc = rfid_batch_gate_impl(c, &c->d_ls2_ctl->ok))) return rc;
-        if ((rc = rfid_batch_decode(c, want_scores))) return rc;
-        if ((rc = rfid_batch_stats(c))) return rc;
+        if ((rc = rfid_batch_gate_impl(c, &c->d_ls2_ctl->ok)) || (rc = rfid_batch_decode(c, want_scores)) || (rc = rfid_batch_stats(c))) { c->y_touched = true; return rc; }
         if (ahead_now) {
-          HIPCHK(c, hipEventRecord(c->ev_y_free[c->y_idx], c->stream));
+          HIPCHK_T(c, hipEventRecord(c->ev_y_free[c->y_idx], c->stream));
           c->y_recorded[c->y_idx] = true;
         } else {
           c->y_touched = true;
@@ -1563,6 +1572,7 @@ int rfid_ctx_set_knob(rfid_ctx *c, const char *name, int value) {
       if (value < e.lo || value > e.hi) return RFID_ERR_INVALID;
       c->knobs.*(e.field) = value;
       if (e.field == &RfidKnobs::long_stream) c->ls_mode = value;
+      if (e.field == &RfidKnobs::la_profile && value) g_la_on = true;
       return RFID_OK;
     }
   return RFID_ERR_INVALID;
@@ -2166,7 +2176,7 @@ int sio_submit(rfid_ctx *c, int b, int64_t n_new, bool flush) {
     c->last_n_raw = n_have;
   }
   if (c->la.on) HIPCHK(c, hipEventRecord(io.ev_y, c->stream));
-  g_la_t[14] += la_now() - tm_submit.t0; g_la_n[14]++;
+  la_count(14, la_now() - tm_submit.t0);
   if (n_out > 0 && n_out < (c->la.on ? SIO_SMALL_DEC_LA : SIO_SMALL_DEC)) {
     // ---- a short pass (a scheduler's 8 k-item buffer, a small file): the long-stream front end is a string of ~45 launches
     //      that one trace of this length does not repay -- the sequential scan (one launch, ~10 ns per sample) goes over it
@@ -2201,7 +2211,7 @@ int sio_submit(rfid_ctx *c, int b, int64_t n_new, bool flush) {
     int enq = 0;
     const double t_ls0 = la_now();
     int rc = ls_enqueue(c, n_out, opt, &enq);
-    g_la_t[13] += la_now() - t_ls0; g_la_n[13]++;
+    la_count(13, la_now() - t_ls0);
     if (rc) return rc;
     ps.enq = enq != 0;
     if (ps.enq && c->la.on) {
@@ -2211,10 +2221,10 @@ int sio_submit(rfid_ctx *c, int b, int64_t n_new, bool flush) {
       const double t_d0 = la_now();
       if ((rc = rfid_batch_decode(c, 0))) return rc;
       const double t_d1 = la_now();
-      g_la_t[15] += t_d1 - t_d0; g_la_n[15]++;
+      la_count(15, t_d1 - t_d0);
       ps.n_hdr = c->la.n_hdr; ps.usual = (ps.n_hdr / 2 + 1) * (EPC_WIN + RN16_WIN);   // (the types alternate)
       if ((rc = sio_enqueue_packet(c, ps.n_hdr, ps.usual, &c->d_ls2_ctl->ok))) return rc;   // (packed only if the front end made the tables)
-      g_la_t[16] += la_now() - t_d1; g_la_n[16]++;
+      la_count(16, la_now() - t_d1);
       ps.prefetched = true;
     }
   }
@@ -2237,7 +2247,7 @@ int sio_collect(rfid_ctx *c) {
   {
     const double t_s0 = la_now();
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    g_la_t[7] += la_now() - t_s0; g_la_n[7]++;
+    la_count(7, la_now() - t_s0);
   }
   ls_note_last_pass(c);
   if (n_out > 0) {
@@ -2566,17 +2576,22 @@ int la_append(rfid_ctx *c, const rfid_cf32 *src, int64_t n, const rfid_cf32 **st
     HIPCHK(c, hipStreamWaitEvent(io.copy_stream, io.ev_hist, 0));         // ... and the history in front of its upload area is in place
   }
   // page-locked memory of the caller's (rfid_host_alloc, hipHostMalloc / hipHostRegister)?  then no staging copy -- but only where the
-  // call does not return before the device has read the samples (it waits for its own filter outputs, which lie behind
-  // the upload): a gate-keyed call and one with late outputs return at once, and the scheduler may reuse its buffer
+  // call does not return before the device has read the samples: a call that takes `staged` waits for its own filter outputs,
+  // which lie behind the upload.  A gate-keyed call, one with late outputs and one that produces no output return at once, and
+  // the scheduler may reuse its buffer.  Asked of the runtime every time (a device-side read of a pageable address is a fault, not
+  // a slow copy: no remembered verdict), and the kernel gets the DEVICE's address of the range (a registered range may have another)
   bool pinned = false;
-  if (!io.ymode && !c->la.late) {
-    if (src == c->la.pin_next) pinned = c->la.pin_was;   // (a call that goes on where the last one ended: a scheduler walking through one buffer;
-    else {                                               //  a wrong guess costs a staging copy or a slower transfer, never a wrong one)
-      hipPointerAttribute_t attr;
-      if (hipPointerGetAttributes(&attr, src) == hipSuccess) pinned = (attr.type == hipMemoryTypeHost);
-      else (void)hipGetLastError();
-    }
-    c->la.pin_next = src + n; c->la.pin_was = pinned;
+  if (!io.ymode && !c->la.late && staged) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer) {
+      const void *last = (const void *)(src + n - 1);
+      hipPointerAttribute_t attr2;   // (the whole range, not just its first sample)
+      if (hipPointerGetAttributes(&attr2, last) == hipSuccess && attr2.type == hipMemoryTypeHost && attr2.devicePointer &&
+          (const char *)attr2.devicePointer - (const char *)attr.devicePointer == (const char *)last - (const char *)src) {
+        pinned = true;
+        src = (const rfid_cf32 *)attr.devicePointer;
+      } else (void)hipGetLastError();
+    } else (void)hipGetLastError();
   }
   if (!pinned) { memcpy(io.h_pin[up] + io.acc_new, src, sizeof(rfid_cf32) * (size_t)n); src = io.h_pin[up] + io.acc_new; }
   if (staged) *staged = src;
@@ -2638,7 +2653,11 @@ int la_wait_flag(rfid_ctx *c, int seq) {
   volatile int *fl = c->la.h_flag;
   long spins = 0;
   while (*fl - seq < 0) {            // (sequence numbers only grow: a later call's flag covers this one's too)
+#if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
+#else
+    __asm__ __volatile__("" ::: "memory");
+#endif
     if (++spins > 2000000L) {        // (~ tens of ms: something is wrong or very slow -- wait the ordinary way)
       HIPCHK(c, hipStreamSynchronize(c->sio.copy_stream));
       break;
@@ -2660,12 +2679,13 @@ int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int o
   if (n_in > io.max_chunk) return fail(c, RFID_ERR_CAPACITY, "look-ahead: rfid_mf_work call larger than the max_chunk_raw given to rfid_lookahead_enable");
   const int64_t n_first = c->mf_seen / DECIM;
   const int n_out = (int)((c->mf_seen + n_in) / DECIM - n_first);
-  const size_t part = la.h_ycap / (size_t)SLOTS;           // outputs one slot of h_y holds
-  const bool grow = n_out > 0 && (size_t)n_out > part;     // (h_y is allocated anew: nothing may be held back in the old one)
+  // (h_y is made once, every slot for the largest call the stream takes -- n_in <= max_chunk was checked above: it never grows, so
+  // no call has to hand out everything held back first, and rfid_mf_must_fetch's answer is all there is to it)
+  const bool grow = n_out > 0 && la.h_y == nullptr;
   // Late outputs: up to SLOTS - 1 sets are held back when a call arrives; it launches its own filter into the free slot first
   // and then hands out whatever the device has finished -- so a call's outputs have two calls' time to get through the device
   // (one call's time was about what they need: the calls still waited ~10 us each).  What MUST be handed out before the launch:
-  // the oldest set when all other slots are taken, everything when h_y has to grow.
+  // the oldest set when all other slots are taken.
   int must = 0;
   if (la.late && n_out > 0) {
     if (grow) must = la.held_total();
@@ -2682,7 +2702,7 @@ int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int o
     rc = la_append(c, in, n_in, n_out > 0 ? &staged : nullptr);
     if (rc) { io.failed = true; return rc; }
   }
-  g_la_t[4] += la_now() - tm.t0; g_la_n[4]++;   // (samples staged)
+  la_count(4, la_now() - tm.t0);   // (samples staged)
   int give = 0;
   // hands out (part of) the oldest set; wait: for the device if it is not through with it yet.  -> false: nothing handed out
   auto hand_out_oldest = [&](bool wait, int &err) -> bool {
@@ -2694,7 +2714,7 @@ int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int o
       if (!wait && *(volatile int *)la.h_flag - h.seq < 0) return false;
       const double t_y0 = la_now();
       err = la_wait_flag(c, h.seq);
-      g_la_t[8] += la_now() - t_y0; g_la_n[8]++;
+      la_count(8, la_now() - t_y0);
       if (err) return false;
       h.ready = true;
       la.y_push(h.y0, from, (size_t)h.n);
@@ -2725,7 +2745,7 @@ int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int o
     if (grow) {   // SLOTS parts: this call's outputs and those of the calls before (late outputs)
       if (la.h_y) { HIPCHK(c, hipStreamSynchronize(io.copy_stream)); (void)hipHostFree(la.h_y); }
       la.h_y = nullptr; la.h_ycap = 0;
-      const size_t want = (size_t)(n_out < 8192 ? 16384 : 2 * n_out);
+      const size_t want = (size_t)(io.max_chunk / DECIM + 2);
       HIPCHK(c, hipHostMalloc((void **)&la.h_y, sizeof(rfid_cf32) * want * (size_t)SLOTS, hipHostMallocDefault));
       la.h_ycap = want * (size_t)SLOTS;
     }
@@ -2755,7 +2775,7 @@ int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int o
     hipLaunchKernelGGL(mf_upload_kernel, dim3((unsigned)tiles), dim3(MF_THREADS), 0, io.copy_stream, a);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(io.ev_up[io.cur], io.copy_stream));
-    g_la_t[5] += la_now() - t_sp; g_la_n[5]++;
+    la_count(5, la_now() - t_sp);
     if (la.late) {
       Held h;
       h.y0 = n_first; h.n = n_out; h.off = 0; h.seq = seq; h.slot = slot; h.ready = false;
@@ -2764,7 +2784,7 @@ int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int o
       const double t_y0 = la_now();
       rc = la_wait_flag(c, seq);
       if (rc) return rc;
-      g_la_t[8] += la_now() - t_y0; g_la_n[8]++;
+      la_count(8, la_now() - t_y0);
       memcpy(out, y_here, sizeof(rfid_cf32) * (size_t)n_out);
       la.y_push(n_first, y_here, (size_t)n_out);
       give = n_out;
@@ -2784,7 +2804,7 @@ int la_mf_work(rfid_ctx *c, const rfid_cf32 *in, int n_in, rfid_cf32 *out, int o
   if (la_should_submit(c)) {
     const double t_c0 = la_now();
     rc = la_submit_pending(c);
-    g_la_t[6] += la_now() - t_c0; g_la_n[6]++;
+    la_count(6, la_now() - t_c0);
     if (rc) return rc;
   }
   *n_produced = give;
