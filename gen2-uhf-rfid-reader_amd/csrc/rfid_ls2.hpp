@@ -1994,9 +1994,14 @@ RFID_KERNEL(64) void ls2_dcb_up2_kernel(Ls2Args a) {
 }
 // the walk over a trace's top-level nodes from its exact start (the centre of its first unit): every node's entry value.
 // One wave per trace; the values are wave-uniform.
-RFID_DEVICE void ls2_dcb_top(const Ls2Args &a, const int s, const int lane) {
+RFID_KERNEL(64) void ls2_dcb_top_kernel(Ls2Args a) {
+  ls2_tail_prio();
   Ls2Ctl *ctl = a.ctl;
+  if (!ls2_fsm_settled(a, ctl)) return;
   const int r = a.round;
+  if (r > 0 && wv::uniform(ctl->dc_count[r - 1]) == 0) return;
+  const int lane = wv::lane_id();
+  const int s = (int)blockIdx.x;
   const int t0 = s * a.max_bc;
   if (s == 0 && lane == 0) ctl->dc_rounds = r + 1;
   if (lane == 0) a.dfront[s] = 0x7fffffff;
@@ -2031,13 +2036,6 @@ RFID_DEVICE void ls2_dcb_top(const Ls2Args &a, const int s, const int lane) {
     }
     tr = ntr; ti = nti;
   }
-}
-RFID_KERNEL(64) void ls2_dcb_top_kernel(Ls2Args a) {
-  ls2_tail_prio();
-  Ls2Ctl *ctl = a.ctl;
-  if (!ls2_fsm_settled(a, ctl)) return;
-  if (a.round > 0 && wv::uniform(ctl->dc_count[a.round - 1]) == 0) return;
-  ls2_dcb_top(a, (int)blockIdx.x, wv::lane_id());
 }
 // down: from a node's entry value to its children's.  Level 1: the children are the units -- their start values (a.dT),
 // which of them are settled, how many are not (Ls2Ctl::dc_count[round]).
@@ -2145,36 +2143,6 @@ RFID_KERNEL(64) void ls2_dcb_down1_kernel(Ls2Args a) {
     if (r == 0 && n_units) { wv::atomic_add(&ctl->n_units, n_units); wv::atomic_add(&ctl->n_dc_pieces, n_units); }
   }
 }
-// The whole chain of a round in ONE launch, for passes of at most 64 blocks per trace (4 096 idle-grid slots: a stream call, a
-// look-ahead pass -- their pace is the number of launches, not the work): one workgroup of sixteen waves per trace -- the blocks'
-// tables (waves over blocks), the walk (wave 0), the units' start values (waves over blocks) -- with two workgroup barriers in
-// place of two launch boundaries.
-constexpr int LS2_DCB_CHAIN_WAVES = 16;
-RFID_KERNEL(64 * LS2_DCB_CHAIN_WAVES) void ls2_dcb_chain1_kernel(Ls2Args a) {
-  ls2_tail_prio();
-  Ls2Ctl *ctl = a.ctl;
-  if (!ls2_fsm_settled(a, ctl)) return;
-  const int r = a.round;
-  if (r > 0 && ctl->dc_count[r - 1] == 0) return;
-  const int tid = (int)threadIdx.x, lane = wv::lane_id(), wave = wv::uniform(tid >> 6);
-  const int s = (int)blockIdx.x;
-  for (int k = wave; k < a.dcb_n1; k += LS2_DCB_CHAIN_WAVES) ls2_dcb_up<1>(a, s * a.dcb_n1 + k, lane);
-  wv::block_sync();   // (the barrier's workgroup-scope fence: the waves of a workgroup share their CU's vector cache)
-  if (wave == 0) ls2_dcb_top(a, s, lane);
-  wv::block_sync();
-  int n_uns = 0, n_units = 0;
-  for (int k = wave; k < a.dcb_n1; k += LS2_DCB_CHAIN_WAVES) {
-    int nu = 0, first_uns = 0;
-    ls2_dcb_down<1>(a, s * a.dcb_n1 + k, lane, nu, n_units, first_uns);
-    if (nu && lane == 0) wv::atomic_min(a.dfront + s, first_uns);
-    n_uns += nu;
-  }
-  if (lane == 0) {
-    if (n_uns) wv::atomic_add(&ctl->dc_count[r], n_uns);
-    if (r == 0 && n_units) { wv::atomic_add(&ctl->n_units, n_units); wv::atomic_add(&ctl->n_dc_pieces, n_units); }
-  }
-}
-
 // The enqueued rounds are used up and units are still unsettled (sums that hover at a binade edge: what a start value does to
 // a unit's end is then no shift, the window catches the chain's prediction for a few units only, and exactness can only walk
 // along the trace).  One workgroup of sixteen waves per trace walks: per turn the sixteen idle-grid slots behind the frontier

@@ -222,10 +222,6 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
     for (int r = 0; r <= a.dc_rounds; ++r) {
       a.round = r;
       LS2_LAUNCH(ls2_dcb_run_kernel, NH, 1, 64, U(a));
-      if (a.dcb_top == 1 && a.dcb_n1 <= 64) {
-        LS2_LAUNCH(ls2_dcb_chain1_kernel, B, 1, 64 * LS2_DCB_CHAIN_WAVES, U(a));   // (short passes: the whole chain in one launch)
-        continue;
-      }
       LS2_LAUNCH(ls2_dcb_up1_kernel, N1, 1, 64, U(a));
       if (a.dcb_top == 2) LS2_LAUNCH(ls2_dcb_up2_kernel, N2, 1, 64, U(a));
       LS2_LAUNCH(ls2_dcb_top_kernel, B, 1, 64, U(a));
