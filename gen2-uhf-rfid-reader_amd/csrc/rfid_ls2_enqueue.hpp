@@ -177,9 +177,9 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
   // dc_est rounds behind the first.  Away from binade edges the first round settles every unit whose margin covers the rounding
   // drift; the few others (a partial sum next to a power of two: ~5 %) are run again centred on the chain's prediction, which is
   // off by an ulp or two per such unit it came through -- the blocks' windows (+- 32) catch that for some thousand units per
-  // round: 2 rounds for a stream of a few thousand units, up to ~8 for configs[2]'s 32 000 (a round here is six small launches
+  // round: one round (and the finishing walk for the handful it may leave) for a stream of a few thousand units, up to ~8 for configs[2]'s 32 000 (a round here is six small launches
   // and a handful of unit runs).  Sums that hover at a binade edge do not settle by rounds at all; the finishing walk takes them
-  a.dc_rounds = (dc_rounds >= 0) ? dc_rounds : ((tiny || small) ? 2 : LS2_DC_ROUNDS);
+  a.dc_rounds = (dc_rounds >= 0) ? dc_rounds : ((tiny || small) ? 1 : LS2_DC_ROUNDS);
   if (a.dc_rounds < 0) a.dc_rounds = 0;
   if (a.dc_rounds > LS2_DC_MAXR) a.dc_rounds = LS2_DC_MAXR;
   if (fused) {
