@@ -136,11 +136,12 @@ struct Ls2Args {
   int *dmar;                    // [NH][2] how far from its centre a start may lie for the unit's end to be a plain shift of candidate 32's / 33's (ulps; 0: nowhere)
   int *dwbase;                  // [NH] the unit's first place in dcand
   float2 *dcand; int dcand_cap; // [dcand_cap][64] dc_est at a gate opening for each candidate
-  // the chain's blocks: 64 idle-grid slots each; per block the centre of its window, its table on that window, which entries are
-  // exact, its margin, whether it holds a unit, and its entry value from the walk
-  int dcb_n1;                   // blocks per trace
+  // the chain's levels: nodes of 64 children (level 1: blocks of units, level 2: groups of blocks); per node the centre of its
+  // first child, its table on that window, which entries are exact, whether it holds anything, and its entry value from the walk
   int dcb_bias;                 // test hook: ulps added to the first round's centres (the ring means), as the rounding drift of a long trace would
+  int dcb_n1, dcb_n2, dcb_top;  // nodes per trace of level 1 / 2; the level the walk runs over (2 when a trace has more than 64 blocks)
   int *n1cen, *n1tab, *n1val, *n1ent, *n1mar; uint64_t *n1exm;
+  int *n2cen, *n2tab, *n2val, *n2ent, *n2mar; uint64_t *n2exm;
   int *seq0;                    // [NS][2] complete windows of the trace before the piece: all, EPC
   int *flat_base;               // [n_streams][2] the trace's first place in the decoder's RN16 / EPC list
   rfid_window *wtab; int wmax; int *wcount;
@@ -1838,8 +1839,8 @@ struct Ls2DcbKids { const int *cen; const int *tab; const uint64_t *exm; const i
 template <int L>
 RFID_DEVICE Ls2DcbKids ls2_dcb_kids(const Ls2Args &a) {
   Ls2DcbKids k;
-  static_assert(L == 1, "one level: blocks of 64 units (a pass has at most ~33 000 idle-grid slots: ~520 blocks, which the walk takes one by one)");
-  k.cen = a.dcen; k.tab = a.dtab; k.exm = nullptr; k.val = nullptr; k.mar = a.dmar; k.per_trace = a.max_bc;
+  if (L == 1) { k.cen = a.dcen; k.tab = a.dtab; k.exm = nullptr; k.val = nullptr; k.mar = a.dmar; k.per_trace = a.max_bc; }
+  else { k.cen = a.n1cen; k.tab = a.n1tab; k.exm = a.n1exm; k.val = a.n1val; k.mar = a.n1mar; k.per_trace = a.dcb_n1; }
   return k;
 }
 // A node's table misses (the entry value lies outside its window and its margin) where its CHILDREN, gone through one by one,
@@ -1850,7 +1851,7 @@ RFID_DEVICE Ls2DcbKids ls2_dcb_kids(const Ls2Args &a) {
 template <int L>
 RFID_DEVICE void ls2_dcb_through(const Ls2Args &a, const int node, int &Tre, int &Tim, bool &exr, bool &exi, const int lane, int &budget) {
   const Ls2DcbKids kd = ls2_dcb_kids<L>(a);
-  const int nper = a.dcb_n1;
+  const int nper = (L == 1) ? a.dcb_n1 : a.dcb_n2;
   const int s = node / nper, k = node - s * nper;
   const int ch0 = s * kd.per_trace + 64 * k;
   const bool in = 64 * k + lane < kd.per_trace;
@@ -1858,7 +1859,7 @@ RFID_DEVICE void ls2_dcb_through(const Ls2Args &a, const int node, int &Tre, int
   // (none of the loads depends on the walk)
   int valid = 0, cre = 0, cim = 0, mre = 0, mim = 0;
   if (in) {
-    valid = (a.dstat[ch0 + lane] >> 2) & 1;
+    valid = (L == 1) ? ((a.dstat[ch0 + lane] >> 2) & 1) : kd.val[ch0 + lane];
     if (valid) { cre = kd.cen[2 * (ch0 + lane)]; cim = kd.cen[2 * (ch0 + lane) + 1]; mre = kd.mar[2 * (ch0 + lane)]; mim = kd.mar[2 * (ch0 + lane) + 1]; }
   }
   uint64_t er_l = ~0ull, ei_l = ~0ull;
@@ -1889,6 +1890,11 @@ RFID_DEVICE void ls2_dcb_through(const Ls2Args &a, const int node, int &Tre, int
       int T2r = Tre, T2i = Tim; bool e2r = exr, e2i = exi;
       ls2_dcb_apply<true>(T2r, e2r, t_re, er, wv::readlane(cre, l), wv::readlane(mre, l));
       ls2_dcb_apply<true>(T2i, e2i, t_im, ei, wv::readlane(cim, l), wv::readlane(mim, l));
+      if (L == 2 && ((exr && !e2r) || (exi && !e2i)) && budget > 0) {
+        budget--;
+        T2r = Tre; T2i = Tim; e2r = exr; e2i = exi;
+        ls2_dcb_through<1>(a, ch0 + l, T2r, T2i, e2r, e2i, lane, budget);
+      }
       Tre = T2r; Tim = T2i; exr = e2r; exi = e2i;
     }
   }
@@ -1897,15 +1903,15 @@ RFID_DEVICE void ls2_dcb_through(const Ls2Args &a, const int node, int &Tre, int
 template <int L>
 RFID_DEVICE void ls2_dcb_up(const Ls2Args &a, const int node, const int lane) {
   const Ls2DcbKids kd = ls2_dcb_kids<L>(a);
-  const int nper = a.dcb_n1;
-  int *ocen = a.n1cen; int *otab = a.n1tab;
-  uint64_t *oexm = a.n1exm; int *oval = a.n1val; int *omar = a.n1mar;
+  const int nper = (L == 1) ? a.dcb_n1 : a.dcb_n2;
+  int *ocen = (L == 1) ? a.n1cen : a.n2cen; int *otab = (L == 1) ? a.n1tab : a.n2tab;
+  uint64_t *oexm = (L == 1) ? a.n1exm : a.n2exm; int *oval = (L == 1) ? a.n1val : a.n2val; int *omar = (L == 1) ? a.n1mar : a.n2mar;
   const int s = node / nper, k = node - s * nper;
   const int ch0 = s * kd.per_trace + 64 * k;
   const bool in = 64 * k + lane < kd.per_trace;
   int valid = 0, cre = 0, cim = 0, mre = 0, mim = 0;
   if (in) {
-    valid = (a.dstat[ch0 + lane] >> 2) & 1;
+    valid = (L == 1) ? ((a.dstat[ch0 + lane] >> 2) & 1) : kd.val[ch0 + lane];
     if (valid) { cre = kd.cen[2 * (ch0 + lane)]; cim = kd.cen[2 * (ch0 + lane) + 1]; mre = kd.mar[2 * (ch0 + lane)]; mim = kd.mar[2 * (ch0 + lane) + 1]; }
   }
   const uint64_t m = wv::ballot(valid != 0);
@@ -1914,7 +1920,7 @@ RFID_DEVICE void ls2_dcb_up(const Ls2Args &a, const int node, const int lane) {
   // the node's window: round 0 around its first child's centre; later around the value the last chain found it entered at --
   // the first child's centre is a ring mean, off by the rounding drift, and an entry value outside the window passes exactly
   // only where EVERY child's margin covers it
-  const int *pent = a.n1ent;
+  const int *pent = (L == 1) ? a.n1ent : a.n2ent;
   const bool recentre = a.round > 0 && wv::uniform(oval[node]) != 0;
   const int bre = recentre ? wv::uniform(pent[4 * node]) : wv::readlane(cre, l), bim = recentre ? wv::uniform(pent[4 * node + 1]) : wv::readlane(cim, l);
   int vre = bre + lane - LS2_DCB_HALF, vim = bim + lane - LS2_DCB_HALF;
@@ -1977,7 +1983,16 @@ RFID_KERNEL(64) void ls2_dcb_up1_kernel(Ls2Args a) {
   const int N = a.n_streams * a.dcb_n1;
   for (int node = (int)blockIdx.x; node < N; node += (int)gridDim.x) ls2_dcb_up<1>(a, node, lane);
 }
-// the walk over a trace's blocks from its exact start (the centre of its first unit): every node's entry value.
+RFID_KERNEL(64) void ls2_dcb_up2_kernel(Ls2Args a) {
+  ls2_tail_prio();
+  Ls2Ctl *ctl = a.ctl;
+  if (!ls2_fsm_settled(a, ctl)) return;
+  if (a.round > 0 && wv::uniform(ctl->dc_count[a.round - 1]) == 0) return;
+  const int lane = wv::lane_id();
+  const int N = a.n_streams * a.dcb_n2;
+  for (int node = (int)blockIdx.x; node < N; node += (int)gridDim.x) ls2_dcb_up<2>(a, node, lane);
+}
+// the walk over a trace's top-level nodes from its exact start (the centre of its first unit): every node's entry value.
 // One wave per trace; the values are wave-uniform.
 RFID_KERNEL(64) void ls2_dcb_top_kernel(Ls2Args a) {
   ls2_tail_prio();
@@ -1991,63 +2006,35 @@ RFID_KERNEL(64) void ls2_dcb_top_kernel(Ls2Args a) {
   if (s == 0 && lane == 0) ctl->dc_rounds = r + 1;
   if (lane == 0) a.dfront[s] = 0x7fffffff;
   if (!(wv::uniform(a.dstat[t0]) & 4)) return;   // an empty trace
-  const int nper = a.dcb_n1;
-  const int *cen = a.n1cen; const int *tab = a.n1tab;
-  const uint64_t *exm = a.n1exm; const int *val = a.n1val; const int *mar = a.n1mar;
-  int *ent = a.n1ent;
+  const bool two = a.dcb_top == 2;
+  const int nper = two ? a.dcb_n2 : a.dcb_n1;
+  const int *cen = two ? a.n2cen : a.n1cen; const int *tab = two ? a.n2tab : a.n1tab;
+  const uint64_t *exm = two ? a.n2exm : a.n1exm; const int *val = two ? a.n2val : a.n1val; const int *mar = two ? a.n2mar : a.n1mar;
+  int *ent = two ? a.n2ent : a.n1ent;
   int Tre = wv::uniform(a.dcen[2 * t0]), Tim = wv::uniform(a.dcen[2 * t0 + 1]);
   bool exr = true, exi = true;
   int budget = LS2_DCB_DESCENTS;
   const int n0 = s * nper;
-  // 64 blocks at a time: their centres, margins, exactness masks and whether they hold anything in one load per lane, their
-  // tables four blocks ahead of the walk (nothing of that depends on the walk)
-  for (int k0 = 0; k0 < nper; k0 += 64) {
-    const bool in = k0 + lane < nper;
-    const int nd = n0 + k0 + (in ? lane : 0);
-    int valid = 0, cre = 0, cim = 0, mre = 0, mim = 0;
-    uint64_t er_l = 0, ei_l = 0;
-    if (in) {
-      valid = val[nd];
-      if (valid) { cre = cen[2 * nd]; cim = cen[2 * nd + 1]; mre = mar[2 * nd]; mim = mar[2 * nd + 1]; er_l = exm[2 * nd]; ei_l = exm[2 * nd + 1]; }
-    }
-    const uint64_t m = wv::ballot(valid != 0);
-    if (m == 0ull) continue;
-    constexpr int AH = 4;
-    int tr[AH], ti[AH], lq[AH];
-    uint64_t rest = m;
-    const int l0 = wv::ffs64(m);
-#pragma unroll
-    for (int u = 0; u < AH; ++u) {
-      lq[u] = rest ? wv::ffs64(rest) : -1;
-      if (rest) rest &= rest - 1ull;
-      const int c = n0 + k0 + ((lq[u] >= 0) ? lq[u] : l0);
-      tr[u] = tab[(int64_t)(2 * c) * 64 + lane]; ti[u] = tab[(int64_t)(2 * c + 1) * 64 + lane];
-    }
-    for (bool more = true; more;) {
-#pragma unroll
-      for (int u = 0; u < AH; ++u) {
-        const int l = lq[u];
-        if (l < 0) { more = false; break; }
-        const int t_re = tr[u], t_im = ti[u];
-        lq[u] = rest ? wv::ffs64(rest) : -1;
-        if (rest) rest &= rest - 1ull;
-        { const int c = n0 + k0 + ((lq[u] >= 0) ? lq[u] : l0); tr[u] = tab[(int64_t)(2 * c) * 64 + lane]; ti[u] = tab[(int64_t)(2 * c + 1) * 64 + lane]; }
-        const int node = n0 + k0 + l;
-        const uint64_t er = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(er_l >> 32), l) << 32) | (uint32_t)wv::readlane((int)(uint32_t)er_l, l);
-        const uint64_t ei = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(ei_l >> 32), l) << 32) | (uint32_t)wv::readlane((int)(uint32_t)ei_l, l);
-        if (lane == 0) { ent[4 * node] = Tre; ent[4 * node + 1] = Tim; ent[4 * node + 2] = exr ? 1 : 0; ent[4 * node + 3] = exi ? 1 : 0; }
-        int T2r = Tre, T2i = Tim; bool e2r = exr, e2i = exi;
-        ls2_dcb_apply<true>(T2r, e2r, t_re, er, wv::readlane(cre, l), wv::readlane(mre, l));
-        ls2_dcb_apply<true>(T2i, e2i, t_im, ei, wv::readlane(cim, l), wv::readlane(mim, l));
-        if (((exr && !e2r) || (exi && !e2i)) && budget > 0) {
-          // the block's table missed an exact entry value: through its units one by one (they may all be hit)
-          budget--;
-          T2r = Tre; T2i = Tim; e2r = exr; e2i = exi;
-          ls2_dcb_through<1>(a, node, T2r, T2i, e2r, e2i, lane, budget);
-        }
-        Tre = T2r; Tim = T2i; exr = e2r; exi = e2i;
+  int tr = tab[(int64_t)(2 * n0) * 64 + lane], ti = tab[(int64_t)(2 * n0 + 1) * 64 + lane];
+  for (int k = 0; k < nper; ++k) {
+    const int node = n0 + k;
+    int ntr = 0, nti = 0;
+    if (k + 1 < nper) { ntr = tab[(int64_t)(2 * (node + 1)) * 64 + lane]; nti = tab[(int64_t)(2 * (node + 1) + 1) * 64 + lane]; }
+    if (wv::uniform(val[node]) != 0) {
+      if (lane == 0) { ent[4 * node] = Tre; ent[4 * node + 1] = Tim; ent[4 * node + 2] = exr ? 1 : 0; ent[4 * node + 3] = exi ? 1 : 0; }
+      int T2r = Tre, T2i = Tim; bool e2r = exr, e2i = exi;
+      ls2_dcb_apply<true>(T2r, e2r, tr, wv::uniform(exm[2 * node]), wv::uniform(cen[2 * node]), wv::uniform(mar[2 * node]));
+      ls2_dcb_apply<true>(T2i, e2i, ti, wv::uniform(exm[2 * node + 1]), wv::uniform(cen[2 * node + 1]), wv::uniform(mar[2 * node + 1]));
+      if (((exr && !e2r) || (exi && !e2i)) && budget > 0) {
+        // the node's table missed an exact entry value: through its children one by one (they may all be hit)
+        budget--;
+        T2r = Tre; T2i = Tim; e2r = exr; e2i = exi;
+        if (two) ls2_dcb_through<2>(a, node, T2r, T2i, e2r, e2i, lane, budget);
+        else ls2_dcb_through<1>(a, node, T2r, T2i, e2r, e2i, lane, budget);
       }
+      Tre = T2r; Tim = T2i; exr = e2r; exi = e2i;
     }
+    tr = ntr; ti = nti;
   }
 }
 // down: from a node's entry value to its children's.  Level 1: the children are the units -- their start values (a.dT),
@@ -2055,15 +2042,15 @@ RFID_KERNEL(64) void ls2_dcb_top_kernel(Ls2Args a) {
 template <int L>
 RFID_DEVICE void ls2_dcb_down(const Ls2Args &a, const int node, const int lane, int &n_uns, int &n_units, int &first_uns) {
   const Ls2DcbKids kd = ls2_dcb_kids<L>(a);
-  const int nper = a.dcb_n1;
-  const int *nval = a.n1val; const int *nent = a.n1ent;
+  const int nper = (L == 1) ? a.dcb_n1 : a.dcb_n2;
+  const int *nval = (L == 1) ? a.n1val : a.n2val; const int *nent = (L == 1) ? a.n1ent : a.n2ent;
   if (wv::uniform(nval[node]) == 0) return;
   const int s = node / nper, k = node - s * nper;
   const int ch0 = s * kd.per_trace + 64 * k;
   const bool in = 64 * k + lane < kd.per_trace;
   int valid = 0, cre = 0, cim = 0, mre = 0, mim = 0;
   if (in) {
-    valid = (a.dstat[ch0 + lane] >> 2) & 1;
+    valid = (L == 1) ? ((a.dstat[ch0 + lane] >> 2) & 1) : kd.val[ch0 + lane];
     if (valid) { cre = kd.cen[2 * (ch0 + lane)]; cim = kd.cen[2 * (ch0 + lane) + 1]; mre = kd.mar[2 * (ch0 + lane)]; mim = kd.mar[2 * (ch0 + lane) + 1]; }
   }
   const uint64_t m = wv::ballot(valid != 0);
@@ -2075,6 +2062,7 @@ RFID_DEVICE void ls2_dcb_down(const Ls2Args &a, const int node, const int lane, 
     er = kd.exm ? wv::uniform(kd.exm[2 * (ch0 + c)]) : ~0ull; ei = kd.exm ? wv::uniform(kd.exm[2 * (ch0 + c) + 1]) : ~0ull;
   };
   const int l0 = wv::ffs64(m);
+  int budget = 64;
   // (the children's tables four ahead of the walk: the loads do not depend on it)
   constexpr int AH = 4;
   int tr[AH], ti[AH], lq[AH]; uint64_t er[AH], ei[AH];
@@ -2108,15 +2096,32 @@ RFID_DEVICE void ls2_dcb_down(const Ls2Args &a, const int node, const int lane, 
         if (lane == 0) { a.dT[2 * c] = Tre; a.dT[2 * c + 1] = Tim; a.dstat[c] = 4 | bits | ((k_re && k_im) ? 0 : 8) | (a.dstat[c] & 0x70); }
         n_units++;
         if (bits != 3) { if (n_uns == 0) first_uns = c; n_uns++; }
+      } else {
+        if (lane == 0) { int *e = a.n1ent + 4 * c; e[0] = Tre; e[1] = Tim; e[2] = exr ? 1 : 0; e[3] = exi ? 1 : 0; }
       }
       {
         int T2r = Tre, T2i = Tim; bool e2r = exr, e2i = exi;
         ls2_dcb_apply<true>(T2r, e2r, t_re, e_re, c_re, m_re);
         ls2_dcb_apply<true>(T2i, e2i, t_im, e_im, c_im, m_im);
+        if (L == 2 && ((exr && !e2r) || (exi && !e2i)) && budget > 0) {   // (the block's table missed: through its units one by one)
+          budget--;
+          T2r = Tre; T2i = Tim; e2r = exr; e2i = exi;
+          ls2_dcb_through<1>(a, c, T2r, T2i, e2r, e2i, lane, budget);
+        }
         Tre = T2r; Tim = T2i; exr = e2r; exi = e2i;
       }
     }
   }
+}
+RFID_KERNEL(64) void ls2_dcb_down2_kernel(Ls2Args a) {
+  ls2_tail_prio();
+  Ls2Ctl *ctl = a.ctl;
+  if (!ls2_fsm_settled(a, ctl)) return;
+  if (a.round > 0 && wv::uniform(ctl->dc_count[a.round - 1]) == 0) return;
+  const int lane = wv::lane_id();
+  const int N = a.n_streams * a.dcb_n2;
+  int u0 = 0, u1 = 0, u2 = 0;
+  for (int node = (int)blockIdx.x; node < N; node += (int)gridDim.x) ls2_dcb_down<2>(a, node, lane, u0, u1, u2);
 }
 RFID_KERNEL(64) void ls2_dcb_down1_kernel(Ls2Args a) {
   ls2_tail_prio();

@@ -21,7 +21,7 @@ struct Ls2Geometry {
   int P = 0, max_b = 0, NS = 0;            // piece length, slots per trace, slots
   int Pc = 0, max_bc = 0;                  // the idle-cut grid
   int64_t vstride = 0, cstride = 0, wb_stride = 0;
-  int n1 = 0;                              // dc_est chain: blocks of 64 idle-grid slots per trace
+  int n1 = 0, n2 = 0;                      // dc_est chain: blocks of 64 idle-grid slots per trace, groups of 64 blocks
 };
 // P: nominal piece length for `n_streams` traces of (at most) n_dec decimated samples; 0 = the traces are too short to cut
 inline Ls2Geometry ls2_geometry(int n_streams, int64_t n_dec, int min_piece = LS2_MIN_PIECE, int target = LS2_TARGET_PIECES) {
@@ -40,12 +40,13 @@ inline Ls2Geometry ls2_geometry(int n_streams, int64_t n_dec, int min_piece = LS
   g.cstride = (n_dec >> 6) + g.max_bc + 3;
   g.wb_stride = n_dec / LS2_WBUCKET + 2;
   g.n1 = (g.max_bc + 63) / 64;
+  g.n2 = (g.n1 + 63) / 64;
   return g;
 }
 
 // work space: one allocation, carved up here (offsets in bytes, 256-byte aligned)
 struct Ls2Layout {
-  size_t cut, cutf, piece, nextv, prevv, upiece, unextv, uprevv, lb_fn, lb_end, lb_water, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, dT, dcen, dtab, dstat, dfront, dmar, dwbase, dcand, n1cen, n1tab, n1val, n1ent, n1mar, n1exm, seq0, flat_base, cflag, cagg, ctl, consumed, total;
+  size_t cut, cutf, piece, nextv, prevv, upiece, unextv, uprevv, lb_fn, lb_end, lb_water, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, dT, dcen, dtab, dstat, dfront, dmar, dwbase, dcand, n1cen, n1tab, n1val, n1ent, n1mar, n1exm, n2cen, n2tab, n2val, n2ent, n2mar, n2exm, seq0, flat_base, cflag, cagg, ctl, consumed, total;
   int dcand_cap;
 };
 // wmax: complete windows a trace can hold (the caller's window table): sizes the dc_est stage's table of gate openings
@@ -74,7 +75,7 @@ inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_strid
   L.aover = take(sizeof(Ls2Aff) * NS);
   L.fsm = take(sizeof(Ls2Fsm) * NS);
   L.wb = take(sizeof(Ls2Win) * B * (size_t)g.wb_stride);
-  const size_t NH = B * (size_t)g.max_bc, N1 = B * (size_t)g.n1;
+  const size_t NH = B * (size_t)g.max_bc, N1 = B * (size_t)g.n1, N2 = B * (size_t)g.n2;
   L.dT = take(sizeof(int) * 2 * NH);
   L.dcen = take(sizeof(int) * 2 * NH);
   L.dtab = take(sizeof(int) * 2 * 64 * NH);
@@ -86,6 +87,8 @@ inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_strid
   L.dcand = take(sizeof(float2) * 64 * (size_t)L.dcand_cap);
   L.n1cen = take(sizeof(int) * 2 * N1); L.n1tab = take(sizeof(int) * 2 * 64 * N1); L.n1val = take(sizeof(int) * N1);
   L.n1ent = take(sizeof(int) * 4 * N1); L.n1mar = take(sizeof(int) * 2 * N1); L.n1exm = take(sizeof(uint64_t) * 2 * N1);
+  L.n2cen = take(sizeof(int) * 2 * N2); L.n2tab = take(sizeof(int) * 2 * 64 * N2); L.n2val = take(sizeof(int) * N2);
+  L.n2ent = take(sizeof(int) * 4 * N2); L.n2mar = take(sizeof(int) * 2 * N2); L.n2exm = take(sizeof(uint64_t) * 2 * N2);
   L.seq0 = take(sizeof(int) * 2 * NS);
   L.flat_base = take(sizeof(int) * 2 * B);
   L.cflag = take(sizeof(int) * B * LS2_CHAIN_GMAX);
@@ -95,6 +98,7 @@ inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_strid
   L.total = off;
   return L;
 }
+inline int &ls2_dcb_top_min();
 inline int &ls2_dcb_bias();
 inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geometry &g) {
   a.P = g.P; a.max_b = g.max_b; a.Pc = g.Pc; a.max_bc = g.max_bc; a.vstride = g.vstride; a.cstride = g.cstride; a.wb_stride = g.wb_stride;
@@ -108,13 +112,15 @@ inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geomet
   a.fsm = (Ls2Fsm *)(base + L.fsm); a.wb = (Ls2Win *)(base + L.wb);
   a.dT = (int *)(base + L.dT); a.dcen = (int *)(base + L.dcen); a.dtab = (int *)(base + L.dtab); a.dstat = (int *)(base + L.dstat); a.dmar = (int *)(base + L.dmar); a.dfront = (int *)(base + L.dfront);
   a.dwbase = (int *)(base + L.dwbase); a.dcand = (float2 *)(base + L.dcand); a.dcand_cap = L.dcand_cap;
-  a.dcb_n1 = g.n1; a.dcb_bias = ls2_dcb_bias();
+  a.dcb_n1 = g.n1; a.dcb_n2 = g.n2; a.dcb_top = (g.n1 > ls2_dcb_top_min()) ? 2 : 1; a.dcb_bias = ls2_dcb_bias();
   a.n1cen = (int *)(base + L.n1cen); a.n1tab = (int *)(base + L.n1tab); a.n1val = (int *)(base + L.n1val); a.n1ent = (int *)(base + L.n1ent); a.n1mar = (int *)(base + L.n1mar); a.n1exm = (uint64_t *)(base + L.n1exm);
+  a.n2cen = (int *)(base + L.n2cen); a.n2tab = (int *)(base + L.n2tab); a.n2val = (int *)(base + L.n2val); a.n2ent = (int *)(base + L.n2ent); a.n2mar = (int *)(base + L.n2mar); a.n2exm = (uint64_t *)(base + L.n2exm);
   a.seq0 = (int *)(base + L.seq0); a.flat_base = (int *)(base + L.flat_base); a.cflag = (int *)(base + L.cflag); a.cagg = (int *)(base + L.cagg); a.ctl = (Ls2Ctl *)(base + L.ctl); a.consumed = (int *)(base + L.consumed);
 }
 
 inline int &ls2_fsm_lanes_min() { static int v = 8192; return v; }   // from this many possible heads on the state machine runs one lane per unit (tests: 0 / a huge number)
 inline int &ls2_chain_slots() { static int v = 2048; return v; }
+inline int &ls2_dcb_top_min() { static int v = 64; return v; }
 inline int &ls2_dcb_bias() { static int v = 0; return v; }   // (tests: Ls2Args::dcb_bias)   // the dc_est chain walks over groups of blocks when a trace has more blocks than this (tests: 0)   // slots per workgroup of a chain launch (tests shrink it)
 
 #ifdef LS2_LAUNCH
@@ -209,15 +215,17 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
     else LS2_LAUNCH(ls2_fsm_kernel, NH, 1, 64, U(a));
     LS2_LAUNCH(ls2_fsm_chain_kernel, (NH + 255) / 256, 1, 256, U(a));
   }
-  // dc_est: every unit from 64 neighbouring start values at once (lane = candidate), the chain of their tables (blocks of 64 units:
-  // up, a walk over the blocks, down); round r > 0 runs what the last run does not cover again, centred on the chain's prediction
+  // dc_est: every unit from 64 neighbouring start values at once (lane = candidate), the chain of their tables in levels of
+  // 64 (up, a walk over the top level, down); round r > 0 runs what is not settled again, centred on the chain's prediction
   {
-    const int N1 = B * a.dcb_n1;
+    const int N1 = B * a.dcb_n1, N2 = B * a.dcb_n2;
     for (int r = 0; r <= a.dc_rounds; ++r) {
       a.round = r;
       LS2_LAUNCH(ls2_dcb_run_kernel, NH, 1, 64, U(a));
       LS2_LAUNCH(ls2_dcb_up1_kernel, N1, 1, 64, U(a));
+      if (a.dcb_top == 2) LS2_LAUNCH(ls2_dcb_up2_kernel, N2, 1, 64, U(a));
       LS2_LAUNCH(ls2_dcb_top_kernel, B, 1, 64, U(a));
+      if (a.dcb_top == 2) LS2_LAUNCH(ls2_dcb_down2_kernel, N2, 1, 64, U(a));
       LS2_LAUNCH(ls2_dcb_down1_kernel, N1, 1, 64, U(a));
     }
     a.round = 0;

@@ -89,6 +89,12 @@ def test_ls2_rerun_rounds_are_exercised(emu_mod, oracle_mod, synth_mod, fused):
     # the proven value before it.  Still accepted, still the sequential scan (the partial fallback, not the whole-pass one)
     r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, dc_rounds=0, fused=fused)
     assert r["ctl"]["dc_finished"] >= 3 and r["ctl"]["dc_count0"] == 0, r["ctl"]      # (the walk takes what it settles off the count)
+    # the chain's second level (groups of 64 blocks of 64 units: traces of more than 4 096 idle-grid slots), the finishing walk
+    # behind one round of it
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, dc_two_levels=True, fused=fused)
+    assert r["ctl"]["dc_reruns"] > 0 and r["ctl"]["dc_finished"] == 0, r["ctl"]
+    r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, dc_two_levels=True, dc_rounds=0, fused=fused)
+    assert r["ctl"]["dc_finished"] >= 3, r["ctl"]
     # few, long pieces: avg_ampl too
     r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, target=6, fused=fused)
     # (the fused first pass guesses with the drift its look-back has found -- on the emulator, where workgroups run one after
@@ -96,10 +102,11 @@ def test_ls2_rerun_rounds_are_exercised(emu_mod, oracle_mod, synth_mod, fused):
     assert r["ctl"]["n_pieces"] <= 8 and (fused or r["ctl"]["avg_reruns"] > 0), r["ctl"]
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(dc_rounds=0)], ids=["rounds", "finishing-walk"])
+@pytest.mark.parametrize("kw", [dict(), dict(dc_rounds=0), dict(dc_two_levels=True)], ids=["rounds", "finishing-walk", "two-levels"])
 def test_ls2_dc_est_chain_over_several_blocks(emu_mod, oracle_mod, synth_mod, kw):
     """Pieces of 64 samples: 235 idle-grid slots = four blocks of the dc_est chain (most slots empty, the units spread over the
-    blocks), on the trace whose dc_est hovers across 16.0: the tables' chain through empty blocks and several blocks must still give the sequential scan's dc_est at every gate opening."""
+    blocks), on the trace whose dc_est hovers across 16.0: the tables' chain through empty nodes, several blocks and -- forced --
+    the second level must still give the sequential scan's dc_est at every gate opening."""
     t = synth_mod.make_trace(n_rounds=20, sigma=0.08, seed=9).samples
     r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, min_piece=64, check_avg=False, **kw)
     c = r["ctl"]
@@ -107,7 +114,7 @@ def test_ls2_dc_est_chain_over_several_blocks(emu_mod, oracle_mod, synth_mod, kw
 
 
 @pytest.mark.parametrize("sigma,bias", [(0.03, 300), (0.01, 5000), (0.002, 1000)])
-@pytest.mark.parametrize("kw", [dict(), dict(dc_rounds=0), dict(dc_rounds=1)], ids=["rounds", "walk-only", "one-round"])
+@pytest.mark.parametrize("kw", [dict(), dict(dc_two_levels=True), dict(dc_rounds=0), dict(dc_rounds=1)], ids=["rounds", "two-levels", "walk-only", "one-round"])
 def test_ls2_dc_est_far_starts_margins_and_reruns(emu_mod, oracle_mod, synth_mod, sigma, bias, kw):
     """What a LONG trace does to the dc_est stage, on a short one: the first round's centres (the ring means) are moved `bias`
     ulps off (the rounding drift of 10^8 additions), so that every unit's true start lies far outside its 64-candidate window.
@@ -120,7 +127,7 @@ def test_ls2_dc_est_far_starts_margins_and_reruns(emu_mod, oracle_mod, synth_mod
     r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, min_piece=64, check_avg=False, dc_bias=bias, **kw)
     c = r["ctl"]
     assert c["n_units"] >= 30 and c["fail"] == 0, c
-    if kw.get("dc_rounds", 3) >= 1:
+    if kw.get("dc_rounds", 3) >= 1 and "dc_two_levels" not in kw:
         assert c["dc_finished"] == 0 and c["dc_rounds"] <= 3, c          # (the second round settles everything away from binade edges)
 
 
