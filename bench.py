@@ -137,18 +137,24 @@ def workload_replicas(torch, rfid, synth, args, device, rank, B, tag):
                          % (tag, B, L, args.sigma))
 
 
-def workload_single_trace(torch, rfid, synth, args, device, rank, fixed_q, n_rounds, n_tags, tag):
-    """One long trace built in HBM from its slot table (different tags / seed per rank)."""
+def workload_single_trace(torch, rfid, synth, args, device, rank, fixed_q, n_rounds, n_tags, tag, reuse=None):
+    """One long trace built in HBM from its slot table (different tags / seed per rank).  reuse: a workload of the same shape whose
+    context and buffer are used again (the trace is synthesised anew, with args.sigma)."""
     tag_ids = tuple(((0x11 + 0x10 * k + rank) & 0xFF) for k in range(n_tags))
     t0 = time.perf_counter()
     kw = {} if args.leak_phase is None else {"leak": complex(np.cos(args.leak_phase), np.sin(args.leak_phase))}
     t = synth.make_trace(n_rounds=n_rounds, fixed_q=fixed_q, tag_ids=tag_ids, sigma=0.0, seed=args.seed + rank,
                          noise=False, render=False, **kw)
     plan_s = time.perf_counter() - t0
-    ctx = rfid.Context(device=device.index, fixed_q=fixed_q, max_num_queries=(1 << 31) - 2)
+    ctx = reuse["ctx"] if reuse else rfid.Context(device=device.index, fixed_q=fixed_q, max_num_queries=(1 << 31) - 2)
     L = ctx.synth_gen2_size(t.plan)
     stride = (L + 1) & ~1
-    data = torch.zeros((1, 2 * stride), dtype=torch.float32, device=device)
+    if reuse:
+        assert reuse["L"] == L and reuse["stride"] == stride
+        ctx.batch_sync()
+        data = reuse["data"]
+    else:
+        data = torch.zeros((1, 2 * stride), dtype=torch.float32, device=device)
     torch.cuda.synchronize()
     ctx.synth_gen2_ptr(t.plan, data.data_ptr(), stride, sigma=args.sigma, seed=args.seed, replica=rank)
     ctx.batch_sync()
@@ -381,7 +387,7 @@ def device_state_static(torch, device):
     return out
 
 
-def measure(torch, wl, steps, warmup, barrier, gather_elapsed=None, n_series=None, back_to_back=True):
+def measure(torch, wl, steps, warmup, barrier, gather_elapsed=None, n_series=None, back_to_back=True, wake_s=None):
     """`warmup` untimed passes, then exactly `steps` timed passes of the workload's whole chain, enqueued one behind the other
     and waited for once (bracketed by `barrier()`, which synchronises the device; back_to_back=False: every pass waited for
     by itself, as rounds 1-3 timed it -- the profiled runs use that, a kernel trace then holds no queueing), then an untimed
@@ -400,7 +406,7 @@ def measure(torch, wl, steps, warmup, barrier, gather_elapsed=None, n_series=Non
     # then run 3 % slower than every later one (profiles/r04/bench_warm.txt).  The same passes are run for WAKE_S of wall
     # time before the W warm-up steps; neither is timed.
     wake_t0, wake_n = time.perf_counter(), 0
-    while time.perf_counter() - wake_t0 < WAKE_S and wake_n < 400:
+    while time.perf_counter() - wake_t0 < (WAKE_S if wake_s is None else wake_s) and wake_n < 400:
         step()
         wake_n += 1
     wake_ms = 1e3 * (time.perf_counter() - wake_t0)
@@ -568,6 +574,21 @@ def other_configs(torch, rfid, synth, args, device, rank):
                                         if k in m["rep"]}
             if not m["parity_ok"]:
                 entry["FAILED"] = True
+            # the same workload at SURVEY 8(d)'s stress noise (sigma = 0.03): a light measurement (2 passes each waited for) of what the
+            # long-stream front end does there.  With the survey's carrier leak (phase 0.7: 25 sin 0.7 = 16.1) dc_est hovers across a
+            # binade edge under this noise and the finishing walk takes most units (long_stream.dc_finished): slower, never wrong
+            try:
+                a2 = copy.copy(a)
+                a2.sigma = 0.03
+                wl2 = workload_single_trace(torch, rfid, synth, a2, device, rank, sp["fixed_q"], sp["n_rounds"], sp["n_tags"], name, reuse=wl)
+                m2 = measure(torch, wl2, 2, 0, torch.cuda.synchronize, None, n_series=1, back_to_back=False, wake_s=0.0)
+                entry["noise"] = {"sigma": 0.03, "ms_per_step_each_waited_for": round(1e3 * statistics.fmean(m2["step_s"]), 4),
+                                  "parity_check": m2["parity_text"],
+                                  "long_stream": {k: m2["rep"][k] for k in ("avg_rounds", "dc_rounds", "dc_reruns", "dc_finished", "verified", "gave_up") if k in m2["rep"]}}
+                if not m2["parity_ok"]:
+                    entry["FAILED"] = True
+            except Exception as e:
+                entry["noise"] = {"skipped": repr(e)}
             res[name] = entry
         finally:
             wl["ctx"].close()

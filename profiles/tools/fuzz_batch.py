@@ -47,7 +47,8 @@ def run(seed):
                 for b, (wb, rb, sb) in enumerate(parity.split_by_stream(w, r, s, B)):
                     parity.compare_trace(wb, rb, sb, st[b], refs[b])
                 if mode == 2:
-                    verdicts.append(ctx.batch_ls_report()["verified"])
+                    rep = ctx.batch_ls_report()
+                    verdicts.append((sigma, rep["verified"], rep["gave_up"], rep["dc_finished"], rep["units"]))
         finally:
             ctx.close()
     return verdicts
@@ -63,4 +64,14 @@ for seed in range(first, first + count):
     except Exception as e:
         bad += 1
         print("seed", seed, "FAILED:", repr(e)[:400])
-print("passed", ok, "failed", bad, "| long-stream passes verified:", sum(ver), "of", len(ver))
+print("passed", ok, "failed", bad, "| long-stream passes verified:", sum(v[1] for v in ver), "of", len(ver))
+# ... by noise level: accepted passes, the reason of the others (rfid_ls_report.gave_up: 1 = the traces were too short to be cut more
+# than once -- nothing to gain, the sequential scan is the faster way), passes whose dc_est went through the finishing walk
+for sg in sorted(set(v[0] for v in ver)):
+    vs = [v for v in ver if v[0] == sg]
+    why = {}
+    for v in vs:
+        if not v[1]:
+            why[v[2]] = why.get(v[2], 0) + 1
+    print("  sigma %-6g passes %3d  verified %3d  gave up by reason %s  finishing walk engaged in %d passes (%d of %d units)"
+          % (sg, len(vs), sum(v[1] for v in vs), dict(sorted(why.items())), sum(1 for v in vs if v[3] > 0), sum(v[3] for v in vs), sum(v[4] for v in vs)))

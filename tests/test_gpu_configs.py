@@ -100,28 +100,40 @@ def test_config2_full_size_multi_tag_inventory(oracle_mod, synth_mod):
         ctx.close()
 
 
-def test_config3_one_long_stream_per_gpu(oracle_mod, synth_mod):
+@pytest.mark.parametrize("sigma,leak_phase", [(0.004, 0.7), (0.03, 0.7), (0.06, 0.7), (0.06, 0.6)],
+                         ids=["sigma0.004", "sigma0.03-hover", "sigma0.06-hover", "sigma0.06-phase0.6"])
+def test_config3_one_long_stream_per_gpu(oracle_mod, synth_mod, sigma, leak_phase):
     """configs[3], the per-GPU workload: one RX stream (2 000 inventory rounds, 30 M raw samples = 15 s on air at
-    2 Msps) -- bit-identical to the oracle, window by window."""
+    2 Msps) -- bit-identical to the oracle, window by window, at SURVEY 8(d)'s noise levels: 0.004, and the stress levels
+    0.03 / 0.06.  With the survey's carrier leak e^{j 0.7} the imaginary part of the filtered carrier is 25 sin 0.7 = 16.105 and
+    dc_est, a 48-sample mean of it, hovers ACROSS the binade edge at 16.0 under the stress noise (its standard deviation there is
+    0.05 / 0.10): until round 5 the dc_est stage proved nothing on such a trace and every pass fell back to the sequential scan.
+    Now the pass is always accepted -- units settle by rounds where the sums keep away from binade edges, and what is left goes
+    through the finishing walk (rfid_ls_report.dc_finished: the partial fallback) -- and the result is the oracle's either way."""
     import rfid
+    leak = complex(np.cos(leak_phase), np.sin(leak_phase))
     t = synth_mod.make_trace(n_rounds=200 if SMALL else 2000, fixed_q=0, tag_ids=(0x5A,), sigma=0.0, seed=303,
-                             noise=False, render=False, t1_jitter_raw=6)
+                             noise=False, render=False, t1_jitter_raw=6, leak=leak)
     ctx = rfid.Context(device=0, max_num_queries=(1 << 31) - 2)
     try:
-        data, L, stride = _gen_trace(ctx, t.plan, sigma=0.004, seed=5, replica=3)
+        data, L, stride = _gen_trace(ctx, t.plan, sigma=sigma, seed=5, replica=3)
         ctx.batch_plan(1, L)
         ctx.batch_process_ptr(data.data_ptr(), stride, L, 0, want_scores=False)
         ctx.batch_sync()
         rep = ctx.batch_ls_report()
         print("long-stream report:", rep)
-        assert rep["verified"] == 1 and rep["pieces"] > 50 and rep["units"] > 50
-        # (the comparison with the oracle below covers dc_est at every window: the runs' values shifted to the true starts)
+        assert rep["verified"] == 1 and rep["gave_up"] == 0 and rep["pieces"] > 50 and rep["units"] > 50
         assert rep["avg_rounds"] >= 1 and rep["dc_rounds"] >= 1 and rep["fsm_rounds"] >= 1, rep
+        if leak_phase != 0.7 or sigma < 0.01:
+            assert rep["dc_finished"] == 0, rep          # (away from binade edges the rounds settle everything)
+        else:
+            assert rep["dc_finished"] > 0, rep           # (the partial fallback was engaged -- and only it)
         w, r, _ = ctx.batch_windows()
         st = ctx.batch_stats()
         o = _oracle_over_device_trace(oracle_mod, data, L, oracle_mod.config(max_num_queries=(1 << 31) - 2))
-        parity.compare_trace_fast(w, r, st[0], o)
-        assert st[0]["n_epc_correct"] == len(t.slots) and st[0]["tag_reads"][0x5A] == len(t.slots)
+        parity.compare_trace_fast(w, r, st[0], o)        # (starts, types, dc_est bit for bit, sync index, h_est, T, bits, CRC, statistics)
+        if sigma < 0.05:
+            assert st[0]["n_epc_correct"] == len(t.slots) and st[0]["tag_reads"][0x5A] == len(t.slots)
     finally:
         ctx.close()
 
