@@ -145,6 +145,17 @@ RFID_DEVICE void await(const int *flag, int v) {
   while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != v) __builtin_amdgcn_s_sleep(2);
 }
 RFID_DEVICE int atomic_max(int *p, int v) { return atomicMax(p, v); }
+// the workgroups of one launch meet: everything a workgroup has written before is visible to all of them behind it.  `target` =
+// arrivals so far expected in the counter (it only counts up: workgroups x meetings).  ALL workgroups concerned must be resident at
+// once -- the caller launches no more of them than the device holds whatever else is running (a few hundred single-wave workgroups).
+RFID_DEVICE void grid_meet(int *counter, int target, int tid) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if (tid == 0) {
+    __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
 // one 8-byte word handed from one workgroup of a launch to another: device-coherent, and NOTHING else is ordered by it (no
 // release / acquire: on this part those write back / invalidate the XCD's whole L2 -- once per wave of a 130 000-wave launch
 // that made the launch 3x slower).  Whatever belongs together has to sit in the one word.

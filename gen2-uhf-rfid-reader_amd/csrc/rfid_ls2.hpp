@@ -133,6 +133,7 @@ struct Ls2Args {
   int *dtab;                    // [NH][2][64] dc_est behind the unit for each candidate
   int *dstat;                   // [NH] bit 0 / 1: re / im settled, bit 2: the slot holds a unit, bit 3: its latest run does not cover the start predicted for it (zeroed before a pass)
   int *dfront;                  // [n_streams] the trace's first idle-grid slot whose unit is not settled (after a chain; INT_MAX: none)
+  int *fscr, *fbar;             // the finishing walk's scratch [n_streams][2][LS2_FIN_GMAX][LS2_FIN_REC] and its meeting counters [n_streams] (zeroed before a pass)
   int *dmar;                    // [NH][2] how far from its centre a start may lie for the unit's end to be a plain shift of candidate 32's / 33's (ulps; 0: nowhere)
   int *dwbase;                  // [NH] the unit's first place in dcand
   float2 *dcand; int dcand_cap; // [dcand_cap][64] dc_est at a gate opening for each candidate
@@ -351,6 +352,7 @@ RFID_KERNEL(256) void ls2_clear_kernel(Ls2Args a) {
   zero4(a.cflag, B * LS2_CHAIN_GMAX);
   zero4(a.consumed, B);
   zero4(a.dstat, B * a.max_bc);
+  zero4(a.fbar, B);
   if (a.fused) { zero8(a.lb_fn, B * a.max_b); zero8(a.lb_end, B * a.max_b); zero4(a.lb_water, B); }
   if (!a.keep_flat_count) zero4(a.flat_count, 2);   // (a first pass that runs beside the pass before: its decoder still reads them)
   zero8(a.votes, 2 * B * a.vstride);
@@ -2145,114 +2147,117 @@ RFID_KERNEL(64) void ls2_dcb_down1_kernel(Ls2Args a) {
 }
 // The enqueued rounds are used up and units are still unsettled (sums that hover at a binade edge: what a start value does to
 // a unit's end is then no shift, the window catches the chain's prediction for a few units only, and exactness can only walk
-// along the trace).  One workgroup of sixteen waves per trace walks: per turn the sixteen idle-grid slots behind the frontier
-// are run at once -- the first from its exact start, the others centred on the last chain's prediction moved along by what the
-// frontier has turned out to be off -- then wave 0 goes through their tables from the exact value: as far as each start lies
-// inside its unit's window (or margin) the units are settled and the frontier moves on; the first miss is the next turn's first
-// unit.  At least one unit per turn, up to sixteen.  Settled units keep their results: the pass costs its clean time plus this
-// walk over the unsettled units -- the partial fallback; the launches behind (window sequence numbers, assembly) find everything
-// settled.
-constexpr int LS2_DCB_FIN_WAVES = 16;
-RFID_KERNEL(64 * LS2_DCB_FIN_WAVES) void ls2_dcb_finish_kernel(Ls2Args a) {
+// along the trace).  The finishing walk: G waves per trace -- on the device G single-wave workgroups, each with a CU (nearly) to
+// itself; WPB waves per workgroup is the same kernel for the test suite's emulator, which runs one workgroup at a time -- take
+// turns.  Per turn wave w runs the w-th idle-grid slot behind the frontier: the first from its exact start, the others centred on
+// the last chain's prediction moved along by what the frontier has turned out to be off; the waves meet (a device-wide barrier
+// over one counter per trace); then EVERY wave goes through the turn's tables from the exact value -- the same arithmetic on the
+// same data, so all of them know the new frontier without a second meeting: as far as each start lies inside its unit's window
+// (or margin) the units are settled, the first miss is the next turn's first unit.  At least one unit per turn, up to G; as
+// many waves take part as the last turn's reach suggests.  Settled units keep their results: the pass costs its clean time plus
+// this walk over the unsettled units -- the partial fallback; the launches behind (window sequence numbers, assembly) find
+// everything settled.  (The turn's tables go through a scratch area in HBM, two sets used alternately: a wave may be one
+// turn ahead of the slowest, never two.)
+constexpr int LS2_FIN_GMAX = 256;       // waves per trace, at most
+constexpr int LS2_FIN_REC = 136;        // ints per wave and set: centre (2), margin (2), in use (1), pad (3), table (2 x 64)
+template <int WPB>
+RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
   ls2_tail_prio();
-  RFID_SHARED float2 lds_dc[LS2_DCB_FIN_WAVES][DC_LEN];
-  RFID_SHARED float2 lds_tmp[LS2_DCB_FIN_WAVES][64];
-  RFID_SHARED float4 lds_q4[LS2_DCB_FIN_WAVES][32];
-  RFID_SHARED int sh_tab[LS2_DCB_FIN_WAVES][2][64];
-  RFID_SHARED int sh_cen[LS2_DCB_FIN_WAVES][2], sh_mar[LS2_DCB_FIN_WAVES][2], sh_on[LS2_DCB_FIN_WAVES];
-  RFID_SHARED int sh_pos, sh_T[2], sh_corr[2], sh_fixed, sh_waves;
+  RFID_SHARED float2 lds_dc[WPB][DC_LEN];
+  RFID_SHARED float2 lds_tmp[WPB][64];
+  RFID_SHARED float4 lds_q4[WPB][32];
   Ls2Ctl *ctl = a.ctl;
   if (!ls2_fsm_settled(a, ctl)) return;
-  if (ctl->dc_count[a.dc_rounds] == 0) return;
-  const int tid = (int)threadIdx.x, lane = wv::lane_id(), wave = wv::uniform(tid >> 6);
-  const int s = (int)blockIdx.x;
+  if (wv::uniform(ctl->dc_count[a.dc_rounds]) == 0) return;
+  const int tid = (int)threadIdx.x, lane = wv::lane_id(), wib = wv::uniform(tid >> 6);
+  const int s = (int)blockIdx.y;
+  const int G = (int)gridDim.x * WPB;                 // waves of this trace
+  const int wid = (int)blockIdx.x * WPB + wib;        // this wave among them
   const int t0 = s * a.max_bc;
-  if (wave == 0) {   // the frontier: the trace's first unit that is not settled (its start value from the last chain is exact)
-    int first = -1;
-    for (int k0 = 0; k0 < a.max_bc && first < 0; k0 += 64) {
-      const int k = k0 + lane;
-      const int st = (k < a.max_bc) ? a.dstat[t0 + k] : 0;
-      const uint64_t m = wv::ballot((st & 4) != 0 && (st & 3) != 3);
-      if (m) first = k0 + wv::ffs64(m);
+  int *scr = a.fscr + (int64_t)s * 2 * LS2_FIN_GMAX * LS2_FIN_REC;
+  int *bar = a.fbar + s;
+  // ---- the frontier (every wave finds it for itself: the same data, the same answer) ----
+  int first = -1;
+  for (int k0 = 0; k0 < a.max_bc && first < 0; k0 += 64) {
+    const int k = k0 + lane;
+    const int st = (k < a.max_bc) ? a.dstat[t0 + k] : 0;
+    const uint64_t m = wv::ballot((st & 4) != 0 && (st & 3) != 3);
+    if (m) first = k0 + wv::ffs64(m);
+  }
+  if (first < 0) return;   // (every wave of the trace leaves: nobody waits at a barrier)
+  // its exact start: the end of the settled unit before it (that unit's start is exact and inside its window or margin).  NOT the
+  // start the chain wrote for it: that came through the tables of whole blocks, and a block's table may have missed where
+  // every unit inside it, walked one by one, was hit
+  int Tre = 0, Tim = 0;
+  {
+    int prev = -1;
+    for (int k1 = first; k1 > 0 && prev < 0; k1 -= 64) {   // the slots k1 - 64 .. k1 - 1
+      const int k = k1 - 64 + lane;
+      const uint64_t m = wv::ballot(k >= 0 && (a.dstat[t0 + ((k >= 0) ? k : 0)] & 4) != 0);
+      if (m) prev = k1 - 64 + (63 - (int)__builtin_clzll(m));
     }
-    // its exact start: the end of the settled unit before it (that unit's start is exact and inside its window or margin).  NOT the
-    // start the chain wrote for it: that came through the tables of whole blocks, and a block's table may have missed where
-    // every unit inside it, walked one by one, was hit
-    int Tre = 0, Tim = 0;
-    if (first >= 0) {
-      int prev = -1;
-      for (int k1 = first; k1 > 0 && prev < 0; k1 -= 64) {   // the slots k1 - 64 .. k1 - 1
-        const int k = k1 - 64 + lane;
-        const uint64_t m = wv::ballot(k >= 0 && (a.dstat[t0 + ((k >= 0) ? k : 0)] & 4) != 0);
-        if (m) prev = k1 - 64 + (63 - (int)__builtin_clzll(m));
-      }
-      if (prev < 0) { Tre = wv::uniform(a.dcen[2 * (t0 + first)]); Tim = wv::uniform(a.dcen[2 * (t0 + first) + 1]); }   // (the trace's first unit: its centre is the exact start)
-      else {
-        const int tp = t0 + prev;
-        Tre = wv::uniform(a.dT[2 * tp]); Tim = wv::uniform(a.dT[2 * tp + 1]);
-        bool exr = true, exi = true;
-        ls2_dcb_apply<true>(Tre, exr, a.dtab[(int64_t)(2 * tp) * 64 + lane], ~0ull, wv::uniform(a.dcen[2 * tp]), wv::uniform(a.dmar[2 * tp]));
-        ls2_dcb_apply<true>(Tim, exi, a.dtab[(int64_t)(2 * tp + 1) * 64 + lane], ~0ull, wv::uniform(a.dcen[2 * tp + 1]), wv::uniform(a.dmar[2 * tp + 1]));
-        if (!(exr && exi)) { if (lane == 0) ctl->fail = 7; first = -1; }   // (a settled unit's end is exact by definition)
-      }
-    }
-    if (lane == 0) {
-      sh_pos = first; sh_fixed = 0; sh_corr[0] = 0; sh_corr[1] = 0; sh_waves = LS2_DCB_FIN_WAVES;
-      if (first >= 0) { sh_corr[0] = Tre - a.dT[2 * (t0 + first)]; sh_corr[1] = Tim - a.dT[2 * (t0 + first) + 1]; sh_T[0] = Tre; sh_T[1] = Tim; }
+    if (prev < 0) { Tre = wv::uniform(a.dcen[2 * (t0 + first)]); Tim = wv::uniform(a.dcen[2 * (t0 + first) + 1]); }   // (the trace's first unit: its centre is the exact start)
+    else {
+      const int tp = t0 + prev;
+      Tre = wv::uniform(a.dT[2 * tp]); Tim = wv::uniform(a.dT[2 * tp + 1]);
+      bool exr = true, exi = true;
+      ls2_dcb_apply<true>(Tre, exr, a.dtab[(int64_t)(2 * tp) * 64 + lane], ~0ull, wv::uniform(a.dcen[2 * tp]), wv::uniform(a.dmar[2 * tp]));
+      ls2_dcb_apply<true>(Tim, exi, a.dtab[(int64_t)(2 * tp + 1) * 64 + lane], ~0ull, wv::uniform(a.dcen[2 * tp + 1]), wv::uniform(a.dmar[2 * tp + 1]));
+      if (!(exr && exi)) { if (lane == 0) ctl->fail = 7; return; }   // (a settled unit's end is exact by definition; every wave sees the same)
     }
   }
-  wv::block_sync();
-  for (;;) {
-    const int pos = sh_pos;
-    if (pos < 0 || pos >= a.max_bc) break;
-    const int k = pos + wave;
+  int pos = first;
+  int corr_re = Tre - wv::uniform(a.dT[2 * (t0 + first)]), corr_im = Tim - wv::uniform(a.dT[2 * (t0 + first) + 1]);
+  int nact = (G < 16) ? G : 16;      // waves that take part in the next turn
+  int fixed = 0, turn = 0;
+  while (pos < a.max_bc) {
+    int *set = scr + (int64_t)(turn & 1) * LS2_FIN_GMAX * LS2_FIN_REC;
+    const int k = pos + wid;
     const int t = t0 + k;
-    // (as many waves as the last turn's reach suggests: sixteen waves of one CU share its LDS, whose return path is what a unit's
-    // run is bound by -- where only the first two or three units of a turn are hit, the others only slow them down)
-    const bool on = wave < sh_waves && k < a.max_bc && (wv::uniform(a.dstat[(k < a.max_bc) ? t : t0]) & 4) != 0;
-    if (on) {
-      // wave 0's unit starts from the exact value; the others from the last chain's prediction + what the frontier was off by
-      const int cre = (wave == 0) ? sh_T[0] : (wv::uniform(a.dT[2 * t]) + sh_corr[0]);
-      const int cim = (wave == 0) ? sh_T[1] : (wv::uniform(a.dT[2 * t + 1]) + sh_corr[1]);
-      int er, ei;
-      ls2_dcb_unit(a, t, true, cre, cim, false, lane, lds_dc[wave], lds_tmp[wave], reinterpret_cast<float2 *>(lds_q4[wave]), er, ei);
-      sh_tab[wave][0][lane] = er; sh_tab[wave][1][lane] = ei;
-      if (lane == 0) { sh_cen[wave][0] = a.dcen[2 * t]; sh_cen[wave][1] = a.dcen[2 * t + 1]; sh_mar[wave][0] = a.dmar[2 * t]; sh_mar[wave][1] = a.dmar[2 * t + 1]; }
-    }
-    if (lane == 0) sh_on[wave] = on ? 1 : 0;
-    wv::block_sync();
-    if (wave == 0) {
-      int Tre = sh_T[0], Tim = sh_T[1];
-      int w = 0, fixed = 0;
-      int corr_re = sh_corr[0], corr_im = sh_corr[1];
-      const int nact = sh_waves;
-      for (; w < nact && pos + w < a.max_bc; ++w) {
-        if (!wv::uniform(sh_on[w])) continue;   // (a slot without a unit)
-        const int tw = t0 + pos + w;
-        const int c_re = wv::uniform(sh_cen[w][0]), c_im = wv::uniform(sh_cen[w][1]), m_re = wv::uniform(sh_mar[w][0]), m_im = wv::uniform(sh_mar[w][1]);
-        const int D_re = (int)((uint32_t)Tre - (uint32_t)c_re), D_im = (int)((uint32_t)Tim - (uint32_t)c_im);
-        const bool k_re = (D_re >= -LS2_DCB_HALF && D_re < LS2_DCB_HALF) || (D_re != (int)0x80000000 && ((D_re < 0) ? -D_re : D_re) <= m_re);
-        const bool k_im = (D_im >= -LS2_DCB_HALF && D_im < LS2_DCB_HALF) || (D_im != (int)0x80000000 && ((D_im < 0) ? -D_im : D_im) <= m_im);
-        if (!(k_re && k_im)) {
-          // a miss: this unit's true start is known now -- the next turn's first unit; the predictions behind move along with it
-          if (w > 0) { corr_re += (int)((uint32_t)Tre - (uint32_t)c_re); corr_im += (int)((uint32_t)Tim - (uint32_t)c_im); }
-          break;
-        }
-        if (lane == 0) { a.dT[2 * tw] = Tre; a.dT[2 * tw + 1] = Tim; a.dstat[tw] = 7; }
-        fixed++;
-        bool exr = true, exi = true;
-        ls2_dcb_apply<true>(Tre, exr, sh_tab[w][0][lane], ~0ull, c_re, m_re);
-        ls2_dcb_apply<true>(Tim, exi, sh_tab[w][1][lane], ~0ull, c_im, m_im);
+    const bool on = wid < nact && k < a.max_bc && (wv::uniform(a.dstat[(k < a.max_bc) ? t : t0]) & 4) != 0;
+    if (wid < nact) {
+      int *rec = set + (int64_t)wid * LS2_FIN_REC;
+      if (on) {
+        // the turn's first unit starts from the exact value; the others from the last chain's prediction + what the frontier was off by
+        const int cre = (wid == 0) ? Tre : (wv::uniform(a.dT[2 * t]) + corr_re);
+        const int cim = (wid == 0) ? Tim : (wv::uniform(a.dT[2 * t + 1]) + corr_im);
+        int er, ei;
+        ls2_dcb_unit(a, t, true, cre, cim, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei);
+        rec[8 + lane] = er; rec[72 + lane] = ei;
+        if (lane == 0) { rec[0] = a.dcen[2 * t]; rec[1] = a.dcen[2 * t + 1]; rec[2] = a.dmar[2 * t]; rec[3] = a.dmar[2 * t + 1]; }
       }
-      if (lane == 0) {
-        sh_pos = pos + w; sh_T[0] = Tre; sh_T[1] = Tim; sh_corr[0] = corr_re; sh_corr[1] = corr_im; sh_fixed += fixed;
-        const int nw = 2 * w + 2;
-        sh_waves = (nw > LS2_DCB_FIN_WAVES) ? LS2_DCB_FIN_WAVES : nw;
-      }
+      if (lane == 0) rec[4] = on ? 1 : 0;
     }
+    // ---- the waves of the trace meet ----
     wv::block_sync();
+    if (gridDim.x > 1) wv::grid_meet(bar, (int)gridDim.x * (turn + 1), tid);
+    wv::block_sync();
+    // ---- through the turn's tables from the exact value ----
+    int w = 0;
+    for (; w < nact && pos + w < a.max_bc; ++w) {
+      const int *rec = set + (int64_t)w * LS2_FIN_REC;
+      if (!wv::uniform(rec[4])) continue;   // (a slot without a unit)
+      const int tw = t0 + pos + w;
+      const int c_re = wv::uniform(rec[0]), c_im = wv::uniform(rec[1]), m_re = wv::uniform(rec[2]), m_im = wv::uniform(rec[3]);
+      const int D_re = (int)((uint32_t)Tre - (uint32_t)c_re), D_im = (int)((uint32_t)Tim - (uint32_t)c_im);
+      const bool k_re = (D_re >= -LS2_DCB_HALF && D_re < LS2_DCB_HALF) || (D_re != (int)0x80000000 && ((D_re < 0) ? -D_re : D_re) <= m_re);
+      const bool k_im = (D_im >= -LS2_DCB_HALF && D_im < LS2_DCB_HALF) || (D_im != (int)0x80000000 && ((D_im < 0) ? -D_im : D_im) <= m_im);
+      if (!(k_re && k_im)) {
+        // a miss: this unit's true start is known now -- the next turn's first unit; the predictions behind move along with it
+        if (w > 0) { corr_re += (int)((uint32_t)Tre - (uint32_t)c_re); corr_im += (int)((uint32_t)Tim - (uint32_t)c_im); }
+        break;
+      }
+      if (w == wid && lane == 0) { a.dT[2 * tw] = Tre; a.dT[2 * tw + 1] = Tim; a.dstat[tw] = 7; }   // (the wave that ran the unit)
+      fixed++;
+      bool exr = true, exi = true;
+      ls2_dcb_apply<true>(Tre, exr, rec[8 + lane], ~0ull, c_re, m_re);
+      ls2_dcb_apply<true>(Tim, exi, rec[72 + lane], ~0ull, c_im, m_im);
+    }
+    pos += w;
+    { const int nw = 2 * w + 2; nact = (nw > G) ? G : nw; }
+    turn++;
   }
-  if (tid == 0 && sh_fixed) { wv::atomic_add(&ctl->dc_count[a.dc_rounds], -sh_fixed); wv::atomic_add(&ctl->dc_finished, sh_fixed); }
+  if (wid == 0 && lane == 0 && fixed) { wv::atomic_add(&ctl->dc_count[a.dc_rounds], -fixed); wv::atomic_add(&ctl->dc_finished, fixed); }
 }
 
 // ---- 5. windows ----------------------------------------------------------------------------------------------------

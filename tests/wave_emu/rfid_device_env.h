@@ -236,6 +236,8 @@ static inline void load4_i32(const int *p, int &a, int &b, int &c, int &d) { a =
 static inline int atomic_add(int *p, int v) { int o = *p; *p = o + v; return o; }
 static inline int atomic_min(int *p, int v) { int o = *p; if (v < o) *p = v; return o; }
 static inline int atomic_max(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
+// (the emulator runs one workgroup at a time: a launch whose workgroups meet has exactly one here)
+static inline void grid_meet(int *, int, int) { fprintf(stderr, "[emu] grid_meet with more than one workgroup\n"); abort(); }
 static inline uint64_t load_u64_agent(const uint64_t *p) { return *(const volatile uint64_t *)p; }
 static inline void store_u64_agent(uint64_t *p, uint64_t v) { *(volatile uint64_t *)p = v; }
 static inline void system_release_fence() {}
