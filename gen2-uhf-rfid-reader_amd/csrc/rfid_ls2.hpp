@@ -2207,7 +2207,10 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
     }
   }
   int pos = first;
-  int corr_re = Tre - wv::uniform(a.dT[2 * (t0 + first)]), corr_im = Tim - wv::uniform(a.dT[2 * (t0 + first) + 1]);
+  int Fre = Tre, Fim = Tim;          // the exact value entering slot `pos` (every wave carries it)
+  int corr_re = Fre - wv::uniform(a.dT[2 * (t0 + first)]), corr_im = Fim - wv::uniform(a.dT[2 * (t0 + first) + 1]);
+  int Cre = Fre, Cim = Fim;          // where this wave centres its unit of the coming turn
+  if (wid > 0 && first + wid < a.max_bc) { Cre = wv::uniform(a.dT[2 * (t0 + first + wid)]) + corr_re; Cim = wv::uniform(a.dT[2 * (t0 + first + wid) + 1]) + corr_im; }
   int nact = (G < 16) ? G : 16;      // waves that take part in the next turn
   int fixed = 0, turn = 0;
   while (pos < a.max_bc) {
@@ -2218,11 +2221,10 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
     if (wid < nact) {
       int *rec = set + (int64_t)wid * LS2_FIN_REC;
       if (on) {
-        // the turn's first unit starts from the exact value; the others from the last chain's prediction + what the frontier was off by
-        const int cre = (wid == 0) ? Tre : (wv::uniform(a.dT[2 * t]) + corr_re);
-        const int cim = (wid == 0) ? Tim : (wv::uniform(a.dT[2 * t + 1]) + corr_im);
+        // the turn's first unit starts from the exact value; the others where the last turn's walk predicted them (or, behind its
+        // reach, the last chain's prediction moved along)
         int er, ei;
-        ls2_dcb_unit(a, t, true, cre, cim, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei);
+        ls2_dcb_unit(a, t, true, Cre, Cim, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei);
         rec[8 + lane] = er; rec[72 + lane] = ei;
         if (lane == 0) { rec[0] = a.dcen[2 * t]; rec[1] = a.dcen[2 * t + 1]; rec[2] = a.dmar[2 * t]; rec[3] = a.dmar[2 * t + 1]; }
       }
@@ -2232,29 +2234,63 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
     wv::block_sync();
     if (gridDim.x > 1) wv::grid_meet(bar, (int)gridDim.x * (turn + 1), tid);
     wv::block_sync();
-    // ---- through the turn's tables from the exact value ----
+    // ---- through the turn's tables from the exact value: as far as the starts are hit the units are settled; behind the first miss
+    //      the walk goes on as a PREDICTION (the missed unit's end continued from its nearest candidate), which is where the
+    //      next turn centres the units this turn has already run once -- a round of the chain within the turn's reach ----
+    int Wre = Fre, Wim = Fim;         // the walk's value
+    int miss = -1;                    // the turn's first slot whose unit was not hit
+    int nxt_re = 0, nxt_im = 0;       // where this wave centres its unit of the next turn
+    bool have_nxt = false;
+    int last_re = 0, last_im = 0, last_t = -1;   // the value entering the turn's last unit, and that unit
+    bool ex = true;
     int w = 0;
     for (; w < nact && pos + w < a.max_bc; ++w) {
       const int *rec = set + (int64_t)w * LS2_FIN_REC;
       if (!wv::uniform(rec[4])) continue;   // (a slot without a unit)
       const int tw = t0 + pos + w;
       const int c_re = wv::uniform(rec[0]), c_im = wv::uniform(rec[1]), m_re = wv::uniform(rec[2]), m_im = wv::uniform(rec[3]);
-      const int D_re = (int)((uint32_t)Tre - (uint32_t)c_re), D_im = (int)((uint32_t)Tim - (uint32_t)c_im);
-      const bool k_re = (D_re >= -LS2_DCB_HALF && D_re < LS2_DCB_HALF) || (D_re != (int)0x80000000 && ((D_re < 0) ? -D_re : D_re) <= m_re);
-      const bool k_im = (D_im >= -LS2_DCB_HALF && D_im < LS2_DCB_HALF) || (D_im != (int)0x80000000 && ((D_im < 0) ? -D_im : D_im) <= m_im);
-      if (!(k_re && k_im)) {
-        // a miss: this unit's true start is known now -- the next turn's first unit; the predictions behind move along with it
-        if (w > 0) { corr_re += (int)((uint32_t)Tre - (uint32_t)c_re); corr_im += (int)((uint32_t)Tim - (uint32_t)c_im); }
-        break;
+      if (ex) {
+        const int D_re = (int)((uint32_t)Wre - (uint32_t)c_re), D_im = (int)((uint32_t)Wim - (uint32_t)c_im);
+        const bool k_re = (D_re >= -LS2_DCB_HALF && D_re < LS2_DCB_HALF) || (D_re != (int)0x80000000 && ((D_re < 0) ? -D_re : D_re) <= m_re);
+        const bool k_im = (D_im >= -LS2_DCB_HALF && D_im < LS2_DCB_HALF) || (D_im != (int)0x80000000 && ((D_im < 0) ? -D_im : D_im) <= m_im);
+        if (k_re && k_im) {
+          if (w == wid && lane == 0) { a.dT[2 * tw] = Wre; a.dT[2 * tw + 1] = Wim; a.dstat[tw] = 7; }   // (the wave that ran the unit)
+          fixed++;
+        } else {
+          ex = false; miss = w;       // this unit's true start is known now: it is the next turn's first unit
+          Fre = Wre; Fim = Wim;
+        }
       }
-      if (w == wid && lane == 0) { a.dT[2 * tw] = Tre; a.dT[2 * tw + 1] = Tim; a.dstat[tw] = 7; }   // (the wave that ran the unit)
-      fixed++;
-      bool exr = true, exi = true;
-      ls2_dcb_apply<true>(Tre, exr, rec[8 + lane], ~0ull, c_re, m_re);
-      ls2_dcb_apply<true>(Tim, exi, rec[72 + lane], ~0ull, c_im, m_im);
+      if (!ex && w == miss + wid) { nxt_re = Wre; nxt_im = Wim; have_nxt = true; }
+      last_re = Wre; last_im = Wim; last_t = tw;
+      bool e1 = true, e2 = true;
+      ls2_dcb_apply<true>(Wre, e1, rec[8 + lane], ~0ull, c_re, m_re);
+      ls2_dcb_apply<true>(Wim, e2, rec[72 + lane], ~0ull, c_im, m_im);
     }
-    pos += w;
-    { const int nw = 2 * w + 2; nact = (nw > G) ? G : nw; }
+    if (ex) {
+      // every unit of the turn was hit: the value behind the last one is exact -- the next turn's first start
+      pos += w;
+      Fre = Wre; Fim = Wim;
+      nxt_re = Wre; nxt_im = Wim; have_nxt = (wid == 0);
+    } else {
+      pos += miss;
+    }
+    // the units behind the turn's reach: the last chain's prediction moved along by what this walk made of the turn's last unit
+    // (a unit this turn did NOT settle: the start values of settled units are being overwritten with their exact ones); when every
+    // unit of the turn was hit, by what the exact value is off at the first unit behind it
+    if (!ex) {
+      if (last_t >= 0 && last_t >= t0 + pos) { corr_re = last_re - wv::uniform(a.dT[2 * last_t]); corr_im = last_im - wv::uniform(a.dT[2 * last_t + 1]); }
+    } else if (pos < a.max_bc) {
+      const int kq = pos + lane;
+      const uint64_t mu = wv::ballot(kq < a.max_bc && (a.dstat[t0 + ((kq < a.max_bc) ? kq : 0)] & 4) != 0);
+      if (mu) { const int tq = t0 + pos + wv::ffs64(mu); corr_re = Fre - wv::uniform(a.dT[2 * tq]); corr_im = Fim - wv::uniform(a.dT[2 * tq + 1]); }
+    }
+    if (have_nxt) { Cre = nxt_re; Cim = nxt_im; }
+    else {
+      const int kn = pos + wid;
+      if (kn < a.max_bc) { Cre = wv::uniform(a.dT[2 * (t0 + kn)]) + corr_re; Cim = wv::uniform(a.dT[2 * (t0 + kn) + 1]) + corr_im; }
+    }
+    { const int nw = 2 * (ex ? w : miss) + 4; nact = (nw > G) ? G : nw; }
     turn++;
   }
   if (wid == 0 && lane == 0 && fixed) { wv::atomic_add(&ctl->dc_count[a.dc_rounds], -fixed); wv::atomic_add(&ctl->dc_finished, fixed); }
