@@ -2159,6 +2159,7 @@ RFID_KERNEL(64) void ls2_dcb_down1_kernel(Ls2Args a) {
 // everything settled.  (The turn's tables go through a scratch area in HBM, two sets used alternately: a wave may be one
 // turn ahead of the slowest, never two.)
 constexpr int LS2_FIN_GMAX = 256;       // waves per trace, at most
+constexpr int LS2_FIN_AHEAD = 64;       // ... that take part in a turn, at least (32 / 64 / 128 / 256 measured on configs[2] / [3] at sigma 0.03 and 0.06: profiles/r06/noise_sweep.txt)
 constexpr int LS2_FIN_REC = 136;        // ints per wave and set: centre (2), margin (2), in use (1), pad (3), table (2 x 64)
 template <int WPB>
 RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
@@ -2211,7 +2212,8 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
   int corr_re = Fre - wv::uniform(a.dT[2 * (t0 + first)]), corr_im = Fim - wv::uniform(a.dT[2 * (t0 + first) + 1]);
   int Cre = Fre, Cim = Fim;          // where this wave centres its unit of the coming turn
   if (wid > 0 && first + wid < a.max_bc) { Cre = wv::uniform(a.dT[2 * (t0 + first + wid)]) + corr_re; Cim = wv::uniform(a.dT[2 * (t0 + first + wid) + 1]) + corr_im; }
-  int nact = (G < 16) ? G : 16;      // waves that take part in the next turn
+  const int ahead = LS2_FIN_AHEAD;
+  int nact = (G < ahead) ? G : ahead;      // waves that take part in the next turn
   int fixed = 0, turn = 0;
   while (pos < a.max_bc) {
     int *set = scr + (int64_t)(turn & 1) * LS2_FIN_GMAX * LS2_FIN_REC;
@@ -2290,7 +2292,10 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
       const int kn = pos + wid;
       if (kn < a.max_bc) { Cre = wv::uniform(a.dT[2 * (t0 + kn)]) + corr_re; Cim = wv::uniform(a.dT[2 * (t0 + kn) + 1]) + corr_im; }
     }
-    { const int nw = 2 * (ex ? w : miss) + 4; nact = (nw > G) ? G : nw; }
+    // (waves of the next turn: twice the reach, and never fewer than LS2_FIN_AHEAD -- the units a few dozen slots behind the frontier are
+    // run again turn after turn, each time centred on a better prediction, so that they are within a window's reach of the truth
+    // when the frontier arrives; every wave has a CU of its own, what more of them cost is the walk over their tables)
+    { int nw = 2 * (ex ? w : miss) + 4; if (nw < ahead) nw = ahead; nact = (nw > G) ? G : nw; }
     turn++;
   }
   if (wid == 0 && lane == 0 && fixed) { wv::atomic_add(&ctl->dc_count[a.dc_rounds], -fixed); wv::atomic_add(&ctl->dc_finished, fixed); }
