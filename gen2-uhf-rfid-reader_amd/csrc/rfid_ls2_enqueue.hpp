@@ -184,7 +184,7 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
   // off by an ulp or two per such unit it came through -- the blocks' windows (+- 32) catch that for some thousand units per
   // round: one round (and the finishing walk for the handful it may leave) for a stream of a few thousand units, up to ~8 for configs[2]'s 32 000 (a round here is six small launches
   // and a handful of unit runs).  Sums that hover at a binade edge do not settle by rounds at all; the finishing walk takes them
-  a.dc_rounds = (dc_rounds >= 0) ? dc_rounds : ((tiny || small) ? 1 : LS2_DC_ROUNDS);
+  a.dc_rounds = (dc_rounds >= 0) ? dc_rounds : (tiny ? 0 : (small ? 1 : LS2_DC_ROUNDS));   // (a look-ahead pass holds a few dozen units: the first round and the walk)
   if (a.dc_rounds < 0) a.dc_rounds = 0;
   if (a.dc_rounds > LS2_DC_MAXR) a.dc_rounds = LS2_DC_MAXR;
   if (fused) {
