@@ -201,3 +201,36 @@ def test_the_same_protocols_on_a_device_that_is_behind(lag):
                         "-k", "late_filter or consumes_ahead or ragged_scheduler or gate_keyed or capacity_and_state or whole_chain or termination"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(HERE))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("mode", [0, 2], ids=["fused-front-end", "long-stream"])
+def test_batch_pass_through_the_library(oracle_mod, synth_mod, mode):
+    """rfid_batch_plan / rfid_batch_process / the getters over a ragged batch of two traces ("device" pointers are host pointers here):
+    the fused front end of many traces, and the long-stream front end with its fused first pass, dc_est chain and finishing walk
+    enqueued by the library's own launch list -- windows, results, scores and statistics equal the oracle's."""
+    import parity
+    import rfid
+    ts = [synth_mod.make_trace(n_rounds=3 + k, seed=70 + k, sigma=0.02, t1_jitter_raw=3).samples for k in range(2)]
+    L = max(map(len, ts))
+    stride = (L + 1) & ~1
+    host = np.zeros((2, stride), dtype=np.complex64)
+    lens = np.array([len(t) for t in ts], dtype=np.int64)
+    lens[0] -= 777
+    for i, t in enumerate(ts):
+        host[i, : len(t)] = t
+    refs = [oracle_mod.run_trace(host[b, : lens[b]]) for b in range(2)]
+    ctx = rfid.Context(device=0)
+    try:
+        ctx.batch_set_long_stream(mode)
+        ctx.batch_plan(2, L)
+        for rep in range(2):
+            ctx.batch_process_ptr(host.ctypes.data, stride, L, lens.ctypes.data, want_scores=True)
+            ctx.batch_sync()
+            w, r, s = ctx.batch_windows(want_scores=True)
+            st = ctx.batch_stats()
+            for b, (wb, rb, sb) in enumerate(parity.split_by_stream(w, r, s, 2)):
+                parity.compare_trace(wb, rb, sb, st[b], refs[b])
+        rep = ctx.batch_ls_report()
+        assert (rep["pieces"] > 0 and rep["verified"] == 1) if mode == 2 else rep["pieces"] == 0, rep
+    finally:
+        ctx.close()
