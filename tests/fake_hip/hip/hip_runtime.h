@@ -2,7 +2,7 @@
 // HOST side of the C-ABI library (gen2-uhf-rfid-reader_amd/csrc/rfid_capi.hip -- contexts, plans, the streaming and look-ahead
 // protocols: ~3 000 lines that otherwise only ever run on a GPU box) with g++ in the GPU-less CI container and drive it from
 // `pytest -m "not gpu"`.  "Device memory" is host memory, a "launch" runs the UNMODIFIED kernel source on the suite's lock-step wave
-// emulator (tests/wave_emu), streams execute in order.  tests/fake_hip/build.py links this into tests/fake_hip/librfid_capi_emu.so,
+// emulator (tests/wave_emu), streams execute in order.  tests/fake_hip/build_capi_emu.py links this into tests/fake_hip/librfid_capi_emu.so,
 // which only tests load (tests/test_capi_protocol.py binds it with ctypes themselves); the product library is built by hipcc from the
 // same source and has no CPU path -- nothing under gen2-uhf-rfid-reader_amd/ knows this directory exists.
 //

@@ -39,7 +39,7 @@ class SmallSynth:
 @pytest.fixture(scope="module", autouse=True)
 def emulated_library():
     """librfid_capi_emu.so in place of librfid_mi355x.so -- for this module's tests, in this process, and put back afterwards"""
-    import build as fake_build
+    import build_capi_emu as fake_build
     import rfid
     from rfid import _capi
     lib = C.CDLL(fake_build.build())
