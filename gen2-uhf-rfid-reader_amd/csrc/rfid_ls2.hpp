@@ -132,6 +132,7 @@ struct Ls2Args {
   int *dcen;                    // [NH][2] centre of the unit's latest run: candidate j started at centre + j - 32 ulps
   int *dtab;                    // [NH][2][64] dc_est behind the unit for each candidate
   int *dstat;                   // [NH] bit 0 / 1: re / im settled, bit 2: the slot holds a unit, bit 3: its latest run does not cover the start predicted for it (zeroed before a pass)
+  uint64_t *dexm;               // [NH][2] which entries of the unit's table are there (all 64; candidates 32 and 33 only behind the thin first round of a long pass)
   int *dfront;                  // [n_streams] the trace's first idle-grid slot whose unit is not settled (after a chain; INT_MAX: none)
   int *fscr, *fbar;             // the finishing walk's scratch [n_streams][2][LS2_FIN_GMAX][LS2_FIN_REC] and its meeting counters [n_streams] (zeroed before a pass)
   int *dmar;                    // [NH][2] how far from its centre a start may lie for the unit's end to be a plain shift of candidate 32's / 33's (ulps; 0: nowhere)
@@ -139,6 +140,7 @@ struct Ls2Args {
   float2 *dcand; int dcand_cap; // [dcand_cap][64] dc_est at a gate opening for each candidate
   // the chain's levels: nodes of 64 children (level 1: blocks of units, level 2: groups of blocks); per node the centre of its
   // first child, its table on that window, which entries are exact, whether it holds anything, and its entry value from the walk
+  int dc_thin;                  // 1: the first round runs every unit from two starts only (long passes; rfid_ls2_enqueue.hpp)
   int dcb_bias;                 // test hook: ulps added to the first round's centres (the ring means), as the rounding drift of a long trace would
   int dcb_n1, dcb_n2, dcb_top;  // nodes per trace of level 1 / 2; the level the walk runs over (2 when a trace has more than 64 blocks)
   int *n1cen, *n1tab, *n1val, *n1ent, *n1mar; uint64_t *n1exm;
@@ -1571,6 +1573,12 @@ RFID_DEVICE int ls2_dcb_slot(const Ls2Args &a, const int t) { const int s = t / 
 // One unit (idle-grid slot t) from 64 neighbouring start values per component: lane j from centre + j - 32 ulps.
 // have_centre: (cre, cim) is the centre (ord images); else the trace's exact start (its first unit) or the ring's mean.
 // -> end_re / end_im: lane j's dc_est behind the unit (ord images); also left in a.dtab, the centre in a.dcen
+// THIN (the first round of a long pass): candidates 32 and 33 only -- the centre and one ulp above it -- with the step's increments
+// summed lane = sample (chain_add_auto2: one integer scan for both where that is provably the same arithmetic), two thirds of
+// the instructions of the 64-candidate form.  Away from binade edges that is all a unit needs: its margin carries the two runs to
+// any start the drift may have left (even distances from candidate 32's run, odd ones from 33's); Ls2Args::dexm says that only
+// those two entries of the unit's table are there.  Where the margin does not reach, the unit is run again in the full form.
+template <bool THIN = false>
 RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_centre, int cre, int cim, const bool reserve, const int lane,
                               float2 *lds_dc, float2 *lds_tmp, float2 *lds_q, int &end_re, int &end_im) {
   const int s = t / a.max_bc;
@@ -1619,6 +1627,12 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
   const bool e0r_ok = ls2_e0_ok(sbr, sbr), e0i_ok = ls2_e0_ok(sbi, sbi);
   Ls2MantRange rgr, rgi;
   ls2_range_init(rgr); ls2_range_init(rgi);
+  // (THIN) the two runs' carries, wave-uniform, and their margins' state (as ls2_avg_piece keeps it for avg_ampl)
+  float tAr = ls2_from_ord(cre), tAi = ls2_from_ord(cim), tBr = ls2_from_ord(cre + 1), tBi = ls2_from_ord(cim + 1);
+  const uint32_t sbrB = wv::f2u(tBr), sbiB = wv::f2u(tBi);
+  const bool e2r_ok = ls2_e0_ok(sbr, sbrB), e2i_ok = ls2_e0_ok(sbi, sbiB);
+  Ls2MantRange rgrB, rgiB;
+  ls2_range_init(rgrB); ls2_range_init(rgiB);
   Ls2Win *wb = a.wb + (int64_t)s * a.wb_stride;
   // where the unit's gate openings go in a.dcand: reserved once (complete windows + the one a trace may end in)
   int wslot = 0;
@@ -1709,6 +1723,34 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
                        }
                      },
                      tre, tim);
+        if (THIN) {
+          float ar, ai, br, bi;   // dc_est after every sample of the step from the two starts
+          const uint32_t cr0 = wv::f2u(tAr), cr1 = wv::f2u(tBr), ci0 = wv::f2u(tAi), ci1 = wv::f2u(tBi);
+          const bool scr = chain_add_auto2(tAr, tBr, tre, lane, ar, br);
+          const bool sci = chain_add_auto2(tAi, tBi, tim, lane, ai, bi);
+          tAr = wv::readlane(ar, 63); tBr = wv::readlane(br, 63);
+          tAi = wv::readlane(ai, 63); tBi = wv::readlane(bi, 63);
+          if (scr && ls2_in_start_binade(cr0, cr1, sbr, sbrB, e2r_ok)) { ls2_range_add(rgr, ar); ls2_range_add(rgrB, br); }
+          else {
+            int mr;
+            if (scr) mr = ls2_margin_scanned(ar, br, cr0, cr1, sbr, sbrB, e2r_ok);
+            else { const int m1 = ls2_margin(ar, sbr), m2 = ls2_margin(br, sbrB); mr = (m1 < m2) ? m1 : m2; }
+            mre = (mr < mre) ? mr : mre;
+          }
+          if (sci && ls2_in_start_binade(ci0, ci1, sbi, sbiB, e2i_ok)) { ls2_range_add(rgi, ai); ls2_range_add(rgiB, bi); }
+          else {
+            int mi;
+            if (sci) mi = ls2_margin_scanned(ai, bi, ci0, ci1, sbi, sbiB, e2i_ok);
+            else { const int m3 = ls2_margin(ai, sbi), m4 = ls2_margin(bi, sbiB); mi = (m3 < m4) ? m3 : m4; }
+            mim = (mi < mim) ? mi : mim;
+          }
+          if (ol != 0xff) {   // a window opened at sample `ol`: dc_est right behind it from both starts (candidates 32, 33 of its record)
+            const float war = wv::readlane(ar, ol), wai = wv::readlane(ai, ol), wbr = wv::readlane(br, ol), wbi = wv::readlane(bi, ol);
+            if (wslot >= 0 && lane < 2) a.dcand[(int64_t)(wslot + nopen) * 64 + LS2_DCB_HALF + lane] = lane ? make_float2(wbr, wbi) : make_float2(war, wai);
+            if (lane == 0) { Ls2Win *w = wb + (upos0 + 64 * k + ol) / LS2_WBUCKET; w->slot = (wslot >= 0) ? (wslot + nopen) : 0; w->unit = t; }
+            nopen++;
+          }
+        } else {
         {
           const float c32r = wv::readlane(acc.x, LS2_DCB_HALF), c32i = wv::readlane(acc.y, LS2_DCB_HALF);
           const float pr = c32r + wv::scan_add_f(tre), pi = c32i + wv::scan_add_f(tim);
@@ -1746,6 +1788,7 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
           }
           nopen++;
         }
+        }   // (!THIN)
       } else {
         g.run_closed = 0;   // the step lies entirely inside a window: dc_est, the ring and its index do not move
         if (ol != 0xff) {   // (an opening sample is closed itself: not reached)
@@ -1765,7 +1808,24 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
     for (int u = 0; u < AHEAD - 1; ++u)
       if (kb + u < nsteps) step(kb + u, buf[u], false);
   }
+  if (THIN) {
+    { const int q = ls2_range_margin(rgr, rgrB); mre = (q < mre) ? q : mre; }
+    { const int q = ls2_range_margin(rgi, rgiB); mim = (q < mim) ? q : mim; }
+    mre = ls2_wave_min(mre) - 4; mim = ls2_wave_min(mim) - 4;     // (the proof's own slack: the two runs may lie an ulp or two apart)
+    if ((((wv::f2u(tAr) ^ sbr) | (wv::f2u(tBr) ^ sbrB)) & 0xff800000u) != 0u || mre < 0) mre = 0;
+    if ((((wv::f2u(tAi) ^ sbi) | (wv::f2u(tBi) ^ sbiB)) & 0xff800000u) != 0u || mim < 0) mim = 0;
+    end_re = (lane == LS2_DCB_HALF + 1) ? ls2_ord(tBr) : ls2_ord(tAr);
+    end_im = (lane == LS2_DCB_HALF + 1) ? ls2_ord(tBi) : ls2_ord(tAi);
+    a.dtab[(int64_t)(2 * t) * 64 + lane] = end_re;
+    a.dtab[(int64_t)(2 * t + 1) * 64 + lane] = end_im;
+    if (lane == 0) {
+      a.dcen[2 * t] = cre; a.dcen[2 * t + 1] = cim; a.dmar[2 * t] = mre; a.dmar[2 * t + 1] = mim;
+      a.dexm[2 * t] = 3ull << LS2_DCB_HALF; a.dexm[2 * t + 1] = 3ull << LS2_DCB_HALF;
+    }
+    return;
+  }
   end_re = ls2_ord(acc.x); end_im = ls2_ord(acc.y);
+  if (lane == 0) { a.dexm[2 * t] = ~0ull; a.dexm[2 * t + 1] = ~0ull; }
   {
     { const int q = ls2_range_margin(rgr, rgr); mre = (q < mre) ? q : mre; }
     { const int q = ls2_range_margin(rgi, rgi); mim = (q < mim) ? q : mim; }
@@ -1811,7 +1871,8 @@ RFID_KERNEL(64) void ls2_dcb_run_kernel(Ls2Args a) {
       if (lane == 0) a.dstat[t] = (st & ~0x70) | (((again < 7) ? again + 1 : 7) << 4);
     }
     int er, ei;
-    ls2_dcb_unit(a, t, r > 0, (r > 0) ? wv::uniform(a.dT[2 * t]) : 0, (r > 0) ? wv::uniform(a.dT[2 * t + 1]) : 0, r == 0, lane, lds_dc, lds_tmp, lds_q, er, ei);
+    if (r == 0 && a.dc_thin) ls2_dcb_unit<true>(a, t, false, 0, 0, true, lane, lds_dc, lds_tmp, lds_q, er, ei);
+    else ls2_dcb_unit<false>(a, t, r > 0, (r > 0) ? wv::uniform(a.dT[2 * t]) : 0, (r > 0) ? wv::uniform(a.dT[2 * t + 1]) : 0, r == 0, lane, lds_dc, lds_tmp, lds_q, er, ei);
     if (r == 0 && lane == 0) a.dstat[t] = 4;
     n_run++;
   }
@@ -1827,21 +1888,28 @@ RFID_DEVICE void ls2_dcb_apply(int &v, bool &ex, const int tab, const uint64_t e
   const int D = (int)((uint32_t)v - (uint32_t)cen);
   const int o = D + LS2_DCB_HALF;
   const int aD = (D < 0) ? -D : D;
-  const bool inw = o >= 0 && o < 64;
-  // outside the window but inside the margin: candidate 32's end (33's for an odd distance) shifted along -- exact
+  const bool inw = o >= 0 && o < 64 && ((exm >> (o & 63)) & 1ull) != 0ull;   // inside the window, at an entry that is there and exact
+  // else, inside the margin: candidate 32's end (33's for an odd distance) shifted along -- exact
   const bool far = !inw && D != (int)0x80000000 && aD <= mar;
   const int par = D & 1;
-  const int oc = inw ? o : (far ? (LS2_DCB_HALF + par) : ((o < 0) ? 0 : 63));
+  const int oe = (o < 0) ? 0 : ((o > 63) ? 63 : o);      // (neither: a guess -- the nearest entry that is there, shifted along)
+  const int og = (((exm >> oe) & 1ull) != 0ull) ? oe : (LS2_DCB_HALF + par);
+  const int oc = inw ? o : (far ? (LS2_DCB_HALF + par) : og);
   const int e = UNIFORM ? wv::readlane(tab, wv::uniform(oc)) : wv::shfl(tab, oc);
   ex = ex && (inw || far) && (((exm >> oc) & 1ull) != 0ull);
   v = (int)((uint32_t)e + (uint32_t)(o - oc));
+}
+// is a start D ulps off the centre covered by the unit's latest run: an entry of its table that is there, or its margin
+RFID_DEVICE bool ls2_dcb_covers(const int D, const uint64_t exm, const int mar) {
+  const int o = D + LS2_DCB_HALF;
+  return (o >= 0 && o < 64 && ((exm >> (o & 63)) & 1ull) != 0ull) || (D != (int)0x80000000 && ((D < 0) ? -D : D) <= mar);
 }
 // what a level's nodes are made of: level 1 = blocks of 64 units, level 2 = groups of 64 blocks
 struct Ls2DcbKids { const int *cen; const int *tab; const uint64_t *exm; const int *val; const int *mar; int per_trace; };
 template <int L>
 RFID_DEVICE Ls2DcbKids ls2_dcb_kids(const Ls2Args &a) {
   Ls2DcbKids k;
-  if (L == 1) { k.cen = a.dcen; k.tab = a.dtab; k.exm = nullptr; k.val = nullptr; k.mar = a.dmar; k.per_trace = a.max_bc; }
+  if (L == 1) { k.cen = a.dcen; k.tab = a.dtab; k.exm = a.dexm; k.val = nullptr; k.mar = a.dmar; k.per_trace = a.max_bc; }
   else { k.cen = a.n1cen; k.tab = a.n1tab; k.exm = a.n1exm; k.val = a.n1val; k.mar = a.n1mar; k.per_trace = a.dcb_n1; }
   return k;
 }
@@ -2090,8 +2158,7 @@ RFID_DEVICE void ls2_dcb_down(const Ls2Args &a, const int node, const int lane, 
         // settled: everything before is, and the unit's own start lies inside its window or its margin (its end, and dc_est at its
         // gate openings, are then known: a table entry, or candidate 32's / 33's shifted along)
         const int D_re = (int)((uint32_t)Tre - (uint32_t)c_re), D_im = (int)((uint32_t)Tim - (uint32_t)c_im);
-        const bool k_re = (D_re >= -LS2_DCB_HALF && D_re < LS2_DCB_HALF) || (D_re != (int)0x80000000 && ((D_re < 0) ? -D_re : D_re) <= m_re);
-        const bool k_im = (D_im >= -LS2_DCB_HALF && D_im < LS2_DCB_HALF) || (D_im != (int)0x80000000 && ((D_im < 0) ? -D_im : D_im) <= m_im);
+        const bool k_re = ls2_dcb_covers(D_re, e_re, m_re), k_im = ls2_dcb_covers(D_im, e_im, m_im);
         const int bits = ((exr && k_re) ? 1 : 0) | ((exi && k_im) ? 2 : 0);
         // (bit 3: the unit's latest run does not cover the start predicted for it -- it is run again, centred on that; a unit whose
         // run does cover it only waits for the units before it)
@@ -2202,8 +2269,8 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
       const int tp = t0 + prev;
       Tre = wv::uniform(a.dT[2 * tp]); Tim = wv::uniform(a.dT[2 * tp + 1]);
       bool exr = true, exi = true;
-      ls2_dcb_apply<true>(Tre, exr, a.dtab[(int64_t)(2 * tp) * 64 + lane], ~0ull, wv::uniform(a.dcen[2 * tp]), wv::uniform(a.dmar[2 * tp]));
-      ls2_dcb_apply<true>(Tim, exi, a.dtab[(int64_t)(2 * tp + 1) * 64 + lane], ~0ull, wv::uniform(a.dcen[2 * tp + 1]), wv::uniform(a.dmar[2 * tp + 1]));
+      ls2_dcb_apply<true>(Tre, exr, a.dtab[(int64_t)(2 * tp) * 64 + lane], wv::uniform(a.dexm[2 * tp]), wv::uniform(a.dcen[2 * tp]), wv::uniform(a.dmar[2 * tp]));
+      ls2_dcb_apply<true>(Tim, exi, a.dtab[(int64_t)(2 * tp + 1) * 64 + lane], wv::uniform(a.dexm[2 * tp + 1]), wv::uniform(a.dcen[2 * tp + 1]), wv::uniform(a.dmar[2 * tp + 1]));
       if (!(exr && exi)) { if (lane == 0) ctl->fail = 7; return; }   // (a settled unit's end is exact by definition; every wave sees the same)
     }
   }
@@ -2253,8 +2320,7 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
       const int c_re = wv::uniform(rec[0]), c_im = wv::uniform(rec[1]), m_re = wv::uniform(rec[2]), m_im = wv::uniform(rec[3]);
       if (ex) {
         const int D_re = (int)((uint32_t)Wre - (uint32_t)c_re), D_im = (int)((uint32_t)Wim - (uint32_t)c_im);
-        const bool k_re = (D_re >= -LS2_DCB_HALF && D_re < LS2_DCB_HALF) || (D_re != (int)0x80000000 && ((D_re < 0) ? -D_re : D_re) <= m_re);
-        const bool k_im = (D_im >= -LS2_DCB_HALF && D_im < LS2_DCB_HALF) || (D_im != (int)0x80000000 && ((D_im < 0) ? -D_im : D_im) <= m_im);
+        const bool k_re = ls2_dcb_covers(D_re, ~0ull, m_re), k_im = ls2_dcb_covers(D_im, ~0ull, m_im);
         if (k_re && k_im) {
           if (w == wid && lane == 0) { a.dT[2 * tw] = Wre; a.dT[2 * tw + 1] = Wim; a.dstat[tw] = 7; }   // (the wave that ran the unit)
           fixed++;
@@ -2391,8 +2457,8 @@ RFID_KERNEL(64) void ls2_assemble_kernel(Ls2Args a) {
         for (int c = 0; c < 2; ++c) {
           const int cen = a.dcen[2 * w.unit + c];
           const int D = a.dT[2 * w.unit + c] - cen;
-          const bool inw = D >= -LS2_DCB_HALF && D < LS2_DCB_HALF;
-          // inside the window: that candidate's own value; else (inside the margin) candidate 32's / 33's run shifted by the even rest
+          const bool inw = D >= -LS2_DCB_HALF && D < LS2_DCB_HALF && ((a.dexm[2 * w.unit + c] >> ((D + LS2_DCB_HALF) & 63)) & 1ull) != 0ull;
+          // an entry that is there: that candidate's own value; else (inside the margin) candidate 32's / 33's run shifted by the even rest
           // of the distance, in ulps of the START's binade (the trajectory is shifted as a whole: rfid_ls2.hpp's header)
           const int par = D & 1;
           const float2 v = a.dcand[(int64_t)w.slot * 64 + (inw ? (D + LS2_DCB_HALF) : (LS2_DCB_HALF + par))];
@@ -2446,7 +2512,7 @@ RFID_KERNEL(64) void ls2_carry_kernel(Ls2Args a) {
   float dc_end[2];
   for (int c = 0; c < 2; ++c) {
     const int D = wv::uniform(a.dT[2 * tl + c]) - wv::uniform(a.dcen[2 * tl + c]);
-    const bool inw = D >= -LS2_DCB_HALF && D < LS2_DCB_HALF;
+    const bool inw = D >= -LS2_DCB_HALF && D < LS2_DCB_HALF && ((wv::uniform(a.dexm[2 * tl + c]) >> ((D + LS2_DCB_HALF) & 63)) & 1ull) != 0ull;
     const int par = D & 1;
     const int e = wv::uniform(a.dtab[(int64_t)(2 * tl + c) * 64 + (inw ? (D + LS2_DCB_HALF) : (LS2_DCB_HALF + par))]);
     dc_end[c] = ls2_from_ord(inw ? e : (e + (D - par)));   // (a unit with a margin ends in the binade it starts in)

@@ -49,7 +49,7 @@ inline Ls2Geometry ls2_geometry(int n_streams, int64_t n_dec, int min_piece = LS
 
 // work space: one allocation, carved up here (offsets in bytes, 256-byte aligned)
 struct Ls2Layout {
-  size_t cut, cutf, piece, nextv, prevv, upiece, unextv, uprevv, lb_fn, lb_end, lb_water, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, dT, dcen, dtab, dstat, dfront, fscr, fbar, dmar, dwbase, dcand, n1cen, n1tab, n1val, n1ent, n1mar, n1exm, n2cen, n2tab, n2val, n2ent, n2mar, n2exm, seq0, flat_base, cflag, cagg, ctl, consumed, total;
+  size_t cut, cutf, piece, nextv, prevv, upiece, unextv, uprevv, lb_fn, lb_end, lb_water, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, dT, dcen, dtab, dstat, dexm, dfront, fscr, fbar, dmar, dwbase, dcand, n1cen, n1tab, n1val, n1ent, n1mar, n1exm, n2cen, n2tab, n2val, n2ent, n2mar, n2exm, seq0, flat_base, cflag, cagg, ctl, consumed, total;
   int dcand_cap;
 };
 // wmax: complete windows a trace can hold (the caller's window table): sizes the dc_est stage's table of gate openings
@@ -84,6 +84,7 @@ inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_strid
   L.dtab = take(sizeof(int) * 2 * 64 * NH);
   L.dstat = take(sizeof(int) * NH);
   L.dmar = take(sizeof(int) * 2 * NH);
+  L.dexm = take(sizeof(uint64_t) * 2 * NH);
   L.dfront = take(sizeof(int) * B);
   L.fscr = take(sizeof(int) * B * 2 * (size_t)LS2_FIN_GMAX * LS2_FIN_REC);
   L.fbar = take(sizeof(int) * B);
@@ -115,7 +116,7 @@ inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geomet
   a.votes = (uint64_t *)(base + L.votes); a.closed = (uint64_t *)(base + L.closed); a.openinfo = (int *)(base + L.openinfo);
   a.arun = (Ls2AvgRun *)(base + L.arun); a.aT = (int *)(base + L.aT); a.alist = (int *)(base + L.alist); a.aover = (Ls2Aff *)(base + L.aover);
   a.fsm = (Ls2Fsm *)(base + L.fsm); a.wb = (Ls2Win *)(base + L.wb);
-  a.dT = (int *)(base + L.dT); a.dcen = (int *)(base + L.dcen); a.dtab = (int *)(base + L.dtab); a.dstat = (int *)(base + L.dstat); a.dmar = (int *)(base + L.dmar); a.dfront = (int *)(base + L.dfront); a.fscr = (int *)(base + L.fscr); a.fbar = (int *)(base + L.fbar);
+  a.dT = (int *)(base + L.dT); a.dcen = (int *)(base + L.dcen); a.dtab = (int *)(base + L.dtab); a.dstat = (int *)(base + L.dstat); a.dmar = (int *)(base + L.dmar); a.dexm = (uint64_t *)(base + L.dexm); a.dfront = (int *)(base + L.dfront); a.fscr = (int *)(base + L.fscr); a.fbar = (int *)(base + L.fbar);
   a.dwbase = (int *)(base + L.dwbase); a.dcand = (float2 *)(base + L.dcand); a.dcand_cap = L.dcand_cap;
   a.dcb_n1 = g.n1; a.dcb_n2 = g.n2; a.dcb_top = (g.n1 > ls2_dcb_top_min()) ? 2 : 1; a.dcb_bias = ls2_dcb_bias();
   a.n1cen = (int *)(base + L.n1cen); a.n1tab = (int *)(base + L.n1tab); a.n1val = (int *)(base + L.n1val); a.n1ent = (int *)(base + L.n1ent); a.n1mar = (int *)(base + L.n1mar); a.n1exm = (uint64_t *)(base + L.n1exm);
@@ -126,7 +127,8 @@ inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geomet
 inline int &ls2_fsm_lanes_min() { static int v = 8192; return v; }   // from this many possible heads on the state machine runs one lane per unit (tests: 0 / a huge number)
 inline int &ls2_chain_slots() { static int v = 2048; return v; }
 inline int &ls2_dcb_top_min() { static int v = 64; return v; }
-inline int &ls2_dcb_bias() { static int v = 0; return v; }   // (tests: Ls2Args::dcb_bias)   // the dc_est chain walks over groups of blocks when a trace has more blocks than this (tests: 0)   // slots per workgroup of a chain launch (tests shrink it)
+inline int &ls2_dcb_bias() { static int v = 0; return v; }   // (tests: Ls2Args::dcb_bias)
+inline int &ls2_dcb_thin() { static int v = -1; return v; }   // (tests: 0 / 1 force the first round's form)   // the dc_est chain walks over groups of blocks when a trace has more blocks than this (tests: 0)   // slots per workgroup of a chain launch (tests shrink it)
 
 #ifdef LS2_LAUNCH
 // One pass (its first launch zeroes Ls2Ctl, the chain flags, the votes, the window buckets and flat_count).  `a` complete but for
@@ -184,9 +186,13 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
   // off by an ulp or two per such unit it came through -- the blocks' windows (+- 32) catch that for some thousand units per
   // round: one round (and the finishing walk for the handful it may leave) for a stream of a few thousand units, up to ~8 for configs[2]'s 32 000 (a round here is six small launches
   // and a handful of unit runs).  Sums that hover at a binade edge do not settle by rounds at all; the finishing walk takes them
-  a.dc_rounds = (dc_rounds >= 0) ? dc_rounds : (tiny ? 0 : (small ? 1 : LS2_DC_ROUNDS));   // (a look-ahead pass holds a few dozen units: the first round and the walk)
+  a.dc_rounds = (dc_rounds >= 0) ? dc_rounds : (tiny ? 0 : (small ? 2 : LS2_DC_ROUNDS));   // (a look-ahead pass holds a few dozen units: the first round and the walk)
   if (a.dc_rounds < 0) a.dc_rounds = 0;
   if (a.dc_rounds > LS2_DC_MAXR) a.dc_rounds = LS2_DC_MAXR;
+  // the first round of a long pass runs every unit from two starts only (ls2_dcb_unit<true>: a third fewer instructions; its margin
+  // is what settles a unit there anyway); short passes take the 64-candidate form at once -- they hold few units, their drift is
+  // small, and one round less is worth more than a cheaper one (test hook: ls2_dcb_thin() = 0 / 1 says so itself)
+  a.dc_thin = (ls2_dcb_thin() >= 0) ? ls2_dcb_thin() : ((small || tiny) ? 0 : 1);
   if (fused) {
     // matched filter + piece boundaries + the first avg_ampl pass in one sweep over the raw samples; then the pieces' links,
     // the idle cuts from the blocks' not-carrier masks (unless given: tests) and the units' table from them
