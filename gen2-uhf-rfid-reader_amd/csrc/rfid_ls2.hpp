@@ -1767,16 +1767,22 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
         lds_q[lane] = make_float2(tre, tim);
         wv::wave_sync();
         if (__builtin_expect(ol == 0xff, 1)) {
+          // (eight reads -- sixteen samples -- in flight at a time: unrolled all the way the compiler issues all 32 reads first,
+          // 128 registers of increments, and the kernel runs at two waves per SIMD: 219 VGPRs, 2.9 ms for configs[2]'s first round)
+#pragma unroll 1
+          for (int j0 = 0; j0 < 32; j0 += 8) {
 #pragma unroll
-          for (int j = 0; j < 32; ++j) {
-            const float4 qq = q4[j];
-            wv::pk_add(acc, make_float2(qq.x, qq.y));
-            wv::pk_add(acc, make_float2(qq.z, qq.w));
+            for (int j = 0; j < 8; ++j) {
+              const float4 qq = q4[j0 + j];
+              wv::pk_add(acc, make_float2(qq.x, qq.y));
+              wv::pk_add(acc, make_float2(qq.z, qq.w));
+            }
           }
         } else {
           // a window opened at sample `ol` of this step: dc_est right behind that sample (the opening sample is still
           // closed, gate_impl.cc:164-180), for every candidate
           float2 snap = acc;
+#pragma unroll 4
           for (int j = 0; j < 64; ++j) {
             wv::pk_add(acc, lds_q[j]);
             if (j == ol) snap = acc;
@@ -1840,14 +1846,10 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
   if (lane == 0) { a.dcen[2 * t] = cre; a.dcen[2 * t + 1] = cim; }
 }
 
-// round 0: every unit from its guess; round r > 0: every unit behind the settled prefix again, centred on the start value the
-// chain of round r - 1 predicted for it.  One wave per idle-grid slot.
-RFID_KERNEL(64) void ls2_dcb_run_kernel(Ls2Args a) {
-  ls2_tail_prio();
-  RFID_SHARED float2 lds_dc[DC_LEN];
-  RFID_SHARED float2 lds_tmp[64];
-  RFID_SHARED float4 lds_q4[32];
-  float2 *lds_q = reinterpret_cast<float2 *>(lds_q4);
+// round 0: every unit from its guess (long passes: the thin form, a kernel of its own -- the two forms in one kernel cost both the
+// registers of the larger); round r > 0: the units the last chain found not covered again, centred on the start it predicted
+template <bool THIN>
+RFID_DEVICE void ls2_dcb_run(const Ls2Args &a, float2 *lds_dc, float2 *lds_tmp, float2 *lds_q) {
   Ls2Ctl *ctl = a.ctl;
   if (!ls2_fsm_settled(a, ctl)) return;
   const int r = a.round;
@@ -1871,12 +1873,24 @@ RFID_KERNEL(64) void ls2_dcb_run_kernel(Ls2Args a) {
       if (lane == 0) a.dstat[t] = (st & ~0x70) | (((again < 7) ? again + 1 : 7) << 4);
     }
     int er, ei;
-    if (r == 0 && a.dc_thin) ls2_dcb_unit<true>(a, t, false, 0, 0, true, lane, lds_dc, lds_tmp, lds_q, er, ei);
-    else ls2_dcb_unit<false>(a, t, r > 0, (r > 0) ? wv::uniform(a.dT[2 * t]) : 0, (r > 0) ? wv::uniform(a.dT[2 * t + 1]) : 0, r == 0, lane, lds_dc, lds_tmp, lds_q, er, ei);
+    ls2_dcb_unit<THIN>(a, t, r > 0, (r > 0) ? wv::uniform(a.dT[2 * t]) : 0, (r > 0) ? wv::uniform(a.dT[2 * t + 1]) : 0, r == 0, lane, lds_dc, lds_tmp, lds_q, er, ei);
     if (r == 0 && lane == 0) a.dstat[t] = 4;
     n_run++;
   }
   if (r > 0 && n_run && lane == 0) wv::atomic_add(&ctl->dc_reruns, n_run);
+}
+RFID_KERNEL(64) void ls2_dcb_run_kernel(Ls2Args a) {
+  ls2_tail_prio();
+  RFID_SHARED float2 lds_dc[DC_LEN];
+  RFID_SHARED float2 lds_tmp[64];
+  RFID_SHARED float4 lds_q4[32];
+  ls2_dcb_run<false>(a, lds_dc, lds_tmp, reinterpret_cast<float2 *>(lds_q4));
+}
+RFID_KERNEL(64) void ls2_dcb_run_thin_kernel(Ls2Args a) {
+  ls2_tail_prio();
+  RFID_SHARED float2 lds_dc[DC_LEN];
+  RFID_SHARED float2 lds_tmp[64];
+  ls2_dcb_run<true>(a, lds_dc, lds_tmp, nullptr);
 }
 
 // ---- the chain of tables ----

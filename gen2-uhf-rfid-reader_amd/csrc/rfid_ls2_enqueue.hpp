@@ -232,7 +232,8 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
     const int N1 = B * a.dcb_n1, N2 = B * a.dcb_n2;
     for (int r = 0; r <= a.dc_rounds; ++r) {
       a.round = r;
-      LS2_LAUNCH(ls2_dcb_run_kernel, NH, 1, 64, U(a));
+      if (r == 0 && a.dc_thin) LS2_LAUNCH(ls2_dcb_run_thin_kernel, NH, 1, 64, U(a));
+      else LS2_LAUNCH(ls2_dcb_run_kernel, NH, 1, 64, U(a));
       LS2_LAUNCH(ls2_dcb_up1_kernel, N1, 1, 64, U(a));
       if (a.dcb_top == 2) LS2_LAUNCH(ls2_dcb_up2_kernel, N2, 1, 64, U(a));
       LS2_LAUNCH(ls2_dcb_top_kernel, B, 1, 64, U(a));
