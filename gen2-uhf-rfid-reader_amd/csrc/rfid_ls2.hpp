@@ -1767,16 +1767,14 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
         lds_q[lane] = make_float2(tre, tim);
         wv::wave_sync();
         if (__builtin_expect(ol == 0xff, 1)) {
-          // (eight reads -- sixteen samples -- in flight at a time: unrolled all the way the compiler issues all 32 reads first,
-          // 128 registers of increments, and the kernel runs at two waves per SIMD: 219 VGPRs, 2.9 ms for configs[2]'s first round)
-#pragma unroll 1
-          for (int j0 = 0; j0 < 32; j0 += 8) {
+          // (unrolled all the way: the reads run ahead of the adds as far as the scheduler lets them.  What must NOT be unrolled is the
+          // gate-opening path below: its 64 conditional snapshots kept 64 increments and as many copies alive -- 219 VGPRs, two
+          // waves per SIMD, 2.9 ms for configs[2]'s first round; 97 VGPRs since)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float4 qq = q4[j0 + j];
-              wv::pk_add(acc, make_float2(qq.x, qq.y));
-              wv::pk_add(acc, make_float2(qq.z, qq.w));
-            }
+          for (int j = 0; j < 32; ++j) {
+            const float4 qq = q4[j];
+            wv::pk_add(acc, make_float2(qq.x, qq.y));
+            wv::pk_add(acc, make_float2(qq.z, qq.w));
           }
         } else {
           // a window opened at sample `ol` of this step: dc_est right behind that sample (the opening sample is still
