@@ -132,7 +132,7 @@ struct Ls2Args {
   int *dcen;                    // [NH][2] centre of the unit's latest run: candidate j started at centre + j - 32 ulps
   int *dtab;                    // [NH][2][64] dc_est behind the unit for each candidate
   int *dstat;                   // [NH] bit 0 / 1: re / im settled, bit 2: the slot holds a unit, bit 3: its latest run does not cover the start predicted for it (zeroed before a pass)
-  uint64_t *dexm;               // [NH][2] which entries of the unit's table are there (all 64; candidates 32 and 33 only behind the thin first round of a long pass)
+  uint64_t *dexm;               // [NH][2] which entries of the unit's table are there (a unit's run leaves all 64)
   int *dfront;                  // [n_streams] the trace's first idle-grid slot whose unit is not settled (after a chain; INT_MAX: none)
   int *fscr, *fbar;             // the finishing walk's scratch [n_streams][2][LS2_FIN_GMAX][LS2_FIN_REC] and its meeting counters [n_streams] (zeroed before a pass)
   int *dmar;                    // [NH][2] how far from its centre a start may lie for the unit's end to be a plain shift of candidate 32's / 33's (ulps; 0: nowhere)
@@ -140,7 +140,6 @@ struct Ls2Args {
   float2 *dcand; int dcand_cap; // [dcand_cap][64] dc_est at a gate opening for each candidate
   // the chain's levels: nodes of 64 children (level 1: blocks of units, level 2: groups of blocks); per node the centre of its
   // first child, its table on that window, which entries are exact, whether it holds anything, and its entry value from the walk
-  int dc_thin;                  // 1: the first round runs every unit from two starts only (long passes; rfid_ls2_enqueue.hpp)
   int dcb_bias;                 // test hook: ulps added to the first round's centres (the ring means), as the rounding drift of a long trace would
   int dcb_n1, dcb_n2, dcb_top;  // nodes per trace of level 1 / 2; the level the walk runs over (2 when a trace has more than 64 blocks)
   int *n1cen, *n1tab, *n1val, *n1ent, *n1mar; uint64_t *n1exm;
@@ -1573,12 +1572,6 @@ RFID_DEVICE int ls2_dcb_slot(const Ls2Args &a, const int t) { const int s = t / 
 // One unit (idle-grid slot t) from 64 neighbouring start values per component: lane j from centre + j - 32 ulps.
 // have_centre: (cre, cim) is the centre (ord images); else the trace's exact start (its first unit) or the ring's mean.
 // -> end_re / end_im: lane j's dc_est behind the unit (ord images); also left in a.dtab, the centre in a.dcen
-// THIN (the first round of a long pass): candidates 32 and 33 only -- the centre and one ulp above it -- with the step's increments
-// summed lane = sample (chain_add_auto2: one integer scan for both where that is provably the same arithmetic), two thirds of
-// the instructions of the 64-candidate form.  Away from binade edges that is all a unit needs: its margin carries the two runs to
-// any start the drift may have left (even distances from candidate 32's run, odd ones from 33's); Ls2Args::dexm says that only
-// those two entries of the unit's table are there.  Where the margin does not reach, the unit is run again in the full form.
-template <bool THIN = false>
 RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_centre, int cre, int cim, const bool reserve, const int lane,
                               float2 *lds_dc, float2 *lds_tmp, float2 *lds_q, int &end_re, int &end_im) {
   const int s = t / a.max_bc;
@@ -1627,12 +1620,6 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
   const bool e0r_ok = ls2_e0_ok(sbr, sbr), e0i_ok = ls2_e0_ok(sbi, sbi);
   Ls2MantRange rgr, rgi;
   ls2_range_init(rgr); ls2_range_init(rgi);
-  // (THIN) the two runs' carries, wave-uniform, and their margins' state (as ls2_avg_piece keeps it for avg_ampl)
-  float tAr = ls2_from_ord(cre), tAi = ls2_from_ord(cim), tBr = ls2_from_ord(cre + 1), tBi = ls2_from_ord(cim + 1);
-  const uint32_t sbrB = wv::f2u(tBr), sbiB = wv::f2u(tBi);
-  const bool e2r_ok = ls2_e0_ok(sbr, sbrB), e2i_ok = ls2_e0_ok(sbi, sbiB);
-  Ls2MantRange rgrB, rgiB;
-  ls2_range_init(rgrB); ls2_range_init(rgiB);
   Ls2Win *wb = a.wb + (int64_t)s * a.wb_stride;
   // where the unit's gate openings go in a.dcand: reserved once (complete windows + the one a trace may end in)
   int wslot = 0;
@@ -1723,34 +1710,6 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
                        }
                      },
                      tre, tim);
-        if (THIN) {
-          float ar, ai, br, bi;   // dc_est after every sample of the step from the two starts
-          const uint32_t cr0 = wv::f2u(tAr), cr1 = wv::f2u(tBr), ci0 = wv::f2u(tAi), ci1 = wv::f2u(tBi);
-          const bool scr = chain_add_auto2(tAr, tBr, tre, lane, ar, br);
-          const bool sci = chain_add_auto2(tAi, tBi, tim, lane, ai, bi);
-          tAr = wv::readlane(ar, 63); tBr = wv::readlane(br, 63);
-          tAi = wv::readlane(ai, 63); tBi = wv::readlane(bi, 63);
-          if (scr && ls2_in_start_binade(cr0, cr1, sbr, sbrB, e2r_ok)) { ls2_range_add(rgr, ar); ls2_range_add(rgrB, br); }
-          else {
-            int mr;
-            if (scr) mr = ls2_margin_scanned(ar, br, cr0, cr1, sbr, sbrB, e2r_ok);
-            else { const int m1 = ls2_margin(ar, sbr), m2 = ls2_margin(br, sbrB); mr = (m1 < m2) ? m1 : m2; }
-            mre = (mr < mre) ? mr : mre;
-          }
-          if (sci && ls2_in_start_binade(ci0, ci1, sbi, sbiB, e2i_ok)) { ls2_range_add(rgi, ai); ls2_range_add(rgiB, bi); }
-          else {
-            int mi;
-            if (sci) mi = ls2_margin_scanned(ai, bi, ci0, ci1, sbi, sbiB, e2i_ok);
-            else { const int m3 = ls2_margin(ai, sbi), m4 = ls2_margin(bi, sbiB); mi = (m3 < m4) ? m3 : m4; }
-            mim = (mi < mim) ? mi : mim;
-          }
-          if (ol != 0xff) {   // a window opened at sample `ol`: dc_est right behind it from both starts (candidates 32, 33 of its record)
-            const float war = wv::readlane(ar, ol), wai = wv::readlane(ai, ol), wbr = wv::readlane(br, ol), wbi = wv::readlane(bi, ol);
-            if (wslot >= 0 && lane < 2) a.dcand[(int64_t)(wslot + nopen) * 64 + LS2_DCB_HALF + lane] = lane ? make_float2(wbr, wbi) : make_float2(war, wai);
-            if (lane == 0) { Ls2Win *w = wb + (upos0 + 64 * k + ol) / LS2_WBUCKET; w->slot = (wslot >= 0) ? (wslot + nopen) : 0; w->unit = t; }
-            nopen++;
-          }
-        } else {
         {
           const float c32r = wv::readlane(acc.x, LS2_DCB_HALF), c32i = wv::readlane(acc.y, LS2_DCB_HALF);
           const float pr = c32r + wv::scan_add_f(tre), pi = c32i + wv::scan_add_f(tim);
@@ -1792,7 +1751,6 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
           }
           nopen++;
         }
-        }   // (!THIN)
       } else {
         g.run_closed = 0;   // the step lies entirely inside a window: dc_est, the ring and its index do not move
         if (ol != 0xff) {   // (an opening sample is closed itself: not reached)
@@ -1812,22 +1770,6 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
     for (int u = 0; u < AHEAD - 1; ++u)
       if (kb + u < nsteps) step(kb + u, buf[u], false);
   }
-  if (THIN) {
-    { const int q = ls2_range_margin(rgr, rgrB); mre = (q < mre) ? q : mre; }
-    { const int q = ls2_range_margin(rgi, rgiB); mim = (q < mim) ? q : mim; }
-    mre = ls2_wave_min(mre) - 4; mim = ls2_wave_min(mim) - 4;     // (the proof's own slack: the two runs may lie an ulp or two apart)
-    if ((((wv::f2u(tAr) ^ sbr) | (wv::f2u(tBr) ^ sbrB)) & 0xff800000u) != 0u || mre < 0) mre = 0;
-    if ((((wv::f2u(tAi) ^ sbi) | (wv::f2u(tBi) ^ sbiB)) & 0xff800000u) != 0u || mim < 0) mim = 0;
-    end_re = (lane == LS2_DCB_HALF + 1) ? ls2_ord(tBr) : ls2_ord(tAr);
-    end_im = (lane == LS2_DCB_HALF + 1) ? ls2_ord(tBi) : ls2_ord(tAi);
-    a.dtab[(int64_t)(2 * t) * 64 + lane] = end_re;
-    a.dtab[(int64_t)(2 * t + 1) * 64 + lane] = end_im;
-    if (lane == 0) {
-      a.dcen[2 * t] = cre; a.dcen[2 * t + 1] = cim; a.dmar[2 * t] = mre; a.dmar[2 * t + 1] = mim;
-      a.dexm[2 * t] = 3ull << LS2_DCB_HALF; a.dexm[2 * t + 1] = 3ull << LS2_DCB_HALF;
-    }
-    return;
-  }
   end_re = ls2_ord(acc.x); end_im = ls2_ord(acc.y);
   if (lane == 0) { a.dexm[2 * t] = ~0ull; a.dexm[2 * t + 1] = ~0ull; }
   {
@@ -1844,9 +1786,10 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
   if (lane == 0) { a.dcen[2 * t] = cre; a.dcen[2 * t + 1] = cim; }
 }
 
-// round 0: every unit from its guess (long passes: the thin form, a kernel of its own -- the two forms in one kernel cost both the
-// registers of the larger); round r > 0: the units the last chain found not covered again, centred on the start it predicted
-template <bool THIN>
+// round 0: every unit from its guess; round r > 0: the units the last chain found not covered again, centred on the start it
+// predicted.  (A first round from two starts only -- candidates 32 / 33 summed lane = sample by the two-carry scan, the unit's margin
+// carrying them to any other start -- was tried for long passes: 2.34 ms for configs[2]'s first round against 1.5 ms in this form,
+// whose 64 candidates cost ONE packed add per sample; profiles/r06/dcb_first_round.txt.)
 RFID_DEVICE void ls2_dcb_run(const Ls2Args &a, float2 *lds_dc, float2 *lds_tmp, float2 *lds_q) {
   Ls2Ctl *ctl = a.ctl;
   if (!ls2_fsm_settled(a, ctl)) return;
@@ -1871,24 +1814,20 @@ RFID_DEVICE void ls2_dcb_run(const Ls2Args &a, float2 *lds_dc, float2 *lds_tmp, 
       if (lane == 0) a.dstat[t] = (st & ~0x70) | (((again < 7) ? again + 1 : 7) << 4);
     }
     int er, ei;
-    ls2_dcb_unit<THIN>(a, t, r > 0, (r > 0) ? wv::uniform(a.dT[2 * t]) : 0, (r > 0) ? wv::uniform(a.dT[2 * t + 1]) : 0, r == 0, lane, lds_dc, lds_tmp, lds_q, er, ei);
+    ls2_dcb_unit(a, t, r > 0, (r > 0) ? wv::uniform(a.dT[2 * t]) : 0, (r > 0) ? wv::uniform(a.dT[2 * t + 1]) : 0, r == 0, lane, lds_dc, lds_tmp, lds_q, er, ei);
     if (r == 0 && lane == 0) a.dstat[t] = 4;
     n_run++;
   }
   if (r > 0 && n_run && lane == 0) wv::atomic_add(&ctl->dc_reruns, n_run);
 }
+// (97 VGPRs, four waves per SIMD.  Five, six and eight waves forced by launch bounds: configs[2]'s eleven launches 2.36 / 2.31 /
+// 2.23 ms against 2.06 -- what the registers give the spills take; profiles/r06/dcb_first_round.txt)
 RFID_KERNEL(64) void ls2_dcb_run_kernel(Ls2Args a) {
   ls2_tail_prio();
   RFID_SHARED float2 lds_dc[DC_LEN];
   RFID_SHARED float2 lds_tmp[64];
   RFID_SHARED float4 lds_q4[32];
-  ls2_dcb_run<false>(a, lds_dc, lds_tmp, reinterpret_cast<float2 *>(lds_q4));
-}
-RFID_KERNEL(64) void ls2_dcb_run_thin_kernel(Ls2Args a) {
-  ls2_tail_prio();
-  RFID_SHARED float2 lds_dc[DC_LEN];
-  RFID_SHARED float2 lds_tmp[64];
-  ls2_dcb_run<true>(a, lds_dc, lds_tmp, nullptr);
+  ls2_dcb_run(a, lds_dc, lds_tmp, reinterpret_cast<float2 *>(lds_q4));
 }
 
 // ---- the chain of tables ----
@@ -1916,14 +1855,35 @@ RFID_DEVICE bool ls2_dcb_covers(const int D, const uint64_t exm, const int mar) 
   const int o = D + LS2_DCB_HALF;
   return (o >= 0 && o < 64 && ((exm >> (o & 63)) & 1ull) != 0ull) || (D != (int)0x80000000 && ((D < 0) ? -D : D) <= mar);
 }
+RFID_DEVICE uint64_t ls2_readlane64(const uint64_t v, const int l) {
+  return ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(v >> 32), l) << 32) | (uint32_t)wv::readlane((int)(uint32_t)v, l);
+}
 // what a level's nodes are made of: level 1 = blocks of 64 units, level 2 = groups of 64 blocks
-struct Ls2DcbKids { const int *cen; const int *tab; const uint64_t *exm; const int *val; const int *mar; int per_trace; };
+struct Ls2DcbKids { const int *cen; const int *tab; const uint64_t *exm; const int *val; const int *mar; int per_trace; int total; };
 template <int L>
 RFID_DEVICE Ls2DcbKids ls2_dcb_kids(const Ls2Args &a) {
   Ls2DcbKids k;
-  if (L == 1) { k.cen = a.dcen; k.tab = a.dtab; k.exm = a.dexm; k.val = nullptr; k.mar = a.dmar; k.per_trace = a.max_bc; }
-  else { k.cen = a.n1cen; k.tab = a.n1tab; k.exm = a.n1exm; k.val = a.n1val; k.mar = a.n1mar; k.per_trace = a.dcb_n1; }
+  if (L == 1) { k.cen = a.dcen; k.tab = a.dtab; k.exm = a.dexm; k.val = nullptr; k.mar = a.dmar; k.per_trace = a.max_bc; k.total = a.n_streams * a.max_bc; }
+  else { k.cen = a.n1cen; k.tab = a.n1tab; k.exm = a.n1exm; k.val = a.n1val; k.mar = a.n1mar; k.per_trace = a.dcb_n1; k.total = a.n_streams * a.dcb_n1; }
   return k;
+}
+// A node's 64 children's tables (2 x 64 rows of 64 values, 32 KB in a row) into LDS with every load in flight at once.  The walks
+// over a node's children used to fetch each child's two rows four children ahead: the tables were written by other CUs a launch
+// ago, a load takes ~2 us, and 64 steps waited half a microsecond each -- 40 - 55 us per chain launch of configs[2], five launches
+// per round.  (Rows of children that do not exist are loaded like the others and never looked at; rows past the array are not.)
+struct alignas(16) Ls2Int4 { int x, y, z, w; };
+constexpr int LS2_DCB_STAGE = 64 * 2 * 64;
+RFID_DEVICE void ls2_dcb_stage(const Ls2DcbKids &kd, const int ch0, int *lds_tab, const int lane) {
+  const Ls2Int4 *src = reinterpret_cast<const Ls2Int4 *>(kd.tab + (int64_t)(2 * ch0) * 64);
+  const int n4 = (kd.total - ch0) * 32;   // (16-byte quarters of rows from the first child's on)
+  Ls2Int4 *dst = reinterpret_cast<Ls2Int4 *>(lds_tab);
+  wv::wave_sync();   // (the last node's reads are over)
+#pragma unroll 8
+  for (int q = 0; q < LS2_DCB_STAGE / 256; ++q) {
+    const int idx = q * 64 + lane;
+    dst[idx] = src[(idx < n4) ? idx : 0];
+  }
+  wv::wave_sync();
 }
 // A node's table misses (the entry value lies outside its window and its margin) where its CHILDREN, gone through one by one,
 // may all be hit: the walk then descends -- (T, ex) through the children of node `node` of level L in order, a level-2 node's
@@ -1967,8 +1927,7 @@ RFID_DEVICE void ls2_dcb_through(const Ls2Args &a, const int node, int &Tre, int
       lq[u] = rest ? wv::ffs64(rest) : -1;
       if (rest) rest &= rest - 1ull;
       { const int c = (lq[u] >= 0) ? lq[u] : 0; tr[u] = kd.tab[(int64_t)(2 * (ch0 + c)) * 64 + lane]; ti[u] = kd.tab[(int64_t)(2 * (ch0 + c) + 1) * 64 + lane]; }
-      const uint64_t er = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(er_l >> 32), l) << 32) | (uint32_t)wv::readlane((int)(uint32_t)er_l, l);
-      const uint64_t ei = ((uint64_t)(uint32_t)wv::readlane((int)(uint32_t)(ei_l >> 32), l) << 32) | (uint32_t)wv::readlane((int)(uint32_t)ei_l, l);
+      const uint64_t er = ls2_readlane64(er_l, l), ei = ls2_readlane64(ei_l, l);
       int T2r = Tre, T2i = Tim; bool e2r = exr, e2i = exi;
       ls2_dcb_apply<true>(T2r, e2r, t_re, er, wv::readlane(cre, l), wv::readlane(mre, l));
       ls2_dcb_apply<true>(T2i, e2i, t_im, ei, wv::readlane(cim, l), wv::readlane(mim, l));
@@ -1983,7 +1942,7 @@ RFID_DEVICE void ls2_dcb_through(const Ls2Args &a, const int node, int &Tre, int
 }
 // up: the 64 children of node `node` of level L composed in order -> the node's table (on the window of its first child)
 template <int L>
-RFID_DEVICE void ls2_dcb_up(const Ls2Args &a, const int node, const int lane) {
+RFID_DEVICE void ls2_dcb_up(const Ls2Args &a, const int node, const int lane, int *lds_tab) {
   const Ls2DcbKids kd = ls2_dcb_kids<L>(a);
   const int nper = (L == 1) ? a.dcb_n1 : a.dcb_n2;
   int *ocen = (L == 1) ? a.n1cen : a.n2cen; int *otab = (L == 1) ? a.n1tab : a.n2tab;
@@ -1996,6 +1955,10 @@ RFID_DEVICE void ls2_dcb_up(const Ls2Args &a, const int node, const int lane) {
     valid = (L == 1) ? ((a.dstat[ch0 + lane] >> 2) & 1) : kd.val[ch0 + lane];
     if (valid) { cre = kd.cen[2 * (ch0 + lane)]; cim = kd.cen[2 * (ch0 + lane) + 1]; mre = kd.mar[2 * (ch0 + lane)]; mim = kd.mar[2 * (ch0 + lane) + 1]; }
   }
+  // (which entries of a child's table are there: with its centre, one load per lane -- a wave-uniform load per child inside the
+  // walk is a full memory round trip per step that nothing can run ahead of: 50 us per chain launch of configs[2], 15 since)
+  uint64_t er_l = ~0ull, ei_l = ~0ull;
+  if (kd.exm && in && valid) { er_l = kd.exm[2 * (ch0 + lane)]; ei_l = kd.exm[2 * (ch0 + lane) + 1]; }
   const uint64_t m = wv::ballot(valid != 0);
   if (m == 0ull) { if (lane == 0) oval[node] = 0; return; }
   int l = wv::ffs64(m);
@@ -2008,34 +1971,17 @@ RFID_DEVICE void ls2_dcb_up(const Ls2Args &a, const int node, const int lane) {
   int vre = bre + lane - LS2_DCB_HALF, vim = bim + lane - LS2_DCB_HALF;
   bool exr = true, exi = true;
   int nmr = 0x3fffffff, nmi = 0x3fffffff;   // the node's own margin: how far from ITS centre an entry value may lie (see below)
-  auto fetch = [&](const int c, int &tr, int &ti, uint64_t &er, uint64_t &ei) {
-    tr = kd.tab[(int64_t)(2 * (ch0 + c)) * 64 + lane]; ti = kd.tab[(int64_t)(2 * (ch0 + c) + 1) * 64 + lane];
-    er = kd.exm ? wv::uniform(kd.exm[2 * (ch0 + c)]) : ~0ull; ei = kd.exm ? wv::uniform(kd.exm[2 * (ch0 + c) + 1]) : ~0ull;
-  };
   auto dev = [&](const int v, const int c) -> int {   // how far candidates 32 / 33 of the node are from the child's centre when they reach it
     const int d0 = wv::readlane(v, LS2_DCB_HALF) - c, d1 = wv::readlane(v, LS2_DCB_HALF + 1) - c;
     const int a0 = (d0 < 0) ? -d0 : d0, a1 = (d1 < 0) ? -d1 : d1;
     return (a0 > a1) ? a0 : a1;
   };
-  // (the children's tables four ahead of the walk: the loads do not depend on it)
-  constexpr int AH = 4;
-  int tr[AH], ti[AH], lq[AH]; uint64_t er[AH], ei[AH];
-  uint64_t rest = m;
-#pragma unroll
-  for (int u = 0; u < AH; ++u) {
-    lq[u] = rest ? wv::ffs64(rest) : -1;
-    if (rest) rest &= rest - 1ull;
-    fetch((lq[u] >= 0) ? lq[u] : l, tr[u], ti[u], er[u], ei[u]);
-  }
-  for (bool more = true; more;) {
-#pragma unroll
-    for (int u = 0; u < AH; ++u) {
-      const int lc = lq[u];
-      if (lc < 0) { more = false; break; }
-      const int t_re = tr[u], t_im = ti[u]; const uint64_t e_re = er[u], e_im = ei[u];
-      lq[u] = rest ? wv::ffs64(rest) : -1;
-      if (rest) rest &= rest - 1ull;
-      fetch((lq[u] >= 0) ? lq[u] : l, tr[u], ti[u], er[u], ei[u]);
+  ls2_dcb_stage(kd, ch0, lds_tab, lane);
+  for (uint64_t rest = m; rest; rest &= rest - 1ull) {
+    {
+      const int lc = wv::ffs64(rest);
+      const int t_re = lds_tab[(2 * lc) * 64 + lane], t_im = lds_tab[(2 * lc + 1) * 64 + lane];
+      const uint64_t e_re = ls2_readlane64(er_l, lc), e_im = ls2_readlane64(ei_l, lc);
       const int c_re = wv::readlane(cre, lc), c_im = wv::readlane(cim, lc), m_re = wv::readlane(mre, lc), m_im = wv::readlane(mim, lc);
       // an entry value D off the node's centre reaches this child D + dev off the child's: a plain shift all the way while that
       // stays inside every child's margin
@@ -2063,7 +2009,8 @@ RFID_KERNEL(64) void ls2_dcb_up1_kernel(Ls2Args a) {
   if (a.round > 0 && wv::uniform(ctl->dc_count[a.round - 1]) == 0) return;
   const int lane = wv::lane_id();
   const int N = a.n_streams * a.dcb_n1;
-  for (int node = (int)blockIdx.x; node < N; node += (int)gridDim.x) ls2_dcb_up<1>(a, node, lane);
+  RFID_SHARED int lds_tab[LS2_DCB_STAGE];
+  for (int node = (int)blockIdx.x; node < N; node += (int)gridDim.x) ls2_dcb_up<1>(a, node, lane, lds_tab);
 }
 RFID_KERNEL(64) void ls2_dcb_up2_kernel(Ls2Args a) {
   ls2_tail_prio();
@@ -2072,7 +2019,8 @@ RFID_KERNEL(64) void ls2_dcb_up2_kernel(Ls2Args a) {
   if (a.round > 0 && wv::uniform(ctl->dc_count[a.round - 1]) == 0) return;
   const int lane = wv::lane_id();
   const int N = a.n_streams * a.dcb_n2;
-  for (int node = (int)blockIdx.x; node < N; node += (int)gridDim.x) ls2_dcb_up<2>(a, node, lane);
+  RFID_SHARED int lds_tab[LS2_DCB_STAGE];
+  for (int node = (int)blockIdx.x; node < N; node += (int)gridDim.x) ls2_dcb_up<2>(a, node, lane, lds_tab);
 }
 // the walk over a trace's top-level nodes from its exact start (the centre of its first unit): every node's entry value.
 // One wave per trace; the values are wave-uniform.
@@ -2098,15 +2046,27 @@ RFID_KERNEL(64) void ls2_dcb_top_kernel(Ls2Args a) {
   int budget = LS2_DCB_DESCENTS;
   const int n0 = s * nper;
   int tr = tab[(int64_t)(2 * n0) * 64 + lane], ti = tab[(int64_t)(2 * n0 + 1) * 64 + lane];
+  // (the nodes' centres, margins and masks 64 nodes at a time, one load per lane: a wave-uniform load inside the walk is a memory
+  // round trip per node that nothing runs ahead of)
+  int v_l = 0, cr_l = 0, ci_l = 0, mr_l = 0, mi_l = 0;
+  uint64_t er_l = 0ull, ei_l = 0ull;
   for (int k = 0; k < nper; ++k) {
     const int node = n0 + k;
+    if ((k & 63) == 0) {
+      const int q = node + lane;
+      const bool in = k + lane < nper;
+      v_l = in ? val[q] : 0;
+      cr_l = in ? cen[2 * q] : 0; ci_l = in ? cen[2 * q + 1] : 0; mr_l = in ? mar[2 * q] : 0; mi_l = in ? mar[2 * q + 1] : 0;
+      er_l = in ? exm[2 * q] : 0ull; ei_l = in ? exm[2 * q + 1] : 0ull;
+    }
+    const int kl = k & 63;
     int ntr = 0, nti = 0;
     if (k + 1 < nper) { ntr = tab[(int64_t)(2 * (node + 1)) * 64 + lane]; nti = tab[(int64_t)(2 * (node + 1) + 1) * 64 + lane]; }
-    if (wv::uniform(val[node]) != 0) {
+    if (wv::readlane(v_l, kl) != 0) {
       if (lane == 0) { ent[4 * node] = Tre; ent[4 * node + 1] = Tim; ent[4 * node + 2] = exr ? 1 : 0; ent[4 * node + 3] = exi ? 1 : 0; }
       int T2r = Tre, T2i = Tim; bool e2r = exr, e2i = exi;
-      ls2_dcb_apply<true>(T2r, e2r, tr, wv::uniform(exm[2 * node]), wv::uniform(cen[2 * node]), wv::uniform(mar[2 * node]));
-      ls2_dcb_apply<true>(T2i, e2i, ti, wv::uniform(exm[2 * node + 1]), wv::uniform(cen[2 * node + 1]), wv::uniform(mar[2 * node + 1]));
+      ls2_dcb_apply<true>(T2r, e2r, tr, ls2_readlane64(er_l, kl), wv::readlane(cr_l, kl), wv::readlane(mr_l, kl));
+      ls2_dcb_apply<true>(T2i, e2i, ti, ls2_readlane64(ei_l, kl), wv::readlane(ci_l, kl), wv::readlane(mi_l, kl));
       if (((exr && !e2r) || (exi && !e2i)) && budget > 0) {
         // the node's table missed an exact entry value: through its children one by one (they may all be hit)
         budget--;
@@ -2122,7 +2082,7 @@ RFID_KERNEL(64) void ls2_dcb_top_kernel(Ls2Args a) {
 // down: from a node's entry value to its children's.  Level 1: the children are the units -- their start values (a.dT),
 // which of them are settled, how many are not (Ls2Ctl::dc_count[round]).
 template <int L>
-RFID_DEVICE void ls2_dcb_down(const Ls2Args &a, const int node, const int lane, int &n_uns, int &n_units, int &first_uns) {
+RFID_DEVICE void ls2_dcb_down(const Ls2Args &a, const int node, const int lane, int &n_uns, int &n_units, int &first_uns, int *lds_tab) {
   const Ls2DcbKids kd = ls2_dcb_kids<L>(a);
   const int nper = (L == 1) ? a.dcb_n1 : a.dcb_n2;
   const int *nval = (L == 1) ? a.n1val : a.n2val; const int *nent = (L == 1) ? a.n1ent : a.n2ent;
@@ -2130,40 +2090,25 @@ RFID_DEVICE void ls2_dcb_down(const Ls2Args &a, const int node, const int lane, 
   const int s = node / nper, k = node - s * nper;
   const int ch0 = s * kd.per_trace + 64 * k;
   const bool in = 64 * k + lane < kd.per_trace;
-  int valid = 0, cre = 0, cim = 0, mre = 0, mim = 0;
+  int valid = 0, cre = 0, cim = 0, mre = 0, mim = 0, st_l = 0;
   if (in) {
-    valid = (L == 1) ? ((a.dstat[ch0 + lane] >> 2) & 1) : kd.val[ch0 + lane];
+    if (L == 1) st_l = a.dstat[ch0 + lane];
+    valid = (L == 1) ? ((st_l >> 2) & 1) : kd.val[ch0 + lane];
     if (valid) { cre = kd.cen[2 * (ch0 + lane)]; cim = kd.cen[2 * (ch0 + lane) + 1]; mre = kd.mar[2 * (ch0 + lane)]; mim = kd.mar[2 * (ch0 + lane) + 1]; }
   }
+  uint64_t er_l = ~0ull, ei_l = ~0ull;   // (one load per lane: see ls2_dcb_up)
+  if (kd.exm && in && valid) { er_l = kd.exm[2 * (ch0 + lane)]; ei_l = kd.exm[2 * (ch0 + lane) + 1]; }
   const uint64_t m = wv::ballot(valid != 0);
   if (m == 0ull) return;
   int Tre = wv::uniform(nent[4 * node]), Tim = wv::uniform(nent[4 * node + 1]);
   bool exr = wv::uniform(nent[4 * node + 2]) != 0, exi = wv::uniform(nent[4 * node + 3]) != 0;
-  auto fetch = [&](const int c, int &tr, int &ti, uint64_t &er, uint64_t &ei) {
-    tr = kd.tab[(int64_t)(2 * (ch0 + c)) * 64 + lane]; ti = kd.tab[(int64_t)(2 * (ch0 + c) + 1) * 64 + lane];
-    er = kd.exm ? wv::uniform(kd.exm[2 * (ch0 + c)]) : ~0ull; ei = kd.exm ? wv::uniform(kd.exm[2 * (ch0 + c) + 1]) : ~0ull;
-  };
-  const int l0 = wv::ffs64(m);
   int budget = 64;
-  // (the children's tables four ahead of the walk: the loads do not depend on it)
-  constexpr int AH = 4;
-  int tr[AH], ti[AH], lq[AH]; uint64_t er[AH], ei[AH];
-  uint64_t rest = m;
-#pragma unroll
-  for (int u = 0; u < AH; ++u) {
-    lq[u] = rest ? wv::ffs64(rest) : -1;
-    if (rest) rest &= rest - 1ull;
-    fetch((lq[u] >= 0) ? lq[u] : l0, tr[u], ti[u], er[u], ei[u]);
-  }
-  for (bool more = true; more;) {
-#pragma unroll
-    for (int u = 0; u < AH; ++u) {
-      const int l = lq[u];
-      if (l < 0) { more = false; break; }
-      const int t_re = tr[u], t_im = ti[u]; const uint64_t e_re = er[u], e_im = ei[u];
-      lq[u] = rest ? wv::ffs64(rest) : -1;
-      if (rest) rest &= rest - 1ull;
-      fetch((lq[u] >= 0) ? lq[u] : l0, tr[u], ti[u], er[u], ei[u]);
+  ls2_dcb_stage(kd, ch0, lds_tab, lane);
+  for (uint64_t rest = m; rest; rest &= rest - 1ull) {
+    {
+      const int l = wv::ffs64(rest);
+      const int t_re = lds_tab[(2 * l) * 64 + lane], t_im = lds_tab[(2 * l + 1) * 64 + lane];
+      const uint64_t e_re = ls2_readlane64(er_l, l), e_im = ls2_readlane64(ei_l, l);
       const int c_re = wv::readlane(cre, l), c_im = wv::readlane(cim, l), m_re = wv::readlane(mre, l), m_im = wv::readlane(mim, l);
       const int c = ch0 + l;
       if (L == 1) {
@@ -2174,7 +2119,8 @@ RFID_DEVICE void ls2_dcb_down(const Ls2Args &a, const int node, const int lane, 
         const int bits = ((exr && k_re) ? 1 : 0) | ((exi && k_im) ? 2 : 0);
         // (bit 3: the unit's latest run does not cover the start predicted for it -- it is run again, centred on that; a unit whose
         // run does cover it only waits for the units before it)
-        if (lane == 0) { a.dT[2 * c] = Tre; a.dT[2 * c + 1] = Tim; a.dstat[c] = 4 | bits | ((k_re && k_im) ? 0 : 8) | (a.dstat[c] & 0x70); }
+        const int again = wv::readlane(st_l, l) & 0x70;
+        if (lane == 0) { a.dT[2 * c] = Tre; a.dT[2 * c + 1] = Tim; a.dstat[c] = 4 | bits | ((k_re && k_im) ? 0 : 8) | again; }
         n_units++;
         if (bits != 3) { if (n_uns == 0) first_uns = c; n_uns++; }
       } else {
@@ -2202,7 +2148,8 @@ RFID_KERNEL(64) void ls2_dcb_down2_kernel(Ls2Args a) {
   const int lane = wv::lane_id();
   const int N = a.n_streams * a.dcb_n2;
   int u0 = 0, u1 = 0, u2 = 0;
-  for (int node = (int)blockIdx.x; node < N; node += (int)gridDim.x) ls2_dcb_down<2>(a, node, lane, u0, u1, u2);
+  RFID_SHARED int lds_tab[LS2_DCB_STAGE];
+  for (int node = (int)blockIdx.x; node < N; node += (int)gridDim.x) ls2_dcb_down<2>(a, node, lane, u0, u1, u2, lds_tab);
 }
 RFID_KERNEL(64) void ls2_dcb_down1_kernel(Ls2Args a) {
   ls2_tail_prio();
@@ -2213,9 +2160,10 @@ RFID_KERNEL(64) void ls2_dcb_down1_kernel(Ls2Args a) {
   const int lane = wv::lane_id();
   const int N = a.n_streams * a.dcb_n1;
   int n_uns = 0, n_units = 0;
+  RFID_SHARED int lds_tab[LS2_DCB_STAGE];
   for (int node = (int)blockIdx.x; node < N; node += (int)gridDim.x) {
     int nu = 0, first_uns = 0;
-    ls2_dcb_down<1>(a, node, lane, nu, n_units, first_uns);
+    ls2_dcb_down<1>(a, node, lane, nu, n_units, first_uns, lds_tab);
     if (nu && lane == 0) wv::atomic_min(a.dfront + first_uns / a.max_bc, first_uns);   // the trace's frontier: its first unit that is not settled
     n_uns += nu;
   }

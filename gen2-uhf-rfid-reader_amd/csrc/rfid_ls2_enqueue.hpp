@@ -125,10 +125,9 @@ inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geomet
 }
 
 inline int &ls2_fsm_lanes_min() { static int v = 8192; return v; }   // from this many possible heads on the state machine runs one lane per unit (tests: 0 / a huge number)
-inline int &ls2_chain_slots() { static int v = 2048; return v; }
-inline int &ls2_dcb_top_min() { static int v = 64; return v; }
+inline int &ls2_chain_slots() { static int v = 2048; return v; }   // slots per workgroup of a chain launch (tests shrink it)
+inline int &ls2_dcb_top_min() { static int v = 64; return v; }   // the dc_est chain walks over groups of blocks when a trace has more blocks than this (tests: 0)
 inline int &ls2_dcb_bias() { static int v = 0; return v; }   // (tests: Ls2Args::dcb_bias)
-inline int &ls2_dcb_thin() { static int v = -1; return v; }   // (tests: 0 / 1 force the first round's form)   // the dc_est chain walks over groups of blocks when a trace has more blocks than this (tests: 0)   // slots per workgroup of a chain launch (tests shrink it)
 
 #ifdef LS2_LAUNCH
 // One pass (its first launch zeroes Ls2Ctl, the chain flags, the votes, the window buckets and flat_count).  `a` complete but for
@@ -189,10 +188,6 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
   a.dc_rounds = (dc_rounds >= 0) ? dc_rounds : (tiny ? 0 : (small ? 2 : LS2_DC_ROUNDS));   // (a look-ahead pass holds a few dozen units: the first round and the walk)
   if (a.dc_rounds < 0) a.dc_rounds = 0;
   if (a.dc_rounds > LS2_DC_MAXR) a.dc_rounds = LS2_DC_MAXR;
-  // the first round of a long pass runs every unit from two starts only (ls2_dcb_unit<true>: a third fewer instructions; its margin
-  // is what settles a unit there anyway); short passes take the 64-candidate form at once -- they hold few units, their drift is
-  // small, and one round less is worth more than a cheaper one (test hook: ls2_dcb_thin() = 0 / 1 says so itself)
-  a.dc_thin = (ls2_dcb_thin() >= 0) ? ls2_dcb_thin() : ((small || tiny) ? 0 : 1);
   if (fused) {
     // matched filter + piece boundaries + the first avg_ampl pass in one sweep over the raw samples; then the pieces' links,
     // the idle cuts from the blocks' not-carrier masks (unless given: tests) and the units' table from them
@@ -232,8 +227,10 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
     const int N1 = B * a.dcb_n1, N2 = B * a.dcb_n2;
     for (int r = 0; r <= a.dc_rounds; ++r) {
       a.round = r;
-      if (r == 0 && a.dc_thin) LS2_LAUNCH(ls2_dcb_run_thin_kernel, NH, 1, 64, U(a));
-      else LS2_LAUNCH(ls2_dcb_run_kernel, NH, 1, 64, U(a));
+      // (late re-run rounds: the waves loop over the slots -- most of these launches have nothing to do, and 32 000 workgroups that
+      // return at once cost 8 us against 4.  The first three keep a wave per slot: a round with work lasts as long as its longest
+      // wave, and a unit's run is 50 - 100 us)
+      LS2_LAUNCH(ls2_dcb_run_kernel, (r <= 3 || NH < 4096) ? NH : 4096, 1, 64, U(a));
       LS2_LAUNCH(ls2_dcb_up1_kernel, N1, 1, 64, U(a));
       if (a.dcb_top == 2) LS2_LAUNCH(ls2_dcb_up2_kernel, N2, 1, 64, U(a));
       LS2_LAUNCH(ls2_dcb_top_kernel, B, 1, 64, U(a));

@@ -122,9 +122,7 @@ def test_ls2_dc_est_far_starts_margins_and_reruns(emu_mod, oracle_mod, synth_mod
     the run's margin reaches; the others are run again, centred on the chain's prediction, and the blocks' windows move to
     where the last chain found their entry values.  (This is where round 6's first GPU run went wrong: a block's table had
     missed, every unit inside it -- walked one by one -- was settled, and the finishing walk took the value the chain had
-    written for the first unit BEHIND the block for exact.  It now takes the end of the settled unit before it.)
-    thin-first-round: the form long passes take -- the first round runs every unit from two starts only (candidates 32 / 33:
-    Ls2Args::dexm), the margin carries them to the true start; the units it does not reach are run again in the 64-candidate form."""
+    written for the first unit BEHIND the block for exact.  It now takes the end of the settled unit before it.)"""
     t = synth_mod.make_trace(n_rounds=30, sigma=sigma, seed=11, leak=1.0 * np.exp(0.6j)).samples
     r = _check(emu_mod, oracle_mod, t[None, :], expect_ok=1, min_piece=64, check_avg=False, dc_bias=bias, **kw)
     c = r["ctl"]

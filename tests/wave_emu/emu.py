@@ -70,7 +70,7 @@ LS2_CTL_FIELDS = (["fail", "ok", "n_pieces", "n_heads"] + [f"avg_count{r}" for r
 
 
 def ls2_process(raw: np.ndarray, lens=None, fixed_q=0, max_num_queries=1000, number_unique_tags=100, min_piece=512,
-                target=131072, state=None, hold_last=False, cuts=None, y_skip=0, chain_slots=64, generous=True, dc_rounds=-1, fsm_lanes=False, dc_two_levels=False, dc_bias=0, dc_thin=-1,
+                target=131072, state=None, hold_last=False, cuts=None, y_skip=0, chain_slots=64, generous=True, dc_rounds=-1, fsm_lanes=False, dc_two_levels=False, dc_bias=0,
                 fused=False):
     """batch_process() with the long-stream front end (rfid_ls2.hpp) in place of the sequential gate scan.
     -> dict(windows, results, scores, stats, ctl, ok[, consumed])"""
@@ -93,7 +93,6 @@ def ls2_process(raw: np.ndarray, lens=None, fixed_q=0, max_num_queries=1000, num
     if lens is not None:
         lens_arr = np.ascontiguousarray(lens, dtype=np.int64)
     lib().emu_ls2_fsm_lanes_min(0 if fsm_lanes else 1 << 30)
-    lib().emu_ls2_dcb_thin(int(dc_thin))   # (the first dc_est round from two starts only, as long passes run it; -1: by the pass's size)
     lib().emu_ls2_dcb_bias(int(dc_bias))   # (ulps added to the first round's centres: what the rounding drift of a long trace does to the ring means)
     lib().emu_ls2_dcb_top_min(0 if dc_two_levels else 64)   # (the dc_est chain's second level, as on traces of more than 4 096 idle-grid slots)
     lib().emu_ls2_chain_slots(int(chain_slots))   # (several workgroups per trace in the chain launches, as on long traces)
