@@ -48,7 +48,7 @@ static_assert(LS2_WBUCKET <= RN16_WIN + T1_SAMPLES, "one window per bucket");
 constexpr int LS2_AVG_ROUNDS = 11;    // re-run rounds after the first pass, per recurrence (a round without work costs two empty launches; configs[2]
                                       // settles in 5 rounds on y-given pieces and in 8 on the fused first pass's, profiles/r05/ls2_rounds.txt)
 constexpr int LS2_FSM_ROUNDS = 3;
-constexpr int LS2_DC_ROUNDS = 10;     // dc_est rounds behind the first that a long pass enqueues (rfid_ls2_enqueue.hpp)
+constexpr int LS2_DC_ROUNDS = 6;      // dc_est rounds behind the first that a long pass enqueues (rfid_ls2_enqueue.hpp; 4 / 6 / 10 measured alike: profiles/r06/noise_sweep.txt)
 constexpr int LS2_MAXR = 12;
 constexpr int LS2_WIDE_BELOW = 64;    // a piece whose margin is below this is re-run from six neighbouring start values at once
 constexpr int LS2_WIDE_LO = -2, LS2_WIDE_HI = 3;
@@ -1891,14 +1891,15 @@ RFID_DEVICE void ls2_dcb_stage(const Ls2DcbKids &kd, const int ch0, int *lds_tab
 // children's tables lie across the lanes.  `budget`: descents the caller still allows (sums that hover at a binade edge miss
 // everywhere: a walk over every unit of a long trace in one wave is what the rounds are there to avoid).
 template <int L>
-RFID_DEVICE void ls2_dcb_through(const Ls2Args &a, const int node, int &Tre, int &Tim, bool &exr, bool &exi, const int lane, int &budget) {
+RFID_DEVICE void ls2_dcb_through(const Ls2Args &a, const int node, int &Tre, int &Tim, bool &exr, bool &exi, const int lane, int &budget,
+                                 int *lds_own, int *lds_kid) {   // (LDS for this node's children's tables / for a child's own descent)
   const Ls2DcbKids kd = ls2_dcb_kids<L>(a);
   const int nper = (L == 1) ? a.dcb_n1 : a.dcb_n2;
   const int s = node / nper, k = node - s * nper;
   const int ch0 = s * kd.per_trace + 64 * k;
   const bool in = 64 * k + lane < kd.per_trace;
-  // the children's centres, margins and which of them exist: one load per lane; their tables four children ahead of the walk
-  // (none of the loads depends on the walk)
+  // the children's centres, margins and which of them exist: one load per lane; their tables through LDS (none of the loads
+  // depends on the walk)
   int valid = 0, cre = 0, cim = 0, mre = 0, mim = 0;
   if (in) {
     valid = (L == 1) ? ((a.dstat[ch0 + lane] >> 2) & 1) : kd.val[ch0 + lane];
@@ -1908,36 +1909,20 @@ RFID_DEVICE void ls2_dcb_through(const Ls2Args &a, const int node, int &Tre, int
   if (kd.exm && in && valid) { er_l = kd.exm[2 * (ch0 + lane)]; ei_l = kd.exm[2 * (ch0 + lane) + 1]; }
   const uint64_t m = wv::ballot(valid != 0);
   if (m == 0ull) return;
-  constexpr int AH = 4;
-  int tr[AH], ti[AH], lq[AH];
-  uint64_t rest = m;
-#pragma unroll
-  for (int u = 0; u < AH; ++u) {
-    lq[u] = rest ? wv::ffs64(rest) : -1;
-    if (rest) rest &= rest - 1ull;
-    const int c = (lq[u] >= 0) ? lq[u] : 0;
-    tr[u] = kd.tab[(int64_t)(2 * (ch0 + c)) * 64 + lane]; ti[u] = kd.tab[(int64_t)(2 * (ch0 + c) + 1) * 64 + lane];
-  }
-  for (;;) {
-#pragma unroll
-    for (int u = 0; u < AH; ++u) {
-      const int l = lq[u];
-      if (l < 0) return;
-      const int t_re = tr[u], t_im = ti[u];
-      lq[u] = rest ? wv::ffs64(rest) : -1;
-      if (rest) rest &= rest - 1ull;
-      { const int c = (lq[u] >= 0) ? lq[u] : 0; tr[u] = kd.tab[(int64_t)(2 * (ch0 + c)) * 64 + lane]; ti[u] = kd.tab[(int64_t)(2 * (ch0 + c) + 1) * 64 + lane]; }
-      const uint64_t er = ls2_readlane64(er_l, l), ei = ls2_readlane64(ei_l, l);
-      int T2r = Tre, T2i = Tim; bool e2r = exr, e2i = exi;
-      ls2_dcb_apply<true>(T2r, e2r, t_re, er, wv::readlane(cre, l), wv::readlane(mre, l));
-      ls2_dcb_apply<true>(T2i, e2i, t_im, ei, wv::readlane(cim, l), wv::readlane(mim, l));
-      if (L == 2 && ((exr && !e2r) || (exi && !e2i)) && budget > 0) {
-        budget--;
-        T2r = Tre; T2i = Tim; e2r = exr; e2i = exi;
-        ls2_dcb_through<1>(a, ch0 + l, T2r, T2i, e2r, e2i, lane, budget);
-      }
-      Tre = T2r; Tim = T2i; exr = e2r; exi = e2i;
+  ls2_dcb_stage(kd, ch0, lds_own, lane);
+  for (uint64_t rest = m; rest; rest &= rest - 1ull) {
+    const int l = wv::ffs64(rest);
+    const int t_re = lds_own[(2 * l) * 64 + lane], t_im = lds_own[(2 * l + 1) * 64 + lane];
+    const uint64_t er = ls2_readlane64(er_l, l), ei = ls2_readlane64(ei_l, l);
+    int T2r = Tre, T2i = Tim; bool e2r = exr, e2i = exi;
+    ls2_dcb_apply<true>(T2r, e2r, t_re, er, wv::readlane(cre, l), wv::readlane(mre, l));
+    ls2_dcb_apply<true>(T2i, e2i, t_im, ei, wv::readlane(cim, l), wv::readlane(mim, l));
+    if (L == 2 && ((exr && !e2r) || (exi && !e2i)) && budget > 0) {
+      budget--;
+      T2r = Tre; T2i = Tim; e2r = exr; e2i = exi;
+      ls2_dcb_through<1>(a, ch0 + l, T2r, T2i, e2r, e2i, lane, budget, lds_kid, nullptr);
     }
+    Tre = T2r; Tim = T2i; exr = e2r; exi = e2i;
   }
 }
 // up: the 64 children of node `node` of level L composed in order -> the node's table (on the window of its first child)
@@ -2033,6 +2018,8 @@ RFID_KERNEL(64) void ls2_dcb_top_kernel(Ls2Args a) {
   const int lane = wv::lane_id();
   const int s = (int)blockIdx.x;
   const int t0 = s * a.max_bc;
+  RFID_SHARED int lds_a[LS2_DCB_STAGE];   // (descents: a node's children's tables, and a child's own children's)
+  RFID_SHARED int lds_b[LS2_DCB_STAGE];
   if (s == 0 && lane == 0) ctl->dc_rounds = r + 1;
   if (lane == 0) a.dfront[s] = 0x7fffffff;
   if (!(wv::uniform(a.dstat[t0]) & 4)) return;   // an empty trace
@@ -2071,8 +2058,8 @@ RFID_KERNEL(64) void ls2_dcb_top_kernel(Ls2Args a) {
         // the node's table missed an exact entry value: through its children one by one (they may all be hit)
         budget--;
         T2r = Tre; T2i = Tim; e2r = exr; e2i = exi;
-        if (two) ls2_dcb_through<2>(a, node, T2r, T2i, e2r, e2i, lane, budget);
-        else ls2_dcb_through<1>(a, node, T2r, T2i, e2r, e2i, lane, budget);
+        if (two) ls2_dcb_through<2>(a, node, T2r, T2i, e2r, e2i, lane, budget, lds_a, lds_b);
+        else ls2_dcb_through<1>(a, node, T2r, T2i, e2r, e2i, lane, budget, lds_a, nullptr);
       }
       Tre = T2r; Tim = T2i; exr = e2r; exi = e2i;
     }
@@ -2082,7 +2069,7 @@ RFID_KERNEL(64) void ls2_dcb_top_kernel(Ls2Args a) {
 // down: from a node's entry value to its children's.  Level 1: the children are the units -- their start values (a.dT),
 // which of them are settled, how many are not (Ls2Ctl::dc_count[round]).
 template <int L>
-RFID_DEVICE void ls2_dcb_down(const Ls2Args &a, const int node, const int lane, int &n_uns, int &n_units, int &first_uns, int *lds_tab) {
+RFID_DEVICE void ls2_dcb_down(const Ls2Args &a, const int node, const int lane, int &n_uns, int &n_units, int &first_uns, int *lds_tab, int *lds_kid) {
   const Ls2DcbKids kd = ls2_dcb_kids<L>(a);
   const int nper = (L == 1) ? a.dcb_n1 : a.dcb_n2;
   const int *nval = (L == 1) ? a.n1val : a.n2val; const int *nent = (L == 1) ? a.n1ent : a.n2ent;
@@ -2133,7 +2120,7 @@ RFID_DEVICE void ls2_dcb_down(const Ls2Args &a, const int node, const int lane, 
         if (L == 2 && ((exr && !e2r) || (exi && !e2i)) && budget > 0) {   // (the block's table missed: through its units one by one)
           budget--;
           T2r = Tre; T2i = Tim; e2r = exr; e2i = exi;
-          ls2_dcb_through<1>(a, c, T2r, T2i, e2r, e2i, lane, budget);
+          ls2_dcb_through<1>(a, c, T2r, T2i, e2r, e2i, lane, budget, lds_kid, nullptr);
         }
         Tre = T2r; Tim = T2i; exr = e2r; exi = e2i;
       }
@@ -2149,7 +2136,8 @@ RFID_KERNEL(64) void ls2_dcb_down2_kernel(Ls2Args a) {
   const int N = a.n_streams * a.dcb_n2;
   int u0 = 0, u1 = 0, u2 = 0;
   RFID_SHARED int lds_tab[LS2_DCB_STAGE];
-  for (int node = (int)blockIdx.x; node < N; node += (int)gridDim.x) ls2_dcb_down<2>(a, node, lane, u0, u1, u2, lds_tab);
+  RFID_SHARED int lds_kid[LS2_DCB_STAGE];
+  for (int node = (int)blockIdx.x; node < N; node += (int)gridDim.x) ls2_dcb_down<2>(a, node, lane, u0, u1, u2, lds_tab, lds_kid);
 }
 RFID_KERNEL(64) void ls2_dcb_down1_kernel(Ls2Args a) {
   ls2_tail_prio();
@@ -2163,7 +2151,7 @@ RFID_KERNEL(64) void ls2_dcb_down1_kernel(Ls2Args a) {
   RFID_SHARED int lds_tab[LS2_DCB_STAGE];
   for (int node = (int)blockIdx.x; node < N; node += (int)gridDim.x) {
     int nu = 0, first_uns = 0;
-    ls2_dcb_down<1>(a, node, lane, nu, n_units, first_uns, lds_tab);
+    ls2_dcb_down<1>(a, node, lane, nu, n_units, first_uns, lds_tab, nullptr);
     if (nu && lane == 0) wv::atomic_min(a.dfront + first_uns / a.max_bc, first_uns);   // the trace's frontier: its first unit that is not settled
     n_uns += nu;
   }
