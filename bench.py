@@ -247,7 +247,8 @@ WAKE_S = 0.08      # seconds of the workload's own passes before the warm-up ste
 # ---------------------------------------------------------------------------------------------------
 # device_state: what the device's clocks / power / temperature were around the timed region.  Boxes of the pool differ by
 # +-3-7 % on an untouched kernel (2.40 -> 2.56 ms); this is what lets a reader attribute that.  sysfs only
-# (readable by an ordinary user), sampled by a thread every few ms while the timed region runs; rocm-smi once, outside it.
+# (readable by an ordinary user), sampled by a thread every few ms while the timed region's passes run ONCE MORE right behind it
+# (inside it the reads cost the headline 3 - 6 %: measure()); rocm-smi once, before the workload is built.
 # ---------------------------------------------------------------------------------------------------
 def _sysfs_card(torch, device):
     """The /sys/class/drm/cardN/device directory of `device` (matched by PCI address; else the index-th amdgpu card)."""
@@ -406,7 +407,7 @@ def measure(torch, wl, steps, warmup, barrier, gather_elapsed=None, n_series=Non
     # then run 3 % slower than every later one (profiles/r04/bench_warm.txt).  The same passes are run for WAKE_S of wall
     # time before the W warm-up steps; neither is timed.
     wake_t0, wake_n = time.perf_counter(), 0
-    while time.perf_counter() - wake_t0 < (WAKE_S if wake_s is None else wake_s) and wake_n < 400:
+    while time.perf_counter() - wake_t0 < (WAKE_S if wake_s is None else wake_s) and wake_n < 4000:
         step()
         wake_n += 1
     wake_ms = 1e3 * (time.perf_counter() - wake_t0)
@@ -415,8 +416,6 @@ def measure(torch, wl, steps, warmup, barrier, gather_elapsed=None, n_series=Non
 
     # ---- the timed region: exactly `steps` passes, nothing else -------------------------------------------------------
     step_s = []
-    sampler = DeviceStateSampler(torch, data.device)      # (a thread reading sysfs every 4 ms: clocks / power / temperature)
-    sampler.start()
     barrier()
     t0 = time.perf_counter()
     if back_to_back:
@@ -430,8 +429,6 @@ def measure(torch, wl, steps, warmup, barrier, gather_elapsed=None, n_series=Non
             step_s.append(time.perf_counter() - ts)
     barrier()
     elapsed = time.perf_counter() - t0
-    sampler.stop()
-    dev_state = sampler.summary(t0, t0 + elapsed)
     ms_by_rank = [1e3 * elapsed / steps]
     if gather_elapsed is not None:
         every = gather_elapsed(elapsed)               # control plane only: every rank's time; the job's = the slowest
@@ -460,6 +457,26 @@ def measure(torch, wl, steps, warmup, barrier, gather_elapsed=None, n_series=Non
             ts = time.perf_counter()
             step()
             step_s.append(time.perf_counter() - ts)
+    # the device's state under this load: the SAME K passes once more, behind everything that is measured, with a thread reading sysfs
+    # every 4 ms (clocks / power / temperature).  Not inside the timed region: there the reads cost the headline 3 - 6 % (the
+    # first half of round 6 sampled inside: 2.84 ms per pass against 2.67 - 2.76 for round 5's tree on the same box -- hwmon and
+    # pp_dpm reads go to the SMU -- and the kernel series right behind such a region still ran 6 % slow: profiles/r06/
+    # device_state_sampling.txt); the replay's own time is reported beside the samples
+    sampler = DeviceStateSampler(torch, data.device)
+    sampler.start()
+    r0 = time.perf_counter()
+    if back_to_back:
+        for _ in range(steps):
+            ctx.batch_process_ptr(ptr, stride, L, 0, want_scores=False)
+        ctx.batch_sync()
+    else:
+        for _ in range(steps):
+            step()
+    r1 = time.perf_counter()
+    sampler.stop()
+    dev_state = sampler.summary(r0, r1)
+    if isinstance(dev_state, dict):
+        dev_state["replay_ms_per_step"] = round(1e3 * (r1 - r0) / steps, 4)
     b2b_ms = (1e3 * elapsed / steps) if back_to_back else None
     k_ms = {k: statistics.fmean(v) for k, v in k_series.items()}
     k_min = {k: min(v) for k, v in k_series.items()}
@@ -632,6 +649,7 @@ def main():
     ap.add_argument("--leak-phase", type=float, default=None, help="configs 2 / 3stream: phase (rad) of the carrier leak L = e^{j phase} (SURVEY 8(d): 0.7); "
                     "0.7 puts 25 sin(0.7) = 16.1 next to a power of two, where dc_est hovers across the binade edge under noise")
     ap.add_argument("--seed", type=int, default=1000)
+    ap.add_argument("--wake-ms", type=float, default=None, help="ms of the workload's own passes before the warm-up steps (default: WAKE_S; untimed)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stream-leg", action="store_true")
@@ -710,7 +728,7 @@ def main():
         return [float(t.item()) for t in every]
 
     m = measure(torch, wl, args.steps, args.warmup, barrier, gather_elapsed if dist is not None else None,
-                back_to_back=not args.no_back_to_back)
+                back_to_back=not args.no_back_to_back, wake_s=None if args.wake_ms is None else args.wake_ms / 1e3)
     elapsed, step_s, k_ms, alg, key, roof, rep = m["elapsed"], m["step_s"], m["k_ms"], m["alg"], m["key"], m["roof"], m["rep"]
     n_epc_ok, n_windows, n_rn16, n_epc = m["n_epc_ok"], m["n_windows"], m["n_rn16"], m["n_epc"]
     parity_ok, parity_text = m["parity_ok"], m["parity_text"]
@@ -742,7 +760,7 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "timed_region": ("the K passes enqueued one behind the other, one wait at the end (barrier + device synchronisation on both sides)"
                          if m["b2b_ms"] is not None else "every pass waited for by itself (--no-back-to-back)"),
-        "device_wake": dict(m["wake"], note="the same passes run for %.0f ms of wall time before the W warm-up steps (the device's clocks after the host's set-up work); untimed" % (1e3 * WAKE_S)),
+        "device_wake": dict(m["wake"], note="the same passes run for %.0f ms of wall time before the W warm-up steps (the device's clocks after the host's set-up work); untimed" % m["wake"]["ms"]),
         "passes_each_waited_for": {"ms_per_step": round(statistics.fmean(step_s) * 1e3, 4), "min_ms_per_step": round(min(step_s) * 1e3, 4),
                                    "median_ms_per_step": round(statistics.median(step_s) * 1e3, 4),
                                    "note": ("the same K passes, each submitted and waited for by itself (the timed region of rounds 1-3); "
@@ -765,9 +783,11 @@ def main():
         "devices_by_rank": devices,
         "control_plane": ("torch.distributed/%s: barrier + all_gather of the ranks' times and checks" % backend) if dist is not None
                          else "single process",
-        "device_state": dict(during_timed_region=m["dev_state"], **dev_static,
-                             note="rank 0's device; during_timed_region = sysfs (pp_dpm_sclk / pp_dpm_mclk starred level, hwmon power and "
-                                  "temperatures) sampled by a thread while the K timed passes ran; the rest read once before the workload was built"),
+        "device_state": dict(under_load=m["dev_state"], **dev_static,
+                             note="rank 0's device; under_load = sysfs (pp_dpm_sclk / pp_dpm_mclk starred level, hwmon power and "
+                                  "temperatures) sampled every 4 ms by a thread while the SAME K passes ran once more behind all "
+                                  "measured series (replay_ms_per_step: that run's own time -- the reads perturb it, which is why they are not "
+                                  "inside the timed region); the rest read once before the workload was built"),
     }
     if rep["pieces"]:
         out["long_stream"] = dict(rep, note="traces cut along time into pieces processed at once (avg_ampl, state machine, dc_est) "
