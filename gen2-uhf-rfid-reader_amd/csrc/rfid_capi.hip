@@ -656,6 +656,8 @@ int ls_enqueue(rfid_ctx *c, int64_t n_dec, const LsOpts &opt, int *enqueued) {
         }
       }
       fprintf(stderr, "[ls2] dc_est: %ld units, %ld settled, finishing walk took %d, rounds used %d of %d enqueued\n", units, settled, k.dc_finished, k.dc_rounds, c->ls2_rounds[2] + 1);
+      fprintf(stderr, "[ls2] finishing walk (trace 0): %d turns; units settled per turn (0, 1, 2-3, 4-7, 8-15, 16-31, 32-63, more): %d %d %d %d %d %d %d %d; first misses inside / outside twice the windows' reach: %d / %d\n",
+              k.fin_turns, k.fin_reach[0], k.fin_reach[1], k.fin_reach[2], k.fin_reach[3], k.fin_reach[4], k.fin_reach[5], k.fin_reach[6], k.fin_reach[7], k.fin_far[0], k.fin_far[1]);
       for (int q = 0; q < 2; ++q) {
         fprintf(stderr, "[ls2] dc_est %s |true start - centre of the latest run| (0, <8, <64, <512, <4096, <32768, <262144, more):", q ? "im" : "re");
         for (int b = 0; b < 8; ++b) fprintf(stderr, " %ld", hd[q][b]);

@@ -76,7 +76,9 @@ struct Ls2Ctl {   // control block in HBM, zeroed before every pass
   int dc_open_alloc;          // places handed out in Ls2Args::dcand
   int dc_finished;            // units the finishing walk took (the rounds were used up: the partial fallback)
   int dc_count[LS2_DC_MAXR + 1];   // units not settled after chain round r
-  int reserved_[11];
+  int fin_turns;              // the finishing walk: turns (trace 0's), ...
+  int fin_reach[8];           //   ... how many units a turn settled: 0, 1, 2-3, 4-7, 8-15, 16-31, 32-63, more
+  int fin_far[2];             //   ... a turn's first miss: inside / outside twice the windows' reach (the components' larger distance)
 };
 struct Ls2AvgRun {   // a piece's latest run
   float s, eA, eB;   // start used, end from it, end from s + 1 ulp
@@ -1572,8 +1574,12 @@ RFID_DEVICE int ls2_dcb_slot(const Ls2Args &a, const int t) { const int s = t / 
 // One unit (idle-grid slot t) from 64 neighbouring start values per component: lane j from centre + j - 32 ulps.
 // have_centre: (cre, cim) is the centre (ord images); else the trace's exact start (its first unit) or the ring's mean.
 // -> end_re / end_im: lane j's dc_est behind the unit (ord images); also left in a.dtab, the centre in a.dcen
+// QUIET (the finishing walk's exploring runs: several waves on one unit, each with a window of its own): nothing is written but
+// what the caller gets back -- the 64 ends, the centre actually used (cen_re / cen_im) and the two margins
+template <bool QUIET = false>
 RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_centre, int cre, int cim, const bool reserve, const int lane,
-                              float2 *lds_dc, float2 *lds_tmp, float2 *lds_q, int &end_re, int &end_im) {
+                              float2 *lds_dc, float2 *lds_tmp, float2 *lds_q, int &end_re, int &end_im,
+                              int *q_cen = nullptr, int *q_mar = nullptr) {
   const int s = t / a.max_bc;
   const int i = ls2_dcb_slot(a, t);
   const int upos0 = wv::uniform(a.piece[i].pos0);
@@ -1622,8 +1628,9 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
   ls2_range_init(rgr); ls2_range_init(rgi);
   Ls2Win *wb = a.wb + (int64_t)s * a.wb_stride;
   // where the unit's gate openings go in a.dcand: reserved once (complete windows + the one a trace may end in)
-  int wslot = 0;
-  if (reserve) {
+  int wslot = -1;
+  if (QUIET) {
+  } else if (reserve) {
     const int want = wv::uniform(a.fsm[i].nwin) + 1;
     int got = 0;
     if (lane == 0) got = wv::atomic_add(&a.ctl->dc_open_alloc, want);
@@ -1725,7 +1732,7 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
         wv::wave_sync();   // (the reads of the step before are over)
         lds_q[lane] = make_float2(tre, tim);
         wv::wave_sync();
-        if (__builtin_expect(ol == 0xff, 1)) {
+        if (__builtin_expect(QUIET || ol == 0xff, 1)) {
           // (unrolled all the way: the reads run ahead of the adds as far as the scheduler lets them.  What must NOT be unrolled is the
           // gate-opening path below: its 64 conditional snapshots kept 64 increments and as many copies alive -- 219 VGPRs, two
           // waves per SIMD, 2.9 ms for configs[2]'s first round; 97 VGPRs since)
@@ -1753,7 +1760,7 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
         }
       } else {
         g.run_closed = 0;   // the step lies entirely inside a window: dc_est, the ring and its index do not move
-        if (ol != 0xff) {   // (an opening sample is closed itself: not reached)
+        if (!QUIET && ol != 0xff) {   // (an opening sample is closed itself: not reached)
           if (wslot >= 0) a.dcand[(int64_t)(wslot + nopen) * 64 + lane] = acc;
           if (lane == 0) { Ls2Win *w = wb + (upos0 + 64 * k + ol) / LS2_WBUCKET; w->slot = (wslot >= 0) ? (wslot + nopen) : 0; w->unit = t; }
           nopen++;
@@ -1771,7 +1778,7 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
       if (kb + u < nsteps) step(kb + u, buf[u], false);
   }
   end_re = ls2_ord(acc.x); end_im = ls2_ord(acc.y);
-  if (lane == 0) { a.dexm[2 * t] = ~0ull; a.dexm[2 * t + 1] = ~0ull; }
+  if (!QUIET && lane == 0) { a.dexm[2 * t] = ~0ull; a.dexm[2 * t + 1] = ~0ull; }
   {
     { const int q = ls2_range_margin(rgr, rgr); mre = (q < mre) ? q : mre; }
     { const int q = ls2_range_margin(rgi, rgi); mim = (q < mim) ? q : mim; }
@@ -1779,6 +1786,7 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
     // (the chain works on the integer image of binary32: a shift by D at the start is a shift by D at the end only if both lie in one binade)
     if (((wv::f2u(wv::readlane(acc.x, LS2_DCB_HALF)) ^ sbr) & 0xff800000u) != 0u || mre < 0) mre = 0;
     if (((wv::f2u(wv::readlane(acc.y, LS2_DCB_HALF)) ^ sbi) & 0xff800000u) != 0u || mim < 0) mim = 0;
+    if (QUIET) { q_mar[0] = mre; q_mar[1] = mim; q_cen[0] = cre; q_cen[1] = cim; return; }
     if (lane == 0) { a.dmar[2 * t] = mre; a.dmar[2 * t + 1] = mim; }
   }
   a.dtab[(int64_t)(2 * t) * 64 + lane] = end_re;
@@ -1848,7 +1856,23 @@ RFID_DEVICE void ls2_dcb_apply(int &v, bool &ex, const int tab, const uint64_t e
   const int oc = inw ? o : (far ? (LS2_DCB_HALF + par) : og);
   const int e = UNIFORM ? wv::readlane(tab, wv::uniform(oc)) : wv::shfl(tab, oc);
   ex = ex && (inw || far) && (((exm >> oc) & 1ull) != 0ull);
-  v = (int)((uint32_t)e + (uint32_t)(o - oc));
+  int step = o - oc;
+  // A guess beyond the window's ends goes on with the table's own slope there, not with 1: on the integer image of binary32 a unit
+  // that starts on one side of a binade edge and ends on the other maps neighbouring starts to ends 2 (or 1/2) apart, and where
+  // the sums hover at an edge every other unit does -- guesses continued with slope 1 were off by as much as they were outside
+  // (most first misses of the finishing walk at sigma = 0.06 lay more than 256 ulps off).  Only guesses: ex is false already.
+  const int a0 = wv::readlane(tab, 0), a2 = wv::readlane(tab, 2), a61 = wv::readlane(tab, 61), a63 = wv::readlane(tab, 63);
+  if (!inw && !far && (o < 0 || o > 63)) {
+    const uint64_t need = (o < 0) ? 5ull : (5ull << 61);
+    int sl = (o < 0) ? (int)((uint32_t)a2 - (uint32_t)a0) : (int)((uint32_t)a63 - (uint32_t)a61);   // the ends of starts two apart
+    if ((exm & need) == need && oc == ((o < 0) ? 0 : 63) && sl >= 1 && sl <= 8 && sl != 2) {
+      int far_by = (o < 0) ? o : (o - 63);
+      far_by = (far_by < -(1 << 20)) ? -(1 << 20) : ((far_by > (1 << 20)) ? (1 << 20) : far_by);
+      const int prod = far_by * sl;
+      step = (prod >= 0) ? ((prod + 1) >> 1) : -((-prod + 1) >> 1);
+    }
+  }
+  v = (int)((uint32_t)e + (uint32_t)step);
 }
 // is a start D ulps off the centre covered by the unit's latest run: an entry of its table that is there, or its margin
 RFID_DEVICE bool ls2_dcb_covers(const int D, const uint64_t exm, const int mar) {
@@ -2173,15 +2197,43 @@ RFID_KERNEL(64) void ls2_dcb_down1_kernel(Ls2Args a) {
 // this walk over the unsettled units -- the partial fallback; the launches behind (window sequence numbers, assembly) find
 // everything settled.  (The turn's tables go through a scratch area in HBM, two sets used alternately: a wave may be one
 // turn ahead of the slowest, never two.)
+//
+// Wide windows (second half of round 6).  What limits a turn's reach is the window: behind a miss every prediction is off by what the
+// missed unit's guess was off, plus a random walk of a few ulps per unit (at a binade edge two neighbouring trajectories do not stay
+// neighbours), and the run of hits ends when that leaves +- 32 -- after ~16 units at sigma = 0.03, ~4 at 0.06.  The first passage of a
+// random walk goes with the SQUARE of the distance: so a unit is explored by LS2_FIN_WIN waves at once, each with a 64-candidate window
+// of its own, side by side (256 candidates, +- 128), in the quiet form of the unit's run (nothing written but the scratch record).
+// A unit that the walk has settled is then run ONCE more in the plain form, centred on its now exact start -- that run leaves the
+// table, dc_est at the gate openings and the records the assembly reads -- by a wave from the far end of the trace's waves while the
+// others explore the next turn's units.
+// the mean of the 48 samples in front of unit t (the dc ring's content at an idle cut: what round 0 centres a unit on) -> false for a
+// trace's first unit (its start is the fresh gate's or the carried state's, exactly)
+RFID_DEVICE bool ls2_dcb_ring_mean(const Ls2Args &a, const int t, const int lane, float &mre, float &mim) {
+  const int s = t / a.max_bc;
+  const int i = ls2_dcb_slot(a, t);
+  if (i == s * a.max_b) return false;
+  const int upos0 = wv::uniform(a.piece[i].pos0);
+  const float2 *yrow = a.y + (int64_t)s * a.y_stride;
+  float2 v = make_float2(0.0f, 0.0f);
+  if (lane < DC_LEN) v = yrow[upos0 - DC_LEN + lane];
+  float pr = v.x, pi = v.y;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { pr += wv::shfl_xor(pr, off); pi += wv::shfl_xor(pi, off); }
+  mre = wv::uniform(pr) / DC_LEN_F; mim = wv::uniform(pi) / DC_LEN_F;
+  return true;
+}
 constexpr int LS2_FIN_GMAX = 256;       // waves per trace, at most
-constexpr int LS2_FIN_AHEAD = 64;       // ... that take part in a turn, at least (32 / 64 / 128 / 256 measured on configs[2] / [3] at sigma 0.03 and 0.06: profiles/r06/noise_sweep.txt)
+constexpr int LS2_FIN_WIN = 4;          // windows (waves) per explored unit when the trace has at least 16 waves
+constexpr int LS2_FIN_AHEAD = 64;       // units explored per turn, at least (as far as the waves go)
 constexpr int LS2_FIN_REC = 136;        // ints per wave and set: centre (2), margin (2), in use (1), pad (3), table (2 x 64)
+constexpr int LS2_FIN_CHUNK = 64;       // scratch records the walk stages through LDS at a time
 template <int WPB>
 RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
   ls2_tail_prio();
   RFID_SHARED float2 lds_dc[WPB][DC_LEN];
   RFID_SHARED float2 lds_tmp[WPB][64];
   RFID_SHARED float4 lds_q4[WPB][32];
+  RFID_SHARED int lds_rec[WPB][LS2_FIN_CHUNK * 128];
   Ls2Ctl *ctl = a.ctl;
   if (!ls2_fsm_settled(a, ctl)) return;
   if (wv::uniform(ctl->dc_count[a.dc_rounds]) == 0) return;
@@ -2189,9 +2241,13 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
   const int s = (int)blockIdx.y;
   const int G = (int)gridDim.x * WPB;                 // waves of this trace
   const int wid = (int)blockIdx.x * WPB + wib;        // this wave among them
+  const int M = (G >= 16) ? LS2_FIN_WIN : 1;          // windows per explored unit
+  const int uw = wid / M, mw = wid - uw * M;          // the unit (behind the frontier) and the window this wave explores
+  const int amax = G / M;                             // units a turn can explore
   const int t0 = s * a.max_bc;
   int *scr = a.fscr + (int64_t)s * 2 * LS2_FIN_GMAX * LS2_FIN_REC;
   int *bar = a.fbar + s;
+  int *ltab = lds_rec[wib];
   // ---- the frontier (every wave finds it for itself: the same data, the same answer) ----
   int first = -1;
   for (int k0 = 0; k0 < a.max_bc && first < 0; k0 += 64) {
@@ -2224,26 +2280,50 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
   }
   int pos = first;
   int Fre = Tre, Fim = Tim;          // the exact value entering slot `pos` (every wave carries it)
-  int corr_re = Fre - wv::uniform(a.dT[2 * (t0 + first)]), corr_im = Fim - wv::uniform(a.dT[2 * (t0 + first) + 1]);
-  int Cre = Fre, Cim = Fim;          // where this wave centres its unit of the coming turn
-  if (wid > 0 && first + wid < a.max_bc) { Cre = wv::uniform(a.dT[2 * (t0 + first + wid)]) + corr_re; Cim = wv::uniform(a.dT[2 * (t0 + first + wid) + 1]) + corr_im; }
-  const int ahead = LS2_FIN_AHEAD;
-  int nact = (G < ahead) ? G : ahead;      // waves that take part in the next turn
+  int nact = (amax < LS2_FIN_AHEAD) ? amax : LS2_FIN_AHEAD;      // units explored in the next turn
+  int fin_t = -1, fin_re = 0, fin_im = 0;                        // the settled unit this wave still has to run in the plain form
   int fixed = 0, turn = 0;
+  auto run_final = [&]() {
+    if (fin_t < 0) return;
+    int er, ei;
+    ls2_dcb_unit(a, fin_t, true, fin_re, fin_im, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei);
+    if (lane == 0) { a.dT[2 * fin_t] = fin_re; a.dT[2 * fin_t + 1] = fin_im; a.dstat[fin_t] = 7; }
+    fin_t = -1;
+  };
   while (pos < a.max_bc) {
     int *set = scr + (int64_t)(turn & 1) * LS2_FIN_GMAX * LS2_FIN_REC;
-    const int k = pos + wid;
+    run_final();                       // (a unit the last turn settled: the others explore meanwhile)
+    const int k = pos + uw;
     const int t = t0 + k;
-    const bool on = wid < nact && k < a.max_bc && (wv::uniform(a.dstat[(k < a.max_bc) ? t : t0]) & 4) != 0;
-    if (wid < nact) {
+    const bool on = uw < nact && k < a.max_bc && (wv::uniform(a.dstat[(k < a.max_bc) ? t : t0]) & 4) != 0;
+    // Where a unit is centred: dc_est is the mean of the last 48 closed samples plus the rounding of every addition so far -- a DRIFT
+    // that moves by a dozen ulps per unit, whatever the sums do at a binade edge.  The exact value at the frontier gives the drift
+    // there (value - ring mean of the frontier's unit); a unit k slots on is centred on ITS ring mean + that drift, off by ~12 sqrt k
+    // ulps: inside +- 128 for the whole turn.  (The first version centred on the chain's predictions: where nothing settles by
+    // rounds those are hundreds of ulps off, a guess through a missed table is off by a share of that, and the run of hits behind
+    // the frontier grew by 4 - 16 units per turn.)
+    float dr_re = 0.0f, dr_im = 0.0f;
+    int tq = -1;                       // the frontier's unit (the first slot from pos on that holds one)
+    {
+      const int kq = pos + lane;
+      const uint64_t mu = wv::ballot(kq < a.max_bc && (a.dstat[t0 + ((kq < a.max_bc) ? kq : 0)] & 4) != 0);
+      if (mu) {
+        tq = t0 + pos + wv::ffs64(mu);
+        float fr, fi;
+        if (ls2_dcb_ring_mean(a, tq, lane, fr, fi)) { dr_re = ls2_from_ord(Fre) - fr; dr_im = ls2_from_ord(Fim) - fi; }
+      }
+    }
+    if (uw < nact) {
       int *rec = set + (int64_t)wid * LS2_FIN_REC;
       if (on) {
-        // the turn's first unit starts from the exact value; the others where the last turn's walk predicted them (or, behind its
-        // reach, the last chain's prediction moved along)
-        int er, ei;
-        ls2_dcb_unit(a, t, true, Cre, Cim, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei);
+        // window mw of M: candidates C + 64 mw - 32 M .. + 63
+        int er, ei, qc[2], qm[2];
+        int Cre = Fre, Cim = Fim;
+        if (t != tq) { float ur, ui; if (ls2_dcb_ring_mean(a, t, lane, ur, ui)) { Cre = ls2_ord(ur + dr_re); Cim = ls2_ord(ui + dr_im); } }
+        const int off = 64 * mw - 32 * M + 32;
+        ls2_dcb_unit<true>(a, t, true, Cre + off, Cim + off, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei, qc, qm);
         rec[8 + lane] = er; rec[72 + lane] = ei;
-        if (lane == 0) { rec[0] = a.dcen[2 * t]; rec[1] = a.dcen[2 * t + 1]; rec[2] = a.dmar[2 * t]; rec[3] = a.dmar[2 * t + 1]; }
+        if (lane == 0) { rec[0] = qc[0]; rec[1] = qc[1]; rec[2] = qm[0]; rec[3] = qm[1]; }
       }
       if (lane == 0) rec[4] = on ? 1 : 0;
     }
@@ -2253,65 +2333,93 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
     wv::block_sync();
     // ---- through the turn's tables from the exact value: as far as the starts are hit the units are settled; behind the first miss
     //      the walk goes on as a PREDICTION (the missed unit's end continued from its nearest candidate), which is where the
-    //      next turn centres the units this turn has already run once -- a round of the chain within the turn's reach ----
+    //      next turn centres the units this turn has already run once -- a round of the chain within the turn's reach.
+    //      The records go through LDS 64 at a time, every load in flight at once; their scalars one load per lane ----
     int Wre = Fre, Wim = Fim;         // the walk's value
     int miss = -1;                    // the turn's first slot whose unit was not hit
-    int nxt_re = 0, nxt_im = 0;       // where this wave centres its unit of the next turn
-    bool have_nxt = false;
-    int last_re = 0, last_im = 0, last_t = -1;   // the value entering the turn's last unit, and that unit
     bool ex = true;
+    int nset = 0;                     // units this turn has settled so far
     int w = 0;
-    for (; w < nact && pos + w < a.max_bc; ++w) {
-      const int *rec = set + (int64_t)w * LS2_FIN_REC;
-      if (!wv::uniform(rec[4])) continue;   // (a slot without a unit)
-      const int tw = t0 + pos + w;
-      const int c_re = wv::uniform(rec[0]), c_im = wv::uniform(rec[1]), m_re = wv::uniform(rec[2]), m_im = wv::uniform(rec[3]);
-      if (ex) {
-        const int D_re = (int)((uint32_t)Wre - (uint32_t)c_re), D_im = (int)((uint32_t)Wim - (uint32_t)c_im);
-        const bool k_re = ls2_dcb_covers(D_re, ~0ull, m_re), k_im = ls2_dcb_covers(D_im, ~0ull, m_im);
-        if (k_re && k_im) {
-          if (w == wid && lane == 0) { a.dT[2 * tw] = Wre; a.dT[2 * tw + 1] = Wim; a.dstat[tw] = 7; }   // (the wave that ran the unit)
-          fixed++;
-        } else {
-          ex = false; miss = w;       // this unit's true start is known now: it is the next turn's first unit
-          Fre = Wre; Fim = Wim;
+    const int upc = LS2_FIN_CHUNK / M;                 // units per staged chunk
+    for (int w0 = 0; w0 < nact && pos + w0 < a.max_bc; w0 += upc) {
+      const int nrec = ((nact - w0 < upc) ? (nact - w0) : upc) * M;
+      const int *rb = set + (int64_t)(w0 * M) * LS2_FIN_REC;
+      int c_re_l = 0, c_im_l = 0, m_re_l = 0, m_im_l = 0, on_l = 0;
+      if (lane < nrec) { const int *r = rb + (int64_t)lane * LS2_FIN_REC; c_re_l = r[0]; c_im_l = r[1]; m_re_l = r[2]; m_im_l = r[3]; on_l = r[4]; }
+      wv::wave_sync();   // (the last chunk's reads are over)
+      {
+        Ls2Int4 *dst = reinterpret_cast<Ls2Int4 *>(ltab);
+        const int half = lane >> 5, q4 = lane & 31;   // (two records per load instruction: 32 lanes x 16 bytes = a record's two rows)
+#pragma unroll 8
+        for (int q = 0; q < LS2_FIN_CHUNK / 2; ++q) {
+          const int r = 2 * q + half;
+          const Ls2Int4 *src = reinterpret_cast<const Ls2Int4 *>(rb + (int64_t)((r < nrec) ? r : 0) * LS2_FIN_REC + 8);
+          dst[r * 32 + q4] = src[q4];
         }
       }
-      if (!ex && w == miss + wid) { nxt_re = Wre; nxt_im = Wim; have_nxt = true; }
-      last_re = Wre; last_im = Wim; last_t = tw;
-      bool e1 = true, e2 = true;
-      ls2_dcb_apply<true>(Wre, e1, rec[8 + lane], ~0ull, c_re, m_re);
-      ls2_dcb_apply<true>(Wim, e2, rec[72 + lane], ~0ull, c_im, m_im);
+      wv::wave_sync();
+      for (int u = 0; u < upc && w0 + u < nact && pos + w0 + u < a.max_bc; ++u) {
+        w = w0 + u;
+        const int r0 = u * M;
+        if (!wv::readlane(on_l, r0)) continue;   // (a slot without a unit)
+        const int tw = t0 + pos + w;
+        // the window of the unit that holds the walk's value (else the outermost on that side: its margin may still reach, or a guess)
+        const int C_re = wv::readlane(c_re_l, r0) + 32 * M - 32, C_im = wv::readlane(c_im_l, r0) + 32 * M - 32;
+        int q_re = ((int)((uint32_t)Wre - (uint32_t)C_re) + 32 * M) >> 6, q_im = ((int)((uint32_t)Wim - (uint32_t)C_im) + 32 * M) >> 6;
+        q_re = (q_re < 0) ? 0 : ((q_re > M - 1) ? M - 1 : q_re); q_im = (q_im < 0) ? 0 : ((q_im > M - 1) ? M - 1 : q_im);
+        const int c_re = wv::readlane(c_re_l, r0 + q_re), c_im = wv::readlane(c_im_l, r0 + q_im);
+        const int m_re = wv::readlane(m_re_l, r0 + q_re), m_im = wv::readlane(m_im_l, r0 + q_im);
+        if (ex) {
+          const int D_re = (int)((uint32_t)Wre - (uint32_t)c_re), D_im = (int)((uint32_t)Wim - (uint32_t)c_im);
+          const bool k_re = ls2_dcb_covers(D_re, ~0ull, m_re), k_im = ls2_dcb_covers(D_im, ~0ull, m_im);
+          if (k_re && k_im) {
+            // settled: its exact start is known.  Wave G - 1 - (how many before it this turn) runs it in the plain form next turn
+            if (wid == G - 1 - nset) { fin_t = tw; fin_re = Wre; fin_im = Wim; }   // (nset < G / M: a wave is asked once per turn)
+            nset++;
+            fixed++;
+          } else {
+            ex = false; miss = w;       // this unit's true start is known now: it is the next turn's first unit
+            Fre = Wre; Fim = Wim;
+            if (wid == 0 && s == 0 && lane == 0) {
+              const int d1 = (D_re < 0) ? -D_re : D_re, d2 = (D_im < 0) ? -D_im : D_im;
+              ctl->fin_far[(((d1 > d2) ? d1 : d2) < 64 * M) ? 0 : 1]++;
+            }
+          }
+        }
+        if (!ex) break;               // (behind the first miss nothing is known: the next turn centres those units anew)
+        bool e1 = true, e2 = true;
+        ls2_dcb_apply<true>(Wre, e1, ltab[((r0 + q_re) * 2) * 64 + lane], ~0ull, c_re, m_re);
+        ls2_dcb_apply<true>(Wim, e2, ltab[((r0 + q_im) * 2 + 1) * 64 + lane], ~0ull, c_im, m_im);
+      }
+      if (!ex) break;
+      w = ((w0 + upc < nact) ? (w0 + upc) : nact);
+      if (pos + w > a.max_bc) w = a.max_bc - pos;
+    }
+    if (wid == 0 && s == 0 && lane == 0) {
+      int b = 0; for (int v = nset; v > 0 && b < 7; v >>= 1) b++;
+      ctl->fin_turns++; ctl->fin_reach[b]++;
     }
     if (ex) {
       // every unit of the turn was hit: the value behind the last one is exact -- the next turn's first start
       pos += w;
       Fre = Wre; Fim = Wim;
-      nxt_re = Wre; nxt_im = Wim; have_nxt = (wid == 0);
     } else {
       pos += miss;
     }
-    // the units behind the turn's reach: the last chain's prediction moved along by what this walk made of the turn's last unit
-    // (a unit this turn did NOT settle: the start values of settled units are being overwritten with their exact ones); when every
-    // unit of the turn was hit, by what the exact value is off at the first unit behind it
-    if (!ex) {
-      if (last_t >= 0 && last_t >= t0 + pos) { corr_re = last_re - wv::uniform(a.dT[2 * last_t]); corr_im = last_im - wv::uniform(a.dT[2 * last_t + 1]); }
-    } else if (pos < a.max_bc) {
-      const int kq = pos + lane;
-      const uint64_t mu = wv::ballot(kq < a.max_bc && (a.dstat[t0 + ((kq < a.max_bc) ? kq : 0)] & 4) != 0);
-      if (mu) { const int tq = t0 + pos + wv::ffs64(mu); corr_re = Fre - wv::uniform(a.dT[2 * tq]); corr_im = Fim - wv::uniform(a.dT[2 * tq + 1]); }
+    // (units of the next turn: twice the reach, and never fewer than LS2_FIN_AHEAD -- the units behind the frontier are run again turn
+    // after turn, each time centred on a better prediction, so that they are within a window's reach of the truth when the frontier
+    // arrives; the waves that still have a settled unit to run in the plain form are left out when enough others remain)
+    {
+      int nw = 2 * (ex ? w : miss) + 4;
+      if (nw < LS2_FIN_AHEAD) nw = LS2_FIN_AHEAD;
+      nw = (nw > amax) ? amax : nw;
+      const int spare = (G - nset) / M;
+      if (spare >= 1 && nw > spare) nw = spare;
+      nact = nw;
     }
-    if (have_nxt) { Cre = nxt_re; Cim = nxt_im; }
-    else {
-      const int kn = pos + wid;
-      if (kn < a.max_bc) { Cre = wv::uniform(a.dT[2 * (t0 + kn)]) + corr_re; Cim = wv::uniform(a.dT[2 * (t0 + kn) + 1]) + corr_im; }
-    }
-    // (waves of the next turn: twice the reach, and never fewer than LS2_FIN_AHEAD -- the units a few dozen slots behind the frontier are
-    // run again turn after turn, each time centred on a better prediction, so that they are within a window's reach of the truth
-    // when the frontier arrives; every wave has a CU of its own, what more of them cost is the walk over their tables)
-    { int nw = 2 * (ex ? w : miss) + 4; if (nw < ahead) nw = ahead; nact = (nw > G) ? G : nw; }
     turn++;
   }
+  run_final();
   if (wid == 0 && lane == 0 && fixed) { wv::atomic_add(&ctl->dc_count[a.dc_rounds], -fixed); wv::atomic_add(&ctl->dc_finished, fixed); }
 }
 
