@@ -136,7 +136,7 @@ struct Ls2Args {
   int *dstat;                   // [NH] bit 0 / 1: re / im settled, bit 2: the slot holds a unit, bit 3: its latest run does not cover the start predicted for it (zeroed before a pass)
   uint64_t *dexm;               // [NH][2] which entries of the unit's table are there (a unit's run leaves all 64)
   int *dfront;                  // [n_streams] the trace's first idle-grid slot whose unit is not settled (after a chain; INT_MAX: none)
-  int *fscr, *fbar;             // the finishing walk's scratch [n_streams][2][LS2_FIN_GMAX][LS2_FIN_REC] and its meeting counters [n_streams] (zeroed before a pass)
+  int *fscr, *fbar;             // the finishing walk's scratch [n_streams][2][waves per trace][LS2_FIN_REC] and its meeting counters [n_streams] (zeroed before a pass)
   int *dmar;                    // [NH][2] how far from its centre a start may lie for the unit's end to be a plain shift of candidate 32's / 33's (ulps; 0: nowhere)
   int *dwbase;                  // [NH] the unit's first place in dcand
   float2 *dcand; int dcand_cap; // [dcand_cap][64] dc_est at a gate opening for each candidate
@@ -1576,7 +1576,7 @@ RFID_DEVICE int ls2_dcb_slot(const Ls2Args &a, const int t) { const int s = t / 
 // -> end_re / end_im: lane j's dc_est behind the unit (ord images); also left in a.dtab, the centre in a.dcen
 // QUIET (the finishing walk's exploring runs: several waves on one unit, each with a window of its own): nothing is written but
 // what the caller gets back -- the 64 ends, the centre actually used (cen_re / cen_im) and the two margins
-template <bool QUIET = false>
+template <bool QUIET = false, bool NOMARGIN = false>   // NOMARGIN (the finishing walk): the margins are not looked at -- not formed, left 0
 RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_centre, int cre, int cim, const bool reserve, const int lane,
                               float2 *lds_dc, float2 *lds_tmp, float2 *lds_q, int &end_re, int &end_im,
                               int *q_cen = nullptr, int *q_mar = nullptr) {
@@ -1650,7 +1650,7 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
     const int *oinfo = a.openinfo + cbase;
     const float2 *ys = yrow + upos0;
     const int nsteps = (n + 63) >> 6;
-    constexpr int AHEAD = 4;
+    constexpr int AHEAD = 4;   // (8 in the finishing walk's one-wave workgroups: no difference)
     float2 buf[AHEAD];
     // (loads clamped, not predicated, and the complete groups of AHEAD steps without a condition around a step: see
     // ls2_avg_piece.  Samples past the unit's end are not closed -- nvalid -- whatever their value.)
@@ -1717,7 +1717,7 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
                        }
                      },
                      tre, tim);
-        {
+        if (!NOMARGIN) {
           const float c32r = wv::readlane(acc.x, LS2_DCB_HALF), c32i = wv::readlane(acc.y, LS2_DCB_HALF);
           const float pr = c32r + wv::scan_add_f(tre), pi = c32i + wv::scan_add_f(tim);
           // (nearly every step stays in the start's binade: there the margin is the range of the mantissas, formed once behind the
@@ -1783,6 +1783,7 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
     { const int q = ls2_range_margin(rgr, rgr); mre = (q < mre) ? q : mre; }
     { const int q = ls2_range_margin(rgi, rgi); mim = (q < mim) ? q : mim; }
     mre = ls2_wave_min(mre) - LS2_DCB_SLACK; mim = ls2_wave_min(mim) - LS2_DCB_SLACK;
+    if (NOMARGIN) { mre = 0; mim = 0; }
     // (the chain works on the integer image of binary32: a shift by D at the start is a shift by D at the end only if both lie in one binade)
     if (((wv::f2u(wv::readlane(acc.x, LS2_DCB_HALF)) ^ sbr) & 0xff800000u) != 0u || mre < 0) mre = 0;
     if (((wv::f2u(wv::readlane(acc.y, LS2_DCB_HALF)) ^ sbi) & 0xff800000u) != 0u || mim < 0) mim = 0;
@@ -2222,7 +2223,8 @@ RFID_DEVICE bool ls2_dcb_ring_mean(const Ls2Args &a, const int t, const int lane
   mre = wv::uniform(pr) / DC_LEN_F; mim = wv::uniform(pi) / DC_LEN_F;
   return true;
 }
-constexpr int LS2_FIN_GMAX = 256;       // waves per trace, at most
+constexpr int LS2_FIN_GMAX = 512;       // waves per trace, at most (256 / 512 / 1 024 measured: profiles/r06/noise_sweep.txt)
+constexpr int LS2_FIN_TOTAL = 1024;     // ... and of all traces together: one-wave workgroups with 33 KB of LDS, four per CU -- they meet, so all of a trace's must be resident
 constexpr int LS2_FIN_WIN = 4;          // windows (waves) per explored unit when the trace has at least 16 waves
 constexpr int LS2_FIN_AHEAD = 64;       // units explored per turn, at least (as far as the waves go)
 constexpr int LS2_FIN_REC = 136;        // ints per wave and set: centre (2), margin (2), in use (1), pad (3), table (2 x 64)
@@ -2245,7 +2247,7 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
   const int uw = wid / M, mw = wid - uw * M;          // the unit (behind the frontier) and the window this wave explores
   const int amax = G / M;                             // units a turn can explore
   const int t0 = s * a.max_bc;
-  int *scr = a.fscr + (int64_t)s * 2 * LS2_FIN_GMAX * LS2_FIN_REC;
+  int *scr = a.fscr + (int64_t)s * 2 * G * LS2_FIN_REC;
   int *bar = a.fbar + s;
   int *ltab = lds_rec[wib];
   // ---- the frontier (every wave finds it for itself: the same data, the same answer) ----
@@ -2286,12 +2288,12 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
   auto run_final = [&]() {
     if (fin_t < 0) return;
     int er, ei;
-    ls2_dcb_unit(a, fin_t, true, fin_re, fin_im, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei);
+    ls2_dcb_unit<false, true>(a, fin_t, true, fin_re, fin_im, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei);
     if (lane == 0) { a.dT[2 * fin_t] = fin_re; a.dT[2 * fin_t + 1] = fin_im; a.dstat[fin_t] = 7; }
     fin_t = -1;
   };
   while (pos < a.max_bc) {
-    int *set = scr + (int64_t)(turn & 1) * LS2_FIN_GMAX * LS2_FIN_REC;
+    int *set = scr + (int64_t)(turn & 1) * G * LS2_FIN_REC;
     run_final();                       // (a unit the last turn settled: the others explore meanwhile)
     const int k = pos + uw;
     const int t = t0 + k;
@@ -2321,7 +2323,7 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
         int Cre = Fre, Cim = Fim;
         if (t != tq) { float ur, ui; if (ls2_dcb_ring_mean(a, t, lane, ur, ui)) { Cre = ls2_ord(ur + dr_re); Cim = ls2_ord(ui + dr_im); } }
         const int off = 64 * mw - 32 * M + 32;
-        ls2_dcb_unit<true>(a, t, true, Cre + off, Cim + off, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei, qc, qm);
+        ls2_dcb_unit<true, true>(a, t, true, Cre + off, Cim + off, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei, qc, qm);
         rec[8 + lane] = er; rec[72 + lane] = ei;
         if (lane == 0) { rec[0] = qc[0]; rec[1] = qc[1]; rec[2] = qm[0]; rec[3] = qm[1]; }
       }

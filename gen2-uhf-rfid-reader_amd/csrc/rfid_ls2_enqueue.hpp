@@ -53,6 +53,14 @@ struct Ls2Layout {
   int dcand_cap;
 };
 // wmax: complete windows a trace can hold (the caller's window table): sizes the dc_est stage's table of gate openings
+// waves per trace of the dc_est finishing walk (its workgroups meet: rfid_ls2.hpp).  The test suite's emulator runs one workgroup at
+// a time: one workgroup of LS2_FIN_WPB waves per trace there
+inline int ls2_fin_waves(int B) {
+  if (LS2_FIN_WPB > 1) return LS2_FIN_WPB;
+  int g = LS2_FIN_TOTAL / (B < 1 ? 1 : B);
+  if (g > LS2_FIN_GMAX) g = LS2_FIN_GMAX;
+  return g < 1 ? 1 : g;
+}
 inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_stride, int wmax) {
   Ls2Layout L;
   size_t off = 0;
@@ -86,7 +94,7 @@ inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_strid
   L.dmar = take(sizeof(int) * 2 * NH);
   L.dexm = take(sizeof(uint64_t) * 2 * NH);
   L.dfront = take(sizeof(int) * B);
-  L.fscr = take(sizeof(int) * B * 2 * (size_t)LS2_FIN_GMAX * LS2_FIN_REC);
+  L.fscr = take(sizeof(int) * B * 2 * (size_t)ls2_fin_waves((int)B) * LS2_FIN_REC);
   L.fbar = take(sizeof(int) * B);
   L.dwbase = take(sizeof(int) * NH);
   L.dcand_cap = (int)(B * (size_t)(wmax > 0 ? wmax : 0) + NH + 8);   // every window + the one a trace may end in, per unit
@@ -242,11 +250,8 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
     a.round = 0;
     {
       // the finishing walk: G waves per trace that meet once per turn -- all of them must be resident at once, so no more than the
-      // device holds beside anything else that may be running (4 096 of its 8 192 wave slots at the very most, 256 per trace)
-      int gw = 4096 / (B * LS2_FIN_WPB);
-      if (gw > LS2_FIN_GMAX / LS2_FIN_WPB) gw = LS2_FIN_GMAX / LS2_FIN_WPB;
-      if (gw < 1) gw = 1;
-      LS2_LAUNCH(ls2_dcb_finish_kernel<LS2_FIN_WPB>, (LS2_FIN_WPB > 1) ? 1 : gw, B, 64 * LS2_FIN_WPB, U(a));
+      // device holds of them (ls2_fin_waves)
+      LS2_LAUNCH(ls2_dcb_finish_kernel<LS2_FIN_WPB>, ls2_fin_waves(B) / LS2_FIN_WPB, B, 64 * LS2_FIN_WPB, U(a));
     }
   }
   a.round = 0;
