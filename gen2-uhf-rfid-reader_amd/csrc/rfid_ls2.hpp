@@ -1787,7 +1787,8 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
     // (the chain works on the integer image of binary32: a shift by D at the start is a shift by D at the end only if both lie in one binade)
     if (((wv::f2u(wv::readlane(acc.x, LS2_DCB_HALF)) ^ sbr) & 0xff800000u) != 0u || mre < 0) mre = 0;
     if (((wv::f2u(wv::readlane(acc.y, LS2_DCB_HALF)) ^ sbi) & 0xff800000u) != 0u || mim < 0) mim = 0;
-    if (QUIET) { q_mar[0] = mre; q_mar[1] = mim; q_cen[0] = cre; q_cen[1] = cim; return; }
+    if (q_cen) { q_cen[0] = cre; q_cen[1] = cim; }
+    if (QUIET) { q_mar[0] = mre; q_mar[1] = mim; return; }
     if (lane == 0) { a.dmar[2 * t] = mre; a.dmar[2 * t + 1] = mim; }
   }
   a.dtab[(int64_t)(2 * t) * 64 + lane] = end_re;
@@ -2225,6 +2226,7 @@ RFID_DEVICE bool ls2_dcb_ring_mean(const Ls2Args &a, const int t, const int lane
 }
 constexpr int LS2_FIN_GMAX = 512;       // waves per trace, at most (256 / 512 / 1 024 measured: profiles/r06/noise_sweep.txt)
 constexpr int LS2_FIN_TOTAL = 1024;     // ... and of all traces together: one-wave workgroups with 33 KB of LDS, four per CU -- they meet, so all of a trace's must be resident
+constexpr int LS2_FIN_WIN_MAX = 8;      // ... at most
 constexpr int LS2_FIN_WIN = 4;          // windows (waves) per explored unit when the trace has at least 16 waves
 constexpr int LS2_FIN_AHEAD = 64;       // units explored per turn, at least (as far as the waves go)
 constexpr int LS2_FIN_REC = 136;        // ints per wave and set: centre (2), margin (2), in use (1), pad (3), table (2 x 64)
@@ -2243,9 +2245,10 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
   const int s = (int)blockIdx.y;
   const int G = (int)gridDim.x * WPB;                 // waves of this trace
   const int wid = (int)blockIdx.x * WPB + wib;        // this wave among them
-  const int M = (G >= 16) ? LS2_FIN_WIN : 1;          // windows per explored unit
-  const int uw = wid / M, mw = wid - uw * M;          // the unit (behind the frontier) and the window this wave explores
-  const int amax = G / M;                             // units a turn can explore
+  // windows per explored unit: LS2_FIN_WIN to LS2_FIN_WIN_MAX, one more pair after a turn that ended in a miss (the drift had left
+  // the windows: wider ones reach further), one fewer after a turn without (more units per turn) -- configs[2] at sigma = 0.03 / 0.06
+  // with 4 / 5 / 6 / 8 throughout: 220 / 276, 170 / 212, 160 / 193, 165 / 183 ms; configs[3] at 0.06: 5.8 / 6.0 / 6.4 / 7.5
+  int M = (G >= 16) ? LS2_FIN_WIN : 1;
   const int t0 = s * a.max_bc;
   int *scr = a.fscr + (int64_t)s * 2 * G * LS2_FIN_REC;
   int *bar = a.fbar + s;
@@ -2282,7 +2285,7 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
   }
   int pos = first;
   int Fre = Tre, Fim = Tim;          // the exact value entering slot `pos` (every wave carries it)
-  int nact = (amax < LS2_FIN_AHEAD) ? amax : LS2_FIN_AHEAD;      // units explored in the next turn
+  int nact = (G / M < LS2_FIN_AHEAD) ? (G / M) : LS2_FIN_AHEAD;      // units explored in the next turn
   int fin_t = -1, fin_re = 0, fin_im = 0;                        // the settled unit this wave still has to run in the plain form
   int fixed = 0, turn = 0;
   auto run_final = [&]() {
@@ -2294,6 +2297,8 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
   };
   while (pos < a.max_bc) {
     int *set = scr + (int64_t)(turn & 1) * G * LS2_FIN_REC;
+    const int uw = wid / M, mw = wid - uw * M;          // the unit (behind the frontier) and the window this wave explores
+    const int pc = (M - 1) / 2;                         // the window centred on the prediction itself: ITS wave runs the plain form (see below)
     run_final();                       // (a unit the last turn settled: the others explore meanwhile)
     const int k = pos + uw;
     const int t = t0 + k;
@@ -2318,12 +2323,15 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
     if (uw < nact) {
       int *rec = set + (int64_t)wid * LS2_FIN_REC;
       if (on) {
-        // window mw of M: candidates C + 64 mw - 32 M .. + 63
-        int er, ei, qc[2], qm[2];
+        // window mw of M: centred on C + 64 (mw - pc) -- C - 96 .. C + 159 in all.  The window around C itself is run in the PLAIN form
+        // (table, dc_est at the gate openings, the records the assembly reads -- all left where the rounds leave them): a unit whose
+        // start falls into it, as most do, is done with that; the others' windows in the quiet form
+        int er, ei, qc[2] = {0, 0}, qm[2] = {0, 0};
         int Cre = Fre, Cim = Fim;
         if (t != tq) { float ur, ui; if (ls2_dcb_ring_mean(a, t, lane, ur, ui)) { Cre = ls2_ord(ur + dr_re); Cim = ls2_ord(ui + dr_im); } }
-        const int off = 64 * mw - 32 * M + 32;
-        ls2_dcb_unit<true, true>(a, t, true, Cre + off, Cim + off, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei, qc, qm);
+        const int off = 64 * (mw - pc);
+        if (mw == pc) ls2_dcb_unit<false, true>(a, t, true, Cre + off, Cim + off, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei, qc, qm);
+        else ls2_dcb_unit<true, true>(a, t, true, Cre + off, Cim + off, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei, qc, qm);
         rec[8 + lane] = er; rec[72 + lane] = ei;
         if (lane == 0) { rec[0] = qc[0]; rec[1] = qc[1]; rec[2] = qm[0]; rec[3] = qm[1]; }
       }
@@ -2340,7 +2348,7 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
     int Wre = Fre, Wim = Fim;         // the walk's value
     int miss = -1;                    // the turn's first slot whose unit was not hit
     bool ex = true;
-    int nset = 0;                     // units this turn has settled so far
+    int nset = 0, nall = 0;           // units this turn has settled so far: those that need a run in the plain form, all
     int w = 0;
     const int upc = LS2_FIN_CHUNK / M;                 // units per staged chunk
     for (int w0 = 0; w0 < nact && pos + w0 < a.max_bc; w0 += upc) {
@@ -2366,8 +2374,8 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
         if (!wv::readlane(on_l, r0)) continue;   // (a slot without a unit)
         const int tw = t0 + pos + w;
         // the window of the unit that holds the walk's value (else the outermost on that side: its margin may still reach, or a guess)
-        const int C_re = wv::readlane(c_re_l, r0) + 32 * M - 32, C_im = wv::readlane(c_im_l, r0) + 32 * M - 32;
-        int q_re = ((int)((uint32_t)Wre - (uint32_t)C_re) + 32 * M) >> 6, q_im = ((int)((uint32_t)Wim - (uint32_t)C_im) + 32 * M) >> 6;
+        const int C_re = wv::readlane(c_re_l, r0 + pc), C_im = wv::readlane(c_im_l, r0 + pc);
+        int q_re = (((int)((uint32_t)Wre - (uint32_t)C_re) + 32) >> 6) + pc, q_im = (((int)((uint32_t)Wim - (uint32_t)C_im) + 32) >> 6) + pc;
         q_re = (q_re < 0) ? 0 : ((q_re > M - 1) ? M - 1 : q_re); q_im = (q_im < 0) ? 0 : ((q_im > M - 1) ? M - 1 : q_im);
         const int c_re = wv::readlane(c_re_l, r0 + q_re), c_im = wv::readlane(c_im_l, r0 + q_im);
         const int m_re = wv::readlane(m_re_l, r0 + q_re), m_im = wv::readlane(m_im_l, r0 + q_im);
@@ -2375,9 +2383,15 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
           const int D_re = (int)((uint32_t)Wre - (uint32_t)c_re), D_im = (int)((uint32_t)Wim - (uint32_t)c_im);
           const bool k_re = ls2_dcb_covers(D_re, ~0ull, m_re), k_im = ls2_dcb_covers(D_im, ~0ull, m_im);
           if (k_re && k_im) {
-            // settled: its exact start is known.  Wave G - 1 - (how many before it this turn) runs it in the plain form next turn
-            if (wid == G - 1 - nset) { fin_t = tw; fin_re = Wre; fin_im = Wim; }   // (nset < G / M: a wave is asked once per turn)
-            nset++;
+            // settled: its exact start is known.  Inside the plain window: that run's results stand (the wave that ran it says so);
+            // else wave G - 1 - (how many such before it this turn) runs the unit in the plain form next turn, centred on its start
+            if (q_re == pc && q_im == pc && D_re >= -LS2_DCB_HALF && D_re < LS2_DCB_HALF && D_im >= -LS2_DCB_HALF && D_im < LS2_DCB_HALF) {
+              if (wid == w * M + pc && lane == 0) { a.dT[2 * tw] = Wre; a.dT[2 * tw + 1] = Wim; a.dstat[tw] = 7; }
+            } else {
+              if (wid == G - 1 - nset) { fin_t = tw; fin_re = Wre; fin_im = Wim; }   // (nset < G / M: a wave is asked once per turn)
+              nset++;
+            }
+            nall++;
             fixed++;
           } else {
             ex = false; miss = w;       // this unit's true start is known now: it is the next turn's first unit
@@ -2398,7 +2412,7 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
       if (pos + w > a.max_bc) w = a.max_bc - pos;
     }
     if (wid == 0 && s == 0 && lane == 0) {
-      int b = 0; for (int v = nset; v > 0 && b < 7; v >>= 1) b++;
+      int b = 0; for (int v = nall; v > 0 && b < 7; v >>= 1) b++;
       ctl->fin_turns++; ctl->fin_reach[b]++;
     }
     if (ex) {
@@ -2414,6 +2428,8 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
     {
       int nw = 2 * (ex ? w : miss) + 4;
       if (nw < LS2_FIN_AHEAD) nw = LS2_FIN_AHEAD;
+      if (G >= 16) M = ex ? ((M > LS2_FIN_WIN) ? M - 1 : M) : ((M + 2 < LS2_FIN_WIN_MAX) ? M + 2 : LS2_FIN_WIN_MAX);
+      const int amax = G / M;                           // units a turn can explore
       nw = (nw > amax) ? amax : nw;
       const int spare = (G - nset) / M;
       if (spare >= 1 && nw > spare) nw = spare;
