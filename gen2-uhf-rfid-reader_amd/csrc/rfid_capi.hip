@@ -65,7 +65,7 @@ struct RfidKnobs {
   int front_unfused = 0;   // RFID_FRONT_UNFUSED     1: many traces through the stage kernels instead of front_end_fused_kernel
   int front_chunks = 1;    // RFID_FRONT_CHUNKS      2..16: the time-chunked stage kernels on two streams (round 1's overlap)
   int fsm_lanes_min = -1;  // RFID_LS2_FSM_LANES_MIN from how many possible units on the state machine runs one lane per unit (-1: 8192)
-  int dc_rounds = -1;      // RFID_LS2_DC_ROUNDS     0..64: dc_est rounds a long-stream pass enqueues behind the first (-1: by the pass's size -- 0 / 2 / 6; what they leave, the finishing walk takes)
+  int dc_rounds = -1;      // RFID_LS2_DC_ROUNDS     0..64: dc_est rounds a long-stream pass enqueues behind the first (-1: by the pass's size -- 0 / 3 / 10; what they leave, the finishing walk takes)
   int la_upload_kernel = 1;  // RFID_LA_UPLOAD_KERNEL  look-ahead: 1 a call's samples are fetched from page-locked memory by a launch, 0 by a transfer
   int front_lds_kb = -1;   // RFID_LS_FRONT_LDS_KB   0..64: extra LDS per workgroup of the long-stream first pass (caps its waves per CU); -1: 10 for long traces
 };

@@ -48,7 +48,7 @@ static_assert(LS2_WBUCKET <= RN16_WIN + T1_SAMPLES, "one window per bucket");
 constexpr int LS2_AVG_ROUNDS = 11;    // re-run rounds after the first pass, per recurrence (a round without work costs two empty launches; configs[2]
                                       // settles in 5 rounds on y-given pieces and in 8 on the fused first pass's, profiles/r05/ls2_rounds.txt)
 constexpr int LS2_FSM_ROUNDS = 3;
-constexpr int LS2_DC_ROUNDS = 6;      // dc_est rounds behind the first that a long pass enqueues (rfid_ls2_enqueue.hpp; 4 / 6 / 10 measured alike: profiles/r06/noise_sweep.txt)
+constexpr int LS2_DC_ROUNDS = 10;     // dc_est rounds behind the first that a long pass enqueues (rfid_ls2_enqueue.hpp: why not fewer)
 constexpr int LS2_MAXR = 12;
 constexpr int LS2_WIDE_BELOW = 64;    // a piece whose margin is below this is re-run from six neighbouring start values at once
 constexpr int LS2_WIDE_LO = -2, LS2_WIDE_HI = 3;

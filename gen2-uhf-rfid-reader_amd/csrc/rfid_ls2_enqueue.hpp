@@ -191,11 +191,12 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
   // dc_est rounds behind the first.  Away from binade edges the first round settles every unit whose margin covers the rounding
   // drift; the few others (a partial sum next to a power of two: ~5 %) are run again centred on the chain's prediction, which is
   // off by an ulp or two per such unit it came through -- the blocks' windows (+- 32) catch that for some thousand units per
-  // round: two rounds for a stream of a few thousand units, three for configs[2]'s 32 000 at every noise level measured away from
-  // binade edges -- six are enqueued (a round without work is six launches that return at once, 4 us each), and what they leave the
-  // finishing walk takes.  Sums that hover at a binade edge do not settle by rounds at all (4, 6 or 10 rounds: 186 - 194 ms for
-  // configs[2] at sigma = 0.03): the finishing walk takes them
-  a.dc_rounds = (dc_rounds >= 0) ? dc_rounds : (tiny ? 0 : (small ? 2 : LS2_DC_ROUNDS));   // (a look-ahead pass holds a few dozen units: the first round and the walk)
+  // round: one to three rounds with work for a stream of a few thousand units, three for configs[2]'s 32 000 at sigma = 0.002 and
+  // five to six at sigma = 0.06 away from binade edges.  Three / ten are enqueued (a round without work is four / six launches that
+  // return at once, 4 us each): the finishing walk takes what the rounds leave FROM THE FIRST UNSETTLED UNIT ON, at ~5 us a unit --
+  // a handful of stragglers early in a long trace would cost more than every empty round together.  Sums that hover at a binade
+  // edge do not settle by rounds at all (4, 6 or 10 rounds measured alike): there the walk is the way
+  a.dc_rounds = (dc_rounds >= 0) ? dc_rounds : (tiny ? 0 : (small ? 3 : LS2_DC_ROUNDS));   // (a look-ahead pass holds a few dozen units: the first round and the walk)
   if (a.dc_rounds < 0) a.dc_rounds = 0;
   if (a.dc_rounds > LS2_DC_MAXR) a.dc_rounds = LS2_DC_MAXR;
   if (fused) {
