@@ -136,6 +136,7 @@ struct Ls2Args {
   int *dstat;                   // [NH] bit 0 / 1: re / im settled, bit 2: the slot holds a unit, bit 3: its latest run does not cover the start predicted for it (zeroed before a pass)
   uint64_t *dexm;               // [NH][2] which entries of the unit's table are there (a unit's run leaves all 64)
   int *dfront;                  // [n_streams] the trace's first idle-grid slot whose unit is not settled (after a chain; INT_MAX: none)
+  float2 *dq;                   // [n_streams][y_stride] the dc_est increments of every closed step, formed once for the finishing walk (ls2_dcb_incr_kernel)
   int *fscr, *fbar;             // the finishing walk's scratch [n_streams][2][waves per trace][LS2_FIN_REC] and its meeting counters [n_streams] (zeroed before a pass)
   int *dmar;                    // [NH][2] how far from its centre a start may lie for the unit's end to be a plain shift of candidate 32's / 33's (ulps; 0: nowhere)
   int *dwbase;                  // [NH] the unit's first place in dcand
@@ -1576,7 +1577,9 @@ RFID_DEVICE int ls2_dcb_slot(const Ls2Args &a, const int t) { const int s = t / 
 // -> end_re / end_im: lane j's dc_est behind the unit (ord images); also left in a.dtab, the centre in a.dcen
 // QUIET (the finishing walk's exploring runs: several waves on one unit, each with a window of its own): nothing is written but
 // what the caller gets back -- the 64 ends, the centre actually used (cen_re / cen_im) and the two margins
-template <bool QUIET = false, bool NOMARGIN = false>   // NOMARGIN (the finishing walk): the margins are not looked at -- not formed, left 0
+// DQ (the finishing walk again): 0 the step's increments are formed here; 1 ONLY that -- they are left in Ls2Args::dq, nothing is summed
+// (ls2_dcb_incr_kernel); 2 they are read from there: a unit's run is then a load, an LDS round trip and the 64 adds of a step
+template <bool QUIET = false, bool NOMARGIN = false, int DQ = 0>   // NOMARGIN (the finishing walk): the margins are not looked at -- not formed, left 0
 RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_centre, int cre, int cim, const bool reserve, const int lane,
                               float2 *lds_dc, float2 *lds_tmp, float2 *lds_q, int &end_re, int &end_im,
                               int *q_cen = nullptr, int *q_mar = nullptr) {
@@ -1593,17 +1596,17 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
     float sre = 0.0f, sim = 0.0f;
     if (a.carry) {
       const GateState *cs = a.carry + s;
-      if (lane < DC_LEN) lds_dc[lane] = make_float2(cs->dcr_re[lane], cs->dcr_im[lane]);
+      if (DQ != 2 && lane < DC_LEN) lds_dc[lane] = make_float2(cs->dcr_re[lane], cs->dcr_im[lane]);
       g.dc_index = wv::uniform(cs->dc_index);
       sre = wv::uniform(cs->dc_re); sim = wv::uniform(cs->dc_im);
     } else {
-      if (lane < DC_LEN) lds_dc[lane] = make_float2(0.0f, 0.0f);
+      if (DQ != 2 && lane < DC_LEN) lds_dc[lane] = make_float2(0.0f, 0.0f);
     }
     cre = ls2_ord(sre); cim = ls2_ord(sim);
   } else {
     // an idle cut: the ring holds the 48 samples before it; without a centre: their mean
     float2 v = make_float2(0.0f, 0.0f);
-    if (lane < DC_LEN) { v = yrow[upos0 - DC_LEN + lane]; lds_dc[lane] = v; }
+    if ((DQ != 2 || !have_centre) && lane < DC_LEN) { v = yrow[upos0 - DC_LEN + lane]; lds_dc[lane] = v; }
     if (!have_centre) {
       float pr = v.x, pi = v.y;   // (lanes >= 48 hold zeros)
 #pragma unroll
@@ -1648,7 +1651,8 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
     const int64_t cbase = (int64_t)s * a.cstride + (upos0 >> 6) + (i - s * a.max_b) / LS2_FINE;
     const uint64_t *closed = a.closed + cbase;
     const int *oinfo = a.openinfo + cbase;
-    const float2 *ys = yrow + upos0;
+    const float2 *ys = ((DQ == 2) ? (const float2 *)(a.dq + (int64_t)s * a.y_stride) : yrow) + upos0;   // (DQ = 2: the step's increments instead of its samples)
+    float2 *dqw = a.dq + (int64_t)s * a.y_stride + upos0;
     const int nsteps = (n + 63) >> 6;
     constexpr int AHEAD = 4;   // (8 in the finishing walk's one-wave workgroups: no difference)
     float2 buf[AHEAD];
@@ -1702,6 +1706,8 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
       const int ol = oi & 0xff;
       if (closedmask != 0) {
         float tre, tim;
+        if (DQ == 2) { const bool isc = ((closedmask >> lane) & 1ull) != 0ull; tre = isc ? yv.x : 0.0f; tim = isc ? yv.y : 0.0f; }   // (lanes past the unit's end loaded something else)
+        else
         gate_dc_incr(g, closedmask, 0ull, nvalid, yv, lane, lds_dc, lds_tmp,
                      [&](float &qre, float &qim) {
                        // (x - x[i-48]) / 48 as the producer wave forms it: x[i-48] from the previous step's lanes 16..63
@@ -1717,6 +1723,11 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
                        }
                      },
                      tre, tim);
+        if (DQ == 1) {
+          if (lane < nvalid) dqw[64 * k + lane] = make_float2(tre, tim);
+          before = yv;
+          return;
+        }
         if (!NOMARGIN) {
           const float c32r = wv::readlane(acc.x, LS2_DCB_HALF), c32i = wv::readlane(acc.y, LS2_DCB_HALF);
           const float pr = c32r + wv::scan_add_f(tre), pi = c32i + wv::scan_add_f(tim);
@@ -1777,6 +1788,7 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
     for (int u = 0; u < AHEAD - 1; ++u)
       if (kb + u < nsteps) step(kb + u, buf[u], false);
   }
+  if (DQ == 1) return;
   end_re = ls2_ord(acc.x); end_im = ls2_ord(acc.y);
   if (!QUIET && lane == 0) { a.dexm[2 * t] = ~0ull; a.dexm[2 * t + 1] = ~0ull; }
   {
@@ -2208,6 +2220,25 @@ RFID_KERNEL(64) void ls2_dcb_down1_kernel(Ls2Args a) {
 // A unit that the walk has settled is then run ONCE more in the plain form, centred on its now exact start -- that run leaves the
 // table, dc_est at the gate openings and the records the assembly reads -- by a wave from the far end of the trace's waves while the
 // others explore the next turn's units.
+// The increments of every closed step of every unit that is not settled, once, for the finishing walk (nothing to do -- the usual
+// case -- and the launch returns): what a unit's start value does NOT enter.  The walk's runs then read them instead of forming them
+// turn after turn, window after window: a turn is as long as a lone wave's run, and forming the increments is two thirds of it
+RFID_KERNEL(64) void ls2_dcb_incr_kernel(Ls2Args a) {
+  ls2_tail_prio();
+  RFID_SHARED float2 lds_dc[DC_LEN];
+  RFID_SHARED float2 lds_tmp[64];
+  Ls2Ctl *ctl = a.ctl;
+  if (!ls2_fsm_settled(a, ctl)) return;
+  if (wv::uniform(ctl->dc_count[a.dc_rounds]) == 0) return;
+  const int lane = wv::lane_id();
+  const int NH = a.n_streams * a.max_bc;
+  for (int t = (int)blockIdx.x; t < NH; t += (int)gridDim.x) {
+    const int st = wv::uniform(a.dstat[t]);
+    if (!(st & 4) || (st & 3) == 3) continue;
+    int er, ei;
+    ls2_dcb_unit<true, true, 1>(a, t, true, 0, 0, false, lane, lds_dc, lds_tmp, nullptr, er, ei);
+  }
+}
 // the mean of the 48 samples in front of unit t (the dc ring's content at an idle cut: what round 0 centres a unit on) -> false for a
 // trace's first unit (its start is the fresh gate's or the carried state's, exactly)
 RFID_DEVICE bool ls2_dcb_ring_mean(const Ls2Args &a, const int t, const int lane, float &mre, float &mim) {
@@ -2291,7 +2322,7 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
   auto run_final = [&]() {
     if (fin_t < 0) return;
     int er, ei;
-    ls2_dcb_unit<false, true>(a, fin_t, true, fin_re, fin_im, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei);
+    ls2_dcb_unit<false, true, 2>(a, fin_t, true, fin_re, fin_im, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei);
     if (lane == 0) { a.dT[2 * fin_t] = fin_re; a.dT[2 * fin_t + 1] = fin_im; a.dstat[fin_t] = 7; }
     fin_t = -1;
   };
@@ -2330,8 +2361,8 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
         int Cre = Fre, Cim = Fim;
         if (t != tq) { float ur, ui; if (ls2_dcb_ring_mean(a, t, lane, ur, ui)) { Cre = ls2_ord(ur + dr_re); Cim = ls2_ord(ui + dr_im); } }
         const int off = 64 * (mw - pc);
-        if (mw == pc) ls2_dcb_unit<false, true>(a, t, true, Cre + off, Cim + off, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei, qc, qm);
-        else ls2_dcb_unit<true, true>(a, t, true, Cre + off, Cim + off, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei, qc, qm);
+        if (mw == pc) ls2_dcb_unit<false, true, 2>(a, t, true, Cre + off, Cim + off, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei, qc, qm);
+        else ls2_dcb_unit<true, true, 2>(a, t, true, Cre + off, Cim + off, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei, qc, qm);
         rec[8 + lane] = er; rec[72 + lane] = ei;
         if (lane == 0) { rec[0] = qc[0]; rec[1] = qc[1]; rec[2] = qm[0]; rec[3] = qm[1]; }
       }

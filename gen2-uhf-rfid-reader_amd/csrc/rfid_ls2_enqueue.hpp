@@ -49,7 +49,7 @@ inline Ls2Geometry ls2_geometry(int n_streams, int64_t n_dec, int min_piece = LS
 
 // work space: one allocation, carved up here (offsets in bytes, 256-byte aligned)
 struct Ls2Layout {
-  size_t cut, cutf, piece, nextv, prevv, upiece, unextv, uprevv, lb_fn, lb_end, lb_water, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, dT, dcen, dtab, dstat, dexm, dfront, fscr, fbar, dmar, dwbase, dcand, n1cen, n1tab, n1val, n1ent, n1mar, n1exm, n2cen, n2tab, n2val, n2ent, n2mar, n2exm, seq0, flat_base, cflag, cagg, ctl, consumed, total;
+  size_t cut, cutf, piece, nextv, prevv, upiece, unextv, uprevv, lb_fn, lb_end, lb_water, votes, closed, openinfo, arun, aT, alist, aover, fsm, wb, dT, dcen, dtab, dstat, dexm, dfront, fscr, fbar, dq, dmar, dwbase, dcand, n1cen, n1tab, n1val, n1ent, n1mar, n1exm, n2cen, n2tab, n2val, n2ent, n2mar, n2exm, seq0, flat_base, cflag, cagg, ctl, consumed, total;
   int dcand_cap;
 };
 // wmax: complete windows a trace can hold (the caller's window table): sizes the dc_est stage's table of gate openings
@@ -96,6 +96,7 @@ inline Ls2Layout ls2_layout(const Ls2Geometry &g, int n_streams, int64_t y_strid
   L.dfront = take(sizeof(int) * B);
   L.fscr = take(sizeof(int) * B * 2 * (size_t)ls2_fin_waves((int)B) * LS2_FIN_REC);
   L.fbar = take(sizeof(int) * B);
+  L.dq = take(sizeof(float2) * B * (size_t)y_stride);
   L.dwbase = take(sizeof(int) * NH);
   L.dcand_cap = (int)(B * (size_t)(wmax > 0 ? wmax : 0) + NH + 8);   // every window + the one a trace may end in, per unit
   L.dcand = take(sizeof(float2) * 64 * (size_t)L.dcand_cap);
@@ -124,7 +125,7 @@ inline void ls2_bind(Ls2Args &a, char *base, const Ls2Layout &L, const Ls2Geomet
   a.votes = (uint64_t *)(base + L.votes); a.closed = (uint64_t *)(base + L.closed); a.openinfo = (int *)(base + L.openinfo);
   a.arun = (Ls2AvgRun *)(base + L.arun); a.aT = (int *)(base + L.aT); a.alist = (int *)(base + L.alist); a.aover = (Ls2Aff *)(base + L.aover);
   a.fsm = (Ls2Fsm *)(base + L.fsm); a.wb = (Ls2Win *)(base + L.wb);
-  a.dT = (int *)(base + L.dT); a.dcen = (int *)(base + L.dcen); a.dtab = (int *)(base + L.dtab); a.dstat = (int *)(base + L.dstat); a.dmar = (int *)(base + L.dmar); a.dexm = (uint64_t *)(base + L.dexm); a.dfront = (int *)(base + L.dfront); a.fscr = (int *)(base + L.fscr); a.fbar = (int *)(base + L.fbar);
+  a.dT = (int *)(base + L.dT); a.dcen = (int *)(base + L.dcen); a.dtab = (int *)(base + L.dtab); a.dstat = (int *)(base + L.dstat); a.dmar = (int *)(base + L.dmar); a.dexm = (uint64_t *)(base + L.dexm); a.dfront = (int *)(base + L.dfront); a.fscr = (int *)(base + L.fscr); a.fbar = (int *)(base + L.fbar); a.dq = (float2 *)(base + L.dq);
   a.dwbase = (int *)(base + L.dwbase); a.dcand = (float2 *)(base + L.dcand); a.dcand_cap = L.dcand_cap;
   a.dcb_n1 = g.n1; a.dcb_n2 = g.n2; a.dcb_top = (g.n1 > ls2_dcb_top_min()) ? 2 : 1; a.dcb_bias = ls2_dcb_bias();
   a.n1cen = (int *)(base + L.n1cen); a.n1tab = (int *)(base + L.n1tab); a.n1val = (int *)(base + L.n1val); a.n1ent = (int *)(base + L.n1ent); a.n1mar = (int *)(base + L.n1mar); a.n1exm = (uint64_t *)(base + L.n1exm);
@@ -252,6 +253,7 @@ inline void ls2_enqueue(Ls2Args a, bool search_cuts = true, int *rounds_out = nu
     {
       // the finishing walk: G waves per trace that meet once per turn -- all of them must be resident at once, so no more than the
       // device holds of them (ls2_fin_waves)
+      LS2_LAUNCH(ls2_dcb_incr_kernel, NH, 1, 64, U(a));
       LS2_LAUNCH(ls2_dcb_finish_kernel<LS2_FIN_WPB>, ls2_fin_waves(B) / LS2_FIN_WPB, B, 64 * LS2_FIN_WPB, U(a));
     }
   }
