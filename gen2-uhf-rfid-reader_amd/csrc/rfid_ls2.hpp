@@ -1743,31 +1743,37 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
         wv::wave_sync();   // (the reads of the step before are over)
         lds_q[lane] = make_float2(tre, tim);
         wv::wave_sync();
-        if (__builtin_expect(QUIET || ol == 0xff, 1)) {
-          // (unrolled all the way: the reads run ahead of the adds as far as the scheduler lets them.  What must NOT be unrolled is the
-          // gate-opening path below: its 64 conditional snapshots kept 64 increments and as many copies alive -- 219 VGPRs, two
-          // waves per SIMD, 2.9 ms for configs[2]'s first round; 97 VGPRs since)
+        {
+          if (!QUIET && __builtin_expect(ol != 0xff, 0)) {
+            // a window opened at sample `ol` of this step: dc_est right behind that sample (the opening sample is still closed,
+            // gate_impl.cc:164-180), for every candidate -- the sums as far as that sample, from the step's start, BESIDE the step's
+            // own 64 below.  (One loop over the 64 samples with a snapshot at `ol` cost 6.5 us a step in a lone wave -- every
+            // iteration a full LDS round trip; unrolled, 219 VGPRs.  A run of the finishing walk in the plain form took 129 us
+            // against 65 in the quiet one.)
+            float2 snap = acc;
+            const int npair = (ol + 1) >> 1;
+#pragma unroll 4
+            for (int j = 0; j < npair; ++j) {
+              const float4 qq = q4[j];
+              wv::pk_add(snap, make_float2(qq.x, qq.y));
+              wv::pk_add(snap, make_float2(qq.z, qq.w));
+            }
+            if ((ol + 1) & 1) wv::pk_add(snap, lds_q[ol]);
+            if (wslot >= 0) a.dcand[(int64_t)(wslot + nopen) * 64 + lane] = snap;
+            if (lane == 0) {
+              Ls2Win *w = wb + (upos0 + 64 * k + ol) / LS2_WBUCKET;
+              w->slot = (wslot >= 0) ? (wslot + nopen) : 0; w->unit = t;
+            }
+            nopen++;
+            wv::wave_sync();   // (and the reads below are reads of their own: kept in registers across both loops they cost the kernel half its waves)
+          }
+          // (unrolled all the way: the reads run ahead of the adds as far as the scheduler lets them)
 #pragma unroll
           for (int j = 0; j < 32; ++j) {
             const float4 qq = q4[j];
             wv::pk_add(acc, make_float2(qq.x, qq.y));
             wv::pk_add(acc, make_float2(qq.z, qq.w));
           }
-        } else {
-          // a window opened at sample `ol` of this step: dc_est right behind that sample (the opening sample is still
-          // closed, gate_impl.cc:164-180), for every candidate
-          float2 snap = acc;
-#pragma unroll 4
-          for (int j = 0; j < 64; ++j) {
-            wv::pk_add(acc, lds_q[j]);
-            if (j == ol) snap = acc;
-          }
-          if (wslot >= 0) a.dcand[(int64_t)(wslot + nopen) * 64 + lane] = snap;
-          if (lane == 0) {
-            Ls2Win *w = wb + (upos0 + 64 * k + ol) / LS2_WBUCKET;
-            w->slot = (wslot >= 0) ? (wslot + nopen) : 0; w->unit = t;
-          }
-          nopen++;
         }
       } else {
         g.run_closed = 0;   // the step lies entirely inside a window: dc_est, the ring and its index do not move
@@ -2261,6 +2267,7 @@ constexpr int LS2_FIN_WIN_MAX = 8;      // ... at most
 constexpr int LS2_FIN_WIN = 4;          // windows (waves) per explored unit when the trace has at least 16 waves
 constexpr int LS2_FIN_AHEAD = 64;       // units explored per turn, at least (as far as the waves go)
 constexpr int LS2_FIN_REC = 136;        // ints per wave and set: centre (2), margin (2), in use (1), pad (3), table (2 x 64)
+constexpr int LS2_FIN_LIST = 256;       // units a turn can hold (the slots of the idle grid that hold one, in order)
 constexpr int LS2_FIN_CHUNK = 64;       // scratch records the walk stages through LDS at a time
 template <int WPB>
 RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
@@ -2269,6 +2276,7 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
   RFID_SHARED float2 lds_tmp[WPB][64];
   RFID_SHARED float4 lds_q4[WPB][32];
   RFID_SHARED int lds_rec[WPB][LS2_FIN_CHUNK * 128];
+  RFID_SHARED int lds_ulist[WPB][LS2_FIN_LIST];
   Ls2Ctl *ctl = a.ctl;
   if (!ls2_fsm_settled(a, ctl)) return;
   if (wv::uniform(ctl->dc_count[a.dc_rounds]) == 0) return;
@@ -2284,6 +2292,7 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
   int *scr = a.fscr + (int64_t)s * 2 * G * LS2_FIN_REC;
   int *bar = a.fbar + s;
   int *ltab = lds_rec[wib];
+  int *ulist = lds_ulist[wib];
   // ---- the frontier (every wave finds it for itself: the same data, the same answer) ----
   int first = -1;
   for (int k0 = 0; k0 < a.max_bc && first < 0; k0 += 64) {
@@ -2331,9 +2340,31 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
     const int uw = wid / M, mw = wid - uw * M;          // the unit (behind the frontier) and the window this wave explores
     const int pc = (M - 1) / 2;                         // the window centred on the prediction itself: ITS wave runs the plain form (see below)
     run_final();                       // (a unit the last turn settled: the others explore meanwhile)
-    const int k = pos + uw;
+    // the turn's units: the next `nact` slots from pos on that hold one (most slots of the idle grid do not: a turn over SLOTS
+    // explored 24 units with 64 slots' waves), every wave for itself from the same flags
+    int nu = 0;
+    {
+      const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      wv::wave_sync();   // (the last turn's reads of the list are over)
+      for (int k0 = pos; k0 < a.max_bc && nu < nact; k0 += 256) {
+        int st[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { const int kk = k0 + 64 * g + lane; st[g] = (kk < a.max_bc) ? a.dstat[t0 + kk] : 0; }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const uint64_t m = wv::ballot((st[g] & 4) != 0);
+          const int at = nu + wv::popc64(m & lt);
+          if ((st[g] & 4) != 0 && at < LS2_FIN_LIST) ulist[at] = k0 + 64 * g + lane;
+          nu += wv::popc64(m);
+        }
+      }
+      wv::wave_sync();
+      if (nu > nact) nu = nact;
+    }
+    if (nu == 0) break;                // (no unit left behind the frontier: every wave sees the same)
+    const int k = (uw < nu) ? ulist[uw] : 0;
     const int t = t0 + k;
-    const bool on = uw < nact && k < a.max_bc && (wv::uniform(a.dstat[(k < a.max_bc) ? t : t0]) & 4) != 0;
+    const bool on = uw < nu;
     // Where a unit is centred: dc_est is the mean of the last 48 closed samples plus the rounding of every addition so far -- a DRIFT
     // that moves by a dozen ulps per unit, whatever the sums do at a binade edge.  The exact value at the frontier gives the drift
     // there (value - ring mean of the frontier's unit); a unit k slots on is centred on ITS ring mean + that drift, off by ~12 sqrt k
@@ -2341,19 +2372,14 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
     // rounds those are hundreds of ulps off, a guess through a missed table is off by a share of that, and the run of hits behind
     // the frontier grew by 4 - 16 units per turn.)
     float dr_re = 0.0f, dr_im = 0.0f;
-    int tq = -1;                       // the frontier's unit (the first slot from pos on that holds one)
+    const int tq = t0 + ulist[0];      // the frontier's unit
     {
-      const int kq = pos + lane;
-      const uint64_t mu = wv::ballot(kq < a.max_bc && (a.dstat[t0 + ((kq < a.max_bc) ? kq : 0)] & 4) != 0);
-      if (mu) {
-        tq = t0 + pos + wv::ffs64(mu);
-        float fr, fi;
-        if (ls2_dcb_ring_mean(a, tq, lane, fr, fi)) { dr_re = ls2_from_ord(Fre) - fr; dr_im = ls2_from_ord(Fim) - fi; }
-      }
+      float fr, fi;
+      if (ls2_dcb_ring_mean(a, tq, lane, fr, fi)) { dr_re = ls2_from_ord(Fre) - fr; dr_im = ls2_from_ord(Fim) - fi; }
     }
-    if (uw < nact) {
+    if (on) {
       int *rec = set + (int64_t)wid * LS2_FIN_REC;
-      if (on) {
+      {
         // window mw of M: centred on C + 64 (mw - pc) -- C - 96 .. C + 159 in all.  The window around C itself is run in the PLAIN form
         // (table, dc_est at the gate openings, the records the assembly reads -- all left where the rounds leave them): a unit whose
         // start falls into it, as most do, is done with that; the others' windows in the quiet form
@@ -2366,7 +2392,6 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
         rec[8 + lane] = er; rec[72 + lane] = ei;
         if (lane == 0) { rec[0] = qc[0]; rec[1] = qc[1]; rec[2] = qm[0]; rec[3] = qm[1]; }
       }
-      if (lane == 0) rec[4] = on ? 1 : 0;
     }
     // ---- the waves of the trace meet ----
     wv::block_sync();
@@ -2382,11 +2407,11 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
     int nset = 0, nall = 0;           // units this turn has settled so far: those that need a run in the plain form, all
     int w = 0;
     const int upc = LS2_FIN_CHUNK / M;                 // units per staged chunk
-    for (int w0 = 0; w0 < nact && pos + w0 < a.max_bc; w0 += upc) {
-      const int nrec = ((nact - w0 < upc) ? (nact - w0) : upc) * M;
+    for (int w0 = 0; w0 < nu; w0 += upc) {
+      const int nrec = ((nu - w0 < upc) ? (nu - w0) : upc) * M;
       const int *rb = set + (int64_t)(w0 * M) * LS2_FIN_REC;
-      int c_re_l = 0, c_im_l = 0, m_re_l = 0, m_im_l = 0, on_l = 0;
-      if (lane < nrec) { const int *r = rb + (int64_t)lane * LS2_FIN_REC; c_re_l = r[0]; c_im_l = r[1]; m_re_l = r[2]; m_im_l = r[3]; on_l = r[4]; }
+      int c_re_l = 0, c_im_l = 0, m_re_l = 0, m_im_l = 0;
+      if (lane < nrec) { const int *r = rb + (int64_t)lane * LS2_FIN_REC; c_re_l = r[0]; c_im_l = r[1]; m_re_l = r[2]; m_im_l = r[3]; }
       wv::wave_sync();   // (the last chunk's reads are over)
       {
         Ls2Int4 *dst = reinterpret_cast<Ls2Int4 *>(ltab);
@@ -2399,11 +2424,10 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
         }
       }
       wv::wave_sync();
-      for (int u = 0; u < upc && w0 + u < nact && pos + w0 + u < a.max_bc; ++u) {
+      for (int u = 0; u < upc && w0 + u < nu; ++u) {
         w = w0 + u;
         const int r0 = u * M;
-        if (!wv::readlane(on_l, r0)) continue;   // (a slot without a unit)
-        const int tw = t0 + pos + w;
+        const int tw = t0 + ulist[w];
         // the window of the unit that holds the walk's value (else the outermost on that side: its margin may still reach, or a guess)
         const int C_re = wv::readlane(c_re_l, r0 + pc), C_im = wv::readlane(c_im_l, r0 + pc);
         int q_re = (((int)((uint32_t)Wre - (uint32_t)C_re) + 32) >> 6) + pc, q_im = (((int)((uint32_t)Wim - (uint32_t)C_im) + 32) >> 6) + pc;
@@ -2439,8 +2463,6 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
         ls2_dcb_apply<true>(Wim, e2, ltab[((r0 + q_im) * 2 + 1) * 64 + lane], ~0ull, c_im, m_im);
       }
       if (!ex) break;
-      w = ((w0 + upc < nact) ? (w0 + upc) : nact);
-      if (pos + w > a.max_bc) w = a.max_bc - pos;
     }
     if (wid == 0 && s == 0 && lane == 0) {
       int b = 0; for (int v = nall; v > 0 && b < 7; v >>= 1) b++;
@@ -2448,20 +2470,21 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
     }
     if (ex) {
       // every unit of the turn was hit: the value behind the last one is exact -- the next turn's first start
-      pos += w;
+      pos = ulist[nu - 1] + 1;
       Fre = Wre; Fim = Wim;
     } else {
-      pos += miss;
+      pos = ulist[miss];
     }
     // (units of the next turn: twice the reach, and never fewer than LS2_FIN_AHEAD -- the units behind the frontier are run again turn
     // after turn, each time centred on a better prediction, so that they are within a window's reach of the truth when the frontier
     // arrives; the waves that still have a settled unit to run in the plain form are left out when enough others remain)
     {
-      int nw = 2 * (ex ? w : miss) + 4;
+      int nw = 2 * (ex ? nu : miss) + 4;
       if (nw < LS2_FIN_AHEAD) nw = LS2_FIN_AHEAD;
       if (G >= 16) M = ex ? ((M > LS2_FIN_WIN) ? M - 1 : M) : ((M + 2 < LS2_FIN_WIN_MAX) ? M + 2 : LS2_FIN_WIN_MAX);
       const int amax = G / M;                           // units a turn can explore
       nw = (nw > amax) ? amax : nw;
+      if (nw > LS2_FIN_LIST) nw = LS2_FIN_LIST;
       const int spare = (G - nset) / M;
       if (spare >= 1 && nw > spare) nw = spare;
       nact = nw;
