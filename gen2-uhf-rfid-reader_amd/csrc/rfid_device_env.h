@@ -95,6 +95,9 @@ RFID_DEVICE uint32_t f2u(float x) { return __float_as_uint(x); }
 // independent ds_reads in flight together instead of the compiler's just-in-time interleaving
 RFID_DEVICE void compiler_fence() { asm volatile("" ::: "memory"); }
 RFID_DEVICE void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// everything this wave has in flight to or from memory is through (behind a rare store inside a loop of read-ahead loads: the waits
+// behind it need not be waits for everything then)
+RFID_DEVICE void drain_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // glibc-2.35 hypotf: (float)sqrt((double)x*x + (double)y*y), double sqrt correctly rounded.  Both products are
 // exact in binary64, so the fma rounds once exactly like the sum.  The square root is the device library's
 // correctly rounded sequence (v_rsq_f64 + two coupled Newton steps + two residual corrections) without its range

@@ -1564,6 +1564,7 @@ RFID_KERNEL(256) void ls2_fsm_chain_kernel(Ls2Args a) {
 constexpr int LS2_DCB_HALF = 32;      // candidate j (= lane) of a unit starts at its centre + j - 32 ulps
 constexpr int LS2_DCB_DESCENTS = 1024;  // nodes a chain walk goes through child by child where their tables miss, per wave and launch
 constexpr int LS2_DCB_AHEAD = 4096;    // re-run rounds look this many idle-grid slots behind a trace's frontier
+constexpr int LS2_DCB_SNAPS = 16;     // gate openings of a unit gathered in LDS before they are written (more: written in between)
 constexpr int LS2_DCB_SLACK = 48;     // taken off a run's margin: the estimate of the partial sums is off by < 33 ulps, + the proof's own 4, + spare
 
 RFID_DEVICE bool ls2_fsm_settled(const Ls2Args &a, const Ls2Ctl *ctl) {
@@ -1582,7 +1583,7 @@ RFID_DEVICE int ls2_dcb_slot(const Ls2Args &a, const int t) { const int s = t / 
 template <bool QUIET = false, bool NOMARGIN = false, int DQ = 0>   // NOMARGIN (the finishing walk): the margins are not looked at -- not formed, left 0
 RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_centre, int cre, int cim, const bool reserve, const int lane,
                               float2 *lds_dc, float2 *lds_tmp, float2 *lds_q, int &end_re, int &end_im,
-                              int *q_cen = nullptr, int *q_mar = nullptr) {
+                              int *q_cen = nullptr, int *q_mar = nullptr, float2 *lds_snap = nullptr, const int snap_cap = 0) {
   const int s = t / a.max_bc;
   const int i = ls2_dcb_slot(a, t);
   const int upos0 = wv::uniform(a.piece[i].pos0);
@@ -1686,6 +1687,26 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
     int oi_l = 0xff;
     int nopen = 0;
     const float4 *q4 = reinterpret_cast<const float4 *>(lds_q);
+    // dc_est at the unit's gate openings: gathered in LDS, written behind the loop.  A global store inside the loop -- even one that is
+    // hardly ever executed -- makes every wait for a read-ahead load a wait for EVERYTHING in flight (loads and stores come back in
+    // no order relative to each other): the loop then ran at one memory round trip per step.  A run of the finishing walk in the
+    // plain form: 129 us against 65 in the quiet one, which has no store; the first dc_est round of configs[2]: 1.52 -> ... ms.
+    int nflushed = 0;
+    int *snap_pos = reinterpret_cast<int *>(lds_snap + (int64_t)snap_cap * 64);
+    auto flush_snaps = [&]() {
+      for (int b = 0; b < nopen - nflushed; ++b) {
+        const int idx = nflushed + b;
+        if (wslot >= 0) a.dcand[(int64_t)(wslot + idx) * 64 + lane] = lds_snap[b * 64 + lane];
+        if (lane == 0) { Ls2Win *w = wb + snap_pos[b] / LS2_WBUCKET; w->slot = (wslot >= 0) ? (wslot + idx) : 0; w->unit = t; }
+      }
+      nflushed = nopen;
+    };
+    auto put_snap = [&](const float2 v, const int at) {
+      if (nopen - nflushed == snap_cap) { flush_snaps(); wv::drain_vm(); }   // (more openings than the buffer holds: hardly ever)
+      lds_snap[(nopen - nflushed) * 64 + lane] = v;
+      if (lane == 0) snap_pos[nopen - nflushed] = at;
+      nopen++;
+    };
     auto step = [&](const int k, float2 &yb, const bool reload) {
       if ((k & 63) == 0) {
         const bool in = k + lane < nsteps;
@@ -1759,12 +1780,7 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
               wv::pk_add(snap, make_float2(qq.z, qq.w));
             }
             if ((ol + 1) & 1) wv::pk_add(snap, lds_q[ol]);
-            if (wslot >= 0) a.dcand[(int64_t)(wslot + nopen) * 64 + lane] = snap;
-            if (lane == 0) {
-              Ls2Win *w = wb + (upos0 + 64 * k + ol) / LS2_WBUCKET;
-              w->slot = (wslot >= 0) ? (wslot + nopen) : 0; w->unit = t;
-            }
-            nopen++;
+            put_snap(snap, upos0 + 64 * k + ol);
             wv::wave_sync();   // (and the reads below are reads of their own: kept in registers across both loops they cost the kernel half its waves)
           }
           // (unrolled all the way: the reads run ahead of the adds as far as the scheduler lets them)
@@ -1777,11 +1793,7 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
         }
       } else {
         g.run_closed = 0;   // the step lies entirely inside a window: dc_est, the ring and its index do not move
-        if (!QUIET && ol != 0xff) {   // (an opening sample is closed itself: not reached)
-          if (wslot >= 0) a.dcand[(int64_t)(wslot + nopen) * 64 + lane] = acc;
-          if (lane == 0) { Ls2Win *w = wb + (upos0 + 64 * k + ol) / LS2_WBUCKET; w->slot = (wslot >= 0) ? (wslot + nopen) : 0; w->unit = t; }
-          nopen++;
-        }
+        if (!QUIET && ol != 0xff) put_snap(acc, upos0 + 64 * k + ol);   // (an opening sample is closed itself: not reached)
       }
       before = yv;
     };
@@ -1793,6 +1805,7 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
 #pragma unroll
     for (int u = 0; u < AHEAD - 1; ++u)
       if (kb + u < nsteps) step(kb + u, buf[u], false);
+    if (!QUIET) flush_snaps();
   }
   if (DQ == 1) return;
   end_re = ls2_ord(acc.x); end_im = ls2_ord(acc.y);
@@ -1818,7 +1831,7 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
 // predicted.  (A first round from two starts only -- candidates 32 / 33 summed lane = sample by the two-carry scan, the unit's margin
 // carrying them to any other start -- was tried for long passes: 2.34 ms for configs[2]'s first round against 1.5 ms in this form,
 // whose 64 candidates cost ONE packed add per sample; profiles/r06/dcb_first_round.txt.)
-RFID_DEVICE void ls2_dcb_run(const Ls2Args &a, float2 *lds_dc, float2 *lds_tmp, float2 *lds_q) {
+RFID_DEVICE void ls2_dcb_run(const Ls2Args &a, float2 *lds_dc, float2 *lds_tmp, float2 *lds_q, float2 *lds_snap) {
   Ls2Ctl *ctl = a.ctl;
   if (!ls2_fsm_settled(a, ctl)) return;
   const int r = a.round;
@@ -1842,7 +1855,7 @@ RFID_DEVICE void ls2_dcb_run(const Ls2Args &a, float2 *lds_dc, float2 *lds_tmp, 
       if (lane == 0) a.dstat[t] = (st & ~0x70) | (((again < 7) ? again + 1 : 7) << 4);
     }
     int er, ei;
-    ls2_dcb_unit(a, t, r > 0, (r > 0) ? wv::uniform(a.dT[2 * t]) : 0, (r > 0) ? wv::uniform(a.dT[2 * t + 1]) : 0, r == 0, lane, lds_dc, lds_tmp, lds_q, er, ei);
+    ls2_dcb_unit(a, t, r > 0, (r > 0) ? wv::uniform(a.dT[2 * t]) : 0, (r > 0) ? wv::uniform(a.dT[2 * t + 1]) : 0, r == 0, lane, lds_dc, lds_tmp, lds_q, er, ei, nullptr, nullptr, lds_snap, LS2_DCB_SNAPS);
     if (r == 0 && lane == 0) a.dstat[t] = 4;
     n_run++;
   }
@@ -1855,7 +1868,8 @@ RFID_KERNEL(64) void ls2_dcb_run_kernel(Ls2Args a) {
   RFID_SHARED float2 lds_dc[DC_LEN];
   RFID_SHARED float2 lds_tmp[64];
   RFID_SHARED float4 lds_q4[32];
-  ls2_dcb_run(a, lds_dc, lds_tmp, reinterpret_cast<float2 *>(lds_q4));
+  RFID_SHARED float2 lds_snap[LS2_DCB_SNAPS * 64 + LS2_DCB_SNAPS / 2];   // (dc_est at the unit's gate openings + where they are)
+  ls2_dcb_run(a, lds_dc, lds_tmp, reinterpret_cast<float2 *>(lds_q4), lds_snap);
 }
 
 // ---- the chain of tables ----
@@ -2331,7 +2345,7 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
   auto run_final = [&]() {
     if (fin_t < 0) return;
     int er, ei;
-    ls2_dcb_unit<false, true, 2>(a, fin_t, true, fin_re, fin_im, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei);
+    ls2_dcb_unit<false, true, 2>(a, fin_t, true, fin_re, fin_im, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei, nullptr, nullptr, reinterpret_cast<float2 *>(ltab), 32);
     if (lane == 0) { a.dT[2 * fin_t] = fin_re; a.dT[2 * fin_t + 1] = fin_im; a.dstat[fin_t] = 7; }
     fin_t = -1;
   };
@@ -2387,7 +2401,7 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
         int Cre = Fre, Cim = Fim;
         if (t != tq) { float ur, ui; if (ls2_dcb_ring_mean(a, t, lane, ur, ui)) { Cre = ls2_ord(ur + dr_re); Cim = ls2_ord(ui + dr_im); } }
         const int off = 64 * (mw - pc);
-        if (mw == pc) ls2_dcb_unit<false, true, 2>(a, t, true, Cre + off, Cim + off, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei, qc, qm);
+        if (mw == pc) ls2_dcb_unit<false, true, 2>(a, t, true, Cre + off, Cim + off, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei, qc, qm, reinterpret_cast<float2 *>(ltab), 32);   // (the walk's LDS is free while the waves run)
         else ls2_dcb_unit<true, true, 2>(a, t, true, Cre + off, Cim + off, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei, qc, qm);
         rec[8 + lane] = er; rec[72 + lane] = ei;
         if (lane == 0) { rec[0] = qc[0]; rec[1] = qc[1]; rec[2] = qm[0]; rec[3] = qm[1]; }

@@ -169,6 +169,7 @@ static inline float fma_f(float a, float b, float c) { return __builtin_fmaf(a, 
 static inline uint32_t f2u(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
 static inline void compiler_fence() {}
 static inline void lds_wait() {}
+static inline void drain_vm() {}
 static inline float hypot_f(float x, float y) {
   return (float)sqrt((double)x * (double)x + (double)y * (double)y);
 }
