@@ -1564,7 +1564,10 @@ RFID_KERNEL(256) void ls2_fsm_chain_kernel(Ls2Args a) {
 constexpr int LS2_DCB_HALF = 32;      // candidate j (= lane) of a unit starts at its centre + j - 32 ulps
 constexpr int LS2_DCB_DESCENTS = 1024;  // nodes a chain walk goes through child by child where their tables miss, per wave and launch
 constexpr int LS2_DCB_AHEAD = 4096;    // re-run rounds look this many idle-grid slots behind a trace's frontier
-constexpr int LS2_DCB_SNAPS = 16;     // gate openings of a unit gathered in LDS before they are written (more: written in between)
+#ifndef LS2_DCB_SNAPS_N      // (the test suite's emulator builds with 2: every unit with three gate openings then takes the in-between path)
+#define LS2_DCB_SNAPS_N 16
+#endif
+constexpr int LS2_DCB_SNAPS = LS2_DCB_SNAPS_N;     // gate openings of a unit gathered in LDS before they are written (more: written in between)
 constexpr int LS2_DCB_SLACK = 48;     // taken off a run's margin: the estimate of the partial sums is off by < 33 ulps, + the proof's own 4, + spare
 
 RFID_DEVICE bool ls2_fsm_settled(const Ls2Args &a, const Ls2Ctl *ctl) {
@@ -2345,7 +2348,7 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
   auto run_final = [&]() {
     if (fin_t < 0) return;
     int er, ei;
-    ls2_dcb_unit<false, true, 2>(a, fin_t, true, fin_re, fin_im, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei, nullptr, nullptr, reinterpret_cast<float2 *>(ltab), 32);
+    ls2_dcb_unit<false, true, 2>(a, fin_t, true, fin_re, fin_im, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei, nullptr, nullptr, reinterpret_cast<float2 *>(ltab), 2 * LS2_DCB_SNAPS);
     if (lane == 0) { a.dT[2 * fin_t] = fin_re; a.dT[2 * fin_t + 1] = fin_im; a.dstat[fin_t] = 7; }
     fin_t = -1;
   };
@@ -2401,7 +2404,7 @@ RFID_KERNEL(64 * WPB) void ls2_dcb_finish_kernel(Ls2Args a) {
         int Cre = Fre, Cim = Fim;
         if (t != tq) { float ur, ui; if (ls2_dcb_ring_mean(a, t, lane, ur, ui)) { Cre = ls2_ord(ur + dr_re); Cim = ls2_ord(ui + dr_im); } }
         const int off = 64 * (mw - pc);
-        if (mw == pc) ls2_dcb_unit<false, true, 2>(a, t, true, Cre + off, Cim + off, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei, qc, qm, reinterpret_cast<float2 *>(ltab), 32);   // (the walk's LDS is free while the waves run)
+        if (mw == pc) ls2_dcb_unit<false, true, 2>(a, t, true, Cre + off, Cim + off, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei, qc, qm, reinterpret_cast<float2 *>(ltab), 2 * LS2_DCB_SNAPS);   // (the walk's LDS is free while the waves run)
         else ls2_dcb_unit<true, true, 2>(a, t, true, Cre + off, Cim + off, false, lane, lds_dc[wib], lds_tmp[wib], reinterpret_cast<float2 *>(lds_q4[wib]), er, ei, qc, qm);
         rec[8 + lane] = er; rec[72 + lane] = ei;
         if (lane == 0) { rec[0] = qc[0]; rec[1] = qc[1]; rec[2] = qm[0]; rec[3] = qm[1]; }

@@ -15,6 +15,7 @@
 #include "rfid_host_math.h"
 #include "rfid_kernels.hpp"
 #include "rfid_gen2_host.h"
+#define LS2_DCB_SNAPS_N 2   // (a unit's gate openings go through LDS two at a time here: the in-between writes are exercised)
 #define LS2_FIN_WPB 16   // (one workgroup at a time here: the finishing walk's waves of a trace share ONE workgroup)
 #define LS2_LAUNCH(kernel, gx, gy, block, args) \
   emu::launch(emu::Idx3{(unsigned)(gx), (unsigned)(gy), 1}, emu::Idx3{(unsigned)(block), 1, 1}, [&]() { rfidk::kernel(args); })
