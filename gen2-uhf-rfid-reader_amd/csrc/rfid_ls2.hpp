@@ -1690,10 +1690,11 @@ RFID_DEVICE void ls2_dcb_unit(const Ls2Args &a, const int t, const bool have_cen
     int oi_l = 0xff;
     int nopen = 0;
     const float4 *q4 = reinterpret_cast<const float4 *>(lds_q);
-    // dc_est at the unit's gate openings: gathered in LDS, written behind the loop.  A global store inside the loop -- even one that is
-    // hardly ever executed -- makes every wait for a read-ahead load a wait for EVERYTHING in flight (loads and stores come back in
-    // no order relative to each other): the loop then ran at one memory round trip per step.  A run of the finishing walk in the
-    // plain form: 129 us against 65 in the quiet one, which has no store; the first dc_est round of configs[2]: 1.52 -> ... ms.
+    // dc_est at the unit's gate openings: gathered in LDS, written behind the loop -- no global store among the loop's read-ahead
+    // loads (where a load and a store may both be in flight the compiler waits for everything).  Measured: nothing.  A run of the
+    // finishing walk in this (plain) form takes 126 us in a lone wave against 62 in the quiet form, the first dc_est round of
+    // configs[2] 1.45 ms against 1.1, and neither the stores, nor the sums behind an opening, nor the in-between writes are it
+    // (each taken out in turn: 125 - 128 us; profiles/r06/noise_sweep.txt) -- the first thing to find next.
     int nflushed = 0;
     int *snap_pos = reinterpret_cast<int *>(lds_snap + (int64_t)snap_cap * 64);
     auto flush_snaps = [&]() {
